@@ -1,0 +1,232 @@
+"""Generate the golden fixtures in tests/golden/*.npz from the REAL reference code.
+
+Run only in the build container (needs /root/reference; nothing here travels to or runs on the
+GPU box -- only the produced .npz/.json data files do):
+
+    python tests/golden/make_golden.py
+
+What is imported from the reference:
+  * meta_learn/svgd.py            -- imports as shipped (numpy + torch only)          -> A9 fixtures
+  * meta_learn/models.py, random_gp.py -- imported under *import shims* for the absent
+    third-party modules gpytorch / pyro / absl (dummy base classes only; they do not compute
+    anything).  Gives the real parameter layout, hyper-prior sampling / log-prob and the
+    per-particle MLP forward                                                        -> A2/A7 fixtures
+  * experiments/data_sim.py       -- SinusoidDataset (numpy only)                     -> A1 fixtures
+The shims cannot execute the GP algebra itself (A4-A6 *is* gpytorch); that part of the oracle is
+pinned by the recorded demo.ipynb log instead (demo_log.json, transcribed here from
+demo.ipynb:115-127,164-166).
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def install_shims():
+    """Dummy stand-ins so that `import gpytorch/pyro/absl` succeed; only class *names* used as
+    base classes by models.py / random_gp.py exist, none of them computes anything."""
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    class _Dummy(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    g = mod('gpytorch')
+    for sub in ['means', 'kernels', 'functions', 'utils', 'utils.broadcasting', 'likelihoods',
+                'likelihoods.noise_models', 'models', 'models.approximate_gp', 'variational',
+                'mlls', 'distributions']:
+        m = mod('gpytorch.' + sub)
+        parent = sys.modules['gpytorch.' + sub.rsplit('.', 1)[0]] if '.' in sub else g
+        setattr(parent, sub.rsplit('.', 1)[-1], m)
+    g.means.Mean = _Dummy
+    g.means.ZeroMean = _Dummy
+    g.kernels.Kernel = _Dummy
+    g.functions.RBFCovariance = object
+    g.utils.broadcasting._mul_broadcast_shape = lambda *a: None
+    g.likelihoods.noise_models._HomoskedasticNoiseBase = _Dummy
+    g.likelihoods._GaussianLikelihoodBase = _Dummy
+    g.models.ExactGP = _Dummy
+    g.models.approximate_gp.ApproximateGP = _Dummy
+    g.variational.CholeskyVariationalDistribution = _Dummy
+    g.variational.VariationalStrategy = _Dummy
+
+    p = mod('pyro')
+    pd = mod('pyro.distributions')
+    p.distributions = pd
+
+    class Normal(torch.distributions.Normal):                 # pyro adds .to_event()
+        def to_event(self, n):
+            return torch.distributions.Independent(self, n)
+    pd.Normal = Normal
+    pd.LogNormal = torch.distributions.LogNormal
+    pd.Independent = torch.distributions.Independent
+
+    a = mod('absl')
+    fl = mod('absl.flags')
+    a.flags = fl
+    fl.FLAGS = types.SimpleNamespace(is_parsed=lambda: False)
+
+    cfg = mod('config')
+    cfg.device = torch.device('cpu')
+
+
+def main():
+    assert os.path.isdir(REF), 'reference not mounted -- fixtures can only be regenerated in the build container'
+    sys.path.insert(0, REF)
+
+    # ------------------------------------------------------------------ A9: svgd.py as shipped
+    svgd = _load('ref_svgd', os.path.join(REF, 'meta_learn', 'svgd.py'))
+
+    class QuadLogProb:
+        """stub target density: log p(x) = -0.5 * sum((x-mu)^2 / s^2) (so that score is known)"""
+        def __init__(self, mu, s):
+            self.mu, self.s = mu, s
+
+        def log_prob(self, X):
+            return (-0.5 * ((X - self.mu) / self.s) ** 2).sum(-1)
+
+    fx = {}
+    for tag, (P, D, bw) in {'small_median': (5, 7, None), 'small_fixed': (5, 7, 0.5),
+                            'cfg3_median': (20, 2534, None), 'cfg3_fixed': (20, 2534, 2.0),
+                            'se_median': (10, 6, None)}.items():
+        gen = torch.Generator().manual_seed(1234 + P + D)
+        X = torch.randn(P, D, generator=gen) * 0.7
+        mu = torch.randn(D, generator=gen)
+        s = torch.rand(D, generator=gen) + 0.5
+        dist = QuadLogProb(mu, s)
+        kern = svgd.RBF_Kernel(bandwidth=bw)
+        phi = svgd.SVGD(dist, kern, optimizer=None).phi(X)
+        score = -(X - mu) / s ** 2
+        dn = svgd.norm_sq(X, X)
+        fx[tag + '_X'] = X.numpy()
+        fx[tag + '_score'] = score.numpy()
+        fx[tag + '_phi'] = phi.detach().numpy()
+        fx[tag + '_bw'] = np.array(kern._bandwidth(dn), dtype=np.float64)
+        fx[tag + '_K'] = kern(X, X).detach().numpy()
+        fx[tag + '_bw_arg'] = np.array(-1.0 if bw is None else bw)
+        # float64 version of the same call
+        X64, mu64, s64 = X.double(), mu.double(), s.double()
+        phi64 = svgd.SVGD(QuadLogProb(mu64, s64), svgd.RBF_Kernel(bandwidth=bw), None).phi(X64)
+        fx[tag + '_phi64'] = phi64.detach().numpy()
+        fx[tag + '_score64'] = (-(X64 - mu64) / s64 ** 2).numpy()
+    np.savez_compressed(os.path.join(OUT, 'svgd_ref.npz'), **fx)
+
+    # ------------------------------------------------------------------ A2/A7 under import shims
+    install_shims()
+    import meta_learn.models as models                         # noqa: E402
+    import meta_learn.random_gp as random_gp                   # noqa: E402
+
+    fx = {}
+    cases = {
+        'nn_nn_d4': dict(size_in=4, covar_module_str='NN', mean_module_str='NN'),
+        'se_const_d4': dict(size_in=4, covar_module_str='SE', mean_module_str='constant'),
+        'se_nn_d1': dict(size_in=1, covar_module_str='SE', mean_module_str='NN'),
+        'nn_const_d2_small': dict(size_in=2, covar_module_str='NN', mean_module_str='constant',
+                                  kernel_nn_layers=(8, 12)),
+    }
+    layouts = {}
+    for tag, kw in cases.items():
+        torch.manual_seed(7)
+        rgp = random_gp.RandomGPMeta(prior_factor=0.01, weight_prior_std=0.5, bias_prior_std=3.0, **kw)
+        shapes = rgp.parameter_shapes()
+        layouts[tag] = [(k, int(v[0])) for k, v in shapes.items()]
+        torch.manual_seed(11)
+        P = 6
+        theta = rgp.sample_params_from_prior(shape=(P,))
+        fx[tag + '_theta'] = theta.numpy()
+        fx[tag + '_logprior'] = rgp._log_prob_prior(theta).numpy()
+        # per-particle MLP forward through the reference's NeuralNetworkVectorized
+        gp = rgp.get_forward_fn(theta)
+        x = torch.randn(9, kw['size_in'], generator=torch.Generator().manual_seed(5))
+        xP = x.view(1, 9, -1).repeat(P, 1, 1)
+        fx[tag + '_x'] = x.numpy()
+        if kw['mean_module_str'] == 'NN':
+            fx[tag + '_mean_out'] = gp.mean_nn(xP).detach().numpy()
+        if kw['covar_module_str'] == 'NN':
+            fx[tag + '_kernel_out'] = gp.kernel_nn(xP).detach().numpy()
+    # the SVGD learner's particle initialisation stream: torch.manual_seed(seed) then one prior draw
+    # (GPR_meta_svgd.py:182 after abstract.py:125-129)
+    torch.manual_seed(30)
+    rgp = random_gp.RandomGPMeta(size_in=1, prior_factor=0.01, weight_prior_std=0.5, bias_prior_std=3.0,
+                                 covar_module_str='NN', mean_module_str='NN')
+    fx['svgd_init_seed30_d1_P10'] = rgp.sample_params_from_prior(shape=(10,)).numpy()
+    # VI posterior init + one rsample (random_gp.py:244-248, GPR_meta_vi.py:220)
+    torch.manual_seed(30)
+    rgp = random_gp.RandomGPMeta(size_in=1, prior_factor=0.01, weight_prior_std=0.5, bias_prior_std=3.0,
+                                 covar_module_str='SE', mean_module_str='constant')
+    post = random_gp.RandomGPPosterior(rgp.parameter_shapes(), cov_type='diag')
+    samp = post.rsample(sample_shape=(4,))
+    fx['vi_init_loc'] = post.loc.detach().numpy()
+    fx['vi_init_scale'] = post.scale.detach().numpy()
+    fx['vi_rsample'] = samp.detach().numpy()
+    fx['vi_logq'] = post.log_prob(samp).detach().numpy()
+    # harmonic-mean pre-factor on a ragged batch (random_gp.py:209-212), arithmetic only
+    sizes = torch.tensor([5., 7., 12., 5.])
+    hm = 1. / (torch.mean(1. / sizes))
+    fx['prefactor_ragged'] = np.array(float(hm / (hm + 4)))
+    # EqualWeightedMixtureDist mean/std/log_prob/cdf on a batched Normal (models.py:74-134)
+    gen = torch.Generator().manual_seed(3)
+    mus, sig = torch.randn(5, 8, generator=gen), torch.rand(5, 8, generator=gen) + 0.3
+    mix = models.EqualWeightedMixtureDist(torch.distributions.Normal(mus, sig), batched=True, num_dists=5)
+    val = torch.randn(8, generator=gen)
+    fx['mix_mus'], fx['mix_sig'], fx['mix_val'] = mus.numpy(), sig.numpy(), val.numpy()
+    fx['mix_mean'], fx['mix_std'] = mix.mean.numpy(), mix.stddev.numpy()
+    fx['mix_cdf'] = mix.cdf(val).numpy()
+    np.savez_compressed(os.path.join(OUT, 'random_gp_ref.npz'), **fx)
+    with open(os.path.join(OUT, 'param_layouts.json'), 'w') as f:
+        json.dump(layouts, f, indent=1)
+
+    # ------------------------------------------------------------------ A1/A12: data + sampling
+    import experiments.data_sim as data_sim                      # noqa: E402
+    env = data_sim.SinusoidDataset(random_state=np.random.RandomState(26))
+    train = env.generate_meta_train_data(n_tasks=20, n_samples=5)
+    test = env.generate_meta_test_data(n_tasks=20, n_samples_context=5, n_samples_test=50)
+    fx = {'train_x': np.stack([x for x, _ in train]), 'train_y': np.stack([y for _, y in train]),
+          'test_cx': np.stack([t[0] for t in test]), 'test_cy': np.stack([t[1] for t in test]),
+          'test_tx': np.stack([t[2] for t in test]), 'test_ty': np.stack([t[3] for t in test])}
+    # rds_numpy.choice(list_of_dicts, size=B) == randint(0, T, B) (abstract.py:125-129, GPR_meta_mll.py:109)
+    rds = np.random.RandomState(31)
+    fx['choice_seed31'] = np.stack([rds.choice(np.arange(20), size=5) for _ in range(4)])
+    np.savez_compressed(os.path.join(OUT, 'sinusoid_demo_data.npz'), **fx)
+
+    # ------------------------------------------------------------------ recorded run of the reference
+    demo_log = {
+        'source': 'demo.ipynb:115-127 (meta_fit log) and demo.ipynb:164-166 (final test metrics)',
+        'config': 'SinusoidDataset(RandomState(26)) 20x5 train, 20x(5+50) test; GPRegressionMetaLearned('
+                  'weight_decay=0.2, num_iter_fit=12000, random_seed=30); log_period=1000',
+        'log': [  # itr, avg loss, valid LL, valid RMSE, calib err
+            [1, 5.755850, -1.559, 1.284, 0.138], [1000, 4.953671, -1.198, 0.849, 0.125],
+            [2000, 3.324356, -0.725, 0.514, 0.138], [3000, 1.704049, -0.464, 0.420, 0.137],
+            [4000, 1.019263, -0.321, 0.419, 0.126], [5000, 0.663038, -0.208, 0.366, 0.127],
+            [6000, 0.437905, -0.121, 0.363, 0.121], [7000, 0.219458, -0.075, 0.345, 0.121],
+            [8000, 0.124243, -0.016, 0.312, 0.130], [9000, -0.004427, 0.027, 0.306, 0.132],
+            [10000, -0.118806, 0.011, 0.311, 0.129], [11000, -0.166441, 0.036, 0.308, 0.133],
+            [12000, -0.203187, 0.033, 0.309, 0.134]],
+        'final_test': {'ll': 0.03293633884750306, 'rmse': 0.3090165838599205,
+                       'calib': 0.13442028164863587},
+    }
+    with open(os.path.join(OUT, 'demo_log.json'), 'w') as f:
+        json.dump(demo_log, f, indent=1)
+    print('fixtures written to', OUT)
+
+
+if __name__ == '__main__':
+    main()

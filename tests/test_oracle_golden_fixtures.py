@@ -1,0 +1,114 @@
+"""Pin the CPU oracle against fixtures produced by the REAL reference code
+(tests/golden/make_golden.py: svgd.py as shipped; models.py / random_gp.py under import shims)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import pacoh_oracle as O
+
+CASES = {
+    'nn_nn_d4': dict(input_dim=4, covar_module='NN', mean_module='NN'),
+    'se_const_d4': dict(input_dim=4, covar_module='SE', mean_module='constant'),
+    'se_nn_d1': dict(input_dim=1, covar_module='SE', mean_module='NN'),
+    'nn_const_d2_small': dict(input_dim=2, covar_module='NN', mean_module='constant',
+                              kernel_nn_layers=(8, 12)),
+}
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_param_layout_matches_reference(golden_dir):
+    with open(os.path.join(golden_dir, 'param_layouts.json')) as f:
+        ref = json.load(f)
+    for tag, kw in CASES.items():
+        cfg = O.GPConfig(**kw)
+        assert [(k, v) for k, v in cfg.layout.items()] == [tuple(e) for e in ref[tag]], tag
+    assert O.GPConfig(**CASES['nn_nn_d4']).D == 2534
+    assert O.GPConfig(**CASES['se_const_d4']).D == 6
+    assert O.GPConfig(**CASES['se_nn_d1']).D == 1155
+
+
+def test_hyperprior_sample_and_logprob_match_reference(golden_dir):
+    fx = _load(golden_dir, 'random_gp_ref.npz')
+    for tag, kw in CASES.items():
+        cfg = O.GPConfig(**kw)
+        pm, ps = O.hyperprior_mean_std(cfg.layout, 0.5, 3.0)
+        torch.manual_seed(11)
+        theta = O.hyperprior_sample(cfg.layout, pm, ps, 6)
+        np.testing.assert_array_equal(theta.numpy(), fx[tag + '_theta'])       # same RNG stream
+        lp = O.hyperprior_log_prob(theta, pm.float(), ps.float())
+        np.testing.assert_allclose(lp.numpy(), fx[tag + '_logprior'], rtol=2e-6)
+
+
+def test_vectorized_mlp_forward_matches_reference(golden_dir):
+    fx = _load(golden_dir, 'random_gp_ref.npz')
+    for tag, kw in CASES.items():
+        cfg = O.GPConfig(**kw)
+        theta = torch.from_numpy(fx[tag + '_theta'])
+        x = torch.from_numpy(fx[tag + '_x'])
+        if cfg.mean_module == 'NN':
+            out = O.mlp_vectorized_forward(x, cfg.block(theta, 'mean_nn.'), cfg.input_dim, 1, cfg.mean_nn_layers)
+            np.testing.assert_allclose(out.numpy(), fx[tag + '_mean_out'], rtol=1e-5, atol=1e-5)
+        if cfg.covar_module == 'NN':
+            out = O.mlp_vectorized_forward(x, cfg.block(theta, 'kernel_nn.'), cfg.input_dim, 2, cfg.kernel_nn_layers)
+            np.testing.assert_allclose(out.numpy(), fx[tag + '_kernel_out'], rtol=1e-5, atol=1e-5)
+
+
+def test_svgd_particle_init_stream(golden_dir):
+    fx = _load(golden_dir, 'random_gp_ref.npz')
+    cfg = O.GPConfig(input_dim=1, covar_module='NN', mean_module='NN')
+    pm, ps = O.hyperprior_mean_std(cfg.layout, 0.5, 3.0)
+    torch.manual_seed(30)
+    O.consume_vectorized_gp_init_rng(cfg)        # model construction precedes the prior draw
+    theta = O.hyperprior_sample(cfg.layout, pm, ps, 10)
+    np.testing.assert_array_equal(theta.numpy(), fx['svgd_init_seed30_d1_P10'])
+
+
+def test_prefactor_ragged(golden_dir):
+    fx = _load(golden_dir, 'random_gp_ref.npz')
+    assert abs(O.meta_pre_factor([5, 7, 12, 5]) - float(fx['prefactor_ragged'])) < 1e-7
+
+
+def test_svgd_phi_closed_form_matches_reference(golden_dir):
+    fx = _load(golden_dir, 'svgd_ref.npz')
+    for tag in ['small_median', 'small_fixed', 'cfg3_median', 'cfg3_fixed', 'se_median']:
+        X, score = torch.from_numpy(fx[tag + '_X']), torch.from_numpy(fx[tag + '_score'])
+        bw_arg = float(fx[tag + '_bw_arg'])
+        phi, bw = O.svgd_phi_closed_form(X, score, None if bw_arg < 0 else bw_arg)
+        assert abs(bw - float(fx[tag + '_bw'])) <= 1e-6 * abs(bw)
+        ref = fx[tag + '_phi']
+        assert np.abs(phi.numpy() - ref).max() <= 2e-5 * np.abs(ref).max(), tag
+        # float64: closed form == autograd of the reference to round-off
+        phi64, _ = O.svgd_phi_closed_form(X.double(), torch.from_numpy(fx[tag + '_score64']), None if bw_arg < 0 else bw_arg)
+        ref64 = fx[tag + '_phi64']
+        assert np.abs(phi64.numpy() - ref64).max() <= 1e-12 * np.abs(ref64).max(), tag
+
+
+def test_mixture_mean_std_cdf(golden_dir):
+    fx = _load(golden_dir, 'random_gp_ref.npz')
+    mus, sig = torch.from_numpy(fx['mix_mus']), torch.from_numpy(fx['mix_sig'])
+    cov = torch.diag_embed(sig ** 2)
+    mu, std = O.mixture_mean_std(mus, cov, np.zeros(1), np.ones(1))
+    np.testing.assert_allclose(mu.numpy(), fx['mix_mean'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(std.numpy(), fx['mix_std'], rtol=1e-5)
+    cdf = torch.distributions.Normal(mus, sig).cdf(torch.from_numpy(fx['mix_val'])).mean(0)
+    np.testing.assert_allclose(cdf.numpy(), fx['mix_cdf'], rtol=1e-6)
+
+
+def test_sinusoid_dataset_and_task_sampling(golden_dir):
+    fx = _load(golden_dir, 'sinusoid_demo_data.npz')
+    env = O.SinusoidDataset(np.random.RandomState(26))
+    train = env.generate_meta_train_data(20, 5)
+    test = env.generate_meta_test_data(20, 5, 50)
+    np.testing.assert_array_equal(np.stack([x for x, _ in train]), fx['train_x'])
+    np.testing.assert_array_equal(np.stack([y for _, y in train]), fx['train_y'])
+    np.testing.assert_array_equal(np.stack([t[2] for t in test]), fx['test_tx'])
+    np.testing.assert_array_equal(np.stack([t[3] for t in test]), fx['test_ty'])
+    rds = np.random.RandomState(31)
+    draws = np.stack([rds.randint(0, 20, 5) for _ in range(4)])
+    np.testing.assert_array_equal(draws, fx['choice_seed31'])
+    assert list(draws[0]) == [18, 16, 2, 6, 10]
