@@ -1,0 +1,191 @@
+/*
+ * pacoh_gp.h -- C ABI of the MI355X-native PACOH task-GP hot path (libpacoh_gp.so).
+ *
+ * The reference (jonasrothfuss/meta_learning_pacoh) has no FFI layer: its boundary for this path
+ * is the Python class API of meta_learn/GPR_meta_{mll,svgd,vi}.py, and all arithmetic below that
+ * API is delegated to torch/gpytorch calls.  Each entry point here replaces one such group of
+ * calls; the comment above it cites the reference lines it stands in for (paths relative to the
+ * reference repository root).  The Python host package (meta_learning_pacoh_amd) binds these
+ * symbols with ctypes and passes `tensor.data_ptr()` of PyTorch-ROCm tensors.
+ *
+ * Conventions
+ *   - plain C, no exceptions, no allocation, no ownership transfer: every buffer is caller-owned
+ *     device memory (gfx950 HBM); scratch is passed in, sized by the *_workspace_bytes() query;
+ *   - every launch goes to the caller's `stream` (a hipStream_t passed as void*), no sync inside,
+ *     safe to capture into a hipGraph; re-entrant; no global state;
+ *   - return value: 0 = launched, <0 = PACOH_E* argument/limit error (nothing launched);
+ *     numerical status (Cholesky jitter / failure) is reported per GP in the optional `info[]`;
+ *   - layout: row-major, batch-major.  A "GP problem" b in [0,B) is the pair
+ *       (task t, hyper-parameter set p) with b = t*P + p   (P = particles / posterior samples).
+ *     Arrays shared between problems are addressed with an integer divisor:
+ *       z[(b / z_div), n, f]   (z_div = 1: per problem, e.g. NN features; z_div = P: per task, SE kernel on x)
+ *       y[(b / y_div), n]      (y_div = P: targets are per task)
+ *     hyper-parameters are per set p = b % P:  lengthscale[P,f], outputscale[P] (NULL = 1), noise[P];
+ *   - dtype: PACOH_F32 or PACOH_F64 for ALL floating buffers of a call;
+ *   - ragged tasks: optional n_valid[(b / y_div)] (int32) gives the number of real points of the
+ *     task (<= n); rows beyond it are ignored (treated as an identity block) and receive zero grads.
+ */
+#ifndef PACOH_GP_H
+#define PACOH_GP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PACOH_F32 0
+#define PACOH_F64 1
+
+#define PACOH_OK 0
+#define PACOH_EINVAL (-1)      /* NULL / negative / inconsistent argument                       */
+#define PACOH_ELIMIT (-2)      /* shape outside what the kernels support (see each function)    */
+#define PACOH_EDTYPE (-3)
+#define PACOH_ELAUNCH (-4)     /* hipGetLastError() after launch != hipSuccess                  */
+
+#define PACOH_MEAN_ZERO 0      /* gpytorch ZeroMean                                              */
+#define PACOH_MEAN_VECTOR 1    /* mean[B,n]   (NN mean, models.py:513-514)                       */
+#define PACOH_MEAN_CONST 2     /* mean[P]     (ConstantMeanLight, models.py:406-416)             */
+
+#define PACOH_MAX_FEATURES 16  /* f (kernel input dim) <= 16                                     */
+#define PACOH_MAX_HIDDEN_LAYERS 3
+#define PACOH_MAX_WIDTH 64     /* MLP hidden width <= 64, d_in <= 16, d_out <= 8                 */
+
+/* info[b] values written by the GP kernels (LAPACK-style): 0 = clean Cholesky; 1..3 = succeeded
+ * after adding diagonal jitter base*10^(k-1), base = 1e-6 (f32) / 1e-8 (f64) -- the retry ladder of
+ * gpytorch.utils.cholesky.psd_safe_cholesky that the reference relies on; -1 = not positive
+ * definite even with jitter (outputs for that problem are NaN). */
+
+int pacoh_abi_version(void);
+
+/* ---- A4: Gram build (materialised) -------------------------------------------------------------
+ * K[b,i,j] = os_p * exp(-0.5 * sum_k ((z1[b,i,k] - z2[b,j,k]) / l_pk)^2)  (+ noise_p if i==j and
+ * add_noise_diag != 0 and z1 == z2 semantics, i.e. square Gram).
+ * Replaces SEKernelLight.forward (meta_learn/models.py:428-446) and
+ * ScaleKernel(RBFKernel(ard)) (GPR_meta_mll.py:218,223); also the K_xs / K_ss blocks of the exact
+ * posterior (GPR_meta_mll.py:174-181).  Any n, m >= 1; f <= 16.  HBM-write bound. */
+int pacoh_gram_rbf_ard(const void* z1, int z1_div, const void* z2, int z2_div,
+                       const void* lengthscale, const void* outputscale, const void* noise,
+                       int add_noise_diag, void* K,
+                       int B, int P, int n, int m, int f, int dtype, void* stream);
+
+/* ---- A5+A6: fused per-datapoint log marginal likelihood, small n -------------------------------
+ * lml[b] = log N(y; mean, os*K + noise*I) / n_b      (the reference's MLL is divided by n)
+ * Replaces gpytorch.mlls.ExactMarginalLogLikelihood(likelihood, model)(model(x), y) at
+ * GPR_meta_mll.py:111-113 and random_gp.py:83-85 (Gram build, +noise, Cholesky with jitter retry,
+ * triangular solves, log-det) without ever writing K to HBM.
+ * Limits: n <= pacoh_gp_small_max_n(dtype, want_grad).  Optional outputs (NULL to skip):
+ * alpha_out[B,n] = (os*K+noise*I)^-1 (y-mean), L_out[B,n,n] lower Cholesky factor, info[B]. */
+int pacoh_gp_small_max_n(int dtype, int want_grad);
+
+int pacoh_gp_lml_fwd(const void* z, int z_div, const void* mean, int mean_mode,
+                     const void* y, int y_div, const void* lengthscale, const void* outputscale,
+                     const void* noise, const int32_t* n_valid,
+                     void* lml, void* alpha_out, void* L_out, int32_t* info,
+                     int B, int P, int n, int f, int dtype, void* stream);
+
+/* Forward + backward in one launch: also writes the gradient of (g_lml[b] * lml[b]) with respect to
+ * the problem's own inputs (replaces loss.backward() through the gpytorch graph,
+ * GPR_meta_mll.py:115, svgd.py:16, GPR_meta_vi.py:108):
+ *   d_z[B,n,f] (NULL if z is data), d_mean ([B,n] for MEAN_VECTOR, [B] for MEAN_CONST, NULL ok),
+ *   d_lengthscale[B,f], d_outputscale[B] (NULL ok), d_noise[B].
+ * Gradients are per problem (un-reduced); g_lml NULL means 1.  Closed forms: SURVEY.md 7(4). */
+int pacoh_gp_lml_fwdbwd(const void* z, int z_div, const void* mean, int mean_mode,
+                        const void* y, int y_div, const void* lengthscale, const void* outputscale,
+                        const void* noise, const int32_t* n_valid, const void* g_lml,
+                        void* lml, void* d_z, void* d_mean, void* d_lengthscale,
+                        void* d_outputscale, void* d_noise, int32_t* info,
+                        int B, int P, int n, int f, int dtype, void* stream);
+
+/* ---- A11: exact posterior predictive -----------------------------------------------------------
+ * mu[b,s]  = mt[b,s] + K*x (Kxx + noise I)^-1 (y - mean)
+ * var[b,s] = os - |L^-1 k*s|^2 + noise                 (diagonal of the predictive covariance)
+ * cov[B,m,m] (optional) = K** - K*x (Kxx+noise I)^-1 Kx* + noise I
+ * Replaces eval-mode ExactGP.__call__ + likelihood(...) (GPR_meta_mll.py:174-181,
+ * GPR_meta_svgd.py:203-212, GPR_meta_vi.py:229-252).  n as for pacoh_gp_lml_fwd; any m >= 1.
+ * mean_tst follows mean_mode (vector: [B,m]).  workspace: pacoh_gp_predict_workspace_bytes(). */
+size_t pacoh_gp_predict_workspace_bytes(int B, int n, int m, int dtype, int want_cov);
+
+int pacoh_gp_predict(const void* z_ctx, int z_div, const void* mean_ctx, int mean_mode,
+                     const void* y, int y_div, const void* z_tst, int zt_div, const void* mean_tst,
+                     const void* lengthscale, const void* outputscale, const void* noise,
+                     const int32_t* n_valid, void* mu, void* var, void* cov, int32_t* info,
+                     void* workspace, int B, int P, int n, int m, int f, int dtype, void* stream);
+
+/* ---- dense path (large n): Cholesky-based Gaussian log-density of materialised covariances -----
+ * logp[b] = log N(resid[b]; 0, A[b]) * scale,  A[B,n,n] symmetric (lower triangle read), destroyed
+ * (overwritten by its Cholesky factor).  With A from pacoh_gram_rbf_ard(..., add_noise_diag=1) and
+ * scale = 1/n this is the LML of the large-context configuration (n = 512, fp64); with A = cov from
+ * pacoh_gp_predict it is the joint test log-likelihood of RegressionModelMetaLearned.eval
+ * (meta_learn/abstract.py:134-163).  Any n; one workgroup per matrix, matrix stays in L2/MALL. */
+int pacoh_mvn_logprob_dense(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info,
+                            double scale, int B, int n, int dtype, void* stream);
+
+/* ---- A2: per-particle ("vectorised") MLP ------------------------------------------------------
+ * out[b] = MLP_{theta_p}(x[b / x_div]),  tanh hidden layers, linear output.  theta points at the
+ * network's block inside the particle matrix, consecutive particles are theta_stride elements apart;
+ * block layout per layer: bias[out] then weight[out,in] row-major -- the reference's flattened layout
+ * (LinearVectorized.parameter_shapes, models.py:319-323).  P = 1 gives the shared-weight network of
+ * PACOH-MAP (NeuralNetwork.forward, models.py:211-217).
+ * Replaces NeuralNetworkVectorized.forward / LinearVectorized.forward (models.py:295-317,343-349).
+ * hidden: HOST array of n_hidden layer widths.  Limits: d_in<=16, widths<=64, d_out<=8, n_hidden<=3. */
+int pacoh_mlp_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P,
+                  int d_in, const int32_t* hidden, int n_hidden, int d_out, void* out,
+                  int B, int n, int dtype, void* stream);
+
+/* Backward: d_theta[P, D_net] (row stride d_theta_stride) = sum over the problems b of particle p of
+ * d out[b]/d theta_p ^T g_out[b]; activations are recomputed from x (nothing is saved by the forward).
+ * Deterministic two-stage reduction through `workspace` (pacoh_mlp_bwd_workspace_bytes). If
+ * `accumulate` != 0 the result is added to d_theta, else it overwrites the block. */
+size_t pacoh_mlp_bwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden,
+                                     int n_hidden, int d_out, int dtype);
+
+int pacoh_mlp_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P,
+                  int d_in, const int32_t* hidden, int n_hidden, int d_out, const void* g_out,
+                  void* d_theta, long d_theta_stride, int accumulate, void* workspace,
+                  int B, int n, int dtype, void* stream);
+
+/* ---- A3 + A7: parameter transforms, hyper-prior ------------------------------------------------
+ * softplus with optional floor, forward:  out = log(1+exp(raw)) + floor            (random_gp.py:69-74;
+ * MAP: gpytorch Positive / GreaterThan(1e-3) constraints, GPR_meta_mll.py:54-55)
+ * backward: d_raw = g * sigmoid(raw).  Elementwise over `count` values. */
+int pacoh_softplus_fwd(const void* raw, void* out, double floor, long count, int dtype, void* stream);
+int pacoh_softplus_bwd(const void* raw, const void* g, void* d_raw, int accumulate, long count,
+                       int dtype, void* stream);
+
+/* logp[p] = sum_d log N(theta[p,d]; prior_mean[d], prior_std[d]);  grad[p,d] (optional, += scaled):
+ * grad += grad_scale * d logp / d theta.  Replaces CatDist.log_prob over the Normal blocks
+ * (random_gp.py:128-157,179-180; models.py:159-181) and its autograd backward. */
+int pacoh_prior_logprob_grad(const void* theta, const void* prior_mean, const void* prior_std,
+                             void* logp, void* grad, double grad_scale, int P, int D, int dtype,
+                             void* stream);
+
+/* ---- A9: SVGD update direction -----------------------------------------------------------------
+ * phi[i,:] = ( sum_j k_ij score[j,:] + 2 gamma sum_j k_ij (X[i,:] - X[j,:]) ) / P,
+ * k_ij = exp(-gamma |X_i - X_j|^2), gamma = 1/(1e-8 + 2 bw^2); bandwidth <= 0 selects the median
+ * heuristic bw = sqrt(median(|X_i-X_j|^2 over the full PxP matrix incl. the zero diagonal) /
+ * (2 ln(P+1))), numpy-median semantics.  Replaces SVGD.phi + RBF_Kernel (meta_learn/svgd.py:12-59).
+ * P <= 64.  workspace: pacoh_svgd_workspace_bytes().  neg != 0 writes -phi (the "gradient" handed to
+ * the optimizer, svgd.py:27).  bw_out (optional, 1 value): the bandwidth used. */
+size_t pacoh_svgd_workspace_bytes(int P, int D, int dtype);
+int pacoh_svgd_phi(const void* X, const void* score, double bandwidth, int neg, void* phi,
+                   void* bw_out, void* workspace, int P, int D, int dtype, void* stream);
+
+/* ---- A8/A9/A10: optimizer step -----------------------------------------------------------------
+ * One fused Adam / AdamW (decoupled weight decay) step over `count` parameters, state m,v in place;
+ * `step` is the 1-based step count (bias correction), matching torch.optim.Adam / AdamW defaults
+ * (GPR_meta_mll.py:255, GPR_meta_svgd.py:220-223, GPR_meta_vi.py:258-261). */
+int pacoh_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq,
+                    double lr, double beta1, double beta2, double eps, double weight_decay,
+                    long step, long count, int dtype, void* stream);
+
+/* ---- reductions used by the host between kernels ----------------------------------------------
+ * out[p, :] (+)= scale * sum_t in[t, p, :]   (in is [T, P, W]); deterministic (fixed order). */
+int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, int T, int P, int W,
+                       int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PACOH_GP_H */

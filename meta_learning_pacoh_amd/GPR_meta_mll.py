@@ -1,0 +1,181 @@
+"""PACOH-MAP on MI355X: same constructor / meta_fit / predict / state_dict API as the reference's
+GPRegressionMetaLearned (meta_learn/GPR_meta_mll.py:12-264); the per-task ExactGP + autograd + AdamW
+loop (:104-117) runs as a handful of HIP kernel launches per iteration over the whole task batch."""
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .abstract import RegressionModelMetaLearned
+from .distributions import GaussianPredictive
+from .engine import GPEngine, ParamLayout, TaskBatch
+from .util import StepLR
+
+
+class GPRegressionMetaLearned(RegressionModelMetaLearned):
+
+    def __init__(self, meta_train_data, learning_mode='both', lr_params=1e-3, weight_decay=0.0, feature_dim=2,
+                 num_iter_fit=10000, covar_module='NN', mean_module='NN', mean_nn_layers=(32, 32),
+                 kernel_nn_layers=(32, 32), task_batch_size=5, normalize_data=True, optimizer='Adam',
+                 lr_decay=1.0, random_seed=None):
+        """Arguments as in the reference (GPR_meta_mll.py:14-38)."""
+        super().__init__(normalize_data, random_seed)
+        assert learning_mode in ['learn_mean', 'learn_kernel', 'both', 'vanilla']
+        assert mean_module in ['NN', 'constant', 'zero'], 'gpytorch module objects are not supported on the HIP path'
+        assert covar_module in ['NN', 'SE'], 'gpytorch module objects are not supported on the HIP path'
+        assert optimizer in ['Adam', 'SGD']
+
+        self.lr_params, self.weight_decay, self.feature_dim = lr_params, weight_decay, feature_dim
+        self.num_iter_fit, self.task_batch_size, self.normalize_data = num_iter_fit, task_batch_size, normalize_data
+        self.optimizer_name, self.learning_mode = optimizer, learning_mode
+
+        meta_train_data = list(meta_train_data)
+        self._check_meta_data_shapes(meta_train_data)
+        self._compute_normalization_stats(meta_train_data)
+
+        self._setup_gp_prior(mean_module, covar_module, learning_mode, feature_dim, mean_nn_layers, kernel_nn_layers)
+        self.engine = GPEngine(self.layout, noise_floor=1e-3)        # GreaterThan(1e-3), GPR_meta_mll.py:54-55
+
+        tasks = [self._prepare_data_per_task(x, y) for x, y in meta_train_data]
+        self.tasks = TaskBatch(tasks, self.device, self.dtype)
+        self._setup_optimizer(optimizer, lr_params, lr_decay)
+        self.fitted = False
+
+    # ------------------------------------------------------------------------------------------
+    def _setup_gp_prior(self, mean_module, covar_module, learning_mode, feature_dim, mean_nn_layers, kernel_nn_layers):
+        """GPR_meta_mll.py:207-251.  Shared parameters live in ONE flat vector theta[1, D] (layout:
+        engine.ParamLayout); RNG consumption order = the reference's: kernel net first, then mean net,
+        each torch.nn.Linear in construction order."""
+        if covar_module == 'NN':
+            assert learning_mode in ['learn_kernel', 'both'], 'neural network parameters must be learned'
+        if mean_module == 'NN':
+            assert learning_mode in ['learn_mean', 'both'], 'neural network parameters must be learned'
+        self.layout = ParamLayout(self.input_dim, mean_module, covar_module, mean_nn_layers, kernel_nn_layers,
+                                  feature_dim, with_outputscale=True)
+        lay = self.layout
+        theta = torch.zeros(lay.D)                     # raw GP hyper-parameters start at 0 (gpytorch default)
+
+        def init_net(prefix, out_dim, layers):
+            prev = self.input_dim
+            names = ['fc_%i' % (i + 1) for i in range(len(layers))] + ['out']
+            for name, size in zip(names, list(layers) + [out_dim]):
+                lin = torch.nn.Linear(prev, size)      # same init + RNG stream as models.py:204-207
+                lo, hi = lay.slices['%s.%s.bias' % (prefix, name)]
+                theta[lo:hi] = lin.bias.detach()
+                lo, hi = lay.slices['%s.%s.weight' % (prefix, name)]
+                theta[lo:hi] = lin.weight.detach().reshape(-1)
+                prev = size
+
+        if covar_module == 'NN':
+            init_net('kernel_nn', feature_dim, kernel_nn_layers)
+        if mean_module == 'NN':
+            init_net('mean_nn', 1, mean_nn_layers)
+        self.theta = theta.reshape(1, -1).to(self.dtype).to(self.device)
+
+        # which segments of theta the optimizer updates (learning_mode, GPR_meta_mll.py:244-251)
+        segs = []
+        if learning_mode in ('learn_kernel', 'both'):
+            if covar_module == 'NN':
+                segs.append(lay.block_range('kernel_nn.'))
+            segs.append(lay.slices['lengthscale_raw'])
+            segs.append(lay.slices['outputscale_raw'])
+        if learning_mode in ('learn_mean', 'both'):
+            if mean_module == 'NN':
+                segs.append(lay.block_range('mean_nn.'))
+            elif mean_module == 'constant':
+                segs.append(lay.slices['constant_mean'])
+        segs.append(lay.slices['noise_raw'])           # the likelihood is always trained (:56)
+        segs = sorted(segs)
+        merged = [list(segs[0])]
+        for lo, hi in segs[1:]:
+            if lo == merged[-1][1]:
+                merged[-1][1] = hi
+            else:
+                merged.append([lo, hi])
+        self.train_segments = [tuple(s) for s in merged]
+        self.shared_parameters = self.train_segments
+
+    def _setup_optimizer(self, optimizer, lr, lr_decay):
+        """AdamW with weight decay on EVERY group (GPR_meta_mll.py:255) / plain SGD; StepLR(1000, lr_decay)."""
+        self.exp_avg = torch.zeros_like(self.theta)
+        self.exp_avg_sq = torch.zeros_like(self.theta)
+        self.opt_step = 0
+        self.lr_scheduler = StepLR(lr, 1000, lr_decay)
+
+    def _apply_update(self, grad):
+        self.opt_step += 1
+        lr = self.lr_scheduler.lr
+        for lo, hi in self.train_segments:
+            p, g = self.theta[0, lo:hi], grad[0, lo:hi]
+            if self.optimizer_name == 'Adam':
+                L.adam_step(p, g, self.exp_avg[0, lo:hi], self.exp_avg_sq[0, lo:hi], lr, self.opt_step,
+                            weight_decay=self.weight_decay)
+            else:
+                p.add_(g, alpha=-lr)
+
+    # ------------------------------------------------------------------------------------------
+    def meta_fit(self, valid_tuples=None, verbose=True, log_period=500, n_iter=None):
+        """GPR_meta_mll.py:82-147: loss = -sum over the sampled tasks of the per-datapoint MLL."""
+        assert (valid_tuples is None) or (all([len(valid_tuple) == 4 for valid_tuple in valid_tuples]))
+        loss_val = float('nan')
+        if len(self.train_segments) > 0:
+            t = time.time()
+            cum_loss = torch.zeros((), dtype=self.dtype, device=self.device)
+            if n_iter is None:
+                n_iter = self.num_iter_fit
+            loss = None
+            for itr in range(1, n_iter + 1):
+                # rds_numpy.choice(task_dicts, size=B) == randint(0, T, B): with replacement (:109)
+                idx = self.rds_numpy.randint(0, self.tasks.T, size=self.task_batch_size)
+                batch = self.tasks.select(torch.from_numpy(idx).to(self.device))
+                lml, grad, _ = self.engine.lml_and_grad(self.theta, batch, weight=-1.0)
+                loss = -lml.sum()
+                self._apply_update(grad)
+                self.lr_scheduler.step()
+                cum_loss += loss
+                if itr == 1 or itr % log_period == 0:
+                    duration = time.time() - t
+                    avg_loss = cum_loss / (log_period if itr > 1 else 1.0)
+                    message = 'Iter %d/%d - Loss: %.6f - Time %.2f sec' % (itr, self.num_iter_fit, avg_loss.item(), duration)
+                    cum_loss.zero_()
+                    t = time.time()
+                    if valid_tuples is not None:
+                        valid_ll, valid_rmse, calibr_err = self.eval_datasets(valid_tuples)
+                        message += ' - Valid-LL: %.3f - Valid-RMSE: %.3f - Calib-Err %.3f' % (valid_ll, valid_rmse, calibr_err)
+                    self._last_log = message
+                    if verbose:
+                        self.logger.info(message)
+            if loss is not None:
+                loss_val = loss.item()
+        else:
+            self.logger.info('Vanilla mode - nothing to fit')
+        self.fitted = True
+        return loss_val
+
+    def predict(self, context_x, context_y, test_x, return_density=False):
+        """GPR_meta_mll.py:149-190 -> (pred_mean, pred_std) numpy, or the predictive distribution."""
+        cx, cy, tx = self._prepare_predict(context_x, context_y, test_x)
+        mu, var, cov, _ = self.engine.predict(self.theta, cx, cy, tx, want_cov=return_density)
+        dist = GaussianPredictive(mu, var, cov, self.y_mean.reshape(-1)[0], self.y_std.reshape(-1)[0], mixture=False)
+        if return_density:
+            return dist
+        return dist.mean.cpu().numpy(), dist.stddev.cpu().numpy()
+
+    # ------------------------------------------------------------------------------------------
+    def state_dict(self):
+        """same dict layout as the reference ({'optimizer', 'model'}, GPR_meta_mll.py:192-205)"""
+        model = OrderedDict((name, self.theta[0, lo:hi].detach().cpu().clone()) for name, (lo, hi) in self.layout.slices.items())
+        return {'optimizer': {'exp_avg': self.exp_avg.cpu().clone(), 'exp_avg_sq': self.exp_avg_sq.cpu().clone(),
+                              'step': self.opt_step, 'epoch': self.lr_scheduler.epoch},
+                'model': model}
+
+    def load_state_dict(self, state_dict):
+        for name, (lo, hi) in self.layout.slices.items():
+            self.theta[0, lo:hi] = state_dict['model'][name].to(self.dtype).to(self.device)
+        opt = state_dict['optimizer']
+        self.exp_avg.copy_(opt['exp_avg'])
+        self.exp_avg_sq.copy_(opt['exp_avg_sq'])
+        self.opt_step = int(opt['step'])
+        self.lr_scheduler.epoch = int(opt['epoch'])

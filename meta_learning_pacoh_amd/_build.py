@@ -1,0 +1,74 @@
+"""Build libpacoh_gp.so (the C-ABI library of hand-written HIP kernels) in-tree for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container; the resulting
+.so travels to the GPU box with the repository snapshot (it is git-ignored, not gpurun-ignored).
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
+OBJ_DIR = os.path.join(HERE, 'build')
+LIB_DIR = os.path.join(HERE, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libpacoh_gp.so')
+SOURCES = ['gp_small.hip', 'gram.hip', 'dense.hip', 'mlp.hip', 'mlp_f32.hip', 'mlp_f64.hip', 'misc.hip', 'meta_fused.hip']
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-Wno-pass-failed', '-Wno-unused-value']
+
+
+def _hipcc():
+    for cand in (shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found: libpacoh_gp.so cannot be built')
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.inc'))]
+    hdrs.append(os.path.join(INCLUDE, 'pacoh_gp.h'))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def build_library(force=False, verbose=True):
+    """Compile every .hip source for gfx950 and link the shared library.  Returns its path."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    hdr_m = _deps_mtime()
+    sources = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    jobs = []
+    for src in sources:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ_DIR, src.replace('.hip', '.o'))
+        stale = force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_m)
+        if stale:
+            jobs.append((sp, op))
+
+    def compile_one(job):
+        sp, op = job
+        cmd = [hipcc] + FLAGS + ['-I', INCLUDE, '-c', sp, '-o', op]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for %s:\n%s' % (sp, r.stdout[-4000:]))
+        return sp
+
+    if jobs:
+        if verbose:
+            print('[pacoh build] compiling %d source(s) for %s' % (len(jobs), ARCH), file=sys.stderr)
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(compile_one, jobs))
+    objs = [os.path.join(OBJ_DIR, s.replace('.hip', '.o')) for s in sources]
+    if jobs or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs):
+        cmd = [hipcc, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIB_PATH] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s' % r.stdout[-4000:])
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build_library(force='--force' in sys.argv))

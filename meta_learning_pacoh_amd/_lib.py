@@ -1,0 +1,278 @@
+"""ctypes binding of libpacoh_gp.so (include/pacoh_gp.h) for PyTorch-ROCm tensors.
+
+PyTorch is used for device memory, streams and torch.distributed only; every arithmetic step of the
+hot path goes through the C ABI below.  There is NO fallback: if the library is missing or a tensor
+is not on a HIP device the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libpacoh_gp.so')
+
+F32, F64 = 0, 1
+MEAN_ZERO, MEAN_VECTOR, MEAN_CONST = 0, 1, 2
+ERRORS = {-1: 'PACOH_EINVAL (bad argument)', -2: 'PACOH_ELIMIT (shape outside kernel limits)',
+          -3: 'PACOH_EDTYPE', -4: 'PACOH_ELAUNCH (HIP launch failed)'}
+
+_c = ctypes
+_vp, _i, _l, _d, _sz = _c.c_void_p, _c.c_int, _c.c_long, _c.c_double, _c.c_size_t
+_ip = _c.POINTER(_c.c_int32)
+
+# symbol -> (restype, argtypes); must list every function declared in include/pacoh_gp.h
+SIGNATURES = {
+    'pacoh_abi_version': (_i, []),
+    'pacoh_gram_rbf_ard': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'pacoh_gp_small_max_n': (_i, [_i, _i]),
+    'pacoh_gp_lml_fwd': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'pacoh_gp_lml_fwdbwd': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _i, _i, _i, _i, _i, _vp]),
+    'pacoh_gp_predict_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'pacoh_gp_predict': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                              _i, _i, _i, _i, _i, _i, _vp]),
+    'pacoh_mvn_logprob_dense': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
+    'pacoh_mlp_fwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _i, _i, _i, _vp]),
+    'pacoh_mlp_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i]),
+    'pacoh_mlp_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _l, _i, _vp, _i, _i, _i, _vp]),
+    'pacoh_softplus_fwd': (_i, [_vp, _vp, _d, _l, _i, _vp]),
+    'pacoh_softplus_bwd': (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),
+    'pacoh_prior_logprob_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
+    'pacoh_svgd_workspace_bytes': (_sz, [_i, _i, _i]),
+    'pacoh_svgd_phi': (_i, [_vp, _vp, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pacoh_adam_step': (_i, [_vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _l, _l, _i, _vp]),
+    'pacoh_reduce_tasks': (_i, [_vp, _vp, _d, _i, _i, _i, _i, _i, _vp]),
+    'pacoh_meta_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'pacoh_meta_lml_grad': (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load (once) and return the ctypes handle; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libpacoh_gp.so not found at %s -- build it with `python -c "import __graft_entry__ as g; '
+                'g.build()"` (needs hipcc). There is no CPU fallback for the PACOH GP path.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            if not hasattr(lib, name):
+                if name.startswith('pacoh_meta_'):
+                    continue          # optional fused path (added in a later build)
+                raise RuntimeError('libpacoh_gp.so does not export %s (stale build?)' % name)
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float64:
+        return F64
+    raise TypeError('PACOH kernels support float32/float64 tensors, got %s' % t.dtype)
+
+
+def _ptr(t, like=None):
+    """device pointer of a contiguous HIP tensor (None -> NULL)"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('PACOH kernels need tensors on a HIP device (got %s); there is no CPU path' % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError('PACOH kernels need contiguous tensors')
+    if like is not None and t.dtype != like.dtype and t.dtype not in (torch.int32,):
+        raise TypeError('mixed dtypes in one PACOH call: %s vs %s' % (t.dtype, like.dtype))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed: %s' % (what, ERRORS.get(rc, rc)))
+
+
+def _hidden_arr(hidden):
+    arr = (ctypes.c_int32 * max(1, len(hidden)))(*hidden)
+    return arr
+
+
+# ------------------------------------------------------------------------------------------------
+# thin typed wrappers (shapes are validated here, the C side validates limits)
+# ------------------------------------------------------------------------------------------------
+
+def gram_rbf_ard(z1, z1_div, z2, z2_div, lengthscale, outputscale, noise, add_noise_diag, B, P):
+    lib = load_library()
+    n, f = z1.shape[-2], z1.shape[-1]
+    m = z2.shape[-2]
+    K = torch.empty(B, n, m, dtype=z1.dtype, device=z1.device)
+    _check(lib.pacoh_gram_rbf_ard(_ptr(z1), z1_div, _ptr(z2, z1), z2_div, _ptr(lengthscale, z1), _ptr(outputscale, z1),
+                                  _ptr(noise, z1), int(bool(add_noise_diag)), _ptr(K), B, P, n, m, f, dtype_code(z1),
+                                  _stream()), 'pacoh_gram_rbf_ard')
+    return K
+
+
+def gp_small_max_n(dtype, want_grad):
+    return load_library().pacoh_gp_small_max_n(F32 if dtype == torch.float32 else F64, int(want_grad))
+
+
+def gp_lml_fwd(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, B, P, n_valid=None,
+               want_alpha=False, want_L=False):
+    lib = load_library()
+    n, f = z.shape[-2], z.shape[-1]
+    dev, dt = z.device, z.dtype
+    lml = torch.empty(B, dtype=dt, device=dev)
+    alpha = torch.empty(B, n, dtype=dt, device=dev) if want_alpha else None
+    L = torch.empty(B, n, n, dtype=dt, device=dev) if want_L else None
+    info = torch.empty(B, dtype=torch.int32, device=dev)
+    _check(lib.pacoh_gp_lml_fwd(_ptr(z), z_div, _ptr(mean, z), mean_mode, _ptr(y, z), y_div, _ptr(lengthscale, z),
+                                _ptr(outputscale, z), _ptr(noise, z), _ptr(n_valid), _ptr(lml), _ptr(alpha), _ptr(L),
+                                _ptr(info), B, P, n, f, dtype_code(z), _stream()), 'pacoh_gp_lml_fwd')
+    return lml, alpha, L, info
+
+
+def gp_lml_fwdbwd(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, B, P, n_valid=None,
+                  g_lml=None, want_dz=True):
+    lib = load_library()
+    n, f = z.shape[-2], z.shape[-1]
+    dev, dt = z.device, z.dtype
+    lml = torch.empty(B, dtype=dt, device=dev)
+    d_z = torch.empty(B, n, f, dtype=dt, device=dev) if want_dz else None
+    if mean_mode == MEAN_VECTOR:
+        d_mean = torch.empty(B, n, dtype=dt, device=dev)
+    elif mean_mode == MEAN_CONST:
+        d_mean = torch.empty(B, dtype=dt, device=dev)
+    else:
+        d_mean = None
+    d_ls = torch.empty(B, f, dtype=dt, device=dev)
+    d_os = torch.empty(B, dtype=dt, device=dev) if outputscale is not None else None
+    d_noise = torch.empty(B, dtype=dt, device=dev)
+    info = torch.empty(B, dtype=torch.int32, device=dev)
+    _check(lib.pacoh_gp_lml_fwdbwd(_ptr(z), z_div, _ptr(mean, z), mean_mode, _ptr(y, z), y_div, _ptr(lengthscale, z),
+                                   _ptr(outputscale, z), _ptr(noise, z), _ptr(n_valid), _ptr(g_lml, z), _ptr(lml),
+                                   _ptr(d_z), _ptr(d_mean), _ptr(d_ls), _ptr(d_os), _ptr(d_noise), _ptr(info),
+                                   B, P, n, f, dtype_code(z), _stream()), 'pacoh_gp_lml_fwdbwd')
+    return lml, d_z, d_mean, d_ls, d_os, d_noise, info
+
+
+def gp_predict(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, z_tst, zt_div, mean_tst, lengthscale, outputscale, noise,
+               B, P, n_valid=None, want_cov=False):
+    lib = load_library()
+    n, f = z_ctx.shape[-2], z_ctx.shape[-1]
+    m = z_tst.shape[-2]
+    dev, dt = z_ctx.device, z_ctx.dtype
+    code = dtype_code(z_ctx)
+    mu = torch.empty(B, m, dtype=dt, device=dev)
+    var = torch.empty(B, m, dtype=dt, device=dev)
+    cov = torch.empty(B, m, m, dtype=dt, device=dev) if want_cov else None
+    ws_bytes = lib.pacoh_gp_predict_workspace_bytes(B, n, m, code, int(want_cov))
+    ws = torch.empty(max(1, ws_bytes), dtype=torch.uint8, device=dev) if want_cov else None
+    info = torch.empty(B, dtype=torch.int32, device=dev)
+    _check(lib.pacoh_gp_predict(_ptr(z_ctx), z_div, _ptr(mean_ctx, z_ctx), mean_mode, _ptr(y, z_ctx), y_div,
+                                _ptr(z_tst, z_ctx), zt_div, _ptr(mean_tst, z_ctx), _ptr(lengthscale, z_ctx),
+                                _ptr(outputscale, z_ctx), _ptr(noise, z_ctx), _ptr(n_valid), _ptr(mu), _ptr(var),
+                                _ptr(cov), _ptr(info), _ptr(ws), B, P, n, m, f, code, _stream()), 'pacoh_gp_predict')
+    return mu, var, cov, info
+
+
+def mvn_logprob_dense(A, resid, scale=1.0, want_alpha=False):
+    """A [B,n,n] is DESTROYED (overwritten with its Cholesky factor)."""
+    lib = load_library()
+    B, n = A.shape[0], A.shape[-1]
+    logp = torch.empty(B, dtype=A.dtype, device=A.device)
+    alpha = torch.empty(B, n, dtype=A.dtype, device=A.device) if want_alpha else None
+    info = torch.empty(B, dtype=torch.int32, device=A.device)
+    _check(lib.pacoh_mvn_logprob_dense(_ptr(A), _ptr(resid, A), _ptr(logp), _ptr(alpha), _ptr(info), float(scale),
+                                       B, n, dtype_code(A), _stream()), 'pacoh_mvn_logprob_dense')
+    return logp, alpha, info
+
+
+def mlp_fwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, B, n):
+    lib = load_library()
+    out = torch.empty(B, n, d_out, dtype=x.dtype, device=x.device)
+    _check(lib.pacoh_mlp_fwd(_ptr(x), x_div, ctypes.c_void_p(theta_block.data_ptr()), theta_stride, P, d_in,
+                             _hidden_arr(hidden), len(hidden), d_out, _ptr(out), B, n, dtype_code(x), _stream()),
+           'pacoh_mlp_fwd')
+    return out
+
+
+def mlp_bwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, g_out, d_theta_block, d_theta_stride,
+            accumulate, B, n, workspace=None):
+    lib = load_library()
+    code = dtype_code(x)
+    harr = _hidden_arr(hidden)
+    need = lib.pacoh_mlp_bwd_workspace_bytes(B, P, n, d_in, harr, len(hidden), d_out, code)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(max(1, need), dtype=torch.uint8, device=x.device)
+    _check(lib.pacoh_mlp_bwd(_ptr(x), x_div, ctypes.c_void_p(theta_block.data_ptr()), theta_stride, P, d_in, harr,
+                             len(hidden), d_out, _ptr(g_out, x), ctypes.c_void_p(d_theta_block.data_ptr()),
+                             d_theta_stride, int(bool(accumulate)), _ptr(workspace), B, n, code, _stream()),
+           'pacoh_mlp_bwd')
+    return workspace
+
+
+def softplus_fwd(raw, floor=0.0):
+    lib = load_library()
+    out = torch.empty_like(raw)
+    _check(lib.pacoh_softplus_fwd(_ptr(raw), _ptr(out), float(floor), raw.numel(), dtype_code(raw), _stream()),
+           'pacoh_softplus_fwd')
+    return out
+
+
+def softplus_bwd(raw, g, d_raw=None, accumulate=False):
+    lib = load_library()
+    if d_raw is None:
+        d_raw = torch.empty_like(raw)
+        accumulate = False
+    _check(lib.pacoh_softplus_bwd(_ptr(raw), _ptr(g, raw), ctypes.c_void_p(d_raw.data_ptr()), int(bool(accumulate)),
+                                  raw.numel(), dtype_code(raw), _stream()), 'pacoh_softplus_bwd')
+    return d_raw
+
+
+def prior_logprob_grad(theta, prior_mean, prior_std, grad=None, grad_scale=1.0):
+    lib = load_library()
+    P, D = theta.shape
+    logp = torch.empty(P, dtype=theta.dtype, device=theta.device)
+    _check(lib.pacoh_prior_logprob_grad(_ptr(theta), _ptr(prior_mean, theta), _ptr(prior_std, theta), _ptr(logp),
+                                        _ptr(grad, theta), float(grad_scale), P, D, dtype_code(theta), _stream()),
+           'pacoh_prior_logprob_grad')
+    return logp
+
+
+def svgd_phi(X, score, bandwidth=None, neg=False, workspace=None):
+    lib = load_library()
+    P, D = X.shape
+    code = dtype_code(X)
+    need = lib.pacoh_svgd_workspace_bytes(P, D, code)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=X.device)
+    phi = torch.empty_like(X)
+    bw_out = torch.empty(1, dtype=X.dtype, device=X.device)
+    bw = -1.0 if bandwidth is None else float(bandwidth)
+    _check(lib.pacoh_svgd_phi(_ptr(X), _ptr(score, X), bw, int(bool(neg)), _ptr(phi), _ptr(bw_out), _ptr(workspace),
+                              P, D, code, _stream()), 'pacoh_svgd_phi')
+    return phi, bw_out, workspace
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    lib = load_library()
+    _check(lib.pacoh_adam_step(_ptr(param), _ptr(grad, param), _ptr(exp_avg, param), _ptr(exp_avg_sq, param),
+                               float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                               param.numel(), dtype_code(param), _stream()), 'pacoh_adam_step')
+
+
+def reduce_tasks(inp, out, scale=1.0, accumulate=False):
+    """out[P,W] (+)= scale * sum_t inp[T,P,W]"""
+    lib = load_library()
+    T, P, W = inp.shape
+    _check(lib.pacoh_reduce_tasks(_ptr(inp), ctypes.c_void_p(out.data_ptr()), float(scale), int(bool(accumulate)),
+                                  T, P, W, dtype_code(inp), _stream()), 'pacoh_reduce_tasks')
+    return out

@@ -1,0 +1,108 @@
+"""Base class of the meta-learners: seeding, normalisation, evaluation metrics, confidence intervals.
+Mirrors RegressionModelMetaLearned (meta_learn/abstract.py:117-272) -- host-side plumbing only."""
+import numpy as np
+import torch
+
+from .config import get_device
+from .util import _handle_input_dimensionality, get_logger
+
+
+class RegressionModelMetaLearned:
+
+    def __init__(self, normalize_data=True, random_seed=None):
+        self.normalize_data = normalize_data
+        self.logger = get_logger()
+        self.input_dim = None
+        self.output_dim = None
+        self.device = get_device()
+        self.dtype = torch.float32
+        if random_seed is not None:                       # abstract.py:125-129
+            torch.manual_seed(random_seed)
+            self.rds_numpy = np.random.RandomState(random_seed + 1)
+        else:
+            self.rds_numpy = np.random
+
+    def predict(self, context_x, context_y, test_x, **kwargs):
+        raise NotImplementedError
+
+    def eval(self, context_x, context_y, test_x, test_y, flatten_y=True, **kwargs):
+        """abstract.py:134-163 -> (avg joint log-likelihood per test point, rmse, calibration error)"""
+        context_x, context_y = _handle_input_dimensionality(context_x, context_y)
+        test_x, test_y = _handle_input_dimensionality(test_x, test_y)
+        test_y_tensor = torch.from_numpy(test_y).float().flatten().to(self.device)
+        pred_dist = self.predict(context_x, context_y, test_x, return_density=True, **kwargs)
+        avg_log_likelihood = torch.mean(pred_dist.log_prob(test_y_tensor) / test_y_tensor.shape[0])
+        rmse = torch.mean(torch.pow(pred_dist.mean - test_y_tensor, 2)).sqrt()
+        calibr_error = _calib_error(pred_dist, test_y_tensor)
+        return avg_log_likelihood.cpu().item(), rmse.cpu().item(), calibr_error.cpu().item()
+
+    def eval_datasets(self, test_tuples, flatten_y=True, **kwargs):
+        """abstract.py:165-181"""
+        assert (all([len(valid_tuple) == 4 for valid_tuple in test_tuples]))
+        ll_list, rmse_list, calibr_err_list = list(zip(*[self.eval(*t, flatten_y=flatten_y, **kwargs) for t in test_tuples]))
+        return np.mean(ll_list), np.mean(rmse_list), np.mean(calibr_err_list)
+
+    def confidence_intervals(self, context_x, context_y, test_x, confidence=0.9, **kwargs):
+        """abstract.py:183-204 -> (ucb, lcb)"""
+        pred_dist = self.predict(context_x, context_y, test_x, return_density=True, **kwargs)
+        alpha = (1 - confidence) / 2
+        m = _handle_input_dimensionality(np.asarray(test_x)).shape[0]
+        ucb = pred_dist.icdf(torch.ones(m) * (1 - alpha))
+        lcb = pred_dist.icdf(torch.ones(m) * alpha)
+        return ucb.cpu(), lcb.cpu()
+
+    # -- normalisation (abstract.py:212-258) --------------------------------------------------------
+    def _compute_normalization_stats(self, meta_train_tuples):
+        X_stack, Y_stack = list(zip(*[_handle_input_dimensionality(x, y) for x, y in meta_train_tuples]))
+        X, Y = np.concatenate(X_stack, axis=0), np.concatenate(Y_stack, axis=0)
+        if self.normalize_data:
+            self.x_mean, self.y_mean = np.mean(X, axis=0), np.mean(Y, axis=0)
+            self.x_std, self.y_std = np.std(X, axis=0) + 1e-8, np.std(Y, axis=0) + 1e-8
+        else:
+            self.x_mean, self.y_mean = np.zeros(X.shape[1]), np.zeros(Y.shape[1])
+            self.x_std, self.y_std = np.ones(X.shape[1]), np.ones(Y.shape[1])
+
+    def _normalize_data(self, X, Y=None):
+        assert hasattr(self, 'x_mean') and hasattr(self, 'x_std'), 'requires computing normalization stats beforehand'
+        X_normalized = (X - self.x_mean[None, :]) / self.x_std[None, :]
+        if Y is None:
+            return X_normalized
+        Y_normalized = (Y - self.y_mean[None, :]) / self.y_std[None, :]
+        return X_normalized, Y_normalized
+
+    def _check_meta_data_shapes(self, meta_train_data):
+        for i in range(len(meta_train_data)):
+            meta_train_data[i] = _handle_input_dimensionality(*meta_train_data[i])
+        self.input_dim = meta_train_data[0][0].shape[-1]
+        self.output_dim = meta_train_data[0][1].shape[-1]
+        assert all([self.input_dim == train_x.shape[-1] and self.output_dim == train_t.shape[-1]
+                    for train_x, train_t in meta_train_data])
+
+    def _prepare_data_per_task(self, x_data, y_data, flatten_y=True):
+        """numpy in, normalised float32 numpy out (the device copy is made by TaskBatch / predict)"""
+        x_data, y_data = _handle_input_dimensionality(x_data, y_data)
+        x_data, y_data = self._normalize_data(x_data, y_data)
+        if flatten_y:
+            assert y_data.shape[1] == 1
+            y_data = y_data.flatten()
+        return x_data.astype(np.float32), y_data.astype(np.float32)
+
+    def _to_device(self, arr):
+        return torch.from_numpy(np.ascontiguousarray(arr)).to(self.dtype).to(self.device)
+
+    def _prepare_predict(self, context_x, context_y, test_x):
+        context_x, context_y = _handle_input_dimensionality(context_x, context_y)
+        test_x = _handle_input_dimensionality(test_x)
+        assert test_x.shape[1] == context_x.shape[1]
+        cx, cy = self._prepare_data_per_task(context_x, context_y)
+        tx = self._normalize_data(X=test_x, Y=None).astype(np.float32)
+        return self._to_device(cx), self._to_device(cy), self._to_device(tx)
+
+
+def _calib_error(pred_dist, test_t_tensor):
+    """abstract.py:260-272 on the vectorised (marginal) predictive"""
+    cdf_vals = pred_dist.cdf(test_t_tensor).flatten()
+    num_points = test_t_tensor.flatten().shape[0]
+    conf_levels = torch.linspace(0.05, 0.95, 20, device=cdf_vals.device)
+    emp_freq_per_conf_level = torch.sum(cdf_vals[:, None] <= conf_levels, dim=0).float() / num_points
+    return torch.sqrt(torch.mean((emp_freq_per_conf_level - conf_levels) ** 2))

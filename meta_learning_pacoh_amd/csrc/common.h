@@ -1,0 +1,85 @@
+// Shared device/host helpers for the PACOH task-GP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/pacoh_gp.h"
+
+#define PACOH_WAVE 64
+
+namespace pacoh {
+
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { using type = float4; static constexpr int W = 4; };
+template <> struct VecOf<double> { using type = double2; static constexpr int W = 2; };
+
+template <typename T> __device__ __forceinline__ T t_exp(T x);
+template <> __device__ __forceinline__ float t_exp<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
+template <typename T> __device__ __forceinline__ T t_log(T x);
+template <> __device__ __forceinline__ float t_log<float>(float x) { return logf(x); }
+template <> __device__ __forceinline__ double t_log<double>(double x) { return log(x); }
+template <typename T> __device__ __forceinline__ T t_sqrt(T x);
+template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
+template <typename T> __device__ __forceinline__ T t_tanh(T x);
+template <> __device__ __forceinline__ float t_tanh<float>(float x) { return tanhf(x); }
+template <> __device__ __forceinline__ double t_tanh<double>(double x) { return tanh(x); }
+template <typename T> __device__ __forceinline__ T t_log1p(T x);
+template <> __device__ __forceinline__ float t_log1p<float>(float x) { return log1pf(x); }
+template <> __device__ __forceinline__ double t_log1p<double>(double x) { return log1p(x); }
+
+// Leading dimension (in elements) of an LDS matrix whose rows are read both "own row per lane"
+// (ds_read_b128, lane i at row i) and "one row broadcast to all lanes".  A multiple of the vector
+// width W whose quotient is odd spreads the 16 lanes of a ds_read_b128 lane-group over all 64 banks
+// (MI355X_MICROARCH.md, LDS): stride = 4*odd dwords -> 16 distinct 16-byte slots.
+template <typename T> __host__ __device__ inline int lds_ld(int n) {
+    const int W = VecOf<T>::W;
+    int q = (n + W - 1) / W;
+    if ((q & 1) == 0) q += 1;
+    return q * W;
+}
+
+// dot product of two LDS rows over the element range [lo, hi) widened to vector boundaries; the
+// caller guarantees that every widened element is zero in at least one of the two rows.
+template <typename T>
+__device__ __forceinline__ T dot_rows(const T* __restrict__ a, const T* __restrict__ b, int lo, int hi) {
+    using V = typename VecOf<T>::type;
+    constexpr int W = VecOf<T>::W;
+    const V* av = reinterpret_cast<const V*>(a);
+    const V* bv = reinterpret_cast<const V*>(b);
+    int v0 = lo / W, v1 = (hi + W - 1) / W;
+    T s0 = 0, s1 = 0;
+    if constexpr (W == 4) {
+        T s2 = 0, s3 = 0;
+#pragma unroll 4
+        for (int v = v0; v < v1; ++v) {
+            V x = av[v], y = bv[v];
+            s0 = fma(x.x, y.x, s0); s1 = fma(x.y, y.y, s1);
+            s2 = fma(x.z, y.z, s2); s3 = fma(x.w, y.w, s3);
+        }
+        return (s0 + s1) + (s2 + s3);
+    } else {
+#pragma unroll 4
+        for (int v = v0; v < v1; ++v) {
+            V x = av[v], y = bv[v];
+            s0 = fma(x.x, y.x, s0); s1 = fma(x.y, y.y, s1);
+        }
+        return s0 + s1;
+    }
+}
+
+template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int mask);
+template <> __device__ __forceinline__ float shfl_xor_t<float>(float v, int mask) { return __shfl_xor(v, mask, 64); }
+template <> __device__ __forceinline__ double shfl_xor_t<double>(double v, int mask) { return __shfl_xor(v, mask, 64); }
+
+// sum over the `gs` consecutive lanes (power of two <= 64) that contain this lane
+template <typename T> __device__ __forceinline__ T subwave_sum(T v, int gs) {
+    for (int m = 1; m < gs; m <<= 1) v += shfl_xor_t<T>(v, m);
+    return v;
+}
+
+inline int check_dtype(int dtype) { return (dtype == PACOH_F32 || dtype == PACOH_F64) ? 0 : PACOH_EDTYPE; }
+inline int launch_status() { return hipGetLastError() == hipSuccess ? PACOH_OK : PACOH_ELAUNCH; }
+
+}  // namespace pacoh

@@ -1,0 +1,221 @@
+// Dense (large-n) path: blocked right-looking Cholesky of materialised covariance matrices that live
+// in HBM/L2, one workgroup per matrix, followed by the triangular solves and the Gaussian log-density.
+// Used for the large-context configuration (n = 512, fp64: K comes from pacoh_gram_rbf_ard) and for
+// the joint test log-likelihood of RegressionModelMetaLearned.eval (meta_learn/abstract.py:134-163),
+// i.e. torch/gpytorch's MultivariateNormal.log_prob -> potrf/potrs on the reference's CPU path.
+#include "common.h"
+
+namespace pacoh {
+
+constexpr int NB = 32;     // panel width
+constexpr int TT = 64;     // trailing-update tile
+
+template <typename T>
+__global__ void __launch_bounds__(256) chol_dense_kernel(T* __restrict__ A, const T* __restrict__ resid,
+                                                         T* __restrict__ logp, T* __restrict__ alpha_out,
+                                                         int32_t* __restrict__ info, T scale, int n) {
+    // all LDS in ONE dynamic array (cdna_hip_programming.md Guideline 17: statics in front of the
+    // dynamic region can shift its base off its natural alignment)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* sm = reinterpret_cast<T*>(smem_raw);
+    T (*Ds)[NB + 1] = reinterpret_cast<T (*)[NB + 1]>(sm);
+    T (*Pa)[NB + 1] = reinterpret_cast<T (*)[NB + 1]>(sm + NB * (NB + 1));
+    T (*Pb)[NB + 1] = reinterpret_cast<T (*)[NB + 1]>(sm + NB * (NB + 1) + TT * (NB + 1));
+    T* invd_s = sm + NB * (NB + 1) + 2 * TT * (NB + 1);
+    T* red = invd_s + NB;
+    int* fail_p = reinterpret_cast<int*>(red + 4);
+    T* rv = red + 8;                                   // [n] residual -> u -> alpha
+#define fail_s (*fail_p)
+
+    const int tid = threadIdx.x;
+    T* Ab = A + (size_t)blockIdx.x * n * n;
+    if (tid == 0) fail_s = 0;
+    for (int q = tid; q < n; q += 256) rv[q] = resid[(size_t)blockIdx.x * n + q];
+    T logdet_part = 0;
+    __syncthreads();
+
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int kb = (n - k0 < NB) ? (n - k0) : NB;
+        // 1. diagonal block -> LDS (identity padded)
+        for (int q = tid; q < NB * NB; q += 256) {
+            int r = q / NB, c = q - r * NB;
+            T v = (r == c) ? T(1) : T(0);
+            if (r < kb && c <= r) v = Ab[(size_t)(k0 + r) * n + k0 + c];
+            Ds[r][c] = v;
+        }
+        __syncthreads();
+        // 2. factor it with one wavefront (lane = row), left-looking, pivot by shuffle
+        if (tid < 64) {
+            const int r = tid & 31;
+            for (int j = 0; j < NB; ++j) {
+                T s = Ds[r][j];
+                for (int c = 0; c < j; ++c) s = fma(-Ds[r][c], Ds[j][c], s);
+                T piv = __shfl(s, j, 64);
+                if (!(piv > T(0))) { if (tid == 0) fail_s = 1; piv = 1; }
+                T d = t_sqrt<T>(piv);
+                if (tid < 32) {
+                    if (r == j) { Ds[j][j] = d; invd_s[j] = T(1) / d; }
+                    else if (r > j) Ds[r][j] = s / d;
+                }
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < NB * NB; q += 256) {
+            int r = q / NB, c = q - r * NB;
+            if (r < kb && c <= r) Ab[(size_t)(k0 + r) * n + k0 + c] = Ds[r][c];
+        }
+        if (tid < kb) logdet_part += t_log<T>(Ds[tid][tid]);
+        // 3. panel below the block: x L11^T = a, one row per thread
+        for (int r = k0 + kb + tid; r < n; r += 256) {
+            T a[NB];
+            T* ap = Ab + (size_t)r * n + k0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) a[c] = (c < kb) ? ap[c] : T(0);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                T s = a[j];
+#pragma unroll
+                for (int c = 0; c < j; ++c) s = fma(-a[c], Ds[j][c], s);
+                a[j] = s * invd_s[j];
+            }
+#pragma unroll
+            for (int c = 0; c < NB; ++c) if (c < kb) ap[c] = a[c];
+        }
+        __syncthreads();
+        // 4. trailing update of the lower triangle: A22 -= L21 L21^T, 64x64 tiles, 4x4 per thread
+        const int t0 = k0 + kb;
+        const int tx = tid & 15, ty = tid >> 4;
+        for (int ti = t0; ti < n; ti += TT) {
+            for (int tj = t0; tj <= ti; tj += TT) {
+                for (int q = tid; q < TT * NB; q += 256) {
+                    int r = q / NB, c = q - r * NB;
+                    Pa[r][c] = (ti + r < n && c < kb) ? Ab[(size_t)(ti + r) * n + k0 + c] : T(0);
+                    Pb[r][c] = (tj + r < n && c < kb) ? Ab[(size_t)(tj + r) * n + k0 + c] : T(0);
+                }
+                __syncthreads();
+                T acc[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u][v] = 0;
+                for (int c = 0; c < NB; ++c) {
+                    T av[4], bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { av[u] = Pa[ty + 16 * u][c]; bv[u] = Pb[tx + 16 * u][c]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[u][v] = fma(av[u], bv[v], acc[u][v]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int gi = ti + ty + 16 * u;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        int gj = tj + tx + 16 * v;
+                        if (gi < n && gj <= gi) Ab[(size_t)gi * n + gj] -= acc[u][v];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- forward solve L u = r, blocked --------------------------------------------------------
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int kb = (n - k0 < NB) ? (n - k0) : NB;
+        for (int q = tid; q < NB * NB; q += 256) {
+            int r = q / NB, c = q - r * NB;
+            Ds[r][c] = (r < kb && c <= r) ? Ab[(size_t)(k0 + r) * n + k0 + c] : ((r == c) ? T(1) : T(0));
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int r = tid & 31;
+            T v = (r < kb) ? rv[k0 + r] : T(0);
+            for (int c = 0; c < NB; ++c) {
+                T uc = __shfl(v, c, 64) / Ds[c][c];
+                if (r == c) v = uc;
+                else if (r > c) v = fma(-Ds[r][c], uc, v);
+            }
+            if (tid < kb) rv[k0 + tid] = v;
+        }
+        __syncthreads();
+        for (int r = k0 + kb + tid; r < n; r += 256) {
+            const T* ap = Ab + (size_t)r * n + k0;
+            T s = rv[r];
+            for (int c = 0; c < kb; ++c) s = fma(-ap[c], rv[k0 + c], s);
+            rv[r] = s;
+        }
+        __syncthreads();
+    }
+    T quad_part = 0;
+    for (int q = tid; q < n; q += 256) quad_part = fma(rv[q], rv[q], quad_part);
+    quad_part = subwave_sum<T>(quad_part, 64);
+    logdet_part = subwave_sum<T>(logdet_part, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = quad_part;
+    __syncthreads();
+    T quad = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = logdet_part;
+    __syncthreads();
+    T logdet = red[0] + red[1] + red[2] + red[3];
+    const bool ok = fail_s == 0;
+    if (tid == 0) {
+        const T LOG2PI = T(1.8378770664093453);
+        T lp = T(-0.5) * (quad + T(2) * logdet + T(n) * LOG2PI) * scale;
+        logp[blockIdx.x] = ok ? lp : T(NAN);
+        if (info) info[blockIdx.x] = ok ? 0 : -1;
+    }
+    if (!alpha_out) return;
+    // ---- backward solve L^T alpha = u, blocked from the bottom ---------------------------------
+    const int nblk = (n + NB - 1) / NB;
+    for (int kbk = nblk - 1; kbk >= 0; --kbk) {
+        const int k0 = kbk * NB;
+        const int kb = (n - k0 < NB) ? (n - k0) : NB;
+        __syncthreads();
+        for (int q = tid; q < NB * NB; q += 256) {
+            int r = q / NB, c = q - r * NB;
+            Ds[r][c] = (r < kb && c <= r) ? Ab[(size_t)(k0 + r) * n + k0 + c] : ((r == c) ? T(1) : T(0));
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int r = tid & 31;
+            T v = (r < kb) ? rv[k0 + r] : T(0);
+            for (int c = NB - 1; c >= 0; --c) {
+                T ac = __shfl(v, c, 64) / Ds[c][c];
+                if (r == c) v = ac;
+                else if (r < c) v = fma(-Ds[c][r], ac, v);
+            }
+            if (tid < kb) rv[k0 + tid] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < k0; i += 256) {
+            T s = rv[i];
+            for (int c = 0; c < kb; ++c) s = fma(-Ab[(size_t)(k0 + c) * n + i], rv[k0 + c], s);
+            rv[i] = s;
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < n; q += 256) alpha_out[(size_t)blockIdx.x * n + q] = ok ? rv[q] : T(NAN);
+}
+
+#undef fail_s
+}  // namespace pacoh
+
+using namespace pacoh;
+
+extern "C" int pacoh_mvn_logprob_dense(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info,
+                                       double scale, int B, int n, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!A || !resid || !logp || B <= 0 || n <= 0) return PACOH_EINVAL;
+    size_t lds = ((size_t)n + NB * (NB + 1) + 2 * TT * (NB + 1) + NB + 8) * (dtype == PACOH_F64 ? 8 : 4);
+    if (lds > 64u * 1024u) return PACOH_ELIMIT;
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(chol_dense_kernel<float>, dim3(B), dim3(256), lds, (hipStream_t)stream, (float*)A,
+                           (const float*)resid, (float*)logp, (float*)alpha_out, info, (float)scale, n);
+    else
+        hipLaunchKernelGGL(chol_dense_kernel<double>, dim3(B), dim3(256), lds, (hipStream_t)stream, (double*)A,
+                           (const double*)resid, (double*)logp, (double*)alpha_out, info, scale, n);
+    return launch_status();
+}

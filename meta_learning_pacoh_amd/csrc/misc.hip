@@ -1,0 +1,256 @@
+// Small kernels around the GP core: parameter transforms (A3), hyper-prior (A7), SVGD update
+// direction (A9), fused Adam/AdamW step (A8-A10).  All are launch-latency sized (P <= 64 particles,
+// D ~ 10^3 parameters); they exist so that a whole meta-training step stays on the device and can be
+// captured into one hipGraph.
+#include "common.h"
+
+namespace pacoh {
+
+// ---- softplus (torch.nn.functional.softplus: beta=1, threshold=20) ------------------------------
+template <typename T>
+__global__ void softplus_fwd_kernel(const T* __restrict__ raw, T* __restrict__ out, T floor_, long count) {
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count) return;
+    T x = raw[q];
+    out[q] = (x > T(20) ? x : t_log1p<T>(t_exp<T>(x))) + floor_;
+}
+
+template <typename T>
+__global__ void softplus_bwd_kernel(const T* __restrict__ raw, const T* __restrict__ g, T* __restrict__ d_raw,
+                                    int accumulate, long count) {
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count) return;
+    T x = raw[q];
+    T sg = x > T(20) ? T(1) : T(1) / (T(1) + t_exp<T>(-x));
+    T v = g[q] * sg;
+    d_raw[q] = accumulate ? d_raw[q] + v : v;
+}
+
+// ---- hyper-prior: independent Normals over all D entries ----------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) prior_kernel(const T* __restrict__ theta, const T* __restrict__ mu,
+                                                    const T* __restrict__ sd, T* __restrict__ logp,
+                                                    T* __restrict__ grad, T grad_scale, int D) {
+    __shared__ T red[4];
+    const int p = blockIdx.x;
+    const T* th = theta + (long)p * D;
+    const T HALF_LOG2PI = T(0.9189385332046727);
+    T acc = 0;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        T s = sd[d];
+        T zv = (th[d] - mu[d]) / s;
+        acc += T(-0.5) * zv * zv - t_log<T>(s) - HALF_LOG2PI;
+        if (grad) grad[(long)p * D + d] += grad_scale * (-zv / s);
+    }
+    acc = subwave_sum<T>(acc, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && logp) logp[p] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- SVGD ---------------------------------------------------------------------------------------
+// stage 1: squared distances, one wave per (i,j) pair, direct differences
+template <typename T>
+__global__ void __launch_bounds__(64) svgd_dist_kernel(const T* __restrict__ X, T* __restrict__ d2, int P, int D) {
+    const int i = blockIdx.x / P, j = blockIdx.x - i * P;
+    if (j > i) return;
+    const T* xi = X + (long)i * D;
+    const T* xj = X + (long)j * D;
+    T acc = 0;
+    for (int d = threadIdx.x; d < D; d += 64) { T df = xi[d] - xj[d]; acc = fma(df, df, acc); }
+    acc = subwave_sum<T>(acc, 64);
+    if (threadIdx.x == 0) { d2[i * P + j] = acc; d2[j * P + i] = acc; }
+}
+
+// stage 2: bandwidth (median heuristic, numpy.median semantics over the full PxP matrix), kernel
+// matrix and its row sums.  One workgroup; bitonic sort of P*P <= 4096 values in LDS.
+template <typename T>
+__global__ void __launch_bounds__(256) svgd_kmat_kernel(const T* __restrict__ d2, T bandwidth, T* __restrict__ Kmat,
+                                                        T* __restrict__ rowsum, T* __restrict__ gamma_out,
+                                                        T* __restrict__ bw_out, int P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* srt = reinterpret_cast<T*>(smem_raw);
+    __shared__ T gam_s;
+    const int N = P * P;
+    int N2 = 1;
+    while (N2 < N) N2 <<= 1;
+    T bw = bandwidth;
+    if (!(bandwidth > T(0))) {
+        for (int q = threadIdx.x; q < N2; q += 256) srt[q] = q < N ? d2[q] : T(INFINITY);
+        __syncthreads();
+        for (int k = 2; k <= N2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int q = threadIdx.x; q < N2; q += 256) {
+                    int ixj = q ^ j;
+                    if (ixj > q) {
+                        T a = srt[q], b = srt[ixj];
+                        bool up = (q & k) == 0;
+                        if ((a > b) == up) { srt[q] = b; srt[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (threadIdx.x == 0) {
+            T med = (N & 1) ? srt[N / 2] : (srt[N / 2 - 1] + srt[N / 2]) * T(0.5);
+            T h = med / (T(2) * t_log<T>(T(P + 1)));
+            T b = t_sqrt<T>(h);
+            gam_s = T(1) / (T(1e-8) + T(2) * b * b);
+            if (bw_out) *bw_out = b;
+        }
+    } else if (threadIdx.x == 0) {
+        gam_s = T(1) / (T(1e-8) + T(2) * bw * bw);
+        if (bw_out) *bw_out = bw;
+    }
+    __syncthreads();
+    const T gam = gam_s;
+    if (threadIdx.x == 0) *gamma_out = gam;
+    for (int q = threadIdx.x; q < N; q += 256) Kmat[q] = t_exp<T>(-gam * d2[q]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += 256) {
+        T s = 0;
+        for (int j = 0; j < P; ++j) s += t_exp<T>(-gam * d2[i * P + j]);
+        rowsum[i] = s;
+    }
+}
+
+// stage 3: phi[i,d] = (sum_j K_ij (s_jd - 2 gamma x_jd) + 2 gamma x_id rowsum_i) / P, one thread per d
+template <typename T>
+__global__ void __launch_bounds__(256) svgd_phi_kernel(const T* __restrict__ X, const T* __restrict__ score,
+                                                       const T* __restrict__ Kmat, const T* __restrict__ rowsum,
+                                                       const T* __restrict__ gamma_p, int neg, T* __restrict__ phi,
+                                                       int P, int D) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);         // [P*P] + rowsum[P]
+    for (int q = threadIdx.x; q < P * P; q += 256) Ks[q] = Kmat[q];
+    for (int q = threadIdx.x; q < P; q += 256) Ks[P * P + q] = rowsum[q];
+    __syncthreads();
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    const T gam2 = T(2) * gamma_p[0];
+    T v[64], xs[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        if (j < P) { T x = X[(long)j * D + d]; xs[j] = x; v[j] = score[(long)j * D + d] - gam2 * x; }
+        else { xs[j] = 0; v[j] = 0; }
+    }
+    const T invP = T(1) / T(P);
+    for (int i = 0; i < P; ++i) {
+        T acc = 0;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) if (j < P) acc = fma(Ks[i * P + j], v[j], acc);
+        T xi = X[(long)i * D + d];
+        T r = (acc + gam2 * xi * Ks[P * P + i]) * invP;
+        phi[(long)i * D + d] = neg ? -r : r;
+    }
+}
+
+// ---- Adam / AdamW, op order of torch.optim._single_tensor_adam -----------------------------------
+template <typename T>
+__global__ void adam_kernel(T* __restrict__ param, const T* __restrict__ grad, T* __restrict__ m, T* __restrict__ v,
+                            T decay_mul, T one_minus_b1, T b2, T one_minus_b2, T step_size, T bc2_sqrt, T eps, long count) {
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count) return;
+    T g = grad[q];
+    T p = param[q] * decay_mul;
+    T mq = m[q];
+    mq = mq + (g - mq) * one_minus_b1;                 // exp_avg.lerp_(grad, 1 - beta1)
+    T vq = v[q] * b2 + one_minus_b2 * g * g;           // mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    T denom = t_sqrt<T>(vq) / bc2_sqrt + eps;
+    p = p - step_size * (mq / denom);
+    param[q] = p; m[q] = mq; v[q] = vq;
+}
+
+}  // namespace pacoh
+
+using namespace pacoh;
+
+extern "C" int pacoh_abi_version(void) { return 1; }
+
+extern "C" int pacoh_softplus_fwd(const void* raw, void* out, double floor_, long count, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!raw || !out || count <= 0) return PACOH_EINVAL;
+    unsigned blocks = (unsigned)((count + 255) / 256);
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(softplus_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)raw, (float*)out, (float)floor_, count);
+    else
+        hipLaunchKernelGGL(softplus_fwd_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)raw, (double*)out, floor_, count);
+    return launch_status();
+}
+
+extern "C" int pacoh_softplus_bwd(const void* raw, const void* g, void* d_raw, int accumulate, long count, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!raw || !g || !d_raw || count <= 0) return PACOH_EINVAL;
+    unsigned blocks = (unsigned)((count + 255) / 256);
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(softplus_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)raw, (const float*)g, (float*)d_raw, accumulate, count);
+    else
+        hipLaunchKernelGGL(softplus_bwd_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)raw, (const double*)g, (double*)d_raw, accumulate, count);
+    return launch_status();
+}
+
+extern "C" int pacoh_prior_logprob_grad(const void* theta, const void* prior_mean, const void* prior_std,
+                                        void* logp, void* grad, double grad_scale, int P, int D, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!theta || !prior_mean || !prior_std || P <= 0 || D <= 0) return PACOH_EINVAL;
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(prior_kernel<float>, dim3(P), dim3(256), 0, (hipStream_t)stream, (const float*)theta,
+                           (const float*)prior_mean, (const float*)prior_std, (float*)logp, (float*)grad, (float)grad_scale, D);
+    else
+        hipLaunchKernelGGL(prior_kernel<double>, dim3(P), dim3(256), 0, (hipStream_t)stream, (const double*)theta,
+                           (const double*)prior_mean, (const double*)prior_std, (double*)logp, (double*)grad, grad_scale, D);
+    return launch_status();
+}
+
+extern "C" size_t pacoh_svgd_workspace_bytes(int P, int D, int dtype) {
+    (void)D;
+    if (P <= 0) return 0;
+    return (size_t)(2 * P * P + P + 8) * (dtype == PACOH_F64 ? 8 : 4);
+}
+
+template <typename T>
+static int svgd_launch(const void* X, const void* score, double bandwidth, int neg, void* phi, void* bw_out,
+                       void* workspace, int P, int D, hipStream_t s) {
+    T* d2 = (T*)workspace;
+    T* Kmat = d2 + P * P;
+    T* rowsum = Kmat + P * P;
+    T* gamma = rowsum + P;
+    hipLaunchKernelGGL(svgd_dist_kernel<T>, dim3(P * P), dim3(64), 0, s, (const T*)X, d2, P, D);
+    int N2 = 1;
+    while (N2 < P * P) N2 <<= 1;
+    hipLaunchKernelGGL(svgd_kmat_kernel<T>, dim3(1), dim3(256), (size_t)N2 * sizeof(T), s, (const T*)d2, (T)bandwidth, Kmat,
+                       rowsum, gamma, (T*)bw_out, P);
+    hipLaunchKernelGGL(svgd_phi_kernel<T>, dim3((D + 255) / 256), dim3(256), (size_t)(P * P + P) * sizeof(T), s,
+                       (const T*)X, (const T*)score, (const T*)Kmat, (const T*)rowsum, (const T*)gamma, neg, (T*)phi, P, D);
+    return launch_status();
+}
+
+extern "C" int pacoh_svgd_phi(const void* X, const void* score, double bandwidth, int neg, void* phi,
+                              void* bw_out, void* workspace, int P, int D, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!X || !score || !phi || !workspace || P <= 0 || D <= 0) return PACOH_EINVAL;
+    if (P > 64) return PACOH_ELIMIT;
+    if (dtype == PACOH_F32) return svgd_launch<float>(X, score, bandwidth, neg, phi, bw_out, workspace, P, D, (hipStream_t)stream);
+    return svgd_launch<double>(X, score, bandwidth, neg, phi, bw_out, workspace, P, D, (hipStream_t)stream);
+}
+
+extern "C" int pacoh_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq,
+                               double lr, double beta1, double beta2, double eps, double weight_decay,
+                               long step, long count, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || count <= 0 || step <= 0) return PACOH_EINVAL;
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const double step_size = lr / bc1;
+    const double bc2_sqrt = sqrt(bc2);
+    const double decay_mul = 1.0 - lr * weight_decay;
+    unsigned blocks = (unsigned)((count + 255) / 256);
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(adam_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)param, (const float*)grad,
+                           (float*)exp_avg, (float*)exp_avg_sq, (float)decay_mul, (float)(1.0 - beta1), (float)beta2,
+                           (float)(1.0 - beta2), (float)step_size, (float)bc2_sqrt, (float)eps, count);
+    else
+        hipLaunchKernelGGL(adam_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (double*)param, (const double*)grad,
+                           (double*)exp_avg, (double*)exp_avg_sq, decay_mul, 1.0 - beta1, beta2, 1.0 - beta2, step_size, bc2_sqrt, eps, count);
+    return launch_status();
+}

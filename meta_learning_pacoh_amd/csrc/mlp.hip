@@ -1,0 +1,82 @@
+// C-ABI entry points of the per-particle MLP (kernels: mlp_impl.h, instantiated in mlp_f32/f64.hip).
+#include "common.h"
+
+namespace pacoh {
+#define PACOH_MLP_DECL(sfx) \
+int mlp_fwd_##sfx(const void*, int, const void*, long, int, int, const int32_t*, int, int, void*, int, int, hipStream_t); \
+int mlp_bwd_##sfx(const void*, int, const void*, long, int, int, const int32_t*, int, int, const void*, void*, long, int, void*, int, int, hipStream_t);
+PACOH_MLP_DECL(f32)
+PACOH_MLP_DECL(f64)
+#undef PACOH_MLP_DECL
+
+template <typename T>
+__global__ void reduce_tasks_kernel(const T* __restrict__ in, T* __restrict__ out, T scale, int accumulate, int C, int P, int Wd) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)P * Wd) return;
+    T s = 0;
+    for (int c = 0; c < C; ++c) s += in[(long)c * P * Wd + idx];
+    out[idx] = accumulate ? out[idx] + scale * s : scale * s;
+}
+}  // namespace pacoh
+
+using namespace pacoh;
+
+extern "C" int pacoh_mlp_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P,
+                             int d_in, const int32_t* hidden, int n_hidden, int d_out, void* out,
+                             int B, int n, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!out) return PACOH_EINVAL;
+    return dtype == PACOH_F32
+        ? mlp_fwd_f32(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, (hipStream_t)stream)
+        : mlp_fwd_f64(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, (hipStream_t)stream);
+}
+
+static int mlp_layout(int d_in, const int32_t* hidden, int n_hidden, int d_out, int& params, int& tile) {
+    if (d_in <= 0 || d_out <= 0 || n_hidden < 0 || n_hidden > PACOH_MAX_HIDDEN_LAYERS || (n_hidden > 0 && !hidden)) return -1;
+    int prev = d_in, mx = 0;
+    params = 0;
+    for (int l = 0; l < n_hidden; ++l) {
+        if (hidden[l] <= 0 || hidden[l] > PACOH_MAX_WIDTH) return -1;
+        params += hidden[l] * (prev + 1); prev = hidden[l]; mx = hidden[l] > mx ? hidden[l] : mx;
+    }
+    params += d_out * (prev + 1);
+    tile = mx <= 32 ? 256 : 128;
+    return 0;
+}
+
+extern "C" size_t pacoh_mlp_bwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden,
+                                                int n_hidden, int d_out, int dtype) {
+    int params, tile;
+    if (P <= 0 || B <= 0 || n <= 0 || mlp_layout(d_in, hidden, n_hidden, d_out, params, tile)) return 0;
+    long rows = (long)(B / P) * n;
+    long tiles = (rows + tile - 1) / tile;
+    long want = (2048 + P - 1) / P;
+    long chunks = tiles < want ? tiles : want;
+    if (chunks < 1) chunks = 1;
+    return (size_t)chunks * P * params * (dtype == PACOH_F64 ? 8 : 4);
+}
+
+extern "C" int pacoh_mlp_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P,
+                             int d_in, const int32_t* hidden, int n_hidden, int d_out, const void* g_out,
+                             void* d_theta, long d_theta_stride, int accumulate, void* workspace,
+                             int B, int n, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!g_out || !d_theta || !workspace) return PACOH_EINVAL;
+    return dtype == PACOH_F32
+        ? mlp_bwd_f32(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, accumulate, workspace, B, n, (hipStream_t)stream)
+        : mlp_bwd_f64(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, accumulate, workspace, B, n, (hipStream_t)stream);
+}
+
+extern "C" int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, int T_, int P, int Wd,
+                                  int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!in || !out || T_ <= 0 || P <= 0 || Wd <= 0) return PACOH_EINVAL;
+    long tot = (long)P * Wd;
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(reduce_tasks_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)in, (float*)out, (float)scale, accumulate, T_, P, Wd);
+    else
+        hipLaunchKernelGGL(reduce_tasks_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const double*)in, (double*)out, scale, accumulate, T_, P, Wd);
+    return launch_status();
+}

@@ -1,0 +1,220 @@
+"""Device engine of the batched task-GP path: from flattened prior parameters theta[P, D] and a batch
+of tasks to per-(task, particle) log marginal likelihoods and d(sum)/d(theta) -- the work the
+reference does with a Python loop over tasks around VectorizedGP.forward / ExactGP + autograd
+(meta_learn/random_gp.py:54-89,204-222; GPR_meta_mll.py:104-117).  Every arithmetic step is a HIP
+kernel behind the C ABI (include/pacoh_gp.h); this file only sequences launches on the current
+stream and owns the parameter layout.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def nn_param_layout(input_dim, output_dim, layer_sizes):
+    """bias BEFORE weight per layer, weight row-major [out,in] (meta_learn/models.py:319-323,351-384)"""
+    layout = OrderedDict()
+    prev = input_dim
+    for i, size in enumerate(layer_sizes):
+        layout['fc_%i.bias' % (i + 1)] = size
+        layout['fc_%i.weight' % (i + 1)] = size * prev
+        prev = size
+    layout['out.bias'] = output_dim
+    layout['out.weight'] = output_dim * prev
+    return layout
+
+
+class ParamLayout:
+    """Flattened prior-parameter vector.  Block order follows VectorizedGP.__init__
+    (meta_learn/random_gp.py:33-51): mean block, kernel_nn block, lengthscale_raw, [outputscale_raw,]
+    noise_raw.  `with_outputscale` adds the ScaleKernel parameter of PACOH-MAP (GPR_meta_mll.py:218)."""
+
+    def __init__(self, input_dim, mean_module='NN', covar_module='NN', mean_nn_layers=(32, 32),
+                 kernel_nn_layers=(32, 32), feature_dim=2, with_outputscale=False):
+        assert mean_module in ('NN', 'constant', 'zero') and covar_module in ('NN', 'SE')
+        self.input_dim, self.mean_module, self.covar_module = input_dim, mean_module, covar_module
+        self.mean_nn_layers, self.kernel_nn_layers = tuple(mean_nn_layers), tuple(kernel_nn_layers)
+        self.feature_dim = feature_dim if covar_module == 'NN' else input_dim
+        self.with_outputscale = with_outputscale
+        blocks = OrderedDict()
+        if mean_module == 'NN':
+            for k, v in nn_param_layout(input_dim, 1, mean_nn_layers).items():
+                blocks['mean_nn.' + k] = v
+        elif mean_module == 'constant':
+            blocks['constant_mean'] = 1
+        if covar_module == 'NN':
+            for k, v in nn_param_layout(input_dim, feature_dim, kernel_nn_layers).items():
+                blocks['kernel_nn.' + k] = v
+        blocks['lengthscale_raw'] = self.feature_dim
+        if with_outputscale:
+            blocks['outputscale_raw'] = 1
+        blocks['noise_raw'] = 1
+        self.blocks = blocks
+        self.slices = OrderedDict()
+        idx = 0
+        for k, v in blocks.items():
+            self.slices[k] = (idx, idx + v)
+            idx += v
+        self.D = idx
+
+    def parameter_shapes(self):
+        return OrderedDict((k, torch.Size((v,))) for k, v in self.blocks.items())
+
+    def block_range(self, prefix):
+        keys = [k for k in self.blocks if k.startswith(prefix)]
+        if not keys:
+            return None
+        return self.slices[keys[0]][0], self.slices[keys[-1]][1]
+
+    def hyper_prior_mean_std(self, weight_prior_std, bias_prior_std):
+        """meta_learn/random_gp.py:126-151"""
+        mean, std = torch.zeros(self.D), torch.ones(self.D)
+        for name, (lo, hi) in self.slices.items():
+            if name == 'noise_raw':
+                mean[lo:hi] = -1.0
+            elif 'mean_nn' in name or 'kernel_nn' in name:
+                std[lo:hi] = weight_prior_std if 'weight' in name else bias_prior_std
+        return mean, std
+
+
+class TaskBatch:
+    """Tasks packed for the device: x[T, n_max, d], y[T, n_max], n_valid[T] (int32); ragged tasks are
+    zero padded (the kernels ignore rows >= n_valid)."""
+
+    def __init__(self, tasks, device, dtype=torch.float32):
+        sizes = [int(x.shape[0]) for x, _ in tasks]
+        self.T, self.n = len(tasks), max(sizes)
+        d = tasks[0][0].shape[1]
+        X = np.zeros((self.T, self.n, d), dtype=np.float64)
+        Y = np.zeros((self.T, self.n), dtype=np.float64)
+        for t, (x, y) in enumerate(tasks):
+            X[t, :sizes[t]] = x
+            Y[t, :sizes[t]] = np.asarray(y).reshape(-1)
+        self.sizes = np.asarray(sizes)
+        self.ragged = bool((self.sizes != self.n).any())
+        self.x = torch.from_numpy(X).to(dtype).to(device)
+        self.y = torch.from_numpy(Y).to(dtype).to(device)
+        self.n_valid = torch.from_numpy(self.sizes.astype(np.int32)).to(device)
+
+    def select(self, idx_tensor):
+        out = TaskBatch.__new__(TaskBatch)
+        out.T, out.n, out.ragged = int(idx_tensor.numel()), self.n, self.ragged
+        out.x = self.x.index_select(0, idx_tensor)
+        out.y = self.y.index_select(0, idx_tensor)
+        out.n_valid = self.n_valid.index_select(0, idx_tensor)
+        out.sizes = None
+        return out
+
+
+class GPEngine:
+    """Sequences the kernels of one LML(+grad) evaluation for all (task, particle) pairs."""
+
+    def __init__(self, layout, noise_floor=0.0):
+        self.layout = layout
+        self.noise_floor = float(noise_floor)
+        self._ws = {}
+
+    # -- pieces -----------------------------------------------------------------------------------
+    def _hypers(self, theta):
+        lay = self.layout
+        lo, hi = lay.slices['lengthscale_raw']
+        ls = L.softplus_fwd(theta[:, lo:hi].contiguous())
+        os_ = None
+        if lay.with_outputscale:
+            a, b = lay.slices['outputscale_raw']
+            os_ = L.softplus_fwd(theta[:, a:b].contiguous()).reshape(-1)
+        a, b = lay.slices['noise_raw']
+        noise = L.softplus_fwd(theta[:, a:b].contiguous(), self.noise_floor).reshape(-1)
+        return ls, os_, noise
+
+    def _features(self, theta, x, T, n):
+        """kernel inputs z (+ divisor) and mean (+ mode) for B = T*P problems"""
+        lay = self.layout
+        P, D = theta.shape
+        B = T * P
+        if lay.covar_module == 'NN':
+            lo, _ = lay.block_range('kernel_nn.')
+            z = L.mlp_fwd(x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers), lay.feature_dim, B, n)
+            z_div = 1
+        else:
+            z, z_div = x, P
+        if lay.mean_module == 'NN':
+            lo, _ = lay.block_range('mean_nn.')
+            mean = L.mlp_fwd(x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.mean_nn_layers), 1, B, n).reshape(B, n)
+            mode = L.MEAN_VECTOR
+        elif lay.mean_module == 'constant':
+            lo, hi = lay.slices['constant_mean']
+            mean, mode = theta[:, lo:hi].contiguous().reshape(-1), L.MEAN_CONST
+        else:
+            mean, mode = None, L.MEAN_ZERO
+        return z, z_div, mean, mode
+
+    # -- public -----------------------------------------------------------------------------------
+    def lml(self, theta, batch):
+        """per-datapoint LML of every (task, particle): [T, P] (no gradients)"""
+        P = theta.shape[0]
+        T, n = batch.T, batch.n
+        ls, os_, noise = self._hypers(theta)
+        z, z_div, mean, mode = self._features(theta, batch.x, T, n)
+        lml, _, _, info = L.gp_lml_fwd(z, z_div, mean, mode, batch.y, P, ls, os_, noise, T * P, P,
+                                       n_valid=batch.n_valid if batch.ragged else None)
+        return lml.reshape(T, P), info
+
+    def lml_and_grad(self, theta, batch, weight=1.0):
+        """returns (lml[T,P], grad[P,D]) with grad = d(weight * sum_t lml[t,p]) / d theta[p]"""
+        lay = self.layout
+        P, D = theta.shape
+        T, n = batch.T, batch.n
+        B = T * P
+        dev, dt = theta.device, theta.dtype
+        ls, os_, noise = self._hypers(theta)
+        z, z_div, mean, mode = self._features(theta, batch.x, T, n)
+        g = torch.full((B,), float(weight), dtype=dt, device=dev)
+        lml, d_z, d_mean, d_ls, d_os, d_noise, info = L.gp_lml_fwdbwd(
+            z, z_div, mean, mode, batch.y, P, ls, os_, noise, B, P,
+            n_valid=batch.n_valid if batch.ragged else None, g_lml=g, want_dz=(lay.covar_module == 'NN'))
+        grad = torch.zeros(P, D, dtype=dt, device=dev)
+        if lay.covar_module == 'NN':
+            lo, _ = lay.block_range('kernel_nn.')
+            self._ws['k'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers),
+                                      lay.feature_dim, d_z, grad[:, lo:], D, False, B, n, self._ws.get('k'))
+        if lay.mean_module == 'NN':
+            lo, _ = lay.block_range('mean_nn.')
+            self._ws['m'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.mean_nn_layers), 1,
+                                      d_mean.reshape(B, n, 1), grad[:, lo:], D, False, B, n, self._ws.get('m'))
+        elif lay.mean_module == 'constant':
+            lo, hi = lay.slices['constant_mean']
+            tmp = torch.empty(P, 1, dtype=dt, device=dev)
+            L.reduce_tasks(d_mean.reshape(T, P, 1), tmp)
+            grad[:, lo:hi] = tmp
+        # hyper-parameters: sum over tasks, then chain through softplus
+        f = lay.feature_dim
+        lo, hi = lay.slices['lengthscale_raw']
+        gl = torch.empty(P, f, dtype=dt, device=dev)
+        L.reduce_tasks(d_ls.reshape(T, P, f), gl)
+        grad[:, lo:hi] = L.softplus_bwd(theta[:, lo:hi].contiguous(), gl)
+        if lay.with_outputscale:
+            a, b = lay.slices['outputscale_raw']
+            go = torch.empty(P, 1, dtype=dt, device=dev)
+            L.reduce_tasks(d_os.reshape(T, P, 1), go)
+            grad[:, a:b] = L.softplus_bwd(theta[:, a:b].contiguous(), go)
+        a, b = lay.slices['noise_raw']
+        gn = torch.empty(P, 1, dtype=dt, device=dev)
+        L.reduce_tasks(d_noise.reshape(T, P, 1), gn)
+        grad[:, a:b] = L.softplus_bwd(theta[:, a:b].contiguous(), gn)
+        return lml.reshape(T, P), grad, info
+
+    def predict(self, theta, ctx_x, ctx_y, tst_x, want_cov=False):
+        """exact posterior predictive of ONE task for every particle: mu[P,m], var[P,m], cov[P,m,m]|None
+        (normalised space, observation noise included)."""
+        lay = self.layout
+        P, D = theta.shape
+        n, m = ctx_x.shape[0], tst_x.shape[0]
+        ls, os_, noise = self._hypers(theta)
+        xc, xt = ctx_x.unsqueeze(0).contiguous(), tst_x.unsqueeze(0).contiguous()
+        zc, zc_div, mc, mode = self._features(theta, xc, 1, n)
+        zt, zt_div, mt, _ = self._features(theta, xt, 1, m)
+        y = ctx_y.reshape(1, n).contiguous()
+        return L.gp_predict(zc, zc_div, mc, mode, y, P, zt, zt_div, mt, ls, os_, noise, P, P, want_cov=want_cov)

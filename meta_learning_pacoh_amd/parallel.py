@@ -1,0 +1,32 @@
+"""Multi-GPU sharding of the task dimension: rank r owns tasks r::world of the step's
+(globally drawn, shared-seed) task batch and all P particles; partial sum_t mll[t,:] and partial score
+[P,D] are summed with ONE all-reduce per step -- torch.distributed 'nccl' backend = RCCL over xGMI on
+the GPU box, 'gloo' in the CPU tests.  Nothing else is exchanged; prior term, SVGD kernel and optimizer
+are replicated (deterministic, identical on every rank)."""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard(indices, rank=None, world_size=None):
+    """this rank's slice of the global task-index list (strided: balances ragged task sizes)"""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    return indices[rank::world_size]
+
+
+def all_reduce_sum_(lik, score):
+    """sum [P] and [P,D] over ranks with one collective on a packed buffer; identity at world size 1"""
+    _, w = world()
+    if w == 1:
+        return lik, score
+    P, D = score.shape
+    buf = torch.cat([score.reshape(-1), lik.reshape(-1)])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf[P * D:].reshape(P), buf[:P * D].reshape(P, D)

@@ -1,0 +1,391 @@
+"""Parity of every HIP kernel (called through the C ABI) against the CPU oracle on seeded inputs.
+Tolerances are the north-star bars: <= 1e-4 rel in fp64 (we assert much tighter), <= 1e-2 rel in fp32;
+gradients are judged norm-wise over the whole gradient array."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pacoh_oracle as O
+
+
+@pytest.fixture(scope='module')
+def L():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    from meta_learning_pacoh_amd import _lib
+    _lib.load_library()
+    return _lib
+
+
+DEV = 'cuda'
+TOL = {torch.float32: 2e-3, torch.float64: 1e-9}       # asserted (bars: 1e-2 / 1e-4)
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def maxrel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float(((a - b).abs() / (b.abs() + 1e-6)).max())
+
+
+def make_problem(T, P, n, f, dtype, seed=0, per_eval_z=True, noise_lo=-1.0):
+    g = torch.Generator().manual_seed(seed)
+    B = T * P
+    z = torch.randn(B if per_eval_z else T, n, f, generator=g, dtype=torch.float64)
+    mean = 0.3 * torch.randn(B, n, generator=g, dtype=torch.float64)
+    y = torch.randn(T, n, generator=g, dtype=torch.float64)
+    ls = torch.nn.functional.softplus(torch.randn(P, f, generator=g, dtype=torch.float64))
+    os_ = torch.nn.functional.softplus(torch.randn(P, generator=g, dtype=torch.float64))
+    noise = torch.nn.functional.softplus(torch.randn(P, generator=g, dtype=torch.float64) + noise_lo)
+    return [t.to(dtype) for t in (z, mean, y, ls, os_, noise)]
+
+
+def oracle_mll(z, mean, y, ls, os_, noise, T, P, per_eval_z=True):
+    """oracle on the same layout: b = t*P + p"""
+    B = T * P
+    n = z.shape[-2]
+    zz = z if per_eval_z else z.unsqueeze(1).expand(T, P, n, z.shape[-1]).reshape(B, n, -1)
+    yy = y.unsqueeze(1).expand(T, P, n).reshape(B, n)
+    lsb = ls.unsqueeze(0).expand(T, P, -1).reshape(B, 1, -1)
+    osb = os_.unsqueeze(0).expand(T, P).reshape(B)
+    nb = noise.unsqueeze(0).expand(T, P).reshape(B)
+    return O.gp_mll(zz, mean, yy, lsb, osb, nb)
+
+
+# ------------------------------------------------------------------------------------------ gram
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('shape', [(3, 2, 64, 64, 2), (2, 3, 37, 50, 3), (1, 1, 5, 7, 1), (2, 2, 130, 128, 8)])
+def test_gram(L, dtype, shape):
+    T, P, n, m, f = shape
+    B = T * P
+    g = torch.Generator().manual_seed(1)
+    z1 = torch.randn(B, n, f, generator=g, dtype=dtype)
+    z2 = torch.randn(T, m, f, generator=g, dtype=dtype)
+    ls = torch.rand(P, f, generator=g, dtype=dtype) + 0.5
+    os_ = torch.rand(P, generator=g, dtype=dtype) + 0.5
+    K = L.gram_rbf_ard(z1.to(DEV), 1, z2.to(DEV), P, ls.to(DEV), os_.to(DEV), None, False, B, P)
+    z2b = z2.unsqueeze(1).expand(T, P, m, f).reshape(B, m, f)
+    lsb = ls.unsqueeze(0).expand(T, P, f).reshape(B, 1, f)
+    ref = os_.unsqueeze(0).expand(T, P).reshape(B, 1, 1) * O.gram_rbf_ard(z1, z2b, lsb)
+    assert maxrel(K, ref) < (1e-5 if dtype == torch.float32 else 1e-12)
+
+
+def test_gram_square_with_noise(L):
+    B, n, f = 4, 48, 2
+    z = torch.randn(B, n, f, dtype=torch.float64)
+    ls, noise = torch.ones(1, f, dtype=torch.float64), torch.tensor([0.25], dtype=torch.float64)
+    K = L.gram_rbf_ard(z.to(DEV), 1, z.to(DEV), 1, ls.to(DEV), None, noise.to(DEV), True, B, 1)
+    ref = O.gram_rbf_ard(z, z, ls) + 0.25 * torch.eye(n, dtype=torch.float64)
+    assert maxrel(K, ref) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------ lml fwd
+CASES = [  # T, P, n, f, per_eval_z
+    (4, 3, 5, 2, True),        # cfg #1 shape (demo)
+    (6, 1, 32, 1, False),      # cfg #2: MAP, SE on inputs, d=1
+    (3, 4, 64, 2, True),       # cfg #3 NN features
+    (3, 4, 64, 4, False),      # cfg #3 SE on d=4 inputs
+    (2, 2, 128, 2, True),      # cfg #4
+    (2, 2, 47, 3, True),       # odd n
+    (1, 2, 9, 16, True),       # max feature dim
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('case', CASES)
+def test_lml_fwd(L, dtype, case):
+    T, P, n, f, pez = case
+    if n > L.gp_small_max_n(dtype, False):
+        pytest.skip('n above small-kernel limit for this dtype')
+    z, mean, y, ls, os_, noise = make_problem(T, P, n, f, dtype, seed=n + f, per_eval_z=pez)
+    ref = oracle_mll(z.double(), mean.double(), y.double(), ls.double(), os_.double(), noise.double(), T, P, pez)
+    lml, alpha, Lf, info = L.gp_lml_fwd(z.to(DEV), 1 if pez else P, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P,
+                                        ls.to(DEV), os_.to(DEV), noise.to(DEV), T * P, P, want_alpha=True, want_L=True)
+    assert int(info.abs().max()) == 0
+    assert maxrel(lml, ref) < TOL[dtype]
+    # factor and alpha of problem 0
+    zz = (z if pez else z.unsqueeze(1).expand(T, P, n, f).reshape(T * P, n, f)).double()
+    K0 = os_[0].double() * O.gram_rbf_ard(zz[0], zz[0], ls[0].double()) + noise[0].double() * torch.eye(n, dtype=torch.float64)
+    L0 = torch.linalg.cholesky(K0)
+    assert relerr(Lf[0], L0) < TOL[dtype]
+    a0 = torch.cholesky_solve((y[0] - mean[0]).double().unsqueeze(-1), L0).squeeze(-1)
+    assert relerr(alpha[0], a0) < (5e-2 if dtype == torch.float32 else 1e-8)
+
+
+def test_lml_mean_modes_and_unit_outputscale(L):
+    T, P, n, f = 3, 2, 20, 2
+    z, mean, y, ls, os_, noise = make_problem(T, P, n, f, torch.float64, seed=3)
+    c = torch.tensor([0.3, -0.7], dtype=torch.float64)
+    one = torch.ones(P, dtype=torch.float64)
+    ref_c = oracle_mll(z, c.unsqueeze(0).expand(T, P).reshape(-1, 1).expand(-1, n), y, ls, one, noise, T, P)
+    lml, *_ = L.gp_lml_fwd(z.to(DEV), 1, c.to(DEV), L.MEAN_CONST, y.to(DEV), P, ls.to(DEV), None, noise.to(DEV), T * P, P)
+    assert maxrel(lml, ref_c) < 1e-10
+    ref_0 = oracle_mll(z, torch.zeros(T * P, n, dtype=torch.float64), y, ls, one, noise, T, P)
+    lml, *_ = L.gp_lml_fwd(z.to(DEV), 1, None, L.MEAN_ZERO, y.to(DEV), P, ls.to(DEV), None, noise.to(DEV), T * P, P)
+    assert maxrel(lml, ref_0) < 1e-10
+
+
+# ------------------------------------------------------------------------------------------ lml bwd
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('case', CASES)
+def test_lml_fwdbwd(L, dtype, case):
+    T, P, n, f, pez = case
+    if n > L.gp_small_max_n(dtype, True):
+        pytest.skip('n above small-kernel limit for this dtype')
+    z, mean, y, ls, os_, noise = make_problem(T, P, n, f, dtype, seed=7 * n + f, per_eval_z=pez)
+    gl = torch.rand(T * P, dtype=dtype) + 0.5
+    leaves = [t.double().clone().requires_grad_(True) for t in (z, mean, ls, os_, noise)]
+    ref = oracle_mll(leaves[0], leaves[1], y.double(), leaves[2], leaves[3], leaves[4], T, P, pez)
+    (ref * gl.double()).sum().backward()
+    out = L.gp_lml_fwdbwd(z.to(DEV), 1 if pez else P, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, ls.to(DEV),
+                          os_.to(DEV), noise.to(DEV), T * P, P, g_lml=gl.to(DEV), want_dz=pez)
+    lml, d_z, d_mean, d_ls, d_os, d_noise, info = out
+    assert int(info.abs().max()) == 0
+    assert maxrel(lml, ref) < TOL[dtype]
+    gtol = 1e-2 if dtype == torch.float32 else 1e-8
+    if pez:
+        assert relerr(d_z, leaves[0].grad) < gtol
+    assert relerr(d_mean, leaves[1].grad) < gtol
+    # per-problem hyper gradients summed over tasks == autograd of the shared hyper-parameters
+    assert relerr(d_ls.reshape(T, P, f).sum(0), leaves[2].grad) < gtol
+    assert relerr(d_os.reshape(T, P).sum(0), leaves[3].grad) < gtol
+    assert relerr(d_noise.reshape(T, P).sum(0), leaves[4].grad) < gtol
+
+
+def test_lml_const_mean_grad(L):
+    T, P, n, f = 3, 2, 24, 2
+    z, _, y, ls, os_, noise = make_problem(T, P, n, f, torch.float64, seed=11)
+    c = torch.tensor([0.3, -0.7], dtype=torch.float64, requires_grad=True)
+    ref = oracle_mll(z, c.unsqueeze(0).expand(T, P).reshape(-1, 1).expand(-1, n), y, ls, os_, noise, T, P)
+    ref.sum().backward()
+    out = L.gp_lml_fwdbwd(z.to(DEV), 1, c.detach().to(DEV), L.MEAN_CONST, y.to(DEV), P, ls.to(DEV), os_.to(DEV),
+                          noise.to(DEV), T * P, P)
+    assert relerr(out[2].reshape(T, P).sum(0), c.grad) < 1e-9
+
+
+def test_lml_ragged_n_valid(L):
+    """tasks of different size padded to a common n (reference: tasks may differ in n, random_gp.py:209-212)"""
+    T, P, n, f = 4, 2, 24, 2
+    sizes = [24, 5, 17, 1]
+    z, mean, y, ls, os_, noise = make_problem(T, P, n, f, torch.float64, seed=5)
+    nv = torch.tensor(sizes, dtype=torch.int32)
+    out = L.gp_lml_fwdbwd(z.to(DEV), 1, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, ls.to(DEV), os_.to(DEV),
+                          noise.to(DEV), T * P, P, n_valid=nv.to(DEV))
+    lml, d_z, d_mean, d_ls, d_os, d_noise, info = [o.cpu() for o in out]
+    for t in range(T):
+        s = sizes[t]
+        for p in range(P):
+            b = t * P + p
+            zz = z[b, :s].clone().requires_grad_(True)
+            mm = mean[b, :s].clone().requires_grad_(True)
+            hy = [h.clone().requires_grad_(True) for h in (ls[p], os_[p], noise[p])]
+            ref = O.gp_mll(zz, mm, y[t, :s], hy[0], hy[1], hy[2])
+            ref.backward()
+            assert abs(float(lml[b] - ref)) < 1e-10 * max(1, abs(float(ref)))
+            assert relerr(d_z[b, :s], zz.grad) < 1e-8 and float(d_z[b, s:].abs().sum()) == 0
+            assert relerr(d_mean[b, :s], mm.grad) < 1e-8 and float(d_mean[b, s:].abs().sum()) == 0
+            assert relerr(d_ls[b], hy[0].grad) < 1e-8
+            assert relerr(d_os[b], hy[1].grad) < 1e-8 and relerr(d_noise[b], hy[2].grad) < 1e-8
+
+
+def test_lml_jitter_ladder_on_rank_deficient_gram(L):
+    """fault injection: identical points + ~zero noise -> plain Cholesky fails in fp32; the kernel
+    must climb gpytorch's psd_safe_cholesky jitter ladder and report it in info[]"""
+    n, f = 32, 2
+    z = torch.zeros(2, n, f, dtype=torch.float32)
+    z[1] = torch.randn(n, f)                                  # problem 1 is healthy
+    y = torch.randn(1, n, dtype=torch.float32)
+    ls = torch.ones(1, f, dtype=torch.float32)
+    noise = torch.tensor([1e-12], dtype=torch.float32)
+    # B=2 problems of ONE task with P=... use P=1, T=2 and the same y
+    yy = y.expand(2, n).contiguous()
+    lml, _, _, info = L.gp_lml_fwd(z.to(DEV), 1, None, L.MEAN_ZERO, yy.to(DEV), 1, ls.to(DEV), None, noise.to(DEV), 2, 1)
+    info = info.cpu()
+    assert int(info[0]) >= 1 and bool(torch.isfinite(lml[0]))
+    jit = 1e-6 * 10 ** (int(info[0]) - 1)
+    K = torch.ones(n, n, dtype=torch.float64) + (1e-12 + jit) * torch.eye(n, dtype=torch.float64)
+    ref = torch.distributions.MultivariateNormal(torch.zeros(n, dtype=torch.float64), K).log_prob(y[0].double()) / n
+    assert abs(float(lml[0]) - float(ref)) < 0.15 * abs(float(ref))    # fp32 at condition ~1e7: loose by nature
+
+
+# ------------------------------------------------------------------------------------------ predict
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('case', [(2, 3, 5, 50, 2), (2, 2, 64, 130, 4), (1, 2, 128, 20, 2)])
+def test_predict(L, dtype, case):
+    T, P, n, m, f = case
+    if n > L.gp_small_max_n(dtype, False):
+        pytest.skip('n above limit')
+    B = T * P
+    z, mean, y, ls, os_, noise = make_problem(T, P, n, f, dtype, seed=m)
+    g = torch.Generator().manual_seed(99)
+    zt = torch.randn(B, m, f, generator=g, dtype=dtype)
+    mt = 0.2 * torch.randn(B, m, generator=g, dtype=dtype)
+    mu, var, cov, info = L.gp_predict(z.to(DEV), 1, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, zt.to(DEV), 1, mt.to(DEV),
+                                      ls.to(DEV), os_.to(DEV), noise.to(DEV), B, P, want_cov=True)
+    yy = y.unsqueeze(1).expand(T, P, n).reshape(B, n).double()
+    lsb = ls.unsqueeze(0).expand(T, P, f).reshape(B, 1, f).double()
+    osb = os_.unsqueeze(0).expand(T, P).reshape(B).double()
+    nb = noise.unsqueeze(0).expand(T, P).reshape(B).double()
+    rm, rc = O.gp_predict(z.double(), mean.double(), yy, zt.double(), mt.double(), lsb, osb, nb)
+    tol = 5e-3 if dtype == torch.float32 else 1e-9
+    assert relerr(mu, rm) < tol
+    assert relerr(var, torch.diagonal(rc, dim1=-2, dim2=-1)) < tol
+    assert relerr(cov, rc) < tol
+
+
+# ------------------------------------------------------------------------------------------ dense
+@pytest.mark.parametrize('dtype,n,B', [(torch.float32, 50, 5), (torch.float64, 50, 3), (torch.float64, 512, 4),
+                                       (torch.float64, 77, 2), (torch.float32, 200, 2)])
+def test_mvn_logprob_dense(L, dtype, n, B):
+    g = torch.Generator().manual_seed(n)
+    z = torch.randn(B, n, 8, generator=g, dtype=torch.float64)
+    ls = torch.full((1, 8), 0.6931 * 3, dtype=torch.float64)
+    A = O.gram_rbf_ard(z, z, ls) + 0.313 * torch.eye(n, dtype=torch.float64)
+    r = torch.randn(B, n, generator=g, dtype=torch.float64)
+    ref = torch.distributions.MultivariateNormal(torch.zeros(n, dtype=torch.float64), A).log_prob(r) / n
+    ralpha = torch.linalg.solve(A, r.unsqueeze(-1)).squeeze(-1)
+    logp, alpha, info = L.mvn_logprob_dense(A.to(dtype).to(DEV).contiguous(), r.to(dtype).to(DEV), 1.0 / n, want_alpha=True)
+    assert int(info.abs().max()) == 0
+    assert maxrel(logp, ref) < (1e-4 if dtype == torch.float32 else 1e-10)
+    assert relerr(alpha, ralpha) < (1e-3 if dtype == torch.float32 else 1e-9)
+
+
+def test_large_context_lml_fp64_gram_plus_dense(L):
+    """config #5 shape at reduced task count: n=512, d=8, fp64, SE kernel; 1e-4 rel bar"""
+    T, n, d = 3, 512, 8
+    tasks = O.sinusoid_tasks_nd(T, n, d, seed0=1000)
+    stats = O.compute_normalization_stats(tasks)
+    xy = [O.prepare_task(x, y, stats, torch.float64) for x, y in tasks]
+    X, Y = torch.stack([a for a, _ in xy]), torch.stack([b for _, b in xy])
+    ls = torch.nn.functional.softplus(torch.zeros(1, d, dtype=torch.float64))
+    noise = torch.nn.functional.softplus(torch.tensor([-1.0], dtype=torch.float64))
+    ref = O.gp_mll(X, torch.zeros(T, n, dtype=torch.float64), Y, ls.unsqueeze(0), 1.0, noise)
+    K = L.gram_rbf_ard(X.to(DEV), 1, X.to(DEV), 1, ls.to(DEV), None, noise.to(DEV), True, T, 1)
+    logp, _, info = L.mvn_logprob_dense(K, Y.to(DEV), 1.0 / n)
+    assert int(info.abs().max()) == 0
+    assert maxrel(logp, ref) < 1e-9
+
+
+# ------------------------------------------------------------------------------------------ MLP
+MLP_CASES = [  # P, T, n, d_in, hidden, d_out
+    (3, 4, 64, 4, (32, 32), 2),
+    (3, 4, 64, 4, (32, 32), 1),
+    (1, 5, 5, 1, (32, 32), 2),          # shared weights (MAP)
+    (2, 3, 9, 2, (8, 12), 2),
+    (2, 2, 33, 3, (64, 64), 1),
+    (2, 2, 7, 2, (), 5),
+    (2, 3, 300, 16, (16,), 8),
+    (2, 2, 10, 2, (16, 16, 16), 2),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('case', MLP_CASES)
+def test_mlp_fwd_bwd(L, dtype, case):
+    P, T, n, d_in, hidden, d_out = case
+    B = T * P
+    layout = O.nn_param_layout(d_in, d_out, hidden)
+    Dn = sum(layout.values())
+    g = torch.Generator().manual_seed(Dn)
+    pad = 3                                                    # the block sits inside a wider particle matrix
+    theta_full = 0.5 * torch.randn(P, Dn + 2 * pad, generator=g, dtype=dtype)
+    x = torch.randn(T, n, d_in, generator=g, dtype=dtype)
+    gout = torch.randn(B, n, d_out, generator=g, dtype=dtype)
+    th_dev = theta_full.to(DEV)
+    out = L.mlp_fwd(x.to(DEV), P, th_dev[:, pad:], Dn + 2 * pad, P, d_in, list(hidden), d_out, B, n)
+    th = theta_full[:, pad:pad + Dn].double().clone().requires_grad_(True)
+    ref = torch.stack([O.mlp_vectorized_forward(x[t].double(), th, d_in, d_out, hidden) for t in range(T)])  # [T,P,n,o]
+    ref_flat = ref.reshape(B, n, d_out)
+    assert relerr(out, ref_flat) < (1e-5 if dtype == torch.float32 else 1e-12)
+    (ref_flat * gout.double()).sum().backward()
+    d_full = torch.full((P, Dn + 2 * pad), 7.0, dtype=dtype, device=DEV)
+    L.mlp_bwd(x.to(DEV), P, th_dev[:, pad:], Dn + 2 * pad, P, d_in, list(hidden), d_out, gout.to(DEV),
+              d_full[:, pad:], Dn + 2 * pad, False, B, n)
+    d_full = d_full.cpu()
+    assert float((d_full[:, :pad] - 7).abs().max()) == 0 and float((d_full[:, pad + Dn:] - 7).abs().max()) == 0
+    assert relerr(d_full[:, pad:pad + Dn], th.grad) < (2e-4 if dtype == torch.float32 else 1e-10)
+    # accumulate=True adds on top
+    d2 = torch.ones(P, Dn, dtype=dtype, device=DEV)
+    th_c = theta_full[:, pad:pad + Dn].contiguous().to(DEV)
+    L.mlp_bwd(x.to(DEV), P, th_c, Dn, P, d_in, list(hidden), d_out, gout.to(DEV), d2, Dn, True, B, n)
+    assert relerr(d2.cpu() - 1, th.grad) < (2e-4 if dtype == torch.float32 else 1e-10)
+
+
+def test_mlp_matches_reference_fixture(L, golden_dir):
+    """per-particle MLP vs outputs of the REAL NeuralNetworkVectorized (fixture from the reference)"""
+    fx = np.load(os.path.join(golden_dir, 'random_gp_ref.npz'))
+    cfg = O.GPConfig(input_dim=4, covar_module='NN', mean_module='NN')
+    theta = torch.from_numpy(fx['nn_nn_d4_theta']).to(DEV)
+    x = torch.from_numpy(fx['nn_nn_d4_x']).unsqueeze(0).to(DEV)          # one task
+    P, D = theta.shape
+    lo, _ = cfg.slices['kernel_nn.fc_1.bias']
+    out = L.mlp_fwd(x, P, theta[:, lo:], D, P, 4, [32, 32], 2, P, 9)
+    assert relerr(out, torch.from_numpy(fx['nn_nn_d4_kernel_out'])) < 1e-5
+    out = L.mlp_fwd(x, P, theta, D, P, 4, [32, 32], 1, P, 9)
+    assert relerr(out, torch.from_numpy(fx['nn_nn_d4_mean_out'])) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ misc
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_softplus_prior_adam(L, dtype):
+    g = torch.Generator().manual_seed(0)
+    raw = torch.randn(50, generator=g, dtype=dtype) * 5
+    raw[0], raw[1] = 25.0, -30.0
+    out = L.softplus_fwd(raw.to(DEV), 1e-3)
+    assert maxrel(out, torch.nn.functional.softplus(raw.double()) + 1e-3) < (1e-6 if dtype == torch.float32 else 1e-14)
+    gg = torch.randn(50, generator=g, dtype=dtype)
+    d = L.softplus_bwd(raw.to(DEV), gg.to(DEV))
+    assert relerr(d, gg.double() * torch.sigmoid(raw.double())) < (1e-6 if dtype == torch.float32 else 1e-14)
+
+    cfg = O.GPConfig(input_dim=2, covar_module='NN', mean_module='NN', mean_nn_layers=(8, 8), kernel_nn_layers=(8, 8))
+    pm, ps = O.hyperprior_mean_std(cfg.layout)
+    theta = torch.randn(7, cfg.D, generator=g, dtype=dtype)
+    th = theta.double().clone().requires_grad_(True)
+    ref = O.hyperprior_log_prob(th, pm, ps)
+    ref.sum().backward()
+    grad = torch.full((7, cfg.D), 2.0, dtype=dtype, device=DEV)
+    lp = L.prior_logprob_grad(theta.to(DEV), pm.to(dtype).to(DEV), ps.to(dtype).to(DEV), grad, 0.01)
+    assert maxrel(lp, ref) < (1e-5 if dtype == torch.float32 else 1e-12)
+    assert relerr(grad.cpu() - 2.0, 0.01 * th.grad) < (1e-5 if dtype == torch.float32 else 1e-12)
+
+    # AdamW: 5 steps against torch.optim.AdamW
+    p0 = torch.randn(300, generator=g, dtype=dtype)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=1e-2, weight_decay=0.2)
+    pd, m, v = p0.to(DEV), torch.zeros(300, dtype=dtype, device=DEV), torch.zeros(300, dtype=dtype, device=DEV)
+    for step in range(1, 6):
+        gr = torch.randn(300, generator=g, dtype=dtype)
+        pt.grad = gr.clone()
+        opt.step()
+        L.adam_step(pd, gr.to(DEV), m, v, 1e-2, step, weight_decay=0.2)
+    assert maxrel(pd, pt.detach()) < (2e-6 if dtype == torch.float32 else 1e-13)
+
+
+def test_svgd_phi_matches_reference_fixture(L, golden_dir):
+    """phi vs the output of the REAL meta_learn/svgd.py (SVGD.phi + RBF_Kernel), fixed and median bandwidth"""
+    fx = np.load(os.path.join(golden_dir, 'svgd_ref.npz'))
+    for tag in ['small_median', 'small_fixed', 'cfg3_median', 'cfg3_fixed', 'se_median']:
+        bw_arg = float(fx[tag + '_bw_arg'])
+        X, score = torch.from_numpy(fx[tag + '_X']).to(DEV), torch.from_numpy(fx[tag + '_score']).to(DEV)
+        phi, bw, _ = L.svgd_phi(X, score, None if bw_arg < 0 else bw_arg)
+        assert abs(float(bw) - float(fx[tag + '_bw'])) < 1e-5 * float(fx[tag + '_bw'])
+        ref = torch.from_numpy(fx[tag + '_phi'])
+        assert float((phi.cpu() - ref).abs().max()) < 1e-2 * float(ref.abs().max()), tag     # fp32 bar
+        assert relerr(phi, ref) < 1e-4, tag
+        X64, s64 = X.double(), torch.from_numpy(fx[tag + '_score64']).to(DEV)
+        phi64, _, _ = L.svgd_phi(X64, s64, None if bw_arg < 0 else bw_arg, neg=True)
+        assert relerr(-phi64, torch.from_numpy(fx[tag + '_phi64'])) < 1e-9, tag
+
+
+def test_reduce_tasks(L):
+    a = torch.randn(13, 4, 9, dtype=torch.float64)
+    out = torch.ones(4, 9, dtype=torch.float64, device=DEV)
+    L.reduce_tasks(a.to(DEV), out, scale=0.5, accumulate=True)
+    assert relerr(out, 1 + 0.5 * a.sum(0)) < 1e-13

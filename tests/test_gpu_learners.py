@@ -1,0 +1,264 @@
+"""End-to-end parity of the three meta-learners (host classes + HIP kernels through the C ABI) against
+the CPU oracle, the recorded reference trajectory (demo.ipynb) and the behaviours asserted by the
+reference's own tests (tests/test_GPR.py:173-222: seed consistency, state_dict round trip)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pacoh_oracle as O
+
+
+@pytest.fixture(scope='module')
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    import meta_learning_pacoh_amd as m
+    return m
+
+
+def relerr(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def demo_data():
+    env = O.SinusoidDataset(np.random.RandomState(26))
+    return env.generate_meta_train_data(20, 5), env.generate_meta_test_data(20, 5, 50)
+
+
+# ------------------------------------------------------------------------------------------ MAP
+def test_map_first_iterations_match_oracle(M):
+    train, test = demo_data()
+    model = M.GPRegressionMetaLearned(train, weight_decay=0.2, num_iter_fit=50, random_seed=30)
+    orc = O.MapOracle(train, weight_decay=0.2, num_iter_fit=50, random_seed=30)
+    # same initial parameters (same RNG consumption order as the reference: kernel net, then mean net)
+    lay = model.layout
+    lo, hi = lay.slices['kernel_nn.fc_1.weight']
+    assert relerr(model.theta[0, lo:hi], orc.kernel_net[0].weight.reshape(-1)) == 0
+    lo, hi = lay.slices['mean_nn.out.bias']
+    assert relerr(model.theta[0, lo:hi], orc.mean_net[-1].bias.reshape(-1)) == 0
+    log_o = orc.meta_fit(test, log_period=50, n_iter=50)
+    model.meta_fit(test, log_period=50, n_iter=50, verbose=False)
+    ll, rmse, calib = model.eval_datasets(test)
+    assert abs(ll - log_o[-1][2]) < 2e-3 and abs(rmse - log_o[-1][3]) < 2e-3 and abs(calib - log_o[-1][4]) < 5e-3
+    # parameters after 50 AdamW steps
+    got = torch.cat([model.theta[0, lay.slices['kernel_nn.fc_2.weight'][0]:lay.slices['kernel_nn.fc_2.weight'][1]].cpu()])
+    assert relerr(got, orc.kernel_net[1].weight.reshape(-1)) < 1e-3
+    cx, cy, tx, _ = test[0]
+    pm, ps = model.predict(cx, cy, tx)
+    mean_n, cov_n = orc.predict_normalized(cx, cy, tx)
+    assert relerr(pm, mean_n * orc.stats[3][0] + orc.stats[2][0]) < 1e-3
+    assert relerr(ps, torch.sqrt(torch.diagonal(cov_n)) * orc.stats[3][0]) < 1e-3
+
+
+def test_map_reproduces_recorded_reference_trajectory(M, golden_dir):
+    """config #1: the demo.py run of the real reference (demo.ipynb:115-127,164-166), now on the HIP path.
+    fp32 trajectories drift with summation order, so later log lines get a wider band."""
+    with open(os.path.join(golden_dir, 'demo_log.json')) as f:
+        gold = json.load(f)
+    train, test = demo_data()
+    model = M.GPRegressionMetaLearned(train, weight_decay=0.2, num_iter_fit=12000, random_seed=30)
+    logs = []
+
+    class Grab:
+        def info(self, msg):
+            logs.append(msg)
+    model.logger = Grab()
+    model.meta_fit(test, log_period=1000)
+    assert len(logs) == 13
+    for msg, ref in zip(logs, gold['log']):
+        parts = msg.replace('Iter ', '').split(' - ')
+        itr = int(parts[0].split('/')[0])
+        loss = float(parts[1].split(': ')[1])
+        ll, rmse, calib = (float(parts[k].split(' ')[-1]) for k in (3, 4, 5))
+        assert itr == ref[0]
+        if itr == 1:
+            assert abs(loss - ref[1]) < 2e-5 and abs(ll - ref[2]) < 1.5e-3 and abs(rmse - ref[3]) < 1.5e-3
+        else:
+            assert abs(loss - ref[1]) < 0.03 + 0.02 * abs(ref[1]), (msg, ref)
+            assert abs(ll - ref[2]) < 0.03 and abs(rmse - ref[3]) < 0.02 and abs(calib - ref[4]) < 0.02, (msg, ref)
+    ll, rmse, calib = model.eval_datasets(test)
+    assert abs(ll - gold['final_test']['ll']) < 0.03
+    assert abs(rmse - gold['final_test']['rmse']) < 0.02
+    assert abs(calib - gold['final_test']['calib']) < 0.02
+
+
+def sample_data_nonstationary(rs, size=1):
+    def _sample_fun():
+        slope = rs.normal(loc=1, scale=0.2)
+        freq = lambda x: 1 + np.abs(x)
+        mean = lambda x: slope * x
+        return lambda x: (mean(x) + np.sin(freq(x) * x)) / 5
+    func = _sample_fun()
+    X = rs.uniform(-5, 5, size=(size, 1))
+    Y = func(X)
+    return X, Y
+
+
+def test_map_seed_consistency_and_state_dict_roundtrip(M):
+    """reference tests/test_GPR.py:173-222"""
+    rs = np.random.RandomState(23)
+    train = [sample_data_nonstationary(rs, 5) for _ in range(3)]
+    test = [sample_data_nonstationary(rs, 55) for _ in range(3)]
+    test = [(x[:5], t[:5], x[5:], t[5:]) for x, t in test]
+    m1 = M.GPRegressionMetaLearned(train[:2], learning_mode='both', num_iter_fit=5, random_seed=22)
+    m2 = M.GPRegressionMetaLearned(train[:2], learning_mode='both', num_iter_fit=5, random_seed=22)
+    m1.meta_fit(valid_tuples=test, verbose=False)
+    m2.meta_fit(valid_tuples=test, verbose=False)
+    for cx, cy, tx, _ in test:
+        p1, p2 = m1.predict(cx, cy, tx), m2.predict(cx, cy, tx)
+        assert np.array_equal(p1[0], p2[0]) and np.array_equal(p1[1], p2[1])          # bitwise, as in the reference
+    for mean_module in ['constant', 'NN']:
+        a = M.GPRegressionMetaLearned(train, learning_mode='both', num_iter_fit=5, mean_module=mean_module, random_seed=22)
+        a.meta_fit(verbose=False)
+        pred_1 = a.predict(*test[0][:3])
+        b = M.GPRegressionMetaLearned(train, learning_mode='both', num_iter_fit=5, mean_module=mean_module, random_seed=25)
+        b.meta_fit(verbose=False)
+        pred_2 = b.predict(*test[0][:3])
+        torch.save(a.state_dict(), '/tmp/test_torch_serialization.pkl')
+        b.load_state_dict(torch.load('/tmp/test_torch_serialization.pkl'))
+        pred_3 = b.predict(*test[0][:3])
+        assert not np.array_equal(pred_1[0], pred_2[0])
+        assert np.array_equal(pred_1[0], pred_3[0]) and np.array_equal(pred_1[1], pred_3[1])
+        a.rds_numpy, b.rds_numpy = np.random.RandomState(55), np.random.RandomState(55)
+        a.meta_fit(verbose=False)
+        b.meta_fit(verbose=False)
+        assert np.array_equal(a.predict(*test[0][:3])[0], b.predict(*test[0][:3])[0])
+
+
+@pytest.mark.parametrize('mean_module,covar_module,mode', [('constant', 'SE', 'both'), ('zero', 'SE', 'learn_kernel'),
+                                                            ('NN', 'SE', 'learn_mean'), ('zero', 'SE', 'vanilla')])
+def test_map_module_variants_match_oracle(M, mean_module, covar_module, mode):
+    train, test = demo_data()
+    model = M.GPRegressionMetaLearned(train, learning_mode=mode, weight_decay=0.1, num_iter_fit=30, mean_module=mean_module,
+                                      covar_module=covar_module, random_seed=4)
+    loss = model.meta_fit(log_period=1000, verbose=False)
+    if mode == 'both':
+        orc = O.MapOracle(train, weight_decay=0.1, num_iter_fit=30, mean_module=mean_module, covar_module=covar_module,
+                          random_seed=4)
+        orc.meta_fit(None, log_period=1000)
+        got = model.eval_datasets(test)
+        ref = orc.eval_datasets(test)
+        assert np.allclose(got, ref, atol=3e-3)
+    else:
+        assert np.isfinite(loss)
+        lay = model.layout
+        lo, hi = lay.slices['lengthscale_raw']
+        moved = float(model.theta[0, lo:hi].abs().sum()) > 0
+        assert moved == (mode in ('learn_kernel',))          # raw lengthscale starts at 0 and only moves if trained
+
+
+# ------------------------------------------------------------------------------------------ SVGD
+def tasks_nd(T, n, d):
+    return O.sinusoid_tasks_nd(T, n, d, seed0=1000)
+
+
+@pytest.mark.parametrize('mean_module,covar_module,d,n', [('NN', 'NN', 4, 64), ('constant', 'SE', 4, 64), ('NN', 'SE', 1, 32)])
+def test_svgd_score_and_step_match_oracle(M, mean_module, covar_module, d, n):
+    T, P = 6, 5
+    tasks = tasks_nd(T, n, d)
+    model = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=P, mean_module=mean_module, covar_module=covar_module,
+                                          random_seed=3, lr=1e-2, bandwidth=None)
+    cfg = O.GPConfig(d, mean_module, covar_module)
+    assert cfg.D == model.layout.D
+    pm, ps = O.hyperprior_mean_std(cfg.layout, 0.5, 3.0)
+    # same particle initialisation stream as the reference (model construction, then one prior draw)
+    torch.manual_seed(3)
+    O.consume_vectorized_gp_init_rng(cfg)
+    theta0 = O.hyperprior_sample(cfg.layout, pm, ps, P)
+    assert relerr(model.particles, theta0) == 0
+    stats = O.compute_normalization_stats(tasks)
+    otasks = [O.prepare_task(x, y, stats, torch.float64) for x, y in tasks]
+    idx = np.arange(T)
+    pre = O.meta_pre_factor([n] * T)
+    lp, score = model._log_prob_and_score(model.particles, idx, pre)
+    lp_o, score_o = O.meta_score(theta0.double(), otasks, cfg, pm, ps, 0.01)
+    assert relerr(lp, lp_o) < 1e-4
+    assert relerr(score, score_o) < 1e-2                       # fp32 bar, norm-wise
+    # three full SVGD steps vs oracle (closed-form phi + torch Adam), same task order
+    X = theta0.double().clone()
+    opt = torch.optim.Adam([X], lr=1e-2)
+    for _ in range(3):
+        _, s = O.meta_score(X, otasks, cfg, pm, ps, 0.01)
+        phi, _ = O.svgd_phi_closed_form(X.detach(), s, None)
+        X.grad = -phi
+        opt.step()
+        model.svgd_step(idx, pre)
+    assert relerr(model.particles, X) < 2e-3
+
+
+def test_svgd_predict_and_eval_match_oracle(M):
+    T, P, n, d = 5, 4, 20, 2
+    tasks = tasks_nd(T, n, d)
+    model = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=P, random_seed=1, num_iter_fit=3)
+    model.meta_fit(verbose=False)
+    cfg = O.GPConfig(d, 'NN', 'NN')
+    theta = model.particles.cpu().double()
+    stats = O.compute_normalization_stats(tasks)
+    x, y = tasks[0]
+    rs = np.random.RandomState(5)
+    tx = rs.uniform(-5, 5, size=(30, d))
+    ty = rs.normal(size=(30, 1)) * 0.3 + 5
+    cx, cy = O.prepare_task(x, y, stats, torch.float64)
+    txn = torch.from_numpy(O.normalize(tx, stats)).float().double()
+    m_c, z_c, ls, noise = O.vectorized_gp_features(theta, cx, cfg)
+    m_t, z_t, _, _ = O.vectorized_gp_features(theta, txn, cfg)
+    mean_n, cov_n = O.gp_predict(z_c, m_c, cy.unsqueeze(0).expand(P, -1), z_t, m_t, ls, 1.0, noise)
+    mu_o, sd_o = O.mixture_mean_std(mean_n, cov_n, stats[2], stats[3])
+    mu, sd = model.predict(x, y, tx)
+    assert relerr(mu, mu_o) < 1e-3 and relerr(sd, sd_o) < 1e-3
+    ll, rmse, calib = model.eval(x, y, tx, ty)
+    ll_o, rmse_o, calib_o = O.eval_metrics(mean_n, cov_n, ty, stats[2], stats[3])
+    assert abs(ll - ll_o) < 1e-3 * max(1, abs(ll_o)) and abs(rmse - rmse_o) < 1e-3 and abs(calib - calib_o) < 0.04
+    ucb, lcb = model.confidence_intervals(x, y, tx, confidence=0.9)
+    assert bool((ucb > lcb).all()) and bool((ucb.numpy() > mu).all()) and bool((lcb.numpy() < mu).all())
+
+
+def test_svgd_ragged_tasks(M):
+    """tasks of different sizes in one meta-batch (harmonic-mean pre-factor, random_gp.py:209-212)"""
+    rs = np.random.RandomState(0)
+    sizes = [5, 12, 7, 5]
+    tasks = [(rs.uniform(-5, 5, size=(s, 2)), rs.normal(size=(s, 1))) for s in sizes]
+    model = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=3, mean_module='constant', covar_module='SE', random_seed=2)
+    cfg = O.GPConfig(2, 'constant', 'SE')
+    pm, ps = O.hyperprior_mean_std(cfg.layout, 0.5, 3.0)
+    stats = O.compute_normalization_stats(tasks)
+    otasks = [O.prepare_task(x, y, stats, torch.float64) for x, y in tasks]
+    pre = O.meta_pre_factor(sizes)
+    lp, score = model._log_prob_and_score(model.particles, np.arange(4), pre)
+    lp_o, score_o = O.meta_score(model.particles.cpu().double(), otasks, cfg, pm, ps, 0.01)
+    assert relerr(lp, lp_o) < 1e-4 and relerr(score, score_o) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------ VI
+def test_vi_elbo_and_grad_match_oracle(M):
+    T, n, d, S = 5, 32, 2, 4
+    tasks = tasks_nd(T, n, d)
+    model = M.GPRegressionMetaLearnedVI(tasks, svi_batch_size=S, random_seed=9, lr=1e-2)
+    cfg = O.GPConfig(d, 'NN', 'NN')
+    pm, ps = O.hyperprior_mean_std(cfg.layout, 0.5, 3.0)
+    stats = O.compute_normalization_stats(tasks)
+    otasks = [O.prepare_task(x, y, stats, torch.float64) for x, y in tasks]
+    loc = model.loc.cpu().double().clone().requires_grad_(True)
+    scale = model.scale.cpu().double().clone().requires_grad_(True)
+    torch.manual_seed(77)
+    eps = torch.normal(torch.zeros(S, cfg.D), torch.ones(S, cfg.D)).double()
+    loss_o = O.vi_neg_elbo(loc, scale, eps, otasks, cfg, pm, ps, 0.01)
+    loss_o.backward()
+    torch.manual_seed(77)
+    loss, grad = model.get_neg_elbo_and_grad(np.arange(T), O.meta_pre_factor([n] * T))
+    assert abs(float(loss) - float(loss_o)) < 1e-4 * abs(float(loss_o))
+    assert relerr(grad[0], loc.grad) < 1e-2 and relerr(grad[1], scale.grad) < 1e-2
+    # a few optimisation steps run and reduce the loss
+    l0 = model.meta_fit(n_iter=1, verbose=False)
+    l1 = model.meta_fit(n_iter=60, verbose=False)
+    assert np.isfinite(l1)
+    mu, sd = model.predict(tasks[0][0], tasks[0][1], tasks[1][0], n_posterior_samples=20)
+    assert mu.shape == (n,) and bool((sd > 0).all())
+    mu_map, sd_map = model.predict(tasks[0][0], tasks[0][1], tasks[1][0], mode='MAP')
+    assert mu_map.shape == (n,)
