@@ -95,6 +95,37 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional per-kernel timing with HIP events on the launch stream (bench.py sets PROFILE = {}):
+# name -> list of (start_event, end_event) around the C-ABI call.
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.end = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.end.record()
+            PROFILE.setdefault(self.name, []).append((self.start, self.end))
+        return False
+
+
+def profile_summary():
+    """{name: (launches, total_ms)} -- call after torch.cuda.synchronize()"""
+    out = {}
+    for name, evs in (PROFILE or {}).items():
+        out[name] = (len(evs), sum(s.elapsed_time(e) for s, e in evs))
+    return out
+
+
 def _check(rc, what):
     if rc != 0:
         raise RuntimeError('%s failed: %s' % (what, ERRORS.get(rc, rc)))
@@ -114,9 +145,10 @@ def gram_rbf_ard(z1, z1_div, z2, z2_div, lengthscale, outputscale, noise, add_no
     n, f = z1.shape[-2], z1.shape[-1]
     m = z2.shape[-2]
     K = torch.empty(B, n, m, dtype=z1.dtype, device=z1.device)
-    _check(lib.pacoh_gram_rbf_ard(_ptr(z1), z1_div, _ptr(z2, z1), z2_div, _ptr(lengthscale, z1), _ptr(outputscale, z1),
-                                  _ptr(noise, z1), int(bool(add_noise_diag)), _ptr(K), B, P, n, m, f, dtype_code(z1),
-                                  _stream()), 'pacoh_gram_rbf_ard')
+    with _Timed('gram_rbf_ard'):
+        _check(lib.pacoh_gram_rbf_ard(_ptr(z1), z1_div, _ptr(z2, z1), z2_div, _ptr(lengthscale, z1), _ptr(outputscale, z1),
+                                      _ptr(noise, z1), int(bool(add_noise_diag)), _ptr(K), B, P, n, m, f, dtype_code(z1),
+                                      _stream()), 'pacoh_gram_rbf_ard')
     return K
 
 
@@ -133,9 +165,10 @@ def gp_lml_fwd(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, no
     alpha = torch.empty(B, n, dtype=dt, device=dev) if want_alpha else None
     L = torch.empty(B, n, n, dtype=dt, device=dev) if want_L else None
     info = torch.empty(B, dtype=torch.int32, device=dev)
-    _check(lib.pacoh_gp_lml_fwd(_ptr(z), z_div, _ptr(mean, z), mean_mode, _ptr(y, z), y_div, _ptr(lengthscale, z),
-                                _ptr(outputscale, z), _ptr(noise, z), _ptr(n_valid), _ptr(lml), _ptr(alpha), _ptr(L),
-                                _ptr(info), B, P, n, f, dtype_code(z), _stream()), 'pacoh_gp_lml_fwd')
+    with _Timed('gp_lml_fwd'):
+        _check(lib.pacoh_gp_lml_fwd(_ptr(z), z_div, _ptr(mean, z), mean_mode, _ptr(y, z), y_div, _ptr(lengthscale, z),
+                                    _ptr(outputscale, z), _ptr(noise, z), _ptr(n_valid), _ptr(lml), _ptr(alpha), _ptr(L),
+                                    _ptr(info), B, P, n, f, dtype_code(z), _stream()), 'pacoh_gp_lml_fwd')
     return lml, alpha, L, info
 
 
@@ -156,10 +189,11 @@ def gp_lml_fwdbwd(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale,
     d_os = torch.empty(B, dtype=dt, device=dev) if outputscale is not None else None
     d_noise = torch.empty(B, dtype=dt, device=dev)
     info = torch.empty(B, dtype=torch.int32, device=dev)
-    _check(lib.pacoh_gp_lml_fwdbwd(_ptr(z), z_div, _ptr(mean, z), mean_mode, _ptr(y, z), y_div, _ptr(lengthscale, z),
-                                   _ptr(outputscale, z), _ptr(noise, z), _ptr(n_valid), _ptr(g_lml, z), _ptr(lml),
-                                   _ptr(d_z), _ptr(d_mean), _ptr(d_ls), _ptr(d_os), _ptr(d_noise), _ptr(info),
-                                   B, P, n, f, dtype_code(z), _stream()), 'pacoh_gp_lml_fwdbwd')
+    with _Timed('gp_lml_fwdbwd'):
+        _check(lib.pacoh_gp_lml_fwdbwd(_ptr(z), z_div, _ptr(mean, z), mean_mode, _ptr(y, z), y_div, _ptr(lengthscale, z),
+                                       _ptr(outputscale, z), _ptr(noise, z), _ptr(n_valid), _ptr(g_lml, z), _ptr(lml),
+                                       _ptr(d_z), _ptr(d_mean), _ptr(d_ls), _ptr(d_os), _ptr(d_noise), _ptr(info),
+                                       B, P, n, f, dtype_code(z), _stream()), 'pacoh_gp_lml_fwdbwd')
     return lml, d_z, d_mean, d_ls, d_os, d_noise, info
 
 
@@ -176,10 +210,11 @@ def gp_predict(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, z_tst, zt_div, mean_
     ws_bytes = lib.pacoh_gp_predict_workspace_bytes(B, n, m, code, int(want_cov))
     ws = torch.empty(max(1, ws_bytes), dtype=torch.uint8, device=dev) if want_cov else None
     info = torch.empty(B, dtype=torch.int32, device=dev)
-    _check(lib.pacoh_gp_predict(_ptr(z_ctx), z_div, _ptr(mean_ctx, z_ctx), mean_mode, _ptr(y, z_ctx), y_div,
-                                _ptr(z_tst, z_ctx), zt_div, _ptr(mean_tst, z_ctx), _ptr(lengthscale, z_ctx),
-                                _ptr(outputscale, z_ctx), _ptr(noise, z_ctx), _ptr(n_valid), _ptr(mu), _ptr(var),
-                                _ptr(cov), _ptr(info), _ptr(ws), B, P, n, m, f, code, _stream()), 'pacoh_gp_predict')
+    with _Timed('gp_predict'):
+        _check(lib.pacoh_gp_predict(_ptr(z_ctx), z_div, _ptr(mean_ctx, z_ctx), mean_mode, _ptr(y, z_ctx), y_div,
+                                    _ptr(z_tst, z_ctx), zt_div, _ptr(mean_tst, z_ctx), _ptr(lengthscale, z_ctx),
+                                    _ptr(outputscale, z_ctx), _ptr(noise, z_ctx), _ptr(n_valid), _ptr(mu), _ptr(var),
+                                    _ptr(cov), _ptr(info), _ptr(ws), B, P, n, m, f, code, _stream()), 'pacoh_gp_predict')
     return mu, var, cov, info
 
 
@@ -190,17 +225,19 @@ def mvn_logprob_dense(A, resid, scale=1.0, want_alpha=False):
     logp = torch.empty(B, dtype=A.dtype, device=A.device)
     alpha = torch.empty(B, n, dtype=A.dtype, device=A.device) if want_alpha else None
     info = torch.empty(B, dtype=torch.int32, device=A.device)
-    _check(lib.pacoh_mvn_logprob_dense(_ptr(A), _ptr(resid, A), _ptr(logp), _ptr(alpha), _ptr(info), float(scale),
-                                       B, n, dtype_code(A), _stream()), 'pacoh_mvn_logprob_dense')
+    with _Timed('mvn_logprob_dense'):
+        _check(lib.pacoh_mvn_logprob_dense(_ptr(A), _ptr(resid, A), _ptr(logp), _ptr(alpha), _ptr(info), float(scale),
+                                           B, n, dtype_code(A), _stream()), 'pacoh_mvn_logprob_dense')
     return logp, alpha, info
 
 
 def mlp_fwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, B, n):
     lib = load_library()
     out = torch.empty(B, n, d_out, dtype=x.dtype, device=x.device)
-    _check(lib.pacoh_mlp_fwd(_ptr(x), x_div, ctypes.c_void_p(theta_block.data_ptr()), theta_stride, P, d_in,
-                             _hidden_arr(hidden), len(hidden), d_out, _ptr(out), B, n, dtype_code(x), _stream()),
-           'pacoh_mlp_fwd')
+    with _Timed('mlp_fwd'):
+        _check(lib.pacoh_mlp_fwd(_ptr(x), x_div, ctypes.c_void_p(theta_block.data_ptr()), theta_stride, P, d_in,
+                                 _hidden_arr(hidden), len(hidden), d_out, _ptr(out), B, n, dtype_code(x), _stream()),
+               'pacoh_mlp_fwd')
     return out
 
 
@@ -212,18 +249,20 @@ def mlp_bwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, g_out, 
     need = lib.pacoh_mlp_bwd_workspace_bytes(B, P, n, d_in, harr, len(hidden), d_out, code)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(max(1, need), dtype=torch.uint8, device=x.device)
-    _check(lib.pacoh_mlp_bwd(_ptr(x), x_div, ctypes.c_void_p(theta_block.data_ptr()), theta_stride, P, d_in, harr,
-                             len(hidden), d_out, _ptr(g_out, x), ctypes.c_void_p(d_theta_block.data_ptr()),
-                             d_theta_stride, int(bool(accumulate)), _ptr(workspace), B, n, code, _stream()),
-           'pacoh_mlp_bwd')
+    with _Timed('mlp_bwd'):
+        _check(lib.pacoh_mlp_bwd(_ptr(x), x_div, ctypes.c_void_p(theta_block.data_ptr()), theta_stride, P, d_in, harr,
+                                 len(hidden), d_out, _ptr(g_out, x), ctypes.c_void_p(d_theta_block.data_ptr()),
+                                 d_theta_stride, int(bool(accumulate)), _ptr(workspace), B, n, code, _stream()),
+               'pacoh_mlp_bwd')
     return workspace
 
 
 def softplus_fwd(raw, floor=0.0):
     lib = load_library()
     out = torch.empty_like(raw)
-    _check(lib.pacoh_softplus_fwd(_ptr(raw), _ptr(out), float(floor), raw.numel(), dtype_code(raw), _stream()),
-           'pacoh_softplus_fwd')
+    with _Timed('softplus_fwd'):
+        _check(lib.pacoh_softplus_fwd(_ptr(raw), _ptr(out), float(floor), raw.numel(), dtype_code(raw), _stream()),
+               'pacoh_softplus_fwd')
     return out
 
 
@@ -232,8 +271,9 @@ def softplus_bwd(raw, g, d_raw=None, accumulate=False):
     if d_raw is None:
         d_raw = torch.empty_like(raw)
         accumulate = False
-    _check(lib.pacoh_softplus_bwd(_ptr(raw), _ptr(g, raw), ctypes.c_void_p(d_raw.data_ptr()), int(bool(accumulate)),
-                                  raw.numel(), dtype_code(raw), _stream()), 'pacoh_softplus_bwd')
+    with _Timed('softplus_bwd'):
+        _check(lib.pacoh_softplus_bwd(_ptr(raw), _ptr(g, raw), ctypes.c_void_p(d_raw.data_ptr()), int(bool(accumulate)),
+                                      raw.numel(), dtype_code(raw), _stream()), 'pacoh_softplus_bwd')
     return d_raw
 
 
@@ -241,9 +281,10 @@ def prior_logprob_grad(theta, prior_mean, prior_std, grad=None, grad_scale=1.0):
     lib = load_library()
     P, D = theta.shape
     logp = torch.empty(P, dtype=theta.dtype, device=theta.device)
-    _check(lib.pacoh_prior_logprob_grad(_ptr(theta), _ptr(prior_mean, theta), _ptr(prior_std, theta), _ptr(logp),
-                                        _ptr(grad, theta), float(grad_scale), P, D, dtype_code(theta), _stream()),
-           'pacoh_prior_logprob_grad')
+    with _Timed('prior_logprob_grad'):
+        _check(lib.pacoh_prior_logprob_grad(_ptr(theta), _ptr(prior_mean, theta), _ptr(prior_std, theta), _ptr(logp),
+                                            _ptr(grad, theta), float(grad_scale), P, D, dtype_code(theta), _stream()),
+               'pacoh_prior_logprob_grad')
     return logp
 
 
@@ -257,22 +298,25 @@ def svgd_phi(X, score, bandwidth=None, neg=False, workspace=None):
     phi = torch.empty_like(X)
     bw_out = torch.empty(1, dtype=X.dtype, device=X.device)
     bw = -1.0 if bandwidth is None else float(bandwidth)
-    _check(lib.pacoh_svgd_phi(_ptr(X), _ptr(score, X), bw, int(bool(neg)), _ptr(phi), _ptr(bw_out), _ptr(workspace),
-                              P, D, code, _stream()), 'pacoh_svgd_phi')
+    with _Timed('svgd_phi'):
+        _check(lib.pacoh_svgd_phi(_ptr(X), _ptr(score, X), bw, int(bool(neg)), _ptr(phi), _ptr(bw_out), _ptr(workspace),
+                                  P, D, code, _stream()), 'pacoh_svgd_phi')
     return phi, bw_out, workspace
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
     lib = load_library()
-    _check(lib.pacoh_adam_step(_ptr(param), _ptr(grad, param), _ptr(exp_avg, param), _ptr(exp_avg_sq, param),
-                               float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
-                               param.numel(), dtype_code(param), _stream()), 'pacoh_adam_step')
+    with _Timed('adam_step'):
+        _check(lib.pacoh_adam_step(_ptr(param), _ptr(grad, param), _ptr(exp_avg, param), _ptr(exp_avg_sq, param),
+                                   float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                   param.numel(), dtype_code(param), _stream()), 'pacoh_adam_step')
 
 
 def reduce_tasks(inp, out, scale=1.0, accumulate=False):
     """out[P,W] (+)= scale * sum_t inp[T,P,W]"""
     lib = load_library()
     T, P, W = inp.shape
-    _check(lib.pacoh_reduce_tasks(_ptr(inp), ctypes.c_void_p(out.data_ptr()), float(scale), int(bool(accumulate)),
-                                  T, P, W, dtype_code(inp), _stream()), 'pacoh_reduce_tasks')
+    with _Timed('reduce_tasks'):
+        _check(lib.pacoh_reduce_tasks(_ptr(inp), ctypes.c_void_p(out.data_ptr()), float(scale), int(bool(accumulate)),
+                                      T, P, W, dtype_code(inp), _stream()), 'pacoh_reduce_tasks')
     return out

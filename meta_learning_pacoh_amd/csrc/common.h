@@ -29,6 +29,33 @@ template <typename T> __device__ __forceinline__ T t_log1p(T x);
 template <> __device__ __forceinline__ float t_log1p<float>(float x) { return log1pf(x); }
 template <> __device__ __forceinline__ double t_log1p<double>(double x) { return log1p(x); }
 
+// exp(x) for the RBF kernel entries (x <= 0).  fp32: hardware exp2 on x*log2(e) with the rounding
+// error of that product folded back in (rel. error ~1e-7, vs ~|x|*6e-8 for the bare __expf); fp64: libm.
+template <typename T> __device__ __forceinline__ T rbf_exp(T x);
+template <> __device__ __forceinline__ double rbf_exp<double>(double x) { return exp(x); }
+template <> __device__ __forceinline__ float rbf_exp<float>(float x) {
+    const float L2E = 1.4426950408889634f, L2E_LO = 1.9259629911266175e-8f;
+    const float hi = x * L2E;
+    const float lo = fmaf(x, L2E, -hi) + x * L2E_LO;
+    const float e = __builtin_amdgcn_exp2f(hi);
+    return fmaf(e, lo * 0.6931471805599453f, e);
+}
+
+// tanh for the MLP activations.  fp32: odd polynomial below 0.25 (rel. error < 4e-7), otherwise
+// (1-t)/(1+t) with t = exp(-2|x|) on the hardware exp2 path; fp64: libm.
+template <typename T> __device__ __forceinline__ T act_tanh(T x);
+template <> __device__ __forceinline__ double act_tanh<double>(double x) { return tanh(x); }
+template <> __device__ __forceinline__ float act_tanh<float>(float x) {
+    const float ax = fabsf(x);
+    if (ax < 0.25f) {
+        const float x2 = x * x;
+        return x * fmaf(x2, fmaf(x2, fmaf(x2, -0.05396825396825397f, 0.13333333333333333f), -0.3333333333333333f), 1.0f);
+    }
+    const float t = __expf(-2.0f * ax);
+    const float r = __fdividef(1.0f - t, 1.0f + t);
+    return copysignf(r, x);
+}
+
 // Leading dimension (in elements) of an LDS matrix whose rows are read both "own row per lane"
 // (ds_read_b128, lane i at row i) and "one row broadcast to all lanes".  A multiple of the vector
 // width W whose quotient is odd spreads the 16 lanes of a ds_read_b128 lane-group over all 64 banks

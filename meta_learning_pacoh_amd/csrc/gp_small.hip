@@ -53,7 +53,7 @@ __device__ __forceinline__ T group_sum(T v, int GS, int i, T* red) {
 }
 
 template <typename T, int FP, int MODE>
-__global__ void gp_small_kernel(GpArgs<T> a) {
+__global__ void __launch_bounds__(256) gp_small_kernel(GpArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
@@ -126,7 +126,7 @@ __global__ void gp_small_kernel(GpArgs<T> a) {
                     T s = 0;
 #pragma unroll
                     for (int c = 0; c < FP; ++c) { T d = zs[c] - zf[k * FP + c]; s = fma(d, d, s); }
-                    aik = os * t_exp<T>(T(-0.5) * s);
+                    aik = os * rbf_exp<T>(T(-0.5) * s);
                     if (i == k) aik += noise + jitter;
                 } else {
                     aik = (i == k) ? T(1) : T(0);
@@ -209,7 +209,7 @@ __global__ void gp_small_kernel(GpArgs<T> a) {
                     T df[FP];
 #pragma unroll
                     for (int c = 0; c < FP; ++c) { df[c] = zf[j * FP + c] - zs[c]; s = fma(df[c], df[c], s); }
-                    T e = t_exp<T>(T(-0.5) * s);
+                    T e = rbf_exp<T>(T(-0.5) * s);
                     dos = fma(Gij, e, dos);
                     T M = Gij * os * e;
 #pragma unroll
@@ -274,7 +274,7 @@ __global__ void gp_small_kernel(GpArgs<T> a) {
                         T sd = 0;
 #pragma unroll
                         for (int c = 0; c < FP; ++c) { T d = zt[c] - zf[r * FP + c]; sd = fma(d, d, sd); }
-                        ks = os * t_exp<T>(T(-0.5) * sd);
+                        ks = os * rbf_exp<T>(T(-0.5) * sd);
                     }
                     T acc = dot_rows<T>(Zmat + (size_t)i * LD, Lmat + (size_t)r * LD, 0, r);
                     T val = (ks - acc) * invd[r];
@@ -308,7 +308,7 @@ __global__ void gp_predict_cov_kernel(const T* __restrict__ z_tst, int zt_div, c
     T sd = 0;
     for (int c = 0; c < f; ++c) { T d = (za[c] - zb[c]) / ls[(long)p * f + c]; sd = fma(d, d, sd); }
     T osv = os ? os[p] : T(1);
-    T k = osv * t_exp<T>(T(-0.5) * sd);
+    T k = osv * rbf_exp<T>(T(-0.5) * sd);
     const T* va = V + (b * m + s1) * (long)n;
     const T* vb = V + (b * m + s2) * (long)n;
     T acc = 0;

@@ -10,53 +10,76 @@
 
 namespace pacoh {
 
+// One workgroup = one problem b and one tile of TI rows x TJ columns (1024 output quads, QPT per
+// thread).  The tile's input rows are staged once into LDS already divided by the lengthscale, so
+// the inner loop is branch-free LDS reads + FMA + exp + one 16-byte store per quad; b, its
+// hyper-parameters and all 64-bit index arithmetic are wave-uniform scalars.
+constexpr int QPT = 4;
+
 template <typename T, int FP>
 __global__ void __launch_bounds__(256) gram_kernel(const T* __restrict__ z1, int z1_div, const T* __restrict__ z2, int z2_div,
                                                    const T* __restrict__ ls, const T* __restrict__ os,
                                                    const T* __restrict__ noise, int add_noise, T* __restrict__ K,
-                                                   int B, int P, int n, int m, int f, int mq /* = ceil(m/VW) */) {
+                                                   int P, int n, int m, int f, int tjq_shift, int tiles_i, int tiles_j) {
     using V = typename VecOf<T>::type;
     constexpr int VW = VecOf<T>::W;
-    const long total = (long)B * n * mq;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* z1s = reinterpret_cast<T*>(smem_raw);
+    const int TJQ = 1 << tjq_shift;                  // quads per tile row
+    const int TJ = TJQ * VW;                         // tile columns
+    const int TI = (QPT * 256) >> tjq_shift;         // tile rows
+    T* z2s = z1s + TI * FP;
+    const int tj = blockIdx.x % tiles_j;
+    const int rest = blockIdx.x / tiles_j;
+    const int ti = rest % tiles_i;
+    const int b = rest / tiles_i;
+    const int p = b % P;
+    const int i0 = ti * TI, j00 = tj * TJ;
+    const T* lp = ls + (long)p * f;
+    const T osv = os ? os[p] : T(1);
+    const T nz = add_noise ? noise[p] : T(0);
+    const T* z1b = z1 + (long)(b / z1_div) * n * f;
+    const T* z2b = z2 + (long)(b / z2_div) * m * f;
+    for (int e = threadIdx.x; e < TI * FP; e += 256) {
+        const int r = e / FP, c = e - r * FP;
+        z1s[e] = (i0 + r < n && c < f) ? z1b[(long)(i0 + r) * f + c] / lp[c] : T(0);
+    }
+    for (int e = threadIdx.x; e < TJ * FP; e += 256) {
+        const int r = e / FP, c = e - r * FP;
+        z2s[e] = (j00 + r < m && c < f) ? z2b[(long)(j00 + r) * f + c] / lp[c] : T(0);
+    }
+    __syncthreads();
+    T* Kb = K + (long)b * n * m;
     const bool vec_ok = (m % VW) == 0;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
-        const int jq = (int)(q % mq);
-        const long bi = q / mq;
-        const int i = (int)(bi % n);
-        const long b = bi / n;
-        const int p = (int)(b % P);
-        const int j0 = jq * VW;
-        T inv[FP], a[FP];
-        const T* lp = ls + (long)p * f;
-        const T* ap = z1 + ((b / z1_div) * n + i) * (long)f;
 #pragma unroll
-        for (int c = 0; c < FP; ++c) {
-            inv[c] = (c < f) ? T(1) / lp[c] : T(0);
-            a[c] = (c < f) ? ap[c] * inv[c] : T(0);
-        }
-        const T osv = os ? os[p] : T(1);
+    for (int u = 0; u < QPT; ++u) {
+        const int q = u * 256 + threadIdx.x;
+        const int il = q >> tjq_shift, jq = q & (TJQ - 1);
+        const int i = i0 + il, j0 = j00 + jq * VW;
+        T a[FP];
+#pragma unroll
+        for (int c = 0; c < FP; ++c) a[c] = z1s[il * FP + c];
         T out[VW];
 #pragma unroll
         for (int v = 0; v < VW; ++v) {
-            const int j = j0 + v;
+            const T* bp = z2s + (jq * VW + v) * FP;
             T s = 0;
-            if (j < m) {
-                const T* bp = z2 + ((b / z2_div) * m + j) * (long)f;
 #pragma unroll
-                for (int c = 0; c < FP; ++c) if (c < f) { T d = a[c] - bp[c] * inv[c]; s = fma(d, d, s); }
-            }
-            T k = osv * t_exp<T>(T(-0.5) * s);
-            if (add_noise && i == j) k += noise[p];
+            for (int c = 0; c < FP; ++c) { T d = a[c] - bp[c]; s = fma(d, d, s); }
+            T k = osv * rbf_exp<T>(T(-0.5) * s);
+            if (i == j0 + v) k += nz;
             out[v] = k;
         }
-        T* kp = K + (b * n + i) * (long)m + j0;
-        if (vec_ok) {
-            V o;
-            if constexpr (VW == 4) { o.x = out[0]; o.y = out[1]; o.z = out[2]; o.w = out[3]; } else { o.x = out[0]; o.y = out[1]; }
-            *reinterpret_cast<V*>(kp) = o;
-        } else {
+        if (i < n && j0 < m) {
+            T* kp = Kb + (long)i * m + j0;
+            if (vec_ok) {
+                V o;
+                if constexpr (VW == 4) { o.x = out[0]; o.y = out[1]; o.z = out[2]; o.w = out[3]; } else { o.x = out[0]; o.y = out[1]; }
+                *reinterpret_cast<V*>(kp) = o;
+            } else {
 #pragma unroll
-            for (int v = 0; v < VW; ++v) if (j0 + v < m) kp[v] = out[v];
+                for (int v = 0; v < VW; ++v) if (j0 + v < m) kp[v] = out[v];
+            }
         }
     }
 }
@@ -66,13 +89,17 @@ static int launch_gram(const void* z1, int z1_div, const void* z2, int z2_div, c
                        const void* noise, int add_noise, void* K, int B, int P, int n, int m, int f, hipStream_t s) {
     constexpr int VW = VecOf<T>::W;
     const int mq = (m + VW - 1) / VW;
-    const long total = (long)B * n * mq;
-    long blocks = (total + 255) / 256;
-    const long cap = 256L * 32;          // 32 resident-ish workgroups per CU worth of grid, grid-stride beyond
-    if (blocks > cap) blocks = cap;
+    int tjq_shift = 0;
+    while ((1 << tjq_shift) < mq && tjq_shift < 6) ++tjq_shift;       // tile: up to 64 quads wide
+    const int TJ = (1 << tjq_shift) * VW, TI = (QPT * 256) >> tjq_shift;
+    const int tiles_i = (n + TI - 1) / TI, tiles_j = (m + TJ - 1) / TJ;
+    const long blocks = (long)B * tiles_i * tiles_j;
+    if (blocks > 0x7fffffffL) return PACOH_ELIMIT;
     const int FP = f <= 2 ? 2 : (f <= 4 ? 4 : (f <= 8 ? 8 : 16));
-#define PACOH_GRAM_CASE(fp) case fp: hipLaunchKernelGGL((gram_kernel<T, fp>), dim3((unsigned)blocks), dim3(256), 0, s, \
-        (const T*)z1, z1_div, (const T*)z2, z2_div, (const T*)ls, (const T*)os, (const T*)noise, add_noise, (T*)K, B, P, n, m, f, mq); break;
+    const size_t lds = (size_t)(TI + TJ) * FP * sizeof(T);
+#define PACOH_GRAM_CASE(fp) case fp: hipLaunchKernelGGL((gram_kernel<T, fp>), dim3((unsigned)blocks), dim3(256), lds, s, \
+        (const T*)z1, z1_div, (const T*)z2, z2_div, (const T*)ls, (const T*)os, (const T*)noise, add_noise, (T*)K, P, n, m, f, \
+        tjq_shift, tiles_i, tiles_j); break;
     switch (FP) { PACOH_GRAM_CASE(2) PACOH_GRAM_CASE(4) PACOH_GRAM_CASE(8) default: PACOH_GRAM_CASE(16) }
 #undef PACOH_GRAM_CASE
     return launch_status();

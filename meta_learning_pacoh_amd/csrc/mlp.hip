@@ -9,13 +9,18 @@ PACOH_MLP_DECL(f32)
 PACOH_MLP_DECL(f64)
 #undef PACOH_MLP_DECL
 
+// out[o] (+)= scale * sum_c in[c, o]; one wavefront per output element, lanes stride over c, fixed order
 template <typename T>
-__global__ void reduce_tasks_kernel(const T* __restrict__ in, T* __restrict__ out, T scale, int accumulate, int C, int P, int Wd) {
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)P * Wd) return;
+__global__ void __launch_bounds__(256) reduce_tasks_kernel(const T* __restrict__ in, T* __restrict__ out, T scale, int accumulate,
+                                                           int C, int P, int Wd) {
+    const long tot = (long)P * Wd;
+    const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= tot) return;
+    const int lane = threadIdx.x & 63;
     T s = 0;
-    for (int c = 0; c < C; ++c) s += in[(long)c * P * Wd + idx];
-    out[idx] = accumulate ? out[idx] + scale * s : scale * s;
+    for (int c = lane; c < C; c += 64) s += in[(long)c * tot + idx];
+    s = subwave_sum<T>(s, 64);
+    if (lane == 0) out[idx] = accumulate ? out[idx] + scale * s : scale * s;
 }
 }  // namespace pacoh
 
@@ -31,7 +36,7 @@ extern "C" int pacoh_mlp_fwd(const void* x, int x_div, const void* theta, long t
         : mlp_fwd_f64(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, (hipStream_t)stream);
 }
 
-static int mlp_layout(int d_in, const int32_t* hidden, int n_hidden, int d_out, int& params, int& tile) {
+static int mlp_layout(int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype, int& params, int& tile) {
     if (d_in <= 0 || d_out <= 0 || n_hidden < 0 || n_hidden > PACOH_MAX_HIDDEN_LAYERS || (n_hidden > 0 && !hidden)) return -1;
     int prev = d_in, mx = 0;
     params = 0;
@@ -40,14 +45,14 @@ static int mlp_layout(int d_in, const int32_t* hidden, int n_hidden, int d_out, 
         params += hidden[l] * (prev + 1); prev = hidden[l]; mx = hidden[l] > mx ? hidden[l] : mx;
     }
     params += d_out * (prev + 1);
-    tile = mx <= 32 ? 256 : 128;
+    tile = (mx <= 32 ? 256 : 128) / (dtype == PACOH_F64 ? 2 : 1);     // = bwd_tile<T>(HP) in mlp_impl.h
     return 0;
 }
 
 extern "C" size_t pacoh_mlp_bwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden,
                                                 int n_hidden, int d_out, int dtype) {
     int params, tile;
-    if (P <= 0 || B <= 0 || n <= 0 || mlp_layout(d_in, hidden, n_hidden, d_out, params, tile)) return 0;
+    if (P <= 0 || B <= 0 || n <= 0 || mlp_layout(d_in, hidden, n_hidden, d_out, dtype, params, tile)) return 0;
     long rows = (long)(B / P) * n;
     long tiles = (rows + tile - 1) / tile;
     long want = (2048 + P - 1) / P;
@@ -73,10 +78,10 @@ extern "C" int pacoh_reduce_tasks(const void* in, void* out, double scale, int a
     if (!in || !out || T_ <= 0 || P <= 0 || Wd <= 0) return PACOH_EINVAL;
     long tot = (long)P * Wd;
     if (dtype == PACOH_F32)
-        hipLaunchKernelGGL(reduce_tasks_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(reduce_tasks_kernel<float>, dim3((unsigned)((tot + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)in, (float*)out, (float)scale, accumulate, T_, P, Wd);
     else
-        hipLaunchKernelGGL(reduce_tasks_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(reduce_tasks_kernel<double>, dim3((unsigned)((tot + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                            (const double*)in, (double*)out, scale, accumulate, T_, P, Wd);
     return launch_status();
 }

@@ -71,7 +71,7 @@ __device__ void load_weights(T* wl, const T* __restrict__ th, const MlpDims& d) 
 }
 
 template <typename T, int IN, int OUT, bool ACT>
-__device__ __forceinline__ void dense(const T* __restrict__ wl, const T (&in)[IN], T (&out)[OUT]) {
+__device__ __forceinline__ void dense(const T* wl, const T (&in)[IN], T (&out)[OUT]) {
     using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
     const T* bias = wl;
@@ -90,13 +90,43 @@ __device__ __forceinline__ void dense(const T* __restrict__ wl, const T (&in)[IN
                 acc = fma(w.x, in[2 * v], acc); acc = fma(w.y, in[2 * v + 1], acc);
             }
         }
-        out[o] = ACT ? t_tanh<T>(acc) : acc;
+        out[o] = ACT ? act_tanh<T>(acc) : acc;
     }
+}
+
+// Same layer with the output loop kept as a real (not unrolled) loop: each result goes to a
+// thread-private LDS column col[o*TPB] and is read back with static indices.  Used by the forward
+// kernel, where the fully unrolled form makes hipcc hoist the whole layer's weight reads in front
+// of the FMAs and spill them (2340 B/lane of scratch in the first build of this kernel).
+template <typename T, int IN, int OUT, bool ACT, int TPB>
+__device__ __forceinline__ void dense_rolled(const T* wl, T* col, const T (&in)[IN], T (&out)[OUT]) {
+    using V = typename VecOf<T>::type;
+    constexpr int W = VecOf<T>::W;
+    const T* bias = wl;
+    const T* Wm = wl + OUT;
+#pragma unroll 1
+    for (int o = 0; o < OUT; ++o) {
+        T acc = bias[o];
+        const V* row = reinterpret_cast<const V*>(Wm + o * IN);
+#pragma unroll
+        for (int v = 0; v < IN / W; ++v) {
+            V w = row[v];
+            if constexpr (W == 4) {
+                acc = fma(w.x, in[4 * v], acc); acc = fma(w.y, in[4 * v + 1], acc);
+                acc = fma(w.z, in[4 * v + 2], acc); acc = fma(w.w, in[4 * v + 3], acc);
+            } else {
+                acc = fma(w.x, in[2 * v], acc); acc = fma(w.y, in[2 * v + 1], acc);
+            }
+        }
+        col[o * TPB] = ACT ? act_tanh<T>(acc) : acc;
+    }
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) out[o] = col[o * TPB];
 }
 
 // d_in[k] = sum_o W[o][k] * delta[o]
 template <typename T, int IN, int OUT>
-__device__ __forceinline__ void dense_back(const T* __restrict__ wl, const T (&delta)[OUT], T (&din)[IN]) {
+__device__ __forceinline__ void dense_back(const T* wl, const T (&delta)[OUT], T (&din)[IN]) {
     using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
     const T* Wm = wl + OUT;
@@ -119,42 +149,55 @@ __device__ __forceinline__ void dense_back(const T* __restrict__ wl, const T (&d
     }
 }
 
+// row r of particle p -> problem b = t*P + p, point i.  All index math is 32-bit (64-bit integer
+// division costs ~150 instructions and a dozen SGPR pairs on gfx950); only the final offsets are 64-bit.
 template <typename T>
-__device__ __forceinline__ const T* row_x(const MlpArgs<T>& a, int p, long r, long& b, int& i) {
-    long t = r / a.n;
-    i = (int)(r - t * a.n);
-    b = t * a.P + p;
-    return a.x + ((b / a.x_div) * a.n + i) * (long)a.dims.d_in;
+__device__ __forceinline__ const T* row_x(const MlpArgs<T>& a, int p, int r, long& b, int& i) {
+    const int t = (int)((unsigned)r / (unsigned)a.n);
+    i = r - t * a.n;
+    const int bi = t * a.P + p;
+    b = bi;
+    const int xb = (a.x_div == 1) ? bi : (int)((unsigned)bi / (unsigned)a.x_div);
+    return a.x + ((long)xb * a.n + i) * (long)a.dims.d_in;
 }
 
-template <typename T, int HP, int NH>
-__global__ void mlp_fwd_kernel(MlpArgs<T> a) {
+template <typename T, int HP, int NH, int TPB>
+__global__ void __launch_bounds__(TPB) mlp_fwd_kernel(MlpArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* wl = reinterpret_cast<T*>(smem_raw);
+    constexpr int WELEMS = (lds_weight_elems<HP, NH>() + 3) & ~3;
+    T* col = wl + WELEMS + threadIdx.x;            // thread-private column, stride TPB
     const int p = blockIdx.y;
     load_weights<T, HP, NH>(wl, a.theta + (long)p * a.theta_stride, a.dims);
-    const long R = a.rows_per_particle;
-    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (long)gridDim.x * blockDim.x) {
+    const int R = (int)a.rows_per_particle;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+        // compiler barrier: without it the (loop-invariant) LDS weight reads are hoisted out of the row
+        // loop into ~1000 registers -> 256 VGPRs + scratch, 1 wave/SIMD
+        asm volatile("" ::: "memory");
         long b; int i;
         const T* xp = row_x(a, p, r, b, i);
         T x[DP];
+        const int d_in = a.dims.d_in;
 #pragma unroll
-        for (int c = 0; c < DP; ++c) x[c] = (c < a.dims.d_in) ? xp[c] : T(0);
+        for (int c = 0; c < DP; ++c) {           // branch-free: clamped (always valid) load + select
+            const T v = xp[c < d_in ? c : d_in - 1];
+            x[c] = (c < d_in) ? v : T(0);
+        }
         T o[OP];
         if constexpr (NH == 0) {
-            dense<T, DP, OP, false>(wl, x, o);
+            dense_rolled<T, DP, OP, false, TPB>(wl, col, x, o);
         } else {
             T h[HP], h2[HP];
-            dense<T, DP, HP, true>(wl, x, h);
+            dense_rolled<T, DP, HP, true, TPB>(wl, col, x, h);
             int off = HP + HP * DP;
 #pragma unroll
             for (int l = 1; l < NH; ++l) {
-                dense<T, HP, HP, true>(wl + off, h, h2);
+                dense_rolled<T, HP, HP, true, TPB>(wl + off, col, h, h2);
 #pragma unroll
                 for (int k = 0; k < HP; ++k) h[k] = h2[k];
                 off += HP + HP * HP;
             }
-            dense<T, HP, OP, false>(wl + off, h, o);
+            dense_rolled<T, HP, OP, false, TPB>(wl + off, col, h, o);
         }
         T* op = a.out + (b * a.n + i) * (long)a.dims.d_out;
 #pragma unroll
@@ -233,15 +276,16 @@ __global__ void __launch_bounds__(TILE) mlp_bwd_kernel(MlpArgs<T> a) {
 #pragma unroll
     for (int q = 0; q < NQO; ++q) for (int c = 0; c < 4; ++c) accO[q][c] = 0;
 
-    const long R = a.rows_per_particle;
-    const long rows_per_chunk = ((R + a.n_chunks - 1) / a.n_chunks + TILE - 1) / TILE * TILE;
-    const long r_begin = (long)blockIdx.x * rows_per_chunk;
-    const long r_end = (r_begin + rows_per_chunk < R) ? r_begin + rows_per_chunk : R;
+    const int R = (int)a.rows_per_particle;
+    const int rows_per_chunk = ((R + a.n_chunks - 1) / a.n_chunks + TILE - 1) / TILE * TILE;
+    const long r_begin_l = (long)blockIdx.x * rows_per_chunk;
+    const int r_begin = r_begin_l < R ? (int)r_begin_l : R;
+    const int r_end = (r_begin_l + rows_per_chunk < R) ? (int)(r_begin_l + rows_per_chunk) : R;
 
-    for (long r0 = r_begin; r0 < r_end; r0 += TILE) {
-        const long r = r0 + threadIdx.x;
+    for (int r0 = r_begin; r0 < r_end; r0 += TILE) {
+        const int r = r0 + threadIdx.x;
         const bool has = r < r_end;
-        const int npts = (int)((r_end - r0 < TILE) ? (r_end - r0) : TILE);
+        const int npts = (r_end - r0 < TILE) ? (r_end - r0) : TILE;
         T x[DP];
         T go[OP];
 #pragma unroll
@@ -251,11 +295,12 @@ __global__ void __launch_bounds__(TILE) mlp_bwd_kernel(MlpArgs<T> a) {
         if (has) {
             long b; int i;
             const T* xp = row_x(a, p, r, b, i);
+            const int d_in = a.dims.d_in, d_out = a.dims.d_out;
 #pragma unroll
-            for (int c = 0; c < DP; ++c) if (c < a.dims.d_in) x[c] = xp[c];
-            const T* gp = a.g_out + (b * a.n + i) * (long)a.dims.d_out;
+            for (int c = 0; c < DP; ++c) { const T v = xp[c < d_in ? c : d_in - 1]; x[c] = (c < d_in) ? v : T(0); }
+            const T* gp = a.g_out + (b * a.n + i) * (long)d_out;
 #pragma unroll
-            for (int c = 0; c < OP; ++c) if (c < a.dims.d_out) go[c] = gp[c];
+            for (int c = 0; c < OP; ++c) { const T v = gp[c < d_out ? c : d_out - 1]; go[c] = (c < d_out) ? v : T(0); }
         }
         if constexpr (NH == 0) {
 #pragma unroll
@@ -356,6 +401,8 @@ static int fill_dims(MlpDims& d, int d_in, const int32_t* hidden, int n_hidden, 
     return PACOH_OK;
 }
 
+template <typename T> constexpr int bwd_tile(int HP) { return (HP == 32 ? 256 : 128) / (sizeof(T) == 8 ? 2 : 1); }
+
 static int bwd_chunks(long rows_per_particle, int P, int tile) {
     // enough workgroups to fill 256 CUs several times over, but at least one tile of rows each
     long tiles = (rows_per_particle + tile - 1) / tile;
@@ -366,19 +413,21 @@ static int bwd_chunks(long rows_per_particle, int P, int tile) {
 
 template <typename T, int HP, int NH>
 static int launch_fwd(MlpArgs<T>& a, hipStream_t s) {
-    size_t lds = (size_t)lds_weight_elems<HP, NH>() * sizeof(T);
-    long blocks = (a.rows_per_particle + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    auto kern = mlp_fwd_kernel<T, HP, NH>;
+    constexpr int TPB = sizeof(T) == 8 ? 128 : 256;
+    size_t lds = (size_t)(((lds_weight_elems<HP, NH>() + 3) & ~3) + TPB * (NH == 0 ? OP : HP)) * sizeof(T);
+    if (lds > 160u * 1024u) return PACOH_ELIMIT;
+    long blocks = (a.rows_per_particle + TPB - 1) / TPB;
+    if (blocks > 8192) blocks = 8192;
+    auto kern = mlp_fwd_kernel<T, HP, NH, TPB>;
     if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PACOH_ELIMIT;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, a.P), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, a.P), dim3(TPB), lds, s, a);
     return launch_status();
 }
 
 template <typename T, int HP, int NH>
 static int launch_bwd(MlpArgs<T>& a, hipStream_t s) {
-    constexpr int TILE = (HP == 32) ? 256 : 128;
+    constexpr int TILE = bwd_tile<T>(HP);
     constexpr int MAXW = (NH == 0) ? DP : HP;
     constexpr int MAXO = (NH == 0) ? OP : HP;
     size_t elems = ((lds_weight_elems<HP, NH>() + 3) & ~3) + ((TILE * (MAXO + 1) + 3) & ~3) + TILE * (MAXW + 4);
@@ -408,6 +457,7 @@ static int mlp_common(MlpArgs<T>& a, const void* x, int x_div, const void* theta
     if (rc) return rc;
     a.x = (const T*)x; a.x_div = x_div; a.theta = (const T*)theta; a.theta_stride = theta_stride;
     a.P = P; a.B = B; a.n = n; a.rows_per_particle = (long)(B / P) * n;
+    if (a.rows_per_particle > 0x3fffffffL || (long)B * n > 0x7fffffffL) return PACOH_ELIMIT;
     a.D_net = mlp_param_count(a.dims);
     return PACOH_OK;
 }
@@ -435,7 +485,7 @@ int mlp_bwd_entry(const void* x, int x_div, const void* theta, long theta_stride
     MlpArgs<T> a = {};
     if ((rc = mlp_common(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, B, n, HP))) return rc;
     a.g_out = (const T*)g_out; a.slab = (T*)workspace;
-    a.n_chunks = bwd_chunks(a.rows_per_particle, P, HP == 32 ? 256 : 128);
+    a.n_chunks = bwd_chunks(a.rows_per_particle, P, bwd_tile<T>(HP));
     if ((rc = dispatch<T, true>(a, HP, stream))) return rc;
     long tot = (long)P * a.D_net;
     hipLaunchKernelGGL(reduce_chunks_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
