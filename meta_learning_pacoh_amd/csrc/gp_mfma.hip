@@ -1,0 +1,394 @@
+// MFMA-blocked fused task-GP kernel for n <= 64, fp32: one 64-lane wavefront per (task, particle)
+// problem, the n x n matrix lives in LDS (17 KB at n = 64 -> 8 problems per CU) and every O(n^3)
+// phase runs on the matrix cores as 16x16 block products (v_mfma_f32_16x16x4_f32, exact fp32):
+//
+//   A = os*K(z) + (noise+jitter) I        row-per-lane Gram build straight into LDS (lower blocks)
+//   blocked right-looking Cholesky        diagonal 16x16 block: factor + invert in registers
+//                                         (row per lane, broadcasts by v_readlane), panel and trailing
+//                                         update as X*Y^T block products
+//   Z = L^-1 (in place, block forward substitution), W = K^-1 = Z^T Z (in place, mirrored to a full
+//   symmetric matrix), u = Z r, alpha = W r, then the gradient sums with lane i owning row i of W.
+//
+// The k index of a block product is permuted (lane group g, chunk s -> k = 4g + s) so that one
+// ds_read_b128 per operand feeds the four MFMAs of a 16x16x16 product, and so that a product held in
+// the accumulator layout is directly the B operand of the next product (no LDS round trip).
+//
+// Same arithmetic as gp_small.hip (which remains the general path: any n <= 128, fp64, predict);
+// reference lines replaced: random_gp.py:54-89, GPR_meta_mll.py:104-117 (through gpytorch).
+#include "common.h"
+
+namespace pacoh {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct GpMfmaArgs {
+    const float* z; int z_div;
+    const float* mean; int mean_mode;
+    const float* y; int y_div;
+    const float* ls; const float* os; const float* noise;
+    const int32_t* n_valid;
+    const float* g_lml;
+    float* lml; int32_t* info;
+    float* d_z; float* d_mean; float* d_ls; float* d_os; float* d_noise;
+    int B, P, n, f;
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// acc += sgn * X * Y^T, X at (xr,xc), Y at (yr,yc) in the LDS matrix
+__device__ __forceinline__ void mm_xyT(f32x4& acc, const float* A, int LD, int xr, int xc, int yr, int yc, int r, int g, float sgn) {
+    const float4 a = *reinterpret_cast<const float4*>(A + (xr + r) * LD + xc + 4 * g);
+    const float4 b = *reinterpret_cast<const float4*>(A + (yr + r) * LD + yc + 4 * g);
+    acc = mfma4(sgn * a.x, b.x, acc); acc = mfma4(sgn * a.y, b.y, acc);
+    acc = mfma4(sgn * a.z, b.z, acc); acc = mfma4(sgn * a.w, b.w, acc);
+}
+
+// acc += X * Y, both from LDS
+__device__ __forceinline__ void mm_xy(f32x4& acc, const float* A, int LD, int xr, int xc, int yr, int yc, int r, int g) {
+    const float4 a = *reinterpret_cast<const float4*>(A + (xr + r) * LD + xc + 4 * g);
+    const float* yp = A + (yr + 4 * g) * LD + yc + r;
+    acc = mfma4(a.x, yp[0], acc); acc = mfma4(a.y, yp[LD], acc);
+    acc = mfma4(a.z, yp[2 * LD], acc); acc = mfma4(a.w, yp[3 * LD], acc);
+}
+
+// acc += sgn * X * S, X from LDS, S a 16x16 block held in accumulator layout
+__device__ __forceinline__ void mm_xs(f32x4& acc, const float* A, int LD, int xr, int xc, const f32x4& S, int r, int g, float sgn) {
+    const float4 a = *reinterpret_cast<const float4*>(A + (xr + r) * LD + xc + 4 * g);
+    acc = mfma4(sgn * a.x, S[0], acc); acc = mfma4(sgn * a.y, S[1], acc);
+    acc = mfma4(sgn * a.z, S[2], acc); acc = mfma4(sgn * a.w, S[3], acc);
+}
+
+// acc += X^T * Y, both from LDS
+__device__ __forceinline__ void mm_xTy(f32x4& acc, const float* A, int LD, int xr, int xc, int yr, int yc, int r, int g) {
+    const float* xp = A + (xr + 4 * g) * LD + xc + r;
+    const float* yp = A + (yr + 4 * g) * LD + yc + r;
+    acc = mfma4(xp[0], yp[0], acc); acc = mfma4(xp[LD], yp[LD], acc);
+    acc = mfma4(xp[2 * LD], yp[2 * LD], acc); acc = mfma4(xp[3 * LD], yp[3 * LD], acc);
+}
+
+__device__ __forceinline__ f32x4 load_c(const float* A, int LD, int br, int bc, int r, int g) {
+    const float* p = A + (br + 4 * g) * LD + bc + r;
+    f32x4 c; c[0] = p[0]; c[1] = p[LD]; c[2] = p[2 * LD]; c[3] = p[3 * LD];
+    return c;
+}
+
+__device__ __forceinline__ void store_c(float* A, int LD, int br, int bc, int r, int g, const f32x4& c) {
+    float* p = A + (br + 4 * g) * LD + bc + r;
+    p[0] = c[0]; p[LD] = c[1]; p[2 * LD] = c[2]; p[3 * LD] = c[3];
+}
+
+// store the TRANSPOSE of the accumulator block at (br, bc): element (4g+s, r) -> A[br + r][bc + 4g + s]
+__device__ __forceinline__ void store_ct(float* A, int LD, int br, int bc, int r, int g, const f32x4& c) {
+    float4 v; v.x = c[0]; v.y = c[1]; v.z = c[2]; v.w = c[3];
+    *reinterpret_cast<float4*>(A + (br + r) * LD + bc + 4 * g) = v;
+}
+
+// v_readlane_b32 of a float (the builtin is declared on int: pass the BITS, not the value)
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Factor the 16x16 diagonal block at (d0,d0): returns false if a pivot is not positive.  On exit the
+// block holds L11^-1 (lower triangular, zeros above) and invd[d0..d0+15] = 1/diag(L11).
+__device__ __forceinline__ bool factor_diag_block(float* A, int LD, int d0, float* invd, int r) {
+    float D[16], Lr[16];
+    {
+        const float4* row = reinterpret_cast<const float4*>(A + (d0 + r) * LD + d0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { float4 q = row[v]; D[4 * v] = q.x; D[4 * v + 1] = q.y; D[4 * v + 2] = q.z; D[4 * v + 3] = q.w; }
+    }
+    bool ok = true;
+    float inv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float pk = readlane_f(D[k], k);                 // D[k][k] (uniform)
+        if (!(pk > 0.0f)) { ok = false; pk = 1.0f; }
+        const float d = sqrtf(pk);
+        inv[k] = 1.0f / d;
+        const float lk = D[k] * inv[k];                                // L[r][k] (valid for r >= k)
+        Lr[k] = lk;
+#pragma unroll
+        for (int j = k + 1; j < 16; ++j) D[j] = fmaf(-lk, readlane_f(lk, j), D[j]);
+    }
+    // X = L11^-1: lane c = r owns column c, x[i] = X[i][c]
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float s = (i == r) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int j = 0; j < i; ++j) s = fmaf(-readlane_f(Lr[j], i), x[j], s);   // L[i][j] from lane i
+        x[i] = s * inv[i];
+    }
+    if (threadIdx.x < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) A[(d0 + i) * LD + d0 + r] = x[i];
+    }
+    // invd: lane r needs inv[r] (static-indexed array, dynamic r) -> select chain
+    float my_inv = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) my_inv = (r == k) ? inv[k] : my_inv;
+    if (threadIdx.x < 16) invd[d0 + r] = my_inv;
+    return ok;
+}
+
+template <int NB, int FP, bool BWD>
+__global__ void __launch_bounds__(64) gp_mfma_kernel(GpMfmaArgs a) {
+    constexpr int NP = 16 * NB;              // padded problem size
+    constexpr int LD = NP + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* A = reinterpret_cast<float*>(smem_raw);        // [NP][LD]
+    float* zf = A + NP * LD;                               // [NP][FP]
+    float* rv = zf + NP * FP;                              // [NP] residual
+    float* av = rv + NP;                                   // [NP] alpha
+    float* invd = av + NP;                                 // [NP]
+
+    const int lane = threadIdx.x;
+    const int r = lane & 15, g = lane >> 4;
+    const long b = blockIdx.x;
+    const int n = a.n, f = a.f;
+    const int p = (int)(b % a.P);
+    const long ty = b / a.y_div;
+    int nv = a.n_valid ? a.n_valid[ty] : n;
+    nv = nv < n ? nv : n; nv = nv < 0 ? 0 : nv;
+
+    float ls[FP];
+#pragma unroll
+    for (int c = 0; c < FP; ++c) ls[c] = (c < f) ? a.ls[(long)p * f + c] : 1.0f;
+    const float os = a.os ? a.os[p] : 1.0f;
+    const float noise = a.noise[p];
+
+    // ---- features (pre-divided by the lengthscale) and residual, lane i = row i ----------------
+    const int i = lane;
+    float zs[FP];
+#pragma unroll
+    for (int c = 0; c < FP; ++c) zs[c] = 0.0f;
+    float ri = 0.0f;
+    if (i < nv) {
+        const float* zp = a.z + ((b / a.z_div) * n + i) * (long)f;
+#pragma unroll
+        for (int c = 0; c < FP; ++c) if (c < f) zs[c] = zp[c] / ls[c];
+        float mi = 0.0f;
+        if (a.mean_mode == PACOH_MEAN_VECTOR) mi = a.mean[b * n + i];
+        else if (a.mean_mode == PACOH_MEAN_CONST) mi = a.mean[p];
+        ri = a.y[ty * n + i] - mi;
+    }
+    if (i < NP) {
+#pragma unroll
+        for (int c = 0; c < FP; ++c) zf[i * FP + c] = zs[c];
+        rv[i] = ri;
+    }
+    __syncthreads();
+
+    // ---- Gram build + blocked Cholesky with the psd_safe_cholesky jitter ladder -----------------
+    int my_info = -1;
+    float jitter = 0.0f;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if (i < NP) {
+            const int ib = i >> 4;
+            for (int jb = 0; jb <= ib; ++jb) {                 // lower block triangle only
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float kv[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int j = jb * 16 + q * 4 + v;
+                        float s = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < FP; ++c) { const float d = zs[c] - zf[j * FP + c]; s = fmaf(d, d, s); }
+                        float k = os * rbf_exp<float>(-0.5f * s);
+                        if (!(i < nv && j < nv)) k = 0.0f;
+                        if (i == j) k = (i < nv) ? k + noise + jitter : 1.0f;
+                        kv[v] = k;
+                    }
+                    float4 o; o.x = kv[0]; o.y = kv[1]; o.z = kv[2]; o.w = kv[3];
+                    *reinterpret_cast<float4*>(A + i * LD + jb * 16 + q * 4) = o;
+                }
+            }
+        }
+        __syncthreads();
+        bool ok = true;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            const int k0 = kb * 16;
+            ok = factor_diag_block(A, LD, k0, invd, r) && ok;
+            __syncthreads();
+            // panel: L[ib][kb] = A[ib][kb] * Linv^T
+#pragma unroll
+            for (int ib = kb + 1; ib < NB; ++ib) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                mm_xyT(acc, A, LD, ib * 16, k0, k0, k0, r, g, 1.0f);
+                __syncthreads();            // all lanes have read A[ib][kb] before it is overwritten
+                store_c(A, LD, ib * 16, k0, r, g, acc);
+            }
+            __syncthreads();
+            // trailing update: A[ib][jb] -= L[ib][kb] L[jb][kb]^T
+#pragma unroll
+            for (int ib = kb + 1; ib < NB; ++ib) {
+#pragma unroll
+                for (int jb = kb + 1; jb <= ib; ++jb) {
+                    f32x4 acc = load_c(A, LD, ib * 16, jb * 16, r, g);
+                    mm_xyT(acc, A, LD, ib * 16, k0, jb * 16, k0, r, g, -1.0f);
+                    store_c(A, LD, ib * 16, jb * 16, r, g, acc);
+                }
+            }
+            __syncthreads();
+        }
+        if (ok) { my_info = attempt; break; }
+        jitter = 1e-6f;
+        for (int q = 0; q < attempt; ++q) jitter *= 10.0f;
+    }
+    const bool okf = my_info >= 0;
+    if (lane == 0 && a.info) a.info[b] = my_info;
+
+    // ---- Z = L^-1 in place: diagonal blocks already hold L11^-1 ---------------------------------
+#pragma unroll
+    for (int jb = 0; jb < NB - 1; ++jb) {
+#pragma unroll
+        for (int ib = jb + 1; ib < NB; ++ib) {
+            f32x4 S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = jb; kb < ib; ++kb) mm_xy(S, A, LD, ib * 16, kb * 16, kb * 16, jb * 16, r, g);
+            f32x4 Zb = {0.f, 0.f, 0.f, 0.f};
+            mm_xs(Zb, A, LD, ib * 16, ib * 16, S, r, g, -1.0f);
+            __syncthreads();
+            store_c(A, LD, ib * 16, jb * 16, r, g, Zb);
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // ---- u = Z r (lane i = row i), quad = |u|^2, logdet ------------------------------------------
+    float ui = 0.0f;
+    if (i < NP) {
+        const float4* zr = reinterpret_cast<const float4*>(A + i * LD);
+        const float4* rr = reinterpret_cast<const float4*>(rv);
+        const int nvec = ((i >> 4) + 1) * 4;                   // columns up to the end of the diagonal block
+        for (int v = 0; v < nvec; ++v) {
+            const float4 zq = zr[v], rq = rr[v];
+            ui = fmaf(zq.x, rq.x, ui); ui = fmaf(zq.y, rq.y, ui); ui = fmaf(zq.z, rq.z, ui); ui = fmaf(zq.w, rq.w, ui);
+        }
+    }
+    const float quad = wave_sum((i < nv) ? ui * ui : 0.0f);
+    const float logdet = wave_sum((i < nv) ? -logf(invd[i < NP ? i : 0]) : 0.0f);
+    float lml = nv > 0 ? -0.5f * (quad + 2.0f * logdet + (float)nv * 1.8378770664093453f) / (float)nv : 0.0f;
+    if (!okf) lml = NAN;
+    if (lane == 0) a.lml[b] = lml;
+    if (!BWD) return;
+
+    // ---- W = Z^T Z in place, mirrored to a full symmetric matrix --------------------------------
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) {
+        f32x4 Wb[NB];
+#pragma unroll
+        for (int jb = 0; jb <= ib; ++jb) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = ib; kb < NB; ++kb) mm_xTy(acc, A, LD, kb * 16, ib * 16, kb * 16, jb * 16, r, g);
+            Wb[jb] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int jb = 0; jb <= ib; ++jb) {
+            store_c(A, LD, ib * 16, jb * 16, r, g, Wb[jb]);
+            if (jb < ib) store_ct(A, LD, jb * 16, ib * 16, r, g, Wb[jb]);
+        }
+        __syncthreads();
+    }
+    // ---- alpha = W r ------------------------------------------------------------------------------
+    float ai = 0.0f;
+    if (i < NP) {
+        const float4* wr = reinterpret_cast<const float4*>(A + i * LD);
+        const float4* rr = reinterpret_cast<const float4*>(rv);
+#pragma unroll 4
+        for (int v = 0; v < NP / 4; ++v) {
+            const float4 wq = wr[v], rq = rr[v];
+            ai = fmaf(wq.x, rq.x, ai); ai = fmaf(wq.y, rq.y, ai); ai = fmaf(wq.z, rq.z, ai); ai = fmaf(wq.w, rq.w, ai);
+        }
+        av[i] = ai;
+    }
+    __syncthreads();
+    // ---- gradient sums: lane i owns row i of W ------------------------------------------------------
+    const float gup = a.g_lml ? a.g_lml[b] : 1.0f;
+    float dz[FP], dls[FP];
+#pragma unroll
+    for (int c = 0; c < FP; ++c) { dz[c] = 0.0f; dls[c] = 0.0f; }
+    float dos = 0.0f, dnz = 0.0f;
+    const float inv2n = nv > 0 ? 0.5f / (float)nv : 0.0f;
+    if (i < nv) {
+        const float* wrow = A + i * LD;
+        for (int j = 0; j < nv; ++j) {
+            const float Gij = (ai * av[j] - wrow[j]) * inv2n;
+            float s = 0.0f, df[FP];
+#pragma unroll
+            for (int c = 0; c < FP; ++c) { df[c] = zf[j * FP + c] - zs[c]; s = fmaf(df[c], df[c], s); }
+            const float e = rbf_exp<float>(-0.5f * s);
+            dos = fmaf(Gij, e, dos);
+            const float M = Gij * os * e;
+#pragma unroll
+            for (int c = 0; c < FP; ++c) { const float md = M * df[c]; dz[c] += md; dls[c] = fmaf(md, df[c], dls[c]); }
+            if (j == i) dnz = Gij;
+        }
+    }
+    const float bad = okf ? 0.0f : NAN;
+    if (a.d_z && i < n) {
+        for (int c = 0; c < f; ++c) a.d_z[(b * n + i) * (long)f + c] = (i < nv) ? 2.0f * gup * dz[c] / ls[c] + bad : 0.0f;
+    }
+    if (a.mean_mode == PACOH_MEAN_VECTOR) {
+        if (a.d_mean && i < n) a.d_mean[b * n + i] = (i < nv) ? gup * ai / (float)nv + bad : 0.0f;
+    } else if (a.mean_mode == PACOH_MEAN_CONST) {
+        const float sa = wave_sum((i < nv) ? ai : 0.0f);
+        if (a.d_mean && lane == 0) a.d_mean[b] = nv > 0 ? gup * sa / (float)nv + bad : 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < FP; ++c) {
+        if (c < f) {
+            const float sc = wave_sum(dls[c]);
+            if (lane == 0) a.d_ls[b * f + c] = gup * sc / ls[c] + bad;
+        }
+    }
+    const float sdos = wave_sum(dos), sdnz = wave_sum(dnz);
+    if (lane == 0) {
+        if (a.d_os) a.d_os[b] = gup * sdos + bad;
+        a.d_noise[b] = gup * sdnz + bad;
+    }
+}
+
+template <int NB, bool BWD>
+static int launch_nb(const GpMfmaArgs& a, int FP, hipStream_t s) {
+    constexpr int NP = 16 * NB, LD = NP + 4;
+    const size_t lds = (size_t)(NP * LD + NP * FP + 3 * NP) * sizeof(float);
+#define PACOH_GPM_CASE(fp) case fp: hipLaunchKernelGGL((gp_mfma_kernel<NB, fp, BWD>), dim3((unsigned)a.B), dim3(64), lds, s, a); break;
+    switch (FP) { PACOH_GPM_CASE(2) PACOH_GPM_CASE(4) PACOH_GPM_CASE(8) default: PACOH_GPM_CASE(16) }
+#undef PACOH_GPM_CASE
+    return launch_status();
+}
+
+// entry used by gp_small.hip's C-ABI functions; returns 1 if this path does not apply
+int gp_mfma_try(const GpMfmaArgs& a, bool bwd, hipStream_t s) {
+    if (a.n > 64 || a.f > PACOH_MAX_FEATURES) return 1;
+    const int NB = (a.n + 15) / 16;
+    const int FP = a.f <= 2 ? 2 : (a.f <= 4 ? 4 : (a.f <= 8 ? 8 : 16));
+    if (bwd) {
+        switch (NB) {
+            case 1: return launch_nb<1, true>(a, FP, s);
+            case 2: return launch_nb<2, true>(a, FP, s);
+            case 3: return launch_nb<3, true>(a, FP, s);
+            default: return launch_nb<4, true>(a, FP, s);
+        }
+    }
+    switch (NB) {
+        case 1: return launch_nb<1, false>(a, FP, s);
+        case 2: return launch_nb<2, false>(a, FP, s);
+        case 3: return launch_nb<3, false>(a, FP, s);
+        default: return launch_nb<4, false>(a, FP, s);
+    }
+}
+
+}  // namespace pacoh

@@ -12,6 +12,7 @@
 //   W = K^-1 = Z^T Z           W_ij = <Z_i, Z_j>   consumed immediately by the gradient sums
 // Reference arithmetic being replaced: random_gp.py:54-89, GPR_meta_mll.py:104-117 (through gpytorch).
 #include "common.h"
+#include <stdlib.h>
 
 namespace pacoh {
 
@@ -372,6 +373,34 @@ static int max_n_for(int want_grad) {
 
 using namespace pacoh;
 
+// MFMA-blocked fp32 path for n <= 64 (gp_mfma.hip); PACOH_DISABLE_MFMA=1 forces the general LDS kernel
+namespace pacoh {
+struct GpMfmaArgs {
+    const float* z; int z_div;
+    const float* mean; int mean_mode;
+    const float* y; int y_div;
+    const float* ls; const float* os; const float* noise;
+    const int32_t* n_valid;
+    const float* g_lml;
+    float* lml; int32_t* info;
+    float* d_z; float* d_mean; float* d_ls; float* d_os; float* d_noise;
+    int B, P, n, f;
+};
+int gp_mfma_try(const GpMfmaArgs& a, bool bwd, hipStream_t s);
+}
+static bool mfma_enabled() {
+    static const bool on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
+    return on;
+}
+static int try_mfma(const GpArgs<float>& a, bool bwd, hipStream_t s) {
+    if (!mfma_enabled() || a.n > 64 || a.B <= 0 || a.P <= 0 || a.f <= 0 || a.f > PACOH_MAX_FEATURES ||
+        a.z_div <= 0 || a.y_div <= 0 || !a.z || !a.y || !a.ls || !a.noise || (a.mean_mode != PACOH_MEAN_ZERO && !a.mean))
+        return 1;
+    GpMfmaArgs m = {a.z, a.z_div, a.mean, a.mean_mode, a.y, a.y_div, a.ls, a.os, a.noise, a.n_valid, a.g_lml,
+                    a.lml, a.info, a.d_z, a.d_mean, a.d_ls, a.d_os, a.d_noise, a.B, a.P, a.n, a.f};
+    return gp_mfma_try(m, bwd, s);
+}
+
 extern "C" int pacoh_gp_small_max_n(int dtype, int want_grad) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     return dtype == PACOH_F32 ? max_n_for<float>(want_grad) : max_n_for<double>(want_grad);
@@ -398,6 +427,7 @@ extern "C" int pacoh_gp_lml_fwd(const void* z, int z_div, const void* mean, int 
     if (dtype == PACOH_F32) {
         auto a = make_args<float>(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, B, P, n, f);
         a.lml = (float*)lml; a.alpha_out = (float*)alpha_out; a.L_out = (float*)L_out; a.info = info;
+        if (!alpha_out && !L_out) { int rc = try_mfma(a, false, (hipStream_t)stream); if (rc != 1) return rc; }
         return launch_gp_small<float, MODE_FWD>(a, (hipStream_t)stream);
     }
     auto a = make_args<double>(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, B, P, n, f);
@@ -417,6 +447,7 @@ extern "C" int pacoh_gp_lml_fwdbwd(const void* z, int z_div, const void* mean, i
         auto a = make_args<float>(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, B, P, n, f);
         a.g_lml = (const float*)g_lml; a.lml = (float*)lml; a.d_z = (float*)d_z; a.d_mean = (float*)d_mean;
         a.d_ls = (float*)d_lengthscale; a.d_os = (float*)d_outputscale; a.d_noise = (float*)d_noise; a.info = info;
+        { int rc = try_mfma(a, true, (hipStream_t)stream); if (rc != 1) return rc; }
         return launch_gp_small<float, MODE_FWDBWD>(a, (hipStream_t)stream);
     }
     auto a = make_args<double>(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, B, P, n, f);
