@@ -17,6 +17,19 @@ from .util import StepLR
 LOG_2PI = math.log(2 * math.pi)
 
 
+def init_vi_posterior(D, init_std=0.1):
+    """RandomGPPosterior.__init__ for cov_type='diag' (meta_learn/random_gp.py:244-247): loc ~ N(0, 0.1),
+    scale (= log std) ~ N(log 0.1, 0.1), drawn in this order from the torch CPU generator -> [2, D]"""
+    loc = torch.normal(0.0, init_std, size=(D,))
+    scale = torch.normal(math.log(0.1), init_std, size=(D,))
+    return torch.stack([loc, scale])
+
+
+def standard_normal(n, D):
+    """the eps of Normal(loc, scale).rsample((n,)) (torch.distributions: _standard_normal)"""
+    return torch.normal(torch.zeros(n, D), torch.ones(n, D))
+
+
 class GPRegressionMetaLearnedVI(_RandomGPLearner):
 
     def __init__(self, meta_train_data, num_iter_fit=10000, feature_dim=1,
@@ -36,10 +49,7 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         meta_train_data = self._setup_random_gp(meta_train_data, mean_module, covar_module, mean_nn_layers,
                                                 kernel_nn_layers, task_batch_size)
         # RandomGPPosterior init (random_gp.py:244-247), torch CPU generator, then moved to the device
-        D, init_std = self.layout.D, 0.1
-        loc = torch.normal(0.0, init_std, size=(D,))
-        scale = torch.normal(math.log(0.1), init_std, size=(D,))
-        self.posterior = torch.stack([loc, scale]).to(self.dtype).to(self.device).contiguous()   # [2, D]
+        self.posterior = init_vi_posterior(self.layout.D).to(self.dtype).to(self.device).contiguous()   # [2, D]
         self.exp_avg = torch.zeros_like(self.posterior)
         self.exp_avg_sq = torch.zeros_like(self.posterior)
         self.opt_step = 0
@@ -57,7 +67,7 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
 
     def _rsample(self, n):
         """Normal(loc, exp(scale)).rsample((n,)): eps from the torch CPU generator (reference stream)"""
-        eps = torch.normal(torch.zeros(n, self.layout.D), torch.ones(n, self.layout.D)).to(self.dtype).to(self.device)
+        eps = standard_normal(n, self.layout.D).to(self.dtype).to(self.device)
         sigma = torch.exp(self.scale)
         return (self.loc + eps * sigma).contiguous(), eps, sigma
 

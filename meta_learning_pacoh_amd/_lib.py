@@ -43,8 +43,6 @@ SIGNATURES = {
     'pacoh_svgd_phi': (_i, [_vp, _vp, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_adam_step': (_i, [_vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _l, _l, _i, _vp]),
     'pacoh_reduce_tasks': (_i, [_vp, _vp, _d, _i, _i, _i, _i, _i, _vp]),
-    'pacoh_meta_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
-    'pacoh_meta_lml_grad': (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 
 _lib = None
@@ -61,8 +59,6 @@ def load_library():
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             if not hasattr(lib, name):
-                if name.startswith('pacoh_meta_'):
-                    continue          # optional fused path (added in a later build)
                 raise RuntimeError('libpacoh_gp.so does not export %s (stale build?)' % name)
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args

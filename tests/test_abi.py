@@ -1,0 +1,88 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads without a GPU,
+exports every symbol include/pacoh_gp.h declares, and validates arguments before launching anything."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from meta_learning_pacoh_amd._build import build_library
+    build_library(verbose=False)              # no-op when the in-tree .so is up to date
+    from meta_learning_pacoh_amd import _lib
+    return _lib.load_library()
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, 'include', 'pacoh_gp.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(pacoh_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    from meta_learning_pacoh_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(lib, name), 'libpacoh_gp.so does not export %s' % name
+        assert name in _lib.SIGNATURES, 'ctypes binding lacks %s' % name
+    for name in _lib.SIGNATURES:
+        assert name in names, '%s is bound but not declared in include/pacoh_gp.h' % name
+
+
+def test_abi_version_and_host_side_queries(lib):
+    assert lib.pacoh_abi_version() == 1
+    assert lib.pacoh_gp_small_max_n(0, 0) >= 128 and lib.pacoh_gp_small_max_n(0, 1) >= 128      # fp32: cfg #4 fits
+    assert lib.pacoh_gp_small_max_n(1, 1) >= 64                                                  # fp64: cfg #3 fits
+    assert lib.pacoh_gp_small_max_n(7, 0) == -3
+    assert lib.pacoh_svgd_workspace_bytes(20, 2534, 0) == (2 * 400 + 20 + 8) * 4
+    hidden = (ctypes.c_int32 * 2)(32, 32)
+    nbytes = lib.pacoh_mlp_bwd_workspace_bytes(20480, 20, 64, 4, hidden, 2, 2, 0)
+    assert nbytes % (20 * (32 * 5 + 32 * 33 + 2 * 33) * 4) == 0 and nbytes > 0
+    assert lib.pacoh_gp_predict_workspace_bytes(4, 64, 50, 0, 1) == 4 * 50 * 64 * 4
+    assert lib.pacoh_gp_predict_workspace_bytes(4, 64, 50, 0, 0) == 0
+
+
+def test_argument_validation_returns_error_codes_without_launching(lib):
+    EINVAL, ELIMIT, EDTYPE = -1, -2, -3
+    null = None
+    assert lib.pacoh_gp_lml_fwd(null, 1, null, 0, null, 1, null, null, null, null, null, null, null, null,
+                                4, 1, 16, 2, 0, null) == EINVAL
+    assert lib.pacoh_gp_lml_fwd(null, 1, null, 0, null, 1, null, null, null, null, null, null, null, null,
+                                4, 1, 16, 2, 5, null) == EDTYPE
+    assert lib.pacoh_gram_rbf_ard(null, 1, null, 1, null, null, null, 0, null, 1, 1, 8, 8, 2, 0, null) == EINVAL
+    fake = ctypes.c_void_p(4096)              # non-NULL; limits are checked before anything is dereferenced
+    assert lib.pacoh_gram_rbf_ard(fake, 1, fake, 1, fake, null, null, 0, fake, 1, 1, 8, 8, 17, 0, null) == ELIMIT
+    assert lib.pacoh_gp_lml_fwdbwd(fake, 1, null, 0, fake, 1, fake, null, fake, null, null, fake, null, null, fake,
+                                   null, fake, null, 2, 1, 4096, 2, 0, null) == ELIMIT       # n too large for LDS
+    assert lib.pacoh_svgd_phi(fake, fake, 0.0, 0, fake, null, fake, 65, 10, 0, null) == ELIMIT
+    assert lib.pacoh_adam_step(null, null, null, null, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 10, 0, null) == EINVAL
+    hidden = (ctypes.c_int32 * 1)(128)
+    assert lib.pacoh_mlp_fwd(fake, 1, fake, 10, 1, 2, hidden, 1, 1, fake, 1, 4, 0, null) == ELIMIT   # width > 64
+
+
+def test_no_cpu_fallback():
+    """the product path must fail loudly without a HIP device"""
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import meta_learning_pacoh_amd as M
+    data = [(np.random.randn(5, 1), np.random.randn(5, 1)) for _ in range(3)]
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        M.GPRegressionMetaLearned(data, random_seed=1)
+    from meta_learning_pacoh_amd import _lib
+    with pytest.raises(RuntimeError, match='HIP device'):
+        _lib.softplus_fwd(torch.zeros(3))
+
+
+def test_product_package_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, 'meta_learning_pacoh_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert 'oracle' not in re.sub(r'#.*', '', src).replace('"""', ''), fn + ' mentions the oracle'

