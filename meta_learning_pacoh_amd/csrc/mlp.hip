@@ -8,6 +8,10 @@ int mlp_bwd_##sfx(const void*, int, const void*, long, int, int, const int32_t*,
 PACOH_MLP_DECL(f32)
 PACOH_MLP_DECL(f64)
 #undef PACOH_MLP_DECL
+// register-resident MFMA path (mlp_mfma.hip): fp32, <= 2 hidden layers of width <= 32; returns 1 if not applicable
+int mlp_mfma_fwd(const void*, int, const void*, long, int, int, const int32_t*, int, int, void*, int, int, hipStream_t);
+size_t mlp_mfma_bwd_workspace(int, int, int, int, const int32_t*, int, int);
+int mlp_mfma_bwd(const void*, int, const void*, long, int, int, const int32_t*, int, int, const void*, void*, long, int, void*, int, int, hipStream_t);
 
 // out[o] (+)= scale * sum_c in[c, o]; one wavefront per output element, lanes stride over c, fixed order
 template <typename T>
@@ -31,6 +35,11 @@ extern "C" int pacoh_mlp_fwd(const void* x, int x_div, const void* theta, long t
                              int B, int n, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!out) return PACOH_EINVAL;
+    if (dtype == PACOH_F32 && x && theta && x_div > 0 && P > 0 && B > 0 && n > 0 && B % P == 0 && d_in > 0 && d_out > 0 &&
+        n_hidden >= 1 && hidden && (long)B * n <= 0x3fffffffL) {
+        int rc = mlp_mfma_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, (hipStream_t)stream);
+        if (rc != 1) return rc;
+    }
     return dtype == PACOH_F32
         ? mlp_fwd_f32(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, (hipStream_t)stream)
         : mlp_fwd_f64(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, (hipStream_t)stream);
@@ -58,7 +67,12 @@ extern "C" size_t pacoh_mlp_bwd_workspace_bytes(int B, int P, int n, int d_in, c
     long want = (2048 + P - 1) / P;
     long chunks = tiles < want ? tiles : want;
     if (chunks < 1) chunks = 1;
-    return (size_t)chunks * P * params * (dtype == PACOH_F64 ? 8 : 4);
+    size_t need = (size_t)chunks * P * params * (dtype == PACOH_F64 ? 8 : 4);
+    if (dtype == PACOH_F32 && n_hidden >= 1) {
+        size_t m = mlp_mfma_bwd_workspace(B, P, n, d_in, hidden, n_hidden, d_out);
+        if (m > need) need = m;
+    }
+    return need;
 }
 
 extern "C" int pacoh_mlp_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P,
@@ -67,6 +81,12 @@ extern "C" int pacoh_mlp_bwd(const void* x, int x_div, const void* theta, long t
                              int B, int n, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!g_out || !d_theta || !workspace) return PACOH_EINVAL;
+    if (dtype == PACOH_F32 && x && theta && x_div > 0 && P > 0 && B > 0 && n > 0 && B % P == 0 && d_in > 0 && d_out > 0 &&
+        n_hidden >= 1 && hidden && (long)B * n <= 0x3fffffffL) {
+        int rc = mlp_mfma_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride,
+                              accumulate, workspace, B, n, (hipStream_t)stream);
+        if (rc != 1) return rc;
+    }
     return dtype == PACOH_F32
         ? mlp_bwd_f32(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, accumulate, workspace, B, n, (hipStream_t)stream)
         : mlp_bwd_f64(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, accumulate, workspace, B, n, (hipStream_t)stream);

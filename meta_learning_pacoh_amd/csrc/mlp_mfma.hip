@@ -1,0 +1,452 @@
+// MFMA per-particle MLP (fp32, hidden widths <= 32, 1-2 hidden layers, d_in <= 16, d_out <= 8):
+// forward and backward with all activations REGISTER-resident, weights in LDS.
+//
+// A wave owns a tile of 64 data points of one particle.  Activations are carried transposed,
+// H^T[feature, point], as 16x16 blocks in the v_mfma_f32_16x16x4_f32 accumulator layout
+// (lane (r = l&15, g = l>>4), reg s  <->  H^T[feature 4g+s][point r]).  With the k index of a block
+// product permuted as k = 4g+s that layout IS the B operand of the next layer's product
+//     H_l^T = tanh(W_l * H_{l-1}^T + b_l)            (A operand: one ds_read_b128 of W_l per 4 MFMAs)
+// and of the delta chain  dH_{l-1}^T = (W_l^T * dH_l^T) .* (1 - H_{l-1}^T^2), so neither the forward
+// nor the delta recursion touches LDS or HBM for activations.  Weight gradients contract over the
+// point index, which needs the plain layout H[point, feature]; a block is transposed on the matrix
+// core itself (P = S^T * I: 4 MFMAs, no memory traffic), after which
+//     dW_l += dH_l^T-blocks x H_{l-1}-blocks          (both operands straight from registers)
+// accumulates in registers across all tiles of the workgroup.  Bias gradients are per-lane partial sums
+// reduced once at the end.  Per-workgroup partial gradients go to a slab summed in fixed order.
+//
+// Replaces LinearVectorized / NeuralNetworkVectorized forward (meta_learn/models.py:295-317,343-349; the
+// torch.bmm at :313) and its autograd backward; P = 1 is NeuralNetwork.forward (models.py:211-217).
+#include "common.h"
+#include <stdlib.h>
+
+namespace pacoh {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct MlpMfmaArgs {
+    const float* x; int x_div;
+    const float* theta; long theta_stride;
+    float* out;                // fwd
+    const float* g_out;        // bwd
+    float* slab;               // bwd: [n_chunks][P][D_net]
+    int P, n, R;               // R = rows (points) per particle
+    int d_in, d_out, nh, h0, h1;
+    int tiles_per_wg;
+    int D_net;
+};
+
+__device__ __forceinline__ f32x4 mfma4x(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// LDS weight image (floats): W1p [32][16+4] | b1p [32] | W2p [32][32+4] | b2p [32] | W3p [16][32+4] | b3p[16]
+constexpr int LW1 = 20, LW2 = 36;
+constexpr int OFF_W1 = 0, OFF_B1 = OFF_W1 + 32 * LW1, OFF_W2 = OFF_B1 + 32, OFF_B2 = OFF_W2 + 32 * LW2,
+              OFF_W3 = OFF_B2 + 32, OFF_B3 = OFF_W3 + 16 * LW2, W_ELEMS = OFF_B3 + 16;
+
+// zero-padded weights of one particle -> LDS.  NH == 1: layer "2" is absent (output reads H1).
+template <int NH>
+__device__ void load_weights_mfma(float* wl, const float* __restrict__ th, const MlpMfmaArgs& a) {
+    for (int q = threadIdx.x; q < W_ELEMS; q += blockDim.x) wl[q] = 0.0f;
+    __syncthreads();
+    int src = 0;
+    // layer 1: [h0][d_in]
+    for (int q = threadIdx.x; q < a.h0; q += blockDim.x) wl[OFF_B1 + q] = th[src + q];
+    for (int q = threadIdx.x; q < a.h0 * a.d_in; q += blockDim.x) { int o = q / a.d_in, k = q - o * a.d_in; wl[OFF_W1 + o * LW1 + k] = th[src + a.h0 + q]; }
+    src += a.h0 * (a.d_in + 1);
+    int prev = a.h0;
+    if (NH == 2) {
+        for (int q = threadIdx.x; q < a.h1; q += blockDim.x) wl[OFF_B2 + q] = th[src + q];
+        for (int q = threadIdx.x; q < a.h1 * prev; q += blockDim.x) { int o = q / prev, k = q - o * prev; wl[OFF_W2 + o * LW2 + k] = th[src + a.h1 + q]; }
+        src += a.h1 * (prev + 1);
+        prev = a.h1;
+    }
+    for (int q = threadIdx.x; q < a.d_out; q += blockDim.x) wl[OFF_B3 + q] = th[src + q];
+    for (int q = threadIdx.x; q < a.d_out * prev; q += blockDim.x) { int o = q / prev, k = q - o * prev; wl[OFF_W3 + o * LW2 + k] = th[src + a.d_out + q]; }
+    __syncthreads();
+}
+
+// (task, point) of tile row row0+q given the tile base (t0, i0): one division per tile (scalar); per row
+// a conditional wrap when n >= 64 (a 64-row tile then crosses at most one task boundary)
+__device__ __forceinline__ void locate(const MlpMfmaArgs& a, int t0, int i0, int q, int& t, int& i) {
+    i = i0 + q; t = t0;
+    if (a.n >= 64) { if (i >= a.n) { i -= a.n; ++t; } }
+    else { const int w = (int)((unsigned)i / (unsigned)a.n); t += w; i -= w * a.n; }
+}
+
+// output row index (problem*n + point) of tile row row0+q, or -1 past the end
+__device__ __forceinline__ long out_row(const MlpMfmaArgs& a, int p, int row0, int t0, int i0, int q) {
+    if (row0 + q >= a.R) return -1;
+    int t, i; locate(a, t0, i0, q, t, i);
+    return (long)(t * a.P + p) * a.n + i;
+}
+
+// address of the input row of tile row row0+q for particle p (nullptr past the end)
+__device__ __forceinline__ const float* xrow(const MlpMfmaArgs& a, int p, int row0, int t0, int i0, int q) {
+    if (row0 + q >= a.R) return nullptr;
+    int t, i; locate(a, t0, i0, q, t, i);
+    const int bi = t * a.P + p;
+    const int xb = a.x_div == 1 ? bi : (int)((unsigned)bi / (unsigned)a.x_div);
+    return a.x + ((long)xb * a.n + i) * (long)a.d_in;
+}
+
+// H1^T blocks [2 feature blocks][4 point blocks] of one tile
+__device__ __forceinline__ void layer1(const float* wl, const MlpMfmaArgs& a, const float* const (&xp)[4], int r, int g, f32x4 (&H)[2][4]) {
+    const int chunks = (a.d_in + 3) >> 2;
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+        f32x4 bias;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bias[s] = wl[OFF_B1 + fb * 16 + 4 * g + s];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) H[fb][pb] = bias;
+    }
+    for (int c = 0; c < chunks; ++c) {
+        const int k = 4 * c + g;                       // natural k mapping: one MFMA per chunk
+        float bx[4];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) bx[pb] = (xp[pb] && k < a.d_in) ? xp[pb][k] : 0.0f;
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) {
+            const float aw = wl[OFF_W1 + (fb * 16 + r) * LW1 + k];
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) H[fb][pb] = mfma4x(aw, bx[pb], H[fb][pb]);
+        }
+    }
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) H[fb][pb][s] = act_tanh<float>(H[fb][pb][s]);
+}
+
+// OUT^T[OB feature blocks][4] = bias + W (rows r of block ob, LD LW2) * IN^T[2][4]
+template <int OB, bool ACT>
+__device__ __forceinline__ void layer_xs(const float* W, const float* B, int r, int g, const f32x4 (&IN)[2][4], f32x4 (&OUT)[OB][4]) {
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) {
+        f32x4 bias;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bias[s] = B[ob * 16 + 4 * g + s];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) OUT[ob][pb] = bias;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const float4 aw = *reinterpret_cast<const float4*>(W + (ob * 16 + r) * LW2 + kb * 16 + 4 * g);
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                f32x4 acc = OUT[ob][pb];
+                acc = mfma4x(aw.x, IN[kb][pb][0], acc); acc = mfma4x(aw.y, IN[kb][pb][1], acc);
+                acc = mfma4x(aw.z, IN[kb][pb][2], acc); acc = mfma4x(aw.w, IN[kb][pb][3], acc);
+                OUT[ob][pb] = acc;
+            }
+        }
+        if (ACT) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) OUT[ob][pb][s] = act_tanh<float>(OUT[ob][pb][s]);
+        }
+    }
+}
+
+// DIN^T[2][4] = W^T (W: [OB*16 rows][LD LW2]) * DOUT^T[OB][4]
+template <int OB>
+__device__ __forceinline__ void layer_xTs(const float* W, int r, int g, const f32x4 (&DOUT)[OB][4], f32x4 (&DIN)[2][4]) {
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) DIN[fb][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) {
+            const float* wp = W + (ob * 16 + 4 * g) * LW2 + fb * 16 + r;
+            const float a0 = wp[0], a1 = wp[LW2], a2 = wp[2 * LW2], a3 = wp[3 * LW2];
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                f32x4 acc = DIN[fb][pb];
+                acc = mfma4x(a0, DOUT[ob][pb][0], acc); acc = mfma4x(a1, DOUT[ob][pb][1], acc);
+                acc = mfma4x(a2, DOUT[ob][pb][2], acc); acc = mfma4x(a3, DOUT[ob][pb][3], acc);
+                DIN[fb][pb] = acc;
+            }
+        }
+    }
+}
+
+// transpose a 16x16 block on the matrix core: P = S^T * I
+__device__ __forceinline__ f32x4 tr_block(const f32x4& S, int r, int g) {
+    f32x4 P = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) P = mfma4x(S[s], (4 * g + s == r) ? 1.0f : 0.0f, P);
+    return P;
+}
+
+// acc[ob][kb] += sum over point blocks of  A_plain[pb][ob]^T-contraction  B_plain[pb][kb]
+__device__ __forceinline__ void wgrad(f32x4& acc, const f32x4& Ap, const f32x4& Bp) {
+    acc = mfma4x(Ap[0], Bp[0], acc); acc = mfma4x(Ap[1], Bp[1], acc);
+    acc = mfma4x(Ap[2], Bp[2], acc); acc = mfma4x(Ap[3], Bp[3], acc);
+}
+
+template <int NH>
+__global__ void __launch_bounds__(256) mlp_mfma_fwd_kernel(MlpMfmaArgs a) {
+    __shared__ __attribute__((aligned(16))) float wl[W_ELEMS];
+    const int p = blockIdx.y;
+    load_weights_mfma<NH>(wl, a.theta + (long)p * a.theta_stride, a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    for (int tl = 0; tl < a.tiles_per_wg; tl += 4) {
+        const int tile = blockIdx.x * a.tiles_per_wg + tl + wave;
+        const int row0 = tile * 64;
+        if (tl + wave >= a.tiles_per_wg || row0 >= a.R) continue;
+        const int t0 = (int)((unsigned)row0 / (unsigned)a.n), i0 = row0 - t0 * a.n;
+        const float* xp[4]; long orow[4];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) { xp[pb] = xrow(a, p, row0, t0, i0, pb * 16 + r); orow[pb] = out_row(a, p, row0, t0, i0, pb * 16 + r); }
+        f32x4 H1[2][4];
+        layer1(wl, a, xp, r, g, H1);
+        f32x4 O[1][4];
+        if (NH == 2) {
+            f32x4 H2[2][4];
+            layer_xs<2, true>(wl + OFF_W2, wl + OFF_B2, r, g, H1, H2);
+            layer_xs<1, false>(wl + OFF_W3, wl + OFF_B3, r, g, H2, O);
+        } else {
+            layer_xs<1, false>(wl + OFF_W3, wl + OFF_B3, r, g, H1, O);
+        }
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            if (orow[pb] >= 0) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { const int o = 4 * g + s; if (o < a.d_out) a.out[orow[pb] * a.d_out + o] = O[0][pb][s]; }
+            }
+        }
+    }
+}
+
+template <int NH>
+__global__ void __launch_bounds__(256) mlp_mfma_bwd_kernel(MlpMfmaArgs a) {
+    __shared__ __attribute__((aligned(16))) float wl[W_ELEMS];
+    __shared__ float red[4 * 64];
+    const int p = blockIdx.y;
+    load_weights_mfma<NH>(wl, a.theta + (long)p * a.theta_stride, a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+
+    f32x4 aW1[2] = {}, aW2[2][2] = {}, aW3[2] = {};       // dW1[ob][0], dW2[ob][kb], dW3[0][kb]
+    f32x4 aB1[2] = {}, aB2[2] = {}, aB3 = {};             // per-lane partial bias sums (feature 4g+s)
+
+    for (int tl = 0; tl < a.tiles_per_wg; tl += 4) {
+        const int tile = blockIdx.x * a.tiles_per_wg + tl + wave;
+        const int row0 = tile * 64;
+        if (tl + wave >= a.tiles_per_wg || row0 >= a.R) continue;
+        const int t0 = (int)((unsigned)row0 / (unsigned)a.n), i0 = row0 - t0 * a.n;
+        const float* xp[4]; long orow[4];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) { xp[pb] = xrow(a, p, row0, t0, i0, pb * 16 + r); orow[pb] = out_row(a, p, row0, t0, i0, pb * 16 + r); }
+        // ---- forward recompute ----------------------------------------------------------------
+        f32x4 H1[2][4], H2[2][4];
+        layer1(wl, a, xp, r, g, H1);
+        if (NH == 2) layer_xs<2, true>(wl + OFF_W2, wl + OFF_B2, r, g, H1, H2);
+        f32x4 (&HL)[2][4] = (NH == 2) ? H2 : H1;            // last hidden activation
+        // ---- G^T (transposed layout) and G (plain layout) straight from HBM ---------------------
+        f32x4 GT[1][4], Gp[4];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int o = 4 * g + s;
+                GT[0][pb][s] = (orow[pb] >= 0 && o < a.d_out) ? a.g_out[orow[pb] * a.d_out + o] : 0.0f;
+            }
+            aB3 += GT[0][pb];
+        }
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const long orw = out_row(a, p, row0, t0, i0, pb * 16 + 4 * g + s);
+                Gp[pb][s] = (orw >= 0 && r < a.d_out) ? a.g_out[orw * a.d_out + r] : 0.0f;
+            }
+        }
+        // ---- output layer: dW3 += G^T-contraction H_last ; dHL^T = W3^T G^T .* (1 - HL^2) ---------
+        f32x4 DL[2][4];
+        layer_xTs<1>(wl + OFF_W3, r, g, GT, DL);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                const f32x4 Hp = tr_block(HL[kb][pb], r, g);          // H_last plain [pt][feat]
+                wgrad(aW3[kb], Gp[pb], Hp);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) DL[kb][pb][s] *= (1.0f - HL[kb][pb][s] * HL[kb][pb][s]);
+            }
+        }
+        if (NH == 2) {
+            // ---- hidden layer 2: dW2 += dH2-contraction H1 ; db2 ; dH1^T = W2^T dH2^T .* (1 - H1^2) ----
+            f32x4 D1[2][4];
+            layer_xTs<2>(wl + OFF_W2, r, g, DL, D1);
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                f32x4 H1p[2], D2p[2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) { H1p[kb] = tr_block(H1[kb][pb], r, g); D2p[kb] = tr_block(DL[kb][pb], r, g); aB2[kb] += DL[kb][pb]; }
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) wgrad(aW2[ob][kb], D2p[ob], H1p[kb]);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) D1[kb][pb][s] *= (1.0f - H1[kb][pb][s] * H1[kb][pb][s]);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) DL[kb][pb] = D1[kb][pb];
+        }
+        // ---- first layer: dW1 += dH1-contraction X ; db1 ---------------------------------------------
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            f32x4 Xp;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float* xq = xrow(a, p, row0, t0, i0, pb * 16 + 4 * g + s);
+                Xp[s] = (xq && r < a.d_in) ? xq[r] : 0.0f;
+            }
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                const f32x4 Dp = tr_block(DL[ob][pb], r, g);
+                wgrad(aW1[ob], Dp, Xp);
+                aB1[ob] += DL[ob][pb];
+            }
+        }
+    }
+    // ---- bias partials: sum over the 16 point-lanes r of each lane group ------------------------------
+    auto red16 = [&](f32x4& v) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float x = v[s];
+            x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+            v[s] = x;
+        }
+    };
+    red16(aB1[0]); red16(aB1[1]); red16(aB2[0]); red16(aB2[1]); red16(aB3);
+    // ---- cross-wave sum (fixed order) and store in the reference's flattened layout ----------------------
+    float* dst = a.slab + ((long)blockIdx.x * a.P + p) * a.D_net;
+    auto xsum = [&](float v) -> float {        // sum of v over the 4 waves, returned to every wave
+        __syncthreads();
+        red[wave * 64 + lane] = v;
+        __syncthreads();
+        return (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+    };
+    const int off1 = 0;
+    const int off2 = a.h0 * (a.d_in + 1);
+    const int off3 = off2 + (NH == 2 ? a.h1 * (a.h0 + 1) : 0);
+    const int hl = NH == 2 ? a.h1 : a.h0;
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int o = ob * 16 + 4 * g + s;
+            float v = xsum(aW1[ob][s]);
+            if (wave == 0 && o < a.h0 && r < a.d_in) dst[off1 + a.h0 + o * a.d_in + r] = v;
+            v = xsum(aB1[ob][s]);
+            if (wave == 0 && o < a.h0 && r == 0) dst[off1 + o] = v;
+            if (NH == 2) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    v = xsum(aW2[ob][kb][s]);
+                    const int k = kb * 16 + r;
+                    if (wave == 0 && o < a.h1 && k < a.h0) dst[off2 + a.h1 + o * a.h0 + k] = v;
+                }
+                v = xsum(aB2[ob][s]);
+                if (wave == 0 && o < a.h1 && r == 0) dst[off2 + o] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int o = 4 * g + s;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            float v = xsum(aW3[kb][s]);
+            const int k = kb * 16 + r;
+            if (wave == 0 && o < a.d_out && k < hl) dst[off3 + a.d_out + o * hl + k] = v;
+        }
+        float v = xsum(aB3[s]);
+        if (wave == 0 && o < a.d_out && r == 0) dst[off3 + o] = v;
+    }
+}
+
+template <typename T>
+__global__ void reduce_slab_kernel(const T* __restrict__ in, T* __restrict__ out, long out_stride, int accumulate, int C, int P, int Wd) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)P * Wd) return;
+    int p = (int)(idx / Wd), w = (int)(idx - (long)p * Wd);
+    T s = 0;
+    for (int c = 0; c < C; ++c) s += in[((long)c * P + p) * Wd + w];
+    T* o = out + (long)p * out_stride + w;
+    *o = accumulate ? *o + s : s;
+}
+
+static bool mlp_mfma_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_out) {
+    static const bool on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
+    if (!on || n_hidden < 1 || n_hidden > 2 || d_in > 16 || d_out > 8) return false;
+    for (int l = 0; l < n_hidden; ++l) if (hidden[l] > 32) return false;
+    return true;
+}
+
+static void fill_args(MlpMfmaArgs& a, const void* x, int x_div, const void* theta, long theta_stride, int P,
+                      int d_in, const int32_t* hidden, int n_hidden, int d_out, int B, int n) {
+    a.x = (const float*)x; a.x_div = x_div; a.theta = (const float*)theta; a.theta_stride = theta_stride;
+    a.P = P; a.n = n; a.R = (B / P) * n; a.d_in = d_in; a.d_out = d_out; a.nh = n_hidden;
+    a.h0 = hidden[0]; a.h1 = n_hidden > 1 ? hidden[1] : 0;
+    a.D_net = a.h0 * (d_in + 1) + (n_hidden > 1 ? a.h1 * (a.h0 + 1) : 0) + d_out * ((n_hidden > 1 ? a.h1 : a.h0) + 1);
+}
+
+static int mfma_bwd_chunks(int R, int P) {
+    const int tiles = (R + 63) / 64;
+    int want = (1024 + P - 1) / P;                    // ~4 workgroups per CU in flight
+    int chunks = tiles / 4 < want ? (tiles + 3) / 4 : want;
+    return chunks < 1 ? 1 : chunks;
+}
+
+// returns 1 if the MFMA path does not apply
+int mlp_mfma_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
+                 int n_hidden, int d_out, void* out, int B, int n, hipStream_t s) {
+    if (!mlp_mfma_applicable(d_in, hidden, n_hidden, d_out)) return 1;
+    MlpMfmaArgs a = {};
+    fill_args(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, B, n);
+    a.out = (float*)out;
+    const int tiles = (a.R + 63) / 64;
+    a.tiles_per_wg = 8;
+    const int wgs = (tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    if (n_hidden == 2) hipLaunchKernelGGL(mlp_mfma_fwd_kernel<2>, dim3(wgs, P), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(mlp_mfma_fwd_kernel<1>, dim3(wgs, P), dim3(256), 0, s, a);
+    return launch_status();
+}
+
+size_t mlp_mfma_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out) {
+    if (!mlp_mfma_applicable(d_in, hidden, n_hidden, d_out)) return 0;
+    MlpMfmaArgs a = {};
+    fill_args(a, nullptr, 1, nullptr, 0, P, d_in, hidden, n_hidden, d_out, B, n);
+    return (size_t)mfma_bwd_chunks(a.R, P) * P * a.D_net * sizeof(float);
+}
+
+int mlp_mfma_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
+                 int n_hidden, int d_out, const void* g_out, void* d_theta, long d_theta_stride, int accumulate,
+                 void* workspace, int B, int n, hipStream_t s) {
+    if (!mlp_mfma_applicable(d_in, hidden, n_hidden, d_out)) return 1;
+    MlpMfmaArgs a = {};
+    fill_args(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, B, n);
+    a.g_out = (const float*)g_out; a.slab = (float*)workspace;
+    const int tiles = (a.R + 63) / 64;
+    const int chunks = mfma_bwd_chunks(a.R, P);
+    a.tiles_per_wg = (tiles + chunks - 1) / chunks;
+    if (n_hidden == 2) hipLaunchKernelGGL(mlp_mfma_bwd_kernel<2>, dim3(chunks, P), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(mlp_mfma_bwd_kernel<1>, dim3(chunks, P), dim3(256), 0, s, a);
+    long tot = (long)P * a.D_net;
+    hipLaunchKernelGGL(reduce_slab_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s,
+                       (const float*)workspace, (float*)d_theta, d_theta_stride, accumulate, chunks, P, a.D_net);
+    return launch_status();
+}
+
+}  // namespace pacoh
