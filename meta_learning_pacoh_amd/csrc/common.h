@@ -46,14 +46,13 @@ template <> __device__ __forceinline__ float rbf_exp<float>(float x) {
 template <typename T> __device__ __forceinline__ T act_tanh(T x);
 template <> __device__ __forceinline__ double act_tanh<double>(double x) { return tanh(x); }
 template <> __device__ __forceinline__ float act_tanh<float>(float x) {
+    // branch-free: both forms are evaluated and selected (a divergent branch per activation costs more)
     const float ax = fabsf(x);
-    if (ax < 0.25f) {
-        const float x2 = x * x;
-        return x * fmaf(x2, fmaf(x2, fmaf(x2, -0.05396825396825397f, 0.13333333333333333f), -0.3333333333333333f), 1.0f);
-    }
-    const float t = __expf(-2.0f * ax);
-    const float r = __fdividef(1.0f - t, 1.0f + t);
-    return copysignf(r, x);
+    const float x2 = x * x;
+    const float poly = x * fmaf(x2, fmaf(x2, fmaf(x2, -0.05396825396825397f, 0.13333333333333333f), -0.3333333333333333f), 1.0f);
+    const float t = __builtin_amdgcn_exp2f(-2.885390081777927f * ax);          // exp(-2|x|)
+    const float rr = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+    return ax < 0.25f ? poly : copysignf(rr, x);
 }
 
 // Leading dimension (in elements) of an LDS matrix whose rows are read both "own row per lane"

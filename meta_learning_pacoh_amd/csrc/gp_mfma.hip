@@ -98,7 +98,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // Factor the 16x16 diagonal block at (d0,d0): returns false if a pivot is not positive.  On exit the
 // block holds L11^-1 (lower triangular, zeros above) and invd[d0..d0+15] = 1/diag(L11).
-__device__ __forceinline__ bool factor_diag_block(float* A, int LD, int d0, float* invd, int r) {
+// Row r of the block sits in the registers of lane r (lanes 16-63 mirror lanes 0-15).  The values every
+// lane needs at step k (column k of the running matrix, later row i of L) are published through LDS and
+// read back as broadcast ds_read_b128 -- this keeps the VALU, which bounds the kernel, free of the
+// 240 v_readlane + IEEE sqrt/divide sequences of a pure register formulation.
+__device__ __forceinline__ bool factor_diag_block(float* A, int LD, int d0, float* invd, float* scr, int r) {
     float D[16], Lr[16];
     {
         const float4* row = reinterpret_cast<const float4*>(A + (d0 + r) * LD + d0);
@@ -109,29 +113,52 @@ __device__ __forceinline__ bool factor_diag_block(float* A, int LD, int d0, floa
     float inv[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        float pk = readlane_f(D[k], k);                 // D[k][k] (uniform)
-        if (!(pk > 0.0f)) { ok = false; pk = 1.0f; }
-        const float d = sqrtf(pk);
-        inv[k] = 1.0f / d;
-        const float lk = D[k] * inv[k];                                // L[r][k] (valid for r >= k)
-        Lr[k] = lk;
+        scr[(k & 1) * 16 + r] = D[k];                                  // column k: D[r][k] (double-buffered)
+        float c[16];
+        {
+            const float4* cp = reinterpret_cast<const float4*>(scr + (k & 1) * 16);
 #pragma unroll
-        for (int j = k + 1; j < 16; ++j) D[j] = fmaf(-lk, readlane_f(lk, j), D[j]);
+            for (int v = 0; v < 4; ++v) { float4 q = cp[v]; c[4 * v] = q.x; c[4 * v + 1] = q.y; c[4 * v + 2] = q.z; c[4 * v + 3] = q.w; }
+        }
+        float pk = c[k];
+        if (!(pk > 0.0f)) { ok = false; pk = 1.0f; }
+        const float rs = __builtin_amdgcn_rsqf(pk);
+        const float rs1 = rs * fmaf(-0.5f * pk * rs, rs, 1.5f);        // one Newton step: 1/sqrt(pk) to fp32 accuracy
+        inv[k] = rs1;
+        Lr[k] = D[k] * rs1;                                            // L[r][k] (valid for r >= k)
+        const float tk = D[k] * (rs1 * rs1);                           // D[r][k] / pk
+#pragma unroll
+        for (int j = k + 1; j < 16; ++j) D[j] = fmaf(-tk, c[j], D[j]); // D[r][j] -= L[r][k] L[j][k]
     }
-    // X = L11^-1: lane c = r owns column c, x[i] = X[i][c]
+    // publish L (row r by lane r) in the block's own storage, then X = L11^-1: lane c = r owns column c
+    if (threadIdx.x < 16) {
+        float4* row = reinterpret_cast<float4*>(A + (d0 + r) * LD + d0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { float4 q; q.x = Lr[4 * v]; q.y = Lr[4 * v + 1]; q.z = Lr[4 * v + 2]; q.w = Lr[4 * v + 3]; row[v] = q; }
+    }
+    __syncthreads();
     float x[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         float s = (i == r) ? 1.0f : 0.0f;
+        if (i > 0) {
+            const float4* lp = reinterpret_cast<const float4*>(A + (d0 + i) * LD + d0);      // row i of L, broadcast
 #pragma unroll
-        for (int j = 0; j < i; ++j) s = fmaf(-readlane_f(Lr[j], i), x[j], s);   // L[i][j] from lane i
+            for (int v = 0; v < (i + 3) / 4; ++v) {
+                const float4 q = lp[v];
+                if (4 * v < i) s = fmaf(-q.x, x[4 * v], s);
+                if (4 * v + 1 < i) s = fmaf(-q.y, x[4 * v + 1], s);
+                if (4 * v + 2 < i) s = fmaf(-q.z, x[4 * v + 2], s);
+                if (4 * v + 3 < i) s = fmaf(-q.w, x[4 * v + 3], s);
+            }
+        }
         x[i] = s * inv[i];
     }
+    __syncthreads();                                                   // every lane has read L before X overwrites it
     if (threadIdx.x < 16) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) A[(d0 + i) * LD + d0 + r] = x[i];
     }
-    // invd: lane r needs inv[r] (static-indexed array, dynamic r) -> select chain
     float my_inv = 0.0f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) my_inv = (r == k) ? inv[k] : my_inv;
@@ -149,6 +176,7 @@ __global__ void __launch_bounds__(64) gp_mfma_kernel(GpMfmaArgs a) {
     float* rv = zf + NP * FP;                              // [NP] residual
     float* av = rv + NP;                                   // [NP] alpha
     float* invd = av + NP;                                 // [NP]
+    float* scr = invd + NP;                                // [64] broadcast scratch of the diagonal-block factorisation
 
     const int lane = threadIdx.x;
     const int r = lane & 15, g = lane >> 4;
@@ -218,7 +246,7 @@ __global__ void __launch_bounds__(64) gp_mfma_kernel(GpMfmaArgs a) {
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
             const int k0 = kb * 16;
-            ok = factor_diag_block(A, LD, k0, invd, r) && ok;
+            ok = factor_diag_block(A, LD, k0, invd, scr, r) && ok;
             __syncthreads();
             // panel: L[ib][kb] = A[ib][kb] * Linv^T
 #pragma unroll
@@ -363,7 +391,7 @@ __global__ void __launch_bounds__(64) gp_mfma_kernel(GpMfmaArgs a) {
 template <int NB, bool BWD>
 static int launch_nb(const GpMfmaArgs& a, int FP, hipStream_t s) {
     constexpr int NP = 16 * NB, LD = NP + 4;
-    const size_t lds = (size_t)(NP * LD + NP * FP + 3 * NP) * sizeof(float);
+    const size_t lds = (size_t)(NP * LD + NP * FP + 3 * NP + 64) * sizeof(float);
 #define PACOH_GPM_CASE(fp) case fp: hipLaunchKernelGGL((gp_mfma_kernel<NB, fp, BWD>), dim3((unsigned)a.B), dim3(64), lds, s, a); break;
     switch (FP) { PACOH_GPM_CASE(2) PACOH_GPM_CASE(4) PACOH_GPM_CASE(8) default: PACOH_GPM_CASE(16) }
 #undef PACOH_GPM_CASE

@@ -376,6 +376,177 @@ __global__ void __launch_bounds__(256) mlp_mfma_bwd_kernel(MlpMfmaArgs a) {
     }
 }
 
+// ---- backward specialised for narrow input/output (d_in <= 4, d_out <= 2: the reference's mean /
+// feature networks).  fp32 MFMA runs at the fp32 VALU rate on gfx950, so padding a 2-row output layer or
+// a 4-column input layer to 16x16 blocks wastes matrix-core time; here only the hidden 32x32 layer uses
+// MFMA (forward, delta and weight-gradient products + the two block transposes the latter needs) while
+// the first/output layers' deltas and weight gradients are per-lane VALU partial sums (reduced over the
+// 16 point-lanes once per wave at the end).  Every wave writes its own partial slab (no barriers).
+template <int NH>
+__global__ void __launch_bounds__(256) mlp_mfma_bwd_small_kernel(MlpMfmaArgs a) {
+    __shared__ __attribute__((aligned(16))) float wl[W_ELEMS];
+    const int p = blockIdx.y;
+    load_weights_mfma<NH>(wl, a.theta + (long)p * a.theta_stride, a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int d_in = a.d_in, d_out = a.d_out;
+
+    float w3r[2][2][4];                                   // W3[o][feature fb*16+4g+s] (rows >= d_out are zero)
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) w3r[o][fb][s] = wl[OFF_W3 + o * LW2 + fb * 16 + 4 * g + s];
+    float idn[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) idn[s] = (4 * g + s == r) ? 1.0f : 0.0f;
+
+    f32x4 aW2[2][2] = {}, aB1[2] = {}, aB2[2] = {};
+    float pW1[2][4][4] = {}, pW3[2][2][4] = {}, pB3[2] = {0.f, 0.f};
+
+    for (int tl = wave; tl < a.tiles_per_wg; tl += 4) {
+        const int row0 = (blockIdx.x * a.tiles_per_wg + tl) * 64;
+        if (row0 >= a.R) break;
+        const int t0 = (int)((unsigned)row0 / (unsigned)a.n), i0 = row0 - t0 * a.n;
+        // ---- branch-free loads: clamp the row, mask afterwards -----------------------------------
+        float xr[4][4], gr[4][2];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            const int q = pb * 16 + r;
+            const bool valid = row0 + q < a.R;
+            int t, i; locate(a, t0, i0, valid ? q : 0, t, i);
+            const int bi = t * a.P + p;
+            const int xb = a.x_div == 1 ? bi : (int)((unsigned)bi / (unsigned)a.x_div);
+            const float* xq = a.x + ((long)xb * a.n + i) * (long)d_in;
+            const float* gq = a.g_out + ((long)bi * a.n + i) * (long)d_out;
+            const float m = valid ? 1.0f : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float v = xq[k < d_in ? k : d_in - 1]; xr[pb][k] = (k < d_in) ? v * m : 0.0f; }
+#pragma unroll
+            for (int o = 0; o < 2; ++o) { const float v = gq[o < d_out ? o : d_out - 1]; gr[pb][o] = (o < d_out) ? v * m : 0.0f; }
+        }
+        // ---- forward recompute -------------------------------------------------------------------
+        f32x4 H1[2][4], H2[2][4];
+        {
+            float bx[4];
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) bx[pb] = g == 0 ? xr[pb][0] : (g == 1 ? xr[pb][1] : (g == 2 ? xr[pb][2] : xr[pb][3]));
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+                f32x4 bias;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bias[s] = wl[OFF_B1 + fb * 16 + 4 * g + s];
+                const float aw = wl[OFF_W1 + (fb * 16 + r) * LW1 + g];
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) {
+                    f32x4 acc = mfma4x(aw, bx[pb], bias);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[s] = act_tanh<float>(acc[s]);
+                    H1[fb][pb] = acc;
+                }
+            }
+        }
+        if (NH == 2) layer_xs<2, true>(wl + OFF_W2, wl + OFF_B2, r, g, H1, H2);
+        f32x4 (&HL)[2][4] = (NH == 2) ? H2 : H1;
+        // ---- output layer on the VALU: dW3/db3 partials, dHL^T in place -------------------------------
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            pB3[0] += gr[pb][0]; pB3[1] += gr[pb][1];
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float h = HL[fb][pb][s];
+                    pW3[0][fb][s] = fmaf(gr[pb][0], h, pW3[0][fb][s]);
+                    pW3[1][fb][s] = fmaf(gr[pb][1], h, pW3[1][fb][s]);
+                    const float d = fmaf(w3r[1][fb][s], gr[pb][1], w3r[0][fb][s] * gr[pb][0]);
+                    HL[fb][pb][s] = d * (1.0f - h * h);
+                }
+        }
+        if (NH == 2) {
+            // ---- hidden layer: dW2 += dH2-contraction H1 (MFMA, operands transposed on the matrix core) ----
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                f32x4 H1p[2], D2p[2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    f32x4 P1 = {0.f, 0.f, 0.f, 0.f}, P2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) { P1 = mfma4x(H1[kb][pb][s], idn[s], P1); P2 = mfma4x(H2[kb][pb][s], idn[s], P2); }
+                    H1p[kb] = P1; D2p[kb] = P2;
+                    aB2[kb] += H2[kb][pb];
+                }
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) wgrad(aW2[ob][kb], D2p[ob], H1p[kb]);
+            }
+            // ---- dH1^T = (W2^T dH2^T) .* (1 - H1^2), written over H1 --------------------------------------
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+                f32x4 acc[4];
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) acc[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob) {
+                    const float* wp = wl + OFF_W2 + (ob * 16 + 4 * g) * LW2 + fb * 16 + r;
+                    const float a0 = wp[0], a1 = wp[LW2], a2 = wp[2 * LW2], a3 = wp[3 * LW2];
+#pragma unroll
+                    for (int pb = 0; pb < 4; ++pb) {
+                        acc[pb] = mfma4x(a0, H2[ob][pb][0], acc[pb]); acc[pb] = mfma4x(a1, H2[ob][pb][1], acc[pb]);
+                        acc[pb] = mfma4x(a2, H2[ob][pb][2], acc[pb]); acc[pb] = mfma4x(a3, H2[ob][pb][3], acc[pb]);
+                    }
+                }
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) { const float h = H1[fb][pb][s]; H1[fb][pb][s] = acc[pb][s] * (1.0f - h * h); }
+            }
+        }
+        // ---- first layer on the VALU: H1 now holds dH1^T ---------------------------------------------------
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                aB1[fb] += H1[fb][pb];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pW1[fb][s][k] = fmaf(H1[fb][pb][s], xr[pb][k], pW1[fb][s][k]);
+            }
+    }
+    // ---- per-lane partials: sum over the 16 point lanes of each lane group ---------------------------------
+    auto r16 = [](float x) {
+        x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+        return x;
+    };
+    float* dst = a.slab + ((long)(blockIdx.x * 4 + wave) * a.P + p) * a.D_net;
+    const int off2 = a.h0 * (d_in + 1);
+    const int off3 = off2 + (NH == 2 ? a.h1 * (a.h0 + 1) : 0);
+    const int hl = NH == 2 ? a.h1 : a.h0;
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int o = fb * 16 + 4 * g + s;
+            const float b1 = r16(aB1[fb][s]);
+            if (r == 0 && o < a.h0) dst[o] = b1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float v = r16(pW1[fb][s][k]); if (r == 0 && o < a.h0 && k < d_in) dst[a.h0 + o * d_in + k] = v; }
+            if (NH == 2) {
+                const float b2 = r16(aB2[fb][s]);
+                if (r == 0 && o < a.h1) dst[off2 + o] = b2;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) { const int k = kb * 16 + r; if (o < a.h1 && k < a.h0) dst[off2 + a.h1 + o * a.h0 + k] = aW2[fb][kb][s]; }
+            }
+#pragma unroll
+            for (int oo = 0; oo < 2; ++oo) { const float v = r16(pW3[oo][fb][s]); if (r == 0 && oo < d_out && o < hl) dst[off3 + d_out + oo * hl + o] = v; }
+        }
+#pragma unroll
+    for (int oo = 0; oo < 2; ++oo) { const float v = r16(pB3[oo]); if (lane == 0 && oo < d_out) dst[off3 + oo] = v; }
+}
+
 template <typename T>
 __global__ void reduce_slab_kernel(const T* __restrict__ in, T* __restrict__ out, long out_stride, int accumulate, int C, int P, int Wd) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -428,7 +599,7 @@ size_t mlp_mfma_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hidd
     if (!mlp_mfma_applicable(d_in, hidden, n_hidden, d_out)) return 0;
     MlpMfmaArgs a = {};
     fill_args(a, nullptr, 1, nullptr, 0, P, d_in, hidden, n_hidden, d_out, B, n);
-    return (size_t)mfma_bwd_chunks(a.R, P) * P * a.D_net * sizeof(float);
+    return (size_t)mfma_bwd_chunks(a.R, P) * 4 * P * a.D_net * sizeof(float);     // x4: per-wave slabs of the narrow-io kernel
 }
 
 int mlp_mfma_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
@@ -441,11 +612,16 @@ int mlp_mfma_bwd(const void* x, int x_div, const void* theta, long theta_stride,
     const int tiles = (a.R + 63) / 64;
     const int chunks = mfma_bwd_chunks(a.R, P);
     a.tiles_per_wg = (tiles + chunks - 1) / chunks;
-    if (n_hidden == 2) hipLaunchKernelGGL(mlp_mfma_bwd_kernel<2>, dim3(chunks, P), dim3(256), 0, s, a);
+    int slabs = chunks;
+    if (d_in <= 4 && d_out <= 2) {              // narrow io: VALU first/output layers, one slab per WAVE
+        slabs = chunks * 4;
+        if (n_hidden == 2) hipLaunchKernelGGL(mlp_mfma_bwd_small_kernel<2>, dim3(chunks, P), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(mlp_mfma_bwd_small_kernel<1>, dim3(chunks, P), dim3(256), 0, s, a);
+    } else if (n_hidden == 2) hipLaunchKernelGGL(mlp_mfma_bwd_kernel<2>, dim3(chunks, P), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(mlp_mfma_bwd_kernel<1>, dim3(chunks, P), dim3(256), 0, s, a);
     long tot = (long)P * a.D_net;
     hipLaunchKernelGGL(reduce_slab_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s,
-                       (const float*)workspace, (float*)d_theta, d_theta_stride, accumulate, chunks, P, a.D_net);
+                       (const float*)workspace, (float*)d_theta, d_theta_stride, accumulate, slabs, P, a.D_net);
     return launch_status();
 }
 
