@@ -154,6 +154,19 @@ int pacoh_softplus_fwd(const void* raw, void* out, double floor, long count, int
 int pacoh_softplus_bwd(const void* raw, const void* g, void* d_raw, int accumulate, long count,
                        int dtype, void* stream);
 
+/* All hyper-parameter transforms of one step in one launch: for every particle p read the raw values inside
+ * theta[P, theta_stride] at element offsets off_ls (f values), off_os (-1: no outputscale), off_noise and write
+ * ls[P,f] = softplus, os[P] = softplus, noise[P] = softplus + noise_floor.  Same reference lines as softplus. */
+int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise,
+                    double noise_floor, void* ls, void* os, void* noise, int dtype, void* stream);
+
+/* ... and their backward: grad[p, off] = sigmoid(raw) * sum_t d_x[t, p, .] for lengthscale / outputscale / noise
+ * (d_ls[T,P,f], d_os[T,P] or NULL, d_noise[T,P]: the per-problem outputs of pacoh_gp_lml_fwdbwd) and the plain sum
+ * for a constant mean (d_const[T,P] at off_const, or NULL / -1).  Deterministic (fixed summation order). */
+int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int T, int off_ls, int f, int off_os, int off_noise,
+                    int off_const, const void* d_ls, const void* d_os, const void* d_noise, const void* d_const,
+                    void* grad, long grad_stride, int dtype, void* stream);
+
 /* logp[p] = sum_d log N(theta[p,d]; prior_mean[d], prior_std[d]);  grad[p,d] (optional, += scaled):
  * grad += grad_scale * d logp / d theta.  Replaces CatDist.log_prob over the Normal blocks
  * (random_gp.py:128-157,179-180; models.py:159-181) and its autograd backward. */

@@ -38,6 +38,8 @@ SIGNATURES = {
     'pacoh_mlp_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _l, _i, _vp, _i, _i, _i, _vp]),
     'pacoh_softplus_fwd': (_i, [_vp, _vp, _d, _l, _i, _vp]),
     'pacoh_softplus_bwd': (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),
+    'pacoh_hyper_fwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
+    'pacoh_hyper_bwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp]),
     'pacoh_prior_logprob_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
     'pacoh_svgd_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_phi': (_i, [_vp, _vp, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -271,6 +273,27 @@ def softplus_bwd(raw, g, d_raw=None, accumulate=False):
         _check(lib.pacoh_softplus_bwd(_ptr(raw), _ptr(g, raw), ctypes.c_void_p(d_raw.data_ptr()), int(bool(accumulate)),
                                       raw.numel(), dtype_code(raw), _stream()), 'pacoh_softplus_bwd')
     return d_raw
+
+
+def hyper_fwd(theta, off_ls, f, off_os, off_noise, noise_floor):
+    lib = load_library()
+    P, D = theta.shape
+    ls = torch.empty(P, f, dtype=theta.dtype, device=theta.device)
+    os_ = torch.empty(P, dtype=theta.dtype, device=theta.device) if off_os >= 0 else None
+    noise = torch.empty(P, dtype=theta.dtype, device=theta.device)
+    with _Timed('hyper_fwd'):
+        _check(lib.pacoh_hyper_fwd(_ptr(theta), D, P, off_ls, f, off_os, off_noise, float(noise_floor), _ptr(ls), _ptr(os_),
+                                   _ptr(noise), dtype_code(theta), _stream()), 'pacoh_hyper_fwd')
+    return ls, os_, noise
+
+
+def hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, grad):
+    lib = load_library()
+    P, D = theta.shape
+    with _Timed('hyper_bwd'):
+        _check(lib.pacoh_hyper_bwd(_ptr(theta), D, P, T, off_ls, f, off_os, off_noise, off_const, _ptr(d_ls, theta),
+                                   _ptr(d_os, theta), _ptr(d_noise, theta), _ptr(d_const, theta), _ptr(grad, theta),
+                                   grad.shape[1], dtype_code(theta), _stream()), 'pacoh_hyper_bwd')
 
 
 def prior_logprob_grad(theta, prior_mean, prior_std, grad=None, grad_scale=1.0):

@@ -26,6 +26,49 @@ __global__ void softplus_bwd_kernel(const T* __restrict__ raw, const T* __restri
     d_raw[q] = accumulate ? d_raw[q] + v : v;
 }
 
+// ---- all GP hyper-parameter transforms of one step in one launch (A3) -------------------------------
+template <typename T> __device__ __forceinline__ T softplus_t(T x) { return x > T(20) ? x : t_log1p<T>(t_exp<T>(x)); }
+template <typename T> __device__ __forceinline__ T sigmoid_t(T x) { return x > T(20) ? T(1) : T(1) / (T(1) + t_exp<T>(-x)); }
+
+template <typename T>
+__global__ void hyper_fwd_kernel(const T* __restrict__ theta, long stride, int P, int off_ls, int f, int off_os, int off_noise,
+                                 T noise_floor, T* __restrict__ ls, T* __restrict__ os, T* __restrict__ noise) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = f + 2;
+    if (q >= P * per) return;
+    const int p = q / per, e = q - p * per;
+    const T* th = theta + (long)p * stride;
+    if (e < f) ls[p * f + e] = softplus_t<T>(th[off_ls + e]);
+    else if (e == f) { if (os && off_os >= 0) os[p] = softplus_t<T>(th[off_os]); }
+    else noise[p] = softplus_t<T>(th[off_noise]) + noise_floor;
+}
+
+// grad[p, off_*] = sigmoid(raw) * sum_t d_*[t, p, .]   (softplus chain rule), constant mean: plain sum; one wave per entry
+template <typename T>
+__global__ void __launch_bounds__(256) hyper_bwd_kernel(const T* __restrict__ theta, long stride, int P, int Tt, int off_ls, int f,
+                                                        int off_os, int off_noise, int off_const, const T* __restrict__ d_ls,
+                                                        const T* __restrict__ d_os, const T* __restrict__ d_noise,
+                                                        const T* __restrict__ d_const, T* __restrict__ grad, long gstride) {
+    const int per = f + 3;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= P * per) return;
+    const int lane = threadIdx.x & 63;
+    const int p = w / per, e = w - p * per;
+    const T* src; int width, col, off;
+    if (e < f) { src = d_ls; width = f; col = e; off = off_ls + e; }
+    else if (e == f) { src = d_os; width = 1; col = 0; off = off_os; }
+    else if (e == f + 1) { src = d_noise; width = 1; col = 0; off = off_noise; }
+    else { src = d_const; width = 1; col = 0; off = off_const; }
+    if (!src || off < 0) return;
+    T s = 0;
+    for (int t = lane; t < Tt; t += 64) s += src[((long)t * P + p) * width + col];
+    s = subwave_sum<T>(s, 64);
+    if (lane == 0) {
+        const T chain = (e == f + 2) ? T(1) : sigmoid_t<T>(theta[(long)p * stride + off]);
+        grad[(long)p * gstride + off] = s * chain;
+    }
+}
+
 // ---- hyper-prior: independent Normals over all D entries ----------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) prior_kernel(const T* __restrict__ theta, const T* __restrict__ mu,
@@ -114,35 +157,21 @@ __global__ void __launch_bounds__(256) svgd_kmat_kernel(const T* __restrict__ d2
     }
 }
 
-// stage 3: phi[i,d] = (sum_j K_ij (s_jd - 2 gamma x_jd) + 2 gamma x_id rowsum_i) / P, one thread per d
+// stage 3: phi[i,d] = (sum_j K_ij (s_jd - 2 gamma x_jd) + 2 gamma x_id rowsum_i) / P; one thread per (i, d)
 template <typename T>
 __global__ void __launch_bounds__(256) svgd_phi_kernel(const T* __restrict__ X, const T* __restrict__ score,
                                                        const T* __restrict__ Kmat, const T* __restrict__ rowsum,
                                                        const T* __restrict__ gamma_p, int neg, T* __restrict__ phi,
                                                        int P, int D) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Ks = reinterpret_cast<T*>(smem_raw);         // [P*P] + rowsum[P]
-    for (int q = threadIdx.x; q < P * P; q += 256) Ks[q] = Kmat[q];
-    for (int q = threadIdx.x; q < P; q += 256) Ks[P * P + q] = rowsum[q];
-    __syncthreads();
+    const int i = blockIdx.y;
     const int d = blockIdx.x * 256 + threadIdx.x;
     if (d >= D) return;
     const T gam2 = T(2) * gamma_p[0];
-    T v[64], xs[64];
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        if (j < P) { T x = X[(long)j * D + d]; xs[j] = x; v[j] = score[(long)j * D + d] - gam2 * x; }
-        else { xs[j] = 0; v[j] = 0; }
-    }
-    const T invP = T(1) / T(P);
-    for (int i = 0; i < P; ++i) {
-        T acc = 0;
-#pragma unroll
-        for (int j = 0; j < 64; ++j) if (j < P) acc = fma(Ks[i * P + j], v[j], acc);
-        T xi = X[(long)i * D + d];
-        T r = (acc + gam2 * xi * Ks[P * P + i]) * invP;
-        phi[(long)i * D + d] = neg ? -r : r;
-    }
+    const T* Ki = Kmat + (long)i * P;                // wave-uniform -> scalar loads
+    T acc = 0;
+    for (int j = 0; j < P; ++j) acc = fma(Ki[j], score[(long)j * D + d] - gam2 * X[(long)j * D + d], acc);
+    const T r = (acc + gam2 * X[(long)i * D + d] * rowsum[i]) / T(P);
+    phi[(long)i * D + d] = neg ? -r : r;
 }
 
 // ---- Adam / AdamW, op order of torch.optim._single_tensor_adam -----------------------------------
@@ -166,6 +195,37 @@ __global__ void adam_kernel(T* __restrict__ param, const T* __restrict__ grad, T
 using namespace pacoh;
 
 extern "C" int pacoh_abi_version(void) { return 1; }
+
+extern "C" int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise,
+                               double noise_floor, void* ls, void* os, void* noise, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!theta || !ls || !noise || P <= 0 || f <= 0 || off_ls < 0 || off_noise < 0) return PACOH_EINVAL;
+    unsigned blocks = (unsigned)((P * (f + 2) + 255) / 256);
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(hyper_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)theta, theta_stride,
+                           P, off_ls, f, off_os, off_noise, (float)noise_floor, (float*)ls, (float*)os, (float*)noise);
+    else
+        hipLaunchKernelGGL(hyper_fwd_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)theta, theta_stride,
+                           P, off_ls, f, off_os, off_noise, noise_floor, (double*)ls, (double*)os, (double*)noise);
+    return launch_status();
+}
+
+extern "C" int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int T_, int off_ls, int f, int off_os, int off_noise,
+                               int off_const, const void* d_ls, const void* d_os, const void* d_noise, const void* d_const,
+                               void* grad, long grad_stride, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!theta || !grad || !d_ls || !d_noise || P <= 0 || T_ <= 0 || f <= 0) return PACOH_EINVAL;
+    unsigned blocks = (unsigned)((P * (f + 3) + 3) / 4);
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(hyper_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)theta, theta_stride, P, T_,
+                           off_ls, f, off_os, off_noise, off_const, (const float*)d_ls, (const float*)d_os, (const float*)d_noise,
+                           (const float*)d_const, (float*)grad, grad_stride);
+    else
+        hipLaunchKernelGGL(hyper_bwd_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)theta, theta_stride, P, T_,
+                           off_ls, f, off_os, off_noise, off_const, (const double*)d_ls, (const double*)d_os, (const double*)d_noise,
+                           (const double*)d_const, (double*)grad, grad_stride);
+    return launch_status();
+}
 
 extern "C" int pacoh_softplus_fwd(const void* raw, void* out, double floor_, long count, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
@@ -220,7 +280,7 @@ static int svgd_launch(const void* X, const void* score, double bandwidth, int n
     while (N2 < P * P) N2 <<= 1;
     hipLaunchKernelGGL(svgd_kmat_kernel<T>, dim3(1), dim3(256), (size_t)N2 * sizeof(T), s, (const T*)d2, (T)bandwidth, Kmat,
                        rowsum, gamma, (T*)bw_out, P);
-    hipLaunchKernelGGL(svgd_phi_kernel<T>, dim3((D + 255) / 256), dim3(256), (size_t)(P * P + P) * sizeof(T), s,
+    hipLaunchKernelGGL(svgd_phi_kernel<T>, dim3((D + 255) / 256, P), dim3(256), 0, s,
                        (const T*)X, (const T*)score, (const T*)Kmat, (const T*)rowsum, (const T*)gamma, neg, (T*)phi, P, D);
     return launch_status();
 }

@@ -117,17 +117,15 @@ class GPEngine:
         self._ws = {}
 
     # -- pieces -----------------------------------------------------------------------------------
-    def _hypers(self, theta):
+    def _hyper_offsets(self):
         lay = self.layout
-        lo, hi = lay.slices['lengthscale_raw']
-        ls = L.softplus_fwd(theta[:, lo:hi].contiguous())
-        os_ = None
-        if lay.with_outputscale:
-            a, b = lay.slices['outputscale_raw']
-            os_ = L.softplus_fwd(theta[:, a:b].contiguous()).reshape(-1)
-        a, b = lay.slices['noise_raw']
-        noise = L.softplus_fwd(theta[:, a:b].contiguous(), self.noise_floor).reshape(-1)
-        return ls, os_, noise
+        off_os = lay.slices['outputscale_raw'][0] if lay.with_outputscale else -1
+        off_c = lay.slices['constant_mean'][0] if lay.mean_module == 'constant' else -1
+        return lay.slices['lengthscale_raw'][0], lay.feature_dim, off_os, lay.slices['noise_raw'][0], off_c
+
+    def _hypers(self, theta):
+        off_ls, f, off_os, off_noise, _ = self._hyper_offsets()
+        return L.hyper_fwd(theta, off_ls, f, off_os, off_noise, self.noise_floor)
 
     def _features(self, theta, x, T, n):
         """kernel inputs z (+ divisor) and mean (+ mode) for B = T*P problems"""
@@ -171,11 +169,14 @@ class GPEngine:
         dev, dt = theta.device, theta.dtype
         ls, os_, noise = self._hypers(theta)
         z, z_div, mean, mode = self._features(theta, batch.x, T, n)
-        g = torch.full((B,), float(weight), dtype=dt, device=dev)
+        gkey = (B, float(weight), dt, dev)
+        g = self._ws.get(gkey)
+        if g is None:
+            g = self._ws[gkey] = torch.full((B,), float(weight), dtype=dt, device=dev)
         lml, d_z, d_mean, d_ls, d_os, d_noise, info = L.gp_lml_fwdbwd(
             z, z_div, mean, mode, batch.y, P, ls, os_, noise, B, P,
             n_valid=batch.n_valid if batch.ragged else None, g_lml=g, want_dz=(lay.covar_module == 'NN'))
-        grad = torch.zeros(P, D, dtype=dt, device=dev)
+        grad = torch.empty(P, D, dtype=dt, device=dev)          # every block is written below
         if lay.covar_module == 'NN':
             lo, _ = lay.block_range('kernel_nn.')
             self._ws['k'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers),
@@ -184,26 +185,10 @@ class GPEngine:
             lo, _ = lay.block_range('mean_nn.')
             self._ws['m'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.mean_nn_layers), 1,
                                       d_mean.reshape(B, n, 1), grad[:, lo:], D, False, B, n, self._ws.get('m'))
-        elif lay.mean_module == 'constant':
-            lo, hi = lay.slices['constant_mean']
-            tmp = torch.empty(P, 1, dtype=dt, device=dev)
-            L.reduce_tasks(d_mean.reshape(T, P, 1), tmp)
-            grad[:, lo:hi] = tmp
-        # hyper-parameters: sum over tasks, then chain through softplus
-        f = lay.feature_dim
-        lo, hi = lay.slices['lengthscale_raw']
-        gl = torch.empty(P, f, dtype=dt, device=dev)
-        L.reduce_tasks(d_ls.reshape(T, P, f), gl)
-        grad[:, lo:hi] = L.softplus_bwd(theta[:, lo:hi].contiguous(), gl)
-        if lay.with_outputscale:
-            a, b = lay.slices['outputscale_raw']
-            go = torch.empty(P, 1, dtype=dt, device=dev)
-            L.reduce_tasks(d_os.reshape(T, P, 1), go)
-            grad[:, a:b] = L.softplus_bwd(theta[:, a:b].contiguous(), go)
-        a, b = lay.slices['noise_raw']
-        gn = torch.empty(P, 1, dtype=dt, device=dev)
-        L.reduce_tasks(d_noise.reshape(T, P, 1), gn)
-        grad[:, a:b] = L.softplus_bwd(theta[:, a:b].contiguous(), gn)
+        # hyper-parameters (+ constant mean): sum over tasks and softplus chain rule in one launch
+        off_ls, f, off_os, off_noise, off_c = self._hyper_offsets()
+        L.hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_c, d_ls, d_os, d_noise,
+                    d_mean if lay.mean_module == 'constant' else None, grad)
         return lml.reshape(T, P), grad, info
 
     def predict(self, theta, ctx_x, ctx_y, tst_x, want_cov=False):
