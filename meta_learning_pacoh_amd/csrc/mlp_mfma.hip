@@ -383,8 +383,19 @@ __global__ void __launch_bounds__(256) mlp_mfma_bwd_kernel(MlpMfmaArgs a) {
 // the first/output layers' deltas and weight gradients are per-lane VALU partial sums (reduced over the
 // 16 point-lanes once per wave at the end).  Every wave writes its own partial slab (no barriers).
 template <int NH>
-__global__ void __launch_bounds__(256) mlp_mfma_bwd_small_kernel(MlpMfmaArgs a) {
+__global__ void __launch_bounds__(256, 2) mlp_mfma_bwd_small_kernel(MlpMfmaArgs a) {
     __shared__ __attribute__((aligned(16))) float wl[W_ELEMS];
+    // per-lane partial sums of the narrow layers' gradients live in lane-private LDS slots ([slot][256 lanes],
+    // conflict-free, deterministic) instead of ~66 registers: that is what lets two waves share a SIMD
+    __shared__ float pacc[66 * 256];
+    float* my = pacc + threadIdx.x;
+#define PW1(fb, s, k) my[(((fb) * 4 + (s)) * 4 + (k)) * 256]
+#define PW3(o, fb, s) my[(32 + ((o) * 2 + (fb)) * 4 + (s)) * 256]
+#define PB1(fb, s) my[(48 + (fb) * 4 + (s)) * 256]
+#define PB2(fb, s) my[(56 + (fb) * 4 + (s)) * 256]
+#define PB3(o) my[(64 + (o)) * 256]
+#pragma unroll
+    for (int q = 0; q < 66; ++q) my[q * 256] = 0.0f;
     const int p = blockIdx.y;
     load_weights_mfma<NH>(wl, a.theta + (long)p * a.theta_stride, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -402,8 +413,7 @@ __global__ void __launch_bounds__(256) mlp_mfma_bwd_small_kernel(MlpMfmaArgs a) 
 #pragma unroll
     for (int s = 0; s < 4; ++s) idn[s] = (4 * g + s == r) ? 1.0f : 0.0f;
 
-    f32x4 aW2[2][2] = {}, aB1[2] = {}, aB2[2] = {};
-    float pW1[2][4][4] = {}, pW3[2][2][4] = {}, pB3[2] = {0.f, 0.f};
+    f32x4 aW2[2][2] = {};
 
     for (int tl = wave; tl < a.tiles_per_wg; tl += 4) {
         const int row0 = (blockIdx.x * a.tiles_per_wg + tl) * 64;
@@ -452,14 +462,14 @@ __global__ void __launch_bounds__(256) mlp_mfma_bwd_small_kernel(MlpMfmaArgs a) 
         // ---- output layer on the VALU: dW3/db3 partials, dHL^T in place -------------------------------
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb) {
-            pB3[0] += gr[pb][0]; pB3[1] += gr[pb][1];
+            PB3(0) += gr[pb][0]; PB3(1) += gr[pb][1];
 #pragma unroll
             for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const float h = HL[fb][pb][s];
-                    pW3[0][fb][s] = fmaf(gr[pb][0], h, pW3[0][fb][s]);
-                    pW3[1][fb][s] = fmaf(gr[pb][1], h, pW3[1][fb][s]);
+                    PW3(0, fb, s) += gr[pb][0] * h;
+                    PW3(1, fb, s) += gr[pb][1] * h;
                     const float d = fmaf(w3r[1][fb][s], gr[pb][1], w3r[0][fb][s] * gr[pb][0]);
                     HL[fb][pb][s] = d * (1.0f - h * h);
                 }
@@ -475,7 +485,8 @@ __global__ void __launch_bounds__(256) mlp_mfma_bwd_small_kernel(MlpMfmaArgs a) 
 #pragma unroll
                     for (int s = 0; s < 4; ++s) { P1 = mfma4x(H1[kb][pb][s], idn[s], P1); P2 = mfma4x(H2[kb][pb][s], idn[s], P2); }
                     H1p[kb] = P1; D2p[kb] = P2;
-                    aB2[kb] += H2[kb][pb];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) PB2(kb, s) += H2[kb][pb][s];
                 }
 #pragma unroll
                 for (int ob = 0; ob < 2; ++ob)
@@ -509,11 +520,12 @@ __global__ void __launch_bounds__(256) mlp_mfma_bwd_small_kernel(MlpMfmaArgs a) 
         for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) {
-                aB1[fb] += H1[fb][pb];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s) {
+                    PB1(fb, s) += H1[fb][pb][s];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) pW1[fb][s][k] = fmaf(H1[fb][pb][s], xr[pb][k], pW1[fb][s][k]);
+                    for (int k = 0; k < 4; ++k) PW1(fb, s, k) += H1[fb][pb][s] * xr[pb][k];
+                }
             }
     }
     // ---- per-lane partials: sum over the 16 point lanes of each lane group ---------------------------------
@@ -530,22 +542,27 @@ __global__ void __launch_bounds__(256) mlp_mfma_bwd_small_kernel(MlpMfmaArgs a) 
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int o = fb * 16 + 4 * g + s;
-            const float b1 = r16(aB1[fb][s]);
+            const float b1 = r16(PB1(fb, s));
             if (r == 0 && o < a.h0) dst[o] = b1;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const float v = r16(pW1[fb][s][k]); if (r == 0 && o < a.h0 && k < d_in) dst[a.h0 + o * d_in + k] = v; }
+            for (int k = 0; k < 4; ++k) { const float v = r16(PW1(fb, s, k)); if (r == 0 && o < a.h0 && k < d_in) dst[a.h0 + o * d_in + k] = v; }
             if (NH == 2) {
-                const float b2 = r16(aB2[fb][s]);
+                const float b2 = r16(PB2(fb, s));
                 if (r == 0 && o < a.h1) dst[off2 + o] = b2;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) { const int k = kb * 16 + r; if (o < a.h1 && k < a.h0) dst[off2 + a.h1 + o * a.h0 + k] = aW2[fb][kb][s]; }
             }
 #pragma unroll
-            for (int oo = 0; oo < 2; ++oo) { const float v = r16(pW3[oo][fb][s]); if (r == 0 && oo < d_out && o < hl) dst[off3 + d_out + oo * hl + o] = v; }
+            for (int oo = 0; oo < 2; ++oo) { const float v = r16(PW3(oo, fb, s)); if (r == 0 && oo < d_out && o < hl) dst[off3 + d_out + oo * hl + o] = v; }
         }
 #pragma unroll
-    for (int oo = 0; oo < 2; ++oo) { const float v = r16(pB3[oo]); if (lane == 0 && oo < d_out) dst[off3 + oo] = v; }
+    for (int oo = 0; oo < 2; ++oo) { const float v = r16(PB3(oo)); if (lane == 0 && oo < d_out) dst[off3 + oo] = v; }
 }
+#undef PW1
+#undef PW3
+#undef PB1
+#undef PB2
+#undef PB3
 
 template <typename T>
 __global__ void reduce_slab_kernel(const T* __restrict__ in, T* __restrict__ out, long out_stride, int accumulate, int C, int P, int Wd) {
@@ -573,11 +590,23 @@ static void fill_args(MlpMfmaArgs& a, const void* x, int x_div, const void* thet
     a.D_net = a.h0 * (d_in + 1) + (n_hidden > 1 ? a.h1 * (a.h0 + 1) : 0) + d_out * ((n_hidden > 1 ? a.h1 : a.h0) + 1);
 }
 
+// Number of workgroups per particle for the backward kernels.  The kernel keeps 2 workgroups (8 waves) per
+// CU resident, i.e. 512 at a time on the 256 CUs; a grid slightly above a multiple of that (e.g. 1040) costs
+// a whole extra round.  Pick the tiles-per-workgroup (a wave takes every 4th tile) that minimises
+// rounds x (tiles per wave + fixed per-workgroup overhead ~0.4 tile).
 static int mfma_bwd_chunks(int R, int P) {
     const int tiles = (R + 63) / 64;
-    int want = (1024 + P - 1) / P;                    // ~4 workgroups per CU in flight
-    int chunks = tiles / 4 < want ? (tiles + 3) / 4 : want;
-    return chunks < 1 ? 1 : chunks;
+    const int resident = 512;
+    int best_tpw = 4;
+    double best = 1e30;
+    for (int tpw = 4; tpw <= 256; tpw += 4) {
+        const long wgs = (long)((tiles + tpw - 1) / tpw) * P;
+        const long rounds = (wgs + resident - 1) / resident;
+        const double cost = (double)rounds * (tpw / 4 + 0.4);
+        if (cost < best - 1e-9) { best = cost; best_tpw = tpw; }
+        if (tpw >= tiles) break;
+    }
+    return (tiles + best_tpw - 1) / best_tpw;
 }
 
 // returns 1 if the MFMA path does not apply
@@ -588,7 +617,7 @@ int mlp_mfma_fwd(const void* x, int x_div, const void* theta, long theta_stride,
     fill_args(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, B, n);
     a.out = (float*)out;
     const int tiles = (a.R + 63) / 64;
-    a.tiles_per_wg = 8;
+    a.tiles_per_wg = 8;            // 2 tiles per wave; measured faster than fewer, larger workgroups
     const int wgs = (tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
     if (n_hidden == 2) hipLaunchKernelGGL(mlp_mfma_fwd_kernel<2>, dim3(wgs, P), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(mlp_mfma_fwd_kernel<1>, dim3(wgs, P), dim3(256), 0, s, a);
