@@ -214,6 +214,7 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1,0 +1,118 @@
+"""Parity at BASELINE.json's FULL configuration sizes.  Where the CPU oracle finishes in seconds the whole
+batch is compared; otherwise size-independent properties are used: additivity of the score over task
+sub-batches, permutation invariance, fp32-vs-fp64 agreement, plus an oracle spot check of random problems."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pacoh_oracle as O
+
+
+@pytest.fixture(scope='module')
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    import meta_learning_pacoh_amd as m
+    return m
+
+
+def relerr(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def test_cfg2_map_256_tasks_n32_d1_se_kernel_all_tasks_vs_oracle(M):
+    env = O.SinusoidDataset(np.random.RandomState(27))
+    train = env.generate_meta_train_data(256, 32)
+    model = M.GPRegressionMetaLearned(train, covar_module='SE', mean_module='NN', task_batch_size=256, random_seed=5)
+    orc = O.MapOracle(train, covar_module='SE', mean_module='NN', task_batch_size=256, random_seed=5)
+    lml, grad, info = model.engine.lml_and_grad(model.theta, model.tasks, weight=-1.0)
+    ref = torch.stack([orc.task_mll(x, y) for x, y in orc.tasks])
+    assert int(info.abs().max()) == 0
+    assert relerr(lml[:, 0], ref) < 1e-4
+    (-ref.sum()).backward()
+    lo, hi = model.layout.slices['mean_nn.fc_2.weight']
+    assert relerr(grad[0, lo:hi], orc.mean_net[1].weight.grad.reshape(-1)) < 1e-2
+    lo, hi = model.layout.slices['lengthscale_raw']
+    assert relerr(grad[0, lo:hi], orc.raw_lengthscale.grad.reshape(-1)) < 1e-2
+
+
+def test_cfg3_svgd_1024_tasks_n64_d4_20_particles_properties(M):
+    T, n, d, P = 1024, 64, 4, 20
+    tasks = O.sinusoid_tasks_nd(T, n, d, seed0=1000)
+    model = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=P, random_seed=0)
+    th = model.particles
+    full = model.tasks
+    lml, grad, info = model.engine.lml_and_grad(th, full, weight=1.0)
+    assert lml.shape == (T, P) and bool(torch.isfinite(lml).all()) and int(info.min()) >= 0
+    # (a) additivity over task sub-batches (what the multi-GPU sharding relies on)
+    parts = [model.tasks.select(torch.arange(q, T, 4, device=th.device)) for q in range(4)]
+    g_sum = sum(model.engine.lml_and_grad(th, pb, weight=1.0)[1] for pb in parts)
+    assert relerr(g_sum, grad) < 1e-4
+    # (b) permutation invariance of the per-task values
+    perm = torch.randperm(T, device=th.device)
+    lml_p, _, _ = model.engine.lml_and_grad(th, model.tasks.select(perm), weight=1.0)
+    assert float((lml_p - lml[perm]).abs().max()) == 0.0
+    # (c) determinism: two evaluations are bit-identical
+    lml2, grad2, _ = model.engine.lml_and_grad(th, full, weight=1.0)
+    assert torch.equal(lml, lml2) and torch.equal(grad, grad2)
+    # (d) oracle spot check of random (task, particle) pairs, fp64 oracle
+    cfg = O.GPConfig(d, 'NN', 'NN')
+    stats = O.compute_normalization_stats(tasks)
+    rs = np.random.RandomState(0)
+    for t in rs.randint(0, T, 6):
+        x, y = O.prepare_task(*tasks[t], stats, torch.float64)
+        ref = O.vectorized_gp_mll(th.cpu().double(), x, y, cfg)
+        assert relerr(lml[t], ref) < 1e-3
+    # (e) gradient of a 16-task sub-batch vs oracle autograd (norm-wise, fp32 bar)
+    sub = list(range(0, 16))
+    otasks = [O.prepare_task(*tasks[t], stats, torch.float64) for t in sub]
+    thd = th.cpu().double().clone().requires_grad_(True)
+    ref = torch.stack([O.vectorized_gp_mll(thd, x, y, cfg) for x, y in otasks], -1).sum()
+    ref.backward()
+    _, g16, _ = model.engine.lml_and_grad(th, model.tasks.select(torch.tensor(sub, device=th.device)), weight=1.0)
+    assert relerr(g16, thd.grad) < 1e-2
+
+
+def test_cfg4_vi_512_tasks_n128_10_samples(M):
+    T, n, d, S = 512, 128, 1, 10
+    env = O.SinusoidDataset(np.random.RandomState(28))
+    tasks = env.generate_meta_train_data(T, n)
+    model = M.GPRegressionMetaLearnedVI(tasks, svi_batch_size=S, random_seed=3)
+    torch.manual_seed(1)
+    theta, eps, sigma = model._rsample(S)
+    lml, grad, info = model.engine.lml_and_grad(theta, model.tasks, weight=1.0)
+    assert lml.shape == (T, S) and bool(torch.isfinite(lml).all())
+    halves = [model.tasks.select(torch.arange(q, T, 2, device=theta.device)) for q in range(2)]
+    g_sum = sum(model.engine.lml_and_grad(theta, h, weight=1.0)[1] for h in halves)
+    assert relerr(g_sum, grad) < 1e-4
+    cfg = O.GPConfig(d, 'NN', 'NN')
+    stats = O.compute_normalization_stats(tasks)
+    for t in (0, 101, 511):
+        x, y = O.prepare_task(*tasks[t], stats, torch.float64)
+        ref = O.vectorized_gp_mll(theta.cpu().double(), x, y, cfg)
+        assert relerr(lml[t], ref) < 2e-3
+    loss = model.meta_fit(n_iter=2, verbose=False)
+    assert np.isfinite(loss)
+
+
+def test_cfg5_large_context_256_tasks_n512_d8_fp64_all_tasks_vs_oracle(M):
+    from meta_learning_pacoh_amd import _lib as L
+    T, n, d = 256, 512, 8
+    tasks = O.sinusoid_tasks_nd(T, n, d, seed0=5000)
+    stats = O.compute_normalization_stats(tasks)
+    xy = [O.prepare_task(x, y, stats, torch.float64) for x, y in tasks]
+    X, Y = torch.stack([a for a, _ in xy]), torch.stack([b for _, b in xy])
+    ls = torch.nn.functional.softplus(torch.zeros(1, d, dtype=torch.float64))
+    noise = torch.nn.functional.softplus(torch.tensor([-1.0], dtype=torch.float64))
+    K = L.gram_rbf_ard(X.cuda(), 1, X.cuda(), 1, ls.cuda(), None, noise.cuda(), True, T, 1)
+    logp, alpha, info = L.mvn_logprob_dense(K, Y.cuda(), 1.0 / n, want_alpha=True)
+    assert int(info.abs().max()) == 0
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    ref = O.gp_mll(X, torch.zeros(T, n, dtype=torch.float64), Y, ls.unsqueeze(0), 1.0, noise)
+    assert float(((logp.cpu() - ref).abs() / ref.abs()).max()) < 1e-8          # bar: 1e-4 rel
+    # K^-1 y round trip: (K + s2 I) alpha == y
+    K2 = L.gram_rbf_ard(X.cuda(), 1, X.cuda(), 1, ls.cuda(), None, noise.cuda(), True, T, 1)
+    assert relerr(torch.bmm(K2, alpha.unsqueeze(-1)).squeeze(-1), Y) < 1e-10
