@@ -191,9 +191,15 @@ def main():
         torch.cuda.synchronize()
         t_k = s.elapsed_time(e) / reps * 1e-3
         alg_bytes = B * (N_CTX * 2 * 4 + N_CTX * N_CTX * 4)
+        traffic = None                      # HBM bytes per launch from the committed PMC profile of this same launch shape
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')) as fh:
+                traffic = json.load(fh)['kernels']['gram_kernel<float, 2>']['hbm_bytes_per_launch']
+        except Exception:
+            pass
         gram = {'kernel': 'gram_rbf_ard', 'bound': 'hbm', 'achieved': round(alg_bytes / t_k / 1e9, 1),
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(alg_bytes / t_k / 1e9 / HBM_PEAK_GBS, 4),
-                'traffic': None, 'bytes_per_gram': N_CTX * 2 * 4 + N_CTX * N_CTX * 4, 'grams': B,
+                'traffic': traffic, 'algorithmic_bytes': alg_bytes, 'bytes_per_gram': N_CTX * 2 * 4 + N_CTX * N_CTX * 4, 'grams': B,
                 'us_per_launch': round(t_k * 1e6, 2)}
 
     if rank == 0:
