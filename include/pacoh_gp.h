@@ -193,6 +193,12 @@ int pacoh_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_
                     double lr, double beta1, double beta2, double eps, double weight_decay,
                     long step, long count, int dtype, void* stream);
 
+/* Same update with the step-dependent scalars in DEVICE memory, scalars = {1 - lr*weight_decay, lr/(1-beta1^step),
+ * sqrt(1-beta2^step), eps} (4 values of `dtype`), so that the launch can be captured once in a hipGraph and replayed
+ * every iteration while the host only refreshes the 4 scalars. */
+int pacoh_adam_step_dev(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, const void* scalars,
+                        double beta1, double beta2, long count, int dtype, void* stream);
+
 /* ---- reductions used by the host between kernels ----------------------------------------------
  * out[p, :] (+)= scale * sum_t in[t, p, :]   (in is [T, P, W]); deterministic (fixed order). */
 int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, int T, int P, int W,

@@ -1,6 +1,7 @@
 """PACOH-MAP on MI355X: same constructor / meta_fit / predict / state_dict API as the reference's
 GPRegressionMetaLearned (meta_learn/GPR_meta_mll.py:12-264); the per-task ExactGP + autograd + AdamW
 loop (:104-117) runs as a handful of HIP kernel launches per iteration over the whole task batch."""
+import os
 import time
 from collections import OrderedDict
 
@@ -115,6 +116,68 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
             else:
                 p.add_(g, alpha=-lr)
 
+    # ---- one meta-training iteration captured in a hipGraph ----------------------------------------
+    # A MAP iteration is ~10 launches of a few microseconds each, i.e. launch-bound.  The sequence
+    # (task gather -> features -> fused GP LML+grad -> MLP backward -> hyper backward -> AdamW) is captured
+    # once and replayed; per iteration the host only refreshes the sampled task indices and the four
+    # step-dependent Adam scalars (device-side operands of pacoh_adam_step_dev).  Same kernels, same order,
+    # same results as the eager path (PACOH_NO_GRAPH=1 selects it).
+    GRAPH_CHUNK = 1024          # iterations whose task draws / Adam scalars are uploaded in one copy
+
+    def _iteration_body(self):
+        # this iteration's row of the pre-uploaded task draws and Adam scalars, selected by a device-side counter
+        idx = self._g_idx_all.index_select(0, self._g_ctr).reshape(-1)
+        self._g_sc.copy_(self._g_sc_all.index_select(0, self._g_ctr).reshape(-1))
+        self._g_ctr.add_(1)
+        batch = self.tasks.select(idx)
+        lml, grad, _ = self.engine.lml_and_grad(self.theta, batch, weight=-1.0)
+        torch.neg(lml.sum(), out=self._g_loss)
+        self._g_cum.add_(self._g_loss)
+        for lo, hi in self.train_segments:
+            L.adam_step_dev(self.theta[0, lo:hi], grad[0, lo:hi], self.exp_avg[0, lo:hi], self.exp_avg_sq[0, lo:hi],
+                            self._g_sc)
+
+    def _build_graph(self):
+        dev = self.device
+        self._g_idx_all = torch.zeros(self.GRAPH_CHUNK, self.task_batch_size, dtype=torch.int64, device=dev)
+        self._g_sc_all = torch.tensor([L.adam_scalars(self.lr_scheduler.lr, 1, weight_decay=self.weight_decay)] * self.GRAPH_CHUNK,
+                                      dtype=self.dtype, device=dev)
+        self._g_sc = self._g_sc_all[0].clone()
+        self._g_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._g_loss = torch.zeros((), dtype=self.dtype, device=dev)
+        self._g_cum = torch.zeros((), dtype=self.dtype, device=dev)
+        saved = [t.clone() for t in (self.theta, self.exp_avg, self.exp_avg_sq)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up (allocates workspaces outside the graph pool)
+            for _ in range(2):
+                self._iteration_body()
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._iteration_body()
+        for t, sv in zip((self.theta, self.exp_avg, self.exp_avg_sq), saved):   # undo the warm-up updates
+            t.copy_(sv)
+        self._g_cum.zero_()
+        self._g_ctr.zero_()
+
+    def _upload_chunk(self, n_steps):
+        """draw the next n_steps task batches (same numpy stream as per-iteration draws) and the Adam scalars of
+        those steps (lr schedule included) and upload them with two copies"""
+        idx = np.stack([self.rds_numpy.randint(0, self.tasks.T, size=self.task_batch_size) for _ in range(n_steps)])
+        sched = StepLR(self.lr_scheduler.base_lr, self.lr_scheduler.step_size, self.lr_scheduler.gamma)
+        sched.epoch = self.lr_scheduler.epoch
+        sc = []
+        for k in range(n_steps):
+            sc.append(L.adam_scalars(sched.lr, self.opt_step + k + 1, weight_decay=self.weight_decay))
+            sched.step()
+        self._g_idx_all[:n_steps].copy_(torch.from_numpy(idx))
+        self._g_sc_all[:n_steps].copy_(torch.tensor(sc, dtype=self.dtype))
+        self._g_ctr.zero_()
+
+    def _use_graph(self):
+        return self.optimizer_name == 'Adam' and os.environ.get('PACOH_NO_GRAPH', '0') != '1'
+
     # ------------------------------------------------------------------------------------------
     def meta_fit(self, valid_tuples=None, verbose=True, log_period=500, n_iter=None):
         """GPR_meta_mll.py:82-147: loss = -sum over the sampled tasks of the per-datapoint MLL."""
@@ -126,15 +189,32 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
             if n_iter is None:
                 n_iter = self.num_iter_fit
             loss = None
+            graphed = self._use_graph()
+            if graphed and getattr(self, '_graph', None) is None:
+                self._build_graph()
+            if graphed:
+                self._g_cum.zero_()
+            left_in_chunk = 0
             for itr in range(1, n_iter + 1):
-                # rds_numpy.choice(task_dicts, size=B) == randint(0, T, B): with replacement (:109)
-                idx = self.rds_numpy.randint(0, self.tasks.T, size=self.task_batch_size)
-                batch = self.tasks.select(torch.from_numpy(idx).to(self.device))
-                lml, grad, _ = self.engine.lml_and_grad(self.theta, batch, weight=-1.0)
-                loss = -lml.sum()
-                self._apply_update(grad)
+                if graphed:
+                    if left_in_chunk == 0:
+                        # up to the next log line (evaluation reads the parameters there) or the chunk size
+                        to_log = 1 if itr == 1 else (log_period - (itr - 1) % log_period)
+                        left_in_chunk = max(1, min(self.GRAPH_CHUNK, to_log, n_iter - itr + 1))
+                        self._upload_chunk(left_in_chunk)
+                    left_in_chunk -= 1
+                    self.opt_step += 1
+                    self._graph.replay()
+                    loss, cum_loss = self._g_loss, self._g_cum
+                else:
+                    # rds_numpy.choice(task_dicts, size=B) == randint(0, T, B): with replacement (:109)
+                    idx = self.rds_numpy.randint(0, self.tasks.T, size=self.task_batch_size)
+                    batch = self.tasks.select(torch.from_numpy(idx).to(self.device))
+                    lml, grad, _ = self.engine.lml_and_grad(self.theta, batch, weight=-1.0)
+                    loss = -lml.sum()
+                    self._apply_update(grad)
+                    cum_loss += loss
                 self.lr_scheduler.step()
-                cum_loss += loss
                 if itr == 1 or itr % log_period == 0:
                     duration = time.time() - t
                     avg_loss = cum_loss / (log_period if itr > 1 else 1.0)

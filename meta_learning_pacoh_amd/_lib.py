@@ -44,6 +44,7 @@ SIGNATURES = {
     'pacoh_svgd_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_phi': (_i, [_vp, _vp, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_adam_step': (_i, [_vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _l, _l, _i, _vp]),
+    'pacoh_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _l, _i, _vp]),
     'pacoh_reduce_tasks': (_i, [_vp, _vp, _d, _i, _i, _i, _i, _i, _vp]),
 }
 
@@ -329,6 +330,19 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999
         _check(lib.pacoh_adam_step(_ptr(param), _ptr(grad, param), _ptr(exp_avg, param), _ptr(exp_avg_sq, param),
                                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
                                    param.numel(), dtype_code(param), _stream()), 'pacoh_adam_step')
+
+
+def adam_scalars(lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """the four step-dependent scalars of pacoh_adam_step_dev (host side, float64)"""
+    return [1.0 - lr * weight_decay, lr / (1.0 - beta1 ** step), (1.0 - beta2 ** step) ** 0.5, eps]
+
+
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, scalars, beta1=0.9, beta2=0.999):
+    lib = load_library()
+    with _Timed('adam_step'):
+        _check(lib.pacoh_adam_step_dev(_ptr(param), _ptr(grad, param), _ptr(exp_avg, param), _ptr(exp_avg_sq, param),
+                                       _ptr(scalars, param), float(beta1), float(beta2), param.numel(), dtype_code(param),
+                                       _stream()), 'pacoh_adam_step_dev')
 
 
 def reduce_tasks(inp, out, scale=1.0, accumulate=False):

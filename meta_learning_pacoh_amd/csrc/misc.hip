@@ -190,6 +190,24 @@ __global__ void adam_kernel(T* __restrict__ param, const T* __restrict__ grad, T
     param[q] = p; m[q] = mq; v[q] = vq;
 }
 
+// same update with the step-dependent scalars read from device memory, so that the launch can be captured once
+// into a hipGraph and replayed every iteration: sc = {decay_mul, step_size, bc2_sqrt, eps}
+template <typename T>
+__global__ void adam_dev_kernel(T* __restrict__ param, const T* __restrict__ grad, T* __restrict__ m, T* __restrict__ v,
+                                const T* __restrict__ sc, T one_minus_b1, T b2, T one_minus_b2, long count) {
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count) return;
+    const T decay_mul = sc[0], step_size = sc[1], bc2_sqrt = sc[2], eps = sc[3];
+    T g = grad[q];
+    T p = param[q] * decay_mul;
+    T mq = m[q];
+    mq = mq + (g - mq) * one_minus_b1;
+    T vq = v[q] * b2 + one_minus_b2 * g * g;
+    T denom = t_sqrt<T>(vq) / bc2_sqrt + eps;
+    p = p - step_size * (mq / denom);
+    param[q] = p; m[q] = mq; v[q] = vq;
+}
+
 }  // namespace pacoh
 
 using namespace pacoh;
@@ -312,5 +330,20 @@ extern "C" int pacoh_adam_step(void* param, const void* grad, void* exp_avg, voi
     else
         hipLaunchKernelGGL(adam_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (double*)param, (const double*)grad,
                            (double*)exp_avg, (double*)exp_avg_sq, decay_mul, 1.0 - beta1, beta2, 1.0 - beta2, step_size, bc2_sqrt, eps, count);
+    return launch_status();
+}
+
+extern "C" int pacoh_adam_step_dev(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, const void* scalars,
+                                   double beta1, double beta2, long count, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !scalars || count <= 0) return PACOH_EINVAL;
+    unsigned blocks = (unsigned)((count + 255) / 256);
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(adam_dev_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)param, (const float*)grad,
+                           (float*)exp_avg, (float*)exp_avg_sq, (const float*)scalars, (float)(1.0 - beta1), (float)beta2,
+                           (float)(1.0 - beta2), count);
+    else
+        hipLaunchKernelGGL(adam_dev_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (double*)param, (const double*)grad,
+                           (double*)exp_avg, (double*)exp_avg_sq, (const double*)scalars, 1.0 - beta1, beta2, 1.0 - beta2, count);
     return launch_status();
 }
