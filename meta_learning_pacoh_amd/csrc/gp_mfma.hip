@@ -102,72 +102,97 @@ __device__ __forceinline__ float wave_sum(float v) {
 // lane needs at step k (column k of the running matrix, later row i of L) are published through LDS and
 // read back as broadcast ds_read_b128 -- this keeps the VALU, which bounds the kernel, free of the
 // 240 v_readlane + IEEE sqrt/divide sequences of a pure register formulation.
-__device__ __forceinline__ bool factor_diag_block(float* A, int LD, int d0, float* invd, float* scr, int r) {
-    float D[16], Lr[16];
-    {
+__device__ __forceinline__ void factor_diag_block(float* A, int LD, int d0, float* invd, float* scr, int r, bool active) {
+    // `active` = this wave does the work (wave 0); other waves of the workgroup only join the barriers.
+    // scr[0..31]: double-buffered column broadcast, scr[40]: "a pivot was not positive" flag (sticky per attempt)
+    float Lr[16], inv[16];
+    if (active) {
+        float D[16];
         const float4* row = reinterpret_cast<const float4*>(A + (d0 + r) * LD + d0);
 #pragma unroll
         for (int v = 0; v < 4; ++v) { float4 q = row[v]; D[4 * v] = q.x; D[4 * v + 1] = q.y; D[4 * v + 2] = q.z; D[4 * v + 3] = q.w; }
-    }
-    bool ok = true;
-    float inv[16];
+        bool ok = true;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        scr[(k & 1) * 16 + r] = D[k];                                  // column k: D[r][k] (double-buffered)
-        float c[16];
-        {
-            const float4* cp = reinterpret_cast<const float4*>(scr + (k & 1) * 16);
+        for (int k = 0; k < 16; ++k) {
+            scr[(k & 1) * 16 + r] = D[k];                                  // column k: D[r][k] (double-buffered)
+            float c[16];
+            {
+                const float4* cp = reinterpret_cast<const float4*>(scr + (k & 1) * 16);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) { float4 q = cp[v]; c[4 * v] = q.x; c[4 * v + 1] = q.y; c[4 * v + 2] = q.z; c[4 * v + 3] = q.w; }
+                for (int v = 0; v < 4; ++v) { float4 q = cp[v]; c[4 * v] = q.x; c[4 * v + 1] = q.y; c[4 * v + 2] = q.z; c[4 * v + 3] = q.w; }
+            }
+            float pk = c[k];
+            if (!(pk > 0.0f)) { ok = false; pk = 1.0f; }
+            const float rs = __builtin_amdgcn_rsqf(pk);
+            const float rs1 = rs * fmaf(-0.5f * pk * rs, rs, 1.5f);        // one Newton step: 1/sqrt(pk) to fp32 accuracy
+            inv[k] = rs1;
+            Lr[k] = D[k] * rs1;                                            // L[r][k] (valid for r >= k)
+            const float tk = D[k] * (rs1 * rs1);                           // D[r][k] / pk
+#pragma unroll
+            for (int j = k + 1; j < 16; ++j) D[j] = fmaf(-tk, c[j], D[j]); // D[r][j] -= L[r][k] L[j][k]
         }
-        float pk = c[k];
-        if (!(pk > 0.0f)) { ok = false; pk = 1.0f; }
-        const float rs = __builtin_amdgcn_rsqf(pk);
-        const float rs1 = rs * fmaf(-0.5f * pk * rs, rs, 1.5f);        // one Newton step: 1/sqrt(pk) to fp32 accuracy
-        inv[k] = rs1;
-        Lr[k] = D[k] * rs1;                                            // L[r][k] (valid for r >= k)
-        const float tk = D[k] * (rs1 * rs1);                           // D[r][k] / pk
+        if (!ok && threadIdx.x == 0) scr[40] = 1.0f;
+        // publish L (row r by lane r) in the block's own storage
+        if (threadIdx.x < 16) {
+            float4* wrow = reinterpret_cast<float4*>(A + (d0 + r) * LD + d0);
 #pragma unroll
-        for (int j = k + 1; j < 16; ++j) D[j] = fmaf(-tk, c[j], D[j]); // D[r][j] -= L[r][k] L[j][k]
-    }
-    // publish L (row r by lane r) in the block's own storage, then X = L11^-1: lane c = r owns column c
-    if (threadIdx.x < 16) {
-        float4* row = reinterpret_cast<float4*>(A + (d0 + r) * LD + d0);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) { float4 q; q.x = Lr[4 * v]; q.y = Lr[4 * v + 1]; q.z = Lr[4 * v + 2]; q.w = Lr[4 * v + 3]; row[v] = q; }
+            for (int v = 0; v < 4; ++v) { float4 q; q.x = Lr[4 * v]; q.y = Lr[4 * v + 1]; q.z = Lr[4 * v + 2]; q.w = Lr[4 * v + 3]; wrow[v] = q; }
+        }
     }
     __syncthreads();
     float x[16];
+    if (active) {                                                          // X = L11^-1: lane c = r owns column c
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        float s = (i == r) ? 1.0f : 0.0f;
-        if (i > 0) {
-            const float4* lp = reinterpret_cast<const float4*>(A + (d0 + i) * LD + d0);      // row i of L, broadcast
+        for (int i = 0; i < 16; ++i) {
+            float s = (i == r) ? 1.0f : 0.0f;
+            if (i > 0) {
+                const float4* lp = reinterpret_cast<const float4*>(A + (d0 + i) * LD + d0);      // row i of L, broadcast
 #pragma unroll
-            for (int v = 0; v < (i + 3) / 4; ++v) {
-                const float4 q = lp[v];
-                if (4 * v < i) s = fmaf(-q.x, x[4 * v], s);
-                if (4 * v + 1 < i) s = fmaf(-q.y, x[4 * v + 1], s);
-                if (4 * v + 2 < i) s = fmaf(-q.z, x[4 * v + 2], s);
-                if (4 * v + 3 < i) s = fmaf(-q.w, x[4 * v + 3], s);
+                for (int v = 0; v < (i + 3) / 4; ++v) {
+                    const float4 q = lp[v];
+                    if (4 * v < i) s = fmaf(-q.x, x[4 * v], s);
+                    if (4 * v + 1 < i) s = fmaf(-q.y, x[4 * v + 1], s);
+                    if (4 * v + 2 < i) s = fmaf(-q.z, x[4 * v + 2], s);
+                    if (4 * v + 3 < i) s = fmaf(-q.w, x[4 * v + 3], s);
+                }
             }
+            x[i] = s * inv[i];
         }
-        x[i] = s * inv[i];
     }
-    __syncthreads();                                                   // every lane has read L before X overwrites it
-    if (threadIdx.x < 16) {
+    __syncthreads();                                                       // every lane has read L before X overwrites it
+    if (active && threadIdx.x < 16) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) A[(d0 + i) * LD + d0 + r] = x[i];
-    }
-    float my_inv = 0.0f;
+        float my_inv = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) my_inv = (r == k) ? inv[k] : my_inv;
-    if (threadIdx.x < 16) invd[d0 + r] = my_inv;
-    return ok;
+        for (int k = 0; k < 16; ++k) my_inv = (r == k) ? inv[k] : my_inv;
+        invd[d0 + r] = my_inv;
+    }
 }
 
-template <int NB, int FP, bool BWD>
-__global__ void __launch_bounds__(64) gp_mfma_kernel(GpMfmaArgs a) {
+// sum over the whole workgroup (NW waves); red = NW floats of LDS scratch
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    if (NW > 1) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        v = red[0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) v += red[q];
+    }
+    return v;
+}
+
+// NB 16x16 block rows/columns (n <= 16*NB), NW = 1 wave (NB <= 4) or 2 waves (NB <= 8) per problem.
+// Storage: the lower block triangle holds A -> L (off-diagonal) and L11^-1 (diagonal blocks); Z = L^-1 is
+// produced TRANSPOSED into the free upper triangle (block (jb,ib) = Z[ib][jb]^T), which makes its block
+// columns independent (no in-place hazard -> split over the waves, no barriers inside) and turns every
+// operand of the later products into a contiguous ds_read_b128; W = K^-1 then overwrites the dead lower
+// triangle row by row and is mirrored into the upper one.
+template <int NB, int NW, int FP, bool BWD>
+__global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
     constexpr int NP = 16 * NB;              // padded problem size
     constexpr int LD = NP + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -176,9 +201,10 @@ __global__ void __launch_bounds__(64) gp_mfma_kernel(GpMfmaArgs a) {
     float* rv = zf + NP * FP;                              // [NP] residual
     float* av = rv + NP;                                   // [NP] alpha
     float* invd = av + NP;                                 // [NP]
-    float* scr = invd + NP;                                // [64] broadcast scratch of the diagonal-block factorisation
+    float* scr = invd + NP;                                // [64] broadcast scratch / cross-wave sums
 
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const long b = blockIdx.x;
     const int n = a.n, f = a.f;
@@ -193,8 +219,8 @@ __global__ void __launch_bounds__(64) gp_mfma_kernel(GpMfmaArgs a) {
     const float os = a.os ? a.os[p] : 1.0f;
     const float noise = a.noise[p];
 
-    // ---- features (pre-divided by the lengthscale) and residual, lane i = row i ----------------
-    const int i = lane;
+    // ---- features (pre-divided by the lengthscale) and residual, thread i = row i -----------------
+    const int i = tid;
     float zs[FP];
 #pragma unroll
     for (int c = 0; c < FP; ++c) zs[c] = 0.0f;
@@ -241,94 +267,125 @@ __global__ void __launch_bounds__(64) gp_mfma_kernel(GpMfmaArgs a) {
                 }
             }
         }
+        if (tid == 0) scr[40] = 0.0f;
         __syncthreads();
-        bool ok = true;
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
             const int k0 = kb * 16;
-            ok = factor_diag_block(A, LD, k0, invd, scr, r) && ok;
+            factor_diag_block(A, LD, k0, invd, scr, r, wave == 0);        // wave 0 works, the others join its barriers
             __syncthreads();
-            // panel: L[ib][kb] = A[ib][kb] * Linv^T
+            // panel: L[ib][kb] = A[ib][kb] * Linv^T   (block rows dealt to the waves)
 #pragma unroll
             for (int ib = kb + 1; ib < NB; ++ib) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                mm_xyT(acc, A, LD, ib * 16, k0, k0, k0, r, g, 1.0f);
-                __syncthreads();            // all lanes have read A[ib][kb] before it is overwritten
-                store_c(A, LD, ib * 16, k0, r, g, acc);
+                if ((ib - kb - 1) % NW == wave) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    mm_xyT(acc, A, LD, ib * 16, k0, k0, k0, r, g, 1.0f);
+                    store_c(A, LD, ib * 16, k0, r, g, acc);   // same wave read it just before: in-order LDS
+                }
             }
             __syncthreads();
             // trailing update: A[ib][jb] -= L[ib][kb] L[jb][kb]^T
+            int q = 0;
 #pragma unroll
             for (int ib = kb + 1; ib < NB; ++ib) {
 #pragma unroll
-                for (int jb = kb + 1; jb <= ib; ++jb) {
-                    f32x4 acc = load_c(A, LD, ib * 16, jb * 16, r, g);
-                    mm_xyT(acc, A, LD, ib * 16, k0, jb * 16, k0, r, g, -1.0f);
-                    store_c(A, LD, ib * 16, jb * 16, r, g, acc);
+                for (int jb = kb + 1; jb <= ib; ++jb, ++q) {
+                    if (q % NW == wave) {
+                        f32x4 acc = load_c(A, LD, ib * 16, jb * 16, r, g);
+                        mm_xyT(acc, A, LD, ib * 16, k0, jb * 16, k0, r, g, -1.0f);
+                        store_c(A, LD, ib * 16, jb * 16, r, g, acc);
+                    }
                 }
             }
             __syncthreads();
         }
+        const bool ok = scr[40] == 0.0f;
+        __syncthreads();                                                   // flag read by all before the next attempt clears it
         if (ok) { my_info = attempt; break; }
         jitter = 1e-6f;
         for (int q = 0; q < attempt; ++q) jitter *= 10.0f;
     }
     const bool okf = my_info >= 0;
-    if (lane == 0 && a.info) a.info[b] = my_info;
+    if (tid == 0 && a.info) a.info[b] = my_info;
 
-    // ---- Z = L^-1 in place: diagonal blocks already hold L11^-1 ---------------------------------
+    // ---- Z = L^-1: block column jb (dealt to the waves), written transposed into the upper triangle ----
 #pragma unroll
     for (int jb = 0; jb < NB - 1; ++jb) {
+        if (jb % NW == wave) {
 #pragma unroll
-        for (int ib = jb + 1; ib < NB; ++ib) {
-            f32x4 S = {0.f, 0.f, 0.f, 0.f};
+            for (int ib = jb + 1; ib < NB; ++ib) {
+                f32x4 S = {0.f, 0.f, 0.f, 0.f};
+                mm_xy(S, A, LD, ib * 16, jb * 16, jb * 16, jb * 16, r, g);               // L[ib][jb] * Linv_jb
 #pragma unroll
-            for (int kb = jb; kb < ib; ++kb) mm_xy(S, A, LD, ib * 16, kb * 16, kb * 16, jb * 16, r, g);
-            f32x4 Zb = {0.f, 0.f, 0.f, 0.f};
-            mm_xs(Zb, A, LD, ib * 16, ib * 16, S, r, g, -1.0f);
-            __syncthreads();
-            store_c(A, LD, ib * 16, jb * 16, r, g, Zb);
-            __syncthreads();
+                for (int kb = jb + 1; kb < ib; ++kb) {                                    // L[ib][kb] * Z[kb][jb]
+                    const float4 aw = *reinterpret_cast<const float4*>(A + (ib * 16 + r) * LD + kb * 16 + 4 * g);
+                    const float4 bz = *reinterpret_cast<const float4*>(A + (jb * 16 + r) * LD + kb * 16 + 4 * g);
+                    S = mfma4(aw.x, bz.x, S); S = mfma4(aw.y, bz.y, S); S = mfma4(aw.z, bz.z, S); S = mfma4(aw.w, bz.w, S);
+                }
+                f32x4 Zb = {0.f, 0.f, 0.f, 0.f};
+                mm_xs(Zb, A, LD, ib * 16, ib * 16, S, r, g, -1.0f);                       // -Linv_ib * S
+                store_ct(A, LD, jb * 16, ib * 16, r, g, Zb);
+            }
         }
     }
     __syncthreads();
-    // ---- u = Z r (lane i = row i), quad = |u|^2, logdet ------------------------------------------
+    // ---- u = Z r (thread i = row i of Z = column i of the upper storage + its diagonal-block row) -------
     float ui = 0.0f;
     if (i < NP) {
-        const float4* zr = reinterpret_cast<const float4*>(A + i * LD);
-        const float4* rr = reinterpret_cast<const float4*>(rv);
-        const int nvec = ((i >> 4) + 1) * 4;                   // columns up to the end of the diagonal block
-        for (int v = 0; v < nvec; ++v) {
+        const int d0 = (i >> 4) * 16;
+        for (int j = 0; j < d0; ++j) ui = fmaf(A[j * LD + i], rv[j], ui);
+        const float4* zr = reinterpret_cast<const float4*>(A + i * LD + d0);
+        const float4* rr = reinterpret_cast<const float4*>(rv + d0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
             const float4 zq = zr[v], rq = rr[v];
             ui = fmaf(zq.x, rq.x, ui); ui = fmaf(zq.y, rq.y, ui); ui = fmaf(zq.z, rq.z, ui); ui = fmaf(zq.w, rq.w, ui);
         }
     }
-    const float quad = wave_sum((i < nv) ? ui * ui : 0.0f);
-    const float logdet = wave_sum((i < nv) ? -logf(invd[i < NP ? i : 0]) : 0.0f);
+    const float quad = block_sum<NW>((i < nv) ? ui * ui : 0.0f, scr);
+    const float logdet = block_sum<NW>((i < nv) ? -logf(invd[i < NP ? i : 0]) : 0.0f, scr);
     float lml = nv > 0 ? -0.5f * (quad + 2.0f * logdet + (float)nv * 1.8378770664093453f) / (float)nv : 0.0f;
     if (!okf) lml = NAN;
-    if (lane == 0) a.lml[b] = lml;
+    if (tid == 0) a.lml[b] = lml;
     if (!BWD) return;
 
-    // ---- W = Z^T Z in place, mirrored to a full symmetric matrix --------------------------------
+    // ---- W = Z^T Z: block rows dealt to the waves, results overwrite the (dead) lower triangle --------
 #pragma unroll
     for (int ib = 0; ib < NB; ++ib) {
-        f32x4 Wb[NB];
+        if (ib % NW == wave) {
+            f32x4 Wb[NB];
 #pragma unroll
-        for (int jb = 0; jb <= ib; ++jb) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int jb = 0; jb <= ib; ++jb) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kb = ib; kb < NB; ++kb) mm_xTy(acc, A, LD, kb * 16, ib * 16, kb * 16, jb * 16, r, g);
-            Wb[jb] = acc;
+                for (int kb = ib + 1; kb < NB; ++kb) mm_xyT(acc, A, LD, ib * 16, kb * 16, jb * 16, kb * 16, r, g, 1.0f);
+                // kb == ib term: Linv_ib^T * Z[ib][jb]
+                const float* xp = A + (ib * 16 + 4 * g) * LD + ib * 16 + r;
+                const float a0 = xp[0], a1 = xp[LD], a2 = xp[2 * LD], a3 = xp[3 * LD];
+                if (jb < ib) {
+                    const float4 bz = *reinterpret_cast<const float4*>(A + (jb * 16 + r) * LD + ib * 16 + 4 * g);
+                    acc = mfma4(a0, bz.x, acc); acc = mfma4(a1, bz.y, acc); acc = mfma4(a2, bz.z, acc); acc = mfma4(a3, bz.w, acc);
+                } else {
+                    acc = mfma4(a0, a0, acc); acc = mfma4(a1, a1, acc); acc = mfma4(a2, a2, acc); acc = mfma4(a3, a3, acc);
+                }
+                Wb[jb] = acc;
+            }
+#pragma unroll
+            for (int jb = 0; jb <= ib; ++jb) store_c(A, LD, ib * 16, jb * 16, r, g, Wb[jb]);
         }
-        __syncthreads();
-#pragma unroll
-        for (int jb = 0; jb <= ib; ++jb) {
-            store_c(A, LD, ib * 16, jb * 16, r, g, Wb[jb]);
-            if (jb < ib) store_ct(A, LD, jb * 16, ib * 16, r, g, Wb[jb]);
-        }
-        __syncthreads();
     }
+    __syncthreads();
+    {   // mirror the strictly-lower blocks into the upper triangle (Z^T is dead now)
+        int q = 0;
+#pragma unroll
+        for (int ib = 1; ib < NB; ++ib) {
+#pragma unroll
+            for (int jb = 0; jb < ib; ++jb, ++q) {
+                if (q % NW == wave) { const f32x4 c = load_c(A, LD, ib * 16, jb * 16, r, g); store_ct(A, LD, jb * 16, ib * 16, r, g, c); }
+            }
+        }
+    }
+    __syncthreads();
     // ---- alpha = W r ------------------------------------------------------------------------------
     float ai = 0.0f;
     if (i < NP) {
@@ -342,7 +399,7 @@ __global__ void __launch_bounds__(64) gp_mfma_kernel(GpMfmaArgs a) {
         av[i] = ai;
     }
     __syncthreads();
-    // ---- gradient sums: lane i owns row i of W ------------------------------------------------------
+    // ---- gradient sums: thread i owns row i of W ---------------------------------------------------
     const float gup = a.g_lml ? a.g_lml[b] : 1.0f;
     float dz[FP], dls[FP];
 #pragma unroll
@@ -371,18 +428,18 @@ __global__ void __launch_bounds__(64) gp_mfma_kernel(GpMfmaArgs a) {
     if (a.mean_mode == PACOH_MEAN_VECTOR) {
         if (a.d_mean && i < n) a.d_mean[b * n + i] = (i < nv) ? gup * ai / (float)nv + bad : 0.0f;
     } else if (a.mean_mode == PACOH_MEAN_CONST) {
-        const float sa = wave_sum((i < nv) ? ai : 0.0f);
-        if (a.d_mean && lane == 0) a.d_mean[b] = nv > 0 ? gup * sa / (float)nv + bad : 0.0f;
+        const float sa = block_sum<NW>((i < nv) ? ai : 0.0f, scr);
+        if (a.d_mean && tid == 0) a.d_mean[b] = nv > 0 ? gup * sa / (float)nv + bad : 0.0f;
     }
 #pragma unroll
     for (int c = 0; c < FP; ++c) {
         if (c < f) {
-            const float sc = wave_sum(dls[c]);
-            if (lane == 0) a.d_ls[b * f + c] = gup * sc / ls[c] + bad;
+            const float sc = block_sum<NW>(dls[c], scr);
+            if (tid == 0) a.d_ls[b * f + c] = gup * sc / ls[c] + bad;
         }
     }
-    const float sdos = wave_sum(dos), sdnz = wave_sum(dnz);
-    if (lane == 0) {
+    const float sdos = block_sum<NW>(dos, scr), sdnz = block_sum<NW>(dnz, scr);
+    if (tid == 0) {
         if (a.d_os) a.d_os[b] = gup * sdos + bad;
         a.d_noise[b] = gup * sdnz + bad;
     }
@@ -390,9 +447,11 @@ __global__ void __launch_bounds__(64) gp_mfma_kernel(GpMfmaArgs a) {
 
 template <int NB, bool BWD>
 static int launch_nb(const GpMfmaArgs& a, int FP, hipStream_t s) {
-    constexpr int NP = 16 * NB, LD = NP + 4;
+    constexpr int NP = 16 * NB, LD = NP + 4, NW = NB <= 4 ? 1 : 2;
     const size_t lds = (size_t)(NP * LD + NP * FP + 3 * NP + 64) * sizeof(float);
-#define PACOH_GPM_CASE(fp) case fp: hipLaunchKernelGGL((gp_mfma_kernel<NB, fp, BWD>), dim3((unsigned)a.B), dim3(64), lds, s, a); break;
+#define PACOH_GPM_CASE(fp) case fp: { auto kern = gp_mfma_kernel<NB, NW, fp, BWD>; \
+        if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PACOH_ELIMIT; \
+        hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(64 * NW), lds, s, a); } break;
     switch (FP) { PACOH_GPM_CASE(2) PACOH_GPM_CASE(4) PACOH_GPM_CASE(8) default: PACOH_GPM_CASE(16) }
 #undef PACOH_GPM_CASE
     return launch_status();
@@ -400,23 +459,12 @@ static int launch_nb(const GpMfmaArgs& a, int FP, hipStream_t s) {
 
 // entry used by gp_small.hip's C-ABI functions; returns 1 if this path does not apply
 int gp_mfma_try(const GpMfmaArgs& a, bool bwd, hipStream_t s) {
-    if (a.n > 64 || a.f > PACOH_MAX_FEATURES) return 1;
+    if (a.n > 128 || a.f > PACOH_MAX_FEATURES) return 1;
     const int NB = (a.n + 15) / 16;
     const int FP = a.f <= 2 ? 2 : (a.f <= 4 ? 4 : (a.f <= 8 ? 8 : 16));
-    if (bwd) {
-        switch (NB) {
-            case 1: return launch_nb<1, true>(a, FP, s);
-            case 2: return launch_nb<2, true>(a, FP, s);
-            case 3: return launch_nb<3, true>(a, FP, s);
-            default: return launch_nb<4, true>(a, FP, s);
-        }
-    }
-    switch (NB) {
-        case 1: return launch_nb<1, false>(a, FP, s);
-        case 2: return launch_nb<2, false>(a, FP, s);
-        case 3: return launch_nb<3, false>(a, FP, s);
-        default: return launch_nb<4, false>(a, FP, s);
-    }
+#define PACOH_GPM_NB(nb) case nb: return bwd ? launch_nb<nb, true>(a, FP, s) : launch_nb<nb, false>(a, FP, s);
+    switch (NB) { PACOH_GPM_NB(1) PACOH_GPM_NB(2) PACOH_GPM_NB(3) PACOH_GPM_NB(4) PACOH_GPM_NB(5) PACOH_GPM_NB(6) PACOH_GPM_NB(7) default: PACOH_GPM_NB(8) }
+#undef PACOH_GPM_NB
 }
 
 }  // namespace pacoh

@@ -373,7 +373,7 @@ static int max_n_for(int want_grad) {
 
 using namespace pacoh;
 
-// MFMA-blocked fp32 path for n <= 64 (gp_mfma.hip); PACOH_DISABLE_MFMA=1 forces the general LDS kernel
+// MFMA-blocked fp32 path for n <= 128 (gp_mfma.hip); PACOH_DISABLE_MFMA=1 forces the general LDS kernel
 namespace pacoh {
 struct GpMfmaArgs {
     const float* z; int z_div;
@@ -393,7 +393,7 @@ static bool mfma_enabled() {
     return on;
 }
 static int try_mfma(const GpArgs<float>& a, bool bwd, hipStream_t s) {
-    if (!mfma_enabled() || a.n > 64 || a.B <= 0 || a.P <= 0 || a.f <= 0 || a.f > PACOH_MAX_FEATURES ||
+    if (!mfma_enabled() || a.n > 128 || a.B <= 0 || a.P <= 0 || a.f <= 0 || a.f > PACOH_MAX_FEATURES ||
         a.z_div <= 0 || a.y_div <= 0 || !a.z || !a.y || !a.ls || !a.noise || (a.mean_mode != PACOH_MEAN_ZERO && !a.mean))
         return 1;
     GpMfmaArgs m = {a.z, a.z_div, a.mean, a.mean_mode, a.y, a.y_div, a.ls, a.os, a.noise, a.n_valid, a.g_lml,
