@@ -155,11 +155,20 @@ def main():
     f_total, f_gp = gp_flops_per_eval(N_CTX, 2, w_nn)               # W_nn = 2400 MAC/point over both nets
     launches, tot_ms = prof[dom]
     per_launch_s = tot_ms / launches * 1e-3
+    dom_traffic = None                  # HBM bytes per launch of the dominant kernel, from the committed PMC profile
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')) as fh:
+            pk = json.load(fh)['kernels']
+        key = {'mlp_bwd': 'mlp_mfma_bwd', 'gp_lml_fwdbwd': 'gp_mfma_kernel', 'mlp_fwd': 'mlp_mfma_fwd'}.get(dom, dom)
+        cands = [v['hbm_bytes_per_launch'] for k, v in pk.items() if key in k]
+        dom_traffic = cands[0] if cands else None
+    except Exception:
+        pass
     if dom in ('gp_lml_fwdbwd', 'meta_lml_grad'):
         flops = (f_gp if dom == 'gp_lml_fwdbwd' else f_total) * evals_per_gpu
         roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': round(flops / per_launch_s / 1e12, 4),
                     'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(flops / per_launch_s / 1e12 / FP32_PEAK_TFLOPS, 5), 'traffic': None,
+                    'frac': round(flops / per_launch_s / 1e12 / FP32_PEAK_TFLOPS, 5), 'traffic': dom_traffic,
                     'note': 'fp32 VALU/LDS kernel priced against the fp32 peak (vector == f32 MFMA rate); '
                             'algorithmic flops per eval = %.0f (SURVEY 8d model)' % (flops / evals_per_gpu)}
     else:
@@ -168,7 +177,9 @@ def main():
         flops = mult * N_CTX * (w_nn / 2) * evals_per_gpu
         roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': round(flops / per_launch_s / 1e12, 4),
                     'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(flops / per_launch_s / 1e12 / FP32_PEAK_TFLOPS, 5), 'traffic': None}
+                    'frac': round(flops / per_launch_s / 1e12 / FP32_PEAK_TFLOPS, 5), 'traffic': dom_traffic,
+                    'note': 'fp32 MFMA + VALU kernel (registers/LDS only between HBM in/out), priced against the fp32 peak with '
+                            'the 2*n*W (fwd) / 6*n*W (bwd, incl. recompute) flop model, W = %d MAC per point' % (w_nn // 2)}
 
     # ---- standalone Gram build (the HBM-write-bound kernel): same problem count, materialised K ----
     gram = None

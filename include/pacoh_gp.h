@@ -199,6 +199,19 @@ int pacoh_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_
 int pacoh_adam_step_dev(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, const void* scalars,
                         double beta1, double beta2, long count, int dtype, void* stream);
 
+/* y += alpha * x: the plain SGD update of the optimizer='SGD' option (torch.optim.SGD(lr), GPR_meta_mll.py:257). */
+int pacoh_axpy(void* y, const void* x, double alpha, long count, int dtype, void* stream);
+
+/* ---- A10: PACOH-VI, diagonal Gaussian hyper-posterior ------------------------------------------------
+ * posterior[2,D] = {loc, scale (= log std)}; eps[S,D] standard normal draws (host RNG stream of the reference).
+ * sample: theta[s,:] = loc + exp(scale)*eps[s,:]  and  log_q[s] = log N(theta_s; loc, exp(scale)^2)
+ * (Normal(loc, scale.exp()).to_event(1).rsample / .log_prob, random_gp.py:244-248, GPR_meta_vi.py:220-221).
+ * grad: d(-mean_s elbo_s)/d posterior from the per-sample score (GPR_meta_vi.py:221-224 + backward):
+ *   grad[0,:] = -mean_s score[s,:];  grad[1,:] = -mean_s (score[s,:]*exp(scale)*eps[s,:] + prior_factor). */
+int pacoh_vi_sample(const void* posterior, const void* eps, void* theta, void* log_q, int S, int D, int dtype, void* stream);
+int pacoh_vi_grad(const void* posterior, const void* eps, const void* score, double prior_factor, void* grad,
+                  int S, int D, int dtype, void* stream);
+
 /* ---- reductions used by the host between kernels ----------------------------------------------
  * out[p, :] (+)= scale * sum_t in[t, p, :]   (in is [T, P, W]); deterministic (fixed order). */
 int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, int T, int P, int W,

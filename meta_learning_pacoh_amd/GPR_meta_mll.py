@@ -114,7 +114,7 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
                 L.adam_step(p, g, self.exp_avg[0, lo:hi], self.exp_avg_sq[0, lo:hi], lr, self.opt_step,
                             weight_decay=self.weight_decay)
             else:
-                p.add_(g, alpha=-lr)
+                L.axpy(p, g, -lr)
 
     # ---- one meta-training iteration captured in a hipGraph ----------------------------------------
     # A MAP iteration is ~10 launches of a few microseconds each, i.e. launch-bound.  The sequence

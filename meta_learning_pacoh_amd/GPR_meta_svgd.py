@@ -147,7 +147,7 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         if self.optimizer_name == 'Adam':
             L.adam_step(self.particles, neg_phi, self.exp_avg, self.exp_avg_sq, self.lr_scheduler.lr, self.opt_step)
         else:
-            self.particles.add_(neg_phi, alpha=-self.lr_scheduler.lr)
+            L.axpy(self.particles, neg_phi, -self.lr_scheduler.lr)
 
     def meta_fit(self, valid_tuples=None, verbose=True, log_period=500, n_iter=None):
         """GPR_meta_svgd.py:82-121"""

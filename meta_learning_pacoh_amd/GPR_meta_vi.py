@@ -66,22 +66,19 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         return self.posterior[1]
 
     def _rsample(self, n):
-        """Normal(loc, exp(scale)).rsample((n,)): eps from the torch CPU generator (reference stream)"""
+        """Normal(loc, exp(scale)).rsample((n,)): eps from the torch CPU generator (reference stream);
+        returns (theta[n,D], eps[n,D], log q(theta)[n])"""
         eps = standard_normal(n, self.layout.D).to(self.dtype).to(self.device)
-        sigma = torch.exp(self.scale)
-        return (self.loc + eps * sigma).contiguous(), eps, sigma
+        theta, log_q = L.vi_sample(self.posterior, eps)
+        return theta, eps, log_q
 
     def get_neg_elbo_and_grad(self, idx_local, pre_factor):
         """GPR_meta_vi.py:216-224 plus its backward, -> (loss, grad[2, D])"""
         S = self.svi_batch_size
-        theta, eps, sigma = self._rsample(S)
+        theta, eps, log_q = self._rsample(S)
         log_prob, score = self._log_prob_and_score(theta, idx_local, pre_factor)
-        log_q = (-0.5 * eps ** 2 - self.scale - 0.5 * LOG_2PI).sum(-1)
-        elbo = log_prob - self.prior_factor * log_q
-        loss = -elbo.mean()
-        g_loc = -score.mean(0)
-        g_scale = -(score * sigma * eps + self.prior_factor).mean(0)
-        return loss, torch.stack([g_loc, g_scale]).contiguous()
+        loss = -(log_prob - self.prior_factor * log_q).mean()
+        return loss, L.vi_grad(self.posterior, eps, score, self.prior_factor)
 
     def meta_fit(self, valid_tuples=None, verbose=True, log_period=500, n_iter=None):
         """GPR_meta_vi.py:84-128"""
@@ -97,7 +94,7 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
             if self.optimizer_name == 'Adam':
                 L.adam_step(self.posterior, grad, self.exp_avg, self.exp_avg_sq, self.lr_scheduler.lr, self.opt_step)
             else:
-                self.posterior.add_(grad, alpha=-self.lr_scheduler.lr)
+                L.axpy(self.posterior, grad, -self.lr_scheduler.lr)
             self.lr_scheduler.step()
             if itr == 1 or itr % log_period == 0:
                 duration = time.time() - t

@@ -45,6 +45,9 @@ SIGNATURES = {
     'pacoh_svgd_phi': (_i, [_vp, _vp, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_adam_step': (_i, [_vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _l, _l, _i, _vp]),
     'pacoh_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _l, _i, _vp]),
+    'pacoh_axpy': (_i, [_vp, _vp, _d, _l, _i, _vp]),
+    'pacoh_vi_sample': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pacoh_vi_grad': (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _vp]),
     'pacoh_reduce_tasks': (_i, [_vp, _vp, _d, _i, _i, _i, _i, _i, _vp]),
 }
 
@@ -343,6 +346,32 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, scalars, beta1=0.9, beta2=0.
         _check(lib.pacoh_adam_step_dev(_ptr(param), _ptr(grad, param), _ptr(exp_avg, param), _ptr(exp_avg_sq, param),
                                        _ptr(scalars, param), float(beta1), float(beta2), param.numel(), dtype_code(param),
                                        _stream()), 'pacoh_adam_step_dev')
+
+
+def axpy(y, x, alpha):
+    lib = load_library()
+    _check(lib.pacoh_axpy(_ptr(y), _ptr(x, y), float(alpha), y.numel(), dtype_code(y), _stream()), 'pacoh_axpy')
+
+
+def vi_sample(posterior, eps):
+    lib = load_library()
+    S, D = eps.shape
+    theta = torch.empty_like(eps)
+    log_q = torch.empty(S, dtype=eps.dtype, device=eps.device)
+    with _Timed('vi_sample'):
+        _check(lib.pacoh_vi_sample(_ptr(posterior), _ptr(eps, posterior), _ptr(theta), _ptr(log_q), S, D, dtype_code(eps),
+                                   _stream()), 'pacoh_vi_sample')
+    return theta, log_q
+
+
+def vi_grad(posterior, eps, score, prior_factor):
+    lib = load_library()
+    S, D = eps.shape
+    grad = torch.empty_like(posterior)
+    with _Timed('vi_grad'):
+        _check(lib.pacoh_vi_grad(_ptr(posterior), _ptr(eps, posterior), _ptr(score, posterior), float(prior_factor),
+                                 _ptr(grad), S, D, dtype_code(eps), _stream()), 'pacoh_vi_grad')
+    return grad
 
 
 def reduce_tasks(inp, out, scale=1.0, accumulate=False):

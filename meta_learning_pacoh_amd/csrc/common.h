@@ -105,7 +105,16 @@ template <typename T> __device__ __forceinline__ T subwave_sum(T v, int gs) {
     return v;
 }
 
-inline int check_dtype(int dtype) { return (dtype == PACOH_F32 || dtype == PACOH_F64) ? 0 : PACOH_EDTYPE; }
-inline int launch_status() { return hipGetLastError() == hipSuccess ? PACOH_OK : PACOH_ELAUNCH; }
+// check_dtype() is the first call of every launcher: it also clears HIP's sticky per-thread "last error", which
+// the host application may have set with benign codes (PyTorch polls events: hipErrorNotReady) -- otherwise
+// launch_status() would blame our launch for somebody else's status.
+inline int check_dtype(int dtype) {
+    (void)hipGetLastError();
+    return (dtype == PACOH_F32 || dtype == PACOH_F64) ? 0 : PACOH_EDTYPE;
+}
+inline int launch_status() {
+    const hipError_t e = hipGetLastError();
+    return (e == hipSuccess || e == hipErrorNotReady) ? PACOH_OK : PACOH_ELAUNCH;
+}
 
 }  // namespace pacoh

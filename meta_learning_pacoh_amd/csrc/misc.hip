@@ -208,6 +208,50 @@ __global__ void adam_dev_kernel(T* __restrict__ param, const T* __restrict__ gra
     param[q] = p; m[q] = mq; v[q] = vq;
 }
 
+// ---- PACOH-VI: reparameterised sample of the diagonal Gaussian posterior and the ELBO gradient (A10) ----
+// theta[s,d] = loc[d] + exp(scale[d]) * eps[s,d];  log_q[s] = sum_d (-eps^2/2 - scale[d] - log(2 pi)/2)
+template <typename T>
+__global__ void __launch_bounds__(256) vi_sample_kernel(const T* __restrict__ post /*[2,D]*/, const T* __restrict__ eps,
+                                                        T* __restrict__ theta, T* __restrict__ log_q, int D) {
+    __shared__ T red[4];
+    const int s_ = blockIdx.x;
+    const T HALF_LOG2PI = T(0.9189385332046727);
+    T acc = 0;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const T e = eps[(long)s_ * D + d], sc = post[D + d];
+        theta[(long)s_ * D + d] = post[d] + t_exp<T>(sc) * e;
+        acc += T(-0.5) * e * e - sc - HALF_LOG2PI;
+    }
+    acc = subwave_sum<T>(acc, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) log_q[s_] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// grad[0,d] = -mean_s score[s,d];  grad[1,d] = -mean_s (score[s,d] * exp(scale[d]) * eps[s,d] + prior_factor)
+template <typename T>
+__global__ void vi_grad_kernel(const T* __restrict__ post, const T* __restrict__ eps, const T* __restrict__ score,
+                               T prior_factor, T* __restrict__ grad, int S, int D) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    const T sig = t_exp<T>(post[D + d]);
+    T gl = 0, gs = 0;
+    for (int s_ = 0; s_ < S; ++s_) {
+        const T sc = score[(long)s_ * D + d];
+        gl += sc;
+        gs += sc * sig * eps[(long)s_ * D + d] + prior_factor;
+    }
+    grad[d] = -gl / T(S);
+    grad[D + d] = -gs / T(S);
+}
+
+// y += alpha * x  (plain SGD step of the optimizer='SGD' option)
+template <typename T>
+__global__ void axpy_kernel(T* __restrict__ y, const T* __restrict__ x, T alpha, long count) {
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < count) y[q] = fma(alpha, x[q], y[q]);
+}
+
 }  // namespace pacoh
 
 using namespace pacoh;
@@ -345,5 +389,42 @@ extern "C" int pacoh_adam_step_dev(void* param, const void* grad, void* exp_avg,
     else
         hipLaunchKernelGGL(adam_dev_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (double*)param, (const double*)grad,
                            (double*)exp_avg, (double*)exp_avg_sq, (const double*)scalars, 1.0 - beta1, beta2, 1.0 - beta2, count);
+    return launch_status();
+}
+
+extern "C" int pacoh_vi_sample(const void* posterior, const void* eps, void* theta, void* log_q, int S, int D, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!posterior || !eps || !theta || !log_q || S <= 0 || D <= 0) return PACOH_EINVAL;
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(vi_sample_kernel<float>, dim3(S), dim3(256), 0, (hipStream_t)stream, (const float*)posterior, (const float*)eps,
+                           (float*)theta, (float*)log_q, D);
+    else
+        hipLaunchKernelGGL(vi_sample_kernel<double>, dim3(S), dim3(256), 0, (hipStream_t)stream, (const double*)posterior, (const double*)eps,
+                           (double*)theta, (double*)log_q, D);
+    return launch_status();
+}
+
+extern "C" int pacoh_vi_grad(const void* posterior, const void* eps, const void* score, double prior_factor, void* grad,
+                             int S, int D, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!posterior || !eps || !score || !grad || S <= 0 || D <= 0) return PACOH_EINVAL;
+    unsigned blocks = (unsigned)((D + 255) / 256);
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(vi_grad_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)posterior, (const float*)eps,
+                           (const float*)score, (float)prior_factor, (float*)grad, S, D);
+    else
+        hipLaunchKernelGGL(vi_grad_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)posterior, (const double*)eps,
+                           (const double*)score, prior_factor, (double*)grad, S, D);
+    return launch_status();
+}
+
+extern "C" int pacoh_axpy(void* y, const void* x, double alpha, long count, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!y || !x || count <= 0) return PACOH_EINVAL;
+    unsigned blocks = (unsigned)((count + 255) / 256);
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(axpy_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)y, (const float*)x, (float)alpha, count);
+    else
+        hipLaunchKernelGGL(axpy_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (double*)y, (const double*)x, alpha, count);
     return launch_status();
 }

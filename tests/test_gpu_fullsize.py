@@ -82,7 +82,7 @@ def test_cfg4_vi_512_tasks_n128_10_samples(M):
     tasks = env.generate_meta_train_data(T, n)
     model = M.GPRegressionMetaLearnedVI(tasks, svi_batch_size=S, random_seed=3)
     torch.manual_seed(1)
-    theta, eps, sigma = model._rsample(S)
+    theta, eps, _ = model._rsample(S)
     lml, grad, info = model.engine.lml_and_grad(theta, model.tasks, weight=1.0)
     assert lml.shape == (T, S) and bool(torch.isfinite(lml).all())
     halves = [model.tasks.select(torch.arange(q, T, 2, device=theta.device)) for q in range(2)]

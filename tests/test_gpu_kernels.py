@@ -250,7 +250,7 @@ def test_mvn_logprob_dense(L, dtype, n, B):
     A = O.gram_rbf_ard(z, z, ls) + 0.313 * torch.eye(n, dtype=torch.float64)
     r = torch.randn(B, n, generator=g, dtype=torch.float64)
     ref = torch.distributions.MultivariateNormal(torch.zeros(n, dtype=torch.float64), A).log_prob(r) / n
-    ralpha = torch.linalg.solve(A, r.unsqueeze(-1)).squeeze(-1)
+    ralpha = torch.cholesky_solve(r.unsqueeze(-1), torch.linalg.cholesky(A)).squeeze(-1)   # (torch.linalg.solve's batched LU is flaky on many-core hosts)
     logp, alpha, info = L.mvn_logprob_dense(A.to(dtype).to(DEV).contiguous(), r.to(dtype).to(DEV), 1.0 / n, want_alpha=True)
     assert int(info.abs().max()) == 0
     assert maxrel(logp, ref) < (1e-4 if dtype == torch.float32 else 1e-10)
@@ -391,3 +391,31 @@ def test_reduce_tasks(L):
     out = torch.ones(4, 9, dtype=torch.float64, device=DEV)
     L.reduce_tasks(a.to(DEV), out, scale=0.5, accumulate=True)
     assert relerr(out, 1 + 0.5 * a.sum(0)) < 1e-13
+
+
+def test_vi_sample_and_grad_match_reference_and_autograd(L, golden_dir):
+    """theta / log q vs RandomGPPosterior.rsample / .log_prob of the real reference (fixture), ELBO gradient vs autograd"""
+    fx = np.load(os.path.join(golden_dir, 'random_gp_ref.npz'))
+    loc, scale = torch.from_numpy(fx['vi_init_loc']), torch.from_numpy(fx['vi_init_scale'])
+    theta_ref, logq_ref = torch.from_numpy(fx['vi_rsample']), torch.from_numpy(fx['vi_logq'])
+    eps = (theta_ref - loc) / torch.exp(scale)
+    post = torch.stack([loc, scale]).to(DEV)
+    theta, log_q = L.vi_sample(post, eps.to(DEV).contiguous())
+    assert relerr(theta, theta_ref) < 1e-6 and relerr(log_q, logq_ref) < 1e-5
+    S, D = 5, 37
+    g = torch.Generator().manual_seed(4)
+    post64 = torch.randn(2, D, generator=g, dtype=torch.float64) * 0.3
+    eps64 = torch.randn(S, D, generator=g, dtype=torch.float64)
+    A = torch.randn(D, D, generator=g, dtype=torch.float64)
+    leaf = post64.clone().requires_grad_(True)
+    th = leaf[0] + torch.exp(leaf[1]) * eps64
+    logp = -0.5 * ((th @ A) ** 2).sum(-1)                           # any differentiable log-density
+    logq = (-0.5 * eps64 ** 2 - leaf[1] - 0.5 * np.log(2 * np.pi)).sum(-1)
+    (-(logp - 0.01 * logq).mean()).backward()
+    thd = th.detach().clone().requires_grad_(True)
+    score = torch.autograd.grad((-0.5 * ((thd @ A) ** 2).sum(-1)).sum(), thd)[0]
+    grad = L.vi_grad(post64.to(DEV), eps64.to(DEV), score.to(DEV), 0.01)
+    assert relerr(grad, leaf.grad) < 1e-12
+    y = torch.ones(10, dtype=torch.float64, device=DEV)
+    L.axpy(y, torch.arange(10, dtype=torch.float64, device=DEV), -0.5)
+    assert relerr(y, 1 - 0.5 * torch.arange(10, dtype=torch.float64)) < 1e-15
