@@ -459,23 +459,33 @@ __global__ void __launch_bounds__(256, 2) mlp_mfma_bwd_small_kernel(MlpMfmaArgs 
         }
         if (NH == 2) layer_xs<2, true>(wl + OFF_W2, wl + OFF_B2, r, g, H1, H2);
         f32x4 (&HL)[2][4] = (NH == 2) ? H2 : H1;
-        // ---- output layer on the VALU: dW3/db3 partials, dHL^T in place -------------------------------
+        // ---- output layer on the VALU: dW3/db3 partials (summed over the tile's 4 point blocks in registers,
+        //      then ONE read-modify-write of the lane's LDS slot), dHL^T in place ------------------------------
+        {
+            float g0 = 0.f, g1 = 0.f;
 #pragma unroll
-        for (int pb = 0; pb < 4; ++pb) {
-            PB3(0) += gr[pb][0]; PB3(1) += gr[pb][1];
+            for (int pb = 0; pb < 4; ++pb) { g0 += gr[pb][0]; g1 += gr[pb][1]; }
+            PB3(0) += g0; PB3(1) += g1;
 #pragma unroll
             for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const float h = HL[fb][pb][s];
-                    PW3(0, fb, s) += gr[pb][0] * h;
-                    PW3(1, fb, s) += gr[pb][1] * h;
-                    const float d = fmaf(w3r[1][fb][s], gr[pb][1], w3r[0][fb][s] * gr[pb][0]);
-                    HL[fb][pb][s] = d * (1.0f - h * h);
+                    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                    for (int pb = 0; pb < 4; ++pb) {
+                        const float h = HL[fb][pb][s];
+                        t0 = fmaf(gr[pb][0], h, t0);
+                        t1 = fmaf(gr[pb][1], h, t1);
+                        const float d = fmaf(w3r[1][fb][s], gr[pb][1], w3r[0][fb][s] * gr[pb][0]);
+                        HL[fb][pb][s] = d * (1.0f - h * h);
+                    }
+                    PW3(0, fb, s) += t0;
+                    PW3(1, fb, s) += t1;
                 }
         }
         if (NH == 2) {
             // ---- hidden layer: dW2 += dH2-contraction H1 (MFMA, operands transposed on the matrix core) ----
+            f32x4 tB2[2] = {};
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) {
                 f32x4 H1p[2], D2p[2];
@@ -485,14 +495,17 @@ __global__ void __launch_bounds__(256, 2) mlp_mfma_bwd_small_kernel(MlpMfmaArgs 
 #pragma unroll
                     for (int s = 0; s < 4; ++s) { P1 = mfma4x(H1[kb][pb][s], idn[s], P1); P2 = mfma4x(H2[kb][pb][s], idn[s], P2); }
                     H1p[kb] = P1; D2p[kb] = P2;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) PB2(kb, s) += H2[kb][pb][s];
+                    tB2[kb] += H2[kb][pb];
                 }
 #pragma unroll
                 for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb) wgrad(aW2[ob][kb], D2p[ob], H1p[kb]);
             }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) PB2(kb, s) += tB2[kb][s];
             // ---- dH1^T = (W2^T dH2^T) .* (1 - H1^2), written over H1 --------------------------------------
 #pragma unroll
             for (int fb = 0; fb < 2; ++fb) {
@@ -515,17 +528,22 @@ __global__ void __launch_bounds__(256, 2) mlp_mfma_bwd_small_kernel(MlpMfmaArgs 
                     for (int s = 0; s < 4; ++s) { const float h = H1[fb][pb][s]; H1[fb][pb][s] = acc[pb][s] * (1.0f - h * h); }
             }
         }
-        // ---- first layer on the VALU: H1 now holds dH1^T ---------------------------------------------------
+        // ---- first layer on the VALU: H1 now holds dH1^T; tile sums in registers, one LDS update per slot ------
 #pragma unroll
         for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) {
+            for (int s = 0; s < 4; ++s) {
+                float tb = 0.f, tw[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    PB1(fb, s) += H1[fb][pb][s];
+                for (int pb = 0; pb < 4; ++pb) {
+                    const float dh = H1[fb][pb][s];
+                    tb += dh;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) PW1(fb, s, k) += H1[fb][pb][s] * xr[pb][k];
+                    for (int k = 0; k < 4; ++k) tw[k] = fmaf(dh, xr[pb][k], tw[k]);
                 }
+                PB1(fb, s) += tb;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) PW1(fb, s, k) += tw[k];
             }
     }
     // ---- per-lane partials: sum over the 16 point lanes of each lane group ---------------------------------
