@@ -4,6 +4,7 @@
 // the joint test log-likelihood of RegressionModelMetaLearned.eval (meta_learn/abstract.py:134-163),
 // i.e. torch/gpytorch's MultivariateNormal.log_prob -> potrf/potrs on the reference's CPU path.
 #include "common.h"
+#include <stdlib.h>
 
 namespace pacoh {
 
@@ -205,10 +206,22 @@ __global__ void __launch_bounds__(256) chol_dense_kernel(T* __restrict__ A, cons
 
 using namespace pacoh;
 
+namespace pacoh {
+int dense_mfma_try(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
+                   int dtype, hipStream_t s);       // dense_mfma.hip; returns 1 if the panel does not fit in LDS
+}
+
 extern "C" int pacoh_mvn_logprob_dense(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info,
                                        double scale, int B, int n, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!A || !resid || !logp || B <= 0 || n <= 0) return PACOH_EINVAL;
+    {
+        static const bool mfma_on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
+        if (mfma_on) {
+            int rc = dense_mfma_try(A, resid, logp, alpha_out, info, scale, B, n, dtype, (hipStream_t)stream);
+            if (rc != 1) return rc;
+        }
+    }
     size_t lds = ((size_t)n + NB * (NB + 1) + 2 * TT * (NB + 1) + NB + 8) * (dtype == PACOH_F64 ? 8 : 4);
     if (lds > 64u * 1024u) return PACOH_ELIMIT;
     if (dtype == PACOH_F32)
