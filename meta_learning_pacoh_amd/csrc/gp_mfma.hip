@@ -102,6 +102,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // lane needs at step k (column k of the running matrix, later row i of L) are published through LDS and
 // read back as broadcast ds_read_b128 -- this keeps the VALU, which bounds the kernel, free of the
 // 240 v_readlane + IEEE sqrt/divide sequences of a pure register formulation.
+template <int NW>
 __device__ __forceinline__ void factor_diag_block(float* A, int LD, int d0, float* invd, float* scr, int r, bool active) {
     // `active` = this wave does the work (wave 0); other waves of the workgroup only join the barriers.
     // scr[0..31]: double-buffered column broadcast, scr[40]: "a pivot was not positive" flag (sticky per attempt)
@@ -139,7 +140,7 @@ __device__ __forceinline__ void factor_diag_block(float* A, int LD, int d0, floa
             for (int v = 0; v < 4; ++v) { float4 q; q.x = Lr[4 * v]; q.y = Lr[4 * v + 1]; q.z = Lr[4 * v + 2]; q.w = Lr[4 * v + 3]; wrow[v] = q; }
         }
     }
-    __syncthreads();
+    if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     float x[16];
     if (active) {                                                          // X = L11^-1: lane c = r owns column c
 #pragma unroll
@@ -159,7 +160,7 @@ __device__ __forceinline__ void factor_diag_block(float* A, int LD, int d0, floa
             x[i] = s * inv[i];
         }
     }
-    __syncthreads();                                                       // every lane has read L before X overwrites it
+    if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();                                                       // every lane has read L before X overwrites it
     if (active && threadIdx.x < 16) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) A[(d0 + i) * LD + d0 + r] = x[i];
@@ -203,6 +204,9 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
     float* invd = av + NP;                                 // [NP]
     float* scr = invd + NP;                                // [64] broadcast scratch / cross-wave sums
 
+    // One wave per problem (NW == 1): LDS instructions of a wave execute in issue order, so cross-lane hand-offs
+    // through LDS need no s_barrier (and no full lgkmcnt drain); only the compiler must not reorder them.
+#define SYNC() do { if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier(); } while (0)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -239,7 +243,7 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
         for (int c = 0; c < FP; ++c) zf[i * FP + c] = zs[c];
         rv[i] = ri;
     }
-    __syncthreads();
+    SYNC();
 
     // ---- Gram build + blocked Cholesky with the psd_safe_cholesky jitter ladder -----------------
     int my_info = -1;
@@ -268,12 +272,12 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
             }
         }
         if (tid == 0) scr[40] = 0.0f;
-        __syncthreads();
+        SYNC();
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
             const int k0 = kb * 16;
-            factor_diag_block(A, LD, k0, invd, scr, r, wave == 0);        // wave 0 works, the others join its barriers
-            __syncthreads();
+            factor_diag_block<NW>(A, LD, k0, invd, scr, r, wave == 0);        // wave 0 works, the others join its barriers
+            SYNC();
             // panel: L[ib][kb] = A[ib][kb] * Linv^T   (block rows dealt to the waves)
 #pragma unroll
             for (int ib = kb + 1; ib < NB; ++ib) {
@@ -283,7 +287,7 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
                     store_c(A, LD, ib * 16, k0, r, g, acc);   // same wave read it just before: in-order LDS
                 }
             }
-            __syncthreads();
+            SYNC();
             // trailing update: A[ib][jb] -= L[ib][kb] L[jb][kb]^T
             int q = 0;
 #pragma unroll
@@ -297,10 +301,10 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
                     }
                 }
             }
-            __syncthreads();
+            SYNC();
         }
         const bool ok = scr[40] == 0.0f;
-        __syncthreads();                                                   // flag read by all before the next attempt clears it
+        SYNC();                                                   // flag read by all before the next attempt clears it
         if (ok) { my_info = attempt; break; }
         jitter = 1e-6f;
         for (int q = 0; q < attempt; ++q) jitter *= 10.0f;
@@ -328,7 +332,7 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
             }
         }
     }
-    __syncthreads();
+    SYNC();
     // ---- u = Z r (thread i = row i of Z = column i of the upper storage + its diagonal-block row) -------
     float ui = 0.0f;
     if (i < NP) {
@@ -374,7 +378,7 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
             for (int jb = 0; jb <= ib; ++jb) store_c(A, LD, ib * 16, jb * 16, r, g, Wb[jb]);
         }
     }
-    __syncthreads();
+    SYNC();
     {   // mirror the strictly-lower blocks into the upper triangle (Z^T is dead now)
         int q = 0;
 #pragma unroll
@@ -385,7 +389,7 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
             }
         }
     }
-    __syncthreads();
+    SYNC();
     // ---- alpha = W r ------------------------------------------------------------------------------
     float ai = 0.0f;
     if (i < NP) {
@@ -398,7 +402,7 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
         }
         av[i] = ai;
     }
-    __syncthreads();
+    SYNC();
     // ---- gradient sums: thread i owns row i of W ---------------------------------------------------
     const float gup = a.g_lml ? a.g_lml[b] : 1.0f;
     float dz[FP], dls[FP];
@@ -444,6 +448,8 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
         a.d_noise[b] = gup * sdnz + bad;
     }
 }
+
+#undef SYNC
 
 template <int NB, bool BWD>
 static int launch_nb(const GpMfmaArgs& a, int FP, hipStream_t s) {

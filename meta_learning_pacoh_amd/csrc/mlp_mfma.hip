@@ -582,15 +582,21 @@ __global__ void __launch_bounds__(256, 2) mlp_mfma_bwd_small_kernel(MlpMfmaArgs 
 #undef PB2
 #undef PB3
 
+// out[p, w] (+)= sum_c in[c, p, w]: 8 lanes per output element split the slabs, fixed order -> deterministic
 template <typename T>
-__global__ void reduce_slab_kernel(const T* __restrict__ in, T* __restrict__ out, long out_stride, int accumulate, int C, int P, int Wd) {
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)P * Wd) return;
-    int p = (int)(idx / Wd), w = (int)(idx - (long)p * Wd);
+__global__ void __launch_bounds__(256) reduce_slab_kernel(const T* __restrict__ in, T* __restrict__ out, long out_stride, int accumulate,
+                                                          int C, int P, int Wd) {
+    const long tot = (long)P * Wd;
+    const long idx = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int part = threadIdx.x & 7;
     T s = 0;
-    for (int c = 0; c < C; ++c) s += in[((long)c * P + p) * Wd + w];
-    T* o = out + (long)p * out_stride + w;
-    *o = accumulate ? *o + s : s;
+    if (idx < tot) for (int c = part; c < C; c += 8) s += in[(long)c * tot + idx];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (idx < tot && part == 0) {
+        const int p = (int)(idx / Wd), w = (int)(idx - (long)p * Wd);
+        T* o = out + (long)p * out_stride + w;
+        *o = accumulate ? *o + s : s;
+    }
 }
 
 static bool mlp_mfma_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_out) {
@@ -667,7 +673,7 @@ int mlp_mfma_bwd(const void* x, int x_div, const void* theta, long theta_stride,
     } else if (n_hidden == 2) hipLaunchKernelGGL(mlp_mfma_bwd_kernel<2>, dim3(chunks, P), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(mlp_mfma_bwd_kernel<1>, dim3(chunks, P), dim3(256), 0, s, a);
     long tot = (long)P * a.D_net;
-    hipLaunchKernelGGL(reduce_slab_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(reduce_slab_kernel<float>, dim3((unsigned)((tot * 8 + 255) / 256)), dim3(256), 0, s,
                        (const float*)workspace, (float*)d_theta, d_theta_stride, accumulate, slabs, P, a.D_net);
     return launch_status();
 }
