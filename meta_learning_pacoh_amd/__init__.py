@@ -8,3 +8,4 @@ __version__ = '0.1.0'
 from .GPR_meta_mll import GPRegressionMetaLearned          # noqa: E402,F401
 from .GPR_meta_svgd import GPRegressionMetaLearnedSVGD     # noqa: E402,F401
 from .GPR_meta_vi import GPRegressionMetaLearnedVI         # noqa: E402,F401
+from .GPR_mll import GPRegressionLearned                   # noqa: E402,F401

@@ -665,6 +665,65 @@ class MapOracle:
         return tuple(res.mean(0))
 
 
+class SingleTaskOracle(MapOracle):
+    """Plain-torch restatement of the single-task learner GPRegressionLearned (meta_learn/GPR_mll.py:11-216,
+    RegressionModel abstract.py:7-115).  It differs from PACOH-MAP in: normalisation statistics of the one
+    training set, the default GaussianLikelihood noise bound 1e-4 [gpytorch-upstream] (GPR_mll.py:88), AdamW's
+    DEFAULT weight decay 1e-2 on every non-NN group (GPR_mll.py:57,69,82,92), only the groups selected by
+    `learning_mode` being trained, and ReduceLROnPlateau stepped at the log lines (GPR_mll.py:104-107,148).
+    Its fit() log is checked against the recorded demo.ipynb output (tests/test_oracle_golden_demo.py)."""
+
+    def __init__(self, train_x, train_t, learning_mode='both', lr=1e-3, weight_decay=0.0, feature_dim=2,
+                 num_iter_fit=1000, covar_module='NN', mean_module='NN', mean_nn_layers=(32, 32),
+                 kernel_nn_layers=(32, 32), normalize_data=True, lr_scheduler=True, random_seed=None,
+                 dtype=torch.float32):
+        super().__init__([(train_x, train_t)], lr_params=lr, weight_decay=weight_decay, feature_dim=feature_dim,
+                         num_iter_fit=num_iter_fit, covar_module=covar_module, mean_module=mean_module,
+                         mean_nn_layers=mean_nn_layers, kernel_nn_layers=kernel_nn_layers, task_batch_size=1,
+                         normalize_data=normalize_data, random_seed=random_seed, dtype=dtype)
+        groups = []
+        if self.kernel_net is not None:
+            groups.append({'params': [q for m in self.kernel_net for q in (m.weight, m.bias)], 'weight_decay': weight_decay})
+        if self.mean_net is not None:
+            groups.append({'params': [q for m in self.mean_net for q in (m.weight, m.bias)], 'weight_decay': weight_decay})
+        groups.append({'params': [self.raw_noise]})
+        if learning_mode in ('learn_kernel', 'both'):
+            groups.append({'params': [self.raw_lengthscale, self.raw_outputscale]})
+        if learning_mode in ('learn_mean', 'both') and mean_module == 'constant':
+            groups.append({'params': [self.constant_mean]})
+        self.optimizer = torch.optim.AdamW(groups, lr=lr)              # default weight_decay = 1e-2
+        self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode='max',
+                                                                    factor=0.2 if lr_scheduler else 1.0)
+        self.train_x, self.train_t = train_x, train_t
+
+    def hypers(self):
+        ls = F.softplus(self.raw_lengthscale)
+        os_ = F.softplus(self.raw_outputscale)
+        noise = F.softplus(self.raw_noise) + 1e-4                      # GreaterThan(1e-4) default
+        return ls, os_, noise.squeeze(0)
+
+    def fit(self, valid_x=None, valid_t=None, log_period=500, n_iter=None):
+        """GPR_mll.py:111-168 -> list of (itr, loss[, valid_ll, rmse, calib])"""
+        n_iter = self.num_iter_fit if n_iter is None else n_iter
+        log = []
+        for itr in range(1, n_iter + 1):
+            self.optimizer.zero_grad()
+            loss = -self.task_mll(*self.tasks[0])
+            loss.backward()
+            self.optimizer.step()
+            if itr == 1 or itr % log_period == 0:
+                rec = (itr, float(loss.detach()))
+                if valid_x is not None:
+                    ev = self.eval(self.train_x, self.train_t, valid_x, valid_t)
+                    self.scheduler.step(ev[0])
+                    rec = rec + tuple(ev)
+                log.append(rec)
+        return log
+
+    def predict_single(self, test_x):
+        return self.predict_normalized(self.train_x, self.train_t, test_x)
+
+
 # --------------------------------------------------------------------------------------
 # synthetic task generators used by bench.py / tests (SURVEY 8d)
 # --------------------------------------------------------------------------------------

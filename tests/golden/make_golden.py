@@ -223,6 +223,12 @@ def main():
         'final_test': {'ll': 0.03293633884750306, 'rmse': 0.3090165838599205,
                        'calib': 0.13442028164863587},
     }
+    # GPRegressionLearned cell of demo.ipynb (single-task baseline), transcribed
+    demo_log['single_task'] = {
+        'source': 'demo.ipynb (GPRegressionLearned cell output)',
+        'config': "x_context, y_context, x_test, y_test = meta_test_data[0]; GPRegressionLearned(x_context, y_context, "
+                  "learning_mode='learn_mean', covar_module='SE', mean_module='constant', random_seed=30).fit(x_test, y_test)",
+        'log': [[1, 1.436, -1.315, 1.402, 0.290], [500, 1.436, -1.309, 1.405, 0.296], [1000, 1.436, -1.309, 1.405, 0.296]]}
     with open(os.path.join(OUT, 'demo_log.json'), 'w') as f:
         json.dump(demo_log, f, indent=1)
     print('fixtures written to', OUT)

@@ -262,3 +262,101 @@ def test_vi_elbo_and_grad_match_oracle(M):
     assert mu.shape == (n,) and bool((sd > 0).all())
     mu_map, sd_map = model.predict(tasks[0][0], tasks[0][1], tasks[1][0], mode='MAP')
     assert mu_map.shape == (n,)
+
+
+# ------------------------------------------------------------------------------------------ single task
+def test_single_task_learner_reproduces_recorded_reference_log(M, golden_dir):
+    """GPRegressionLearned cell of demo.ipynb (learn_mean / SE / constant, seed 30) on the HIP path"""
+    with open(os.path.join(golden_dir, 'demo_log.json')) as f:
+        gold = json.load(f)['single_task']['log']
+    _, test = demo_data()
+    xc, yc, xt, yt = test[0]
+    gp = M.GPRegressionLearned(xc, yc, learning_mode='learn_mean', covar_module='SE', mean_module='constant', random_seed=30)
+    logs = []
+    for n_it in (1, 499, 500):
+        loss = gp.fit(xt, yt, verbose=False, n_iter=n_it, log_period=10 ** 9)
+        logs.append((loss,) + gp.eval(xt, yt))
+    for got, ref in zip(logs, gold):
+        for k in range(4):
+            assert abs(got[k] - ref[k + 1]) < 1.5e-3, (got, ref)
+
+
+@pytest.mark.parametrize('mode,covar,mean', [('both', 'NN', 'NN'), ('learn_kernel', 'SE', 'zero'), ('both', 'SE', 'constant'),
+                                             ('vanilla', 'SE', 'constant')])
+def test_single_task_learner_matches_oracle(M, mode, covar, mean):
+    tasks = O.sinusoid_tasks_nd(2, 40, 2, seed0=77)
+    (x, t), (vx, vt) = tasks[0], (tasks[0][0][:15] + 0.3, tasks[0][1][:15])
+    kw = dict(learning_mode=mode, covar_module=covar, mean_module=mean, weight_decay=0.1, lr=5e-3, random_seed=12)
+    gp = M.GPRegressionLearned(x, t, **kw)
+    orc = O.SingleTaskOracle(x, t, **kw)
+    log_o = orc.fit(vx, vt, log_period=20, n_iter=60)
+    loss = gp.fit(vx, vt, verbose=False, log_period=20, n_iter=60)
+    assert abs(loss - log_o[-1][1]) < 2e-3 * max(1.0, abs(log_o[-1][1]))
+    ll, rmse, calib = gp.eval(vx, vt)
+    assert abs(ll - log_o[-1][2]) < 5e-3 * max(1.0, abs(log_o[-1][2])) and abs(rmse - log_o[-1][3]) < 2e-3
+    lay = gp.layout
+    for name, ref in (('noise_raw', orc.raw_noise), ('lengthscale_raw', orc.raw_lengthscale), ('outputscale_raw', orc.raw_outputscale)):
+        lo, hi = lay.slices[name]
+        assert torch.allclose(gp.theta[0, lo:hi].cpu(), ref.detach().reshape(-1), atol=2e-4), name
+    pm, ps = gp.predict(vx)
+    mean_n, cov_n = orc.predict_single(vx)
+    assert relerr(pm, mean_n * orc.stats[3][0] + orc.stats[2][0]) < 1e-3
+    assert relerr(ps, torch.sqrt(torch.diagonal(cov_n)) * orc.stats[3][0]) < 2e-3
+    ucb, lcb = gp.confidence_intervals(vx)
+    assert bool((ucb > lcb).all())
+
+
+def test_single_task_state_dict_round_trip(M):
+    x, t = O.sinusoid_tasks_nd(1, 30, 1, seed0=5)[0]
+    a = M.GPRegressionLearned(x, t, random_seed=3)
+    a.fit(verbose=False, n_iter=20)
+    b = M.GPRegressionLearned(x, t, random_seed=4)
+    b.load_state_dict(a.state_dict())
+    pa, pb = a.predict(x[:7]), b.predict(x[:7])
+    assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1])
+    a.fit(verbose=False, n_iter=5); b.fit(verbose=False, n_iter=5)
+    assert torch.equal(a.theta, b.theta)
+
+
+def _toy_1d():
+    """data of the reference's single-task tests (tests/test_GPR.py:12-33)"""
+    np.random.seed(25)
+    x = np.linspace(-2, 2, num=60)
+    y_two = x * 0 + 2 + np.random.normal(scale=0.02, size=x.shape)
+    return x, y_two, np.sin(4 * x)
+
+
+def test_single_task_random_seed_consistency(M):
+    """tests/test_GPR.py:26-39"""
+    x, y_two, _ = _toy_1d()
+    kw = dict(learning_mode='both', num_iter_fit=5, mean_module='NN', covar_module='NN')
+    g1, g2, g3 = (M.GPRegressionLearned(x, y_two, random_seed=s, **kw) for s in (22, 22, 23))
+    for g in (g1, g2, g3):
+        g.fit(verbose=False)
+    xt = np.linspace(-2.1, 2.1, num=80)
+    p1, p2, p3 = g1.predict(xt), g2.predict(xt), g3.predict(xt)
+    assert np.array_equal(p1[0], p2[0]) and np.array_equal(p1[1], p2[1])
+    assert not np.array_equal(p1[0], p3[0])
+
+
+def test_single_task_mean_and_kernel_learning_help(M):
+    """tests/test_GPR.py:67-84,113-143: a learned NN mean / NN kernel beats the vanilla GP on sin(4x)"""
+    x, _, y_sin = _toy_1d()
+    torch.manual_seed(22)
+    vanilla = M.GPRegressionLearned(x, y_sin, learning_mode='vanilla', num_iter_fit=20, mean_module='constant', covar_module='SE')
+    vanilla.fit(verbose=False)
+    learn_mean = M.GPRegressionLearned(x, y_sin, learning_mode='learn_mean', num_iter_fit=100, mean_module='NN',
+                                       covar_module='SE', mean_nn_layers=(16, 16))
+    learn_mean.fit(verbose=False)
+    ll_v, rmse_v, _ = vanilla.eval(x, y_sin)
+    ll_m, rmse_m, _ = learn_mean.eval(x, y_sin)
+    assert ll_m > ll_v and rmse_m < rmse_v
+    for mode in ('learn_kernel', 'both'):
+        base = M.GPRegressionLearned(x, y_sin, learning_mode='learn_kernel', num_iter_fit=1, mean_module='zero', covar_module='NN')
+        base.fit(verbose=False)
+        learned = M.GPRegressionLearned(x, y_sin, learning_mode=mode, num_iter_fit=500, mean_module='constant', covar_module='NN',
+                                        kernel_nn_layers=(16, 16), mean_nn_layers=(16, 16))
+        learned.fit(valid_x=x, valid_t=y_sin, verbose=False)
+        ll_b, rmse_b, _ = base.eval(x, y_sin)
+        ll_k, rmse_k, _ = learned.eval(x, y_sin)
+        assert ll_k > ll_b and rmse_k < rmse_b

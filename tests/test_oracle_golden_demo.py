@@ -34,3 +34,19 @@ def test_map_oracle_reproduces_recorded_reference_trajectory(golden_dir):
     assert abs(final[0] - gold['final_test']['ll']) < 2e-3
     assert abs(final[1] - gold['final_test']['rmse']) < 2e-3
     assert abs(final[2] - gold['final_test']['calib']) < 2e-3
+
+
+def test_single_task_oracle_reproduces_recorded_reference_log(golden_dir):
+    """GPRegressionLearned cell of demo.ipynb: loss / valid-LL / RMSE / calibration printed with 3 decimals"""
+    with open(os.path.join(golden_dir, 'demo_log.json')) as f:
+        gold = json.load(f)['single_task']
+    env = O.SinusoidDataset(np.random.RandomState(26))
+    env.generate_meta_train_data(20, 5)
+    xc, yc, xt, yt = env.generate_meta_test_data(20, 5, 50)[0]
+    model = O.SingleTaskOracle(xc, yc, learning_mode='learn_mean', covar_module='SE', mean_module='constant', random_seed=30)
+    log = model.fit(xt, yt)
+    assert len(log) == len(gold['log'])
+    for got, ref in zip(log, gold['log']):
+        assert got[0] == ref[0]
+        for k in (1, 2, 3, 4):
+            assert abs(got[k] - ref[k]) < 6e-4, (got, ref)
