@@ -185,6 +185,18 @@ size_t pacoh_svgd_workspace_bytes(int P, int D, int dtype);
 int pacoh_svgd_phi(const void* X, const void* score, double bandwidth, int neg, void* phi,
                    void* bw_out, void* workspace, int P, int D, int dtype, void* stream);
 
+/* Same update direction with the IMQ particle kernel k_ij = (alpha + sum_d (X_jd - X_id)^2 / h_d)^beta
+ * (alpha > 0, beta < 0).  bandwidth > 0: h_d = bandwidth for every d.  bandwidth <= 0: per-dimension median
+ * heuristic h_d = lower-median_{a<b} (X_bd - X_ad)^2 / ln(P+1) (torch.median semantics), written to h_out[D]
+ * (required in that case); phi then also carries the derivative through h_d that the reference's autograd
+ * produces (the bandwidth is built from the differentiable squared differences).
+ * Replaces SVGD.phi + IMQSteinKernel (meta_learn/svgd.py:12-23, 63-97; selected at GPR_meta_svgd.py:176-177).
+ * P <= 64.  workspace: pacoh_svgd_imq_workspace_bytes(). */
+size_t pacoh_svgd_imq_workspace_bytes(int P, int D, int dtype);
+int pacoh_svgd_phi_imq(const void* X, const void* score, double alpha, double beta, double bandwidth,
+                       int neg, void* phi, void* h_out, void* workspace, int P, int D, int dtype,
+                       void* stream);
+
 /* ---- A8/A9/A10: optimizer step -----------------------------------------------------------------
  * One fused Adam / AdamW (decoupled weight decay) step over `count` parameters, state m,v in place;
  * `step` is the 1-based step count (bias correction), matching torch.optim.Adam / AdamW defaults

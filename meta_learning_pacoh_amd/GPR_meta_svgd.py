@@ -119,8 +119,9 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         super().__init__(normalize_data, random_seed)
         assert mean_module in ['NN', 'constant', 'zero'] and covar_module in ['NN', 'SE']
         assert optimizer in ['Adam', 'SGD']
-        if kernel != 'RBF':
-            raise NotImplementedError('only the RBF particle kernel is on the HIP path (IMQ: SURVEY 8f, next)')
+        if kernel not in ('RBF', 'IMQ'):                       # GPR_meta_svgd.py:173-179
+            raise NotImplementedError
+        self.kernel = kernel
         assert num_particles <= 64, 'pacoh_svgd_phi supports up to 64 particles'
         self.num_iter_fit, self.prior_factor, self.feature_dim = num_iter_fit, prior_factor, feature_dim
         self.weight_prior_std, self.bias_prior_std = weight_prior_std, bias_prior_std
@@ -141,8 +142,9 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
     def svgd_step(self, idx_local, pre_factor):
         """SVGD.step (meta_learn/svgd.py:25-28): particles.grad = -phi; optimizer.step()"""
         _, score = self._log_prob_and_score(self.particles, idx_local, pre_factor)
-        neg_phi, self.last_bandwidth, self._svgd_ws = L.svgd_phi(self.particles, score, self.bandwidth, neg=True,
-                                                                 workspace=self._svgd_ws)
+        phi_fn = L.svgd_phi if self.kernel == 'RBF' else L.svgd_phi_imq     # IMQ: alpha=0.5, beta=-0.5 (svgd.py:70)
+        neg_phi, self.last_bandwidth, self._svgd_ws = phi_fn(self.particles, score, bandwidth=self.bandwidth, neg=True,
+                                                             workspace=self._svgd_ws)
         self.opt_step += 1
         if self.optimizer_name == 'Adam':
             L.adam_step(self.particles, neg_phi, self.exp_avg, self.exp_avg_sq, self.lr_scheduler.lr, self.opt_step)

@@ -43,6 +43,8 @@ SIGNATURES = {
     'pacoh_prior_logprob_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
     'pacoh_svgd_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_phi': (_i, [_vp, _vp, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pacoh_svgd_imq_workspace_bytes': (_sz, [_i, _i, _i]),
+    'pacoh_svgd_phi_imq': (_i, [_vp, _vp, _d, _d, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_adam_step': (_i, [_vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _l, _l, _i, _vp]),
     'pacoh_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _l, _i, _vp]),
     'pacoh_axpy': (_i, [_vp, _vp, _d, _l, _i, _vp]),
@@ -325,6 +327,24 @@ def svgd_phi(X, score, bandwidth=None, neg=False, workspace=None):
         _check(lib.pacoh_svgd_phi(_ptr(X), _ptr(score, X), bw, int(bool(neg)), _ptr(phi), _ptr(bw_out), _ptr(workspace),
                                   P, D, code, _stream()), 'pacoh_svgd_phi')
     return phi, bw_out, workspace
+
+
+def svgd_phi_imq(X, score, alpha=0.5, beta=-0.5, bandwidth=None, neg=False, workspace=None):
+    """-> (phi[P,D], h[D] | None (fixed bandwidth), workspace)"""
+    lib = load_library()
+    P, D = X.shape
+    code = dtype_code(X)
+    need = lib.pacoh_svgd_imq_workspace_bytes(P, D, code)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=X.device)
+    phi = torch.empty_like(X)
+    h_out = torch.empty(D, dtype=X.dtype, device=X.device) if bandwidth is None else None
+    bw = -1.0 if bandwidth is None else float(bandwidth)
+    with _Timed('svgd_phi'):
+        _check(lib.pacoh_svgd_phi_imq(_ptr(X), _ptr(score, X), float(alpha), float(beta), bw, int(bool(neg)), _ptr(phi),
+                                      _ptr(h_out) if h_out is not None else None, _ptr(workspace), P, D, code, _stream()),
+               'pacoh_svgd_phi_imq')
+    return phi, h_out, workspace
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):

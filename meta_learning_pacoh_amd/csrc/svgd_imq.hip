@@ -1,0 +1,200 @@
+// SVGD update direction with the IMQ (inverse multi-quadratic) particle kernel and its per-dimension
+// median bandwidth: replaces SVGD.phi + IMQSteinKernel.forward/_bandwidth (meta_learn/svgd.py:12-23, 63-97),
+// selected by GPRegressionMetaLearnedSVGD(kernel='IMQ') (GPR_meta_svgd.py:176-177).
+//
+//   h_d      = lower-median_{a<b} (x_bd - x_ad)^2 / log(P+1)              (or the caller's scalar bandwidth)
+//   base_ij  = alpha + sum_d (x_jd - x_id)^2 / h_d,   k_ij = base_ij^beta,   kb_ij = beta base_ij^(beta-1)
+//   phi_jd   = ( sum_i k_ji s_id - (2/h_d) sum_i kb_ij (x_jd - x_id)
+//                + [j == b_d] (sum_il kb_il (x_ld - x_id)^2 / h_d^2) 2 (x_bd - x_ad) / log(P+1) ) / P
+// The last term is the derivative THROUGH the median bandwidth: the reference builds h from the differentiable
+// squared differences, so autograd sends a gradient to the later particle b of each dimension's median pair.
+//
+// All three kernels are HBM/latency-trivial (P*D = 50k elements at the headline shape); they are laid out so that
+// every global access is coalesced along d and the P^2 matrices are read through scalar loads.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pacoh_gp.h"
+#include "common.h"
+
+using namespace pacoh;
+
+namespace {
+
+template <typename T> struct BitsOf;
+template <> struct BitsOf<float> { using U = uint32_t; static constexpr int NB = 32; };
+template <> struct BitsOf<double> { using U = uint64_t; static constexpr int NB = 64; };
+__device__ __forceinline__ uint32_t to_bits(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ uint64_t to_bits(double v) { return (uint64_t)__double_as_longlong(v); }
+__device__ __forceinline__ float from_bits(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ double from_bits(uint64_t u) { return __longlong_as_double((long long)u); }
+
+// ---- stage 1: per-dimension lower median over the P(P-1)/2 pairs --------------------------------------------
+// 16 dimensions per 256-thread workgroup, 16 lanes per dimension.  The k-th smallest of the (non-negative)
+// squared differences is found by bisection on the IEEE bit pattern (monotone for v >= 0): NB-1 rounds of
+// "count values below the candidate", each lane counting its share of the pairs, 4 shuffles per round.
+template <typename T>
+__global__ void __launch_bounds__(256) imq_bw_kernel(const T* __restrict__ X, T* __restrict__ h, T* __restrict__ dh,
+                                                     int32_t* __restrict__ bidx, T log_p1, int P, int D) {
+    using U = typename BitsOf<T>::U;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int Pp = P | 1;
+    T* xs = reinterpret_cast<T*>(smem_raw);                          // [16][Pp]
+    uint16_t* tab = reinterpret_cast<uint16_t*>(xs + 16 * Pp);       // [npairs]  (a << 8 | b), row-major a < b
+    const int npairs = P * (P - 1) / 2;
+    const int d0 = blockIdx.x * 16;
+    for (int idx = threadIdx.x; idx < P * 16; idx += 256) {
+        const int p = idx >> 4, c = idx & 15;
+        const int d = min(d0 + c, D - 1);
+        xs[c * Pp + p] = X[(long)p * D + d];
+    }
+    for (int a = threadIdx.x; a < P - 1; a += 256) {
+        int q = a * P - a * (a + 1) / 2;                            // index of pair (a, a+1)
+        for (int b = a + 1; b < P; ++b) tab[q++] = (uint16_t)((a << 8) | b);
+    }
+    __syncthreads();
+    const int dl = threadIdx.x >> 4, ln = threadIdx.x & 15;
+    const T* xd = xs + dl * Pp;
+    const int k = (npairs - 1) / 2;
+    U result = 0;
+    for (int bit = BitsOf<T>::NB - 2; bit >= 0; --bit) {
+        const U cand = result | (U(1) << bit);
+        int cnt = 0;
+        for (int q = ln; q < npairs; q += 16) {
+            const int pr = tab[q];
+            const T df = xd[pr & 255] - xd[pr >> 8];
+            cnt += to_bits(df * df) < cand ? 1 : 0;
+        }
+        cnt += __shfl_xor(cnt, 1, 64); cnt += __shfl_xor(cnt, 2, 64);
+        cnt += __shfl_xor(cnt, 4, 64); cnt += __shfl_xor(cnt, 8, 64);
+        if (cnt <= k) result = cand;
+    }
+    // first pair (row-major) that attains the median
+    int qmin = 0x7fffffff;
+    for (int q = ln; q < npairs; q += 16) {
+        const int pr = tab[q];
+        const T df = xd[pr & 255] - xd[pr >> 8];
+        if (to_bits(df * df) == result) qmin = min(qmin, q);
+    }
+    qmin = min(qmin, __shfl_xor(qmin, 1, 64)); qmin = min(qmin, __shfl_xor(qmin, 2, 64));
+    qmin = min(qmin, __shfl_xor(qmin, 4, 64)); qmin = min(qmin, __shfl_xor(qmin, 8, 64));
+    const int d = d0 + dl;
+    if (ln == 0 && d < D) {
+        const int pr = tab[min(qmin, npairs - 1)];
+        const int a = pr >> 8, b = pr & 255;
+        h[d] = from_bits(result) / log_p1;
+        dh[d] = T(2) * (xd[b] - xd[a]) / log_p1;
+        bidx[d] = b;
+    }
+}
+
+// ---- stage 2: base_ij, k_ij, kb_ij; one wave per pair j <= i -------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64) imq_kmat_kernel(const T* __restrict__ X, const T* __restrict__ h, T h_fixed,
+                                                      T alpha, T beta, T* __restrict__ Kmat, T* __restrict__ Kb,
+                                                      int P, int D) {
+    const int i = blockIdx.x / P, j = blockIdx.x - i * P;
+    if (j > i) return;
+    const T* xi = X + (long)i * D;
+    const T* xj = X + (long)j * D;
+    T acc = 0;
+    for (int d = threadIdx.x; d < D; d += 64) {
+        const T df = xi[d] - xj[d];
+        acc += df * df / (h ? h[d] : h_fixed);
+    }
+    acc = subwave_sum<T>(acc, 64);
+    if (threadIdx.x == 0) {
+        const T base = alpha + acc;
+        const T kv = t_exp<T>(beta * t_log<T>(base));
+        const T kb = beta * kv / base;
+        Kmat[i * P + j] = kv; Kmat[j * P + i] = kv;
+        Kb[i * P + j] = kb; Kb[j * P + i] = kb;
+    }
+}
+
+// ---- stage 3: phi; one thread per dimension, particle columns staged in LDS -----------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64) imq_phi_kernel(const T* __restrict__ X, const T* __restrict__ score,
+                                                     const T* __restrict__ Kmat, const T* __restrict__ Kb,
+                                                     const T* __restrict__ h, const T* __restrict__ dh,
+                                                     const int32_t* __restrict__ bidx, T h_fixed, int neg,
+                                                     T* __restrict__ phi, int P, int D) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* xs = reinterpret_cast<T*>(smem_raw);          // [P][64]
+    T* ss = xs + P * 64;                             // [P][64]
+    const int t = threadIdx.x;
+    const int d = blockIdx.x * 64 + t;
+    const int dc = min(d, D - 1);
+    for (int p = 0; p < P; ++p) {
+        xs[p * 64 + t] = X[(long)p * D + dc];
+        ss[p * 64 + t] = score[(long)p * D + dc];
+    }
+    // lane-private columns: no barrier needed
+    const T hd = h ? h[dc] : h_fixed;
+    const T two_over_h = T(2) / hd;
+    const T sgn = (neg ? T(-1) : T(1)) / T(P);
+    T S = 0;
+    for (int j = 0; j < P; ++j) {
+        const T xj = xs[j * 64 + t];
+        const T* Kj = Kmat + j * P;                  // wave-uniform -> scalar loads
+        const T* Kbj = Kb + j * P;
+        T acc = 0, g = 0;
+        for (int i = 0; i < P; ++i) {
+            const T df = xj - xs[i * 64 + t];
+            const T kb = Kbj[i];
+            acc = fma(Kj[i], ss[i * 64 + t], acc);
+            g = fma(kb, df, g);
+            S = fma(kb * df, df, S);
+        }
+        if (d < D) phi[(long)j * D + d] = sgn * (acc - two_over_h * g);
+    }
+    if (h && d < D) {
+        const long q = (long)bidx[d] * D + d;
+        phi[q] += sgn * (S / (hd * hd)) * dh[d];
+    }
+}
+
+template <typename T>
+int imq_launch(const void* X, const void* score, double alpha, double beta, double bandwidth, int neg, void* phi,
+               void* h_out, void* workspace, int P, int D, hipStream_t s) {
+    T* Kmat = (T*)workspace;
+    T* Kb = Kmat + P * P;
+    T* dh = Kb + P * P;
+    int32_t* bidx = (int32_t*)(dh + D);
+    T* harr = (T*)h_out;
+    const bool median = !(bandwidth > 0.0);
+    if (median) {
+        const int Pp = P | 1;
+        size_t lds = (size_t)16 * Pp * sizeof(T) + (size_t)(P * (P - 1) / 2) * sizeof(uint16_t);
+        hipLaunchKernelGGL(imq_bw_kernel<T>, dim3((D + 15) / 16), dim3(256), lds, s, (const T*)X, harr, dh, bidx,
+                           (T)log((double)P + 1.0), P, D);
+    }
+    hipLaunchKernelGGL(imq_kmat_kernel<T>, dim3(P * P), dim3(64), 0, s, (const T*)X, median ? (const T*)harr : (const T*)nullptr,
+                       (T)bandwidth, (T)alpha, (T)beta, Kmat, Kb, P, D);
+    hipLaunchKernelGGL(imq_phi_kernel<T>, dim3((D + 63) / 64), dim3(64), (size_t)2 * P * 64 * sizeof(T), s, (const T*)X,
+                       (const T*)score, (const T*)Kmat, (const T*)Kb, median ? (const T*)harr : (const T*)nullptr,
+                       (const T*)dh, (const int32_t*)bidx, (T)bandwidth, neg, (T*)phi, P, D);
+    return launch_status();
+}
+
+}  // namespace
+
+extern "C" size_t pacoh_svgd_imq_workspace_bytes(int P, int D, int dtype) {
+    if (P <= 0 || D <= 0) return 0;
+    const size_t e = dtype == PACOH_F64 ? 8 : 4;
+    return (size_t)(2 * P * P + D) * e + (size_t)D * sizeof(int32_t) + 16;
+}
+
+extern "C" int pacoh_svgd_phi_imq(const void* X, const void* score, double alpha, double beta, double bandwidth,
+                                  int neg, void* phi, void* h_out, void* workspace, int P, int D, int dtype,
+                                  void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!X || !score || !phi || !workspace || P <= 0 || D <= 0) return PACOH_EINVAL;
+    if (!(alpha > 0.0) || !(beta < 0.0)) return PACOH_EINVAL;        // svgd.py:72-73
+    const bool median = !(bandwidth > 0.0);
+    if (median && (!h_out || P < 2)) return PACOH_EINVAL;
+    if (P > 64) return PACOH_ELIMIT;
+    if (dtype == PACOH_F32)
+        return imq_launch<float>(X, score, alpha, beta, bandwidth, neg, phi, h_out, workspace, P, D, (hipStream_t)stream);
+    return imq_launch<double>(X, score, alpha, beta, bandwidth, neg, phi, h_out, workspace, P, D, (hipStream_t)stream);
+}

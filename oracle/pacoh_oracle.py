@@ -447,6 +447,46 @@ def svgd_phi_closed_form(X, score, bandwidth=None):
     return (K @ score + grad_K) / X.shape[0], bw
 
 
+def svgd_imq_bandwidth(X):
+    """IMQSteinKernel._bandwidth (svgd.py:78-89): per-dimension LOWER median (torch.median) of the squared
+    coordinate differences over the pairs i < j, divided by log(P+1).  Also returns the pair (a, b), a < b,
+    that attains the median in each dimension -- the reference's autograd differentiates through it."""
+    P = X.shape[0]
+    iu, ju = torch.triu_indices(P, P, offset=1)                      # row-major pairs i < j
+    sq = (X[ju] - X[iu]) ** 2                                        # [npairs, D]
+    k = (sq.shape[0] - 1) // 2
+    srt, order = torch.sort(sq, dim=0, stable=True)
+    med, arg = srt[k], order[k]
+    return med / math.log(P + 1), iu[arg], ju[arg]
+
+
+def svgd_phi_imq_closed_form(X, score, alpha=0.5, beta=-0.5, bandwidth=None):
+    """SVGD.phi with IMQSteinKernel (svgd.py:12-23, 63-97) in closed form.
+       base_ij = alpha + sum_d (x_jd - x_id)^2 / h_d,  k_ij = base_ij^beta,  kb_ij = beta base_ij^(beta-1)
+       grad_K[j,d] = -sum_i kb_ij 2 (x_jd - x_id) / h_d                              (direct term)
+                     + [j == b_d] (sum_il kb_il (x_ld - x_id)^2 / h_d^2) * 2 (x_bd - x_ad) / log(P+1)
+       The second term is the derivative through the median bandwidth (the reference builds h from the
+       differentiable `norm_sq`, whose X-side is the later particle b of the median pair (a, b), svgd.py:85-87,92);
+       it is absent for a fixed bandwidth.  phi = (K score + grad_K) / P."""
+    P = X.shape[0]
+    diff = X.unsqueeze(0) - X.unsqueeze(1)                           # [i, j, d] = x_j - x_i
+    nsq = diff ** 2
+    if bandwidth is None:
+        h, a_idx, b_idx = svgd_imq_bandwidth(X)
+    else:
+        h = torch.as_tensor(bandwidth, dtype=X.dtype)
+    base = alpha + (nsq / h).sum(-1)
+    K = torch.exp(beta * torch.log(base))
+    Kb = beta * K / base
+    grad_K = -(Kb.unsqueeze(-1) * 2 * diff / h).sum(0)               # sum over i -> [j, d]
+    if bandwidth is None:
+        S = -(Kb.unsqueeze(-1) * nsq).sum((0, 1)) / h ** 2           # d sum(K) / d h_d
+        d_idx = torch.arange(X.shape[1])
+        dh = 2 * (X[b_idx, d_idx] - X[a_idx, d_idx]) / math.log(P + 1)
+        grad_K[b_idx, d_idx] -= S * dh
+    return (K @ score + grad_K) / P, h
+
+
 # --------------------------------------------------------------------------------------
 # A10  VI                                               GPR_meta_vi.py:216-224, random_gp.py:224-251
 # --------------------------------------------------------------------------------------

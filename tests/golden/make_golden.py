@@ -129,6 +129,27 @@ def main():
         fx[tag + '_score64'] = (-(X64 - mu64) / s64 ** 2).numpy()
     np.savez_compressed(os.path.join(OUT, 'svgd_ref.npz'), **fx)
 
+    # ------------------------------------------------------------------ A9 (IMQ particle kernel)
+    fx = {}
+    for tag, (P, D, bw) in {'small_median': (5, 7, None), 'small_fixed': (5, 7, 0.5), 'tiny_median': (4, 3, None),
+                            'cfg3_median': (20, 2534, None), 'p20_fixed': (20, 300, 1.5),
+                            'p10_median': (10, 642, None)}.items():
+        gen = torch.Generator().manual_seed(99 + P + D)
+        X = torch.randn(P, D, generator=gen) * 0.7
+        mu = torch.randn(D, generator=gen)
+        s = torch.rand(D, generator=gen) + 0.5
+        for sfx, dt in (('', torch.float32), ('64', torch.float64)):
+            Xd, mud, sd = X.to(dt), mu.to(dt), s.to(dt)
+            kern = svgd.IMQSteinKernel(bandwidth=bw)
+            phi = svgd.SVGD(QuadLogProb(mud, sd), kern, optimizer=None).phi(Xd)
+            fx[tag + '_phi' + sfx] = phi.detach().numpy()
+            fx[tag + '_K' + sfx] = kern(Xd, Xd).detach().numpy()
+        fx[tag + '_X'], fx[tag + '_mu'], fx[tag + '_s'] = X.numpy(), mu.numpy(), s.numpy()   # score = -(X - mu) / s^2
+        fx[tag + '_bw_arg'] = np.array(-1.0 if bw is None else bw)
+    np.savez_compressed(os.path.join(OUT, 'svgd_imq_ref.npz'), **fx)
+    if len(sys.argv) > 1 and sys.argv[1] == 'imq':
+        return
+
     # ------------------------------------------------------------------ A2/A7 under import shims
     install_shims()
     import meta_learn.models as models                         # noqa: E402

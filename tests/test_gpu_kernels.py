@@ -419,3 +419,36 @@ def test_vi_sample_and_grad_match_reference_and_autograd(L, golden_dir):
     y = torch.ones(10, dtype=torch.float64, device=DEV)
     L.axpy(y, torch.arange(10, dtype=torch.float64, device=DEV), -0.5)
     assert relerr(y, 1 - 0.5 * torch.arange(10, dtype=torch.float64)) < 1e-15
+
+
+@pytest.mark.parametrize('tag', ['small_median', 'small_fixed', 'tiny_median', 'cfg3_median', 'p20_fixed', 'p10_median'])
+def test_svgd_phi_imq_matches_reference_fixture(L, golden_dir, tag):
+    """phi vs the output of the REAL meta_learn/svgd.py (SVGD.phi + IMQSteinKernel, svgd.py:63-97), including the
+    gradient that the reference's autograd sends through the per-dimension median bandwidth"""
+    fx = np.load(os.path.join(golden_dir, 'svgd_imq_ref.npz'))
+    bw_arg = float(fx[tag + '_bw_arg'])
+    bw = None if bw_arg < 0 else bw_arg
+    for dt, sfx, tol in ((torch.float32, '', 2e-5), (torch.float64, '64', 1e-11)):
+        X, mu, s = (torch.from_numpy(fx[tag + k]).to(dt).cuda() for k in ('_X', '_mu', '_s'))
+        score = (-(X - mu) / s ** 2).contiguous()
+        phi, h, _ = L.svgd_phi_imq(X, score, 0.5, -0.5, bw)
+        assert relerr(phi, torch.from_numpy(fx[tag + '_phi' + sfx])) < tol, (tag, dt)
+        nphi, _, _ = L.svgd_phi_imq(X, score, 0.5, -0.5, bw, neg=True)
+        assert torch.equal(nphi, -phi)
+        if bw is None:                               # bandwidths: exact order statistics of the squared differences
+            h_o, _, _ = O.svgd_imq_bandwidth(X.cpu())
+            assert relerr(h, h_o) < (1e-6 if dt == torch.float32 else 1e-14)
+
+
+def test_svgd_phi_imq_other_exponents_and_limits(L):
+    g = torch.Generator().manual_seed(4)
+    X = torch.randn(33, 101, generator=g, dtype=torch.float64)
+    score = torch.randn(33, 101, generator=g, dtype=torch.float64)
+    for alpha, beta, bw in ((1.3, -1.0, None), (0.2, -0.25, 0.7)):
+        phi, _, _ = L.svgd_phi_imq(X.cuda(), score.cuda(), alpha, beta, bw)
+        phi_o, _ = O.svgd_phi_imq_closed_form(X, score, alpha, beta, bw)
+        assert relerr(phi, phi_o) < 1e-11
+    with pytest.raises(RuntimeError):
+        L.svgd_phi_imq(X.cuda(), score.cuda(), -1.0, -0.5, None)           # alpha must be positive (svgd.py:72)
+    with pytest.raises(RuntimeError):
+        L.svgd_phi_imq(torch.zeros(65, 8).cuda(), torch.zeros(65, 8).cuda())  # P <= 64

@@ -360,3 +360,27 @@ def test_single_task_mean_and_kernel_learning_help(M):
         ll_b, rmse_b, _ = base.eval(x, y_sin)
         ll_k, rmse_k, _ = learned.eval(x, y_sin)
         assert ll_k > ll_b and rmse_k < rmse_b
+
+
+def test_svgd_imq_kernel_steps_match_oracle(M):
+    """GPRegressionMetaLearnedSVGD(kernel='IMQ') (GPR_meta_svgd.py:176-177): three steps vs oracle phi + torch Adam"""
+    T, P, n, d = 6, 5, 16, 2
+    tasks = tasks_nd(T, n, d)
+    model = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=P, random_seed=3, lr=1e-2, kernel='IMQ')
+    cfg = O.GPConfig(d, 'NN', 'NN')
+    pm, ps = O.hyperprior_mean_std(cfg.layout, 0.5, 3.0)
+    stats = O.compute_normalization_stats(tasks)
+    otasks = [O.prepare_task(x, y, stats, torch.float64) for x, y in tasks]
+    idx, pre = np.arange(T), O.meta_pre_factor([n] * T)
+    X = model.particles.cpu().double().clone()
+    opt = torch.optim.Adam([X], lr=1e-2)
+    for _ in range(3):
+        _, s = O.meta_score(X, otasks, cfg, pm, ps, 0.01)
+        phi, _ = O.svgd_phi_imq_closed_form(X.detach(), s)
+        X.grad = -phi
+        opt.step()
+        model.svgd_step(idx, pre)
+    assert relerr(model.particles, X) < 2e-3
+    model.meta_fit(verbose=False, n_iter=5)
+    with pytest.raises(NotImplementedError):
+        M.GPRegressionMetaLearnedSVGD(tasks, num_particles=P, kernel='laplace')

@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import pacoh_oracle as O
@@ -112,3 +113,24 @@ def test_sinusoid_dataset_and_task_sampling(golden_dir):
     draws = np.stack([rds.randint(0, 20, 5) for _ in range(4)])
     np.testing.assert_array_equal(draws, fx['choice_seed31'])
     assert list(draws[0]) == [18, 16, 2, 6, 10]
+
+
+# ---- IMQ particle kernel (svgd.py:63-97), fixtures generated from the reference's svgd.py as shipped ----
+IMQ_TAGS = ['small_median', 'small_fixed', 'tiny_median', 'cfg3_median', 'p20_fixed', 'p10_median']
+
+
+def imq_case(golden_dir, tag, dt):
+    fx = np.load(os.path.join(golden_dir, 'svgd_imq_ref.npz'))
+    X, mu, s = (torch.from_numpy(fx[tag + k]).to(dt) for k in ('_X', '_mu', '_s'))
+    sfx = '64' if dt == torch.float64 else ''
+    bw = float(fx[tag + '_bw_arg'])
+    return X, -(X - mu) / s ** 2, (None if bw < 0 else bw), torch.from_numpy(fx[tag + '_phi' + sfx]), torch.from_numpy(fx[tag + '_K' + sfx])
+
+
+@pytest.mark.parametrize('tag', IMQ_TAGS)
+@pytest.mark.parametrize('dt', [torch.float32, torch.float64])
+def test_oracle_imq_phi_matches_reference(golden_dir, tag, dt):
+    X, score, bw, phi_ref, _ = imq_case(golden_dir, tag, dt)
+    phi, _ = O.svgd_phi_imq_closed_form(X, score, bandwidth=bw)
+    tol = 1e-12 if dt == torch.float64 else 2e-5
+    assert float((phi - phi_ref).norm() / phi_ref.norm()) < tol
