@@ -224,6 +224,17 @@ int pacoh_vi_sample(const void* posterior, const void* eps, void* theta, void* l
 int pacoh_vi_grad(const void* posterior, const void* eps, const void* score, double prior_factor, void* grad,
                   int S, int D, int dtype, void* stream);
 
+/* Full-covariance hyper-posterior (cov_type='full'): posterior[D+1,D] = {loc; tril_cov[D,D]} (entries above the
+ * diagonal are ignored, as torch.tril does).  theta[s,:] = loc + tril(tril_cov) eps[s,:],
+ * log_q[s] = log N(theta_s; loc, L L^T) (optional).  grad[D+1,D]: grad[0,:] = -mean_s score[s,:];
+ * grad[1+i,j] = -mean_s score[s,i] eps[s,j] - [i==j] prior_factor / L[i,i] for j <= i, exactly 0 above the diagonal.
+ * Replaces MultivariateNormal(loc, scale_tril=tril(tril_cov)).rsample / .log_prob and the autograd backward
+ * (random_gp.py:249-251, GPR_meta_vi.py:220-224). */
+int pacoh_vi_sample_full(const void* posterior, const void* eps, void* theta, void* log_q, int S, int D, int dtype,
+                         void* stream);
+int pacoh_vi_grad_full(const void* posterior, const void* eps, const void* score, double prior_factor, void* grad,
+                       int S, int D, int dtype, void* stream);
+
 /* ---- reductions used by the host between kernels ----------------------------------------------
  * out[p, :] (+)= scale * sum_t in[t, p, :]   (in is [T, P, W]); deterministic (fixed order). */
 int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, int T, int P, int W,

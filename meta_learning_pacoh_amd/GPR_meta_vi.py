@@ -1,9 +1,10 @@
 """PACOH-VI on MI355X: API of GPRegressionMetaLearnedVI (meta_learn/GPR_meta_vi.py:14-262) with the
-diagonal Gaussian variational hyper-posterior (random_gp.py:224-248).  The reparameterised ELBO gradient
-needs only the per-sample score from the device engine:
-  theta_s = loc + exp(scale) * eps_s
+diagonal or full-covariance Gaussian variational hyper-posterior (random_gp.py:224-251).  The reparameterised
+ELBO gradient needs only the per-sample score from the device engine:
+  diag:  theta_s = loc + exp(scale) * eps_s          full:  theta_s = loc + tril(tril_cov) eps_s
   elbo_s  = log p(theta_s) - prior_factor * log q(theta_s),   loss = -mean_s elbo_s
-  dloss/dloc = -mean_s score_s;   dloss/dscale = -mean_s (score_s * exp(scale) * eps_s + prior_factor)."""
+  dloss/dloc = -mean_s score_s;   dloss/dscale = -mean_s (score_s * exp(scale) * eps_s + prior_factor)
+  dloss/dL_ij = -mean_s score_si eps_sj - [i == j] prior_factor / L_ii   (j <= i; zero above the diagonal)."""
 import math
 import time
 
@@ -25,6 +26,14 @@ def init_vi_posterior(D, init_std=0.1):
     return torch.stack([loc, scale])
 
 
+def init_vi_posterior_full(D, init_std=0.1):
+    """RandomGPPosterior.__init__ for cov_type='full' (random_gp.py:244,249-250): loc ~ N(0, 0.1), then
+    tril_cov = diag(U(0.05, 0.1)) -> [D+1, D] (row 0 = loc, rows 1.. = tril_cov)"""
+    loc = torch.normal(0.0, init_std, size=(D,))
+    tril = torch.diag(torch.ones(D).uniform_(0.05, 0.1))
+    return torch.cat([loc.reshape(1, D), tril], dim=0)
+
+
 def standard_normal(n, D):
     """the eps of Normal(loc, scale).rsample((n,)) (torch.distributions: _standard_normal)"""
     return torch.normal(torch.zeros(n, D), torch.ones(n, D))
@@ -41,15 +50,16 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         super().__init__(normalize_data, random_seed)
         assert mean_module in ['NN', 'constant', 'zero'] and covar_module in ['NN', 'SE']
         assert optimizer in ['Adam', 'SGD']
-        if cov_type != 'diag':
-            raise NotImplementedError("cov_type='full' (D x D scale_tril) is not on the HIP path yet (SURVEY 8f, next)")
+        assert cov_type in ['diag', 'full']
+        self.cov_type = cov_type
         self.num_iter_fit, self.prior_factor, self.feature_dim = num_iter_fit, prior_factor, feature_dim
         self.weight_prior_std, self.bias_prior_std = weight_prior_std, bias_prior_std
         self.svi_batch_size, self.optimizer_name = svi_batch_size, optimizer
         meta_train_data = self._setup_random_gp(meta_train_data, mean_module, covar_module, mean_nn_layers,
                                                 kernel_nn_layers, task_batch_size)
         # RandomGPPosterior init (random_gp.py:244-247), torch CPU generator, then moved to the device
-        self.posterior = init_vi_posterior(self.layout.D).to(self.dtype).to(self.device).contiguous()   # [2, D]
+        init = init_vi_posterior if cov_type == 'diag' else init_vi_posterior_full
+        self.posterior = init(self.layout.D).to(self.dtype).to(self.device).contiguous()   # [2, D] | [D+1, D]
         self.exp_avg = torch.zeros_like(self.posterior)
         self.exp_avg_sq = torch.zeros_like(self.posterior)
         self.opt_step = 0
@@ -63,22 +73,23 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
 
     @property
     def scale(self):
-        return self.posterior[1]
+        """diag: log std [D];  full: the tril_cov parameter [D, D]"""
+        return self.posterior[1] if self.cov_type == 'diag' else self.posterior[1:]
 
     def _rsample(self, n):
         """Normal(loc, exp(scale)).rsample((n,)): eps from the torch CPU generator (reference stream);
         returns (theta[n,D], eps[n,D], log q(theta)[n])"""
         eps = standard_normal(n, self.layout.D).to(self.dtype).to(self.device)
-        theta, log_q = L.vi_sample(self.posterior, eps)
+        theta, log_q = L.vi_sample(self.posterior, eps, full=self.cov_type == 'full')
         return theta, eps, log_q
 
     def get_neg_elbo_and_grad(self, idx_local, pre_factor):
-        """GPR_meta_vi.py:216-224 plus its backward, -> (loss, grad[2, D])"""
+        """GPR_meta_vi.py:216-224 plus its backward, -> (loss, grad[2, D] | grad[D+1, D])"""
         S = self.svi_batch_size
         theta, eps, log_q = self._rsample(S)
         log_prob, score = self._log_prob_and_score(theta, idx_local, pre_factor)
         loss = -(log_prob - self.prior_factor * log_q).mean()
-        return loss, L.vi_grad(self.posterior, eps, score, self.prior_factor)
+        return loss, L.vi_grad(self.posterior, eps, score, self.prior_factor, full=self.cov_type == 'full')
 
     def meta_fit(self, valid_tuples=None, verbose=True, log_period=500, n_iter=None):
         """GPR_meta_vi.py:84-128"""

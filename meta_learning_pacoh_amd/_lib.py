@@ -50,6 +50,8 @@ SIGNATURES = {
     'pacoh_axpy': (_i, [_vp, _vp, _d, _l, _i, _vp]),
     'pacoh_vi_sample': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_vi_grad': (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _vp]),
+    'pacoh_vi_sample_full': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pacoh_vi_grad_full': (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _vp]),
     'pacoh_reduce_tasks': (_i, [_vp, _vp, _d, _i, _i, _i, _i, _i, _vp]),
 }
 
@@ -373,24 +375,28 @@ def axpy(y, x, alpha):
     _check(lib.pacoh_axpy(_ptr(y), _ptr(x, y), float(alpha), y.numel(), dtype_code(y), _stream()), 'pacoh_axpy')
 
 
-def vi_sample(posterior, eps):
+def vi_sample(posterior, eps, full=False):
+    """posterior [2, D] (diagonal) or, with full=True, [D+1, D] (full covariance: loc row, then tril_cov)"""
     lib = load_library()
     S, D = eps.shape
+    assert posterior.shape == ((D + 1, D) if full else (2, D))
     theta = torch.empty_like(eps)
     log_q = torch.empty(S, dtype=eps.dtype, device=eps.device)
+    fn, name = (lib.pacoh_vi_sample_full, 'pacoh_vi_sample_full') if full else (lib.pacoh_vi_sample, 'pacoh_vi_sample')
     with _Timed('vi_sample'):
-        _check(lib.pacoh_vi_sample(_ptr(posterior), _ptr(eps, posterior), _ptr(theta), _ptr(log_q), S, D, dtype_code(eps),
-                                   _stream()), 'pacoh_vi_sample')
+        _check(fn(_ptr(posterior), _ptr(eps, posterior), _ptr(theta), _ptr(log_q), S, D, dtype_code(eps), _stream()), name)
     return theta, log_q
 
 
-def vi_grad(posterior, eps, score, prior_factor):
+def vi_grad(posterior, eps, score, prior_factor, full=False):
     lib = load_library()
     S, D = eps.shape
+    assert posterior.shape == ((D + 1, D) if full else (2, D))
     grad = torch.empty_like(posterior)
+    fn, name = (lib.pacoh_vi_grad_full, 'pacoh_vi_grad_full') if full else (lib.pacoh_vi_grad, 'pacoh_vi_grad')
     with _Timed('vi_grad'):
-        _check(lib.pacoh_vi_grad(_ptr(posterior), _ptr(eps, posterior), _ptr(score, posterior), float(prior_factor),
-                                 _ptr(grad), S, D, dtype_code(eps), _stream()), 'pacoh_vi_grad')
+        _check(fn(_ptr(posterior), _ptr(eps, posterior), _ptr(score, posterior), float(prior_factor),
+                  _ptr(grad), S, D, dtype_code(eps), _stream()), name)
     return grad
 
 

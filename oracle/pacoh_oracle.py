@@ -501,6 +501,37 @@ def vi_neg_elbo(loc, log_scale, eps, tasks, cfg, prior_mean, prior_std, prior_fa
     return -(lp - prior_factor * log_q).mean()
 
 
+def vi_full_init(D):
+    """RandomGPPosterior.__init__ for cov_type='full' (random_gp.py:244,249-250): loc ~ N(0, 0.1), then
+    tril_cov = diag(U(0.05, 0.1)), drawn in this order from the torch CPU generator."""
+    loc = torch.normal(0.0, 0.1, size=(D,))
+    tril = torch.diag(torch.ones(D).uniform_(0.05, 0.1))
+    return loc, tril
+
+
+def vi_full_sample(loc, tril_cov, eps):
+    """MultivariateNormal(loc, scale_tril=tril(tril_cov)).rsample / .log_prob (random_gp.py:251) with the
+    standard-normal draw eps made explicit: theta_s = loc + L eps_s,
+    log q(theta_s) = -0.5 |L^-1 (theta_s - loc)|^2 - sum_d log L_dd - D/2 log(2 pi)."""
+    Lt = torch.tril(tril_cov)
+    theta = loc + eps @ Lt.t()
+    D = loc.shape[0]
+    log_q = -0.5 * (eps ** 2).sum(-1) - torch.log(torch.diagonal(Lt)).sum() - 0.5 * D * LOG_2PI
+    return theta, log_q
+
+
+def vi_full_grad(tril_cov, eps, score, prior_factor):
+    """gradient of  -mean_s [log p(theta_s) - prior_factor log q(theta_s)]  w.r.t. (loc, tril_cov) given the
+    per-sample score d log p / d theta_s (closed form of the autograd backward of GPR_meta_vi.py:220-224):
+       d/d loc = -mean_s score_s;   d/d L_ij (i >= j) = -mean_s score_si eps_sj - [i == j] prior_factor / L_ii;
+    entries above the diagonal get exactly 0 (torch.tril mask)."""
+    S = eps.shape[0]
+    Lt = torch.tril(tril_cov)
+    g_tril = torch.tril(-(score.t() @ eps) / S)
+    g_tril = g_tril - torch.diag(prior_factor / torch.diagonal(Lt))
+    return -score.mean(0), g_tril
+
+
 # --------------------------------------------------------------------------------------
 # A11  posterior predictive + eval metrics
 # --------------------------------------------------------------------------------------

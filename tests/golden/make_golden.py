@@ -88,7 +88,43 @@ def install_shims():
     cfg.device = torch.device('cpu')
 
 
+def make_vi_full():
+    """RandomGPPosterior(cov_type='full') (random_gp.py:249-251): init stream, rsample, log_prob and the autograd
+    gradient of a reparameterised objective -> vi_full_ref.npz"""
+    install_shims()
+    sys.path.insert(0, REF)
+    import meta_learn.random_gp as random_gp
+    fx = {}
+    torch.manual_seed(30)
+    rgp = random_gp.RandomGPMeta(size_in=2, prior_factor=0.01, weight_prior_std=0.5, bias_prior_std=3.0,
+                                 covar_module_str='NN', mean_module_str='constant', kernel_nn_layers=(4,))
+    post = random_gp.RandomGPPosterior(rgp.parameter_shapes(), cov_type='full')
+    fx['init_loc'] = post.loc.detach().numpy()
+    fx['init_tril'] = post.tril_cov.detach().numpy().copy()
+    # perturb the strictly-lower AND upper parts so that the tril() mask and the off-diagonal algebra are exercised
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        post.tril_cov.add_(0.008 * torch.randn(post.tril_cov.shape, generator=gen))
+    fx['tril'] = post.tril_cov.detach().numpy()
+    samp = post.rsample(sample_shape=(6,))
+    fx['rsample'] = samp.detach().numpy()
+    logq = post.log_prob(samp)
+    fx['logq'] = logq.detach().numpy()
+    # stand-in log-density with a known score: log p(theta) = -0.5 |A theta|^2  (the GP part is pinned elsewhere)
+    D = post.loc.shape[0]
+    A = torch.randn(D, D, generator=gen) / D ** 0.5
+    fx['A'] = A.numpy()
+    loss = -(-0.5 * ((samp @ A.t()) ** 2).sum(-1) - 0.01 * logq).mean()
+    loss.backward()
+    fx['loss'] = np.array(loss.item())
+    fx['grad_loc'] = post.loc.grad.numpy()
+    fx['grad_tril'] = post.tril_cov.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'vi_full_ref.npz'), **fx)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'vi_full':
+        return make_vi_full()
     assert os.path.isdir(REF), 'reference not mounted -- fixtures can only be regenerated in the build container'
     sys.path.insert(0, REF)
 
@@ -252,6 +288,7 @@ def main():
         'log': [[1, 1.436, -1.315, 1.402, 0.290], [500, 1.436, -1.309, 1.405, 0.296], [1000, 1.436, -1.309, 1.405, 0.296]]}
     with open(os.path.join(OUT, 'demo_log.json'), 'w') as f:
         json.dump(demo_log, f, indent=1)
+    make_vi_full()
     print('fixtures written to', OUT)
 
 

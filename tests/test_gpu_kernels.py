@@ -452,3 +452,35 @@ def test_svgd_phi_imq_other_exponents_and_limits(L):
         L.svgd_phi_imq(X.cuda(), score.cuda(), -1.0, -0.5, None)           # alpha must be positive (svgd.py:72)
     with pytest.raises(RuntimeError):
         L.svgd_phi_imq(torch.zeros(65, 8).cuda(), torch.zeros(65, 8).cuda())  # P <= 64
+
+
+def test_vi_full_covariance_matches_reference_fixture(L, golden_dir):
+    """theta / log q / ELBO gradient vs RandomGPPosterior(cov_type='full') of the real reference (fixture)"""
+    fx = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, 'vi_full_ref.npz')).items()}
+    D = fx['init_loc'].shape[0]
+    post = torch.cat([fx['init_loc'].reshape(1, D), fx['tril']]).to(DEV).contiguous()
+    eps = torch.linalg.solve_triangular(torch.tril(fx['tril']).double(), (fx['rsample'] - fx['init_loc']).double().t(),
+                                        upper=False).t().float().contiguous()
+    theta, log_q = L.vi_sample(post, eps.to(DEV), full=True)
+    assert relerr(theta, fx['rsample']) < 1e-6 and relerr(log_q, fx['logq']) < 1e-5
+    score = (-(theta.cpu() @ fx['A'].t()) @ fx['A']).contiguous()
+    grad = L.vi_grad(post, eps.to(DEV), score.to(DEV), 0.01, full=True)
+    assert relerr(grad[0], fx['grad_loc']) < 1e-5 and relerr(grad[1:], fx['grad_tril']) < 1e-5
+    assert float(torch.triu(grad[1:], 1).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_vi_full_covariance_headline_size(L, dtype):
+    S, D = 10, 2534
+    g = torch.Generator().manual_seed(8)
+    loc = torch.randn(D, generator=g, dtype=dtype) * 0.1
+    tril = torch.diag(torch.rand(D, generator=g, dtype=dtype) * 0.05 + 0.05) + 0.001 * torch.randn(D, D, generator=g, dtype=dtype)
+    eps, score = torch.randn(S, D, generator=g, dtype=dtype), torch.randn(S, D, generator=g, dtype=dtype)
+    post = torch.cat([loc.reshape(1, D), tril]).to(DEV)
+    theta, log_q = L.vi_sample(post, eps.to(DEV), full=True)
+    th_o, lq_o = O.vi_full_sample(loc.double(), tril.double(), eps.double())
+    tol = 1e-5 if dtype == torch.float32 else 1e-13
+    assert relerr(theta, th_o) < tol and relerr(log_q, lq_o) < tol
+    grad = L.vi_grad(post, eps.to(DEV), score.to(DEV), 0.01, full=True)
+    gl, gt = O.vi_full_grad(tril.double(), eps.double(), score.double(), 0.01)
+    assert relerr(grad[0], gl) < tol and relerr(grad[1:], gt) < tol

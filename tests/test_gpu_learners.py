@@ -384,3 +384,42 @@ def test_svgd_imq_kernel_steps_match_oracle(M):
     model.meta_fit(verbose=False, n_iter=5)
     with pytest.raises(NotImplementedError):
         M.GPRegressionMetaLearnedSVGD(tasks, num_particles=P, kernel='laplace')
+
+
+def test_vi_full_covariance_steps_match_oracle(M):
+    """GPRegressionMetaLearnedVI(cov_type='full') (random_gp.py:249-251): init stream and three Adam steps vs the oracle"""
+    T, n, d, S = 4, 12, 2, 3
+    tasks = tasks_nd(T, n, d)
+    kw = dict(mean_module='constant', covar_module='NN', kernel_nn_layers=(4,))
+    model = M.GPRegressionMetaLearnedVI(tasks, svi_batch_size=S, random_seed=9, lr=1e-2, cov_type='full', **kw)
+    cfg = O.GPConfig(d, 'constant', 'NN', kernel_nn_layers=(4,))
+    D = cfg.D
+    torch.manual_seed(9)
+    O.consume_vectorized_gp_init_rng(cfg)
+    loc, tril = O.vi_full_init(D)
+    assert torch.equal(model.loc.cpu(), loc) and torch.equal(model.scale.cpu(), tril)
+    pm, ps = O.hyperprior_mean_std(cfg.layout, 0.5, 3.0)
+    stats = O.compute_normalization_stats(tasks)
+    otasks = [O.prepare_task(x, y, stats, torch.float64) for x, y in tasks]
+    loc, tril = loc.double().requires_grad_(True), tril.double().requires_grad_(True)
+    opt = torch.optim.Adam([loc, tril], lr=1e-2)
+    idx, pre = np.arange(T), O.meta_pre_factor([n] * T)
+    for _ in range(3):
+        rng = torch.get_rng_state()
+        eps = torch.normal(torch.zeros(S, D), torch.ones(S, D)).double()
+        torch.set_rng_state(rng)                                  # the model draws the same eps
+        opt.zero_grad()
+        theta, log_q = O.vi_full_sample(loc, tril, eps)
+        lp = O.meta_log_prob(theta, otasks, cfg, pm, ps, 0.01)
+        loss_o = -(lp - 0.01 * log_q).mean()
+        loss_o.backward()
+        opt.step()
+        loss, grad = model.get_neg_elbo_and_grad(idx, pre)
+        assert abs(float(loss) - float(loss_o)) < 1e-3 * max(1.0, abs(float(loss_o)))
+        model.opt_step += 1
+        M._lib.adam_step(model.posterior, grad, model.exp_avg, model.exp_avg_sq, 1e-2, model.opt_step)
+    assert relerr(model.loc, loc) < 2e-3 and relerr(model.scale, tril) < 2e-3
+    model.meta_fit(verbose=False, n_iter=3)
+    x, y = tasks[0]
+    mu, sd = model.predict(x, y, x[:5], n_posterior_samples=7)
+    assert np.isfinite(mu).all() and (sd > 0).all()

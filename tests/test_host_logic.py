@@ -99,3 +99,15 @@ def test_task_batch_packing_and_sharding():
     lik, score = torch.ones(3), torch.ones(3, 4)
     a, b = parallel.all_reduce_sum_(lik, score)                  # world size 1: identity
     assert a is lik and b is score
+
+
+def test_vi_full_posterior_init_stream(golden_dir):
+    """cov_type='full' init (random_gp.py:244,249-250): same torch-generator stream as the real reference"""
+    from meta_learning_pacoh_amd.GPR_meta_vi import init_vi_posterior_full
+    fx = np.load(os.path.join(golden_dir, 'vi_full_ref.npz'))
+    lay = ParamLayout(2, 'constant', 'NN', kernel_nn_layers=(4,))
+    torch.manual_seed(30)
+    consume_vectorized_gp_init_rng(lay)
+    post = init_vi_posterior_full(lay.D)
+    np.testing.assert_array_equal(post[0].numpy(), fx['init_loc'])
+    np.testing.assert_array_equal(post[1:].numpy(), fx['init_tril'])

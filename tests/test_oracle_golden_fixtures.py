@@ -134,3 +134,26 @@ def test_oracle_imq_phi_matches_reference(golden_dir, tag, dt):
     phi, _ = O.svgd_phi_imq_closed_form(X, score, bandwidth=bw)
     tol = 1e-12 if dt == torch.float64 else 2e-5
     assert float((phi - phi_ref).norm() / phi_ref.norm()) < tol
+
+
+def test_oracle_vi_full_covariance_matches_reference(golden_dir):
+    """RandomGPPosterior(cov_type='full') of the real reference: init stream, rsample, log_prob, autograd gradient"""
+    fx = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, 'vi_full_ref.npz')).items()}
+    cfg = O.GPConfig(2, 'constant', 'NN', kernel_nn_layers=(4,))
+    D = fx['init_loc'].shape[0]
+    assert cfg.D == D
+    torch.manual_seed(30)
+    O.consume_vectorized_gp_init_rng(cfg)
+    loc, tril = O.vi_full_init(D)
+    assert torch.equal(loc, fx['init_loc']) and torch.equal(tril, fx['init_tril'])
+    eps = torch.normal(torch.zeros(6, D), torch.ones(6, D))
+    theta, log_q = O.vi_full_sample(loc, fx['tril'], eps)
+    assert float((theta - fx['rsample']).abs().max()) < 1e-6
+    assert float((log_q - fx['logq']).abs().max()) < 2e-5 * float(fx['logq'].abs().max())
+    score = -(theta @ fx['A'].t()) @ fx['A']
+    g_loc, g_tril = O.vi_full_grad(fx['tril'], eps, score, 0.01)
+    assert float((g_loc - fx['grad_loc']).norm() / fx['grad_loc'].norm()) < 1e-5
+    assert float((g_tril - fx['grad_tril']).norm() / fx['grad_tril'].norm()) < 1e-5
+    assert float(torch.triu(g_tril, 1).abs().max()) == 0.0
+    loss = -(-0.5 * ((theta @ fx['A'].t()) ** 2).sum(-1) - 0.01 * log_q).mean()
+    assert abs(float(loss) - float(fx['loss'])) < 1e-5
