@@ -205,7 +205,9 @@ def main():
         traffic = None                      # HBM bytes per launch from the committed PMC profile of this same launch shape
         try:
             with open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')) as fh:
-                traffic = json.load(fh)['kernels']['gram_kernel<float, 2>']['hbm_bytes_per_launch']
+                kern = json.load(fh)['kernels']
+                key = [k for k in kern if k.startswith('gram_kernel<float, 2')][0]
+                traffic = kern[key]['hbm_bytes_per_launch']
         except Exception:
             pass
         gram = {'kernel': 'gram_rbf_ard', 'bound': 'hbm', 'achieved': round(alg_bytes / t_k / 1e9, 1),

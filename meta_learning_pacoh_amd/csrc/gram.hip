@@ -10,47 +10,25 @@
 
 namespace pacoh {
 
-// One workgroup = one problem b and one tile of TI rows x TJ columns (1024 output quads, QPT per
+// One unit = one problem b and one tile of TI rows x TJ columns (1024 output quads, QPT per
 // thread).  The tile's input rows are staged once into LDS already divided by the lengthscale, so
-// the inner loop is branch-free LDS reads + FMA + exp + one 16-byte store per quad; b, its
-// hyper-parameters and all 64-bit index arithmetic are wave-uniform scalars.
+// the inner loop is LDS reads + FMA + exp + one 16-byte store per quad; b, its hyper-parameters and
+// all 64-bit index arithmetic are wave-uniform scalars.
+//
+// Interior tiles (the whole tile inside the matrix, row length a multiple of the vector width) take a
+// branch-free body: no bounds tests, no exec-mask regions, so the compiler issues the LDS reads of all
+// QPT quads up front and the QPT stores back to back.  With the per-quad bounds tests in place the same
+// arithmetic ran at 3.6 TB/s instead of 5+ (each quad became its own basic block: read, wait, compute,
+// store, serialised).  Edge tiles keep the checked body.
 constexpr int QPT = 4;
 
-template <typename T, int FP>
-__global__ void __launch_bounds__(256) gram_kernel(const T* __restrict__ z1, int z1_div, const T* __restrict__ z2, int z2_div,
-                                                   const T* __restrict__ ls, const T* __restrict__ os,
-                                                   const T* __restrict__ noise, int add_noise, T* __restrict__ K,
-                                                   int P, int n, int m, int f, int tjq_shift, int tiles_i, int tiles_j) {
+template <typename T, int FP, bool FULL, bool NOISE>
+__device__ __forceinline__ void gram_tile_body(const T* __restrict__ z1s, const T* __restrict__ z2s, T* __restrict__ Kb,
+                                               T osv, T nz, int i0, int j00, int n, int m, int tjq_shift) {
     using V = typename VecOf<T>::type;
     constexpr int VW = VecOf<T>::W;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* z1s = reinterpret_cast<T*>(smem_raw);
-    const int TJQ = 1 << tjq_shift;                  // quads per tile row
-    const int TJ = TJQ * VW;                         // tile columns
-    const int TI = (QPT * 256) >> tjq_shift;         // tile rows
-    T* z2s = z1s + TI * FP;
-    const int tj = blockIdx.x % tiles_j;
-    const int rest = blockIdx.x / tiles_j;
-    const int ti = rest % tiles_i;
-    const int b = rest / tiles_i;
-    const int p = b % P;
-    const int i0 = ti * TI, j00 = tj * TJ;
-    const T* lp = ls + (long)p * f;
-    const T osv = os ? os[p] : T(1);
-    const T nz = add_noise ? noise[p] : T(0);
-    const T* z1b = z1 + (long)(b / z1_div) * n * f;
-    const T* z2b = z2 + (long)(b / z2_div) * m * f;
-    for (int e = threadIdx.x; e < TI * FP; e += 256) {
-        const int r = e / FP, c = e - r * FP;
-        z1s[e] = (i0 + r < n && c < f) ? z1b[(long)(i0 + r) * f + c] / lp[c] : T(0);
-    }
-    for (int e = threadIdx.x; e < TJ * FP; e += 256) {
-        const int r = e / FP, c = e - r * FP;
-        z2s[e] = (j00 + r < m && c < f) ? z2b[(long)(j00 + r) * f + c] / lp[c] : T(0);
-    }
-    __syncthreads();
-    T* Kb = K + (long)b * n * m;
-    const bool vec_ok = (m % VW) == 0;
+    const int TJQ = 1 << tjq_shift;
+    const bool vec_ok = FULL || (m % VW) == 0;
 #pragma unroll
     for (int u = 0; u < QPT; ++u) {
         const int q = u * 256 + threadIdx.x;
@@ -67,10 +45,10 @@ __global__ void __launch_bounds__(256) gram_kernel(const T* __restrict__ z1, int
 #pragma unroll
             for (int c = 0; c < FP; ++c) { T d = a[c] - bp[c]; s = fma(d, d, s); }
             T k = osv * rbf_exp<T>(T(-0.5) * s);
-            if (i == j0 + v) k += nz;
+            if (NOISE) k += (i == j0 + v) ? nz : T(0);
             out[v] = k;
         }
-        if (i < n && j0 < m) {
+        if (FULL || (i < n && j0 < m)) {
             T* kp = Kb + (long)i * m + j0;
             if (vec_ok) {
                 V o;
@@ -84,6 +62,103 @@ __global__ void __launch_bounds__(256) gram_kernel(const T* __restrict__ z1, int
     }
 }
 
+// A workgroup owns G consecutive units (unit = problem x tile).  All G units' inputs are fetched first (G*R loads per
+// thread in flight together), divided by the lengthscale and written to LDS behind ONE barrier; the G tile bodies then run
+// back to back without further synchronisation (4*G 16-byte stores per thread per prologue).
+// ALLFULL (chosen by the host when every tile is interior and every workgroup complete) compiles the kernel WITHOUT any
+// bounds-checked code.  Measured at 20480 Grams of 64x64, f=2, fp32 (tools/gram_bench.py): 97 us with per-quad bounds tests,
+// 88 us with a branch-free interior body beside the checked one, 80 us after removing the index divisions, 62 us (5.56 TB/s)
+// once the checked code is not in the kernel at all -- the never-executed generic paths cost 25 % through the compiler's
+// register allocation and conservative s_waitcnt placement at their join points.  A pure 16-byte fill of the same buffer
+// reaches 5.6-6.5 TB/s (tools/write_roof.hip).  A persistent software-pipelined variant (prefetch unit u+1 while storing
+// unit u) was measured slower: its per-unit barrier and in-order vmcnt waits behind the stores serialise it.
+template <typename T, int FP, int R, int G, bool ALLFULL>
+__global__ void __launch_bounds__(256) gram_kernel(const T* __restrict__ z1, int z1_div, const T* __restrict__ z2, int z2_div,
+                                                   const T* __restrict__ ls, const T* __restrict__ os,
+                                                   const T* __restrict__ noise, int add_noise, T* __restrict__ K,
+                                                   int P, int n, int m, int f, int tjq_shift, int tiles_i, int tiles_j,
+                                                   int total_units) {
+    constexpr int VW = VecOf<T>::W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int TJ = VW << tjq_shift;                  // tile columns
+    const int TI = (QPT * 256) >> tjq_shift;         // tile rows
+    const int E1 = TI * FP, E = (TI + TJ) * FP;      // staged elements per unit: z1 rows, then z2 rows
+    T* lds0 = reinterpret_cast<T*>(smem_raw);
+    const bool mvec = (m % VW) == 0;
+    const int u0 = blockIdx.x * G;
+    // decompose the first unit once; the others follow by incrementing
+    int tjs[G], tis[G], bs[G], ps[G];
+    {
+        int tj = u0 % tiles_j;
+        int rest = u0 / tiles_j;
+        int ti = rest % tiles_i;
+        int b = rest / tiles_i;
+        int p = b % P;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            tjs[g] = tj; tis[g] = ti; bs[g] = b; ps[g] = p;
+            if (++tj == tiles_j) { tj = 0; if (++ti == tiles_i) { ti = 0; ++b; if (++p == P) p = 0; } }
+        }
+    }
+    T pre[G][R], lpre[G][R];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const bool live = u0 + g < total_units;
+        const int fb = bs[g];
+        const T* lp = ls + (long)ps[g] * f;
+        const T* z1b = z1 + (long)(z1_div == 1 ? fb : fb / z1_div) * n * f;
+        const T* z2b = z2 + (long)(z2_div == 1 ? fb : fb / z2_div) * m * f;
+        const int i0 = tis[g] * TI, j00 = tjs[g] * TJ;
+        const bool interior = ALLFULL || ((i0 + TI <= n) && (j00 + TJ <= m) && f == FP);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int e = r * 256 + threadIdx.x;
+            T v = 0, l = 1;
+            if ((ALLFULL || live) && e < E) {
+                const bool first = e < E1;
+                const int e2 = first ? e : e - E1;
+                if (interior) {                      // contiguous rows, no bounds tests
+                    v = (first ? z1b + (long)i0 * FP : z2b + (long)j00 * FP)[e2];
+                    l = lp[e2 % FP];
+                } else {
+                    const int row = e2 / FP, c = e2 - row * FP;
+                    const int gr = (first ? i0 : j00) + row;
+                    if (c < f && gr < (first ? n : m)) { v = (first ? z1b : z2b)[(long)gr * f + c]; l = lp[c]; }
+                }
+            }
+            pre[g][r] = v; lpre[g][r] = l;
+        }
+    }
+    T osv[G], nz[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { osv[g] = os ? os[ps[g]] : T(1); nz[g] = add_noise ? noise[ps[g]] : T(0); }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int e = r * 256 + threadIdx.x;
+            if (e < E) lds0[g * E + e] = pre[g][r] / lpre[g][r];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (!ALLFULL && u0 + g >= total_units) break;
+        const T* z1s = lds0 + g * E;
+        const T* z2s = z1s + E1;
+        const int i0 = tis[g] * TI, j00 = tjs[g] * TJ;
+        T* Kb = K + (long)bs[g] * n * m;
+        const bool full = ALLFULL || ((i0 + TI <= n) && (j00 + TJ <= m) && mvec);
+        if (full) {
+            if (add_noise && i0 < j00 + TJ && j00 < i0 + TI)      // only tiles that touch the diagonal
+                gram_tile_body<T, FP, true, true>(z1s, z2s, Kb, osv[g], nz[g], i0, j00, n, m, tjq_shift);
+            else
+                gram_tile_body<T, FP, true, false>(z1s, z2s, Kb, osv[g], nz[g], i0, j00, n, m, tjq_shift);
+        } else if (!ALLFULL) {
+            gram_tile_body<T, FP, false, true>(z1s, z2s, Kb, osv[g], nz[g], i0, j00, n, m, tjq_shift);
+        }
+    }
+}
+
 template <typename T>
 static int launch_gram(const void* z1, int z1_div, const void* z2, int z2_div, const void* ls, const void* os,
                        const void* noise, int add_noise, void* K, int B, int P, int n, int m, int f, hipStream_t s) {
@@ -93,15 +168,31 @@ static int launch_gram(const void* z1, int z1_div, const void* z2, int z2_div, c
     while ((1 << tjq_shift) < mq && tjq_shift < 6) ++tjq_shift;       // tile: up to 64 quads wide
     const int TJ = (1 << tjq_shift) * VW, TI = (QPT * 256) >> tjq_shift;
     const int tiles_i = (n + TI - 1) / TI, tiles_j = (m + TJ - 1) / TJ;
-    const long blocks = (long)B * tiles_i * tiles_j;
-    if (blocks > 0x7fffffffL) return PACOH_ELIMIT;
+    const long units = (long)B * tiles_i * tiles_j;
+    if (units > 0x7fffffffL) return PACOH_ELIMIT;
     const int FP = f <= 2 ? 2 : (f <= 4 ? 4 : (f <= 8 ? 8 : 16));
-    const size_t lds = (size_t)(TI + TJ) * FP * sizeof(T);
-#define PACOH_GRAM_CASE(fp) case fp: hipLaunchKernelGGL((gram_kernel<T, fp>), dim3((unsigned)blocks), dim3(256), lds, s, \
+    const int E = (TI + TJ) * FP;
+    const int R = (E + 255) / 256;                                    // staged elements per thread and unit: 1..65
+    int G = R <= 4 ? 2 : 1;                                           // units per workgroup (measured: 2 best at n=64; 1, 4 within 10 %)
+    while (G > 1 && units / G < 2048) G >>= 1;                        // keep >= 8 workgroups per CU
+    if (R > 4) G = 1;
+    const size_t lds = (size_t)G * E * sizeof(T);
+    const long blocks = (units + G - 1) / G;
+    // every tile interior and every workgroup complete: the kernel variant without any bounds-checked code
+    const bool allfull = (n % TI) == 0 && (m % TJ) == 0 && f == FP && (units % G) == 0;
+#define PACOH_GRAM_LAUNCH(fp, r, g) if (allfull) PACOH_GRAM_LAUNCH2(fp, r, g, true); else PACOH_GRAM_LAUNCH2(fp, r, g, false)
+#define PACOH_GRAM_LAUNCH2(fp, r, g, af) hipLaunchKernelGGL((gram_kernel<T, fp, r, g, af>), dim3((unsigned)blocks), dim3(256), lds, s, \
         (const T*)z1, z1_div, (const T*)z2, z2_div, (const T*)ls, (const T*)os, (const T*)noise, add_noise, (T*)K, P, n, m, f, \
-        tjq_shift, tiles_i, tiles_j); break;
+        tjq_shift, tiles_i, tiles_j, (int)units)
+#define PACOH_GRAM_RG(fp, r) do { if (G >= 2) { PACOH_GRAM_LAUNCH(fp, r, 2); } else { PACOH_GRAM_LAUNCH(fp, r, 1); } } while (0)
+#define PACOH_GRAM_CASE(fp) case fp: \
+        if (R <= 1) PACOH_GRAM_RG(fp, 1); else if (R <= 2) PACOH_GRAM_RG(fp, 2); else if (R <= 4) PACOH_GRAM_RG(fp, 4); \
+        else if (R <= 8) { PACOH_GRAM_LAUNCH(fp, 8, 1); } else if (R <= 17) { PACOH_GRAM_LAUNCH(fp, 17, 1); } else { PACOH_GRAM_LAUNCH(fp, 65, 1); } break;
     switch (FP) { PACOH_GRAM_CASE(2) PACOH_GRAM_CASE(4) PACOH_GRAM_CASE(8) default: PACOH_GRAM_CASE(16) }
 #undef PACOH_GRAM_CASE
+#undef PACOH_GRAM_RG
+#undef PACOH_GRAM_LAUNCH
+#undef PACOH_GRAM_LAUNCH2
     return launch_status();
 }
 
