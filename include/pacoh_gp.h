@@ -122,6 +122,25 @@ int pacoh_gp_predict(const void* z_ctx, int z_div, const void* mean_ctx, int mea
 int pacoh_mvn_logprob_dense(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info,
                             double scale, int B, int n, int dtype, void* stream);
 
+/* ---- large-n GP path: the same LML (+ gradients) and posterior predictive with every n x n matrix in HBM ----------
+ * Same arguments, outputs, jitter ladder and ragged-task rules as pacoh_gp_lml_fwdbwd / pacoh_gp_predict (and the same
+ * reference lines), for context sets beyond pacoh_gp_small_max_n(): Gram build -> MFMA-panel Cholesky -> in-place
+ * triangular inverse -> K^-1 = Z^T Z (batched MFMA GEMM) -> gradient contractions.  d_lengthscale == NULL selects
+ * forward only (lml, info).  workspace: the *_workspace_bytes() queries (O(B n^2)).
+ * Limit: the 32-column factorisation panel must fit in LDS (n <= ~1000 fp32, ~520 fp64), else PACOH_ELIMIT. */
+size_t pacoh_gp_lml_dense_workspace_bytes(int B, int n, int f, int dtype, int want_grad);
+int pacoh_gp_lml_dense(const void* z, int z_div, const void* mean, int mean_mode, const void* y, int y_div,
+                       const void* lengthscale, const void* outputscale, const void* noise,
+                       const int32_t* n_valid, const void* g_lml, void* lml, void* d_z, void* d_mean,
+                       void* d_lengthscale, void* d_outputscale, void* d_noise, int32_t* info,
+                       void* workspace, int B, int P, int n, int f, int dtype, void* stream);
+size_t pacoh_gp_predict_dense_workspace_bytes(int B, int n, int m, int dtype);
+int pacoh_gp_predict_dense(const void* z_ctx, int z_div, const void* mean_ctx, int mean_mode, const void* y,
+                           int y_div, const void* z_tst, int zt_div, const void* mean_tst,
+                           const void* lengthscale, const void* outputscale, const void* noise,
+                           const int32_t* n_valid, void* mu, void* var, void* cov, int32_t* info,
+                           void* workspace, int B, int P, int n, int m, int f, int dtype, void* stream);
+
 /* ---- A2: per-particle ("vectorised") MLP ------------------------------------------------------
  * out[b] = MLP_{theta_p}(x[b / x_div]),  tanh hidden layers, linear output.  theta points at the
  * network's block inside the particle matrix, consecutive particles are theta_stride elements apart;

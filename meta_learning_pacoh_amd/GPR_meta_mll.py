@@ -176,7 +176,9 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         self._g_ctr.zero_()
 
     def _use_graph(self):
-        return self.optimizer_name == 'Adam' and os.environ.get('PACOH_NO_GRAPH', '0') != '1'
+        # (large contexts run the HBM-resident path, whose launch sequence sets kernel attributes: keep it eager)
+        return (self.optimizer_name == 'Adam' and os.environ.get('PACOH_NO_GRAPH', '0') != '1'
+                and self.tasks.n <= L.gp_small_max_n(self.dtype, True) and not L.FORCE_DENSE)
 
     # ------------------------------------------------------------------------------------------
     def meta_fit(self, valid_tuples=None, verbose=True, log_period=500, n_iter=None):

@@ -32,6 +32,12 @@ SIGNATURES = {
     'pacoh_gp_predict_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'pacoh_gp_predict': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _i, _i, _i, _i, _i, _i, _vp]),
+    'pacoh_gp_lml_dense_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'pacoh_gp_lml_dense': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _i, _i, _i, _i, _i, _vp]),
+    'pacoh_gp_predict_dense_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'pacoh_gp_predict_dense': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _i, _i, _i, _i, _i, _i, _vp]),
     'pacoh_mvn_logprob_dense': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
     'pacoh_mlp_fwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _i, _i, _i, _vp]),
     'pacoh_mlp_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i]),
@@ -158,6 +164,9 @@ def gram_rbf_ard(z1, z1_div, z2, z2_div, lengthscale, outputscale, noise, add_no
     return K
 
 
+FORCE_DENSE = False          # tests: route every LML / predictive call through the large-n (HBM-resident) path
+
+
 def gp_small_max_n(dtype, want_grad):
     return load_library().pacoh_gp_small_max_n(F32 if dtype == torch.float32 else F64, int(want_grad))
 
@@ -171,11 +180,54 @@ def gp_lml_fwd(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, no
     alpha = torch.empty(B, n, dtype=dt, device=dev) if want_alpha else None
     L = torch.empty(B, n, n, dtype=dt, device=dev) if want_L else None
     info = torch.empty(B, dtype=torch.int32, device=dev)
+    if FORCE_DENSE or n > gp_small_max_n(dt, False):
+        if want_alpha or want_L:
+            raise RuntimeError('alpha / L outputs are only available on the small-n path (n <= %d)' % gp_small_max_n(dt, False))
+        lml = _gp_lml_dense(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, None, B, P, info, False)[0]
+        return lml, None, None, info
     with _Timed('gp_lml_fwd'):
         _check(lib.pacoh_gp_lml_fwd(_ptr(z), z_div, _ptr(mean, z), mean_mode, _ptr(y, z), y_div, _ptr(lengthscale, z),
                                     _ptr(outputscale, z), _ptr(noise, z), _ptr(n_valid), _ptr(lml), _ptr(alpha), _ptr(L),
                                     _ptr(info), B, P, n, f, dtype_code(z), _stream()), 'pacoh_gp_lml_fwd')
     return lml, alpha, L, info
+
+
+_DENSE_WS = {}
+
+
+def _workspace(key, nbytes, device):
+    """grow-only scratch buffer per (purpose, device): the dense path needs O(B n^2) bytes"""
+    ws = _DENSE_WS.get((key, device))
+    if ws is None or ws.numel() < nbytes:
+        ws = _DENSE_WS[(key, device)] = torch.empty(max(1, nbytes), dtype=torch.uint8, device=device)
+    return ws
+
+
+def _gp_lml_dense(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, g_lml, B, P, info,
+                  want_grad, want_dz=True):
+    """large-n path (matrices materialised in HBM): -> (lml, d_z, d_mean, d_ls, d_os, d_noise)"""
+    lib = load_library()
+    n, f = z.shape[-2], z.shape[-1]
+    dev, dt = z.device, z.dtype
+    code = dtype_code(z)
+    lml = torch.empty(B, dtype=dt, device=dev)
+    d_z = d_mean = d_ls = d_os = d_noise = None
+    if want_grad:
+        d_z = torch.empty(B, n, f, dtype=dt, device=dev) if want_dz else None
+        if mean_mode == MEAN_VECTOR:
+            d_mean = torch.empty(B, n, dtype=dt, device=dev)
+        elif mean_mode == MEAN_CONST:
+            d_mean = torch.empty(B, dtype=dt, device=dev)
+        d_ls = torch.empty(B, f, dtype=dt, device=dev)
+        d_os = torch.empty(B, dtype=dt, device=dev) if outputscale is not None else None
+        d_noise = torch.empty(B, dtype=dt, device=dev)
+    ws = _workspace('lml', lib.pacoh_gp_lml_dense_workspace_bytes(B, n, f, code, int(want_grad)), dev)
+    with _Timed('gp_lml_dense'):
+        _check(lib.pacoh_gp_lml_dense(_ptr(z), z_div, _ptr(mean, z), mean_mode, _ptr(y, z), y_div, _ptr(lengthscale, z),
+                                      _ptr(outputscale, z), _ptr(noise, z), _ptr(n_valid), _ptr(g_lml, z), _ptr(lml), _ptr(d_z),
+                                      _ptr(d_mean), _ptr(d_ls), _ptr(d_os), _ptr(d_noise), _ptr(info), _ptr(ws),
+                                      B, P, n, f, code, _stream()), 'pacoh_gp_lml_dense')
+    return lml, d_z, d_mean, d_ls, d_os, d_noise
 
 
 def gp_lml_fwdbwd(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, B, P, n_valid=None,
@@ -195,6 +247,9 @@ def gp_lml_fwdbwd(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale,
     d_os = torch.empty(B, dtype=dt, device=dev) if outputscale is not None else None
     d_noise = torch.empty(B, dtype=dt, device=dev)
     info = torch.empty(B, dtype=torch.int32, device=dev)
+    if FORCE_DENSE or n > gp_small_max_n(dt, True):
+        return _gp_lml_dense(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, g_lml, B, P, info,
+                             True, want_dz) + (info,)
     with _Timed('gp_lml_fwdbwd'):
         _check(lib.pacoh_gp_lml_fwdbwd(_ptr(z), z_div, _ptr(mean, z), mean_mode, _ptr(y, z), y_div, _ptr(lengthscale, z),
                                        _ptr(outputscale, z), _ptr(noise, z), _ptr(n_valid), _ptr(g_lml, z), _ptr(lml),
@@ -213,9 +268,18 @@ def gp_predict(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, z_tst, zt_div, mean_
     mu = torch.empty(B, m, dtype=dt, device=dev)
     var = torch.empty(B, m, dtype=dt, device=dev)
     cov = torch.empty(B, m, m, dtype=dt, device=dev) if want_cov else None
+    info = torch.empty(B, dtype=torch.int32, device=dev)
+    if FORCE_DENSE or n > gp_small_max_n(dt, False):
+        ws = _workspace('predict', lib.pacoh_gp_predict_dense_workspace_bytes(B, n, m, code), dev)
+        with _Timed('gp_predict_dense'):
+            _check(lib.pacoh_gp_predict_dense(_ptr(z_ctx), z_div, _ptr(mean_ctx, z_ctx), mean_mode, _ptr(y, z_ctx), y_div,
+                                              _ptr(z_tst, z_ctx), zt_div, _ptr(mean_tst, z_ctx), _ptr(lengthscale, z_ctx),
+                                              _ptr(outputscale, z_ctx), _ptr(noise, z_ctx), _ptr(n_valid), _ptr(mu), _ptr(var),
+                                              _ptr(cov), _ptr(info), _ptr(ws), B, P, n, m, f, code, _stream()),
+                   'pacoh_gp_predict_dense')
+        return mu, var, cov, info
     ws_bytes = lib.pacoh_gp_predict_workspace_bytes(B, n, m, code, int(want_cov))
     ws = torch.empty(max(1, ws_bytes), dtype=torch.uint8, device=dev) if want_cov else None
-    info = torch.empty(B, dtype=torch.int32, device=dev)
     with _Timed('gp_predict'):
         _check(lib.pacoh_gp_predict(_ptr(z_ctx), z_div, _ptr(mean_ctx, z_ctx), mean_mode, _ptr(y, z_ctx), y_div,
                                     _ptr(z_tst, z_ctx), zt_div, _ptr(mean_tst, z_ctx), _ptr(lengthscale, z_ctx),

@@ -14,7 +14,9 @@ constexpr int TT = 64;     // trailing-update tile
 template <typename T>
 __global__ void __launch_bounds__(256) chol_dense_kernel(T* __restrict__ A, const T* __restrict__ resid,
                                                          T* __restrict__ logp, T* __restrict__ alpha_out,
-                                                         int32_t* __restrict__ info, T scale, int n) {
+                                                         int32_t* __restrict__ info, T scale, int n, int attempt) {
+    // jitter-ladder retries (attempt > 0) only touch the problems that have not succeeded yet
+    if (attempt > 0 && info && info[blockIdx.x] >= 0) return;
     // all LDS in ONE dynamic array (cdna_hip_programming.md Guideline 17: statics in front of the
     // dynamic region can shift its base off its natural alignment)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -166,7 +168,7 @@ __global__ void __launch_bounds__(256) chol_dense_kernel(T* __restrict__ A, cons
         const T LOG2PI = T(1.8378770664093453);
         T lp = T(-0.5) * (quad + T(2) * logdet + T(n) * LOG2PI) * scale;
         logp[blockIdx.x] = ok ? lp : T(NAN);
-        if (info) info[blockIdx.x] = ok ? 0 : -1;
+        if (info) info[blockIdx.x] = ok ? attempt : -1;
     }
     if (!alpha_out) return;
     // ---- backward solve L^T alpha = u, blocked from the bottom ---------------------------------
@@ -208,27 +210,32 @@ using namespace pacoh;
 
 namespace pacoh {
 int dense_mfma_try(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
-                   int dtype, hipStream_t s);       // dense_mfma.hip; returns 1 if the panel does not fit in LDS
+                   int dtype, int attempt, hipStream_t s);       // dense_mfma.hip; returns 1 if the panel does not fit in LDS
+
+// Cholesky + solves + log-density of B materialised matrices; attempt > 0 re-runs only problems with info[b] < 0
+// (and then writes info[b] = attempt on success): the psd_safe_cholesky ladder of the dense path.
+int dense_chol_launch(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
+                      int dtype, int attempt, hipStream_t stream) {
+    static const bool mfma_on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
+    if (mfma_on) {
+        int rc = dense_mfma_try(A, resid, logp, alpha_out, info, scale, B, n, dtype, attempt, stream);
+        if (rc != 1) return rc;
+    }
+    size_t lds = ((size_t)n + NB * (NB + 1) + 2 * TT * (NB + 1) + NB + 8) * (dtype == PACOH_F64 ? 8 : 4);
+    if (lds > 64u * 1024u) return PACOH_ELIMIT;
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(chol_dense_kernel<float>, dim3(B), dim3(256), lds, stream, (float*)A,
+                           (const float*)resid, (float*)logp, (float*)alpha_out, info, (float)scale, n, attempt);
+    else
+        hipLaunchKernelGGL(chol_dense_kernel<double>, dim3(B), dim3(256), lds, stream, (double*)A,
+                           (const double*)resid, (double*)logp, (double*)alpha_out, info, scale, n, attempt);
+    return launch_status();
 }
+}  // namespace pacoh
 
 extern "C" int pacoh_mvn_logprob_dense(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info,
                                        double scale, int B, int n, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!A || !resid || !logp || B <= 0 || n <= 0) return PACOH_EINVAL;
-    {
-        static const bool mfma_on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
-        if (mfma_on) {
-            int rc = dense_mfma_try(A, resid, logp, alpha_out, info, scale, B, n, dtype, (hipStream_t)stream);
-            if (rc != 1) return rc;
-        }
-    }
-    size_t lds = ((size_t)n + NB * (NB + 1) + 2 * TT * (NB + 1) + NB + 8) * (dtype == PACOH_F64 ? 8 : 4);
-    if (lds > 64u * 1024u) return PACOH_ELIMIT;
-    if (dtype == PACOH_F32)
-        hipLaunchKernelGGL(chol_dense_kernel<float>, dim3(B), dim3(256), lds, (hipStream_t)stream, (float*)A,
-                           (const float*)resid, (float*)logp, (float*)alpha_out, info, (float)scale, n);
-    else
-        hipLaunchKernelGGL(chol_dense_kernel<double>, dim3(B), dim3(256), lds, (hipStream_t)stream, (double*)A,
-                           (const double*)resid, (double*)logp, (double*)alpha_out, info, scale, n);
-    return launch_status();
+    return dense_chol_launch(A, resid, logp, alpha_out, info, scale, B, n, dtype, 0, (hipStream_t)stream);
 }

@@ -1,0 +1,615 @@
+// Dense (large-n) GP path: LML forward + backward and the posterior predictive for context sets that do not fit the
+// LDS-resident kernels (gp_mfma.hip / gp_small.hip).  Same mathematics and outputs as pacoh_gp_lml_fwdbwd /
+// pacoh_gp_predict (reference call sites: random_gp.py:54-89,204-222, GPR_meta_mll.py:104-117,174-181 and the gpytorch
+// ExactGP / ExactMarginalLogLikelihood / psd_safe_cholesky code behind them), with every n x n matrix materialised in HBM:
+//
+//   A  = os K(z,z) + (noise + jitter) I          gram.hip               (retry of failed problems: regram_failed_kernel)
+//   L  = chol(A), alpha = A^-1 r, log-density    dense_mfma.hip / dense.hip (one workgroup per matrix, MFMA panels)
+//   Z  = L^-1 in place                           trtri_dense_kernel     (one workgroup per matrix, MFMA panels)
+//   W  = Z^T Z = A^-1                            bgemm_kernel           (batched MFMA GEMM from L2, triangular k-ranges)
+//   G  = (alpha alpha^T - W) / 2n -> d_z, d_mean, d_lengthscale, d_outputscale, d_noise
+//                                                dense_grad_rows_kernel (one wave per row) + dense_finish_kernel
+//   predictive: V = Z K_xs, cov = K_ss + noise I - V^T V, mu = m_s + K_xs^T alpha        (bgemm_kernel, small kernels)
+//
+// fp32 and fp64 (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64).  Limits: the 32-column panel of the Cholesky /
+// inverse must fit in LDS (n <= ~1000 fp32, ~520 fp64).
+#include "common.h"
+
+namespace pacoh {
+
+int dense_chol_launch(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
+                      int dtype, int attempt, hipStream_t stream);                                  // dense.hip
+
+namespace {
+
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+using f64x4_t = __attribute__((ext_vector_type(4))) double;
+
+template <typename T> struct Mf;
+template <> struct Mf<float> {
+    using acc = f32x4_t;
+    static __device__ __forceinline__ acc mma(float a, float b, acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int g, int q) { return 4 * g + q; }
+};
+template <> struct Mf<double> {
+    using acc = f64x4_t;
+    static __device__ __forceinline__ acc mma(double a, double b, acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int g, int q) { return g + 4 * q; }
+};
+
+constexpr int DNB = 32;            // panel width
+constexpr int DLP = 36;            // leading dimension of LDS panels
+
+__device__ __forceinline__ int clamp_nv(const int32_t* n_valid, long ty, int n) {
+    int nv = n_valid ? n_valid[ty] : n;
+    nv = nv < n ? nv : n;
+    return nv < 0 ? 0 : nv;
+}
+
+// ---- residual r = y - mean (zero on padded rows) ------------------------------------------------------------------------
+template <typename T>
+__global__ void dense_resid_kernel(const T* __restrict__ y, int y_div, const T* __restrict__ mean, int mean_mode,
+                                   const int32_t* __restrict__ n_valid, T* __restrict__ resid, int P, int n, long total) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= total) return;
+    const long b = q / n;
+    const int i = (int)(q - b * n);
+    const long ty = b / y_div;
+    const int nv = clamp_nv(n_valid, ty, n);
+    T m = 0;
+    if (mean_mode == PACOH_MEAN_VECTOR) m = mean[q];
+    else if (mean_mode == PACOH_MEAN_CONST) m = mean[b % P];
+    resid[q] = i < nv ? y[ty * n + i] - m : T(0);
+}
+
+// ---- ragged tasks: rows / columns >= n_valid become an identity block -----------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) dense_mask_kernel(T* __restrict__ A, const int32_t* __restrict__ n_valid, int y_div,
+                                                         const int32_t* __restrict__ info, int attempt, int n) {
+    const long b = blockIdx.y;
+    if (attempt > 0 && info[b] >= 0) return;
+    const int nv = clamp_nv(n_valid, b / y_div, n);
+    if (nv >= n) return;
+    const int i = blockIdx.x;
+    T* row = A + (b * n + i) * (long)n;
+    for (int j = threadIdx.x; j < n; j += 256)
+        if (i >= nv || j >= nv) row[j] = (i == j) ? T(1) : T(0);
+}
+
+// rows >= n_valid of a [B, n, m] matrix := 0
+template <typename T>
+__global__ void __launch_bounds__(256) dense_zero_rows_kernel(T* __restrict__ X, const int32_t* __restrict__ n_valid, int y_div,
+                                                              int n, int m) {
+    const long b = blockIdx.y;
+    const int i = blockIdx.x;
+    if (i < clamp_nv(n_valid, b / y_div, n)) return;
+    T* row = X + (b * n + i) * (long)m;
+    for (int j = threadIdx.x; j < m; j += 256) row[j] = T(0);
+}
+
+// ---- jitter-ladder retry: rebuild A = os K + (noise + jitter) I for the problems whose factorisation failed ---------------
+template <typename T>
+__global__ void __launch_bounds__(256) regram_failed_kernel(const T* __restrict__ z, int z_div, const T* __restrict__ ls,
+                                                            const T* __restrict__ os, const T* __restrict__ noise,
+                                                            const int32_t* __restrict__ info, T jitter, T* __restrict__ A,
+                                                            int P, int n, int f) {
+    const long b = blockIdx.y;
+    if (info[b] >= 0) return;
+    const int p = (int)(b % P);
+    const int i = blockIdx.x;
+    const T* zb = z + (b / z_div) * (long)n * f;
+    const T osv = os ? os[p] : T(1);
+    const T dg = noise[p] + jitter;
+    T* row = A + (b * n + i) * (long)n;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        T s = 0;
+        for (int c = 0; c < f; ++c) { const T d = zb[(long)i * f + c] / ls[(long)p * f + c] - zb[(long)j * f + c] / ls[(long)p * f + c]; s = fma(d, d, s); }
+        row[j] = osv * rbf_exp<T>(T(-0.5) * s) + (i == j ? dg : T(0));
+    }
+}
+
+// ---- Z = L^-1 in place (lower triangle), right-to-left over 32-column panels ------------------------------------------------
+//   Z11 = L11^-1 (one wavefront, LDS);  Q = L21 Z11 (MFMA, LDS panel);  Z21 = -Z22 Q (MFMA: Z22 blocks from L2, Q from LDS)
+template <typename T>
+__global__ void __launch_bounds__(256) trtri_dense_kernel(T* __restrict__ A, const int32_t* __restrict__ info, int n, int mpad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* sm = reinterpret_cast<T*>(smem_raw);
+    T (*Ds)[DNB + 1] = reinterpret_cast<T (*)[DNB + 1]>(sm);          // L11
+    T* Li = sm + DNB * (DNB + 1);                                      // Z11 = L11^-1, [32][DLP]
+    T* Pn = Li + DNB * DLP;                                            // panel L21 -> Q, [mpad][DLP]
+    using Acc = typename Mf<T>::acc;
+    if (info && info[blockIdx.x] < 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    T* Ab = A + (size_t)blockIdx.x * n * n;
+    const int nblk = (n + DNB - 1) / DNB;
+    for (int kbk = nblk - 1; kbk >= 0; --kbk) {
+        const int k0 = kbk * DNB;
+        const int kb = (n - k0 < DNB) ? (n - k0) : DNB;
+        const int t0 = k0 + kb, m = n - t0;
+        for (int q = tid; q < DNB * DNB; q += 256) {
+            const int rr = q / DNB, c = q - rr * DNB;
+            T v = (rr == c) ? T(1) : T(0);
+            if (rr < kb && c <= rr) v = Ab[(size_t)(k0 + rr) * n + k0 + c];
+            Ds[rr][c] = v;
+        }
+        __syncthreads();
+        if (tid < 64) {                              // lane c owns column c of the inverse (both half-waves compute it)
+            const int rr = tid & 31;
+            T x[DNB];
+#pragma unroll
+            for (int i = 0; i < DNB; ++i) {
+                T s = (i == rr) ? T(1) : T(0);
+#pragma unroll
+                for (int j = 0; j < i; ++j) s = fma(-Ds[i][j], x[j], s);
+                x[i] = s / Ds[i][i];
+            }
+            if (tid < 32) {
+#pragma unroll
+                for (int i = 0; i < DNB; ++i) Li[i * DLP + rr] = x[i];
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < DNB * DNB; q += 256) {
+            const int rr = q / DNB, c = q - rr * DNB;
+            if (rr < kb && c <= rr) Ab[(size_t)(k0 + rr) * n + k0 + c] = Li[rr * DLP + c];
+        }
+        if (m > 0) {
+            const int mb = (m + 15) / 16;
+            for (int q = tid; q < mb * 16 * DNB; q += 256) {
+                const int rr = q / DNB, c = q - rr * DNB;
+                Pn[(size_t)rr * DLP + c] = (rr < m && c < kb) ? Ab[(size_t)(t0 + rr) * n + k0 + c] : T(0);
+            }
+            __syncthreads();
+            // Q = L21 Z11, in place (a wave owns whole row blocks and reads them completely before writing)
+            for (int ib = wave; ib < mb; ib += 4) {
+                Acc acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int c = 0; c < DNB / 4; ++c) {
+                    const T a = Pn[(size_t)(ib * 16 + r) * DLP + 4 * c + g];
+                    acc0 = Mf<T>::mma(a, Li[(4 * c + g) * DLP + r], acc0);
+                    acc1 = Mf<T>::mma(a, Li[(4 * c + g) * DLP + 16 + r], acc1);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = ib * 16 + Mf<T>::row(g, q);
+                    Pn[(size_t)row * DLP + r] = acc0[q];
+                    Pn[(size_t)row * DLP + 16 + r] = acc1[q];
+                }
+            }
+            __syncthreads();
+            // Z21 = -Z22 Q: row block ib needs the (already inverted) blocks Z22[ib][0..ib]; heavy blocks first
+            for (int ib = mb - 1 - wave; ib >= 0; ib -= 4) {
+                Acc acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+                const int rowi = ib * 16 + r;
+                const T* arow = Ab + (size_t)(t0 + rowi) * n + t0;
+                for (int kb2 = 0; kb2 <= ib; ++kb2) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int kc = kb2 * 16 + 4 * c + g;
+                        const T a = (rowi < m && kc <= rowi) ? arow[kc] : T(0);
+                        acc0 = Mf<T>::mma(a, Pn[(size_t)kc * DLP + r], acc0);
+                        acc1 = Mf<T>::mma(a, Pn[(size_t)kc * DLP + 16 + r], acc1);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = ib * 16 + Mf<T>::row(g, q);
+                    if (row < m) {
+                        if (r < kb) Ab[(size_t)(t0 + row) * n + k0 + r] = -acc0[q];
+                        if (16 + r < kb) Ab[(size_t)(t0 + row) * n + k0 + 16 + r] = -acc1[q];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- batched GEMM on the matrix cores, operands straight from HBM/L2 --------------------------------------------------------
+//   C[b] (M x N) = alpha op(A[b]) op(B[b]) + beta C[b];  op = identity or transpose of the STORED matrix;
+//   lowerA / lowerB: the stored matrix is lower triangular (entries above its diagonal are ignored and the k-range of every
+//   output tile is clipped accordingly).  One wave per 32x32 output tile, k consumed 16 at a time with the permuted
+//   k index (k = 4g + s) so that both operands of the four MFMAs of a chunk come from consecutive addresses per lane.
+struct GemmArgs {
+    const void* A; const void* B; void* C;
+    long sA, sB, sC;
+    int lda, ldb, ldc, M, N, K;
+    int transA, transB, lowerA, lowerB;
+    double alpha, beta;
+    const int32_t* info;         // optional: skip problems with info[b] < 0
+};
+
+template <typename T>
+__device__ __forceinline__ T gemm_ld(const T* __restrict__ X, int ld, int row, int col, int R, int Cn, bool lower) {
+    if (row >= R || col >= Cn || (lower && col > row)) return T(0);
+    return X[(long)row * ld + col];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bgemm_kernel(GemmArgs ga) {
+    using Acc = typename Mf<T>::acc;
+    const int b = blockIdx.y;
+    if (ga.info && ga.info[b] < 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int tiles_n = (ga.N + 63) / 64;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int i0 = tm * 64 + (wave >> 1) * 32, j0 = tn * 64 + (wave & 1) * 32;
+    if (i0 >= ga.M || j0 >= ga.N) return;
+    const T* A = (const T*)ga.A + (long)b * ga.sA;
+    const T* Bm = (const T*)ga.B + (long)b * ga.sB;
+    T* C = (T*)ga.C + (long)b * ga.sC;
+    // stored shapes
+    const int Ar = ga.transA ? ga.K : ga.M, Ac = ga.transA ? ga.M : ga.K;
+    const int Br = ga.transB ? ga.N : ga.K, Bc = ga.transB ? ga.K : ga.N;
+    int klo = 0, khi = ga.K;
+    if (ga.lowerA) { if (ga.transA) klo = max(klo, i0); else khi = min(khi, i0 + 32); }
+    if (ga.lowerB) { if (ga.transB) khi = min(khi, j0 + 32); else klo = max(klo, j0); }
+    klo &= ~15;
+    Acc acc[2][2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) acc[ib][jb] = Acc{0, 0, 0, 0};
+    for (int kk = klo; kk < khi; kk += 16) {
+        T av[2][4], bv[2][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = kk + 4 * g + s;
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                const int i = i0 + 16 * ib + r;
+                av[ib][s] = ga.transA ? gemm_ld<T>(A, ga.lda, k, i, Ar, Ac, ga.lowerA) : gemm_ld<T>(A, ga.lda, i, k, Ar, Ac, ga.lowerA);
+            }
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                const int j = j0 + 16 * jb + r;
+                bv[jb][s] = ga.transB ? gemm_ld<T>(Bm, ga.ldb, j, k, Br, Bc, ga.lowerB) : gemm_ld<T>(Bm, ga.ldb, k, j, Br, Bc, ga.lowerB);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) acc[ib][jb] = Mf<T>::mma(av[ib][s], bv[jb][s], acc[ib][jb]);
+    }
+    const T alpha = (T)ga.alpha, beta = (T)ga.beta;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + 16 * ib + Mf<T>::row(g, q), j = j0 + 16 * jb + r;
+                if (i < ga.M && j < ga.N) {
+                    T* cp = C + (long)i * ga.ldc + j;
+                    *cp = beta == T(0) ? alpha * acc[ib][jb][q] : fma(alpha, acc[ib][jb][q], beta * *cp);
+                }
+            }
+}
+
+template <typename T>
+void launch_bgemm(const GemmArgs& ga, int Bn, hipStream_t s) {
+    const int tiles = ((ga.M + 63) / 64) * ((ga.N + 63) / 64);
+    hipLaunchKernelGGL(bgemm_kernel<T>, dim3(tiles, Bn), dim3(256), 0, s, ga);
+}
+
+// ---- gradient sums, one wave per matrix row -----------------------------------------------------------------------------------
+//   rowpart[b, i, 0..f) = sum_j M_ij df_c^2,  [f] = sum_j G_ij e_ij,  [f+1] = G_ii,  [f+2] = alpha_i
+template <typename T, int FP>
+__global__ void __launch_bounds__(256) dense_grad_rows_kernel(const T* __restrict__ z, int z_div, const T* __restrict__ lsp,
+                                                              const T* __restrict__ osp, const int32_t* __restrict__ n_valid,
+                                                              int y_div, const T* __restrict__ g_lml, const T* __restrict__ alpha,
+                                                              const T* __restrict__ Wm, const int32_t* __restrict__ info,
+                                                              T* __restrict__ d_z, T* __restrict__ d_mean, int mean_mode,
+                                                              T* __restrict__ rowpart, int P, int n, int f) {
+    const long b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int p = (int)(b % P);
+    const int nv = clamp_nv(n_valid, b / y_div, n);
+    const bool failed = info[b] < 0;
+    const T gup = g_lml ? g_lml[b] : T(1);
+    const int W3 = f + 3;
+    T* rp = rowpart + (b * n + i) * (long)W3;
+    if (failed || i >= nv) {
+        const T v = failed ? T(NAN) : T(0);
+        if (lane == 0) {
+            if (d_z) for (int c = 0; c < f; ++c) d_z[(b * n + i) * (long)f + c] = v;
+            if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = v;
+            for (int c = 0; c < W3; ++c) rp[c] = v;
+        }
+        return;
+    }
+    T ls[FP], zi[FP];
+    const T* zb = z + (b / z_div) * (long)n * f;
+#pragma unroll
+    for (int c = 0; c < FP; ++c) {
+        ls[c] = c < f ? lsp[(long)p * f + c] : T(1);
+        zi[c] = c < f ? zb[(long)i * f + c] / ls[c] : T(0);
+    }
+    const T os = osp ? osp[p] : T(1);
+    const T ai = alpha[b * n + i];
+    const T inv2n = T(0.5) / T(nv);
+    const T* wrow = Wm + (b * n + i) * (long)n;
+    T dz[FP], dls[FP];
+#pragma unroll
+    for (int c = 0; c < FP; ++c) { dz[c] = 0; dls[c] = 0; }
+    T dos = 0, dnz = 0;
+    for (int j = lane; j < nv; j += 64) {
+        const T Gij = (ai * alpha[b * n + j] - wrow[j]) * inv2n;
+        T s = 0, df[FP];
+#pragma unroll
+        for (int c = 0; c < FP; ++c) {
+            df[c] = c < f ? zb[(long)j * f + c] / ls[c] - zi[c] : T(0);
+            s = fma(df[c], df[c], s);
+        }
+        const T e = rbf_exp<T>(T(-0.5) * s);
+        dos = fma(Gij, e, dos);
+        const T M = Gij * os * e;
+#pragma unroll
+        for (int c = 0; c < FP; ++c) { const T md = M * df[c]; dz[c] += md; dls[c] = fma(md, df[c], dls[c]); }
+        if (j == i) dnz = Gij;
+    }
+#pragma unroll
+    for (int c = 0; c < FP; ++c) { dz[c] = subwave_sum<T>(dz[c], 64); dls[c] = subwave_sum<T>(dls[c], 64); }
+    dos = subwave_sum<T>(dos, 64);
+    dnz = subwave_sum<T>(dnz, 64);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < FP; ++c) {
+            if (c < f) {
+                if (d_z) d_z[(b * n + i) * (long)f + c] = T(2) * gup * dz[c] / ls[c];
+                rp[c] = dls[c];
+            }
+        }
+        rp[f] = dos; rp[f + 1] = dnz; rp[f + 2] = ai;
+        if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = gup * ai / T(nv);
+    }
+}
+
+// ---- per-problem results: lml and the reduced hyper-parameter gradients; one wave per problem ---------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64) dense_finish_kernel(const T* __restrict__ logp, const T* __restrict__ rowpart,
+                                                          const T* __restrict__ lsp, const int32_t* __restrict__ n_valid, int y_div,
+                                                          const T* __restrict__ g_lml, const int32_t* __restrict__ info,
+                                                          T* __restrict__ lml, T* __restrict__ d_mean, int mean_mode,
+                                                          T* __restrict__ d_ls, T* __restrict__ d_os, T* __restrict__ d_noise,
+                                                          int P, int n, int f, int bwd) {
+    const long b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int p = (int)(b % P);
+    const int nv = clamp_nv(n_valid, b / y_div, n);
+    const bool failed = info[b] < 0;
+    const T LOG2PI = T(1.8378770664093453);
+    if (lane == 0) {
+        // logp counts log(2 pi) for all n rows; the identity rows of a ragged task contribute nothing else
+        T v = nv > 0 ? (logp[b] + T(0.5) * T(n - nv) * LOG2PI) / T(nv) : T(0);
+        lml[b] = failed ? T(NAN) : v;
+    }
+    if (!bwd) return;
+    const T gup = g_lml ? g_lml[b] : T(1);
+    const int W3 = f + 3;
+    for (int c = 0; c < W3; ++c) {
+        T s = 0;
+        for (int i = lane; i < n; i += 64) s += rowpart[(b * n + i) * (long)W3 + c];
+        s = subwave_sum<T>(s, 64);
+        if (lane == 0) {
+            if (failed) s = T(NAN);
+            if (c < f) d_ls[b * f + c] = gup * s / lsp[(long)p * f + c];
+            else if (c == f) { if (d_os) d_os[b] = gup * s; }
+            else if (c == f + 1) d_noise[b] = gup * s;
+            else if (d_mean && mean_mode == PACOH_MEAN_CONST) d_mean[b] = nv > 0 ? gup * s / T(nv) : T(0);
+        }
+    }
+}
+
+// ---- predictive pieces ---------------------------------------------------------------------------------------------------------
+// mu[b,s] = mean_tst + sum_k Kxs[b,k,s] alpha[b,k];  var[b,s] = os + noise - sum_k V[b,k,s]^2;  one thread per (b, s)
+template <typename T>
+__global__ void dense_predict_finish_kernel(const T* __restrict__ Kxs, const T* __restrict__ V, const T* __restrict__ alpha,
+                                            const T* __restrict__ mean_tst, int mean_mode, const T* __restrict__ osp,
+                                            const T* __restrict__ noise, const int32_t* __restrict__ info,
+                                            T* __restrict__ mu, T* __restrict__ var, T* __restrict__ cov, int P, int n, int m,
+                                            long total) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= total) return;
+    const long b = q / m;
+    const int s = (int)(q - b * m);
+    const int p = (int)(b % P);
+    const bool failed = info[b] < 0;
+    T acc = 0, vv = 0;
+    for (int k = 0; k < n; ++k) {
+        acc = fma(Kxs[(b * n + k) * (long)m + s], alpha[b * n + k], acc);
+        const T v = V[(b * n + k) * (long)m + s];
+        vv = fma(v, v, vv);
+    }
+    T mt = 0;
+    if (mean_mode == PACOH_MEAN_VECTOR) mt = mean_tst[q];
+    else if (mean_mode == PACOH_MEAN_CONST) mt = mean_tst[p];
+    const T bad = failed ? T(NAN) : T(0);
+    mu[q] = mt + acc + bad;
+    var[q] = (osp ? osp[p] : T(1)) + noise[p] - vv + bad;
+    if (cov && failed) for (int t = 0; t < m; ++t) cov[(b * m + s) * (long)m + t] = T(NAN);
+}
+
+template <typename T>
+size_t trtri_lds(int n, int* mpad_out) {
+    const int mpad = n > DNB ? (n - DNB + 15) / 16 * 16 : 16;
+    *mpad_out = mpad;
+    return ((size_t)DNB * (DNB + 1) + (size_t)DNB * DLP + (size_t)mpad * DLP) * sizeof(T);
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <typename T>
+int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, const void* y, int y_div, const void* ls,
+                   const void* os, const void* noise, const int32_t* n_valid, const void* g_lml, void* lml, void* d_z,
+                   void* d_mean, void* d_ls, void* d_os, void* d_noise, int32_t* info, void* workspace, int B, int P, int n,
+                   int f, int dtype, hipStream_t s) {
+    const bool bwd = d_ls != nullptr;
+    const size_t nn = (size_t)B * n * n;
+    unsigned char* w = (unsigned char*)workspace;
+    T* A = (T*)w;                 w += align256(nn * sizeof(T));
+    T* Wm = (T*)w;                w += bwd ? align256(nn * sizeof(T)) : 0;
+    T* resid = (T*)w;             w += align256((size_t)B * n * sizeof(T));
+    T* alpha = (T*)w;             w += align256((size_t)B * n * sizeof(T));
+    T* logp = (T*)w;              w += align256((size_t)B * sizeof(T));
+    T* rowpart = (T*)w;
+    int mpad = 0;
+    const size_t lds = trtri_lds<T>(n, &mpad);
+    if (bwd && lds > 160u * 1024u) return PACOH_ELIMIT;
+    const long total = (long)B * n;
+    hipLaunchKernelGGL(dense_resid_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T*)y, y_div,
+                       (const T*)mean, mean_mode, n_valid, resid, P, n, total);
+    const double jitter_base = dtype == PACOH_F32 ? 1e-6 : 1e-8;            // psd_safe_cholesky [gpytorch-upstream]
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if (attempt == 0) {
+            int rc = pacoh_gram_rbf_ard(z, z_div, z, z_div, ls, os, noise, 1, A, B, P, n, n, f, dtype, s);
+            if (rc) return rc;
+        } else {
+            double jit = jitter_base;
+            for (int q = 1; q < attempt; ++q) jit *= 10.0;
+            hipLaunchKernelGGL(regram_failed_kernel<T>, dim3(n, B), dim3(256), 0, s, (const T*)z, z_div, (const T*)ls, (const T*)os,
+                               (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f);
+        }
+        if (n_valid) hipLaunchKernelGGL(dense_mask_kernel<T>, dim3(n, B), dim3(256), 0, s, A, n_valid, y_div, (const int32_t*)info, attempt, n);
+        int rc = dense_chol_launch(A, resid, logp, alpha, info, 1.0, B, n, dtype, attempt, s);
+        if (rc) return rc;
+    }
+    if (bwd) {
+        auto kern = trtri_dense_kernel<T>;
+        if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PACOH_ELIMIT;
+        hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, A, (const int32_t*)info, n, mpad);
+        GemmArgs ga = {A, A, Wm, (long)n * n, (long)n * n, (long)n * n, n, n, n, n, n, n, 1, 0, 1, 1, 1.0, 0.0, info};
+        launch_bgemm<T>(ga, B, s);                                          // W = Z^T Z
+        const int FP = f <= 2 ? 2 : (f <= 4 ? 4 : (f <= 8 ? 8 : 16));
+#define PACOH_DG_CASE(fp) case fp: hipLaunchKernelGGL((dense_grad_rows_kernel<T, fp>), dim3((n + 3) / 4, B), dim3(256), 0, s, \
+        (const T*)z, z_div, (const T*)ls, (const T*)os, n_valid, y_div, (const T*)g_lml, (const T*)alpha, (const T*)Wm, \
+        (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f); break;
+        switch (FP) { PACOH_DG_CASE(2) PACOH_DG_CASE(4) PACOH_DG_CASE(8) default: PACOH_DG_CASE(16) }
+#undef PACOH_DG_CASE
+    }
+    hipLaunchKernelGGL(dense_finish_kernel<T>, dim3(B), dim3(64), 0, s, (const T*)logp, (const T*)rowpart, (const T*)ls, n_valid,
+                       y_div, (const T*)g_lml, (const int32_t*)info, (T*)lml, (T*)d_mean, mean_mode, (T*)d_ls, (T*)d_os,
+                       (T*)d_noise, P, n, f, bwd ? 1 : 0);
+    return launch_status();
+}
+
+template <typename T>
+int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int mean_mode, const void* y, int y_div,
+                       const void* z_tst, int zt_div, const void* mean_tst, const void* ls, const void* os, const void* noise,
+                       const int32_t* n_valid, void* mu, void* var, void* cov, int32_t* info, void* workspace, int B, int P,
+                       int n, int m, int f, int dtype, hipStream_t s) {
+    const size_t nn = (size_t)B * n * n, nm = (size_t)B * n * m;
+    unsigned char* w = (unsigned char*)workspace;
+    T* A = (T*)w;                 w += align256(nn * sizeof(T));
+    T* Kxs = (T*)w;               w += align256(nm * sizeof(T));
+    T* V = (T*)w;                 w += align256(nm * sizeof(T));
+    T* resid = (T*)w;             w += align256((size_t)B * n * sizeof(T));
+    T* alpha = (T*)w;             w += align256((size_t)B * n * sizeof(T));
+    T* logp = (T*)w;
+    int mpad = 0;
+    const size_t lds = trtri_lds<T>(n, &mpad);
+    if (lds > 160u * 1024u) return PACOH_ELIMIT;
+    const long total = (long)B * n;
+    hipLaunchKernelGGL(dense_resid_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T*)y, y_div,
+                       (const T*)mean_ctx, mean_mode, n_valid, resid, P, n, total);
+    const double jitter_base = dtype == PACOH_F32 ? 1e-6 : 1e-8;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if (attempt == 0) {
+            int rc = pacoh_gram_rbf_ard(z_ctx, z_div, z_ctx, z_div, ls, os, noise, 1, A, B, P, n, n, f, dtype, s);
+            if (rc) return rc;
+        } else {
+            double jit = jitter_base;
+            for (int q = 1; q < attempt; ++q) jit *= 10.0;
+            hipLaunchKernelGGL(regram_failed_kernel<T>, dim3(n, B), dim3(256), 0, s, (const T*)z_ctx, z_div, (const T*)ls,
+                               (const T*)os, (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f);
+        }
+        if (n_valid) hipLaunchKernelGGL(dense_mask_kernel<T>, dim3(n, B), dim3(256), 0, s, A, n_valid, y_div, (const int32_t*)info, attempt, n);
+        int rc = dense_chol_launch(A, resid, logp, alpha, info, 1.0, B, n, dtype, attempt, s);
+        if (rc) return rc;
+    }
+    auto kern = trtri_dense_kernel<T>;
+    if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PACOH_ELIMIT;
+    hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, A, (const int32_t*)info, n, mpad);
+    int rc = pacoh_gram_rbf_ard(z_ctx, z_div, z_tst, zt_div, ls, os, nullptr, 0, Kxs, B, P, n, m, f, dtype, s);
+    if (rc) return rc;
+    // padded context rows carry no information: Z's identity rows would pass those rows of K_xs straight into V
+    if (n_valid) hipLaunchKernelGGL(dense_zero_rows_kernel<T>, dim3(n, B), dim3(256), 0, s, Kxs, n_valid, y_div, n, m);
+    GemmArgs gv = {A, Kxs, V, (long)n * n, (long)n * m, (long)n * m, n, m, m, n, m, n, 0, 0, 1, 0, 1.0, 0.0, info};
+    launch_bgemm<T>(gv, B, s);                                              // V = Z K_xs
+    if (cov) {
+        rc = pacoh_gram_rbf_ard(z_tst, zt_div, z_tst, zt_div, ls, os, noise, 1, cov, B, P, m, m, f, dtype, s);
+        if (rc) return rc;
+        GemmArgs gc = {V, V, cov, (long)n * m, (long)n * m, (long)m * m, m, m, m, m, m, n, 1, 0, 0, 0, -1.0, 1.0, info};
+        launch_bgemm<T>(gc, B, s);                                          // cov = K_ss + noise I - V^T V
+    }
+    const long tot2 = (long)B * m;
+    hipLaunchKernelGGL(dense_predict_finish_kernel<T>, dim3((unsigned)((tot2 + 127) / 128)), dim3(128), 0, s, (const T*)Kxs, (const T*)V,
+                       (const T*)alpha, (const T*)mean_tst, mean_mode, (const T*)os, (const T*)noise, (const int32_t*)info,
+                       (T*)mu, (T*)var, (T*)cov, P, n, m, tot2);
+    return launch_status();
+}
+
+}  // namespace
+}  // namespace pacoh
+
+using namespace pacoh;
+
+extern "C" size_t pacoh_gp_lml_dense_workspace_bytes(int B, int n, int f, int dtype, int want_grad) {
+    if (B <= 0 || n <= 0 || f <= 0) return 0;
+    const size_t e = dtype == PACOH_F64 ? 8 : 4;
+    const size_t nn = (size_t)B * n * n;
+    return align256(nn * e) * (want_grad ? 2 : 1) + 2 * align256((size_t)B * n * e) + align256((size_t)B * e) +
+           align256((size_t)B * n * (f + 3) * e) + 256;
+}
+
+extern "C" int pacoh_gp_lml_dense(const void* z, int z_div, const void* mean, int mean_mode, const void* y, int y_div,
+                                  const void* lengthscale, const void* outputscale, const void* noise, const int32_t* n_valid,
+                                  const void* g_lml, void* lml, void* d_z, void* d_mean, void* d_lengthscale, void* d_outputscale,
+                                  void* d_noise, int32_t* info, void* workspace, int B, int P, int n, int f, int dtype,
+                                  void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!z || !y || !lengthscale || !noise || !lml || !info || !workspace || B <= 0 || P <= 0 || n <= 0 || f <= 0 || z_div <= 0 ||
+        y_div <= 0)
+        return PACOH_EINVAL;
+    if (mean_mode != PACOH_MEAN_ZERO && !mean) return PACOH_EINVAL;
+    if (d_lengthscale && !d_noise) return PACOH_EINVAL;
+    if (f > PACOH_MAX_FEATURES) return PACOH_ELIMIT;
+    if (dtype == PACOH_F32)
+        return lml_dense_impl<float>(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, g_lml, lml, d_z,
+                                     d_mean, d_lengthscale, d_outputscale, d_noise, info, workspace, B, P, n, f, dtype, (hipStream_t)stream);
+    return lml_dense_impl<double>(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, g_lml, lml, d_z,
+                                  d_mean, d_lengthscale, d_outputscale, d_noise, info, workspace, B, P, n, f, dtype, (hipStream_t)stream);
+}
+
+extern "C" size_t pacoh_gp_predict_dense_workspace_bytes(int B, int n, int m, int dtype) {
+    if (B <= 0 || n <= 0 || m <= 0) return 0;
+    const size_t e = dtype == PACOH_F64 ? 8 : 4;
+    return align256((size_t)B * n * n * e) + 2 * align256((size_t)B * n * m * e) + 2 * align256((size_t)B * n * e) +
+           align256((size_t)B * e) + 256;
+}
+
+extern "C" int pacoh_gp_predict_dense(const void* z_ctx, int z_div, const void* mean_ctx, int mean_mode, const void* y, int y_div,
+                                      const void* z_tst, int zt_div, const void* mean_tst, const void* lengthscale,
+                                      const void* outputscale, const void* noise, const int32_t* n_valid, void* mu, void* var,
+                                      void* cov, int32_t* info, void* workspace, int B, int P, int n, int m, int f, int dtype,
+                                      void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!z_ctx || !y || !z_tst || !lengthscale || !noise || !mu || !var || !info || !workspace || B <= 0 || P <= 0 || n <= 0 ||
+        m <= 0 || f <= 0 || z_div <= 0 || y_div <= 0 || zt_div <= 0)
+        return PACOH_EINVAL;
+    if (mean_mode != PACOH_MEAN_ZERO && (!mean_ctx || !mean_tst)) return PACOH_EINVAL;
+    if (f > PACOH_MAX_FEATURES) return PACOH_ELIMIT;
+    if (dtype == PACOH_F32)
+        return predict_dense_impl<float>(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, z_tst, zt_div, mean_tst, lengthscale, outputscale,
+                                         noise, n_valid, mu, var, cov, info, workspace, B, P, n, m, f, dtype, (hipStream_t)stream);
+    return predict_dense_impl<double>(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, z_tst, zt_div, mean_tst, lengthscale, outputscale,
+                                      noise, n_valid, mu, var, cov, info, workspace, B, P, n, m, f, dtype, (hipStream_t)stream);
+}

@@ -32,7 +32,8 @@ constexpr int DLP = 36;            // leading dimension of the LDS panel / inver
 template <typename T>
 __global__ void __launch_bounds__(256) chol_dense_mfma_kernel(T* __restrict__ A, const T* __restrict__ resid,
                                                               T* __restrict__ logp, T* __restrict__ alpha_out,
-                                                              int32_t* __restrict__ info, T scale, int n, int mpad) {
+                                                              int32_t* __restrict__ info, T scale, int n, int mpad, int attempt) {
+    if (attempt > 0 && info && info[blockIdx.x] >= 0) return;      // jitter-ladder retry: only the failed problems
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* sm = reinterpret_cast<T*>(smem_raw);
     T (*Ds)[DNB + 1] = reinterpret_cast<T (*)[DNB + 1]>(sm);          // diagonal block / L11
@@ -197,7 +198,7 @@ __global__ void __launch_bounds__(256) chol_dense_mfma_kernel(T* __restrict__ A,
         const T LOG2PI = T(1.8378770664093453);
         const T lp = T(-0.5) * (quad + T(2) * logdet + T(n) * LOG2PI) * scale;
         logp[blockIdx.x] = ok ? lp : T(NAN);
-        if (info) info[blockIdx.x] = ok ? 0 : -1;
+        if (info) info[blockIdx.x] = ok ? attempt : -1;
     }
     if (!alpha_out) return;
     // ---- backward solve L^T alpha = u, blocked from the bottom ----------------------------------------
@@ -235,7 +236,7 @@ __global__ void __launch_bounds__(256) chol_dense_mfma_kernel(T* __restrict__ A,
 // returns 1 when the panel does not fit in LDS (caller falls back to the VALU kernel of dense.hip)
 template <typename T>
 static int launch_dense_mfma(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale,
-                             int B, int n, hipStream_t s) {
+                             int B, int n, int attempt, hipStream_t s) {
     const int mpad = n > DNB ? (n - DNB + 15) / 16 * 16 : 16;        // rows of the largest panel, in 16-row blocks
     const size_t elems = (size_t)DNB * (DNB + 1) + (size_t)DNB * DLP + (size_t)mpad * DLP + 8 + n;
     const size_t lds = elems * sizeof(T);
@@ -243,14 +244,14 @@ static int launch_dense_mfma(void* A, const void* resid, void* logp, void* alpha
     auto kern = chol_dense_mfma_kernel<T>;
     if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return 1;
-    hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, (T*)A, (const T*)resid, (T*)logp, (T*)alpha_out, info, (T)scale, n, mpad);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, (T*)A, (const T*)resid, (T*)logp, (T*)alpha_out, info, (T)scale, n, mpad, attempt);
     return launch_status();
 }
 
 int dense_mfma_try(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
-                   int dtype, hipStream_t s) {
-    return dtype == PACOH_F32 ? launch_dense_mfma<float>(A, resid, logp, alpha_out, info, scale, B, n, s)
-                              : launch_dense_mfma<double>(A, resid, logp, alpha_out, info, scale, B, n, s);
+                   int dtype, int attempt, hipStream_t s) {
+    return dtype == PACOH_F32 ? launch_dense_mfma<float>(A, resid, logp, alpha_out, info, scale, B, n, attempt, s)
+                              : launch_dense_mfma<double>(A, resid, logp, alpha_out, info, scale, B, n, attempt, s);
 }
 
 }  // namespace pacoh

@@ -1,0 +1,160 @@
+"""Large-n GP path (every n x n matrix materialised in HBM: gram -> MFMA-panel Cholesky -> triangular inverse -> batched MFMA
+GEMM -> gradient contractions; csrc/dense_gp.hip) against the CPU oracle: same checks as the LDS-resident kernels, at sizes
+beyond their limit and -- with the routing forced -- at small sizes where both device paths must agree."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pacoh_oracle as O
+from tests.test_gpu_kernels import make_problem, maxrel, oracle_mll, relerr
+
+DEV = 'cuda:0'
+TOL = {torch.float32: 2e-3, torch.float64: 1e-9}
+
+
+@pytest.fixture()
+def L():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    from meta_learning_pacoh_amd import _lib
+    _lib.FORCE_DENSE = True
+    yield _lib
+    _lib.FORCE_DENSE = False
+
+
+CASES = [
+    (2, 2, 64, 2, True),       # small: both device paths exist
+    (3, 2, 47, 3, False),      # odd n, shared inputs (SE kernel on x)
+    (2, 2, 200, 3, True),      # beyond the LDS-resident limit
+    (1, 2, 300, 2, True),
+    (2, 1, 512, 8, False),     # cfg #5 shape
+    (1, 1, 33, 16, True),      # max feature dim, one row past a panel
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('case', CASES)
+def test_dense_lml_fwdbwd(L, dtype, case):
+    T, P, n, f, pez = case
+    z, mean, y, ls, os_, noise = make_problem(T, P, n, f, dtype, seed=7 * n + f, per_eval_z=pez, noise_lo=0.0)
+    gl = torch.rand(T * P, dtype=dtype) + 0.5
+    leaves = [t.double().clone().requires_grad_(True) for t in (z, mean, ls, os_, noise)]
+    ref = oracle_mll(leaves[0], leaves[1], y.double(), leaves[2], leaves[3], leaves[4], T, P, pez)
+    (ref * gl.double()).sum().backward()
+    out = L.gp_lml_fwdbwd(z.to(DEV), 1 if pez else P, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, ls.to(DEV),
+                          os_.to(DEV), noise.to(DEV), T * P, P, g_lml=gl.to(DEV), want_dz=pez)
+    lml, d_z, d_mean, d_ls, d_os, d_noise, info = out
+    assert int(info.abs().max()) == 0
+    assert maxrel(lml, ref) < TOL[dtype]
+    gtol = 1e-2 if dtype == torch.float32 else 1e-7
+    if pez:
+        assert relerr(d_z, leaves[0].grad) < gtol
+    assert relerr(d_mean, leaves[1].grad) < gtol
+    assert relerr(d_ls.reshape(T, P, f).sum(0), leaves[2].grad) < gtol
+    assert relerr(d_os.reshape(T, P).sum(0), leaves[3].grad) < gtol
+    assert relerr(d_noise.reshape(T, P).sum(0), leaves[4].grad) < gtol
+    # forward-only entry point gives the same value
+    lml2, _, _, info2 = L.gp_lml_fwd(z.to(DEV), 1 if pez else P, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, ls.to(DEV),
+                                     os_.to(DEV), noise.to(DEV), T * P, P)
+    assert torch.equal(lml2, lml) and int(info2.abs().max()) == 0
+
+
+def test_dense_matches_lds_resident_kernels(L):
+    """same inputs through both device paths (fp32, headline shape n=64, f=2)"""
+    T, P, n, f = 4, 3, 64, 2
+    z, mean, y, ls, os_, noise = [t.to(DEV) for t in make_problem(T, P, n, f, torch.float32, seed=1)]
+    dense = L.gp_lml_fwdbwd(z, 1, mean, L.MEAN_VECTOR, y, P, ls, os_, noise, T * P, P)
+    L.FORCE_DENSE = False
+    small = L.gp_lml_fwdbwd(z, 1, mean, L.MEAN_VECTOR, y, P, ls, os_, noise, T * P, P)
+    for a, b in zip(dense[:6], small[:6]):
+        assert relerr(a, b) < 2e-3
+
+
+def test_dense_const_and_zero_mean(L):
+    T, P, n, f = 3, 2, 150, 2
+    z, _, y, ls, os_, noise = make_problem(T, P, n, f, torch.float64, seed=11)
+    c = torch.tensor([0.3, -0.7], dtype=torch.float64, requires_grad=True)
+    ref = oracle_mll(z, c.unsqueeze(0).expand(T, P).reshape(-1, 1).expand(-1, n), y, ls, os_, noise, T, P)
+    ref.sum().backward()
+    out = L.gp_lml_fwdbwd(z.to(DEV), 1, c.detach().to(DEV), L.MEAN_CONST, y.to(DEV), P, ls.to(DEV), os_.to(DEV),
+                          noise.to(DEV), T * P, P)
+    assert maxrel(out[0], ref) < 1e-9 and relerr(out[2].reshape(T, P).sum(0), c.grad) < 1e-8
+    one = torch.ones(P, dtype=torch.float64)
+    ref0 = oracle_mll(z, torch.zeros(T * P, n, dtype=torch.float64), y, ls, one, noise, T, P)
+    out0 = L.gp_lml_fwdbwd(z.to(DEV), 1, None, L.MEAN_ZERO, y.to(DEV), P, ls.to(DEV), None, noise.to(DEV), T * P, P)
+    assert maxrel(out0[0], ref0) < 1e-9 and out0[2] is None and out0[4] is None
+
+
+def test_dense_ragged_n_valid(L):
+    T, P, n, f = 4, 2, 140, 2
+    sizes = [140, 5, 77, 1]
+    z, mean, y, ls, os_, noise = make_problem(T, P, n, f, torch.float64, seed=5)
+    nv = torch.tensor(sizes, dtype=torch.int32)
+    out = L.gp_lml_fwdbwd(z.to(DEV), 1, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, ls.to(DEV), os_.to(DEV),
+                          noise.to(DEV), T * P, P, n_valid=nv.to(DEV))
+    lml, d_z, d_mean, d_ls, d_os, d_noise, info = [o.cpu() for o in out]
+    for t in range(T):
+        s = sizes[t]
+        for p in range(P):
+            b = t * P + p
+            zz = z[b, :s].clone().requires_grad_(True)
+            mm = mean[b, :s].clone().requires_grad_(True)
+            hy = [h.clone().requires_grad_(True) for h in (ls[p], os_[p], noise[p])]
+            ref = O.gp_mll(zz, mm, y[t, :s], hy[0], hy[1], hy[2])
+            ref.backward()
+            assert abs(float(lml[b] - ref)) < 1e-9 * max(1, abs(float(ref)))
+            assert relerr(d_z[b, :s], zz.grad) < 1e-7 and float(d_z[b, s:].abs().sum()) == 0
+            assert relerr(d_mean[b, :s], mm.grad) < 1e-7 and float(d_mean[b, s:].abs().sum()) == 0
+            assert relerr(d_ls[b], hy[0].grad) < 1e-7
+            assert relerr(d_os[b], hy[1].grad) < 1e-7 and relerr(d_noise[b], hy[2].grad) < 1e-7
+
+
+def test_dense_jitter_ladder(L):
+    """identical points + ~zero noise: the fp32 factorisation fails, the retry launches re-build only that problem with
+    gpytorch's psd_safe_cholesky jitter and report the attempt in info[]"""
+    n, f = 160, 2
+    z = torch.zeros(2, n, f, dtype=torch.float32)           # one task, two hyper-parameter sets: b = p
+    z[1] = torch.randn(n, f)
+    y = torch.randn(1, n, dtype=torch.float32)
+    ls = torch.ones(2, f, dtype=torch.float32)
+    noise = torch.tensor([1e-12, 0.3], dtype=torch.float32)
+    out = L.gp_lml_fwdbwd(z.to(DEV), 1, None, L.MEAN_ZERO, y.to(DEV), 2, ls.to(DEV), None, noise.to(DEV), 2, 2)
+    lml, info = out[0].cpu(), out[-1].cpu()
+    assert int(info[0]) >= 1 and int(info[1]) == 0
+    assert bool(torch.isfinite(lml).all()) and bool(torch.isfinite(out[3]).all())
+    # the healthy problem is untouched by the retries
+    ref1 = O.gp_mll(z[1].double(), torch.zeros(n, dtype=torch.float64), y[0].double(), ls[1].double(),
+                    torch.tensor(1.0, dtype=torch.float64), noise[1].double())
+    assert abs(float(lml[1]) - float(ref1)) < 1e-3 * abs(float(ref1))
+    jit = 1e-6 * 10 ** (int(info[0]) - 1)
+    K = torch.ones(n, n, dtype=torch.float64) + (1e-12 + jit) * torch.eye(n, dtype=torch.float64)
+    ref0 = torch.distributions.MultivariateNormal(torch.zeros(n, dtype=torch.float64), K).log_prob(y[0].double()) / n
+    assert abs(float(lml[0]) - float(ref0)) < 0.2 * abs(float(ref0))     # fp32 at condition ~1e8: loose by nature
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('case', [(2, 2, 64, 130, 4), (1, 2, 200, 50, 2), (1, 1, 300, 7, 3)])
+def test_dense_predict(L, dtype, case):
+    T, P, n, m, f = case
+    B = T * P
+    z, mean, y, ls, os_, noise = make_problem(T, P, n, f, dtype, seed=m, noise_lo=0.0)
+    g = torch.Generator().manual_seed(99)
+    zt = torch.randn(B, m, f, generator=g, dtype=dtype)
+    mt = 0.2 * torch.randn(B, m, generator=g, dtype=dtype)
+    mu, var, cov, info = L.gp_predict(z.to(DEV), 1, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, zt.to(DEV), 1, mt.to(DEV),
+                                      ls.to(DEV), os_.to(DEV), noise.to(DEV), B, P, want_cov=True)
+    yy = y.unsqueeze(1).expand(T, P, n).reshape(B, n).double()
+    lsb = ls.unsqueeze(0).expand(T, P, f).reshape(B, 1, f).double()
+    osb = os_.unsqueeze(0).expand(T, P).reshape(B).double()
+    nb = noise.unsqueeze(0).expand(T, P).reshape(B).double()
+    rm, rc = O.gp_predict(z.double(), mean.double(), yy, zt.double(), mt.double(), lsb, osb, nb)
+    tol = 5e-3 if dtype == torch.float32 else 1e-8
+    assert int(info.abs().max()) == 0
+    assert relerr(mu, rm) < tol
+    assert relerr(var, torch.diagonal(rc, dim1=-2, dim2=-1)) < tol
+    assert relerr(cov, rc) < tol
+    mu2, var2, cov2, _ = L.gp_predict(z.to(DEV), 1, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, zt.to(DEV), 1, mt.to(DEV),
+                                      ls.to(DEV), os_.to(DEV), noise.to(DEV), B, P, want_cov=False)
+    assert cov2 is None and torch.equal(mu2, mu) and torch.equal(var2, var)

@@ -423,3 +423,46 @@ def test_vi_full_covariance_steps_match_oracle(M):
     x, y = tasks[0]
     mu, sd = model.predict(x, y, x[:5], n_posterior_samples=7)
     assert np.isfinite(mu).all() and (sd > 0).all()
+
+
+# ------------------------------------------------------------------------------------------ large contexts (HBM-resident path)
+def test_map_large_context_matches_oracle(M):
+    """n_ctx = 200 > LDS-resident limit: meta_fit / predict / eval run through csrc/dense_gp.hip"""
+    tasks = tasks_nd(3, 200, 2)
+    kw = dict(weight_decay=0.1, num_iter_fit=8, task_batch_size=2, random_seed=5, lr_params=5e-3)
+    model = M.GPRegressionMetaLearned(tasks, **kw)
+    orc = O.MapOracle(tasks, **kw)
+    model.meta_fit(verbose=False)
+    orc.meta_fit(None, log_period=100)
+    lay = model.layout
+    for name, ref in (('noise_raw', orc.raw_noise), ('lengthscale_raw', orc.raw_lengthscale), ('outputscale_raw', orc.raw_outputscale)):
+        lo, hi = lay.slices[name]
+        assert torch.allclose(model.theta[0, lo:hi].cpu(), ref.detach().reshape(-1), atol=3e-4), name
+    lo, hi = lay.slices['kernel_nn.fc_2.weight']
+    assert relerr(model.theta[0, lo:hi], orc.kernel_net[1].weight.reshape(-1)) < 2e-3
+    cx, cy = tasks[0]
+    tx = tasks[1][0][:40]
+    pm, ps = model.predict(cx, cy, tx)
+    mean_n, cov_n = orc.predict_normalized(cx, cy, tx)
+    assert relerr(pm, mean_n * orc.stats[3][0] + orc.stats[2][0]) < 2e-3
+    assert relerr(ps, torch.sqrt(torch.diagonal(cov_n)) * orc.stats[3][0]) < 5e-3
+    ll, rmse, calib = model.eval(cx, cy, tx, tasks[1][1][:40])
+    ll_o, rmse_o, calib_o = orc.eval(cx, cy, tx, tasks[1][1][:40])
+    assert abs(ll - ll_o) < 5e-3 * max(1, abs(ll_o)) and abs(rmse - rmse_o) < 2e-3
+
+
+def test_svgd_large_context_score_matches_oracle(M):
+    T, P, n, d = 3, 3, 160, 2
+    tasks = tasks_nd(T, n, d)
+    model = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=P, random_seed=3, lr=1e-2)
+    cfg = O.GPConfig(d, 'NN', 'NN')
+    pm, ps = O.hyperprior_mean_std(cfg.layout, 0.5, 3.0)
+    stats = O.compute_normalization_stats(tasks)
+    otasks = [O.prepare_task(x, y, stats, torch.float64) for x, y in tasks]
+    pre = O.meta_pre_factor([n] * T)
+    lp, score = model._log_prob_and_score(model.particles, np.arange(T), pre)
+    lp_o, score_o = O.meta_score(model.particles.cpu().double(), otasks, cfg, pm, ps, 0.01)
+    assert relerr(lp, lp_o) < 1e-4 and relerr(score, score_o) < 1e-2
+    model.meta_fit(verbose=False, n_iter=3)
+    mu, sd = model.predict(tasks[0][0], tasks[0][1], tasks[1][0][:9])
+    assert np.isfinite(mu).all() and (sd > 0).all()

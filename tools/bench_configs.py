@@ -43,4 +43,13 @@ out['cfg5_dense_256x512_d8_fp64'] = {'ms_per_pass': dt * 1e3, 'evals_per_s': 256
                                      'gram_ms': prof['gram_rbf_ard'][1] / prof['gram_rbf_ard'][0],
                                      'gram_GBs': 256 * (512 * 8 * 8 + 512 * 512 * 8) / (prof['gram_rbf_ard'][1] / prof['gram_rbf_ard'][0] * 1e-3) / 1e9,
                                      'chol_ms': prof['mvn_logprob_dense'][1] / prof['mvn_logprob_dense'][0]}
+# cfg 5, full LML + gradient through the HBM-resident path (pacoh_gp_lml_dense): gram, Cholesky, triangular inverse, Z^T Z, contractions
+os1 = torch.ones(1, dtype=torch.float64, device='cuda')
+def cfg5_grad():
+    L.gp_lml_fwdbwd(X, 1, None, L.MEAN_ZERO, Y, 1, ls, os1, nz, 256, 1)
+dt = timeit(cfg5_grad, reps=5, warm=2)
+out['cfg5_dense_lml_plus_grad_256x512_d8_fp64'] = {'ms_per_pass': dt * 1e3, 'evals_per_s': 256 / dt}
+Xf, Yf, lsf, nzf, osf = X.float(), Y.float(), ls.float(), nz.float(), os1.float()
+dt = timeit(lambda: L.gp_lml_fwdbwd(Xf, 1, None, L.MEAN_ZERO, Yf, 1, lsf, osf, nzf, 256, 1), reps=5, warm=2)
+out['cfg5_dense_lml_plus_grad_256x512_d8_fp32'] = {'ms_per_pass': dt * 1e3, 'evals_per_s': 256 / dt}
 print(json.dumps(out, indent=1))
