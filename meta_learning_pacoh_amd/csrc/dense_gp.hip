@@ -62,6 +62,19 @@ __global__ void dense_resid_kernel(const T* __restrict__ y, int y_div, const T* 
     resid[q] = i < nv ? y[ty * n + i] - m : T(0);
 }
 
+// ---- zs[b,i,c] = z[b / z_div, i, c] / lengthscale[p,c]: the gradient contractions read pre-scaled coordinates ----------------
+template <typename T>
+__global__ void dense_scale_kernel(const T* __restrict__ z, int z_div, const T* __restrict__ ls, T* __restrict__ zs, int P, int n,
+                                   int f, long total) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= total) return;
+    const int c = (int)(q % f);
+    const long bi = q / f;
+    const long b = bi / n;
+    const int i = (int)(bi - b * n);
+    zs[q] = z[((b / z_div) * n + i) * (long)f + c] / ls[(b % P) * (long)f + c];
+}
+
 // ---- ragged tasks: rows / columns >= n_valid become an identity block -----------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) dense_mask_kernel(T* __restrict__ A, const int32_t* __restrict__ n_valid, int y_div,
@@ -96,28 +109,30 @@ __global__ void __launch_bounds__(256) regram_failed_kernel(const T* __restrict_
     const long b = blockIdx.y;
     if (info[b] >= 0) return;
     const int p = (int)(b % P);
-    const int i = blockIdx.x;
     const T* zb = z + (b / z_div) * (long)n * f;
     const T osv = os ? os[p] : T(1);
     const T dg = noise[p] + jitter;
-    T* row = A + (b * n + i) * (long)n;
-    for (int j = threadIdx.x; j < n; j += 256) {
-        T s = 0;
-        for (int c = 0; c < f; ++c) { const T d = zb[(long)i * f + c] / ls[(long)p * f + c] - zb[(long)j * f + c] / ls[(long)p * f + c]; s = fma(d, d, s); }
-        row[j] = osv * rbf_exp<T>(T(-0.5) * s) + (i == j ? dg : T(0));
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {          // few workgroups per problem: the usual case is the early exit above
+        T* row = A + (b * n + i) * (long)n;
+        for (int j = threadIdx.x; j < n; j += 256) {
+            T s = 0;
+            for (int c = 0; c < f; ++c) { const T d = zb[(long)i * f + c] / ls[(long)p * f + c] - zb[(long)j * f + c] / ls[(long)p * f + c]; s = fma(d, d, s); }
+            row[j] = osv * rbf_exp<T>(T(-0.5) * s) + (i == j ? dg : T(0));
+        }
     }
 }
 
 // ---- Z = L^-1 in place (lower triangle), right-to-left over 32-column panels ------------------------------------------------
 //   Z11 = L11^-1 (one wavefront, LDS);  Q = L21 Z11 (MFMA, LDS panel);  Z21 = -Z22 Q (MFMA: Z22 blocks from L2, Q from LDS)
-template <typename T>
-__global__ void __launch_bounds__(256) trtri_dense_kernel(T* __restrict__ A, const int32_t* __restrict__ info, int n, int mpad) {
+template <typename T, int NT>
+__global__ void __launch_bounds__(NT) trtri_dense_kernel(T* __restrict__ A, const int32_t* __restrict__ info, int n, int mpad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* sm = reinterpret_cast<T*>(smem_raw);
     T (*Ds)[DNB + 1] = reinterpret_cast<T (*)[DNB + 1]>(sm);          // L11
     T* Li = sm + DNB * (DNB + 1);                                      // Z11 = L11^-1, [32][DLP]
     T* Pn = Li + DNB * DLP;                                            // panel L21 -> Q, [mpad][DLP]
     using Acc = typename Mf<T>::acc;
+    constexpr int NW = NT / 64;
     if (info && info[blockIdx.x] < 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -127,7 +142,7 @@ __global__ void __launch_bounds__(256) trtri_dense_kernel(T* __restrict__ A, con
         const int k0 = kbk * DNB;
         const int kb = (n - k0 < DNB) ? (n - k0) : DNB;
         const int t0 = k0 + kb, m = n - t0;
-        for (int q = tid; q < DNB * DNB; q += 256) {
+        for (int q = tid; q < DNB * DNB; q += NT) {
             const int rr = q / DNB, c = q - rr * DNB;
             T v = (rr == c) ? T(1) : T(0);
             if (rr < kb && c <= rr) v = Ab[(size_t)(k0 + rr) * n + k0 + c];
@@ -150,19 +165,19 @@ __global__ void __launch_bounds__(256) trtri_dense_kernel(T* __restrict__ A, con
             }
         }
         __syncthreads();
-        for (int q = tid; q < DNB * DNB; q += 256) {
+        for (int q = tid; q < DNB * DNB; q += NT) {
             const int rr = q / DNB, c = q - rr * DNB;
             if (rr < kb && c <= rr) Ab[(size_t)(k0 + rr) * n + k0 + c] = Li[rr * DLP + c];
         }
         if (m > 0) {
             const int mb = (m + 15) / 16;
-            for (int q = tid; q < mb * 16 * DNB; q += 256) {
+            for (int q = tid; q < mb * 16 * DNB; q += NT) {
                 const int rr = q / DNB, c = q - rr * DNB;
                 Pn[(size_t)rr * DLP + c] = (rr < m && c < kb) ? Ab[(size_t)(t0 + rr) * n + k0 + c] : T(0);
             }
             __syncthreads();
             // Q = L21 Z11, in place (a wave owns whole row blocks and reads them completely before writing)
-            for (int ib = wave; ib < mb; ib += 4) {
+            for (int ib = wave; ib < mb; ib += NW) {
                 Acc acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
                 for (int c = 0; c < DNB / 4; ++c) {
@@ -179,7 +194,7 @@ __global__ void __launch_bounds__(256) trtri_dense_kernel(T* __restrict__ A, con
             }
             __syncthreads();
             // Z21 = -Z22 Q: row block ib needs the (already inverted) blocks Z22[ib][0..ib]; heavy blocks first
-            for (int ib = mb - 1 - wave; ib >= 0; ib -= 4) {
+            for (int ib = mb - 1 - wave; ib >= 0; ib -= NW) {
                 Acc acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
                 const int rowi = ib * 16 + r;
                 const T* arow = Ab + (size_t)(t0 + rowi) * n + t0;
@@ -218,6 +233,7 @@ struct GemmArgs {
     int transA, transB, lowerA, lowerB;
     double alpha, beta;
     const int32_t* info;         // optional: skip problems with info[b] < 0
+    int symC;                    // C is symmetric: only tiles on / below the diagonal are computed, then mirrored
 };
 
 template <typename T>
@@ -235,6 +251,7 @@ __global__ void __launch_bounds__(256) bgemm_kernel(GemmArgs ga) {
     const int r = lane & 15, g = lane >> 4;
     const int tiles_n = (ga.N + 63) / 64;
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    if (ga.symC && tn > tm) return;
     const int i0 = tm * 64 + (wave >> 1) * 32, j0 = tn * 64 + (wave & 1) * 32;
     if (i0 >= ga.M || j0 >= ga.N) return;
     const T* A = (const T*)ga.A + (long)b * ga.sA;
@@ -252,20 +269,41 @@ __global__ void __launch_bounds__(256) bgemm_kernel(GemmArgs ga) {
     for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) acc[ib][jb] = Acc{0, 0, 0, 0};
+    const bool edge_free = i0 + 32 <= ga.M && j0 + 32 <= ga.N;
     for (int kk = klo; kk < khi; kk += 16) {
         T av[2][4], bv[2][4];
+        // chunk entirely inside the matrices and inside the stored triangles: plain loads, no per-element tests
+        const bool ina = !ga.lowerA || (ga.transA ? kk >= i0 + 31 : kk + 15 <= i0);
+        const bool inb = !ga.lowerB || (ga.transB ? kk + 15 <= j0 : kk >= j0 + 31);
+        if (edge_free && kk + 16 <= ga.K && ina && inb) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = kk + 4 * g + s;
+            for (int s = 0; s < 4; ++s) {
+                const int k = kk + 4 * g + s;
 #pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-                const int i = i0 + 16 * ib + r;
-                av[ib][s] = ga.transA ? gemm_ld<T>(A, ga.lda, k, i, Ar, Ac, ga.lowerA) : gemm_ld<T>(A, ga.lda, i, k, Ar, Ac, ga.lowerA);
+                for (int ib = 0; ib < 2; ++ib) {
+                    const int i = i0 + 16 * ib + r;
+                    av[ib][s] = ga.transA ? A[(long)k * ga.lda + i] : A[(long)i * ga.lda + k];
+                }
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    const int j = j0 + 16 * jb + r;
+                    bv[jb][s] = ga.transB ? Bm[(long)j * ga.ldb + k] : Bm[(long)k * ga.ldb + j];
+                }
             }
+        } else {
 #pragma unroll
-            for (int jb = 0; jb < 2; ++jb) {
-                const int j = j0 + 16 * jb + r;
-                bv[jb][s] = ga.transB ? gemm_ld<T>(Bm, ga.ldb, j, k, Br, Bc, ga.lowerB) : gemm_ld<T>(Bm, ga.ldb, k, j, Br, Bc, ga.lowerB);
+            for (int s = 0; s < 4; ++s) {
+                const int k = kk + 4 * g + s;
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    const int i = i0 + 16 * ib + r;
+                    av[ib][s] = ga.transA ? gemm_ld<T>(A, ga.lda, k, i, Ar, Ac, ga.lowerA) : gemm_ld<T>(A, ga.lda, i, k, Ar, Ac, ga.lowerA);
+                }
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    const int j = j0 + 16 * jb + r;
+                    bv[jb][s] = ga.transB ? gemm_ld<T>(Bm, ga.ldb, j, k, Br, Bc, ga.lowerB) : gemm_ld<T>(Bm, ga.ldb, k, j, Br, Bc, ga.lowerB);
+                }
             }
         }
 #pragma unroll
@@ -285,7 +323,9 @@ __global__ void __launch_bounds__(256) bgemm_kernel(GemmArgs ga) {
                 const int i = i0 + 16 * ib + Mf<T>::row(g, q), j = j0 + 16 * jb + r;
                 if (i < ga.M && j < ga.N) {
                     T* cp = C + (long)i * ga.ldc + j;
-                    *cp = beta == T(0) ? alpha * acc[ib][jb][q] : fma(alpha, acc[ib][jb][q], beta * *cp);
+                    const T v = beta == T(0) ? alpha * acc[ib][jb][q] : fma(alpha, acc[ib][jb][q], beta * *cp);
+                    *cp = v;
+                    if (ga.symC && tm != tn) C[(long)j * ga.ldc + i] = v;
                 }
             }
 }
@@ -299,7 +339,7 @@ void launch_bgemm(const GemmArgs& ga, int Bn, hipStream_t s) {
 // ---- gradient sums, one wave per matrix row -----------------------------------------------------------------------------------
 //   rowpart[b, i, 0..f) = sum_j M_ij df_c^2,  [f] = sum_j G_ij e_ij,  [f+1] = G_ii,  [f+2] = alpha_i
 template <typename T, int FP>
-__global__ void __launch_bounds__(256) dense_grad_rows_kernel(const T* __restrict__ z, int z_div, const T* __restrict__ lsp,
+__global__ void __launch_bounds__(256) dense_grad_rows_kernel(const T* __restrict__ zs, const T* __restrict__ lsp,
                                                               const T* __restrict__ osp, const int32_t* __restrict__ n_valid,
                                                               int y_div, const T* __restrict__ g_lml, const T* __restrict__ alpha,
                                                               const T* __restrict__ Wm, const int32_t* __restrict__ info,
@@ -325,11 +365,11 @@ __global__ void __launch_bounds__(256) dense_grad_rows_kernel(const T* __restric
         return;
     }
     T ls[FP], zi[FP];
-    const T* zb = z + (b / z_div) * (long)n * f;
+    const T* zb = zs + b * (long)n * f;
 #pragma unroll
     for (int c = 0; c < FP; ++c) {
         ls[c] = c < f ? lsp[(long)p * f + c] : T(1);
-        zi[c] = c < f ? zb[(long)i * f + c] / ls[c] : T(0);
+        zi[c] = c < f ? zb[(long)i * f + c] : T(0);
     }
     const T os = osp ? osp[p] : T(1);
     const T ai = alpha[b * n + i];
@@ -344,7 +384,7 @@ __global__ void __launch_bounds__(256) dense_grad_rows_kernel(const T* __restric
         T s = 0, df[FP];
 #pragma unroll
         for (int c = 0; c < FP; ++c) {
-            df[c] = c < f ? zb[(long)j * f + c] / ls[c] - zi[c] : T(0);
+            df[c] = c < f ? zb[(long)j * f + c] - zi[c] : T(0);
             s = fma(df[c], df[c], s);
         }
         const T e = rbf_exp<T>(T(-0.5) * s);
@@ -437,6 +477,17 @@ __global__ void dense_predict_finish_kernel(const T* __restrict__ Kxs, const T* 
 }
 
 template <typename T>
+int launch_trtri(T* A, const int32_t* info, int B, int n, int mpad, size_t lds, hipStream_t s) {
+#define PACOH_TRTRI_LAUNCH(nt) do { auto kern = trtri_dense_kernel<T, nt>; \
+        if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return PACOH_ELIMIT; \
+        hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, s, A, info, n, mpad); } while (0)
+    if (n >= 256) PACOH_TRTRI_LAUNCH(1024); else if (n >= 96) PACOH_TRTRI_LAUNCH(512); else PACOH_TRTRI_LAUNCH(256);
+#undef PACOH_TRTRI_LAUNCH
+    return 0;
+}
+
+template <typename T>
 size_t trtri_lds(int n, int* mpad_out) {
     const int mpad = n > DNB ? (n - DNB + 15) / 16 * 16 : 16;
     *mpad_out = mpad;
@@ -458,7 +509,8 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
     T* resid = (T*)w;             w += align256((size_t)B * n * sizeof(T));
     T* alpha = (T*)w;             w += align256((size_t)B * n * sizeof(T));
     T* logp = (T*)w;              w += align256((size_t)B * sizeof(T));
-    T* rowpart = (T*)w;
+    T* rowpart = (T*)w;           w += align256((size_t)B * n * (f + 3) * sizeof(T));
+    T* zsc = (T*)w;
     int mpad = 0;
     const size_t lds = trtri_lds<T>(n, &mpad);
     if (bwd && lds > 160u * 1024u) return PACOH_ELIMIT;
@@ -473,7 +525,7 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
         } else {
             double jit = jitter_base;
             for (int q = 1; q < attempt; ++q) jit *= 10.0;
-            hipLaunchKernelGGL(regram_failed_kernel<T>, dim3(n, B), dim3(256), 0, s, (const T*)z, z_div, (const T*)ls, (const T*)os,
+            hipLaunchKernelGGL(regram_failed_kernel<T>, dim3(n < 8 ? n : 8, B), dim3(256), 0, s, (const T*)z, z_div, (const T*)ls, (const T*)os,
                                (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f);
         }
         if (n_valid) hipLaunchKernelGGL(dense_mask_kernel<T>, dim3(n, B), dim3(256), 0, s, A, n_valid, y_div, (const int32_t*)info, attempt, n);
@@ -481,15 +533,16 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
         if (rc) return rc;
     }
     if (bwd) {
-        auto kern = trtri_dense_kernel<T>;
-        if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return PACOH_ELIMIT;
-        hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, A, (const int32_t*)info, n, mpad);
-        GemmArgs ga = {A, A, Wm, (long)n * n, (long)n * n, (long)n * n, n, n, n, n, n, n, 1, 0, 1, 1, 1.0, 0.0, info};
+        int rc = launch_trtri<T>(A, info, B, n, mpad, lds, s);
+        if (rc) return rc;
+        GemmArgs ga = {A, A, Wm, (long)n * n, (long)n * n, (long)n * n, n, n, n, n, n, n, 1, 0, 1, 1, 1.0, 0.0, info, 1};
         launch_bgemm<T>(ga, B, s);                                          // W = Z^T Z
+        const long tz = (long)B * n * f;
+        hipLaunchKernelGGL(dense_scale_kernel<T>, dim3((unsigned)((tz + 255) / 256)), dim3(256), 0, s, (const T*)z, z_div, (const T*)ls, zsc,
+                           P, n, f, tz);
         const int FP = f <= 2 ? 2 : (f <= 4 ? 4 : (f <= 8 ? 8 : 16));
 #define PACOH_DG_CASE(fp) case fp: hipLaunchKernelGGL((dense_grad_rows_kernel<T, fp>), dim3((n + 3) / 4, B), dim3(256), 0, s, \
-        (const T*)z, z_div, (const T*)ls, (const T*)os, n_valid, y_div, (const T*)g_lml, (const T*)alpha, (const T*)Wm, \
+        (const T*)zsc, (const T*)ls, (const T*)os, n_valid, y_div, (const T*)g_lml, (const T*)alpha, (const T*)Wm, \
         (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f); break;
         switch (FP) { PACOH_DG_CASE(2) PACOH_DG_CASE(4) PACOH_DG_CASE(8) default: PACOH_DG_CASE(16) }
 #undef PACOH_DG_CASE
@@ -527,27 +580,27 @@ int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int m
         } else {
             double jit = jitter_base;
             for (int q = 1; q < attempt; ++q) jit *= 10.0;
-            hipLaunchKernelGGL(regram_failed_kernel<T>, dim3(n, B), dim3(256), 0, s, (const T*)z_ctx, z_div, (const T*)ls,
+            hipLaunchKernelGGL(regram_failed_kernel<T>, dim3(n < 8 ? n : 8, B), dim3(256), 0, s, (const T*)z_ctx, z_div, (const T*)ls,
                                (const T*)os, (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f);
         }
         if (n_valid) hipLaunchKernelGGL(dense_mask_kernel<T>, dim3(n, B), dim3(256), 0, s, A, n_valid, y_div, (const int32_t*)info, attempt, n);
         int rc = dense_chol_launch(A, resid, logp, alpha, info, 1.0, B, n, dtype, attempt, s);
         if (rc) return rc;
     }
-    auto kern = trtri_dense_kernel<T>;
-    if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return PACOH_ELIMIT;
-    hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, A, (const int32_t*)info, n, mpad);
+    {
+        int rc = launch_trtri<T>(A, info, B, n, mpad, lds, s);
+        if (rc) return rc;
+    }
     int rc = pacoh_gram_rbf_ard(z_ctx, z_div, z_tst, zt_div, ls, os, nullptr, 0, Kxs, B, P, n, m, f, dtype, s);
     if (rc) return rc;
     // padded context rows carry no information: Z's identity rows would pass those rows of K_xs straight into V
     if (n_valid) hipLaunchKernelGGL(dense_zero_rows_kernel<T>, dim3(n, B), dim3(256), 0, s, Kxs, n_valid, y_div, n, m);
-    GemmArgs gv = {A, Kxs, V, (long)n * n, (long)n * m, (long)n * m, n, m, m, n, m, n, 0, 0, 1, 0, 1.0, 0.0, info};
+    GemmArgs gv = {A, Kxs, V, (long)n * n, (long)n * m, (long)n * m, n, m, m, n, m, n, 0, 0, 1, 0, 1.0, 0.0, info, 0};
     launch_bgemm<T>(gv, B, s);                                              // V = Z K_xs
     if (cov) {
         rc = pacoh_gram_rbf_ard(z_tst, zt_div, z_tst, zt_div, ls, os, noise, 1, cov, B, P, m, m, f, dtype, s);
         if (rc) return rc;
-        GemmArgs gc = {V, V, cov, (long)n * m, (long)n * m, (long)m * m, m, m, m, m, m, n, 1, 0, 0, 0, -1.0, 1.0, info};
+        GemmArgs gc = {V, V, cov, (long)n * m, (long)n * m, (long)m * m, m, m, m, m, m, n, 1, 0, 0, 0, -1.0, 1.0, info, 1};
         launch_bgemm<T>(gc, B, s);                                          // cov = K_ss + noise I - V^T V
     }
     const long tot2 = (long)B * m;
@@ -567,7 +620,7 @@ extern "C" size_t pacoh_gp_lml_dense_workspace_bytes(int B, int n, int f, int dt
     const size_t e = dtype == PACOH_F64 ? 8 : 4;
     const size_t nn = (size_t)B * n * n;
     return align256(nn * e) * (want_grad ? 2 : 1) + 2 * align256((size_t)B * n * e) + align256((size_t)B * e) +
-           align256((size_t)B * n * (f + 3) * e) + 256;
+           align256((size_t)B * n * (f + 3) * e) + align256((size_t)B * n * f * e) + 256;
 }
 
 extern "C" int pacoh_gp_lml_dense(const void* z, int z_div, const void* mean, int mean_mode, const void* y, int y_div,

@@ -3,8 +3,9 @@
 // by one wavefront in LDS; the panel below it is staged in LDS once (<= 138 KB at n = 512 fp64) and
 // L21 = A21 * L11^-T as well as the trailing update A22 -= L21 L21^T run on the matrix cores
 // (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, one LDS operand read per lane per MFMA), each 16x16
-// block of A22 making exactly one HBM/L2 round trip per panel.  Solves and log-density as in dense.hip,
-// which remains the fallback for matrices whose panel does not fit in LDS.
+// block of A22 making exactly one HBM/L2 round trip per panel.  The forward solve is fused into the panel loop and the
+// backward solve multiplies by the saved inverse diagonal blocks, so neither has a serial substitution chain.  dense.hip
+// remains the fallback for matrices whose panel does not fit in LDS.
 // Replaces torch/gpytorch MultivariateNormal.log_prob -> LAPACK potrf/potrs on the reference's CPU path
 // (large-context configuration; joint test log-likelihood of abstract.py:134-163).
 #include "common.h"
@@ -29,8 +30,74 @@ template <> struct Mf<double> {
 constexpr int DNB = 32;            // panel width
 constexpr int DLP = 36;            // leading dimension of the LDS panel / inverse images
 
+// Cholesky factor and inverse of the 32x32 diagonal block held in Ds (lower part, identity padded), by ONE wavefront.
+// Right-looking with row rr in the registers of lane rr: per step the lanes publish column j to LDS, read it back as broadcast
+// reads (all reads of a step are issued together), and apply the rank-1 update to their own row.  The left-looking form this
+// replaces waited for an LDS round trip per inner iteration (496 of them) and cost 40 us per block in fp64; this one ~4 us.
+// On return Ds holds L11 (lower), invd[j] = 1 / L11[j][j], Li = L11^-1 (row major, zeros above the diagonal).
 template <typename T>
-__global__ void __launch_bounds__(256) chol_dense_mfma_kernel(T* __restrict__ A, const T* __restrict__ resid,
+__device__ __forceinline__ void factor_invert_diag32(T (*Ds)[DNB + 1], T* __restrict__ Li, T* __restrict__ colb /*[64]*/,
+                                                     T* __restrict__ invd /*[32]*/, T* __restrict__ fail, int lane) {
+#ifdef PACOH_FACT_DEBUG
+    long long tf0 = wall_clock64();
+#endif
+    const int rr = lane & 31, h = lane >> 5;         // lane = (row rr, column half h): 16 columns of the row in registers
+    const bool wr = lane < 32;
+    T a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = Ds[rr][16 * h + c];
+#pragma unroll
+    for (int j = 0; j < DNB; ++j) {
+        const int jh = j >> 4, jl = j & 15;
+        T* cb = colb + (j & 1) * DNB;
+        if (h == jh) cb[rr] = a[jl];
+        __builtin_amdgcn_wave_barrier();             // LDS ops of one wave execute in order; only the compiler must keep it
+        // one batch of reads per step (pivot, own entry, the 16 entries of this lane's column half), issued together
+        T piv = cb[j];
+        const T own = cb[rr];
+        T cv[16];
+#pragma unroll
+        for (int cl = 0; cl < 16; ++cl) cv[cl] = cb[16 * h + cl];
+        if (!(piv > T(0))) { if (lane == 0) *fail = 1; piv = 1; }
+        const T d = t_sqrt<T>(piv);
+        const T inv = T(1) / d;
+        if (lane == 0) invd[j] = inv;
+        const T lown = own * inv;                    // L[rr][j] (meaningful for rr > j)
+        const T nl2 = -lown * inv;
+#pragma unroll
+        for (int cl = 0; cl < 16; ++cl) {
+            const T upd = fma(nl2, cv[cl], a[cl]);   // a[rr][c] -= L[rr][j] L[c][j]
+            a[cl] = (16 * h + cl > j) ? upd : a[cl];
+        }
+        if (h == jh) a[jl] = (rr == j) ? d : lown;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);           // keep the 32 unrolled steps from being interleaved (register pressure)
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) if (16 * h + c <= rr) Ds[rr][16 * h + c] = a[c];
+    __builtin_amdgcn_wave_barrier();
+#ifdef PACOH_FACT_DEBUG
+    long long tf1 = wall_clock64();
+#endif
+    // inverse: lane rr owns column rr of X = L11^-1 and keeps it in LDS (Li[i][rr]: lane-private words, conflict-free);
+    // L entries and 1/diag come as broadcast reads.  Deliberately NOT fully unrolled: with everything unrolled the compiler
+    // hoists all 496 broadcast loads to the top and spills ~1000 registers.
+    if (wr) {
+#pragma unroll 1
+        for (int i = 0; i < DNB; ++i) {
+            T sacc = (i == rr) ? T(1) : T(0);
+#pragma unroll 8
+            for (int j = 0; j < i; ++j) sacc = fma(-Ds[i][j], Li[j * DLP + rr], sacc);
+            Li[i * DLP + rr] = (i < rr) ? T(0) : sacc * invd[i];
+        }
+    }
+#ifdef PACOH_FACT_DEBUG
+    if (lane == 0) { g_tdbg[0] = tf1 - tf0; g_tdbg[1] = wall_clock64() - tf1; }
+#endif
+}
+
+template <typename T, int NT>
+__global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, const T* __restrict__ resid,
                                                               T* __restrict__ logp, T* __restrict__ alpha_out,
                                                               int32_t* __restrict__ info, T scale, int n, int mpad, int attempt) {
     if (attempt > 0 && info && info[blockIdx.x] >= 0) return;      // jitter-ladder retry: only the failed problems
@@ -39,15 +106,16 @@ __global__ void __launch_bounds__(256) chol_dense_mfma_kernel(T* __restrict__ A,
     T (*Ds)[DNB + 1] = reinterpret_cast<T (*)[DNB + 1]>(sm);          // diagonal block / L11
     T* Li = sm + DNB * (DNB + 1);                                      // L11^-1, [32][DLP]
     T* Pn = Li + DNB * DLP;                                            // panel, [mpad][DLP]
-    T* red = Pn + (size_t)mpad * DLP;                                  // [8]: sums, fail flag
-    T* rv = red + 8;                                                   // [n]
+    T* red = Pn + (size_t)mpad * DLP;                                  // [128]: per-wave sums [0..16), fail flag [16], column scratch [32..96), 1/diag [96..128)
+    T* rv = red + 128;                                                 // [n] residual -> u -> alpha
+    constexpr int NW = NT / 64;
     using Acc = typename Mf<T>::acc;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     T* Ab = A + (size_t)blockIdx.x * n * n;
-    if (tid == 0) red[4] = 0;
-    for (int q = tid; q < n; q += 256) rv[q] = resid[(size_t)blockIdx.x * n + q];
+    if (tid == 0) red[16] = 0;
+    for (int q = tid; q < n; q += NT) rv[q] = resid[(size_t)blockIdx.x * n + q];
     T logdet_part = 0;
     __syncthreads();
 
@@ -55,56 +123,46 @@ __global__ void __launch_bounds__(256) chol_dense_mfma_kernel(T* __restrict__ A,
         const int kb = (n - k0 < DNB) ? (n - k0) : DNB;
         const int t0 = k0 + kb, m = n - t0;                            // trailing rows
         // 1. diagonal block -> LDS (identity padded)
-        for (int q = tid; q < DNB * DNB; q += 256) {
+        for (int q = tid; q < DNB * DNB; q += NT) {
             const int rr = q / DNB, c = q - rr * DNB;
             T v = (rr == c) ? T(1) : T(0);
             if (rr < kb && c <= rr) v = Ab[(size_t)(k0 + rr) * n + k0 + c];
             Ds[rr][c] = v;
         }
         __syncthreads();
-        // 2. wave 0: factor (left-looking, pivot by shuffle) and invert (lane c owns column c of L11^-1)
+        // 2. wave 0: factor and invert the diagonal block
         if (tid < 64) {
-            const int rr = tid & 31;
-            for (int j = 0; j < DNB; ++j) {
-                T s = Ds[rr][j];
-                for (int c = 0; c < j; ++c) s = fma(-Ds[rr][c], Ds[j][c], s);
-                T piv = __shfl(s, j, 64);
-                if (!(piv > T(0))) { if (tid == 0) red[4] = 1; piv = 1; }
-                const T d = t_sqrt<T>(piv);
-                if (tid < 32) {
-                    if (rr == j) Ds[j][j] = d;
-                    else if (rr > j) Ds[rr][j] = s / d;
-                }
-            }
+            factor_invert_diag32<T>(Ds, Li, red + 32, red + 96, red + 16, tid);
             if (tid < kb) logdet_part += t_log<T>(Ds[tid][tid]);
-            T x[DNB];
-#pragma unroll
-            for (int i = 0; i < DNB; ++i) {
-                T s = (i == rr) ? T(1) : T(0);
-#pragma unroll
-                for (int j = 0; j < i; ++j) s = fma(-Ds[i][j], x[j], s);
-                x[i] = s / Ds[i][i];
-            }
-            if (tid < 32) {
-#pragma unroll
-                for (int i = 0; i < DNB; ++i) Li[i * DLP + rr] = x[i];                 // row-major L11^-1 (zeros above)
-            }
         }
         __syncthreads();
-        for (int q = tid; q < DNB * DNB; q += 256) {
+        // L11 -> lower triangle; the strictly-lower part of L11^-1 is kept, transposed, in the (otherwise unused) strictly
+        // upper part of the diagonal block: the backward solve reads it from there (its diagonal is 1 / L11's diagonal)
+        for (int q = tid; q < DNB * DNB; q += NT) {
             const int rr = q / DNB, c = q - rr * DNB;
             if (rr < kb && c <= rr) Ab[(size_t)(k0 + rr) * n + k0 + c] = Ds[rr][c];
+            if (rr < kb && c < rr) Ab[(size_t)(k0 + c) * n + k0 + rr] = Li[rr * DLP + c];
+        }
+        // forward solve, fused: u_k = L11^-1 r_k now, r_rest -= L21 u_k once L21 is in LDS (no serial substitution chain)
+        T u_reg = 0;
+        if (tid < kb) {
+            for (int c = 0; c <= tid; ++c) u_reg = fma(Li[tid * DLP + c], rv[k0 + c], u_reg);
+        }
+        if (m <= 0) {
+            __syncthreads();
+            if (tid < kb) rv[k0 + tid] = u_reg;
         }
         if (m > 0) {
             // 3. stage the panel A21 (m x kb, zero padded to 16-row blocks x 32 columns)
             const int mb = (m + 15) / 16;
-            for (int q = tid; q < mb * 16 * DNB; q += 256) {
+            for (int q = tid; q < mb * 16 * DNB; q += NT) {
                 const int rr = q / DNB, c = q - rr * DNB;
                 Pn[(size_t)rr * DLP + c] = (rr < m && c < kb) ? Ab[(size_t)(t0 + rr) * n + k0 + c] : T(0);
             }
             __syncthreads();
+            if (tid < kb) rv[k0 + tid] = u_reg;
             // 4. L21 = A21 * L11^-T on the matrix core, in place in LDS and written back to HBM
-            for (int ib = wave; ib < mb; ib += 4) {
+            for (int ib = wave; ib < mb; ib += NW) {
                 Acc acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
                 for (int c = 0; c < DNB / 4; ++c) {
@@ -124,29 +182,56 @@ __global__ void __launch_bounds__(256) chol_dense_mfma_kernel(T* __restrict__ A,
                 }
             }
             __syncthreads();
-            // 5. trailing update A22 -= L21 L21^T, lower 16x16 blocks dealt to the waves
-            int cnt = 0;
-            for (int ib = 0; ib < mb; ++ib) {
-                for (int jb = 0; jb <= ib; ++jb, ++cnt) {
-                    if ((cnt & 3) != wave) continue;
-                    Acc acc;
-                    T* cp = Ab + (size_t)(t0 + ib * 16) * n + t0 + jb * 16 + r;
-                    const bool colok = jb * 16 + r < m;
+            for (int rr = tid; rr < m; rr += NT) {                          // r_rest -= L21 u_k (L21 rows from the LDS panel)
+                T sacc = rv[t0 + rr];
+#pragma unroll 8
+                for (int c = 0; c < DNB; ++c) sacc = fma(-Pn[(size_t)rr * DLP + c], (c < kb) ? rv[k0 + c] : T(0), sacc);
+                rv[t0 + rr] = sacc;
+            }
+            // 5. trailing update A22 -= L21 L21^T: the lower 16x16 blocks are dealt to the waves, two per step so that the
+            //    L2/HBM round trip of one block's accumulator overlaps the other's MFMAs
+            const int total = mb * (mb + 1) / 2;
+            for (int c0 = wave; c0 < total; c0 += 2 * NW) {
+                int ibs[2], jbs[2];
+                bool live[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = c0 + u * NW;
+                    live[u] = c < total;
+                    int ib = (int)((sqrtf(8.0f * (float)c + 1.0f) - 1.0f) * 0.5f);
+                    while (ib * (ib + 1) / 2 > c) --ib;
+                    while ((ib + 1) * (ib + 2) / 2 <= c) ++ib;
+                    ibs[u] = ib; jbs[u] = c - ib * (ib + 1) / 2;
+                }
+                Acc acc[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const T* cp = Ab + (size_t)(t0 + ibs[u] * 16) * n + t0 + jbs[u] * 16 + r;
+                    const bool colok = live[u] && jbs[u] * 16 + r < m;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int row = Mf<T>::row(g, q);
-                        acc[q] = (colok && ib * 16 + row < m) ? cp[(size_t)row * n] : T(0);
+                        acc[u][q] = (colok && ibs[u] * 16 + row < m) ? cp[(size_t)row * n] : T(0);
                     }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (!live[u]) continue;
 #pragma unroll
                     for (int c = 0; c < DNB / 4; ++c) {
-                        const T a = -Pn[(size_t)(ib * 16 + r) * DLP + 4 * c + g];
-                        const T b = Pn[(size_t)(jb * 16 + r) * DLP + 4 * c + g];
-                        acc = Mf<T>::mma(a, b, acc);
+                        const T a = -Pn[(size_t)(ibs[u] * 16 + r) * DLP + 4 * c + g];
+                        const T b = Pn[(size_t)(jbs[u] * 16 + r) * DLP + 4 * c + g];
+                        acc[u] = Mf<T>::mma(a, b, acc[u]);
                     }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    T* cp = Ab + (size_t)(t0 + ibs[u] * 16) * n + t0 + jbs[u] * 16 + r;
+                    const bool colok = live[u] && jbs[u] * 16 + r < m;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int row = Mf<T>::row(g, q);
-                        if (colok && ib * 16 + row < m) cp[(size_t)row * n] = acc[q];
+                        if (colok && ibs[u] * 16 + row < m) cp[(size_t)row * n] = acc[u][q];
                     }
                 }
             }
@@ -154,46 +239,22 @@ __global__ void __launch_bounds__(256) chol_dense_mfma_kernel(T* __restrict__ A,
         __syncthreads();
     }
 
-    // ---- forward solve L u = r, blocked (L read back from HBM/L2) ----------------------------------
-    for (int k0 = 0; k0 < n; k0 += DNB) {
-        const int kb = (n - k0 < DNB) ? (n - k0) : DNB;
-        for (int q = tid; q < DNB * DNB; q += 256) {
-            const int rr = q / DNB, c = q - rr * DNB;
-            Ds[rr][c] = (rr < kb && c <= rr) ? Ab[(size_t)(k0 + rr) * n + k0 + c] : ((rr == c) ? T(1) : T(0));
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int rr = tid & 31;
-            T v = (rr < kb) ? rv[k0 + rr] : T(0);
-            for (int c = 0; c < DNB; ++c) {
-                const T uc = __shfl(v, c, 64) / Ds[c][c];
-                if (rr == c) v = uc;
-                else if (rr > c) v = fma(-Ds[rr][c], uc, v);
-            }
-            if (tid < kb) rv[k0 + tid] = v;
-        }
-        __syncthreads();
-        for (int rr = k0 + kb + tid; rr < n; rr += 256) {
-            const T* ap = Ab + (size_t)rr * n + k0;
-            T s = rv[rr];
-            for (int c = 0; c < kb; ++c) s = fma(-ap[c], rv[k0 + c], s);
-            rv[rr] = s;
-        }
-        __syncthreads();
-    }
+    // (the forward solve L u = r happened panel by panel above: rv holds u)
     T quad_part = 0;
-    for (int q = tid; q < n; q += 256) quad_part = fma(rv[q], rv[q], quad_part);
+    for (int q = tid; q < n; q += NT) quad_part = fma(rv[q], rv[q], quad_part);
     quad_part = subwave_sum<T>(quad_part, 64);
     logdet_part = subwave_sum<T>(logdet_part, 64);
     __syncthreads();
     if (lane == 0) red[wave] = quad_part;
     __syncthreads();
-    const T quad = red[0] + red[1] + red[2] + red[3];
+    T quad = 0;
+    for (int w = 0; w < NW; ++w) quad += red[w];
     __syncthreads();
     if (lane == 0) red[wave] = logdet_part;
     __syncthreads();
-    const T logdet = red[0] + red[1] + red[2] + red[3];
-    const bool ok = red[4] == T(0);
+    T logdet = 0;
+    for (int w = 0; w < NW; ++w) logdet += red[w];
+    const bool ok = red[16] == T(0);
     if (tid == 0) {
         const T LOG2PI = T(1.8378770664093453);
         const T lp = T(-0.5) * (quad + T(2) * logdet + T(n) * LOG2PI) * scale;
@@ -201,36 +262,30 @@ __global__ void __launch_bounds__(256) chol_dense_mfma_kernel(T* __restrict__ A,
         if (info) info[blockIdx.x] = ok ? attempt : -1;
     }
     if (!alpha_out) return;
-    // ---- backward solve L^T alpha = u, blocked from the bottom ----------------------------------------
+    // ---- backward solve L^T alpha = u, blocked from the bottom: alpha_k = L11^-T w_k as a 32x32 product with the inverse
+    //      block saved in the upper triangle, then w_i -= sum_c L[k0+c][i] alpha[k0+c] for the rows above
     const int nblk = (n + DNB - 1) / DNB;
     for (int kbk = nblk - 1; kbk >= 0; --kbk) {
         const int k0 = kbk * DNB;
         const int kb = (n - k0 < DNB) ? (n - k0) : DNB;
         __syncthreads();
-        for (int q = tid; q < DNB * DNB; q += 256) {
-            const int rr = q / DNB, c = q - rr * DNB;
-            Ds[rr][c] = (rr < kb && c <= rr) ? Ab[(size_t)(k0 + rr) * n + k0 + c] : ((rr == c) ? T(1) : T(0));
+        T a_reg = 0;
+        if (tid < kb) {
+            const T* zrow = Ab + (size_t)(k0 + tid) * n + k0;           // [tid] = L diag, [c > tid] = Z11[c][tid]
+            a_reg = rv[k0 + tid] / zrow[tid];
+            for (int c = tid + 1; c < kb; ++c) a_reg = fma(zrow[c], rv[k0 + c], a_reg);
         }
         __syncthreads();
-        if (tid < 64) {
-            const int rr = tid & 31;
-            T v = (rr < kb) ? rv[k0 + rr] : T(0);
-            for (int c = DNB - 1; c >= 0; --c) {
-                const T ac = __shfl(v, c, 64) / Ds[c][c];
-                if (rr == c) v = ac;
-                else if (rr < c) v = fma(-Ds[c][rr], ac, v);
-            }
-            if (tid < kb) rv[k0 + tid] = v;
-        }
+        if (tid < kb) rv[k0 + tid] = a_reg;
         __syncthreads();
-        for (int i = tid; i < k0; i += 256) {
-            T s = rv[i];
-            for (int c = 0; c < kb; ++c) s = fma(-Ab[(size_t)(k0 + c) * n + i], rv[k0 + c], s);
-            rv[i] = s;
+        for (int i = tid; i < k0; i += NT) {
+            T sacc = rv[i];
+            for (int c = 0; c < kb; ++c) sacc = fma(-Ab[(size_t)(k0 + c) * n + i], rv[k0 + c], sacc);
+            rv[i] = sacc;
         }
     }
     __syncthreads();
-    for (int q = tid; q < n; q += 256) alpha_out[(size_t)blockIdx.x * n + q] = ok ? rv[q] : T(NAN);
+    for (int q = tid; q < n; q += NT) alpha_out[(size_t)blockIdx.x * n + q] = ok ? rv[q] : T(NAN);
 }
 
 // returns 1 when the panel does not fit in LDS (caller falls back to the VALU kernel of dense.hip)
@@ -238,13 +293,17 @@ template <typename T>
 static int launch_dense_mfma(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale,
                              int B, int n, int attempt, hipStream_t s) {
     const int mpad = n > DNB ? (n - DNB + 15) / 16 * 16 : 16;        // rows of the largest panel, in 16-row blocks
-    const size_t elems = (size_t)DNB * (DNB + 1) + (size_t)DNB * DLP + (size_t)mpad * DLP + 8 + n;
+    const size_t elems = (size_t)DNB * (DNB + 1) + (size_t)DNB * DLP + (size_t)mpad * DLP + 128 + n;
     const size_t lds = elems * sizeof(T);
     if (lds > 160u * 1024u) return 1;
-    auto kern = chol_dense_mfma_kernel<T>;
-    if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return 1;
-    hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, (T*)A, (const T*)resid, (T*)logp, (T*)alpha_out, info, (T)scale, n, mpad, attempt);
+    // one workgroup per matrix: large matrices get 16 wavefronts (4 per SIMD) so that the trailing update's independent
+    // 16x16 blocks hide each other's L2 and MFMA latency (256 threads = 1 wave per SIMD ran the n = 512 factorisation 2x slower)
+#define PACOH_CHOL_LAUNCH(nt) do { auto kern = chol_dense_mfma_kernel<T, nt>; \
+        if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return 1; \
+        hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, s, (T*)A, (const T*)resid, (T*)logp, (T*)alpha_out, info, (T)scale, n, mpad, attempt); } while (0)
+    if (n >= 256) PACOH_CHOL_LAUNCH(1024); else if (n >= 96) PACOH_CHOL_LAUNCH(512); else PACOH_CHOL_LAUNCH(256);
+#undef PACOH_CHOL_LAUNCH
     return launch_status();
 }
 
