@@ -131,8 +131,8 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         self._g_ctr.add_(1)
         batch = self.tasks.select(idx)
         lml, grad, _ = self.engine.lml_and_grad(self.theta, batch, weight=-1.0)
-        torch.neg(lml.sum(), out=self._g_loss)
-        self._g_cum.add_(self._g_loss)
+        L.reduce_tasks(lml.reshape(-1, 1, 1), self._g_loss.reshape(1, 1), scale=-1.0)            # loss = -sum_t mll_t
+        L.axpy(self._g_cum.reshape(1), self._g_loss.reshape(1), 1.0)
         for lo, hi in self.train_segments:
             L.adam_step_dev(self.theta[0, lo:hi], grad[0, lo:hi], self.exp_avg[0, lo:hi], self.exp_avg_sq[0, lo:hi],
                             self._g_sc)
@@ -213,9 +213,10 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
                     idx = self.rds_numpy.randint(0, self.tasks.T, size=self.task_batch_size)
                     batch = self.tasks.select(torch.from_numpy(idx).to(self.device))
                     lml, grad, _ = self.engine.lml_and_grad(self.theta, batch, weight=-1.0)
-                    loss = -lml.sum()
+                    loss = torch.empty((), dtype=self.dtype, device=self.device)
+                    L.reduce_tasks(lml.reshape(-1, 1, 1), loss.reshape(1, 1), scale=-1.0)
                     self._apply_update(grad)
-                    cum_loss += loss
+                    L.axpy(cum_loss.reshape(1), loss.reshape(1), 1.0)
                 self.lr_scheduler.step()
                 if itr == 1 or itr % log_period == 0:
                     duration = time.time() - t

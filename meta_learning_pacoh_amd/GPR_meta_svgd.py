@@ -91,13 +91,15 @@ class _RandomGPLearner(RegressionModelMetaLearned):
         if len(idx_local) > 0:
             batch = self.tasks.select(torch.from_numpy(np.ascontiguousarray(idx_local)).to(self.device))
             lml, score, _ = self.engine.lml_and_grad(theta, batch, weight=pre_factor)
-            lik = pre_factor * lml.sum(0)
+            lik = torch.empty(P, dtype=theta.dtype, device=theta.device)
+            L.reduce_tasks(lml.reshape(batch.T, P, 1), lik.reshape(P, 1), scale=pre_factor)     # pre_factor * sum_t mll[t,p]
         else:
             score = torch.zeros_like(theta)
             lik = torch.zeros(P, dtype=theta.dtype, device=theta.device)
         lik, score = parallel.all_reduce_sum_(lik, score)             # ONE exchange per step
         logprior = L.prior_logprob_grad(theta, self.prior_mean, self.prior_std, score, self.prior_factor)
-        return self.prior_factor * logprior + lik, score
+        L.axpy(lik, logprior, self.prior_factor)                      # lik += prior_factor * log p(theta)
+        return lik, score
 
     def _mixture_predict(self, theta, context_x, context_y, test_x, return_density, mixture=True):
         cx, cy, tx = self._prepare_predict(context_x, context_y, test_x)

@@ -88,7 +88,9 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         S = self.svi_batch_size
         theta, eps, log_q = self._rsample(S)
         log_prob, score = self._log_prob_and_score(theta, idx_local, pre_factor)
-        loss = -(log_prob - self.prior_factor * log_q).mean()
+        loss = torch.empty((), dtype=theta.dtype, device=theta.device)      # -mean_s (log p(theta_s) - prior_factor log q(theta_s))
+        L.reduce_tasks(log_prob.reshape(S, 1, 1), loss.reshape(1, 1), scale=-1.0 / S)
+        L.reduce_tasks(log_q.reshape(S, 1, 1), loss.reshape(1, 1), scale=self.prior_factor / S, accumulate=True)
         return loss, L.vi_grad(self.posterior, eps, score, self.prior_factor, full=self.cov_type == 'full')
 
     def meta_fit(self, valid_tuples=None, verbose=True, log_period=500, n_iter=None):

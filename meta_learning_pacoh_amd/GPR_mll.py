@@ -119,7 +119,8 @@ class GPRegressionLearned:
         loss = None
         for itr in range(1, n_iter + 1):
             lml, grad, _ = self.engine.lml_and_grad(self.theta, self.task, weight=-1.0)
-            loss = -lml.sum()
+            loss = torch.empty((), dtype=self.dtype, device=self.device)
+            L.reduce_tasks(lml.reshape(-1, 1, 1), loss.reshape(1, 1), scale=-1.0)
             self.opt_step += 1
             for lo, hi, wd in self.train_segments:
                 p, g = self.theta[0, lo:hi], grad[0, lo:hi]
