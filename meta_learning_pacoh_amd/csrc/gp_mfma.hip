@@ -116,6 +116,7 @@ __device__ __forceinline__ void factor_diag_block(float* A, int LD, int d0, floa
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             scr[(k & 1) * 16 + r] = D[k];                                  // column k: D[r][k] (double-buffered)
+            asm volatile("" ::: "memory");                                 // keep the compiler from sinking the write below the reads
             float c[16];
             {
                 const float4* cp = reinterpret_cast<const float4*>(scr + (k & 1) * 16);
@@ -205,8 +206,9 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
     float* scr = invd + NP;                                // [64] broadcast scratch / cross-wave sums
 
     // One wave per problem (NW == 1): LDS instructions of a wave execute in issue order, so cross-lane hand-offs
-    // through LDS need no s_barrier (and no full lgkmcnt drain); only the compiler must not reorder them.
-#define SYNC() do { if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier(); } while (0)
+    // through LDS need no s_barrier (and no full lgkmcnt drain); only the compiler must not reorder them (the empty asm
+    // memory clobber pins it; wavefront-scope fences would do too but cost a full counter drain each).
+#define SYNC() do { if (NW > 1) __syncthreads(); else { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); } } while (0)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -411,18 +413,43 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
     float dos = 0.0f, dnz = 0.0f;
     const float inv2n = nv > 0 ? 0.5f / (float)nv : 0.0f;
     if (i < nv) {
+        // four columns per iteration from 16-byte LDS reads (four independent exp chains in flight).  The loop runs over the
+        // padded size: for j >= nv both alpha_j and W_ij are exactly 0 (identity block), so those columns contribute nothing.
         const float* wrow = A + i * LD;
-        for (int j = 0; j < nv; ++j) {
-            const float Gij = (ai * av[j] - wrow[j]) * inv2n;
-            float s = 0.0f, df[FP];
+        dnz = (ai * ai - wrow[i]) * inv2n;
+#pragma unroll 2
+        for (int j4 = 0; j4 < NP; j4 += 4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wrow + j4);
+            const float4 a4 = *reinterpret_cast<const float4*>(av + j4);
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w}, avv[4] = {a4.x, a4.y, a4.z, a4.w};
+            float zj[4][FP];
+            if constexpr (FP % 4 == 0) {
 #pragma unroll
-            for (int c = 0; c < FP; ++c) { df[c] = zf[j * FP + c] - zs[c]; s = fmaf(df[c], df[c], s); }
-            const float e = rbf_exp<float>(-0.5f * s);
-            dos = fmaf(Gij, e, dos);
-            const float M = Gij * os * e;
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int c = 0; c < FP; ++c) { const float md = M * df[c]; dz[c] += md; dls[c] = fmaf(md, df[c], dls[c]); }
-            if (j == i) dnz = Gij;
+                    for (int c4 = 0; c4 < FP; c4 += 4) {
+                        const float4 q = *reinterpret_cast<const float4*>(zf + (j4 + u) * FP + c4);
+                        zj[u][c4] = q.x; zj[u][c4 + 1] = q.y; zj[u][c4 + 2] = q.z; zj[u][c4 + 3] = q.w;
+                    }
+            } else {                                  // FP == 2: two rows per 16-byte read
+#pragma unroll
+                for (int u = 0; u < 4; u += 2) {
+                    const float4 q = *reinterpret_cast<const float4*>(zf + (j4 + u) * FP);
+                    zj[u][0] = q.x; zj[u][1] = q.y; zj[u + 1][0] = q.z; zj[u + 1][1] = q.w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float Gij = (ai * avv[u] - wv[u]) * inv2n;
+                float s = 0.0f, df[FP];
+#pragma unroll
+                for (int c = 0; c < FP; ++c) { df[c] = zj[u][c] - zs[c]; s = fmaf(df[c], df[c], s); }
+                const float e = rbf_exp<float>(-0.5f * s);
+                dos = fmaf(Gij, e, dos);
+                const float M = Gij * os * e;
+#pragma unroll
+                for (int c = 0; c < FP; ++c) { const float md = M * df[c]; dz[c] += md; dls[c] = fmaf(md, df[c], dls[c]); }
+            }
         }
     }
     const float bad = okf ? 0.0f : NAN;
