@@ -149,14 +149,16 @@ __device__ __forceinline__ void factor_diag_block(float* A, int LD, int d0, floa
             float s = (i == r) ? 1.0f : 0.0f;
             if (i > 0) {
                 const float4* lp = reinterpret_cast<const float4*>(A + (d0 + i) * LD + d0);      // row i of L, broadcast
+                float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;                                           // four short FMA chains, not one long one
 #pragma unroll
                 for (int v = 0; v < (i + 3) / 4; ++v) {
                     const float4 q = lp[v];
                     if (4 * v < i) s = fmaf(-q.x, x[4 * v], s);
-                    if (4 * v + 1 < i) s = fmaf(-q.y, x[4 * v + 1], s);
-                    if (4 * v + 2 < i) s = fmaf(-q.z, x[4 * v + 2], s);
-                    if (4 * v + 3 < i) s = fmaf(-q.w, x[4 * v + 3], s);
+                    if (4 * v + 1 < i) s1 = fmaf(-q.y, x[4 * v + 1], s1);
+                    if (4 * v + 2 < i) s2 = fmaf(-q.z, x[4 * v + 2], s2);
+                    if (4 * v + 3 < i) s3 = fmaf(-q.w, x[4 * v + 3], s3);
                 }
+                s = (s + s1) + (s2 + s3);
             }
             x[i] = s * inv[i];
         }
@@ -339,14 +341,20 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
     float ui = 0.0f;
     if (i < NP) {
         const int d0 = (i >> 4) * 16;
-        for (int j = 0; j < d0; ++j) ui = fmaf(A[j * LD + i], rv[j], ui);
+        float u1 = 0.0f, u2 = 0.0f, u3 = 0.0f;                      // four FMA chains
+        for (int j = 0; j < d0; j += 4) {
+            const float4 rq = *reinterpret_cast<const float4*>(rv + j);
+            ui = fmaf(A[j * LD + i], rq.x, ui); u1 = fmaf(A[(j + 1) * LD + i], rq.y, u1);
+            u2 = fmaf(A[(j + 2) * LD + i], rq.z, u2); u3 = fmaf(A[(j + 3) * LD + i], rq.w, u3);
+        }
         const float4* zr = reinterpret_cast<const float4*>(A + i * LD + d0);
         const float4* rr = reinterpret_cast<const float4*>(rv + d0);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const float4 zq = zr[v], rq = rr[v];
-            ui = fmaf(zq.x, rq.x, ui); ui = fmaf(zq.y, rq.y, ui); ui = fmaf(zq.z, rq.z, ui); ui = fmaf(zq.w, rq.w, ui);
+            ui = fmaf(zq.x, rq.x, ui); u1 = fmaf(zq.y, rq.y, u1); u2 = fmaf(zq.z, rq.z, u2); u3 = fmaf(zq.w, rq.w, u3);
         }
+        ui = (ui + u1) + (u2 + u3);
     }
     const float quad = block_sum<NW>((i < nv) ? ui * ui : 0.0f, scr);
     const float logdet = block_sum<NW>((i < nv) ? -logf(invd[i < NP ? i : 0]) : 0.0f, scr);
@@ -397,11 +405,13 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
     if (i < NP) {
         const float4* wr = reinterpret_cast<const float4*>(A + i * LD);
         const float4* rr = reinterpret_cast<const float4*>(rv);
+        float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 #pragma unroll 4
         for (int v = 0; v < NP / 4; ++v) {
             const float4 wq = wr[v], rq = rr[v];
-            ai = fmaf(wq.x, rq.x, ai); ai = fmaf(wq.y, rq.y, ai); ai = fmaf(wq.z, rq.z, ai); ai = fmaf(wq.w, rq.w, ai);
+            ai = fmaf(wq.x, rq.x, ai); a1 = fmaf(wq.y, rq.y, a1); a2 = fmaf(wq.z, rq.z, a2); a3 = fmaf(wq.w, rq.w, a3);
         }
+        ai = (ai + a1) + (a2 + a3);
         av[i] = ai;
     }
     SYNC();
