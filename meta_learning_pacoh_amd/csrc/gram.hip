@@ -37,14 +37,24 @@ __device__ __forceinline__ void gram_tile_body(const T* __restrict__ z1s, const 
         T a[FP];
 #pragma unroll
         for (int c = 0; c < FP; ++c) a[c] = z1s[il * FP + c];
+        // z2 is staged feature-major ([FP][TJ]): one 16-byte read per feature brings that feature for the lane's VW
+        // columns and consecutive lanes read consecutive addresses (the point-major layout put the lanes FP*VW elements
+        // apart: 128-byte strides = 32-way bank conflicts at f = 8 in fp64)
+        T sacc[VW];
+#pragma unroll
+        for (int v = 0; v < VW; ++v) sacc[v] = 0;
+#pragma unroll
+        for (int c = 0; c < FP; ++c) {
+            const V bq = *reinterpret_cast<const V*>(z2s + c * (VW << tjq_shift) + jq * VW);
+            T bvals[VW];
+            if constexpr (VW == 4) { bvals[0] = bq.x; bvals[1] = bq.y; bvals[2] = bq.z; bvals[3] = bq.w; } else { bvals[0] = bq.x; bvals[1] = bq.y; }
+#pragma unroll
+            for (int v = 0; v < VW; ++v) { const T d = a[c] - bvals[v]; sacc[v] = fma(d, d, sacc[v]); }
+        }
         T out[VW];
 #pragma unroll
         for (int v = 0; v < VW; ++v) {
-            const T* bp = z2s + (jq * VW + v) * FP;
-            T s = 0;
-#pragma unroll
-            for (int c = 0; c < FP; ++c) { T d = a[c] - bp[c]; s = fma(d, d, s); }
-            T k = osv * rbf_exp<T>(T(-0.5) * s);
+            T k = osv * rbf_exp<T>(T(-0.5) * sacc[v]);
             if (NOISE) k += (i == j0 + v) ? nz : T(0);
             out[v] = k;
         }
@@ -137,7 +147,12 @@ __global__ void __launch_bounds__(256) gram_kernel(const T* __restrict__ z1, int
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int e = r * 256 + threadIdx.x;
-            if (e < E) lds0[g * E + e] = pre[g][r] / lpre[g][r];
+            if (e < E) {
+                // z1 rows stay point-major (one row is broadcast to a wave); z2 goes in feature-major
+                const int e2 = e - E1;
+                const int dst = e < E1 ? e : E1 + (e2 % FP) * TJ + e2 / FP;
+                lds0[g * E + dst] = pre[g][r] / lpre[g][r];
+            }
         }
     __syncthreads();
 #pragma unroll

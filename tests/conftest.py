@@ -17,3 +17,11 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _fixed_torch_seed():
+    """every test starts from the same torch CPU generator state (a few tests draw inputs without their own generator)"""
+    import torch
+    torch.manual_seed(1234)
+    yield

@@ -115,9 +115,10 @@ def test_dense_jitter_ladder(L):
     """identical points + ~zero noise: the fp32 factorisation fails, the retry launches re-build only that problem with
     gpytorch's psd_safe_cholesky jitter and report the attempt in info[]"""
     n, f = 160, 2
+    gen = torch.Generator().manual_seed(21)
     z = torch.zeros(2, n, f, dtype=torch.float32)           # one task, two hyper-parameter sets: b = p
-    z[1] = torch.randn(n, f)
-    y = torch.randn(1, n, dtype=torch.float32)
+    z[1] = torch.randn(n, f, generator=gen)
+    y = torch.randn(1, n, dtype=torch.float32, generator=gen)
     ls = torch.ones(2, f, dtype=torch.float32)
     noise = torch.tensor([1e-12, 0.3], dtype=torch.float32)
     out = L.gp_lml_fwdbwd(z.to(DEV), 1, None, L.MEAN_ZERO, y.to(DEV), 2, ls.to(DEV), None, noise.to(DEV), 2, 2)

@@ -199,9 +199,10 @@ def test_lml_jitter_ladder_on_rank_deficient_gram(L):
     """fault injection: identical points + ~zero noise -> plain Cholesky fails in fp32; the kernel
     must climb gpytorch's psd_safe_cholesky jitter ladder and report it in info[]"""
     n, f = 32, 2
+    gen = torch.Generator().manual_seed(20)                   # fixed draw: the fp32 error of this ill-conditioned case depends on y
     z = torch.zeros(2, n, f, dtype=torch.float32)
-    z[1] = torch.randn(n, f)                                  # problem 1 is healthy
-    y = torch.randn(1, n, dtype=torch.float32)
+    z[1] = torch.randn(n, f, generator=gen)                   # problem 1 is healthy
+    y = torch.randn(1, n, dtype=torch.float32, generator=gen)
     ls = torch.ones(1, f, dtype=torch.float32)
     noise = torch.tensor([1e-12], dtype=torch.float32)
     # B=2 problems of ONE task with P=... use P=1, T=2 and the same y
