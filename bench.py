@@ -95,7 +95,6 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--fused', type=int, default=-1, help='1/0 force the fused meta kernel on/off (default: auto)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -114,8 +113,6 @@ def main():
     tasks = make_tasks(T_global, N_CTX, DIM)
     model = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=PARTICLES, covar_module='NN', mean_module='NN',
                                           task_batch_size=-1, lr=1e-3, random_seed=0)
-    if args.fused >= 0 and hasattr(model.engine, 'use_fused'):
-        model.engine.use_fused = bool(args.fused)
     D = model.layout.D
 
     def step():

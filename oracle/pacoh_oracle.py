@@ -12,12 +12,15 @@ Pinning status ("how do we know the oracle equals the reference?"):
     (unpinned in requirements.txt:5 / setup.py:18, era v1.0.x), which is absent from this image,
     so it is restated from its published algorithm (ExactMarginalLogLikelihood = MVN log-prob / n,
     exact GP posterior, softplus constraints);
-  * PINNED against genuine reference output: the PACOH-MAP trajectory recorded in
-    ``demo.ipynb:115-127,164-166`` (tests/test_oracle_golden_demo.py reproduces the log),
-  * PINNED against the imported reference: ``meta_learn/svgd.py`` (SVGD phi, RBF kernel, median
-    heuristic) and, under import shims, ``meta_learn/models.py`` / ``random_gp.py`` (parameter
-    layout, hyper-prior sampling + log-prob, vectorised MLP forward) -- fixtures in
-    ``tests/golden/*.npz`` produced by ``tests/golden/make_golden.py``;
+  * PINNED against genuine reference output: the PACOH-MAP trajectory and the single-task
+    GPRegressionLearned log recorded in ``demo.ipynb`` (tests/test_oracle_golden_demo.py reproduces
+    both logs to the printed digits),
+  * PINNED against the imported reference: ``meta_learn/svgd.py`` (SVGD phi with the RBF and the IMQ
+    particle kernel, median heuristics, the gradient through the IMQ median bandwidth) and, under
+    import shims, ``meta_learn/models.py`` / ``random_gp.py`` (parameter layout, hyper-prior sampling +
+    log-prob, vectorised MLP forward, diagonal and full-covariance VI posterior: init stream, rsample,
+    log_prob, autograd gradient) -- fixtures in ``tests/golden/*.npz`` produced by
+    ``tests/golden/make_golden.py``;
   * UNPINNED by any recorded reference output (restated from the source only): the SVGD/VI GP
     flavour end-to-end values (unit outputscale, no noise floor, m~/(m~+T) pre-factor, mixture
     predictive).  See DESIGN.md "Oracle".
