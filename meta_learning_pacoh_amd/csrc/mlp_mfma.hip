@@ -188,7 +188,9 @@ __device__ __forceinline__ void wgrad(f32x4& acc, const f32x4& Ap, const f32x4& 
 }
 
 template <int NH>
-__global__ void __launch_bounds__(256) mlp_mfma_fwd_kernel(MlpMfmaArgs a) {
+// (256, 5): five waves per SIMD (<= 102 VGPRs, one spilled register); the default allocation took 140 registers = three
+// waves per SIMD and ran 4 % slower -- the forward pass is tanh/latency-bound, extra waves hide it
+__global__ void __launch_bounds__(256, 5) mlp_mfma_fwd_kernel(MlpMfmaArgs a) {
     __shared__ __attribute__((aligned(16))) float wl[W_ELEMS];
     const int p = blockIdx.y;
     load_weights_mfma<NH>(wl, a.theta + (long)p * a.theta_stride, a);
