@@ -65,18 +65,17 @@ template <> __device__ __forceinline__ float rbf_exp<float>(float x) {
     return fmaf(e, lo * 0.6931471805599453f, e);
 }
 
-// tanh for the MLP activations.  fp32: odd polynomial below 0.25 (rel. error < 4e-7), otherwise
-// (1-t)/(1+t) with t = exp(-2|x|) on the hardware exp2 path; fp64: libm.
+// tanh for the MLP activations.  fp32: 1 - 2 / (1 + exp(2x)) on the hardware exp2 / rcp: five instructions, no branches,
+// correct limits for both signs (exp2 overflow -> rcp(inf) = 0 -> +1; exp2 underflow -> 1 - 2 = -1).  Its ABSOLUTE error is
+// ~1e-7 everywhere (one rounding of a value near 1); the relative error grows like 1e-7 / |x| for tiny |x|, which is
+// irrelevant for activations (they enter the next layer additively) -- the earlier variant that switched to an odd
+// polynomial below 0.25 for full relative accuracy cost 17 instructions + two exec-mask branches per activation, and tanh
+// is what bounds the MLP kernels (52 % of the backward kernel is the forward recompute).  fp64: libm.
 template <typename T> __device__ __forceinline__ T act_tanh(T x);
 template <> __device__ __forceinline__ double act_tanh<double>(double x) { return tanh(x); }
 template <> __device__ __forceinline__ float act_tanh<float>(float x) {
-    // branch-free: both forms are evaluated and selected (a divergent branch per activation costs more)
-    const float ax = fabsf(x);
-    const float x2 = x * x;
-    const float poly = x * fmaf(x2, fmaf(x2, fmaf(x2, -0.05396825396825397f, 0.13333333333333333f), -0.3333333333333333f), 1.0f);
-    const float t = __builtin_amdgcn_exp2f(-2.885390081777927f * ax);          // exp(-2|x|)
-    const float rr = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
-    return ax < 0.25f ? poly : copysignf(rr, x);
+    const float e = __builtin_amdgcn_exp2f(2.885390081777927f * x);            // exp(2x)
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
 }
 
 // Leading dimension (in elements) of an LDS matrix whose rows are read both "own row per lane"
