@@ -188,9 +188,10 @@ __device__ __forceinline__ void wgrad(f32x4& acc, const f32x4& Ap, const f32x4& 
 }
 
 template <int NH>
-// (256, 5): five waves per SIMD (<= 102 VGPRs, one spilled register); the default allocation took 140 registers = three
-// waves per SIMD and ran 4 % slower -- the forward pass is tanh/latency-bound, extra waves hide it
-__global__ void __launch_bounds__(256, 5) mlp_mfma_fwd_kernel(MlpMfmaArgs a) {
+// (256, 4): the allocator then settles at 96 VGPRs without spills = five waves per SIMD; the default allocation took 140
+// registers (three waves per SIMD, 4 % slower -- the forward pass is latency-bound, extra waves hide it) and asking for five
+// waves outright made it spill 11 registers (36 MB of scratch traffic per launch in the PMC counters)
+__global__ void __launch_bounds__(256, 4) mlp_mfma_fwd_kernel(MlpMfmaArgs a) {
     __shared__ __attribute__((aligned(16))) float wl[W_ELEMS];
     const int p = blockIdx.y;
     load_weights_mfma<NH>(wl, a.theta + (long)p * a.theta_stride, a);
