@@ -181,10 +181,13 @@ int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int
 
 /* ... and their backward: grad[p, off] = sigmoid(raw) * sum_t d_x[t, p, .] for lengthscale / outputscale / noise
  * (d_ls[T,P,f], d_os[T,P] or NULL, d_noise[T,P]: the per-problem outputs of pacoh_gp_lml_fwdbwd) and the plain sum
- * for a constant mean (d_const[T,P] at off_const, or NULL / -1).  Deterministic (fixed summation order). */
+ * for a constant mean (d_const[T,P] at off_const, or NULL / -1).  Optionally (lml, lik both non-NULL) the same pass over the
+ * tasks also writes lik[p] = lik_scale * sum_t lml[t,p], the likelihood term of RandomGPMeta.log_prob (random_gp.py:204-222).
+ * Deterministic (fixed summation order). */
 int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int T, int off_ls, int f, int off_os, int off_noise,
                     int off_const, const void* d_ls, const void* d_os, const void* d_noise, const void* d_const,
-                    void* grad, long grad_stride, int dtype, void* stream);
+                    void* grad, long grad_stride, const void* lml, void* lik, double lik_scale, int dtype,
+                    void* stream);
 
 /* logp[p] = sum_d log N(theta[p,d]; prior_mean[d], prior_std[d]);  grad[p,d] (optional, += scaled):
  * grad += grad_scale * d logp / d theta.  Replaces CatDist.log_prob over the Normal blocks

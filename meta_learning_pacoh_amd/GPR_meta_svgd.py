@@ -90,9 +90,8 @@ class _RandomGPLearner(RegressionModelMetaLearned):
         P = theta.shape[0]
         if len(idx_local) > 0:
             batch = self.tasks.select(torch.from_numpy(np.ascontiguousarray(idx_local)).to(self.device))
-            lml, score, _ = self.engine.lml_and_grad(theta, batch, weight=pre_factor)
-            lik = torch.empty(P, dtype=theta.dtype, device=theta.device)
-            L.reduce_tasks(lml.reshape(batch.T, P, 1), lik.reshape(P, 1), scale=pre_factor)     # pre_factor * sum_t mll[t,p]
+            lik = torch.empty(P, dtype=theta.dtype, device=theta.device)             # pre_factor * sum_t mll[t,p]
+            lml, score, _ = self.engine.lml_and_grad(theta, batch, weight=pre_factor, lik_out=lik, lik_scale=pre_factor)
         else:
             score = torch.zeros_like(theta)
             lik = torch.zeros(P, dtype=theta.dtype, device=theta.device)

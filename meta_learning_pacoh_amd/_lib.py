@@ -45,7 +45,7 @@ SIGNATURES = {
     'pacoh_softplus_fwd': (_i, [_vp, _vp, _d, _l, _i, _vp]),
     'pacoh_softplus_bwd': (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),
     'pacoh_hyper_fwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
-    'pacoh_hyper_bwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp]),
+    'pacoh_hyper_bwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _d, _i, _vp]),
     'pacoh_prior_logprob_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
     'pacoh_svgd_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_phi': (_i, [_vp, _vp, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -359,13 +359,16 @@ def hyper_fwd(theta, off_ls, f, off_os, off_noise, noise_floor):
     return ls, os_, noise
 
 
-def hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, grad):
+def hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, grad, lml=None, lik=None,
+              lik_scale=1.0):
+    """lml [T*P] and lik [P] (both or neither): lik[p] = lik_scale * sum_t lml[t, p] in the same launch"""
     lib = load_library()
     P, D = theta.shape
     with _Timed('hyper_bwd'):
         _check(lib.pacoh_hyper_bwd(_ptr(theta), D, P, T, off_ls, f, off_os, off_noise, off_const, _ptr(d_ls, theta),
                                    _ptr(d_os, theta), _ptr(d_noise, theta), _ptr(d_const, theta), _ptr(grad, theta),
-                                   grad.shape[1], dtype_code(theta), _stream()), 'pacoh_hyper_bwd')
+                                   grad.shape[1], _ptr(lml, theta), _ptr(lik, theta), float(lik_scale), dtype_code(theta),
+                                   _stream()), 'pacoh_hyper_bwd')
 
 
 def prior_logprob_grad(theta, prior_mean, prior_std, grad=None, grad_scale=1.0):

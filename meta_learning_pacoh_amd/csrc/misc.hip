@@ -43,27 +43,34 @@ __global__ void hyper_fwd_kernel(const T* __restrict__ theta, long stride, int P
     else noise[p] = softplus_t<T>(th[off_noise]) + noise_floor;
 }
 
-// grad[p, off_*] = sigmoid(raw) * sum_t d_*[t, p, .]   (softplus chain rule), constant mean: plain sum; one wave per entry
+// grad[p, off_*] = sigmoid(raw) * sum_t d_*[t, p, .]   (softplus chain rule), constant mean: plain sum; optionally also
+// lik[p] = lik_scale * sum_t lml[t, p] (the likelihood term of the meta log-probability rides along: same loop over tasks).
+// One 256-thread workgroup per entry, fixed summation order (deterministic).
 template <typename T>
 __global__ void __launch_bounds__(256) hyper_bwd_kernel(const T* __restrict__ theta, long stride, int P, int Tt, int off_ls, int f,
                                                         int off_os, int off_noise, int off_const, const T* __restrict__ d_ls,
                                                         const T* __restrict__ d_os, const T* __restrict__ d_noise,
-                                                        const T* __restrict__ d_const, T* __restrict__ grad, long gstride) {
-    const int per = f + 3;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= P * per) return;
-    const int lane = threadIdx.x & 63;
+                                                        const T* __restrict__ d_const, T* __restrict__ grad, long gstride,
+                                                        const T* __restrict__ lml, T* __restrict__ lik, T lik_scale) {
+    __shared__ T red[4];
+    const int per = f + 4;
+    const int w = blockIdx.x;
     const int p = w / per, e = w - p * per;
     const T* src; int width, col, off;
     if (e < f) { src = d_ls; width = f; col = e; off = off_ls + e; }
     else if (e == f) { src = d_os; width = 1; col = 0; off = off_os; }
     else if (e == f + 1) { src = d_noise; width = 1; col = 0; off = off_noise; }
-    else { src = d_const; width = 1; col = 0; off = off_const; }
+    else if (e == f + 2) { src = d_const; width = 1; col = 0; off = off_const; }
+    else { src = lml; width = 1; col = 0; off = 0; }
     if (!src || off < 0) return;
     T s = 0;
-    for (int t = lane; t < Tt; t += 64) s += src[((long)t * P + p) * width + col];
+    for (int t = threadIdx.x; t < Tt; t += 256) s += src[((long)t * P + p) * width + col];
     s = subwave_sum<T>(s, 64);
-    if (lane == 0) {
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = (red[0] + red[1]) + (red[2] + red[3]);
+        if (e == f + 3) { if (lik) lik[p] = lik_scale * s; return; }
         const T chain = (e == f + 2) ? T(1) : sigmoid_t<T>(theta[(long)p * stride + off]);
         grad[(long)p * gstride + off] = s * chain;
     }
@@ -283,18 +290,20 @@ extern "C" int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int 
 
 extern "C" int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int T_, int off_ls, int f, int off_os, int off_noise,
                                int off_const, const void* d_ls, const void* d_os, const void* d_noise, const void* d_const,
-                               void* grad, long grad_stride, int dtype, void* stream) {
+                               void* grad, long grad_stride, const void* lml, void* lik, double lik_scale, int dtype,
+                               void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!theta || !grad || !d_ls || !d_noise || P <= 0 || T_ <= 0 || f <= 0) return PACOH_EINVAL;
-    unsigned blocks = (unsigned)((P * (f + 3) + 3) / 4);
+    if ((lml == nullptr) != (lik == nullptr)) return PACOH_EINVAL;
+    unsigned blocks = (unsigned)(P * (f + 4));
     if (dtype == PACOH_F32)
         hipLaunchKernelGGL(hyper_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)theta, theta_stride, P, T_,
                            off_ls, f, off_os, off_noise, off_const, (const float*)d_ls, (const float*)d_os, (const float*)d_noise,
-                           (const float*)d_const, (float*)grad, grad_stride);
+                           (const float*)d_const, (float*)grad, grad_stride, (const float*)lml, (float*)lik, (float)lik_scale);
     else
         hipLaunchKernelGGL(hyper_bwd_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)theta, theta_stride, P, T_,
                            off_ls, f, off_os, off_noise, off_const, (const double*)d_ls, (const double*)d_os, (const double*)d_noise,
-                           (const double*)d_const, (double*)grad, grad_stride);
+                           (const double*)d_const, (double*)grad, grad_stride, (const double*)lml, (double*)lik, lik_scale);
     return launch_status();
 }
 

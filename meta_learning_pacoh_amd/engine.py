@@ -160,8 +160,9 @@ class GPEngine:
                                        n_valid=batch.n_valid if batch.ragged else None)
         return lml.reshape(T, P), info
 
-    def lml_and_grad(self, theta, batch, weight=1.0):
-        """returns (lml[T,P], grad[P,D]) with grad = d(weight * sum_t lml[t,p]) / d theta[p]"""
+    def lml_and_grad(self, theta, batch, weight=1.0, lik_out=None, lik_scale=1.0):
+        """returns (lml[T,P], grad[P,D]) with grad = d(weight * sum_t lml[t,p]) / d theta[p];
+        lik_out[P] (optional) receives lik_scale * sum_t lml[t,p] from the same launch that reduces the hyper-gradients"""
         lay = self.layout
         P, D = theta.shape
         T, n = batch.T, batch.n
@@ -188,7 +189,8 @@ class GPEngine:
         # hyper-parameters (+ constant mean): sum over tasks and softplus chain rule in one launch
         off_ls, f, off_os, off_noise, off_c = self._hyper_offsets()
         L.hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_c, d_ls, d_os, d_noise,
-                    d_mean if lay.mean_module == 'constant' else None, grad)
+                    d_mean if lay.mean_module == 'constant' else None, grad,
+                    lml=lml if lik_out is not None else None, lik=lik_out, lik_scale=lik_scale)
         return lml.reshape(T, P), grad, info
 
     def predict(self, theta, ctx_x, ctx_y, tst_x, want_cov=False):
