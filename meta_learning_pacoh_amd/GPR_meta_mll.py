@@ -11,7 +11,7 @@ import torch
 from . import _lib as L
 from .abstract import RegressionModelMetaLearned
 from .distributions import GaussianPredictive
-from .engine import GPEngine, ParamLayout, TaskBatch
+from .engine import AsyncUploader, GPEngine, ParamLayout, TaskBatch
 from .util import StepLR
 
 
@@ -211,7 +211,9 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
                 else:
                     # rds_numpy.choice(task_dicts, size=B) == randint(0, T, B): with replacement (:109)
                     idx = self.rds_numpy.randint(0, self.tasks.T, size=self.task_batch_size)
-                    batch = self.tasks.select(torch.from_numpy(idx).to(self.device))
+                    if getattr(self, '_idx_up', None) is None:
+                        self._idx_up = AsyncUploader(self.device, torch.int64)
+                    batch = self.tasks.select(self._idx_up.upload(idx))
                     lml, grad, _ = self.engine.lml_and_grad(self.theta, batch, weight=-1.0)
                     loss = torch.empty((), dtype=self.dtype, device=self.device)
                     L.reduce_tasks(lml.reshape(-1, 1, 1), loss.reshape(1, 1), scale=-1.0)

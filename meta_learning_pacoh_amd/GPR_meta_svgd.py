@@ -11,7 +11,7 @@ from . import _lib as L
 from . import parallel
 from .abstract import RegressionModelMetaLearned
 from .distributions import GaussianPredictive
-from .engine import GPEngine, ParamLayout, TaskBatch
+from .engine import AsyncUploader, GPEngine, ParamLayout, TaskBatch
 from .util import StepLR
 
 
@@ -84,12 +84,18 @@ class _RandomGPLearner(RegressionModelMetaLearned):
         local = parallel.shard(idx)
         return local, pre
 
+    def _idx_uploader(self):
+        up = getattr(self, '_idx_up', None)
+        if up is None:
+            up = self._idx_up = AsyncUploader(self.device, torch.int64)
+        return up
+
     def _log_prob_and_score(self, theta, idx_local, pre_factor):
         """RandomGPMeta.log_prob and its gradient (random_gp.py:204-222; svgd.py:15-16):
         log_prob[p] = prior_factor*log p(theta_p) + pre_factor * sum_t mll[t,p]"""
         P = theta.shape[0]
         if len(idx_local) > 0:
-            batch = self.tasks.select(torch.from_numpy(np.ascontiguousarray(idx_local)).to(self.device))
+            batch = self.tasks.select(self._idx_uploader().upload(idx_local))
             lik = torch.empty(P, dtype=theta.dtype, device=theta.device)             # pre_factor * sum_t mll[t,p]
             lml, score, _ = self.engine.lml_and_grad(theta, batch, weight=pre_factor, lik_out=lik, lik_scale=pre_factor)
         else:

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from .engine import AsyncUploader
 from .GPR_meta_svgd import _RandomGPLearner
 from .util import StepLR
 
@@ -79,7 +80,10 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
     def _rsample(self, n):
         """Normal(loc, exp(scale)).rsample((n,)): eps from the torch CPU generator (reference stream);
         returns (theta[n,D], eps[n,D], log q(theta)[n])"""
-        eps = standard_normal(n, self.layout.D).to(self.dtype).to(self.device)
+        up = getattr(self, '_eps_up', None)
+        if up is None:
+            up = self._eps_up = AsyncUploader(self.device, self.dtype)
+        eps = up.upload(standard_normal(n, self.layout.D))
         theta, log_q = L.vi_sample(self.posterior, eps, full=self.cov_type == 'full')
         return theta, eps, log_q
 

@@ -108,6 +108,34 @@ class TaskBatch:
         return out
 
 
+class AsyncUploader:
+    """Host -> device upload of small per-step arrays (task indices, reparameterisation noise) WITHOUT stalling the host:
+    a ring of pinned staging buffers, each guarded by an event, and non-blocking copies on the current stream.  A plain
+    `torch.from_numpy(a).to(device)` from pageable memory blocks the host until everything queued before it has run, i.e. it
+    is a stream synchronisation every step: the GPU then idles while the host issues the first launches of the next step."""
+
+    def __init__(self, device, dtype, slots=8):
+        self.device, self.dtype, self.slots = device, dtype, slots
+        self.host, self.events, self.k = [None] * slots, [None] * slots, 0
+
+    def upload(self, array):
+        a = array.contiguous() if torch.is_tensor(array) else torch.from_numpy(np.ascontiguousarray(array))
+        k = self.k
+        self.k = (k + 1) % self.slots
+        if self.events[k] is not None:
+            self.events[k].synchronize()                 # the copy that last used this slot has executed (normally long ago)
+        buf = self.host[k]
+        if buf is None or buf.numel() < a.numel():
+            buf = self.host[k] = torch.empty(max(a.numel(), 1), dtype=self.dtype).pin_memory()
+        view = buf[:a.numel()].reshape(a.shape)
+        view.copy_(a)                                    # (converts dtype if needed)
+        out = torch.empty(a.shape, dtype=self.dtype, device=self.device)
+        out.copy_(view, non_blocking=True)
+        ev = self.events[k] = self.events[k] or torch.cuda.Event()
+        ev.record()
+        return out
+
+
 class GPEngine:
     """Sequences the kernels of one LML(+grad) evaluation for all (task, particle) pairs."""
 
