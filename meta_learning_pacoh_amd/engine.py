@@ -116,18 +116,21 @@ class AsyncUploader:
 
     def __init__(self, device, dtype, slots=8):
         self.device, self.dtype, self.slots = device, dtype, slots
-        self.host, self.events, self.k = [None] * slots, [None] * slots, 0
+        self.pool, self.cap, self.events, self.k = None, 0, [None] * slots, 0
 
     def upload(self, array):
         a = array.contiguous() if torch.is_tensor(array) else torch.from_numpy(np.ascontiguousarray(array))
+        if a.numel() > self.cap:                         # (re)allocate the whole ring with ONE pinned allocation
+            for ev in self.events:
+                if ev is not None:
+                    ev.synchronize()
+            self.cap = max(a.numel(), 1)
+            self.pool = torch.empty(self.slots * self.cap, dtype=self.dtype).pin_memory()
         k = self.k
         self.k = (k + 1) % self.slots
         if self.events[k] is not None:
             self.events[k].synchronize()                 # the copy that last used this slot has executed (normally long ago)
-        buf = self.host[k]
-        if buf is None or buf.numel() < a.numel():
-            buf = self.host[k] = torch.empty(max(a.numel(), 1), dtype=self.dtype).pin_memory()
-        view = buf[:a.numel()].reshape(a.shape)
+        view = self.pool[k * self.cap:k * self.cap + a.numel()].reshape(a.shape)
         view.copy_(a)                                    # (converts dtype if needed)
         out = torch.empty(a.shape, dtype=self.dtype, device=self.device)
         out.copy_(view, non_blocking=True)

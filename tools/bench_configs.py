@@ -18,7 +18,7 @@ out = {}
 rs = np.random.RandomState(27)
 tasks = [(rs.uniform(-5, 5, (32, 1)), rs.normal(size=(32, 1))) for _ in range(256)]
 m = M.GPRegressionMetaLearned(tasks, covar_module='SE', mean_module='NN', task_batch_size=256, random_seed=1)
-dt = timeit(lambda: m.meta_fit(n_iter=1, verbose=False, log_period=10**9))
+dt = timeit(lambda: m.meta_fit(n_iter=50, verbose=False, log_period=10**9), reps=4, warm=1) / 50
 out['cfg2_map_256x32_d1'] = {'ms_per_iter': dt * 1e3, 'evals_per_s': 256 / dt}
 # demo-sized MAP (cfg 1): 5 tasks of 5 points per iteration
 tasks5 = [(rs.uniform(-5, 5, (5, 1)), rs.normal(size=(5, 1))) for _ in range(20)]
@@ -28,7 +28,7 @@ out['cfg1_map_demo_5x5'] = {'ms_per_iter': dt * 1e3, 'evals_per_s': 5 / dt}
 # cfg 4: PACOH-VI, 512 tasks, n=128, S=10, NN mean + kernel
 tasks = [(rs.uniform(-5, 5, (128, 1)), rs.normal(size=(128, 1))) for _ in range(512)]
 v = M.GPRegressionMetaLearnedVI(tasks, svi_batch_size=10, random_seed=1)
-dt = timeit(lambda: v.meta_fit(n_iter=1, verbose=False, log_period=10**9), reps=5, warm=2)
+dt = timeit(lambda: v.meta_fit(n_iter=20, verbose=False, log_period=10**9), reps=4, warm=1) / 20
 out['cfg4_vi_512x128_S10'] = {'ms_per_iter': dt * 1e3, 'evals_per_s': 5120 / dt}
 # cfg 5: large context, 256 tasks, n=512, d=8, fp64: Gram build + dense Cholesky LML
 X = torch.randn(256, 512, 8, dtype=torch.float64, device='cuda'); Y = torch.randn(256, 512, dtype=torch.float64, device='cuda')
