@@ -101,10 +101,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, '--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)'
-    torch.cuda.set_device(local_rank)
+    # PACOH_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks (ranks then share
+    # devices; RCCL itself refuses two ranks per device).  The measured job always uses 'nccl' = RCCL over xGMI.
+    backend = os.environ.get('PACOH_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(backend)
 
     import meta_learning_pacoh_amd as M
     from meta_learning_pacoh_amd import _lib as L

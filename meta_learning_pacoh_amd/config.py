@@ -9,4 +9,7 @@ def get_device():
     if not torch.cuda.is_available():
         raise RuntimeError('meta_learning_pacoh_amd needs a HIP device (MI355X); there is no CPU fallback. '
                            'For CPU use the reference implementation.')
-    return torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    local_rank = int(os.environ.get('LOCAL_RANK', '-1'))
+    if 0 <= local_rank < torch.cuda.device_count():
+        return torch.device('cuda', local_rank)
+    return torch.device('cuda', torch.cuda.current_device())     # single-process use, or ranks sharing a device in tests

@@ -1,0 +1,73 @@
+"""N > 1 path on REAL kernels: two processes share the one MI355X of the test box (gloo transport with HIP tensors -- RCCL refuses
+two ranks on one device), each runs the SVGD learner on its shard of every step's task batch, and after three steps both ranks
+must hold the particles of the single-process run.  Only the transport differs from the multi-GPU job (`nccl` = RCCL there)."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pacoh_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(world_rank, world, port, out_dir, kind):
+    if world > 1:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(world_rank), WORLD_SIZE=str(world))
+        dist.init_process_group('gloo', rank=world_rank, world_size=world)
+    torch.cuda.set_device(0)
+    import meta_learning_pacoh_amd as M
+    tasks = O.sinusoid_tasks_nd(9, 16, 2, seed0=300)
+    if kind == 'svgd':
+        model = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=4, task_batch_size=6, lr=1e-2, random_seed=11)
+        model.meta_fit(verbose=False, n_iter=3)
+        state = model.particles
+    else:
+        model = M.GPRegressionMetaLearnedVI(tasks, svi_batch_size=3, task_batch_size=6, lr=1e-2, random_seed=11,
+                                            mean_module='constant', covar_module='SE')
+        model.meta_fit(verbose=False, n_iter=3)
+        state = model.posterior
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, '%s_w%d_r%d.npy' % (kind, world, world_rank)), state.cpu().numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind', ['svgd', 'vi'])
+def test_two_ranks_on_one_gpu_match_single_process(kind):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    with tempfile.TemporaryDirectory() as out:
+        ctx = mp.get_context('spawn')
+        p = ctx.Process(target=_run, args=(0, 1, 0, out, kind))
+        p.start(); p.join(600)
+        assert p.exitcode == 0
+        port = _free_port()
+        procs = [ctx.Process(target=_run, args=(r, 2, port, out, kind)) for r in range(2)]
+        for q in procs:
+            q.start()
+        for q in procs:
+            q.join(600)
+            assert q.exitcode == 0
+        ref = np.load(os.path.join(out, '%s_w1_r0.npy' % kind))
+        r0 = np.load(os.path.join(out, '%s_w2_r0.npy' % kind))
+        r1 = np.load(os.path.join(out, '%s_w2_r1.npy' % kind))
+        assert np.array_equal(r0, r1)                                  # replicas stay bit-identical
+        assert np.isfinite(ref).all()
+        # sharding only changes the order of the sum over tasks (fp32 re-association), amplified by three Adam steps
+        assert np.abs(r0 - ref).max() < 2e-3 * max(1.0, np.abs(ref).max())
+        assert np.linalg.norm(r0 - ref) < 1e-3 * np.linalg.norm(ref)
