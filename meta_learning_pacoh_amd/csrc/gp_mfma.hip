@@ -253,7 +253,38 @@ __global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
     int my_info = -1;
     float jitter = 0.0f;
     for (int attempt = 0; attempt < 4; ++attempt) {
-        if (i < NP) {
+        if constexpr (NB == 4 && NW == 1) {
+            // balanced build of the lower block triangle (10 blocks = 40 entries per lane): a lane of block row 0 / 1 also
+            // fills the first 24 / 8 columns of row i+48 / i+16, so nobody computes the 64 entries of the longest rows
+            // (the row-per-lane loop below runs as long as its busiest lane: 64 entries, 37 % of them idle on average)
+            const int ib = i >> 4;
+            const int nown = ib == 0 ? 4 : (ib == 1 ? 8 : 10);           // quads of the lane's own row
+            const int hoff = ib == 0 ? 48 : (ib == 1 ? 16 : 0);          // helper row offset
+            const int c0 = ib == 2 ? 8 : (ib == 3 ? 24 : 0);             // first own column
+#pragma unroll 2
+            for (int qq = 0; qq < 10; ++qq) {
+                const bool help = qq >= nown;
+                const int row = help ? i + hoff : i;
+                const int col = help ? 4 * (qq - nown) : c0 + 4 * qq;
+                float zr[FP];
+#pragma unroll
+                for (int c = 0; c < FP; ++c) zr[c] = zf[row * FP + c];
+                float kv[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int j = col + v;
+                    float s = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < FP; ++c) { const float d = zr[c] - zf[j * FP + c]; s = fmaf(d, d, s); }
+                    float k = os * rbf_exp<float>(-0.5f * s);
+                    if (!(row < nv && j < nv)) k = 0.0f;
+                    if (row == j) k = (row < nv) ? k + noise + jitter : 1.0f;
+                    kv[v] = k;
+                }
+                float4 o; o.x = kv[0]; o.y = kv[1]; o.z = kv[2]; o.w = kv[3];
+                *reinterpret_cast<float4*>(A + row * LD + col) = o;
+            }
+        } else if (i < NP) {
             const int ib = i >> 4;
             for (int jb = 0; jb <= ib; ++jb) {                 // lower block triangle only
 #pragma unroll
