@@ -257,6 +257,13 @@ int pacoh_vi_sample_full(const void* posterior, const void* eps, void* theta, vo
 int pacoh_vi_grad_full(const void* posterior, const void* eps, const void* score, double prior_factor, void* grad,
                        int S, int D, int dtype, void* stream);
 
+/* ---- A12: the step's task batch -----------------------------------------------------------------------------------
+ * out_x[b,:,:] = x[idx[b],:,:], out_y[b,:] = y[idx[b],:], out_n_valid[b] = n_valid[idx[b]] (both NULL for equal-sized tasks)
+ * for the Tb task indices drawn by the host (with replacement: GPR_meta_mll.py:109, GPR_meta_svgd.py:102) -- one launch
+ * instead of three framework gathers.  x[T,n,d], y[T,n], idx int64. */
+int pacoh_gather_tasks(const void* x, const void* y, const int32_t* n_valid, const int64_t* idx, void* out_x,
+                       void* out_y, int32_t* out_n_valid, int Tb, int n, int d, int dtype, void* stream);
+
 /* ---- reductions used by the host between kernels ----------------------------------------------
  * out[p, :] (+)= scale * sum_t in[t, p, :]   (in is [T, P, W]); deterministic (fixed order). */
 int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, int T, int P, int W,

@@ -58,6 +58,7 @@ SIGNATURES = {
     'pacoh_vi_grad': (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _vp]),
     'pacoh_vi_sample_full': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_vi_grad_full': (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _vp]),
+    'pacoh_gather_tasks': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'pacoh_reduce_tasks': (_i, [_vp, _vp, _d, _i, _i, _i, _i, _i, _vp]),
 }
 
@@ -465,6 +466,19 @@ def vi_grad(posterior, eps, score, prior_factor, full=False):
         _check(fn(_ptr(posterior), _ptr(eps, posterior), _ptr(score, posterior), float(prior_factor),
                   _ptr(grad), S, D, dtype_code(eps), _stream()), name)
     return grad
+
+
+def gather_tasks(x, y, n_valid, idx):
+    """x[T,n,d], y[T,n], n_valid[T] int32, idx[Tb] int64 (device) -> (x[idx], y[idx], n_valid[idx]) in one launch"""
+    lib = load_library()
+    Tb = int(idx.numel())
+    n, d = x.shape[1], x.shape[2]
+    ox = torch.empty(Tb, n, d, dtype=x.dtype, device=x.device)
+    oy = torch.empty(Tb, n, dtype=x.dtype, device=x.device)
+    onv = torch.empty(Tb, dtype=torch.int32, device=x.device) if n_valid is not None else None
+    _check(lib.pacoh_gather_tasks(_ptr(x), _ptr(y, x), _ptr(n_valid), _ptr(idx), _ptr(ox), _ptr(oy), _ptr(onv), Tb, n, d,
+                                  dtype_code(x), _stream()), 'pacoh_gather_tasks')
+    return ox, oy, onv
 
 
 def reduce_tasks(inp, out, scale=1.0, accumulate=False):

@@ -268,9 +268,40 @@ __global__ void axpy_kernel(T* __restrict__ y, const T* __restrict__ x, T alpha,
     if (q < count) y[q] = fma(alpha, x[q], y[q]);
 }
 
+// gather of a step's task batch: out_x[b] = x[idx[b]], out_y[b] = y[idx[b]], out_nv[b] = n_valid[idx[b]]; one workgroup per
+// selected task, 16-byte copies when the row sizes allow
+template <typename T>
+__global__ void __launch_bounds__(256) gather_tasks_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                           const int32_t* __restrict__ n_valid, const long* __restrict__ idx,
+                                                           T* __restrict__ ox, T* __restrict__ oy, int32_t* __restrict__ onv,
+                                                           int nx, int ny) {
+    const long b = blockIdx.x, t = idx[b];
+    const T* sx = x + t * nx;
+    const T* sy = y + t * ny;
+    T* dx = ox + b * nx;
+    T* dy = oy + b * ny;
+    for (int q = threadIdx.x; q < nx; q += 256) dx[q] = sx[q];
+    for (int q = threadIdx.x; q < ny; q += 256) dy[q] = sy[q];
+    if (threadIdx.x == 0 && n_valid) onv[b] = n_valid[t];
+}
+
 }  // namespace pacoh
 
 using namespace pacoh;
+
+extern "C" int pacoh_gather_tasks(const void* x, const void* y, const int32_t* n_valid, const int64_t* idx, void* out_x,
+                                  void* out_y, int32_t* out_n_valid, int Tb, int n, int d, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!x || !y || !idx || !out_x || !out_y || Tb <= 0 || n <= 0 || d <= 0) return PACOH_EINVAL;
+    if ((n_valid == nullptr) != (out_n_valid == nullptr)) return PACOH_EINVAL;
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(gather_tasks_kernel<float>, dim3(Tb), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)y,
+                           n_valid, (const long*)idx, (float*)out_x, (float*)out_y, out_n_valid, n * d, n);
+    else
+        hipLaunchKernelGGL(gather_tasks_kernel<double>, dim3(Tb), dim3(256), 0, (hipStream_t)stream, (const double*)x, (const double*)y,
+                           n_valid, (const long*)idx, (double*)out_x, (double*)out_y, out_n_valid, n * d, n);
+    return launch_status();
+}
 
 extern "C" int pacoh_abi_version(void) { return 1; }
 

@@ -101,9 +101,7 @@ class TaskBatch:
     def select(self, idx_tensor):
         out = TaskBatch.__new__(TaskBatch)
         out.T, out.n, out.ragged = int(idx_tensor.numel()), self.n, self.ragged
-        out.x = self.x.index_select(0, idx_tensor)
-        out.y = self.y.index_select(0, idx_tensor)
-        out.n_valid = self.n_valid.index_select(0, idx_tensor)
+        out.x, out.y, out.n_valid = L.gather_tasks(self.x, self.y, self.n_valid, idx_tensor)
         out.sizes = None
         return out
 
