@@ -207,6 +207,17 @@ size_t pacoh_svgd_workspace_bytes(int P, int D, int dtype);
 int pacoh_svgd_phi(const void* X, const void* score, double bandwidth, int neg, void* phi,
                    void* bw_out, void* workspace, int P, int D, int dtype, void* stream);
 
+/* One whole SVGD step on the particles in three launches (distances, bandwidth + kernel matrix, update):
+ * X_out[i,:] = optimizer_step(X[i,:], grad = -phi[i,:]) with phi as above computed from score[j,:] + prior_factor *
+ * d log N(X[j,:]; prior_mean, prior_std) / dX (prior_mean/std NULL: score is used as is).  use_adam != 0: torch.optim.Adam
+ * (lr, beta1, beta2, eps, 1-based step; state exp_avg / exp_avg_sq updated in place); use_adam == 0: X_out = X + lr * phi
+ * (SGD on grad = -phi).  X_out must not alias X.  Replaces RandomGPMeta's prior backward + SVGD.step
+ * (random_gp.py:128-157, svgd.py:12-28, GPR_meta_svgd.py:220-223).  workspace as for pacoh_svgd_phi. */
+int pacoh_svgd_update(const void* X, const void* score, const void* prior_mean, const void* prior_std,
+                      double prior_factor, double bandwidth, int use_adam, double lr, double beta1, double beta2,
+                      double eps, long step, void* exp_avg, void* exp_avg_sq, void* X_out, void* bw_out,
+                      void* workspace, int P, int D, int dtype, void* stream);
+
 /* Same update direction with the IMQ particle kernel k_ij = (alpha + sum_d (X_jd - X_id)^2 / h_d)^beta
  * (alpha > 0, beta < 0).  bandwidth > 0: h_d = bandwidth for every d.  bandwidth <= 0: per-dimension median
  * heuristic h_d = lower-median_{a<b} (X_bd - X_ad)^2 / ln(P+1) (torch.median semantics), written to h_out[D]

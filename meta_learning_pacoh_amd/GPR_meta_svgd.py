@@ -90,9 +90,10 @@ class _RandomGPLearner(RegressionModelMetaLearned):
             up = self._idx_up = AsyncUploader(self.device, torch.int64)
         return up
 
-    def _log_prob_and_score(self, theta, idx_local, pre_factor):
+    def _log_prob_and_score(self, theta, idx_local, pre_factor, with_prior=True):
         """RandomGPMeta.log_prob and its gradient (random_gp.py:204-222; svgd.py:15-16):
-        log_prob[p] = prior_factor*log p(theta_p) + pre_factor * sum_t mll[t,p]"""
+        log_prob[p] = prior_factor*log p(theta_p) + pre_factor * sum_t mll[t,p]
+        (with_prior=False: the likelihood term and its score only -- the fused SVGD update adds the prior's score itself)"""
         P = theta.shape[0]
         if len(idx_local) > 0:
             batch = self.tasks.select(self._idx_uploader().upload(idx_local))
@@ -102,6 +103,8 @@ class _RandomGPLearner(RegressionModelMetaLearned):
             score = torch.zeros_like(theta)
             lik = torch.zeros(P, dtype=theta.dtype, device=theta.device)
         lik, score = parallel.all_reduce_sum_(lik, score)             # ONE exchange per step
+        if not with_prior:
+            return lik, score
         logprior = L.prior_logprob_grad(theta, self.prior_mean, self.prior_std, score, self.prior_factor)
         L.axpy(lik, logprior, self.prior_factor)                      # lik += prior_factor * log p(theta)
         return lik, score
@@ -148,8 +151,16 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
 
     def svgd_step(self, idx_local, pre_factor):
         """SVGD.step (meta_learn/svgd.py:25-28): particles.grad = -phi; optimizer.step()"""
+        if self.kernel == 'RBF':
+            # prior score + phi + optimizer step in one kernel (three launches with the distance / bandwidth kernels)
+            _, score = self._log_prob_and_score(self.particles, idx_local, pre_factor, with_prior=False)
+            self.opt_step += 1
+            self.particles, self.last_bandwidth, self._svgd_ws = L.svgd_update(
+                self.particles, score, self.prior_mean, self.prior_std, self.prior_factor, self.bandwidth, self.optimizer_name,
+                self.lr_scheduler.lr, self.opt_step, self.exp_avg, self.exp_avg_sq, workspace=self._svgd_ws)
+            return
         _, score = self._log_prob_and_score(self.particles, idx_local, pre_factor)
-        phi_fn = L.svgd_phi if self.kernel == 'RBF' else L.svgd_phi_imq     # IMQ: alpha=0.5, beta=-0.5 (svgd.py:70)
+        phi_fn = L.svgd_phi_imq                                             # IMQ: alpha=0.5, beta=-0.5 (svgd.py:70)
         neg_phi, self.last_bandwidth, self._svgd_ws = phi_fn(self.particles, score, bandwidth=self.bandwidth, neg=True,
                                                              workspace=self._svgd_ws)
         self.opt_step += 1

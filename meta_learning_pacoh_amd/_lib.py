@@ -49,6 +49,7 @@ SIGNATURES = {
     'pacoh_prior_logprob_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
     'pacoh_svgd_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_phi': (_i, [_vp, _vp, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pacoh_svgd_update': (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _d, _d, _d, _d, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_svgd_imq_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_phi_imq': (_i, [_vp, _vp, _d, _d, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_adam_step': (_i, [_vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _l, _l, _i, _vp]),
@@ -397,6 +398,26 @@ def svgd_phi(X, score, bandwidth=None, neg=False, workspace=None):
         _check(lib.pacoh_svgd_phi(_ptr(X), _ptr(score, X), bw, int(bool(neg)), _ptr(phi), _ptr(bw_out), _ptr(workspace),
                                   P, D, code, _stream()), 'pacoh_svgd_phi')
     return phi, bw_out, workspace
+
+
+def svgd_update(X, score, prior_mean, prior_std, prior_factor, bandwidth, optimizer, lr, step, exp_avg, exp_avg_sq,
+                workspace=None, beta1=0.9, beta2=0.999, eps=1e-8):
+    """one fused SVGD step (RBF kernel): prior score + phi + optimizer -> (X_new, bandwidth, workspace)"""
+    lib = load_library()
+    P, D = X.shape
+    code = dtype_code(X)
+    need = lib.pacoh_svgd_workspace_bytes(P, D, code)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=X.device)
+    X_out = torch.empty_like(X)
+    bw_out = torch.empty(1, dtype=X.dtype, device=X.device)
+    bw = -1.0 if bandwidth is None else float(bandwidth)
+    with _Timed('svgd_phi'):
+        _check(lib.pacoh_svgd_update(_ptr(X), _ptr(score, X), _ptr(prior_mean, X), _ptr(prior_std, X), float(prior_factor), bw,
+                                     int(optimizer == 'Adam'), float(lr), float(beta1), float(beta2), float(eps), int(step),
+                                     _ptr(exp_avg, X), _ptr(exp_avg_sq, X), _ptr(X_out), _ptr(bw_out), _ptr(workspace), P, D, code,
+                                     _stream()), 'pacoh_svgd_update')
+    return X_out, bw_out, workspace
 
 
 def svgd_phi_imq(X, score, alpha=0.5, beta=-0.5, bandwidth=None, neg=False, workspace=None):

@@ -249,6 +249,46 @@ __global__ void __launch_bounds__(256) svgd_phi_kernel(const T* __restrict__ X, 
     phi[(long)i * D + d] = neg ? -r : r;
 }
 
+// stage 3, fused variant used by the SVGD learner's step: the hyper-prior's score is added on the fly
+// (score_j += prior_factor * d log N(x_j; mu, sd) / dx), phi is formed as above and the optimizer step on particle i is applied
+// in the same thread (Adam with the op order of adam_kernel, or plain SGD), written to X_out (other threads still read X).
+// Replaces prior.log_prob's backward + SVGD.phi + optimizer.step (random_gp.py:128-157, svgd.py:12-28) for one step.
+template <typename T>
+__global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ X, const T* __restrict__ score,
+                                                          const T* __restrict__ mu, const T* __restrict__ sd, T prior_factor,
+                                                          const T* __restrict__ Kmat, const T* __restrict__ rowsum,
+                                                          const T* __restrict__ gamma_p, int use_adam, T lr, T one_minus_b1, T b2,
+                                                          T one_minus_b2, T step_size, T bc2_sqrt, T eps,
+                                                          T* __restrict__ m, T* __restrict__ v, T* __restrict__ X_out, int P, int D) {
+    const int i = blockIdx.y;
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    const T gam2 = T(2) * gamma_p[0];
+    const T* Ki = Kmat + (long)i * P;                // wave-uniform -> scalar loads
+    const T md = mu ? mu[d] : T(0), sdv = mu ? sd[d] : T(1);
+    const T pscale = mu ? prior_factor / (sdv * sdv) : T(0);
+    T acc = 0;
+    for (int j = 0; j < P; ++j) {
+        const T xj = X[(long)j * D + d];
+        const T sj = score[(long)j * D + d] - pscale * (xj - md);
+        acc = fma(Ki[j], sj - gam2 * xj, acc);
+    }
+    const T xi = X[(long)i * D + d];
+    const T r = (acc + gam2 * xi * rowsum[i]) / T(P);        // phi[i,d]
+    const long q = (long)i * D + d;
+    if (use_adam) {
+        const T g = -r;                                       // particles.grad = -phi (svgd.py:27)
+        T mq = m[q];
+        mq = mq + (g - mq) * one_minus_b1;
+        const T vq = v[q] * b2 + one_minus_b2 * g * g;
+        const T denom = t_sqrt<T>(vq) / bc2_sqrt + eps;
+        X_out[q] = xi - step_size * (mq / denom);
+        m[q] = mq; v[q] = vq;
+    } else {
+        X_out[q] = fma(lr, r, xi);
+    }
+}
+
 // ---- Adam / AdamW, op order of torch.optim._single_tensor_adam -----------------------------------
 template <typename T>
 __global__ void adam_kernel(T* __restrict__ param, const T* __restrict__ grad, T* __restrict__ m, T* __restrict__ v,
@@ -460,6 +500,39 @@ extern "C" int pacoh_svgd_phi(const void* X, const void* score, double bandwidth
     if (P > 64) return PACOH_ELIMIT;
     if (dtype == PACOH_F32) return svgd_launch<float>(X, score, bandwidth, neg, phi, bw_out, workspace, P, D, (hipStream_t)stream);
     return svgd_launch<double>(X, score, bandwidth, neg, phi, bw_out, workspace, P, D, (hipStream_t)stream);
+}
+
+template <typename T>
+static int svgd_update_launch(const void* X, const void* score, const void* mu, const void* sd, double prior_factor, double bandwidth,
+                              int use_adam, double lr, double beta1, double beta2, double eps, long step, void* m, void* v,
+                              void* X_out, void* bw_out, void* workspace, int P, int D, hipStream_t s) {
+    T* d2 = (T*)workspace;
+    T* Kmat = d2 + P * P;
+    T* rowsum = Kmat + P * P;
+    T* gamma = rowsum + P;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(svgd_dist_kernel<T>, dim3(P * P), dim3(256), 0, s, (const T*)X, d2, P, D);
+    hipLaunchKernelGGL(svgd_kmat_kernel<T>, dim3(1), dim3(256), 0, s, (const T*)d2, (T)bandwidth, Kmat, rowsum, gamma, (T*)bw_out, P);
+    hipLaunchKernelGGL(svgd_update_kernel<T>, dim3((D + 255) / 256, P), dim3(256), 0, s, (const T*)X, (const T*)score, (const T*)mu,
+                       (const T*)sd, (T)prior_factor, (const T*)Kmat, (const T*)rowsum, (const T*)gamma, use_adam, (T)lr,
+                       (T)(1.0 - beta1), (T)beta2, (T)(1.0 - beta2), (T)(lr / bc1), (T)sqrt(bc2), (T)eps, (T*)m, (T*)v, (T*)X_out, P, D);
+    return launch_status();
+}
+
+extern "C" int pacoh_svgd_update(const void* X, const void* score, const void* prior_mean, const void* prior_std,
+                                 double prior_factor, double bandwidth, int use_adam, double lr, double beta1, double beta2,
+                                 double eps, long step, void* exp_avg, void* exp_avg_sq, void* X_out, void* bw_out,
+                                 void* workspace, int P, int D, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!X || !score || !X_out || X_out == X || !workspace || P <= 0 || D <= 0) return PACOH_EINVAL;
+    if ((prior_mean == nullptr) != (prior_std == nullptr)) return PACOH_EINVAL;
+    if (use_adam && (!exp_avg || !exp_avg_sq || step <= 0)) return PACOH_EINVAL;
+    if (P > 64) return PACOH_ELIMIT;
+    if (dtype == PACOH_F32)
+        return svgd_update_launch<float>(X, score, prior_mean, prior_std, prior_factor, bandwidth, use_adam, lr, beta1, beta2, eps, step,
+                                         exp_avg, exp_avg_sq, X_out, bw_out, workspace, P, D, (hipStream_t)stream);
+    return svgd_update_launch<double>(X, score, prior_mean, prior_std, prior_factor, bandwidth, use_adam, lr, beta1, beta2, eps, step,
+                                      exp_avg, exp_avg_sq, X_out, bw_out, workspace, P, D, (hipStream_t)stream);
 }
 
 extern "C" int pacoh_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq,
