@@ -485,3 +485,17 @@ def test_vi_full_covariance_headline_size(L, dtype):
     grad = L.vi_grad(post, eps.to(DEV), score.to(DEV), 0.01, full=True)
     gl, gt = O.vi_full_grad(tril.double(), eps.double(), score.double(), 0.01)
     assert relerr(grad[0], gl) < tol and relerr(grad[1:], gt) < tol
+
+
+def test_gather_tasks(L):
+    """pacoh_gather_tasks == three index_selects (task batch of a step, drawn with replacement)"""
+    g = torch.Generator().manual_seed(2)
+    for dtype in (torch.float32, torch.float64):
+        x = torch.randn(11, 9, 3, generator=g, dtype=dtype).to(DEV)
+        y = torch.randn(11, 9, generator=g, dtype=dtype).to(DEV)
+        nv = torch.randint(1, 10, (11,), generator=g, dtype=torch.int32).to(DEV)
+        idx = torch.tensor([10, 0, 3, 3, 7, 10], dtype=torch.int64, device=DEV)
+        ox, oy, onv = L.gather_tasks(x, y, nv, idx)
+        assert torch.equal(ox, x.index_select(0, idx)) and torch.equal(oy, y.index_select(0, idx)) and torch.equal(onv, nv.index_select(0, idx))
+        ox2, oy2, onv2 = L.gather_tasks(x, y, None, idx)
+        assert onv2 is None and torch.equal(ox2, ox) and torch.equal(oy2, oy)
