@@ -207,7 +207,7 @@ size_t pacoh_svgd_workspace_bytes(int P, int D, int dtype);
 int pacoh_svgd_phi(const void* X, const void* score, double bandwidth, int neg, void* phi,
                    void* bw_out, void* workspace, int P, int D, int dtype, void* stream);
 
-/* One whole SVGD step on the particles in three launches (distances, bandwidth + kernel matrix, update):
+/* One whole SVGD step on the particles in two launches (distances; bandwidth + kernel row + update):
  * X_out[i,:] = optimizer_step(X[i,:], grad = -phi[i,:]) with phi as above computed from score[j,:] + prior_factor *
  * d log N(X[j,:]; prior_mean, prior_std) / dX (prior_mean/std NULL: score is used as is).  use_adam != 0: torch.optim.Adam
  * (lr, beta1, beta2, eps, 1-based step; state exp_avg / exp_avg_sq updated in place); use_adam == 0: X_out = X + lr * phi

@@ -249,22 +249,45 @@ __global__ void __launch_bounds__(256) svgd_phi_kernel(const T* __restrict__ X, 
     phi[(long)i * D + d] = neg ? -r : r;
 }
 
-// stage 3, fused variant used by the SVGD learner's step: the hyper-prior's score is added on the fly
-// (score_j += prior_factor * d log N(x_j; mu, sd) / dx), phi is formed as above and the optimizer step on particle i is applied
-// in the same thread (Adam with the op order of adam_kernel, or plain SGD), written to X_out (other threads still read X).
-// Replaces prior.log_prob's backward + SVGD.phi + optimizer.step (random_gp.py:128-157, svgd.py:12-28) for one step.
+// stages 2 + 3, fused variant used by the SVGD learner's step.  Every workgroup (particle i, 256 dimensions) recomputes the
+// bandwidth from the P x P distance matrix (one wavefront, ~1.5 us, all workgroups in parallel) and its own kernel row
+// k_i. = exp(-gamma d2[i,.]) -- cheaper than a separate single-workgroup launch in front.  Then the hyper-prior's score is
+// added on the fly (score_j += prior_factor * d log N(x_j; mu, sd) / dx), phi is formed as above and the optimizer step on
+// particle i is applied in the same thread (Adam with the op order of adam_kernel, or plain SGD), written to X_out (other
+// threads still read X).  Replaces prior.log_prob's backward + SVGD.phi + optimizer.step (random_gp.py:128-157,
+// svgd.py:12-28) for one step.
 template <typename T>
 __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ X, const T* __restrict__ score,
                                                           const T* __restrict__ mu, const T* __restrict__ sd, T prior_factor,
-                                                          const T* __restrict__ Kmat, const T* __restrict__ rowsum,
-                                                          const T* __restrict__ gamma_p, int use_adam, T lr, T one_minus_b1, T b2,
+                                                          const T* __restrict__ d2, T bandwidth, T* __restrict__ bw_out,
+                                                          int use_adam, T lr, T one_minus_b1, T b2,
                                                           T one_minus_b2, T step_size, T bc2_sqrt, T eps,
                                                           T* __restrict__ m, T* __restrict__ v, T* __restrict__ X_out, int P, int D) {
+    __shared__ T Ki[64];
+    __shared__ T gam_s, rowsum_s;
     const int i = blockIdx.y;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        T bw = bandwidth;
+        if (!(bandwidth > T(0))) {
+            const int npairs = P * (P - 1) / 2;
+            T med;
+            if (npairs <= 256) med = wave_median_full_matrix<T, 4>(d2, P, lane);
+            else if (npairs <= 512) med = wave_median_full_matrix<T, 8>(d2, P, lane);
+            else if (npairs <= 1024) med = wave_median_full_matrix<T, 16>(d2, P, lane);
+            else med = wave_median_full_matrix<T, 32>(d2, P, lane);
+            bw = t_sqrt<T>(med / (T(2) * t_log<T>(T(P + 1))));
+        }
+        const T gam = T(1) / (T(1e-8) + T(2) * bw * bw);
+        const T kv = lane < P ? t_exp<T>(-gam * d2[i * P + lane]) : T(0);
+        Ki[lane] = kv;
+        const T rs = subwave_sum<T>(kv, 64);
+        if (lane == 0) { gam_s = gam; rowsum_s = rs; if (bw_out && blockIdx.x == 0 && i == 0) *bw_out = bw; }
+    }
+    __syncthreads();
     const int d = blockIdx.x * 256 + threadIdx.x;
     if (d >= D) return;
-    const T gam2 = T(2) * gamma_p[0];
-    const T* Ki = Kmat + (long)i * P;                // wave-uniform -> scalar loads
+    const T gam2 = T(2) * gam_s;
     const T md = mu ? mu[d] : T(0), sdv = mu ? sd[d] : T(1);
     const T pscale = mu ? prior_factor / (sdv * sdv) : T(0);
     T acc = 0;
@@ -274,7 +297,7 @@ __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ 
         acc = fma(Ki[j], sj - gam2 * xj, acc);
     }
     const T xi = X[(long)i * D + d];
-    const T r = (acc + gam2 * xi * rowsum[i]) / T(P);        // phi[i,d]
+    const T r = (acc + gam2 * xi * rowsum_s) / T(P);          // phi[i,d]
     const long q = (long)i * D + d;
     if (use_adam) {
         const T g = -r;                                       // particles.grad = -phi (svgd.py:27)
@@ -507,14 +530,10 @@ static int svgd_update_launch(const void* X, const void* score, const void* mu, 
                               int use_adam, double lr, double beta1, double beta2, double eps, long step, void* m, void* v,
                               void* X_out, void* bw_out, void* workspace, int P, int D, hipStream_t s) {
     T* d2 = (T*)workspace;
-    T* Kmat = d2 + P * P;
-    T* rowsum = Kmat + P * P;
-    T* gamma = rowsum + P;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(svgd_dist_kernel<T>, dim3(P * P), dim3(256), 0, s, (const T*)X, d2, P, D);
-    hipLaunchKernelGGL(svgd_kmat_kernel<T>, dim3(1), dim3(256), 0, s, (const T*)d2, (T)bandwidth, Kmat, rowsum, gamma, (T*)bw_out, P);
     hipLaunchKernelGGL(svgd_update_kernel<T>, dim3((D + 255) / 256, P), dim3(256), 0, s, (const T*)X, (const T*)score, (const T*)mu,
-                       (const T*)sd, (T)prior_factor, (const T*)Kmat, (const T*)rowsum, (const T*)gamma, use_adam, (T)lr,
+                       (const T*)sd, (T)prior_factor, (const T*)d2, (T)bandwidth, (T*)bw_out, use_adam, (T)lr,
                        (T)(1.0 - beta1), (T)beta2, (T)(1.0 - beta2), (T)(lr / bc1), (T)sqrt(bc2), (T)eps, (T*)m, (T*)v, (T*)X_out, P, D);
     return launch_status();
 }
