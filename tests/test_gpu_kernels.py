@@ -499,3 +499,28 @@ def test_gather_tasks(L):
         assert torch.equal(ox, x.index_select(0, idx)) and torch.equal(oy, y.index_select(0, idx)) and torch.equal(onv, nv.index_select(0, idx))
         ox2, oy2, onv2 = L.gather_tasks(x, y, None, idx)
         assert onv2 is None and torch.equal(ox2, ox) and torch.equal(oy2, oy)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('optimizer,bandwidth,with_prior', [('Adam', None, True), ('SGD', 0.8, True), ('Adam', 1.7, False)])
+def test_svgd_update_fused(L, dtype, optimizer, bandwidth, with_prior):
+    """pacoh_svgd_update (prior score + phi + optimizer in one kernel) == oracle phi on the prior-augmented score + torch optimizer"""
+    g = torch.Generator().manual_seed(17)
+    P, D, pf, lr = 7, 301, 0.3, 1e-2
+    X = torch.randn(P, D, generator=g, dtype=torch.float64)
+    score = torch.randn(P, D, generator=g, dtype=torch.float64)
+    mu, sd = torch.randn(D, generator=g, dtype=torch.float64), torch.rand(D, generator=g, dtype=torch.float64) + 0.5
+    Xo = X.clone().requires_grad_(True)
+    opt = torch.optim.Adam([Xo], lr=lr) if optimizer == 'Adam' else torch.optim.SGD([Xo], lr=lr)
+    Xd, m, v = X.to(dtype).to(DEV), torch.zeros(P, D, dtype=dtype, device=DEV), torch.zeros(P, D, dtype=dtype, device=DEV)
+    ws = None
+    for step in (1, 2, 3):
+        s_tot = score + (pf * (-(Xo.detach() - mu) / sd ** 2) if with_prior else 0.0)
+        phi, bw_o = O.svgd_phi_closed_form(Xo.detach(), s_tot, bandwidth)
+        Xo.grad = -phi
+        opt.step()
+        Xd, bw, ws = L.svgd_update(Xd, score.to(dtype).to(DEV), mu.to(dtype).to(DEV) if with_prior else None,
+                                   sd.to(dtype).to(DEV) if with_prior else None, pf, bandwidth, optimizer, lr, step, m, v, workspace=ws)
+        assert abs(float(bw) - float(bw_o)) < 1e-5 * float(bw_o)
+    tol = 2e-4 if dtype == torch.float32 else 1e-10
+    assert relerr(Xd, Xo.detach()) < tol
