@@ -94,15 +94,14 @@ class _RandomGPLearner(RegressionModelMetaLearned):
         """RandomGPMeta.log_prob and its gradient (random_gp.py:204-222; svgd.py:15-16):
         log_prob[p] = prior_factor*log p(theta_p) + pre_factor * sum_t mll[t,p]
         (with_prior=False: the likelihood term and its score only -- the fused SVGD update adds the prior's score itself)"""
-        P = theta.shape[0]
+        P, D = theta.shape
+        packed, score, lik = parallel.packed_score_buffer(P, D, theta.dtype, theta.device)   # lik = pre_factor * sum_t mll[t,p]
         if len(idx_local) > 0:
             batch = self.tasks.select(self._idx_uploader().upload(idx_local))
-            lik = torch.empty(P, dtype=theta.dtype, device=theta.device)             # pre_factor * sum_t mll[t,p]
-            lml, score, _ = self.engine.lml_and_grad(theta, batch, weight=pre_factor, lik_out=lik, lik_scale=pre_factor)
+            self.engine.lml_and_grad(theta, batch, weight=pre_factor, lik_out=lik, lik_scale=pre_factor, grad_out=score)
         else:
-            score = torch.zeros_like(theta)
-            lik = torch.zeros(P, dtype=theta.dtype, device=theta.device)
-        lik, score = parallel.all_reduce_sum_(lik, score)             # ONE exchange per step
+            packed.zero_()
+        lik, score = parallel.all_reduce_sum_(lik, score, packed)     # ONE exchange per step, no packing copies
         if not with_prior:
             return lik, score
         logprior = L.prior_logprob_grad(theta, self.prior_mean, self.prior_std, score, self.prior_factor)

@@ -189,9 +189,10 @@ class GPEngine:
                                        n_valid=batch.n_valid if batch.ragged else None)
         return lml.reshape(T, P), info
 
-    def lml_and_grad(self, theta, batch, weight=1.0, lik_out=None, lik_scale=1.0):
+    def lml_and_grad(self, theta, batch, weight=1.0, lik_out=None, lik_scale=1.0, grad_out=None):
         """returns (lml[T,P], grad[P,D]) with grad = d(weight * sum_t lml[t,p]) / d theta[p];
-        lik_out[P] (optional) receives lik_scale * sum_t lml[t,p] from the same launch that reduces the hyper-gradients"""
+        lik_out[P] (optional) receives lik_scale * sum_t lml[t,p] from the same launch that reduces the hyper-gradients;
+        grad_out[P,D] (optional, contiguous) is used for the gradient instead of a fresh tensor"""
         lay = self.layout
         P, D = theta.shape
         T, n = batch.T, batch.n
@@ -206,7 +207,7 @@ class GPEngine:
         lml, d_z, d_mean, d_ls, d_os, d_noise, info = L.gp_lml_fwdbwd(
             z, z_div, mean, mode, batch.y, P, ls, os_, noise, B, P,
             n_valid=batch.n_valid if batch.ragged else None, g_lml=g, want_dz=(lay.covar_module == 'NN'))
-        grad = torch.empty(P, D, dtype=dt, device=dev)          # every block is written below
+        grad = grad_out if grad_out is not None else torch.empty(P, D, dtype=dt, device=dev)   # every block is written below
         if lay.covar_module == 'NN':
             lo, _ = lay.block_range('kernel_nn.')
             self._ws['k'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers),

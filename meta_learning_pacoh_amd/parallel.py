@@ -21,12 +21,23 @@ def shard(indices, rank=None, world_size=None):
     return indices[rank::world_size]
 
 
-def all_reduce_sum_(lik, score):
-    """sum [P] and [P,D] over ranks with one collective on a packed buffer; identity at world size 1"""
+def packed_score_buffer(P, D, dtype, device):
+    """one buffer holding score[P,D] followed by lik[P], so that the step's single all-reduce needs no packing copies:
+    returns (buf, score view, lik view)"""
+    buf = torch.empty(P * D + P, dtype=dtype, device=device)
+    return buf, buf[:P * D].view(P, D), buf[P * D:]
+
+
+def all_reduce_sum_(lik, score, packed=None):
+    """sum [P] and [P,D] over ranks with one collective on a packed buffer; identity at world size 1.
+    `packed`: the buffer of packed_score_buffer() whose views lik / score are (reduced in place, no copies)"""
     _, w = world()
     if w == 1:
         return lik, score
     P, D = score.shape
+    if packed is not None:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        return lik, score
     buf = torch.cat([score.reshape(-1), lik.reshape(-1)])
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf[P * D:].reshape(P), buf[:P * D].reshape(P, D)
