@@ -195,6 +195,7 @@ def gp_lml_fwd(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, no
 
 
 _DENSE_WS = {}
+DENSE_WS_BYTES = 8 << 30          # scratch budget of the large-n path; larger meta-batches are processed in slabs of whole tasks
 
 
 def _workspace(key, nbytes, device):
@@ -223,12 +224,32 @@ def _gp_lml_dense(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale,
         d_ls = torch.empty(B, f, dtype=dt, device=dev)
         d_os = torch.empty(B, dtype=dt, device=dev) if outputscale is not None else None
         d_noise = torch.empty(B, dtype=dt, device=dev)
-    ws = _workspace('lml', lib.pacoh_gp_lml_dense_workspace_bytes(B, n, f, code, int(want_grad)), dev)
+    # The scratch is O(B n^2): whole tasks (all their P problems) are processed in slabs that keep it under DENSE_WS_BYTES.
+    T_ = B // P
+    per_task = max(1, lib.pacoh_gp_lml_dense_workspace_bytes(P, n, f, code, int(want_grad)))
+    tb = T_
+    if B == T_ * P and z_div in (1, P) and y_div in (1, P) and T_ > 1:
+        tb = max(1, min(T_, DENSE_WS_BYTES // per_task))
+
+    def sl(t, b0, b1, div=1):
+        return None if t is None else t[b0 // div:(b1 + div - 1) // div]
+
     with _Timed('gp_lml_dense'):
-        _check(lib.pacoh_gp_lml_dense(_ptr(z), z_div, _ptr(mean, z), mean_mode, _ptr(y, z), y_div, _ptr(lengthscale, z),
-                                      _ptr(outputscale, z), _ptr(noise, z), _ptr(n_valid), _ptr(g_lml, z), _ptr(lml), _ptr(d_z),
-                                      _ptr(d_mean), _ptr(d_ls), _ptr(d_os), _ptr(d_noise), _ptr(info), _ptr(ws),
-                                      B, P, n, f, code, _stream()), 'pacoh_gp_lml_dense')
+        for t0 in range(0, T_ if tb < T_ else 1, tb):
+            if tb >= T_:
+                b0, b1 = 0, B
+            else:
+                b0, b1 = t0 * P, min(T_, t0 + tb) * P
+            Bc = b1 - b0
+            ws = _workspace('lml', lib.pacoh_gp_lml_dense_workspace_bytes(Bc, n, f, code, int(want_grad)), dev)
+            mean_c = sl(mean, b0, b1) if mean_mode == MEAN_VECTOR else mean
+            d_mean_c = sl(d_mean, b0, b1) if d_mean is not None else None          # [B,n] (vector) or [B] (const): both per problem
+            _check(lib.pacoh_gp_lml_dense(_ptr(sl(z, b0, b1, z_div)), z_div, _ptr(mean_c, z), mean_mode, _ptr(sl(y, b0, b1, y_div), z),
+                                          y_div, _ptr(lengthscale, z), _ptr(outputscale, z), _ptr(noise, z),
+                                          _ptr(sl(n_valid, b0, b1, y_div)), _ptr(sl(g_lml, b0, b1), z), _ptr(sl(lml, b0, b1)),
+                                          _ptr(sl(d_z, b0, b1)), _ptr(d_mean_c), _ptr(sl(d_ls, b0, b1)), _ptr(sl(d_os, b0, b1)),
+                                          _ptr(sl(d_noise, b0, b1)), _ptr(sl(info, b0, b1)), _ptr(ws),
+                                          Bc, P, n, f, code, _stream()), 'pacoh_gp_lml_dense')
     return lml, d_z, d_mean, d_ls, d_os, d_noise
 
 

@@ -159,3 +159,25 @@ def test_dense_predict(L, dtype, case):
     mu2, var2, cov2, _ = L.gp_predict(z.to(DEV), 1, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, zt.to(DEV), 1, mt.to(DEV),
                                       ls.to(DEV), os_.to(DEV), noise.to(DEV), B, P, want_cov=False)
     assert cov2 is None and torch.equal(mu2, mu) and torch.equal(var2, var)
+
+
+def test_dense_path_slabs_match_single_pass(L):
+    """meta-batches whose O(B n^2) scratch exceeds the budget are processed in slabs of whole tasks: same results"""
+    T, P, n, f = 5, 3, 150, 2
+    z, mean, y, ls, os_, noise = [t.to(DEV) for t in make_problem(T, P, n, f, torch.float64, seed=3)]
+    nv = torch.tensor([150, 40, 150, 7, 99], dtype=torch.int32, device=DEV)
+    gl = (torch.rand(T * P, dtype=torch.float64) + 0.5).to(DEV)
+    full = L.gp_lml_fwdbwd(z, 1, mean, L.MEAN_VECTOR, y, P, ls, os_, noise, T * P, P, n_valid=nv, g_lml=gl)
+    budget = L.DENSE_WS_BYTES
+    try:
+        L.DENSE_WS_BYTES = 2 * L.load_library().pacoh_gp_lml_dense_workspace_bytes(P, n, f, L.F64, 1) + 1     # two tasks per slab
+        slabs = L.gp_lml_fwdbwd(z, 1, mean, L.MEAN_VECTOR, y, P, ls, os_, noise, T * P, P, n_valid=nv, g_lml=gl)
+        shared = L.gp_lml_fwdbwd(z[::P].contiguous(), P, None, L.MEAN_ZERO, y, P, ls, os_, noise, T * P, P, want_dz=False)
+        L.DENSE_WS_BYTES = budget
+        shared_full = L.gp_lml_fwdbwd(z[::P].contiguous(), P, None, L.MEAN_ZERO, y, P, ls, os_, noise, T * P, P, want_dz=False)
+    finally:
+        L.DENSE_WS_BYTES = budget
+    for a, b in zip(full, slabs):
+        assert torch.equal(a, b)
+    for a, b in zip(shared_full, shared):
+        assert (a is None and b is None) or torch.equal(a, b)
