@@ -338,76 +338,90 @@ void launch_bgemm(const GemmArgs& ga, int Bn, hipStream_t s) {
 
 // ---- gradient sums, one wave per matrix row -----------------------------------------------------------------------------------
 //   rowpart[b, i, 0..f) = sum_j M_ij df_c^2,  [f] = sum_j G_ij e_ij,  [f+1] = G_ii,  [f+2] = alpha_i
-template <typename T, int FP>
+// A workgroup (4 waves) owns ROWS consecutive rows of one problem.  With LDS = true the problem's pre-scaled coordinates
+// (feature-major, so that consecutive lanes read consecutive words) and alpha are staged in LDS once per workgroup; without
+// it every row re-read them through L1/L2 (n*f*8 bytes per row: 4.3 GB of cache traffic at n = 512, d = 8, 256 problems --
+// that, not the arithmetic, bounded the kernel).
+template <typename T, int FP, bool LDS>
 __global__ void __launch_bounds__(256) dense_grad_rows_kernel(const T* __restrict__ zs, const T* __restrict__ lsp,
                                                               const T* __restrict__ osp, const int32_t* __restrict__ n_valid,
                                                               int y_div, const T* __restrict__ g_lml, const T* __restrict__ alpha,
                                                               const T* __restrict__ Wm, const int32_t* __restrict__ info,
                                                               T* __restrict__ d_z, T* __restrict__ d_mean, int mean_mode,
-                                                              T* __restrict__ rowpart, int P, int n, int f) {
+                                                              T* __restrict__ rowpart, int P, int n, int f, int rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* zt = reinterpret_cast<T*>(smem_raw);          // [f][n]  (LDS only)
+    T* al = zt + (size_t)f * n;                       // [n]
     const long b = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = (int)(b % P);
     const int nv = clamp_nv(n_valid, b / y_div, n);
     const bool failed = info[b] < 0;
     const T gup = g_lml ? g_lml[b] : T(1);
     const int W3 = f + 3;
-    T* rp = rowpart + (b * n + i) * (long)W3;
-    if (failed || i >= nv) {
-        const T v = failed ? T(NAN) : T(0);
-        if (lane == 0) {
-            if (d_z) for (int c = 0; c < f; ++c) d_z[(b * n + i) * (long)f + c] = v;
-            if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = v;
-            for (int c = 0; c < W3; ++c) rp[c] = v;
-        }
-        return;
-    }
-    T ls[FP], zi[FP];
     const T* zb = zs + b * (long)n * f;
-#pragma unroll
-    for (int c = 0; c < FP; ++c) {
-        ls[c] = c < f ? lsp[(long)p * f + c] : T(1);
-        zi[c] = c < f ? zb[(long)i * f + c] : T(0);
+    const T* ab = alpha + b * (long)n;
+    if (LDS) {
+        for (int e = threadIdx.x; e < n * f; e += 256) { const int j = e / f, c = e - j * f; zt[c * n + j] = zb[e]; }
+        for (int j = threadIdx.x; j < n; j += 256) al[j] = ab[j];
+        __syncthreads();
     }
+    T ls[FP];
+#pragma unroll
+    for (int c = 0; c < FP; ++c) ls[c] = c < f ? lsp[(long)p * f + c] : T(1);
     const T os = osp ? osp[p] : T(1);
-    const T ai = alpha[b * n + i];
-    const T inv2n = T(0.5) / T(nv);
-    const T* wrow = Wm + (b * n + i) * (long)n;
-    T dz[FP], dls[FP];
-#pragma unroll
-    for (int c = 0; c < FP; ++c) { dz[c] = 0; dls[c] = 0; }
-    T dos = 0, dnz = 0;
-    for (int j = lane; j < nv; j += 64) {
-        const T Gij = (ai * alpha[b * n + j] - wrow[j]) * inv2n;
-        T s = 0, df[FP];
-#pragma unroll
-        for (int c = 0; c < FP; ++c) {
-            df[c] = c < f ? zb[(long)j * f + c] - zi[c] : T(0);
-            s = fma(df[c], df[c], s);
-        }
-        const T e = rbf_exp<T>(T(-0.5) * s);
-        dos = fma(Gij, e, dos);
-        const T M = Gij * os * e;
-#pragma unroll
-        for (int c = 0; c < FP; ++c) { const T md = M * df[c]; dz[c] += md; dls[c] = fma(md, df[c], dls[c]); }
-        if (j == i) dnz = Gij;
-    }
-#pragma unroll
-    for (int c = 0; c < FP; ++c) { dz[c] = subwave_sum<T>(dz[c], 64); dls[c] = subwave_sum<T>(dls[c], 64); }
-    dos = subwave_sum<T>(dos, 64);
-    dnz = subwave_sum<T>(dnz, 64);
-    if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < FP; ++c) {
-            if (c < f) {
-                if (d_z) d_z[(b * n + i) * (long)f + c] = T(2) * gup * dz[c] / ls[c];
-                rp[c] = dls[c];
+    const T inv2n = nv > 0 ? T(0.5) / T(nv) : T(0);
+    const int i_end = min(n, (int)(blockIdx.x + 1) * rows);
+    for (int i = blockIdx.x * rows + wave; i < i_end; i += 4) {
+        T* rp = rowpart + (b * n + i) * (long)W3;
+        if (failed || i >= nv) {
+            const T v = failed ? T(NAN) : T(0);
+            if (lane == 0) {
+                if (d_z) for (int c = 0; c < f; ++c) d_z[(b * n + i) * (long)f + c] = v;
+                if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = v;
+                for (int c = 0; c < W3; ++c) rp[c] = v;
             }
+            continue;
         }
-        rp[f] = dos; rp[f + 1] = dnz; rp[f + 2] = ai;
-        if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = gup * ai / T(nv);
+        T zi[FP];
+#pragma unroll
+        for (int c = 0; c < FP; ++c) zi[c] = c < f ? (LDS ? zt[c * n + i] : zb[(long)i * f + c]) : T(0);
+        const T ai = LDS ? al[i] : ab[i];
+        const T* wrow = Wm + (b * n + i) * (long)n;
+        T dz[FP], dls[FP];
+#pragma unroll
+        for (int c = 0; c < FP; ++c) { dz[c] = 0; dls[c] = 0; }
+        T dos = 0, dnz = 0;
+        for (int j = lane; j < nv; j += 64) {
+            const T Gij = (ai * (LDS ? al[j] : ab[j]) - wrow[j]) * inv2n;
+            T s = 0, df[FP];
+#pragma unroll
+            for (int c = 0; c < FP; ++c) {
+                df[c] = c < f ? (LDS ? zt[c * n + j] : zb[(long)j * f + c]) - zi[c] : T(0);
+                s = fma(df[c], df[c], s);
+            }
+            const T e = rbf_exp<T>(T(-0.5) * s);
+            dos = fma(Gij, e, dos);
+            const T M = Gij * os * e;
+#pragma unroll
+            for (int c = 0; c < FP; ++c) { const T md = M * df[c]; dz[c] += md; dls[c] = fma(md, df[c], dls[c]); }
+            if (j == i) dnz = Gij;
+        }
+#pragma unroll
+        for (int c = 0; c < FP; ++c) { dz[c] = subwave_sum<T>(dz[c], 64); dls[c] = subwave_sum<T>(dls[c], 64); }
+        dos = subwave_sum<T>(dos, 64);
+        dnz = subwave_sum<T>(dnz, 64);
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < FP; ++c) {
+                if (c < f) {
+                    if (d_z) d_z[(b * n + i) * (long)f + c] = T(2) * gup * dz[c] / ls[c];
+                    rp[c] = dls[c];
+                }
+            }
+            rp[f] = dos; rp[f + 1] = dnz; rp[f + 2] = ai;
+            if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = gup * ai / T(nv);
+        }
     }
 }
 
@@ -541,9 +555,18 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
         hipLaunchKernelGGL(dense_scale_kernel<T>, dim3((unsigned)((tz + 255) / 256)), dim3(256), 0, s, (const T*)z, z_div, (const T*)ls, zsc,
                            P, n, f, tz);
         const int FP = f <= 2 ? 2 : (f <= 4 ? 4 : (f <= 8 ? 8 : 16));
-#define PACOH_DG_CASE(fp) case fp: hipLaunchKernelGGL((dense_grad_rows_kernel<T, fp>), dim3((n + 3) / 4, B), dim3(256), 0, s, \
-        (const T*)zsc, (const T*)ls, (const T*)os, n_valid, y_div, (const T*)g_lml, (const T*)alpha, (const T*)Wm, \
-        (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f); break;
+        // 16 rows per workgroup with the coordinates staged in LDS when they fit, else 4 rows per workgroup from L1/L2
+        const size_t glds = ((size_t)n * f + n) * sizeof(T);
+        const bool use_lds = glds <= 60u * 1024u;
+        const int rows = use_lds ? 16 : 4;
+#define PACOH_DG_CASE(fp) case fp: \
+        if (use_lds) hipLaunchKernelGGL((dense_grad_rows_kernel<T, fp, true>), dim3((n + rows - 1) / rows, B), dim3(256), glds, s, \
+            (const T*)zsc, (const T*)ls, (const T*)os, n_valid, y_div, (const T*)g_lml, (const T*)alpha, (const T*)Wm, \
+            (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f, rows); \
+        else hipLaunchKernelGGL((dense_grad_rows_kernel<T, fp, false>), dim3((n + rows - 1) / rows, B), dim3(256), 0, s, \
+            (const T*)zsc, (const T*)ls, (const T*)os, n_valid, y_div, (const T*)g_lml, (const T*)alpha, (const T*)Wm, \
+            (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f, rows); \
+        break;
         switch (FP) { PACOH_DG_CASE(2) PACOH_DG_CASE(4) PACOH_DG_CASE(8) default: PACOH_DG_CASE(16) }
 #undef PACOH_DG_CASE
     }
