@@ -466,3 +466,32 @@ def test_svgd_large_context_score_matches_oracle(M):
     model.meta_fit(verbose=False, n_iter=3)
     mu, sd = model.predict(tasks[0][0], tasks[0][1], tasks[1][0][:9])
     assert np.isfinite(mu).all() and (sd > 0).all()
+
+
+def test_svgd_120_iterations_track_oracle_on_demo_data(M):
+    """longer horizon: PACOH-SVGD on the demo sinusoid tasks (20 x 5 points, 10 particles, sampled task batches of 5) for 120
+    iterations on the HIP path vs the oracle's SVGD loop (closed-form phi + torch Adam) fed the same task draws -- the particles
+    stay close and the test-set metrics agree"""
+    train, test = demo_data()
+    P, B, iters, lr = 10, 5, 120, 3e-3
+    model = M.GPRegressionMetaLearnedSVGD(train, num_particles=P, task_batch_size=B, lr=lr, random_seed=30)
+    cfg = O.GPConfig(1, 'NN', 'NN')
+    pm, ps = O.hyperprior_mean_std(cfg.layout, 0.5, 3.0)
+    stats = O.compute_normalization_stats(train)
+    otasks = [O.prepare_task(x, y, stats, torch.float64) for x, y in train]
+    X = model.particles.cpu().double().clone()
+    opt = torch.optim.Adam([X], lr=lr)
+    rds = np.random.RandomState(31)                                 # the learner's task stream: RandomState(seed + 1)
+    for _ in range(iters):
+        idx = rds.randint(0, len(train), size=B)
+        _, s = O.meta_score(X, [otasks[i] for i in idx], cfg, pm, ps, 0.01)
+        phi, _ = O.svgd_phi_closed_form(X.detach(), s, None)
+        X.grad = -phi
+        opt.step()
+    model.meta_fit(verbose=False, n_iter=iters)
+    assert relerr(model.particles, X) < 2e-2
+    # test-set metrics of the two particle sets through the same (HIP) predictive
+    ll, rmse, calib = model.eval_datasets(test)
+    model.particles.copy_(X.to(model.particles.dtype))
+    ll_o, rmse_o, calib_o = model.eval_datasets(test)
+    assert abs(ll - ll_o) < 0.03 and abs(rmse - rmse_o) < 0.02 and abs(calib - calib_o) < 0.03
