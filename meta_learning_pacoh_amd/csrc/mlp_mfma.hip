@@ -391,6 +391,9 @@ __global__ void __launch_bounds__(256, 2) mlp_mfma_bwd_small_kernel(MlpMfmaArgs 
     // per-lane partial sums of the narrow layers' gradients live in lane-private LDS slots ([slot][256 lanes],
     // conflict-free, deterministic) instead of ~66 registers: that is what lets two waves share a SIMD
     __shared__ float pacc[66 * 256];
+    // per-wave scratch for 16x16 block transposes through LDS (row stride 17 floats -- all that fits beside two resident
+    // workgroups' accumulators); the matrix cores did these transposes before (64 of a tile's 256 MFMAs)
+    __shared__ float tscr[4 * 16 * 17];
     float* my = pacc + threadIdx.x;
 #define PW1(fb, s, k) my[(((fb) * 4 + (s)) * 4 + (k)) * 256]
 #define PW3(o, fb, s) my[(32 + ((o) * 2 + (fb)) * 4 + (s)) * 256]
@@ -494,9 +497,19 @@ __global__ void __launch_bounds__(256, 2) mlp_mfma_bwd_small_kernel(MlpMfmaArgs 
                 f32x4 H1p[2], D2p[2];
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-                    f32x4 P1 = {0.f, 0.f, 0.f, 0.f}, P2 = {0.f, 0.f, 0.f, 0.f};
+                    // block transpose: lane (r,g) holds X[feature 4g+s][point r] in register s and needs X[feature r][point 4g+q]
+                    float* tw_ = tscr + (threadIdx.x >> 6) * 272;
+                    f32x4 P1, P2;
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) { P1 = mfma4x(H1[kb][pb][s], idn[s], P1); P2 = mfma4x(H2[kb][pb][s], idn[s], P2); }
+                    for (int s = 0; s < 4; ++s) tw_[(4 * g + s) * 17 + r] = H1[kb][pb][s];
+                    asm volatile("" ::: "memory");
+                    for (int q = 0; q < 4; ++q) P1[q] = tw_[r * 17 + 4 * g + q];
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) tw_[(4 * g + s) * 17 + r] = H2[kb][pb][s];
+                    asm volatile("" ::: "memory");
+                    for (int q = 0; q < 4; ++q) P2[q] = tw_[r * 17 + 4 * g + q];
+                    asm volatile("" ::: "memory");
                     H1p[kb] = P1; D2p[kb] = P2;
                     tB2[kb] += H2[kb][pb];
                 }
