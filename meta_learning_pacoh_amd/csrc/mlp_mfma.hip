@@ -187,7 +187,9 @@ __device__ __forceinline__ void wgrad(f32x4& acc, const f32x4& Ap, const f32x4& 
     acc = mfma4x(Ap[2], Bp[2], acc); acc = mfma4x(Ap[3], Bp[3], acc);
 }
 
-template <int NH>
+template <int NH, bool NARROW>
+// NARROW (d_out <= 2): the output layer runs on the VALU (8 FMAs per point and output + two cross-lane adds) instead of a
+// 16-row MFMA layer of which 14 rows would be padding (32 of the tile's 104 MFMAs).
 // (256, 4): the allocator then settles at 96 VGPRs without spills = five waves per SIMD; the default allocation took 140
 // registers (three waves per SIMD, 4 % slower -- the forward pass is latency-bound, extra waves hide it) and asking for five
 // waves outright made it spill 11 registers (36 MB of scratch traffic per launch in the PMC counters)
@@ -197,6 +199,17 @@ __global__ void __launch_bounds__(256, 4) mlp_mfma_fwd_kernel(MlpMfmaArgs a) {
     load_weights_mfma<NH>(wl, a.theta + (long)p * a.theta_stride, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
+    float w3r[2][2][4], b3r[2];                          // NARROW: W3[o][feature fb*16+4g+s] (rows >= d_out are zero), b3[o]
+    if (NARROW) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            b3r[o] = wl[OFF_B3 + o];
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) w3r[o][fb][s] = wl[OFF_W3 + o * LW2 + fb * 16 + 4 * g + s];
+        }
+    }
     for (int tl = 0; tl < a.tiles_per_wg; tl += 4) {
         const int tile = blockIdx.x * a.tiles_per_wg + tl + wave;
         const int row0 = tile * 64;
@@ -207,19 +220,33 @@ __global__ void __launch_bounds__(256, 4) mlp_mfma_fwd_kernel(MlpMfmaArgs a) {
         for (int pb = 0; pb < 4; ++pb) { xp[pb] = xrow(a, p, row0, t0, i0, pb * 16 + r); orow[pb] = out_row(a, p, row0, t0, i0, pb * 16 + r); }
         f32x4 H1[2][4];
         layer1(wl, a, xp, r, g, H1);
-        f32x4 O[1][4];
-        if (NH == 2) {
-            f32x4 H2[2][4];
-            layer_xs<2, true>(wl + OFF_W2, wl + OFF_B2, r, g, H1, H2);
-            layer_xs<1, false>(wl + OFF_W3, wl + OFF_B3, r, g, H2, O);
+        f32x4 H2[2][4];
+        if (NH == 2) layer_xs<2, true>(wl + OFF_W2, wl + OFF_B2, r, g, H1, H2);
+        const f32x4 (&HL)[2][4] = (NH == 2) ? H2 : H1;
+        if (NARROW) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) { v0 = fmaf(w3r[0][fb][s], HL[fb][pb][s], v0); v1 = fmaf(w3r[1][fb][s], HL[fb][pb][s], v1); }
+                v0 += __shfl_xor(v0, 16, 64); v0 += __shfl_xor(v0, 32, 64);           // sum over the four feature groups g
+                v1 += __shfl_xor(v1, 16, 64); v1 += __shfl_xor(v1, 32, 64);
+                if (g == 0 && orow[pb] >= 0) {
+                    a.out[orow[pb] * a.d_out] = v0 + b3r[0];
+                    if (a.d_out > 1) a.out[orow[pb] * a.d_out + 1] = v1 + b3r[1];
+                }
+            }
         } else {
-            layer_xs<1, false>(wl + OFF_W3, wl + OFF_B3, r, g, H1, O);
-        }
+            f32x4 O[1][4];
+            layer_xs<1, false>(wl + OFF_W3, wl + OFF_B3, r, g, HL, O);
 #pragma unroll
-        for (int pb = 0; pb < 4; ++pb) {
-            if (orow[pb] >= 0) {
+            for (int pb = 0; pb < 4; ++pb) {
+                if (orow[pb] >= 0) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) { const int o = 4 * g + s; if (o < a.d_out) a.out[orow[pb] * a.d_out + o] = O[0][pb][s]; }
+                    for (int s = 0; s < 4; ++s) { const int o = 4 * g + s; if (o < a.d_out) a.out[orow[pb] * a.d_out + o] = O[0][pb][s]; }
+                }
             }
         }
     }
@@ -659,8 +686,13 @@ int mlp_mfma_fwd(const void* x, int x_div, const void* theta, long theta_stride,
     const int tiles = (a.R + 63) / 64;
     a.tiles_per_wg = 8;            // 2 tiles per wave; measured faster than fewer, larger workgroups
     const int wgs = (tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
-    if (n_hidden == 2) hipLaunchKernelGGL(mlp_mfma_fwd_kernel<2>, dim3(wgs, P), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(mlp_mfma_fwd_kernel<1>, dim3(wgs, P), dim3(256), 0, s, a);
+    if (d_out <= 2) {
+        if (n_hidden == 2) hipLaunchKernelGGL((mlp_mfma_fwd_kernel<2, true>), dim3(wgs, P), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((mlp_mfma_fwd_kernel<1, true>), dim3(wgs, P), dim3(256), 0, s, a);
+    } else {
+        if (n_hidden == 2) hipLaunchKernelGGL((mlp_mfma_fwd_kernel<2, false>), dim3(wgs, P), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((mlp_mfma_fwd_kernel<1, false>), dim3(wgs, P), dim3(256), 0, s, a);
+    }
     return launch_status();
 }
 
