@@ -280,6 +280,22 @@ int pacoh_gather_tasks(const void* x, const void* y, const int32_t* n_valid, con
 int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, int T, int P, int W,
                        int dtype, void* stream);
 
+/* ---- 8e: the step's one exchange ----------------------------------------------------------------------------------
+ * buf[0..count) := sum over ranks of buf (in place), enqueued on the caller's stream: RCCL ncclAllReduce(ncclSum) over xGMI.
+ * Sums the per-rank partial  sum_t mll[t,:]  and partial score [P,D] of the task-sharded objective
+ * (random_gp.py:214-219; MAP: GPR_meta_mll.py:109-113) -- the reference is single-process and has no equivalent.
+ * The communicator is an opaque handle owned by the caller: rank 0 calls pacoh_comm_unique_id(), ships the
+ * PACOH_COMM_ID_BYTES bytes to the other ranks out of band (the host package uses its torch.distributed store), then every
+ * rank calls pacoh_comm_init() with the HIP device it computes on current.  RCCL itself is bound at the first call
+ * (dlopen of librccl.so.1, reusing the copy already mapped into the process if there is one), so the library loads on
+ * hosts without RCCL; the comm functions then return PACOH_ENOCOMM.  >0 return = the ncclResult_t RCCL reported. */
+#define PACOH_COMM_ID_BYTES 128
+#define PACOH_ENOCOMM (-5)     /* librccl could not be loaded / symbol missing                   */
+int pacoh_comm_unique_id(void* id_out);
+int pacoh_comm_init(const void* id, int rank, int world, void** comm_out);
+int pacoh_allreduce_sum(void* buf, long count, int dtype, void* comm, void* stream);
+int pacoh_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

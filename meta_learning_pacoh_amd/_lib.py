@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libpacoh_gp.so')
 F32, F64 = 0, 1
 MEAN_ZERO, MEAN_VECTOR, MEAN_CONST = 0, 1, 2
 ERRORS = {-1: 'PACOH_EINVAL (bad argument)', -2: 'PACOH_ELIMIT (shape outside kernel limits)',
-          -3: 'PACOH_EDTYPE', -4: 'PACOH_ELAUNCH (HIP launch failed)'}
+          -3: 'PACOH_EDTYPE', -4: 'PACOH_ELAUNCH (HIP launch failed)', -5: 'PACOH_ENOCOMM (librccl not loadable)'}
+COMM_ID_BYTES = 128
 
 _c = ctypes
 _vp, _i, _l, _d, _sz = _c.c_void_p, _c.c_int, _c.c_long, _c.c_double, _c.c_size_t
@@ -61,6 +62,10 @@ SIGNATURES = {
     'pacoh_vi_grad_full': (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _vp]),
     'pacoh_gather_tasks': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'pacoh_reduce_tasks': (_i, [_vp, _vp, _d, _i, _i, _i, _i, _i, _vp]),
+    'pacoh_comm_unique_id': (_i, [_vp]),
+    'pacoh_comm_init': (_i, [_vp, _i, _i, _c.POINTER(_vp)]),
+    'pacoh_allreduce_sum': (_i, [_vp, _l, _i, _vp, _vp]),
+    'pacoh_comm_destroy': (_i, [_vp]),
 }
 
 _lib = None
@@ -531,3 +536,34 @@ def reduce_tasks(inp, out, scale=1.0, accumulate=False):
         _check(lib.pacoh_reduce_tasks(_ptr(inp), ctypes.c_void_p(out.data_ptr()), float(scale), int(bool(accumulate)),
                                       T, P, W, dtype_code(inp), _stream()), 'pacoh_reduce_tasks')
     return out
+
+
+def comm_unique_id():
+    """PACOH_COMM_ID_BYTES bytes naming a new RCCL communicator (rank 0 calls this and ships them to the other ranks)"""
+    lib = load_library()
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    _check(lib.pacoh_comm_unique_id(buf), 'pacoh_comm_unique_id')
+    return buf.raw
+
+
+def comm_init(uid, rank, world_size):
+    """opaque communicator handle for this rank on the current HIP device"""
+    lib = load_library()
+    if len(uid) != COMM_ID_BYTES:
+        raise ValueError('communicator id must be %d bytes' % COMM_ID_BYTES)
+    handle = ctypes.c_void_p()
+    _check(lib.pacoh_comm_init(ctypes.create_string_buffer(bytes(uid), COMM_ID_BYTES), int(rank), int(world_size),
+                               ctypes.byref(handle)), 'pacoh_comm_init')
+    return handle
+
+
+def allreduce_sum(buf, comm):
+    """buf := sum over ranks of buf, in place, enqueued on the current stream (RCCL)"""
+    lib = load_library()
+    with _Timed('allreduce_sum'):
+        _check(lib.pacoh_allreduce_sum(_ptr(buf), buf.numel(), dtype_code(buf), comm, _stream()), 'pacoh_allreduce_sum')
+    return buf
+
+
+def comm_destroy(comm):
+    _check(load_library().pacoh_comm_destroy(comm), 'pacoh_comm_destroy')

@@ -2,9 +2,19 @@
 (globally drawn, shared-seed) task batch and all P particles; partial sum_t mll[t,:] and partial score
 [P,D] are summed with ONE all-reduce per step -- torch.distributed 'nccl' backend = RCCL over xGMI on
 the GPU box, 'gloo' in the CPU tests.  Nothing else is exchanged; prior term, SVGD kernel and optimizer
-are replicated (deterministic, identical on every rank)."""
+are replicated (deterministic, identical on every rank).
+
+The collective itself is torch.distributed's by default.  PACOH_COMM=rccl (or enable_direct_rccl()) switches the packed-buffer
+reduce to the library's own pacoh_allreduce_sum: the same RCCL all-reduce, enqueued on the stream the kernels run on, so the
+step has no cross-stream event hop; torch.distributed is then only the out-of-band channel for the communicator id."""
+import os
+
 import torch
 import torch.distributed as dist
+
+from . import _lib as L
+
+_direct = None      # RcclComm once enable_direct_rccl() has run
 
 
 def world():
@@ -19,6 +29,47 @@ def shard(indices, rank=None, world_size=None):
     rank = r if rank is None else rank
     world_size = w if world_size is None else world_size
     return indices[rank::world_size]
+
+
+class RcclComm:
+    """pacoh_comm_* handle of this rank (include/pacoh_gp.h, section 8e): created collectively by every rank"""
+
+    def __init__(self):
+        rank, w = world()
+        uid = [L.comm_unique_id() if rank == 0 else None]
+        if w > 1:
+            dist.broadcast_object_list(uid, src=0)
+        self.world_size = w
+        self.handle = L.comm_init(uid[0], rank, w)
+
+    def all_reduce_(self, buf):
+        return L.allreduce_sum(buf, self.handle)
+
+    def close(self):
+        if self.handle is not None:
+            L.comm_destroy(self.handle)
+            self.handle = None
+
+
+def enable_direct_rccl():
+    """collective call (all ranks): route the step's all-reduce through pacoh_allreduce_sum from now on"""
+    global _direct
+    if _direct is None:
+        _direct = RcclComm()
+    return _direct
+
+
+def disable_direct_rccl():
+    global _direct
+    if _direct is not None:
+        _direct.close()
+        _direct = None
+
+
+def _direct_comm():
+    if _direct is None and os.environ.get('PACOH_COMM', '') == 'rccl':
+        enable_direct_rccl()
+    return _direct
 
 
 def packed_score_buffer(P, D, dtype, device):
@@ -36,7 +87,11 @@ def all_reduce_sum_(lik, score, packed=None):
         return lik, score
     P, D = score.shape
     if packed is not None:
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        comm = _direct_comm()
+        if comm is not None:
+            comm.all_reduce_(packed)
+        else:
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM)
         return lik, score
     buf = torch.cat([score.reshape(-1), lik.reshape(-1)])
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)

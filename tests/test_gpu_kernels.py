@@ -501,6 +501,31 @@ def test_gather_tasks(L):
         assert onv2 is None and torch.equal(ox2, ox) and torch.equal(oy2, oy)
 
 
+def test_allreduce_sum_single_rank_communicator(L):
+    """pacoh_comm_* / pacoh_allreduce_sum (RCCL on the launch stream): a one-rank communicator sums to itself, stays ordered with
+    the kernels enqueued around it, and a second communicator can coexist; bad arguments are refused before RCCL is touched"""
+    from meta_learning_pacoh_amd import parallel
+    comm = parallel.RcclComm()
+    assert comm.world_size == 1 and comm.handle.value
+    for dtype in (torch.float32, torch.float64):
+        buf, score, lik = parallel.packed_score_buffer(20, 2534, dtype, DEV)
+        ref = torch.randn(buf.numel(), dtype=dtype, generator=torch.Generator().manual_seed(4)).to(DEV)
+        buf.copy_(ref)
+        L.axpy(buf, ref, 1.0)                       # kernel before, collective, kernel after: one stream, no host sync
+        comm.all_reduce_(buf)
+        L.axpy(buf, ref, -1.0)
+        assert torch.equal(buf, ref)
+        assert torch.equal(score, ref[:20 * 2534].view(20, 2534)) and torch.equal(lik, ref[20 * 2534:])
+    other = parallel.RcclComm()
+    other.all_reduce_(buf)
+    other.close()
+    lib = L.load_library()
+    assert lib.pacoh_allreduce_sum(None, 4, 0, comm.handle, None) == -1
+    assert lib.pacoh_allreduce_sum(buf.data_ptr(), 4, 7, comm.handle, None) == -3
+    assert lib.pacoh_allreduce_sum(buf.data_ptr(), 4, 0, None, None) == -1
+    comm.close()
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
 @pytest.mark.parametrize('optimizer,bandwidth,with_prior', [('Adam', None, True), ('SGD', 0.8, True), ('Adam', 1.7, False)])
 def test_svgd_update_fused(L, dtype, optimizer, bandwidth, with_prior):
