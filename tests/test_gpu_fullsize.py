@@ -116,3 +116,39 @@ def test_cfg5_large_context_256_tasks_n512_d8_fp64_all_tasks_vs_oracle(M):
     # K^-1 y round trip: (K + s2 I) alpha == y
     K2 = L.gram_rbf_ard(X.cuda(), 1, X.cuda(), 1, ls.cuda(), None, noise.cuda(), True, T, 1)
     assert relerr(torch.bmm(K2, alpha.unsqueeze(-1)).squeeze(-1), Y) < 1e-10
+
+
+def test_bench_line_contract():
+    """`python bench.py` (child process) prints ONE JSON line with the driver's keys, BASELINE.json's metric, a live
+    roofline object and a bounded cpu_baseline; value is consistent with ms_per_step."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '2'], cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in d, key
+    base = json.load(open(os.path.join(root, 'BASELINE.json')))
+    assert d['metric'].split(';')[0].strip() in base['metric']
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 2 and d['scaling'] == 'weak' and d['data'] == 'synthetic'
+    assert d['higher_is_better'] is True and d['vs_baseline'] is None and d['dtype'] == 'f32'
+    assert 'workload' in d['config'] and 'model' not in d['config'] and d['config']['finite'] is True
+    evals = d['config']['evals_per_step']
+    assert evals == 1024 * 20
+    assert abs(d['value'] - evals / (d['ms_per_step'] * 1e-3)) <= 1e-3 * d['value']
+    roof = d['roofline']
+    assert roof['bound'] in ('hbm', 'mfma') and roof['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3 and 0 < roof['frac'] < 1
+    gram = d['gram_roofline']
+    assert gram['bound'] == 'hbm' and gram['peak'] == 8000.0 and gram['algorithmic_bytes'] == 16896 * evals
+    assert gram['frac'] >= 0.40                      # BASELINE.json: >= 40 % of the HBM roofline on the Gram build
+    cpu = d['cpu_baseline']
+    assert cpu['kind'] in ('port', 'reference') and cpu['value'] > 0 and cpu['cores'] >= 1 and cpu['sample']
+    assert d['value'] >= 10000                       # BASELINE.json: >= 10 k evals/s on one MI355X

@@ -495,3 +495,33 @@ def test_svgd_120_iterations_track_oracle_on_demo_data(M):
     model.particles.copy_(X.to(model.particles.dtype))
     ll_o, rmse_o, calib_o = model.eval_datasets(test)
     assert abs(ll - ll_o) < 0.03 and abs(rmse - rmse_o) < 0.02 and abs(calib - calib_o) < 0.03
+
+
+def test_more_meta_train_tasks_help_and_meta_beats_single_task(M):
+    """behaviours the reference asserts in tests/test_GPR.py:224-278: meta-learning on 10 tasks generalises better than on 2
+    (test log-likelihood up, RMSE down), and beats GPs fitted per test task from the 5 context points alone"""
+    rs = np.random.RandomState(23)
+    train = [sample_data_nonstationary(rs, 5) for _ in range(10)]
+    test = [sample_data_nonstationary(rs, 55) for _ in range(10)]
+    test = [(x[:5], t[:5], x[5:], t[5:]) for x, t in test]
+    res = {}
+    for k in (2, 10):
+        torch.manual_seed(40)
+        m = M.GPRegressionMetaLearned(train[:k], learning_mode='both', mean_nn_layers=(16, 16), kernel_nn_layers=(16, 16),
+                                      num_iter_fit=3000, covar_module='SE', mean_module='NN', weight_decay=0.0)
+        m.meta_fit(valid_tuples=test, verbose=False)
+        res[k] = m.eval_datasets(test)
+    assert res[10][0] > res[2][0] and res[10][1] < res[2][1]
+
+    torch.manual_seed(60)
+    meta = M.GPRegressionMetaLearned(train, learning_mode='both', mean_nn_layers=(64, 64), covar_module='SE', mean_module='NN',
+                                     weight_decay=0.0, num_iter_fit=1000)
+    meta.meta_fit(valid_tuples=test, verbose=False)
+    ll_meta = meta.eval_datasets(test)[0]
+    ll_single = []
+    for cx, cy, tx, ty in test:
+        g = M.GPRegressionLearned(cx, cy, learning_mode='both', mean_nn_layers=(64, 64), covar_module='SE', mean_module='NN',
+                                  weight_decay=0.0, num_iter_fit=1000)
+        g.fit(valid_x=tx, valid_t=ty, verbose=False)
+        ll_single.append(g.eval(tx, ty)[0])
+    assert ll_meta > float(np.mean(ll_single))
