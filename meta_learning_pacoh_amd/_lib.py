@@ -62,6 +62,9 @@ SIGNATURES = {
     'pacoh_vi_grad_full': (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _vp]),
     'pacoh_gather_tasks': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'pacoh_reduce_tasks': (_i, [_vp, _vp, _d, _i, _i, _i, _i, _i, _vp]),
+    'pacoh_mixture_cdf': (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _i, _i, _vp]),
+    'pacoh_mixture_icdf': (_i, [_vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _i, _i, _i, _i, _i, _vp]),
+    'pacoh_calib_error': (_i, [_vp, _vp, _i, _i, _vp]),
     'pacoh_comm_unique_id': (_i, [_vp]),
     'pacoh_comm_init': (_i, [_vp, _i, _i, _c.POINTER(_vp)]),
     'pacoh_allreduce_sum': (_i, [_vp, _l, _i, _vp, _vp]),
@@ -536,6 +539,46 @@ def reduce_tasks(inp, out, scale=1.0, accumulate=False):
         _check(lib.pacoh_reduce_tasks(_ptr(inp), ctypes.c_void_p(out.data_ptr()), float(scale), int(bool(accumulate)),
                                       T, P, W, dtype_code(inp), _stream()), 'pacoh_reduce_tasks')
     return out
+
+
+def mixture_cdf(mu_n, var_n, value, y_mean, y_std):
+    """cdf[m] of the equal-weight mixture of the P un-normalised Gaussian marginals (mu_n, var_n: [P,m] normalised space)"""
+    lib = load_library()
+    P, m = mu_n.shape
+    value = value.to(mu_n.dtype).flatten().contiguous()
+    if value.numel() != m:
+        raise ValueError('one value per test point expected (%d), got %d' % (m, value.numel()))
+    out = torch.empty(m, dtype=mu_n.dtype, device=mu_n.device)
+    with _Timed('mixture_cdf'):
+        _check(lib.pacoh_mixture_cdf(_ptr(mu_n), _ptr(var_n, mu_n), _ptr(value, mu_n), _ptr(out), float(y_mean), float(y_std), P, m,
+                                     dtype_code(mu_n), _stream()), 'pacoh_mixture_cdf')
+    return out
+
+
+def mixture_icdf(mu_n, var_n, quantile, y_mean, y_std, closed_form=False, lo=-1e8, hi=1e8, eps=1e-6, max_iter=10000):
+    """quantiles[m] of the same marginals: bisection with the reference's stopping rule in one launch, or (closed_form, P == 1)
+    the Gaussian quantile"""
+    lib = load_library()
+    P, m = mu_n.shape
+    quantile = quantile.to(mu_n.dtype).flatten().contiguous()
+    if quantile.numel() != m:
+        raise ValueError('one quantile per test point expected (%d), got %d' % (m, quantile.numel()))
+    out = torch.empty(m, dtype=mu_n.dtype, device=mu_n.device)
+    with _Timed('mixture_icdf'):
+        _check(lib.pacoh_mixture_icdf(_ptr(mu_n), _ptr(var_n, mu_n), _ptr(quantile, mu_n), _ptr(out), float(y_mean), float(y_std),
+                                      float(lo), float(hi), float(eps), int(max_iter), int(bool(closed_form)), P, m,
+                                      dtype_code(mu_n), _stream()), 'pacoh_mixture_icdf')
+    return out
+
+
+def calib_error(cdf_vals):
+    """calibration RMSE over the 20 confidence levels linspace(0.05, 0.95) -> 0-dim tensor"""
+    lib = load_library()
+    cdf_vals = cdf_vals.flatten().contiguous()
+    out = torch.empty(1, dtype=cdf_vals.dtype, device=cdf_vals.device)
+    with _Timed('calib_error'):
+        _check(lib.pacoh_calib_error(_ptr(cdf_vals), _ptr(out), cdf_vals.numel(), dtype_code(cdf_vals), _stream()), 'pacoh_calib_error')
+    return out[0]
 
 
 def comm_unique_id():

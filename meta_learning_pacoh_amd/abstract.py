@@ -3,6 +3,7 @@ Mirrors RegressionModelMetaLearned (meta_learn/abstract.py:117-272) -- host-side
 import numpy as np
 import torch
 
+from . import _lib as L
 from .config import get_device
 from .util import _handle_input_dimensionality, get_logger
 
@@ -101,8 +102,4 @@ class RegressionModelMetaLearned:
 
 def _calib_error(pred_dist, test_t_tensor):
     """abstract.py:260-272 on the vectorised (marginal) predictive"""
-    cdf_vals = pred_dist.cdf(test_t_tensor).flatten()
-    num_points = test_t_tensor.flatten().shape[0]
-    conf_levels = torch.linspace(0.05, 0.95, 20, device=cdf_vals.device)
-    emp_freq_per_conf_level = torch.sum(cdf_vals[:, None] <= conf_levels, dim=0).float() / num_points
-    return torch.sqrt(torch.mean((emp_freq_per_conf_level - conf_levels) ** 2))
+    return L.calib_error(pred_dist.cdf(test_t_tensor))

@@ -9,7 +9,6 @@ import math
 import torch
 
 from . import _lib as L
-from .util import find_root_by_bounding
 
 
 class GaussianPredictive:
@@ -62,15 +61,13 @@ class GaussianPredictive:
         return torch.logsumexp(logp, dim=0, keepdim=True) - math.log(self.num_dists)
 
     def cdf(self, value):
+        """marginal cdf per test point (mixture: mean over components, models.py:124-131)"""
         value = torch.as_tensor(value, dtype=self._mu_n.dtype, device=self._mu_n.device)
-        c = torch.distributions.Normal(self._means, torch.sqrt(self._vars)).cdf(value)
-        return c.mean(0) if self.mixture else c[0]
+        return L.mixture_cdf(self._mu_n.contiguous(), self._var_n.contiguous(), value, self.y_mean, self.y_std)
 
     def icdf(self, quantile):
+        """marginal quantiles per test point: Gaussian closed form for one component, the reference's bisection (models.py:136-140,
+        util.py:9-42) for the mixture -- one kernel launch either way"""
         quantile = torch.as_tensor(quantile, dtype=self._mu_n.dtype, device=self._mu_n.device)
-        if not self.mixture:
-            return torch.distributions.Normal(self._means[0], torch.sqrt(self._vars[0])).icdf(quantile.flatten())
-        q = quantile.flatten()
-        left = -1e8 * torch.ones_like(q)
-        right = 1e8 * torch.ones_like(q)
-        return find_root_by_bounding(lambda x: self.cdf(x) - q, left, right)       # models.py:136-140
+        return L.mixture_icdf(self._mu_n.contiguous(), self._var_n.contiguous(), quantile, self.y_mean, self.y_std,
+                              closed_form=not self.mixture)

@@ -1,10 +1,8 @@
-"""Host-side helpers mirroring meta_learn/util.py (logger, shape handling, LR schedule, bisection)."""
+"""Host-side helpers mirroring meta_learn/util.py (logger, shape handling, LR schedule; the quantile bisection of util.py:9-42 is the HIP kernel behind pacoh_mixture_icdf)."""
 import logging
 import os
-import warnings
 
 import numpy as np
-import torch
 
 
 def _handle_input_dimensionality(x, y=None):
@@ -61,23 +59,3 @@ class StepLR:
         if self.gamma >= 1.0:
             return self.base_lr
         return self.base_lr * self.gamma ** (self.epoch // self.step_size)
-
-
-def find_root_by_bounding(fun, left, right, eps=1e-6, max_iter=1e4):
-    """meta_learn/util.py:9-42: vectorised bisection on a monotone function."""
-    assert callable(fun)
-    n_iter = 0
-    approx_error = 1e12
-    while approx_error > eps:
-        middle = (right + left) / 2
-        f = fun(middle)
-        left_of_zero = (f < 0).flatten()
-        left[left_of_zero] = middle[left_of_zero]
-        right[~left_of_zero] = middle[~left_of_zero]
-        assert torch.all(left <= right).item()
-        approx_error = torch.max(torch.abs(right - left)) / 2
-        n_iter += 1
-        if n_iter > max_iter:
-            warnings.warn('Max_iter has been reached - stopping newton method for determining quantiles')
-            return torch.Tensor([np.nan for _ in range(len(left))])
-    return middle

@@ -19,11 +19,12 @@ Pinning status ("how do we know the oracle equals the reference?"):
     particle kernel, median heuristics, the gradient through the IMQ median bandwidth) and, under
     import shims, ``meta_learn/models.py`` / ``random_gp.py`` (parameter layout, hyper-prior sampling +
     log-prob, vectorised MLP forward, diagonal and full-covariance VI posterior: init stream, rsample,
-    log_prob, autograd gradient) -- fixtures in ``tests/golden/*.npz`` produced by
-    ``tests/golden/make_golden.py``;
+    log_prob, autograd gradient; EqualWeightedMixtureDist / AffineTransformedDistribution cdf and icdf) and
+    ``meta_learn/abstract.py`` (_calib_error), with ``meta_learn/util.py`` (the quantile bisection) underneath
+    -- fixtures in ``tests/golden/*.npz`` produced by ``tests/golden/make_golden.py``;
   * UNPINNED by any recorded reference output (restated from the source only): the SVGD/VI GP
-    flavour end-to-end values (unit outputscale, no noise floor, m~/(m~+T) pre-factor, mixture
-    predictive).  See DESIGN.md "Oracle".
+    flavour end-to-end values (unit outputscale, no noise floor, m~/(m~+T) pre-factor; the mixture
+    predictive's moments, cdf and quantiles ARE pinned, the GP posterior feeding it is not).  See DESIGN.md "Oracle".
 
 All ``file:line`` citations are relative to the reference repository root.
 """
@@ -599,6 +600,37 @@ def eval_metrics(mean_n, cov_n, test_y, y_mean, y_std):
     rmse = torch.sqrt(torch.mean((mean_p.mean(0) - ty) ** 2))
     cdf = torch.distributions.Normal(mean_p, std_p).cdf(ty.unsqueeze(0)).mean(0)  # models.py:124-131
     return float(avg_ll), float(rmse), float(calib_error(cdf))
+
+
+def mixture_cdf(mean_n, var_n, value, y_mean, y_std):
+    """EqualWeightedMixtureDist.cdf (models.py:124-131) of the un-normalised components (AffineTransformedDistribution,
+    models.py:15-43): mean over the P components of Phi((value - (y_mean + y_std mu)) / (y_std sigma)).  mean_n, var_n [P,m]."""
+    y_mean_t, y_std_t = float(np.asarray(y_mean).reshape(-1)[0]), float(np.asarray(y_std).reshape(-1)[0])
+    value = torch.as_tensor(value, dtype=mean_n.dtype).flatten()
+    z = (value.unsqueeze(0) - (mean_n * y_std_t + y_mean_t)) / (torch.sqrt(var_n) * y_std_t)
+    return (0.5 * (1 + torch.erf(z / math.sqrt(2.0)))).mean(0)
+
+
+def mixture_icdf(mean_n, var_n, quantile, y_mean, y_std, lo=-1e8, hi=1e8, eps=1e-6, max_iter=10000):
+    """EqualWeightedMixtureDist.icdf (models.py:136-140): the interval-halving root search of util.py:9-42 on
+    cdf(x) - quantile, every element starting from [lo, hi], stopping when the LARGEST half-width is <= eps and
+    returning the last midpoint (NaN for every element past max_iter).  One Gaussian (P == 1): see gaussian_icdf."""
+    q = torch.as_tensor(quantile, dtype=mean_n.dtype).flatten()
+    left, right = torch.full_like(q, lo), torch.full_like(q, hi)
+    for _ in range(int(max_iter)):          # the reference gives up (NaN) when round max_iter + 1 would be needed
+        mid = (left + right) / 2
+        below = mixture_cdf(mean_n, var_n, mid, y_mean, y_std) - q < 0
+        left, right = torch.where(below, mid, left), torch.where(below, right, mid)
+        if not float((right - left).abs().max()) / 2 > eps:
+            return mid
+    return torch.full_like(q, float('nan'))
+
+
+def gaussian_icdf(mean_n, var_n, quantile, y_mean, y_std):
+    """AffineTransformedDistribution(Normal).icdf (models.py:15-43): y_mean + y_std (mu + sigma sqrt(2) erfinv(2q - 1))"""
+    y_mean_t, y_std_t = float(np.asarray(y_mean).reshape(-1)[0]), float(np.asarray(y_std).reshape(-1)[0])
+    q = torch.as_tensor(quantile, dtype=mean_n.dtype).flatten()
+    return y_mean_t + y_std_t * (mean_n + torch.sqrt(var_n) * math.sqrt(2.0) * torch.erfinv(2 * q - 1))
 
 
 def mixture_mean_std(mean_n, cov_n, y_mean, y_std):

@@ -122,7 +122,42 @@ def make_vi_full():
     np.savez_compressed(os.path.join(OUT, 'vi_full_ref.npz'), **fx)
 
 
+def make_mixture_quantiles():
+    """EqualWeightedMixtureDist.cdf / .icdf (models.py:127-140, bisection of util.py:9-42), the single-Gaussian
+    AffineTransformedDistribution cdf / icdf (models.py:15-43) and _calib_error (abstract.py:260-272) -> mixture_quantiles_ref.npz"""
+    install_shims()
+    sys.path.insert(0, REF)
+    import meta_learn.models as models
+    import meta_learn.abstract as abstract
+    fx = {}
+    gen = torch.Generator().manual_seed(11)
+    P, m = 6, 40
+    mus, sig = torch.randn(P, m, generator=gen) * 0.8 + 1.5, torch.rand(P, m, generator=gen) * 0.6 + 0.05
+    y_mean, y_std = np.array([4.2]), np.array([1.7])
+    base = torch.distributions.Normal(mus, sig)
+    affine = models.AffineTransformedDistribution(base, normalization_mean=y_mean, normalization_std=y_std)
+    mix = models.EqualWeightedMixtureDist(affine, batched=True, num_dists=P)
+    val = torch.randn(m, generator=gen) * 2.0 + 6.5
+    q = torch.rand(m, generator=gen) * 0.98 + 0.01
+    fx['mus'], fx['sig'], fx['y_mean'], fx['y_std'] = mus.numpy(), sig.numpy(), y_mean, y_std
+    fx['val'], fx['q'] = val.numpy(), q.numpy()
+    fx['mix_cdf'] = mix.cdf(val).numpy()
+    fx['mix_icdf'] = mix.icdf(q.clone()).numpy()
+    fx['mix_icdf_05'] = mix.icdf(torch.ones(m) * 0.05).numpy()
+    fx['mix_icdf_95'] = mix.icdf(torch.ones(m) * 0.95).numpy()
+    fx['mix_calib'] = np.array(abstract._calib_error(mix, val).item())
+    single = models.AffineTransformedDistribution(torch.distributions.Normal(mus[0], sig[0]), normalization_mean=y_mean,
+                                                  normalization_std=y_std)
+    fx['single_cdf'] = single.cdf(val).numpy()
+    fx['single_icdf'] = single.icdf(q).numpy()
+    fx['single_calib'] = np.array(abstract._calib_error(single, val).item())
+    np.savez_compressed(os.path.join(OUT, 'mixture_quantiles_ref.npz'), **fx)
+    print('mixture_quantiles_ref.npz written')
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'mixture_quantiles':
+        return make_mixture_quantiles()
     if len(sys.argv) > 1 and sys.argv[1] == 'vi_full':
         return make_vi_full()
     assert os.path.isdir(REF), 'reference not mounted -- fixtures can only be regenerated in the build container'
@@ -289,6 +324,7 @@ def main():
     with open(os.path.join(OUT, 'demo_log.json'), 'w') as f:
         json.dump(demo_log, f, indent=1)
     make_vi_full()
+    make_mixture_quantiles()
     print('fixtures written to', OUT)
 
 

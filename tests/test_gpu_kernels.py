@@ -549,3 +549,83 @@ def test_svgd_update_fused(L, dtype, optimizer, bandwidth, with_prior):
         assert abs(float(bw) - float(bw_o)) < 1e-5 * float(bw_o)
     tol = 2e-4 if dtype == torch.float32 else 1e-10
     assert relerr(Xd, Xo.detach()) < tol
+
+
+# ------------------------------------------------------------------------------------------ predictive cdf / quantiles / calibration
+def test_mixture_cdf_icdf_calib_match_reference_fixture(L, golden_dir):
+    """pacoh_mixture_cdf / _icdf / pacoh_calib_error vs EqualWeightedMixtureDist.cdf / .icdf, AffineTransformedDistribution and
+    _calib_error of the REAL reference (fixture mixture_quantiles_ref.npz)"""
+    fx = np.load(os.path.join(golden_dir, 'mixture_quantiles_ref.npz'))
+    ym, ys = float(fx['y_mean'][0]), float(fx['y_std'][0])
+    for dtype in (torch.float32, torch.float64):
+        mus = torch.from_numpy(fx['mus']).to(dtype).to(DEV)
+        var = (torch.from_numpy(fx['sig']).to(dtype) ** 2).to(DEV)
+        val, q = torch.from_numpy(fx['val']).to(dtype).to(DEV), torch.from_numpy(fx['q']).to(dtype).to(DEV)
+        cdf = L.mixture_cdf(mus, var, val, ym, ys)
+        np.testing.assert_allclose(cdf.cpu().numpy(), fx['mix_cdf'], rtol=2e-5, atol=2e-7)
+        np.testing.assert_allclose(L.mixture_icdf(mus, var, q, ym, ys).cpu().numpy(), fx['mix_icdf'], rtol=0, atol=1e-5)
+        for key, level in (('mix_icdf_05', 0.05), ('mix_icdf_95', 0.95)):
+            x = L.mixture_icdf(mus, var, torch.full((40,), level, dtype=dtype, device=DEV), ym, ys)
+            np.testing.assert_allclose(x.cpu().numpy(), fx[key], rtol=0, atol=1e-5)
+        assert abs(float(L.calib_error(cdf)) - float(fx['mix_calib'])) < 1e-6
+        c1 = L.mixture_cdf(mus[:1].contiguous(), var[:1].contiguous(), val, ym, ys)
+        np.testing.assert_allclose(c1.cpu().numpy(), fx['single_cdf'], rtol=2e-5, atol=2e-7)
+        x1 = L.mixture_icdf(mus[:1].contiguous(), var[:1].contiguous(), q, ym, ys, closed_form=True)
+        np.testing.assert_allclose(x1.cpu().numpy(), fx['single_icdf'], rtol=3e-6)
+        assert abs(float(L.calib_error(c1)) - float(fx['single_calib'])) < 1e-6
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('P,m', [(1, 1), (3, 50), (20, 500), (100, 333), (7, 1500), (64, 2048)])
+def test_mixture_cdf_icdf_calib_match_oracle(L, dtype, P, m):
+    """same three entry points vs the oracle's restatement on random mixtures (all lane-sharing widths of the quantile kernel)"""
+    from oracle import pacoh_oracle as O
+    g = torch.Generator().manual_seed(100 * P + m)
+    mus = torch.randn(P, m, generator=g, dtype=torch.float64) * 0.7
+    var = (torch.rand(P, m, generator=g, dtype=torch.float64) * 0.8 + 0.05) ** 2
+    val = torch.randn(m, generator=g, dtype=torch.float64) * 1.5 + 0.3
+    q = torch.rand(m, generator=g, dtype=torch.float64) * 0.98 + 0.01
+    ym, ys = 0.3, 1.4
+    d = lambda t: t.to(dtype).to(DEV)
+    cdf = L.mixture_cdf(d(mus), d(var), d(val), ym, ys)
+    cdf_o = O.mixture_cdf(mus.to(dtype).double(), var.to(dtype).double(), val.to(dtype).double(), ym, ys)
+    assert float((cdf.double().cpu() - cdf_o).abs().max()) < (3e-6 if dtype == torch.float32 else 1e-13)
+    x = L.mixture_icdf(d(mus), d(var), d(q), ym, ys)
+    x_o = O.mixture_icdf(mus.to(dtype).double(), var.to(dtype).double(), q.to(dtype).double(), ym, ys)
+    assert bool(torch.isfinite(x).all())
+    assert float((x.double().cpu() - x_o).abs().max()) < (2e-5 if dtype == torch.float32 else 2.1e-6)
+    # the quantiles invert the cdf
+    back = L.mixture_cdf(d(mus), d(var), x, ym, ys)
+    assert float((back.double().cpu() - q).abs().max()) < (2e-5 if dtype == torch.float32 else 3e-6)
+    assert abs(float(L.calib_error(cdf)) - float(O.calib_error(cdf.cpu()))) < 1e-6
+    if P == 1:
+        xc = L.mixture_icdf(d(mus), d(var), d(q), ym, ys, closed_form=True)
+        xo = O.gaussian_icdf(mus[0].to(dtype), var[0].to(dtype), q.to(dtype), ym, ys)
+        assert relerr(xc, xo) < (1e-5 if dtype == torch.float32 else 1e-12)
+        assert float((xc - x).abs().max()) < 1e-5
+
+
+def test_mixture_icdf_stopping_rule_and_limits(L):
+    """the reference's search (util.py:9-42) never reaches eps = 1e-6 once one fp32 ulp of the quantile exceeds 2e-6 (|y| >= 32):
+    it then returns NaN for EVERY element after max_iter rounds -- the kernel reports the same outcome (and detects the stall at once);
+    a standard-normal quantile (reference tests/test_utils.py:243-260); argument limits"""
+    from oracle import pacoh_oracle as O
+    mus = torch.zeros(2, 3)
+    var = torch.ones(2, 3)
+    q = torch.tensor([0.3, 0.5, 0.975])
+    x = L.mixture_icdf(mus.to(DEV), var.to(DEV), q.to(DEV), 0.0, 1.0)
+    assert abs(float(x[2]) - 1.959964) < 1e-5 and abs(float(x[1])) < 2e-6
+    far = L.mixture_icdf(mus.to(DEV), var.to(DEV), q.to(DEV), 100.0, 1.0)
+    far_o = O.mixture_icdf(mus, var, q, 100.0, 1.0)
+    assert bool(torch.isnan(far_o).all()) and bool(torch.isnan(far).all())
+    ok64 = L.mixture_icdf(mus.double().to(DEV), var.double().to(DEV), q.double().to(DEV), 100.0, 1.0)
+    assert abs(float(ok64[2]) - 101.959964) < 1e-5
+    few = L.mixture_icdf(mus.to(DEV), var.to(DEV), q.to(DEV), 0.0, 1.0, max_iter=10)         # cannot converge in 10 halvings of 2e8
+    assert bool(torch.isnan(few).all())
+    lib = L.load_library()
+    big = torch.zeros(1, 2049, device=DEV)
+    assert lib.pacoh_mixture_icdf(big.data_ptr(), big.data_ptr(), big.data_ptr(), big.data_ptr(), 0.0, 1.0, -1e8, 1e8, 1e-6, 10000, 0,
+                                  1, 2049, 0, None) == -2
+    assert lib.pacoh_mixture_icdf(big.data_ptr(), big.data_ptr(), big.data_ptr(), big.data_ptr(), 0.0, 1.0, -1e8, 1e8, 1e-6, 10000, 1,
+                                  2, 8, 0, None) == -1
+    assert lib.pacoh_mixture_cdf(big.data_ptr(), big.data_ptr(), big.data_ptr(), big.data_ptr(), 0.0, 0.0, 1, 8, 0, None) == -1

@@ -12,7 +12,7 @@ from meta_learning_pacoh_amd.engine import ParamLayout, TaskBatch
 from meta_learning_pacoh_amd.GPR_meta_svgd import (consume_vectorized_gp_init_rng, harmonic_pre_factor,
                                                    sample_hyper_prior)
 from meta_learning_pacoh_amd.GPR_meta_vi import init_vi_posterior, standard_normal
-from meta_learning_pacoh_amd.util import StepLR, _handle_input_dimensionality, find_root_by_bounding
+from meta_learning_pacoh_amd.util import StepLR, _handle_input_dimensionality
 from oracle import pacoh_oracle as O
 
 CASES = {
@@ -79,10 +79,6 @@ def test_prefactor_steplr_and_shapes(golden_dir):
     assert StepLR(1e-3, 1000, 1.0).lr == 1e-3
     x, y = _handle_input_dimensionality(np.zeros(5), np.zeros(5))
     assert x.shape == (5, 1) and y.shape == (5, 1)
-    # quantiles by bisection (reference tests/test_utils.py:243-260)
-    q = find_root_by_bounding(lambda v: torch.distributions.Normal(0., 1.).cdf(v) - 0.975,
-                              -1e3 * torch.ones(3), 1e3 * torch.ones(3))
-    assert float((q - 1.959964).abs().max()) < 1e-4
 
 
 def test_task_batch_packing_and_sharding():

@@ -100,6 +100,24 @@ def test_mixture_mean_std_cdf(golden_dir):
     np.testing.assert_allclose(cdf.numpy(), fx['mix_cdf'], rtol=1e-6)
 
 
+def test_mixture_cdf_icdf_and_calibration(golden_dir):
+    """oracle cdf / bisection quantiles / calibration error vs EqualWeightedMixtureDist, AffineTransformedDistribution and
+    _calib_error of the reference (fixture made by make_golden.py mixture_quantiles from the real classes)"""
+    fx = _load(golden_dir, 'mixture_quantiles_ref.npz')
+    for dt, tol in ((torch.float32, 1e-5), (torch.float64, 1e-5)):          # the reference bisects to 1e-6 on an fp32 cdf (a few ulp at y ~ 8)
+        mus, var = torch.from_numpy(fx['mus']).to(dt), torch.from_numpy(fx['sig']).to(dt) ** 2
+        cdf = O.mixture_cdf(mus, var, fx['val'], fx['y_mean'], fx['y_std'])
+        np.testing.assert_allclose(cdf.numpy(), fx['mix_cdf'], rtol=2e-5, atol=2e-7)
+        for key, q in (('mix_icdf', fx['q']), ('mix_icdf_05', np.full(40, 0.05, np.float32)), ('mix_icdf_95', np.full(40, 0.95, np.float32))):
+            x = O.mixture_icdf(mus, var, q, fx['y_mean'], fx['y_std'])
+            np.testing.assert_allclose(x.numpy(), fx[key], rtol=0, atol=tol)
+        assert abs(float(O.calib_error(cdf)) - float(fx['mix_calib'])) < 1e-6
+        c1 = O.mixture_cdf(mus[:1], var[:1], fx['val'], fx['y_mean'], fx['y_std'])
+        np.testing.assert_allclose(c1.numpy(), fx['single_cdf'], rtol=2e-5, atol=2e-7)
+        np.testing.assert_allclose(O.gaussian_icdf(mus[0], var[0], fx['q'], fx['y_mean'], fx['y_std']).numpy(), fx['single_icdf'], rtol=2e-6)
+        assert abs(float(O.calib_error(c1)) - float(fx['single_calib'])) < 1e-6
+
+
 def test_sinusoid_dataset_and_task_sampling(golden_dir):
     fx = _load(golden_dir, 'sinusoid_demo_data.npz')
     env = O.SinusoidDataset(np.random.RandomState(26))
