@@ -284,7 +284,8 @@ int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, 
  * The predictive is a mixture of P Gaussians over m test points held in normalised space, mu[P,m], var[P,m] (P = particles /
  * posterior samples; P = 1: the single MAP Gaussian); y = y_mean + y_std * y_n is applied on the fly
  * (AffineTransformedDistribution, meta_learn/models.py:15-43).
- *   pacoh_mixture_cdf:  cdf[j] = mean_p Phi((value[j] - (y_mean + y_std mu[p,j])) / (y_std sqrt(var[p,j])))
+ *   pacoh_mixture_cdf:  cdf[t,j] = mean_p Phi((value[t,j] - (y_mean + y_std mu[t,p,j])) / (y_std sqrt(var[t,p,j]))) for a batch of T
+ *                       test tasks (mu, var [T,P,m] = the [T*P, m] output of pacoh_gp_predict; value, cdf [T,m]; T <= 65535)
  *                       EqualWeightedMixtureDist.cdf (models.py:124-131); used by _calib_error (abstract.py:260-272).
  *   pacoh_mixture_icdf: out[j] = the quantile[j]-quantile of that marginal.  closed_form = 0: the interval-halving search of
  *                       find_root_by_bounding (meta_learn/util.py:9-42) as called by EqualWeightedMixtureDist.icdf
@@ -292,13 +293,15 @@ int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, 
  *                       (all elements halved together until the largest half-width <= eps; more than max_iter rounds -> NaN for
  *                       every element), in ONE launch; m <= PACOH_MAX_QUANTILES.  closed_form = 1 (P must be 1): the Gaussian
  *                       quantile y_mean + y_std (mu + sigma sqrt(2) erfinv(2q - 1)) of TransformedDistribution.icdf.
- *   pacoh_calib_error:  out[0] = sqrt(mean_k (#{j: cdf[j] <= c_k} / m - c_k)^2), c = linspace(0.05, 0.95, 20) (abstract.py:260-272). */
+ *   pacoh_calib_error:  out[t] = sqrt(mean_k (#{j: cdf[t,j] <= c_k} / m - c_k)^2), c = linspace(0.05, 0.95, 20) (abstract.py:260-272);
+ *                       one launch for the T test tasks of eval_datasets (abstract.py:165-181).
+ * pacoh_mixture_icdf takes ONE task (mu, var [P,m]). */
 #define PACOH_MAX_QUANTILES 2048
-int pacoh_mixture_cdf(const void* mu, const void* var, const void* value, void* cdf, double y_mean, double y_std, int P, int m,
-                      int dtype, void* stream);
+int pacoh_mixture_cdf(const void* mu, const void* var, const void* value, void* cdf, double y_mean, double y_std, int T, int P,
+                      int m, int dtype, void* stream);
 int pacoh_mixture_icdf(const void* mu, const void* var, const void* quantile, void* out, double y_mean, double y_std, double lo,
                        double hi, double eps, int max_iter, int closed_form, int P, int m, int dtype, void* stream);
-int pacoh_calib_error(const void* cdf, void* out, int m, int dtype, void* stream);
+int pacoh_calib_error(const void* cdf, void* out, int T, int m, int dtype, void* stream);
 
 /* ---- 8e: the step's one exchange ----------------------------------------------------------------------------------
  * buf[0..count) := sum over ranks of buf (in place), enqueued on the caller's stream: RCCL ncclAllReduce(ncclSum) over xGMI.

@@ -248,6 +248,9 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
             return dist
         return dist.mean.cpu().numpy(), dist.stddev.cpu().numpy()
 
+    def _eval_params(self, **kwargs):
+        return (self.theta, False) if not kwargs else None
+
     # ------------------------------------------------------------------------------------------
     def state_dict(self):
         """same dict layout as the reference ({'optimizer', 'model'}, GPR_meta_mll.py:192-205)"""

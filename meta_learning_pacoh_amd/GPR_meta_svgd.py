@@ -194,6 +194,9 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         """GPR_meta_svgd.py:123-159: equal-weighted mixture over the particles' GP posteriors"""
         return self._mixture_predict(self.particles, context_x, context_y, test_x, return_density)
 
+    def _eval_params(self, **kwargs):
+        return (self.particles, True) if not kwargs else None
+
     def state_dict(self):
         return {'particles': self.particles.cpu().clone(), 'exp_avg': self.exp_avg.cpu().clone(),
                 'exp_avg_sq': self.exp_avg_sq.cpu().clone(), 'step': self.opt_step, 'epoch': self.lr_scheduler.epoch}

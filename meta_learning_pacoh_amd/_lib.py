@@ -62,9 +62,9 @@ SIGNATURES = {
     'pacoh_vi_grad_full': (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _vp]),
     'pacoh_gather_tasks': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'pacoh_reduce_tasks': (_i, [_vp, _vp, _d, _i, _i, _i, _i, _i, _vp]),
-    'pacoh_mixture_cdf': (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _i, _i, _vp]),
+    'pacoh_mixture_cdf': (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _i, _i, _i, _vp]),
     'pacoh_mixture_icdf': (_i, [_vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _i, _i, _i, _i, _i, _vp]),
-    'pacoh_calib_error': (_i, [_vp, _vp, _i, _i, _vp]),
+    'pacoh_calib_error': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'pacoh_comm_unique_id': (_i, [_vp]),
     'pacoh_comm_init': (_i, [_vp, _i, _i, _c.POINTER(_vp)]),
     'pacoh_allreduce_sum': (_i, [_vp, _l, _i, _vp, _vp]),
@@ -542,17 +542,17 @@ def reduce_tasks(inp, out, scale=1.0, accumulate=False):
 
 
 def mixture_cdf(mu_n, var_n, value, y_mean, y_std):
-    """cdf[m] of the equal-weight mixture of the P un-normalised Gaussian marginals (mu_n, var_n: [P,m] normalised space)"""
+    """cdf of the equal-weight mixture of the P un-normalised Gaussian marginals per test point.  One task: mu_n, var_n [P,m]
+    (normalised space), value [m] -> [m]; a batch of tasks: [T,P,m], value [T,m] -> [T,m]"""
     lib = load_library()
-    P, m = mu_n.shape
-    value = value.to(mu_n.dtype).flatten().contiguous()
-    if value.numel() != m:
-        raise ValueError('one value per test point expected (%d), got %d' % (m, value.numel()))
-    out = torch.empty(m, dtype=mu_n.dtype, device=mu_n.device)
+    batched = mu_n.dim() == 3
+    T, (P, m) = (mu_n.shape[0] if batched else 1), mu_n.shape[-2:]
+    value = value.to(mu_n.dtype).reshape(T, m).contiguous()
+    out = torch.empty(T, m, dtype=mu_n.dtype, device=mu_n.device)
     with _Timed('mixture_cdf'):
-        _check(lib.pacoh_mixture_cdf(_ptr(mu_n), _ptr(var_n, mu_n), _ptr(value, mu_n), _ptr(out), float(y_mean), float(y_std), P, m,
+        _check(lib.pacoh_mixture_cdf(_ptr(mu_n), _ptr(var_n, mu_n), _ptr(value, mu_n), _ptr(out), float(y_mean), float(y_std), T, P, m,
                                      dtype_code(mu_n), _stream()), 'pacoh_mixture_cdf')
-    return out
+    return out if batched else out[0]
 
 
 def mixture_icdf(mu_n, var_n, quantile, y_mean, y_std, closed_form=False, lo=-1e8, hi=1e8, eps=1e-6, max_iter=10000):
@@ -572,13 +572,15 @@ def mixture_icdf(mu_n, var_n, quantile, y_mean, y_std, closed_form=False, lo=-1e
 
 
 def calib_error(cdf_vals):
-    """calibration RMSE over the 20 confidence levels linspace(0.05, 0.95) -> 0-dim tensor"""
+    """calibration RMSE over the 20 confidence levels linspace(0.05, 0.95): cdf_vals [m] -> 0-dim tensor, [T,m] -> [T]"""
     lib = load_library()
-    cdf_vals = cdf_vals.flatten().contiguous()
-    out = torch.empty(1, dtype=cdf_vals.dtype, device=cdf_vals.device)
+    batched = cdf_vals.dim() == 2
+    cdf_vals = cdf_vals.reshape(cdf_vals.shape[0] if batched else 1, -1).contiguous()
+    T, m = cdf_vals.shape
+    out = torch.empty(T, dtype=cdf_vals.dtype, device=cdf_vals.device)
     with _Timed('calib_error'):
-        _check(lib.pacoh_calib_error(_ptr(cdf_vals), _ptr(out), cdf_vals.numel(), dtype_code(cdf_vals), _stream()), 'pacoh_calib_error')
-    return out[0]
+        _check(lib.pacoh_calib_error(_ptr(cdf_vals), _ptr(out), T, m, dtype_code(cdf_vals), _stream()), 'pacoh_calib_error')
+    return out if batched else out[0]
 
 
 def comm_unique_id():

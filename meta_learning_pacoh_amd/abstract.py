@@ -1,11 +1,16 @@
 """Base class of the meta-learners: seeding, normalisation, evaluation metrics, confidence intervals.
 Mirrors RegressionModelMetaLearned (meta_learn/abstract.py:117-272) -- host-side plumbing only."""
+import math
+
 import numpy as np
 import torch
 
 from . import _lib as L
 from .config import get_device
 from .util import _handle_input_dimensionality, get_logger
+
+
+EVAL_COV_BYTES = 1 << 30       # predictive covariances held at once by eval_datasets
 
 
 class RegressionModelMetaLearned:
@@ -38,10 +43,54 @@ class RegressionModelMetaLearned:
         return avg_log_likelihood.cpu().item(), rmse.cpu().item(), calibr_error.cpu().item()
 
     def eval_datasets(self, test_tuples, flatten_y=True, **kwargs):
-        """abstract.py:165-181"""
+        """abstract.py:165-181: mean over the test tasks of eval()'s three metrics.  Learners whose predictive parameters do not
+        depend on the call (_eval_params: MAP -> the parameter row, SVGD -> the particles) evaluate all test tasks of equal shape
+        in ONE batched pass over T*P posterior GPs (this runs every log_period inside meta_fit); others loop over eval()."""
         assert (all([len(valid_tuple) == 4 for valid_tuple in test_tuples]))
-        ll_list, rmse_list, calibr_err_list = list(zip(*[self.eval(*t, flatten_y=flatten_y, **kwargs) for t in test_tuples]))
-        return np.mean(ll_list), np.mean(rmse_list), np.mean(calibr_err_list)
+        params = self._eval_params(**kwargs) if flatten_y else None
+        if params is None:
+            ll_list, rmse_list, calibr_err_list = list(zip(*[self.eval(*t, flatten_y=flatten_y, **kwargs) for t in test_tuples]))
+            return np.mean(ll_list), np.mean(rmse_list), np.mean(calibr_err_list)
+        theta, mixture = params
+        tuples, groups = [], {}
+        for i, (cx, cy, tx, ty) in enumerate(test_tuples):
+            cx, cy = _handle_input_dimensionality(cx, cy)
+            tx, ty = _handle_input_dimensionality(tx, ty)
+            assert tx.shape[1] == cx.shape[1]
+            tuples.append((cx, cy, tx, ty))
+            groups.setdefault((cx.shape[0], tx.shape[0]), []).append(i)
+        metrics = np.empty((len(tuples), 3), dtype=np.float64)
+        for (_, m), members in groups.items():
+            per_pass = max(1, int(EVAL_COV_BYTES // (theta.shape[0] * m * m * 4)))        # bound the [T*P, m, m] covariances
+            for lo in range(0, len(members), per_pass):
+                ids = members[lo:lo + per_pass]
+                metrics[ids] = self._eval_tasks(theta, mixture, [tuples[i] for i in ids])
+        return np.mean(metrics[:, 0]), np.mean(metrics[:, 1]), np.mean(metrics[:, 2])
+
+    def _eval_params(self, **kwargs):
+        """(theta[P,D], mixture) if predict() uses the same parameters for every task, else None"""
+        return None
+
+    def _eval_tasks(self, theta, mixture, tuples):
+        """eval() of T equally shaped test tasks in one pass -> float64 [T, 3] (avg joint log-likelihood, rmse, calibration error)"""
+        T, P = len(tuples), theta.shape[0]
+        ctx = [self._prepare_data_per_task(cx, cy) for cx, cy, _, _ in tuples]
+        cx = self._to_device(np.stack([c[0] for c in ctx]))
+        cy = self._to_device(np.stack([c[1] for c in ctx]))
+        tx = self._to_device(np.stack([self._normalize_data(X=t[2], Y=None).astype(np.float32) for t in tuples]))
+        ty = torch.from_numpy(np.stack([t[3].flatten() for t in tuples])).float().to(self.dtype).to(self.device)      # [T,m]
+        m = ty.shape[1]
+        mu, var, cov, _ = self.engine.predict_tasks(theta, cx, cy, tx, want_cov=True)
+        y_mean, y_std = float(self.y_mean.reshape(-1)[0]), float(self.y_std.reshape(-1)[0])
+        mu3, var3 = mu.view(T, P, m), var.view(T, P, m)
+        resid = ((ty - y_mean) / y_std).unsqueeze(1) - mu3
+        logp, _, _ = L.mvn_logprob_dense(cov, resid.reshape(T * P, m).contiguous(), 1.0)         # cov is consumed
+        logp = logp.view(T, P) - m * math.log(y_std)
+        ll = torch.logsumexp(logp, dim=1) - math.log(P) if mixture else logp[:, 0]
+        mean = (mu3 * y_std + y_mean).mean(1) if mixture else mu3[:, 0] * y_std + y_mean
+        rmse = torch.mean(torch.pow(mean - ty, 2), dim=1).sqrt()
+        calib = L.calib_error(L.mixture_cdf(mu3, var3, ty, y_mean, y_std))
+        return torch.stack([ll / m, rmse, calib], dim=1).double().cpu().numpy()
 
     def confidence_intervals(self, context_x, context_y, test_x, confidence=0.9, **kwargs):
         """abstract.py:183-204 -> (ucb, lcb)"""

@@ -36,7 +36,8 @@ __global__ void mixture_cdf_kernel(const T* __restrict__ mu, const T* __restrict
                                    T ym, T ys, int P, int m) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
-    out[j] = cdf_partial(mu, var, P, m, j, value[j], ym, ys, 0, 1) / T(P);
+    const long t = blockIdx.y;                                  // task of the batch: mu[t,P,m], value[t,m]
+    out[t * m + j] = cdf_partial(mu + t * P * m, var + t * P * m, P, m, j, value[t * m + j], ym, ys, 0, 1) / T(P);
 }
 
 template <typename T>
@@ -108,12 +109,14 @@ __global__ void __launch_bounds__(ICDF_THREADS) mixture_icdf_kernel(const T* __r
     }
 }
 
-// out[0] = sqrt(mean_k (#{j: cdf[j] <= level_k} / m - level_k)^2), level = linspace(0.05, 0.95, 20) in fp32 as torch builds it
+// per task t of the batch: out[t] = sqrt(mean_k (#{j: cdf[j] <= level_k} / m - level_k)^2), level = linspace(0.05, 0.95, 20) in fp32 as torch builds it
 template <typename T>
 __global__ void __launch_bounds__(256) calib_error_kernel(const T* __restrict__ cdf, T* __restrict__ out, int m) {
     constexpr int NL = 20;
     __shared__ int count[NL];
     const int tid = threadIdx.x;
+    cdf += (long)blockIdx.x * m;                                // one workgroup per task of the batch
+    out += blockIdx.x;
     if (tid < NL) count[tid] = 0;
     __syncthreads();
     const float step = (0.95f - 0.05f) / float(NL - 1);
@@ -150,16 +153,16 @@ __global__ void __launch_bounds__(256) calib_error_kernel(const T* __restrict__ 
 
 using namespace pacoh;
 
-extern "C" int pacoh_mixture_cdf(const void* mu, const void* var, const void* value, void* cdf, double y_mean, double y_std, int P, int m,
-                                 int dtype, void* stream) {
+extern "C" int pacoh_mixture_cdf(const void* mu, const void* var, const void* value, void* cdf, double y_mean, double y_std, int T, int P,
+                                 int m, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
-    if (!mu || !var || !value || !cdf || P <= 0 || m <= 0 || !(y_std > 0)) return PACOH_EINVAL;
-    const unsigned blocks = (unsigned)((m + 63) / 64);
+    if (!mu || !var || !value || !cdf || T <= 0 || T > 65535 || P <= 0 || m <= 0 || !(y_std > 0)) return PACOH_EINVAL;
+    const dim3 blocks((unsigned)((m + 63) / 64), (unsigned)T);
     if (dtype == PACOH_F32)
-        hipLaunchKernelGGL(mixture_cdf_kernel<float>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, (const float*)mu, (const float*)var,
+        hipLaunchKernelGGL(mixture_cdf_kernel<float>, blocks, dim3(64), 0, (hipStream_t)stream, (const float*)mu, (const float*)var,
                            (const float*)value, (float*)cdf, (float)y_mean, (float)y_std, P, m);
     else
-        hipLaunchKernelGGL(mixture_cdf_kernel<double>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, (const double*)mu, (const double*)var,
+        hipLaunchKernelGGL(mixture_cdf_kernel<double>, blocks, dim3(64), 0, (hipStream_t)stream, (const double*)mu, (const double*)var,
                            (const double*)value, (double*)cdf, y_mean, y_std, P, m);
     return launch_status();
 }
@@ -194,12 +197,12 @@ extern "C" int pacoh_mixture_icdf(const void* mu, const void* var, const void* q
     return launch_status();
 }
 
-extern "C" int pacoh_calib_error(const void* cdf, void* out, int m, int dtype, void* stream) {
+extern "C" int pacoh_calib_error(const void* cdf, void* out, int T, int m, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
-    if (!cdf || !out || m <= 0) return PACOH_EINVAL;
+    if (!cdf || !out || T <= 0 || m <= 0) return PACOH_EINVAL;
     if (dtype == PACOH_F32)
-        hipLaunchKernelGGL(calib_error_kernel<float>, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)cdf, (float*)out, m);
+        hipLaunchKernelGGL(calib_error_kernel<float>, dim3(T), dim3(256), 0, (hipStream_t)stream, (const float*)cdf, (float*)out, m);
     else
-        hipLaunchKernelGGL(calib_error_kernel<double>, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)cdf, (double*)out, m);
+        hipLaunchKernelGGL(calib_error_kernel<double>, dim3(T), dim3(256), 0, (hipStream_t)stream, (const double*)cdf, (double*)out, m);
     return launch_status();
 }

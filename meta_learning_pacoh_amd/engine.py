@@ -226,12 +226,15 @@ class GPEngine:
     def predict(self, theta, ctx_x, ctx_y, tst_x, want_cov=False):
         """exact posterior predictive of ONE task for every particle: mu[P,m], var[P,m], cov[P,m,m]|None
         (normalised space, observation noise included)."""
-        lay = self.layout
-        P, D = theta.shape
-        n, m = ctx_x.shape[0], tst_x.shape[0]
+        return self.predict_tasks(theta, ctx_x.unsqueeze(0), ctx_y.reshape(1, -1), tst_x.unsqueeze(0), want_cov=want_cov)
+
+    def predict_tasks(self, theta, ctx_x, ctx_y, tst_x, want_cov=False):
+        """the same for T tasks of equal shape in one pass: ctx_x[T,n,d], ctx_y[T,n], tst_x[T,m,d] ->
+        mu[T*P,m], var[T*P,m], cov[T*P,m,m]|None, info[T*P]; problem b = t*P + p"""
+        P = theta.shape[0]
+        T, n = ctx_x.shape[0], ctx_x.shape[1]
+        m = tst_x.shape[1]
         ls, os_, noise = self._hypers(theta)
-        xc, xt = ctx_x.unsqueeze(0).contiguous(), tst_x.unsqueeze(0).contiguous()
-        zc, zc_div, mc, mode = self._features(theta, xc, 1, n)
-        zt, zt_div, mt, _ = self._features(theta, xt, 1, m)
-        y = ctx_y.reshape(1, n).contiguous()
-        return L.gp_predict(zc, zc_div, mc, mode, y, P, zt, zt_div, mt, ls, os_, noise, P, P, want_cov=want_cov)
+        zc, zc_div, mc, mode = self._features(theta, ctx_x.contiguous(), T, n)
+        zt, zt_div, mt, _ = self._features(theta, tst_x.contiguous(), T, m)
+        return L.gp_predict(zc, zc_div, mc, mode, ctx_y.contiguous(), P, zt, zt_div, mt, ls, os_, noise, T * P, P, want_cov=want_cov)

@@ -628,4 +628,4 @@ def test_mixture_icdf_stopping_rule_and_limits(L):
                                   1, 2049, 0, None) == -2
     assert lib.pacoh_mixture_icdf(big.data_ptr(), big.data_ptr(), big.data_ptr(), big.data_ptr(), 0.0, 1.0, -1e8, 1e8, 1e-6, 10000, 1,
                                   2, 8, 0, None) == -1
-    assert lib.pacoh_mixture_cdf(big.data_ptr(), big.data_ptr(), big.data_ptr(), big.data_ptr(), 0.0, 0.0, 1, 8, 0, None) == -1
+    assert lib.pacoh_mixture_cdf(big.data_ptr(), big.data_ptr(), big.data_ptr(), big.data_ptr(), 0.0, 0.0, 1, 1, 8, 0, None) == -1

@@ -525,3 +525,33 @@ def test_more_meta_train_tasks_help_and_meta_beats_single_task(M):
         g.fit(valid_x=tx, valid_t=ty, verbose=False)
         ll_single.append(g.eval(tx, ty)[0])
     assert ll_meta > float(np.mean(ll_single))
+
+
+def test_eval_datasets_batched_equals_per_task_eval(M):
+    """eval_datasets (abstract.py:165-181) runs all equally shaped test tasks in one batched pass for MAP and SVGD: same numbers as
+    the reference's loop over eval(), also with test tasks of mixed shapes and when the covariance budget forces several passes"""
+    import meta_learning_pacoh_amd.abstract as A
+    train, test = demo_data()
+    env = O.SinusoidDataset(np.random.RandomState(3))
+    odd = env.generate_meta_test_data(3, 8, 30) + env.generate_meta_test_data(2, 5, 30)
+    mixed = test + odd
+    models = [M.GPRegressionMetaLearned(train, num_iter_fit=30, random_seed=4),
+              M.GPRegressionMetaLearned(train, num_iter_fit=30, mean_module='constant', covar_module='SE', random_seed=4),
+              M.GPRegressionMetaLearnedSVGD(train, num_iter_fit=10, num_particles=6, random_seed=4)]
+    for model in models:
+        model.meta_fit(verbose=False)
+        for tuples in (test, mixed):
+            loop = np.array([model.eval(*t) for t in tuples]).mean(0)
+            batched = np.array(model.eval_datasets(tuples))
+            assert np.all(np.isfinite(batched))
+            np.testing.assert_allclose(batched, loop, rtol=2e-5, atol=2e-6)
+        budget, A.EVAL_COV_BYTES = A.EVAL_COV_BYTES, 7 * model._eval_params()[0].shape[0] * 50 * 50 * 4      # 7 tasks per pass
+        try:
+            np.testing.assert_allclose(np.array(model.eval_datasets(test)), np.array([model.eval(*t) for t in test]).mean(0),
+                                       rtol=2e-5, atol=2e-6)
+        finally:
+            A.EVAL_COV_BYTES = budget
+    vi = M.GPRegressionMetaLearnedVI(train, num_iter_fit=5, svi_batch_size=3, random_seed=4)
+    vi.meta_fit(verbose=False)
+    assert vi._eval_params() is None                       # posterior samples are drawn per predict() call: the per-task loop stays
+    assert np.all(np.isfinite(vi.eval_datasets(test[:3], n_posterior_samples=5)))
