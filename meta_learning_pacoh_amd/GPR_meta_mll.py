@@ -249,7 +249,7 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         return dist.mean.cpu().numpy(), dist.stddev.cpu().numpy()
 
     def _eval_params(self, **kwargs):
-        return (self.theta, False) if not kwargs else None
+        return (self.theta, False, False) if not kwargs else None
 
     # ------------------------------------------------------------------------------------------
     def state_dict(self):

@@ -195,7 +195,7 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         return self._mixture_predict(self.particles, context_x, context_y, test_x, return_density)
 
     def _eval_params(self, **kwargs):
-        return (self.particles, True) if not kwargs else None
+        return (self.particles, True, False) if not kwargs else None
 
     def state_dict(self):
         return {'particles': self.particles.cpu().clone(), 'exp_avg': self.exp_avg.cpu().clone(),

@@ -134,6 +134,21 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         theta = self.loc.reshape(1, -1).contiguous()
         return self._mixture_predict(theta, context_x, context_y, test_x, return_density, mixture=False)
 
+    def _eval_params(self, n_posterior_samples=100, mode='Bayes', **kwargs):
+        """eval_datasets in one batched pass: predict() draws n_posterior_samples fresh parameter rows per call, so T tasks need
+        T draws from the torch CPU generator in task order (the reference's stream) -- one sampling launch over all T*n rows"""
+        if kwargs:
+            return None
+        assert mode in ['bayes', 'Bayes', 'MAP', 'map']
+        if mode in ('MAP', 'map'):
+            return self.loc.reshape(1, -1).contiguous(), False, False
+
+        def draw(T):
+            eps = torch.cat([standard_normal(n_posterior_samples, self.layout.D) for _ in range(T)])
+            theta, _ = L.vi_sample(self.posterior, eps.to(self.dtype).to(self.device), full=self.cov_type == 'full')
+            return theta
+        return draw, True, True
+
     def state_dict(self):
         return {'posterior': self.posterior.cpu().clone(), 'exp_avg': self.exp_avg.cpu().clone(),
                 'exp_avg_sq': self.exp_avg_sq.cpu().clone(), 'step': self.opt_step, 'epoch': self.lr_scheduler.epoch}

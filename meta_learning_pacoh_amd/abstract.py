@@ -44,14 +44,15 @@ class RegressionModelMetaLearned:
 
     def eval_datasets(self, test_tuples, flatten_y=True, **kwargs):
         """abstract.py:165-181: mean over the test tasks of eval()'s three metrics.  Learners whose predictive parameters do not
-        depend on the call (_eval_params: MAP -> the parameter row, SVGD -> the particles) evaluate all test tasks of equal shape
-        in ONE batched pass over T*P posterior GPs (this runs every log_period inside meta_fit); others loop over eval()."""
+        depend on the task (_eval_params: MAP -> the parameter row, SVGD -> the particles, VI -> posterior samples drawn per task in
+        task order) evaluate all test tasks of equal shape in ONE batched pass over T*P posterior GPs (this runs every log_period
+        inside meta_fit); others loop over eval()."""
         assert (all([len(valid_tuple) == 4 for valid_tuple in test_tuples]))
         params = self._eval_params(**kwargs) if flatten_y else None
         if params is None:
             ll_list, rmse_list, calibr_err_list = list(zip(*[self.eval(*t, flatten_y=flatten_y, **kwargs) for t in test_tuples]))
             return np.mean(ll_list), np.mean(rmse_list), np.mean(calibr_err_list)
-        theta, mixture = params
+        theta, mixture, per_task = params
         tuples, groups = [], {}
         for i, (cx, cy, tx, ty) in enumerate(test_tuples):
             cx, cy = _handle_input_dimensionality(cx, cy)
@@ -59,28 +60,37 @@ class RegressionModelMetaLearned:
             assert tx.shape[1] == cx.shape[1]
             tuples.append((cx, cy, tx, ty))
             groups.setdefault((cx.shape[0], tx.shape[0]), []).append(i)
+        if per_task:                                      # a callable: T*P parameter rows, P fresh ones per task, drawn in task order
+            theta = theta(len(tuples))
+            P = theta.shape[0] // len(tuples)
+            theta = theta.view(len(tuples), P, -1)
+        else:
+            P = theta.shape[0]
         metrics = np.empty((len(tuples), 3), dtype=np.float64)
         for (_, m), members in groups.items():
-            per_pass = max(1, int(EVAL_COV_BYTES // (theta.shape[0] * m * m * 4)))        # bound the [T*P, m, m] covariances
+            per_pass = max(1, int(EVAL_COV_BYTES // (P * m * m * 4)))        # bound the [T*P, m, m] covariances
             for lo in range(0, len(members), per_pass):
                 ids = members[lo:lo + per_pass]
-                metrics[ids] = self._eval_tasks(theta, mixture, [tuples[i] for i in ids])
+                rows = theta[ids].reshape(len(ids) * P, -1) if per_task else theta
+                metrics[ids] = self._eval_tasks(rows, mixture, [tuples[i] for i in ids], per_task)
         return np.mean(metrics[:, 0]), np.mean(metrics[:, 1]), np.mean(metrics[:, 2])
 
     def _eval_params(self, **kwargs):
-        """(theta[P,D], mixture) if predict() uses the same parameters for every task, else None"""
+        """what predict(**kwargs) conditions on, for the batched pass: (theta[P,D], mixture, False) when every task uses the same
+        parameter rows; (callable T -> theta[T*P,D], mixture, True) when each predict() call draws its own; None = loop over eval()"""
         return None
 
-    def _eval_tasks(self, theta, mixture, tuples):
+    def _eval_tasks(self, theta, mixture, tuples, per_task=False):
         """eval() of T equally shaped test tasks in one pass -> float64 [T, 3] (avg joint log-likelihood, rmse, calibration error)"""
-        T, P = len(tuples), theta.shape[0]
+        T = len(tuples)
+        P = theta.shape[0] // T if per_task else theta.shape[0]
         ctx = [self._prepare_data_per_task(cx, cy) for cx, cy, _, _ in tuples]
         cx = self._to_device(np.stack([c[0] for c in ctx]))
         cy = self._to_device(np.stack([c[1] for c in ctx]))
         tx = self._to_device(np.stack([self._normalize_data(X=t[2], Y=None).astype(np.float32) for t in tuples]))
         ty = torch.from_numpy(np.stack([t[3].flatten() for t in tuples])).float().to(self.dtype).to(self.device)      # [T,m]
         m = ty.shape[1]
-        mu, var, cov, _ = self.engine.predict_tasks(theta, cx, cy, tx, want_cov=True)
+        mu, var, cov, _ = self.engine.predict_tasks(theta, cx, cy, tx, want_cov=True, theta_per_task=per_task)
         y_mean, y_std = float(self.y_mean.reshape(-1)[0]), float(self.y_std.reshape(-1)[0])
         mu3, var3 = mu.view(T, P, m), var.view(T, P, m)
         resid = ((ty - y_mean) / y_std).unsqueeze(1) - mu3

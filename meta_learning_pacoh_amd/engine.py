@@ -156,20 +156,22 @@ class GPEngine:
         off_ls, f, off_os, off_noise, _ = self._hyper_offsets()
         return L.hyper_fwd(theta, off_ls, f, off_os, off_noise, self.noise_floor)
 
-    def _features(self, theta, x, T, n):
-        """kernel inputs z (+ divisor) and mean (+ mode) for B = T*P problems"""
+    def _features(self, theta, x, T, n, theta_per_task=False):
+        """kernel inputs z (+ divisor) and mean (+ mode) for B = T*P problems (b = t*P + p: task t, parameter row p).
+        theta_per_task: theta holds T*S rows, S of its own per task -- the same kernels with P = T*S parameter rows, ONE
+        problem per row (B = T*S) and inputs shared by S consecutive problems"""
         lay = self.layout
         P, D = theta.shape
-        B = T * P
+        B, x_div = (P, P // T) if theta_per_task else (T * P, P)
         if lay.covar_module == 'NN':
             lo, _ = lay.block_range('kernel_nn.')
-            z = L.mlp_fwd(x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers), lay.feature_dim, B, n)
+            z = L.mlp_fwd(x, x_div, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers), lay.feature_dim, B, n)
             z_div = 1
         else:
-            z, z_div = x, P
+            z, z_div = x, x_div
         if lay.mean_module == 'NN':
             lo, _ = lay.block_range('mean_nn.')
-            mean = L.mlp_fwd(x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.mean_nn_layers), 1, B, n).reshape(B, n)
+            mean = L.mlp_fwd(x, x_div, theta[:, lo:], D, P, lay.input_dim, list(lay.mean_nn_layers), 1, B, n).reshape(B, n)
             mode = L.MEAN_VECTOR
         elif lay.mean_module == 'constant':
             lo, hi = lay.slices['constant_mean']
@@ -228,13 +230,15 @@ class GPEngine:
         (normalised space, observation noise included)."""
         return self.predict_tasks(theta, ctx_x.unsqueeze(0), ctx_y.reshape(1, -1), tst_x.unsqueeze(0), want_cov=want_cov)
 
-    def predict_tasks(self, theta, ctx_x, ctx_y, tst_x, want_cov=False):
+    def predict_tasks(self, theta, ctx_x, ctx_y, tst_x, want_cov=False, theta_per_task=False):
         """the same for T tasks of equal shape in one pass: ctx_x[T,n,d], ctx_y[T,n], tst_x[T,m,d] ->
-        mu[T*P,m], var[T*P,m], cov[T*P,m,m]|None, info[T*P]; problem b = t*P + p"""
-        P = theta.shape[0]
+        mu[T*P,m], var[T*P,m], cov[T*P,m,m]|None, info[T*P]; problem b = t*P + p.  theta_per_task: theta is [T*P, D], rows
+        t*P .. t*P+P-1 belong to task t (fresh posterior samples per task)"""
+        rows = theta.shape[0]
         T, n = ctx_x.shape[0], ctx_x.shape[1]
         m = tst_x.shape[1]
+        P = rows // T if theta_per_task else rows
         ls, os_, noise = self._hypers(theta)
-        zc, zc_div, mc, mode = self._features(theta, ctx_x.contiguous(), T, n)
-        zt, zt_div, mt, _ = self._features(theta, tst_x.contiguous(), T, m)
-        return L.gp_predict(zc, zc_div, mc, mode, ctx_y.contiguous(), P, zt, zt_div, mt, ls, os_, noise, T * P, P, want_cov=want_cov)
+        zc, zc_div, mc, mode = self._features(theta, ctx_x.contiguous(), T, n, theta_per_task)
+        zt, zt_div, mt, _ = self._features(theta, tst_x.contiguous(), T, m, theta_per_task)
+        return L.gp_predict(zc, zc_div, mc, mode, ctx_y.contiguous(), P, zt, zt_div, mt, ls, os_, noise, T * P, rows, want_cov=want_cov)

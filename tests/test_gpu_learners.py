@@ -551,7 +551,14 @@ def test_eval_datasets_batched_equals_per_task_eval(M):
                                        rtol=2e-5, atol=2e-6)
         finally:
             A.EVAL_COV_BYTES = budget
-    vi = M.GPRegressionMetaLearnedVI(train, num_iter_fit=5, svi_batch_size=3, random_seed=4)
-    vi.meta_fit(verbose=False)
-    assert vi._eval_params() is None                       # posterior samples are drawn per predict() call: the per-task loop stays
-    assert np.all(np.isfinite(vi.eval_datasets(test[:3], n_posterior_samples=5)))
+    # VI draws fresh posterior samples inside every predict(): the batched pass draws them per task in task order (same CPU stream)
+    for cov_type, layers in (('diag', (32, 32)), ('full', (8,))):
+        vi = M.GPRegressionMetaLearnedVI(train, num_iter_fit=5, svi_batch_size=3, cov_type=cov_type, mean_nn_layers=layers,
+                                         kernel_nn_layers=layers, random_seed=4)
+        vi.meta_fit(verbose=False)
+        for kw in ({'n_posterior_samples': 7}, {'mode': 'MAP'}, {}):
+            torch.manual_seed(9)
+            loop = np.array([vi.eval(*t, **kw) for t in mixed]).mean(0)
+            torch.manual_seed(9)
+            batched = np.array(vi.eval_datasets(mixed, **kw))
+            np.testing.assert_allclose(batched, loop, rtol=2e-5, atol=2e-6)
