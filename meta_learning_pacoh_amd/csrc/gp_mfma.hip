@@ -96,75 +96,76 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// Factor the 16x16 diagonal block at (d0,d0): returns false if a pivot is not positive.  On exit the
+// value of lane LANE of the own 16-lane row, in every lane of that row: one DPP move (row_newbcast), no LDS, no SGPR round trip.
+// Left to the compiler to schedule: it hoists these moves into the shadow of the rsq / Newton chain.  (Hand-fused
+// v_fmac_f32_dpp in volatile inline assembly has 13 % fewer instructions and is 8 % slower: it pins the order.)
+template <int LANE>
+__device__ __forceinline__ float row_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + LANE, 0xF, 0xF, true));
+}
+
+// right-looking elimination of the 16x16 block held one row per lane (D[j] = running A[r][j]), steps K..15, fully unrolled so that
+// every broadcast lane is a compile-time constant.  Step K: pivot = A[K][K] from lane K; A[r][j] -= (A[r][K] / pivot) * A[j][K],
+// the column entry A[j][K] coming from lane j's register D[K].
+template <int K, int J>
+__device__ __forceinline__ void factor_update(float (&D)[16], float ntk) {
+    if constexpr (J < 16) {
+        D[J] = fmaf(row_bcast<J>(D[K]), ntk, D[J]);
+        factor_update<K, J + 1>(D, ntk);
+    }
+}
+template <int K>
+__device__ __forceinline__ void factor_steps(float (&D)[16], float (&Lr)[16], float (&inv)[16], bool& ok) {
+    if constexpr (K < 16) {
+        float pk = row_bcast<K>(D[K]);
+        if (!(pk > 0.0f)) { ok = false; pk = 1.0f; }
+        const float rs = __builtin_amdgcn_rsqf(pk);
+        const float rs1 = rs * fmaf(-0.5f * pk * rs, rs, 1.5f);            // one Newton step: 1/sqrt(pk) to fp32 accuracy
+        inv[K] = rs1;
+        Lr[K] = D[K] * rs1;                                                // L[r][K] (valid for r >= K)
+        factor_update<K, K + 1>(D, -(D[K] * (rs1 * rs1)));                 // -A[r][K] / pk
+        factor_steps<K + 1>(D, Lr, inv, ok);
+    }
+}
+// X = L^-1 by forward substitution, lane c = r owns column c: x[I] = (delta(I,c) - sum_{J<I} L[I][J] x[J]) / L[I][I], with L[I][J]
+// taken from lane I's register Lr[J]; four short FMA chains per row instead of one long one
+template <int I, int J>
+__device__ __forceinline__ void inverse_row(const float (&Lr)[16], const float (&x)[16], float (&s)[4]) {
+    if constexpr (J < I) {
+        s[J & 3] = fmaf(-row_bcast<I>(Lr[J]), x[J], s[J & 3]);
+        inverse_row<I, J + 1>(Lr, x, s);
+    }
+}
+template <int I>
+__device__ __forceinline__ void inverse_rows(const float (&Lr)[16], const float (&inv)[16], float (&x)[16], int r) {
+    if constexpr (I < 16) {
+        float s[4] = {(I == r) ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f};
+        inverse_row<I, 0>(Lr, x, s);
+        x[I] = ((s[0] + s[1]) + (s[2] + s[3])) * inv[I];
+        inverse_rows<I + 1>(Lr, inv, x, r);
+    }
+}
+
+// Factor the 16x16 diagonal block at (d0,d0); a pivot that is not positive raises the sticky flag scr[40].  On exit the
 // block holds L11^-1 (lower triangular, zeros above) and invd[d0..d0+15] = 1/diag(L11).
-// Row r of the block sits in the registers of lane r (lanes 16-63 mirror lanes 0-15).  The values every
-// lane needs at step k (column k of the running matrix, later row i of L) are published through LDS and
-// read back as broadcast ds_read_b128 -- this keeps the VALU, which bounds the kernel, free of the
-// 240 v_readlane + IEEE sqrt/divide sequences of a pure register formulation.
+// Row r of the block sits in the registers of lane r (lanes 16-63 mirror lanes 0-15: four identical 16-lane rows).  Everything a
+// lane needs from another row -- the pivot and column K of the running matrix at step K, later row I of L -- arrives by DPP
+// row_newbcast straight from that lane's register: the whole factor + inverse runs without LDS traffic, barriers or waitcnts
+// (the 32 dependent write -> broadcast-read LDS round trips of the previous formulation were a third of the kernel's time;
+// v_readlane to SGPRs, tried before that, costs VALU->SGPR->VALU wait states on every one of its 240 values).
 template <int NW>
 __device__ __forceinline__ void factor_diag_block(float* A, int LD, int d0, float* invd, float* scr, int r, bool active) {
-    // `active` = this wave does the work (wave 0); other waves of the workgroup only join the barriers.
-    // scr[0..31]: double-buffered column broadcast, scr[40]: "a pivot was not positive" flag (sticky per attempt)
-    float Lr[16], inv[16];
-    if (active) {
-        float D[16];
-        const float4* row = reinterpret_cast<const float4*>(A + (d0 + r) * LD + d0);
+    // `active` = this wave does the work (wave 0); the caller brackets the call with SYNC() for the other waves.
+    if (!active) return;
+    float D[16], Lr[16], inv[16], x[16];
+    const float4* row = reinterpret_cast<const float4*>(A + (d0 + r) * LD + d0);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { float4 q = row[v]; D[4 * v] = q.x; D[4 * v + 1] = q.y; D[4 * v + 2] = q.z; D[4 * v + 3] = q.w; }
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            scr[(k & 1) * 16 + r] = D[k];                                  // column k: D[r][k] (double-buffered)
-            asm volatile("" ::: "memory");                                 // keep the compiler from sinking the write below the reads
-            float c[16];
-            {
-                const float4* cp = reinterpret_cast<const float4*>(scr + (k & 1) * 16);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) { float4 q = cp[v]; c[4 * v] = q.x; c[4 * v + 1] = q.y; c[4 * v + 2] = q.z; c[4 * v + 3] = q.w; }
-            }
-            float pk = c[k];
-            if (!(pk > 0.0f)) { ok = false; pk = 1.0f; }
-            const float rs = __builtin_amdgcn_rsqf(pk);
-            const float rs1 = rs * fmaf(-0.5f * pk * rs, rs, 1.5f);        // one Newton step: 1/sqrt(pk) to fp32 accuracy
-            inv[k] = rs1;
-            Lr[k] = D[k] * rs1;                                            // L[r][k] (valid for r >= k)
-            const float tk = D[k] * (rs1 * rs1);                           // D[r][k] / pk
-#pragma unroll
-            for (int j = k + 1; j < 16; ++j) D[j] = fmaf(-tk, c[j], D[j]); // D[r][j] -= L[r][k] L[j][k]
-        }
-        if (!ok && threadIdx.x == 0) scr[40] = 1.0f;
-        // publish L (row r by lane r) in the block's own storage
-        if (threadIdx.x < 16) {
-            float4* wrow = reinterpret_cast<float4*>(A + (d0 + r) * LD + d0);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) { float4 q; q.x = Lr[4 * v]; q.y = Lr[4 * v + 1]; q.z = Lr[4 * v + 2]; q.w = Lr[4 * v + 3]; wrow[v] = q; }
-        }
-    }
-    if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-    float x[16];
-    if (active) {                                                          // X = L11^-1: lane c = r owns column c
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float s = (i == r) ? 1.0f : 0.0f;
-            if (i > 0) {
-                const float4* lp = reinterpret_cast<const float4*>(A + (d0 + i) * LD + d0);      // row i of L, broadcast
-                float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;                                           // four short FMA chains, not one long one
-#pragma unroll
-                for (int v = 0; v < (i + 3) / 4; ++v) {
-                    const float4 q = lp[v];
-                    if (4 * v < i) s = fmaf(-q.x, x[4 * v], s);
-                    if (4 * v + 1 < i) s1 = fmaf(-q.y, x[4 * v + 1], s1);
-                    if (4 * v + 2 < i) s2 = fmaf(-q.z, x[4 * v + 2], s2);
-                    if (4 * v + 3 < i) s3 = fmaf(-q.w, x[4 * v + 3], s3);
-                }
-                s = (s + s1) + (s2 + s3);
-            }
-            x[i] = s * inv[i];
-        }
-    }
-    if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();                                                       // every lane has read L before X overwrites it
-    if (active && threadIdx.x < 16) {
+    for (int v = 0; v < 4; ++v) { float4 q = row[v]; D[4 * v] = q.x; D[4 * v + 1] = q.y; D[4 * v + 2] = q.z; D[4 * v + 3] = q.w; }
+    bool ok = true;
+    factor_steps<0>(D, Lr, inv, ok);
+    if (!ok && threadIdx.x == 0) scr[40] = 1.0f;
+    inverse_rows<0>(Lr, inv, x, r);
+    if (threadIdx.x < 16) {                                                // every row was read (in program order) before X lands
 #pragma unroll
         for (int i = 0; i < 16; ++i) A[(d0 + i) * LD + d0 + r] = x[i];
         float my_inv = 0.0f;
