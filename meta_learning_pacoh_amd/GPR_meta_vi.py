@@ -8,7 +8,6 @@ ELBO gradient needs only the per-sample score from the device engine:
 import math
 import time
 
-import numpy as np
 import torch
 
 from . import _lib as L

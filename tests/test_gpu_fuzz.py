@@ -1,0 +1,157 @@
+"""Seeded sweep over random shapes of the fused LML + gradient entry point (pacoh_gp_lml_fwdbwd through the host wrapper, which
+routes n above the LDS-resident limit to pacoh_gp_lml_dense): every kernel variant the dispatcher can pick -- block counts 1..8,
+one and two waves, every feature-count specialisation, shared and per-problem inputs, all mean modes, with and without outputscale,
+ragged tasks -- against the oracle's autograd, problem by problem."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pacoh_oracle as O
+
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def L():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    from meta_learning_pacoh_amd import _lib
+    _lib.load_library()
+    return _lib
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def draw_case(seed):
+    rs = np.random.RandomState(seed)
+    edges = [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 80, 96, 111, 112, 113, 127, 128, 129, 160, 200, 257]
+    n = int(edges[rs.randint(len(edges))]) if rs.rand() < 0.7 else int(rs.randint(1, 140))
+    f = int(rs.randint(1, 17)) if rs.rand() < 0.4 else int(rs.choice([1, 2, 2, 4]))
+    P = int(rs.randint(1, 8))
+    T = int(rs.randint(1, 7))
+    return dict(n=n, f=f, P=P, T=T, shared_z=bool(rs.rand() < 0.3), mean_mode=int(rs.randint(3)), with_os=bool(rs.rand() < 0.5),
+                ragged=bool(rs.rand() < 0.5), weighted=bool(rs.rand() < 0.5))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('seed', list(range(40)))
+def test_lml_fwdbwd_random_shapes(L, dtype, seed):
+    c = draw_case(seed)
+    n, f, P, T = c['n'], c['f'], c['P'], c['T']
+    B = T * P
+    g = torch.Generator().manual_seed(1000 + seed)
+    z = torch.randn(T if c['shared_z'] else B, n, f, generator=g, dtype=torch.float64)
+    y = torch.randn(T, n, generator=g, dtype=torch.float64)
+    ls = torch.nn.functional.softplus(torch.randn(P, f, generator=g, dtype=torch.float64)) + 0.3
+    os_ = torch.nn.functional.softplus(torch.randn(P, generator=g, dtype=torch.float64)) + 0.2 if c['with_os'] else None
+    noise = torch.nn.functional.softplus(torch.randn(P, generator=g, dtype=torch.float64) - 1.0) + 0.05
+    mode = (L.MEAN_ZERO, L.MEAN_VECTOR, L.MEAN_CONST)[c['mean_mode']]
+    mean = {L.MEAN_ZERO: None, L.MEAN_VECTOR: 0.3 * torch.randn(B, n, generator=g, dtype=torch.float64),
+            L.MEAN_CONST: torch.randn(P, generator=g, dtype=torch.float64)}[mode]
+    sizes = torch.randint(1, n + 1, (T,), generator=g) if c['ragged'] else torch.full((T,), n)
+    if c['ragged']:
+        sizes[0] = n                                                                # at least one full task
+    gl = torch.rand(B, generator=g, dtype=torch.float64) + 0.5 if c['weighted'] else None
+    q = lambda t: None if t is None else t.to(dtype)                                 # the kernel's inputs, rounded to its dtype
+    zq, yq, lsq, osq, nq, mq, glq = q(z), q(y), q(ls), q(os_), q(noise), q(mean), q(gl)
+    d = lambda t: None if t is None else t.to(DEV)
+    out = L.gp_lml_fwdbwd(d(zq), P if c['shared_z'] else 1, d(mq), mode, d(yq), P, d(lsq), d(osq), d(nq), B, P,
+                          n_valid=d(sizes.to(torch.int32)) if c['ragged'] else None, g_lml=d(glq), want_dz=not c['shared_z'])
+    lml, d_z, d_mean, d_ls, d_os, d_noise, info = [None if o is None else o.cpu() for o in out]
+    assert int(info.abs().max()) == 0, c
+    ltol, gtol = (2e-4, 1e-2) if dtype == torch.float32 else (1e-9, 1e-7)
+    ref_lml = torch.zeros(B, dtype=torch.float64)
+    ref = dict(z=torch.zeros(B, n, f, dtype=torch.float64), mean=torch.zeros(B, n, dtype=torch.float64), const=torch.zeros(B, dtype=torch.float64),
+               ls=torch.zeros(B, f, dtype=torch.float64), os=torch.zeros(B, dtype=torch.float64), noise=torch.zeros(B, dtype=torch.float64))
+    for t in range(T):
+        s = int(sizes[t])
+        for p in range(P):
+            b = t * P + p
+            zz = zq[t if c['shared_z'] else b, :s].double().clone().requires_grad_(True)
+            hy = [lsq[p].double().clone().requires_grad_(True), (osq[p].double().clone() if osq is not None else torch.tensor(1.0, dtype=torch.float64)).requires_grad_(True),
+                  nq[p].double().clone().requires_grad_(True)]
+            if mode == L.MEAN_VECTOR:
+                mm = mq[b, :s].double().clone().requires_grad_(True)
+                mvec = mm
+            elif mode == L.MEAN_CONST:
+                mm = mq[p].double().clone().requires_grad_(True)
+                mvec = mm.expand(s)
+            else:
+                mm, mvec = None, torch.zeros(s, dtype=torch.float64)
+            val = O.gp_mll(zz, mvec, yq[t, :s].double(), hy[0], hy[1], hy[2])
+            (val * (glq[b].double() if glq is not None else 1.0)).backward()
+            ref_lml[b] = val.detach()
+            ref['z'][b, :s] = zz.grad
+            ref['ls'][b], ref['os'][b], ref['noise'][b] = hy[0].grad, hy[1].grad, hy[2].grad
+            if mode == L.MEAN_VECTOR:
+                ref['mean'][b, :s] = mm.grad
+            elif mode == L.MEAN_CONST:
+                ref['const'][b] = mm.grad
+    assert float(((lml.double() - ref_lml).abs() / (ref_lml.abs() + 1.0)).max()) < ltol, c
+    if not c['shared_z']:
+        assert relerr(d_z, ref['z']) < gtol, c
+        for t in range(T):                                                           # padded rows get exactly zero
+            assert float(d_z.reshape(T, P, n, f)[t, :, int(sizes[t]):].abs().sum()) == 0.0
+    if mode == L.MEAN_VECTOR:
+        assert relerr(d_mean, ref['mean']) < gtol, c
+    elif mode == L.MEAN_CONST:
+        assert relerr(d_mean.reshape(-1), ref['const']) < gtol, c
+    assert relerr(d_ls, ref['ls']) < gtol, c
+    if c['with_os']:
+        assert relerr(d_os, ref['os']) < gtol, c
+    assert relerr(d_noise, ref['noise']) < gtol, c
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('seed', list(range(24)))
+def test_predict_random_shapes(L, dtype, seed):
+    """posterior predictive (pacoh_gp_predict, or pacoh_gp_predict_dense above the LDS-resident limit) on random shapes: mean,
+    variance and full covariance per problem vs the oracle; ragged contexts, shared / per-problem inputs, all mean modes"""
+    c = draw_case(500 + seed)
+    n, f, P, T = c['n'], c['f'], c['P'], c['T']
+    rs = np.random.RandomState(seed)
+    m = int(rs.choice([1, 7, 16, 50, 65, 130]))
+    B = T * P
+    g = torch.Generator().manual_seed(3000 + seed)
+    shared = c['shared_z']
+    zc = torch.randn(T if shared else B, n, f, generator=g, dtype=torch.float64)
+    zt = torch.randn(T if shared else B, m, f, generator=g, dtype=torch.float64)
+    y = torch.randn(T, n, generator=g, dtype=torch.float64)
+    ls = torch.nn.functional.softplus(torch.randn(P, f, generator=g, dtype=torch.float64)) + 0.3
+    os_ = torch.nn.functional.softplus(torch.randn(P, generator=g, dtype=torch.float64)) + 0.2 if c['with_os'] else None
+    noise = torch.nn.functional.softplus(torch.randn(P, generator=g, dtype=torch.float64) - 1.0) + 0.05
+    mode = (L.MEAN_ZERO, L.MEAN_VECTOR, L.MEAN_CONST)[c['mean_mode']]
+    mc = {L.MEAN_ZERO: None, L.MEAN_VECTOR: 0.3 * torch.randn(B, n, generator=g, dtype=torch.float64),
+          L.MEAN_CONST: torch.randn(P, generator=g, dtype=torch.float64)}[mode]
+    mt = 0.3 * torch.randn(B, m, generator=g, dtype=torch.float64) if mode == L.MEAN_VECTOR else mc        # constant mean: the same [P] vector
+    sizes = torch.randint(1, n + 1, (T,), generator=g) if c['ragged'] else torch.full((T,), n)
+    q = lambda t: None if t is None else t.to(dtype)
+    zcq, ztq, yq, lsq, osq, nq, mcq, mtq = q(zc), q(zt), q(y), q(ls), q(os_), q(noise), q(mc), q(mt)
+    d = lambda t: None if t is None else t.to(DEV)
+    div = P if shared else 1
+    mu, var, cov, info = L.gp_predict(d(zcq), div, d(mcq), mode, d(yq), P, d(ztq), div, d(mtq), d(lsq), d(osq), d(nq), B, P,
+                                      n_valid=d(sizes.to(torch.int32)) if c['ragged'] else None, want_cov=True)
+    assert int(info.abs().max().cpu()) == 0, c
+    tol = 2e-3 if dtype == torch.float32 else 1e-9
+    for t in range(T):
+        s = int(sizes[t])
+        for p in range(P):
+            b = t * P + p
+            src = t if shared else b
+            if mode == L.MEAN_VECTOR:
+                m_c, m_t = mcq[b, :s].double(), mtq[b].double()
+            elif mode == L.MEAN_CONST:
+                m_c, m_t = mcq[p].double().expand(s), mcq[p].double().expand(m)
+            else:
+                m_c, m_t = torch.zeros(s, dtype=torch.float64), torch.zeros(m, dtype=torch.float64)
+            mean_o, cov_o = O.gp_predict(zcq[src, :s].double(), m_c, yq[t, :s].double(), ztq[src].double(), m_t, lsq[p].double(),
+                                         1.0 if osq is None else osq[p].double(), nq[p].double())
+            scale = float(cov_o.diagonal().abs().max())
+            assert float((mu[b].double().cpu() - mean_o).abs().max()) < tol * (1 + float(mean_o.abs().max())), (c, m)
+            assert float((var[b].double().cpu() - cov_o.diagonal()).abs().max()) < tol * scale, (c, m)
+            assert float((cov[b].double().cpu() - cov_o).abs().max()) < tol * scale, (c, m)

@@ -4,7 +4,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import meta_learning_pacoh_amd as M
 from meta_learning_pacoh_amd import _lib as L
-from bench import make_tasks
 
 
 def timeit(fn, reps=10, warm=3):
