@@ -155,3 +155,37 @@ def test_predict_random_shapes(L, dtype, seed):
             assert float((mu[b].double().cpu() - mean_o).abs().max()) < tol * (1 + float(mean_o.abs().max())), (c, m)
             assert float((var[b].double().cpu() - cov_o.diagonal()).abs().max()) < tol * scale, (c, m)
             assert float((cov[b].double().cpu() - cov_o).abs().max()) < tol * scale, (c, m)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('seed', list(range(30)))
+def test_mlp_random_shapes(L, dtype, seed):
+    """per-particle MLP forward + parameter gradient (pacoh_mlp_fwd / pacoh_mlp_bwd) on random architectures and batch shapes: the
+    MFMA kernels (two equal hidden layers of 16/32/64, wide or narrow output), the general kernels (anything else up to three
+    hidden layers of <= 64, d_in <= 16, d_out <= 8) and the sizes either side of their tile boundaries, vs the oracle's autograd"""
+    rs = np.random.RandomState(7000 + seed)
+    P, T = int(rs.randint(1, 8)), int(rs.randint(1, 6))
+    n = int(rs.choice([1, 5, 15, 16, 17, 63, 64, 65, 100, 128, 200]))
+    d_in = int(rs.choice([1, 2, 4, 4, 8, 16])) if rs.rand() < 0.7 else int(rs.randint(1, 17))
+    d_out = int(rs.choice([1, 2, 2, 3, 8]))
+    if rs.rand() < 0.5:
+        w = int(rs.choice([16, 32, 64]))
+        hidden = (w, w)
+    else:
+        hidden = tuple(int(rs.randint(1, 65)) for _ in range(int(rs.randint(0, 4))))
+    B = T * P
+    layout = O.nn_param_layout(d_in, d_out, hidden)
+    Dn = sum(layout.values())
+    g = torch.Generator().manual_seed(8000 + seed)
+    theta = (0.5 * torch.randn(P, Dn, generator=g, dtype=torch.float64)).to(dtype)
+    x = torch.randn(T, n, d_in, generator=g, dtype=torch.float64).to(dtype)
+    gout = torch.randn(B, n, d_out, generator=g, dtype=torch.float64).to(dtype)
+    tag = (P, T, n, d_in, hidden, d_out)
+    out = L.mlp_fwd(x.to(DEV), P, theta.to(DEV), Dn, P, d_in, list(hidden), d_out, B, n)
+    th = theta.double().clone().requires_grad_(True)
+    ref = torch.stack([O.mlp_vectorized_forward(x[t].double(), th, d_in, d_out, hidden) for t in range(T)]).reshape(B, n, d_out)
+    assert relerr(out, ref) < (2e-5 if dtype == torch.float32 else 1e-12), tag
+    (ref * gout.double()).sum().backward()
+    d_theta = torch.zeros(P, Dn, dtype=dtype, device=DEV)
+    L.mlp_bwd(x.to(DEV), P, theta.to(DEV), Dn, P, d_in, list(hidden), d_out, gout.to(DEV), d_theta, Dn, False, B, n)
+    assert relerr(d_theta, th.grad) < (5e-4 if dtype == torch.float32 else 1e-10), tag
