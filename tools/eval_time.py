@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import meta_learning_pacoh_amd as M                      # noqa: E402
-from oracle import pacoh_oracle as O                     # noqa: E402  (data generator only)
+from bench import make_tasks                             # noqa: E402  (synthetic sinusoid tasks)
 
 
 def timed(fn, reps=20):
@@ -22,9 +22,13 @@ def timed(fn, reps=20):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-env = O.SinusoidDataset(np.random.RandomState(26))
-train, test = env.generate_meta_train_data(20, 5), env.generate_meta_test_data(20, 5, 50)
-big = env.generate_meta_test_data(100, 20, 200)
+def split(tasks, n_ctx):
+    return [(x[:n_ctx], y[:n_ctx], x[n_ctx:], y[n_ctx:]) for x, y in tasks]
+
+
+train = make_tasks(20, 5, 1)
+test = split(make_tasks(20, 55, 1, seed0=5000), 5)
+big = split(make_tasks(100, 220, 1, seed0=7000), 20)
 for name, model in (('MAP', M.GPRegressionMetaLearned(train, num_iter_fit=20, random_seed=1)),
                     ('SVGD P=10', M.GPRegressionMetaLearnedSVGD(train, num_iter_fit=5, num_particles=10, random_seed=1))):
     model.meta_fit(verbose=False)
