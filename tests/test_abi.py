@@ -86,3 +86,7 @@ def test_product_package_does_not_import_the_oracle():
         if fn.endswith('.py'):
             src = open(os.path.join(pkg, fn)).read()
             assert 'oracle' not in re.sub(r'#.*', '', src).replace('"""', ''), fn + ' mentions the oracle'
+    tools = os.path.join(ROOT, 'tools')                        # measurement helpers are not allowed to lean on the checker either
+    for fn in os.listdir(tools):
+        if fn.endswith('.py'):
+            assert not re.search(r'^\s*(from|import)\s+oracle', open(os.path.join(tools, fn)).read(), re.M), fn + ' imports the oracle'
