@@ -90,10 +90,21 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// v + (v of the lane a DPP control selects); rows a row_mask leaves out contribute 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF));
+}
+// sum over the 64 lanes, returned in every lane (as a scalar): six DPP adds and one v_readlane instead of six dependent
+// ds_bpermute round trips (__shfl_xor)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v = dpp_add<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);      // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);      // row_mirror: every lane holds the sum of its 16-lane row
+    v = dpp_add<0x142, 0xA>(v);      // row_bcast15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);      // row_bcast31 into rows 2 and 3: lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // value of lane LANE of the own 16-lane row, in every lane of that row: one DPP move (row_newbcast), no LDS, no SGPR round trip.
