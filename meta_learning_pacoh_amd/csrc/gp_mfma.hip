@@ -207,8 +207,10 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // columns independent (no in-place hazard -> split over the waves, no barriers inside) and turns every
 // operand of the later products into a contiguous ds_read_b128; W = K^-1 then overwrites the dead lower
 // triangle row by row and is mirrored into the upper one.
+// Occupancy: LDS admits 8 problems per CU (2 waves per SIMD) at n = 64 and the kernel takes the 189 VGPRs that allows; up to
+// n = 48 LDS admits 3 waves per SIMD, which is worth squeezing into 168 VGPRs (a few spilled dwords): -7 % at n = 48, -10 % at n = 32.
 template <int NB, int NW, int FP, bool BWD>
-__global__ void __launch_bounds__(64 * NW) gp_mfma_kernel(GpMfmaArgs a) {
+__global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma_kernel(GpMfmaArgs a) {
     constexpr int NP = 16 * NB;              // padded problem size
     constexpr int LD = NP + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
