@@ -92,8 +92,8 @@ def cpu_baseline(budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)     # 0.15 s of GPU time; 20 steps still carry ~4 % of start-up per step
+    ap.add_argument('--warmup', type=int, default=10)     # (the first step after a synchronise waits for the host to issue it)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
