@@ -113,7 +113,15 @@ def _ptr(t, like=None):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (follows torch.cuda.stream() / graph capture).  The raw
+    accessors skip ~8 us of Python per call (a tenth of the host time of a step); the public API is the fallback"""
+    if _raw_stream is not None and _raw_device is not None:
+        return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -629,3 +629,18 @@ def test_mixture_icdf_stopping_rule_and_limits(L):
     assert lib.pacoh_mixture_icdf(big.data_ptr(), big.data_ptr(), big.data_ptr(), big.data_ptr(), 0.0, 1.0, -1e8, 1e8, 1e-6, 10000, 1,
                                   2, 8, 0, None) == -1
     assert lib.pacoh_mixture_cdf(big.data_ptr(), big.data_ptr(), big.data_ptr(), big.data_ptr(), 0.0, 0.0, 1, 1, 8, 0, None) == -1
+
+
+def test_launch_stream_follows_torch_current_stream(L):
+    """every C-ABI call goes to torch's CURRENT stream (side streams, graph capture): the raw accessor the binding uses must agree
+    with the public API inside and outside a torch.cuda.stream() block"""
+    assert (L._stream().value or 0) == torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert (L._stream().value or 0) == side.cuda_stream
+        x = torch.ones(1000, device=DEV)
+        y = torch.zeros(1000, device=DEV)
+        L.axpy(y, x, 2.0)
+    side.synchronize()
+    assert float(y.sum()) == 2000.0
+    assert (L._stream().value or 0) == torch.cuda.current_stream().cuda_stream
