@@ -195,10 +195,10 @@ def main():
         B = evals_per_gpu
         z = torch.randn(B, N_CTX, 2, device='cuda')
         ls = torch.rand(PARTICLES, 2, device='cuda') + 0.5
-        for _ in range(3):
+        for _ in range(10):
             L.gram_rbf_ard(z, 1, z, 1, ls, None, None, False, B, PARTICLES)
         torch.cuda.synchronize()
-        reps = 20
+        reps = 100
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         K = torch.empty(B, N_CTX, N_CTX, device='cuda')
         lib = L.load_library()

@@ -24,10 +24,11 @@ def run(B, P, n, f, dt, iters=30):
     t = a.elapsed_time(b) / iters * 1e-3
     es = z.element_size()
     byt = B * (n * f * es + n * n * es)
-    print('B=%d n=%d f=%d %s: %.1f us  %.1f GB/s' % (B, n, f, dt, t * 1e6, byt / t / 1e9))
+    print('B=%d n=%d f=%d %s, %d launches: %.1f us  %.1f GB/s' % (B, n, f, dt, iters, t * 1e6, byt / t / 1e9))
 
 
-run(20480, 20, 64, 2, torch.float32)
+for it in (10, 20, 50, 100, 400, 20):
+    run(20480, 20, 64, 2, torch.float32, iters=it)
 run(20480, 20, 64, 4, torch.float32)
 run(2560, 10, 128, 2, torch.float32)
 run(256, 1, 512, 8, torch.float64)

@@ -37,6 +37,8 @@ int main() {
         float t0 = run<0, 4>(buf, nq, 20), t1 = run<1, 4>(buf, nq, 20), t2 = run<0, 1>(buf, nq, 20), t3 = run<0, 16>(buf, nq, 20);
         printf("bytes %ld: plain qpt4 %.1f GB/s | nt qpt4 %.1f GB/s | plain qpt1 %.1f GB/s | plain qpt16 %.1f GB/s\n", bytes,
                bytes / t0 * 1e-6, bytes / t1 * 1e-6, bytes / t2 * 1e-6, bytes / t3 * 1e-6);
+        float t100 = run<0, 4>(buf, nq, 100), t400 = run<0, 4>(buf, nq, 400);
+        printf("   sustained, plain qpt4: %.1f GB/s over 100 launches, %.1f GB/s over 400\n", bytes / t100 * 1e-6, bytes / t400 * 1e-6);
         hipFree(buf);
     }
     return 0;
