@@ -49,8 +49,8 @@ extern "C" {
 #define PACOH_MEAN_CONST 2     /* mean[P]     (ConstantMeanLight, models.py:406-416)             */
 
 #define PACOH_MAX_FEATURES 16  /* f (kernel input dim) <= 16                                     */
-#define PACOH_MAX_HIDDEN_LAYERS 3
-#define PACOH_MAX_WIDTH 64     /* MLP hidden width <= 64, d_in <= 16, d_out <= 8                 */
+#define PACOH_MLP_MAX_HIDDEN_LAYERS 63   /* per-particle MLP: any layer_sizes up to this depth ...          */
+#define PACOH_MLP_MAX_WIDTH 65536        /* ... and this width (the reference has no limit: models.py:328-349) */
 
 /* info[b] values written by the GP kernels (LAPACK-style): 0 = clean Cholesky; 1..3 = succeeded
  * after adding diagonal jitter base*10^(k-1), base = 1e-6 (f32) / 1e-8 (f64) -- the retry ladder of
@@ -148,9 +148,15 @@ int pacoh_gp_predict_dense(const void* z_ctx, int z_div, const void* mean_ctx, i
  * (LinearVectorized.parameter_shapes, models.py:319-323).  P = 1 gives the shared-weight network of
  * PACOH-MAP (NeuralNetwork.forward, models.py:211-217).
  * Replaces NeuralNetworkVectorized.forward / LinearVectorized.forward (models.py:295-317,343-349).
- * hidden: HOST array of n_hidden layer widths.  Limits: d_in<=16, widths<=64, d_out<=8, n_hidden<=3. */
+ * hidden: HOST array of n_hidden layer widths -- ANY layer_sizes, as the reference (models.py:328-349; the launchers run
+ * 4 x 32 and 4 x 128: experiments/meta_GPR_SVGD_base_exp.py:29-30, meta_GPR_mll_base_exp.py:29-30), n_hidden >= 0.
+ * Shapes outside the register-/LDS-resident kernels (fp32: <= 4 hidden layers of width <= 32 with d_in <= 4, d_out <= 2, or
+ * <= 2 layers with d_in <= 16, d_out <= 8; both dtypes: <= 3 layers of width <= 64) run layer by layer on the matrix cores
+ * through `workspace` (pacoh_mlp_fwd_workspace_bytes; 0 bytes = not needed, NULL allowed). */
+size_t pacoh_mlp_fwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out,
+                                     int dtype);
 int pacoh_mlp_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P,
-                  int d_in, const int32_t* hidden, int n_hidden, int d_out, void* out,
+                  int d_in, const int32_t* hidden, int n_hidden, int d_out, void* out, void* workspace,
                   int B, int n, int dtype, void* stream);
 
 /* Backward: d_theta[P, D_net] (row stride d_theta_stride) = sum over the problems b of particle p of
@@ -164,6 +170,22 @@ int pacoh_mlp_bwd(const void* x, int x_div, const void* theta, long theta_stride
                   int d_in, const int32_t* hidden, int n_hidden, int d_out, const void* g_out,
                   void* d_theta, long d_theta_stride, int accumulate, void* workspace,
                   int B, int n, int dtype, void* stream);
+
+/* The mean network AND the kernel-feature network of one step (VectorizedGP.forward evaluates both on the same inputs,
+ * random_gp.py:54-68; LearnedGPRegressionModel.forward, models.py:505-519) in one call: two networks of the SAME hidden
+ * shape whose blocks start at element offsets off_a / off_b of the theta rows (theta, d_theta point at the ROW start here).
+ * Same semantics as two pacoh_mlp_fwd / pacoh_mlp_bwd calls; on the fused fp32 path it is ONE launch. */
+size_t pacoh_mlp2_fwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out_a,
+                                      int d_out_b, int dtype);
+int pacoh_mlp2_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
+                   const int32_t* hidden, int n_hidden, long off_a, int d_out_a, void* out_a, long off_b, int d_out_b,
+                   void* out_b, void* workspace, int B, int n, int dtype, void* stream);
+size_t pacoh_mlp2_bwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out_a,
+                                      int d_out_b, int dtype);
+int pacoh_mlp2_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
+                   const int32_t* hidden, int n_hidden, long off_a, int d_out_a, const void* g_a, long off_b,
+                   int d_out_b, const void* g_b, void* d_theta, long d_theta_stride, int accumulate,
+                   void* workspace, int B, int n, int dtype, void* stream);
 
 /* ---- A3 + A7: parameter transforms, hyper-prior ------------------------------------------------
  * softplus with optional floor, forward:  out = log(1+exp(raw)) + floor            (random_gp.py:69-74;

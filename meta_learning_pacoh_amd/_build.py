@@ -15,7 +15,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 OBJ_DIR = os.path.join(HERE, 'build')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpacoh_gp.so')
-SOURCES = ['gp_small.hip', 'gp_mfma.hip', 'gram.hip', 'dense.hip', 'dense_mfma.hip', 'dense_gp.hip', 'mlp.hip', 'mlp_mfma.hip', 'mlp_f32.hip', 'mlp_f64.hip', 'misc.hip', 'svgd_imq.hip', 'vi_full.hip', 'comm.hip', 'predictive.hip']
+SOURCES = ['gp_small.hip', 'gp_mfma.hip', 'gram.hip', 'dense.hip', 'dense_mfma.hip', 'dense_gp.hip', 'mlp.hip', 'mlp_mfma.hip', 'mlp_fused.hip', 'mlp_layers.hip', 'mlp_f32.hip', 'mlp_f64.hip', 'misc.hip', 'svgd_imq.hip', 'vi_full.hip', 'comm.hip', 'predictive.hip']
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-Wno-pass-failed', '-Wno-unused-value']
 

@@ -40,9 +40,14 @@ SIGNATURES = {
     'pacoh_gp_predict_dense': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _i, _i, _i, _i, _i, _i, _vp]),
     'pacoh_mvn_logprob_dense': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
-    'pacoh_mlp_fwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _i, _i, _i, _vp]),
+    'pacoh_mlp_fwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i]),
+    'pacoh_mlp_fwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_mlp_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i]),
     'pacoh_mlp_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _l, _i, _vp, _i, _i, _i, _vp]),
+    'pacoh_mlp2_fwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
+    'pacoh_mlp2_fwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp]),
+    'pacoh_mlp2_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
+    'pacoh_mlp2_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _i, _i, _i, _vp]),
     'pacoh_softplus_fwd': (_i, [_vp, _vp, _d, _l, _i, _vp]),
     'pacoh_softplus_bwd': (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),
     'pacoh_hyper_fwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
@@ -340,12 +345,27 @@ def mvn_logprob_dense(A, resid, scale=1.0, want_alpha=False):
     return logp, alpha, info
 
 
+_MLP_WS = {}
+
+
+def _mlp_fwd_ws(need, device):
+    """grow-only scratch of the layer-wise MLP forward (only shapes outside the register-resident kernels need any)"""
+    if need == 0:
+        return None
+    ws = _MLP_WS.get(device)
+    if ws is None or ws.numel() < need:
+        ws = _MLP_WS[device] = torch.empty(need, dtype=torch.uint8, device=device)
+    return ws
+
+
 def mlp_fwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, B, n):
     lib = load_library()
     out = torch.empty(B, n, d_out, dtype=x.dtype, device=x.device)
+    harr, code = _hidden_arr(hidden), dtype_code(x)
+    ws = _mlp_fwd_ws(lib.pacoh_mlp_fwd_workspace_bytes(B, P, n, d_in, harr, len(hidden), d_out, code), x.device)
     with _Timed('mlp_fwd'):
         _check(lib.pacoh_mlp_fwd(_ptr(x), x_div, ctypes.c_void_p(theta_block.data_ptr()), theta_stride, P, d_in,
-                                 _hidden_arr(hidden), len(hidden), d_out, _ptr(out), B, n, dtype_code(x), _stream()),
+                                 harr, len(hidden), d_out, _ptr(out), _ptr(ws), B, n, code, _stream()),
                'pacoh_mlp_fwd')
     return out
 
@@ -363,6 +383,35 @@ def mlp_bwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, g_out, 
                                  len(hidden), d_out, _ptr(g_out, x), ctypes.c_void_p(d_theta_block.data_ptr()),
                                  d_theta_stride, int(bool(accumulate)), _ptr(workspace), B, n, code, _stream()),
                'pacoh_mlp_bwd')
+    return workspace
+
+
+def mlp2_fwd(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, off_b, d_out_b, B, n):
+    """two networks of the same hidden shape (blocks at element offsets off_a / off_b of the rows of theta[P, D]) on the
+    same inputs: -> (out_a[B,n,d_out_a], out_b[B,n,d_out_b]); one launch on the fused fp32 path"""
+    lib = load_library()
+    out_a = torch.empty(B, n, d_out_a, dtype=x.dtype, device=x.device)
+    out_b = torch.empty(B, n, d_out_b, dtype=x.dtype, device=x.device)
+    harr, code = _hidden_arr(hidden), dtype_code(x)
+    ws = _mlp_fwd_ws(lib.pacoh_mlp2_fwd_workspace_bytes(B, P, n, d_in, harr, len(hidden), d_out_a, d_out_b, code), x.device)
+    with _Timed('mlp_fwd'):
+        _check(lib.pacoh_mlp2_fwd(_ptr(x), x_div, _ptr(theta, x), theta.shape[1], P, d_in, harr, len(hidden), off_a, d_out_a,
+                                  _ptr(out_a), off_b, d_out_b, _ptr(out_b), _ptr(ws), B, n, code, _stream()), 'pacoh_mlp2_fwd')
+    return out_a, out_b
+
+
+def mlp2_bwd(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, g_a, off_b, d_out_b, g_b, d_theta, accumulate, B, n,
+             workspace=None):
+    """backward of mlp2_fwd into the rows of d_theta[P, D] (blocks at off_a / off_b); returns the workspace for reuse"""
+    lib = load_library()
+    harr, code = _hidden_arr(hidden), dtype_code(x)
+    need = lib.pacoh_mlp2_bwd_workspace_bytes(B, P, n, d_in, harr, len(hidden), d_out_a, d_out_b, code)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(max(1, need), dtype=torch.uint8, device=x.device)
+    with _Timed('mlp_bwd'):
+        _check(lib.pacoh_mlp2_bwd(_ptr(x), x_div, _ptr(theta, x), theta.shape[1], P, d_in, harr, len(hidden), off_a, d_out_a,
+                                  _ptr(g_a, x), off_b, d_out_b, _ptr(g_b, x), _ptr(d_theta, x), d_theta.shape[1],
+                                  int(bool(accumulate)), _ptr(workspace), B, n, code, _stream()), 'pacoh_mlp2_bwd')
     return workspace
 
 

@@ -1,5 +1,13 @@
-// C-ABI entry points of the per-particle MLP (kernels: mlp_impl.h, instantiated in mlp_f32/f64.hip).
+// C-ABI entry points of the per-particle MLP.  Four implementations, picked per call by shape and dtype:
+//   fused   (mlp_fused.hip)  fp32, 1-4 hidden layers of width <= 32, d_in <= 4, d_out <= 2: register-resident MFMA kernels,
+//                            one launch for the mean AND the kernel-feature network (pacoh_mlp2_*)
+//   mfma    (mlp_mfma.hip)   fp32, 1-2 hidden layers of width <= 32, d_in <= 16, d_out <= 8: the same idea with padded io layers
+//   valu    (mlp_impl.h)     fp32/fp64, 0-3 hidden layers of width <= 64: thread per data point, weights in LDS
+//   layers  (mlp_layers.hip) everything else (any depth, any width, fp32/fp64): layer-by-layer MFMA GEMMs through a workspace
+// PACOH_MLP_PATH=fused|mfma|valu|layers restricts the choice to that path and the ones after it (tests, A/B timing).
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace pacoh {
 #define PACOH_MLP_DECL(sfx) \
@@ -8,10 +16,23 @@ int mlp_bwd_##sfx(const void*, int, const void*, long, int, int, const int32_t*,
 PACOH_MLP_DECL(f32)
 PACOH_MLP_DECL(f64)
 #undef PACOH_MLP_DECL
-// register-resident MFMA path (mlp_mfma.hip): fp32, <= 2 hidden layers of width <= 32; returns 1 if not applicable
+// mlp_mfma.hip; return 1 if not applicable
 int mlp_mfma_fwd(const void*, int, const void*, long, int, int, const int32_t*, int, int, void*, int, int, hipStream_t);
 size_t mlp_mfma_bwd_workspace(int, int, int, int, const int32_t*, int, int);
 int mlp_mfma_bwd(const void*, int, const void*, long, int, int, const int32_t*, int, int, const void*, void*, long, int, void*, int, int, hipStream_t);
+bool mlp_mfma_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_out);
+// mlp_fused.hip
+bool mlp_fused_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_out);
+int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
+                  int n_hidden, int nets, const long* off, const int* d_out, void* const* out, int B, int n, hipStream_t s);
+size_t mlp_fused_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int nets);
+int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
+                  int n_hidden, int nets, const long* off, const int* d_out, const void* const* g_out, void* d_theta,
+                  long d_theta_stride, int accumulate, void* workspace, int B, int n, hipStream_t s);
+// mlp_layers.hip
+size_t mlp_layers_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype, int bwd);
+int mlp_layers_fwd(const void*, int, const void*, long, int, int, const int32_t*, int, int, void*, void*, int, int, int, hipStream_t);
+int mlp_layers_bwd(const void*, int, const void*, long, int, int, const int32_t*, int, int, const void*, void*, long, int, void*, int, int, int, hipStream_t);
 
 // out[o] (+)= scale * sum_c in[c, o]; one wavefront per output element, lanes stride over c, fixed order
 template <typename T>
@@ -26,53 +47,102 @@ __global__ void __launch_bounds__(256) reduce_tasks_kernel(const T* __restrict__
     s = subwave_sum<T>(s, 64);
     if (lane == 0) out[idx] = accumulate ? out[idx] + scale * s : scale * s;
 }
-}  // namespace pacoh
 
-using namespace pacoh;
+enum MlpPath { PATH_FUSED = 0, PATH_MFMA = 1, PATH_VALU = 2, PATH_LAYERS = 3 };
 
-extern "C" int pacoh_mlp_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P,
-                             int d_in, const int32_t* hidden, int n_hidden, int d_out, void* out,
-                             int B, int n, int dtype, void* stream) {
-    if (check_dtype(dtype)) return PACOH_EDTYPE;
-    if (!out) return PACOH_EINVAL;
-    if (dtype == PACOH_F32 && x && theta && x_div > 0 && P > 0 && B > 0 && n > 0 && B % P == 0 && d_in > 0 && d_out > 0 &&
-        n_hidden >= 1 && hidden && (long)B * n <= 0x3fffffffL) {
-        int rc = mlp_mfma_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, (hipStream_t)stream);
-        if (rc != 1) return rc;
-    }
-    return dtype == PACOH_F32
-        ? mlp_fwd_f32(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, (hipStream_t)stream)
-        : mlp_fwd_f64(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, (hipStream_t)stream);
+static int first_allowed_path() {          // read on every call (a getenv): tests switch paths inside one process
+    const char* e = getenv("PACOH_MLP_PATH");
+    if (!e) return (int)PATH_FUSED;
+    if (!strcmp(e, "mfma")) return (int)PATH_MFMA;
+    if (!strcmp(e, "valu")) return (int)PATH_VALU;
+    if (!strcmp(e, "layers")) return (int)PATH_LAYERS;
+    return (int)PATH_FUSED;
 }
 
-static int mlp_layout(int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype, int& params, int& tile) {
-    if (d_in <= 0 || d_out <= 0 || n_hidden < 0 || n_hidden > PACOH_MAX_HIDDEN_LAYERS || (n_hidden > 0 && !hidden)) return -1;
-    int prev = d_in, mx = 0;
-    params = 0;
+static bool valu_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_out) {
+    if (n_hidden > 3 || d_in > 16 || d_out > 8) return false;
+    for (int l = 0; l < n_hidden; ++l) if (hidden[l] > 64) return false;
+    return true;
+}
+
+static int args_ok(int d_in, const int32_t* hidden, int n_hidden, int d_out) {
+    if (d_in <= 0 || d_out <= 0 || n_hidden < 0 || (n_hidden > 0 && !hidden)) return PACOH_EINVAL;
+    if (n_hidden > PACOH_MLP_MAX_HIDDEN_LAYERS) return PACOH_ELIMIT;
     for (int l = 0; l < n_hidden; ++l) {
-        if (hidden[l] <= 0 || hidden[l] > PACOH_MAX_WIDTH) return -1;
-        params += hidden[l] * (prev + 1); prev = hidden[l]; mx = hidden[l] > mx ? hidden[l] : mx;
+        if (hidden[l] <= 0) return PACOH_EINVAL;
+        if (hidden[l] > PACOH_MLP_MAX_WIDTH) return PACOH_ELIMIT;
     }
-    params += d_out * (prev + 1);
-    tile = (mx <= 32 ? 256 : 128) / (dtype == PACOH_F64 ? 2 : 1);     // = bwd_tile<T>(HP) in mlp_impl.h
-    return 0;
+    return PACOH_OK;
 }
 
-extern "C" size_t pacoh_mlp_bwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden,
-                                                int n_hidden, int d_out, int dtype) {
-    int params, tile;
-    if (P <= 0 || B <= 0 || n <= 0 || mlp_layout(d_in, hidden, n_hidden, d_out, dtype, params, tile)) return 0;
+static MlpPath pick_path(int dtype, int d_in, const int32_t* hidden, int n_hidden, int d_out, long rows_total) {
+    const int first = first_allowed_path();
+    const bool f32 = dtype == PACOH_F32 && rows_total <= 0x3fffffffL;
+    if (first <= PATH_FUSED && f32 && mlp_fused_applicable(d_in, hidden, n_hidden, d_out)) return PATH_FUSED;
+    if (first <= PATH_MFMA && f32 && mlp_mfma_applicable(d_in, hidden, n_hidden, d_out)) return PATH_MFMA;
+    if (first <= PATH_VALU && valu_applicable(d_in, hidden, n_hidden, d_out)) return PATH_VALU;
+    return PATH_LAYERS;
+}
+
+static size_t valu_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype) {
+    int prev = d_in, mx = 0;
+    long params = 0;
+    for (int l = 0; l < n_hidden; ++l) { params += (long)hidden[l] * (prev + 1); prev = hidden[l]; mx = hidden[l] > mx ? hidden[l] : mx; }
+    params += (long)d_out * (prev + 1);
+    const int tile = (mx <= 32 ? 256 : 128) / (dtype == PACOH_F64 ? 2 : 1);     // = bwd_tile<T>(HP) in mlp_impl.h
     long rows = (long)(B / P) * n;
     long tiles = (rows + tile - 1) / tile;
     long want = (2048 + P - 1) / P;
     long chunks = tiles < want ? tiles : want;
     if (chunks < 1) chunks = 1;
-    size_t need = (size_t)chunks * P * params * (dtype == PACOH_F64 ? 8 : 4);
-    if (dtype == PACOH_F32 && n_hidden >= 1) {
-        size_t m = mlp_mfma_bwd_workspace(B, P, n, d_in, hidden, n_hidden, d_out);
-        if (m > need) need = m;
+    return (size_t)chunks * P * params * (dtype == PACOH_F64 ? 8 : 4);
+}
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace pacoh
+
+using namespace pacoh;
+
+extern "C" size_t pacoh_mlp_fwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out,
+                                                int dtype) {
+    if (P <= 0 || B <= 0 || n <= 0 || args_ok(d_in, hidden, n_hidden, d_out)) return 0;
+    if (pick_path(dtype, d_in, hidden, n_hidden, d_out, (long)B * n) != PATH_LAYERS) return 0;
+    return mlp_layers_workspace(B, P, n, d_in, hidden, n_hidden, d_out, dtype, 0);
+}
+
+extern "C" int pacoh_mlp_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P,
+                             int d_in, const int32_t* hidden, int n_hidden, int d_out, void* out, void* workspace,
+                             int B, int n, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!out || !x || !theta || x_div <= 0 || P <= 0 || B <= 0 || n <= 0 || B % P != 0) return PACOH_EINVAL;
+    int rc = args_ok(d_in, hidden, n_hidden, d_out);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    switch (pick_path(dtype, d_in, hidden, n_hidden, d_out, (long)B * n)) {
+    case PATH_FUSED: {
+        const long off = 0;
+        void* const outs[1] = {out};
+        return mlp_fused_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 1, &off, &d_out, outs, B, n, s);
     }
-    return need;
+    case PATH_MFMA:
+        return mlp_mfma_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, s);
+    case PATH_VALU:
+        return dtype == PACOH_F32 ? mlp_fwd_f32(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, s)
+                                  : mlp_fwd_f64(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, s);
+    default:
+        return mlp_layers_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, workspace, B, n, dtype, s);
+    }
+}
+
+extern "C" size_t pacoh_mlp_bwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden,
+                                                int n_hidden, int d_out, int dtype) {
+    if (P <= 0 || B <= 0 || n <= 0 || args_ok(d_in, hidden, n_hidden, d_out)) return 0;
+    switch (pick_path(dtype, d_in, hidden, n_hidden, d_out, (long)B * n)) {
+    case PATH_FUSED: return mlp_fused_bwd_workspace(B, P, n, d_in, hidden, n_hidden, d_out, 1);
+    case PATH_MFMA: return mlp_mfma_bwd_workspace(B, P, n, d_in, hidden, n_hidden, d_out);
+    case PATH_VALU: return valu_bwd_workspace(B, P, n, d_in, hidden, n_hidden, d_out, dtype);
+    default: return mlp_layers_workspace(B, P, n, d_in, hidden, n_hidden, d_out, dtype, 1);
+    }
 }
 
 extern "C" int pacoh_mlp_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P,
@@ -80,16 +150,92 @@ extern "C" int pacoh_mlp_bwd(const void* x, int x_div, const void* theta, long t
                              void* d_theta, long d_theta_stride, int accumulate, void* workspace,
                              int B, int n, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
-    if (!g_out || !d_theta || !workspace) return PACOH_EINVAL;
-    if (dtype == PACOH_F32 && x && theta && x_div > 0 && P > 0 && B > 0 && n > 0 && B % P == 0 && d_in > 0 && d_out > 0 &&
-        n_hidden >= 1 && hidden && (long)B * n <= 0x3fffffffL) {
-        int rc = mlp_mfma_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride,
-                              accumulate, workspace, B, n, (hipStream_t)stream);
-        if (rc != 1) return rc;
+    if (!g_out || !d_theta || !workspace || !x || !theta || x_div <= 0 || P <= 0 || B <= 0 || n <= 0 || B % P != 0) return PACOH_EINVAL;
+    int rc = args_ok(d_in, hidden, n_hidden, d_out);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    switch (pick_path(dtype, d_in, hidden, n_hidden, d_out, (long)B * n)) {
+    case PATH_FUSED: {
+        const long off = 0;
+        const void* const gs[1] = {g_out};
+        return mlp_fused_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 1, &off, &d_out, gs, d_theta, d_theta_stride,
+                             accumulate, workspace, B, n, s);
     }
-    return dtype == PACOH_F32
-        ? mlp_bwd_f32(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, accumulate, workspace, B, n, (hipStream_t)stream)
-        : mlp_bwd_f64(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, accumulate, workspace, B, n, (hipStream_t)stream);
+    case PATH_MFMA:
+        return mlp_mfma_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride,
+                            accumulate, workspace, B, n, s);
+    case PATH_VALU:
+        return dtype == PACOH_F32
+            ? mlp_bwd_f32(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, accumulate, workspace, B, n, s)
+            : mlp_bwd_f64(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, accumulate, workspace, B, n, s);
+    default:
+        return mlp_layers_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride,
+                              accumulate, workspace, B, n, dtype, s);
+    }
+}
+
+// ---- two networks of the same hidden shape on the same inputs (the mean and the kernel-feature network of a step) --------
+extern "C" size_t pacoh_mlp2_fwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out_a,
+                                                 int d_out_b, int dtype) {
+    const size_t a = pacoh_mlp_fwd_workspace_bytes(B, P, n, d_in, hidden, n_hidden, d_out_a, dtype);
+    const size_t b = pacoh_mlp_fwd_workspace_bytes(B, P, n, d_in, hidden, n_hidden, d_out_b, dtype);
+    return a > b ? a : b;                       // the two networks run one after the other on the general path
+}
+
+extern "C" int pacoh_mlp2_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
+                              const int32_t* hidden, int n_hidden, long off_a, int d_out_a, void* out_a, long off_b, int d_out_b,
+                              void* out_b, void* workspace, int B, int n, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!out_a || !out_b || !x || !theta || x_div <= 0 || P <= 0 || B <= 0 || n <= 0 || B % P != 0 || off_a < 0 || off_b < 0) return PACOH_EINVAL;
+    int rc = args_ok(d_in, hidden, n_hidden, d_out_a);
+    if (rc || (rc = args_ok(d_in, hidden, n_hidden, d_out_b))) return rc;
+    if (pick_path(dtype, d_in, hidden, n_hidden, d_out_a, (long)B * n) == PATH_FUSED &&
+        pick_path(dtype, d_in, hidden, n_hidden, d_out_b, (long)B * n) == PATH_FUSED) {
+        const long off[2] = {off_a, off_b};
+        const int dout[2] = {d_out_a, d_out_b};
+        void* const outs[2] = {out_a, out_b};
+        return mlp_fused_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 2, off, dout, outs, B, n, (hipStream_t)stream);
+    }
+    const size_t es = dtype == PACOH_F64 ? 8 : 4;
+    rc = pacoh_mlp_fwd(x, x_div, (const char*)theta + off_a * es, theta_stride, P, d_in, hidden, n_hidden, d_out_a, out_a, workspace, B, n, dtype, stream);
+    if (rc) return rc;
+    return pacoh_mlp_fwd(x, x_div, (const char*)theta + off_b * es, theta_stride, P, d_in, hidden, n_hidden, d_out_b, out_b, workspace, B, n, dtype, stream);
+}
+
+extern "C" size_t pacoh_mlp2_bwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out_a,
+                                                 int d_out_b, int dtype) {
+    if (P <= 0 || B <= 0 || n <= 0 || args_ok(d_in, hidden, n_hidden, d_out_a) || args_ok(d_in, hidden, n_hidden, d_out_b)) return 0;
+    if (pick_path(dtype, d_in, hidden, n_hidden, d_out_a, (long)B * n) == PATH_FUSED &&
+        pick_path(dtype, d_in, hidden, n_hidden, d_out_b, (long)B * n) == PATH_FUSED)
+        return mlp_fused_bwd_workspace(B, P, n, d_in, hidden, n_hidden, d_out_a, 2) + mlp_fused_bwd_workspace(B, P, n, d_in, hidden, n_hidden, d_out_b, 2);
+    const size_t a = pacoh_mlp_bwd_workspace_bytes(B, P, n, d_in, hidden, n_hidden, d_out_a, dtype);
+    const size_t b = pacoh_mlp_bwd_workspace_bytes(B, P, n, d_in, hidden, n_hidden, d_out_b, dtype);
+    return align256(a > b ? a : b);
+}
+
+extern "C" int pacoh_mlp2_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
+                              const int32_t* hidden, int n_hidden, long off_a, int d_out_a, const void* g_a, long off_b,
+                              int d_out_b, const void* g_b, void* d_theta, long d_theta_stride, int accumulate,
+                              void* workspace, int B, int n, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!g_a || !g_b || !d_theta || !workspace || !x || !theta || x_div <= 0 || P <= 0 || B <= 0 || n <= 0 || B % P != 0 || off_a < 0 || off_b < 0)
+        return PACOH_EINVAL;
+    int rc = args_ok(d_in, hidden, n_hidden, d_out_a);
+    if (rc || (rc = args_ok(d_in, hidden, n_hidden, d_out_b))) return rc;
+    if (pick_path(dtype, d_in, hidden, n_hidden, d_out_a, (long)B * n) == PATH_FUSED &&
+        pick_path(dtype, d_in, hidden, n_hidden, d_out_b, (long)B * n) == PATH_FUSED) {
+        const long off[2] = {off_a, off_b};
+        const int dout[2] = {d_out_a, d_out_b};
+        const void* const gs[2] = {g_a, g_b};
+        return mlp_fused_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 2, off, dout, gs, d_theta, d_theta_stride,
+                             accumulate, workspace, B, n, (hipStream_t)stream);
+    }
+    const size_t es = dtype == PACOH_F64 ? 8 : 4;
+    rc = pacoh_mlp_bwd(x, x_div, (const char*)theta + off_a * es, theta_stride, P, d_in, hidden, n_hidden, d_out_a, g_a,
+                       (char*)d_theta + off_a * es, d_theta_stride, accumulate, workspace, B, n, dtype, stream);
+    if (rc) return rc;
+    return pacoh_mlp_bwd(x, x_div, (const char*)theta + off_b * es, theta_stride, P, d_in, hidden, n_hidden, d_out_b, g_b,
+                         (char*)d_theta + off_b * es, d_theta_stride, accumulate, workspace, B, n, dtype, stream);
 }
 
 extern "C" int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, int T_, int P, int Wd,

@@ -1,0 +1,555 @@
+// Fused per-particle MLP, fp32, 1-4 tanh hidden layers of width <= 32, d_in <= 4, d_out <= 2 -- the mean and the
+// kernel-feature network of the reference's launchers (experiments/meta_GPR_{SVGD,vi}_base_exp.py: 4 x 32; class default
+// 2 x 32) -- forward and backward, ONE launch for both networks of a step (blockIdx.z selects the network).
+//
+// A wave owns a tile of 16*PB data points of one particle.  Activations are carried transposed, H^T[feature, point], as
+// 16x16 blocks in the v_mfma_f32_16x16x4_f32 accumulator layout (lane (r = l&15, g = l>>4), register s  <->
+// H^T[feature 4g+s][point r]); with the k index of a block product permuted as k = 4g+s that layout IS the B operand of
+// the next layer's product and of the delta recursion, weights are the A operand (one ds_read_b128 per 4 MFMAs).
+// Weight gradients contract over the point index and need the other orientation, X[feature r][point 4g+q] ("plain"):
+// 16x16 blocks are turned through a per-wave LDS scratch (row stride 17 words, conflict-free both ways).
+// The narrow first (d_in <= 4) and output (d_out <= 2) layers run on the VALU; their gradient partial sums are taken in
+// the PLAIN orientation, where a lane owns a feature and sums over points: 10 + 6 accumulator registers per lane and
+// two cross-lane adds at the very end (the earlier formulation summed in the transposed orientation, where a lane owns
+// a point: 66 lane-private accumulators per lane, kept in 67 KB of LDS).  Hidden-layer bias gradients fall out of the
+// same plain-orientation deltas the weight gradient needs.  Every wave writes its own partial slab; slabs are summed in
+// fixed order (deterministic).
+//
+// Replaces LinearVectorized / NeuralNetworkVectorized forward (meta_learn/models.py:295-317,343-349; the torch.bmm at
+// :313) and its autograd backward; P = 1 is NeuralNetwork.forward (models.py:211-217).
+#include "common.h"
+#include <stdlib.h>
+
+namespace pacoh {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int FMAXNH = 4;
+constexpr int LWH = 36;                       // leading dimension of a hidden weight matrix in LDS
+constexpr int HBLK = 32 * LWH + 32;           // one hidden layer: W[32][36] | b[32]
+constexpr int F_OFF_W1 = 0;                   // W1 [32][4]
+constexpr int F_OFF_B1 = 128;                 // b1 [32]
+constexpr int F_OFF_H = 160;                  // hidden layers 2..NH
+__host__ __device__ constexpr int f_off_out(int nh) { return F_OFF_H + (nh - 1) * HBLK; }      // W_out [2][32] | b_out [2] (+2 pad)
+__host__ __device__ constexpr int f_welems(int nh) { return f_off_out(nh) + 68; }
+constexpr int TSTRIDE = 8;                    // staged tile row: x[4] | g[2] | pad[2]
+constexpr int TRS = 16 * 17;                  // one transpose scratch block
+
+struct FusedNet {
+    long theta_off;            // element offset of the network's block inside a theta row
+    float* out;                // fwd: [B, n, d_out]
+    const float* g_out;        // bwd: [B, n, d_out]
+    float* slab;               // bwd: [slabs][P][D_net]
+    int d_out, D_net;
+};
+
+struct FusedArgs {
+    const float* x; int x_div;
+    const float* theta; long theta_stride;
+    FusedNet net[2];
+    int P, n, R;               // R = rows (points) per particle
+    int d_in, nh;
+    int h[FMAXNH];
+    int tiles_per_wg;
+};
+
+__device__ __forceinline__ f32x4 fmfma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// zero-padded weights of one particle's network -> LDS
+template <int NH>
+__device__ void fused_load_weights(float* wl, const float* __restrict__ th, const FusedArgs& a, int d_out) {
+    for (int q = threadIdx.x; q < f_welems(NH); q += blockDim.x) wl[q] = 0.0f;
+    __syncthreads();
+    int src = 0;
+    const int h0 = a.h[0], d_in = a.d_in;
+    for (int q = threadIdx.x; q < h0; q += blockDim.x) wl[F_OFF_B1 + q] = th[q];
+    for (int q = threadIdx.x; q < h0 * d_in; q += blockDim.x) { const int o = q / d_in, k = q - o * d_in; wl[F_OFF_W1 + o * 4 + k] = th[h0 + q]; }
+    src += h0 * (d_in + 1);
+    int prev = h0;
+#pragma unroll
+    for (int l = 1; l < NH; ++l) {
+        const int hl = a.h[l];
+        float* dst = wl + F_OFF_H + (l - 1) * HBLK;
+        for (int q = threadIdx.x; q < hl; q += blockDim.x) dst[32 * LWH + q] = th[src + q];
+        for (int q = threadIdx.x; q < hl * prev; q += blockDim.x) { const int o = q / prev, k = q - o * prev; dst[o * LWH + k] = th[src + hl + q]; }
+        src += hl * (prev + 1);
+        prev = hl;
+    }
+    float* dst = wl + f_off_out(NH);
+    for (int q = threadIdx.x; q < d_out; q += blockDim.x) dst[64 + q] = th[src + q];
+    for (int q = threadIdx.x; q < d_out * prev; q += blockDim.x) { const int o = q / prev, k = q - o * prev; dst[o * 32 + k] = th[src + d_out + q]; }
+    __syncthreads();
+}
+
+// Stage the tile's inputs (and upstream gradients) in the wave's LDS block: st[pt][0..3] = x (zero padded), st[pt][4..5] = g
+// (zero for rows past the end).  Returns the output row (problem*n + point) of this lane's point, or -1.
+template <int PB, bool BWD>
+__device__ __forceinline__ long stage_tile(const FusedArgs& a, const FusedNet& nt, int p, int row0, float* st, int lane) {
+    long orow = -1;
+    if (lane < 16 * PB) {
+        const int row = row0 + lane;
+        const bool valid = row < a.R;
+        const int rr = valid ? row : a.R - 1;
+        const int t = (int)((unsigned)rr / (unsigned)a.n), i = rr - t * a.n;
+        const int bi = t * a.P + p;
+        const int xb = a.x_div == 1 ? bi : (int)((unsigned)bi / (unsigned)a.x_div);
+        const float* xq = a.x + ((long)xb * a.n + i) * (long)a.d_in;
+        float4 xv;
+        xv.x = xq[0];
+        xv.y = a.d_in > 1 ? xq[1] : 0.0f;
+        xv.z = a.d_in > 2 ? xq[2] : 0.0f;
+        xv.w = a.d_in > 3 ? xq[3] : 0.0f;
+        *reinterpret_cast<float4*>(st + lane * TSTRIDE) = xv;
+        const long o = (long)bi * a.n + i;
+        if (BWD) {
+            const float* gq = nt.g_out + o * nt.d_out;
+            float2 gv;
+            gv.x = valid ? gq[0] : 0.0f;
+            gv.y = (valid && nt.d_out > 1) ? gq[1] : 0.0f;
+            *reinterpret_cast<float2*>(st + lane * TSTRIDE + 4) = gv;
+        }
+        orow = valid ? o : -1;
+    }
+    asm volatile("" ::: "memory");                   // LDS operations of one wave execute in order: only the compiler must keep it
+    return orow;
+}
+
+// H1^T = tanh(W1 x + b1): one MFMA per (feature block, point block), k = g covers d_in <= 4
+template <int PB>
+__device__ __forceinline__ void f_layer1(const float* wl, const float* st, int r, int g, f32x4 (&H)[2][PB]) {
+    float bx[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) bx[pb] = st[(pb * 16 + r) * TSTRIDE + g];
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+        f32x4 bias;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bias[s] = wl[F_OFF_B1 + fb * 16 + 4 * g + s];
+        const float aw = wl[F_OFF_W1 + (fb * 16 + r) * 4 + g];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            f32x4 acc = fmfma(aw, bx[pb], bias);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[s] = act_tanh<float>(acc[s]);
+            H[fb][pb] = acc;
+        }
+    }
+}
+
+// OUT^T = tanh(W IN^T + b), W: LDS [32][LWH] | b[32]
+template <int PB>
+__device__ __forceinline__ void f_hidden(const float* W, int r, int g, const f32x4 (&IN)[2][PB], f32x4 (&OUT)[2][PB]) {
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+        f32x4 bias;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bias[s] = W[32 * LWH + ob * 16 + 4 * g + s];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) OUT[ob][pb] = bias;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const float4 aw = *reinterpret_cast<const float4*>(W + (ob * 16 + r) * LWH + kb * 16 + 4 * g);
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                f32x4 acc = OUT[ob][pb];
+                acc = fmfma(aw.x, IN[kb][pb][0], acc); acc = fmfma(aw.y, IN[kb][pb][1], acc);
+                acc = fmfma(aw.z, IN[kb][pb][2], acc); acc = fmfma(aw.w, IN[kb][pb][3], acc);
+                OUT[ob][pb] = acc;
+            }
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) OUT[ob][pb][s] = act_tanh<float>(OUT[ob][pb][s]);
+    }
+}
+
+// D_in^T = (W^T D_out^T) .* (1 - H_in^2), written over H_in
+template <int PB>
+__device__ __forceinline__ void f_delta(const float* W, int r, int g, const f32x4 (&DOUT)[2][PB], f32x4 (&HIN)[2][PB]) {
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+        f32x4 acc[PB];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) acc[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            const float* wp = W + (ob * 16 + 4 * g) * LWH + fb * 16 + r;
+            const float a0 = wp[0], a1 = wp[LWH], a2 = wp[2 * LWH], a3 = wp[3 * LWH];
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                acc[pb] = fmfma(a0, DOUT[ob][pb][0], acc[pb]); acc[pb] = fmfma(a1, DOUT[ob][pb][1], acc[pb]);
+                acc[pb] = fmfma(a2, DOUT[ob][pb][2], acc[pb]); acc[pb] = fmfma(a3, DOUT[ob][pb][3], acc[pb]);
+            }
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { const float h = HIN[fb][pb][s]; HIN[fb][pb][s] = acc[pb][s] * (1.0f - h * h); }
+    }
+}
+
+// 16x16 block: lane (r,g) holds X[feature 4g+s][point r] in register s, returns X[feature r][point 4g+q] in register q
+__device__ __forceinline__ f32x4 f_turn(float* scr, const f32x4& v, int r, int g) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) scr[(4 * g + s) * 17 + r] = v[s];
+    asm volatile("" ::: "memory");
+    f32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = scr[r * 17 + 4 * g + q];
+    asm volatile("" ::: "memory");
+    return o;
+}
+
+__device__ __forceinline__ void f_wgrad(f32x4& acc, const f32x4& Ap, const f32x4& Bp) {
+    acc = fmfma(Ap[0], Bp[0], acc); acc = fmfma(Ap[1], Bp[1], acc);
+    acc = fmfma(Ap[2], Bp[2], acc); acc = fmfma(Ap[3], Bp[3], acc);
+}
+
+// ---- forward ------------------------------------------------------------------------------------------------------
+template <int NH, int PB, int MINW>
+__global__ void __launch_bounds__(256, MINW) mlp_fused_fwd_kernel(FusedArgs a) {
+    __shared__ __attribute__((aligned(16))) float wl[f_welems(NH)];
+    __shared__ __attribute__((aligned(16))) float stage[4][16 * PB * TSTRIDE];
+    const FusedNet& nt = a.net[blockIdx.z];
+    const int p = blockIdx.y;
+    fused_load_weights<NH>(wl, a.theta + (long)p * a.theta_stride + nt.theta_off, a, nt.d_out);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    float* st = stage[wave];
+    const float* wo = wl + f_off_out(NH);
+    float w3r[2][2][4];                                   // W_out[o][feature fb*16+4g+s] (rows >= d_out are zero)
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) w3r[o][fb][s] = wo[o * 32 + fb * 16 + 4 * g + s];
+    const float b30 = wo[64], b31 = wo[65];
+    constexpr int TP = 16 * PB;
+    for (int tl = wave; tl < a.tiles_per_wg; tl += 4) {
+        const int row0 = (blockIdx.x * a.tiles_per_wg + tl) * TP;
+        if (row0 >= a.R) break;
+        const long orow_l = stage_tile<PB, false>(a, nt, p, row0, st, lane);
+        f32x4 HA[2][PB], HB[2][PB];
+        f_layer1<PB>(wl, st, r, g, HA);
+#pragma unroll
+        for (int l = 1; l < NH; ++l) {
+            if (l & 1) f_hidden<PB>(wl + F_OFF_H + (l - 1) * HBLK, r, g, HA, HB);
+            else f_hidden<PB>(wl + F_OFF_H + (l - 1) * HBLK, r, g, HB, HA);
+        }
+        const f32x4 (&HL)[2][PB] = ((NH - 1) & 1) ? HB : HA;
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { v0 = fmaf(w3r[0][fb][s], HL[fb][pb][s], v0); v1 = fmaf(w3r[1][fb][s], HL[fb][pb][s], v1); }
+            v0 += __shfl_xor(v0, 16, 64); v0 += __shfl_xor(v0, 32, 64);           // sum over the four feature groups g
+            v1 += __shfl_xor(v1, 16, 64); v1 += __shfl_xor(v1, 32, 64);
+            const long orow = __shfl(orow_l, pb * 16 + r, 64);                     // the row of point pb*16 + r
+            if (g == 0 && orow >= 0) {
+                nt.out[orow * nt.d_out] = v0 + b30;
+                if (nt.d_out > 1) nt.out[orow * nt.d_out + 1] = v1 + b31;
+            }
+        }
+    }
+}
+
+// ---- backward -----------------------------------------------------------------------------------------------------
+template <int NH, int PB, int MINW>
+__global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
+    __shared__ __attribute__((aligned(16))) float wl[f_welems(NH)];
+    __shared__ __attribute__((aligned(16))) float stage[4][16 * PB * TSTRIDE];
+    __shared__ float tscr[4][2 * TRS];
+    const FusedNet& nt = a.net[blockIdx.z];
+    const int p = blockIdx.y;
+    fused_load_weights<NH>(wl, a.theta + (long)p * a.theta_stride + nt.theta_off, a, nt.d_out);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    float* st = stage[wave];
+    float* sc0 = tscr[wave];
+    float* sc1 = tscr[wave] + TRS;
+    const float* wo = wl + f_off_out(NH);
+    float w3r[2][2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) w3r[o][fb][s] = wo[o * 32 + fb * 16 + 4 * g + s];
+
+    // accumulators (plain orientation: this lane = feature r of a block, partial sums over the points 4g+q of every block)
+    f32x4 aW[NH > 1 ? NH - 1 : 1][2][2] = {};             // hidden weight gradients, accumulator layout [out 4g+s][in r]
+    float aBh[NH > 1 ? NH - 1 : 1][2] = {};               // hidden bias gradients [layer][feature block]
+    float aW1[2][4] = {}, aB1[2] = {};                    // first layer [feature block][k]
+    float aWo[2][2] = {}, aBo[2] = {};                    // output layer [o][feature block]
+
+    constexpr int TP = 16 * PB;
+    for (int tl = wave; tl < a.tiles_per_wg; tl += 4) {
+        const int row0 = (blockIdx.x * a.tiles_per_wg + tl) * TP;
+        if (row0 >= a.R) break;
+        stage_tile<PB, true>(a, nt, p, row0, st, lane);
+        // ---- forward recompute, all activations kept ---------------------------------------------------------------
+        f32x4 H[NH][2][PB];
+        f_layer1<PB>(wl, st, r, g, H[0]);
+#pragma unroll
+        for (int l = 1; l < NH; ++l) f_hidden<PB>(wl + F_OFF_H + (l - 1) * HBLK, r, g, H[l - 1], H[l]);
+        // ---- output layer (VALU): dW_out, db_out in the plain orientation; delta of the last hidden layer over H[NH-1] ---
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const f32x4 Hp0 = f_turn(sc0, H[NH - 1][0][pb], r, g);
+            const f32x4 Hp1 = f_turn(sc1, H[NH - 1][1][pb], r, g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float2 gp = *reinterpret_cast<const float2*>(st + (pb * 16 + 4 * g + q) * TSTRIDE + 4);
+                aWo[0][0] = fmaf(gp.x, Hp0[q], aWo[0][0]); aWo[0][1] = fmaf(gp.x, Hp1[q], aWo[0][1]);
+                aWo[1][0] = fmaf(gp.y, Hp0[q], aWo[1][0]); aWo[1][1] = fmaf(gp.y, Hp1[q], aWo[1][1]);
+                aBo[0] += gp.x; aBo[1] += gp.y;
+            }
+            const float2 gr = *reinterpret_cast<const float2*>(st + (pb * 16 + r) * TSTRIDE + 4);
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float h = H[NH - 1][fb][pb][s];
+                    const float d = fmaf(w3r[1][fb][s], gr.y, w3r[0][fb][s] * gr.x);
+                    H[NH - 1][fb][pb][s] = d * (1.0f - h * h);
+                }
+        }
+        // ---- hidden layers NH .. 2: H[l] holds delta_l^T, H[l-1] the activations below it ---------------------------------
+#pragma unroll
+        for (int l = NH - 1; l >= 1; --l) {
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                f32x4 Dp[2], Hp[2];
+                Dp[0] = f_turn(sc0, H[l][0][pb], r, g);     Hp[0] = f_turn(sc1, H[l - 1][0][pb], r, g);
+                Dp[1] = f_turn(sc0, H[l][1][pb], r, g);     Hp[1] = f_turn(sc1, H[l - 1][1][pb], r, g);
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob) {
+                    aBh[l - 1][ob] += (Dp[ob][0] + Dp[ob][1]) + (Dp[ob][2] + Dp[ob][3]);
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) f_wgrad(aW[l - 1][ob][kb], Dp[ob], Hp[kb]);
+                }
+            }
+            f_delta<PB>(wl + F_OFF_H + (l - 1) * HBLK, r, g, H[l], H[l - 1]);
+        }
+        // ---- first layer (VALU, plain orientation): H[0] holds delta_1^T ----------------------------------------------------
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const f32x4 Dp0 = f_turn(sc0, H[0][0][pb], r, g);
+            const f32x4 Dp1 = f_turn(sc1, H[0][1][pb], r, g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 xp = *reinterpret_cast<const float4*>(st + (pb * 16 + 4 * g + q) * TSTRIDE);
+                aW1[0][0] = fmaf(Dp0[q], xp.x, aW1[0][0]); aW1[0][1] = fmaf(Dp0[q], xp.y, aW1[0][1]);
+                aW1[0][2] = fmaf(Dp0[q], xp.z, aW1[0][2]); aW1[0][3] = fmaf(Dp0[q], xp.w, aW1[0][3]);
+                aW1[1][0] = fmaf(Dp1[q], xp.x, aW1[1][0]); aW1[1][1] = fmaf(Dp1[q], xp.y, aW1[1][1]);
+                aW1[1][2] = fmaf(Dp1[q], xp.z, aW1[1][2]); aW1[1][3] = fmaf(Dp1[q], xp.w, aW1[1][3]);
+                aB1[0] += Dp0[q]; aB1[1] += Dp1[q];
+            }
+        }
+    }
+    // ---- sums over the four point groups g, then this wave's slab in the reference's flattened layout -------------------
+    auto rg = [](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
+    float* dst = nt.slab + ((long)(blockIdx.x * 4 + wave) * a.P + p) * nt.D_net;
+    const int d_in = a.d_in, h0 = a.h[0];
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+        const int o = fb * 16 + r;
+        const float b = rg(aB1[fb]);
+        if (g == 0 && o < h0) dst[o] = b;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float v = rg(aW1[fb][k]); if (g == 0 && o < h0 && k < d_in) dst[h0 + o * d_in + k] = v; }
+    }
+    int off = h0 * (d_in + 1), prev = h0;
+#pragma unroll
+    for (int l = 1; l < NH; ++l) {
+        const int hl = a.h[l];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            const float b = rg(aBh[l - 1][ob]);
+            if (g == 0 && ob * 16 + r < hl) dst[off + ob * 16 + r] = b;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int o = ob * 16 + 4 * g + s, k = kb * 16 + r;
+                    if (o < hl && k < prev) dst[off + hl + o * prev + k] = aW[l - 1][ob][kb][s];
+                }
+        }
+        off += hl * (prev + 1);
+        prev = hl;
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const float b = rg(aBo[o]);
+        if (lane == 0 && o < nt.d_out) dst[off + o] = b;
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) { const float v = rg(aWo[o][fb]); if (g == 0 && o < nt.d_out && fb * 16 + r < prev) dst[off + nt.d_out + o * prev + fb * 16 + r] = v; }
+    }
+}
+
+// out[p, w] (+)= sum_c in[c, p, w] for up to two networks in one launch (blockIdx.y): 8 lanes per output element split the
+// slabs, fixed order -> deterministic
+struct SlabReduce { const float* in; float* out; int Wd; };
+__global__ void __launch_bounds__(256) fused_reduce_slab_kernel(SlabReduce s0, SlabReduce s1, long out_stride, int accumulate, int C, int P) {
+    const SlabReduce& sr = blockIdx.y ? s1 : s0;
+    const long tot = (long)P * sr.Wd;
+    const long idx = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int part = threadIdx.x & 7;
+    float s = 0;
+    if (idx < tot) for (int c = part; c < C; c += 8) s += sr.in[(long)c * tot + idx];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (idx < tot && part == 0) {
+        const int p = (int)(idx / sr.Wd), w = (int)(idx - (long)p * sr.Wd);
+        float* o = sr.out + (long)p * out_stride + w;
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+static int fused_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && e[0]) ? atoi(e) : dflt;
+}
+
+bool mlp_fused_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_out) {
+    static const bool on = fused_env("PACOH_DISABLE_FUSED_MLP", 0) == 0;
+    if (!on || n_hidden < 1 || n_hidden > FMAXNH || d_in < 1 || d_in > 4 || d_out < 1 || d_out > 2) return false;
+    for (int l = 0; l < n_hidden; ++l) if (hidden[l] < 1 || hidden[l] > 32) return false;
+    return true;
+}
+
+static int fused_dnet(int d_in, const int32_t* hidden, int n_hidden, int d_out) {
+    int prev = d_in, c = 0;
+    for (int l = 0; l < n_hidden; ++l) { c += hidden[l] * (prev + 1); prev = hidden[l]; }
+    return c + d_out * (prev + 1);
+}
+
+static int fused_bwd_pb(int n_hidden) { return fused_env("PACOH_FUSED_BWD_PB", n_hidden <= 2 ? 4 : 2); }
+static int fused_fwd_pb(int) { return fused_env("PACOH_FUSED_FWD_PB", 4); }
+
+// resident workgroups of a kernel on the whole chip (occupancy query, cached per kernel)
+template <typename K> static int resident_wgs(K kern) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    return per_cu * cus;
+}
+
+// Workgroups per (particle, network) for the backward: a grid slightly above a multiple of what is resident costs a whole
+// extra round; pick the tiles per workgroup (a wave takes every 4th tile) that minimises rounds x (tiles per wave + overhead)
+static int fused_chunks(int R, int P, int nets, int tp, int resident, double overhead) {
+    const int tiles = (R + tp - 1) / tp;
+    int best_tpw = 4;
+    double best = 1e30;
+    for (int tpw = 4; tpw <= 1024; tpw += 4) {
+        const long wgs = (long)((tiles + tpw - 1) / tpw) * P * nets;
+        const long rounds = (wgs + resident - 1) / resident;
+        const double cost = (double)rounds * (tpw / 4 + overhead);
+        if (cost < best - 1e-9) { best = cost; best_tpw = tpw; }
+        if (tpw >= tiles) break;
+    }
+    return (tiles + best_tpw - 1) / best_tpw;
+}
+
+static void fused_fill(FusedArgs& a, const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
+                       const int32_t* hidden, int n_hidden, int B, int n) {
+    a.x = (const float*)x; a.x_div = x_div; a.theta = (const float*)theta; a.theta_stride = theta_stride;
+    a.P = P; a.n = n; a.R = (B / P) * n; a.d_in = d_in; a.nh = n_hidden;
+    for (int l = 0; l < FMAXNH; ++l) a.h[l] = l < n_hidden ? hidden[l] : 0;
+}
+
+// M is applied to the parenthesised kernel instantiation (the commas of the template arguments must not split macro arguments)
+#define PACOH_FUSED_DISPATCH(KERNEL, nh, pb, M)                                                          \
+    do {                                                                                                 \
+        if (pb == 4) {                                                                                   \
+            if (nh == 1) { M((KERNEL<1, 4, 2>)); } else if (nh == 2) { M((KERNEL<2, 4, 2>)); }            \
+            else if (nh == 3) { M((KERNEL<3, 4, 1>)); } else { M((KERNEL<4, 4, 1>)); }                    \
+        } else {                                                                                         \
+            if (nh == 1) { M((KERNEL<1, 2, 2>)); } else if (nh == 2) { M((KERNEL<2, 2, 2>)); }            \
+            else if (nh == 3) { M((KERNEL<3, 2, 2>)); } else { M((KERNEL<4, 2, 2>)); }                    \
+        }                                                                                                \
+    } while (0)
+
+// nets = 1 or 2 networks of the SAME hidden shape at element offsets off[k] of the theta rows
+int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
+                  int n_hidden, int nets, const long* off, const int* d_out, void* const* out, int B, int n, hipStream_t s) {
+    FusedArgs a = {};
+    fused_fill(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, B, n);
+    for (int k = 0; k < nets; ++k) { a.net[k].theta_off = off[k]; a.net[k].out = (float*)out[k]; a.net[k].d_out = d_out[k]; }
+    const int pb = fused_fwd_pb(n_hidden) == 2 ? 2 : 4;
+    const int tiles = (a.R + 16 * pb - 1) / (16 * pb);
+    a.tiles_per_wg = fused_env("PACOH_FUSED_FWD_TPW", 8);          // 2 tiles per wave
+    const int wgs = (tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+#define PACOH_LAUNCH_FWD(K) hipLaunchKernelGGL((K), dim3(wgs, P, nets), dim3(256), 0, s, a)
+    if (pb == 4) {
+        if (n_hidden == 1) PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<1, 4, 4>)); else if (n_hidden == 2) PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<2, 4, 4>));
+        else if (n_hidden == 3) PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<3, 4, 4>)); else PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<4, 4, 4>));
+    } else {
+        if (n_hidden == 1) PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<1, 2, 4>)); else if (n_hidden == 2) PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<2, 2, 4>));
+        else if (n_hidden == 3) PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<3, 2, 4>)); else PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<4, 2, 4>));
+    }
+#undef PACOH_LAUNCH_FWD
+    return launch_status();
+}
+
+struct FusedBwdPlan { int pb, chunks, tiles_per_wg; };
+
+static FusedBwdPlan fused_bwd_plan(int R, int P, int nets, int n_hidden) {
+    FusedBwdPlan pl;
+    pl.pb = fused_bwd_pb(n_hidden) == 2 ? 2 : 4;
+    static int resident[FMAXNH + 1][2] = {};
+    int& res = resident[n_hidden][pl.pb == 4];
+    if (res == 0) {
+#define PACOH_OCC(K) res = resident_wgs(K)
+        PACOH_FUSED_DISPATCH(mlp_fused_bwd_kernel, n_hidden, pl.pb, PACOH_OCC);
+#undef PACOH_OCC
+    }
+    const int tp = 16 * pl.pb;
+    pl.chunks = fused_chunks(R, P, nets, tp, res, 0.4 * 64 / tp);
+    const int tiles = (R + tp - 1) / tp;
+    pl.tiles_per_wg = (tiles + pl.chunks - 1) / pl.chunks;
+    return pl;
+}
+
+// bytes of slab space for ONE network of a (possibly two-network) backward launch
+size_t mlp_fused_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int nets) {
+    const FusedBwdPlan pl = fused_bwd_plan((B / P) * n, P, nets, n_hidden);
+    return (size_t)pl.chunks * 4 * P * fused_dnet(d_in, hidden, n_hidden, d_out) * sizeof(float);
+}
+
+int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
+                  int n_hidden, int nets, const long* off, const int* d_out, const void* const* g_out, void* d_theta,
+                  long d_theta_stride, int accumulate, void* workspace, int B, int n, hipStream_t s) {
+    FusedArgs a = {};
+    fused_fill(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, B, n);
+    const FusedBwdPlan pl = fused_bwd_plan(a.R, P, nets, n_hidden);
+    a.tiles_per_wg = pl.tiles_per_wg;
+    float* ws = (float*)workspace;
+    SlabReduce sr[2] = {};
+    int wmax = 0;
+    for (int k = 0; k < nets; ++k) {
+        a.net[k].theta_off = off[k]; a.net[k].g_out = (const float*)g_out[k]; a.net[k].d_out = d_out[k];
+        a.net[k].D_net = fused_dnet(d_in, hidden, n_hidden, d_out[k]);
+        a.net[k].slab = ws;
+        sr[k].in = ws; sr[k].out = (float*)d_theta + off[k]; sr[k].Wd = a.net[k].D_net;
+        ws += (size_t)pl.chunks * 4 * P * a.net[k].D_net;
+        if (a.net[k].D_net > wmax) wmax = a.net[k].D_net;
+    }
+#define PACOH_LAUNCH_BWD(K) hipLaunchKernelGGL(K, dim3(pl.chunks, P, nets), dim3(256), 0, s, a)
+    PACOH_FUSED_DISPATCH(mlp_fused_bwd_kernel, n_hidden, pl.pb, PACOH_LAUNCH_BWD);
+#undef PACOH_LAUNCH_BWD
+    const long tot = (long)P * wmax;
+    hipLaunchKernelGGL(fused_reduce_slab_kernel, dim3((unsigned)((tot * 8 + 255) / 256), nets), dim3(256), 0, s,
+                       sr[0], sr[1], d_theta_stride, accumulate, pl.chunks * 4, P);
+    return launch_status();
+}
+
+}  // namespace pacoh

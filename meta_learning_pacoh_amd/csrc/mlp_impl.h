@@ -13,12 +13,14 @@
 
 namespace pacoh {
 
+constexpr int VALU_MAX_HIDDEN = 3;    // limits of THIS path (the general layer-wise path, mlp_layers.hip, has none)
+constexpr int VALU_MAX_WIDTH = 64;
 constexpr int DP = 16;   // padded input width
 constexpr int OP = 8;    // padded output width
 
 struct MlpDims {
     int d_in, d_out, n_hidden;
-    int hidden[PACOH_MAX_HIDDEN_LAYERS];
+    int hidden[VALU_MAX_HIDDEN];
 };
 
 template <typename T>
@@ -387,13 +389,13 @@ __global__ void reduce_chunks_kernel(const T* __restrict__ in, T* __restrict__ o
 
 static int fill_dims(MlpDims& d, int d_in, const int32_t* hidden, int n_hidden, int d_out, int& HPsel) {
     if (d_in <= 0 || d_out <= 0 || n_hidden < 0 || (n_hidden > 0 && !hidden)) return PACOH_EINVAL;
-    if (d_in > DP || d_out > OP || n_hidden > PACOH_MAX_HIDDEN_LAYERS) return PACOH_ELIMIT;
+    if (d_in > DP || d_out > OP || n_hidden > VALU_MAX_HIDDEN) return PACOH_ELIMIT;
     d.d_in = d_in; d.d_out = d_out; d.n_hidden = n_hidden;
     int mx = 0;
-    for (int l = 0; l < PACOH_MAX_HIDDEN_LAYERS; ++l) d.hidden[l] = 0;
+    for (int l = 0; l < VALU_MAX_HIDDEN; ++l) d.hidden[l] = 0;
     for (int l = 0; l < n_hidden; ++l) {
         if (hidden[l] <= 0) return PACOH_EINVAL;
-        if (hidden[l] > PACOH_MAX_WIDTH) return PACOH_ELIMIT;
+        if (hidden[l] > VALU_MAX_WIDTH) return PACOH_ELIMIT;
         d.hidden[l] = hidden[l];
         mx = hidden[l] > mx ? hidden[l] : mx;
     }

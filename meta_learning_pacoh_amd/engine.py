@@ -156,6 +156,13 @@ class GPEngine:
         off_ls, f, off_os, off_noise, _ = self._hyper_offsets()
         return L.hyper_fwd(theta, off_ls, f, off_os, off_noise, self.noise_floor)
 
+    def _paired_nets(self):
+        """both networks present with the same hidden shape -> (mean block offset, kernel block offset), else None"""
+        lay = self.layout
+        if lay.mean_module == 'NN' and lay.covar_module == 'NN' and lay.mean_nn_layers == lay.kernel_nn_layers:
+            return lay.block_range('mean_nn.')[0], lay.block_range('kernel_nn.')[0]
+        return None
+
     def _features(self, theta, x, T, n, theta_per_task=False):
         """kernel inputs z (+ divisor) and mean (+ mode) for B = T*P problems (b = t*P + p: task t, parameter row p).
         theta_per_task: theta holds T*S rows, S of its own per task -- the same kernels with P = T*S parameter rows, ONE
@@ -163,6 +170,11 @@ class GPEngine:
         lay = self.layout
         P, D = theta.shape
         B, x_div = (P, P // T) if theta_per_task else (T * P, P)
+        pair = self._paired_nets()
+        if pair is not None:                               # mean + kernel-feature network in one call (one launch on the fused path)
+            mean, z = L.mlp2_fwd(x, x_div, theta, P, lay.input_dim, list(lay.mean_nn_layers), pair[0], 1, pair[1],
+                                 lay.feature_dim, B, n)
+            return z, 1, mean.reshape(B, n), L.MEAN_VECTOR
         if lay.covar_module == 'NN':
             lo, _ = lay.block_range('kernel_nn.')
             z = L.mlp_fwd(x, x_div, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers), lay.feature_dim, B, n)
@@ -202,22 +214,30 @@ class GPEngine:
         dev, dt = theta.device, theta.dtype
         ls, os_, noise = self._hypers(theta)
         z, z_div, mean, mode = self._features(theta, batch.x, T, n)
-        gkey = (B, float(weight), dt, dev)
-        g = self._ws.get(gkey)
-        if g is None:
-            g = self._ws[gkey] = torch.full((B,), float(weight), dtype=dt, device=dev)
+        gkey = ('g', B, dt, dev)                        # ONE upstream-gradient vector per batch shape, refilled when the weight changes
+        ent = self._ws.get(gkey)
+        if ent is None or ent[1] != float(weight):
+            g = ent[0] if ent is not None else torch.empty(B, dtype=dt, device=dev)
+            g.fill_(float(weight))
+            ent = self._ws[gkey] = (g, float(weight))
+        g = ent[0]
         lml, d_z, d_mean, d_ls, d_os, d_noise, info = L.gp_lml_fwdbwd(
             z, z_div, mean, mode, batch.y, P, ls, os_, noise, B, P,
             n_valid=batch.n_valid if batch.ragged else None, g_lml=g, want_dz=(lay.covar_module == 'NN'))
         grad = grad_out if grad_out is not None else torch.empty(P, D, dtype=dt, device=dev)   # every block is written below
-        if lay.covar_module == 'NN':
-            lo, _ = lay.block_range('kernel_nn.')
-            self._ws['k'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers),
-                                      lay.feature_dim, d_z, grad[:, lo:], D, False, B, n, self._ws.get('k'))
-        if lay.mean_module == 'NN':
-            lo, _ = lay.block_range('mean_nn.')
-            self._ws['m'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.mean_nn_layers), 1,
-                                      d_mean.reshape(B, n, 1), grad[:, lo:], D, False, B, n, self._ws.get('m'))
+        pair = self._paired_nets()
+        if pair is not None:
+            self._ws['mk'] = L.mlp2_bwd(batch.x, P, theta, P, lay.input_dim, list(lay.mean_nn_layers), pair[0], 1,
+                                        d_mean.reshape(B, n, 1), pair[1], lay.feature_dim, d_z, grad, False, B, n, self._ws.get('mk'))
+        else:
+            if lay.covar_module == 'NN':
+                lo, _ = lay.block_range('kernel_nn.')
+                self._ws['k'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers),
+                                          lay.feature_dim, d_z, grad[:, lo:], D, False, B, n, self._ws.get('k'))
+            if lay.mean_module == 'NN':
+                lo, _ = lay.block_range('mean_nn.')
+                self._ws['m'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.mean_nn_layers), 1,
+                                          d_mean.reshape(B, n, 1), grad[:, lo:], D, False, B, n, self._ws.get('m'))
         # hyper-parameters (+ constant mean): sum over tasks and softplus chain rule in one launch
         off_ls, f, off_os, off_noise, off_c = self._hyper_offsets()
         L.hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_c, d_ls, d_os, d_noise,

@@ -155,9 +155,55 @@ def make_mixture_quantiles():
     print('mixture_quantiles_ref.npz written')
 
 
+def make_deep_mlp():
+    """The networks the reference's launchers actually build -- NeuralNetworkVectorized 4 x 32 (experiments/
+    meta_GPR_SVGD_base_exp.py:29-30,83), the shared NeuralNetwork 4 x 128 of PACOH-MAP (meta_GPR_mll_base_exp.py:29-30) and an
+    irregular layer_sizes tuple (models.py:328-349 takes any) -- forward outputs and the autograd gradient of sum(out * g)
+    with respect to the flattened parameters -> deep_mlp_ref.npz"""
+    install_shims()
+    sys.path.insert(0, REF)
+    import meta_learn.models as models
+    fx = {}
+    cases = {'v4x32_d1_o2': (1, 2, (32, 32, 32, 32), 5, 23), 'v4x32_d4_o1': (4, 1, (32, 32, 32, 32), 3, 70),
+             'v3x32_d2_o2': (2, 2, (32, 32, 32), 4, 19), 'v4x128_d2_o2': (2, 2, (128, 128, 128, 128), 2, 37),
+             'v_irregular_d3_o3': (3, 3, (40, 17, 128, 9, 64), 3, 21)}
+    for tag, (d_in, d_out, layers, P, n) in cases.items():
+        gen = torch.Generator().manual_seed(len(tag) + d_in + n)
+        net = models.NeuralNetworkVectorized(d_in, d_out, layer_sizes=layers)
+        D = sum(int(v[-1]) for v in net.parameter_shapes().values())
+        scale = torch.cat([torch.full((int(v[-1]),), 3.0 if k.endswith('bias') else 0.5) for k, v in net.parameter_shapes().items()])
+        theta = (torch.randn(P, D, generator=gen) * scale * 0.6).requires_grad_(True)
+        net.set_parameters_as_vector(theta)
+        x = torch.randn(n, d_in, generator=gen)
+        g = torch.randn(P, n, d_out, generator=gen)
+        out = net(x)                                          # 2-D inputs are tiled over the P parameter sets (models.py:305-309)
+        (out * g).sum().backward()
+        fx[tag + '_theta'], fx[tag + '_x'], fx[tag + '_g'] = theta.detach().numpy(), x.numpy(), g.numpy()
+        fx[tag + '_out'], fx[tag + '_grad'] = out.detach().numpy(), theta.grad.numpy()
+        fx[tag + '_layers'] = np.array(layers)
+    # the shared-weight torch.nn network of PACOH-MAP at the launcher's 4 x 128, its parameters flattened bias-before-weight
+    torch.manual_seed(28)
+    net = models.NeuralNetwork(input_dim=1, output_dim=2, layer_sizes=(128, 128, 128, 128))
+    names = ['fc_1', 'fc_2', 'fc_3', 'fc_4', 'out']
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(10, 1, generator=gen)                     # 2 tasks x 5 points, the launcher's batch (meta_GPR_mll_base_exp.py:33,40)
+    g = torch.randn(10, 2, generator=gen)
+    out = net(x)
+    (out * g).sum().backward()
+    fx['s4x128_theta'] = torch.cat([torch.cat([getattr(net, k).bias.detach().reshape(-1), getattr(net, k).weight.detach().reshape(-1)])
+                                    for k in names]).numpy()
+    fx['s4x128_grad'] = torch.cat([torch.cat([getattr(net, k).bias.grad.reshape(-1), getattr(net, k).weight.grad.reshape(-1)])
+                                   for k in names]).numpy()
+    fx['s4x128_x'], fx['s4x128_g'], fx['s4x128_out'] = x.numpy(), g.numpy(), out.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, 'deep_mlp_ref.npz'), **fx)
+    print('deep_mlp_ref.npz written')
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'mixture_quantiles':
         return make_mixture_quantiles()
+    if len(sys.argv) > 1 and sys.argv[1] == 'deep_mlp':
+        return make_deep_mlp()
     if len(sys.argv) > 1 and sys.argv[1] == 'vi_full':
         return make_vi_full()
     assert os.path.isdir(REF), 'reference not mounted -- fixtures can only be regenerated in the build container'
@@ -325,6 +371,7 @@ def main():
         json.dump(demo_log, f, indent=1)
     make_vi_full()
     make_mixture_quantiles()
+    make_deep_mlp()
     print('fixtures written to', OUT)
 
 

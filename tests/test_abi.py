@@ -35,7 +35,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_abi_version_and_host_side_queries(lib):
-    assert lib.pacoh_abi_version() == 1
+    assert lib.pacoh_abi_version() == 2
     assert lib.pacoh_gp_small_max_n(0, 0) >= 128 and lib.pacoh_gp_small_max_n(0, 1) >= 128      # fp32: cfg #4 fits
     assert lib.pacoh_gp_small_max_n(1, 1) >= 64                                                  # fp64: cfg #3 fits
     assert lib.pacoh_gp_small_max_n(7, 0) == -3
@@ -61,8 +61,15 @@ def test_argument_validation_returns_error_codes_without_launching(lib):
                                    null, fake, null, 2, 1, 4096, 2, 0, null) == ELIMIT       # n too large for LDS
     assert lib.pacoh_svgd_phi(fake, fake, 0.0, 0, fake, null, fake, 65, 10, 0, null) == ELIMIT
     assert lib.pacoh_adam_step(null, null, null, null, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 10, 0, null) == EINVAL
-    hidden = (ctypes.c_int32 * 1)(128)
-    assert lib.pacoh_mlp_fwd(fake, 1, fake, 10, 1, 2, hidden, 1, 1, fake, 1, 4, 0, null) == ELIMIT   # width > 64
+    hidden = (ctypes.c_int32 * 1)(1 << 20)
+    assert lib.pacoh_mlp_fwd(fake, 1, fake, 10, 1, 2, hidden, 1, 1, fake, null, 1, 4, 0, null) == ELIMIT   # width > PACOH_MLP_MAX_WIDTH
+    hidden = (ctypes.c_int32 * 4)(128, 128, 128, 128)            # the PACOH-MAP launcher's network: general path, needs a workspace
+    assert lib.pacoh_mlp_fwd_workspace_bytes(10, 1, 5, 1, hidden, 4, 2, 0) > 0
+    assert lib.pacoh_mlp_fwd(fake, 1, fake, 10, 1, 1, hidden, 4, 2, fake, null, 10, 5, 0, null) == EINVAL  # ... refused without one
+    hidden = (ctypes.c_int32 * 4)(32, 32, 32, 32)                # the SVGD / VI launchers' network: register-resident, no workspace
+    assert lib.pacoh_mlp_fwd_workspace_bytes(20, 10, 20, 1, hidden, 4, 2, 0) == 0
+    assert lib.pacoh_mlp2_fwd_workspace_bytes(20, 10, 20, 1, hidden, 4, 1, 2, 0) == 0
+    assert lib.pacoh_mlp2_bwd_workspace_bytes(20, 10, 20, 1, hidden, 4, 1, 2, 0) > 0
 
 
 def test_no_cpu_fallback():

@@ -284,12 +284,38 @@ MLP_CASES = [  # P, T, n, d_in, hidden, d_out
     (2, 2, 7, 2, (), 5),
     (2, 3, 300, 16, (16,), 8),
     (2, 2, 10, 2, (16, 16, 16), 2),
+    (3, 5, 64, 4, (32, 32, 32, 32), 2),      # the SVGD / VI launchers' networks (experiments/meta_GPR_SVGD_base_exp.py:29-30)
+    (3, 5, 64, 4, (32, 32, 32, 32), 1),
+    (2, 3, 20, 1, (32, 32, 32), 2),
+    (2, 7, 33, 2, (24, 32, 9, 31), 2),       # ragged widths <= 32, tiles crossing task boundaries
+    (1, 2, 5, 1, (128, 128, 128, 128), 2),   # PACOH-MAP launcher (experiments/meta_GPR_mll_base_exp.py:29-30): shared 4 x 128 net
+    (2, 3, 70, 4, (128, 128, 128, 128), 1),
+    (2, 2, 21, 3, (40, 17, 128, 9, 64), 3),  # any layer_sizes (models.py:328-349)
+    (1, 1, 1, 1, (7,) * 9, 1),               # deep and tiny
+    (2, 2, 40, 20, (48,), 11),               # wide io
+    (1, 3, 300, 2, (), 1),
 ]
+MLP_PATHS = [None, 'mfma', 'valu', 'layers']      # PACOH_MLP_PATH: first implementation the dispatcher may pick
+
+
+@pytest.fixture
+def mlp_path(request):
+    old = os.environ.get('PACOH_MLP_PATH')
+    if request.param is None:
+        os.environ.pop('PACOH_MLP_PATH', None)
+    else:
+        os.environ['PACOH_MLP_PATH'] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop('PACOH_MLP_PATH', None)
+    else:
+        os.environ['PACOH_MLP_PATH'] = old
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('mlp_path', MLP_PATHS, indirect=True)
 @pytest.mark.parametrize('case', MLP_CASES)
-def test_mlp_fwd_bwd(L, dtype, case):
+def test_mlp_fwd_bwd(L, dtype, case, mlp_path):
     P, T, n, d_in, hidden, d_out = case
     B = T * P
     layout = O.nn_param_layout(d_in, d_out, hidden)
@@ -317,6 +343,75 @@ def test_mlp_fwd_bwd(L, dtype, case):
     th_c = theta_full[:, pad:pad + Dn].contiguous().to(DEV)
     L.mlp_bwd(x.to(DEV), P, th_c, Dn, P, d_in, list(hidden), d_out, gout.to(DEV), d2, Dn, True, B, n)
     assert relerr(d2.cpu() - 1, th.grad) < (2e-4 if dtype == torch.float32 else 1e-10)
+
+
+MLP2_CASES = [  # P, T, n, d_in, hidden, x_div_is_P
+    (20, 8, 64, 4, (32, 32), True),                  # cfg #3 shape
+    (10, 2, 20, 1, (32, 32, 32, 32), True),          # experiments/meta_GPR_SVGD_base_exp.py defaults: 4 x 32, 20 points, 10 particles
+    (3, 3, 37, 2, (32,), True),
+    (4, 5, 16, 3, (20, 32, 11), False),              # inputs per problem (x_div = 1)
+    (2, 3, 9, 2, (128, 128, 128, 128), True),        # not fused: two sequential general-path calls
+    (2, 2, 12, 6, (32, 32), True),                   # d_in > 4: padded-io MFMA kernels, twice
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('case', MLP2_CASES)
+def test_mlp2_mean_and_kernel_network_in_one_call(L, dtype, case):
+    """pacoh_mlp2_fwd / pacoh_mlp2_bwd: the mean (d_out 1) and the kernel-feature (d_out 2) network of a step, blocks inside one
+    particle matrix in the reference's order (mean_nn.* first, random_gp.py:33-46) vs the oracle, and vs the single-network calls"""
+    P, T, n, d_in, hidden, shared_x = case
+    B = T * P
+    Dm = sum(O.nn_param_layout(d_in, 1, hidden).values())
+    Dk = sum(O.nn_param_layout(d_in, 2, hidden).values())
+    D = Dm + Dk + 3
+    g = torch.Generator().manual_seed(Dm + n)
+    theta = 0.5 * torch.randn(P, D, generator=g, dtype=dtype)
+    x = torch.randn(T if shared_x else B, n, d_in, generator=g, dtype=dtype)
+    x_div = P if shared_x else 1
+    g_m = torch.randn(B, n, 1, generator=g, dtype=dtype)
+    g_k = torch.randn(B, n, 2, generator=g, dtype=dtype)
+    th_dev, x_dev = theta.to(DEV), x.to(DEV)
+    mean, z = L.mlp2_fwd(x_dev, x_div, th_dev, P, d_in, list(hidden), 0, 1, Dm, 2, B, n)
+    th = theta.double().clone().requires_grad_(True)
+    xb = (x.unsqueeze(1).expand(T, P, n, d_in) if shared_x else x.reshape(T, P, n, d_in)).double()
+    ref_m = torch.stack([O.mlp_vectorized_forward(xb[t], th[:, :Dm], d_in, 1, hidden) for t in range(T)]).reshape(B, n, 1)
+    ref_k = torch.stack([O.mlp_vectorized_forward(xb[t], th[:, Dm:Dm + Dk], d_in, 2, hidden) for t in range(T)]).reshape(B, n, 2)
+    tol_f, tol_b = (1e-5, 2e-4) if dtype == torch.float32 else (1e-12, 1e-10)
+    assert relerr(mean, ref_m) < tol_f and relerr(z, ref_k) < tol_f
+    ((ref_m * g_m.double()).sum() + (ref_k * g_k.double()).sum()).backward()
+    grad = torch.full((P, D), 5.0, dtype=dtype, device=DEV)
+    L.mlp2_bwd(x_dev, x_div, th_dev, P, d_in, list(hidden), 0, 1, g_m.to(DEV), Dm, 2, g_k.to(DEV), grad, False, B, n)
+    assert float((grad[:, Dm + Dk:] - 5).abs().max()) == 0                       # outside the two blocks: untouched
+    assert relerr(grad[:, :Dm + Dk], th.grad[:, :Dm + Dk]) < tol_b
+    # the single-network entry points give the same numbers
+    m1 = L.mlp_fwd(x_dev, x_div, th_dev, D, P, d_in, list(hidden), 1, B, n)
+    z1 = L.mlp_fwd(x_dev, x_div, th_dev[:, Dm:], D, P, d_in, list(hidden), 2, B, n)
+    assert relerr(m1, mean) < 1e-6 and relerr(z1, z) < 1e-6
+
+
+@pytest.mark.parametrize('tag', ['v4x32_d1_o2', 'v4x32_d4_o1', 'v3x32_d2_o2', 'v4x128_d2_o2', 'v_irregular_d3_o3', 's4x128'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_deep_mlp_matches_reference_fixture(L, golden_dir, tag, dtype):
+    """forward outputs and parameter gradients of the REAL NeuralNetworkVectorized (4 x 32, 4 x 128, irregular layer_sizes) and of
+    the real shared 4 x 128 NeuralNetwork of the PACOH-MAP launcher (deep_mlp_ref.npz, made by tests/golden/make_golden.py)"""
+    fx = np.load(os.path.join(golden_dir, 'deep_mlp_ref.npz'))
+    if tag == 's4x128':
+        layers, theta = (128, 128, 128, 128), torch.from_numpy(fx['s4x128_theta']).reshape(1, -1)
+        gq = torch.from_numpy(fx['s4x128_g']).unsqueeze(0)
+        ref_out, ref_grad = torch.from_numpy(fx['s4x128_out']).unsqueeze(0), torch.from_numpy(fx['s4x128_grad']).reshape(1, -1)
+    else:
+        layers, theta = [int(v) for v in fx[tag + '_layers']], torch.from_numpy(fx[tag + '_theta'])
+        gq, ref_out, ref_grad = (torch.from_numpy(fx[tag + k]) for k in ('_g', '_out', '_grad'))
+    x = torch.from_numpy(fx[tag + '_x']).unsqueeze(0)                          # one task, shared by the P parameter sets
+    P, D = theta.shape
+    n, d_in, d_out = x.shape[1], x.shape[2], gq.shape[-1]
+    th, xd = theta.to(dtype).to(DEV).contiguous(), x.to(dtype).to(DEV)
+    out = L.mlp_fwd(xd, P, th, D, P, d_in, list(layers), d_out, P, n)
+    assert relerr(out, ref_out) < 2e-5
+    grad = torch.empty(P, D, dtype=dtype, device=DEV)
+    L.mlp_bwd(xd, P, th, D, P, d_in, list(layers), d_out, gq.to(dtype).to(DEV).contiguous(), grad, D, False, P, n)
+    assert relerr(grad, ref_grad) < 2e-4
 
 
 def test_mlp_matches_reference_fixture(L, golden_dir):

@@ -59,6 +59,30 @@ def test_vectorized_mlp_forward_matches_reference(golden_dir):
             np.testing.assert_allclose(out.numpy(), fx[tag + '_kernel_out'], rtol=1e-5, atol=1e-5)
 
 
+DEEP_CASES = ['v4x32_d1_o2', 'v4x32_d4_o1', 'v3x32_d2_o2', 'v4x128_d2_o2', 'v_irregular_d3_o3']
+
+
+@pytest.mark.parametrize('tag', DEEP_CASES + ['s4x128'])
+def test_deep_mlp_forward_and_gradient_match_reference(golden_dir, tag):
+    """the launchers' 4 x 32 / 4 x 128 networks and an irregular layer_sizes tuple: outputs and parameter gradients of the real
+    NeuralNetworkVectorized / NeuralNetwork (deep_mlp_ref.npz) vs the oracle's restatement + autograd"""
+    fx = _load(golden_dir, 'deep_mlp_ref.npz')
+    if tag == 's4x128':
+        layers, theta = (128, 128, 128, 128), torch.from_numpy(fx['s4x128_theta']).reshape(1, -1)
+        g = torch.from_numpy(fx['s4x128_g']).unsqueeze(0)
+        ref_out, ref_grad = fx['s4x128_out'][None], fx['s4x128_grad'][None]
+    else:
+        layers, theta = tuple(int(v) for v in fx[tag + '_layers']), torch.from_numpy(fx[tag + '_theta'])
+        g = torch.from_numpy(fx[tag + '_g'])
+        ref_out, ref_grad = fx[tag + '_out'], fx[tag + '_grad']
+    x = torch.from_numpy(fx[tag + '_x'])
+    theta = theta.clone().requires_grad_(True)
+    out = O.mlp_vectorized_forward(x, theta, x.shape[1], g.shape[-1], layers)
+    assert np.allclose(out.detach().numpy(), ref_out, rtol=2e-5, atol=2e-5)
+    (out * g).sum().backward()
+    assert np.linalg.norm(theta.grad.numpy() - ref_grad) < 1e-5 * np.linalg.norm(ref_grad)
+
+
 def test_svgd_particle_init_stream(golden_dir):
     fx = _load(golden_dir, 'random_gp_ref.npz')
     cfg = O.GPConfig(input_dim=1, covar_module='NN', mean_module='NN')
