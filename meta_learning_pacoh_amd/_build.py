@@ -17,6 +17,10 @@ LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpacoh_gp.so')
 SOURCES = ['gp_small.hip', 'gp_mfma.hip', 'gram.hip', 'dense.hip', 'dense_mfma.hip', 'dense_gp.hip', 'mlp.hip', 'mlp_mfma.hip', 'mlp_fused.hip', 'mlp_layers.hip', 'mlp_f32.hip', 'mlp_f64.hip', 'misc.hip', 'svgd_imq.hip', 'vi_full.hip', 'comm.hip', 'predictive.hip']
 ARCH = 'gfx950'
+# per-source flags.  mlp_fused.hip: the compiler's automatic v_pk_fma_f32 / v_pk_add_f32 pairing costs the MFMA-paced backward
+# kernel 11-13 % (240 -> 213 us at cfg #3; packed fp32 issues at half rate and needs extra moves) -- the GP kernel is the
+# opposite case (5 % slower without it), so this is not a global flag
+PER_FILE_FLAGS = {'mlp_fused.hip': ['-fno-slp-vectorize']}
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-Wno-pass-failed', '-Wno-unused-value']
 
 
@@ -33,9 +37,13 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def build_library(force=False, verbose=True):
-    """Compile every .hip source for gfx950 and link the shared library.  Returns its path."""
-    os.makedirs(OBJ_DIR, exist_ok=True)
+def build_library(force=False, verbose=True, variant=None, extra_flags=()):
+    """Compile every .hip source for gfx950 and link the shared library.  Returns its path.
+    variant / extra_flags: an experimental build next to the product library (lib/libpacoh_gp_<variant>.so, selected at run time
+    with PACOH_LIB=<path>) compiled with additional flags, e.g. -DPACOH_EXP_...=1, for same-box A/B timing of kernel variants."""
+    obj_dir = OBJ_DIR if variant is None else OBJ_DIR + '_' + variant
+    lib_path = LIB_PATH if variant is None else os.path.join(LIB_DIR, 'libpacoh_gp_%s.so' % variant)
+    os.makedirs(obj_dir, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = _hipcc()
     hdr_m = _deps_mtime()
@@ -43,14 +51,14 @@ def build_library(force=False, verbose=True):
     jobs = []
     for src in sources:
         sp = os.path.join(CSRC, src)
-        op = os.path.join(OBJ_DIR, src.replace('.hip', '.o'))
+        op = os.path.join(obj_dir, src.replace('.hip', '.o'))
         stale = force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_m)
         if stale:
             jobs.append((sp, op))
 
     def compile_one(job):
         sp, op = job
-        cmd = [hipcc] + FLAGS + ['-I', INCLUDE, '-c', sp, '-o', op]
+        cmd = [hipcc] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(sp), []) + list(extra_flags) + ['-I', INCLUDE, '-c', sp, '-o', op]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (sp, r.stdout[-4000:]))
@@ -61,14 +69,18 @@ def build_library(force=False, verbose=True):
             print('[pacoh build] compiling %d source(s) for %s' % (len(jobs), ARCH), file=sys.stderr)
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
-    objs = [os.path.join(OBJ_DIR, s.replace('.hip', '.o')) for s in sources]
-    if jobs or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs):
-        cmd = [hipcc, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIB_PATH] + objs
+    objs = [os.path.join(obj_dir, s.replace('.hip', '.o')) for s in sources]
+    if jobs or not os.path.exists(lib_path) or os.path.getmtime(lib_path) < max(os.path.getmtime(o) for o in objs):
+        cmd = [hipcc, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', lib_path] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n%s' % r.stdout[-4000:])
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == '__main__':
-    print(build_library(force='--force' in sys.argv))
+    # python -m meta_learning_pacoh_amd._build [--force] [--variant NAME -DFLAG ...]
+    argv = sys.argv[1:]
+    variant = argv[argv.index('--variant') + 1] if '--variant' in argv else None
+    flags = [a for a in argv if a.startswith(('-D', '-f', '-m'))]
+    print(build_library(force='--force' in argv, variant=variant, extra_flags=flags))

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libpacoh_gp.so')
+LIB_PATH = os.environ.get('PACOH_LIB') or os.path.join(_HERE, 'lib', 'libpacoh_gp.so')     # PACOH_LIB: an experimental build (_build.py --variant)
 
 F32, F64 = 0, 1
 MEAN_ZERO, MEAN_VECTOR, MEAN_CONST = 0, 1, 2

@@ -33,7 +33,12 @@ constexpr int F_OFF_H = 160;                  // hidden layers 2..NH
 __host__ __device__ constexpr int f_off_out(int nh) { return F_OFF_H + (nh - 1) * HBLK; }      // W_out [2][32] | b_out [2] (+2 pad)
 __host__ __device__ constexpr int f_welems(int nh) { return f_off_out(nh) + 68; }
 constexpr int TSTRIDE = 8;                    // staged tile row: x[4] | g[2] | pad[2]
-constexpr int TRS = 16 * 17;                  // one transpose scratch block
+#ifdef PACOH_EXP_TURN128
+constexpr int TLD = 20;                       // scratch row stride: b128 writes and strided b32 reads both conflict-free
+#else
+constexpr int TLD = 17;
+#endif
+constexpr int TRS = 16 * TLD;                 // one transpose scratch block
 
 struct FusedNet {
     long theta_off;            // element offset of the network's block inside a theta row
@@ -193,12 +198,19 @@ __device__ __forceinline__ void f_delta(const float* W, int r, int g, const f32x
 
 // 16x16 block: lane (r,g) holds X[feature 4g+s][point r] in register s, returns X[feature r][point 4g+q] in register q
 __device__ __forceinline__ f32x4 f_turn(float* scr, const f32x4& v, int r, int g) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) scr[(4 * g + s) * 17 + r] = v[s];
-    asm volatile("" ::: "memory");
     f32x4 o;
+#ifdef PACOH_EXP_TURN128
+    *reinterpret_cast<f32x4*>(scr + r * TLD + 4 * g) = v;          // scr[point r][feature 4g+s]
+    asm volatile("" ::: "memory");
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = scr[r * 17 + 4 * g + q];
+    for (int q = 0; q < 4; ++q) o[q] = scr[(4 * g + q) * TLD + r];
+#else
+#pragma unroll
+    for (int s = 0; s < 4; ++s) scr[(4 * g + s) * TLD + r] = v[s];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = scr[r * TLD + 4 * g + q];
+#endif
     asm volatile("" ::: "memory");
     return o;
 }
@@ -264,7 +276,7 @@ template <int NH, int PB, int MINW>
 __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) float wl[f_welems(NH)];
     __shared__ __attribute__((aligned(16))) float stage[4][16 * PB * TSTRIDE];
-    __shared__ float tscr[4][2 * TRS];
+    __shared__ __attribute__((aligned(16))) float tscr[4][2 * TRS];
     const FusedNet& nt = a.net[blockIdx.z];
     const int p = blockIdx.y;
     fused_load_weights<NH>(wl, a.theta + (long)p * a.theta_stride + nt.theta_off, a, nt.d_out);
@@ -466,11 +478,16 @@ static void fused_fill(FusedArgs& a, const void* x, int x_div, const void* theta
     for (int l = 0; l < FMAXNH; ++l) a.h[l] = l < n_hidden ? hidden[l] : 0;
 }
 
+#ifdef PACOH_EXP_BWD_MINW3
+constexpr int BWD_MINW = 3;
+#else
+constexpr int BWD_MINW = 2;
+#endif
 // M is applied to the parenthesised kernel instantiation (the commas of the template arguments must not split macro arguments)
 #define PACOH_FUSED_DISPATCH(KERNEL, nh, pb, M)                                                          \
     do {                                                                                                 \
         if (pb == 4) {                                                                                   \
-            if (nh == 1) { M((KERNEL<1, 4, 2>)); } else if (nh == 2) { M((KERNEL<2, 4, 2>)); }            \
+            if (nh == 1) { M((KERNEL<1, 4, BWD_MINW>)); } else if (nh == 2) { M((KERNEL<2, 4, BWD_MINW>)); }  \
             else if (nh == 3) { M((KERNEL<3, 4, 1>)); } else { M((KERNEL<4, 4, 1>)); }                    \
         } else {                                                                                         \
             if (nh == 1) { M((KERNEL<1, 2, 2>)); } else if (nh == 2) { M((KERNEL<2, 2, 2>)); }            \
@@ -486,7 +503,7 @@ int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride
     for (int k = 0; k < nets; ++k) { a.net[k].theta_off = off[k]; a.net[k].out = (float*)out[k]; a.net[k].d_out = d_out[k]; }
     const int pb = fused_fwd_pb(n_hidden) == 2 ? 2 : 4;
     const int tiles = (a.R + 16 * pb - 1) / (16 * pb);
-    a.tiles_per_wg = fused_env("PACOH_FUSED_FWD_TPW", 8);          // 2 tiles per wave
+    a.tiles_per_wg = fused_env("PACOH_FUSED_FWD_TPW", 16);         // 4 tiles per wave (4 / 8 / 16 / 32: 109 / 100 / 95 / 94 us at cfg #3)
     const int wgs = (tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
 #define PACOH_LAUNCH_FWD(K) hipLaunchKernelGGL((K), dim3(wgs, P, nets), dim3(256), 0, s, a)
     if (pb == 4) {

@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--particles', type=int, default=20)
     ap.add_argument('--n', type=int, default=64)
     ap.add_argument('--d', type=int, default=4)
+    ap.add_argument('--quick', action='store_true', help='default tile shapes only')
     args = ap.parse_args()
     hidden = [int(v) for v in args.layers.split(',')]
     T, P, n, d = args.tasks, args.particles, args.n, args.d
@@ -76,10 +77,13 @@ def main():
 
     rows = []
     for path in (None, 'mfma'):
-        if path == 'mfma' and len(hidden) > 2:
+        if path == 'mfma' and (len(hidden) > 2 or args.quick):
             continue
         setenv(PACOH_MLP_PATH=path)
-        if path is None:
+        if path is None and args.quick:
+            rows.append(('fused fwd pair', timeit(pair_fwd, args.reps)))
+            rows.append(('fused bwd pair', timeit(pair_bwd, args.reps)))
+        elif path is None:
             for pb in (4, 2):
                 setenv(PACOH_FUSED_FWD_PB=pb)
                 for tpw in (4, 8, 16, 32):
