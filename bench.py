@@ -1,19 +1,21 @@
 #!/usr/bin/env python
 """Benchmark of the PACOH task-GP hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the one the metric is quoted on): PACOH-SVGD meta-training,
-1024 tasks per GPU, n_ctx = 64, d = 4, 20 particles, NN(32,32) mean + NN(32,32) kernel features
-(D = 2534 prior parameters per particle), fp32.  One "step" = one full svgd_step over every
-(task, particle) pair held by the job: per-particle MLP features -> fused Gram/Cholesky/solve/log-det
-LML and its gradient -> MLP backward -> hyper-prior gradient -> SVGD phi -> Adam.  One "eval" = one
-(task, particle) LML + gradient.  Weak scaling: every rank processes 1024 tasks x 20 particles, the
-score [20 x 2534] is summed with one RCCL all-reduce per step.
+Default workload (BASELINE.json configs[2], the one the metric is quoted on): PACOH-SVGD meta-training, 1024 tasks,
+n_ctx = 64, d = 4, 20 particles, NN(32,32) mean + NN(32,32) kernel features (D = 2534 prior parameters per particle), fp32.
+One "step" = one full SVGD step over every (task, particle) pair held by the job, exactly as meta_fit runs it (task draw ->
+task gather -> per-particle MLP features -> fused Gram/Cholesky/solve/log-det LML and its gradient -> MLP backward ->
+hyper-parameter reductions -> [all-reduce] -> prior score + SVGD phi + Adam), replayed from the captured step graph.
+One "eval" = one (task, particle) LML + gradient.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus 8 --steps 20 --warmup 5
+        bench.py --gpus 8 --steps 200 --warmup 10 [--scaling strong]
 
-Prints ONE JSON line on rank 0.
+--scaling weak (default): every rank holds 1024 tasks (global batch 1024 x N); --scaling strong: 1024 tasks in total, sharded
+over the N ranks (cfg #3 as BASELINE.json words it).  Either way the score [20 x 2534] (+ 20 likelihood sums) is summed with
+ONE all-reduce per step.  --config 2 | 4 | 5 times the other BASELINE configurations the same way (parity-test cases; the
+headline metric is config 3).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -27,9 +29,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TASKS_PER_GPU, N_CTX, DIM, PARTICLES = 1024, 64, 4, 20
+TASKS, N_CTX, DIM, PARTICLES = 1024, 64, 4, 20
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy peak)
-FP32_PEAK_TFLOPS = 157.3       # fp32 vector peak == fp32-input MFMA peak
+FP32_PEAK_TFLOPS = 157.3       # fp32 vector peak == fp32-input MFMA peak (MI355X_MICROARCH.md)
+FP64_PEAK_TFLOPS = 78.6        # fp64 matrix peak: AMD's MI355X figure; tools/mfma_peak.hip measures what v_mfma_f64_16x16x4 sustains
+PMC_PROFILE = os.path.join('profiles', 'r02_pmc_hbm_traffic.json')
 
 
 def make_tasks(n_tasks, n, d, seed0=1000):
@@ -47,15 +51,22 @@ def make_tasks(n_tasks, n, d, seed0=1000):
     return tasks
 
 
-def gp_flops_per_eval(n, f, w_nn):
-    """SURVEY.md 8(d) flop model: F = 6 n W_nn + n^2(3f+2) + n^3/3 + 2n^2 + [bwd] 2n^3/3 + 2n^2 + 4 n^2 f"""
-    gp = n * n * (3 * f + 2) + n ** 3 / 3 + 2 * n * n + 2 * n ** 3 / 3 + 2 * n * n + 4 * n * n * f
-    return 6 * n * w_nn + gp, gp
+def gp_flops(n, f):
+    """n^2(3f+2) + n^3/3 + 2n^2 + [bwd] 2n^3/3 + 2n^2 + 4 n^2 f per LML+grad evaluation"""
+    return n * n * (3 * f + 2) + n ** 3 / 3 + 2 * n * n + 2 * n ** 3 / 3 + 2 * n * n + 4 * n * n * f
+
+
+def net_macs(d_in, layers, d_out):
+    prev, w = d_in, 0
+    for h in layers:
+        w += prev * h
+        prev = h
+    return w + prev * d_out
 
 
 def cpu_baseline(budget_s=12.0):
     """The CPU oracle (plain torch restatement of the reference's arithmetic, oracle/pacoh_oracle.py) on
-    the host cores, on a bounded sample of the same workload.  Reported baseline only."""
+    the host cores, on a bounded sample of the config-3 workload.  Reported baseline only."""
     from oracle import pacoh_oracle as O
     cores = os.cpu_count() or 1
     T_s = 32
@@ -66,6 +77,7 @@ def cpu_baseline(budget_s=12.0):
     pm, ps = O.hyperprior_mean_std(cfg.layout, 0.5, 3.0)
     torch.manual_seed(0)
     theta = O.hyperprior_sample(cfg.layout, pm, ps, PARTICLES)
+
     def rate(loop, threads, budget):
         torch.set_num_threads(threads)
         O.meta_score(theta, otasks, cfg, pm, ps, 0.01, loop=loop)          # warm-up
@@ -89,11 +101,27 @@ def cpu_baseline(budget_s=12.0):
                       % (T_s, PARTICLES, N_CTX, DIM, cands, cores, {k: round(v) for k, v in probe.items()}, best, looped)}
 
 
+def pmc_traffic(substr):
+    """HBM bytes per launch of the kernel whose name contains `substr`, from the COMMITTED rocprofv3 PMC profile of this
+    workload (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH correction; tools/pmc_summary.py) -- not measured in
+    this run"""
+    try:
+        with open(os.path.join(ROOT, PMC_PROFILE)) as fh:
+            for k, v in json.load(fh)['kernels'].items():
+                if substr in k:
+                    return v['hbm_bytes_per_launch']
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)     # 0.15 s of GPU time; 20 steps still carry ~4 % of start-up per step
-    ap.add_argument('--warmup', type=int, default=10)     # (the first step after a synchronise waits for the host to issue it)
+    ap.add_argument('--steps', type=int, default=200)     # 0.12 s of GPU time at config 3
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--config', type=int, choices=[2, 3, 4, 5], default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -105,7 +133,10 @@ def main():
     # devices; RCCL itself refuses two ranks per device).  The measured job always uses 'nccl' = RCCL over xGMI.
     backend = os.environ.get('PACOH_BENCH_BACKEND', 'nccl')
     dev_index = local_rank if backend == 'nccl' else local_rank % max(1, torch.cuda.device_count())
+    if backend != 'nccl':
+        os.environ['PACOH_SHARE_DEVICE'] = '1'
     torch.cuda.set_device(dev_index)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if backend == 'nccl':
@@ -116,134 +147,198 @@ def main():
     import meta_learning_pacoh_amd as M
     from meta_learning_pacoh_amd import _lib as L
 
-    T_global = TASKS_PER_GPU * world
-    tasks = make_tasks(T_global, N_CTX, DIM)
-    model = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=PARTICLES, covar_module='NN', mean_module='NN',
-                                          task_batch_size=-1, lr=1e-3, random_seed=0)
-    D = model.layout.D
-
-    def step():
-        idx_local, pre = model._sample_task_batch()
-        model.svgd_step(idx_local, pre)
+    wl = WORKLOADS[args.config](world, args.scaling, M, L)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    wl['run'](max(1, args.warmup))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    wl['run'](args.steps)
+    t_issued = time.perf_counter()                       # the host has issued every step (nothing synchronises inside)
     barrier()
     elapsed = time.perf_counter() - t0
+    host_ms = (t_issued - t0) / args.steps * 1e3
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    finite = bool(torch.isfinite(model.particles).all())
+    finite = wl['finite']()
+    ms_per_step = elapsed / args.steps * 1e3
 
-    # ---- per-kernel breakdown with HIP events on the launch stream (separate, instrumented steps) ----
+    # ---- per-kernel breakdown with HIP events on the launch stream: a separate pass that issues the SAME launch sequence
+    #      eagerly (PACOH_NO_GRAPH=1; events cannot be read out of a graph replay) ----------------------------------------
+    prof_steps = min(args.steps, 50)
+    os.environ['PACOH_NO_GRAPH'] = '1'
+    wl['run'](2)
+    torch.cuda.synchronize()
     L.PROFILE = {}
-    for _ in range(args.steps):
-        step()
+    wl['run'](prof_steps)
     torch.cuda.synchronize()
     prof = L.profile_summary()
     L.PROFILE = None
-    kernel_ms = {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
-    dom = max(prof.items(), key=lambda kv: kv[1][1])[0]
-    evals_per_gpu = TASKS_PER_GPU * PARTICLES
-    w_nn = 2 * (DIM * 32 + 32 * 32) + 32 * 1 + 32 * 2
-    f_total, f_gp = gp_flops_per_eval(N_CTX, 2, w_nn)               # W_nn = 2400 MAC/point over both nets
-    pmc_kernels = {}                    # HBM bytes per launch of each kernel, from the committed PMC profile
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')) as fh:
-            pmc_kernels = json.load(fh)['kernels']
-    except Exception:
-        pass
+    os.environ.pop('PACOH_NO_GRAPH')
+    kernel_ms = {k: round(v[1] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+    kernel_sum = sum(v[1] for v in prof.values()) / prof_steps
+    peak = FP64_PEAK_TFLOPS if wl['dtype'] == 'f64' else FP32_PEAK_TFLOPS
 
     def kernel_roofline(name):
-        """fp32-peak roofline of one fused kernel from its HIP-event time in this run (flop models: SURVEY 8d)"""
         launches, tot_ms = prof[name]
-        per_launch_s = tot_ms / launches * 1e-3
-        key = {'mlp_bwd': 'mlp_mfma_bwd', 'gp_lml_fwdbwd': 'gp_mfma_kernel', 'mlp_fwd': 'mlp_mfma_fwd'}.get(name, name)
-        cands = [v['hbm_bytes_per_launch'] for k, v in pmc_kernels.items() if key in k]
-        traffic = cands[0] if cands else None
-        if name in ('gp_lml_fwdbwd', 'meta_lml_grad'):
-            flops = (f_gp if name == 'gp_lml_fwdbwd' else f_total) * evals_per_gpu
-            note = ('fp32 VALU/LDS kernel priced against the fp32 peak (vector == f32 MFMA rate); '
-                    'algorithmic flops per eval = %.0f (SURVEY 8d model)' % (flops / evals_per_gpu))
-        else:
-            # MLP kernels: algorithmic flops 2*n*W per eval forward, 4*n*W backward (+ recompute)
-            mult = 2 if name == 'mlp_fwd' else 6
-            flops = mult * N_CTX * (w_nn / 2) * evals_per_gpu
-            note = ('fp32 MFMA + VALU kernel (registers/LDS only between HBM in/out), priced against the fp32 peak with '
-                    'the 2*n*W (fwd) / 6*n*W (bwd, incl. recompute) flop model, W = %d MAC per point' % (w_nn // 2))
-        return {'kernel': name, 'bound': 'mfma', 'achieved': round(flops / per_launch_s / 1e12, 4), 'peak': FP32_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(flops / per_launch_s / 1e12 / FP32_PEAK_TFLOPS, 5), 'traffic': traffic, 'note': note}
+        per_step_s = tot_ms / prof_steps * 1e-3
+        alg, exe = wl['flops'][name]
+        key = wl.get('pmc_keys', {}).get(name)
+        return {'kernel': name, 'bound': 'mfma', 'achieved': round(alg / per_step_s / 1e12, 3), 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': round(alg / per_step_s / 1e12 / peak, 5), 'algorithmic_frac': round(alg / per_step_s / 1e12 / peak, 5),
+                'executed_frac': round(exe / per_step_s / 1e12 / peak, 5),
+                'ms_per_step': round(per_step_s * 1e3, 4), 'launches_per_step': launches / prof_steps,
+                'traffic': pmc_traffic(key) if key else None,
+                'traffic_source': 'committed PMC profile %s (not measured in this run)' % PMC_PROFILE,
+                'note': 'algorithmic flops per step and GPU (SURVEY 8d model; MLP backward = 4 n W, its forward recompute is '
+                        'counted only in executed_frac) / HIP-event time of the kernel in this run / %s peak %.1f TFLOP/s'
+                        % ('fp64 matrix' if wl['dtype'] == 'f64' else 'fp32', peak)}
 
-    roofline = kernel_roofline(dom)
-    # the two heaviest kernels trade places from run to run (0.30 ms each): report every fused kernel's fraction as well
-    kernel_rooflines = {k: {'achieved': r['achieved'], 'frac': r['frac'], 'unit': 'TFLOP/s'}
-                        for k, r in ((k, kernel_roofline(k)) for k in ('gp_lml_fwdbwd', 'mlp_bwd', 'mlp_fwd') if k in prof)}
+    modelled = [k for k in wl['flops'] if k in prof]
+    dom = max(modelled, key=lambda k: prof[k][1]) if modelled else None
+    roofline = kernel_roofline(dom) if dom else None
+    kernel_rooflines = {k: {kk: r[kk] for kk in ('achieved', 'algorithmic_frac', 'executed_frac', 'ms_per_step', 'unit')}
+                        for k, r in ((k, kernel_roofline(k)) for k in modelled)}
+    step_flops = sum(wl['flops'][k][0] for k in modelled)
 
-    # ---- standalone Gram build (the HBM-write-bound kernel): same problem count, materialised K ----
-    gram = None
-    if rank == 0:
-        B = evals_per_gpu
-        z = torch.randn(B, N_CTX, 2, device='cuda')
-        ls = torch.rand(PARTICLES, 2, device='cuda') + 0.5
-        for _ in range(10):
-            L.gram_rbf_ard(z, 1, z, 1, ls, None, None, False, B, PARTICLES)
-        torch.cuda.synchronize()
-        reps = 100
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        K = torch.empty(B, N_CTX, N_CTX, device='cuda')
-        lib = L.load_library()
-        s.record()
-        for _ in range(reps):
-            lib.pacoh_gram_rbf_ard(z.data_ptr(), 1, z.data_ptr(), 1, ls.data_ptr(), None, None, 0, K.data_ptr(),
-                                   B, PARTICLES, N_CTX, N_CTX, 2, 0, torch.cuda.current_stream().cuda_stream)
-        e.record()
-        torch.cuda.synchronize()
-        t_k = s.elapsed_time(e) / reps * 1e-3
-        alg_bytes = B * (N_CTX * 2 * 4 + N_CTX * N_CTX * 4)
-        traffic = None                      # HBM bytes per launch from the committed PMC profile of this same launch shape
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')) as fh:
-                kern = json.load(fh)['kernels']
-                key = [k for k in kern if k.startswith('gram_kernel<float, 2')][0]
-                traffic = kern[key]['hbm_bytes_per_launch']
-        except Exception:
-            pass
-        gram = {'kernel': 'gram_rbf_ard', 'bound': 'hbm', 'achieved': round(alg_bytes / t_k / 1e9, 1),
-                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(alg_bytes / t_k / 1e9 / HBM_PEAK_GBS, 4),
-                'traffic': traffic, 'algorithmic_bytes': alg_bytes, 'bytes_per_gram': N_CTX * 2 * 4 + N_CTX * N_CTX * 4, 'grams': B,
-                'us_per_launch': round(t_k * 1e6, 2)}
+    gram = gram_leg(L) if (rank == 0 and args.config == 3) else None
 
     if rank == 0:
-        cpu = None if args.no_cpu_baseline or world > 1 else cpu_baseline()
-        value = T_global * PARTICLES * args.steps / elapsed
+        cpu = None if (args.no_cpu_baseline or world > 1 or args.config != 3) else cpu_baseline()
+        value = wl['evals_per_step'] * args.steps / elapsed
         out = {
-            'metric': 'task-GP LML+grad evals/sec (n_ctx=64, d=4, 20 particles)',
+            'metric': 'task-GP LML+grad evals/sec (n_ctx=64, d=4, 20 particles)' if args.config == 3 else wl['metric'],
             'value': round(value, 1), 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'PACOH-SVGD svgd_step, cfg#3: %d tasks/GPU x %d particles, n_ctx=%d, d=%d, '
-                                   'NN(32,32) mean + NN(32,32) kernel (D=%d), task sharding + 1 RCCL all-reduce/step'
-                                   % (TASKS_PER_GPU, PARTICLES, N_CTX, DIM, D),
-                       'tasks_per_gpu': TASKS_PER_GPU, 'particles': PARTICLES, 'n_ctx': N_CTX, 'd': DIM,
-                       'evals_per_step': T_global * PARTICLES, 'parallelism': 'task-shard x%d' % world,
-                       'finite': finite},
-            'roofline': roofline, 'kernel_rooflines': kernel_rooflines, 'gram_roofline': gram, 'kernel_ms_per_step': kernel_ms, 'cpu_baseline': cpu,
+            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': args.scaling,
+            'vs_baseline': None, 'dtype': wl['dtype'], 'data': 'synthetic',
+            'backend': (backend if world > 1 else None), 'world_size_seen': (dist.get_world_size() if world > 1 else 1),
+            'host_ms_per_step': round(host_ms, 4),
+            'config': dict({'workload': wl['describe'], 'evals_per_step': wl['evals_per_step'],
+                            'parallelism': 'task-shard x%d' % world, 'finite': finite}, **wl.get('extra', {})),
+            'roofline': roofline, 'kernel_rooflines': kernel_rooflines,
+            'step_algorithmic_tflops': round(step_flops / (ms_per_step * 1e-3) / 1e12, 3),
+            'gram_roofline': gram,
+            'kernel_ms_per_step': kernel_ms,
+            'kernel_sum_ms_per_step': round(kernel_sum, 4),
+            'launch_gaps_ms_per_step': round(ms_per_step - kernel_sum, 4),
+            'cpu_baseline': cpu,
         }
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
+
+def gram_leg(L):
+    """standalone Gram build (the HBM-write-bound kernel): the config-3 problem count, materialised K"""
+    B = TASKS * PARTICLES
+    z = torch.randn(B, N_CTX, 2, device='cuda')
+    ls = torch.rand(PARTICLES, 2, device='cuda') + 0.5
+    for _ in range(10):
+        L.gram_rbf_ard(z, 1, z, 1, ls, None, None, False, B, PARTICLES)
+    torch.cuda.synchronize()
+    reps = 100
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    K = torch.empty(B, N_CTX, N_CTX, device='cuda')
+    lib = L.load_library()
+    s.record()
+    for _ in range(reps):
+        lib.pacoh_gram_rbf_ard(z.data_ptr(), 1, z.data_ptr(), 1, ls.data_ptr(), None, None, 0, K.data_ptr(),
+                               B, PARTICLES, N_CTX, N_CTX, 2, 0, torch.cuda.current_stream().cuda_stream)
+    e.record()
+    torch.cuda.synchronize()
+    t_k = s.elapsed_time(e) / reps * 1e-3
+    alg_bytes = B * (N_CTX * 2 * 4 + N_CTX * N_CTX * 4)
+    return {'kernel': 'gram_rbf_ard', 'bound': 'hbm', 'achieved': round(alg_bytes / t_k / 1e9, 1),
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(alg_bytes / t_k / 1e9 / HBM_PEAK_GBS, 4),
+            'traffic': pmc_traffic('gram_kernel<float, 2'),
+            'traffic_source': 'committed PMC profile %s (not measured in this run)' % PMC_PROFILE,
+            'algorithmic_bytes': alg_bytes, 'bytes_per_gram': N_CTX * 2 * 4 + N_CTX * N_CTX * 4, 'grams': B,
+            'us_per_launch': round(t_k * 1e6, 2)}
+
+
+# ---- workloads: each returns run(n_steps), evals per step (whole job), flop models per HIP-event name (per step and GPU) ----
+def _rand_tasks(T, n, d, seed):
+    rs = np.random.RandomState(seed)
+    return [(rs.uniform(-5, 5, (n, d)), rs.normal(size=(n, 1))) for _ in range(T)]
+
+
+def wl_cfg3(world, scaling, M, L):
+    T_global = TASKS * world if scaling == 'weak' else TASKS
+    model = M.GPRegressionMetaLearnedSVGD(make_tasks(T_global, N_CTX, DIM), num_particles=PARTICLES, covar_module='NN',
+                                          mean_module='NN', task_batch_size=-1, lr=1e-3, random_seed=0)
+    ev = T_global * PARTICLES / world
+    w = net_macs(DIM, (32, 32), 1) + net_macs(DIM, (32, 32), 2)                 # 2400 MAC per point over both networks
+    return dict(run=model._train_steps, evals_per_step=T_global * PARTICLES, dtype='f32',
+                finite=lambda: bool(torch.isfinite(model.particles).all()),
+                flops={'gp_lml_fwdbwd': (gp_flops(N_CTX, 2) * ev,) * 2, 'mlp_fwd': (2 * N_CTX * w * ev,) * 2,
+                       'mlp_bwd': (4 * N_CTX * w * ev, 6 * N_CTX * w * ev)},
+                pmc_keys={'gp_lml_fwdbwd': 'gp_mfma_kernel', 'mlp_fwd': 'mlp_fused_fwd', 'mlp_bwd': 'mlp_fused_bwd'},
+                describe='PACOH-SVGD step as meta_fit runs it (hipGraph replay), cfg#3: %d tasks %s x %d particles, n_ctx=%d, d=%d, '
+                         'NN(32,32) mean + NN(32,32) kernel (D=%d), task sharding + 1 all-reduce/step'
+                         % (TASKS, 'per GPU' if scaling == 'weak' else 'in total', PARTICLES, N_CTX, DIM, model.layout.D),
+                extra={'tasks_total': T_global, 'particles': PARTICLES, 'n_ctx': N_CTX, 'd': DIM})
+
+
+def wl_cfg2(world, scaling, M, L):
+    """PACOH-MAP, 256 sinusoid-like tasks, n_ctx = 32, d = 1, SE kernel + NN(32,32) mean, the full task batch every iteration"""
+    T = 256 * world if scaling == 'weak' else 256
+    model = M.GPRegressionMetaLearned(_rand_tasks(T, 32, 1, 27), covar_module='SE', mean_module='NN', task_batch_size=T, random_seed=1)
+    ev = T / world
+    w = net_macs(1, (32, 32), 1)
+    return dict(run=model._train_steps, evals_per_step=T, dtype='f32', finite=lambda: bool(torch.isfinite(model.theta).all()),
+                metric='task-GP LML+grad evals/sec (PACOH-MAP, 256 tasks, n_ctx=32, d=1, SE kernel)',
+                flops={'gp_lml_fwdbwd': (gp_flops(32, 1) * ev,) * 2, 'mlp_fwd': (2 * 32 * w * ev,) * 2,
+                       'mlp_bwd': (4 * 32 * w * ev, 6 * 32 * w * ev)},
+                describe='PACOH-MAP iteration (hipGraph replay), cfg#2: %d tasks x n_ctx=32, d=1, SE kernel + NN(32,32) mean, AdamW' % T,
+                extra={'tasks_total': T, 'n_ctx': 32, 'd': 1})
+
+
+def wl_cfg4(world, scaling, M, L):
+    """PACOH-VI, 512 tasks, n_ctx = 128, NN(32,32) mean + kernel features, 10 posterior samples per step"""
+    T, S = (512 * world if scaling == 'weak' else 512), 10
+    model = M.GPRegressionMetaLearnedVI(_rand_tasks(T, 128, 1, 28), svi_batch_size=S, random_seed=1)
+    ev = T * S / world
+    w = net_macs(1, (32, 32), 1) + net_macs(1, (32, 32), 2)
+    return dict(run=model._train_steps, evals_per_step=T * S, dtype='f32', finite=lambda: bool(torch.isfinite(model.posterior).all()),
+                metric='task-GP LML+grad evals/sec (PACOH-VI, 512 tasks, n_ctx=128, 10 posterior samples)',
+                flops={'gp_lml_fwdbwd': (gp_flops(128, 2) * ev,) * 2, 'mlp_fwd': (2 * 128 * w * ev,) * 2,
+                       'mlp_bwd': (4 * 128 * w * ev, 6 * 128 * w * ev)},
+                describe='PACOH-VI step (hipGraph replay), cfg#4: %d tasks x %d samples, n_ctx=128, d=1, NN(32,32) mean + kernel' % (T, S),
+                extra={'tasks_total': T, 'samples': S, 'n_ctx': 128, 'd': 1})
+
+
+def wl_cfg5(world, scaling, M, L):
+    """Large-context stress: 256 tasks, n_ctx = 512, d = 8, fp64, SE kernel: LML + gradient through the HBM-resident path.
+    A single GP does not shard: N ranks run N replicas (no collective)."""
+    B, n, d = 256, 512, 8
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(B, n, d, dtype=torch.float64, generator=g).cuda()
+    Y = torch.randn(B, n, dtype=torch.float64, generator=g).cuda()
+    ls = torch.full((1, d), 0.6931, dtype=torch.float64, device='cuda')
+    nz = torch.tensor([0.313], dtype=torch.float64, device='cuda')
+    os1 = torch.ones(1, dtype=torch.float64, device='cuda')
+    last = {}
+
+    def run(k):
+        for _ in range(k):
+            last['out'] = L.gp_lml_fwdbwd(X, 1, None, L.MEAN_ZERO, Y, 1, ls, os1, nz, B, 1)
+    fl = gp_flops(n, d) * B
+    return dict(run=run, evals_per_step=B * world, dtype='f64', finite=lambda: bool(torch.isfinite(last['out'][0]).all()),
+                metric='task-GP LML+grad evals/sec (n_ctx=512, d=8, fp64)',
+                flops={'gp_lml_dense': (fl, fl)},
+                describe='cfg#5 large-context stress: %d GPs x n_ctx=512, d=8, fp64, SE kernel, LML + gradients (Gram -> MFMA-panel '
+                         'Cholesky -> triangular inverse -> Z^T Z -> contractions); replicas only across ranks' % B,
+                extra={'problems_per_gpu': B, 'n_ctx': n, 'd': d})
+
+
+WORKLOADS = {2: wl_cfg2, 3: wl_cfg3, 4: wl_cfg4, 5: wl_cfg5}
 
 if __name__ == '__main__':
     main()

@@ -205,11 +205,14 @@ int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int
  * (d_ls[T,P,f], d_os[T,P] or NULL, d_noise[T,P]: the per-problem outputs of pacoh_gp_lml_fwdbwd) and the plain sum
  * for a constant mean (d_const[T,P] at off_const, or NULL / -1).  Optionally (lml, lik both non-NULL) the same pass over the
  * tasks also writes lik[p] = lik_scale * sum_t lml[t,p], the likelihood term of RandomGPMeta.log_prob (random_gp.py:204-222).
- * Deterministic (fixed summation order). */
+ * Deterministic (fixed summation order).
+ * info[T*P] / fail_flag (both or neither): the per-problem status of pacoh_gp_lml_fwdbwd rides along; *fail_flag |= 1 if any
+ * problem's Cholesky failed even with jitter -- where gpytorch's psd_safe_cholesky raises NotPSDError; the host reads the flag
+ * at its next synchronisation point and raises there. */
 int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int T, int off_ls, int f, int off_os, int off_noise,
                     int off_const, const void* d_ls, const void* d_os, const void* d_noise, const void* d_const,
-                    void* grad, long grad_stride, const void* lml, void* lik, double lik_scale, int dtype,
-                    void* stream);
+                    void* grad, long grad_stride, const void* lml, void* lik, double lik_scale,
+                    const int32_t* info, int32_t* fail_flag, int dtype, void* stream);
 
 /* logp[p] = sum_d log N(theta[p,d]; prior_mean[d], prior_std[d]);  grad[p,d] (optional, += scaled):
  * grad += grad_scale * d logp / d theta.  Replaces CatDist.log_prob over the Normal blocks
@@ -239,6 +242,35 @@ int pacoh_svgd_update(const void* X, const void* score, const void* prior_mean, 
                       double prior_factor, double bandwidth, int use_adam, double lr, double beta1, double beta2,
                       double eps, long step, void* exp_avg, void* exp_avg_sq, void* X_out, void* bw_out,
                       void* workspace, int P, int D, int dtype, void* stream);
+
+/* ---- whole steps as hipGraphs: per-step operands in device memory ----------------------------------------------------------
+ * A meta-training step is ~12 launches; issued one by one from Python the host needs ~0.35 ms per step, more than the GPU
+ * needs on small configurations or small per-GPU shards.  The step is therefore captured once and replayed; everything that
+ * changes from step to step -- the sampled task indices (GPR_meta_svgd.py:102, GPR_meta_mll.py:109), the harmonic pre-factor
+ * of the batch (random_gp.py:209-212), the learning rate of the StepLR schedule and Adam's bias corrections -- is uploaded for
+ * many steps at once and selected on the device:
+ *   pacoh_step_select: row = *counter; idx_out[0..tb) = idx_all[row, :]; sc_out[0..n_sc) = sc_all[row, :]; aux_out[0..n_aux) =
+ *     aux_all[row, :] (optional payload of `dtype` values: PACOH-VI's reparameterisation noise of the step); *counter = row + 1.
+ *   step scalars (one row of `dtype` values, PACOH_SC_COUNT of them):
+ *     [PACOH_SC_SCORE_SCALE] factor on the likelihood score (the pre-factor), [PACOH_SC_LR] learning rate,
+ *     [PACOH_SC_ADAM .. +3] = {1 - lr*weight_decay, lr/(1-beta1^step), sqrt(1-beta2^step), eps}: the operand block of
+ *     pacoh_adam_step_dev.
+ *   pacoh_scale_dev:   buf[0..count) *= *scalar   (scalar in device memory, e.g. &sc[PACOH_SC_SCORE_SCALE]).
+ *   pacoh_svgd_update_dev: pacoh_svgd_update with score_scale, lr and the Adam scalars read from `scalars` (a step-scalar row):
+ *     phi is built from score_scale * score[j,:] + prior_factor * d log prior / dX; X is updated IN PLACE (the distance launch
+ *     snapshots the particles into the workspace first: pacoh_svgd_update_dev_workspace_bytes). */
+#define PACOH_SC_SCORE_SCALE 0
+#define PACOH_SC_LR 1
+#define PACOH_SC_ADAM 4
+#define PACOH_SC_COUNT 8
+int pacoh_step_select(const int64_t* idx_all, int tb, const void* sc_all, int n_sc, const void* aux_all, long n_aux,
+                      int64_t* counter, int64_t* idx_out, void* sc_out, void* aux_out, int dtype, void* stream);
+int pacoh_scale_dev(void* buf, const void* scalar, long count, int dtype, void* stream);
+size_t pacoh_svgd_update_dev_workspace_bytes(int P, int D, int dtype);
+int pacoh_svgd_update_dev(void* X, const void* score, const void* prior_mean, const void* prior_std,
+                          double prior_factor, double bandwidth, int use_adam, const void* scalars, double beta1,
+                          double beta2, void* exp_avg, void* exp_avg_sq, void* bw_out, void* workspace, int P, int D,
+                          int dtype, void* stream);
 
 /* Same update direction with the IMQ particle kernel k_ij = (alpha + sum_d (X_jd - X_id)^2 / h_d)^beta
  * (alpha > 0, beta < 0).  bandwidth > 0: h_d = bandwidth for every d.  bandwidth <= 0: per-dimension median

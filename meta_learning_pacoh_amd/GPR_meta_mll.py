@@ -9,9 +9,10 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import parallel
 from .abstract import RegressionModelMetaLearned
 from .distributions import GaussianPredictive
-from .engine import AsyncUploader, GPEngine, ParamLayout, TaskBatch
+from .engine import GPEngine, NotPSDError, ParamLayout, StepFeed, TaskBatch, capture_graph
 from .util import StepLR
 
 
@@ -104,81 +105,104 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         self.exp_avg_sq = torch.zeros_like(self.theta)
         self.opt_step = 0
         self.lr_scheduler = StepLR(lr, 1000, lr_decay)
+        self._feed = self._graphs = None
 
-    def _apply_update(self, grad):
-        self.opt_step += 1
-        lr = self.lr_scheduler.lr
-        for lo, hi in self.train_segments:
-            p, g = self.theta[0, lo:hi], grad[0, lo:hi]
-            if self.optimizer_name == 'Adam':
-                L.adam_step(p, g, self.exp_avg[0, lo:hi], self.exp_avg_sq[0, lo:hi], lr, self.opt_step,
-                            weight_decay=self.weight_decay)
-            else:
-                L.axpy(p, g, -lr)
+    # ---- one meta-training iteration captured in hipGraph(s) ---------------------------------------------------------------------
+    # A MAP iteration is ~10 launches of a few microseconds each, i.e. launch-bound.  The sequence (task gather -> features ->
+    # fused GP LML+grad -> MLP backward -> hyper backward -> loss | AdamW) is captured once and replayed; the sampled task indices
+    # and the step-dependent Adam scalars of up to GRAPH_CHUNK iterations are uploaded at once (engine.StepFeed).  With several
+    # ranks the task batch is sharded (rank r evaluates idx[r::world]) and grad[1,D] + loss -- sums over tasks
+    # (GPR_meta_mll.py:109-113) -- are all-reduced between the two graphs of a step.  Same kernels, same order, same results
+    # eagerly (PACOH_NO_GRAPH=1).
+    GRAPH_CHUNK = 1024
 
-    # ---- one meta-training iteration captured in a hipGraph ----------------------------------------
-    # A MAP iteration is ~10 launches of a few microseconds each, i.e. launch-bound.  The sequence
-    # (task gather -> features -> fused GP LML+grad -> MLP backward -> hyper backward -> AdamW) is captured
-    # once and replayed; per iteration the host only refreshes the sampled task indices and the four
-    # step-dependent Adam scalars (device-side operands of pacoh_adam_step_dev).  Same kernels, same order,
-    # same results as the eager path (PACOH_NO_GRAPH=1 selects it).
-    GRAPH_CHUNK = 1024          # iterations whose task draws / Adam scalars are uploaded in one copy
+    def _setup_step(self):
+        if getattr(self, '_feed', None) is not None:
+            return
+        D = self.layout.D
+        tb_local = len(parallel.shard(np.arange(self.task_batch_size)))
+        self._packed = torch.zeros(D + 1, dtype=self.dtype, device=self.device)      # grad[1, D] | loss: ONE all-reduce operand
+        self._grad, self._g_loss = self._packed[:D].view(1, D), self._packed[D:]
+        self._g_cum = torch.zeros((), dtype=self.dtype, device=self.device)
+        self._fail = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._feed = StepFeed(self.device, self.dtype, tb_local, chunk=self.GRAPH_CHUNK)
+        self._graphs = None
 
-    def _iteration_body(self):
-        # this iteration's row of the pre-uploaded task draws and Adam scalars, selected by a device-side counter
-        idx = self._g_idx_all.index_select(0, self._g_ctr).reshape(-1)
-        self._g_sc.copy_(self._g_sc_all.index_select(0, self._g_ctr).reshape(-1))
-        self._g_ctr.add_(1)
-        batch = self.tasks.select(idx)
-        lml, grad, _ = self.engine.lml_and_grad(self.theta, batch, weight=-1.0)
+    def _body_likelihood(self):
+        self._feed.select()
+        if self._feed.tb == 0:                             # more ranks than tasks in the batch: this rank contributes zeros
+            self._packed.zero_()
+            return
+        batch = self.tasks.select(self._feed.idx)
+        lml, _, _ = self.engine.lml_and_grad(self.theta, batch, weight=-1.0, grad_out=self._grad, fail_flag=self._fail)
         L.reduce_tasks(lml.reshape(-1, 1, 1), self._g_loss.reshape(1, 1), scale=-1.0)            # loss = -sum_t mll_t
-        L.axpy(self._g_cum.reshape(1), self._g_loss.reshape(1), 1.0)
+
+    def _body_update(self):
+        L.axpy(self._g_cum.reshape(1), self._g_loss, 1.0)
         for lo, hi in self.train_segments:
-            L.adam_step_dev(self.theta[0, lo:hi], grad[0, lo:hi], self.exp_avg[0, lo:hi], self.exp_avg_sq[0, lo:hi],
-                            self._g_sc)
+            if self.optimizer_name == 'Adam':
+                L.adam_step_dev(self.theta[0, lo:hi], self._grad[0, lo:hi], self.exp_avg[0, lo:hi], self.exp_avg_sq[0, lo:hi],
+                                self._feed.sc[L.SC_ADAM:L.SC_ADAM + 4])
+            else:
+                L.axpy(self.theta[0, lo:hi], self._grad[0, lo:hi], -self.lr_scheduler.lr)       # (eager only: host scalar)
 
-    def _build_graph(self):
-        dev = self.device
-        self._g_idx_all = torch.zeros(self.GRAPH_CHUNK, self.task_batch_size, dtype=torch.int64, device=dev)
-        self._g_sc_all = torch.tensor([L.adam_scalars(self.lr_scheduler.lr, 1, weight_decay=self.weight_decay)] * self.GRAPH_CHUNK,
-                                      dtype=self.dtype, device=dev)
-        self._g_sc = self._g_sc_all[0].clone()
-        self._g_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
-        self._g_loss = torch.zeros((), dtype=self.dtype, device=dev)
-        self._g_cum = torch.zeros((), dtype=self.dtype, device=dev)
-        saved = [t.clone() for t in (self.theta, self.exp_avg, self.exp_avg_sq)]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                      # warm-up (allocates workspaces outside the graph pool)
-            for _ in range(2):
-                self._iteration_body()
-        torch.cuda.current_stream().wait_stream(side)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._iteration_body()
-        for t, sv in zip((self.theta, self.exp_avg, self.exp_avg_sq), saved):   # undo the warm-up updates
+    def _build_graphs(self):
+        state = (self.theta, self.exp_avg, self.exp_avg_sq, self._feed.ctr, self._fail, self._g_cum)
+        saved = [t.clone() for t in state]
+        if parallel.world()[1] == 1:
+            def whole():
+                self._body_likelihood()
+                self._body_update()
+            self._graphs = (capture_graph(whole),)
+        else:
+            self._graphs = (capture_graph(self._body_likelihood), capture_graph(self._body_update))
+        for t, sv in zip(state, saved):
             t.copy_(sv)
-        self._g_cum.zero_()
-        self._g_ctr.zero_()
 
-    def _upload_chunk(self, n_steps):
-        """draw the next n_steps task batches (same numpy stream as per-iteration draws) and the Adam scalars of
-        those steps (lr schedule included) and upload them with two copies"""
-        idx = np.stack([self.rds_numpy.randint(0, self.tasks.T, size=self.task_batch_size) for _ in range(n_steps)])
-        sched = StepLR(self.lr_scheduler.base_lr, self.lr_scheduler.step_size, self.lr_scheduler.gamma)
-        sched.epoch = self.lr_scheduler.epoch
-        sc = []
-        for k in range(n_steps):
-            sc.append(L.adam_scalars(sched.lr, self.opt_step + k + 1, weight_decay=self.weight_decay))
-            sched.step()
-        self._g_idx_all[:n_steps].copy_(torch.from_numpy(idx))
-        self._g_sc_all[:n_steps].copy_(torch.tensor(sc, dtype=self.dtype))
-        self._g_ctr.zero_()
+    def _all_reduce(self):
+        if parallel.world()[1] > 1:
+            parallel.all_reduce_buffer_(self._packed)
+
+    def _run_step(self, graphed):
+        if graphed:
+            self._graphs[0].replay()
+            if len(self._graphs) > 1:
+                self._all_reduce()
+                self._graphs[1].replay()
+        else:
+            self._body_likelihood()
+            self._all_reduce()
+            self._body_update()
 
     def _use_graph(self):
         # (large contexts run the HBM-resident path, whose launch sequence sets kernel attributes: keep it eager)
         return (self.optimizer_name == 'Adam' and os.environ.get('PACOH_NO_GRAPH', '0') != '1'
                 and self.tasks.n <= L.gp_small_max_n(self.dtype, True) and not L.FORCE_DENSE)
+
+    def _train_steps(self, n_steps):
+        self._setup_step()
+        graphed = self._use_graph()
+        while n_steps > 0:
+            k = min(n_steps, self.GRAPH_CHUNK) if self.optimizer_name == 'Adam' else 1     # SGD reads the host-side learning rate
+            idx_rows, sc_rows = [], []
+            sched = StepLR(self.lr_scheduler.base_lr, self.lr_scheduler.step_size, self.lr_scheduler.gamma)
+            sched.epoch = self.lr_scheduler.epoch
+            for j in range(k):
+                # rds_numpy.choice(task_dicts, size=B) == randint(0, T, B): with replacement (GPR_meta_mll.py:109)
+                idx = self.rds_numpy.randint(0, self.tasks.T, size=self.task_batch_size)
+                idx_rows.append(parallel.shard(idx))
+                sc_rows.append(L.step_scalars(1.0, sched.lr, self.opt_step + j + 1, weight_decay=self.weight_decay))
+                sched.step()
+            parallel.check_same_draws(idx_rows, sc_rows)
+            self._feed.upload(np.stack(idx_rows) if self._feed.tb > 0 else None, sc_rows)
+            if graphed and self._graphs is None:
+                self._build_graphs()
+            for _ in range(k):
+                self._run_step(graphed)
+            self.opt_step += k
+            for _ in range(k):
+                self.lr_scheduler.step()
+            n_steps -= k
 
     # ------------------------------------------------------------------------------------------
     def meta_fit(self, valid_tuples=None, verbose=True, log_period=500, n_iter=None):
@@ -187,44 +211,21 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         loss_val = float('nan')
         if len(self.train_segments) > 0:
             t = time.time()
-            cum_loss = torch.zeros((), dtype=self.dtype, device=self.device)
             if n_iter is None:
                 n_iter = self.num_iter_fit
-            loss = None
-            graphed = self._use_graph()
-            if graphed and getattr(self, '_graph', None) is None:
-                self._build_graph()
-            if graphed:
-                self._g_cum.zero_()
-            left_in_chunk = 0
-            for itr in range(1, n_iter + 1):
-                if graphed:
-                    if left_in_chunk == 0:
-                        # up to the next log line (evaluation reads the parameters there) or the chunk size
-                        to_log = 1 if itr == 1 else (log_period - (itr - 1) % log_period)
-                        left_in_chunk = max(1, min(self.GRAPH_CHUNK, to_log, n_iter - itr + 1))
-                        self._upload_chunk(left_in_chunk)
-                    left_in_chunk -= 1
-                    self.opt_step += 1
-                    self._graph.replay()
-                    loss, cum_loss = self._g_loss, self._g_cum
-                else:
-                    # rds_numpy.choice(task_dicts, size=B) == randint(0, T, B): with replacement (:109)
-                    idx = self.rds_numpy.randint(0, self.tasks.T, size=self.task_batch_size)
-                    if getattr(self, '_idx_up', None) is None:
-                        self._idx_up = AsyncUploader(self.device, torch.int64)
-                    batch = self.tasks.select(self._idx_up.upload(idx))
-                    lml, grad, _ = self.engine.lml_and_grad(self.theta, batch, weight=-1.0)
-                    loss = torch.empty((), dtype=self.dtype, device=self.device)
-                    L.reduce_tasks(lml.reshape(-1, 1, 1), loss.reshape(1, 1), scale=-1.0)
-                    self._apply_update(grad)
-                    L.axpy(cum_loss.reshape(1), loss.reshape(1), 1.0)
-                self.lr_scheduler.step()
+            self._setup_step()
+            self._g_cum.zero_()
+            itr = 0
+            while itr < n_iter:
+                nxt = 1 if itr == 0 else min(n_iter, (itr // log_period + 1) * log_period)      # up to the next log line
+                self._train_steps(nxt - itr)
+                itr = nxt
                 if itr == 1 or itr % log_period == 0:
                     duration = time.time() - t
-                    avg_loss = cum_loss / (log_period if itr > 1 else 1.0)
+                    avg_loss = self._g_cum / (log_period if itr > 1 else 1.0)
                     message = 'Iter %d/%d - Loss: %.6f - Time %.2f sec' % (itr, self.num_iter_fit, avg_loss.item(), duration)
-                    cum_loss.zero_()
+                    self._check_numerics()
+                    self._g_cum.zero_()
                     t = time.time()
                     if valid_tuples is not None:
                         valid_ll, valid_rmse, calibr_err = self.eval_datasets(valid_tuples)
@@ -232,12 +233,20 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
                     self._last_log = message
                     if verbose:
                         self.logger.info(message)
-            if loss is not None:
-                loss_val = loss.item()
+            if n_iter > 0:
+                loss_val = self._g_loss.item()
+            self._check_numerics()
         else:
             self.logger.info('Vanilla mode - nothing to fit')
         self.fitted = True
         return loss_val
+
+    def _check_numerics(self):
+        """raise where the reference raises: gpytorch's psd_safe_cholesky -> NotPSDError (read at synchronisation points only)"""
+        flag = getattr(self, '_fail', None)
+        if flag is not None and int(flag.item()) != 0:
+            flag.zero_()
+            raise NotPSDError('a task kernel matrix was not positive definite even after adding jitter (1e-6 .. 1e-4)')
 
     def predict(self, context_x, context_y, test_x, return_density=False):
         """GPR_meta_mll.py:149-190 -> (pred_mean, pred_std) numpy, or the predictive distribution."""

@@ -2,6 +2,7 @@
 One svgd_step = [MLP fwd x2] -> fused GP LML fwd+bwd over tasks x particles -> [MLP bwd x2] ->
 hyper-prior grad -> SVGD phi -> Adam, all HIP kernels on one stream; with torch.distributed
 initialised, tasks are sharded over ranks and the score is all-reduced once per step (RCCL)."""
+import os
 import time
 
 import numpy as np
@@ -11,7 +12,7 @@ from . import _lib as L
 from . import parallel
 from .abstract import RegressionModelMetaLearned
 from .distributions import GaussianPredictive
-from .engine import AsyncUploader, GPEngine, ParamLayout, TaskBatch
+from .engine import AsyncUploader, GPEngine, NotPSDError, ParamLayout, StepFeed, TaskBatch, capture_graph
 from .util import StepLR
 
 
@@ -84,6 +85,41 @@ class _RandomGPLearner(RegressionModelMetaLearned):
         local = parallel.shard(idx)
         return local, pre
 
+    # ---- the training loop's steps, captured in hipGraphs ---------------------------------------------------------------------
+    # One step is ~12 launches; issued one by one from Python that is ~0.35 ms of host time, more than the GPU needs for a small
+    # configuration or a 1/8 shard of a large one.  The step's kernels read everything that changes between steps (task draws,
+    # pre-factor, learning rate, Adam's bias corrections) from device buffers filled for up to GRAPH_CHUNK steps at once
+    # (engine.StepFeed), so the launch sequence is captured once and replayed.  With several ranks the step is two graphs around
+    # the eager all-reduce of the packed score buffer.  PACOH_NO_GRAPH=1 runs the very same launch sequence eagerly.
+    GRAPH_CHUNK = 1024
+
+    def _graphs_allowed(self):
+        return (os.environ.get('PACOH_NO_GRAPH', '0') != '1' and self.tasks.n <= L.gp_small_max_n(self.dtype, True)
+                and not L.FORCE_DENSE)
+
+    def _local_batch_size(self):
+        return len(parallel.shard(np.arange(self.task_batch_size)))
+
+    def _draw_steps(self, k, lr_scheduler, first_step, weight_decay=0.0):
+        """task draws (this rank's shard) and step scalars of the next k steps; same numpy stream as k single draws"""
+        idx_rows, sc_rows = [], []
+        sched = StepLR(lr_scheduler.base_lr, lr_scheduler.step_size, lr_scheduler.gamma)
+        sched.epoch = lr_scheduler.epoch
+        for j in range(k):
+            local, pre = self._sample_task_batch()
+            idx_rows.append(local)
+            sc_rows.append(L.step_scalars(pre, sched.lr, first_step + j, weight_decay=weight_decay))
+            sched.step()
+        parallel.check_same_draws(idx_rows, sc_rows)
+        return np.stack(idx_rows) if len(idx_rows[0]) > 0 else None, sc_rows
+
+    def _check_numerics(self):
+        """raise where the reference raises: gpytorch's psd_safe_cholesky -> NotPSDError (read at synchronisation points only)"""
+        flag = getattr(self, '_fail', None)
+        if flag is not None and int(flag.item()) != 0:
+            flag.zero_()
+            raise NotPSDError('a task kernel matrix was not positive definite even after adding jitter (1e-6 .. 1e-4)')
+
     def _idx_uploader(self):
         up = getattr(self, '_idx_up', None)
         if up is None:
@@ -145,18 +181,86 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         self.opt_step = 0
         self.lr_scheduler = StepLR(lr, 1000, lr_decay)
         self._svgd_ws = None
+        self._feed = self._graphs = None
         self._setup_tasks(meta_train_data)
         self.fitted = False
 
+    # ---- one SVGD step = likelihood body -> [all-reduce] -> update body ----------------------------------------------------------
+    def _setup_step(self, tb_local):
+        if getattr(self, '_feed', None) is not None and self._feed.tb == tb_local:
+            return
+        P, D = self.particles.shape
+        self._packed, self._score, self._lik = parallel.packed_score_buffer(P, D, self.dtype, self.device)
+        self._fail = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._bw_out = torch.zeros(1, dtype=self.dtype, device=self.device)
+        self._feed = StepFeed(self.device, self.dtype, tb_local, chunk=self.GRAPH_CHUNK)
+        self._graphs = None
+
+    def _body_likelihood(self):
+        """score[P,D] = d/d theta_p sum_t mll[t,p] over this rank's tasks (unscaled), lik[P] the sums themselves"""
+        self._feed.select()
+        if self._feed.tb == 0:
+            self._packed.zero_()
+            return
+        batch = self.tasks.select(self._feed.idx)
+        self.engine.lml_and_grad(self.particles, batch, weight=1.0, lik_out=self._lik, lik_scale=1.0, grad_out=self._score,
+                                 fail_flag=self._fail)
+
+    def _body_update(self):
+        """prior score + pre-factor + bandwidth + phi + optimizer in two launches, particles updated in place"""
+        _, self._svgd_ws = L.svgd_update_dev(self.particles, self._score, self.prior_mean, self.prior_std, self.prior_factor,
+                                             self.bandwidth, self.optimizer_name, self._feed.sc, self.exp_avg, self.exp_avg_sq,
+                                             workspace=self._svgd_ws, bw_out=self._bw_out)
+        self.last_bandwidth = self._bw_out
+
+    def _build_graphs(self):
+        saved = [t.clone() for t in (self.particles, self.exp_avg, self.exp_avg_sq, self._feed.ctr, self._fail)]
+        if parallel.world()[1] == 1:
+            def whole():
+                self._body_likelihood()
+                self._body_update()
+            self._graphs = (capture_graph(whole),)
+        else:
+            self._graphs = (capture_graph(self._body_likelihood), capture_graph(self._body_update))
+        for t, sv in zip((self.particles, self.exp_avg, self.exp_avg_sq, self._feed.ctr, self._fail), saved):
+            t.copy_(sv)                                   # undo what the warm-up runs did
+
+    def _run_step(self, graphed):
+        if graphed:
+            self._graphs[0].replay()
+            if len(self._graphs) > 1:
+                parallel.all_reduce_sum_(self._lik, self._score, self._packed)
+                self._graphs[1].replay()
+        else:
+            self._body_likelihood()
+            parallel.all_reduce_sum_(self._lik, self._score, self._packed)
+            self._body_update()
+
+    def _train_steps(self, n_steps):
+        """the next n_steps SVGD steps of the training loop (task draws from rds_numpy, lr from the scheduler)"""
+        self._setup_step(self._local_batch_size())
+        graphed = self._graphs_allowed()
+        while n_steps > 0:
+            k = min(n_steps, self.GRAPH_CHUNK)
+            idx_rows, sc_rows = self._draw_steps(k, self.lr_scheduler, self.opt_step + 1)
+            self._feed.upload(idx_rows, sc_rows)
+            if graphed and self._graphs is None:
+                self._build_graphs()                      # (captured with real operands in the feed; state and counter are restored)
+            for _ in range(k):
+                self._run_step(graphed)
+            self.opt_step += k
+            for _ in range(k):
+                self.lr_scheduler.step()
+            n_steps -= k
+
     def svgd_step(self, idx_local, pre_factor):
-        """SVGD.step (meta_learn/svgd.py:25-28): particles.grad = -phi; optimizer.step()"""
+        """SVGD.step (meta_learn/svgd.py:25-28) on an explicit task draw: particles.grad = -phi; optimizer.step()"""
         if self.kernel == 'RBF':
-            # prior score + phi + optimizer step in one kernel (three launches with the distance / bandwidth kernels)
-            _, score = self._log_prob_and_score(self.particles, idx_local, pre_factor, with_prior=False)
+            self._setup_step(len(idx_local))
             self.opt_step += 1
-            self.particles, self.last_bandwidth, self._svgd_ws = L.svgd_update(
-                self.particles, score, self.prior_mean, self.prior_std, self.prior_factor, self.bandwidth, self.optimizer_name,
-                self.lr_scheduler.lr, self.opt_step, self.exp_avg, self.exp_avg_sq, workspace=self._svgd_ws)
+            self._feed.upload(np.asarray(idx_local).reshape(1, -1) if len(idx_local) > 0 else None,
+                              [L.step_scalars(pre_factor, self.lr_scheduler.lr, self.opt_step)])
+            self._run_step(False)
             return
         _, score = self._log_prob_and_score(self.particles, idx_local, pre_factor)
         phi_fn = L.svgd_phi_imq                                             # IMQ: alpha=0.5, beta=-0.5 (svgd.py:70)
@@ -174,12 +278,20 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         t = time.time()
         if n_iter is None:
             n_iter = self.num_iter_fit
-        for itr in range(1, n_iter + 1):
-            idx_local, pre = self._sample_task_batch()
-            self.svgd_step(idx_local, pre)
-            self.lr_scheduler.step()
+        itr = 0
+        while itr < n_iter:
+            nxt = 1 if itr == 0 else min(n_iter, (itr // log_period + 1) * log_period)      # up to the next log line
+            if self.kernel == 'RBF':
+                self._train_steps(nxt - itr)
+            else:
+                for _ in range(nxt - itr):
+                    idx_local, pre = self._sample_task_batch()
+                    self.svgd_step(idx_local, pre)
+                    self.lr_scheduler.step()
+            itr = nxt
             if itr == 1 or itr % log_period == 0:
                 torch.cuda.synchronize()
+                self._check_numerics()
                 duration = time.time() - t
                 t = time.time()
                 message = 'Iter %d/%d - Time %.2f sec' % (itr, self.num_iter_fit, duration)
@@ -188,6 +300,7 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
                     message += ' - Valid-LL: %.3f - Valid-RMSE: %.3f - Calib-Err %.3f' % (valid_ll, valid_rmse, calibr_err)
                 if verbose:
                     self.logger.info(message)
+        self._check_numerics()
         self.fitted = True
 
     def predict(self, context_x, context_y, test_x, return_density=False):

@@ -11,7 +11,8 @@ import time
 import torch
 
 from . import _lib as L
-from .engine import AsyncUploader
+from . import parallel
+from .engine import AsyncUploader, StepFeed, capture_graph
 from .GPR_meta_svgd import _RandomGPLearner
 from .util import StepLR
 
@@ -64,6 +65,7 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         self.exp_avg_sq = torch.zeros_like(self.posterior)
         self.opt_step = 0
         self.lr_scheduler = StepLR(lr, 1000, lr_decay)
+        self._feed = self._graphs = None
         self._setup_tasks(meta_train_data)
         self.fitted = False
 
@@ -96,6 +98,81 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         L.reduce_tasks(log_q.reshape(S, 1, 1), loss.reshape(1, 1), scale=self.prior_factor / S, accumulate=True)
         return loss, L.vi_grad(self.posterior, eps, score, self.prior_factor, full=self.cov_type == 'full')
 
+    # ---- one VI step as hipGraph(s): sample + likelihood score -> [all-reduce] -> ELBO gradient + Adam ---------------------------
+    def _setup_step(self, tb_local):
+        if getattr(self, '_feed', None) is not None and self._feed.tb == tb_local:
+            return
+        S, D = self.svi_batch_size, self.layout.D
+        self._packed, self._score, self._lik = parallel.packed_score_buffer(S, D, self.dtype, self.device)
+        self._fail = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._loss = torch.zeros((), dtype=self.dtype, device=self.device)
+        chunk = max(1, min(self.GRAPH_CHUNK, (64 << 20) // (S * D * 4)))         # the noise of a chunk stays below 64 MB
+        self._feed = StepFeed(self.device, self.dtype, tb_local, chunk=chunk, aux_shape=(S, D))
+        self._graphs = None
+
+    def _body_likelihood(self):
+        self._feed.select()
+        self._theta, self._log_q = L.vi_sample(self.posterior, self._feed.aux, full=self.cov_type == 'full')
+        if self._feed.tb == 0:
+            self._packed.zero_()
+            return
+        batch = self.tasks.select(self._feed.idx)
+        self.engine.lml_and_grad(self._theta, batch, weight=1.0, lik_out=self._lik, lik_scale=1.0, grad_out=self._score,
+                                 fail_flag=self._fail)
+
+    def _body_update(self):
+        S = self.svi_batch_size
+        L.scale_dev(self._packed, self._feed.sc[L.SC_SCORE_SCALE:L.SC_SCORE_SCALE + 1])      # pre-factor on score and likelihood
+        logprior = L.prior_logprob_grad(self._theta, self.prior_mean, self.prior_std, self._score, self.prior_factor)
+        L.axpy(self._lik, logprior, self.prior_factor)
+        L.reduce_tasks(self._lik.reshape(S, 1, 1), self._loss.reshape(1, 1), scale=-1.0 / S)
+        L.reduce_tasks(self._log_q.reshape(S, 1, 1), self._loss.reshape(1, 1), scale=self.prior_factor / S, accumulate=True)
+        grad = L.vi_grad(self.posterior, self._feed.aux, self._score, self.prior_factor, full=self.cov_type == 'full')
+        L.adam_step_dev(self.posterior, grad, self.exp_avg, self.exp_avg_sq, self._feed.sc[L.SC_ADAM:L.SC_ADAM + 4])
+
+    def _build_graphs(self):
+        state = (self.posterior, self.exp_avg, self.exp_avg_sq, self._feed.ctr, self._fail)
+        saved = [t.clone() for t in state]
+        if parallel.world()[1] == 1:
+            def whole():
+                self._body_likelihood()
+                self._body_update()
+            self._graphs = (capture_graph(whole),)
+        else:
+            self._graphs = (capture_graph(self._body_likelihood), capture_graph(self._body_update))
+        for t, sv in zip(state, saved):
+            t.copy_(sv)
+
+    def _run_step(self, graphed):
+        if graphed:
+            self._graphs[0].replay()
+            if len(self._graphs) > 1:
+                parallel.all_reduce_sum_(self._lik, self._score, self._packed)
+                self._graphs[1].replay()
+        else:
+            self._body_likelihood()
+            parallel.all_reduce_sum_(self._lik, self._score, self._packed)
+            self._body_update()
+
+    def _train_steps(self, n_steps):
+        self._setup_step(self._local_batch_size())
+        graphed = self._graphs_allowed()
+        S, D = self.svi_batch_size, self.layout.D
+        while n_steps > 0:
+            k = min(n_steps, self._feed.chunk)
+            idx_rows, sc_rows = self._draw_steps(k, self.lr_scheduler, self.opt_step + 1)
+            eps = torch.stack([standard_normal(S, D) for _ in range(k)])        # the reference's stream: one rsample per step
+            self._feed.upload(idx_rows, sc_rows, eps)
+            if graphed and self._graphs is None:
+                self._build_graphs()                      # (captured with real operands in the feed; state and counter are restored)
+            for _ in range(k):
+                self._run_step(graphed)
+            self.opt_step += k
+            for _ in range(k):
+                self.lr_scheduler.step()
+            n_steps -= k
+        return self._loss
+
     def meta_fit(self, valid_tuples=None, verbose=True, log_period=500, n_iter=None):
         """GPR_meta_vi.py:84-128"""
         assert (valid_tuples is None) or (all([len(valid_tuple) == 4 for valid_tuple in valid_tuples]))
@@ -103,26 +180,33 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         if n_iter is None:
             n_iter = self.num_iter_fit
         loss = None
-        for itr in range(1, n_iter + 1):
-            idx_local, pre = self._sample_task_batch()
-            loss, grad = self.get_neg_elbo_and_grad(idx_local, pre)
-            self.opt_step += 1
+        itr = 0
+        while itr < n_iter:
+            nxt = 1 if itr == 0 else min(n_iter, (itr // log_period + 1) * log_period)      # up to the next log line
             if self.optimizer_name == 'Adam':
-                L.adam_step(self.posterior, grad, self.exp_avg, self.exp_avg_sq, self.lr_scheduler.lr, self.opt_step)
+                loss = self._train_steps(nxt - itr)
             else:
-                L.axpy(self.posterior, grad, -self.lr_scheduler.lr)
-            self.lr_scheduler.step()
+                for _ in range(nxt - itr):
+                    idx_local, pre = self._sample_task_batch()
+                    loss, grad = self.get_neg_elbo_and_grad(idx_local, pre)
+                    self.opt_step += 1
+                    L.axpy(self.posterior, grad, -self.lr_scheduler.lr)
+                    self.lr_scheduler.step()
+            itr = nxt
             if itr == 1 or itr % log_period == 0:
                 duration = time.time() - t
                 t = time.time()
                 message = 'Iter %d/%d - Loss: %.6f - Time %.2f sec' % (itr, self.num_iter_fit, loss.item(), duration)
+                self._check_numerics()
                 if valid_tuples is not None:
                     valid_ll, valid_rmse, calibr_err = self.eval_datasets(valid_tuples)
                     message += ' - Valid-LL: %.3f - Valid-RMSE: %.3f - Calib-Err %.3f' % (valid_ll, valid_rmse, calibr_err)
                 if verbose:
                     self.logger.info(message)
         self.fitted = True
-        return loss.item() if loss is not None else float('nan')
+        out = loss.item() if loss is not None else float('nan')
+        self._check_numerics()
+        return out
 
     def predict(self, context_x, context_y, test_x, n_posterior_samples=100, mode='Bayes', return_density=False):
         """GPR_meta_vi.py:130-174: 'Bayes' averages over posterior samples, 'MAP' uses the posterior mode"""

@@ -10,7 +10,7 @@ from . import _lib as L
 from .abstract import _calib_error
 from .config import get_device
 from .distributions import GaussianPredictive
-from .engine import GPEngine, ParamLayout, TaskBatch
+from .engine import GPEngine, NotPSDError, ParamLayout, TaskBatch
 from .util import _handle_input_dimensionality, get_logger
 
 
@@ -23,7 +23,8 @@ class _ReduceLROnPlateau:
         self.best, self.num_bad = -float('inf'), 0
 
     def step(self, metric):
-        if metric > self.best * (1 + self.threshold if self.best > 0 else 1 - self.threshold) or self.best == -float('inf'):
+        # torch's rule for mode='max', threshold_mode='rel' is `metric > best * (1 + threshold)` whatever the sign of best
+        if metric > self.best * (1.0 + self.threshold):
             self.best, self.num_bad = metric, 0
         else:
             self.num_bad += 1
@@ -117,8 +118,9 @@ class GPRegressionLearned:
         t = time.time()
         n_iter = self.num_iter_fit if n_iter is None else n_iter
         loss = None
+        fail = torch.zeros(1, dtype=torch.int32, device=self.device)
         for itr in range(1, n_iter + 1):
-            lml, grad, _ = self.engine.lml_and_grad(self.theta, self.task, weight=-1.0)
+            lml, grad, _ = self.engine.lml_and_grad(self.theta, self.task, weight=-1.0, fail_flag=fail)
             loss = torch.empty((), dtype=self.dtype, device=self.device)
             L.reduce_tasks(lml.reshape(-1, 1, 1), loss.reshape(1, 1), scale=-1.0)
             self.opt_step += 1
@@ -133,6 +135,8 @@ class GPRegressionLearned:
                 duration = time.time() - t
                 t = time.time()
                 message = 'Iter %d/%d - Loss: %.3f - Time %.3f sec' % (itr, self.num_iter_fit, loss.item(), duration)
+                if int(fail.item()) != 0:                 # gpytorch raises inside the loss evaluation (psd_safe_cholesky)
+                    raise NotPSDError('the kernel matrix was not positive definite even after adding jitter (1e-6 .. 1e-4)')
                 if valid_x is not None:
                     valid_ll, valid_rmse, calibr_err = self.eval(valid_x, valid_t)
                     self.lr_scheduler.step(valid_ll)

@@ -51,7 +51,11 @@ SIGNATURES = {
     'pacoh_softplus_fwd': (_i, [_vp, _vp, _d, _l, _i, _vp]),
     'pacoh_softplus_bwd': (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),
     'pacoh_hyper_fwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
-    'pacoh_hyper_bwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _d, _i, _vp]),
+    'pacoh_hyper_bwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _d, _vp, _vp, _i, _vp]),
+    'pacoh_step_select': (_i, [_vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _i, _vp]),
+    'pacoh_scale_dev': (_i, [_vp, _vp, _l, _i, _vp]),
+    'pacoh_svgd_update_dev_workspace_bytes': (_sz, [_i, _i, _i]),
+    'pacoh_svgd_update_dev': (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _vp, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_prior_logprob_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
     'pacoh_svgd_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_phi': (_i, [_vp, _vp, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -105,6 +109,10 @@ def dtype_code(t):
     raise TypeError('PACOH kernels support float32/float64 tensors, got %s' % t.dtype)
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _ptr(t, like=None):
     """device pointer of a contiguous HIP tensor (None -> NULL)"""
     if t is None:
@@ -115,11 +123,12 @@ def _ptr(t, like=None):
         raise RuntimeError('PACOH kernels need contiguous tensors')
     if like is not None and t.dtype != like.dtype and t.dtype not in (torch.int32,):
         raise TypeError('mixed dtypes in one PACOH call: %s vs %s' % (t.dtype, like.dtype))
+    if _raw_device is not None and t.device.index != _raw_device():
+        # launches go to the CURRENT device's stream: a pointer into another device's memory would fault or be read cross-device
+        raise RuntimeError('tensor on %s but the current HIP device is %d: call torch.cuda.set_device first' % (t.device, _raw_device()))
     return ctypes.c_void_p(t.data_ptr())
 
 
-_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
-_raw_device = getattr(torch._C, '_cuda_getDevice', None)
 
 
 def _stream():
@@ -448,15 +457,17 @@ def hyper_fwd(theta, off_ls, f, off_os, off_noise, noise_floor):
 
 
 def hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, grad, lml=None, lik=None,
-              lik_scale=1.0):
-    """lml [T*P] and lik [P] (both or neither): lik[p] = lik_scale * sum_t lml[t, p] in the same launch"""
+              lik_scale=1.0, info=None, fail_flag=None):
+    """lml [T*P] and lik [P] (both or neither): lik[p] = lik_scale * sum_t lml[t, p] in the same launch;
+    info [T*P] and fail_flag [1] (int32, both or neither): fail_flag |= any(info < 0)"""
     lib = load_library()
     P, D = theta.shape
     with _Timed('hyper_bwd'):
         _check(lib.pacoh_hyper_bwd(_ptr(theta), D, P, T, off_ls, f, off_os, off_noise, off_const, _ptr(d_ls, theta),
                                    _ptr(d_os, theta), _ptr(d_noise, theta), _ptr(d_const, theta), _ptr(grad, theta),
-                                   grad.shape[1], _ptr(lml, theta), _ptr(lik, theta), float(lik_scale), dtype_code(theta),
-                                   _stream()), 'pacoh_hyper_bwd')
+                                   grad.shape[1], _ptr(lml, theta), _ptr(lik, theta), float(lik_scale),
+                                   _ptr(info if fail_flag is not None else None), _ptr(fail_flag if info is not None else None),
+                                   dtype_code(theta), _stream()), 'pacoh_hyper_bwd')
 
 
 def prior_logprob_grad(theta, prior_mean, prior_std, grad=None, grad_scale=1.0):
@@ -506,6 +517,53 @@ def svgd_update(X, score, prior_mean, prior_std, prior_factor, bandwidth, optimi
     return X_out, bw_out, workspace
 
 
+SC_SCORE_SCALE, SC_LR, SC_ADAM, SC_COUNT = 0, 1, 4, 8          # PACOH_SC_* of include/pacoh_gp.h
+
+
+def step_scalars(score_scale, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """one row of step scalars (host side, float64): see pacoh_step_select in include/pacoh_gp.h"""
+    row = [0.0] * SC_COUNT
+    row[SC_SCORE_SCALE], row[SC_LR] = score_scale, lr
+    row[SC_ADAM:SC_ADAM + 4] = adam_scalars(lr, step, beta1, beta2, eps, weight_decay)
+    return row
+
+
+def step_select(idx_all, sc_all, counter, idx_out, sc_out, aux_all=None, aux_out=None):
+    """idx_out := idx_all[counter], sc_out := sc_all[counter], aux_out := aux_all[counter], counter += 1 (graph-capturable)"""
+    lib = load_library()
+    tb = idx_all.shape[1] if idx_all is not None else 0
+    n_aux = aux_all[0].numel() if aux_all is not None else 0
+    with _Timed('step_select'):
+        _check(lib.pacoh_step_select(_ptr(idx_all), tb, _ptr(sc_all), sc_all.shape[1], _ptr(aux_all, sc_all), n_aux, _ptr(counter),
+                                     _ptr(idx_out), _ptr(sc_out), _ptr(aux_out, sc_all), dtype_code(sc_all), _stream()), 'pacoh_step_select')
+
+
+def scale_dev(buf, scalar):
+    """buf *= scalar[0] with the scalar in device memory"""
+    with _Timed('scale_dev'):
+        _check(load_library().pacoh_scale_dev(_ptr(buf), _ptr(scalar, buf), buf.numel(), dtype_code(buf), _stream()), 'pacoh_scale_dev')
+
+
+def svgd_update_dev(X, score, prior_mean, prior_std, prior_factor, bandwidth, optimizer, scalars, exp_avg, exp_avg_sq,
+                    workspace=None, bw_out=None, beta1=0.9, beta2=0.999):
+    """the fused SVGD step with its step-dependent scalars in device memory; X is updated in place -> (bandwidth, workspace)"""
+    lib = load_library()
+    P, D = X.shape
+    code = dtype_code(X)
+    need = lib.pacoh_svgd_update_dev_workspace_bytes(P, D, code)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=X.device)
+    if bw_out is None:
+        bw_out = torch.empty(1, dtype=X.dtype, device=X.device)
+    bw = -1.0 if bandwidth is None else float(bandwidth)
+    with _Timed('svgd_phi'):
+        _check(lib.pacoh_svgd_update_dev(_ptr(X), _ptr(score, X), _ptr(prior_mean, X), _ptr(prior_std, X), float(prior_factor), bw,
+                                         int(optimizer == 'Adam'), _ptr(scalars, X), float(beta1), float(beta2), _ptr(exp_avg, X),
+                                         _ptr(exp_avg_sq, X), _ptr(bw_out), _ptr(workspace), P, D, code, _stream()),
+               'pacoh_svgd_update_dev')
+    return bw_out, workspace
+
+
 def svgd_phi_imq(X, score, alpha=0.5, beta=-0.5, bandwidth=None, neg=False, workspace=None):
     """-> (phi[P,D], h[D] | None (fixed bandwidth), workspace)"""
     lib = load_library()
@@ -547,7 +605,8 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, scalars, beta1=0.9, beta2=0.
 
 def axpy(y, x, alpha):
     lib = load_library()
-    _check(lib.pacoh_axpy(_ptr(y), _ptr(x, y), float(alpha), y.numel(), dtype_code(y), _stream()), 'pacoh_axpy')
+    with _Timed('axpy'):
+        _check(lib.pacoh_axpy(_ptr(y), _ptr(x, y), float(alpha), y.numel(), dtype_code(y), _stream()), 'pacoh_axpy')
 
 
 def vi_sample(posterior, eps, full=False):
@@ -583,8 +642,9 @@ def gather_tasks(x, y, n_valid, idx):
     ox = torch.empty(Tb, n, d, dtype=x.dtype, device=x.device)
     oy = torch.empty(Tb, n, dtype=x.dtype, device=x.device)
     onv = torch.empty(Tb, dtype=torch.int32, device=x.device) if n_valid is not None else None
-    _check(lib.pacoh_gather_tasks(_ptr(x), _ptr(y, x), _ptr(n_valid), _ptr(idx), _ptr(ox), _ptr(oy), _ptr(onv), Tb, n, d,
-                                  dtype_code(x), _stream()), 'pacoh_gather_tasks')
+    with _Timed('gather_tasks'):
+        _check(lib.pacoh_gather_tasks(_ptr(x), _ptr(y, x), _ptr(n_valid), _ptr(idx), _ptr(ox), _ptr(oy), _ptr(onv), Tb, n, d,
+                                      dtype_code(x), _stream()), 'pacoh_gather_tasks')
     return ox, oy, onv
 
 

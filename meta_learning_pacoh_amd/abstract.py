@@ -22,6 +22,9 @@ class RegressionModelMetaLearned:
         self.output_dim = None
         self.device = get_device()
         self.dtype = torch.float32
+        from . import parallel
+        if random_seed is None:
+            random_seed = parallel.broadcast_seed(None)   # several ranks must draw the same task batches: agree on rank 0's seed
         if random_seed is not None:                       # abstract.py:125-129
             torch.manual_seed(random_seed)
             self.rds_numpy = np.random.RandomState(random_seed + 1)
@@ -111,32 +114,30 @@ class RegressionModelMetaLearned:
         lcb = pred_dist.icdf(torch.ones(m) * alpha)
         return ucb.cpu(), lcb.cpu()
 
-    # -- normalisation (abstract.py:212-258) --------------------------------------------------------
+    # -- normalisation: pooled z-scoring over all meta-training points (contract of abstract.py:212-258) --------------------
     def _compute_normalization_stats(self, meta_train_tuples):
-        X_stack, Y_stack = list(zip(*[_handle_input_dimensionality(x, y) for x, y in meta_train_tuples]))
-        X, Y = np.concatenate(X_stack, axis=0), np.concatenate(Y_stack, axis=0)
-        if self.normalize_data:
-            self.x_mean, self.y_mean = np.mean(X, axis=0), np.mean(Y, axis=0)
-            self.x_std, self.y_std = np.std(X, axis=0) + 1e-8, np.std(Y, axis=0) + 1e-8
-        else:
-            self.x_mean, self.y_mean = np.zeros(X.shape[1]), np.zeros(Y.shape[1])
-            self.x_std, self.y_std = np.ones(X.shape[1]), np.ones(Y.shape[1])
+        """x_mean/x_std [d], y_mean/y_std [1] over the points of ALL tasks (population std + 1e-8); identity if not normalising"""
+        pooled = [np.concatenate(cols, axis=0) for cols in zip(*(_handle_input_dimensionality(x, y) for x, y in meta_train_tuples))]
+        stats = []
+        for a in pooled:
+            if self.normalize_data:
+                stats.append((a.mean(axis=0), a.std(axis=0) + 1e-8))
+            else:
+                stats.append((np.zeros(a.shape[1]), np.ones(a.shape[1])))
+        (self.x_mean, self.x_std), (self.y_mean, self.y_std) = stats
 
     def _normalize_data(self, X, Y=None):
-        assert hasattr(self, 'x_mean') and hasattr(self, 'x_std'), 'requires computing normalization stats beforehand'
-        X_normalized = (X - self.x_mean[None, :]) / self.x_std[None, :]
-        if Y is None:
-            return X_normalized
-        Y_normalized = (Y - self.y_mean[None, :]) / self.y_std[None, :]
-        return X_normalized, Y_normalized
+        if not hasattr(self, 'x_std'):
+            raise AssertionError('requires computing normalization stats beforehand')
+        Xn = (X - self.x_mean) / self.x_std
+        return Xn if Y is None else (Xn, (Y - self.y_mean) / self.y_std)
 
     def _check_meta_data_shapes(self, meta_train_data):
-        for i in range(len(meta_train_data)):
-            meta_train_data[i] = _handle_input_dimensionality(*meta_train_data[i])
-        self.input_dim = meta_train_data[0][0].shape[-1]
-        self.output_dim = meta_train_data[0][1].shape[-1]
-        assert all([self.input_dim == train_x.shape[-1] and self.output_dim == train_t.shape[-1]
-                    for train_x, train_t in meta_train_data])
+        """every task as 2-D (x, y) in place; all tasks share the input / output widths, which are recorded"""
+        meta_train_data[:] = [_handle_input_dimensionality(x, y) for x, y in meta_train_data]
+        widths = {(x.shape[-1], y.shape[-1]) for x, y in meta_train_data}
+        assert len(widths) == 1, 'tasks disagree on the input / output dimensionality: %s' % sorted(widths)
+        (self.input_dim, self.output_dim), = widths
 
     def _prepare_data_per_task(self, x_data, y_data, flatten_y=True):
         """numpy in, normalised float32 numpy out (the device copy is made by TaskBatch / predict)"""

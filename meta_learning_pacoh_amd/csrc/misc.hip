@@ -51,9 +51,18 @@ __global__ void __launch_bounds__(256) hyper_bwd_kernel(const T* __restrict__ th
                                                         int off_os, int off_noise, int off_const, const T* __restrict__ d_ls,
                                                         const T* __restrict__ d_os, const T* __restrict__ d_noise,
                                                         const T* __restrict__ d_const, T* __restrict__ grad, long gstride,
-                                                        const T* __restrict__ lml, T* __restrict__ lik, T lik_scale) {
+                                                        const T* __restrict__ lml, T* __restrict__ lik, T lik_scale,
+                                                        const int32_t* __restrict__ info, int32_t* __restrict__ fail_flag) {
     __shared__ T red[4];
     const int per = f + 4;
+    // the step's numerical status rides along: any problem whose jittered Cholesky failed (info < 0) raises the caller's flag
+    // (gpytorch's psd_safe_cholesky raises NotPSDError at that point; the host checks the flag at its next synchronisation)
+    if (info && fail_flag && blockIdx.x % per == f + 1) {
+        const int pp = blockIdx.x / per;
+        bool bad = false;
+        for (int t = threadIdx.x; t < Tt; t += 256) bad |= info[(long)t * P + pp] < 0;
+        if (bad) atomicOr(fail_flag, 1);
+    }
     const int w = blockIdx.x;
     const int p = w / per, e = w - p * per;
     const T* src; int width, col, off;
@@ -107,11 +116,16 @@ __global__ void __launch_bounds__(1024) prior_kernel(const T* __restrict__ theta
 // ---- SVGD ---------------------------------------------------------------------------------------
 // stage 1: squared distances, one 256-thread workgroup per (i,j) pair, direct differences
 template <typename T>
-__global__ void __launch_bounds__(256) svgd_dist_kernel(const T* __restrict__ X, T* __restrict__ d2, int P, int D) {
+__global__ void __launch_bounds__(256) svgd_dist_kernel(const T* __restrict__ X, T* __restrict__ d2, int P, int D, T* __restrict__ snap = nullptr) {
     __shared__ T red[4];
     const int i = blockIdx.x / P, j = blockIdx.x - i * P;
     if (j > i) return;
     const T* xi = X + (long)i * D;
+    if (snap && i == j) {                       // the diagonal pairs copy their particle: the in-place update reads the snapshot
+        for (int d = threadIdx.x; d < D; d += 256) snap[(long)i * D + d] = xi[d];
+        if (threadIdx.x == 0) d2[i * P + i] = T(0);
+        return;
+    }
     const T* xj = X + (long)j * D;
     T acc = 0;
     for (int d = threadIdx.x; d < D; d += 256) { T df = xi[d] - xj[d]; acc = fma(df, df, acc); }
@@ -262,7 +276,10 @@ __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ 
                                                           const T* __restrict__ d2, T bandwidth, T* __restrict__ bw_out,
                                                           int use_adam, T lr, T one_minus_b1, T b2,
                                                           T one_minus_b2, T step_size, T bc2_sqrt, T eps,
-                                                          T* __restrict__ m, T* __restrict__ v, T* __restrict__ X_out, int P, int D) {
+                                                          T* __restrict__ m, T* __restrict__ v, T* __restrict__ X_out, int P, int D,
+                                                          const T* __restrict__ sc = nullptr) {
+    T score_scale = T(1);
+    if (sc) { score_scale = sc[0]; lr = sc[1]; step_size = sc[5]; bc2_sqrt = sc[6]; eps = sc[7]; }     // PACOH_SC_* (pacoh_gp.h)
     __shared__ T Ki[64];
     __shared__ T gam_s, rowsum_s;
     const int i = blockIdx.y;
@@ -293,7 +310,7 @@ __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ 
     T acc = 0;
     for (int j = 0; j < P; ++j) {
         const T xj = X[(long)j * D + d];
-        const T sj = score[(long)j * D + d] - pscale * (xj - md);
+        const T sj = score_scale * score[(long)j * D + d] - pscale * (xj - md);
         acc = fma(Ki[j], sj - gam2 * xj, acc);
     }
     const T xi = X[(long)i * D + d];
@@ -407,9 +424,59 @@ __global__ void __launch_bounds__(256) gather_tasks_kernel(const T* __restrict__
     if (threadIdx.x == 0 && n_valid) onv[b] = n_valid[t];
 }
 
+// this step's row of the pre-uploaded task draws and step scalars, selected by a device-side counter (then advanced): what
+// lets a whole meta-training step be captured once in a hipGraph and replayed with nothing but the replay call on the host
+template <typename T>
+__global__ void __launch_bounds__(256) step_select_kernel(const long* __restrict__ idx_all, int tb, const T* __restrict__ sc_all, int n_sc,
+                                                          const T* __restrict__ aux_all, long n_aux, long* __restrict__ counter,
+                                                          long* __restrict__ idx_out, T* __restrict__ sc_out, T* __restrict__ aux_out) {
+    const long row = *counter;
+    if (blockIdx.x == 0) {
+        for (int q = threadIdx.x; q < tb; q += 256) idx_out[q] = idx_all[row * tb + q];
+        for (int q = threadIdx.x; q < n_sc; q += 256) sc_out[q] = sc_all[row * n_sc + q];
+    } else {                                    // blocks 1.. copy the auxiliary payload (PACOH-VI: the step's reparameterisation noise)
+        for (long q = (long)(blockIdx.x - 1) * 256 + threadIdx.x; q < n_aux; q += (long)(gridDim.x - 1) * 256) aux_out[q] = aux_all[row * n_aux + q];
+    }
+}
+// (the counter is advanced by its own one-thread launch after every block has read it)
+__global__ void step_advance_kernel(long* __restrict__ counter) { *counter += 1; }
+
+template <typename T>
+__global__ void scale_dev_kernel(T* __restrict__ buf, const T* __restrict__ sc, long count) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < count) buf[q] *= sc[0];
+}
+
 }  // namespace pacoh
 
 using namespace pacoh;
+
+extern "C" int pacoh_step_select(const int64_t* idx_all, int tb, const void* sc_all, int n_sc, const void* aux_all, long n_aux,
+                                 int64_t* counter, int64_t* idx_out, void* sc_out, void* aux_out, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!counter || tb < 0 || n_sc < 0 || n_aux < 0 || (tb > 0 && (!idx_all || !idx_out)) || (n_sc > 0 && (!sc_all || !sc_out)) ||
+        (n_aux > 0 && (!aux_all || !aux_out))) return PACOH_EINVAL;
+    long ab = n_aux > 0 ? (n_aux + 2047) / 2048 : 0;
+    if (ab > 256) ab = 256;
+    const dim3 grid((unsigned)(1 + ab));
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(step_select_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const long*)idx_all, tb, (const float*)sc_all,
+                           n_sc, (const float*)aux_all, n_aux, (long*)counter, (long*)idx_out, (float*)sc_out, (float*)aux_out);
+    else
+        hipLaunchKernelGGL(step_select_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, (const long*)idx_all, tb, (const double*)sc_all,
+                           n_sc, (const double*)aux_all, n_aux, (long*)counter, (long*)idx_out, (double*)sc_out, (double*)aux_out);
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long*)counter);
+    return launch_status();
+}
+
+extern "C" int pacoh_scale_dev(void* buf, const void* scalar, long count, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!buf || !scalar || count <= 0) return PACOH_EINVAL;
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    if (dtype == PACOH_F32) hipLaunchKernelGGL(scale_dev_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)buf, (const float*)scalar, count);
+    else hipLaunchKernelGGL(scale_dev_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (double*)buf, (const double*)scalar, count);
+    return launch_status();
+}
 
 extern "C" int pacoh_gather_tasks(const void* x, const void* y, const int32_t* n_valid, const int64_t* idx, void* out_x,
                                   void* out_y, int32_t* out_n_valid, int Tb, int n, int d, int dtype, void* stream) {
@@ -443,8 +510,8 @@ extern "C" int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int 
 
 extern "C" int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int T_, int off_ls, int f, int off_os, int off_noise,
                                int off_const, const void* d_ls, const void* d_os, const void* d_noise, const void* d_const,
-                               void* grad, long grad_stride, const void* lml, void* lik, double lik_scale, int dtype,
-                               void* stream) {
+                               void* grad, long grad_stride, const void* lml, void* lik, double lik_scale,
+                               const int32_t* info, int32_t* fail_flag, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!theta || !grad || !d_ls || !d_noise || P <= 0 || T_ <= 0 || f <= 0) return PACOH_EINVAL;
     if ((lml == nullptr) != (lik == nullptr)) return PACOH_EINVAL;
@@ -452,11 +519,11 @@ extern "C" int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int 
     if (dtype == PACOH_F32)
         hipLaunchKernelGGL(hyper_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)theta, theta_stride, P, T_,
                            off_ls, f, off_os, off_noise, off_const, (const float*)d_ls, (const float*)d_os, (const float*)d_noise,
-                           (const float*)d_const, (float*)grad, grad_stride, (const float*)lml, (float*)lik, (float)lik_scale);
+                           (const float*)d_const, (float*)grad, grad_stride, (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag);
     else
         hipLaunchKernelGGL(hyper_bwd_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)theta, theta_stride, P, T_,
                            off_ls, f, off_os, off_noise, off_const, (const double*)d_ls, (const double*)d_os, (const double*)d_noise,
-                           (const double*)d_const, (double*)grad, grad_stride, (const double*)lml, (double*)lik, lik_scale);
+                           (const double*)d_const, (double*)grad, grad_stride, (const double*)lml, (double*)lik, lik_scale, info, fail_flag);
     return launch_status();
 }
 
@@ -499,6 +566,40 @@ extern "C" size_t pacoh_svgd_workspace_bytes(int P, int D, int dtype) {
     (void)D;
     if (P <= 0) return 0;
     return (size_t)(2 * P * P + P + 8) * (dtype == PACOH_F64 ? 8 : 4);
+}
+
+extern "C" size_t pacoh_svgd_update_dev_workspace_bytes(int P, int D, int dtype) {
+    if (P <= 0 || D <= 0) return 0;
+    return (size_t)(P * P + (long)P * D) * (dtype == PACOH_F64 ? 8 : 4);          // distances + snapshot of the particles
+}
+
+template <typename T>
+static int svgd_update_dev_launch(void* X, const void* score, const void* mu, const void* sd, double prior_factor, double bandwidth,
+                                  int use_adam, const void* scalars, double beta1, double beta2, void* m, void* v, void* bw_out,
+                                  void* workspace, int P, int D, hipStream_t s) {
+    T* d2 = (T*)workspace;
+    T* snap = d2 + P * P;
+    hipLaunchKernelGGL(svgd_dist_kernel<T>, dim3(P * P), dim3(256), 0, s, (const T*)X, d2, P, D, snap);
+    hipLaunchKernelGGL(svgd_update_kernel<T>, dim3((D + 255) / 256, P), dim3(256), 0, s, (const T*)snap, (const T*)score, (const T*)mu,
+                       (const T*)sd, (T)prior_factor, (const T*)d2, (T)bandwidth, (T*)bw_out, use_adam, T(0),
+                       (T)(1.0 - beta1), (T)beta2, (T)(1.0 - beta2), T(0), T(1), T(0), (T*)m, (T*)v, (T*)X, P, D, (const T*)scalars);
+    return launch_status();
+}
+
+extern "C" int pacoh_svgd_update_dev(void* X, const void* score, const void* prior_mean, const void* prior_std,
+                                     double prior_factor, double bandwidth, int use_adam, const void* scalars, double beta1,
+                                     double beta2, void* exp_avg, void* exp_avg_sq, void* bw_out, void* workspace, int P, int D,
+                                     int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!X || !score || !scalars || !workspace || P <= 0 || D <= 0) return PACOH_EINVAL;
+    if ((prior_mean == nullptr) != (prior_std == nullptr)) return PACOH_EINVAL;
+    if (use_adam && (!exp_avg || !exp_avg_sq)) return PACOH_EINVAL;
+    if (P > 64) return PACOH_ELIMIT;
+    if (dtype == PACOH_F32)
+        return svgd_update_dev_launch<float>(X, score, prior_mean, prior_std, prior_factor, bandwidth, use_adam, scalars, beta1, beta2,
+                                             exp_avg, exp_avg_sq, bw_out, workspace, P, D, (hipStream_t)stream);
+    return svgd_update_dev_launch<double>(X, score, prior_mean, prior_std, prior_factor, bandwidth, use_adam, scalars, beta1, beta2,
+                                          exp_avg, exp_avg_sq, bw_out, workspace, P, D, (hipStream_t)stream);
 }
 
 template <typename T>

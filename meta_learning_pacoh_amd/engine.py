@@ -137,6 +137,71 @@ class AsyncUploader:
         return out
 
 
+class StepFeed:
+    """Per-step operands of a graph-captured meta-training step (include/pacoh_gp.h, "whole steps as hipGraphs"): the task draws
+    of up to `chunk` steps idx_all[chunk, tb], their step scalars sc_all[chunk, SC_COUNT] and an optional per-step payload
+    aux_all[chunk, ...] (PACOH-VI: the reparameterisation noise) are uploaded with one copy each from pinned memory; select() --
+    the first launch of the captured step -- moves the current row into the fixed buffers idx / sc / aux the kernels read and
+    advances the device-side counter."""
+
+    def __init__(self, device, dtype, tb, chunk=1024, aux_shape=None):
+        self.device, self.dtype, self.tb, self.chunk = device, dtype, int(tb), int(chunk)
+        self.idx_all = torch.zeros(chunk, tb, dtype=torch.int64, device=device) if tb > 0 else None
+        self.idx = torch.zeros(tb, dtype=torch.int64, device=device) if tb > 0 else None
+        self.sc_all = torch.zeros(chunk, L.SC_COUNT, dtype=dtype, device=device)
+        self.sc = torch.zeros(L.SC_COUNT, dtype=dtype, device=device)
+        self.ctr = torch.zeros(1, dtype=torch.int64, device=device)
+        self._h_idx = torch.zeros(chunk, max(tb, 1), dtype=torch.int64).pin_memory()
+        self._h_sc = torch.zeros(chunk, L.SC_COUNT, dtype=dtype).pin_memory()
+        self.aux_all = self.aux = self._h_aux = None
+        if aux_shape is not None:
+            self.aux_all = torch.zeros((chunk,) + tuple(aux_shape), dtype=dtype, device=device)
+            self.aux = torch.zeros(tuple(aux_shape), dtype=dtype, device=device)
+            self._h_aux = torch.zeros((chunk,) + tuple(aux_shape), dtype=dtype).pin_memory()
+        self._ev = None
+
+    def upload(self, idx_rows, sc_rows, aux_rows=None):
+        """idx_rows: int array [k, tb]; sc_rows: k rows of L.step_scalars(); aux_rows: tensor [k, ...] | None; resets the counter"""
+        k = len(sc_rows)
+        assert 0 < k <= self.chunk
+        if self._ev is not None:
+            self._ev.synchronize()                       # the previous chunk's copies have read the pinned buffers
+        self._h_sc[:k].copy_(torch.tensor(sc_rows, dtype=torch.float64))
+        self.sc_all[:k].copy_(self._h_sc[:k], non_blocking=True)
+        if self.tb > 0:
+            self._h_idx[:k].copy_(torch.from_numpy(np.ascontiguousarray(idx_rows)).reshape(k, self.tb))
+            self.idx_all[:k].copy_(self._h_idx[:k], non_blocking=True)
+        if self.aux_all is not None:
+            self._h_aux[:k].copy_(aux_rows)
+            self.aux_all[:k].copy_(self._h_aux[:k], non_blocking=True)
+        self.ctr.zero_()
+        self._ev = self._ev or torch.cuda.Event()
+        self._ev.record()
+
+    def select(self):
+        L.step_select(self.idx_all, self.sc_all, self.ctr, self.idx, self.sc, self.aux_all, self.aux)
+
+
+def capture_graph(body, warmup=2):
+    """hipGraph of body(): warm-up runs on a side stream first (workspaces get allocated outside the graph's pool), then the
+    capture; the caller restores whatever state the warm-up runs changed"""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            body()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        body()
+    return graph
+
+
+class NotPSDError(RuntimeError):
+    """a task's kernel matrix was not positive definite even with the jitter ladder -- what gpytorch's psd_safe_cholesky raises
+    (gpytorch.utils.errors.NotPSDError) inside the reference's loss evaluation"""
+
+
 class GPEngine:
     """Sequences the kernels of one LML(+grad) evaluation for all (task, particle) pairs."""
 
@@ -203,10 +268,11 @@ class GPEngine:
                                        n_valid=batch.n_valid if batch.ragged else None)
         return lml.reshape(T, P), info
 
-    def lml_and_grad(self, theta, batch, weight=1.0, lik_out=None, lik_scale=1.0, grad_out=None):
+    def lml_and_grad(self, theta, batch, weight=1.0, lik_out=None, lik_scale=1.0, grad_out=None, fail_flag=None):
         """returns (lml[T,P], grad[P,D]) with grad = d(weight * sum_t lml[t,p]) / d theta[p];
         lik_out[P] (optional) receives lik_scale * sum_t lml[t,p] from the same launch that reduces the hyper-gradients;
-        grad_out[P,D] (optional, contiguous) is used for the gradient instead of a fresh tensor"""
+        grad_out[P,D] (optional, contiguous) is used for the gradient instead of a fresh tensor;
+        fail_flag (optional int32[1]) is raised by that launch if any problem's Cholesky failed even with jitter"""
         lay = self.layout
         P, D = theta.shape
         T, n = batch.T, batch.n
@@ -214,13 +280,15 @@ class GPEngine:
         dev, dt = theta.device, theta.dtype
         ls, os_, noise = self._hypers(theta)
         z, z_div, mean, mode = self._features(theta, batch.x, T, n)
-        gkey = ('g', B, dt, dev)                        # ONE upstream-gradient vector per batch shape, refilled when the weight changes
-        ent = self._ws.get(gkey)
-        if ent is None or ent[1] != float(weight):
-            g = ent[0] if ent is not None else torch.empty(B, dtype=dt, device=dev)
-            g.fill_(float(weight))
-            ent = self._ws[gkey] = (g, float(weight))
-        g = ent[0]
+        g = None                                        # weight 1: the kernels take g_lml = NULL
+        if float(weight) != 1.0:
+            gkey = ('g', B, dt, dev)                    # ONE upstream-gradient vector per batch shape, refilled when the weight changes
+            ent = self._ws.get(gkey)
+            if ent is None or ent[1] != float(weight):
+                g = ent[0] if ent is not None else torch.empty(B, dtype=dt, device=dev)
+                g.fill_(float(weight))
+                ent = self._ws[gkey] = (g, float(weight))
+            g = ent[0]
         lml, d_z, d_mean, d_ls, d_os, d_noise, info = L.gp_lml_fwdbwd(
             z, z_div, mean, mode, batch.y, P, ls, os_, noise, B, P,
             n_valid=batch.n_valid if batch.ragged else None, g_lml=g, want_dz=(lay.covar_module == 'NN'))
@@ -242,7 +310,8 @@ class GPEngine:
         off_ls, f, off_os, off_noise, off_c = self._hyper_offsets()
         L.hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_c, d_ls, d_os, d_noise,
                     d_mean if lay.mean_module == 'constant' else None, grad,
-                    lml=lml if lik_out is not None else None, lik=lik_out, lik_scale=lik_scale)
+                    lml=lml if lik_out is not None else None, lik=lik_out, lik_scale=lik_scale,
+                    info=info if fail_flag is not None else None, fail_flag=fail_flag)
         return lml.reshape(T, P), grad, info
 
     def predict(self, theta, ctx_x, ctx_y, tst_x, want_cov=False):

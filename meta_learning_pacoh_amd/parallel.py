@@ -31,6 +31,30 @@ def shard(indices, rank=None, world_size=None):
     return indices[rank::world_size]
 
 
+def broadcast_seed(seed):
+    """rank 0's seed on every rank (None at world size 1: nothing to agree on).  Multi-rank runs draw the GLOBAL task batch and
+    PACOH-VI's reparameterisation noise from host generators on every rank; unseeded, each rank would draw its own and the
+    all-reduce would silently sum gradients of different objectives"""
+    _, w = world()
+    if w == 1:
+        return seed
+    box = [int(seed) if seed is not None else int.from_bytes(os.urandom(4), 'little') & 0x7fffffff]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def check_same_draws(idx_rows, sc_rows):
+    """PACOH_CHECK_RANKS=1 (debug): assert that every rank drew the same pre-factors / learning rates for the chunk, i.e. that
+    the host generators of the ranks are in step (the local index lists differ by construction, the scalars must not)"""
+    _, w = world()
+    if w == 1 or os.environ.get('PACOH_CHECK_RANKS', '0') != '1':
+        return
+    mine = [float(sum(r)) for r in sc_rows]
+    box = [None] * w
+    dist.all_gather_object(box, mine)
+    assert all(b == box[0] for b in box), 'ranks drew different task batches: host RNG streams are out of step'
+
+
 class RcclComm:
     """pacoh_comm_* handle of this rank (include/pacoh_gp.h, section 8e): created collectively by every rank"""
 
@@ -77,6 +101,19 @@ def packed_score_buffer(P, D, dtype, device):
     returns (buf, score view, lik view)"""
     buf = torch.empty(P * D + P, dtype=dtype, device=device)
     return buf, buf[:P * D].view(P, D), buf[P * D:]
+
+
+def all_reduce_buffer_(buf):
+    """buf := sum over ranks of buf, in place (identity at world size 1): the step's one exchange"""
+    _, w = world()
+    if w == 1:
+        return buf
+    comm = _direct_comm()
+    if comm is not None:
+        comm.all_reduce_(buf)
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf
 
 
 def all_reduce_sum_(lik, score, packed=None):

@@ -1,45 +1,50 @@
-"""Host-side helpers mirroring meta_learn/util.py (logger, shape handling, LR schedule; the quantile bisection of util.py:9-42 is the HIP kernel behind pacoh_mixture_icdf)."""
+"""Host-side helpers with the interface of meta_learn/util.py: input shape handling (util.py:44-58), the 'gp-priors' logger
+(util.py:60-92) and the learning-rate schedule.  (The quantile bisection of util.py:9-42 is the HIP kernel behind
+pacoh_mixture_icdf.)"""
 import logging
 import os
 
 import numpy as np
 
+LOG_FORMAT = '[%%(asctime)s -%s%%(levelname)s]  %%(message)s'       # the reference's line format, experiment name spliced in
+
+
+def _as_columns(a, what):
+    """1-D array -> one column; anything but a 1-D or 2-D array is refused"""
+    a = np.asarray(a)
+    if a.ndim not in (1, 2):
+        raise AssertionError('%s must be a 1-D or 2-D array, got %d dimensions' % (what, a.ndim))
+    return a.reshape(-1, 1) if a.ndim == 1 else a
+
 
 def _handle_input_dimensionality(x, y=None):
-    """meta_learn/util.py:44-58"""
-    if x.ndim == 1:
-        x = np.expand_dims(x, -1)
-    assert x.ndim == 2
-    if y is not None:
-        if y.ndim == 1:
-            y = np.expand_dims(y, -1)
-        assert x.shape[0] == y.shape[0]
-        assert y.ndim == 2
-        return x, y
-    return x
+    """(x[, y]) as 2-D arrays [n, d] (/ [n, d_y]) with matching numbers of rows -- the contract of util.py:44-58"""
+    x = _as_columns(x, 'x')
+    if y is None:
+        return x
+    y = _as_columns(y, 'y')
+    if len(x) != len(y):
+        raise AssertionError('x and y hold different numbers of points: %d vs %d' % (len(x), len(y)))
+    return x, y
 
 
 def get_logger(log_dir=None, log_file='output.log', expname=''):
-    """meta_learn/util.py:60-92 (without the absl flag lookup): 'gp-priors' logger, same format."""
+    """The process-wide 'gp-priors' logger, configured on first use: INFO to the console and, given log_dir, to
+    log_dir/log_file; later calls return it unchanged.  `logger.log_dir` records where the file handler writes."""
     logger = logging.getLogger('gp-priors')
+    if logger.handlers:
+        return logger
     logger.setLevel(logging.INFO)
-    if len(logger.handlers) == 0:
-        if len(expname) > 0:
-            expname = ' %s - ' % expname
-        formatter = logging.Formatter('[%(asctime)s -' + '%s' % expname + '%(levelname)s]  %(message)s')
-        sh = logging.StreamHandler()
-        sh.setFormatter(formatter)
-        sh.setLevel(logging.INFO)
-        logger.addHandler(sh)
-        logger.propagate = False
-        if log_dir is not None and len(log_dir) > 0:
-            fh = logging.FileHandler(os.path.join(log_dir, log_file))
-            fh.setFormatter(formatter)
-            fh.setLevel(logging.INFO)
-            logger.addHandler(fh)
-            logger.log_dir = log_dir
-        else:
-            logger.log_dir = None
+    logger.propagate = False
+    formatter = logging.Formatter(LOG_FORMAT % (' %s - ' % expname if expname else ''))
+    sinks = [logging.StreamHandler()]
+    logger.log_dir = log_dir if log_dir else None
+    if logger.log_dir:
+        sinks.append(logging.FileHandler(os.path.join(log_dir, log_file)))
+    for sink in sinks:
+        sink.setLevel(logging.INFO)
+        sink.setFormatter(formatter)
+        logger.addHandler(sink)
     return logger
 
 

@@ -562,3 +562,90 @@ def test_eval_datasets_batched_equals_per_task_eval(M):
             torch.manual_seed(9)
             batched = np.array(vi.eval_datasets(mixed, **kw))
             np.testing.assert_allclose(batched, loop, rtol=2e-5, atol=2e-6)
+
+
+# ---- whole steps as hipGraphs: same launch sequence replayed -> bit-identical to issuing it eagerly ------------------------------
+
+def _fit(M, kind, tasks, n_iter, **kw):
+    if kind == 'svgd':
+        m = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=5, task_batch_size=4, lr=1e-2, lr_decay=0.9, random_seed=3, **kw)
+        m.meta_fit(verbose=False, n_iter=n_iter, log_period=3)
+        return m, m.particles
+    if kind == 'vi':
+        m = M.GPRegressionMetaLearnedVI(tasks, svi_batch_size=3, task_batch_size=4, lr=1e-2, random_seed=3, **kw)
+        m.meta_fit(verbose=False, n_iter=n_iter, log_period=3)
+        return m, m.posterior
+    m = M.GPRegressionMetaLearned(tasks, task_batch_size=4, lr_params=1e-2, weight_decay=0.05, lr_decay=0.9, random_seed=3, **kw)
+    m.meta_fit(verbose=False, n_iter=n_iter, log_period=3)
+    return m, m.theta
+
+
+@pytest.mark.parametrize('layers', [(32, 32), (32, 32, 32, 32), (128, 128, 128, 128)])
+@pytest.mark.parametrize('kind', ['svgd', 'vi', 'map'])
+def test_graph_replay_is_bit_identical_to_eager_launches(M, kind, layers, monkeypatch):
+    """meta_fit replays captured step graphs; PACOH_NO_GRAPH=1 issues the same launches one by one: identical bits, also for the
+    launchers' 4 x 32 / 4 x 128 networks, ragged tasks (per-step pre-factor from the device scalars) and a decaying learning rate"""
+    if kind != 'map' and layers[0] == 128:
+        pytest.skip('4 x 128 is the PACOH-MAP launcher configuration')
+    rs = np.random.RandomState(7)
+    tasks = []
+    for t in range(6):
+        n = 9 + 2 * (t % 3)                                   # ragged: 9, 11, 13 points
+        x = rs.uniform(-3, 3, size=(n, 2))
+        tasks.append((x, np.sin(x[:, :1]) + 0.3 * x[:, 1:] + 0.05 * rs.randn(n, 1)))
+    kw = dict(mean_nn_layers=layers, kernel_nn_layers=layers)
+    monkeypatch.setenv('PACOH_NO_GRAPH', '1')
+    m_e, eager = _fit(M, kind, tasks, 8, **kw)
+    assert m_e._graphs is None
+    monkeypatch.delenv('PACOH_NO_GRAPH')
+    m_g, graphed = _fit(M, kind, tasks, 8, **kw)
+    assert m_g._graphs is not None and len(m_g._graphs) == 1
+    assert bool(torch.isfinite(graphed).all()) and torch.equal(eager, graphed)
+    assert m_e.opt_step == m_g.opt_step == 8 and m_e.lr_scheduler.epoch == 8
+
+
+def test_launcher_networks_run_through_the_learners(M):
+    """experiments/meta_GPR_SVGD_base_exp.py:29-30,83 (4 x 32, 10 particles, bandwidth 0.1, prior_factor 0.1, 2 tasks per step) and
+    experiments/meta_GPR_mll_base_exp.py:29-30 (4 x 128, 2 tasks x 5 points per step): construct, train a few steps, predict; the
+    SVGD likelihood score is checked against the oracle"""
+    tasks = O.sinusoid_tasks_nd(20, 20, 1, seed0=40)
+    layers = (32, 32, 32, 32)
+    m = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=10, task_batch_size=2, lr=1e-3, lr_decay=0.98, bandwidth=0.1,
+                                      prior_factor=0.1, weight_prior_std=0.5, mean_nn_layers=layers, kernel_nn_layers=layers,
+                                      random_seed=28)
+    idx = np.array([3, 11])
+    pre = O.meta_pre_factor([20, 20])
+    _, score = m._log_prob_and_score(m.particles, idx, pre, with_prior=False)
+    cfg = O.GPConfig(1, 'NN', 'NN', mean_nn_layers=layers, kernel_nn_layers=layers)
+    stats = O.compute_normalization_stats(tasks)
+    otasks = [O.prepare_task(*tasks[i], stats, torch.float64) for i in idx]
+    th = m.particles.detach().cpu().double().requires_grad_(True)
+    lik = pre * torch.stack([O.vectorized_gp_mll(th, *ot, cfg) for ot in otasks], -1).sum(-1)
+    (ref,) = torch.autograd.grad(lik.sum(), th)
+    assert float((score.cpu().double() - ref).norm() / ref.norm()) < 2e-3
+    m.meta_fit(verbose=False, n_iter=20, log_period=10)
+    mean, std = m.predict(*tasks[0], tasks[1][0])
+    assert np.isfinite(mean).all() and np.isfinite(std).all() and (std > 0).all()
+    tasks5 = O.sinusoid_tasks_nd(20, 5, 1, seed0=41)
+    layers = (128, 128, 128, 128)
+    mm = M.GPRegressionMetaLearned(tasks5, task_batch_size=2, lr_params=1e-3, lr_decay=0.98, mean_nn_layers=layers,
+                                   kernel_nn_layers=layers, random_seed=28)
+    l0 = mm.meta_fit(verbose=False, n_iter=1)
+    mm.meta_fit(verbose=False, n_iter=150, log_period=50)
+    mean, std = mm.predict(*tasks5[0], tasks5[1][0])
+    assert np.isfinite(l0) and np.isfinite(mean).all() and (std > 0).all()
+
+
+def test_failed_cholesky_raises_like_the_reference(M):
+    """NaN parameters make every jittered Cholesky fail (info = -1); gpytorch raises NotPSDError inside the loss evaluation, the
+    learners raise at their next synchronisation point instead of training on NaNs silently"""
+    from meta_learning_pacoh_amd.engine import NotPSDError
+    tasks = O.sinusoid_tasks_nd(5, 8, 1, seed0=50)
+    m = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=3, task_batch_size=3, random_seed=1)
+    m.particles[1, m.layout.slices['lengthscale_raw'][0]] = float('nan')
+    with pytest.raises(NotPSDError):
+        m.meta_fit(verbose=False, n_iter=2)
+    mm = M.GPRegressionMetaLearned(tasks, task_batch_size=3, random_seed=1)
+    mm.theta[0, mm.layout.slices['noise_raw'][0]] = float('nan')
+    with pytest.raises(NotPSDError):
+        mm.meta_fit(verbose=False, n_iter=2)

@@ -53,6 +53,24 @@ def _worker(rank, world, port, out_dir):
     (score_full,) = torch.autograd.grad(full.sum(), th2)
     ok = bool(torch.allclose(lik, full.detach(), rtol=1e-12, atol=1e-12)) and \
         bool(torch.allclose(score, score_full, rtol=1e-10, atol=1e-12))
+    # PACOH-MAP's operand: grad[1, D] | loss in one buffer, summed in place
+    buf = torch.arange(5, dtype=torch.float64) * (rank + 1)
+    parallel.all_reduce_buffer_(buf)
+    ok = ok and bool(torch.equal(buf, torch.arange(5, dtype=torch.float64) * 3))
+    # unseeded learners agree on rank 0's seed; a given seed is kept as rank 0 gave it
+    s_none = parallel.broadcast_seed(None)
+    s_given = parallel.broadcast_seed(100 + rank)
+    box = [None, None]
+    dist.all_gather_object(box, (s_none, s_given))
+    ok = ok and box[0] == box[1] and s_given == 100 and isinstance(s_none, int)
+    # the debug check of the host RNG streams: equal draws pass, different ones are caught
+    os.environ['PACOH_CHECK_RANKS'] = '1'
+    parallel.check_same_draws([np.arange(3)], [[1.0, 2.0]])
+    try:
+        parallel.check_same_draws([np.arange(3)], [[1.0, 2.0 + rank]])
+        ok = False
+    except AssertionError:
+        pass
     with open(os.path.join(out_dir, 'rank%d.txt' % rank), 'w') as f:
         f.write('ok' if ok else 'mismatch')
     dist.destroy_process_group()
