@@ -16,6 +16,7 @@
 // Same arithmetic as gp_small.hip (which remains the general path: any n <= 128, fp64, predict);
 // reference lines replaced: random_gp.py:54-89, GPR_meta_mll.py:104-117 (through gpytorch).
 #include "common.h"
+#include <stdlib.h>
 
 namespace pacoh {
 
@@ -32,6 +33,17 @@ struct GpMfmaArgs {
     float* d_z; float* d_mean; float* d_ls; float* d_os; float* d_noise;
     int B, P, n, f;
 };
+
+#ifdef PACOH_GP_STAMPS
+// diagnostic build (python -m meta_learning_pacoh_amd._build --variant stamps -DPACOH_GP_STAMPS=1, tools/gp_stamps.py): s_memtime at
+// the phase boundaries of every problem's wave, kept in registers and written once at the end to a slot of a device array of its
+// own (no output depends on it, no atomics); summed by pacoh_debug_gp_stamps()
+constexpr int STAMP_SLOTS = 32768;
+__device__ unsigned int g_gp_stamps[STAMP_SLOTS][12];
+#define STAMP(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); st_[k] += (unsigned int)(t_ - t_prev); t_prev = t_; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -107,83 +119,96 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-// value of lane LANE of the own 16-lane row, in every lane of that row: one DPP move (row_newbcast), no LDS, no SGPR round trip.
-// Left to the compiler to schedule: it hoists these moves into the shadow of the rsq / Newton chain.  (Hand-fused
-// v_fmac_f32_dpp in volatile inline assembly has 13 % fewer instructions and is 8 % slower: it pins the order.)
-template <int LANE>
-__device__ __forceinline__ float row_bcast(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + LANE, 0xF, 0xF, true));
-}
-
-// right-looking elimination of the 16x16 block held one row per lane (D[j] = running A[r][j]), steps K..15, fully unrolled so that
-// every broadcast lane is a compile-time constant.  Step K: pivot = A[K][K] from lane K; A[r][j] -= (A[r][K] / pivot) * A[j][K],
-// the column entry A[j][K] coming from lane j's register D[K].
-template <int K, int J>
-__device__ __forceinline__ void factor_update(float (&D)[16], float ntk) {
-    if constexpr (J < 16) {
-        D[J] = fmaf(row_bcast<J>(D[K]), ntk, D[J]);
-        factor_update<K, J + 1>(D, ntk);
-    }
-}
-template <int K>
-__device__ __forceinline__ void factor_steps(float (&D)[16], float (&Lr)[16], float (&inv)[16], bool& ok) {
-    if constexpr (K < 16) {
-        float pk = row_bcast<K>(D[K]);
-        if (!(pk > 0.0f)) { ok = false; pk = 1.0f; }
-        const float rs = __builtin_amdgcn_rsqf(pk);
-        const float rs1 = rs * fmaf(-0.5f * pk * rs, rs, 1.5f);            // one Newton step: 1/sqrt(pk) to fp32 accuracy
-        inv[K] = rs1;
-        Lr[K] = D[K] * rs1;                                                // L[r][K] (valid for r >= K)
-        factor_update<K, K + 1>(D, -(D[K] * (rs1 * rs1)));                 // -A[r][K] / pk
-        factor_steps<K + 1>(D, Lr, inv, ok);
-    }
-}
-// X = L^-1 by forward substitution, lane c = r owns column c: x[I] = (delta(I,c) - sum_{J<I} L[I][J] x[J]) / L[I][I], with L[I][J]
-// taken from lane I's register Lr[J]; four short FMA chains per row instead of one long one
-template <int I, int J>
-__device__ __forceinline__ void inverse_row(const float (&Lr)[16], const float (&x)[16], float (&s)[4]) {
-    if constexpr (J < I) {
-        s[J & 3] = fmaf(-row_bcast<I>(Lr[J]), x[J], s[J & 3]);
-        inverse_row<I, J + 1>(Lr, x, s);
-    }
-}
-template <int I>
-__device__ __forceinline__ void inverse_rows(const float (&Lr)[16], const float (&inv)[16], float (&x)[16], int r) {
-    if constexpr (I < 16) {
-        float s[4] = {(I == r) ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f};
-        inverse_row<I, 0>(Lr, x, s);
-        x[I] = ((s[0] + s[1]) + (s[2] + s[3])) * inv[I];
-        inverse_rows<I + 1>(Lr, inv, x, r);
-    }
-}
-
-// Factor the 16x16 diagonal block at (d0,d0); a pivot that is not positive raises the sticky flag scr[40].  On exit the
-// block holds L11^-1 (lower triangular, zeros above) and invd[d0..d0+15] = 1/diag(L11).
-// Row r of the block sits in the registers of lane r (lanes 16-63 mirror lanes 0-15: four identical 16-lane rows).  Everything a
-// lane needs from another row -- the pivot and column K of the running matrix at step K, later row I of L -- arrives by DPP
-// row_newbcast straight from that lane's register: the whole factor + inverse runs without LDS traffic, barriers or waitcnts
-// (the 32 dependent write -> broadcast-read LDS round trips of the previous formulation were a third of the kernel's time;
-// v_readlane to SGPRs, tried before that, costs VALU->SGPR->VALU wait states on every one of its 240 values).
+// Factor the 16x16 diagonal block at (d0,d0) and invert its factor; a pivot that is not positive raises the sticky flag scr[40]
+// (the block then fills with NaNs, which the retry with more jitter rebuilds from scratch).
+// On exit the block holds L11^-1 (lower triangular, zeros above) and invd[d0..d0+15] = 1/diag(L11).
+//
+// The block S is held in the MFMA accumulator layout (lane (r,g), register s <-> S[4g+s][r]) and eliminated FOUR columns at a
+// time.  Step k: the pivot rows 4k..4k+3 sit in the registers of lane row g = k.  The 4x4 pivot block reaches every lane as
+// ten v_readlane broadcasts (wave-uniform values), the four pivot-row entries of a lane's own column as four ds_bpermute
+// (off the critical path).  Every lane then runs the 4x4 Cholesky Lp in its own registers -- a chain of 4 x (rsq, mul, fma),
+// no cross-lane traffic -- solves its row of the 16x4 panel X Lp^T = S[:,k] by forward substitution, and the rank-4 trailing
+// update S -= X X^T is ONE v_mfma_f32_16x16x4_f32 whose A and B operand are the same register.  The inverse L11^-1 is built
+// alongside by block forward substitution: rows 4k..4k+3 of Z solve Lp Z_k = E_k - (L11 Z)[k], the product L11 Z being four
+// MFMAs with Z (accumulator layout = B operand) straight from registers.  hardware rsq (1 ulp) is used as is.
+// This replaces a column-by-column elimination whose 240 + 240 cross-lane broadcasts (DPP row_newbcast, one per update) formed
+// 16 + 16 dependent steps per block: 5.6 k cycles per block = 35 % of the kernel, and took 100 more registers.
 template <int NW>
-__device__ __forceinline__ void factor_diag_block(float* A, int LD, int d0, float* invd, float* scr, int r, bool active) {
+__device__ __forceinline__ void factor_diag_block(float* A, int LD, int d0, float* invd, float* scr, int r, int g, bool active) {
     // `active` = this wave does the work (wave 0); the caller brackets the call with SYNC() for the other waves.
     if (!active) return;
-    float D[16], Lr[16], inv[16], x[16];
-    const float4* row = reinterpret_cast<const float4*>(A + (d0 + r) * LD + d0);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) { float4 q = row[v]; D[4 * v] = q.x; D[4 * v + 1] = q.y; D[4 * v + 2] = q.z; D[4 * v + 3] = q.w; }
+    float* blk = A + d0 * LD + d0;
+    f32x4 C = load_c(A, LD, d0, d0, r, g);                  // S[4g+s][r]
+    f32x4 Z = {0.f, 0.f, 0.f, 0.f};                         // rows 4g+s of L11^-1, filled block row by block row
     bool ok = true;
-    factor_steps<0>(D, Lr, inv, ok);
-    if (!ok && threadIdx.x == 0) scr[40] = 1.0f;
-    inverse_rows<0>(Lr, inv, x, r);
-    if (threadIdx.x < 16) {                                                // every row was read (in program order) before X lands
 #pragma unroll
-        for (int i = 0; i < 16; ++i) A[(d0 + i) * LD + d0 + r] = x[i];
-        float my_inv = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) my_inv = (r == k) ? inv[k] : my_inv;
-        invd[d0 + r] = my_inv;
+    for (int k = 0; k < 4; ++k) {
+        // pivot block P[c][j] = S[4k+c][4k+j] = register c of lane (r = 4k+j, g = k): wave-uniform
+        const int l0 = 20 * k;
+        const float p00 = readlane_f(C[0], l0), p10 = readlane_f(C[1], l0), p20 = readlane_f(C[2], l0), p30 = readlane_f(C[3], l0);
+        const float p11 = readlane_f(C[1], l0 + 1), p21 = readlane_f(C[2], l0 + 1), p31 = readlane_f(C[3], l0 + 1);
+        const float p22 = readlane_f(C[2], l0 + 2), p32 = readlane_f(C[3], l0 + 2), p33 = readlane_f(C[3], l0 + 3);
+        // rt[c] = S[4k+c][r] = register c of lane (r, g = k)
+        const int src = (16 * k + r) * 4;
+        // (elements copied to scalars first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index)
+        const float c0 = C[0], c1 = C[1], c2 = C[2], c3 = C[3];
+        const float rt0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c0)));
+        const float rt1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c1)));
+        const float rt2 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c2)));
+        const float rt3 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c3)));
+        // ---- 4x4 Cholesky of the pivot block, in every lane: the chain is rsq -> mul -> fma per pivot -----------------------
+        const float r0 = __builtin_amdgcn_rsqf(p00);
+        const float l10 = p10 * r0, l20 = p20 * r0, l30 = p30 * r0;
+        const float q11 = fmaf(-l10, l10, p11);
+        const float r1 = __builtin_amdgcn_rsqf(q11);
+        const float l21 = fmaf(-l20, l10, p21) * r1, l31 = fmaf(-l30, l10, p31) * r1;
+        const float q22 = fmaf(-l21, l21, fmaf(-l20, l20, p22));
+        const float r2 = __builtin_amdgcn_rsqf(q22);
+        const float l32 = fmaf(-l31, l21, fmaf(-l30, l20, p32)) * r2;
+        const float q33 = fmaf(-l32, l32, fmaf(-l31, l31, fmaf(-l30, l30, p33)));
+        const float r3 = __builtin_amdgcn_rsqf(q33);
+        ok = ok && (p00 > 0.0f) && (q11 > 0.0f) && (q22 > 0.0f) && (q33 > 0.0f);        // (off the chain; NaNs compare false)
+        // ---- this lane's row of the panel: X Lp^T = S[:, 4k..4k+3] by forward substitution = column block k of L11 -----------
+        float x0 = rt0 * r0;
+        float x1 = fmaf(-x0, l10, rt1) * r1;
+        float x2 = fmaf(-x1, l21, fmaf(-x0, l20, rt2)) * r2;
+        float x3 = fmaf(-x2, l32, fmaf(-x1, l31, fmaf(-x0, l30, rt3))) * r3;
+        const int rr = r - 4 * k;                            // row inside (0..3) / below (>= 4) / above (< 0) the pivot block
+        if (rr < 0) x0 = 0.0f;
+        if (rr < 1) x1 = 0.0f;
+        if (rr < 2) x2 = 0.0f;
+        if (rr < 3) x3 = 0.0f;
+        if (g == 0) {
+            float4 v; v.x = x0; v.y = x1; v.z = x2; v.w = x3;
+            *reinterpret_cast<float4*>(blk + r * LD + 4 * k) = v;       // L11[:, 4k..4k+3], zeros above the diagonal
+            if (rr >= 0 && rr < 4) invd[d0 + r] = rr == 0 ? r0 : (rr == 1 ? r1 : (rr == 2 ? r2 : r3));
+        }
+        // ---- trailing update S[i][j] -= sum_c X[i][c] X[j][c] for i, j >= 4k+4: one MFMA, A operand == B operand ----------
+        if (k < 3) {
+            const float xg = g == 0 ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));
+            const float am = rr >= 4 ? xg : 0.0f;
+            C = mfma4(-am, am, C);
+        }
+        // ---- rows 4k..4k+3 of L11^-1: Lp Z_k = E_k - (L11 Z)[k-th block row] -------------------------------------------------
+        f32x4 Y = {0.f, 0.f, 0.f, 0.f};
+        if (k > 0) {
+            asm volatile("" ::: "memory");
+            const float4 lw = *reinterpret_cast<const float4*>(blk + r * LD + 4 * g);   // (columns >= 4k meet zero rows of Z)
+            Y = mfma4(lw.x, Z[0], Y); Y = mfma4(lw.y, Z[1], Y); Y = mfma4(lw.z, Z[2], Y); Y = mfma4(lw.w, Z[3], Y);
+        }
+        if (g == k) {
+            const float t0 = (rr == 0 ? 1.0f : 0.0f) - Y[0], t1 = (rr == 1 ? 1.0f : 0.0f) - Y[1];
+            const float t2 = (rr == 2 ? 1.0f : 0.0f) - Y[2], t3 = (rr == 3 ? 1.0f : 0.0f) - Y[3];
+            const float z0 = t0 * r0;
+            const float z1 = fmaf(-z0, l10, t1) * r1;
+            const float z2 = fmaf(-z1, l21, fmaf(-z0, l20, t2)) * r2;
+            const float z3 = fmaf(-z2, l32, fmaf(-z1, l31, fmaf(-z0, l30, t3))) * r3;
+            Z[0] = z0; Z[1] = z1; Z[2] = z2; Z[3] = z3;
+        }
     }
+    if (!ok && threadIdx.x == 0) scr[40] = 1.0f;
+    asm volatile("" ::: "memory");
+    store_c(A, LD, d0, d0, r, g, Z);                         // every read of L11 was issued before (in-order LDS)
 }
 
 // sum over the whole workgroup (NW waves); red = NW floats of LDS scratch
@@ -230,11 +255,16 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
     const int r = lane & 15, g = lane >> 4;
     const long b = blockIdx.x;
     const int n = a.n, f = a.f;
-    const int p = (int)(b % a.P);
-    const long ty = b / a.y_div;
+    // (32-bit unsigned divisions: the 64-bit ones cost ~100 instructions each, three of them per problem)
+    const int p = (int)(blockIdx.x % (unsigned)a.P);
+    const long ty = blockIdx.x / (unsigned)a.y_div;
     int nv = a.n_valid ? a.n_valid[ty] : n;
     nv = nv < n ? nv : n; nv = nv < 0 ? 0 : nv;
 
+#ifdef PACOH_GP_STAMPS
+    unsigned int st_[12] = {};
+    unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
     float ls[FP];
 #pragma unroll
     for (int c = 0; c < FP; ++c) ls[c] = (c < f) ? a.ls[(long)p * f + c] : 1.0f;
@@ -248,7 +278,7 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
     for (int c = 0; c < FP; ++c) zs[c] = 0.0f;
     float ri = 0.0f;
     if (i < nv) {
-        const float* zp = a.z + ((b / a.z_div) * n + i) * (long)f;
+        const float* zp = a.z + ((long)(blockIdx.x / (unsigned)a.z_div) * n + i) * (long)f;
 #pragma unroll
         for (int c = 0; c < FP; ++c) if (c < f) zs[c] = zp[c] / ls[c];
         float mi = 0.0f;
@@ -262,6 +292,7 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
         rv[i] = ri;
     }
     SYNC();
+    STAMP(0);                                  // loads
 
     // ---- Gram build + blocked Cholesky with the psd_safe_cholesky jitter ladder -----------------
     int my_info = -1;
@@ -275,6 +306,31 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
             const int nown = ib == 0 ? 4 : (ib == 1 ? 8 : 10);           // quads of the lane's own row
             const int hoff = ib == 0 ? 48 : (ib == 1 ? 16 : 0);          // helper row offset
             const int c0 = ib == 2 ? 8 : (ib == 3 ? 24 : 0);             // first own column
+            if (nv == NP) {
+                // every row is a real data point (the usual case): no validity masks, and the diagonal term is added afterwards by
+                // one read-modify-write per lane instead of a test in each of the 40 entries (11 instead of ~20 instructions each)
+#pragma unroll 2
+                for (int qq = 0; qq < 10; ++qq) {
+                    const bool help = qq >= nown;
+                    const int row = help ? i + hoff : i;
+                    const int col = help ? 4 * (qq - nown) : c0 + 4 * qq;
+                    float zr[FP];
+#pragma unroll
+                    for (int c = 0; c < FP; ++c) zr[c] = zf[row * FP + c];
+                    float kv[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        float s = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < FP; ++c) { const float d = zr[c] - zf[(col + v) * FP + c]; s = fmaf(d, d, s); }
+                        kv[v] = os * rbf_exp<float>(-0.5f * s);
+                    }
+                    float4 o; o.x = kv[0]; o.y = kv[1]; o.z = kv[2]; o.w = kv[3];
+                    *reinterpret_cast<float4*>(A + row * LD + col) = o;
+                }
+                asm volatile("" ::: "memory");                           // (own row: written by this lane just above, in-order LDS)
+                A[i * LD + i] += noise + jitter;
+            } else {
 #pragma unroll 2
             for (int qq = 0; qq < 10; ++qq) {
                 const bool help = qq >= nown;
@@ -297,6 +353,7 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
                 }
                 float4 o; o.x = kv[0]; o.y = kv[1]; o.z = kv[2]; o.w = kv[3];
                 *reinterpret_cast<float4*>(A + row * LD + col) = o;
+            }
             }
         } else if (i < NP) {
             const int ib = i >> 4;
@@ -322,11 +379,13 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
         }
         if (tid == 0) scr[40] = 0.0f;
         SYNC();
+        STAMP(1);                              // Gram build
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
             const int k0 = kb * 16;
-            factor_diag_block<NW>(A, LD, k0, invd, scr, r, wave == 0);        // wave 0 works, the others join its barriers
+            factor_diag_block<NW>(A, LD, k0, invd, scr, r, g, wave == 0);      // wave 0 works, the others join its barriers
             SYNC();
+            STAMP(2);                          // diagonal blocks
             // panel: L[ib][kb] = A[ib][kb] * Linv^T   (block rows dealt to the waves)
 #pragma unroll
             for (int ib = kb + 1; ib < NB; ++ib) {
@@ -351,6 +410,7 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
                 }
             }
             SYNC();
+            STAMP(3);                          // panel + trailing update
         }
         const bool ok = scr[40] == 0.0f;
         SYNC();                                                   // flag read by all before the next attempt clears it
@@ -382,6 +442,7 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
         }
     }
     SYNC();
+    STAMP(4);                                  // Z = L^-1
     // ---- u = Z r (thread i = row i of Z = column i of the upper storage + its diagonal-block row) -------
     float ui = 0.0f;
     if (i < NP) {
@@ -406,6 +467,7 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
     float lml = nv > 0 ? -0.5f * (quad + 2.0f * logdet + (float)nv * 1.8378770664093453f) / (float)nv : 0.0f;
     if (!okf) lml = NAN;
     if (tid == 0) a.lml[b] = lml;
+    STAMP(5);                                  // u, quadratic form, log-det, lml
     if (!BWD) return;
 
     // ---- W = Z^T Z: block rows dealt to the waves, results overwrite the (dead) lower triangle --------
@@ -445,6 +507,7 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
         }
     }
     SYNC();
+    STAMP(6);                                  // W = Z^T Z + mirror
     // ---- alpha = W r ------------------------------------------------------------------------------
     float ai = 0.0f;
     if (i < NP) {
@@ -460,6 +523,7 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
         av[i] = ai;
     }
     SYNC();
+    STAMP(7);                                  // alpha
     // ---- gradient sums: thread i owns row i of W ---------------------------------------------------
     const float gup = a.g_lml ? a.g_lml[b] : 1.0f;
     float dz[FP], dls[FP];
@@ -507,6 +571,7 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
             }
         }
     }
+    STAMP(8);                                  // gradient loop
     const float bad = okf ? 0.0f : NAN;
     if (a.d_z && i < n) {
         for (int c = 0; c < f; ++c) a.d_z[(b * n + i) * (long)f + c] = (i < nv) ? 2.0f * gup * dz[c] / ls[c] + bad : 0.0f;
@@ -529,14 +594,23 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
         if (a.d_os) a.d_os[b] = gup * sdos + bad;
         a.d_noise[b] = gup * sdnz + bad;
     }
+    STAMP(9);                                  // reductions + stores
+#ifdef PACOH_GP_STAMPS
+    if (lane == 0) {
+        unsigned int* dst = g_gp_stamps[blockIdx.x % STAMP_SLOTS];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) dst[k] += st_[k];
+    }
+#endif
 }
 
 #undef SYNC
 
-template <int NB, bool BWD>
-static int launch_nb(const GpMfmaArgs& a, int FP, hipStream_t s) {
-    constexpr int NP = 16 * NB, LD = NP + 4, NW = NB <= 4 ? 1 : 2;
-    const size_t lds = (size_t)(NP * LD + NP * FP + 3 * NP + 64) * sizeof(float);
+template <int NB, int NW, bool BWD>
+static int launch_nb_nw(const GpMfmaArgs& a, int FP, hipStream_t s) {
+    constexpr int NP = 16 * NB, LD = NP + 4;
+    size_t lds = (size_t)(NP * LD + NP * FP + 3 * NP + 64) * sizeof(float);
+    { const char* e = getenv("PACOH_GP_LDS_PAD"); if (e && e[0]) lds += (size_t)atol(e); }   // occupancy experiments (tools/gp_time.py)
 #define PACOH_GPM_CASE(fp) case fp: { auto kern = gp_mfma_kernel<NB, NW, fp, BWD>; \
         if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PACOH_ELIMIT; \
         hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(64 * NW), lds, s, a); } break;
@@ -544,6 +618,28 @@ static int launch_nb(const GpMfmaArgs& a, int FP, hipStream_t s) {
 #undef PACOH_GPM_CASE
     return launch_status();
 }
+
+template <int NB, bool BWD>
+static int launch_nb(const GpMfmaArgs& a, int FP, hipStream_t s) {
+    if constexpr (NB == 4) {
+        const char* e = getenv("PACOH_GP_NW2");            // experiment: two waves per n <= 64 problem
+        if (e && e[0] == '1') return launch_nb_nw<NB, 2, BWD>(a, FP, s);
+    }
+    return launch_nb_nw<NB, (NB <= 4 ? 1 : 2), BWD>(a, FP, s);
+}
+
+#ifdef PACOH_GP_STAMPS
+extern "C" int pacoh_debug_gp_stamps(unsigned long long* out16, int reset) {
+    static unsigned int host[STAMP_SLOTS][12];
+    if (out16) {
+        if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gp_stamps), sizeof(host)) != hipSuccess) return -1;
+        for (int k = 0; k < 16; ++k) out16[k] = 0;
+        for (int q = 0; q < STAMP_SLOTS; ++q) for (int k = 0; k < 12; ++k) out16[k] += host[q][k];
+    }
+    if (reset) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_gp_stamps)) != hipSuccess || hipMemset(p, 0, sizeof(host)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 // entry used by gp_small.hip's C-ABI functions; returns 1 if this path does not apply
 int gp_mfma_try(const GpMfmaArgs& a, bool bwd, hipStream_t s) {
