@@ -1,0 +1,448 @@
+// Register-resident fused task-GP kernel, fp32, n <= 64, f <= 4: one 64-lane wavefront per (task, particle) problem, and the
+// n x n matrix never leaves the VECTOR REGISTERS: every 16x16 block is held in the v_mfma_f32_16x16x4_f32 accumulator layout
+// (lane (r = l&15, g = l>>4), register s  <->  X[4g+s][r]; four registers per block, the upper block triangle = 40 registers).
+// LDS holds only the vectors (features, residual, alpha: ~2 KB per problem), so occupancy is set by registers, not by the 17.9 KB
+// matrix image the LDS-resident kernel (gp_mfma.hip) needs -- that one is latency-bound with two waves per SIMD.
+//
+// One primitive does all the O(n^3) work.  With the k index of a 16x16x16 product permuted as k = 4g+s, an accumulator-layout
+// block is directly an MFMA operand: as B it stands for itself, as A for its TRANSPOSE.  So  mmT(X, Y) = X^T Y  maps two
+// register blocks to a register block (4 MFMAs, no memory traffic), and a block is transposed by mmT(X, I).  In terms of the
+// upper factor R = L^T (K = R^T R):
+//   Gram build        U[I][J] = os k(z_i, z_j) (+ noise, jitter on the diagonal), I <= J, straight into accumulator layout
+//   Cholesky          diagonal block: factor16() (4x4 pivot blocks, see below) -> Z_K = L_KK^-1;  V_K = Z_K^T = mmT(Z_K, I)
+//                     panel R[K][J] = L_KK^-1 U[K][J] = mmT(V_K, U[K][J]);  trailing U[I][J] -= R[K][I]^T R[K][J] = mmT(R[K][I], R[K][J])
+//   u = L^-1 r        block forward substitution on replicated vectors: u_K = mmT(V_K, r_K - sum_m R[m][K]^T u_m)
+//   L^-1 (backward)   G[I][J] = -L_II^-1 sum_m L[I][m] G[m][J] = -mmT(V_I, sum_m mmT(R[m][I], G[m][J]))
+//   W = K^-1          W[I][J] = sum_m G[m][I]^T G[m][J] = mmT(G[m][I], G[m][J]);   alpha = L^-T u = sum_I mmT(G[I][K], u_I)
+//   gradient sums     in accumulator layout over the UPPER block triangle only (40 entries per lane instead of 64 rows x
+//                     columns): an off-diagonal entry feeds the row sum of i and the column sum of j; row sums are reduced
+//                     over the 16 lanes of a row by DPP, column sums over the four lane rows by two lane exchanges.
+// factor16(): the 16x16 diagonal block is eliminated four columns at a time -- the 4x4 pivot block reaches every lane by ten
+// v_readlane broadcasts, every lane runs the 4x4 Cholesky in its own registers (rsq -> mul -> fma per pivot), solves its row of
+// the 16x4 panel, the rank-4 trailing update is one MFMA (A operand == B operand), and L_KK^-1 is built alongside by block
+// forward substitution with L_KK^T kept in registers too.
+//
+// Same arithmetic as gp_mfma.hip / gp_small.hip; reference lines replaced: random_gp.py:54-89, GPR_meta_mll.py:104-117
+// (ExactMarginalLogLikelihood + autograd through gpytorch).
+#include "common.h"
+#include <stdlib.h>
+
+namespace pacoh {
+
+struct GpMfmaArgs {            // (same struct as in gp_small.hip / gp_mfma.hip)
+    const float* z; int z_div;
+    const float* mean; int mean_mode;
+    const float* y; int y_div;
+    const float* ls; const float* os; const float* noise;
+    const int32_t* n_valid;
+    const float* g_lml;
+    float* lml; int32_t* info;
+    float* d_z; float* d_mean; float* d_ls; float* d_os; float* d_noise;
+    int B, P, n, f;
+};
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ f32x4 mfma_(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// acc + X^T Y  /  acc - X^T Y   (X, Y, acc: 16x16 blocks in accumulator layout)
+__device__ __forceinline__ f32x4 mmT(const f32x4& X, const f32x4& Y, f32x4 acc) {
+    acc = mfma_(X[0], Y[0], acc); acc = mfma_(X[1], Y[1], acc); acc = mfma_(X[2], Y[2], acc); acc = mfma_(X[3], Y[3], acc);
+    return acc;
+}
+__device__ __forceinline__ f32x4 mmT_neg(const f32x4& X, const f32x4& Y, f32x4 acc) {
+    acc = mfma_(-X[0], Y[0], acc); acc = mfma_(-X[1], Y[1], acc); acc = mfma_(-X[2], Y[2], acc); acc = mfma_(-X[3], Y[3], acc);
+    return acc;
+}
+
+__device__ __forceinline__ float readlane_(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF));
+}
+// sum over the 16 lanes of the own lane row, in every lane of the row
+__device__ __forceinline__ float row_sum_(float v) {
+    v = dpp_add_<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
+    v = dpp_add_<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
+    v = dpp_add_<0x141, 0xF>(v);      // row_half_mirror
+    v = dpp_add_<0x140, 0xF>(v);      // row_mirror
+    return v;
+}
+// sum over the 64 lanes, as a wave-uniform value
+__device__ __forceinline__ float wave_sum_(float v) {
+    v = row_sum_(v);
+    v = dpp_add_<0x142, 0xA>(v);      // row_bcast15 into rows 1 and 3
+    v = dpp_add_<0x143, 0xC>(v);      // row_bcast31 into rows 2 and 3: lane 63 holds the total
+    return readlane_(v, 63);
+}
+
+// Cholesky of the 16x16 block C (accumulator layout, symmetric) and the inverse of its factor: on exit Z = L^-1 (accumulator
+// layout, zeros above the diagonal).  `ok` is cleared by a pivot that is not positive (the block then fills with NaNs; the
+// retry with more jitter starts from a fresh Gram matrix).  The 16 reciprocal square roots of the pivots are handed out one
+// per lane (lane base + 4k + j keeps pivot 4k+j in myr) for the log-determinant.
+__device__ __forceinline__ void factor16(f32x4 C, f32x4& Z, float& myr, bool& ok, int lane_base, int lane, int r, int g) {
+    f32x4 Lt = {0.f, 0.f, 0.f, 0.f};                        // L^T in accumulator layout: register s of lane (r, g) = L[r][4g+s]
+    Z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // pivot block P[c][j] = C[4k+c][4k+j] = register c of lane (r = 4k+j, g = k): wave-uniform
+        const float c0 = C[0], c1 = C[1], c2 = C[2], c3 = C[3];
+        const int l0 = 20 * k;
+        const float p00 = readlane_(c0, l0), p10 = readlane_(c1, l0), p20 = readlane_(c2, l0), p30 = readlane_(c3, l0);
+        const float p11 = readlane_(c1, l0 + 1), p21 = readlane_(c2, l0 + 1), p31 = readlane_(c3, l0 + 1);
+        const float p22 = readlane_(c2, l0 + 2), p32 = readlane_(c3, l0 + 2), p33 = readlane_(c3, l0 + 3);
+        // rt[c] = C[4k+c][r] = register c of lane (r, g = k)
+        const int src = (16 * k + r) * 4;
+        const float rt0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c0)));
+        const float rt1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c1)));
+        const float rt2 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c2)));
+        const float rt3 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c3)));
+        const float r0 = __builtin_amdgcn_rsqf(p00);
+        const float l10 = p10 * r0, l20 = p20 * r0, l30 = p30 * r0;
+        const float q11 = fmaf(-l10, l10, p11);
+        const float r1 = __builtin_amdgcn_rsqf(q11);
+        const float l21 = fmaf(-l20, l10, p21) * r1, l31 = fmaf(-l30, l10, p31) * r1;
+        const float q22 = fmaf(-l21, l21, fmaf(-l20, l20, p22));
+        const float r2 = __builtin_amdgcn_rsqf(q22);
+        const float l32 = fmaf(-l31, l21, fmaf(-l30, l20, p32)) * r2;
+        const float q33 = fmaf(-l32, l32, fmaf(-l31, l31, fmaf(-l30, l30, p33)));
+        const float r3 = __builtin_amdgcn_rsqf(q33);
+        ok = ok && (p00 > 0.0f) && (q11 > 0.0f) && (q22 > 0.0f) && (q33 > 0.0f);
+        const int lp = lane - lane_base - 4 * k;
+        myr = lp == 0 ? r0 : (lp == 1 ? r1 : (lp == 2 ? r2 : (lp == 3 ? r3 : myr)));
+        // this lane's row of the panel: X Lp^T = C[:, 4k..4k+3] by forward substitution = L[r][4k..4k+3]
+        float x0 = rt0 * r0;
+        float x1 = fmaf(-x0, l10, rt1) * r1;
+        float x2 = fmaf(-x1, l21, fmaf(-x0, l20, rt2)) * r2;
+        float x3 = fmaf(-x2, l32, fmaf(-x1, l31, fmaf(-x0, l30, rt3))) * r3;
+        const int rr = r - 4 * k;                            // row inside (0..3) / below (>= 4) / above (< 0) the pivot block
+        if (rr < 0) x0 = 0.0f;
+        if (rr < 1) x1 = 0.0f;
+        if (rr < 2) x2 = 0.0f;
+        if (rr < 3) x3 = 0.0f;
+        if (g == k) { Lt[0] = x0; Lt[1] = x1; Lt[2] = x2; Lt[3] = x3; }
+        if (k < 3) {                                         // C[i][j] -= sum_c X[i][c] X[j][c] for i, j >= 4k+4: one MFMA
+            const float xg = g == 0 ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));
+            const float am = rr >= 4 ? xg : 0.0f;
+            C = mfma_(-am, am, C);
+        }
+        // rows 4k..4k+3 of L^-1: Lp Z_k = E_k - (L Z)[k-th block row]   (columns >= 4k of L meet zero rows of Z)
+        f32x4 Y = {0.f, 0.f, 0.f, 0.f};
+        if (k > 0) Y = mmT(Lt, Z, Y);
+        if (g == k) {
+            const float t0 = (rr == 0 ? 1.0f : 0.0f) - Y[0], t1 = (rr == 1 ? 1.0f : 0.0f) - Y[1];
+            const float t2 = (rr == 2 ? 1.0f : 0.0f) - Y[2], t3 = (rr == 3 ? 1.0f : 0.0f) - Y[3];
+            const float z0 = t0 * r0;
+            const float z1 = fmaf(-z0, l10, t1) * r1;
+            const float z2 = fmaf(-z1, l21, fmaf(-z0, l20, t2)) * r2;
+            const float z3 = fmaf(-z2, l32, fmaf(-z1, l31, fmaf(-z0, l30, t3))) * r3;
+            Z[0] = z0; Z[1] = z1; Z[2] = z2; Z[3] = z3;
+        }
+    }
+}
+
+__host__ __device__ constexpr int uidx(int NB, int K, int J) { return K * NB - K * (K - 1) / 2 + (J - K); }   // upper block (K <= J)
+
+}  // namespace
+
+// waves per SIMD the register allocation aims at (occupancy is what this kernel lives on): the n <= 64 backward kernel needs 151
+// registers (3 waves; its 12 KB LDS image of W admits 13 problems per CU), up to n = 48 everything fits 128 (4 waves)
+#ifdef PACOH_GPR_MINW
+#define GPR_MINW(NB, FP, BWD) PACOH_GPR_MINW
+#else
+#define GPR_MINW(NB, FP, BWD) ((NB) == 4 ? ((FP) == 4 && (BWD) ? 2 : 3) : 4)
+#endif
+template <int NB, int FP, bool BWD>
+__global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfmaArgs a) {
+    constexpr int NP = 16 * NB;
+    constexpr int NU = NB * (NB + 1) / 2;
+    __shared__ __attribute__((aligned(16))) float zf[NP * FP];      // features / lengthscale
+    __shared__ __attribute__((aligned(16))) float rv[NP];           // residual
+    __shared__ __attribute__((aligned(16))) float av[NP];           // alpha
+    __shared__ __attribute__((aligned(16))) float dzc[BWD ? NP * FP : 1];   // d_z before the chain-rule factors
+    // W = K^-1, upper block triangle, each block as the 64 lanes' accumulator registers (one 16-byte slot per lane): parked here
+    // between the matrix-core phase that produces it and the gradient loop that consumes it, so that the two phases do not have
+    // to share the register file (2.5 KB per block; with it a problem holds 12 KB of LDS = 13 problems per CU)
+    __shared__ __attribute__((aligned(16))) float Wl[BWD ? NU * 256 : 4];
+#define WSYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)   // in-order LDS within one wave
+    // The kernel is one long unrolled instruction stream of mutually independent block computations; left alone, the scheduler
+    // interleaves dozens of them (40 exp chains of the Gram build at once) and the register file overflows.  Fences between the
+    // blocks keep the live set at what the algorithm needs.
+#define SCHED_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    const int lane = threadIdx.x;
+    const int r = lane & 15, g = lane >> 4;
+    const long b = blockIdx.x;
+    const int n = a.n, f = a.f;
+    const int p = (int)(blockIdx.x % (unsigned)a.P);
+    const long ty = blockIdx.x / (unsigned)a.y_div;
+    int nv = a.n_valid ? a.n_valid[ty] : n;
+    nv = nv < n ? nv : n; nv = nv < 0 ? 0 : nv;
+
+    float ls[FP];
+#pragma unroll
+    for (int c = 0; c < FP; ++c) ls[c] = (c < f) ? a.ls[(long)p * f + c] : 1.0f;
+    const float os = a.os ? a.os[p] : 1.0f;
+    const float noise = a.noise[p];
+
+    // ---- features (pre-divided by the lengthscale) and residual, lane i = row i -------------------------------------------
+    const int i = lane;
+    float zs[FP];
+#pragma unroll
+    for (int c = 0; c < FP; ++c) zs[c] = 0.0f;
+    float ri = 0.0f;
+    if (i < nv) {
+        const float* zp = a.z + ((long)(blockIdx.x / (unsigned)a.z_div) * n + i) * (long)f;
+#pragma unroll
+        for (int c = 0; c < FP; ++c) if (c < f) zs[c] = zp[c] / ls[c];
+        float mi = 0.0f;
+        if (a.mean_mode == PACOH_MEAN_VECTOR) mi = a.mean[b * n + i];
+        else if (a.mean_mode == PACOH_MEAN_CONST) mi = a.mean[p];
+        ri = a.y[ty * n + i] - mi;
+    }
+    if (i < NP) {
+#pragma unroll
+        for (int c = 0; c < FP; ++c) zf[i * FP + c] = zs[c];
+        rv[i] = ri;
+    }
+    WSYNC();
+
+    f32x4 Id;                                                 // identity block in accumulator layout
+#pragma unroll
+    for (int s = 0; s < 4; ++s) Id[s] = (4 * g + s == r) ? 1.0f : 0.0f;
+
+    // ---- Gram build + blocked Cholesky (upper factor R = L^T) with the psd_safe_cholesky jitter ladder ------------------------
+    f32x4 U[NU];                                              // U[uidx(K,J)], K <= J: block (K,J) of the matrix -> R[K][J]
+    f32x4 Zd[NB];                                             // L_KK^-1
+    f32x4 uB[NB];                                             // u = L^-1 r, replicated: register s of lane (r,g) = u[16K + 4g+s]
+    f32x4 G[NB][NB];                                          // strictly-lower blocks of L^-1 (backward only)
+    float myr = 1.0f;                                         // 1/sqrt(pivot `lane`) (1 for padding rows)
+    int my_info = -1;
+    float jitter = 0.0f;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            float zr[4][FP];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < FP; ++c) zr[s][c] = zf[(16 * I + 4 * g + s) * FP + c];
+#pragma unroll
+            for (int J = I; J < NB; ++J) {
+                float zc[FP];
+#pragma unroll
+                for (int c = 0; c < FP; ++c) zc[c] = zf[(16 * J + r) * FP + c];
+                const int jj = 16 * J + r;
+                f32x4 blk;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int ii = 16 * I + 4 * g + s;
+                    float q = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < FP; ++c) { const float d = zr[s][c] - zc[c]; q = fmaf(d, d, q); }
+                    float k = os * rbf_exp<float>(-0.5f * q);
+                    if (nv < NP) { if (!(ii < nv && jj < nv)) k = 0.0f; }
+                    if (I == J) { if (ii == jj) k = (ii < nv) ? k + noise + jitter : 1.0f; }
+                    blk[s] = -k;                              // (the NEGATED matrix is stored: see the trailing update)
+                }
+                U[uidx(NB, I, J)] = blk;
+                SCHED_FENCE();
+            }
+        }
+        bool ok = true;
+        myr = 1.0f;
+        // Step K also finishes everything that only needs block rows <= K of R: u_K and (backward) block row K of L^-1, so that
+        // V_K is a temporary and column K of R is dead afterwards -- the matrix drains out of the register file as the loop advances.
+#pragma unroll
+        for (int K = 0; K < NB; ++K) {
+            SCHED_FENCE();
+            // Signs: the matrix cores only accumulate (D = C + A B), and negating an operand costs four moves plus four more live
+            // registers per product.  So the blocks not yet eliminated are kept NEGATED (Un = -A): the trailing update becomes
+            // Un[I][J] += R[K][I]^T R[K][J] with both operands as they are, and every other product of the step takes the one
+            // negated operand Vn = -L_KK^-T.
+            factor16(-U[uidx(NB, K, K)], Zd[K], myr, ok, 16 * K, lane, r, g);
+            SCHED_FENCE();
+            const f32x4 Vn = mmT_neg(Zd[K], Id, f32x4{0.f, 0.f, 0.f, 0.f});          // -L_KK^-T
+#pragma unroll
+            for (int J = K + 1; J < NB; ++J) U[uidx(NB, K, J)] = mmT(Vn, U[uidx(NB, K, J)], f32x4{0.f, 0.f, 0.f, 0.f});   // R[K][J] = L_KK^-1 A[K][J]
+            SCHED_FENCE();
+            {   // u_K = L_KK^-1 (r_K - sum_m L[K][m] u_m), L[K][m] = R[m][K]^T: accumulate tn = -r_K + sum_m R[m][K]^T u_m
+                f32x4 tn = -*reinterpret_cast<const f32x4*>(rv + 16 * K + 4 * g);
+#pragma unroll
+                for (int m = 0; m < K; ++m) tn = mmT(U[uidx(NB, m, K)], uB[m], tn);
+                uB[K] = mmT(Vn, tn, f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+            SCHED_FENCE();
+            if (BWD) {
+#pragma unroll
+                for (int J = 0; J < K; ++J) {                                          // G[K][J] = -L_KK^-1 sum_m L[K][m] Linv[m][J]
+                    f32x4 S = mmT(U[uidx(NB, J, K)], Zd[J], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                    for (int m = J + 1; m < K; ++m) S = mmT(U[uidx(NB, m, K)], G[m][J], S);
+                    G[K][J] = mmT(Vn, S, f32x4{0.f, 0.f, 0.f, 0.f});
+                    SCHED_FENCE();
+                }
+            }
+#pragma unroll
+            for (int I = K + 1; I < NB; ++I)
+#pragma unroll
+                for (int J = I; J < NB; ++J) U[uidx(NB, I, J)] = mmT(U[uidx(NB, K, I)], U[uidx(NB, K, J)], U[uidx(NB, I, J)]);
+        }
+        if (ok) { my_info = attempt; break; }                // (wave-uniform)
+        jitter = 1e-6f;
+        for (int q = 0; q < attempt; ++q) jitter *= 10.0f;
+    }
+    const bool okf = my_info >= 0;
+    if (lane == 0 && a.info) a.info[b] = my_info;
+
+    float q2 = 0.0f;
+#pragma unroll
+    for (int K = 0; K < NB; ++K) q2 += (uB[K][0] * uB[K][0] + uB[K][1] * uB[K][1]) + (uB[K][2] * uB[K][2] + uB[K][3] * uB[K][3]);
+    const float quad = wave_sum_(r == 0 ? q2 : 0.0f);
+    const float logdet = wave_sum_(-logf(myr));               // log det = 2 sum log L_ii; padding rows have pivot 1
+    float lml = nv > 0 ? -0.5f * (quad + 2.0f * logdet + (float)nv * 1.8378770664093453f) / (float)nv : 0.0f;
+    if (!okf) lml = NAN;
+    if (lane == 0) a.lml[b] = lml;
+    if (!BWD) return;
+
+    SCHED_FENCE();
+    // ---- alpha = L^-T u (replicated), published to LDS for the column-indexed uses ----------------------------------------------
+    f32x4 aB[NB];
+#pragma unroll
+    for (int K = 0; K < NB; ++K) {
+        f32x4 t = mmT(Zd[K], uB[K], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int I = K + 1; I < NB; ++I) t = mmT(G[I][K], uB[I], t);
+        aB[K] = t;
+        if (r == 0) *reinterpret_cast<f32x4*>(av + 16 * K + 4 * g) = t;
+        SCHED_FENCE();
+    }
+    // ---- W = K^-1, upper block triangle: W[I][J] = sum_{m >= J} Linv[m][I]^T Linv[m][J]  ->  LDS --------------------------------
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+#pragma unroll
+        for (int J = I; J < NB; ++J) {
+            f32x4 Wb = mmT(I == J ? Zd[J] : G[J][I], Zd[J], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int m = J + 1; m < NB; ++m) Wb = mmT(G[m][I], G[m][J], Wb);
+            *reinterpret_cast<f32x4*>(Wl + uidx(NB, I, J) * 256 + lane * 4) = Wb;
+        }
+    }
+    SCHED_FENCE();
+    WSYNC();
+    // ---- gradient sums over the upper block triangle -----------------------------------------------------------------------------
+    const float gup = a.g_lml ? a.g_lml[b] : 1.0f;
+    const float inv2n = nv > 0 ? 0.5f / (float)nv : 0.0f;
+    float dls[FP];
+#pragma unroll
+    for (int c = 0; c < FP; ++c) dls[c] = 0.0f;
+    float dos = 0.0f, dnz = 0.0f;
+    // Every ordered pair (i, j) is visited, column block by column block: lane (r, g) holds the entries (i = 16I + 4g+s, j = 16J + r),
+    // so everything destined for point j -- d_z[j] = sum_i M_ij (z_i - z_j) -- accumulates in the lane over s and I and needs only
+    // two lane exchanges (over g) per column block at the end.  (Using the symmetry instead -- upper blocks only, each entry feeding
+    // the row sum of i as well -- saves 24 of the 64 exponentials per lane but needs sums over the 16 lanes of a row: 128 DPP adds,
+    // and the compiler kept every block row's partial sums alive to the end of the kernel, 100 registers over budget.)
+    // W[I][J] for I > J is the transpose of the stored block (J, I): read element by element from its LDS image.
+    // (real loops, all operands from LDS: fully unrolled, the compiler hoists the loads of every iteration to the top and spills)
+#pragma unroll 1
+    for (int J = 0; J < NB; ++J) {
+        float zc[FP], colacc[FP];
+#pragma unroll
+        for (int c = 0; c < FP; ++c) { zc[c] = zf[(16 * J + r) * FP + c]; colacc[c] = 0.0f; }
+        const float aj = av[16 * J + r];
+#pragma unroll 1
+        for (int I = 0; I < NB; ++I) {
+            f32x4 Wb;
+            if (I <= J) {
+                Wb = *reinterpret_cast<const f32x4*>(Wl + (I * NB - I * (I - 1) / 2 + (J - I)) * 256 + lane * 4);
+            } else {
+                const float* wt = Wl + (J * NB - J * (J - 1) / 2 + (I - J)) * 256 + (16 * (r >> 2)) * 4 + (r & 3);   // element (r, 4g+s) of block (J, I)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Wb[s] = wt[(4 * g + s) * 4];
+            }
+            const f32x4 ai4 = *reinterpret_cast<const f32x4*>(av + 16 * I + 4 * g);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float zi[FP];
+#pragma unroll
+                for (int c = 0; c < FP; ++c) zi[c] = zf[(16 * I + 4 * g + s) * FP + c];
+                float Gij = (ai4[s] * aj - Wb[s]) * inv2n;
+                if (I == J) {
+                    const int ii = 16 * I + 4 * g + s;
+                    if (ii >= nv) Gij = 0.0f;                 // identity padding: its diagonal must not count
+                    if (4 * g + s == r) dnz += Gij;
+                }
+                float q = 0.0f, df[FP];
+#pragma unroll
+                for (int c = 0; c < FP; ++c) { df[c] = zi[c] - zc[c]; q = fmaf(df[c], df[c], q); }
+                const float e = rbf_exp<float>(-0.5f * q);
+                dos = fmaf(Gij, e, dos);
+                const float M = Gij * os * e;
+#pragma unroll
+                for (int c = 0; c < FP; ++c) {
+                    const float md = M * df[c];
+                    colacc[c] += md;
+                    dls[c] = fmaf(md, df[c], dls[c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < FP; ++c) {
+            float v = colacc[c];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (g == 0) dzc[(16 * J + r) * FP + c] = v;
+        }
+    }
+    WSYNC();
+    const float bad = okf ? 0.0f : NAN;
+    const float ai = i < NP ? av[i] : 0.0f;
+    if (a.d_z && i < n) {
+        for (int c = 0; c < f; ++c)
+            a.d_z[(b * n + i) * (long)f + c] = (i < nv) ? 2.0f * gup * dzc[i * FP + c] / ls[c] + bad : 0.0f;
+    }
+    if (a.mean_mode == PACOH_MEAN_VECTOR) {
+        if (a.d_mean && i < n) a.d_mean[b * n + i] = (i < nv) ? gup * ai / (float)nv + bad : 0.0f;
+    } else if (a.mean_mode == PACOH_MEAN_CONST) {
+        const float sa = wave_sum_((i < nv) ? ai : 0.0f);
+        if (a.d_mean && lane == 0) a.d_mean[b] = nv > 0 ? gup * sa / (float)nv + bad : 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < FP; ++c) {
+        if (c < f) {
+            const float sc = wave_sum_(dls[c]);
+            if (lane == 0) a.d_ls[b * f + c] = gup * sc / ls[c] + bad;
+        }
+    }
+    const float sdos = wave_sum_(dos), sdnz = wave_sum_(dnz);
+    if (lane == 0) {
+        if (a.d_os) a.d_os[b] = gup * sdos + bad;
+        a.d_noise[b] = gup * sdnz + bad;
+    }
+#undef WSYNC
+#undef SCHED_FENCE
+}
+
+template <int NB, bool BWD>
+static int launch_reg(const GpMfmaArgs& a, int FP, hipStream_t s) {
+    if (FP == 2) hipLaunchKernelGGL((gp_reg_kernel<NB, 2, BWD>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((gp_reg_kernel<NB, 4, BWD>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+    return launch_status();
+}
+
+// returns 1 if this path does not apply (n > 64, f > 4, or PACOH_GP_REG=0)
+int gp_reg_try(const GpMfmaArgs& a, bool bwd, hipStream_t s) {
+    const char* e = getenv("PACOH_GP_REG");
+    if (e && e[0] == '0') return 1;
+    if (a.n > 64 || a.f > 4 || a.n < 1) return 1;
+    const int NB = (a.n + 15) / 16;
+    const int FP = a.f <= 2 ? 2 : 4;
+#define PACOH_GPR_NB(nb) case nb: return bwd ? launch_reg<nb, true>(a, FP, s) : launch_reg<nb, false>(a, FP, s);
+    switch (NB) { PACOH_GPR_NB(1) PACOH_GPR_NB(2) PACOH_GPR_NB(3) default: PACOH_GPR_NB(4) }
+#undef PACOH_GPR_NB
+}
+
+}  // namespace pacoh

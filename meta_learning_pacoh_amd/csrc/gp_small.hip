@@ -387,6 +387,7 @@ struct GpMfmaArgs {
     int B, P, n, f;
 };
 int gp_mfma_try(const GpMfmaArgs& a, bool bwd, hipStream_t s);
+int gp_reg_try(const GpMfmaArgs& a, bool bwd, hipStream_t s);      // register-resident kernel (gp_reg.hip): n <= 64, f <= 4
 }
 static bool mfma_enabled() {
     static const bool on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
@@ -398,6 +399,9 @@ static int try_mfma(const GpArgs<float>& a, bool bwd, hipStream_t s) {
         return 1;
     GpMfmaArgs m = {a.z, a.z_div, a.mean, a.mean_mode, a.y, a.y_div, a.ls, a.os, a.noise, a.n_valid, a.g_lml,
                     a.lml, a.info, a.d_z, a.d_mean, a.d_ls, a.d_os, a.d_noise, a.B, a.P, a.n, a.f};
+    // the forward-only entry points may ask for alpha / L outputs, which only the LDS-resident kernels produce: they do not come here
+    const int rc = gp_reg_try(m, bwd, s);
+    if (rc != 1) return rc;
     return gp_mfma_try(m, bwd, s);
 }
 
