@@ -154,7 +154,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    wl['run'](max(1, args.warmup))
+    # (at least 3 x StepMode.PROBE untimed steps: the learners time graph replay against eager launches on their first steps and
+    #  keep the faster -- that decision must not fall into the timed region)
+    wl['run'](max(24, args.warmup))
     barrier()
     t0 = time.perf_counter()
     wl['run'](args.steps)
@@ -218,7 +220,7 @@ def main():
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': wl['dtype'], 'data': 'synthetic',
             'backend': (backend if world > 1 else None), 'world_size_seen': (dist.get_world_size() if world > 1 else 1),
-            'host_ms_per_step': round(host_ms, 4),
+            'host_ms_per_step': round(host_ms, 4), 'step_mode': wl.get('mode', lambda: None)(),
             'config': dict({'workload': wl['describe'], 'evals_per_step': wl['evals_per_step'],
                             'parallelism': 'task-shard x%d' % world, 'finite': finite}, **wl.get('extra', {})),
             'roofline': roofline, 'kernel_rooflines': kernel_rooflines,
@@ -269,13 +271,19 @@ def _rand_tasks(T, n, d, seed):
     return [(rs.uniform(-5, 5, (n, d)), rs.normal(size=(n, 1))) for _ in range(T)]
 
 
+def _mode(model):
+    """how the learner ended up issuing its steps: {'graph': bool, 'eager_ms': .., 'graph_ms': ..} (engine.StepMode)"""
+    sm = model._step_mode
+    return dict({'graph': bool(sm.use_graph) if sm.use_graph is not None else True}, **(sm.timings or {}))
+
+
 def wl_cfg3(world, scaling, M, L):
     T_global = TASKS * world if scaling == 'weak' else TASKS
     model = M.GPRegressionMetaLearnedSVGD(make_tasks(T_global, N_CTX, DIM), num_particles=PARTICLES, covar_module='NN',
                                           mean_module='NN', task_batch_size=-1, lr=1e-3, random_seed=0)
     ev = T_global * PARTICLES / world
     w = net_macs(DIM, (32, 32), 1) + net_macs(DIM, (32, 32), 2)                 # 2400 MAC per point over both networks
-    return dict(run=model._train_steps, evals_per_step=T_global * PARTICLES, dtype='f32',
+    return dict(run=model._train_steps, evals_per_step=T_global * PARTICLES, dtype='f32', mode=lambda: _mode(model),
                 finite=lambda: bool(torch.isfinite(model.particles).all()),
                 flops={'gp_lml_fwdbwd': (gp_flops(N_CTX, 2) * ev,) * 2, 'mlp_fwd': (2 * N_CTX * w * ev,) * 2,
                        'mlp_bwd': (4 * N_CTX * w * ev, 6 * N_CTX * w * ev)},
@@ -292,7 +300,7 @@ def wl_cfg2(world, scaling, M, L):
     model = M.GPRegressionMetaLearned(_rand_tasks(T, 32, 1, 27), covar_module='SE', mean_module='NN', task_batch_size=T, random_seed=1)
     ev = T / world
     w = net_macs(1, (32, 32), 1)
-    return dict(run=model._train_steps, evals_per_step=T, dtype='f32', finite=lambda: bool(torch.isfinite(model.theta).all()),
+    return dict(run=model._train_steps, evals_per_step=T, dtype='f32', finite=lambda: bool(torch.isfinite(model.theta).all()), mode=lambda: _mode(model),
                 metric='task-GP LML+grad evals/sec (PACOH-MAP, 256 tasks, n_ctx=32, d=1, SE kernel)',
                 flops={'gp_lml_fwdbwd': (gp_flops(32, 1) * ev,) * 2, 'mlp_fwd': (2 * 32 * w * ev,) * 2,
                        'mlp_bwd': (4 * 32 * w * ev, 6 * 32 * w * ev)},
@@ -306,7 +314,7 @@ def wl_cfg4(world, scaling, M, L):
     model = M.GPRegressionMetaLearnedVI(_rand_tasks(T, 128, 1, 28), svi_batch_size=S, random_seed=1)
     ev = T * S / world
     w = net_macs(1, (32, 32), 1) + net_macs(1, (32, 32), 2)
-    return dict(run=model._train_steps, evals_per_step=T * S, dtype='f32', finite=lambda: bool(torch.isfinite(model.posterior).all()),
+    return dict(run=model._train_steps, evals_per_step=T * S, dtype='f32', finite=lambda: bool(torch.isfinite(model.posterior).all()), mode=lambda: _mode(model),
                 metric='task-GP LML+grad evals/sec (PACOH-VI, 512 tasks, n_ctx=128, 10 posterior samples)',
                 flops={'gp_lml_fwdbwd': (gp_flops(128, 2) * ev,) * 2, 'mlp_fwd': (2 * 128 * w * ev,) * 2,
                        'mlp_bwd': (4 * 128 * w * ev, 6 * 128 * w * ev)},

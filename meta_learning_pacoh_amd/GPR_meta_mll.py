@@ -12,7 +12,7 @@ from . import _lib as L
 from . import parallel
 from .abstract import RegressionModelMetaLearned
 from .distributions import GaussianPredictive
-from .engine import GPEngine, NotPSDError, ParamLayout, StepFeed, TaskBatch, capture_graph
+from .engine import GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, capture_graph
 from .util import StepLR
 
 
@@ -106,6 +106,7 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         self.opt_step = 0
         self.lr_scheduler = StepLR(lr, 1000, lr_decay)
         self._feed = self._graphs = None
+        self._step_mode = StepMode()
 
     # ---- one meta-training iteration captured in hipGraph(s) ---------------------------------------------------------------------
     # A MAP iteration is ~10 launches of a few microseconds each, i.e. launch-bound.  The sequence (task gather -> features ->
@@ -184,21 +185,21 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         graphed = self._use_graph()
         while n_steps > 0:
             k = min(n_steps, self.GRAPH_CHUNK) if self.optimizer_name == 'Adam' else 1     # SGD reads the host-side learning rate
-            idx_rows, sc_rows = [], []
-            sched = StepLR(self.lr_scheduler.base_lr, self.lr_scheduler.step_size, self.lr_scheduler.gamma)
-            sched.epoch = self.lr_scheduler.epoch
-            for j in range(k):
-                # rds_numpy.choice(task_dicts, size=B) == randint(0, T, B): with replacement (GPR_meta_mll.py:109)
-                idx = self.rds_numpy.randint(0, self.tasks.T, size=self.task_batch_size)
-                idx_rows.append(parallel.shard(idx))
-                sc_rows.append(L.step_scalars(1.0, sched.lr, self.opt_step + j + 1, weight_decay=self.weight_decay))
-                sched.step()
-            parallel.check_same_draws(idx_rows, sc_rows)
-            self._feed.upload(np.stack(idx_rows) if self._feed.tb > 0 else None, sc_rows)
+            # rds_numpy.choice(task_dicts, size=B) == randint(0, T, B): with replacement (GPR_meta_mll.py:109); one call of shape
+            # [k, B] consumes the numpy stream exactly like k calls
+            idx = self.rds_numpy.randint(0, self.tasks.T, size=(k, self.task_batch_size))
+            sc_rows = L.step_scalar_rows(1.0, self.lr_scheduler.lrs(k), self.opt_step + 1, weight_decay=self.weight_decay)
+            rank, world = parallel.world()
+            local = np.ascontiguousarray(idx[:, rank::world])
+            parallel.check_same_draws(local, sc_rows)
+            self._feed.upload(local if self._feed.tb > 0 else None, sc_rows)
             if graphed and self._graphs is None:
                 self._build_graphs()
-            for _ in range(k):
-                self._run_step(graphed)
+            if graphed:
+                self._step_mode.run(k, self._run_step)    # replay or eager launches, whichever is faster here (engine.StepMode)
+            else:
+                for _ in range(k):
+                    self._run_step(False)
             self.opt_step += k
             for _ in range(k):
                 self.lr_scheduler.step()

@@ -12,7 +12,7 @@ from . import _lib as L
 from . import parallel
 from .abstract import RegressionModelMetaLearned
 from .distributions import GaussianPredictive
-from .engine import AsyncUploader, GPEngine, NotPSDError, ParamLayout, StepFeed, TaskBatch, capture_graph
+from .engine import AsyncUploader, GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, capture_graph
 from .util import StepLR
 
 
@@ -101,17 +101,17 @@ class _RandomGPLearner(RegressionModelMetaLearned):
         return len(parallel.shard(np.arange(self.task_batch_size)))
 
     def _draw_steps(self, k, lr_scheduler, first_step, weight_decay=0.0):
-        """task draws (this rank's shard) and step scalars of the next k steps; same numpy stream as k single draws"""
-        idx_rows, sc_rows = [], []
-        sched = StepLR(lr_scheduler.base_lr, lr_scheduler.step_size, lr_scheduler.gamma)
-        sched.epoch = lr_scheduler.epoch
-        for j in range(k):
-            local, pre = self._sample_task_batch()
-            idx_rows.append(local)
-            sc_rows.append(L.step_scalars(pre, sched.lr, first_step + j, weight_decay=weight_decay))
-            sched.step()
-        parallel.check_same_draws(idx_rows, sc_rows)
-        return np.stack(idx_rows) if len(idx_rows[0]) > 0 else None, sc_rows
+        """task draws (this rank's shard) and step scalars of the next k steps, vectorised: one randint call of shape [k, B] consumes
+        the numpy stream exactly like k calls of size B (GPR_meta_svgd.py:102 draws one batch per iteration)"""
+        idx = self.rds_numpy.randint(0, self.tasks.T, size=(k, self.task_batch_size))
+        sizes = self.tasks.sizes[idx].astype(np.float32)                       # harmonic pre-factor per step (random_gp.py:209-212)
+        hm = np.float32(1.0) / np.mean(np.float32(1.0) / sizes, axis=1, dtype=np.float32)
+        pre = (hm / (hm + np.float32(self.task_batch_size))).astype(np.float64)
+        sc_rows = L.step_scalar_rows(pre, lr_scheduler.lrs(k), first_step, weight_decay=weight_decay)
+        rank, world = parallel.world()
+        local = np.ascontiguousarray(idx[:, rank::world])
+        parallel.check_same_draws(local, sc_rows)
+        return (local if local.shape[1] > 0 else None), sc_rows
 
     def _check_numerics(self):
         """raise where the reference raises: gpytorch's psd_safe_cholesky -> NotPSDError (read at synchronisation points only)"""
@@ -182,6 +182,7 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         self.lr_scheduler = StepLR(lr, 1000, lr_decay)
         self._svgd_ws = None
         self._feed = self._graphs = None
+        self._step_mode = StepMode()
         self._setup_tasks(meta_train_data)
         self.fitted = False
 
@@ -246,8 +247,11 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
             self._feed.upload(idx_rows, sc_rows)
             if graphed and self._graphs is None:
                 self._build_graphs()                      # (captured with real operands in the feed; state and counter are restored)
-            for _ in range(k):
-                self._run_step(graphed)
+            if graphed:
+                self._step_mode.run(k, self._run_step)    # replay or eager launches, whichever is faster here (engine.StepMode)
+            else:
+                for _ in range(k):
+                    self._run_step(False)
             self.opt_step += k
             for _ in range(k):
                 self.lr_scheduler.step()

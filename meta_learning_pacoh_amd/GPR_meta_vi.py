@@ -12,7 +12,7 @@ import torch
 
 from . import _lib as L
 from . import parallel
-from .engine import AsyncUploader, StepFeed, capture_graph
+from .engine import AsyncUploader, StepFeed, StepMode, capture_graph
 from .GPR_meta_svgd import _RandomGPLearner
 from .util import StepLR
 
@@ -66,6 +66,7 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         self.opt_step = 0
         self.lr_scheduler = StepLR(lr, 1000, lr_decay)
         self._feed = self._graphs = None
+        self._step_mode = StepMode()
         self._setup_tasks(meta_train_data)
         self.fitted = False
 
@@ -165,8 +166,11 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
             self._feed.upload(idx_rows, sc_rows, eps)
             if graphed and self._graphs is None:
                 self._build_graphs()                      # (captured with real operands in the feed; state and counter are restored)
-            for _ in range(k):
-                self._run_step(graphed)
+            if graphed:
+                self._step_mode.run(k, self._run_step)    # replay or eager launches, whichever is faster here (engine.StepMode)
+            else:
+                for _ in range(k):
+                    self._run_step(False)
             self.opt_step += k
             for _ in range(k):
                 self.lr_scheduler.step()

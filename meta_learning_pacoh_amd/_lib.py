@@ -528,6 +528,21 @@ def step_scalars(score_scale, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight
     return row
 
 
+def step_scalar_rows(score_scale, lrs, first_step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """step_scalars() for k consecutive steps at once: score_scale [k] (or a float), lrs [k] -> float64 array [k, SC_COUNT]"""
+    import numpy as np
+    lrs = np.asarray(lrs, dtype=np.float64)
+    k = lrs.shape[0]
+    steps = first_step + np.arange(k, dtype=np.float64)
+    rows = np.zeros((k, SC_COUNT), dtype=np.float64)
+    rows[:, SC_SCORE_SCALE], rows[:, SC_LR] = score_scale, lrs
+    rows[:, SC_ADAM] = 1.0 - lrs * weight_decay
+    rows[:, SC_ADAM + 1] = lrs / (1.0 - beta1 ** steps)
+    rows[:, SC_ADAM + 2] = (1.0 - beta2 ** steps) ** 0.5
+    rows[:, SC_ADAM + 3] = eps
+    return rows
+
+
 def step_select(idx_all, sc_all, counter, idx_out, sc_out, aux_all=None, aux_out=None):
     """idx_out := idx_all[counter], sc_out := sc_all[counter], aux_out := aux_all[counter], counter += 1 (graph-capturable)"""
     lib = load_library()

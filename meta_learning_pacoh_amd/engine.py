@@ -5,6 +5,8 @@ reference does with a Python loop over tasks around VectorizedGP.forward / Exact
 kernel behind the C ABI (include/pacoh_gp.h); this file only sequences launches on the current
 stream and owns the parameter layout.
 """
+import os
+import time
 from collections import OrderedDict
 
 import numpy as np
@@ -151,32 +153,36 @@ class StepFeed:
         self.sc_all = torch.zeros(chunk, L.SC_COUNT, dtype=dtype, device=device)
         self.sc = torch.zeros(L.SC_COUNT, dtype=dtype, device=device)
         self.ctr = torch.zeros(1, dtype=torch.int64, device=device)
-        self._h_idx = torch.zeros(chunk, max(tb, 1), dtype=torch.int64).pin_memory()
-        self._h_sc = torch.zeros(chunk, L.SC_COUNT, dtype=dtype).pin_memory()
+        # two pinned staging sets, used alternately: the host prepares and enqueues chunk k+1 while the GPU still runs chunk k
+        # (with one set it would have to wait for chunk k's upload, which sits in the stream behind chunk k-1's steps)
+        self._h_idx = [torch.zeros(chunk, max(tb, 1), dtype=torch.int64).pin_memory() for _ in range(2)]
+        self._h_sc = [torch.zeros(chunk, L.SC_COUNT, dtype=dtype).pin_memory() for _ in range(2)]
         self.aux_all = self.aux = self._h_aux = None
         if aux_shape is not None:
             self.aux_all = torch.zeros((chunk,) + tuple(aux_shape), dtype=dtype, device=device)
             self.aux = torch.zeros(tuple(aux_shape), dtype=dtype, device=device)
-            self._h_aux = torch.zeros((chunk,) + tuple(aux_shape), dtype=dtype).pin_memory()
-        self._ev = None
+            self._h_aux = [torch.zeros((chunk,) + tuple(aux_shape), dtype=dtype).pin_memory() for _ in range(2)]
+        self._ev, self._slot = [None, None], 0
 
     def upload(self, idx_rows, sc_rows, aux_rows=None):
         """idx_rows: int array [k, tb]; sc_rows: k rows of L.step_scalars(); aux_rows: tensor [k, ...] | None; resets the counter"""
         k = len(sc_rows)
         assert 0 < k <= self.chunk
-        if self._ev is not None:
-            self._ev.synchronize()                       # the previous chunk's copies have read the pinned buffers
-        self._h_sc[:k].copy_(torch.tensor(sc_rows, dtype=torch.float64))
-        self.sc_all[:k].copy_(self._h_sc[:k], non_blocking=True)
+        q = self._slot
+        self._slot = 1 - q
+        if self._ev[q] is not None:
+            self._ev[q].synchronize()                    # the copies that last read this staging set have executed
+        self._h_sc[q][:k].copy_(torch.as_tensor(np.asarray(sc_rows, dtype=np.float64)))
+        self.sc_all[:k].copy_(self._h_sc[q][:k], non_blocking=True)
         if self.tb > 0:
-            self._h_idx[:k].copy_(torch.from_numpy(np.ascontiguousarray(idx_rows)).reshape(k, self.tb))
-            self.idx_all[:k].copy_(self._h_idx[:k], non_blocking=True)
+            self._h_idx[q][:k].copy_(torch.from_numpy(np.ascontiguousarray(idx_rows)).reshape(k, self.tb))
+            self.idx_all[:k].copy_(self._h_idx[q][:k], non_blocking=True)
         if self.aux_all is not None:
-            self._h_aux[:k].copy_(aux_rows)
-            self.aux_all[:k].copy_(self._h_aux[:k], non_blocking=True)
+            self._h_aux[q][:k].copy_(aux_rows)
+            self.aux_all[:k].copy_(self._h_aux[q][:k], non_blocking=True)
         self.ctr.zero_()
-        self._ev = self._ev or torch.cuda.Event()
-        self._ev.record()
+        self._ev[q] = self._ev[q] or torch.cuda.Event()
+        self._ev[q].record()
 
     def select(self):
         L.step_select(self.idx_all, self.sc_all, self.ctr, self.idx, self.sc, self.aux_all, self.aux)
@@ -195,6 +201,42 @@ def capture_graph(body, warmup=2):
     with torch.cuda.graph(graph):
         body()
     return graph
+
+
+class StepMode:
+    """Replay the captured step graph(s) or issue the same launches one by one?  The graph wins when Python's ~10 us per launch
+    is what limits the step (PACOH-MAP, small batches); this ROCm's hipGraphLaunch, however, costs its internal submission
+    thread ~10-20 us per kernel node, so for a 12-node step that takes the GPU 0.15 ms the replay is the slower way (0.26 ms
+    against 0.16 ms, tools/host_issue_time.py) while a 0.6 ms step hides it completely.  Both produce identical bits, so the
+    choice is made by timing PROBE steps of each kind on the real training steps.  PACOH_GRAPH=1 / 0 forces a mode."""
+    PROBE = 8
+
+    def __init__(self):
+        self.use_graph = None
+        forced = os.environ.get('PACOH_GRAPH', '')
+        if forced in ('0', '1'):
+            self.use_graph = forced == '1'
+        self.timings = None
+
+    def run(self, n_steps, step):
+        """issue n_steps calls of step(graphed); the first 2 * PROBE of a long enough run decide the mode"""
+        done = 0
+        if self.use_graph is None and n_steps >= 3 * self.PROBE:
+            t = []
+            for graphed in (False, True):
+                step(graphed)                                  # (not timed: first-use effects)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(self.PROBE - 1):
+                    step(graphed)
+                torch.cuda.synchronize()
+                t.append((time.perf_counter() - t0) / (self.PROBE - 1))
+            self.timings = {'eager_ms': t[0] * 1e3, 'graph_ms': t[1] * 1e3}
+            self.use_graph = t[1] < t[0]
+            done = 2 * self.PROBE
+        graphed = True if self.use_graph is None else self.use_graph
+        for _ in range(n_steps - done):
+            step(graphed)
 
 
 class NotPSDError(RuntimeError):

@@ -49,7 +49,7 @@ def check_same_draws(idx_rows, sc_rows):
     _, w = world()
     if w == 1 or os.environ.get('PACOH_CHECK_RANKS', '0') != '1':
         return
-    mine = [float(sum(r)) for r in sc_rows]
+    mine = [float(sum(r)) for r in sc_rows]          # (rows may be lists or a numpy array)
     box = [None] * w
     dist.all_gather_object(box, mine)
     assert all(b == box[0] for b in box), 'ranks drew different task batches: host RNG streams are out of step'

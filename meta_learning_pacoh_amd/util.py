@@ -64,3 +64,9 @@ class StepLR:
         if self.gamma >= 1.0:
             return self.base_lr
         return self.base_lr * self.gamma ** (self.epoch // self.step_size)
+
+    def lrs(self, k):
+        """learning rates of the next k steps (the scheduler itself is not advanced)"""
+        if self.gamma >= 1.0:
+            return np.full(k, self.base_lr, dtype=np.float64)
+        return self.base_lr * self.gamma ** ((self.epoch + np.arange(k)) // self.step_size).astype(np.float64)

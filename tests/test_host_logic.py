@@ -108,3 +108,27 @@ def test_vi_full_posterior_init_stream(golden_dir):
     post = init_vi_posterior_full(lay.D)
     np.testing.assert_array_equal(post[0].numpy(), fx['init_loc'])
     np.testing.assert_array_equal(post[1:].numpy(), fx['init_tril'])
+
+
+def test_vectorised_step_draws_equal_per_step_draws():
+    """the training loops draw the task batches, pre-factors and optimizer scalars of a whole chunk of steps at once: one randint
+    call of shape [k, B] must consume the numpy stream like k calls of size B (the reference draws per iteration,
+    GPR_meta_svgd.py:102), and the vectorised scalars must equal the per-step formulas bit for bit"""
+    from meta_learning_pacoh_amd.GPR_meta_svgd import harmonic_pre_factor
+    from meta_learning_pacoh_amd import _lib as L
+    sizes = np.array([5, 7, 12, 5, 9, 20])
+    a, b = np.random.RandomState(4), np.random.RandomState(4)
+    idx = b.randint(0, 6, size=(5, 4))
+    s = sizes[idx].astype(np.float32)
+    hm = np.float32(1) / np.mean(np.float32(1) / s, axis=1, dtype=np.float32)
+    pre = (hm / (hm + np.float32(4))).astype(np.float64)
+    sched = StepLR(1e-3, 2, 0.9)
+    sched.epoch = 3
+    rows = L.step_scalar_rows(pre, sched.lrs(5), 11, weight_decay=0.1)
+    for j in range(5):
+        i = a.randint(0, 6, size=4)
+        assert (i == idx[j]).all()
+        ref = L.step_scalars(harmonic_pre_factor(sizes[i]), sched.lr, 11 + j, weight_decay=0.1)
+        sched.step()
+        assert np.array_equal(rows[j], np.asarray(ref))
+    assert a.randint(0, 10 ** 6) == b.randint(0, 10 ** 6)          # both streams are at the same position afterwards

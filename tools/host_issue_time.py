@@ -14,9 +14,13 @@ import meta_learning_pacoh_amd as M  # noqa: E402
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 model = M.GPRegressionMetaLearnedSVGD(bench.make_tasks(T, 64, 4), num_particles=20, covar_module='NN', mean_module='NN',
                                       task_batch_size=-1, lr=1e-3, random_seed=0)
-for mode in ('graph', 'eager'):
+for mode in ('eager', 'graph', 'eager', 'graph'):          # (alternating: the first measurement also pays for a cold host)
+    os.environ['PACOH_GRAPH'] = '1' if mode == 'graph' else '0'
     if mode == 'eager':
         os.environ['PACOH_NO_GRAPH'] = '1'
+    else:
+        os.environ.pop('PACOH_NO_GRAPH', None)
+    model._step_mode.use_graph = mode == 'graph'
     model._train_steps(20)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
