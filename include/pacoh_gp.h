@@ -266,6 +266,15 @@ int pacoh_svgd_update(const void* X, const void* score, const void* prior_mean, 
 int pacoh_step_select(const int64_t* idx_all, int tb, const void* sc_all, int n_sc, const void* aux_all, long n_aux,
                       int64_t* counter, int64_t* idx_out, void* sc_out, void* aux_out, int dtype, void* stream);
 int pacoh_scale_dev(void* buf, const void* scalar, long count, int dtype, void* stream);
+/* pacoh_step_begin: the first launch of a captured step -- pacoh_step_select (without the index copy), pacoh_gather_tasks on
+ * idx_all[row, :] (tb tasks; x[T,n,d], y[T,n], optional n_valid) and, when theta is given, pacoh_hyper_fwd, all in ONE launch;
+ * a one-thread launch behind it advances *counter (`ticket`: reserved, one int32 of device memory).
+ * Four launches (~4.5 us each, more than the kernels need) become two. */
+int pacoh_step_begin(const int64_t* idx_all, int tb, const void* sc_all, int n_sc, const void* aux_all, long n_aux,
+                     int64_t* counter, int32_t* ticket, void* sc_out, void* aux_out,
+                     const void* x, const void* y, const int32_t* n_valid, void* out_x, void* out_y, int32_t* out_n_valid, int n, int d,
+                     const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise, double noise_floor,
+                     void* ls, void* os, void* noise, int dtype, void* stream);
 size_t pacoh_svgd_update_dev_workspace_bytes(int P, int D, int dtype);
 int pacoh_svgd_update_dev(void* X, const void* score, const void* prior_mean, const void* prior_std,
                           double prior_factor, double bandwidth, int use_adam, const void* scalars, double beta1,

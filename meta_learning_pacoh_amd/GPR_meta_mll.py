@@ -130,12 +130,11 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         self._graphs = None
 
     def _body_likelihood(self):
-        self._feed.select()
-        if self._feed.tb == 0:                             # more ranks than tasks in the batch: this rank contributes zeros
+        batch, hyp = self._feed.begin(self.tasks, self.engine, self.theta)          # select + gather + hyper transforms: one launch
+        if batch is None:                                  # more ranks than tasks in the batch: this rank contributes zeros
             self._packed.zero_()
             return
-        batch = self.tasks.select(self._feed.idx)
-        lml, _, _ = self.engine.lml_and_grad(self.theta, batch, weight=-1.0, grad_out=self._grad, fail_flag=self._fail)
+        lml, _, _ = self.engine.lml_and_grad(self.theta, batch, weight=-1.0, grad_out=self._grad, fail_flag=self._fail, hypers=hyp)
         L.reduce_tasks(lml.reshape(-1, 1, 1), self._g_loss.reshape(1, 1), scale=-1.0)            # loss = -sum_t mll_t
 
     def _body_update(self):

@@ -199,13 +199,12 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
 
     def _body_likelihood(self):
         """score[P,D] = d/d theta_p sum_t mll[t,p] over this rank's tasks (unscaled), lik[P] the sums themselves"""
-        self._feed.select()
-        if self._feed.tb == 0:
+        batch, hyp = self._feed.begin(self.tasks, self.engine, self.particles)      # select + gather + hyper transforms: one launch
+        if batch is None:
             self._packed.zero_()
             return
-        batch = self.tasks.select(self._feed.idx)
         self.engine.lml_and_grad(self.particles, batch, weight=1.0, lik_out=self._lik, lik_scale=1.0, grad_out=self._score,
-                                 fail_flag=self._fail)
+                                 fail_flag=self._fail, hypers=hyp)
 
     def _body_update(self):
         """prior score + pre-factor + bandwidth + phi + optimizer in two launches, particles updated in place"""

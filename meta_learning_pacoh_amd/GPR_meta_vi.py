@@ -112,12 +112,11 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         self._graphs = None
 
     def _body_likelihood(self):
-        self._feed.select()
+        batch, _ = self._feed.begin(self.tasks)            # select (incl. the step's noise) + task gather: one launch
         self._theta, self._log_q = L.vi_sample(self.posterior, self._feed.aux, full=self.cov_type == 'full')
-        if self._feed.tb == 0:
+        if batch is None:
             self._packed.zero_()
             return
-        batch = self.tasks.select(self._feed.idx)
         self.engine.lml_and_grad(self._theta, batch, weight=1.0, lik_out=self._lik, lik_scale=1.0, grad_out=self._score,
                                  fail_flag=self._fail)
 

@@ -54,6 +54,8 @@ SIGNATURES = {
     'pacoh_hyper_bwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _d, _vp, _vp, _i, _vp]),
     'pacoh_step_select': (_i, [_vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _i, _vp]),
     'pacoh_scale_dev': (_i, [_vp, _vp, _l, _i, _vp]),
+    'pacoh_step_begin': (_i, [_vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                              _vp, _l, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
     'pacoh_svgd_update_dev_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_update_dev': (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _vp, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_prior_logprob_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
@@ -551,6 +553,35 @@ def step_select(idx_all, sc_all, counter, idx_out, sc_out, aux_all=None, aux_out
     with _Timed('step_select'):
         _check(lib.pacoh_step_select(_ptr(idx_all), tb, _ptr(sc_all), sc_all.shape[1], _ptr(aux_all, sc_all), n_aux, _ptr(counter),
                                      _ptr(idx_out), _ptr(sc_out), _ptr(aux_out, sc_all), dtype_code(sc_all), _stream()), 'pacoh_step_select')
+
+
+def step_begin(feed, tasks, out, theta=None, hyper=None, hyper_out=None):
+    """first launch of a captured step: feed (engine.StepFeed) row -> feed.sc / feed.aux, task gather tasks[idx] -> out = (x, y, n_valid
+    | None), hyper-parameter transforms of theta -> hyper_out = (ls, os | None, noise) with hyper = (off_ls, f, off_os, off_noise,
+    noise_floor), counter advanced: ONE launch"""
+    lib = load_library()
+    tb = feed.tb
+    n_aux = feed.aux_all[0].numel() if feed.aux_all is not None else 0
+    x = y = nv = ox = oy = onv = None
+    n = d = 0
+    if tb > 0:
+        x, y, nv = tasks.x, tasks.y, (tasks.n_valid if tasks.ragged else None)
+        ox, oy, onv = out
+        n, d = x.shape[1], x.shape[2]
+    off_ls = f = off_os = off_noise = 0
+    floor = 0.0
+    ls = os_ = noise = None
+    P, stride = 0, 0
+    if theta is not None:
+        off_ls, f, off_os, off_noise, floor = hyper
+        ls, os_, noise = hyper_out
+        P, stride = theta.shape
+    with _Timed('step_begin'):
+        _check(lib.pacoh_step_begin(_ptr(feed.idx_all), tb, _ptr(feed.sc_all), feed.sc_all.shape[1], _ptr(feed.aux_all, feed.sc_all), n_aux,
+                                    _ptr(feed.ctr), _ptr(feed.ticket), _ptr(feed.sc), _ptr(feed.aux, feed.sc_all),
+                                    _ptr(x, feed.sc_all), _ptr(y, feed.sc_all), _ptr(nv), _ptr(ox), _ptr(oy), _ptr(onv), n, d,
+                                    _ptr(theta, feed.sc_all), stride, P, off_ls, f, off_os, off_noise, float(floor), _ptr(ls), _ptr(os_),
+                                    _ptr(noise), dtype_code(feed.sc_all), _stream()), 'pacoh_step_begin')
 
 
 def scale_dev(buf, scalar):

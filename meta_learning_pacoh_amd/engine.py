@@ -153,6 +153,7 @@ class StepFeed:
         self.sc_all = torch.zeros(chunk, L.SC_COUNT, dtype=dtype, device=device)
         self.sc = torch.zeros(L.SC_COUNT, dtype=dtype, device=device)
         self.ctr = torch.zeros(1, dtype=torch.int64, device=device)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=device)      # last-block ticket of pacoh_step_begin
         # two pinned staging sets, used alternately: the host prepares and enqueues chunk k+1 while the GPU still runs chunk k
         # (with one set it would have to wait for chunk k's upload, which sits in the stream behind chunk k-1's steps)
         self._h_idx = [torch.zeros(chunk, max(tb, 1), dtype=torch.int64).pin_memory() for _ in range(2)]
@@ -186,6 +187,30 @@ class StepFeed:
 
     def select(self):
         L.step_select(self.idx_all, self.sc_all, self.ctr, self.idx, self.sc, self.aux_all, self.aux)
+
+    def begin(self, tasks, engine=None, theta=None):
+        """select() + the step's task gather (+ the hyper-parameter transforms of theta through `engine`) in ONE launch
+        -> (TaskBatch | None, hypers | None)"""
+        batch = hyp = None
+        out = None
+        if self.tb > 0:
+            batch = TaskBatch.__new__(TaskBatch)
+            batch.T, batch.n, batch.ragged, batch.sizes = self.tb, tasks.n, tasks.ragged, None
+            batch.x = torch.empty(self.tb, tasks.n, tasks.x.shape[2], dtype=tasks.x.dtype, device=tasks.x.device)
+            batch.y = torch.empty(self.tb, tasks.n, dtype=tasks.x.dtype, device=tasks.x.device)
+            batch.n_valid = torch.empty(self.tb, dtype=torch.int32, device=tasks.x.device) if tasks.ragged else None
+            out = (batch.x, batch.y, batch.n_valid)
+        hyper = hyper_out = None
+        if theta is not None and self.tb > 0:
+            off_ls, f, off_os, off_noise, _ = engine._hyper_offsets()
+            P = theta.shape[0]
+            ls = torch.empty(P, f, dtype=theta.dtype, device=theta.device)
+            os_ = torch.empty(P, dtype=theta.dtype, device=theta.device) if off_os >= 0 else None
+            noise = torch.empty(P, dtype=theta.dtype, device=theta.device)
+            hyper, hyper_out = (off_ls, f, off_os, off_noise, engine.noise_floor), (ls, os_, noise)
+            hyp = hyper_out
+        L.step_begin(self, tasks, out, theta if hyp is not None else None, hyper, hyper_out)
+        return batch, hyp
 
 
 def capture_graph(body, warmup=2):
@@ -310,7 +335,7 @@ class GPEngine:
                                        n_valid=batch.n_valid if batch.ragged else None)
         return lml.reshape(T, P), info
 
-    def lml_and_grad(self, theta, batch, weight=1.0, lik_out=None, lik_scale=1.0, grad_out=None, fail_flag=None):
+    def lml_and_grad(self, theta, batch, weight=1.0, lik_out=None, lik_scale=1.0, grad_out=None, fail_flag=None, hypers=None):
         """returns (lml[T,P], grad[P,D]) with grad = d(weight * sum_t lml[t,p]) / d theta[p];
         lik_out[P] (optional) receives lik_scale * sum_t lml[t,p] from the same launch that reduces the hyper-gradients;
         grad_out[P,D] (optional, contiguous) is used for the gradient instead of a fresh tensor;
@@ -320,7 +345,7 @@ class GPEngine:
         T, n = batch.T, batch.n
         B = T * P
         dev, dt = theta.device, theta.dtype
-        ls, os_, noise = self._hypers(theta)
+        ls, os_, noise = hypers if hypers is not None else self._hypers(theta)      # (hypers: already transformed by pacoh_step_begin)
         z, z_div, mean, mode = self._features(theta, batch.x, T, n)
         g = None                                        # weight 1: the kernels take g_lml = NULL
         if float(weight) != 1.0:
