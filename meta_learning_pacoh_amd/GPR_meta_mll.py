@@ -13,6 +13,7 @@ from . import parallel
 from .abstract import RegressionModelMetaLearned
 from .distributions import GaussianPredictive
 from .engine import GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, capture_graph
+from .modules import apply_initial_values, resolve_covar_module, resolve_mean_module
 from .util import StepLR
 
 
@@ -25,8 +26,10 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         """Arguments as in the reference (GPR_meta_mll.py:14-38)."""
         super().__init__(normalize_data, random_seed)
         assert learning_mode in ['learn_mean', 'learn_kernel', 'both', 'vanilla']
-        assert mean_module in ['NN', 'constant', 'zero'], 'gpytorch module objects are not supported on the HIP path'
-        assert covar_module in ['NN', 'SE'], 'gpytorch module objects are not supported on the HIP path'
+        # strings as the reference, or ZeroMean / ConstantMean / (Scale)RBFKernel objects (modules.py); other objects cannot run here
+        mean_module, self._mean_init = resolve_mean_module(mean_module)
+        covar_module, self._covar_init, self._learn_outputscale = resolve_covar_module(covar_module)
+        assert mean_module in ['NN', 'constant', 'zero'] and covar_module in ['NN', 'SE']
         assert optimizer in ['Adam', 'SGD']
 
         self.lr_params, self.weight_decay, self.feature_dim = lr_params, weight_decay, feature_dim
@@ -74,6 +77,7 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
             init_net('kernel_nn', feature_dim, kernel_nn_layers)
         if mean_module == 'NN':
             init_net('mean_nn', 1, mean_nn_layers)
+        apply_initial_values(theta, lay, dict(self._mean_init, **self._covar_init))     # (values carried by module objects)
         self.theta = theta.reshape(1, -1).to(self.dtype).to(self.device)
 
         # which segments of theta the optimizer updates (learning_mode, GPR_meta_mll.py:244-251)
@@ -82,7 +86,8 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
             if covar_module == 'NN':
                 segs.append(lay.block_range('kernel_nn.'))
             segs.append(lay.slices['lengthscale_raw'])
-            segs.append(lay.slices['outputscale_raw'])
+            if self._learn_outputscale:                    # (a plain RBFKernel object has no output scale to learn)
+                segs.append(lay.slices['outputscale_raw'])
         if learning_mode in ('learn_mean', 'both'):
             if mean_module == 'NN':
                 segs.append(lay.block_range('mean_nn.'))

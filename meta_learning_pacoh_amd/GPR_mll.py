@@ -11,6 +11,7 @@ from .abstract import _calib_error
 from .config import get_device
 from .distributions import GaussianPredictive
 from .engine import GPEngine, NotPSDError, ParamLayout, TaskBatch
+from .modules import apply_initial_values, resolve_covar_module, resolve_mean_module
 from .util import _handle_input_dimensionality, get_logger
 
 
@@ -40,8 +41,10 @@ class GPRegressionLearned:
                  optimizer='Adam', normalize_data=True, lr_scheduler=True, random_seed=None):
         """Arguments as in the reference (GPR_mll.py:13-36)."""
         assert learning_mode in ['learn_mean', 'learn_kernel', 'both', 'vanilla']
-        assert mean_module in ['NN', 'constant', 'zero'], 'gpytorch module objects are not supported on the HIP path'
-        assert covar_module in ['NN', 'SE'], 'gpytorch module objects are not supported on the HIP path'
+        # strings as the reference, or ZeroMean / ConstantMean / (Scale)RBFKernel objects (modules.py); other objects cannot run here
+        mean_module, mean_init = resolve_mean_module(mean_module)
+        covar_module, covar_init, learn_os = resolve_covar_module(covar_module)
+        assert mean_module in ['NN', 'constant', 'zero'] and covar_module in ['NN', 'SE']
         assert optimizer in ['Adam', 'SGD']
         self.normalize_data, self.logger = normalize_data, get_logger()
         self.device, self.dtype = get_device(), torch.float32
@@ -89,6 +92,7 @@ class GPRegressionLearned:
             init_net('kernel_nn', feature_dim, kernel_nn_layers)
         if mean_module == 'NN':
             init_net('mean_nn', 1, mean_nn_layers)
+        apply_initial_values(theta, lay, dict(mean_init, **covar_init))
         self.theta = theta.reshape(1, -1).to(self.dtype).to(self.device)
         # GaussianLikelihood() default noise constraint is GreaterThan(1e-4) [gpytorch-upstream]
         self.engine = GPEngine(lay, noise_floor=1e-4)
@@ -103,7 +107,8 @@ class GPRegressionLearned:
         segs.append(lay.slices['noise_raw'] + (1e-2,))
         if learning_mode in ('learn_kernel', 'both'):
             segs.append(lay.slices['lengthscale_raw'] + (1e-2,))
-            segs.append(lay.slices['outputscale_raw'] + (1e-2,))
+            if learn_os:
+                segs.append(lay.slices['outputscale_raw'] + (1e-2,))
         if learning_mode in ('learn_mean', 'both') and mean_module == 'constant':
             segs.append(lay.slices['constant_mean'] + (1e-2,))
         self.train_segments = segs

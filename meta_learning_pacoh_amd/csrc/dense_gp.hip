@@ -14,6 +14,7 @@
 // fp32 and fp64 (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64).  Limits: the 32-column panel of the Cholesky /
 // inverse must fit in LDS (n <= ~1000 fp32, ~520 fp64).
 #include "common.h"
+#include <stdlib.h>
 
 namespace pacoh {
 
@@ -330,8 +331,105 @@ __global__ void __launch_bounds__(256) bgemm_kernel(GemmArgs ga) {
             }
 }
 
+// ---- W = Z^T Z for lower-triangular Z (the inverse Cholesky factor): LDS-tiled ------------------------------------------------
+// One workgroup (4 waves) per 128 x 128 tile of the lower block triangle of W, k in slabs of 16 rows of Z: both operands of a
+// slab are ROW segments of Z (Z[k][i0..i0+128), Z[k][j0..j0+128)), loaded once per workgroup with coalesced 128-element rows
+// into a double-buffered LDS image (entries above Z's diagonal as zeros) and read from there by the four waves, each of which
+// holds a 64 x 64 sub-tile as 4 x 4 accumulator blocks.  Against the direct-from-L2 bgemm_kernel above (one wave per 32 x 32
+// tile, every wave fetching its own operands: ~55 B/clk/CU of L2 traffic, the kernel's bound) this moves 4x fewer bytes per MFMA.
+// k runs from the tile's first row (Z[k][i] = 0 for k < i) to n.  Tiles above the diagonal are mirrored from below.
+template <typename T>
+__global__ void __launch_bounds__(256, 2) ztz_kernel(const T* __restrict__ Zall, T* __restrict__ Wall, int n, const int32_t* __restrict__ info) {
+    using Acc = typename Mf<T>::acc;
+    constexpr int TS = 128, KS = 16, LDT = TS + 4;
+    __shared__ __attribute__((aligned(16))) T As[2][KS][LDT];
+    __shared__ __attribute__((aligned(16))) T Bs[2][KS][LDT];
+    const int b = blockIdx.y;
+    if (info && info[b] < 0) return;
+    // lower-triangle tile index -> (tm, tn), tn <= tm
+    int tm = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+    while (tm * (tm + 1) / 2 > (int)blockIdx.x) --tm;
+    while ((tm + 1) * (tm + 2) / 2 <= (int)blockIdx.x) ++tm;
+    const int tn = blockIdx.x - tm * (tm + 1) / 2;
+    const int i0 = tm * TS, j0 = tn * TS;
+    const T* Z = Zall + (long)b * n * n;
+    T* W = Wall + (long)b * n * n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;          // this wave's 64 x 64 sub-tile
+    Acc acc[4][4];
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = Acc{0, 0, 0, 0};
+    // staging: thread t loads slab row t / 16, columns 8 * (t % 16) .. + 8 of both operands
+    const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 8;
+    auto load_slab = [&](int k0, T (&ra)[8], T (&rb)[8]) {
+        const int k = k0 + lr;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int ci = i0 + lc + q, cj = j0 + lc + q;
+            ra[q] = (k < n && ci < n && ci <= k) ? Z[(long)k * n + ci] : T(0);
+            rb[q] = (k < n && cj < n && cj <= k) ? Z[(long)k * n + cj] : T(0);
+        }
+    };
+    auto store_slab = [&](int buf, const T (&ra)[8], const T (&rb)[8]) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { As[buf][lr][lc + q] = ra[q]; Bs[buf][lr][lc + q] = rb[q]; }
+    };
+    const int kbeg = i0;                                           // (i0 >= j0: rows above the tile's first row contribute nothing)
+    T ra[8], rb[8];
+    load_slab(kbeg, ra, rb);
+    store_slab(0, ra, rb);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < n; k0 += KS) {
+        const bool more = k0 + KS < n;
+        if (more) load_slab(k0 + KS, ra, rb);                      // global loads of the next slab fly under this slab's MFMAs
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            T av[4], bv[4];
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) av[ib] = As[buf][4 * g + s][wi + 16 * ib + r];
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) bv[jb] = Bs[buf][4 * g + s][wj + 16 * jb + r];
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = Mf<T>::mma(av[ib], bv[jb], acc[ib][jb]);
+        }
+        if (more) store_slab(buf ^ 1, ra, rb);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + wi + 16 * ib + Mf<T>::row(g, q), j = j0 + wj + 16 * jb + r;
+                if (i < n && j < n && (tm != tn || j <= i)) {
+                    W[(long)i * n + j] = acc[ib][jb][q];
+                    W[(long)j * n + i] = acc[ib][jb][q];
+                }
+            }
+}
+
+template <typename T>
+void launch_ztz(const T* Z, T* W, int n, const int32_t* info, int Bn, hipStream_t s) {
+    const int t = (n + 127) / 128;
+    hipLaunchKernelGGL(ztz_kernel<T>, dim3(t * (t + 1) / 2, Bn), dim3(256), 0, s, Z, W, n, info);
+}
+
 template <typename T>
 void launch_bgemm(const GemmArgs& ga, int Bn, hipStream_t s) {
+    static const bool tiled = []() { const char* e = getenv("PACOH_ZTZ_TILED"); return !(e && e[0] == '0'); }();
+    if (tiled && ga.A == ga.B && ga.transA && !ga.transB && ga.lowerA && ga.lowerB && ga.symC && ga.M == ga.N && ga.M == ga.K &&
+        ga.lda == ga.M && ga.ldb == ga.M && ga.ldc == ga.M && ga.alpha == 1.0 && ga.beta == 0.0 && ga.M >= 128) {
+        launch_ztz<T>((const T*)ga.A, (T*)ga.C, ga.M, ga.info, Bn, s);
+        return;
+    }
     const int tiles = ((ga.M + 63) / 64) * ((ga.N + 63) / 64);
     hipLaunchKernelGGL(bgemm_kernel<T>, dim3(tiles, Bn), dim3(256), 0, s, ga);
 }

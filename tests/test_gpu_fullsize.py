@@ -34,9 +34,10 @@ def test_cfg2_map_256_tasks_n32_d1_se_kernel_all_tasks_vs_oracle(M):
     assert relerr(lml[:, 0], ref) < 1e-4
     (-ref.sum()).backward()
     lo, hi = model.layout.slices['mean_nn.fc_2.weight']
-    assert relerr(grad[0, lo:hi], orc.mean_net[1].weight.grad.reshape(-1)) < 1e-2
+    # fp32 bar: 1e-2 norm-wise; asserted with the headroom the kernels actually have, so that a regression shows before the bar
+    assert relerr(grad[0, lo:hi], orc.mean_net[1].weight.grad.reshape(-1)) < 2e-3
     lo, hi = model.layout.slices['lengthscale_raw']
-    assert relerr(grad[0, lo:hi], orc.raw_lengthscale.grad.reshape(-1)) < 1e-2
+    assert relerr(grad[0, lo:hi], orc.raw_lengthscale.grad.reshape(-1)) < 2e-3
 
 
 def test_cfg3_svgd_1024_tasks_n64_d4_20_particles_properties(M):
@@ -66,14 +67,18 @@ def test_cfg3_svgd_1024_tasks_n64_d4_20_particles_properties(M):
         x, y = O.prepare_task(*tasks[t], stats, torch.float64)
         ref = O.vectorized_gp_mll(th.cpu().double(), x, y, cfg)
         assert relerr(lml[t], ref) < 1e-3
-    # (e) gradient of a 16-task sub-batch vs oracle autograd (norm-wise, fp32 bar)
-    sub = list(range(0, 16))
+    # (e) the full score [P, D] of a 64-task sub-batch vs oracle autograd in fp64: norm-wise over the whole array and per particle
+    #     (bar 1e-2 in fp32; asserted at 2e-3 so that a regression shows before the bar is crossed)
+    sub = list(range(0, 64))
     otasks = [O.prepare_task(*tasks[t], stats, torch.float64) for t in sub]
     thd = th.cpu().double().clone().requires_grad_(True)
     ref = torch.stack([O.vectorized_gp_mll(thd, x, y, cfg) for x, y in otasks], -1).sum()
     ref.backward()
-    _, g16, _ = model.engine.lml_and_grad(th, model.tasks.select(torch.tensor(sub, device=th.device)), weight=1.0)
-    assert relerr(g16, thd.grad) < 1e-2
+    _, g64, _ = model.engine.lml_and_grad(th, model.tasks.select(torch.tensor(sub, device=th.device)), weight=1.0)
+    assert g64.shape == (P, model.layout.D)
+    assert relerr(g64, thd.grad) < 2e-3
+    per_particle = [relerr(g64[q], thd.grad[q]) for q in range(P)]
+    assert max(per_particle) < 5e-3, per_particle
 
 
 def test_cfg4_vi_512_tasks_n128_10_samples(M):

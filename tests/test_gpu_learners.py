@@ -649,3 +649,38 @@ def test_failed_cholesky_raises_like_the_reference(M):
     mm.theta[0, mm.layout.slices['noise_raw'][0]] = float('nan')
     with pytest.raises(NotPSDError):
         mm.meta_fit(verbose=False, n_iter=2)
+
+
+def test_module_objects_run_like_their_string_options(M):
+    """GPRegressionMetaLearned(mean_module=ConstantMean(), covar_module=ScaleKernel(RBFKernel())) (objects, as the reference accepts
+    them: GPR_meta_mll.py:207-251) trains exactly like mean_module='constant', covar_module='SE' when the objects carry the default
+    raw values, starts from their values otherwise, and an unsupported kernel object is refused"""
+    class ConstantMean:
+        def __init__(self, c=0.0):
+            self.constant = torch.nn.Parameter(torch.tensor([c]))
+
+    class RBFKernel:
+        def __init__(self, d, raw=0.0):
+            self.raw_lengthscale = torch.nn.Parameter(torch.full((1, d), raw))
+
+    class ScaleKernel:
+        def __init__(self, base, raw=0.0):
+            self.base_kernel, self.raw_outputscale = base, torch.nn.Parameter(torch.tensor(raw))
+
+    class CosineKernel:
+        pass
+
+    tasks = O.sinusoid_tasks_nd(8, 12, 2, seed0=70)
+    a = M.GPRegressionMetaLearned(tasks, mean_module='constant', covar_module='SE', task_batch_size=4, random_seed=9)
+    b = M.GPRegressionMetaLearned(tasks, mean_module=ConstantMean(), covar_module=ScaleKernel(RBFKernel(2)), task_batch_size=4, random_seed=9)
+    a.meta_fit(verbose=False, n_iter=6)
+    b.meta_fit(verbose=False, n_iter=6)
+    assert torch.equal(a.theta, b.theta)
+    c = M.GPRegressionMetaLearned(tasks, mean_module=ConstantMean(0.3), covar_module=ScaleKernel(RBFKernel(2, 0.5), -0.2), task_batch_size=4,
+                                  random_seed=9)
+    lay = c.layout
+    assert abs(float(c.theta[0, lay.slices['constant_mean'][0]]) - 0.3) < 1e-7
+    assert abs(float(c.theta[0, lay.slices['outputscale_raw'][0]]) + 0.2) < 1e-7
+    assert torch.allclose(c.theta[0, lay.slices['lengthscale_raw'][0]:lay.slices['lengthscale_raw'][1]].cpu(), torch.full((2,), 0.5))
+    with pytest.raises(NotImplementedError):
+        M.GPRegressionMetaLearned(tasks, mean_module='constant', covar_module=CosineKernel())

@@ -132,3 +132,52 @@ def test_vectorised_step_draws_equal_per_step_draws():
         sched.step()
         assert np.array_equal(rows[j], np.asarray(ref))
     assert a.randint(0, 10 ** 6) == b.randint(0, 10 ** 6)          # both streams are at the same position afterwards
+
+
+def test_module_objects_are_resolved_by_class_name():
+    """mean_module / covar_module objects (GPR_meta_mll.py:207-251): ZeroMean / ConstantMean / RBFKernel / ScaleKernel(RBFKernel) map to
+    the string options with their raw hyper-parameters as initial values; anything else is refused (it cannot run on the RBF kernels)"""
+    import torch
+    from meta_learning_pacoh_amd.engine import ParamLayout
+    from meta_learning_pacoh_amd.modules import apply_initial_values, resolve_covar_module, resolve_mean_module
+
+    class Mean:                      # stand-ins with gpytorch's class names (gpytorch is not installed here or on the GPU box)
+        pass
+
+    class ZeroMean(Mean):
+        pass
+
+    class ConstantMean(Mean):
+        def __init__(self, c):
+            self.constant = torch.nn.Parameter(torch.tensor([c]))
+
+    class Kernel:
+        pass
+
+    class RBFKernel(Kernel):
+        def __init__(self, raw):
+            self.raw_lengthscale = torch.nn.Parameter(torch.tensor([raw]))
+
+    class ScaleKernel(Kernel):
+        def __init__(self, base, raw):
+            self.base_kernel, self.raw_outputscale = base, torch.nn.Parameter(torch.tensor(raw))
+
+    class CosineKernel(Kernel):
+        pass
+
+    assert resolve_mean_module('NN') == ('NN', {}) and resolve_mean_module(ZeroMean()) == ('zero', {})
+    kind, init = resolve_mean_module(ConstantMean(0.25))
+    assert kind == 'constant' and init == {'constant_mean': 0.25}
+    kind, init, learn = resolve_covar_module(ScaleKernel(RBFKernel([0.5, -1.0]), 0.75))
+    assert kind == 'SE' and learn and init == {'lengthscale_raw': [0.5, -1.0], 'outputscale_raw': 0.75}
+    kind, init, learn = resolve_covar_module(RBFKernel([0.1]))
+    assert kind == 'SE' and not learn and abs(np.log1p(np.exp(init['outputscale_raw'])) - 1.0) < 1e-12
+    with pytest.raises(NotImplementedError):
+        resolve_covar_module(CosineKernel())
+    with pytest.raises(NotImplementedError):
+        resolve_mean_module(Mean())
+    lay = ParamLayout(2, 'constant', 'SE', with_outputscale=True)
+    theta = torch.zeros(lay.D)
+    apply_initial_values(theta, lay, {'constant_mean': 0.25, 'lengthscale_raw': [0.5, -1.0], 'outputscale_raw': 0.75})
+    assert theta[lay.slices['constant_mean'][0]] == 0.25 and theta[lay.slices['outputscale_raw'][0]] == 0.75
+    assert theta[lay.slices['lengthscale_raw'][0]:lay.slices['lengthscale_raw'][1]].tolist() == [0.5, -1.0]
