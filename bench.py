@@ -287,7 +287,7 @@ def wl_cfg3(world, scaling, M, L):
                 finite=lambda: bool(torch.isfinite(model.particles).all()),
                 flops={'gp_lml_fwdbwd': (gp_flops(N_CTX, 2) * ev,) * 2, 'mlp_fwd': (2 * N_CTX * w * ev,) * 2,
                        'mlp_bwd': (4 * N_CTX * w * ev, 6 * N_CTX * w * ev)},
-                pmc_keys={'gp_lml_fwdbwd': 'gp_mfma_kernel', 'mlp_fwd': 'mlp_fused_fwd', 'mlp_bwd': 'mlp_fused_bwd'},
+                pmc_keys={'gp_lml_fwdbwd': 'gp_reg_kernel', 'mlp_fwd': 'mlp_fused_fwd', 'mlp_bwd': 'mlp_fused_bwd'},
                 describe='PACOH-SVGD step as meta_fit runs it (hipGraph replay), cfg#3: %d tasks %s x %d particles, n_ctx=%d, d=%d, '
                          'NN(32,32) mean + NN(32,32) kernel (D=%d), task sharding + 1 all-reduce/step'
                          % (TASKS, 'per GPU' if scaling == 'weak' else 'in total', PARTICLES, N_CTX, DIM, model.layout.D),
