@@ -81,27 +81,29 @@ __device__ __forceinline__ float wave_sum_(float v) {
     return readlane_(v, 63);
 }
 
-// Cholesky of the 16x16 block C (accumulator layout, symmetric) and the inverse of its factor: on exit Z = L^-1 (accumulator
-// layout, zeros above the diagonal).  `ok` is cleared by a pivot that is not positive (the block then fills with NaNs; the
-// retry with more jitter starts from a fresh Gram matrix).  The 16 reciprocal square roots of the pivots are handed out one
-// per lane (lane base + 4k + j keeps pivot 4k+j in myr) for the log-determinant.
-__device__ __forceinline__ void factor16(f32x4 C, f32x4& Z, float& myr, bool& ok, int lane_base, int lane, int r, int g) {
+// Cholesky of the 16x16 block C = -Cn (accumulator layout, symmetric; handed over NEGATED, as the kernel stores the matrix) and
+// the inverse of its factor: on exit Z = L^-1 (accumulator layout, zeros above the diagonal).  nId = -identity.  The diagonal of L
+// is multiplied into `dprod` (lane (r, g = r>>2) takes L[r][r], the other lanes 1) for the log-determinant; a pivot that is not
+// positive turns its lane's product into NaN (q * rsq(q)), which is also how the caller notices the failure.
+// What is NOT computed: the entries of L^T above the 4-column panel being eliminated are left as they fall out of the
+// substitution (garbage): they only ever meet rows of Z that are still zero, or produce rows of the product nobody reads.
+__device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const f32x4& nId, int r, int g) {
     f32x4 Lt = {0.f, 0.f, 0.f, 0.f};                        // L^T in accumulator layout: register s of lane (r, g) = L[r][4g+s]
     Z = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         // pivot block P[c][j] = C[4k+c][4k+j] = register c of lane (r = 4k+j, g = k): wave-uniform
-        const float c0 = C[0], c1 = C[1], c2 = C[2], c3 = C[3];
+        const float c0 = Cn[0], c1 = Cn[1], c2 = Cn[2], c3 = Cn[3];
         const int l0 = 20 * k;
-        const float p00 = readlane_(c0, l0), p10 = readlane_(c1, l0), p20 = readlane_(c2, l0), p30 = readlane_(c3, l0);
-        const float p11 = readlane_(c1, l0 + 1), p21 = readlane_(c2, l0 + 1), p31 = readlane_(c3, l0 + 1);
-        const float p22 = readlane_(c2, l0 + 2), p32 = readlane_(c3, l0 + 2), p33 = readlane_(c3, l0 + 3);
+        const float p00 = -readlane_(c0, l0), p10 = -readlane_(c1, l0), p20 = -readlane_(c2, l0), p30 = -readlane_(c3, l0);
+        const float p11 = -readlane_(c1, l0 + 1), p21 = -readlane_(c2, l0 + 1), p31 = -readlane_(c3, l0 + 1);
+        const float p22 = -readlane_(c2, l0 + 2), p32 = -readlane_(c3, l0 + 2), p33 = -readlane_(c3, l0 + 3);
         // rt[c] = C[4k+c][r] = register c of lane (r, g = k)
         const int src = (16 * k + r) * 4;
-        const float rt0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c0)));
-        const float rt1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c1)));
-        const float rt2 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c2)));
-        const float rt3 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c3)));
+        const float rt0 = -__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c0)));
+        const float rt1 = -__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c1)));
+        const float rt2 = -__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c2)));
+        const float rt3 = -__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c3)));
         const float r0 = __builtin_amdgcn_rsqf(p00);
         const float l10 = p10 * r0, l20 = p20 * r0, l30 = p30 * r0;
         const float q11 = fmaf(-l10, l10, p11);
@@ -112,38 +114,31 @@ __device__ __forceinline__ void factor16(f32x4 C, f32x4& Z, float& myr, bool& ok
         const float l32 = fmaf(-l31, l21, fmaf(-l30, l20, p32)) * r2;
         const float q33 = fmaf(-l32, l32, fmaf(-l31, l31, fmaf(-l30, l30, p33)));
         const float r3 = __builtin_amdgcn_rsqf(q33);
-        ok = ok && (p00 > 0.0f) && (q11 > 0.0f) && (q22 > 0.0f) && (q33 > 0.0f);
-        const int lp = lane - lane_base - 4 * k;
-        myr = lp == 0 ? r0 : (lp == 1 ? r1 : (lp == 2 ? r2 : (lp == 3 ? r3 : myr)));
         // this lane's row of the panel: X Lp^T = C[:, 4k..4k+3] by forward substitution = L[r][4k..4k+3]
-        float x0 = rt0 * r0;
-        float x1 = fmaf(-x0, l10, rt1) * r1;
-        float x2 = fmaf(-x1, l21, fmaf(-x0, l20, rt2)) * r2;
-        float x3 = fmaf(-x2, l32, fmaf(-x1, l31, fmaf(-x0, l30, rt3))) * r3;
-        const int rr = r - 4 * k;                            // row inside (0..3) / below (>= 4) / above (< 0) the pivot block
-        if (rr < 0) x0 = 0.0f;
-        if (rr < 1) x1 = 0.0f;
-        if (rr < 2) x2 = 0.0f;
-        if (rr < 3) x3 = 0.0f;
+        const float x0 = rt0 * r0;
+        const float x1 = fmaf(-x0, l10, rt1) * r1;
+        const float x2 = fmaf(-x1, l21, fmaf(-x0, l20, rt2)) * r2;
+        const float x3 = fmaf(-x2, l32, fmaf(-x1, l31, fmaf(-x0, l30, rt3))) * r3;
         if (g == k) { Lt[0] = x0; Lt[1] = x1; Lt[2] = x2; Lt[3] = x3; }
-        if (k < 3) {                                         // C[i][j] -= sum_c X[i][c] X[j][c] for i, j >= 4k+4: one MFMA
+        if (k < 3) {                                         // Cn[i][j] += sum_c X[i][c] X[j][c] for i, j >= 4k+4: one MFMA
             const float xg = g == 0 ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));
-            const float am = rr >= 4 ? xg : 0.0f;
-            C = mfma_(-am, am, C);
+            const float am = r >= 4 * k + 4 ? xg : 0.0f;
+            Cn = mfma_(am, am, Cn);
         }
         // rows 4k..4k+3 of L^-1: Lp Z_k = E_k - (L Z)[k-th block row]   (columns >= 4k of L meet zero rows of Z)
-        f32x4 Y = {0.f, 0.f, 0.f, 0.f};
-        if (k > 0) Y = mmT(Lt, Z, Y);
+        f32x4 Yn = nId;                                      // Yn = -E + L Z; in the lanes g == k, -E_k is what nId holds
+        if (k > 0) Yn = mmT(Lt, Z, Yn);
         if (g == k) {
-            const float t0 = (rr == 0 ? 1.0f : 0.0f) - Y[0], t1 = (rr == 1 ? 1.0f : 0.0f) - Y[1];
-            const float t2 = (rr == 2 ? 1.0f : 0.0f) - Y[2], t3 = (rr == 3 ? 1.0f : 0.0f) - Y[3];
-            const float z0 = t0 * r0;
-            const float z1 = fmaf(-z0, l10, t1) * r1;
-            const float z2 = fmaf(-z1, l21, fmaf(-z0, l20, t2)) * r2;
-            const float z3 = fmaf(-z2, l32, fmaf(-z1, l31, fmaf(-z0, l30, t3))) * r3;
+            const float z0 = -Yn[0] * r0;
+            const float z1 = fmaf(-z0, l10, -Yn[1]) * r1;
+            const float z2 = fmaf(-z1, l21, fmaf(-z0, l20, -Yn[2])) * r2;
+            const float z3 = fmaf(-z2, l32, fmaf(-z1, l31, fmaf(-z0, l30, -Yn[3]))) * r3;
             Z[0] = z0; Z[1] = z1; Z[2] = z2; Z[3] = z3;
         }
     }
+    const int c = r & 3;
+    const float dsel = c == 0 ? Lt[0] : (c == 1 ? Lt[1] : (c == 2 ? Lt[2] : Lt[3]));
+    if (g == (r >> 2)) dprod *= dsel;
 }
 
 __host__ __device__ constexpr int uidx(int NB, int K, int J) { return K * NB - K * (K - 1) / 2 + (J - K); }   // upper block (K <= J)
@@ -183,9 +178,13 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     int nv = a.n_valid ? a.n_valid[ty] : n;
     nv = nv < n ? nv : n; nv = nv < 0 ? 0 : nv;
 
-    float ls[FP];
+    // The features are kept as z * KAPPA / lengthscale, KAPPA^2 = log2(e) / 2: a kernel entry is then exp2(-|dz|^2), ONE
+    // instruction on top of the squared distance (104 entries per lane pass through it: 40 of the upper block triangle in the
+    // Gram build, 64 in the gradient loop), and the constant comes back out in the chain-rule factors at the very end.
+    constexpr float KAPPA = 0.8493218002880191f, INV_KAPPA2 = 1.3862943611198906f;
+    float kls[FP];                                            // KAPPA / lengthscale
 #pragma unroll
-    for (int c = 0; c < FP; ++c) ls[c] = (c < f) ? a.ls[(long)p * f + c] : 1.0f;
+    for (int c = 0; c < FP; ++c) kls[c] = (c < f) ? KAPPA / a.ls[(long)p * f + c] : 1.0f;
     const float os = a.os ? a.os[p] : 1.0f;
     const float noise = a.noise[p];
 
@@ -198,7 +197,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     if (i < nv) {
         const float* zp = a.z + ((long)(blockIdx.x / (unsigned)a.z_div) * n + i) * (long)f;
 #pragma unroll
-        for (int c = 0; c < FP; ++c) if (c < f) zs[c] = zp[c] / ls[c];
+        for (int c = 0; c < FP; ++c) if (c < f) zs[c] = zp[c] * kls[c];
         float mi = 0.0f;
         if (a.mean_mode == PACOH_MEAN_VECTOR) mi = a.mean[b * n + i];
         else if (a.mean_mode == PACOH_MEAN_CONST) mi = a.mean[p];
@@ -211,16 +210,16 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     }
     WSYNC();
 
-    f32x4 Id;                                                 // identity block in accumulator layout
+    f32x4 nId;                                                // -identity block in accumulator layout
 #pragma unroll
-    for (int s = 0; s < 4; ++s) Id[s] = (4 * g + s == r) ? 1.0f : 0.0f;
+    for (int s = 0; s < 4; ++s) nId[s] = (4 * g + s == r) ? -1.0f : 0.0f;
 
     // ---- Gram build + blocked Cholesky (upper factor R = L^T) with the psd_safe_cholesky jitter ladder ------------------------
     f32x4 U[NU];                                              // U[uidx(K,J)], K <= J: block (K,J) of the matrix -> R[K][J]
     f32x4 Zd[NB];                                             // L_KK^-1
     f32x4 uB[NB];                                             // u = L^-1 r, replicated: register s of lane (r,g) = u[16K + 4g+s]
     f32x4 G[NB][NB];                                          // strictly-lower blocks of L^-1 (backward only)
-    float myr = 1.0f;                                         // 1/sqrt(pivot `lane`) (1 for padding rows)
+    float dprod = 1.0f;                                       // this lane's share of prod_i L_ii (padding rows: 1)
     int my_info = -1;
     float jitter = 0.0f;
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -244,7 +243,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
                     float q = 0.0f;
 #pragma unroll
                     for (int c = 0; c < FP; ++c) { const float d = zr[s][c] - zc[c]; q = fmaf(d, d, q); }
-                    float k = os * rbf_exp<float>(-0.5f * q);
+                    float k = os * __builtin_amdgcn_exp2f(-q);
                     if (nv < NP) { if (!(ii < nv && jj < nv)) k = 0.0f; }
                     if (I == J) { if (ii == jj) k = (ii < nv) ? k + noise + jitter : 1.0f; }
                     blk[s] = -k;                              // (the NEGATED matrix is stored: see the trailing update)
@@ -253,8 +252,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
                 SCHED_FENCE();
             }
         }
-        bool ok = true;
-        myr = 1.0f;
+        dprod = 1.0f;
         // Step K also finishes everything that only needs block rows <= K of R: u_K and (backward) block row K of L^-1, so that
         // V_K is a temporary and column K of R is dead afterwards -- the matrix drains out of the register file as the loop advances.
 #pragma unroll
@@ -264,9 +262,9 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
             // registers per product.  So the blocks not yet eliminated are kept NEGATED (Un = -A): the trailing update becomes
             // Un[I][J] += R[K][I]^T R[K][J] with both operands as they are, and every other product of the step takes the one
             // negated operand Vn = -L_KK^-T.
-            factor16(-U[uidx(NB, K, K)], Zd[K], myr, ok, 16 * K, lane, r, g);
+            factor16(U[uidx(NB, K, K)], Zd[K], dprod, nId, r, g);
             SCHED_FENCE();
-            const f32x4 Vn = mmT_neg(Zd[K], Id, f32x4{0.f, 0.f, 0.f, 0.f});          // -L_KK^-T
+            const f32x4 Vn = mmT(Zd[K], nId, f32x4{0.f, 0.f, 0.f, 0.f});             // -L_KK^-T
 #pragma unroll
             for (int J = K + 1; J < NB; ++J) U[uidx(NB, K, J)] = mmT(Vn, U[uidx(NB, K, J)], f32x4{0.f, 0.f, 0.f, 0.f});   // R[K][J] = L_KK^-1 A[K][J]
             SCHED_FENCE();
@@ -292,7 +290,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
 #pragma unroll
                 for (int J = I; J < NB; ++J) U[uidx(NB, I, J)] = mmT(U[uidx(NB, K, I)], U[uidx(NB, K, J)], U[uidx(NB, I, J)]);
         }
-        if (ok) { my_info = attempt; break; }                // (wave-uniform)
+        if (__builtin_amdgcn_ballot_w64(dprod > 0.0f) == ~0ull) { my_info = attempt; break; }   // every pivot positive (wave-uniform)
         jitter = 1e-6f;
         for (int q = 0; q < attempt; ++q) jitter *= 10.0f;
     }
@@ -303,7 +301,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
 #pragma unroll
     for (int K = 0; K < NB; ++K) q2 += (uB[K][0] * uB[K][0] + uB[K][1] * uB[K][1]) + (uB[K][2] * uB[K][2] + uB[K][3] * uB[K][3]);
     const float quad = wave_sum_(r == 0 ? q2 : 0.0f);
-    const float logdet = wave_sum_(-logf(myr));               // log det = 2 sum log L_ii; padding rows have pivot 1
+    const float logdet = wave_sum_(logf(dprod));              // log det = 2 sum log L_ii; padding rows have pivot 1
     float lml = nv > 0 ? -0.5f * (quad + 2.0f * logdet + (float)nv * 1.8378770664093453f) / (float)nv : 0.0f;
     if (!okf) lml = NAN;
     if (lane == 0) a.lml[b] = lml;
@@ -336,11 +334,11 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     WSYNC();
     // ---- gradient sums over the upper block triangle -----------------------------------------------------------------------------
     const float gup = a.g_lml ? a.g_lml[b] : 1.0f;
-    const float inv2n = nv > 0 ? 0.5f / (float)nv : 0.0f;
+    const float osn = nv > 0 ? 0.5f * os / (float)nv : 0.0f;   // the outputscale rides on the 1/(2 n) factor: M_ij = G_ij os e_ij
     float dls[FP];
 #pragma unroll
     for (int c = 0; c < FP; ++c) dls[c] = 0.0f;
-    float dos = 0.0f, dnz = 0.0f;
+    float msum = 0.0f, dnz = 0.0f;                              // sum of M (= os d lml/d os), os x trace part (= os d lml/d noise)
     // Every ordered pair (i, j) is visited, column block by column block: lane (r, g) holds the entries (i = 16I + 4g+s, j = 16J + r),
     // so everything destined for point j -- d_z[j] = sum_i M_ij (z_i - z_j) -- accumulates in the lane over s and I and needs only
     // two lane exchanges (over g) per column block at the end.  (Using the symmetry instead -- upper blocks only, each entry feeding
@@ -370,7 +368,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
                 float zi[FP];
 #pragma unroll
                 for (int c = 0; c < FP; ++c) zi[c] = zf[(16 * I + 4 * g + s) * FP + c];
-                float Gij = (ai4[s] * aj - Wb[s]) * inv2n;
+                float Gij = (ai4[s] * aj - Wb[s]) * osn;
                 if (I == J) {
                     const int ii = 16 * I + 4 * g + s;
                     if (ii >= nv) Gij = 0.0f;                 // identity padding: its diagonal must not count
@@ -379,9 +377,8 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
                 float q = 0.0f, df[FP];
 #pragma unroll
                 for (int c = 0; c < FP; ++c) { df[c] = zi[c] - zc[c]; q = fmaf(df[c], df[c], q); }
-                const float e = rbf_exp<float>(-0.5f * q);
-                dos = fmaf(Gij, e, dos);
-                const float M = Gij * os * e;
+                const float M = Gij * __builtin_amdgcn_exp2f(-q);
+                msum += M;
 #pragma unroll
                 for (int c = 0; c < FP; ++c) {
                     const float md = M * df[c];
@@ -402,7 +399,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     const float ai = i < NP ? av[i] : 0.0f;
     if (a.d_z && i < n) {
         for (int c = 0; c < f; ++c)
-            a.d_z[(b * n + i) * (long)f + c] = (i < nv) ? 2.0f * gup * dzc[i * FP + c] / ls[c] + bad : 0.0f;
+            a.d_z[(b * n + i) * (long)f + c] = (i < nv) ? (2.0f * INV_KAPPA2) * gup * dzc[i * FP + c] * kls[c] + bad : 0.0f;
     }
     if (a.mean_mode == PACOH_MEAN_VECTOR) {
         if (a.d_mean && i < n) a.d_mean[b * n + i] = (i < nv) ? gup * ai / (float)nv + bad : 0.0f;
@@ -414,13 +411,13 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     for (int c = 0; c < FP; ++c) {
         if (c < f) {
             const float sc = wave_sum_(dls[c]);
-            if (lane == 0) a.d_ls[b * f + c] = gup * sc / ls[c] + bad;
+            if (lane == 0) a.d_ls[b * f + c] = (INV_KAPPA2 / KAPPA) * gup * sc * kls[c] + bad;
         }
     }
-    const float sdos = wave_sum_(dos), sdnz = wave_sum_(dnz);
+    const float sdos = wave_sum_(msum), sdnz = wave_sum_(dnz);
     if (lane == 0) {
-        if (a.d_os) a.d_os[b] = gup * sdos + bad;
-        a.d_noise[b] = gup * sdnz + bad;
+        if (a.d_os) a.d_os[b] = gup * sdos / os + bad;
+        a.d_noise[b] = gup * sdnz / os + bad;
     }
 #undef WSYNC
 #undef SCHED_FENCE
