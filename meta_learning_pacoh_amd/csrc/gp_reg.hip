@@ -150,7 +150,7 @@ __host__ __device__ constexpr int uidx(int NB, int K, int J) { return K * NB - K
 #ifdef PACOH_GPR_MINW
 #define GPR_MINW(NB, FP, BWD) PACOH_GPR_MINW
 #else
-#define GPR_MINW(NB, FP, BWD) ((NB) == 4 ? ((FP) == 4 && (BWD) ? 2 : 3) : 4)
+#define GPR_MINW(NB, FP, BWD) ((NB) == 4 && (FP) == 4 ? ((BWD) ? 2 : 3) : 4)
 #endif
 template <int NB, int FP, bool BWD>
 __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfmaArgs a) {
@@ -160,10 +160,10 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     __shared__ __attribute__((aligned(16))) float rv[NP];           // residual
     __shared__ __attribute__((aligned(16))) float av[NP];           // alpha
     __shared__ __attribute__((aligned(16))) float dzc[BWD ? NP * FP : 1];   // d_z before the chain-rule factors
-    // W = K^-1, upper block triangle, each block as the 64 lanes' accumulator registers (one 16-byte slot per lane): parked here
-    // between the matrix-core phase that produces it and the gradient loop that consumes it, so that the two phases do not have
-    // to share the register file (2.5 KB per block; with it a problem holds 12 KB of LDS = 13 problems per CU)
-    __shared__ __attribute__((aligned(16))) float Wl[BWD ? NU * 256 : 4];
+    // W = K^-1, strictly upper block triangle, each block as the 64 lanes' accumulator registers (one 16-byte slot per lane): parked
+    // here between the matrix-core phase that produces it and the gradient loop that consumes it, so that the two phases do not
+    // have to share the register file (1 KB per block; with it a problem holds 7.7 KB of LDS = 20 problems per CU)
+    __shared__ __attribute__((aligned(16))) float Wl[BWD && NB > 1 ? (NU - NB) * 256 : 4];
 #define WSYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)   // in-order LDS within one wave
     // The kernel is one long unrolled instruction stream of mutually independent block computations; left alone, the scheduler
     // interleaves dozens of them (40 exp chains of the Gram build at once) and the register file overflows.  Fences between the
@@ -319,20 +319,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
         if (r == 0) *reinterpret_cast<f32x4*>(av + 16 * K + 4 * g) = t;
         SCHED_FENCE();
     }
-    // ---- W = K^-1, upper block triangle: W[I][J] = sum_{m >= J} Linv[m][I]^T Linv[m][J]  ->  LDS --------------------------------
-#pragma unroll
-    for (int I = 0; I < NB; ++I) {
-#pragma unroll
-        for (int J = I; J < NB; ++J) {
-            f32x4 Wb = mmT(I == J ? Zd[J] : G[J][I], Zd[J], f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-            for (int m = J + 1; m < NB; ++m) Wb = mmT(G[m][I], G[m][J], Wb);
-            *reinterpret_cast<f32x4*>(Wl + uidx(NB, I, J) * 256 + lane * 4) = Wb;
-        }
-    }
-    SCHED_FENCE();
-    WSYNC();
-    // ---- gradient sums over the upper block triangle -----------------------------------------------------------------------------
+    // ---- gradient sums ---------------------------------------------------------------------------------------------------------------
     const float gup = a.g_lml ? a.g_lml[b] : 1.0f;
     const float osn = nv > 0 ? 0.5f * os / (float)nv : 0.0f;   // the outputscale rides on the 1/(2 n) factor: M_ij = G_ij os e_ij
     float dls[FP];
@@ -344,7 +331,61 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     // two lane exchanges (over g) per column block at the end.  (Using the symmetry instead -- upper blocks only, each entry feeding
     // the row sum of i as well -- saves 24 of the 64 exponentials per lane but needs sums over the 16 lanes of a row: 128 DPP adds,
     // and the compiler kept every block row's partial sums alive to the end of the kernel, 100 registers over budget.)
-    // W[I][J] for I > J is the transpose of the stored block (J, I): read element by element from its LDS image.
+    // the four entries of one block in this lane: M_ij (z_i - z_j) into colacc (point j), M_ij (z_i - z_j)^2 into dls, M_ij into msum
+    auto block_entries = [&](const f32x4& Wb, const int I, const float (&zc)[FP], const float aj, float (&colacc)[FP], const bool diag) {
+        const f32x4 ai4 = *reinterpret_cast<const f32x4*>(av + 16 * I + 4 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float zi[FP];
+#pragma unroll
+            for (int c = 0; c < FP; ++c) zi[c] = zf[(16 * I + 4 * g + s) * FP + c];
+            float Gij = (ai4[s] * aj - Wb[s]) * osn;
+            if (diag) {
+                const int ii = 16 * I + 4 * g + s;
+                if (ii >= nv) Gij = 0.0f;                     // identity padding: its diagonal must not count
+                if (4 * g + s == r) dnz += Gij;
+            }
+            float q = 0.0f, df[FP];
+#pragma unroll
+            for (int c = 0; c < FP; ++c) { df[c] = zi[c] - zc[c]; q = fmaf(df[c], df[c], q); }
+            const float M = Gij * __builtin_amdgcn_exp2f(-q);
+            msum += M;
+#pragma unroll
+            for (int c = 0; c < FP; ++c) {
+                const float md = M * df[c];
+                colacc[c] += md;
+                dls[c] = fmaf(md, df[c], dls[c]);
+            }
+        }
+    };
+    // ---- W = K^-1, upper block triangle: W[I][J] = sum_{m >= J} Linv[m][I]^T Linv[m][J].  A diagonal block is consumed where it
+    //      is produced; the strictly upper blocks are parked in LDS for the loop below, which needs each of them twice (as block
+    //      (I,J) and, transposed, as block (J,I)) -------------------------------------------------------------------------------------
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+#pragma unroll
+        for (int J = I; J < NB; ++J) {
+            f32x4 Wb = mmT(I == J ? Zd[J] : G[J][I], Zd[J], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int m = J + 1; m < NB; ++m) Wb = mmT(G[m][I], G[m][J], Wb);
+            if (I == J) {
+                float zc[FP], colacc[FP];
+#pragma unroll
+                for (int c = 0; c < FP; ++c) { zc[c] = zf[(16 * J + r) * FP + c]; colacc[c] = 0.0f; }
+                block_entries(Wb, I, zc, av[16 * J + r], colacc, true);
+#pragma unroll
+                for (int c = 0; c < FP; ++c) {
+                    float v = colacc[c];
+                    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                    if (g == 0) dzc[(16 * J + r) * FP + c] = v;
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(Wl + (uidx(NB, I, J) - (I + 1)) * 256 + lane * 4) = Wb;
+            }
+            SCHED_FENCE();
+        }
+    }
+    WSYNC();
     // (real loops, all operands from LDS: fully unrolled, the compiler hoists the loads of every iteration to the top and spills)
 #pragma unroll 1
     for (int J = 0; J < NB; ++J) {
@@ -354,44 +395,22 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
         const float aj = av[16 * J + r];
 #pragma unroll 1
         for (int I = 0; I < NB; ++I) {
+            if (I == J) continue;
             f32x4 Wb;
-            if (I <= J) {
-                Wb = *reinterpret_cast<const f32x4*>(Wl + (I * NB - I * (I - 1) / 2 + (J - I)) * 256 + lane * 4);
-            } else {
-                const float* wt = Wl + (J * NB - J * (J - 1) / 2 + (I - J)) * 256 + (16 * (r >> 2)) * 4 + (r & 3);   // element (r, 4g+s) of block (J, I)
+            if (I < J) {
+                Wb = *reinterpret_cast<const f32x4*>(Wl + (I * NB - I * (I - 1) / 2 + (J - I) - (I + 1)) * 256 + lane * 4);
+            } else {                                          // transpose of the stored block (J, I): element (r, 4g+s) of it
+                const float* wt = Wl + (J * NB - J * (J - 1) / 2 + (I - J) - (J + 1)) * 256 + (16 * (r >> 2)) * 4 + (r & 3);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) Wb[s] = wt[(4 * g + s) * 4];
             }
-            const f32x4 ai4 = *reinterpret_cast<const f32x4*>(av + 16 * I + 4 * g);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                float zi[FP];
-#pragma unroll
-                for (int c = 0; c < FP; ++c) zi[c] = zf[(16 * I + 4 * g + s) * FP + c];
-                float Gij = (ai4[s] * aj - Wb[s]) * osn;
-                if (I == J) {
-                    const int ii = 16 * I + 4 * g + s;
-                    if (ii >= nv) Gij = 0.0f;                 // identity padding: its diagonal must not count
-                    if (4 * g + s == r) dnz += Gij;
-                }
-                float q = 0.0f, df[FP];
-#pragma unroll
-                for (int c = 0; c < FP; ++c) { df[c] = zi[c] - zc[c]; q = fmaf(df[c], df[c], q); }
-                const float M = Gij * __builtin_amdgcn_exp2f(-q);
-                msum += M;
-#pragma unroll
-                for (int c = 0; c < FP; ++c) {
-                    const float md = M * df[c];
-                    colacc[c] += md;
-                    dls[c] = fmaf(md, df[c], dls[c]);
-                }
-            }
+            block_entries(Wb, I, zc, aj, colacc, false);
         }
 #pragma unroll
         for (int c = 0; c < FP; ++c) {
             float v = colacc[c];
             v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-            if (g == 0) dzc[(16 * J + r) * FP + c] = v;
+            if (g == 0) dzc[(16 * J + r) * FP + c] += v;
         }
     }
     WSYNC();
