@@ -73,6 +73,19 @@ __device__ __forceinline__ float row_sum_(float v) {
     v = dpp_add_<0x140, 0xF>(v);      // row_mirror
     return v;
 }
+// sum over the four lane rows (lanes of equal r), in every lane
+__device__ __forceinline__ float xg_sum_(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+// this lane's share of (X^T v)[r] = sum_{g,s} X[4g+s][r] v[4g+s]  (X in accumulator layout, v replicated: register s of lane
+// (r, g) = v[4g+s]); xg_sum_() of it is the product, in "column layout" (lane (r, .) holds entry r).  A matrix-vector product
+// on the matrix cores costs a full 16x16x16 block product (128 issue cycles); this is four fmas (+ 1/4 of the row exchange)
+__device__ __forceinline__ float mvT_(const f32x4& X, const f32x4& v, float acc) {
+    acc = fmaf(X[0], v[0], acc); acc = fmaf(X[1], v[1], acc); acc = fmaf(X[2], v[2], acc); acc = fmaf(X[3], v[3], acc);
+    return acc;
+}
 // sum over the 64 lanes, as a wave-uniform value
 __device__ __forceinline__ float wave_sum_(float v) {
     v = row_sum_(v);
@@ -141,6 +154,18 @@ __device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const
     if (g == (r >> 2)) dprod *= dsel;
 }
 
+// A kernel argument read where it is needed.  The compiler loads the whole argument struct into scalar registers at kernel
+// entry (one s_load_dwordx16 tuple among others) and, this kernel being short of scalar registers, spills it and reloads all
+// sixteen words at every use of one of them: ~230 v_writelane / v_readlane per problem.  The pointers only needed for the final
+// stores are fetched from the kernel-argument segment at that point instead (a scalar-cache hit).
+template <typename T>
+__device__ __forceinline__ T late_arg(unsigned offset) {
+    typedef const char __attribute__((address_space(4))) * kptr_t;
+    kptr_t kp = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(const volatile T __attribute__((address_space(4)))*)(kp + offset);
+}
+#define LATE(field) late_arg<decltype(GpMfmaArgs::field)>((unsigned)__builtin_offsetof(GpMfmaArgs, field))
+
 __host__ __device__ constexpr int uidx(int NB, int K, int J) { return K * NB - K * (K - 1) / 2 + (J - K); }   // upper block (K <= J)
 
 }  // namespace
@@ -159,6 +184,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     __shared__ __attribute__((aligned(16))) float zf[NP * FP];      // features / lengthscale
     __shared__ __attribute__((aligned(16))) float rv[NP];           // residual
     __shared__ __attribute__((aligned(16))) float av[NP];           // alpha
+    __shared__ __attribute__((aligned(16))) float tv[16];           // column layout -> replicated layout of one 16-vector
     __shared__ __attribute__((aligned(16))) float dzc[BWD ? NP * FP : 1];   // d_z before the chain-rule factors
     // W = K^-1, strictly upper block triangle, each block as the 64 lanes' accumulator registers (one 16-byte slot per lane): parked
     // here between the matrix-core phase that produces it and the gradient loop that consumes it, so that the two phases do not
@@ -194,7 +220,12 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
 #pragma unroll
     for (int c = 0; c < FP; ++c) zs[c] = 0.0f;
     float ri = 0.0f;
+    // Padding rows (nv <= i < 16 NB) must come out as rows of the identity.  They are placed far away from every other point --
+    // each at its own distance, so that exp2(-|dz|^2) is exactly 0 against anything else -- instead of masking 104 entries per lane
+    // with compares the compiler hoists out of the retry loop into scalar registers it does not have.
+    zs[0] = 1e10f * (float)(i + 1);
     if (i < nv) {
+        zs[0] = 0.0f;
         const float* zp = a.z + ((long)(blockIdx.x / (unsigned)a.z_div) * n + i) * (long)f;
 #pragma unroll
         for (int c = 0; c < FP; ++c) if (c < f) zs[c] = zp[c] * kls[c];
@@ -235,18 +266,16 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
                 float zc[FP];
 #pragma unroll
                 for (int c = 0; c < FP; ++c) zc[c] = zf[(16 * J + r) * FP + c];
-                const int jj = 16 * J + r;
+                // the diagonal gets noise + jitter (a padding row: 1 - os, its kernel entry being os) through the -identity block
+                const float dadd = (I == J) ? ((16 * J + r < nv) ? noise + jitter : 1.0f - os) : 0.0f;
                 f32x4 blk;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const int ii = 16 * I + 4 * g + s;
                     float q = 0.0f;
 #pragma unroll
                     for (int c = 0; c < FP; ++c) { const float d = zr[s][c] - zc[c]; q = fmaf(d, d, q); }
-                    float k = os * __builtin_amdgcn_exp2f(-q);
-                    if (nv < NP) { if (!(ii < nv && jj < nv)) k = 0.0f; }
-                    if (I == J) { if (ii == jj) k = (ii < nv) ? k + noise + jitter : 1.0f; }
-                    blk[s] = -k;                              // (the NEGATED matrix is stored: see the trailing update)
+                    const float k = os * __builtin_amdgcn_exp2f(-q);
+                    blk[s] = (I == J) ? fmaf(nId[s], dadd, -k) : -k;     // (the NEGATED matrix is stored: see the trailing update)
                 }
                 U[uidx(NB, I, J)] = blk;
                 SCHED_FENCE();
@@ -268,10 +297,19 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
 #pragma unroll
             for (int J = K + 1; J < NB; ++J) U[uidx(NB, K, J)] = mmT(Vn, U[uidx(NB, K, J)], f32x4{0.f, 0.f, 0.f, 0.f});   // R[K][J] = L_KK^-1 A[K][J]
             SCHED_FENCE();
-            {   // u_K = L_KK^-1 (r_K - sum_m L[K][m] u_m), L[K][m] = R[m][K]^T: accumulate tn = -r_K + sum_m R[m][K]^T u_m
+            {   // u_K = L_KK^-1 (r_K - sum_m L[K][m] u_m), L[K][m] = R[m][K]^T: tn = -r_K + sum_m R[m][K]^T u_m on the vector
+                // units (mvT_), turned into the replicated layout through 64 bytes of LDS; the product with L_KK^-1 on the matrix cores
                 f32x4 tn = -*reinterpret_cast<const f32x4*>(rv + 16 * K + 4 * g);
+                if (K > 0) {
+                    float tp = 0.0f;
 #pragma unroll
-                for (int m = 0; m < K; ++m) tn = mmT(U[uidx(NB, m, K)], uB[m], tn);
+                    for (int m = 0; m < K; ++m) tp = mvT_(U[uidx(NB, m, K)], uB[m], tp);
+                    tp = xg_sum_(tp);
+                    if (g == 0) tv[r] = tp;
+                    WSYNC();
+                    tn += *reinterpret_cast<const f32x4*>(tv + 4 * g);
+                    WSYNC();
+                }
                 uB[K] = mmT(Vn, tn, f32x4{0.f, 0.f, 0.f, 0.f});
             }
             SCHED_FENCE();
@@ -295,7 +333,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
         for (int q = 0; q < attempt; ++q) jitter *= 10.0f;
     }
     const bool okf = my_info >= 0;
-    if (lane == 0 && a.info) a.info[b] = my_info;
+    { int32_t* info_p = LATE(info); if (lane == 0 && info_p) info_p[b] = my_info; }
 
     float q2 = 0.0f;
 #pragma unroll
@@ -304,23 +342,23 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     const float logdet = wave_sum_(logf(dprod));              // log det = 2 sum log L_ii; padding rows have pivot 1
     float lml = nv > 0 ? -0.5f * (quad + 2.0f * logdet + (float)nv * 1.8378770664093453f) / (float)nv : 0.0f;
     if (!okf) lml = NAN;
-    if (lane == 0) a.lml[b] = lml;
+    if (lane == 0) LATE(lml)[b] = lml;
     if (!BWD) return;
 
     SCHED_FENCE();
-    // ---- alpha = L^-T u (replicated), published to LDS for the column-indexed uses ----------------------------------------------
-    f32x4 aB[NB];
+    // ---- alpha = L^-T u: alpha_K = sum_{I >= K} Linv[I][K]^T u_I, on the vector units, published to LDS ---------------------------
 #pragma unroll
     for (int K = 0; K < NB; ++K) {
-        f32x4 t = mmT(Zd[K], uB[K], f32x4{0.f, 0.f, 0.f, 0.f});
+        float ap = mvT_(Zd[K], uB[K], 0.0f);
 #pragma unroll
-        for (int I = K + 1; I < NB; ++I) t = mmT(G[I][K], uB[I], t);
-        aB[K] = t;
-        if (r == 0) *reinterpret_cast<f32x4*>(av + 16 * K + 4 * g) = t;
-        SCHED_FENCE();
+        for (int I = K + 1; I < NB; ++I) ap = mvT_(G[I][K], uB[I], ap);
+        ap = xg_sum_(ap);
+        if (g == 0) av[16 * K + r] = ap;
     }
+    SCHED_FENCE();
     // ---- gradient sums ---------------------------------------------------------------------------------------------------------------
-    const float gup = a.g_lml ? a.g_lml[b] : 1.0f;
+    const float* g_lml_p = LATE(g_lml);
+    const float gup = g_lml_p ? g_lml_p[b] : 1.0f;
     const float osn = nv > 0 ? 0.5f * os / (float)nv : 0.0f;   // the outputscale rides on the 1/(2 n) factor: M_ij = G_ij os e_ij
     float dls[FP];
 #pragma unroll
@@ -340,11 +378,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
 #pragma unroll
             for (int c = 0; c < FP; ++c) zi[c] = zf[(16 * I + 4 * g + s) * FP + c];
             float Gij = (ai4[s] * aj - Wb[s]) * osn;
-            if (diag) {
-                const int ii = 16 * I + 4 * g + s;
-                if (ii >= nv) Gij = 0.0f;                     // identity padding: its diagonal must not count
-                if (4 * g + s == r) dnz += Gij;
-            }
+            if (diag) dnz = fmaf(nId[s], Gij, dnz);           // minus the trace part (padding rows: taken out again below)
             float q = 0.0f, df[FP];
 #pragma unroll
             for (int c = 0; c < FP; ++c) { df[c] = zi[c] - zc[c]; q = fmaf(df[c], df[c], q); }
@@ -416,27 +450,33 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     WSYNC();
     const float bad = okf ? 0.0f : NAN;
     const float ai = i < NP ? av[i] : 0.0f;
-    if (a.d_z && i < n) {
+    float* d_z_p = LATE(d_z);
+    if (d_z_p && i < n) {
         for (int c = 0; c < f; ++c)
-            a.d_z[(b * n + i) * (long)f + c] = (i < nv) ? (2.0f * INV_KAPPA2) * gup * dzc[i * FP + c] * kls[c] + bad : 0.0f;
+            d_z_p[(b * n + i) * (long)f + c] = (i < nv) ? (2.0f * INV_KAPPA2) * gup * dzc[i * FP + c] * kls[c] + bad : 0.0f;
     }
     if (a.mean_mode == PACOH_MEAN_VECTOR) {
-        if (a.d_mean && i < n) a.d_mean[b * n + i] = (i < nv) ? gup * ai / (float)nv + bad : 0.0f;
+        float* d_mean_p = LATE(d_mean);
+        if (d_mean_p && i < n) d_mean_p[b * n + i] = (i < nv) ? gup * ai / (float)nv + bad : 0.0f;
     } else if (a.mean_mode == PACOH_MEAN_CONST) {
         const float sa = wave_sum_((i < nv) ? ai : 0.0f);
-        if (a.d_mean && lane == 0) a.d_mean[b] = nv > 0 ? gup * sa / (float)nv + bad : 0.0f;
+        float* d_mean_p = LATE(d_mean);
+        if (d_mean_p && lane == 0) d_mean_p[b] = nv > 0 ? gup * sa / (float)nv + bad : 0.0f;
     }
 #pragma unroll
     for (int c = 0; c < FP; ++c) {
         if (c < f) {
             const float sc = wave_sum_(dls[c]);
-            if (lane == 0) a.d_ls[b * f + c] = (INV_KAPPA2 / KAPPA) * gup * sc * kls[c] + bad;
+            if (lane == 0) LATE(d_ls)[b * f + c] = (INV_KAPPA2 / KAPPA) * gup * sc * kls[c] + bad;
         }
     }
-    const float sdos = wave_sum_(msum), sdnz = wave_sum_(dnz);
+    // a padding row's diagonal entry is G_ii = (0 - 1) osn exactly, with kernel entry 1: out of both sums again
+    const float padc = (float)(NP - nv) * osn;
+    const float sdos = wave_sum_(msum) + padc, sdnz = padc - wave_sum_(dnz);
     if (lane == 0) {
-        if (a.d_os) a.d_os[b] = gup * sdos / os + bad;
-        a.d_noise[b] = gup * sdnz / os + bad;
+        float* d_os_p = LATE(d_os);
+        if (d_os_p) d_os_p[b] = gup * sdos / os + bad;
+        LATE(d_noise)[b] = gup * sdnz / os + bad;
     }
 #undef WSYNC
 #undef SCHED_FENCE
