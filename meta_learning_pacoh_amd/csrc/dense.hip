@@ -209,11 +209,18 @@ __global__ void __launch_bounds__(256) chol_dense_kernel(T* __restrict__ A, cons
 using namespace pacoh;
 
 namespace pacoh {
+bool dense_mfma_fits(int n, int dtype);                    // dense_mfma.hip
 int dense_mfma_try(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
                    int dtype, int attempt, hipStream_t s);       // dense_mfma.hip; returns 1 if the panel does not fit in LDS
 
 // Cholesky + solves + log-density of B materialised matrices; attempt > 0 re-runs only problems with info[b] < 0
 // (and then writes info[b] = attempt on success): the psd_safe_cholesky ladder of the dense path.
+// true when dense_chol_launch() takes the MFMA kernel, which leaves the inverses of the diagonal blocks in the upper triangle
+bool dense_chol_saves_inverse(int n, int dtype) {
+    const char* e = getenv("PACOH_DISABLE_MFMA");
+    return !(e && e[0] == '1') && dense_mfma_fits(n, dtype);
+}
+
 int dense_chol_launch(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
                       int dtype, int attempt, hipStream_t stream) {
     static const bool mfma_on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();

@@ -20,6 +20,7 @@ namespace pacoh {
 
 int dense_chol_launch(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
                       int dtype, int attempt, hipStream_t stream);                                  // dense.hip
+bool dense_chol_saves_inverse(int n, int dtype);                                                     // dense.hip
 
 namespace {
 
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(256) regram_failed_kernel(const T* __restrict_
 // ---- Z = L^-1 in place (lower triangle), right-to-left over 32-column panels ------------------------------------------------
 //   Z11 = L11^-1 (one wavefront, LDS);  Q = L21 Z11 (MFMA, LDS panel);  Z21 = -Z22 Q (MFMA: Z22 blocks from L2, Q from LDS)
 template <typename T, int NT>
-__global__ void __launch_bounds__(NT) trtri_dense_kernel(T* __restrict__ A, const int32_t* __restrict__ info, int n, int mpad) {
+__global__ void __launch_bounds__(NT) trtri_dense_kernel(T* __restrict__ A, const int32_t* __restrict__ info, int n, int mpad, int saved_inv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* sm = reinterpret_cast<T*>(smem_raw);
     T (*Ds)[DNB + 1] = reinterpret_cast<T (*)[DNB + 1]>(sm);          // L11
@@ -143,6 +144,18 @@ __global__ void __launch_bounds__(NT) trtri_dense_kernel(T* __restrict__ A, cons
         const int k0 = kbk * DNB;
         const int kb = (n - k0 < DNB) ? (n - k0) : DNB;
         const int t0 = k0 + kb, m = n - t0;
+        if (saved_inv) {
+            // the MFMA Cholesky (dense_mfma.hip) left Z11 behind: strictly lower part transposed in the strictly upper part of the
+            // diagonal block, and the diagonal of L11 itself (re-deriving it here: 496 dependent fp64 fmas + 32 divisions per lane
+            // by one wave while fifteen wait -- a third of this kernel's time at n = 512)
+            for (int q = tid; q < DNB * DNB; q += NT) {
+                const int rr = q / DNB, c = q - rr * DNB;
+                T v = T(0);
+                if (rr < kb && c < rr) v = Ab[(size_t)(k0 + c) * n + k0 + rr];
+                if (rr == c) v = rr < kb ? T(1) / Ab[(size_t)(k0 + rr) * n + k0 + rr] : T(1);
+                Li[rr * DLP + c] = v;
+            }
+        } else {
         for (int q = tid; q < DNB * DNB; q += NT) {
             const int rr = q / DNB, c = q - rr * DNB;
             T v = (rr == c) ? T(1) : T(0);
@@ -164,6 +177,7 @@ __global__ void __launch_bounds__(NT) trtri_dense_kernel(T* __restrict__ A, cons
 #pragma unroll
                 for (int i = 0; i < DNB; ++i) Li[i * DLP + rr] = x[i];
             }
+        }
         }
         __syncthreads();
         for (int q = tid; q < DNB * DNB; q += NT) {
@@ -589,11 +603,11 @@ __global__ void dense_predict_finish_kernel(const T* __restrict__ Kxs, const T* 
 }
 
 template <typename T>
-int launch_trtri(T* A, const int32_t* info, int B, int n, int mpad, size_t lds, hipStream_t s) {
+int launch_trtri(T* A, const int32_t* info, int B, int n, int mpad, size_t lds, int saved_inv, hipStream_t s) {
 #define PACOH_TRTRI_LAUNCH(nt) do { auto kern = trtri_dense_kernel<T, nt>; \
         if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return PACOH_ELIMIT; \
-        hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, s, A, info, n, mpad); } while (0)
+        hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, s, A, info, n, mpad, saved_inv); } while (0)
     if (n >= 256) PACOH_TRTRI_LAUNCH(1024); else if (n >= 96) PACOH_TRTRI_LAUNCH(512); else PACOH_TRTRI_LAUNCH(256);
 #undef PACOH_TRTRI_LAUNCH
     return 0;
@@ -645,7 +659,7 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
         if (rc) return rc;
     }
     if (bwd) {
-        int rc = launch_trtri<T>(A, info, B, n, mpad, lds, s);
+        int rc = launch_trtri<T>(A, info, B, n, mpad, lds, dense_chol_saves_inverse(n, dtype) ? 1 : 0, s);
         if (rc) return rc;
         GemmArgs ga = {A, A, Wm, (long)n * n, (long)n * n, (long)n * n, n, n, n, n, n, n, 1, 0, 1, 1, 1.0, 0.0, info, 1};
         launch_bgemm<T>(ga, B, s);                                          // W = Z^T Z
@@ -709,7 +723,7 @@ int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int m
         if (rc) return rc;
     }
     {
-        int rc = launch_trtri<T>(A, info, B, n, mpad, lds, s);
+        int rc = launch_trtri<T>(A, info, B, n, mpad, lds, dense_chol_saves_inverse(n, dtype) ? 1 : 0, s);
         if (rc) return rc;
     }
     int rc = pacoh_gram_rbf_ard(z_ctx, z_div, z_tst, zt_div, ls, os, nullptr, 0, Kxs, B, P, n, m, f, dtype, s);

@@ -30,70 +30,166 @@ template <> struct Mf<double> {
 constexpr int DNB = 32;            // panel width
 constexpr int DLP = 36;            // leading dimension of the LDS panel / inverse images
 
+// d = sqrt(piv), inv = 1 / d.  fp64: the libm sqrt followed by a division is ~60 dependent double-precision instructions on the
+// critical path of every elimination step; v_rsq_f64 (2^-26) with two Newton steps and one correction each for d and inv is 14.
+template <typename T> __device__ __forceinline__ void pivot_sqrt_inv(T piv, T& d, T& inv);
+template <> __device__ __forceinline__ void pivot_sqrt_inv<float>(float piv, float& d, float& inv) { d = sqrtf(piv); inv = 1.0f / d; }
+template <> __device__ __forceinline__ void pivot_sqrt_inv<double>(double x, double& d, double& inv) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-x * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    d = x * y;
+    d = fma(0.5 * y, fma(-d, d, x), d);
+    inv = fma(y, fma(-d, y, 1.0), y);
+}
+
+// value of v in lane `src` (compile-time constant), as a wave-uniform value
+template <typename T> __device__ __forceinline__ T bcast_lane(T v, int src);
+template <> __device__ __forceinline__ float bcast_lane<float>(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+template <> __device__ __forceinline__ double bcast_lane<double>(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// a -= lj * (lj of lane SRC): the broadcast (v_readlane into a scalar register pair) and the fma that consumes it as ONE unit.
+// (s_nop 1: gfx940+ needs two wait states between a VALU write of a scalar register and a VALU read of it; with one the fma
+// now and then sees the previous broadcast.)  Written as separate operations the compiler issues the thirty-odd broadcasts of an elimination step first and the fmas
+// after them, runs out of scalar registers and spills each value through v_writelane / v_readlane (550 spills per block).
+template <int SRC> __device__ __forceinline__ void bcast_fnma(float& a, float lj) {
+    asm volatile("v_readlane_b32 s90, %1, %2\n\ts_nop 1\n\tv_fma_f32 %0, -%1, s90, %0" : "+v"(a) : "v"(lj), "n"(SRC) : "s90");
+}
+template <int SRC> __device__ __forceinline__ void bcast_fnma(double& a, double lj) {
+    const long long b = __double_as_longlong(lj);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    asm volatile("v_readlane_b32 s90, %1, %3\n\tv_readlane_b32 s91, %2, %3\n\ts_nop 1\n\tv_fma_f64 %0, -%4, s[90:91], %0"
+                 : "+v"(a) : "v"(lo), "v"(hi), "n"(SRC), "v"(lj) : "s90", "s91");
+}
+// acc += x * (v of lane SRC)
+template <int SRC> __device__ __forceinline__ void bcast_fma(float& acc, float x, float v) {
+    asm volatile("v_readlane_b32 s90, %2, %3\n\ts_nop 1\n\tv_fma_f32 %0, %1, s90, %0" : "+v"(acc) : "v"(x), "v"(v), "n"(SRC) : "s90");
+}
+template <int SRC> __device__ __forceinline__ void bcast_fma(double& acc, double x, double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    asm volatile("v_readlane_b32 s90, %2, %4\n\tv_readlane_b32 s91, %3, %4\n\ts_nop 1\n\tv_fma_f64 %0, %1, s[90:91], %0"
+                 : "+v"(acc) : "v"(x), "v"(lo), "v"(hi), "n"(SRC) : "s90", "s91");
+}
+// two of them per block: the broadcasts of the second cover the wait states of the first
+template <int S0, int S1> __device__ __forceinline__ void bcast_fnma2(float& a0, float& a1, float lj) {
+    asm volatile("v_readlane_b32 s90, %2, %3\n\tv_readlane_b32 s91, %2, %4\n\ts_nop 0\n\tv_fma_f32 %0, -%2, s90, %0\n\tv_fma_f32 %1, -%2, s91, %1"
+                 : "+v"(a0), "+v"(a1) : "v"(lj), "n"(S0), "n"(S1) : "s90", "s91");
+}
+template <int S0, int S1> __device__ __forceinline__ void bcast_fnma2(double& a0, double& a1, double lj) {
+    const long long b = __double_as_longlong(lj);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    asm volatile("v_readlane_b32 s90, %2, %4\n\tv_readlane_b32 s91, %3, %4\n\tv_readlane_b32 s92, %2, %5\n\tv_readlane_b32 s93, %3, %5\n\t"
+                 "s_nop 0\n\tv_fma_f64 %0, -%6, s[90:91], %0\n\tv_fma_f64 %1, -%6, s[92:93], %1"
+                 : "+v"(a0), "+v"(a1) : "v"(lo), "v"(hi), "n"(S0), "n"(S1), "v"(lj) : "s90", "s91", "s92", "s93");
+}
+template <int S0, int S1> __device__ __forceinline__ void bcast_fma2(float& acc0, float& acc1, float x0, float x1, float v) {
+    asm volatile("v_readlane_b32 s90, %4, %5\n\tv_readlane_b32 s91, %4, %6\n\ts_nop 0\n\tv_fma_f32 %0, %2, s90, %0\n\tv_fma_f32 %1, %3, s91, %1"
+                 : "+v"(acc0), "+v"(acc1) : "v"(x0), "v"(x1), "v"(v), "n"(S0), "n"(S1) : "s90", "s91");
+}
+template <int S0, int S1> __device__ __forceinline__ void bcast_fma2(double& acc0, double& acc1, double x0, double x1, double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    asm volatile("v_readlane_b32 s90, %4, %6\n\tv_readlane_b32 s91, %5, %6\n\tv_readlane_b32 s92, %4, %7\n\tv_readlane_b32 s93, %5, %7\n\t"
+                 "s_nop 0\n\tv_fma_f64 %0, %2, s[90:91], %0\n\tv_fma_f64 %1, %3, s[92:93], %1"
+                 : "+v"(acc0), "+v"(acc1) : "v"(x0), "v"(x1), "v"(lo), "v"(hi), "n"(S0), "n"(S1) : "s90", "s91", "s92", "s93");
+}
+// Row rr of X = L^-1, in place over row rr of L (X L = I, columns from the right): X[rr][C] L[C][C] = delta - sum_{k>C} X[rr][k] L[k][C].
+// Column C of L is read (broadcast from the lanes k > C) for the last time in step C, which is also where X[rr][C] is born:
+// the entry takes its register.
+template <typename T, int C, int K> struct InvRow {
+    static __device__ __forceinline__ void run(const T (&a)[DNB], T& acc0, T& acc1) {
+        if constexpr (K + 1 < DNB) { bcast_fma2<K, K + 1>(acc0, acc1, a[K], a[K + 1], a[C]); InvRow<T, C, K + 2>::run(a, acc0, acc1); }
+        else { bcast_fma<K>(acc0, a[K], a[C]); }
+    }
+};
+template <typename T, int C> struct InvRow<T, C, DNB> { static __device__ __forceinline__ void run(const T (&)[DNB], T&, T&) {} };
+template <typename T, int C> struct InvSteps {
+    static __device__ __forceinline__ void run(T (&a)[DNB], const T* __restrict__ invd, int rr) {
+        T acc0 = 0, acc1 = 0;
+        InvRow<T, C, C + 1>::run(a, acc0, acc1);
+        T xc = (((rr == C) ? T(1) : T(0)) - (acc0 + acc1)) * invd[C];
+        asm volatile("s_nop 1" : "+v"(xc));          // (the next step's first broadcast reads registers written just now, see above)
+        a[C] = xc;
+        InvSteps<T, C - 1>::run(a, invd, rr);
+    }
+};
+template <typename T> struct InvSteps<T, -1> { static __device__ __forceinline__ void run(T (&)[DNB], const T*, int) {} };
+
+template <typename T, int J, int C> struct ElimRow {
+    static __device__ __forceinline__ void run(T (&a)[DNB], T lj) {
+        if constexpr (C + 1 < DNB) { bcast_fnma2<C, C + 1>(a[C], a[C + 1], lj); ElimRow<T, J, C + 2>::run(a, lj); }
+        else { bcast_fnma<C>(a[C], lj); }
+    }
+};
+template <typename T, int J> struct ElimRow<T, J, DNB> { static __device__ __forceinline__ void run(T (&)[DNB], T) {} };
+template <typename T, int J> struct ElimSteps {
+    static __device__ __forceinline__ void run(T (&a)[DNB], T* __restrict__ invd, bool& bad, int lane) {
+        T piv = bcast_lane<T>(a[J], J);
+        if (!(piv > T(0))) { bad = true; piv = 1; }
+        T d, inv;
+        pivot_sqrt_inv<T>(piv, d, inv);
+        if (lane == 0) invd[J] = inv;
+        T lj = a[J] * inv;                           // L[rr][J] (meaningful for rr > J; lane J: piv / d = d up to one rounding)
+        asm volatile("s_nop 1" : "+v"(lj));          // VALU write -> v_readlane of the same register needs a wait state the compiler
+                                                     // cannot place: the first broadcast below sits inside an asm block
+        ElimRow<T, J, J + 1>::run(a, lj);            // a[rr][c] -= L[rr][J] L[c][J], c > J
+        a[J] = lj;
+        ElimSteps<T, J + 1>::run(a, invd, bad, lane);
+    }
+};
+template <typename T> struct ElimSteps<T, DNB> { static __device__ __forceinline__ void run(T (&)[DNB], T*, bool&, int) {} };
+
 // Cholesky factor and inverse of the 32x32 diagonal block held in Ds (lower part, identity padded), by ONE wavefront.
-// Right-looking with row rr in the registers of lane rr: per step the lanes publish column j to LDS, read it back as broadcast
-// reads (all reads of a step are issued together), and apply the rank-1 update to their own row.  The left-looking form this
-// replaces waited for an LDS round trip per inner iteration (496 of them) and cost 40 us per block in fp64; this one ~4 us.
+// Lane rr keeps row rr in registers (both half-waves do the same work).  Right-looking: per step the pivot and the entries of
+// column j reach the other lanes as v_readlane broadcasts into scalar registers -- no LDS round trip inside the elimination (the
+// version this replaces published every column through LDS and waited for it 32 times: 27 us per block in fp64 with fifteen waves
+// idle, a third of the whole factorisation at n = 512).  The inverse X = L11^-1 is then built column per lane, X kept in
+// registers, L11 entries as LDS broadcast reads.
 // On return Ds holds L11 (lower), invd[j] = 1 / L11[j][j], Li = L11^-1 (row major, zeros above the diagonal).
 template <typename T>
-__device__ __forceinline__ void factor_invert_diag32(T (*Ds)[DNB + 1], T* __restrict__ Li, T* __restrict__ colb /*[64]*/,
+__device__ __forceinline__ void factor_invert_diag32(T (*Ds)[DNB + 1], T* __restrict__ Li, T* __restrict__ colb /*unused*/,
                                                      T* __restrict__ invd /*[32]*/, T* __restrict__ fail, int lane) {
+    int rr = lane & 31;
+    asm volatile("" : "+v"(rr));                     // (opaque: or the compiler lifts every lane mask below out of the panel loop
+                                                     //  of the caller and spills hundreds of scalar registers to keep them)
+    T a[DNB];
+#pragma unroll
+    for (int c = 0; c < DNB; ++c) a[c] = Ds[rr][c];
+    bool bad = false;
 #ifdef PACOH_FACT_DEBUG
-    long long tf0 = wall_clock64();
+    const long long tf0 = wall_clock64();
 #endif
-    const int rr = lane & 31, h = lane >> 5;         // lane = (row rr, column half h): 16 columns of the row in registers
-    const bool wr = lane < 32;
-    T a[16];
+    ElimSteps<T, 0>::run(a, invd, bad, lane);
+#ifdef PACOH_FACT_DEBUG
+    const long long tf1 = wall_clock64();
+#endif
+    if (bad && lane == 0) *fail = 1;
+    if (lane < 32) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = Ds[rr][16 * h + c];
-#pragma unroll
-    for (int j = 0; j < DNB; ++j) {
-        const int jh = j >> 4, jl = j & 15;
-        T* cb = colb + (j & 1) * DNB;
-        if (h == jh) cb[rr] = a[jl];
-        __builtin_amdgcn_wave_barrier();             // LDS ops of one wave execute in order; only the compiler must keep it
-        // one batch of reads per step (pivot, own entry, the 16 entries of this lane's column half), issued together
-        T piv = cb[j];
-        const T own = cb[rr];
-        T cv[16];
-#pragma unroll
-        for (int cl = 0; cl < 16; ++cl) cv[cl] = cb[16 * h + cl];
-        if (!(piv > T(0))) { if (lane == 0) *fail = 1; piv = 1; }
-        const T d = t_sqrt<T>(piv);
-        const T inv = T(1) / d;
-        if (lane == 0) invd[j] = inv;
-        const T lown = own * inv;                    // L[rr][j] (meaningful for rr > j)
-        const T nl2 = -lown * inv;
-#pragma unroll
-        for (int cl = 0; cl < 16; ++cl) {
-            const T upd = fma(nl2, cv[cl], a[cl]);   // a[rr][c] -= L[rr][j] L[c][j]
-            a[cl] = (16 * h + cl > j) ? upd : a[cl];
-        }
-        if (h == jh) a[jl] = (rr == j) ? d : lown;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_sched_barrier(0);           // keep the 32 unrolled steps from being interleaved (register pressure)
+        for (int c = 0; c < DNB; ++c) Ds[rr][c] = a[c];          // (above the diagonal: leftovers nobody reads)
     }
-#pragma unroll
-    for (int c = 0; c < 16; ++c) if (16 * h + c <= rr) Ds[rr][16 * h + c] = a[c];
     __builtin_amdgcn_wave_barrier();
-#ifdef PACOH_FACT_DEBUG
-    long long tf1 = wall_clock64();
-#endif
-    // inverse: lane rr owns column rr of X = L11^-1 and keeps it in LDS (Li[i][rr]: lane-private words, conflict-free);
-    // L entries and 1/diag come as broadcast reads.  Deliberately NOT fully unrolled: with everything unrolled the compiler
-    // hoists all 496 broadcast loads to the top and spills ~1000 registers.
-    if (wr) {
-#pragma unroll 1
-        for (int i = 0; i < DNB; ++i) {
-            T sacc = (i == rr) ? T(1) : T(0);
-#pragma unroll 8
-            for (int j = 0; j < i; ++j) sacc = fma(-Ds[i][j], Li[j * DLP + rr], sacc);
-            Li[i * DLP + rr] = (i < rr) ? T(0) : sacc * invd[i];
-        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // inverse, row rr per lane, in the registers that held row rr of L (InvSteps above)
+    InvSteps<T, DNB - 1>::run(a, invd, rr);
+    if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < DNB; ++c) Li[rr * DLP + c] = a[c];          // (zeros above the diagonal: sums of 0 x finite)
     }
 #ifdef PACOH_FACT_DEBUG
     if (lane == 0) { g_tdbg[0] = tf1 - tf0; g_tdbg[1] = wall_clock64() - tf1; }
 #endif
+    __builtin_amdgcn_wave_barrier();
 }
 
 template <typename T, int NT>
@@ -118,6 +214,13 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
     for (int q = tid; q < n; q += NT) rv[q] = resid[(size_t)blockIdx.x * n + q];
     T logdet_part = 0;
     __syncthreads();
+#ifdef PACOH_CHOL_STAMPS      // diagnostic build: python -m meta_learning_pacoh_amd._build --variant cst -DPACOH_CHOL_STAMPS=1 (tools/dense_quick.sh)
+    long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tp_ = wall_clock64();
+#define CSTAMP(k) do { __syncthreads(); const long long t_ = wall_clock64(); ph_[k] += t_ - tp_; tp_ = t_; } while (0)
+#else
+#define CSTAMP(k) do {} while (0)
+#endif
 
     for (int k0 = 0; k0 < n; k0 += DNB) {
         const int kb = (n - k0 < DNB) ? (n - k0) : DNB;
@@ -130,12 +233,14 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
             Ds[rr][c] = v;
         }
         __syncthreads();
+        CSTAMP(0);
         // 2. wave 0: factor and invert the diagonal block
         if (tid < 64) {
             factor_invert_diag32<T>(Ds, Li, red + 32, red + 96, red + 16, tid);
             if (tid < kb) logdet_part += t_log<T>(Ds[tid][tid]);
         }
         __syncthreads();
+        CSTAMP(1);
         // L11 -> lower triangle; the strictly-lower part of L11^-1 is kept, transposed, in the (otherwise unused) strictly
         // upper part of the diagonal block: the backward solve reads it from there (its diagonal is 1 / L11's diagonal)
         for (int q = tid; q < DNB * DNB; q += NT) {
@@ -160,6 +265,7 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
                 Pn[(size_t)rr * DLP + c] = (rr < m && c < kb) ? Ab[(size_t)(t0 + rr) * n + k0 + c] : T(0);
             }
             __syncthreads();
+            CSTAMP(2);
             if (tid < kb) rv[k0 + tid] = u_reg;
             // 4. L21 = A21 * L11^-T on the matrix core, in place in LDS and written back to HBM
             for (int ib = wave; ib < mb; ib += NW) {
@@ -182,12 +288,14 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
                 }
             }
             __syncthreads();
+            CSTAMP(3);
             for (int rr = tid; rr < m; rr += NT) {                          // r_rest -= L21 u_k (L21 rows from the LDS panel)
                 T sacc = rv[t0 + rr];
 #pragma unroll 8
                 for (int c = 0; c < DNB; ++c) sacc = fma(-Pn[(size_t)rr * DLP + c], (c < kb) ? rv[k0 + c] : T(0), sacc);
                 rv[t0 + rr] = sacc;
             }
+            CSTAMP(4);
             // 5. trailing update A22 -= L21 L21^T: the lower 16x16 blocks are dealt to the waves, two per step so that the
             //    L2/HBM round trip of one block's accumulator overlaps the other's MFMAs
             const int total = mb * (mb + 1) / 2;
@@ -237,7 +345,14 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
             }
         }
         __syncthreads();
+        CSTAMP(5);
     }
+#ifdef PACOH_CHOL_STAMPS
+    if (tid == 0 && blockIdx.x == 0)
+        printf("chol phases (us): load diag %.1f | factor+invert %.1f | write L11, stage panel %.1f | panel solve %.1f | resid %.1f | trailing %.1f\n",
+               ph_[0] * 0.01, ph_[1] * 0.01, ph_[2] * 0.01, ph_[3] * 0.01, ph_[4] * 0.01, ph_[5] * 0.01);
+#endif
+#undef CSTAMP
 
     // (the forward solve L u = r happened panel by panel above: rv holds u)
     T quad_part = 0;
@@ -305,6 +420,12 @@ static int launch_dense_mfma(void* A, const void* resid, void* logp, void* alpha
     if (n >= 256) PACOH_CHOL_LAUNCH(1024); else if (n >= 96) PACOH_CHOL_LAUNCH(512); else PACOH_CHOL_LAUNCH(256);
 #undef PACOH_CHOL_LAUNCH
     return launch_status();
+}
+
+bool dense_mfma_fits(int n, int dtype) {
+    const int mpad = n > DNB ? (n - DNB + 15) / 16 * 16 : 16;
+    const size_t elems = (size_t)DNB * (DNB + 1) + (size_t)DNB * DLP + (size_t)mpad * DLP + 128 + n;
+    return elems * (dtype == PACOH_F32 ? 4 : 8) <= 160u * 1024u;
 }
 
 int dense_mfma_try(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
