@@ -260,7 +260,8 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
         if (m > 0) {
             // 3. stage the panel A21 (m x kb, zero padded to 16-row blocks x 32 columns)
             const int mb = (m + 15) / 16;
-            for (int q = tid; q < mb * 16 * DNB; q += NT) {
+#pragma unroll 4
+            for (int q = tid; q < mb * 16 * DNB; q += NT) {                 // (unrolled: four loads per thread in flight)
                 const int rr = q / DNB, c = q - rr * DNB;
                 Pn[(size_t)rr * DLP + c] = (rr < m && c < kb) ? Ab[(size_t)(t0 + rr) * n + k0 + c] : T(0);
             }
@@ -370,6 +371,9 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
     T logdet = 0;
     for (int w = 0; w < NW; ++w) logdet += red[w];
     const bool ok = red[16] == T(0);
+#ifdef PACOH_CHOL_STAMPS
+    long long tq_ = wall_clock64();
+#endif
     if (tid == 0) {
         const T LOG2PI = T(1.8378770664093453);
         const T lp = T(-0.5) * (quad + T(2) * logdet + T(n) * LOG2PI) * scale;
@@ -384,22 +388,37 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
         const int k0 = kbk * DNB;
         const int kb = (n - k0 < DNB) ? (n - k0) : DNB;
         __syncthreads();
+        // the diagonal block (L11's diagonal, Z11^T above it) through LDS: read from global memory inside the dot product below,
+        // every one of its up to 31 steps waited for an L2 round trip (18 us per panel, 0.3 ms of the n = 512 factorisation)
+        for (int q = tid; q < DNB * DNB; q += NT) {
+            const int rr = q / DNB, c = q - rr * DNB;
+            Ds[rr][c] = (rr < kb && c < kb) ? Ab[(size_t)(k0 + rr) * n + k0 + c] : T(0);
+        }
+        __syncthreads();
         T a_reg = 0;
         if (tid < kb) {
-            const T* zrow = Ab + (size_t)(k0 + tid) * n + k0;           // [tid] = L diag, [c > tid] = Z11[c][tid]
-            a_reg = rv[k0 + tid] / zrow[tid];
-            for (int c = tid + 1; c < kb; ++c) a_reg = fma(zrow[c], rv[k0 + c], a_reg);
+            a_reg = rv[k0 + tid] / Ds[tid][tid];                        // [tid][tid] = L diag, [tid][c > tid] = Z11[c][tid]
+#pragma unroll 8
+            for (int c = tid + 1; c < kb; ++c) a_reg = fma(Ds[tid][c], rv[k0 + c], a_reg);
         }
         __syncthreads();
         if (tid < kb) rv[k0 + tid] = a_reg;
         __syncthreads();
         for (int i = tid; i < k0; i += NT) {
             T sacc = rv[i];
-            for (int c = 0; c < kb; ++c) sacc = fma(-Ab[(size_t)(k0 + c) * n + i], rv[k0 + c], sacc);
+            if (kb == DNB) {
+#pragma unroll
+                for (int c = 0; c < DNB; ++c) sacc = fma(-Ab[(size_t)(k0 + c) * n + i], rv[k0 + c], sacc);   // (32 independent loads in flight)
+            } else {
+                for (int c = 0; c < kb; ++c) sacc = fma(-Ab[(size_t)(k0 + c) * n + i], rv[k0 + c], sacc);
+            }
             rv[i] = sacc;
         }
     }
     __syncthreads();
+#ifdef PACOH_CHOL_STAMPS
+    if (tid == 0 && blockIdx.x == 0) printf("chol backward solve (us): %.1f\n", (wall_clock64() - tq_) * 0.01);
+#endif
     for (int q = tid; q < n; q += NT) alpha_out[(size_t)blockIdx.x * n + q] = ok ? rv[q] : T(NAN);
 }
 
