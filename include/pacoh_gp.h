@@ -51,6 +51,7 @@ extern "C" {
 #define PACOH_MAX_FEATURES 16  /* f (kernel input dim) <= 16                                     */
 #define PACOH_MLP_MAX_HIDDEN_LAYERS 63   /* per-particle MLP: any layer_sizes up to this depth ...          */
 #define PACOH_MLP_MAX_WIDTH 65536        /* ... and this width (the reference has no limit: models.py:328-349) */
+#define PACOH_SVGD_MAX_PARTICLES 1024    /* RBF-SVGD entry points (the reference has no limit; its sweeps use 10 / 50); IMQ: 64 */
 
 /* info[b] values written by the GP kernels (LAPACK-style): 0 = clean Cholesky; 1..3 = succeeded
  * after adding diagonal jitter base*10^(k-1), base = 1e-6 (f32) / 1e-8 (f64) -- the retry ladder of
@@ -226,7 +227,8 @@ int pacoh_prior_logprob_grad(const void* theta, const void* prior_mean, const vo
  * k_ij = exp(-gamma |X_i - X_j|^2), gamma = 1/(1e-8 + 2 bw^2); bandwidth <= 0 selects the median
  * heuristic bw = sqrt(median(|X_i-X_j|^2 over the full PxP matrix incl. the zero diagonal) /
  * (2 ln(P+1))), numpy-median semantics.  Replaces SVGD.phi + RBF_Kernel (meta_learn/svgd.py:12-59).
- * P <= 64.  workspace: pacoh_svgd_workspace_bytes().  neg != 0 writes -phi (the "gradient" handed to
+ * P <= PACOH_SVGD_MAX_PARTICLES (up to 64 particles the median is a register sort inside the consuming kernel, beyond that one
+ * extra launch finds it by bisection).  workspace: pacoh_svgd_workspace_bytes().  neg != 0 writes -phi (the "gradient" handed to
  * the optimizer, svgd.py:27).  bw_out (optional, 1 value): the bandwidth used. */
 size_t pacoh_svgd_workspace_bytes(int P, int D, int dtype);
 int pacoh_svgd_phi(const void* X, const void* score, double bandwidth, int neg, void* phi,

@@ -1,5 +1,5 @@
 // Small kernels around the GP core: parameter transforms (A3), hyper-prior (A7), SVGD update
-// direction (A9), fused Adam/AdamW step (A8-A10).  All are launch-latency sized (P <= 64 particles,
+// direction (A9), fused Adam/AdamW step (A8-A10).  All are launch-latency sized (tens of particles,
 // D ~ 10^3 parameters); they exist so that a whole meta-training step stays on the device and can be
 // captured into one hipGraph.
 #include "common.h"
@@ -206,11 +206,49 @@ __device__ __forceinline__ T wave_median_full_matrix(const T* __restrict__ d2, i
     return (mids[0] + mids[1]) * T(0.5);
 }
 
+// More than 64 particles (the register sort above holds 2048 pair values): the two middle order statistics of the full matrix by
+// bisection on the IEEE bit pattern (monotone for values >= 0), one 1024-thread workgroup per statistic: per round every thread
+// counts its share of the pairs below the candidate straight from d2 (L2-resident), 31 / 63 rounds.  mids[h] receives entry
+// (N-1)/2 resp. N/2 of the sorted P x P matrix; the consumers average them.  No limit on P from this kernel.
+template <typename T> struct MedBits;
+template <> struct MedBits<float> { using U = uint32_t; static constexpr int NB = 32;
+    static __device__ __forceinline__ U to(float v) { return __float_as_uint(v); } static __device__ __forceinline__ float from(U u) { return __uint_as_float(u); } };
+template <> struct MedBits<double> { using U = uint64_t; static constexpr int NB = 64;
+    static __device__ __forceinline__ U to(double v) { return (U)__double_as_longlong(v); } static __device__ __forceinline__ double from(U u) { return __longlong_as_double((long long)u); } };
+template <typename T>
+__global__ void __launch_bounds__(1024) svgd_median_large_kernel(const T* __restrict__ d2, int P, T* __restrict__ mids) {
+    using U = typename MedBits<T>::U;
+    __shared__ int part[16];
+    __shared__ int total_s;
+    const long N = (long)P * P;
+    const long m = blockIdx.x == 0 ? (N - 1) / 2 : N / 2;
+    if (m < P) { if (threadIdx.x == 0) mids[blockIdx.x] = T(0); return; }        // (P zeros lead the sorted matrix)
+    const int k = (int)((m - P) >> 1);               // index into the sorted list of the P(P-1)/2 pair values
+    U result = 0;
+    for (int bit = MedBits<T>::NB - 2; bit >= 0; --bit) {
+        const U cand = result | (U(1) << bit);
+        int cnt = 0;
+        for (long q = threadIdx.x; q < N; q += 1024) {
+            const int i = (int)(q / P), j = (int)(q - (long)i * P);
+            if (i < j) cnt += MedBits<T>::to(d2[q]) < cand ? 1 : 0;
+        }
+#pragma unroll
+        for (int w = 1; w < 64; w <<= 1) cnt += __shfl_xor(cnt, w, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += part[w]; total_s = t; }
+        __syncthreads();
+        if (total_s <= k) result = cand;             // (uniform: every thread reads the same total)
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mids[blockIdx.x] = MedBits<T>::from(result);
+}
+
 // stage 2: bandwidth (median heuristic), kernel matrix and its row sums.  One workgroup; wave 0 finds the median.
 template <typename T>
 __global__ void __launch_bounds__(256) svgd_kmat_kernel(const T* __restrict__ d2, T bandwidth, T* __restrict__ Kmat,
                                                         T* __restrict__ rowsum, T* __restrict__ gamma_out,
-                                                        T* __restrict__ bw_out, int P) {
+                                                        T* __restrict__ bw_out, int P, const T* __restrict__ mids = nullptr) {
     __shared__ T gam_s;
     const int N = P * P;
     T bw = bandwidth;
@@ -219,7 +257,8 @@ __global__ void __launch_bounds__(256) svgd_kmat_kernel(const T* __restrict__ d2
             const int lane = threadIdx.x;
             const int npairs = P * (P - 1) / 2;
             T med;
-            if (npairs <= 256) med = wave_median_full_matrix<T, 4>(d2, P, lane);
+            if (mids) med = (mids[0] + mids[1]) * T(0.5);                    // P > 64: svgd_median_large_kernel ran in front
+            else if (npairs <= 256) med = wave_median_full_matrix<T, 4>(d2, P, lane);
             else if (npairs <= 512) med = wave_median_full_matrix<T, 8>(d2, P, lane);
             else if (npairs <= 1024) med = wave_median_full_matrix<T, 16>(d2, P, lane);
             else med = wave_median_full_matrix<T, 32>(d2, P, lane);
@@ -277,10 +316,10 @@ __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ 
                                                           int use_adam, T lr, T one_minus_b1, T b2,
                                                           T one_minus_b2, T step_size, T bc2_sqrt, T eps,
                                                           T* __restrict__ m, T* __restrict__ v, T* __restrict__ X_out, int P, int D,
-                                                          const T* __restrict__ sc = nullptr) {
+                                                          const T* __restrict__ sc = nullptr, const T* __restrict__ mids = nullptr) {
     T score_scale = T(1);
     if (sc) { score_scale = sc[0]; lr = sc[1]; step_size = sc[5]; bc2_sqrt = sc[6]; eps = sc[7]; }     // PACOH_SC_* (pacoh_gp.h)
-    __shared__ T Ki[64];
+    __shared__ T Ki[PACOH_SVGD_MAX_PARTICLES];
     __shared__ T gam_s, rowsum_s;
     const int i = blockIdx.y;
     if (threadIdx.x < 64) {
@@ -289,16 +328,17 @@ __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ 
         if (!(bandwidth > T(0))) {
             const int npairs = P * (P - 1) / 2;
             T med;
-            if (npairs <= 256) med = wave_median_full_matrix<T, 4>(d2, P, lane);
+            if (mids) med = (mids[0] + mids[1]) * T(0.5);                    // P > 64: svgd_median_large_kernel ran in front
+            else if (npairs <= 256) med = wave_median_full_matrix<T, 4>(d2, P, lane);
             else if (npairs <= 512) med = wave_median_full_matrix<T, 8>(d2, P, lane);
             else if (npairs <= 1024) med = wave_median_full_matrix<T, 16>(d2, P, lane);
             else med = wave_median_full_matrix<T, 32>(d2, P, lane);
             bw = t_sqrt<T>(med / (T(2) * t_log<T>(T(P + 1))));
         }
         const T gam = T(1) / (T(1e-8) + T(2) * bw * bw);
-        const T kv = lane < P ? t_exp<T>(-gam * d2[i * P + lane]) : T(0);
-        Ki[lane] = kv;
-        const T rs = subwave_sum<T>(kv, 64);
+        T ksum = 0;
+        for (int j = lane; j < P; j += 64) { const T kv = t_exp<T>(-gam * d2[i * P + j]); Ki[j] = kv; ksum += kv; }
+        const T rs = subwave_sum<T>(ksum, 64);
         if (lane == 0) { gam_s = gam; rowsum_s = rs; if (bw_out && blockIdx.x == 0 && i == 0) *bw_out = bw; }
     }
     __syncthreads();
@@ -650,7 +690,7 @@ extern "C" size_t pacoh_svgd_workspace_bytes(int P, int D, int dtype) {
 
 extern "C" size_t pacoh_svgd_update_dev_workspace_bytes(int P, int D, int dtype) {
     if (P <= 0 || D <= 0) return 0;
-    return (size_t)(P * P + (long)P * D) * (dtype == PACOH_F64 ? 8 : 4);          // distances + snapshot of the particles
+    return (size_t)(P * P + (long)P * D + 2) * (dtype == PACOH_F64 ? 8 : 4);      // distances + snapshot of the particles + median pair
 }
 
 template <typename T>
@@ -659,10 +699,16 @@ static int svgd_update_dev_launch(void* X, const void* score, const void* mu, co
                                   void* workspace, int P, int D, hipStream_t s) {
     T* d2 = (T*)workspace;
     T* snap = d2 + P * P;
+    T* mids = nullptr;
     hipLaunchKernelGGL(svgd_dist_kernel<T>, dim3(P * P), dim3(256), 0, s, (const T*)X, d2, P, D, snap);
+    if (P > 64 && !(bandwidth > 0.0)) {
+        mids = snap + (long)P * D;
+        hipLaunchKernelGGL(svgd_median_large_kernel<T>, dim3(2), dim3(1024), 0, s, (const T*)d2, P, mids);
+    }
     hipLaunchKernelGGL(svgd_update_kernel<T>, dim3((D + 255) / 256, P), dim3(256), 0, s, (const T*)snap, (const T*)score, (const T*)mu,
                        (const T*)sd, (T)prior_factor, (const T*)d2, (T)bandwidth, (T*)bw_out, use_adam, T(0),
-                       (T)(1.0 - beta1), (T)beta2, (T)(1.0 - beta2), T(0), T(1), T(0), (T*)m, (T*)v, (T*)X, P, D, (const T*)scalars);
+                       (T)(1.0 - beta1), (T)beta2, (T)(1.0 - beta2), T(0), T(1), T(0), (T*)m, (T*)v, (T*)X, P, D, (const T*)scalars,
+                       (const T*)mids);
     return launch_status();
 }
 
@@ -674,7 +720,7 @@ extern "C" int pacoh_svgd_update_dev(void* X, const void* score, const void* pri
     if (!X || !score || !scalars || !workspace || P <= 0 || D <= 0) return PACOH_EINVAL;
     if ((prior_mean == nullptr) != (prior_std == nullptr)) return PACOH_EINVAL;
     if (use_adam && (!exp_avg || !exp_avg_sq)) return PACOH_EINVAL;
-    if (P > 64) return PACOH_ELIMIT;
+    if (P > PACOH_SVGD_MAX_PARTICLES) return PACOH_ELIMIT;
     if (dtype == PACOH_F32)
         return svgd_update_dev_launch<float>(X, score, prior_mean, prior_std, prior_factor, bandwidth, use_adam, scalars, beta1, beta2,
                                              exp_avg, exp_avg_sq, bw_out, workspace, P, D, (hipStream_t)stream);
@@ -689,9 +735,14 @@ static int svgd_launch(const void* X, const void* score, double bandwidth, int n
     T* Kmat = d2 + P * P;
     T* rowsum = Kmat + P * P;
     T* gamma = rowsum + P;
+    T* mids = nullptr;                                // (the workspace has 8 spare elements behind rowsum: [0] gamma, [2..3] median pair)
     hipLaunchKernelGGL(svgd_dist_kernel<T>, dim3(P * P), dim3(256), 0, s, (const T*)X, d2, P, D);
+    if (P > 64 && !(bandwidth > 0.0)) {
+        mids = gamma + 2;
+        hipLaunchKernelGGL(svgd_median_large_kernel<T>, dim3(2), dim3(1024), 0, s, (const T*)d2, P, mids);
+    }
     hipLaunchKernelGGL(svgd_kmat_kernel<T>, dim3(1), dim3(256), 0, s, (const T*)d2, (T)bandwidth, Kmat,
-                       rowsum, gamma, (T*)bw_out, P);
+                       rowsum, gamma, (T*)bw_out, P, (const T*)mids);
     hipLaunchKernelGGL(svgd_phi_kernel<T>, dim3((D + 255) / 256, P), dim3(256), 0, s,
                        (const T*)X, (const T*)score, (const T*)Kmat, (const T*)rowsum, (const T*)gamma, neg, (T*)phi, P, D);
     return launch_status();
@@ -701,7 +752,7 @@ extern "C" int pacoh_svgd_phi(const void* X, const void* score, double bandwidth
                               void* bw_out, void* workspace, int P, int D, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!X || !score || !phi || !workspace || P <= 0 || D <= 0) return PACOH_EINVAL;
-    if (P > 64) return PACOH_ELIMIT;
+    if (P > PACOH_SVGD_MAX_PARTICLES) return PACOH_ELIMIT;
     if (dtype == PACOH_F32) return svgd_launch<float>(X, score, bandwidth, neg, phi, bw_out, workspace, P, D, (hipStream_t)stream);
     return svgd_launch<double>(X, score, bandwidth, neg, phi, bw_out, workspace, P, D, (hipStream_t)stream);
 }
@@ -711,11 +762,17 @@ static int svgd_update_launch(const void* X, const void* score, const void* mu, 
                               int use_adam, double lr, double beta1, double beta2, double eps, long step, void* m, void* v,
                               void* X_out, void* bw_out, void* workspace, int P, int D, hipStream_t s) {
     T* d2 = (T*)workspace;
+    T* mids = nullptr;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(svgd_dist_kernel<T>, dim3(P * P), dim3(256), 0, s, (const T*)X, d2, P, D);
+    if (P > 64 && !(bandwidth > 0.0)) {
+        mids = d2 + 2 * P * P + P + 2;                // (pacoh_svgd_workspace_bytes: same slots as in pacoh_svgd_phi)
+        hipLaunchKernelGGL(svgd_median_large_kernel<T>, dim3(2), dim3(1024), 0, s, (const T*)d2, P, mids);
+    }
     hipLaunchKernelGGL(svgd_update_kernel<T>, dim3((D + 255) / 256, P), dim3(256), 0, s, (const T*)X, (const T*)score, (const T*)mu,
                        (const T*)sd, (T)prior_factor, (const T*)d2, (T)bandwidth, (T*)bw_out, use_adam, (T)lr,
-                       (T)(1.0 - beta1), (T)beta2, (T)(1.0 - beta2), (T)(lr / bc1), (T)sqrt(bc2), (T)eps, (T*)m, (T*)v, (T*)X_out, P, D);
+                       (T)(1.0 - beta1), (T)beta2, (T)(1.0 - beta2), (T)(lr / bc1), (T)sqrt(bc2), (T)eps, (T*)m, (T*)v, (T*)X_out, P, D,
+                       (const T*)nullptr, (const T*)mids);
     return launch_status();
 }
 
@@ -727,7 +784,7 @@ extern "C" int pacoh_svgd_update(const void* X, const void* score, const void* p
     if (!X || !score || !X_out || X_out == X || !workspace || P <= 0 || D <= 0) return PACOH_EINVAL;
     if ((prior_mean == nullptr) != (prior_std == nullptr)) return PACOH_EINVAL;
     if (use_adam && (!exp_avg || !exp_avg_sq || step <= 0)) return PACOH_EINVAL;
-    if (P > 64) return PACOH_ELIMIT;
+    if (P > PACOH_SVGD_MAX_PARTICLES) return PACOH_ELIMIT;
     if (dtype == PACOH_F32)
         return svgd_update_launch<float>(X, score, prior_mean, prior_std, prior_factor, bandwidth, use_adam, lr, beta1, beta2, eps, step,
                                          exp_avg, exp_avg_sq, X_out, bw_out, workspace, P, D, (hipStream_t)stream);

@@ -59,7 +59,7 @@ def test_argument_validation_returns_error_codes_without_launching(lib):
     assert lib.pacoh_gram_rbf_ard(fake, 1, fake, 1, fake, null, null, 0, fake, 1, 1, 8, 8, 17, 0, null) == ELIMIT
     assert lib.pacoh_gp_lml_fwdbwd(fake, 1, null, 0, fake, 1, fake, null, fake, null, null, fake, null, null, fake,
                                    null, fake, null, 2, 1, 4096, 2, 0, null) == ELIMIT       # n too large for LDS
-    assert lib.pacoh_svgd_phi(fake, fake, 0.0, 0, fake, null, fake, 65, 10, 0, null) == ELIMIT
+    assert lib.pacoh_svgd_phi(fake, fake, 0.0, 0, fake, null, fake, 1025, 10, 0, null) == ELIMIT      # PACOH_SVGD_MAX_PARTICLES
     assert lib.pacoh_adam_step(null, null, null, null, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 10, 0, null) == EINVAL
     hidden = (ctypes.c_int32 * 1)(1 << 20)
     assert lib.pacoh_mlp_fwd(fake, 1, fake, 10, 1, 2, hidden, 1, 1, fake, null, 1, 4, 0, null) == ELIMIT   # width > PACOH_MLP_MAX_WIDTH

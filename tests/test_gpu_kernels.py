@@ -646,6 +646,33 @@ def test_svgd_update_fused(L, dtype, optimizer, bandwidth, with_prior):
     assert relerr(Xd, Xo.detach()) < tol
 
 
+@pytest.mark.parametrize('P', [65, 100, 200])
+def test_svgd_many_particles(L, P):
+    """more than 64 particles: the median comes from the bisection kernel instead of the register sort -- phi and the fused update
+    against the oracle (numpy.median of the full P x P matrix), odd and even P, fp32 and fp64"""
+    g = torch.Generator().manual_seed(P)
+    D, pf, lr = 77, 0.3, 1e-2
+    X = torch.randn(P, D, generator=g, dtype=torch.float64)
+    score = torch.randn(P, D, generator=g, dtype=torch.float64)
+    mu, sd = torch.randn(D, generator=g, dtype=torch.float64), torch.rand(D, generator=g, dtype=torch.float64) + 0.5
+    phi_o, bw_o = O.svgd_phi_closed_form(X, score, None)
+    for dtype, tol in ((torch.float64, 1e-10), (torch.float32, 2e-4)):
+        phi, bw, _ = L.svgd_phi(X.to(dtype).to(DEV), score.to(dtype).to(DEV), None)
+        assert abs(float(bw) - float(bw_o)) < (1e-12 if dtype == torch.float64 else 1e-5) * float(bw_o)
+        assert relerr(phi, phi_o) < tol
+        # fused step (prior score + phi + SGD), host scalars and device scalars
+        s_tot = score + pf * (-(X - mu) / sd ** 2)
+        phi_p, _ = O.svgd_phi_closed_form(X, s_tot, None)
+        args = [t.to(dtype).to(DEV) for t in (X, score, mu, sd)]
+        m, v = torch.zeros(P, D, dtype=dtype, device=DEV), torch.zeros(P, D, dtype=dtype, device=DEV)
+        Xn, bw2, _ = L.svgd_update(args[0], args[1], args[2], args[3], pf, None, 'SGD', lr, 1, m, v)
+        assert relerr(Xn, X + lr * phi_p) < tol and abs(float(bw2) - float(bw_o)) < 1e-5 * float(bw_o)
+        Xd = args[0].clone()
+        sc = torch.tensor(L.step_scalars(1.0, lr, 1), dtype=dtype, device=DEV)
+        L.svgd_update_dev(Xd, args[1], args[2], args[3], pf, None, 'SGD', sc, m, v)
+        assert relerr(Xd, X + lr * phi_p) < tol
+
+
 # ------------------------------------------------------------------------------------------ predictive cdf / quantiles / calibration
 def test_mixture_cdf_icdf_calib_match_reference_fixture(L, golden_dir):
     """pacoh_mixture_cdf / _icdf / pacoh_calib_error vs EqualWeightedMixtureDist.cdf / .icdf, AffineTransformedDistribution and

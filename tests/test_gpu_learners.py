@@ -684,3 +684,26 @@ def test_module_objects_run_like_their_string_options(M):
     assert torch.allclose(c.theta[0, lay.slices['lengthscale_raw'][0]:lay.slices['lengthscale_raw'][1]].cpu(), torch.full((2,), 0.5))
     with pytest.raises(NotImplementedError):
         M.GPRegressionMetaLearned(tasks, mean_module='constant', covar_module=CosineKernel())
+
+
+def test_svgd_with_more_than_64_particles(M, monkeypatch):
+    """80 particles (the reference has no limit): graph replay == eager launches, bandwidth == numpy.median heuristic on the final
+    particles' predecessor, finite predictions"""
+    tasks = O.sinusoid_tasks_nd(6, 12, 1, seed0=50)
+    runs = []
+    for no_graph in ('0', '1'):
+        monkeypatch.setenv('PACOH_NO_GRAPH', no_graph)
+        monkeypatch.setenv('PACOH_GRAPH', '1')
+        m = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=80, task_batch_size=3, lr=1e-2, mean_nn_layers=(8, 8),
+                                          kernel_nn_layers=(8, 8), random_seed=5)
+        before = m.particles.clone()
+        m.meta_fit(verbose=False, n_iter=1)
+        _, bw_o = O.svgd_phi_closed_form(before.cpu().double(), torch.zeros_like(before).cpu().double(), None)
+        assert abs(float(m.last_bandwidth) - float(bw_o)) < 1e-5 * float(bw_o)
+        m.meta_fit(verbose=False, n_iter=11, log_period=4)
+        runs.append(m.particles.clone())
+        mean, std = m.predict(*tasks[0], tasks[1][0])
+        assert np.isfinite(mean).all() and (std > 0).all()
+    assert torch.equal(runs[0], runs[1])
+    with pytest.raises(AssertionError):
+        M.GPRegressionMetaLearnedSVGD(tasks, num_particles=80, kernel='IMQ', random_seed=5)
