@@ -270,18 +270,23 @@ int pacoh_step_select(const int64_t* idx_all, int tb, const void* sc_all, int n_
 int pacoh_scale_dev(void* buf, const void* scalar, long count, int dtype, void* stream);
 /* pacoh_step_begin: the first launch of a captured step -- pacoh_step_select (without the index copy), pacoh_gather_tasks on
  * idx_all[row, :] (tb tasks; x[T,n,d], y[T,n], optional n_valid) and, when theta is given, pacoh_hyper_fwd, all in ONE launch;
- * a one-thread launch behind it advances *counter (`ticket`: reserved, one int32 of device memory).
- * Four launches (~4.5 us each, more than the kernels need) become two. */
+ * advance != 0: a one-thread launch behind it advances *counter; advance == 0: the caller hands `counter` to the step's LAST
+ * launch instead (pacoh_svgd_update_dev / pacoh_adam_step_dev, step_counter), which advances it -- nothing in between reads it.
+ * svgd_X (optional, [svgd_P, svgd_D]): the step's particles; their squared-distance matrix and the snapshot the in-place update
+ * reads are then produced by extra workgroups of this launch into svgd_workspace (pacoh_svgd_update_dev_workspace_bytes), and
+ * pacoh_svgd_update_dev is called with dist_done = 1.  (`ticket`: reserved, one int32 of device memory.)
+ * Every launch of a step costs ~4.5 us between dependent kernels, more than these kernels need: six launches become one. */
 int pacoh_step_begin(const int64_t* idx_all, int tb, const void* sc_all, int n_sc, const void* aux_all, long n_aux,
                      int64_t* counter, int32_t* ticket, void* sc_out, void* aux_out,
                      const void* x, const void* y, const int32_t* n_valid, void* out_x, void* out_y, int32_t* out_n_valid, int n, int d,
                      const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise, double noise_floor,
-                     void* ls, void* os, void* noise, int dtype, void* stream);
+                     void* ls, void* os, void* noise, int advance, const void* svgd_X, void* svgd_workspace, int svgd_P, int svgd_D,
+                     int dtype, void* stream);
 size_t pacoh_svgd_update_dev_workspace_bytes(int P, int D, int dtype);
 int pacoh_svgd_update_dev(void* X, const void* score, const void* prior_mean, const void* prior_std,
                           double prior_factor, double bandwidth, int use_adam, const void* scalars, double beta1,
                           double beta2, void* exp_avg, void* exp_avg_sq, void* bw_out, void* workspace, int P, int D,
-                          int dtype, void* stream);
+                          int dist_done, int64_t* step_counter, int dtype, void* stream);
 
 /* Same update direction with the IMQ particle kernel k_ij = (alpha + sum_d (X_jd - X_id)^2 / h_d)^beta
  * (alpha > 0, beta < 0).  bandwidth > 0: h_d = bandwidth for every d.  bandwidth <= 0: per-dimension median
@@ -305,9 +310,9 @@ int pacoh_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_
 
 /* Same update with the step-dependent scalars in DEVICE memory, scalars = {1 - lr*weight_decay, lr/(1-beta1^step),
  * sqrt(1-beta2^step), eps} (4 values of `dtype`), so that the launch can be captured once in a hipGraph and replayed
- * every iteration while the host only refreshes the 4 scalars. */
+ * every iteration while the host only refreshes the 4 scalars.  step_counter (optional): advanced by one (see pacoh_step_begin). */
 int pacoh_adam_step_dev(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, const void* scalars,
-                        double beta1, double beta2, long count, int dtype, void* stream);
+                        double beta1, double beta2, long count, int64_t* step_counter, int dtype, void* stream);
 
 /* y += alpha * x: the plain SGD update of the optimizer='SGD' option (torch.optim.SGD(lr), GPR_meta_mll.py:257). */
 int pacoh_axpy(void* y, const void* x, double alpha, long count, int dtype, void* stream);

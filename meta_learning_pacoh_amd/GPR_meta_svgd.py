@@ -195,11 +195,13 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         self._fail = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._bw_out = torch.zeros(1, dtype=self.dtype, device=self.device)
         self._feed = StepFeed(self.device, self.dtype, tb_local, chunk=self.GRAPH_CHUNK)
+        self._svgd_ws = L.svgd_update_workspace(self.particles, self._svgd_ws)
         self._graphs = None
 
     def _body_likelihood(self):
         """score[P,D] = d/d theta_p sum_t mll[t,p] over this rank's tasks (unscaled), lik[P] the sums themselves"""
-        batch, hyp = self._feed.begin(self.tasks, self.engine, self.particles)      # select + gather + hyper transforms: one launch
+        # select + gather + hyper transforms + the particles' distance matrix: one launch; the counter is advanced by the update
+        batch, hyp = self._feed.begin(self.tasks, self.engine, self.particles, advance=False, svgd=(self.particles, self._svgd_ws))
         if batch is None:
             self._packed.zero_()
             return
@@ -207,10 +209,12 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
                                  fail_flag=self._fail, hypers=hyp)
 
     def _body_update(self):
-        """prior score + pre-factor + bandwidth + phi + optimizer in two launches, particles updated in place"""
+        """prior score + pre-factor + bandwidth + phi + optimizer in one launch (distances: _body_likelihood), particles updated
+        in place, step counter advanced"""
         _, self._svgd_ws = L.svgd_update_dev(self.particles, self._score, self.prior_mean, self.prior_std, self.prior_factor,
                                              self.bandwidth, self.optimizer_name, self._feed.sc, self.exp_avg, self.exp_avg_sq,
-                                             workspace=self._svgd_ws, bw_out=self._bw_out)
+                                             workspace=self._svgd_ws, bw_out=self._bw_out, dist_done=True,
+                                             step_counter=self._feed.ctr)
         self.last_bandwidth = self._bw_out
 
     def _build_graphs(self):

@@ -112,7 +112,8 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         self._graphs = None
 
     def _body_likelihood(self):
-        batch, _ = self._feed.begin(self.tasks)            # select (incl. the step's noise) + task gather: one launch
+        batch, _ = self._feed.begin(self.tasks, advance=False)    # select (incl. the step's noise) + task gather: one launch; the
+                                                                  # Adam launch at the end of the step advances the counter
         self._theta, self._log_q = L.vi_sample(self.posterior, self._feed.aux, full=self.cov_type == 'full')
         if batch is None:
             self._packed.zero_()
@@ -128,7 +129,8 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         L.reduce_tasks(self._lik.reshape(S, 1, 1), self._loss.reshape(1, 1), scale=-1.0 / S)
         L.reduce_tasks(self._log_q.reshape(S, 1, 1), self._loss.reshape(1, 1), scale=self.prior_factor / S, accumulate=True)
         grad = L.vi_grad(self.posterior, self._feed.aux, self._score, self.prior_factor, full=self.cov_type == 'full')
-        L.adam_step_dev(self.posterior, grad, self.exp_avg, self.exp_avg_sq, self._feed.sc[L.SC_ADAM:L.SC_ADAM + 4])
+        L.adam_step_dev(self.posterior, grad, self.exp_avg, self.exp_avg_sq, self._feed.sc[L.SC_ADAM:L.SC_ADAM + 4],
+                        step_counter=self._feed.ctr)
 
     def _build_graphs(self):
         state = (self.posterior, self.exp_avg, self.exp_avg_sq, self._feed.ctr, self._fail)

@@ -55,9 +55,9 @@ SIGNATURES = {
     'pacoh_step_select': (_i, [_vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _i, _vp]),
     'pacoh_scale_dev': (_i, [_vp, _vp, _l, _i, _vp]),
     'pacoh_step_begin': (_i, [_vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
-                              _vp, _l, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
+                              _vp, _l, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_svgd_update_dev_workspace_bytes': (_sz, [_i, _i, _i]),
-    'pacoh_svgd_update_dev': (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _vp, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pacoh_svgd_update_dev': (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _vp, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     'pacoh_prior_logprob_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
     'pacoh_svgd_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_phi': (_i, [_vp, _vp, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -65,7 +65,7 @@ SIGNATURES = {
     'pacoh_svgd_imq_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_phi_imq': (_i, [_vp, _vp, _d, _d, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_adam_step': (_i, [_vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _l, _l, _i, _vp]),
-    'pacoh_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _l, _i, _vp]),
+    'pacoh_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _l, _vp, _i, _vp]),
     'pacoh_axpy': (_i, [_vp, _vp, _d, _l, _i, _vp]),
     'pacoh_vi_sample': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_vi_grad': (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _vp]),
@@ -556,11 +556,26 @@ def step_select(idx_all, sc_all, counter, idx_out, sc_out, aux_all=None, aux_out
                                      _ptr(idx_out), _ptr(sc_out), _ptr(aux_out, sc_all), dtype_code(sc_all), _stream()), 'pacoh_step_select')
 
 
-def step_begin(feed, tasks, out, theta=None, hyper=None, hyper_out=None):
+def svgd_update_workspace(X, workspace=None):
+    """workspace of svgd_update_dev / of the distance part of step_begin for particles X"""
+    lib = load_library()
+    need = lib.pacoh_svgd_update_dev_workspace_bytes(X.shape[0], X.shape[1], dtype_code(X))
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=X.device)
+    return workspace
+
+
+def step_begin(feed, tasks, out, theta=None, hyper=None, hyper_out=None, advance=True, svgd=None):
     """first launch of a captured step: feed (engine.StepFeed) row -> feed.sc / feed.aux, task gather tasks[idx] -> out = (x, y, n_valid
     | None), hyper-parameter transforms of theta -> hyper_out = (ls, os | None, noise) with hyper = (off_ls, f, off_os, off_noise,
-    noise_floor), counter advanced: ONE launch"""
+    noise_floor): ONE launch.  advance=False leaves the counter to the step's last launch (svgd_update_dev / adam_step_dev with
+    step_counter=feed.ctr); svgd = (particles, workspace) adds their distance matrix + snapshot (svgd_update_dev(dist_done=True))"""
     lib = load_library()
+    sv_X = sv_ws = None
+    sv_P = sv_D = 0
+    if svgd is not None:
+        sv_X, sv_ws = svgd
+        sv_P, sv_D = sv_X.shape
     tb = feed.tb
     n_aux = feed.aux_all[0].numel() if feed.aux_all is not None else 0
     x = y = nv = ox = oy = onv = None
@@ -582,7 +597,8 @@ def step_begin(feed, tasks, out, theta=None, hyper=None, hyper_out=None):
                                     _ptr(feed.ctr), _ptr(feed.ticket), _ptr(feed.sc), _ptr(feed.aux, feed.sc_all),
                                     _ptr(x, feed.sc_all), _ptr(y, feed.sc_all), _ptr(nv), _ptr(ox), _ptr(oy), _ptr(onv), n, d,
                                     _ptr(theta, feed.sc_all), stride, P, off_ls, f, off_os, off_noise, float(floor), _ptr(ls), _ptr(os_),
-                                    _ptr(noise), dtype_code(feed.sc_all), _stream()), 'pacoh_step_begin')
+                                    _ptr(noise), int(bool(advance)), _ptr(sv_X, feed.sc_all), _ptr(sv_ws), sv_P, sv_D,
+                                    dtype_code(feed.sc_all), _stream()), 'pacoh_step_begin')
 
 
 def scale_dev(buf, scalar):
@@ -592,21 +608,22 @@ def scale_dev(buf, scalar):
 
 
 def svgd_update_dev(X, score, prior_mean, prior_std, prior_factor, bandwidth, optimizer, scalars, exp_avg, exp_avg_sq,
-                    workspace=None, bw_out=None, beta1=0.9, beta2=0.999):
-    """the fused SVGD step with its step-dependent scalars in device memory; X is updated in place -> (bandwidth, workspace)"""
+                    workspace=None, bw_out=None, beta1=0.9, beta2=0.999, dist_done=False, step_counter=None):
+    """the fused SVGD step with its step-dependent scalars in device memory; X is updated in place -> (bandwidth, workspace).
+    dist_done: step_begin(svgd=(X, workspace)) already filled the workspace; step_counter: see step_begin(advance=False)"""
     lib = load_library()
     P, D = X.shape
     code = dtype_code(X)
-    need = lib.pacoh_svgd_update_dev_workspace_bytes(P, D, code)
-    if workspace is None or workspace.numel() * workspace.element_size() < need:
-        workspace = torch.empty(need, dtype=torch.uint8, device=X.device)
+    assert not dist_done or workspace is not None
+    workspace = svgd_update_workspace(X, workspace)
     if bw_out is None:
         bw_out = torch.empty(1, dtype=X.dtype, device=X.device)
     bw = -1.0 if bandwidth is None else float(bandwidth)
     with _Timed('svgd_phi'):
         _check(lib.pacoh_svgd_update_dev(_ptr(X), _ptr(score, X), _ptr(prior_mean, X), _ptr(prior_std, X), float(prior_factor), bw,
                                          int(optimizer == 'Adam'), _ptr(scalars, X), float(beta1), float(beta2), _ptr(exp_avg, X),
-                                         _ptr(exp_avg_sq, X), _ptr(bw_out), _ptr(workspace), P, D, code, _stream()),
+                                         _ptr(exp_avg_sq, X), _ptr(bw_out), _ptr(workspace), P, D, int(bool(dist_done)),
+                                         _ptr(step_counter), code, _stream()),
                'pacoh_svgd_update_dev')
     return bw_out, workspace
 
@@ -642,12 +659,12 @@ def adam_scalars(lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
     return [1.0 - lr * weight_decay, lr / (1.0 - beta1 ** step), (1.0 - beta2 ** step) ** 0.5, eps]
 
 
-def adam_step_dev(param, grad, exp_avg, exp_avg_sq, scalars, beta1=0.9, beta2=0.999):
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, scalars, beta1=0.9, beta2=0.999, step_counter=None):
     lib = load_library()
     with _Timed('adam_step'):
         _check(lib.pacoh_adam_step_dev(_ptr(param), _ptr(grad, param), _ptr(exp_avg, param), _ptr(exp_avg_sq, param),
-                                       _ptr(scalars, param), float(beta1), float(beta2), param.numel(), dtype_code(param),
-                                       _stream()), 'pacoh_adam_step_dev')
+                                       _ptr(scalars, param), float(beta1), float(beta2), param.numel(), _ptr(step_counter),
+                                       dtype_code(param), _stream()), 'pacoh_adam_step_dev')
 
 
 def axpy(y, x, alpha):

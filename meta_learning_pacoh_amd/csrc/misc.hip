@@ -116,9 +116,9 @@ __global__ void __launch_bounds__(1024) prior_kernel(const T* __restrict__ theta
 // ---- SVGD ---------------------------------------------------------------------------------------
 // stage 1: squared distances, one 256-thread workgroup per (i,j) pair, direct differences
 template <typename T>
-__global__ void __launch_bounds__(256) svgd_dist_kernel(const T* __restrict__ X, T* __restrict__ d2, int P, int D, T* __restrict__ snap = nullptr) {
+__device__ __forceinline__ void svgd_dist_block(const T* __restrict__ X, T* __restrict__ d2, int P, int D, T* __restrict__ snap, int pair) {
     __shared__ T red[4];
-    const int i = blockIdx.x / P, j = blockIdx.x - i * P;
+    const int i = pair / P, j = pair - i * P;
     if (j > i) return;
     const T* xi = X + (long)i * D;
     if (snap && i == j) {                       // the diagonal pairs copy their particle: the in-place update reads the snapshot
@@ -133,6 +133,10 @@ __global__ void __launch_bounds__(256) svgd_dist_kernel(const T* __restrict__ X,
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) { const T tot = (red[0] + red[1]) + (red[2] + red[3]); d2[i * P + j] = tot; d2[j * P + i] = tot; }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) svgd_dist_kernel(const T* __restrict__ X, T* __restrict__ d2, int P, int D, T* __restrict__ snap = nullptr) {
+    svgd_dist_block<T>(X, d2, P, D, snap, (int)blockIdx.x);
 }
 
 // Median of the full PxP squared-distance matrix (numpy.median semantics) from its P(P-1)/2 distinct off-diagonal entries:
@@ -316,7 +320,9 @@ __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ 
                                                           int use_adam, T lr, T one_minus_b1, T b2,
                                                           T one_minus_b2, T step_size, T bc2_sqrt, T eps,
                                                           T* __restrict__ m, T* __restrict__ v, T* __restrict__ X_out, int P, int D,
-                                                          const T* __restrict__ sc = nullptr, const T* __restrict__ mids = nullptr) {
+                                                          const T* __restrict__ sc = nullptr, const T* __restrict__ mids = nullptr,
+                                                          long* __restrict__ step_counter = nullptr) {
+    if (step_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *step_counter += 1;   // (as in adam_dev_kernel)
     T score_scale = T(1);
     if (sc) { score_scale = sc[0]; lr = sc[1]; step_size = sc[5]; bc2_sqrt = sc[6]; eps = sc[7]; }     // PACOH_SC_* (pacoh_gp.h)
     __shared__ T Ki[PACOH_SVGD_MAX_PARTICLES];
@@ -389,8 +395,10 @@ __global__ void adam_kernel(T* __restrict__ param, const T* __restrict__ grad, T
 // into a hipGraph and replayed every iteration: sc = {decay_mul, step_size, bc2_sqrt, eps}
 template <typename T>
 __global__ void adam_dev_kernel(T* __restrict__ param, const T* __restrict__ grad, T* __restrict__ m, T* __restrict__ v,
-                                const T* __restrict__ sc, T one_minus_b1, T b2, T one_minus_b2, long count) {
+                                const T* __restrict__ sc, T one_minus_b1, T b2, T one_minus_b2, long count,
+                                long* __restrict__ step_counter = nullptr) {
     long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q == 0 && step_counter) *step_counter += 1;  // the step's last launch also advances the feed (pacoh_step_begin, advance = 0)
     if (q >= count) return;
     const T decay_mul = sc[0], step_size = sc[1], bc2_sqrt = sc[2], eps = sc[3];
     T g = grad[q];
@@ -493,6 +501,8 @@ struct StepBeginArgs {
     T* sc_out; T* aux_out;
     const T* x; const T* y; const int32_t* n_valid; T* ox; T* oy; int32_t* onv; int nx, ny;
     const T* theta; long stride; int P, off_ls, f, off_os, off_noise; T noise_floor; T* ls; T* os; T* noise;
+    int aux_blocks;                                  // blocks [tb+2, tb+2+aux_blocks) copy the auxiliary payload
+    const T* sv_X; T* sv_d2; T* sv_snap; int sv_P, sv_D;         // blocks behind them: SVGD pairwise distances + particle snapshot
 };
 
 template <typename T>
@@ -521,9 +531,13 @@ __global__ void __launch_bounds__(256) step_begin_kernel(StepBeginArgs<T> a) {
                 else a.noise[p] = softplus_t<T>(th[a.off_noise]) + a.noise_floor;
             }
         }
-    } else {
-        const int nb = gridDim.x - (a.tb + 2);
+    } else if (blk < a.tb + 2 + a.aux_blocks) {
+        const int nb = a.aux_blocks;
         for (long q = (long)(blk - a.tb - 2) * 256 + threadIdx.x; q < a.n_aux; q += (long)nb * 256) a.aux_out[q] = a.aux_all[row * a.n_aux + q];
+    } else {
+        // the particles do not change before the step's update: their distance matrix (and the snapshot the in-place update reads)
+        // can be had here, a launch earlier and off the path behind the all-reduce
+        svgd_dist_block<T>(a.sv_X, a.sv_d2, a.sv_P, a.sv_D, a.sv_snap, blk - (a.tb + 2 + a.aux_blocks));
     }
 }
 
@@ -559,14 +573,18 @@ template <typename T>
 static int step_begin_launch(const int64_t* idx_all, int tb, const void* sc_all, int n_sc, const void* aux_all, long n_aux, int64_t* counter,
                              int32_t* ticket, void* sc_out, void* aux_out, const void* x, const void* y, const int32_t* n_valid, void* out_x,
                              void* out_y, int32_t* out_n_valid, int n, int d, const void* theta, long theta_stride, int P, int off_ls, int f,
-                             int off_os, int off_noise, double noise_floor, void* ls, void* os, void* noise, hipStream_t s) {
-    StepBeginArgs<T> a = {(const long*)idx_all, tb, (const T*)sc_all, n_sc, (const T*)aux_all, n_aux, (long*)counter, ticket, (T*)sc_out,
-                          (T*)aux_out, (const T*)x, (const T*)y, n_valid, (T*)out_x, (T*)out_y, out_n_valid, n * d, n, (const T*)theta,
-                          theta_stride, P, off_ls, f, off_os, off_noise, (T)noise_floor, (T*)ls, (T*)os, (T*)noise};
+                             int off_os, int off_noise, double noise_floor, void* ls, void* os, void* noise, int advance,
+                             const void* svgd_X, void* svgd_workspace, int svgd_P, int svgd_D, hipStream_t s) {
     long ab = n_aux > 0 ? (n_aux + 2047) / 2048 : 0;
     if (ab > 256) ab = 256;
-    hipLaunchKernelGGL(step_begin_kernel<T>, dim3((unsigned)(tb + 2 + ab)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, (long*)counter);
+    T* d2 = (T*)svgd_workspace;                       // (layout of pacoh_svgd_update_dev_workspace_bytes: distances | snapshot | median pair)
+    StepBeginArgs<T> a = {(const long*)idx_all, tb, (const T*)sc_all, n_sc, (const T*)aux_all, n_aux, (long*)counter, ticket, (T*)sc_out,
+                          (T*)aux_out, (const T*)x, (const T*)y, n_valid, (T*)out_x, (T*)out_y, out_n_valid, n * d, n, (const T*)theta,
+                          theta_stride, P, off_ls, f, off_os, off_noise, (T)noise_floor, (T*)ls, (T*)os, (T*)noise,
+                          (int)ab, (const T*)svgd_X, d2, svgd_X ? d2 + svgd_P * svgd_P : nullptr, svgd_P, svgd_D};
+    const long sb = svgd_X ? (long)svgd_P * svgd_P : 0;
+    hipLaunchKernelGGL(step_begin_kernel<T>, dim3((unsigned)(tb + 2 + ab + sb)), dim3(256), 0, s, a);
+    if (advance) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, (long*)counter);
     return launch_status();
 }
 
@@ -574,19 +592,22 @@ extern "C" int pacoh_step_begin(const int64_t* idx_all, int tb, const void* sc_a
                                 int64_t* counter, int32_t* ticket, void* sc_out, void* aux_out,
                                 const void* x, const void* y, const int32_t* n_valid, void* out_x, void* out_y, int32_t* out_n_valid, int n, int d,
                                 const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise, double noise_floor,
-                                void* ls, void* os, void* noise, int dtype, void* stream) {
+                                void* ls, void* os, void* noise, int advance, const void* svgd_X, void* svgd_workspace, int svgd_P, int svgd_D,
+                                int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!counter || !ticket || tb < 0 || n_sc < 0 || n_aux < 0 || (n_sc > 0 && (!sc_all || !sc_out)) || (n_aux > 0 && (!aux_all || !aux_out)))
         return PACOH_EINVAL;
     if (tb > 0 && (!idx_all || !x || !y || !out_x || !out_y || n <= 0 || d <= 0 || (n_valid == nullptr) != (out_n_valid == nullptr))) return PACOH_EINVAL;
     if (theta && (!ls || !noise || P <= 0 || f <= 0)) return PACOH_EINVAL;
+    if (svgd_X && (!svgd_workspace || svgd_P <= 0 || svgd_D <= 0)) return PACOH_EINVAL;
+    if (svgd_X && svgd_P > PACOH_SVGD_MAX_PARTICLES) return PACOH_ELIMIT;
     if (dtype == PACOH_F32)
         return step_begin_launch<float>(idx_all, tb, sc_all, n_sc, aux_all, n_aux, counter, ticket, sc_out, aux_out, x, y, n_valid, out_x, out_y,
                                         out_n_valid, n, d, theta, theta_stride, P, off_ls, f, off_os, off_noise, noise_floor, ls, os, noise,
-                                        (hipStream_t)stream);
+                                        advance, svgd_X, svgd_workspace, svgd_P, svgd_D, (hipStream_t)stream);
     return step_begin_launch<double>(idx_all, tb, sc_all, n_sc, aux_all, n_aux, counter, ticket, sc_out, aux_out, x, y, n_valid, out_x, out_y,
                                      out_n_valid, n, d, theta, theta_stride, P, off_ls, f, off_os, off_noise, noise_floor, ls, os, noise,
-                                     (hipStream_t)stream);
+                                     advance, svgd_X, svgd_workspace, svgd_P, svgd_D, (hipStream_t)stream);
 }
 
 extern "C" int pacoh_scale_dev(void* buf, const void* scalar, long count, int dtype, void* stream) {
@@ -612,7 +633,7 @@ extern "C" int pacoh_gather_tasks(const void* x, const void* y, const int32_t* n
     return launch_status();
 }
 
-extern "C" int pacoh_abi_version(void) { return 2; }
+extern "C" int pacoh_abi_version(void) { return 3; }
 
 extern "C" int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise,
                                double noise_floor, void* ls, void* os, void* noise, int dtype, void* stream) {
@@ -696,11 +717,11 @@ extern "C" size_t pacoh_svgd_update_dev_workspace_bytes(int P, int D, int dtype)
 template <typename T>
 static int svgd_update_dev_launch(void* X, const void* score, const void* mu, const void* sd, double prior_factor, double bandwidth,
                                   int use_adam, const void* scalars, double beta1, double beta2, void* m, void* v, void* bw_out,
-                                  void* workspace, int P, int D, hipStream_t s) {
+                                  void* workspace, int P, int D, int dist_done, int64_t* step_counter, hipStream_t s) {
     T* d2 = (T*)workspace;
     T* snap = d2 + P * P;
     T* mids = nullptr;
-    hipLaunchKernelGGL(svgd_dist_kernel<T>, dim3(P * P), dim3(256), 0, s, (const T*)X, d2, P, D, snap);
+    if (!dist_done) hipLaunchKernelGGL(svgd_dist_kernel<T>, dim3(P * P), dim3(256), 0, s, (const T*)X, d2, P, D, snap);
     if (P > 64 && !(bandwidth > 0.0)) {
         mids = snap + (long)P * D;
         hipLaunchKernelGGL(svgd_median_large_kernel<T>, dim3(2), dim3(1024), 0, s, (const T*)d2, P, mids);
@@ -708,14 +729,14 @@ static int svgd_update_dev_launch(void* X, const void* score, const void* mu, co
     hipLaunchKernelGGL(svgd_update_kernel<T>, dim3((D + 255) / 256, P), dim3(256), 0, s, (const T*)snap, (const T*)score, (const T*)mu,
                        (const T*)sd, (T)prior_factor, (const T*)d2, (T)bandwidth, (T*)bw_out, use_adam, T(0),
                        (T)(1.0 - beta1), (T)beta2, (T)(1.0 - beta2), T(0), T(1), T(0), (T*)m, (T*)v, (T*)X, P, D, (const T*)scalars,
-                       (const T*)mids);
+                       (const T*)mids, (long*)step_counter);
     return launch_status();
 }
 
 extern "C" int pacoh_svgd_update_dev(void* X, const void* score, const void* prior_mean, const void* prior_std,
                                      double prior_factor, double bandwidth, int use_adam, const void* scalars, double beta1,
                                      double beta2, void* exp_avg, void* exp_avg_sq, void* bw_out, void* workspace, int P, int D,
-                                     int dtype, void* stream) {
+                                     int dist_done, int64_t* step_counter, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!X || !score || !scalars || !workspace || P <= 0 || D <= 0) return PACOH_EINVAL;
     if ((prior_mean == nullptr) != (prior_std == nullptr)) return PACOH_EINVAL;
@@ -723,9 +744,9 @@ extern "C" int pacoh_svgd_update_dev(void* X, const void* score, const void* pri
     if (P > PACOH_SVGD_MAX_PARTICLES) return PACOH_ELIMIT;
     if (dtype == PACOH_F32)
         return svgd_update_dev_launch<float>(X, score, prior_mean, prior_std, prior_factor, bandwidth, use_adam, scalars, beta1, beta2,
-                                             exp_avg, exp_avg_sq, bw_out, workspace, P, D, (hipStream_t)stream);
+                                             exp_avg, exp_avg_sq, bw_out, workspace, P, D, dist_done, step_counter, (hipStream_t)stream);
     return svgd_update_dev_launch<double>(X, score, prior_mean, prior_std, prior_factor, bandwidth, use_adam, scalars, beta1, beta2,
-                                          exp_avg, exp_avg_sq, bw_out, workspace, P, D, (hipStream_t)stream);
+                                          exp_avg, exp_avg_sq, bw_out, workspace, P, D, dist_done, step_counter, (hipStream_t)stream);
 }
 
 template <typename T>
@@ -814,17 +835,18 @@ extern "C" int pacoh_adam_step(void* param, const void* grad, void* exp_avg, voi
 }
 
 extern "C" int pacoh_adam_step_dev(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, const void* scalars,
-                                   double beta1, double beta2, long count, int dtype, void* stream) {
+                                   double beta1, double beta2, long count, int64_t* step_counter, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!param || !grad || !exp_avg || !exp_avg_sq || !scalars || count <= 0) return PACOH_EINVAL;
     unsigned blocks = (unsigned)((count + 255) / 256);
     if (dtype == PACOH_F32)
         hipLaunchKernelGGL(adam_dev_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)param, (const float*)grad,
                            (float*)exp_avg, (float*)exp_avg_sq, (const float*)scalars, (float)(1.0 - beta1), (float)beta2,
-                           (float)(1.0 - beta2), count);
+                           (float)(1.0 - beta2), count, (long*)step_counter);
     else
         hipLaunchKernelGGL(adam_dev_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (double*)param, (const double*)grad,
-                           (double*)exp_avg, (double*)exp_avg_sq, (const double*)scalars, 1.0 - beta1, beta2, 1.0 - beta2, count);
+                           (double*)exp_avg, (double*)exp_avg_sq, (const double*)scalars, 1.0 - beta1, beta2, 1.0 - beta2, count,
+                           (long*)step_counter);
     return launch_status();
 }
 

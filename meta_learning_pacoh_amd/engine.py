@@ -188,9 +188,10 @@ class StepFeed:
     def select(self):
         L.step_select(self.idx_all, self.sc_all, self.ctr, self.idx, self.sc, self.aux_all, self.aux)
 
-    def begin(self, tasks, engine=None, theta=None):
-        """select() + the step's task gather (+ the hyper-parameter transforms of theta through `engine`) in ONE launch
-        -> (TaskBatch | None, hypers | None)"""
+    def begin(self, tasks, engine=None, theta=None, advance=True, svgd=None):
+        """select() + the step's task gather (+ the hyper-parameter transforms of theta through `engine`, + the SVGD distance
+        matrix of svgd = (particles, workspace)) in ONE launch -> (TaskBatch | None, hypers | None); advance=False: the step's
+        last launch advances the counter (L.step_begin)"""
         batch = hyp = None
         out = None
         if self.tb > 0:
@@ -209,7 +210,7 @@ class StepFeed:
             noise = torch.empty(P, dtype=theta.dtype, device=theta.device)
             hyper, hyper_out = (off_ls, f, off_os, off_noise, engine.noise_floor), (ls, os_, noise)
             hyp = hyper_out
-        L.step_begin(self, tasks, out, theta if hyp is not None else None, hyper, hyper_out)
+        L.step_begin(self, tasks, out, theta if hyp is not None else None, hyper, hyper_out, advance=advance, svgd=svgd)
         return batch, hyp
 
 
