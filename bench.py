@@ -158,6 +158,22 @@ def main():
     #  keep the faster -- that decision must not fall into the timed region)
     wl['run'](max(24, args.warmup))
     barrier()
+    # A fresh box needs a second or two of the real launch path before it issues steps at its steady rate (first process after boot:
+    # hipGraphLaunch measured at 0.18 ms per step against 0.03 ms a minute later, enough to starve a 0.5 ms step).  More untimed steps,
+    # in chunks, until two consecutive chunks take the same time (or 5 s have passed); every rank runs the same number of chunks.
+    prev, t_warm = None, time.perf_counter()
+    for _ in range(40):
+        t_c = time.perf_counter()
+        wl['run'](64)
+        barrier()
+        cur = time.perf_counter() - t_c
+        stable = prev is not None and abs(cur - prev) <= 0.03 * prev and time.perf_counter() - t_warm >= 1.0
+        flag = torch.tensor([1.0 if (stable or time.perf_counter() - t_warm > 5.0) else 0.0], device='cuda')
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) > 0:
+            break
+        prev = cur
     t0 = time.perf_counter()
     wl['run'](args.steps)
     t_issued = time.perf_counter()                       # the host has issued every step (nothing synchronises inside)

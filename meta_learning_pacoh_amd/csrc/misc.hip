@@ -354,7 +354,18 @@ __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ 
     const T md = mu ? mu[d] : T(0), sdv = mu ? sd[d] : T(1);
     const T pscale = mu ? prior_factor / (sdv * sdv) : T(0);
     T acc = 0;
-    for (int j = 0; j < P; ++j) {
+    int j = 0;
+    for (; j + 4 <= P; j += 4) {                     // four particles' loads in flight (a rolled loop waited for each pair in turn)
+        T xj[4], sc4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { xj[u] = X[(long)(j + u) * D + d]; sc4[u] = score[(long)(j + u) * D + d]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const T sj = score_scale * sc4[u] - pscale * (xj[u] - md);
+            acc = fma(Ki[j + u], sj - gam2 * xj[u], acc);
+        }
+    }
+    for (; j < P; ++j) {
         const T xj = X[(long)j * D + d];
         const T sj = score_scale * score[(long)j * D + d] - pscale * (xj - md);
         acc = fma(Ki[j], sj - gam2 * xj, acc);
