@@ -211,7 +211,7 @@ using namespace pacoh;
 namespace pacoh {
 bool dense_mfma_fits(int n, int dtype);                    // dense_mfma.hip
 int dense_mfma_try(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
-                   int dtype, int attempt, hipStream_t s);       // dense_mfma.hip; returns 1 if the panel does not fit in LDS
+                   int dtype, int attempt, int u_only, hipStream_t s);       // dense_mfma.hip; returns 1 if the panel does not fit in LDS
 
 // Cholesky + solves + log-density of B materialised matrices; attempt > 0 re-runs only problems with info[b] < 0
 // (and then writes info[b] = attempt on success): the psd_safe_cholesky ladder of the dense path.
@@ -221,11 +221,12 @@ bool dense_chol_saves_inverse(int n, int dtype) {
     return !(e && e[0] == '1') && dense_mfma_fits(n, dtype);
 }
 
+// u_only (only honoured on the MFMA path, i.e. when dense_chol_saves_inverse()): alpha_out receives u = L^-1 r instead of alpha
 int dense_chol_launch(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
-                      int dtype, int attempt, hipStream_t stream) {
+                      int dtype, int attempt, hipStream_t stream, int u_only) {
     static const bool mfma_on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
     if (mfma_on) {
-        int rc = dense_mfma_try(A, resid, logp, alpha_out, info, scale, B, n, dtype, attempt, stream);
+        int rc = dense_mfma_try(A, resid, logp, alpha_out, info, scale, B, n, dtype, attempt, u_only, stream);
         if (rc != 1) return rc;
     }
     size_t lds = ((size_t)n + NB * (NB + 1) + 2 * TT * (NB + 1) + NB + 8) * (dtype == PACOH_F64 ? 8 : 4);
@@ -244,5 +245,5 @@ extern "C" int pacoh_mvn_logprob_dense(void* A, const void* resid, void* logp, v
                                        double scale, int B, int n, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!A || !resid || !logp || B <= 0 || n <= 0) return PACOH_EINVAL;
-    return dense_chol_launch(A, resid, logp, alpha_out, info, scale, B, n, dtype, 0, (hipStream_t)stream);
+    return dense_chol_launch(A, resid, logp, alpha_out, info, scale, B, n, dtype, 0, (hipStream_t)stream, 0);
 }

@@ -19,7 +19,7 @@
 namespace pacoh {
 
 int dense_chol_launch(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
-                      int dtype, int attempt, hipStream_t stream);                                  // dense.hip
+                      int dtype, int attempt, hipStream_t stream, int u_only = 0);                  // dense.hip
 bool dense_chol_saves_inverse(int n, int dtype);                                                     // dense.hip
 
 namespace {
@@ -602,6 +602,31 @@ __global__ void dense_predict_finish_kernel(const T* __restrict__ Kxs, const T* 
     if (cov && failed) for (int t = 0; t < m; ++t) cov[(b * m + s) * (long)m + t] = T(NAN);
 }
 
+// alpha = Z^T u for the lower-triangular Z = L^-1 (after trtri_dense_kernel): alpha[i] = sum_{j >= i} Z[j][i] u[j].  The blocked
+// backward solve inside the Cholesky kernel did the same with one dependent L2/HBM round trip per 32-row panel (0.2 ms at
+// n = 512, one workgroup per matrix); here every load is independent: one workgroup per (matrix, 64 columns), four row groups.
+template <typename T>
+__global__ void __launch_bounds__(256) dense_alpha_kernel(const T* __restrict__ Zall, const T* __restrict__ u, T* __restrict__ alpha,
+                                                          const int32_t* __restrict__ info, int n) {
+    __shared__ T part[4][64];
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const T* Z = Zall + (size_t)b * n * n;
+    const T* ub = u + (size_t)b * n;
+    T acc = 0;
+    if (i < n) {
+        const int j0 = blockIdx.x * 64;               // rows below the chunk's first column; entries above the diagonal are not Z
+#pragma unroll 8
+        for (int j = j0 + rg; j < n; j += 4) acc = fma((j >= i) ? Z[(size_t)j * n + i] : T(0), ub[j], acc);
+    }
+    part[rg][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rg == 0 && i < n) {
+        const T tot = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        alpha[(size_t)b * n + i] = (info && info[b] < 0) ? T(NAN) : tot;
+    }
+}
+
 template <typename T>
 int launch_trtri(T* A, const int32_t* info, int B, int n, int mpad, size_t lds, int saved_inv, hipStream_t s) {
 #define PACOH_TRTRI_LAUNCH(nt) do { auto kern = trtri_dense_kernel<T, nt>; \
@@ -644,6 +669,7 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
     hipLaunchKernelGGL(dense_resid_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T*)y, y_div,
                        (const T*)mean, mean_mode, n_valid, resid, P, n, total);
     const double jitter_base = dtype == PACOH_F32 ? 1e-6 : 1e-8;            // psd_safe_cholesky [gpytorch-upstream]
+    const bool u_only = bwd && dense_chol_saves_inverse(n, dtype);          // alpha comes from Z afterwards (dense_alpha_kernel)
     for (int attempt = 0; attempt < 4; ++attempt) {
         if (attempt == 0) {
             int rc = pacoh_gram_rbf_ard(z, z_div, z, z_div, ls, os, noise, 1, A, B, P, n, n, f, dtype, s);
@@ -655,12 +681,17 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
                                (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f);
         }
         if (n_valid) hipLaunchKernelGGL(dense_mask_kernel<T>, dim3(n, B), dim3(256), 0, s, A, n_valid, y_div, (const int32_t*)info, attempt, n);
-        int rc = dense_chol_launch(A, resid, logp, alpha, info, 1.0, B, n, dtype, attempt, s);
+        int rc = dense_chol_launch(A, resid, logp, bwd ? alpha : nullptr, info, 1.0, B, n, dtype, attempt, s, u_only ? 1 : 0);
         if (rc) return rc;
     }
     if (bwd) {
         int rc = launch_trtri<T>(A, info, B, n, mpad, lds, dense_chol_saves_inverse(n, dtype) ? 1 : 0, s);
         if (rc) return rc;
+        if (u_only) {                                  // alpha = Z^T u into the residual buffer (free after the last factorisation attempt)
+            hipLaunchKernelGGL(dense_alpha_kernel<T>, dim3((n + 63) / 64, B), dim3(256), 0, s, (const T*)A, (const T*)alpha, resid,
+                               (const int32_t*)info, n);
+            T* t = alpha; alpha = resid; resid = t;
+        }
         GemmArgs ga = {A, A, Wm, (long)n * n, (long)n * n, (long)n * n, n, n, n, n, n, n, 1, 0, 1, 1, 1.0, 0.0, info, 1};
         launch_bgemm<T>(ga, B, s);                                          // W = Z^T Z
         const long tz = (long)B * n * f;

@@ -195,7 +195,8 @@ __device__ __forceinline__ void factor_invert_diag32(T (*Ds)[DNB + 1], T* __rest
 template <typename T, int NT>
 __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, const T* __restrict__ resid,
                                                               T* __restrict__ logp, T* __restrict__ alpha_out,
-                                                              int32_t* __restrict__ info, T scale, int n, int mpad, int attempt) {
+                                                              int32_t* __restrict__ info, T scale, int n, int mpad, int attempt,
+                                                              int u_only) {
     if (attempt > 0 && info && info[blockIdx.x] >= 0) return;      // jitter-ladder retry: only the failed problems
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* sm = reinterpret_cast<T*>(smem_raw);
@@ -381,29 +382,57 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
         if (info) info[blockIdx.x] = ok ? attempt : -1;
     }
     if (!alpha_out) return;
+    if (u_only) {      // the caller goes on to Z = L^-1 and takes alpha = Z^T u from there (dense_alpha_kernel): no backward solve here
+        for (int q = tid; q < n; q += NT) alpha_out[(size_t)blockIdx.x * n + q] = ok ? rv[q] : T(NAN);
+        return;
+    }
     // ---- backward solve L^T alpha = u, blocked from the bottom: alpha_k = L11^-T w_k as a 32x32 product with the inverse
     //      block saved in the upper triangle, then w_i -= sum_c L[k0+c][i] alpha[k0+c] for the rows above
     const int nblk = (n + DNB - 1) / DNB;
+    // The diagonal block (L11's diagonal, Z11^T above it) goes through LDS, double-buffered (Ds and the Li area): the block of
+    // panel k-1 is fetched while the rows above panel k are updated.  Read from global memory inside the dot product, every one
+    // of its up to 31 steps waited for an L2 round trip (18 us per panel, 0.3 ms of the n = 512 factorisation).
+    T (*Db[2])[DNB + 1] = {Ds, reinterpret_cast<T (*)[DNB + 1]>(Li)};
+    auto fetch_diag = [&](int kbk, T (*D)[DNB + 1]) {
+        const int k0 = kbk * DNB;
+        const int kb = (n - k0 < DNB) ? (n - k0) : DNB;
+        for (int q = tid; q < DNB * DNB; q += NT) {
+            const int rr = q / DNB, c = q - rr * DNB;
+            D[rr][c] = (rr < kb && c < kb) ? Ab[(size_t)(k0 + rr) * n + k0 + c] : T(0);
+        }
+    };
+    __syncthreads();
+#ifdef PACOH_CHOL_STAMPS
+    long long bs_[3] = {0, 0, 0}, bt_ = wall_clock64();
+#define BSTAMP(k) do { __syncthreads(); const long long t_ = wall_clock64(); bs_[k] += t_ - bt_; bt_ = t_; } while (0)
+#else
+#define BSTAMP(k) do {} while (0)
+#endif
+    fetch_diag(nblk - 1, Db[(nblk - 1) & 1]);
     for (int kbk = nblk - 1; kbk >= 0; --kbk) {
         const int k0 = kbk * DNB;
         const int kb = (n - k0 < DNB) ? (n - k0) : DNB;
+        T (*D)[DNB + 1] = Db[kbk & 1];
         __syncthreads();
-        // the diagonal block (L11's diagonal, Z11^T above it) through LDS: read from global memory inside the dot product below,
-        // every one of its up to 31 steps waited for an L2 round trip (18 us per panel, 0.3 ms of the n = 512 factorisation)
-        for (int q = tid; q < DNB * DNB; q += NT) {
-            const int rr = q / DNB, c = q - rr * DNB;
-            Ds[rr][c] = (rr < kb && c < kb) ? Ab[(size_t)(k0 + rr) * n + k0 + c] : T(0);
+        // alpha_k[t] = w[t] / L[t][t] + sum_{c > t} Z11[c][t] w[c]: one product per thread (t = tid / 32, c = tid % 32; a
+        // 256-thread workgroup takes four passes), summed over the 32 lanes of a row
+        T a_new = 0;
+        for (int t = tid >> 5; t < DNB; t += NT >> 5) {
+            const int c = tid & 31;
+            T pr = 0;
+            if (t < kb && c < kb) {
+                if (c == t) pr = rv[k0 + t] / D[t][t];
+                else if (c > t) pr = D[t][c] * rv[k0 + c];
+            }
+            pr = subwave_sum<T>(pr, 32);
+            if (c == 0 && t < kb) red[32 + t] = pr;               // (red[32..96): scratch, unused since the register factor)
         }
         __syncthreads();
-        T a_reg = 0;
-        if (tid < kb) {
-            a_reg = rv[k0 + tid] / Ds[tid][tid];                        // [tid][tid] = L diag, [tid][c > tid] = Z11[c][tid]
-#pragma unroll 8
-            for (int c = tid + 1; c < kb; ++c) a_reg = fma(Ds[tid][c], rv[k0 + c], a_reg);
-        }
+        if (tid < kb) rv[k0 + tid] = red[32 + tid];
         __syncthreads();
-        if (tid < kb) rv[k0 + tid] = a_reg;
-        __syncthreads();
+        BSTAMP(0);
+        if (kbk > 0) fetch_diag(kbk - 1, Db[(kbk - 1) & 1]);      // (no dependence on this panel's alpha)
+        BSTAMP(1);
         for (int i = tid; i < k0; i += NT) {
             T sacc = rv[i];
             if (kb == DNB) {
@@ -414,10 +443,14 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
             }
             rv[i] = sacc;
         }
+        BSTAMP(2);
     }
+#undef BSTAMP
     __syncthreads();
 #ifdef PACOH_CHOL_STAMPS
-    if (tid == 0 && blockIdx.x == 0) printf("chol backward solve (us): %.1f\n", (wall_clock64() - tq_) * 0.01);
+    if (tid == 0 && blockIdx.x == 0)
+        printf("chol backward solve (us): %.1f (dot %.1f | fetch next diagonal block %.1f | update rows above %.1f)\n",
+               (wall_clock64() - tq_) * 0.01, bs_[0] * 0.01, bs_[1] * 0.01, bs_[2] * 0.01);
 #endif
     for (int q = tid; q < n; q += NT) alpha_out[(size_t)blockIdx.x * n + q] = ok ? rv[q] : T(NAN);
 }
@@ -425,7 +458,7 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
 // returns 1 when the panel does not fit in LDS (caller falls back to the VALU kernel of dense.hip)
 template <typename T>
 static int launch_dense_mfma(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale,
-                             int B, int n, int attempt, hipStream_t s) {
+                             int B, int n, int attempt, int u_only, hipStream_t s) {
     const int mpad = n > DNB ? (n - DNB + 15) / 16 * 16 : 16;        // rows of the largest panel, in 16-row blocks
     const size_t elems = (size_t)DNB * (DNB + 1) + (size_t)DNB * DLP + (size_t)mpad * DLP + 128 + n;
     const size_t lds = elems * sizeof(T);
@@ -435,7 +468,7 @@ static int launch_dense_mfma(void* A, const void* resid, void* logp, void* alpha
 #define PACOH_CHOL_LAUNCH(nt) do { auto kern = chol_dense_mfma_kernel<T, nt>; \
         if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return 1; \
-        hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, s, (T*)A, (const T*)resid, (T*)logp, (T*)alpha_out, info, (T)scale, n, mpad, attempt); } while (0)
+        hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, s, (T*)A, (const T*)resid, (T*)logp, (T*)alpha_out, info, (T)scale, n, mpad, attempt, u_only); } while (0)
     if (n >= 256) PACOH_CHOL_LAUNCH(1024); else if (n >= 96) PACOH_CHOL_LAUNCH(512); else PACOH_CHOL_LAUNCH(256);
 #undef PACOH_CHOL_LAUNCH
     return launch_status();
@@ -448,9 +481,9 @@ bool dense_mfma_fits(int n, int dtype) {
 }
 
 int dense_mfma_try(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
-                   int dtype, int attempt, hipStream_t s) {
-    return dtype == PACOH_F32 ? launch_dense_mfma<float>(A, resid, logp, alpha_out, info, scale, B, n, attempt, s)
-                              : launch_dense_mfma<double>(A, resid, logp, alpha_out, info, scale, B, n, attempt, s);
+                   int dtype, int attempt, int u_only, hipStream_t s) {
+    return dtype == PACOH_F32 ? launch_dense_mfma<float>(A, resid, logp, alpha_out, info, scale, B, n, attempt, u_only, s)
+                              : launch_dense_mfma<double>(A, resid, logp, alpha_out, info, scale, B, n, attempt, u_only, s);
 }
 
 }  // namespace pacoh
