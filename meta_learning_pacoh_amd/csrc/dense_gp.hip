@@ -537,6 +537,101 @@ __global__ void __launch_bounds__(256) dense_grad_rows_kernel(const T* __restric
     }
 }
 
+// Same sums with the roles turned: a LANE owns row i (64 rows per workgroup), the four waves split the columns j, and W[i][j] is
+// read as W[j][i] (W = K^-1 is symmetric: consecutive lanes, consecutive addresses).  Everything a row accumulates stays in its
+// lane -- the row-per-wave kernel above spends as long in its 2 f + 2 cross-lane reductions per row (216 ds_bpermute at f = 8 in
+// fp64) as in the 8 entries per lane they follow -- and z_j, alpha_j are LDS broadcasts.  Needs the coordinates in LDS.
+template <typename T, int FP>
+__global__ void __launch_bounds__(256) dense_grad_cols_kernel(const T* __restrict__ zs, const T* __restrict__ lsp,
+                                                              const T* __restrict__ osp, const int32_t* __restrict__ n_valid,
+                                                              int y_div, const T* __restrict__ g_lml, const T* __restrict__ alpha,
+                                                              const T* __restrict__ Wm, const int32_t* __restrict__ info,
+                                                              T* __restrict__ d_z, T* __restrict__ d_mean, int mean_mode,
+                                                              T* __restrict__ rowpart, int P, int n, int f) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* zt = reinterpret_cast<T*>(smem_raw);          // [f][n]
+    T* al = zt + (size_t)f * n;                       // [n]
+    T* red = al + n;                                  // [3][64][2 FP + 2]: partial sums of waves 1..3
+    const long b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = (int)(b % P);
+    const int nv = clamp_nv(n_valid, b / y_div, n);
+    const bool failed = info[b] < 0;
+    const T gup = g_lml ? g_lml[b] : T(1);
+    const int W3 = f + 3;
+    const T* zb = zs + b * (long)n * f;
+    const T* ab = alpha + b * (long)n;
+    for (int e = threadIdx.x; e < n * f; e += 256) { const int j = e / f, c = e - j * f; zt[c * n + j] = zb[e]; }
+    for (int j = threadIdx.x; j < n; j += 256) al[j] = ab[j];
+    __syncthreads();
+    const T os = osp ? osp[p] : T(1);
+    const T inv2n = nv > 0 ? T(0.5) / T(nv) : T(0);
+    const int i = blockIdx.x * 64 + lane;
+    const bool live = i < nv && !failed;
+    const int ic = i < n ? i : n - 1;
+    T zi[FP];
+#pragma unroll
+    for (int c = 0; c < FP; ++c) zi[c] = c < f ? zt[c * n + ic] : T(0);
+    const T ai = al[ic];
+    const T* wcol = Wm + b * (long)n * n + ic;        // W[j][i] at wcol[j * n]
+    T dz[FP], dls[FP];
+#pragma unroll
+    for (int c = 0; c < FP; ++c) { dz[c] = 0; dls[c] = 0; }
+    T dos = 0, dnz = 0;
+    if (!failed) {
+#pragma unroll 2
+        for (int j = wave; j < nv; j += 4) {
+            const T Gij = (ai * al[j] - wcol[(long)j * n]) * inv2n;
+            T s = 0, df[FP];
+#pragma unroll
+            for (int c = 0; c < FP; ++c) {
+                df[c] = c < f ? zt[c * n + j] - zi[c] : T(0);
+                s = fma(df[c], df[c], s);
+            }
+            const T e = rbf_exp<T>(T(-0.5) * s);
+            dos = fma(Gij, e, dos);
+            const T M = Gij * os * e;
+#pragma unroll
+            for (int c = 0; c < FP; ++c) { const T md = M * df[c]; dz[c] += md; dls[c] = fma(md, df[c], dls[c]); }
+            if (j == i) dnz = Gij;
+        }
+    }
+    constexpr int NR = 2 * FP + 2;
+    if (wave > 0) {
+        T* r = red + ((size_t)(wave - 1) * 64 + lane) * NR;
+#pragma unroll
+        for (int c = 0; c < FP; ++c) { r[c] = dz[c]; r[FP + c] = dls[c]; }
+        r[2 * FP] = dos; r[2 * FP + 1] = dnz;
+    }
+    __syncthreads();
+    if (wave == 0 && i < n) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {                 // fixed order: deterministic
+            const T* r = red + ((size_t)w * 64 + lane) * NR;
+#pragma unroll
+            for (int c = 0; c < FP; ++c) { dz[c] += r[c]; dls[c] += r[FP + c]; }
+            dos += r[2 * FP]; dnz += r[2 * FP + 1];
+        }
+        T* rp = rowpart + (b * n + i) * (long)W3;
+        if (!live) {
+            const T v = failed ? T(NAN) : T(0);
+            if (d_z) for (int c = 0; c < f; ++c) d_z[(b * n + i) * (long)f + c] = v;
+            if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = v;
+            for (int c = 0; c < W3; ++c) rp[c] = v;
+        } else {
+#pragma unroll
+            for (int c = 0; c < FP; ++c) {
+                if (c < f) {
+                    if (d_z) d_z[(b * n + i) * (long)f + c] = T(2) * gup * dz[c] / lsp[(long)p * f + c];
+                    rp[c] = dls[c];
+                }
+            }
+            rp[f] = dos; rp[f + 1] = dnz; rp[f + 2] = ai;
+            if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = gup * ai / T(nv);
+        }
+    }
+}
+
 // ---- per-problem results: lml and the reduced hyper-parameter gradients; one wave per problem ---------------------------------
 template <typename T>
 __global__ void __launch_bounds__(64) dense_finish_kernel(const T* __restrict__ logp, const T* __restrict__ rowpart,
@@ -702,8 +797,13 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
         const size_t glds = ((size_t)n * f + n) * sizeof(T);
         const bool use_lds = glds <= 60u * 1024u;
         const int rows = use_lds ? 16 : 4;
+        static const bool cols_on = []() { const char* e = getenv("PACOH_GRAD_COLS"); return !(e && e[0] == '0'); }();
 #define PACOH_DG_CASE(fp) case fp: \
-        if (use_lds) hipLaunchKernelGGL((dense_grad_rows_kernel<T, fp, true>), dim3((n + rows - 1) / rows, B), dim3(256), glds, s, \
+        if (use_lds && cols_on && glds + 3 * 64 * (2 * fp + 2) * sizeof(T) <= 64u * 1024u) \
+            hipLaunchKernelGGL((dense_grad_cols_kernel<T, fp>), dim3((n + 63) / 64, B), dim3(256), glds + 3 * 64 * (2 * fp + 2) * sizeof(T), s, \
+            (const T*)zsc, (const T*)ls, (const T*)os, n_valid, y_div, (const T*)g_lml, (const T*)alpha, (const T*)Wm, \
+            (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f); \
+        else if (use_lds) hipLaunchKernelGGL((dense_grad_rows_kernel<T, fp, true>), dim3((n + rows - 1) / rows, B), dim3(256), glds, s, \
             (const T*)zsc, (const T*)ls, (const T*)os, n_valid, y_div, (const T*)g_lml, (const T*)alpha, (const T*)Wm, \
             (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f, rows); \
         else hipLaunchKernelGGL((dense_grad_rows_kernel<T, fp, false>), dim3((n + rows - 1) / rows, B), dim3(256), 0, s, \
