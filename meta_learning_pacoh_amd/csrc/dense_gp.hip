@@ -213,13 +213,24 @@ __global__ void __launch_bounds__(NT) trtri_dense_kernel(T* __restrict__ A, cons
                 Acc acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
                 const int rowi = ib * 16 + r;
                 const T* arow = Ab + (size_t)(t0 + rowi) * n + t0;
+                // (the operands of the NEXT 16 columns are requested before this block's MFMAs: the loop otherwise alternates
+                //  between an L2 round trip and eight MFMAs)
+                T an[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const int kc = 4 * c + g; an[c] = (rowi < m && kc <= rowi) ? arow[kc] : T(0); }
                 for (int kb2 = 0; kb2 <= ib; ++kb2) {
+                    T ac[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ac[c] = an[c];
+                    if (kb2 < ib) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { const int kc = (kb2 + 1) * 16 + 4 * c + g; an[c] = (rowi < m && kc <= rowi) ? arow[kc] : T(0); }
+                    }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int kc = kb2 * 16 + 4 * c + g;
-                        const T a = (rowi < m && kc <= rowi) ? arow[kc] : T(0);
-                        acc0 = Mf<T>::mma(a, Pn[(size_t)kc * DLP + r], acc0);
-                        acc1 = Mf<T>::mma(a, Pn[(size_t)kc * DLP + 16 + r], acc1);
+                        acc0 = Mf<T>::mma(ac[c], Pn[(size_t)kc * DLP + r], acc0);
+                        acc1 = Mf<T>::mma(ac[c], Pn[(size_t)kc * DLP + 16 + r], acc1);
                     }
                 }
 #pragma unroll
