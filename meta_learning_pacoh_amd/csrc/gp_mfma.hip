@@ -265,9 +265,12 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
     unsigned int st_[12] = {};
     unsigned long long t_prev = __builtin_readcyclecounter();
 #endif
-    float ls[FP];
+    // features are kept as z * KAPPA / lengthscale, KAPPA^2 = log2(e) / 2: a kernel entry is exp2(-|dz|^2), one v_exp_f32 on the
+    // squared distance (as in gp_reg.hip; the compensated exp was six instructions for each of the 3 n / 2 entries a thread visits)
+    constexpr float KAPPA = 0.8493218002880191f, INV_KAPPA2 = 1.3862943611198906f;
+    float kls[FP];
 #pragma unroll
-    for (int c = 0; c < FP; ++c) ls[c] = (c < f) ? a.ls[(long)p * f + c] : 1.0f;
+    for (int c = 0; c < FP; ++c) kls[c] = (c < f) ? KAPPA / a.ls[(long)p * f + c] : 1.0f;
     const float os = a.os ? a.os[p] : 1.0f;
     const float noise = a.noise[p];
 
@@ -280,7 +283,7 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
     if (i < nv) {
         const float* zp = a.z + ((long)(blockIdx.x / (unsigned)a.z_div) * n + i) * (long)f;
 #pragma unroll
-        for (int c = 0; c < FP; ++c) if (c < f) zs[c] = zp[c] / ls[c];
+        for (int c = 0; c < FP; ++c) if (c < f) zs[c] = zp[c] * kls[c];
         float mi = 0.0f;
         if (a.mean_mode == PACOH_MEAN_VECTOR) mi = a.mean[b * n + i];
         else if (a.mean_mode == PACOH_MEAN_CONST) mi = a.mean[p];
@@ -323,7 +326,7 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
                         float s = 0.0f;
 #pragma unroll
                         for (int c = 0; c < FP; ++c) { const float d = zr[c] - zf[(col + v) * FP + c]; s = fmaf(d, d, s); }
-                        kv[v] = os * rbf_exp<float>(-0.5f * s);
+                        kv[v] = os * __builtin_amdgcn_exp2f(-s);
                     }
                     float4 o; o.x = kv[0]; o.y = kv[1]; o.z = kv[2]; o.w = kv[3];
                     *reinterpret_cast<float4*>(A + row * LD + col) = o;
@@ -346,7 +349,7 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
                     float s = 0.0f;
 #pragma unroll
                     for (int c = 0; c < FP; ++c) { const float d = zr[c] - zf[j * FP + c]; s = fmaf(d, d, s); }
-                    float k = os * rbf_exp<float>(-0.5f * s);
+                    float k = os * __builtin_amdgcn_exp2f(-s);
                     if (!(row < nv && j < nv)) k = 0.0f;
                     if (row == j) k = (row < nv) ? k + noise + jitter : 1.0f;
                     kv[v] = k;
@@ -367,7 +370,7 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
                         float s = 0.0f;
 #pragma unroll
                         for (int c = 0; c < FP; ++c) { const float d = zs[c] - zf[j * FP + c]; s = fmaf(d, d, s); }
-                        float k = os * rbf_exp<float>(-0.5f * s);
+                        float k = os * __builtin_amdgcn_exp2f(-s);
                         if (!(i < nv && j < nv)) k = 0.0f;
                         if (i == j) k = (i < nv) ? k + noise + jitter : 1.0f;
                         kv[v] = k;
@@ -529,8 +532,9 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
     float dz[FP], dls[FP];
 #pragma unroll
     for (int c = 0; c < FP; ++c) { dz[c] = 0.0f; dls[c] = 0.0f; }
-    float dos = 0.0f, dnz = 0.0f;
+    float msum = 0.0f, dnz = 0.0f;                        // sum of M_ij = os x (d lml / d os)
     const float inv2n = nv > 0 ? 0.5f / (float)nv : 0.0f;
+    const float osn = inv2n * os;                         // the outputscale rides on the 1/(2n) factor
     if (i < nv) {
         // four columns per iteration from 16-byte LDS reads (four independent exp chains in flight).  The loop runs over the
         // padded size: for j >= nv both alpha_j and W_ij are exactly 0 (identity block), so those columns contribute nothing.
@@ -559,13 +563,12 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float Gij = (ai * avv[u] - wv[u]) * inv2n;
+                const float Gij = (ai * avv[u] - wv[u]) * osn;
                 float s = 0.0f, df[FP];
 #pragma unroll
                 for (int c = 0; c < FP; ++c) { df[c] = zj[u][c] - zs[c]; s = fmaf(df[c], df[c], s); }
-                const float e = rbf_exp<float>(-0.5f * s);
-                dos = fmaf(Gij, e, dos);
-                const float M = Gij * os * e;
+                const float M = Gij * __builtin_amdgcn_exp2f(-s);
+                msum += M;
 #pragma unroll
                 for (int c = 0; c < FP; ++c) { const float md = M * df[c]; dz[c] += md; dls[c] = fmaf(md, df[c], dls[c]); }
             }
@@ -574,7 +577,7 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
     STAMP(8);                                  // gradient loop
     const float bad = okf ? 0.0f : NAN;
     if (a.d_z && i < n) {
-        for (int c = 0; c < f; ++c) a.d_z[(b * n + i) * (long)f + c] = (i < nv) ? 2.0f * gup * dz[c] / ls[c] + bad : 0.0f;
+        for (int c = 0; c < f; ++c) a.d_z[(b * n + i) * (long)f + c] = (i < nv) ? (2.0f * INV_KAPPA2) * gup * dz[c] * kls[c] + bad : 0.0f;
     }
     if (a.mean_mode == PACOH_MEAN_VECTOR) {
         if (a.d_mean && i < n) a.d_mean[b * n + i] = (i < nv) ? gup * ai / (float)nv + bad : 0.0f;
@@ -586,10 +589,10 @@ __global__ void __launch_bounds__(64 * NW, (NB <= 3 && FP <= 4 ? 3 : 2)) gp_mfma
     for (int c = 0; c < FP; ++c) {
         if (c < f) {
             const float sc = block_sum<NW>(dls[c], scr);
-            if (tid == 0) a.d_ls[b * f + c] = gup * sc / ls[c] + bad;
+            if (tid == 0) a.d_ls[b * f + c] = (INV_KAPPA2 / KAPPA) * gup * sc * kls[c] + bad;
         }
     }
-    const float sdos = block_sum<NW>(dos, scr), sdnz = block_sum<NW>(dnz, scr);
+    const float sdos = block_sum<NW>(msum, scr) / os, sdnz = block_sum<NW>(dnz, scr);
     if (tid == 0) {
         if (a.d_os) a.d_os[b] = gup * sdos + bad;
         a.d_noise[b] = gup * sdnz + bad;
