@@ -613,7 +613,6 @@ template <int NB, int NW, bool BWD>
 static int launch_nb_nw(const GpMfmaArgs& a, int FP, hipStream_t s) {
     constexpr int NP = 16 * NB, LD = NP + 4;
     size_t lds = (size_t)(NP * LD + NP * FP + 3 * NP + 64) * sizeof(float);
-    { const char* e = getenv("PACOH_GP_LDS_PAD"); if (e && e[0]) lds += (size_t)atol(e); }   // occupancy experiments (tools/gp_time.py)
 #define PACOH_GPM_CASE(fp) case fp: { auto kern = gp_mfma_kernel<NB, NW, fp, BWD>; \
         if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PACOH_ELIMIT; \
         hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(64 * NW), lds, s, a); } break;
@@ -624,10 +623,6 @@ static int launch_nb_nw(const GpMfmaArgs& a, int FP, hipStream_t s) {
 
 template <int NB, bool BWD>
 static int launch_nb(const GpMfmaArgs& a, int FP, hipStream_t s) {
-    if constexpr (NB == 4) {
-        const char* e = getenv("PACOH_GP_NW2");            // experiment: two waves per n <= 64 problem
-        if (e && e[0] == '1') return launch_nb_nw<NB, 2, BWD>(a, FP, s);
-    }
     return launch_nb_nw<NB, (NB <= 4 ? 1 : 2), BWD>(a, FP, s);
 }
 

@@ -170,13 +170,9 @@ __host__ __device__ constexpr int uidx(int NB, int K, int J) { return K * NB - K
 
 }  // namespace
 
-// waves per SIMD the register allocation aims at (occupancy is what this kernel lives on): the n <= 64 backward kernel needs 151
-// registers (3 waves; its 12 KB LDS image of W admits 13 problems per CU), up to n = 48 everything fits 128 (4 waves)
-#ifdef PACOH_GPR_MINW
-#define GPR_MINW(NB, FP, BWD) PACOH_GPR_MINW
-#else
+// waves per SIMD the register allocation aims at: 4 (the n <= 64, f <= 2 backward kernel needs 122 registers and 7.7 KB of LDS);
+// with f <= 4 the n = 64 kernels need 168 - 186 registers (3 resp. 2 waves)
 #define GPR_MINW(NB, FP, BWD) ((NB) == 4 && (FP) == 4 ? ((BWD) ? 2 : 3) : 4)
-#endif
 template <int NB, int FP, bool BWD>
 __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfmaArgs a) {
     constexpr int NP = 16 * NB;

@@ -33,11 +33,7 @@ constexpr int F_OFF_H = 160;                  // hidden layers 2..NH
 __host__ __device__ constexpr int f_off_out(int nh) { return F_OFF_H + (nh - 1) * HBLK; }      // W_out [2][32] | b_out [2] (+2 pad)
 __host__ __device__ constexpr int f_welems(int nh) { return f_off_out(nh) + 68; }
 constexpr int TSTRIDE = 8;                    // staged tile row: x[4] | g[2] | pad[2]
-#ifdef PACOH_EXP_TURN128
-constexpr int TLD = 20;                       // scratch row stride: b128 writes and strided b32 reads both conflict-free
-#else
-constexpr int TLD = 17;
-#endif
+constexpr int TLD = 17;                       // scratch row stride of a block transpose: conflict-free both ways
 constexpr int TRS = 16 * TLD;                 // one transpose scratch block
 
 struct FusedNet {
@@ -199,18 +195,12 @@ __device__ __forceinline__ void f_delta(const float* W, int r, int g, const f32x
 // 16x16 block: lane (r,g) holds X[feature 4g+s][point r] in register s, returns X[feature r][point 4g+q] in register q
 __device__ __forceinline__ f32x4 f_turn(float* scr, const f32x4& v, int r, int g) {
     f32x4 o;
-#ifdef PACOH_EXP_TURN128
-    *reinterpret_cast<f32x4*>(scr + r * TLD + 4 * g) = v;          // scr[point r][feature 4g+s]
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = scr[(4 * g + q) * TLD + r];
-#else
+    // (16-byte writes + strided reads, row stride 20, were 22 % slower at 64-point tiles)
 #pragma unroll
     for (int s = 0; s < 4; ++s) scr[(4 * g + s) * TLD + r] = v[s];
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int q = 0; q < 4; ++q) o[q] = scr[r * TLD + 4 * g + q];
-#endif
     asm volatile("" ::: "memory");
     return o;
 }
@@ -478,11 +468,7 @@ static void fused_fill(FusedArgs& a, const void* x, int x_div, const void* theta
     for (int l = 0; l < FMAXNH; ++l) a.h[l] = l < n_hidden ? hidden[l] : 0;
 }
 
-#ifdef PACOH_EXP_BWD_MINW3
-constexpr int BWD_MINW = 3;
-#else
-constexpr int BWD_MINW = 2;
-#endif
+constexpr int BWD_MINW = 2;                   // (168 registers: three waves per SIMD fit anyway; forcing 128 spills)
 // M is applied to the parenthesised kernel instantiation (the commas of the template arguments must not split macro arguments)
 #define PACOH_FUSED_DISPATCH(KERNEL, nh, pb, M)                                                          \
     do {                                                                                                 \
