@@ -98,10 +98,11 @@ __device__ __forceinline__ float wave_sum_(float v) {
 // the inverse of its factor: on exit Z = L^-1 (accumulator layout, zeros above the diagonal).  nId = -identity.  The diagonal of L
 // is multiplied into `dprod` (lane (r, g = r>>2) takes L[r][r], the other lanes 1) for the log-determinant; a pivot that is not
 // positive turns its lane's product into NaN (q * rsq(q)), which is also how the caller notices the failure.
-// What is NOT computed: the entries of L^T above the 4-column panel being eliminated are left as they fall out of the
-// substitution (garbage): they only ever meet rows of Z that are still zero, or produce rows of the product nobody reads.
+// What is NOT computed: the entries of L above the 4-column panel being eliminated are left as they fall out of the
+// substitution (garbage): they only ever produce rows of L Z that have been consumed already.
 __device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const f32x4& nId, int r, int g) {
-    f32x4 Lt = {0.f, 0.f, 0.f, 0.f};                        // L^T in accumulator layout: register s of lane (r, g) = L[r][4g+s]
+    f32x4 Tn = nId;                                         // -E + L Z, built up by one rank-4 MFMA per step (see below)
+    float dsel = 1.0f;                                      // L[r][r] in the lanes g == r >> 2
     Z = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -132,25 +133,33 @@ __device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const
         const float x1 = fmaf(-x0, l10, rt1) * r1;
         const float x2 = fmaf(-x1, l21, fmaf(-x0, l20, rt2)) * r2;
         const float x3 = fmaf(-x2, l32, fmaf(-x1, l31, fmaf(-x0, l30, rt3))) * r3;
-        if (g == k) { Lt[0] = x0; Lt[1] = x1; Lt[2] = x2; Lt[3] = x3; }
+        const float xg = g == 0 ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));      // L[r][4k+g]
         if (k < 3) {                                         // Cn[i][j] += sum_c X[i][c] X[j][c] for i, j >= 4k+4: one MFMA
-            const float xg = g == 0 ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));
             const float am = r >= 4 * k + 4 ? xg : 0.0f;
             Cn = mfma_(am, am, Cn);
         }
-        // rows 4k..4k+3 of L^-1: Lp Z_k = E_k - (L Z)[k-th block row]   (columns >= 4k of L meet zero rows of Z)
-        f32x4 Yn = nId;                                      // Yn = -E + L Z; in the lanes g == k, -E_k is what nId holds
-        if (k > 0) Yn = mmT(Lt, Z, Yn);
+        // rows 4k..4k+3 of L^-1: Lp Z_k = E_k - (L Z)[k-th block row]; the lanes g == k hold that block row of Tn = -E + L Z
         if (g == k) {
-            const float z0 = -Yn[0] * r0;
-            const float z1 = fmaf(-z0, l10, -Yn[1]) * r1;
-            const float z2 = fmaf(-z1, l21, fmaf(-z0, l20, -Yn[2])) * r2;
-            const float z3 = fmaf(-z2, l32, fmaf(-z1, l31, fmaf(-z0, l30, -Yn[3]))) * r3;
+            const int c = r & 3;
+            dsel = c == 0 ? x0 : (c == 1 ? x1 : (c == 2 ? x2 : x3));
+            const float z0 = -Tn[0] * r0;
+            const float z1 = fmaf(-z0, l10, -Tn[1]) * r1;
+            const float z2 = fmaf(-z1, l21, fmaf(-z0, l20, -Tn[2])) * r2;
+            const float z3 = fmaf(-z2, l32, fmaf(-z1, l31, fmaf(-z0, l30, -Tn[3]))) * r3;
             Z[0] = z0; Z[1] = z1; Z[2] = z2; Z[3] = z3;
         }
+        if (k < 3) {
+            // Tn += L[:, 4k..4k+3] Z[4k..4k+3, :]: ONE MFMA (k index = the four new columns) -- A[i][kk] = L[i][4k+kk] is xg of lane
+            // (i, kk); B[kk][j] = Z[4k+kk][j] lives in register kk of lane (j, k) and reaches lane (j, kk) by four lane reads.  (Forming
+            // the block row of L Z as a full product with L^T kept in registers took four MFMAs per step for a 4-row result.)
+            const float w0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(Z[0])));
+            const float w1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(Z[1])));
+            const float w2 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(Z[2])));
+            const float w3 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(Z[3])));
+            const float zb = g == 0 ? w0 : (g == 1 ? w1 : (g == 2 ? w2 : w3));
+            Tn = mfma_(xg, zb, Tn);
+        }
     }
-    const int c = r & 3;
-    const float dsel = c == 0 ? Lt[0] : (c == 1 ? Lt[1] : (c == 2 ? Lt[2] : Lt[3]));
     if (g == (r >> 2)) dprod *= dsel;
 }
 
