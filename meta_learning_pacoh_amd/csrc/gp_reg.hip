@@ -1,26 +1,29 @@
 // Register-resident fused task-GP kernel, fp32, n <= 64, f <= 4: one 64-lane wavefront per (task, particle) problem, and the
 // n x n matrix never leaves the VECTOR REGISTERS: every 16x16 block is held in the v_mfma_f32_16x16x4_f32 accumulator layout
 // (lane (r = l&15, g = l>>4), register s  <->  X[4g+s][r]; four registers per block, the upper block triangle = 40 registers).
-// LDS holds only the vectors (features, residual, alpha: ~2 KB per problem), so occupancy is set by registers, not by the 17.9 KB
-// matrix image the LDS-resident kernel (gp_mfma.hip) needs -- that one is latency-bound with two waves per SIMD.
+// LDS holds the vectors (features, residual, alpha) and, between the matrix-core phase and the gradient loop, the six strictly
+// upper blocks of K^-1: 7.7 KB per problem; with 122 registers that is four waves per SIMD.
 //
-// One primitive does all the O(n^3) work.  With the k index of a 16x16x16 product permuted as k = 4g+s, an accumulator-layout
+// fp32 MFMAs and vector instructions share one issue budget on gfx950 (tools/mfma_valu_overlap.hip, tools/valu_rates.hip): the
+// kernel takes 32 cycles x MFMAs + the sum of its vector instructions, so everything below is about doing the work in few of both.
+//
+// One primitive does the O(n^3) work.  With the k index of a 16x16x16 product permuted as k = 4g+s, an accumulator-layout
 // block is directly an MFMA operand: as B it stands for itself, as A for its TRANSPOSE.  So  mmT(X, Y) = X^T Y  maps two
 // register blocks to a register block (4 MFMAs, no memory traffic), and a block is transposed by mmT(X, I).  In terms of the
-// upper factor R = L^T (K = R^T R):
-//   Gram build        U[I][J] = os k(z_i, z_j) (+ noise, jitter on the diagonal), I <= J, straight into accumulator layout
-//   Cholesky          diagonal block: factor16() (4x4 pivot blocks, see below) -> Z_K = L_KK^-1;  V_K = Z_K^T = mmT(Z_K, I)
-//                     panel R[K][J] = L_KK^-1 U[K][J] = mmT(V_K, U[K][J]);  trailing U[I][J] -= R[K][I]^T R[K][J] = mmT(R[K][I], R[K][J])
-//   u = L^-1 r        block forward substitution on replicated vectors: u_K = mmT(V_K, r_K - sum_m R[m][K]^T u_m)
-//   L^-1 (backward)   G[I][J] = -L_II^-1 sum_m L[I][m] G[m][J] = -mmT(V_I, sum_m mmT(R[m][I], G[m][J]))
-//   W = K^-1          W[I][J] = sum_m G[m][I]^T G[m][J] = mmT(G[m][I], G[m][J]);   alpha = L^-T u = sum_I mmT(G[I][K], u_I)
-//   gradient sums     in accumulator layout over the UPPER block triangle only (40 entries per lane instead of 64 rows x
-//                     columns): an off-diagonal entry feeds the row sum of i and the column sum of j; row sums are reduced
-//                     over the 16 lanes of a row by DPP, column sums over the four lane rows by two lane exchanges.
+// upper factor R = L^T (K = R^T R); the not-yet-eliminated blocks are kept NEGATED so that no operand needs negating:
+//   Gram build        U[I][J] = -(os k(z_i, z_j) + (noise, jitter on the diagonal)), I <= J, straight into accumulator layout;
+//                     features pre-scaled so that k = exp2(-|dz|^2): one v_exp_f32 per entry; padding rows = far-away points
+//   Cholesky          diagonal block: factor16() (4x4 pivot blocks, see below) -> Z_K = L_KK^-1;  V_K = -Z_K^T = mmT(Z_K, -I)
+//                     panel R[K][J] = L_KK^-1 A[K][J] = mmT(V_K, U[K][J]);  trailing U[I][J] += mmT(R[K][I], R[K][J])
+//   u = L^-1 r        t = -r_K + sum_m R[m][K]^T u_m on the vector units (mvT_, four fmas per block), u_K = mmT(V_K, t)
+//   L^-1 (backward)   G[I][J] = -L_II^-1 sum_m L[I][m] G[m][J] = mmT(V_I, sum_m mmT(R[m][I], G[m][J]))
+//   W = K^-1          W[I][J] = sum_m G[m][I]^T G[m][J];   alpha = L^-T u = sum_I G[I][K]^T u_I on the vector units
+//   gradient sums     every ordered pair (i, j), column block by column block: what is destined for point j accumulates in the
+//                     lane and needs two lane exchanges per block; diagonal blocks of W are consumed where they are produced
 // factor16(): the 16x16 diagonal block is eliminated four columns at a time -- the 4x4 pivot block reaches every lane by ten
 // v_readlane broadcasts, every lane runs the 4x4 Cholesky in its own registers (rsq -> mul -> fma per pivot), solves its row of
 // the 16x4 panel, the rank-4 trailing update is one MFMA (A operand == B operand), and L_KK^-1 is built alongside by block
-// forward substitution with L_KK^T kept in registers too.
+// forward substitution, its right-hand side -E + L Z likewise by one rank-4 MFMA per step.
 //
 // Same arithmetic as gp_mfma.hip / gp_small.hip; reference lines replaced: random_gp.py:54-89, GPR_meta_mll.py:104-117
 // (ExactMarginalLogLikelihood + autograd through gpytorch).
