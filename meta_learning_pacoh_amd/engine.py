@@ -231,38 +231,54 @@ def capture_graph(body, warmup=2):
 
 class StepMode:
     """Replay the captured step graph(s) or issue the same launches one by one?  The graph wins when Python's ~10 us per launch
-    is what limits the step (PACOH-MAP, small batches); this ROCm's hipGraphLaunch, however, costs its internal submission
-    thread ~10-20 us per kernel node, so for a 12-node step that takes the GPU 0.15 ms the replay is the slower way (0.26 ms
-    against 0.16 ms, tools/host_issue_time.py) while a 0.6 ms step hides it completely.  Both produce identical bits, so the
-    choice is made by timing PROBE steps of each kind on the real training steps.  PACOH_GRAPH=1 / 0 forces a mode."""
+    is what limits the step (PACOH-MAP, small batches, slow hosts); when the host keeps ahead anyway -- a 0.5 ms step issued in
+    0.1 ms -- plain launches are 1-3 % faster on this ROCm (the replay leaves a slightly larger gap between its kernel nodes).  Both
+    produce identical bits, so the choice is made by timing the real training steps: a first look after PROBE steps of each kind
+    (the first steps of a process are not representative: cold host, clocks ramping), a second, longer one once 4 * REPROBE more
+    steps have run; plain launches are only chosen when they win by 3 %.  PACOH_GRAPH=1 / 0 forces a mode."""
     PROBE = 8
+    REPROBE = 16
+    MARGIN = 0.97        # eager launches must beat the replay by 3 %: the replay frees the host (0.01-0.03 ms per step against 0.1-0.2)
 
     def __init__(self):
         self.use_graph = None
         forced = os.environ.get('PACOH_GRAPH', '')
-        if forced in ('0', '1'):
+        self.forced = forced in ('0', '1')
+        if self.forced:
             self.use_graph = forced == '1'
         self.timings = None
+        self._since = 0
+        self._looks = 0
+
+    @staticmethod
+    def _time(step, graphed, n):
+        step(graphed)                                      # (not timed: first-use effects)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n - 1):
+            step(graphed)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (n - 1)
 
     def run(self, n_steps, step):
-        """issue n_steps calls of step(graphed); the first 2 * PROBE of a long enough run decide the mode"""
+        """issue n_steps calls of step(graphed); some of them are timed to decide the mode (see the class comment)"""
         done = 0
-        if self.use_graph is None and n_steps >= 3 * self.PROBE:
-            t = []
-            for graphed in (False, True):
-                step(graphed)                                  # (not timed: first-use effects)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(self.PROBE - 1):
-                    step(graphed)
-                torch.cuda.synchronize()
-                t.append((time.perf_counter() - t0) / (self.PROBE - 1))
-            self.timings = {'eager_ms': t[0] * 1e3, 'graph_ms': t[1] * 1e3}
-            self.use_graph = t[1] < t[0]
-            done = 2 * self.PROBE
+        if not self.forced:
+            n = 0
+            if self._looks == 0 and n_steps >= 3 * self.PROBE:
+                n = self.PROBE
+            elif self._looks == 1 and self._since >= 4 * self.REPROBE and n_steps >= 3 * self.REPROBE:
+                n = self.REPROBE
+            if n:
+                t = [self._time(step, graphed, n) for graphed in (False, True)]
+                self.timings = {'eager_ms': t[0] * 1e3, 'graph_ms': t[1] * 1e3, 'steps_each': n}
+                self.use_graph = not (t[0] < self.MARGIN * t[1])
+                self._looks += 1
+                done = 2 * n
         graphed = True if self.use_graph is None else self.use_graph
         for _ in range(n_steps - done):
             step(graphed)
+        self._since += n_steps
 
 
 class NotPSDError(RuntimeError):
