@@ -58,23 +58,33 @@ __device__ __forceinline__ f32x4 fmfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// zero-padded weights of one particle's network -> LDS
+// tanh(y) = 1 - 2 / (1 + exp2(TSC y)), TSC = 2 log2(e).  The weights and biases of every tanh layer are multiplied by TSC when
+// they are copied to LDS, so the matrix cores deliver the exp2 argument itself and an activation costs v_exp + v_add + v_rcp +
+// v_fma (one instruction less, on each of the 64 activations per lane, tile and pass).  The backward pass multiplies by the
+// SCALED hidden weights in its delta recursion, so delta_l comes out as TSC^(NH - l) times the true one (l = 1..NH): the
+// accumulated weight gradients are scaled back once, where the slab is written.
+constexpr float TSC = 2.8853900817779268f, INV_TSC = 0.34657359027997264f;
+__device__ __forceinline__ float tanh_pre(float a) {
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)), 1.0f);
+}
+
+// zero-padded weights of one particle's network -> LDS (tanh layers pre-multiplied by TSC)
 template <int NH>
 __device__ void fused_load_weights(float* wl, const float* __restrict__ th, const FusedArgs& a, int d_out) {
     for (int q = threadIdx.x; q < f_welems(NH); q += blockDim.x) wl[q] = 0.0f;
     __syncthreads();
     int src = 0;
     const int h0 = a.h[0], d_in = a.d_in;
-    for (int q = threadIdx.x; q < h0; q += blockDim.x) wl[F_OFF_B1 + q] = th[q];
-    for (int q = threadIdx.x; q < h0 * d_in; q += blockDim.x) { const int o = q / d_in, k = q - o * d_in; wl[F_OFF_W1 + o * 4 + k] = th[h0 + q]; }
+    for (int q = threadIdx.x; q < h0; q += blockDim.x) wl[F_OFF_B1 + q] = TSC * th[q];
+    for (int q = threadIdx.x; q < h0 * d_in; q += blockDim.x) { const int o = q / d_in, k = q - o * d_in; wl[F_OFF_W1 + o * 4 + k] = TSC * th[h0 + q]; }
     src += h0 * (d_in + 1);
     int prev = h0;
 #pragma unroll
     for (int l = 1; l < NH; ++l) {
         const int hl = a.h[l];
         float* dst = wl + F_OFF_H + (l - 1) * HBLK;
-        for (int q = threadIdx.x; q < hl; q += blockDim.x) dst[32 * LWH + q] = th[src + q];
-        for (int q = threadIdx.x; q < hl * prev; q += blockDim.x) { const int o = q / prev, k = q - o * prev; dst[o * LWH + k] = th[src + hl + q]; }
+        for (int q = threadIdx.x; q < hl; q += blockDim.x) dst[32 * LWH + q] = TSC * th[src + q];
+        for (int q = threadIdx.x; q < hl * prev; q += blockDim.x) { const int o = q / prev, k = q - o * prev; dst[o * LWH + k] = TSC * th[src + hl + q]; }
         src += hl * (prev + 1);
         prev = hl;
     }
@@ -133,7 +143,7 @@ __device__ __forceinline__ void f_layer1(const float* wl, const float* st, int r
         for (int pb = 0; pb < PB; ++pb) {
             f32x4 acc = fmfma(aw, bx[pb], bias);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc[s] = act_tanh<float>(acc[s]);
+            for (int s = 0; s < 4; ++s) acc[s] = tanh_pre(acc[s]);
             H[fb][pb] = acc;
         }
     }
@@ -163,7 +173,7 @@ __device__ __forceinline__ void f_hidden(const float* W, int r, int g, const f32
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) OUT[ob][pb][s] = act_tanh<float>(OUT[ob][pb][s]);
+            for (int s = 0; s < 4; ++s) OUT[ob][pb][s] = tanh_pre(OUT[ob][pb][s]);
     }
 }
 
@@ -359,13 +369,17 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
     auto rg = [](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
     float* dst = nt.slab + ((long)(blockIdx.x * 4 + wave) * a.P + p) * nt.D_net;
     const int d_in = a.d_in, h0 = a.h[0];
+    float unscale[NH];                                 // layer j+1's delta carries TSC^(NH-1-j) (see tanh_pre)
+    unscale[NH - 1] = 1.0f;
+#pragma unroll
+    for (int j = NH - 2; j >= 0; --j) unscale[j] = unscale[j + 1] * INV_TSC;
 #pragma unroll
     for (int fb = 0; fb < 2; ++fb) {
         const int o = fb * 16 + r;
-        const float b = rg(aB1[fb]);
+        const float b = rg(aB1[fb]) * unscale[0];
         if (g == 0 && o < h0) dst[o] = b;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const float v = rg(aW1[fb][k]); if (g == 0 && o < h0 && k < d_in) dst[h0 + o * d_in + k] = v; }
+        for (int k = 0; k < 4; ++k) { const float v = rg(aW1[fb][k]) * unscale[0]; if (g == 0 && o < h0 && k < d_in) dst[h0 + o * d_in + k] = v; }
     }
     int off = h0 * (d_in + 1), prev = h0;
 #pragma unroll
@@ -373,14 +387,14 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
         const int hl = a.h[l];
 #pragma unroll
         for (int ob = 0; ob < 2; ++ob) {
-            const float b = rg(aBh[l - 1][ob]);
+            const float b = rg(aBh[l - 1][ob]) * unscale[l];
             if (g == 0 && ob * 16 + r < hl) dst[off + ob * 16 + r] = b;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int o = ob * 16 + 4 * g + s, k = kb * 16 + r;
-                    if (o < hl && k < prev) dst[off + hl + o * prev + k] = aW[l - 1][ob][kb][s];
+                    if (o < hl && k < prev) dst[off + hl + o * prev + k] = aW[l - 1][ob][kb][s] * unscale[l];
                 }
         }
         off += hl * (prev + 1);
