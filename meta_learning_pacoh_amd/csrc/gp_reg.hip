@@ -1,4 +1,4 @@
-// Register-resident fused task-GP kernel, fp32, n <= 64, f <= 4: one 64-lane wavefront per (task, particle) problem, and the
+// Register-resident fused task-GP kernel, fp32, n <= 128, f <= 4: one 64-lane wavefront per (task, particle) problem, and the
 // n x n matrix never leaves the VECTOR REGISTERS: every 16x16 block is held in the v_mfma_f32_16x16x4_f32 accumulator layout
 // (lane (r = l&15, g = l>>4), register s  <->  X[4g+s][r]; four registers per block, the upper block triangle = 40 registers).
 // LDS holds the vectors (features, residual, alpha) and, between the matrix-core phase and the gradient loop, the six strictly
@@ -184,7 +184,7 @@ __host__ __device__ constexpr int uidx(int NB, int K, int J) { return K * NB - K
 
 // waves per SIMD the register allocation aims at: 4 (the n <= 64, f <= 2 backward kernel needs 122 registers and 7.7 KB of LDS);
 // with f <= 4 the n = 64 kernels need 168 - 186 registers (3 resp. 2 waves)
-#define GPR_MINW(NB, FP, BWD) ((NB) == 4 && (FP) == 4 ? ((BWD) ? 2 : 3) : 4)
+#define GPR_MINW(NB, FP, BWD) ((NB) > 4 ? 1 : ((NB) == 4 && (FP) == 4 ? ((BWD) ? 2 : 3) : 4))
 template <int NB, int FP, bool BWD>
 __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfmaArgs a) {
     constexpr int NP = 16 * NB;
@@ -222,30 +222,34 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     const float os = a.os ? a.os[p] : 1.0f;
     const float noise = a.noise[p];
 
-    // ---- features (pre-divided by the lengthscale) and residual, lane i = row i -------------------------------------------
-    const int i = lane;
-    float zs[FP];
+    // ---- features (pre-divided by the lengthscale) and residual, lane l = rows l, l + 64, ... --------------------------------
+    constexpr int RPL = (NP + 63) / 64;                       // rows per lane (1 up to n = 64)
 #pragma unroll
-    for (int c = 0; c < FP; ++c) zs[c] = 0.0f;
-    float ri = 0.0f;
-    // Padding rows (nv <= i < 16 NB) must come out as rows of the identity.  They are placed far away from every other point --
-    // each at its own distance, so that exp2(-|dz|^2) is exactly 0 against anything else -- instead of masking 104 entries per lane
-    // with compares the compiler hoists out of the retry loop into scalar registers it does not have.
-    zs[0] = 1e10f * (float)(i + 1);
-    if (i < nv) {
-        zs[0] = 0.0f;
-        const float* zp = a.z + ((long)(blockIdx.x / (unsigned)a.z_div) * n + i) * (long)f;
+    for (int rr = 0; rr < RPL; ++rr) {
+        const int i = lane + 64 * rr;
+        float zs[FP];
 #pragma unroll
-        for (int c = 0; c < FP; ++c) if (c < f) zs[c] = zp[c] * kls[c];
-        float mi = 0.0f;
-        if (a.mean_mode == PACOH_MEAN_VECTOR) mi = a.mean[b * n + i];
-        else if (a.mean_mode == PACOH_MEAN_CONST) mi = a.mean[p];
-        ri = a.y[ty * n + i] - mi;
-    }
-    if (i < NP) {
+        for (int c = 0; c < FP; ++c) zs[c] = 0.0f;
+        float ri = 0.0f;
+        // Padding rows (nv <= i < 16 NB) must come out as rows of the identity.  They are placed far away from every other point --
+        // each at its own distance, so that exp2(-|dz|^2) is exactly 0 against anything else -- instead of masking 104 entries per
+        // lane with compares the compiler hoists out of the retry loop into scalar registers it does not have.
+        zs[0] = 1e10f * (float)(i + 1);
+        if (i < nv) {
+            zs[0] = 0.0f;
+            const float* zp = a.z + ((long)(blockIdx.x / (unsigned)a.z_div) * n + i) * (long)f;
 #pragma unroll
-        for (int c = 0; c < FP; ++c) zf[i * FP + c] = zs[c];
-        rv[i] = ri;
+            for (int c = 0; c < FP; ++c) if (c < f) zs[c] = zp[c] * kls[c];
+            float mi = 0.0f;
+            if (a.mean_mode == PACOH_MEAN_VECTOR) mi = a.mean[b * n + i];
+            else if (a.mean_mode == PACOH_MEAN_CONST) mi = a.mean[p];
+            ri = a.y[ty * n + i] - mi;
+        }
+        if (i < NP) {
+#pragma unroll
+            for (int c = 0; c < FP; ++c) zf[i * FP + c] = zs[c];
+            rv[i] = ri;
+        }
     }
     WSYNC();
 
@@ -457,17 +461,24 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     }
     WSYNC();
     const float bad = okf ? 0.0f : NAN;
-    const float ai = i < NP ? av[i] : 0.0f;
     float* d_z_p = LATE(d_z);
-    if (d_z_p && i < n) {
-        for (int c = 0; c < f; ++c)
-            d_z_p[(b * n + i) * (long)f + c] = (i < nv) ? (2.0f * INV_KAPPA2) * gup * dzc[i * FP + c] * kls[c] + bad : 0.0f;
+    float asum = 0.0f;
+#pragma unroll
+    for (int rr = 0; rr < RPL; ++rr) {
+        const int i = lane + 64 * rr;
+        const float ai = i < NP ? av[i] : 0.0f;
+        if (d_z_p && i < n) {
+            for (int c = 0; c < f; ++c)
+                d_z_p[(b * n + i) * (long)f + c] = (i < nv) ? (2.0f * INV_KAPPA2) * gup * dzc[i * FP + c] * kls[c] + bad : 0.0f;
+        }
+        if (a.mean_mode == PACOH_MEAN_VECTOR) {
+            float* d_mean_p = LATE(d_mean);
+            if (d_mean_p && i < n) d_mean_p[b * n + i] = (i < nv) ? gup * ai / (float)nv + bad : 0.0f;
+        }
+        asum += (i < nv) ? ai : 0.0f;
     }
-    if (a.mean_mode == PACOH_MEAN_VECTOR) {
-        float* d_mean_p = LATE(d_mean);
-        if (d_mean_p && i < n) d_mean_p[b * n + i] = (i < nv) ? gup * ai / (float)nv + bad : 0.0f;
-    } else if (a.mean_mode == PACOH_MEAN_CONST) {
-        const float sa = wave_sum_((i < nv) ? ai : 0.0f);
+    if (a.mean_mode == PACOH_MEAN_CONST) {
+        const float sa = wave_sum_(asum);
         float* d_mean_p = LATE(d_mean);
         if (d_mean_p && lane == 0) d_mean_p[b] = nv > 0 ? gup * sa / (float)nv + bad : 0.0f;
     }
@@ -497,15 +508,18 @@ static int launch_reg(const GpMfmaArgs& a, int FP, hipStream_t s) {
     return launch_status();
 }
 
-// returns 1 if this path does not apply (n > 64, f > 4, or PACOH_GP_REG=0)
+// returns 1 if this path does not apply (n > 128, f > 4, or PACOH_GP_REG=0)
 int gp_reg_try(const GpMfmaArgs& a, bool bwd, hipStream_t s) {
     const char* e = getenv("PACOH_GP_REG");
     if (e && e[0] == '0') return 1;
-    if (a.n > 64 || a.f > 4 || a.n < 1) return 1;
+    // (n > 64: one wave still holds the whole matrix -- 240 registers + 148 accumulation registers at n = 128, one wave per SIMD --
+    //  and beats the LDS-resident kernel, which also runs one wave per SIMD there but moves every block through LDS: 2.4x at n = 128)
+    static const int max_n = []() { const char* m = getenv("PACOH_GP_REG_MAX_N"); return m && m[0] ? atoi(m) : 128; }();
+    if (a.n > max_n || a.n > 128 || a.f > 4 || a.n < 1) return 1;
     const int NB = (a.n + 15) / 16;
     const int FP = a.f <= 2 ? 2 : 4;
 #define PACOH_GPR_NB(nb) case nb: return bwd ? launch_reg<nb, true>(a, FP, s) : launch_reg<nb, false>(a, FP, s);
-    switch (NB) { PACOH_GPR_NB(1) PACOH_GPR_NB(2) PACOH_GPR_NB(3) default: PACOH_GPR_NB(4) }
+    switch (NB) { PACOH_GPR_NB(1) PACOH_GPR_NB(2) PACOH_GPR_NB(3) PACOH_GPR_NB(4) case 5: PACOH_GPR_NB(6) default: PACOH_GPR_NB(8) }
 #undef PACOH_GPR_NB
 }
 
