@@ -154,9 +154,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # (at least 3 x StepMode.PROBE untimed steps: the learners time graph replay against eager launches on their first steps and
-    #  keep the faster -- that decision must not fall into the timed region)
-    wl['run'](max(24, args.warmup))
+    # (enough untimed steps for the learners' first look at graph replay vs plain launches -- engine.StepMode -- and, in the chunks
+    #  below, their second: neither decision falls into the timed region)
+    wl['run'](max(32, args.warmup))
     barrier()
     # A fresh box needs a second or two of the real launch path before it issues steps at its steady rate (first process after boot:
     # hipGraphLaunch measured at 0.18 ms per step against 0.03 ms a minute later, enough to starve a 0.5 ms step).  More untimed steps,

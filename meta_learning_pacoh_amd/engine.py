@@ -236,8 +236,8 @@ class StepMode:
     produce identical bits, so the choice is made by timing the real training steps: a first look after PROBE steps of each kind
     (the first steps of a process are not representative: cold host, clocks ramping), a second, longer one once 4 * REPROBE more
     steps have run; plain launches are only chosen when they win by 3 %.  PACOH_GRAPH=1 / 0 forces a mode."""
-    PROBE = 8
-    REPROBE = 16
+    PROBE = 6
+    REPROBE = 12
     MARGIN = 0.97        # eager launches must beat the replay by 3 %: the replay frees the host (0.01-0.03 ms per step against 0.1-0.2)
 
     def __init__(self):
@@ -265,16 +265,18 @@ class StepMode:
         done = 0
         if not self.forced:
             n = 0
-            if self._looks == 0 and n_steps >= 3 * self.PROBE:
+            if self._looks == 0 and n_steps >= 5 * self.PROBE:
                 n = self.PROBE
-            elif self._looks == 1 and self._since >= 4 * self.REPROBE and n_steps >= 3 * self.REPROBE:
+            elif self._looks == 1 and self._since >= 4 * self.REPROBE and n_steps >= 4 * self.REPROBE:
                 n = self.REPROBE
             if n:
-                t = [self._time(step, graphed, n) for graphed in (False, True)]
+                # (each kind twice, interleaved, the faster sample counts: one hiccup of the host or the clocks during a handful of
+                #  steps must not decide the mode for the rest of the run)
+                t = [min(pair) for pair in zip(*[[self._time(step, graphed, n) for graphed in (False, True)] for _ in range(2)])]
                 self.timings = {'eager_ms': t[0] * 1e3, 'graph_ms': t[1] * 1e3, 'steps_each': n}
                 self.use_graph = not (t[0] < self.MARGIN * t[1])
                 self._looks += 1
-                done = 2 * n
+                done = 4 * n
         graphed = True if self.use_graph is None else self.use_graph
         for _ in range(n_steps - done):
             step(graphed)

@@ -20,7 +20,7 @@ for mode in ('eager', 'graph', 'eager', 'graph'):          # (alternating: the f
         os.environ['PACOH_NO_GRAPH'] = '1'
     else:
         os.environ.pop('PACOH_NO_GRAPH', None)
-    model._step_mode.use_graph = mode == 'graph'
+    model._step_mode.use_graph, model._step_mode.forced = mode == 'graph', True
     model._train_steps(20)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
