@@ -314,6 +314,17 @@ int pacoh_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_
 int pacoh_adam_step_dev(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, const void* scalars,
                         double beta1, double beta2, long count, int64_t* step_counter, int dtype, void* stream);
 
+/* The update half of a captured PACOH-VI step (diagonal posterior, Adam) in one launch: pre-factor scalars[PACOH_SC_SCORE_SCALE] on
+ * the likelihood score[S,D] and values lik[S] (both left untouched), hyper-prior score and log-density at theta[S,D], the ELBO value
+ * -> loss_out[1], the reparameterisation gradient of pacoh_vi_grad and the Adam step of pacoh_adam_step_dev on posterior[2,D]
+ * (GPR_meta_vi.py:216-224, 258-261); step_counter as for pacoh_adam_step_dev.  workspace: pacoh_vi_update_dev_workspace_bytes(),
+ * zeroed by the caller before the first use (every launch leaves it ready for the next). */
+size_t pacoh_vi_update_dev_workspace_bytes(int D, int dtype);
+int pacoh_vi_update_dev(void* posterior, const void* eps, const void* theta, const void* score, const void* lik,
+                        const void* log_q, const void* prior_mean, const void* prior_std, double prior_factor,
+                        const void* scalars, double beta1, double beta2, void* exp_avg, void* exp_avg_sq, void* loss_out,
+                        int64_t* step_counter, void* workspace, int S, int D, int dtype, void* stream);
+
 /* y += alpha * x: the plain SGD update of the optimizer='SGD' option (torch.optim.SGD(lr), GPR_meta_mll.py:257). */
 int pacoh_axpy(void* y, const void* x, double alpha, long count, int dtype, void* stream);
 

@@ -6,6 +6,7 @@ ELBO gradient needs only the per-sample score from the device engine:
   dloss/dloc = -mean_s score_s;   dloss/dscale = -mean_s (score_s * exp(scale) * eps_s + prior_factor)
   dloss/dL_ij = -mean_s score_si eps_sj - [i == j] prior_factor / L_ii   (j <= i; zero above the diagonal)."""
 import math
+import os
 import time
 
 import torch
@@ -107,6 +108,7 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         self._packed, self._score, self._lik = parallel.packed_score_buffer(S, D, self.dtype, self.device)
         self._fail = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._loss = torch.zeros((), dtype=self.dtype, device=self.device)
+        self._vi_ws = L.vi_update_workspace(self.posterior)
         chunk = max(1, min(self.GRAPH_CHUNK, (64 << 20) // (S * D * 4)))         # the noise of a chunk stays below 64 MB
         self._feed = StepFeed(self.device, self.dtype, tb_local, chunk=chunk, aux_shape=(S, D))
         self._graphs = None
@@ -123,6 +125,11 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
 
     def _body_update(self):
         S = self.svi_batch_size
+        if self.cov_type == 'diag' and os.environ.get('PACOH_VI_UNFUSED') != '1':      # (Adam: _train_steps is only used with it)
+            L.vi_update_dev(self.posterior, self._feed.aux, self._theta, self._score, self._lik, self._log_q, self.prior_mean,
+                            self.prior_std, self.prior_factor, self._feed.sc, self.exp_avg, self.exp_avg_sq, self._loss,
+                            self._vi_ws, step_counter=self._feed.ctr)
+            return
         L.scale_dev(self._packed, self._feed.sc[L.SC_SCORE_SCALE:L.SC_SCORE_SCALE + 1])      # pre-factor on score and likelihood
         logprior = L.prior_logprob_grad(self._theta, self.prior_mean, self.prior_std, self._score, self.prior_factor)
         L.axpy(self._lik, logprior, self.prior_factor)

@@ -66,6 +66,8 @@ SIGNATURES = {
     'pacoh_svgd_phi_imq': (_i, [_vp, _vp, _d, _d, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_adam_step': (_i, [_vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _l, _l, _i, _vp]),
     'pacoh_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _l, _vp, _i, _vp]),
+    'pacoh_vi_update_dev_workspace_bytes': (_sz, [_i, _i]),
+    'pacoh_vi_update_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_axpy': (_i, [_vp, _vp, _d, _l, _i, _vp]),
     'pacoh_vi_sample': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_vi_grad': (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _vp]),
@@ -665,6 +667,26 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, scalars, beta1=0.9, beta2=0.
         _check(lib.pacoh_adam_step_dev(_ptr(param), _ptr(grad, param), _ptr(exp_avg, param), _ptr(exp_avg_sq, param),
                                        _ptr(scalars, param), float(beta1), float(beta2), param.numel(), _ptr(step_counter),
                                        dtype_code(param), _stream()), 'pacoh_adam_step_dev')
+
+
+def vi_update_dev(posterior, eps, theta, score, lik, log_q, prior_mean, prior_std, prior_factor, scalars, exp_avg, exp_avg_sq,
+                  loss_out, workspace, step_counter=None, beta1=0.9, beta2=0.999):
+    """update half of a PACOH-VI step (diagonal posterior, Adam) in one launch: pacoh_vi_update_dev in include/pacoh_gp.h;
+    workspace = vi_update_workspace(posterior), allocated (zeroed) once"""
+    lib = load_library()
+    S, D = theta.shape
+    with _Timed('vi_update'):
+        _check(lib.pacoh_vi_update_dev(_ptr(posterior), _ptr(eps, posterior), _ptr(theta, posterior), _ptr(score, posterior),
+                                       _ptr(lik, posterior), _ptr(log_q, posterior), _ptr(prior_mean, posterior),
+                                       _ptr(prior_std, posterior), float(prior_factor), _ptr(scalars, posterior), float(beta1),
+                                       float(beta2), _ptr(exp_avg, posterior), _ptr(exp_avg_sq, posterior), _ptr(loss_out, posterior),
+                                       _ptr(step_counter), _ptr(workspace), S, D, dtype_code(posterior), _stream()), 'pacoh_vi_update_dev')
+
+
+def vi_update_workspace(posterior):
+    lib = load_library()
+    need = lib.pacoh_vi_update_dev_workspace_bytes(posterior.shape[1], dtype_code(posterior))
+    return torch.zeros(need, dtype=torch.uint8, device=posterior.device)
 
 
 def axpy(y, x, alpha):

@@ -459,6 +459,76 @@ __global__ void vi_grad_kernel(const T* __restrict__ post, const T* __restrict__
     grad[D + d] = -gs / T(S);
 }
 
+// The whole update half of a PACOH-VI step (diagonal posterior, Adam) in ONE launch -- pre-factor on the likelihood score, hyper-prior
+// score and log-density, ELBO value, reparameterisation gradient (vi_grad_kernel) and the Adam step with its scalars from device
+// memory: the seven launches it replaces cost ~5 us each between dependent kernels, more than their work.  sc = a step-scalar row
+// (PACOH_SC_*).  One thread per dimension d; the scalar loss from per-block partial sums, combined in block order by the last block to finish.
+//   s~[s,d]   = sc[0] score[s,d] - prior_factor (theta[s,d] - mu[d]) / sd[d]^2
+//   grad_loc  = -mean_s s~[s,d];   grad_scale = -mean_s (s~[s,d] exp(scale[d]) eps[s,d] + prior_factor)          (GPR_meta_vi.py:216-224)
+//   loss      = -mean_s (sc[0] lik[s] + prior_factor log N(theta_s; mu, sd)) + prior_factor mean_s log_q[s]
+template <typename T>
+__global__ void __launch_bounds__(256) vi_update_kernel(T* __restrict__ post, const T* __restrict__ eps, const T* __restrict__ theta,
+                                                        const T* __restrict__ score, const T* __restrict__ lik, const T* __restrict__ log_q,
+                                                        const T* __restrict__ mu, const T* __restrict__ sd, T prior_factor,
+                                                        const T* __restrict__ sc, T one_minus_b1, T b2, T one_minus_b2,
+                                                        T* __restrict__ m, T* __restrict__ v, T* __restrict__ loss,
+                                                        long* __restrict__ step_counter, T* __restrict__ partial /*[gridDim.x]*/,
+                                                        unsigned* __restrict__ ticket, int S, int D) {
+    __shared__ T red[4];
+    __shared__ bool last_s;
+    const T pref = sc[0];
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && step_counter) *step_counter += 1;
+    T lp = 0;                                          // this dimension's share of sum_s log N(theta_s; mu, sd)
+    if (d < D) {
+        const T sig = t_exp<T>(post[D + d]);
+        const T md = mu[d], sdv = sd[d];
+        const T pscale = prior_factor / (sdv * sdv);
+        const T lconst = t_log<T>(sdv) + T(0.9189385332046727);
+        T gl = 0, gs = 0;
+        for (int s_ = 0; s_ < S; ++s_) {
+            const long q = (long)s_ * D + d;
+            const T dv = theta[q] - md, zv = dv / sdv;
+            lp += T(-0.5) * zv * zv - lconst;
+            const T st = pref * score[q] - pscale * dv;
+            gl += st;
+            gs += st * sig * eps[q] + prior_factor;
+        }
+        const T decay_mul = sc[4], step_size = sc[5], bc2_sqrt = sc[6], epsv = sc[7];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                  // loc, then log-scale: the op order of adam_dev_kernel
+            const long q = (long)h * D + d;
+            const T g = -(h == 0 ? gl : gs) / T(S);
+            T p = post[q] * decay_mul;
+            T mq = m[q];
+            mq = mq + (g - mq) * one_minus_b1;
+            const T vq = v[q] * b2 + one_minus_b2 * g * g;
+            const T denom = t_sqrt<T>(vq) / bc2_sqrt + epsv;
+            p = p - step_size * (mq / denom);
+            post[q] = p; m[q] = mq; v[q] = vq;
+        }
+    }
+    // ---- the loss (a logged value): block partials of the log-prior, combined in block order by whichever block finishes last
+    lp = subwave_sum<T>(lp, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lp;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        __threadfence();
+        last_s = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last_s && threadIdx.x == 0) {
+        __threadfence();
+        T tot = 0, lq = 0;
+        for (unsigned k = 0; k < gridDim.x; ++k) tot += ((volatile T*)partial)[k];
+        tot *= prior_factor;
+        for (int s_ = 0; s_ < S; ++s_) { tot += pref * lik[s_]; lq += log_q[s_]; }
+        *loss = (prior_factor * lq - tot) / T(S);
+        *ticket = 0;                                   // (ready for the next launch / replay)
+    }
+}
+
 // y += alpha * x  (plain SGD step of the optimizer='SGD' option)
 template <typename T>
 __global__ void axpy_kernel(T* __restrict__ y, const T* __restrict__ x, T alpha, long count) {
@@ -884,6 +954,34 @@ extern "C" int pacoh_vi_grad(const void* posterior, const void* eps, const void*
     else
         hipLaunchKernelGGL(vi_grad_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)posterior, (const double*)eps,
                            (const double*)score, prior_factor, (double*)grad, S, D);
+    return launch_status();
+}
+
+extern "C" size_t pacoh_vi_update_dev_workspace_bytes(int D, int dtype) {
+    return D > 0 ? 16 + (size_t)((D + 255) / 256) * (dtype == PACOH_F64 ? 8 : 4) : 0;
+}
+
+extern "C" int pacoh_vi_update_dev(void* posterior, const void* eps, const void* theta, const void* score, const void* lik,
+                                   const void* log_q, const void* prior_mean, const void* prior_std, double prior_factor,
+                                   const void* scalars, double beta1, double beta2, void* exp_avg, void* exp_avg_sq, void* loss_out,
+                                   int64_t* step_counter, void* workspace, int S, int D, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!posterior || !eps || !theta || !score || !lik || !log_q || !prior_mean || !prior_std || !scalars || !exp_avg || !exp_avg_sq ||
+        !loss_out || !workspace || S <= 0 || D <= 0) return PACOH_EINVAL;
+    const unsigned blocks = (unsigned)((D + 255) / 256);
+    unsigned* ticket = (unsigned*)workspace;           // [0]: ticket (zero before the first launch; every launch leaves it zero)
+    void* partial = (char*)workspace + 16;             // [16 ..): one partial sum per block
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(vi_update_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)posterior, (const float*)eps,
+                           (const float*)theta, (const float*)score, (const float*)lik, (const float*)log_q, (const float*)prior_mean,
+                           (const float*)prior_std, (float)prior_factor, (const float*)scalars, (float)(1.0 - beta1), (float)beta2,
+                           (float)(1.0 - beta2), (float*)exp_avg, (float*)exp_avg_sq, (float*)loss_out, (long*)step_counter,
+                           (float*)partial, ticket, S, D);
+    else
+        hipLaunchKernelGGL(vi_update_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (double*)posterior, (const double*)eps,
+                           (const double*)theta, (const double*)score, (const double*)lik, (const double*)log_q, (const double*)prior_mean,
+                           (const double*)prior_std, prior_factor, (const double*)scalars, 1.0 - beta1, beta2, 1.0 - beta2,
+                           (double*)exp_avg, (double*)exp_avg_sq, (double*)loss_out, (long*)step_counter, (double*)partial, ticket, S, D);
     return launch_status();
 }
 

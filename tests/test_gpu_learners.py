@@ -707,3 +707,19 @@ def test_svgd_with_more_than_64_particles(M, monkeypatch):
     assert torch.equal(runs[0], runs[1])
     with pytest.raises(AssertionError):
         M.GPRegressionMetaLearnedSVGD(tasks, num_particles=80, kernel='IMQ', random_seed=5)
+
+
+def test_vi_fused_update_equals_the_launch_sequence_it_replaces(M, monkeypatch):
+    """pacoh_vi_update_dev (pre-factor + hyper-prior score and density + ELBO value + reparameterisation gradient + Adam in one
+    launch) against the seven launches it replaces, over a few steps of the same learner"""
+    tasks = O.sinusoid_tasks_nd(8, 10, 1, seed0=60)
+    out = []
+    for unfused in ('1', '0'):
+        monkeypatch.setenv('PACOH_VI_UNFUSED', unfused)
+        monkeypatch.setenv('PACOH_GRAPH', '0')
+        m = M.GPRegressionMetaLearnedVI(tasks, svi_batch_size=4, task_batch_size=3, lr=1e-2, lr_decay=0.9, mean_nn_layers=(8, 8),
+                                        kernel_nn_layers=(8, 8), random_seed=9)
+        loss = m.meta_fit(verbose=False, n_iter=7, log_period=3)
+        out.append((m.posterior.clone(), float(loss)))
+    assert float((out[0][0] - out[1][0]).abs().max()) < 2e-5 * float(out[0][0].abs().max())
+    assert abs(out[0][1] - out[1][1]) < 1e-5 * abs(out[0][1])
