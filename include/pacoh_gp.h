@@ -310,9 +310,12 @@ int pacoh_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_
 
 /* Same update with the step-dependent scalars in DEVICE memory, scalars = {1 - lr*weight_decay, lr/(1-beta1^step),
  * sqrt(1-beta2^step), eps} (4 values of `dtype`), so that the launch can be captured once in a hipGraph and replayed
- * every iteration while the host only refreshes the 4 scalars.  step_counter (optional): advanced by one (see pacoh_step_begin). */
+ * every iteration while the host only refreshes the 4 scalars.  step_counter (optional): advanced by one (see pacoh_step_begin).
+ * loss_cum / loss (optional, one value each): *loss_cum += *loss, the running sum behind the averaged loss the reference logs
+ * (GPR_meta_mll.py:119-125) -- one launch less per PACOH-MAP iteration. */
 int pacoh_adam_step_dev(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, const void* scalars,
-                        double beta1, double beta2, long count, int64_t* step_counter, int dtype, void* stream);
+                        double beta1, double beta2, long count, int64_t* step_counter, void* loss_cum, const void* loss,
+                        int dtype, void* stream);
 
 /* The update half of a captured PACOH-VI step (diagonal posterior, Adam) in one launch: pre-factor scalars[PACOH_SC_SCORE_SCALE] on
  * the likelihood score[S,D] and values lik[S] (both left untouched), hyper-prior score and log-density at theta[S,D], the ELBO value

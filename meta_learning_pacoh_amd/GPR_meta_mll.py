@@ -140,19 +140,22 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         if batch is None:                                  # more ranks than tasks in the batch: this rank contributes zeros
             self._packed.zero_()
             return
-        lml, _, _ = self.engine.lml_and_grad(self.theta, batch, weight=-1.0, grad_out=self._grad, fail_flag=self._fail, hypers=hyp)
-        L.reduce_tasks(lml.reshape(-1, 1, 1), self._g_loss.reshape(1, 1), scale=-1.0)            # loss = -sum_t mll_t
+        # loss = -sum_t mll_t rides in the hyper-parameter reduction (lik_out), the gradient of it in grad_out
+        self.engine.lml_and_grad(self.theta, batch, weight=-1.0, lik_out=self._g_loss, lik_scale=-1.0, grad_out=self._grad,
+                                 fail_flag=self._fail, hypers=hyp)
 
     def _adam_advances(self):
         return self.optimizer_name == 'Adam' and len(self.train_segments) > 0
 
     def _body_update(self):
-        L.axpy(self._g_cum.reshape(1), self._g_loss, 1.0)
+        if not self._adam_advances():
+            L.axpy(self._g_cum.reshape(1), self._g_loss, 1.0)
         for k, (lo, hi) in enumerate(self.train_segments):
             if self.optimizer_name == 'Adam':
-                last = k == len(self.train_segments) - 1
+                last = k == len(self.train_segments) - 1           # (the last launch also advances the feed and sums the loss)
                 L.adam_step_dev(self.theta[0, lo:hi], self._grad[0, lo:hi], self.exp_avg[0, lo:hi], self.exp_avg_sq[0, lo:hi],
-                                self._feed.sc[L.SC_ADAM:L.SC_ADAM + 4], step_counter=self._feed.ctr if last else None)
+                                self._feed.sc[L.SC_ADAM:L.SC_ADAM + 4], step_counter=self._feed.ctr if last else None,
+                                loss_cum=self._g_cum.reshape(1) if last else None, loss=self._g_loss if last else None)
             else:
                 L.axpy(self.theta[0, lo:hi], self._grad[0, lo:hi], -self.lr_scheduler.lr)       # (eager only: host scalar)
 

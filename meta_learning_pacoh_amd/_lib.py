@@ -65,7 +65,7 @@ SIGNATURES = {
     'pacoh_svgd_imq_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_phi_imq': (_i, [_vp, _vp, _d, _d, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_adam_step': (_i, [_vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _l, _l, _i, _vp]),
-    'pacoh_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _l, _vp, _i, _vp]),
+    'pacoh_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _l, _vp, _vp, _vp, _i, _vp]),
     'pacoh_vi_update_dev_workspace_bytes': (_sz, [_i, _i]),
     'pacoh_vi_update_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_axpy': (_i, [_vp, _vp, _d, _l, _i, _vp]),
@@ -661,12 +661,12 @@ def adam_scalars(lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
     return [1.0 - lr * weight_decay, lr / (1.0 - beta1 ** step), (1.0 - beta2 ** step) ** 0.5, eps]
 
 
-def adam_step_dev(param, grad, exp_avg, exp_avg_sq, scalars, beta1=0.9, beta2=0.999, step_counter=None):
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, scalars, beta1=0.9, beta2=0.999, step_counter=None, loss_cum=None, loss=None):
     lib = load_library()
     with _Timed('adam_step'):
         _check(lib.pacoh_adam_step_dev(_ptr(param), _ptr(grad, param), _ptr(exp_avg, param), _ptr(exp_avg_sq, param),
                                        _ptr(scalars, param), float(beta1), float(beta2), param.numel(), _ptr(step_counter),
-                                       dtype_code(param), _stream()), 'pacoh_adam_step_dev')
+                                       _ptr(loss_cum, param), _ptr(loss, param), dtype_code(param), _stream()), 'pacoh_adam_step_dev')
 
 
 def vi_update_dev(posterior, eps, theta, score, lik, log_q, prior_mean, prior_std, prior_factor, scalars, exp_avg, exp_avg_sq,

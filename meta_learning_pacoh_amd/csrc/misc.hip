@@ -407,9 +407,11 @@ __global__ void adam_kernel(T* __restrict__ param, const T* __restrict__ grad, T
 template <typename T>
 __global__ void adam_dev_kernel(T* __restrict__ param, const T* __restrict__ grad, T* __restrict__ m, T* __restrict__ v,
                                 const T* __restrict__ sc, T one_minus_b1, T b2, T one_minus_b2, long count,
-                                long* __restrict__ step_counter = nullptr) {
+                                long* __restrict__ step_counter = nullptr, T* __restrict__ cum = nullptr,
+                                const T* __restrict__ loss = nullptr) {
     long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q == 0 && step_counter) *step_counter += 1;  // the step's last launch also advances the feed (pacoh_step_begin, advance = 0)
+    if (q == 0 && cum) *cum += *loss;                // ... and keeps the running sum of the logged loss (GPR_meta_mll.py:119-125)
     if (q >= count) return;
     const T decay_mul = sc[0], step_size = sc[1], bc2_sqrt = sc[2], eps = sc[3];
     T g = grad[q];
@@ -916,18 +918,19 @@ extern "C" int pacoh_adam_step(void* param, const void* grad, void* exp_avg, voi
 }
 
 extern "C" int pacoh_adam_step_dev(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, const void* scalars,
-                                   double beta1, double beta2, long count, int64_t* step_counter, int dtype, void* stream) {
+                                   double beta1, double beta2, long count, int64_t* step_counter, void* loss_cum, const void* loss,
+                                   int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
-    if (!param || !grad || !exp_avg || !exp_avg_sq || !scalars || count <= 0) return PACOH_EINVAL;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !scalars || count <= 0 || (loss_cum && !loss)) return PACOH_EINVAL;
     unsigned blocks = (unsigned)((count + 255) / 256);
     if (dtype == PACOH_F32)
         hipLaunchKernelGGL(adam_dev_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)param, (const float*)grad,
                            (float*)exp_avg, (float*)exp_avg_sq, (const float*)scalars, (float)(1.0 - beta1), (float)beta2,
-                           (float)(1.0 - beta2), count, (long*)step_counter);
+                           (float)(1.0 - beta2), count, (long*)step_counter, (float*)loss_cum, (const float*)loss);
     else
         hipLaunchKernelGGL(adam_dev_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (double*)param, (const double*)grad,
                            (double*)exp_avg, (double*)exp_avg_sq, (const double*)scalars, 1.0 - beta1, beta2, 1.0 - beta2, count,
-                           (long*)step_counter);
+                           (long*)step_counter, (double*)loss_cum, (const double*)loss);
     return launch_status();
 }
 
