@@ -12,7 +12,7 @@ from . import _lib as L
 from . import parallel
 from .abstract import RegressionModelMetaLearned
 from .distributions import GaussianPredictive
-from .engine import GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, capture_graph
+from .engine import GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, capture_graph, replay_steps, GRAPH_STEPS
 from .modules import apply_initial_values, resolve_covar_module, resolve_mean_module
 from .util import StepLR
 
@@ -167,6 +167,11 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
                 self._body_likelihood()
                 self._body_update()
             self._graphs = (capture_graph(whole),)
+
+            def several():
+                for _ in range(GRAPH_STEPS):
+                    whole()
+            self._graph_many = capture_graph(several)
         else:
             self._graphs = (capture_graph(self._body_likelihood), capture_graph(self._body_update))
         for t, sv in zip(state, saved):
@@ -208,7 +213,9 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
             if graphed and self._graphs is None:
                 self._build_graphs()
             if graphed:
-                self._step_mode.run(k, self._run_step)    # replay or eager launches, whichever is faster here (engine.StepMode)
+                # replay or eager launches, whichever is faster here (engine.StepMode); several steps per replay where possible
+                many = (lambda n: replay_steps(n, self._graphs[0], self._graph_many)) if len(self._graphs) == 1 else None
+                self._step_mode.run(k, self._run_step, many)
             else:
                 for _ in range(k):
                     self._run_step(False)

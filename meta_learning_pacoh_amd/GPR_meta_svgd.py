@@ -12,7 +12,7 @@ from . import _lib as L
 from . import parallel
 from .abstract import RegressionModelMetaLearned
 from .distributions import GaussianPredictive
-from .engine import AsyncUploader, GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, capture_graph
+from .engine import AsyncUploader, GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, capture_graph, replay_steps, GRAPH_STEPS
 from .util import StepLR
 
 
@@ -224,6 +224,11 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
                 self._body_likelihood()
                 self._body_update()
             self._graphs = (capture_graph(whole),)
+
+            def several():
+                for _ in range(GRAPH_STEPS):
+                    whole()
+            self._graph_many = capture_graph(several)
         else:
             self._graphs = (capture_graph(self._body_likelihood), capture_graph(self._body_update))
         for t, sv in zip((self.particles, self.exp_avg, self.exp_avg_sq, self._feed.ctr, self._fail), saved):
@@ -251,7 +256,9 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
             if graphed and self._graphs is None:
                 self._build_graphs()                      # (captured with real operands in the feed; state and counter are restored)
             if graphed:
-                self._step_mode.run(k, self._run_step)    # replay or eager launches, whichever is faster here (engine.StepMode)
+                # replay or eager launches, whichever is faster here (engine.StepMode); several steps per replay where possible
+                many = (lambda n: replay_steps(n, self._graphs[0], self._graph_many)) if len(self._graphs) == 1 else None
+                self._step_mode.run(k, self._run_step, many)
             else:
                 for _ in range(k):
                     self._run_step(False)

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib as L
 from . import parallel
-from .engine import AsyncUploader, StepFeed, StepMode, capture_graph
+from .engine import AsyncUploader, StepFeed, StepMode, capture_graph, replay_steps, GRAPH_STEPS
 from .GPR_meta_svgd import _RandomGPLearner
 from .util import StepLR
 
@@ -150,6 +150,11 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
                 self._body_likelihood()
                 self._body_update()
             self._graphs = (capture_graph(whole),)
+
+            def several():
+                for _ in range(GRAPH_STEPS):
+                    whole()
+            self._graph_many = capture_graph(several)
         else:
             self._graphs = (capture_graph(self._body_likelihood), capture_graph(self._body_update))
         for t, sv in zip(state, saved):
@@ -178,7 +183,9 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
             if graphed and self._graphs is None:
                 self._build_graphs()                      # (captured with real operands in the feed; state and counter are restored)
             if graphed:
-                self._step_mode.run(k, self._run_step)    # replay or eager launches, whichever is faster here (engine.StepMode)
+                # replay or eager launches, whichever is faster here (engine.StepMode); several steps per replay where possible
+                many = (lambda n: replay_steps(n, self._graphs[0], self._graph_many)) if len(self._graphs) == 1 else None
+                self._step_mode.run(k, self._run_step, many)
             else:
                 for _ in range(k):
                     self._run_step(False)

@@ -214,6 +214,21 @@ class StepFeed:
         return batch, hyp
 
 
+GRAPH_STEPS = 4      # steps per graph of the second graph the learners capture at world size 1 (hipGraphLaunch costs the host per
+                     # launch, not per node: 0.006-0.012 ms per step with one step per graph, 0.003 with four -- what keeps the GPU fed
+                     # when the host is busy with somebody else's job; tools/graph_steps_probe.py)
+
+
+def replay_steps(n, graph_one, graph_many):
+    """n steps through graph_many (GRAPH_STEPS steps per replay) and graph_one (the remainder)"""
+    if graph_many is not None:
+        for _ in range(n // GRAPH_STEPS):
+            graph_many.replay()
+        n -= (n // GRAPH_STEPS) * GRAPH_STEPS
+    for _ in range(n):
+        graph_one.replay()
+
+
 def capture_graph(body, warmup=2):
     """hipGraph of body(): warm-up runs on a side stream first (workspaces get allocated outside the graph's pool), then the
     capture; the caller restores whatever state the warm-up runs changed"""
@@ -260,8 +275,9 @@ class StepMode:
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / (n - 1)
 
-    def run(self, n_steps, step):
-        """issue n_steps calls of step(graphed); some of them are timed to decide the mode (see the class comment)"""
+    def run(self, n_steps, step, replay_many=None):
+        """issue n_steps calls of step(graphed); some of them are timed to decide the mode (see the class comment).  replay_many(n)
+        (optional) replays n steps with as few graph launches as the learner has graphs for (several steps per graph)"""
         done = 0
         if not self.forced:
             n = 0
@@ -278,8 +294,11 @@ class StepMode:
                 self._looks += 1
                 done = 4 * n
         graphed = True if self.use_graph is None else self.use_graph
-        for _ in range(n_steps - done):
-            step(graphed)
+        if graphed and replay_many is not None:
+            replay_many(n_steps - done)
+        else:
+            for _ in range(n_steps - done):
+                step(graphed)
         self._since += n_steps
 
 
