@@ -154,7 +154,8 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
             def several():
                 for _ in range(GRAPH_STEPS):
                     whole()
-            self._graph_many = capture_graph(several)
+            # (the large-context path allocates O(tasks x n^2) scratch per step inside the graph's pool: one step per graph there)
+            self._graph_many = capture_graph(several) if self.tasks.n <= 128 else None
         else:
             self._graphs = (capture_graph(self._body_likelihood), capture_graph(self._body_update))
         for t, sv in zip(state, saved):
