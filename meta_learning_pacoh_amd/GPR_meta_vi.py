@@ -36,9 +36,16 @@ def init_vi_posterior_full(D, init_std=0.1):
     return torch.cat([loc.reshape(1, D), tril], dim=0)
 
 
+_NORMAL_ARGS = {}
+
+
 def standard_normal(n, D):
-    """the eps of Normal(loc, scale).rsample((n,)) (torch.distributions: _standard_normal)"""
-    return torch.normal(torch.zeros(n, D), torch.ones(n, D))
+    """the eps of Normal(loc, scale).rsample((n,)) (torch.distributions: _standard_normal): the same call, hence the same use of
+    the CPU generator, as the reference's; its two constant operands are kept between calls"""
+    args = _NORMAL_ARGS.get((n, D))
+    if args is None:
+        args = _NORMAL_ARGS[(n, D)] = (torch.zeros(n, D), torch.ones(n, D))
+    return torch.normal(*args)
 
 
 class GPRegressionMetaLearnedVI(_RandomGPLearner):
