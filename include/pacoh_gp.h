@@ -175,18 +175,23 @@ int pacoh_mlp_bwd(const void* x, int x_div, const void* theta, long theta_stride
 /* The mean network AND the kernel-feature network of one step (VectorizedGP.forward evaluates both on the same inputs,
  * random_gp.py:54-68; LearnedGPRegressionModel.forward, models.py:505-519) in one call: two networks of the SAME hidden
  * shape whose blocks start at element offsets off_a / off_b of the theta rows (theta, d_theta point at the ROW start here).
- * Same semantics as two pacoh_mlp_fwd / pacoh_mlp_bwd calls; on the fused fp32 path it is ONE launch. */
+ * Same semantics as two pacoh_mlp_fwd / pacoh_mlp_bwd calls; on the fused fp32 path it is ONE launch.
+ * Activation stash (what autograd's saved tensors are to the reference's backward, models.py:313-315): `stash` (optional, NULL =
+ * none; pacoh_mlp2_stash_bytes() bytes, 0 = this shape keeps none) receives the top hidden layer's activations from the forward;
+ * handed to the pacoh_mlp2_bwd call of the SAME x / theta / shapes it replaces their recomputation.  Same results either way. */
 size_t pacoh_mlp2_fwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out_a,
                                       int d_out_b, int dtype);
+size_t pacoh_mlp2_stash_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out_a,
+                              int d_out_b, int dtype);
 int pacoh_mlp2_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
                    const int32_t* hidden, int n_hidden, long off_a, int d_out_a, void* out_a, long off_b, int d_out_b,
-                   void* out_b, void* workspace, int B, int n, int dtype, void* stream);
+                   void* out_b, void* workspace, void* stash, int B, int n, int dtype, void* stream);
 size_t pacoh_mlp2_bwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out_a,
                                       int d_out_b, int dtype);
 int pacoh_mlp2_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
                    const int32_t* hidden, int n_hidden, long off_a, int d_out_a, const void* g_a, long off_b,
                    int d_out_b, const void* g_b, void* d_theta, long d_theta_stride, int accumulate,
-                   void* workspace, int B, int n, int dtype, void* stream);
+                   void* workspace, const void* stash, int B, int n, int dtype, void* stream);
 
 /* ---- A3 + A7: parameter transforms, hyper-prior ------------------------------------------------
  * softplus with optional floor, forward:  out = log(1+exp(raw)) + floor            (random_gp.py:69-74;

@@ -45,9 +45,10 @@ SIGNATURES = {
     'pacoh_mlp_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i]),
     'pacoh_mlp_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _l, _i, _vp, _i, _i, _i, _vp]),
     'pacoh_mlp2_fwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
-    'pacoh_mlp2_fwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp]),
+    'pacoh_mlp2_stash_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
+    'pacoh_mlp2_fwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_mlp2_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
-    'pacoh_mlp2_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _i, _i, _i, _vp]),
+    'pacoh_mlp2_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_softplus_fwd': (_i, [_vp, _vp, _d, _l, _i, _vp]),
     'pacoh_softplus_bwd': (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),
     'pacoh_hyper_fwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
@@ -85,6 +86,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 4              # pacoh_abi_version() of the library this table was written for
 
 
 def load_library():
@@ -101,6 +103,9 @@ def load_library():
                 raise RuntimeError('libpacoh_gp.so does not export %s (stale build?)' % name)
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.pacoh_abi_version() != ABI_VERSION:           # same symbols, other argument lists: calling on would corrupt memory
+            raise RuntimeError('%s has ABI version %d, this binding expects %d (stale build?)'
+                               % (LIB_PATH, lib.pacoh_abi_version(), ABI_VERSION))
         _lib = lib
     return _lib
 
@@ -358,24 +363,29 @@ def mvn_logprob_dense(A, resid, scale=1.0, want_alpha=False):
     return logp, alpha, info
 
 
-_MLP_WS = {}
-
-
-def _mlp_fwd_ws(need, device):
-    """grow-only scratch of the layer-wise MLP forward (only shapes outside the register-resident kernels need any)"""
+def _mlp_fwd_ws(need, device, holder):
+    """scratch of the layer-wise MLP forward (only shapes outside the register-resident kernels need any).  It lives in the
+    CALLER's `holder` dict (an engine's workspace table), keyed by size class, and a buffer is never dropped once handed out: a
+    captured step graph bakes the raw pointer in, so a later, larger eager call (predict with a big test set) must not free what
+    the graph still writes to.  holder=None: a fresh buffer per call."""
     if need == 0:
         return None
-    ws = _MLP_WS.get(device)
-    if ws is None or ws.numel() < need:
-        ws = _MLP_WS[device] = torch.empty(need, dtype=torch.uint8, device=device)
+    if holder is None:
+        return torch.empty(need, dtype=torch.uint8, device=device)
+    pool = holder.setdefault(('mlp_fwd_ws', device), [])
+    for ws in pool:
+        if ws.numel() >= need:
+            return ws
+    ws = torch.empty(need, dtype=torch.uint8, device=device)
+    pool.append(ws)
     return ws
 
 
-def mlp_fwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, B, n):
+def mlp_fwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, B, n, ws_holder=None):
     lib = load_library()
     out = torch.empty(B, n, d_out, dtype=x.dtype, device=x.device)
     harr, code = _hidden_arr(hidden), dtype_code(x)
-    ws = _mlp_fwd_ws(lib.pacoh_mlp_fwd_workspace_bytes(B, P, n, d_in, harr, len(hidden), d_out, code), x.device)
+    ws = _mlp_fwd_ws(lib.pacoh_mlp_fwd_workspace_bytes(B, P, n, d_in, harr, len(hidden), d_out, code), x.device, ws_holder)
     with _Timed('mlp_fwd'):
         _check(lib.pacoh_mlp_fwd(_ptr(x), x_div, ctypes.c_void_p(theta_block.data_ptr()), theta_stride, P, d_in,
                                  harr, len(hidden), d_out, _ptr(out), _ptr(ws), B, n, code, _stream()),
@@ -399,22 +409,37 @@ def mlp_bwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, g_out, 
     return workspace
 
 
-def mlp2_fwd(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, off_b, d_out_b, B, n):
+MLP_STASH_MAX_BYTES = 8 << 30     # no activation stash beyond this (the backward then recomputes, as in rounds 1-2)
+
+
+def mlp2_stash(x, P, d_in, hidden, d_out_a, d_out_b, B, n, stash=None):
+    """activation stash for a mlp2_fwd / mlp2_bwd pair of these shapes (reused if large enough) or None if this shape keeps none"""
+    lib = load_library()
+    need = lib.pacoh_mlp2_stash_bytes(B, P, n, d_in, _hidden_arr(hidden), len(hidden), d_out_a, d_out_b, dtype_code(x))
+    if need == 0 or need > MLP_STASH_MAX_BYTES:
+        return None
+    if stash is None or stash.numel() < need:
+        stash = torch.empty(need, dtype=torch.uint8, device=x.device)
+    return stash
+
+
+def mlp2_fwd(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, off_b, d_out_b, B, n, ws_holder=None, stash=None):
     """two networks of the same hidden shape (blocks at element offsets off_a / off_b of the rows of theta[P, D]) on the
-    same inputs: -> (out_a[B,n,d_out_a], out_b[B,n,d_out_b]); one launch on the fused fp32 path"""
+    same inputs: -> (out_a[B,n,d_out_a], out_b[B,n,d_out_b]); one launch on the fused fp32 path.  stash (mlp2_stash()) receives
+    the activations the matching mlp2_bwd(stash=...) would otherwise recompute"""
     lib = load_library()
     out_a = torch.empty(B, n, d_out_a, dtype=x.dtype, device=x.device)
     out_b = torch.empty(B, n, d_out_b, dtype=x.dtype, device=x.device)
     harr, code = _hidden_arr(hidden), dtype_code(x)
-    ws = _mlp_fwd_ws(lib.pacoh_mlp2_fwd_workspace_bytes(B, P, n, d_in, harr, len(hidden), d_out_a, d_out_b, code), x.device)
+    ws = _mlp_fwd_ws(lib.pacoh_mlp2_fwd_workspace_bytes(B, P, n, d_in, harr, len(hidden), d_out_a, d_out_b, code), x.device, ws_holder)
     with _Timed('mlp_fwd'):
         _check(lib.pacoh_mlp2_fwd(_ptr(x), x_div, _ptr(theta, x), theta.shape[1], P, d_in, harr, len(hidden), off_a, d_out_a,
-                                  _ptr(out_a), off_b, d_out_b, _ptr(out_b), _ptr(ws), B, n, code, _stream()), 'pacoh_mlp2_fwd')
+                                  _ptr(out_a), off_b, d_out_b, _ptr(out_b), _ptr(ws), _ptr(stash), B, n, code, _stream()), 'pacoh_mlp2_fwd')
     return out_a, out_b
 
 
 def mlp2_bwd(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, g_a, off_b, d_out_b, g_b, d_theta, accumulate, B, n,
-             workspace=None):
+             workspace=None, stash=None):
     """backward of mlp2_fwd into the rows of d_theta[P, D] (blocks at off_a / off_b); returns the workspace for reuse"""
     lib = load_library()
     harr, code = _hidden_arr(hidden), dtype_code(x)
@@ -424,7 +449,7 @@ def mlp2_bwd(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, g_a, off_b, d_out
     with _Timed('mlp_bwd'):
         _check(lib.pacoh_mlp2_bwd(_ptr(x), x_div, _ptr(theta, x), theta.shape[1], P, d_in, harr, len(hidden), off_a, d_out_a,
                                   _ptr(g_a, x), off_b, d_out_b, _ptr(g_b, x), _ptr(d_theta, x), d_theta.shape[1],
-                                  int(bool(accumulate)), _ptr(workspace), B, n, code, _stream()), 'pacoh_mlp2_bwd')
+                                  int(bool(accumulate)), _ptr(workspace), _ptr(stash), B, n, code, _stream()), 'pacoh_mlp2_bwd')
     return workspace
 
 

@@ -24,11 +24,13 @@ bool mlp_mfma_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_ou
 // mlp_fused.hip
 bool mlp_fused_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_out);
 int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
-                  int n_hidden, int nets, const long* off, const int* d_out, void* const* out, int B, int n, hipStream_t s);
+                  int n_hidden, int nets, const long* off, const int* d_out, void* const* out, void* stash, int B, int n,
+                  hipStream_t s);
+size_t mlp_fused_stash_bytes(int B, int P, int n, int n_hidden, int nets);
 size_t mlp_fused_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int nets);
 int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
                   int n_hidden, int nets, const long* off, const int* d_out, const void* const* g_out, void* d_theta,
-                  long d_theta_stride, int accumulate, void* workspace, int B, int n, hipStream_t s);
+                  long d_theta_stride, int accumulate, void* workspace, const void* stash, int B, int n, hipStream_t s);
 // mlp_layers.hip
 size_t mlp_layers_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype, int bwd);
 int mlp_layers_fwd(const void*, int, const void*, long, int, int, const int32_t*, int, int, void*, void*, int, int, int, hipStream_t);
@@ -122,7 +124,7 @@ extern "C" int pacoh_mlp_fwd(const void* x, int x_div, const void* theta, long t
     case PATH_FUSED: {
         const long off = 0;
         void* const outs[1] = {out};
-        return mlp_fused_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 1, &off, &d_out, outs, B, n, s);
+        return mlp_fused_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 1, &off, &d_out, outs, nullptr, B, n, s);
     }
     case PATH_MFMA:
         return mlp_mfma_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, s);
@@ -159,7 +161,7 @@ extern "C" int pacoh_mlp_bwd(const void* x, int x_div, const void* theta, long t
         const long off = 0;
         const void* const gs[1] = {g_out};
         return mlp_fused_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 1, &off, &d_out, gs, d_theta, d_theta_stride,
-                             accumulate, workspace, B, n, s);
+                             accumulate, workspace, nullptr, B, n, s);
     }
     case PATH_MFMA:
         return mlp_mfma_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride,
@@ -182,9 +184,17 @@ extern "C" size_t pacoh_mlp2_fwd_workspace_bytes(int B, int P, int n, int d_in, 
     return a > b ? a : b;                       // the two networks run one after the other on the general path
 }
 
+extern "C" size_t pacoh_mlp2_stash_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out_a,
+                                         int d_out_b, int dtype) {
+    if (P <= 0 || B <= 0 || n <= 0 || B % P != 0 || args_ok(d_in, hidden, n_hidden, d_out_a) || args_ok(d_in, hidden, n_hidden, d_out_b)) return 0;
+    if (pick_path(dtype, d_in, hidden, n_hidden, d_out_a, (long)B * n) != PATH_FUSED ||
+        pick_path(dtype, d_in, hidden, n_hidden, d_out_b, (long)B * n) != PATH_FUSED) return 0;
+    return mlp_fused_stash_bytes(B, P, n, n_hidden, 2);
+}
+
 extern "C" int pacoh_mlp2_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
                               const int32_t* hidden, int n_hidden, long off_a, int d_out_a, void* out_a, long off_b, int d_out_b,
-                              void* out_b, void* workspace, int B, int n, int dtype, void* stream) {
+                              void* out_b, void* workspace, void* stash, int B, int n, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!out_a || !out_b || !x || !theta || x_div <= 0 || P <= 0 || B <= 0 || n <= 0 || B % P != 0 || off_a < 0 || off_b < 0) return PACOH_EINVAL;
     int rc = args_ok(d_in, hidden, n_hidden, d_out_a);
@@ -194,7 +204,7 @@ extern "C" int pacoh_mlp2_fwd(const void* x, int x_div, const void* theta, long 
         const long off[2] = {off_a, off_b};
         const int dout[2] = {d_out_a, d_out_b};
         void* const outs[2] = {out_a, out_b};
-        return mlp_fused_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 2, off, dout, outs, B, n, (hipStream_t)stream);
+        return mlp_fused_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 2, off, dout, outs, stash, B, n, (hipStream_t)stream);
     }
     const size_t es = dtype == PACOH_F64 ? 8 : 4;
     rc = pacoh_mlp_fwd(x, x_div, (const char*)theta + off_a * es, theta_stride, P, d_in, hidden, n_hidden, d_out_a, out_a, workspace, B, n, dtype, stream);
@@ -216,7 +226,7 @@ extern "C" size_t pacoh_mlp2_bwd_workspace_bytes(int B, int P, int n, int d_in, 
 extern "C" int pacoh_mlp2_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
                               const int32_t* hidden, int n_hidden, long off_a, int d_out_a, const void* g_a, long off_b,
                               int d_out_b, const void* g_b, void* d_theta, long d_theta_stride, int accumulate,
-                              void* workspace, int B, int n, int dtype, void* stream) {
+                              void* workspace, const void* stash, int B, int n, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!g_a || !g_b || !d_theta || !workspace || !x || !theta || x_div <= 0 || P <= 0 || B <= 0 || n <= 0 || B % P != 0 || off_a < 0 || off_b < 0)
         return PACOH_EINVAL;
@@ -228,7 +238,7 @@ extern "C" int pacoh_mlp2_bwd(const void* x, int x_div, const void* theta, long 
         const int dout[2] = {d_out_a, d_out_b};
         const void* const gs[2] = {g_a, g_b};
         return mlp_fused_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 2, off, dout, gs, d_theta, d_theta_stride,
-                             accumulate, workspace, B, n, (hipStream_t)stream);
+                             accumulate, workspace, stash, B, n, (hipStream_t)stream);
     }
     const size_t es = dtype == PACOH_F64 ? 8 : 4;
     rc = pacoh_mlp_bwd(x, x_div, (const char*)theta + off_a * es, theta_stride, P, d_in, hidden, n_hidden, d_out_a, g_a,

@@ -7,7 +7,14 @@
 // H^T[feature 4g+s][point r]); with the k index of a block product permuted as k = 4g+s that layout IS the B operand of
 // the next layer's product and of the delta recursion, weights are the A operand (one ds_read_b128 per 4 MFMAs).
 // Weight gradients contract over the point index and need the other orientation, X[feature r][point 4g+q] ("plain"):
-// 16x16 blocks are turned through a per-wave LDS scratch (row stride 17 words, conflict-free both ways).
+// 16x16 blocks are turned through a per-wave LDS scratch: row stride 17 words
+// and a skew of (0, 12, 32, 44) words for the four groups of four rows, which
+// makes BOTH directions conflict-free under gfx950's dword-access banking (bank = word mod 32, the two 32-lane halves of a
+// wave are serviced separately; see f_turn).
+// Activation stash (round 3): the forward can park the top hidden layers' activations in HBM ([particle][16-point block]
+// [layer][feature block] -> one 1-KiB wave store each, in the accumulator layout as it stands in the registers) and the
+// backward reads them back instead of recomputing them: for the 2 x 32 networks of cfg #3 that removes 64 of the backward's
+// 200 MFMAs and 32 of its 64 tanh per tile for 16 KiB of traffic per tile each way.
 // The narrow first (d_in <= 4) and output (d_out <= 2) layers run on the VALU; their gradient partial sums are taken in
 // the PLAIN orientation, where a lane owns a feature and sums over points: 10 + 6 accumulator registers per lane and
 // two cross-lane adds at the very end (the earlier formulation summed in the transposed orientation, where a lane owns
@@ -33,14 +40,16 @@ constexpr int F_OFF_H = 160;                  // hidden layers 2..NH
 __host__ __device__ constexpr int f_off_out(int nh) { return F_OFF_H + (nh - 1) * HBLK; }      // W_out [2][32] | b_out [2] (+2 pad)
 __host__ __device__ constexpr int f_welems(int nh) { return f_off_out(nh) + 68; }
 constexpr int TSTRIDE = 8;                    // staged tile row: x[4] | g[2] | pad[2]
-constexpr int TLD = 17;                       // scratch row stride of a block transpose: conflict-free both ways
-constexpr int TRS = 16 * TLD;                 // one transpose scratch block
+constexpr int TLD = 17;                       // scratch row stride of a block transpose; row i sits tskew(i >> 2) words further on
+__host__ __device__ constexpr int tskew(int k) { return 12 * (k & 1) + 32 * (k >> 1); }
+constexpr int TRS = 320;                      // one transpose scratch block (16 * 17 + tskew(3) + 4, rounded)
 
 struct FusedNet {
     long theta_off;            // element offset of the network's block inside a theta row
     float* out;                // fwd: [B, n, d_out]
     const float* g_out;        // bwd: [B, n, d_out]
     float* slab;               // bwd: [slabs][P][D_net]
+    float* stash;              // activation stash of this network (fwd: written, bwd: read), NULL = none
     int d_out, D_net;
 };
 
@@ -52,7 +61,14 @@ struct FusedArgs {
     int d_in, nh;
     int h[FMAXNH];
     int tiles_per_wg;
+    int n_stash;               // the top n_stash hidden layers travel through FusedNet::stash (0 = recompute everything)
+    int nblk;                  // 16-point blocks per particle in the stash (a multiple of 4)
 };
+
+// stash element (particle p, 16-point block blk, slot, feature block fb): 256 floats, lane-major f32x4
+__device__ __forceinline__ long stash_off(const FusedArgs& a, int p, int blk, int slot, int fb, int lane) {
+    return (((((long)p * a.nblk + blk) * a.n_stash + slot) * 2 + fb) << 8) + (lane << 2);
+}
 
 __device__ __forceinline__ f32x4 fmfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -202,15 +218,22 @@ __device__ __forceinline__ void f_delta(const float* W, int r, int g, const f32x
     }
 }
 
-// 16x16 block: lane (r,g) holds X[feature 4g+s][point r] in register s, returns X[feature r][point 4g+q] in register q
-__device__ __forceinline__ f32x4 f_turn(float* scr, const f32x4& v, int r, int g) {
+// 16x16 block: lane (r,g) holds X[feature 4g+s][point r] in register s, returns X[feature r][point 4g+q] in register q.
+// Scratch word of element (i, j): 17 i + tskew(i >> 2) + j, tskew = (0, 12, 32, 44) = (0, 12, 0, 12) mod 32.  Dword LDS accesses
+// are banked modulo 32 words and serviced per 32-lane half (g in {0,1} | {2,3}).  Writes: register s of lane (r,g) goes to word
+// 17 s + r + 68 g + tskew(g): the two lane rows of a half land 80 = 16 (mod 32) banks apart -> 32 distinct banks.  Reads: lane
+// (r,g) reads words 17 r + tskew(r >> 2) + 4 g + q; over r = 0..15 the first two terms take every bank with bit 2 clear exactly once
+// ({0,17,2,19 | 16,1,18,3 | 8,25,10,27 | 24,9,26,11}), 4 g fills in the others -> 32 distinct banks.  (The plain stride-17 layout of
+// rounds 1-2 was 2-way conflicted in both directions: SQ_LDS_BANK_CONFLICT exceeded the LDS-active cycles of the backward kernel.)
+// wr = 68 g + tskew(g) + r and rd = 17 r + tskew(r >> 2) + 4 g are computed once per wave.
+// (16-byte writes + strided reads, row stride 20, were 22 % slower at 64-point tiles)
+__device__ __forceinline__ f32x4 f_turn(float* scr, const f32x4& v, int wr, int rd) {
     f32x4 o;
-    // (16-byte writes + strided reads, row stride 20, were 22 % slower at 64-point tiles)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) scr[(4 * g + s) * TLD + r] = v[s];
+    for (int s = 0; s < 4; ++s) scr[wr + s * TLD] = v[s];
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = scr[r * TLD + 4 * g + q];
+    for (int q = 0; q < 4; ++q) o[q] = scr[rd + q];
     asm volatile("" ::: "memory");
     return o;
 }
@@ -218,6 +241,48 @@ __device__ __forceinline__ f32x4 f_turn(float* scr, const f32x4& v, int r, int g
 __device__ __forceinline__ void f_wgrad(f32x4& acc, const f32x4& Ap, const f32x4& Bp) {
     acc = fmfma(Ap[0], Bp[0], acc); acc = fmfma(Ap[1], Bp[1], acc);
     acc = fmfma(Ap[2], Bp[2], acc); acc = fmfma(Ap[3], Bp[3], acc);
+}
+
+#ifndef PACOH_STASH_NT
+#define PACOH_STASH_NT 1
+#endif
+__device__ __forceinline__ void stash_st(const f32x4& v, f32x4* q) {
+#if PACOH_STASH_NT & 1
+    __builtin_nontemporal_store(v, q);
+#else
+    *q = v;
+#endif
+}
+__device__ __forceinline__ f32x4 stash_ld(const f32x4* q) {
+#if PACOH_STASH_NT & 2
+    return __builtin_nontemporal_load(q);
+#else
+    return *q;
+#endif
+}
+
+template <int PB>
+__device__ __forceinline__ void stash_put(const FusedArgs& a, const FusedNet& nt, int p, int blk0, int slot, int lane,
+                                          const f32x4 (&H)[2][PB]) {
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+            stash_st(H[fb][pb], reinterpret_cast<f32x4*>(nt.stash + stash_off(a, p, blk0 + pb, slot, fb, lane)));
+}
+
+// blocks that start past the end of the particle's rows were never written by a forward with a smaller tile: zeros
+template <int PB>
+__device__ __forceinline__ void stash_get(const FusedArgs& a, const FusedNet& nt, int p, int blk0, int slot, int lane,
+                                          f32x4 (&H)[2][PB]) {
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        const bool in = (blk0 + pb) * 16 < a.R;
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+            H[fb][pb] = in ? stash_ld(reinterpret_cast<const f32x4*>(nt.stash + stash_off(a, p, blk0 + pb, slot, fb, lane)))
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------------
@@ -246,11 +311,15 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_fwd_kernel(FusedArgs a) {
         if (row0 >= a.R) break;
         const long orow_l = stage_tile<PB, false>(a, nt, p, row0, st, lane);
         f32x4 HA[2][PB], HB[2][PB];
+        const int blk0 = row0 >> 4;
+        const int ns = nt.stash ? a.n_stash : 0;
         f_layer1<PB>(wl, st, r, g, HA);
+        if (ns >= NH) stash_put<PB>(a, nt, p, blk0, 0, lane, HA);
 #pragma unroll
         for (int l = 1; l < NH; ++l) {
             if (l & 1) f_hidden<PB>(wl + F_OFF_H + (l - 1) * HBLK, r, g, HA, HB);
             else f_hidden<PB>(wl + F_OFF_H + (l - 1) * HBLK, r, g, HB, HA);
+            if (l >= NH - ns) stash_put<PB>(a, nt, p, blk0, l - (NH - ns), lane, (l & 1) ? HB : HA);
         }
         const f32x4 (&HL)[2][PB] = ((NH - 1) & 1) ? HB : HA;
 #pragma unroll
@@ -285,6 +354,7 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
     float* st = stage[wave];
     float* sc0 = tscr[wave];
     float* sc1 = tscr[wave] + TRS;
+    const int twr = 4 * TLD * g + tskew(g) + r, trd = TLD * r + tskew(r >> 2) + 4 * g;
     const float* wo = wl + f_off_out(NH);
     float w3r[2][2][4];
 #pragma unroll
@@ -305,16 +375,22 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
         const int row0 = (blockIdx.x * a.tiles_per_wg + tl) * TP;
         if (row0 >= a.R) break;
         stage_tile<PB, true>(a, nt, p, row0, st, lane);
-        // ---- forward recompute, all activations kept ---------------------------------------------------------------
+        // ---- activations: the top `ns` hidden layers from the forward's stash, the ones below recomputed -------------
         f32x4 H[NH][2][PB];
-        f_layer1<PB>(wl, st, r, g, H[0]);
+        const int blk0 = row0 >> 4;
+        const int ns = nt.stash ? a.n_stash : 0;
 #pragma unroll
-        for (int l = 1; l < NH; ++l) f_hidden<PB>(wl + F_OFF_H + (l - 1) * HBLK, r, g, H[l - 1], H[l]);
+        for (int l = NH - 1; l >= 0; --l)
+            if (l >= NH - ns) stash_get<PB>(a, nt, p, blk0, l - (NH - ns), lane, H[l]);
+        if (ns < NH) f_layer1<PB>(wl, st, r, g, H[0]);
+#pragma unroll
+        for (int l = 1; l < NH; ++l)
+            if (l < NH - ns) f_hidden<PB>(wl + F_OFF_H + (l - 1) * HBLK, r, g, H[l - 1], H[l]);
         // ---- output layer (VALU): dW_out, db_out in the plain orientation; delta of the last hidden layer over H[NH-1] ---
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
-            const f32x4 Hp0 = f_turn(sc0, H[NH - 1][0][pb], r, g);
-            const f32x4 Hp1 = f_turn(sc1, H[NH - 1][1][pb], r, g);
+            const f32x4 Hp0 = f_turn(sc0, H[NH - 1][0][pb], twr, trd);
+            const f32x4 Hp1 = f_turn(sc1, H[NH - 1][1][pb], twr, trd);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float2 gp = *reinterpret_cast<const float2*>(st + (pb * 16 + 4 * g + q) * TSTRIDE + 4);
@@ -338,8 +414,8 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) {
                 f32x4 Dp[2], Hp[2];
-                Dp[0] = f_turn(sc0, H[l][0][pb], r, g);     Hp[0] = f_turn(sc1, H[l - 1][0][pb], r, g);
-                Dp[1] = f_turn(sc0, H[l][1][pb], r, g);     Hp[1] = f_turn(sc1, H[l - 1][1][pb], r, g);
+                Dp[0] = f_turn(sc0, H[l][0][pb], twr, trd);     Hp[0] = f_turn(sc1, H[l - 1][0][pb], twr, trd);
+                Dp[1] = f_turn(sc0, H[l][1][pb], twr, trd);     Hp[1] = f_turn(sc1, H[l - 1][1][pb], twr, trd);
 #pragma unroll
                 for (int ob = 0; ob < 2; ++ob) {
                     aBh[l - 1][ob] += (Dp[ob][0] + Dp[ob][1]) + (Dp[ob][2] + Dp[ob][3]);
@@ -352,8 +428,8 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
         // ---- first layer (VALU, plain orientation): H[0] holds delta_1^T ----------------------------------------------------
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
-            const f32x4 Dp0 = f_turn(sc0, H[0][0][pb], r, g);
-            const f32x4 Dp1 = f_turn(sc1, H[0][1][pb], r, g);
+            const f32x4 Dp0 = f_turn(sc0, H[0][0][pb], twr, trd);
+            const f32x4 Dp1 = f_turn(sc1, H[0][1][pb], twr, trd);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 xp = *reinterpret_cast<const float4*>(st + (pb * 16 + 4 * g + q) * TSTRIDE);
@@ -475,14 +551,38 @@ static int fused_chunks(int R, int P, int nets, int tp, int resident, double ove
     return (tiles + best_tpw - 1) / best_tpw;
 }
 
+// Hidden layers (counted from the top) whose activations the forward parks in HBM for the backward.  Default 1: the last hidden
+// layer (cfg #3, 2 x 32: backward 206 -> ?? us, forward +?? us for 2 x 335 MB of traffic); PACOH_MLP_STASH=0 recomputes everything
+static int fused_n_stash(int n_hidden) {
+    const int want = fused_env("PACOH_MLP_STASH", 1);              // (read per call: tests and tools/mlp_time.py switch it)
+    return want < 0 ? 0 : (want > n_hidden ? n_hidden : want);
+}
+static int fused_nblk(int B, int P, int n) { return 4 * (int)(((long)(B / P) * n + 63) / 64); }
+
+// bytes of activation stash for `nets` networks (0: this build / shape keeps none)
+size_t mlp_fused_stash_bytes(int B, int P, int n, int n_hidden, int nets) {
+    return (size_t)nets * P * fused_nblk(B, P, n) * fused_n_stash(n_hidden) * 2 * 256 * sizeof(float);
+}
+
 static void fused_fill(FusedArgs& a, const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
-                       const int32_t* hidden, int n_hidden, int B, int n) {
+                       const int32_t* hidden, int n_hidden, int B, int n, const void* stash, int nets) {
     a.x = (const float*)x; a.x_div = x_div; a.theta = (const float*)theta; a.theta_stride = theta_stride;
     a.P = P; a.n = n; a.R = (B / P) * n; a.d_in = d_in; a.nh = n_hidden;
     for (int l = 0; l < FMAXNH; ++l) a.h[l] = l < n_hidden ? hidden[l] : 0;
+    a.n_stash = stash ? fused_n_stash(n_hidden) : 0;
+    a.nblk = fused_nblk(B, P, n);
+    const size_t per_net = (size_t)P * a.nblk * a.n_stash * 2 * 256;
+    for (int k = 0; k < 2; ++k) a.net[k].stash = (a.n_stash > 0 && k < nets) ? (float*)stash + k * per_net : nullptr;
 }
 
-constexpr int BWD_MINW = 2;                   // (168 registers: three waves per SIMD fit anyway; forcing 128 spills)
+#ifndef PACOH_BWD_MINW
+#define PACOH_BWD_MINW 3
+#endif
+constexpr int BWD_MINW = PACOH_BWD_MINW;      // NH <= 2, 64-point tiles: three waves per SIMD (168 registers; forcing 128 spills)
+#ifndef PACOH_BWD_MINW_PB2
+#define PACOH_BWD_MINW_PB2 2
+#endif
+constexpr int BWD_MINW_PB2 = PACOH_BWD_MINW_PB2;
 // M is applied to the parenthesised kernel instantiation (the commas of the template arguments must not split macro arguments)
 #define PACOH_FUSED_DISPATCH(KERNEL, nh, pb, M)                                                          \
     do {                                                                                                 \
@@ -490,16 +590,17 @@ constexpr int BWD_MINW = 2;                   // (168 registers: three waves per
             if (nh == 1) { M((KERNEL<1, 4, BWD_MINW>)); } else if (nh == 2) { M((KERNEL<2, 4, BWD_MINW>)); }  \
             else if (nh == 3) { M((KERNEL<3, 4, 1>)); } else { M((KERNEL<4, 4, 1>)); }                    \
         } else {                                                                                         \
-            if (nh == 1) { M((KERNEL<1, 2, 2>)); } else if (nh == 2) { M((KERNEL<2, 2, 2>)); }            \
+            if (nh == 1) { M((KERNEL<1, 2, BWD_MINW_PB2>)); } else if (nh == 2) { M((KERNEL<2, 2, BWD_MINW_PB2>)); }            \
             else if (nh == 3) { M((KERNEL<3, 2, 2>)); } else { M((KERNEL<4, 2, 2>)); }                    \
         }                                                                                                \
     } while (0)
 
 // nets = 1 or 2 networks of the SAME hidden shape at element offsets off[k] of the theta rows
 int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
-                  int n_hidden, int nets, const long* off, const int* d_out, void* const* out, int B, int n, hipStream_t s) {
+                  int n_hidden, int nets, const long* off, const int* d_out, void* const* out, void* stash, int B, int n,
+                  hipStream_t s) {
     FusedArgs a = {};
-    fused_fill(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, B, n);
+    fused_fill(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, B, n, stash, nets);
     for (int k = 0; k < nets; ++k) { a.net[k].theta_off = off[k]; a.net[k].out = (float*)out[k]; a.net[k].d_out = d_out[k]; }
     const int pb = fused_fwd_pb(n_hidden) == 2 ? 2 : 4;
     const int tiles = (a.R + 16 * pb - 1) / (16 * pb);
@@ -544,9 +645,9 @@ size_t mlp_fused_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hid
 
 int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
                   int n_hidden, int nets, const long* off, const int* d_out, const void* const* g_out, void* d_theta,
-                  long d_theta_stride, int accumulate, void* workspace, int B, int n, hipStream_t s) {
+                  long d_theta_stride, int accumulate, void* workspace, const void* stash, int B, int n, hipStream_t s) {
     FusedArgs a = {};
-    fused_fill(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, B, n);
+    fused_fill(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, B, n, stash, nets);
     const FusedBwdPlan pl = fused_bwd_plan(a.R, P, nets, n_hidden);
     a.tiles_per_wg = pl.tiles_per_wg;
     float* ws = (float*)workspace;

@@ -333,27 +333,35 @@ class GPEngine:
             return lay.block_range('mean_nn.')[0], lay.block_range('kernel_nn.')[0]
         return None
 
-    def _features(self, theta, x, T, n, theta_per_task=False):
+    def _features(self, theta, x, T, n, theta_per_task=False, keep=False):
         """kernel inputs z (+ divisor) and mean (+ mode) for B = T*P problems (b = t*P + p: task t, parameter row p).
         theta_per_task: theta holds T*S rows, S of its own per task -- the same kernels with P = T*S parameter rows, ONE
-        problem per row (B = T*S) and inputs shared by S consecutive problems"""
+        problem per row (B = T*S) and inputs shared by S consecutive problems.  keep: park the activations the backward of the
+        SAME step needs in self._ws['stash'] (lml_and_grad)"""
         lay = self.layout
         P, D = theta.shape
         B, x_div = (P, P // T) if theta_per_task else (T * P, P)
         pair = self._paired_nets()
         if pair is not None:                               # mean + kernel-feature network in one call (one launch on the fused path)
+            stash = None
+            if keep:
+                key = ('stash', B, n)                      # one stash per batch shape: a captured graph keeps using its own
+                stash = self._ws[key] = L.mlp2_stash(x, P, lay.input_dim, list(lay.mean_nn_layers), 1, lay.feature_dim, B, n,
+                                                     self._ws.get(key))
             mean, z = L.mlp2_fwd(x, x_div, theta, P, lay.input_dim, list(lay.mean_nn_layers), pair[0], 1, pair[1],
-                                 lay.feature_dim, B, n)
+                                 lay.feature_dim, B, n, ws_holder=self._ws, stash=stash)
             return z, 1, mean.reshape(B, n), L.MEAN_VECTOR
         if lay.covar_module == 'NN':
             lo, _ = lay.block_range('kernel_nn.')
-            z = L.mlp_fwd(x, x_div, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers), lay.feature_dim, B, n)
+            z = L.mlp_fwd(x, x_div, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers), lay.feature_dim, B, n,
+                          ws_holder=self._ws)
             z_div = 1
         else:
             z, z_div = x, x_div
         if lay.mean_module == 'NN':
             lo, _ = lay.block_range('mean_nn.')
-            mean = L.mlp_fwd(x, x_div, theta[:, lo:], D, P, lay.input_dim, list(lay.mean_nn_layers), 1, B, n).reshape(B, n)
+            mean = L.mlp_fwd(x, x_div, theta[:, lo:], D, P, lay.input_dim, list(lay.mean_nn_layers), 1, B, n,
+                             ws_holder=self._ws).reshape(B, n)
             mode = L.MEAN_VECTOR
         elif lay.mean_module == 'constant':
             lo, hi = lay.slices['constant_mean']
@@ -384,7 +392,7 @@ class GPEngine:
         B = T * P
         dev, dt = theta.device, theta.dtype
         ls, os_, noise = hypers if hypers is not None else self._hypers(theta)      # (hypers: already transformed by pacoh_step_begin)
-        z, z_div, mean, mode = self._features(theta, batch.x, T, n)
+        z, z_div, mean, mode = self._features(theta, batch.x, T, n, keep=True)
         g = None                                        # weight 1: the kernels take g_lml = NULL
         if float(weight) != 1.0:
             gkey = ('g', B, dt, dev)                    # ONE upstream-gradient vector per batch shape, refilled when the weight changes
@@ -401,7 +409,8 @@ class GPEngine:
         pair = self._paired_nets()
         if pair is not None:
             self._ws['mk'] = L.mlp2_bwd(batch.x, P, theta, P, lay.input_dim, list(lay.mean_nn_layers), pair[0], 1,
-                                        d_mean.reshape(B, n, 1), pair[1], lay.feature_dim, d_z, grad, False, B, n, self._ws.get('mk'))
+                                        d_mean.reshape(B, n, 1), pair[1], lay.feature_dim, d_z, grad, False, B, n, self._ws.get('mk'),
+                                        stash=self._ws.get(('stash', B, n)))
         else:
             if lay.covar_module == 'NN':
                 lo, _ = lay.block_range('kernel_nn.')

@@ -35,7 +35,8 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_abi_version_and_host_side_queries(lib):
-    assert lib.pacoh_abi_version() == 3
+    from meta_learning_pacoh_amd import _lib
+    assert lib.pacoh_abi_version() == _lib.ABI_VERSION == 4
     assert lib.pacoh_gp_small_max_n(0, 0) >= 128 and lib.pacoh_gp_small_max_n(0, 1) >= 128      # fp32: cfg #4 fits
     assert lib.pacoh_gp_small_max_n(1, 1) >= 64                                                  # fp64: cfg #3 fits
     assert lib.pacoh_gp_small_max_n(7, 0) == -3
@@ -70,6 +71,11 @@ def test_argument_validation_returns_error_codes_without_launching(lib):
     assert lib.pacoh_mlp_fwd_workspace_bytes(20, 10, 20, 1, hidden, 4, 2, 0) == 0
     assert lib.pacoh_mlp2_fwd_workspace_bytes(20, 10, 20, 1, hidden, 4, 1, 2, 0) == 0
     assert lib.pacoh_mlp2_bwd_workspace_bytes(20, 10, 20, 1, hidden, 4, 1, 2, 0) > 0
+    # activation stash: one hidden layer, 2 networks x 10 particles x 4 sixteen-point blocks (20 rows -> one 64-point tile) x 2 KiB
+    assert lib.pacoh_mlp2_stash_bytes(20, 10, 20, 1, hidden, 4, 1, 2, 0) == 2 * 10 * 4 * 2048
+    assert lib.pacoh_mlp2_stash_bytes(20, 10, 20, 1, hidden, 4, 1, 2, 1) == 0                 # fp64: not the fused path
+    hidden = (ctypes.c_int32 * 4)(128, 128, 128, 128)
+    assert lib.pacoh_mlp2_stash_bytes(20, 10, 20, 1, hidden, 4, 1, 2, 0) == 0
 
 
 def test_no_cpu_fallback():

@@ -352,6 +352,8 @@ MLP2_CASES = [  # P, T, n, d_in, hidden, x_div_is_P
     (4, 5, 16, 3, (20, 32, 11), False),              # inputs per problem (x_div = 1)
     (2, 3, 9, 2, (128, 128, 128, 128), True),        # not fused: two sequential general-path calls
     (2, 2, 12, 6, (32, 32), True),                   # d_in > 4: padded-io MFMA kernels, twice
+    (5, 7, 23, 4, (32, 32), True),                   # rows per particle (161) end inside a 64-point tile
+    (3, 33, 64, 4, (32, 32, 32), True),              # several tiles per wave, three hidden layers
 ]
 
 
@@ -384,6 +386,20 @@ def test_mlp2_mean_and_kernel_network_in_one_call(L, dtype, case):
     L.mlp2_bwd(x_dev, x_div, th_dev, P, d_in, list(hidden), 0, 1, g_m.to(DEV), Dm, 2, g_k.to(DEV), grad, False, B, n)
     assert float((grad[:, Dm + Dk:] - 5).abs().max()) == 0                       # outside the two blocks: untouched
     assert relerr(grad[:, :Dm + Dk], th.grad[:, :Dm + Dk]) < tol_b
+    # the forward's activation stash (round 3) replaces the backward's recomputation of the top hidden layer: same outputs, same
+    # gradient up to the rounding of a different instruction order (none: the stashed registers are the recomputed ones)
+    stash = L.mlp2_stash(x_dev, P, d_in, list(hidden), 1, 2, B, n)
+    fused = dtype == torch.float32 and d_in <= 4 and len(hidden) <= 4 and max(hidden) <= 32
+    assert (stash is not None) == fused
+    if stash is not None:
+        stash.fill_(0xff)                                                         # (NaN patterns: every block read must have been written)
+        mean_s, z_s = L.mlp2_fwd(x_dev, x_div, th_dev, P, d_in, list(hidden), 0, 1, Dm, 2, B, n, stash=stash)
+        assert torch.equal(mean_s, mean) and torch.equal(z_s, z)
+        grad_s = torch.full((P, D), 5.0, dtype=dtype, device=DEV)
+        L.mlp2_bwd(x_dev, x_div, th_dev, P, d_in, list(hidden), 0, 1, g_m.to(DEV), Dm, 2, g_k.to(DEV), grad_s, False, B, n, stash=stash)
+        assert bool(torch.isfinite(grad_s).all())
+        assert relerr(grad_s[:, :Dm + Dk], th.grad[:, :Dm + Dk]) < tol_b
+        assert relerr(grad_s, grad) < 1e-6
     # the single-network entry points give the same numbers
     m1 = L.mlp_fwd(x_dev, x_div, th_dev, D, P, d_in, list(hidden), 1, B, n)
     z1 = L.mlp_fwd(x_dev, x_div, th_dev[:, Dm:], D, P, d_in, list(hidden), 2, B, n)

@@ -60,6 +60,13 @@ def main():
     def pair_bwd():
         ws['p'] = L.mlp2_bwd(x, P, theta, P, d, hidden, 0, 1, g_m, Dm, 2, g_k, grad, False, B, n, ws.get('p'))
 
+    def stash_pair(fwd_only=False, bwd_only=False):
+        st = ws['stash'] = L.mlp2_stash(x, P, d, hidden, 1, 2, B, n, ws.get('stash'))
+        if not bwd_only:
+            L.mlp2_fwd(x, P, theta, P, d, hidden, 0, 1, Dm, 2, B, n, stash=st)
+        if not fwd_only:
+            ws['p'] = L.mlp2_bwd(x, P, theta, P, d, hidden, 0, 1, g_m, Dm, 2, g_k, grad, False, B, n, ws.get('p'), stash=st)
+
     def two_fwd():
         L.mlp_fwd(x, P, theta, D, P, d, hidden, 1, B, n)
         L.mlp_fwd(x, P, theta[:, Dm:], D, P, d, hidden, 2, B, n)
@@ -83,6 +90,15 @@ def main():
         if path is None and args.quick:
             rows.append(('fused fwd pair', timeit(pair_fwd, args.reps)))
             rows.append(('fused bwd pair', timeit(pair_bwd, args.reps)))
+            for ns in range(0, len(hidden) + 1):
+                setenv(PACOH_MLP_STASH=ns)
+                ws.clear()
+                stash_pair()
+                rows.append(('stash %d layer(s): fwd' % ns, timeit(lambda: stash_pair(fwd_only=True), args.reps)))
+                rows.append(('stash %d layer(s): bwd' % ns, timeit(lambda: stash_pair(bwd_only=True), args.reps)))
+                rows.append(('stash %d layer(s): fwd + bwd' % ns, timeit(stash_pair, args.reps)))
+            setenv(PACOH_MLP_STASH=None)
+            ws.clear()
         elif path is None:
             for pb in (4, 2):
                 setenv(PACOH_FUSED_FWD_PB=pb)

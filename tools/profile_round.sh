@@ -4,7 +4,9 @@
 tag=${1:-rXX}
 out=gpurun_out/$tag
 mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export TMPDIR=/tmp
+cd "$root" || exit 1
 python bench.py > $out/bench.json 2> $out/bench.err
 python bench.py --scaling strong --no-cpu-baseline > $out/bench_strong1.json 2>> $out/bench.err
 for c in 2 4 5; do python bench.py --config $c --no-cpu-baseline > $out/bench_cfg$c.json 2>> $out/bench.err; done
