@@ -12,7 +12,7 @@ from . import _lib as L
 from . import parallel
 from .abstract import RegressionModelMetaLearned
 from .distributions import GaussianPredictive
-from .engine import GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, capture_graph, replay_steps, GRAPH_STEPS
+from .engine import GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, build_step_graphs, replay_steps, run_step
 from .modules import apply_initial_values, resolve_covar_module, resolve_mean_module
 from .util import StepLR
 
@@ -159,39 +159,20 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
             else:
                 L.axpy(self.theta[0, lo:hi], self._grad[0, lo:hi], -self.lr_scheduler.lr)       # (eager only: host scalar)
 
+    def _all_reduce(self):
+        parallel.all_reduce_buffer_(self._packed)         # ONE exchange per iteration: grad [1, D] | loss, in place
+
     def _build_graphs(self):
         state = (self.theta, self.exp_avg, self.exp_avg_sq, self._feed.ctr, self._fail, self._g_cum)
         saved = [t.clone() for t in state]
-        if parallel.world()[1] == 1:
-            def whole():
-                self._body_likelihood()
-                self._body_update()
-            self._graphs = (capture_graph(whole),)
-
-            def several():
-                for _ in range(GRAPH_STEPS):
-                    whole()
-            # (the large-context path allocates O(tasks x n^2) scratch per step inside the graph's pool: one step per graph there)
-            self._graph_many = capture_graph(several) if self.tasks.n <= 128 else None
-        else:
-            self._graphs = (capture_graph(self._body_likelihood), capture_graph(self._body_update))
+        # (the large-context path allocates O(tasks x n^2) scratch per step inside the graph's pool: one step per graph there)
+        self._graphs, self._graph_many = build_step_graphs(self._body_likelihood, self._all_reduce, self._body_update, self._feed,
+                                                           many_ok=self.tasks.n <= 128)
         for t, sv in zip(state, saved):
             t.copy_(sv)
 
-    def _all_reduce(self):
-        if parallel.world()[1] > 1:
-            parallel.all_reduce_buffer_(self._packed)
-
     def _run_step(self, graphed):
-        if graphed:
-            self._graphs[0].replay()
-            if len(self._graphs) > 1:
-                self._all_reduce()
-                self._graphs[1].replay()
-        else:
-            self._body_likelihood()
-            self._all_reduce()
-            self._body_update()
+        run_step(self._graphs, graphed, self._body_likelihood, self._all_reduce, self._body_update)
 
     def _use_graph(self):
         # (large contexts run the HBM-resident path, whose launch sequence sets kernel attributes: keep it eager)
@@ -265,8 +246,12 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
     def _check_numerics(self):
         """raise where the reference raises: gpytorch's psd_safe_cholesky -> NotPSDError (read at synchronisation points only)"""
         flag = getattr(self, '_fail', None)
-        if flag is not None and int(flag.item()) != 0:
-            flag.zero_()
+        bad = flag is not None and int(flag.item()) != 0
+        if not bad and parallel.world()[1] > 1 and getattr(self, '_g_loss', None) is not None:
+            bad = not bool(torch.isfinite(self._g_loss).all())    # another rank's shard failed: its NaN loss came through the all-reduce
+        if bad:
+            if flag is not None:
+                flag.zero_()
             raise NotPSDError('a task kernel matrix was not positive definite even after adding jitter (1e-6 .. 1e-4)')
 
     def predict(self, context_x, context_y, test_x, return_density=False):

@@ -12,7 +12,7 @@ from . import _lib as L
 from . import parallel
 from .abstract import RegressionModelMetaLearned
 from .distributions import GaussianPredictive
-from .engine import AsyncUploader, GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, capture_graph, replay_steps, GRAPH_STEPS
+from .engine import AsyncUploader, GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, build_step_graphs, replay_steps, run_step
 from .util import StepLR
 
 
@@ -116,8 +116,14 @@ class _RandomGPLearner(RegressionModelMetaLearned):
     def _check_numerics(self):
         """raise where the reference raises: gpytorch's psd_safe_cholesky -> NotPSDError (read at synchronisation points only)"""
         flag = getattr(self, '_fail', None)
-        if flag is not None and int(flag.item()) != 0:
-            flag.zero_()
+        bad = flag is not None and int(flag.item()) != 0
+        if not bad and parallel.world()[1] > 1 and getattr(self, '_lik', None) is not None:
+            # another rank's shard failed: its NaN likelihood sums reach every rank through the all-reduce, so that all ranks raise
+            # at the same synchronisation point (a rank raising alone would leave the others waiting in the next collective)
+            bad = not bool(torch.isfinite(self._lik).all())
+        if bad:
+            if flag is not None:
+                flag.zero_()
             raise NotPSDError('a task kernel matrix was not positive definite even after adding jitter (1e-6 .. 1e-4)')
 
     def _idx_uploader(self):
@@ -217,34 +223,20 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
                                              step_counter=self._feed.ctr)
         self.last_bandwidth = self._bw_out
 
-    def _build_graphs(self):
-        saved = [t.clone() for t in (self.particles, self.exp_avg, self.exp_avg_sq, self._feed.ctr, self._fail)]
-        if parallel.world()[1] == 1:
-            def whole():
-                self._body_likelihood()
-                self._body_update()
-            self._graphs = (capture_graph(whole),)
+    def _exchange(self):
+        parallel.all_reduce_buffer_(self._packed)         # ONE exchange per step: score [P, D] | lik [P], in place
 
-            def several():
-                for _ in range(GRAPH_STEPS):
-                    whole()
-            # (the large-context path allocates O(tasks x n^2) scratch per step inside the graph's pool: one step per graph there)
-            self._graph_many = capture_graph(several) if self.tasks.n <= 128 else None
-        else:
-            self._graphs = (capture_graph(self._body_likelihood), capture_graph(self._body_update))
-        for t, sv in zip((self.particles, self.exp_avg, self.exp_avg_sq, self._feed.ctr, self._fail), saved):
+    def _build_graphs(self):
+        state = (self.particles, self.exp_avg, self.exp_avg_sq, self._feed.ctr, self._fail)
+        saved = [t.clone() for t in state]
+        # (the large-context path allocates O(tasks x n^2) scratch per step inside the graph's pool: one step per graph there)
+        self._graphs, self._graph_many = build_step_graphs(self._body_likelihood, self._exchange, self._body_update, self._feed,
+                                                           many_ok=self.tasks.n <= 128)
+        for t, sv in zip(state, saved):
             t.copy_(sv)                                   # undo what the warm-up runs did
 
     def _run_step(self, graphed):
-        if graphed:
-            self._graphs[0].replay()
-            if len(self._graphs) > 1:
-                parallel.all_reduce_sum_(self._lik, self._score, self._packed)
-                self._graphs[1].replay()
-        else:
-            self._body_likelihood()
-            parallel.all_reduce_sum_(self._lik, self._score, self._packed)
-            self._body_update()
+        run_step(self._graphs, graphed, self._body_likelihood, self._exchange, self._body_update)
 
     def _train_steps(self, n_steps):
         """the next n_steps SVGD steps of the training loop (task draws from rds_numpy, lr from the scheduler)"""

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib as L
 from . import parallel
-from .engine import AsyncUploader, StepFeed, StepMode, capture_graph, replay_steps, GRAPH_STEPS
+from .engine import AsyncUploader, StepFeed, StepMode, build_step_graphs, replay_steps, run_step
 from .GPR_meta_svgd import _RandomGPLearner
 from .util import StepLR
 
@@ -149,35 +149,20 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         L.adam_step_dev(self.posterior, grad, self.exp_avg, self.exp_avg_sq, self._feed.sc[L.SC_ADAM:L.SC_ADAM + 4],
                         step_counter=self._feed.ctr)
 
+    def _exchange(self):
+        parallel.all_reduce_buffer_(self._packed)         # ONE exchange per step: score [S, D] | lik [S], in place
+
     def _build_graphs(self):
         state = (self.posterior, self.exp_avg, self.exp_avg_sq, self._feed.ctr, self._fail)
         saved = [t.clone() for t in state]
-        if parallel.world()[1] == 1:
-            def whole():
-                self._body_likelihood()
-                self._body_update()
-            self._graphs = (capture_graph(whole),)
-
-            def several():
-                for _ in range(GRAPH_STEPS):
-                    whole()
-            # (the large-context path allocates O(tasks x n^2) scratch per step inside the graph's pool: one step per graph there)
-            self._graph_many = capture_graph(several) if self.tasks.n <= 128 else None
-        else:
-            self._graphs = (capture_graph(self._body_likelihood), capture_graph(self._body_update))
+        # (the large-context path allocates O(tasks x n^2) scratch per step inside the graph's pool: one step per graph there)
+        self._graphs, self._graph_many = build_step_graphs(self._body_likelihood, self._exchange, self._body_update, self._feed,
+                                                           many_ok=self.tasks.n <= 128)
         for t, sv in zip(state, saved):
             t.copy_(sv)
 
     def _run_step(self, graphed):
-        if graphed:
-            self._graphs[0].replay()
-            if len(self._graphs) > 1:
-                parallel.all_reduce_sum_(self._lik, self._score, self._packed)
-                self._graphs[1].replay()
-        else:
-            self._body_likelihood()
-            parallel.all_reduce_sum_(self._lik, self._score, self._packed)
-            self._body_update()
+        run_step(self._graphs, graphed, self._body_likelihood, self._exchange, self._body_update)
 
     def _train_steps(self, n_steps):
         self._setup_step(self._local_batch_size())

@@ -103,7 +103,16 @@ __device__ __forceinline__ float wave_sum_(float v) {
 // positive turns its lane's product into NaN (q * rsq(q)), which is also how the caller notices the failure.
 // What is NOT computed: the entries of L above the 4-column panel being eliminated are left as they fall out of the
 // substitution (garbage): they only ever produce rows of L Z that have been consumed already.
-__device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const f32x4& nId, int r, int g) {
+#ifndef PACOH_F16_LDS
+#define PACOH_F16_LDS 2
+#endif
+// fs: 128 floats of per-wave LDS.  The four registers of the lane row g == k (rows 4k..4k+3 of the block, one column per lane) have
+// to reach all four lane rows twice per step (the panel rows of C, then the fresh rows of Z).  As four ds_bpermute each that is
+// 8 x 24 issue cycles per step (tools/valu_rates.hip); as one 16-lane ds_write_b128 + one ds_read_b128 (the four lanes of equal r
+// read one address: a broadcast) it is 2 x (13 + 4) -- and the pivot block comes out of the same 256 bytes by four uniform
+// ds_read_b128 instead of ten v_readlane (4.7 cycles each, and their scalar results make every instruction of the 4x4 Cholesky
+// a scalar-operand instruction: 4.7 instead of 3.2 cycles).
+__device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const f32x4& nId, int r, int g, float* fs) {
     f32x4 Tn = nId;                                         // -E + L Z, built up by one rank-4 MFMA per step (see below)
     float dsel = 1.0f;                                      // L[r][r] in the lanes g == r >> 2
     Z = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -111,16 +120,34 @@ __device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const
     for (int k = 0; k < 4; ++k) {
         // pivot block P[c][j] = C[4k+c][4k+j] = register c of lane (r = 4k+j, g = k): wave-uniform
         const float c0 = Cn[0], c1 = Cn[1], c2 = Cn[2], c3 = Cn[3];
-        const int l0 = 20 * k;
-        const float p00 = -readlane_(c0, l0), p10 = -readlane_(c1, l0), p20 = -readlane_(c2, l0), p30 = -readlane_(c3, l0);
-        const float p11 = -readlane_(c1, l0 + 1), p21 = -readlane_(c2, l0 + 1), p31 = -readlane_(c3, l0 + 1);
-        const float p22 = -readlane_(c2, l0 + 2), p32 = -readlane_(c3, l0 + 2), p33 = -readlane_(c3, l0 + 3);
-        // rt[c] = C[4k+c][r] = register c of lane (r, g = k)
         const int src = (16 * k + r) * 4;
+#if PACOH_F16_LDS >= 1
+        if (g == k) *reinterpret_cast<f32x4*>(fs + 4 * r) = Cn;
+        asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
+        const f32x4 rtv = *reinterpret_cast<const f32x4*>(fs + 4 * r);
+        const float rt0 = -rtv[0], rt1 = -rtv[1], rt2 = -rtv[2], rt3 = -rtv[3];
+#else
+        // rt[c] = C[4k+c][r] = register c of lane (r, g = k)
         const float rt0 = -__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c0)));
         const float rt1 = -__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c1)));
         const float rt2 = -__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c2)));
         const float rt3 = -__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c3)));
+#endif
+#if PACOH_F16_LDS >= 2
+        const f32x4 pc0 = *reinterpret_cast<const f32x4*>(fs + 16 * k), pc1 = *reinterpret_cast<const f32x4*>(fs + 16 * k + 4);
+        const f32x4 pc2 = *reinterpret_cast<const f32x4*>(fs + 16 * k + 8), pc3 = *reinterpret_cast<const f32x4*>(fs + 16 * k + 12);
+        const float p00 = -pc0[0], p10 = -pc0[1], p20 = -pc0[2], p30 = -pc0[3];
+        const float p11 = -pc1[1], p21 = -pc1[2], p31 = -pc1[3];
+        const float p22 = -pc2[2], p32 = -pc2[3], p33 = -pc3[3];
+#else
+        const int l0 = 20 * k;
+        const float p00 = -readlane_(c0, l0), p10 = -readlane_(c1, l0), p20 = -readlane_(c2, l0), p30 = -readlane_(c3, l0);
+        const float p11 = -readlane_(c1, l0 + 1), p21 = -readlane_(c2, l0 + 1), p31 = -readlane_(c3, l0 + 1);
+        const float p22 = -readlane_(c2, l0 + 2), p32 = -readlane_(c3, l0 + 2), p33 = -readlane_(c3, l0 + 3);
+#endif
+#if PACOH_F16_LDS >= 1
+        asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
+#endif
         const float r0 = __builtin_amdgcn_rsqf(p00);
         const float l10 = p10 * r0, l20 = p20 * r0, l30 = p30 * r0;
         const float q11 = fmaf(-l10, l10, p11);
@@ -155,10 +182,18 @@ __device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const
             // Tn += L[:, 4k..4k+3] Z[4k..4k+3, :]: ONE MFMA (k index = the four new columns) -- A[i][kk] = L[i][4k+kk] is xg of lane
             // (i, kk); B[kk][j] = Z[4k+kk][j] lives in register kk of lane (j, k) and reaches lane (j, kk) by four lane reads.  (Forming
             // the block row of L Z as a full product with L^T kept in registers took four MFMAs per step for a 4-row result.)
+#if PACOH_F16_LDS >= 1
+            if (g == k) *reinterpret_cast<f32x4*>(fs + 64 + 4 * r) = Z;
+            asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(fs + 64 + 4 * r);
+            asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
+            const float w0 = wv[0], w1 = wv[1], w2 = wv[2], w3 = wv[3];
+#else
             const float w0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(Z[0])));
             const float w1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(Z[1])));
             const float w2 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(Z[2])));
             const float w3 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(Z[3])));
+#endif
             const float zb = g == 0 ? w0 : (g == 1 ? w1 : (g == 2 ? w2 : w3));
             Tn = mfma_(xg, zb, Tn);
         }
@@ -193,6 +228,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     __shared__ __attribute__((aligned(16))) float rv[NP];           // residual
     __shared__ __attribute__((aligned(16))) float av[NP];           // alpha
     __shared__ __attribute__((aligned(16))) float tv[16];           // column layout -> replicated layout of one 16-vector
+    __shared__ __attribute__((aligned(16))) float fsc[128];         // factor16(): lane row k -> all lane rows
     __shared__ __attribute__((aligned(16))) float dzc[BWD ? NP * FP : 1];   // d_z before the chain-rule factors
     // W = K^-1, strictly upper block triangle, each block as the 64 lanes' accumulator registers (one 16-byte slot per lane): parked
     // here between the matrix-core phase that produces it and the gradient loop that consumes it, so that the two phases do not
@@ -303,7 +339,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
             // registers per product.  So the blocks not yet eliminated are kept NEGATED (Un = -A): the trailing update becomes
             // Un[I][J] += R[K][I]^T R[K][J] with both operands as they are, and every other product of the step takes the one
             // negated operand Vn = -L_KK^-T.
-            factor16(U[uidx(NB, K, K)], Zd[K], dprod, nId, r, g);
+            factor16(U[uidx(NB, K, K)], Zd[K], dprod, nId, r, g, fsc);
             SCHED_FENCE();
             const f32x4 Vn = mmT(Zd[K], nId, f32x4{0.f, 0.f, 0.f, 0.f});             // -L_KK^-T
 #pragma unroll
@@ -372,16 +408,17 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     const float* g_lml_p = LATE(g_lml);
     const float gup = g_lml_p ? g_lml_p[b] : 1.0f;
     const float osn = nv > 0 ? 0.5f * os / (float)nv : 0.0f;   // the outputscale rides on the 1/(2 n) factor: M_ij = G_ij os e_ij
-    float dls[FP];
-#pragma unroll
-    for (int c = 0; c < FP; ++c) dls[c] = 0.0f;
-    float msum = 0.0f, dnz = 0.0f;                              // sum of M (= os d lml/d os), os x trace part (= os d lml/d noise)
+    float msum = 0.0f, dnz = 0.0f;                              // sum of M (= os d lml/d os), os x trace part (= os d lml/d noise); x osn at the end
     // Every ordered pair (i, j) is visited, column block by column block: lane (r, g) holds the entries (i = 16I + 4g+s, j = 16J + r),
     // so everything destined for point j -- d_z[j] = sum_i M_ij (z_i - z_j) -- accumulates in the lane over s and I and needs only
     // two lane exchanges (over g) per column block at the end.  (Using the symmetry instead -- upper blocks only, each entry feeding
     // the row sum of i as well -- saves 24 of the 64 exponentials per lane but needs sums over the 16 lanes of a row: 128 DPP adds,
     // and the compiler kept every block row's partial sums alive to the end of the kernel, 100 registers over budget.)
     // the four entries of one block in this lane: M_ij (z_i - z_j) into colacc (point j), M_ij (z_i - z_j)^2 into dls, M_ij into msum
+    // Instruction diet of round 3 (64 entries per lane pass through here): the factor os / (2 n) is applied to the finished sums
+    // instead of every entry, and the lengthscale gradient sum_ij M_ij (z_i - z_j)^2 is not accumulated at all -- M being symmetric
+    // it equals -2 sum_j (z_j - c) . colsum_j for any constant c (sum_j colsum_j = 0), i.e. it falls out of the finished d_z sums
+    // with one multiply per point: 10 instead of 15 vector instructions per entry at f = 2.
     auto block_entries = [&](const f32x4& Wb, const int I, const float (&zc)[FP], const float aj, float (&colacc)[FP], const bool diag) {
         const f32x4 ai4 = *reinterpret_cast<const f32x4*>(av + 16 * I + 4 * g);
 #pragma unroll
@@ -389,7 +426,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
             float zi[FP];
 #pragma unroll
             for (int c = 0; c < FP; ++c) zi[c] = zf[(16 * I + 4 * g + s) * FP + c];
-            float Gij = (ai4[s] * aj - Wb[s]) * osn;
+            const float Gij = fmaf(ai4[s], aj, -Wb[s]);
             if (diag) dnz = fmaf(nId[s], Gij, dnz);           // minus the trace part (padding rows: taken out again below)
             float q = 0.0f, df[FP];
 #pragma unroll
@@ -397,11 +434,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
             const float M = Gij * __builtin_amdgcn_exp2f(-q);
             msum += M;
 #pragma unroll
-            for (int c = 0; c < FP; ++c) {
-                const float md = M * df[c];
-                colacc[c] += md;
-                dls[c] = fmaf(md, df[c], dls[c]);
-            }
+            for (int c = 0; c < FP; ++c) colacc[c] = fmaf(M, df[c], colacc[c]);
         }
     };
     // ---- W = K^-1, upper block triangle: W[I][J] = sum_{m >= J} Linv[m][I]^T Linv[m][J].  A diagonal block is consumed where it
@@ -463,13 +496,23 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     const float bad = okf ? 0.0f : NAN;
     float* d_z_p = LATE(d_z);
     float asum = 0.0f;
+    float dls[FP];                                              // sum_j (z_j - z_0) colsum_j (see block_entries)
+#pragma unroll
+    for (int c = 0; c < FP; ++c) dls[c] = 0.0f;
 #pragma unroll
     for (int rr = 0; rr < RPL; ++rr) {
         const int i = lane + 64 * rr;
         const float ai = i < NP ? av[i] : 0.0f;
+        float dzi[FP];
+#pragma unroll
+        for (int c = 0; c < FP; ++c) {
+            dzi[c] = i < NP ? dzc[i * FP + c] : 0.0f;
+            if (i < nv) dls[c] = fmaf(zf[i * FP + c] - zf[c], dzi[c], dls[c]);
+        }
         if (d_z_p && i < n) {
-            for (int c = 0; c < f; ++c)
-                d_z_p[(b * n + i) * (long)f + c] = (i < nv) ? (2.0f * INV_KAPPA2) * gup * dzc[i * FP + c] * kls[c] + bad : 0.0f;
+#pragma unroll
+            for (int c = 0; c < FP; ++c)
+                if (c < f) d_z_p[(b * n + i) * (long)f + c] = (i < nv) ? (2.0f * INV_KAPPA2) * osn * gup * dzi[c] * kls[c] + bad : 0.0f;
         }
         if (a.mean_mode == PACOH_MEAN_VECTOR) {
             float* d_mean_p = LATE(d_mean);
@@ -485,13 +528,13 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
 #pragma unroll
     for (int c = 0; c < FP; ++c) {
         if (c < f) {
-            const float sc = wave_sum_(dls[c]);
+            const float sc = -2.0f * osn * wave_sum_(dls[c]);
             if (lane == 0) LATE(d_ls)[b * f + c] = (INV_KAPPA2 / KAPPA) * gup * sc * kls[c] + bad;
         }
     }
     // a padding row's diagonal entry is G_ii = (0 - 1) osn exactly, with kernel entry 1: out of both sums again
     const float padc = (float)(NP - nv) * osn;
-    const float sdos = wave_sum_(msum) + padc, sdnz = padc - wave_sum_(dnz);
+    const float sdos = osn * wave_sum_(msum) + padc, sdnz = padc - osn * wave_sum_(dnz);
     if (lane == 0) {
         float* d_os_p = LATE(d_os);
         if (d_os_p) d_os_p[b] = gup * sdos / os + bad;

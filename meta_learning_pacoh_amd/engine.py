@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import parallel
 
 
 def nn_param_layout(input_dim, output_dim, layer_sizes):
@@ -147,6 +148,7 @@ class StepFeed:
     advances the device-side counter."""
 
     def __init__(self, device, dtype, tb, chunk=1024, aux_shape=None):
+        chunk = max(int(chunk), GRAPH_STEPS)              # (a several-steps graph reads GRAPH_STEPS consecutive rows)
         self.device, self.dtype, self.tb, self.chunk = device, dtype, int(tb), int(chunk)
         self.idx_all = torch.zeros(chunk, tb, dtype=torch.int64, device=device) if tb > 0 else None
         self.idx = torch.zeros(tb, dtype=torch.int64, device=device) if tb > 0 else None
@@ -173,14 +175,21 @@ class StepFeed:
         self._slot = 1 - q
         if self._ev[q] is not None:
             self._ev[q].synchronize()                    # the copies that last read this staging set have executed
+        # Rows k .. GRAPH_STEPS-1 repeat the last real row: the warm-up and capture runs of the several-steps graph read GRAPH_STEPS
+        # rows whatever k is (meta_fit's first chunk is ONE step), and must see valid task indices and step scalars there -- not
+        # stale rows, not the zeros of a fresh buffer (lr = 0 and bias correction 0 give NaN optimizer state)
+        kk = max(k, GRAPH_STEPS)
         self._h_sc[q][:k].copy_(torch.as_tensor(np.asarray(sc_rows, dtype=np.float64)))
-        self.sc_all[:k].copy_(self._h_sc[q][:k], non_blocking=True)
+        self._h_sc[q][k:kk] = self._h_sc[q][k - 1]
+        self.sc_all[:kk].copy_(self._h_sc[q][:kk], non_blocking=True)
         if self.tb > 0:
             self._h_idx[q][:k].copy_(torch.from_numpy(np.ascontiguousarray(idx_rows)).reshape(k, self.tb))
-            self.idx_all[:k].copy_(self._h_idx[q][:k], non_blocking=True)
+            self._h_idx[q][k:kk] = self._h_idx[q][k - 1]
+            self.idx_all[:kk].copy_(self._h_idx[q][:kk], non_blocking=True)
         if self.aux_all is not None:
             self._h_aux[q][:k].copy_(aux_rows)
-            self.aux_all[:k].copy_(self._h_aux[q][:k], non_blocking=True)
+            self._h_aux[q][k:kk] = self._h_aux[q][k - 1]
+            self.aux_all[:kk].copy_(self._h_aux[q][:kk], non_blocking=True)
         self.ctr.zero_()
         self._ev[q] = self._ev[q] or torch.cuda.Event()
         self._ev[q].record()
@@ -229,19 +238,59 @@ def replay_steps(n, graph_one, graph_many):
         graph_one.replay()
 
 
-def capture_graph(body, warmup=2):
+def capture_graph(body, warmup=2, before=None):
     """hipGraph of body(): warm-up runs on a side stream first (workspaces get allocated outside the graph's pool), then the
-    capture; the caller restores whatever state the warm-up runs changed"""
+    capture; before() (not captured) runs in front of every one of these runs -- the learners rewind their feed's step counter
+    with it, so that no run reads past the rows the feed holds; the caller restores whatever state the runs changed"""
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(warmup):
+            if before is not None:
+                before()
             body()
     torch.cuda.current_stream().wait_stream(side)
+    if before is not None:
+        before()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    # several ranks: torch.distributed's watchdog thread polls events while this thread captures; with the default (global) capture
+    # mode that is an error raised into the capture
+    kw = {'capture_error_mode': 'thread_local'} if parallel.world()[1] > 1 else {}
+    with torch.cuda.graph(graph, **kw):
         body()
     return graph
+
+
+def build_step_graphs(body_likelihood, exchange, body_update, feed, many_ok=True):
+    """the hipGraphs of one meta-training step = body_likelihood -> exchange (the all-reduce of the packed buffer) -> body_update:
+    ((whole step,), four steps) when the exchange can be captured (world size 1, or RCCL on the compute stream:
+    parallel.collective_in_graph()), else ((likelihood, update), None) around the eager torch.distributed call"""
+    def rewind():
+        feed.ctr.zero_()
+    if parallel.collective_in_graph():
+        def whole():
+            body_likelihood()
+            exchange()
+            body_update()
+
+        def several():
+            for _ in range(GRAPH_STEPS):
+                whole()
+        return (capture_graph(whole, before=rewind),), (capture_graph(several, before=rewind) if many_ok else None)
+    return (capture_graph(body_likelihood, before=rewind), capture_graph(body_update, before=rewind)), None
+
+
+def run_step(graphs, graphed, body_likelihood, exchange, body_update):
+    """one step: replayed from build_step_graphs()'s graphs, or the same launches issued one by one"""
+    if graphed:
+        graphs[0].replay()
+        if len(graphs) > 1:
+            exchange()
+            graphs[1].replay()
+    else:
+        body_likelihood()
+        exchange()
+        body_update()
 
 
 class StepMode:

@@ -1,20 +1,28 @@
 """Multi-GPU sharding of the task dimension: rank r owns tasks r::world of the step's
 (globally drawn, shared-seed) task batch and all P particles; partial sum_t mll[t,:] and partial score
-[P,D] are summed with ONE all-reduce per step -- torch.distributed 'nccl' backend = RCCL over xGMI on
-the GPU box, 'gloo' in the CPU tests.  Nothing else is exchanged; prior term, SVGD kernel and optimizer
-are replicated (deterministic, identical on every rank).
+[P,D] are summed with ONE all-reduce per step over RCCL / xGMI.  Nothing else is exchanged; prior term,
+SVGD kernel and optimizer are replicated (deterministic, identical on every rank).
 
-The collective itself is torch.distributed's by default.  PACOH_COMM=rccl (or enable_direct_rccl()) switches the packed-buffer
-reduce to the library's own pacoh_allreduce_sum: the same RCCL all-reduce, enqueued on the stream the kernels run on, so the
-step has no cross-stream event hop; torch.distributed is then only the out-of-band channel for the communicator id."""
+Which call carries the exchange (round 3):
+* torch.distributed backend 'nccl' (one rank per GPU -- the measured configuration): the library's own pacoh_allreduce_sum, i.e.
+  RCCL's ncclAllReduce enqueued on the stream the kernels run on -- no cross-stream event hop, and CAPTURED INSIDE the step's
+  hipGraph, so that a multi-rank step is one graph (and four steps per replay) exactly like a single-rank one.  The communicator is
+  created once (its id travels through the c10d store) and proves itself before it is trusted: an eager all-reduce and a captured +
+  replayed one on known values, agreed on by all ranks; if anything fails the learners fall back to
+* torch.distributed.all_reduce between two graphs per step (also what the 'gloo' CPU tests and the two-ranks-on-one-GPU tests
+  use: RCCL refuses two ranks per device).  PACOH_COMM=torch forces this path, PACOH_COMM=rccl the first one regardless of backend.
+The packed buffer is P*D + P floats whatever the number of tasks: splitting a shard in halves does not shrink what has to be
+reduced, it doubles it -- the exchange is latency-bound (203 KB at cfg #3) and sits between the last gradient kernel and the
+update, so the lever is its latency (same stream, inside the graph), not pipelining."""
 import os
+import warnings
 
 import torch
 import torch.distributed as dist
 
 from . import _lib as L
 
-_direct = None      # RcclComm once enable_direct_rccl() has run
+_direct = None      # RcclComm once enable_direct_rccl() has run; False = tried and given up (torch.distributed carries the exchange)
 
 
 def world():
@@ -55,19 +63,83 @@ def check_same_draws(idx_rows, sc_rows):
     assert all(b == box[0] for b in box), 'ranks drew different task batches: host RNG streams are out of step'
 
 
-class RcclComm:
-    """pacoh_comm_* handle of this rank (include/pacoh_gp.h, section 8e): created collectively by every rank"""
+_comm_serial = 0
 
-    def __init__(self):
+
+def _exchange_unique_id(rank, w):
+    """rank 0's fresh RCCL communicator id on every rank: through the c10d key-value store (host side, no collective, no device
+    traffic) when torch.distributed has one, else as a broadcast object"""
+    global _comm_serial
+    _comm_serial += 1
+    if w == 1:
+        return L.comm_unique_id()
+    store = None
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:
+        store = None
+    if store is not None:
+        key = 'pacoh_rccl_uid_%d' % _comm_serial
+        if rank == 0:
+            store.set(key, L.comm_unique_id())
+        return bytes(store.get(key))
+    uid = [L.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    return uid[0]
+
+
+class RcclComm:
+    """pacoh_comm_* handle of this rank (include/pacoh_gp.h, section 8e): created collectively by every rank.  graph_ok: the
+    all-reduce survived capture into a hipGraph and two replays with the right sums on EVERY rank (self_test)"""
+
+    def __init__(self, self_test=True):
         rank, w = world()
-        uid = [L.comm_unique_id() if rank == 0 else None]
-        if w > 1:
-            dist.broadcast_object_list(uid, src=0)
-        self.world_size = w
-        self.handle = L.comm_init(uid[0], rank, w)
+        self.rank, self.world_size = rank, w
+        self.handle = L.comm_init(_exchange_unique_id(rank, w), rank, w)
+        self.graph_ok = False
+        if self_test:
+            self.graph_ok = self._self_test()
 
     def all_reduce_(self, buf):
         return L.allreduce_sum(buf, self.handle)
+
+    def _self_test(self):
+        """eager all-reduce, then the same call captured in a hipGraph and replayed twice, on values whose sums are known; every rank
+        must see every check pass (the verdicts are combined with a MIN all-reduce through torch.distributed)"""
+        w, rank = self.world_size, self.rank
+        dev = torch.device('cuda', torch.cuda.current_device())
+        total = w * (w + 1) / 2.0
+        ok = True
+        try:
+            buf = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=dev)
+            self.all_reduce_(buf)
+            torch.cuda.synchronize()
+            ok = ok and bool((buf == total).all())
+            buf.fill_(float(rank + 1))
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.all_reduce_(buf)                      # (warm-up on the capture stream's side, as capture_graph does)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            buf.fill_(float(rank + 1))
+            graph = torch.cuda.CUDAGraph()
+            kw = {'capture_error_mode': 'thread_local'} if w > 1 else {}      # (torch.distributed's watchdog thread: see capture_graph)
+            with torch.cuda.graph(graph, **kw):
+                self.all_reduce_(buf)
+            graph.replay()                                 # every rank: total
+            graph.replay()                                 # every rank: w * total
+            torch.cuda.synchronize()
+            ok = ok and bool((buf == w * total).all())
+            del graph
+        except Exception as exc:                           # a capture the RCCL build does not support, a launch error, ...
+            warnings.warn('pacoh: in-graph RCCL all-reduce self-test failed on rank %d: %r' % (rank, exc))
+            ok = False
+        if w > 1:
+            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item() > 0)
+        return ok
 
     def close(self):
         if self.handle is not None:
@@ -78,22 +150,53 @@ class RcclComm:
 def enable_direct_rccl():
     """collective call (all ranks): route the step's all-reduce through pacoh_allreduce_sum from now on"""
     global _direct
-    if _direct is None:
+    if not _direct:
         _direct = RcclComm()
     return _direct
 
 
 def disable_direct_rccl():
     global _direct
-    if _direct is not None:
+    if _direct:
         _direct.close()
-        _direct = None
+    _direct = None
+
+
+def _want_direct():
+    """policy (see the module comment): RCCL on the compute stream whenever every rank has its own GPU"""
+    mode = os.environ.get('PACOH_COMM', '')
+    if mode == 'torch':
+        return False
+    if mode == 'rccl':
+        return True                                       # (also at world size 1: tests capture the collective on one GPU)
+    return world()[1] > 1 and dist.get_backend() == 'nccl'
 
 
 def _direct_comm():
-    if _direct is None and os.environ.get('PACOH_COMM', '') == 'rccl':
-        enable_direct_rccl()
-    return _direct
+    """the RcclComm carrying the step's exchange, or None (torch.distributed carries it).  Collective on first use: every rank
+    reaches it at the same point of the program (the learners call collective_in_graph() when they set up their step)"""
+    global _direct
+    if _direct is None and _want_direct():
+        try:
+            _direct = RcclComm()
+        except Exception as exc:
+            warnings.warn('pacoh: RCCL communicator could not be created (%r): torch.distributed carries the all-reduce' % (exc,))
+            _direct = False
+        if _direct and world()[1] > 1 and not _direct.graph_ok:
+            # the communicator exists but does not survive graph capture here: use it eagerly?  No -- one code path less to
+            # trust on hardware this build never saw: fall back to torch.distributed between two graphs
+            _direct.close()
+            _direct = False
+    return _direct or None
+
+
+def collective_in_graph():
+    """True: the step's exchange may be captured inside the step graph (world size 1: there is none, or a forced world-size-1
+    communicator that passed its self-test); False: two graphs per step around an eager torch.distributed.all_reduce"""
+    comm = _direct_comm()
+    if comm is not None:
+        return comm.graph_ok
+    return world()[1] == 1
 
 
 def packed_score_buffer(P, D, dtype, device):
@@ -105,13 +208,10 @@ def packed_score_buffer(P, D, dtype, device):
 
 def all_reduce_buffer_(buf):
     """buf := sum over ranks of buf, in place (identity at world size 1): the step's one exchange"""
-    _, w = world()
-    if w == 1:
-        return buf
     comm = _direct_comm()
     if comm is not None:
         comm.all_reduce_(buf)
-    else:
+    elif world()[1] > 1:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 
@@ -119,17 +219,13 @@ def all_reduce_buffer_(buf):
 def all_reduce_sum_(lik, score, packed=None):
     """sum [P] and [P,D] over ranks with one collective on a packed buffer; identity at world size 1.
     `packed`: the buffer of packed_score_buffer() whose views lik / score are (reduced in place, no copies)"""
+    if packed is not None:
+        all_reduce_buffer_(packed)
+        return lik, score
     _, w = world()
     if w == 1:
         return lik, score
     P, D = score.shape
-    if packed is not None:
-        comm = _direct_comm()
-        if comm is not None:
-            comm.all_reduce_(packed)
-        else:
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM)
-        return lik, score
     buf = torch.cat([score.reshape(-1), lik.reshape(-1)])
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf[P * D:].reshape(P), buf[:P * D].reshape(P, D)

@@ -580,6 +580,35 @@ def _fit(M, kind, tasks, n_iter, **kw):
     return m, m.theta
 
 
+@pytest.mark.parametrize('kind', ['svgd', 'vi', 'map'])
+def test_step_graph_with_the_captured_rccl_all_reduce(M, kind, monkeypatch):
+    """the multi-rank step as ONE hipGraph: PACOH_COMM=rccl puts the step's exchange -- pacoh_allreduce_sum on the compute stream, a
+    world-size-1 RCCL communicator on this one-GPU box -- INSIDE the captured step (and the four-steps-per-replay graph); the
+    communicator's own capture self-test must pass, and the replayed run must equal the run without any collective bit for bit"""
+    from meta_learning_pacoh_amd import parallel
+    rs = np.random.RandomState(7)
+    tasks = [(x, np.sin(x[:, :1]) + 0.3 * x[:, 1:] + 0.05 * rs.randn(12, 1)) for x in (rs.uniform(-3, 3, size=(12, 2)) for _ in range(6))]
+    parallel.disable_direct_rccl()
+    m_ref, ref = _fit(M, kind, tasks, 11)
+    assert parallel._direct_comm() is None
+    monkeypatch.setenv('PACOH_COMM', 'rccl')
+    try:
+        calls = []
+        real = parallel.RcclComm.all_reduce_
+        monkeypatch.setattr(parallel.RcclComm, 'all_reduce_', lambda self, buf: (calls.append(buf.numel()), real(self, buf))[1])
+        m_c, got = _fit(M, kind, tasks, 11)
+        comm = parallel._direct_comm()
+        assert comm is not None and comm.world_size == 1 and comm.graph_ok and parallel.collective_in_graph()
+        assert m_c._graphs is not None and len(m_c._graphs) == 1 and m_c._graph_many is not None
+        # captured, not called per step: 3 self-test calls + (2 warm-ups + 1 capture) x (1 + 4 steps) = 18 Python-level calls for
+        # 11 steps, every one of them on the learner's packed buffer
+        assert len(calls) == 3 + 3 * 5 and set(calls[3:]) == {m_c._packed.numel()}
+        assert bool(torch.isfinite(got).all()) and torch.equal(ref, got)
+    finally:
+        monkeypatch.delenv('PACOH_COMM')
+        parallel.disable_direct_rccl()
+
+
 @pytest.mark.parametrize('layers', [(32, 32), (32, 32, 32, 32), (128, 128, 128, 128)])
 @pytest.mark.parametrize('kind', ['svgd', 'vi', 'map'])
 def test_graph_replay_is_bit_identical_to_eager_launches(M, kind, layers, monkeypatch):
