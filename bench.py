@@ -123,6 +123,7 @@ def main():
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
     ap.add_argument('--config', type=int, choices=[2, 3, 4, 5], default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -186,21 +187,79 @@ def main():
         elapsed = float(tt.item())
     finite = wl['finite']()
     ms_per_step = elapsed / args.steps * 1e3
+    evals_per_step, metric, dtype, describe, extra = wl['evals_per_step'], wl.get('metric'), wl['dtype'], wl['describe'], wl.get('extra', {})
+    step_mode = wl.get('mode', lambda: None)()
+    from meta_learning_pacoh_amd import parallel
+    comm = parallel._direct_comm() if world > 1 else None
+    exchange = None if world == 1 else ('pacoh_allreduce_sum (RCCL) on the compute stream, captured in the step graph' if comm is not None
+                                        else 'torch.distributed.all_reduce between two graphs per step')
 
-    # ---- per-kernel breakdown with HIP events on the launch stream: a separate pass that issues the SAME launch sequence
-    #      eagerly (PACOH_NO_GRAPH=1; events cannot be read out of a graph replay) ----------------------------------------
-    prof_steps = min(args.steps, 50)
+    pp = profile_pass(wl, L, min(args.steps, 50))
+    kernel_ms, kernel_sum, prof_ms = pp['kernel_ms'], pp['kernel_sum'], pp['ms_per_step']
+    roofline, kernel_rooflines, step_flops = rooflines(wl, pp)
+
+    gram = gram_leg(L) if (rank == 0 and args.config == 3) else None
+
+    # the other BASELINE configurations (parity-test cases, not the headline): bounded legs on the same box so that their numbers
+    # are driver-visible too -- N = 1, default config only
+    others = None
+    if rank == 0 and world == 1 and args.config == 3 and not args.no_other_configs:
+        del wl
+        torch.cuda.empty_cache()
+        others = {'cfg%d' % c: other_config_leg(c, M, L) for c in (2, 4, 5)}
+
+    if rank == 0:
+        cpu = None if (args.no_cpu_baseline or world > 1 or args.config != 3) else cpu_baseline()
+        value = evals_per_step * args.steps / elapsed
+        out = {
+            'metric': 'task-GP LML+grad evals/sec (n_ctx=64, d=4, 20 particles)' if args.config == 3 else metric,
+            'value': round(value, 1), 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': args.scaling,
+            'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
+            'backend': (backend if world > 1 else None), 'world_size_seen': (dist.get_world_size() if world > 1 else 1),
+            'exchange': exchange,
+            'host_ms_per_step': round(host_ms, 4), 'step_mode': step_mode,
+            'config': dict({'workload': describe, 'evals_per_step': evals_per_step,
+                            'parallelism': 'task-shard x%d' % world, 'finite': finite}, **extra),
+            'roofline': roofline, 'kernel_rooflines': kernel_rooflines,
+            'step_algorithmic_tflops': round(step_flops / (ms_per_step * 1e-3) / 1e12, 3),
+            'gram_roofline': gram,
+            # per-kernel HIP-event times come from a SEPARATE pass that issues the same launch sequence eagerly (events cannot be
+            # read out of a graph replay); that pass's own wall time per step is printed next to them: kernel_sum <= profile pass
+            'kernel_ms_per_step': kernel_ms,
+            'kernel_sum_ms_per_step': round(kernel_sum, 4),
+            'profile_pass_ms_per_step': round(prof_ms, 4),
+            'launch_gaps_ms_per_step': round(prof_ms - kernel_sum, 4),
+            'other_configs': others,
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def profile_pass(wl, L, prof_steps):
+    """per-kernel times with HIP events on the launch stream: the SAME launch sequence issued eagerly (PACOH_NO_GRAPH=1), and the
+    wall time per step of that very pass"""
     os.environ['PACOH_NO_GRAPH'] = '1'
     wl['run'](2)
     torch.cuda.synchronize()
     L.PROFILE = {}
+    t0 = time.perf_counter()
     wl['run'](prof_steps)
     torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
     prof = L.profile_summary()
     L.PROFILE = None
     os.environ.pop('PACOH_NO_GRAPH')
-    kernel_ms = {k: round(v[1] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
-    kernel_sum = sum(v[1] for v in prof.values()) / prof_steps
+    return {'prof': prof, 'steps': prof_steps, 'ms_per_step': wall / prof_steps * 1e3,
+            'kernel_ms': {k: round(v[1] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+            'kernel_sum': sum(v[1] for v in prof.values()) / prof_steps}
+
+
+def rooflines(wl, pp):
+    prof, prof_steps = pp['prof'], pp['steps']
     peak = FP64_PEAK_TFLOPS if wl['dtype'] == 'f64' else FP32_PEAK_TFLOPS
 
     def kernel_roofline(name):
@@ -214,8 +273,9 @@ def main():
                 'ms_per_step': round(per_step_s * 1e3, 4), 'launches_per_step': launches / prof_steps,
                 'traffic': pmc_traffic(key) if key else None,
                 'traffic_source': 'committed PMC profile %s (not measured in this run)' % PMC_PROFILE,
-                'note': 'algorithmic flops per step and GPU (SURVEY 8d model; MLP backward = 4 n W, its forward recompute is '
-                        'counted only in executed_frac) / HIP-event time of the kernel in this run / %s peak %.1f TFLOP/s'
+                'note': 'algorithmic flops per step and GPU (SURVEY 8d model; MLP backward = 4 n W, the part of the forward it still '
+                        'recomputes -- the first layer, the rest comes from the activation stash -- is counted only in executed_frac) '
+                        '/ HIP-event time of the kernel in this run / %s peak %.1f TFLOP/s'
                         % ('fp64 matrix' if wl['dtype'] == 'f64' else 'fp32', peak)}
 
     modelled = [k for k in wl['flops'] if k in prof]
@@ -223,34 +283,31 @@ def main():
     roofline = kernel_roofline(dom) if dom else None
     kernel_rooflines = {k: {kk: r[kk] for kk in ('achieved', 'algorithmic_frac', 'executed_frac', 'ms_per_step', 'unit')}
                         for k, r in ((k, kernel_roofline(k)) for k in modelled)}
-    step_flops = sum(wl['flops'][k][0] for k in modelled)
+    return roofline, kernel_rooflines, sum(wl['flops'][k][0] for k in modelled)
 
-    gram = gram_leg(L) if (rank == 0 and args.config == 3) else None
 
-    if rank == 0:
-        cpu = None if (args.no_cpu_baseline or world > 1 or args.config != 3) else cpu_baseline()
-        value = wl['evals_per_step'] * args.steps / elapsed
-        out = {
-            'metric': 'task-GP LML+grad evals/sec (n_ctx=64, d=4, 20 particles)' if args.config == 3 else wl['metric'],
-            'value': round(value, 1), 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': args.scaling,
-            'vs_baseline': None, 'dtype': wl['dtype'], 'data': 'synthetic',
-            'backend': (backend if world > 1 else None), 'world_size_seen': (dist.get_world_size() if world > 1 else 1),
-            'host_ms_per_step': round(host_ms, 4), 'step_mode': wl.get('mode', lambda: None)(),
-            'config': dict({'workload': wl['describe'], 'evals_per_step': wl['evals_per_step'],
-                            'parallelism': 'task-shard x%d' % world, 'finite': finite}, **wl.get('extra', {})),
-            'roofline': roofline, 'kernel_rooflines': kernel_rooflines,
-            'step_algorithmic_tflops': round(step_flops / (ms_per_step * 1e-3) / 1e12, 3),
-            'gram_roofline': gram,
-            'kernel_ms_per_step': kernel_ms,
-            'kernel_sum_ms_per_step': round(kernel_sum, 4),
-            'launch_gaps_ms_per_step': round(ms_per_step - kernel_sum, 4),
-            'cpu_baseline': cpu,
-        }
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+def other_config_leg(cfg, M, L, steps=100):
+    """one of BASELINE.json's other configurations, timed like the headline one but bounded (about 2-3 s): 64 untimed steps, `steps`
+    timed ones between synchronisations, then the eager per-kernel pass"""
+    wl = WORKLOADS[cfg](1, 'weak', M, L)
+    wl['run'](64)
+    torch.cuda.synchronize()
+    wl['run'](32)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wl['run'](steps)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    pp = profile_pass(wl, L, min(steps, 30))
+    roofline, _, step_flops = rooflines(wl, pp)
+    out = {'metric': wl['metric'], 'workload': wl['describe'], 'dtype': wl['dtype'], 'steps': steps, 'ms_per_step': round(ms, 4),
+           'value': round(wl['evals_per_step'] / (ms * 1e-3), 1), 'unit': 'evals/s', 'finite': wl['finite'](),
+           'step_algorithmic_tflops': round(step_flops / (ms * 1e-3) / 1e12, 3),
+           'dominant_kernel': None if roofline is None else {k: roofline[k] for k in ('kernel', 'achieved', 'peak', 'unit', 'algorithmic_frac', 'ms_per_step')},
+           'kernel_ms_per_step': pp['kernel_ms'], 'profile_pass_ms_per_step': round(pp['ms_per_step'], 4)}
+    del wl
+    torch.cuda.empty_cache()
+    return out
 
 
 def gram_leg(L):
@@ -299,10 +356,11 @@ def wl_cfg3(world, scaling, M, L):
                                           mean_module='NN', task_batch_size=-1, lr=1e-3, random_seed=0)
     ev = T_global * PARTICLES / world
     w = net_macs(DIM, (32, 32), 1) + net_macs(DIM, (32, 32), 2)                 # 2400 MAC per point over both networks
+    w1 = 2 * DIM * 32                                                           # ... of which the first layers (recomputed by the backward)
     return dict(run=model._train_steps, evals_per_step=T_global * PARTICLES, dtype='f32', mode=lambda: _mode(model),
                 finite=lambda: bool(torch.isfinite(model.particles).all()),
                 flops={'gp_lml_fwdbwd': (gp_flops(N_CTX, 2) * ev,) * 2, 'mlp_fwd': (2 * N_CTX * w * ev,) * 2,
-                       'mlp_bwd': (4 * N_CTX * w * ev, 6 * N_CTX * w * ev)},
+                       'mlp_bwd': (4 * N_CTX * w * ev, (4 * w + 2 * w1) * N_CTX * ev)},
                 pmc_keys={'gp_lml_fwdbwd': 'gp_reg_kernel', 'mlp_fwd': 'mlp_fused_fwd', 'mlp_bwd': 'mlp_fused_bwd'},
                 describe='PACOH-SVGD step as meta_fit runs it (hipGraph replay), cfg#3: %d tasks %s x %d particles, n_ctx=%d, d=%d, '
                          'NN(32,32) mean + NN(32,32) kernel (D=%d), task sharding + 1 all-reduce/step'
@@ -333,7 +391,7 @@ def wl_cfg4(world, scaling, M, L):
     return dict(run=model._train_steps, evals_per_step=T * S, dtype='f32', finite=lambda: bool(torch.isfinite(model.posterior).all()), mode=lambda: _mode(model),
                 metric='task-GP LML+grad evals/sec (PACOH-VI, 512 tasks, n_ctx=128, 10 posterior samples)',
                 flops={'gp_lml_fwdbwd': (gp_flops(128, 2) * ev,) * 2, 'mlp_fwd': (2 * 128 * w * ev,) * 2,
-                       'mlp_bwd': (4 * 128 * w * ev, 6 * 128 * w * ev)},
+                       'mlp_bwd': (4 * 128 * w * ev, (4 * w + 2 * 2 * 32) * 128 * ev)},
                 describe='PACOH-VI step (hipGraph replay), cfg#4: %d tasks x %d samples, n_ctx=128, d=1, NN(32,32) mean + kernel' % (T, S),
                 extra={'tasks_total': T, 'samples': S, 'n_ctx': 128, 'd': 1})
 

@@ -99,6 +99,16 @@ def test_cfg4_vi_512_tasks_n128_10_samples(M):
         x, y = O.prepare_task(*tasks[t], stats, torch.float64)
         ref = O.vectorized_gp_mll(theta.cpu().double(), x, y, cfg)
         assert relerr(lml[t], ref) < 2e-3
+    # the full score [S, D] of a 16-task sub-batch at n = 128 vs oracle autograd in fp64 (bar 1e-2 in fp32; asserted at 2e-3)
+    sub = list(range(7, 512, 32))
+    assert len(sub) == 16
+    otasks = [O.prepare_task(*tasks[t], stats, torch.float64) for t in sub]
+    thd = theta.cpu().double().clone().requires_grad_(True)
+    torch.stack([O.vectorized_gp_mll(thd, x, y, cfg) for x, y in otasks], -1).sum().backward()
+    _, g16, _ = model.engine.lml_and_grad(theta, model.tasks.select(torch.tensor(sub, device=theta.device)), weight=1.0)
+    assert g16.shape == (S, model.layout.D)
+    assert relerr(g16, thd.grad) < 2e-3
+    assert max(relerr(g16[q], thd.grad[q]) for q in range(S)) < 5e-3
     loss = model.meta_fit(n_iter=2, verbose=False)
     assert np.isfinite(loss)
 
@@ -121,6 +131,19 @@ def test_cfg5_large_context_256_tasks_n512_d8_fp64_all_tasks_vs_oracle(M):
     # K^-1 y round trip: (K + s2 I) alpha == y
     K2 = L.gram_rbf_ard(X.cuda(), 1, X.cuda(), 1, ls.cuda(), None, noise.cuda(), True, T, 1)
     assert relerr(torch.bmm(K2, alpha.unsqueeze(-1)).squeeze(-1), Y) < 1e-10
+    # the gradient path at full size (pacoh_gp_lml_dense over all 256 problems: Cholesky -> triangular inverse -> Z^T Z ->
+    # contractions): LML of every problem, gradients of 4 of them against oracle autograd in fp64 at 1e-7
+    Xd, Yd = X.cuda(), Y.cuda()
+    os1 = torch.ones(1, dtype=torch.float64, device='cuda')
+    lml, d_z, d_mean, d_ls, d_os, d_noise, info2 = L.gp_lml_fwdbwd(Xd, 1, None, L.MEAN_ZERO, Yd, 1, ls.cuda(), os1, noise.cuda(), T, 1)
+    assert int(info2.abs().max()) == 0 and float(((lml.cpu() - ref).abs() / ref.abs()).max()) < 1e-8
+    for t in (0, 85, 170, 255):
+        z = X[t:t + 1].clone().requires_grad_(True)
+        lsr, nzr, osr = ls.clone().requires_grad_(True), noise.clone().requires_grad_(True), torch.ones((), dtype=torch.float64, requires_grad=True)
+        O.gp_mll(z, torch.zeros(1, n, dtype=torch.float64), Y[t:t + 1], lsr.unsqueeze(0), osr, nzr).sum().backward()
+        assert relerr(d_z[t], z.grad[0]) < 1e-7
+        assert relerr(d_ls[t], lsr.grad.reshape(-1)) < 1e-7
+        assert relerr(d_noise[t], nzr.grad.reshape(-1)[0]) < 1e-7 and relerr(d_os[t], osr.grad) < 1e-7
 
 
 def test_bench_line_contract():
@@ -161,5 +184,15 @@ def test_bench_line_contract():
     # (separate eager pass) plus the reported launch gaps add up to the step
     assert d['world_size_seen'] == 1 and d['host_ms_per_step'] < d['ms_per_step']
     assert 0 < roof['algorithmic_frac'] <= roof['executed_frac'] < 1 and 'not measured in this run' in roof['traffic_source']
-    assert abs(d['kernel_sum_ms_per_step'] + d['launch_gaps_ms_per_step'] - d['ms_per_step']) < 1e-3
+    # the per-kernel breakdown describes its OWN pass: kernel times <= that pass's wall time per step
+    assert abs(d['kernel_sum_ms_per_step'] + d['launch_gaps_ms_per_step'] - d['profile_pass_ms_per_step']) < 1e-3
+    assert d['kernel_sum_ms_per_step'] <= d['profile_pass_ms_per_step'] and d['launch_gaps_ms_per_step'] >= 0
     assert abs(sum(d['kernel_ms_per_step'].values()) - d['kernel_sum_ms_per_step']) < 1e-2
+    # the other BASELINE configurations ride along, bounded, so that the driver sees them too
+    oc = d['other_configs']
+    assert set(oc) == {'cfg2', 'cfg4', 'cfg5'}
+    for leg in oc.values():
+        assert leg['finite'] is True and leg['value'] > 0 and leg['ms_per_step'] > 0
+        assert abs(leg['value'] - {'cfg2': 256, 'cfg4': 5120, 'cfg5': 256}[[k for k, v in oc.items() if v is leg][0]] / (leg['ms_per_step'] * 1e-3)) <= 2e-3 * leg['value']
+        assert 0 < leg['dominant_kernel']['algorithmic_frac'] < 1
+    assert oc['cfg5']['dtype'] == 'f64' and oc['cfg2']['dtype'] == oc['cfg4']['dtype'] == 'f32'
