@@ -73,3 +73,60 @@ def test_jitter_retry_on_rank_deficient_gram():
     z = torch.zeros(6, 2)                      # all points identical -> K = ones, singular w/o noise
     L = O.psd_safe_cholesky(O.gram_rbf_ard(z, z, torch.ones(2)))
     assert torch.isfinite(L).all()
+
+
+def test_svgd_vi_flavour_restated_independently_with_numpy_and_scipy():
+    """The SVGD / VI flavour of the GP (SEKernelLight with unit outputscale, plain-softplus noise without a floor, the m~/(m~+T)
+    pre-factor, prior_factor on the hyper-prior: models.py:418-446, random_gp.py:54-89,204-222) has no recorded reference output to
+    pin it (gpytorch is absent).  Second, independent restatement: numpy loops over the reference's flattened parameter layout
+    (bias before weight, row-major [out, in]) + scipy.stats.multivariate_normal, against the oracle's torch code."""
+    d, hidden, f = 3, (8, 8), 2
+    cfg = O.GPConfig(input_dim=d, mean_module='NN', covar_module='NN', mean_nn_layers=hidden, kernel_nn_layers=hidden)
+    pm, ps = O.hyperprior_mean_std(cfg.layout, 0.5, 3.0)
+    torch.manual_seed(4)
+    theta = O.hyperprior_sample(cfg.layout, pm, ps, 3).double()
+    rs = np.random.RandomState(2)
+    tasks = [(rs.randn(n, d), rs.randn(n)) for n in (7, 11, 11, 5)]
+
+    def net(vec, x, d_out):                              # bias BEFORE weight per layer (models.py:319-323), tanh hidden layers
+        h, pos, prev = x, 0, d
+        widths = list(hidden) + [d_out]
+        for li, width in enumerate(widths):
+            b = vec[pos:pos + width]
+            W = vec[pos + width:pos + width + width * prev].reshape(width, prev)
+            pos += width * (prev + 1)
+            h = h @ W.T + b
+            if li < len(widths) - 1:
+                h = np.tanh(h)
+            prev = width
+        assert pos == len(vec)
+        return h
+
+    def softplus(v):
+        return np.log1p(np.exp(v))
+
+    th = theta.numpy()
+    Dm = sum(O.nn_param_layout(d, 1, hidden).values())
+    Dk = sum(O.nn_param_layout(d, f, hidden).values())
+    assert th.shape[1] == Dm + Dk + f + 1
+    total = np.zeros(3)
+    for x, y in tasks:
+        n = len(y)
+        ref_t = O.vectorized_gp_mll(theta, torch.from_numpy(x), torch.from_numpy(y), cfg).numpy()
+        for p in range(3):
+            m = net(th[p, :Dm], x, 1)[:, 0]
+            z = net(th[p, Dm:Dm + Dk], x, f)
+            ell, s2 = softplus(th[p, Dm + Dk:Dm + Dk + f]), softplus(th[p, Dm + Dk + f])
+            zs = z / ell
+            K = np.exp(-0.5 * ((zs[:, None, :] - zs[None, :, :]) ** 2).sum(-1))          # unit outputscale
+            val = scipy.stats.multivariate_normal(m, K + s2 * np.eye(n), allow_singular=False).logpdf(y) / n
+            assert abs(val - ref_t[p]) < 1e-9 * max(1.0, abs(val))
+            total[p] += val
+    sizes = np.array([len(y) for _, y in tasks], dtype=np.float64)
+    hm = 1.0 / np.mean(1.0 / sizes)
+    pre = hm / (hm + len(tasks))                          # T = the BATCH length (random_gp.py:209)
+    logprior = scipy.stats.norm(pm.numpy(), ps.numpy()).logpdf(th).sum(1)
+    want = 0.01 * logprior + pre * total
+    got = O.meta_log_prob(theta, [(torch.from_numpy(x), torch.from_numpy(y)) for x, y in tasks], cfg, pm, ps, 0.01, loop=True)
+    # (the pre-factor is a float32 quantity in the reference and in the oracle: random_gp.py:209-212)
+    assert np.abs(got.numpy() - want).max() < 1e-6 * np.abs(want).max()
