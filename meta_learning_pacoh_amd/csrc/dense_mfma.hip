@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     T* Ab = A + (size_t)blockIdx.x * n * n;
-    if (tid == 0) red[16] = 0;
+    if (tid == 0) { red[16] = 0; red[100] = 0; red[101] = 0; }
     for (int q = tid; q < n; q += NT) rv[q] = resid[(size_t)blockIdx.x * n + q];
     T logdet_part = 0;
     __syncthreads();
@@ -223,25 +223,71 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
 #define CSTAMP(k) do {} while (0)
 #endif
 
-    for (int k0 = 0; k0 < n; k0 += DNB) {
-        const int kb = (n - k0 < DNB) ? (n - k0) : DNB;
-        const int t0 = k0 + kb, m = n - t0;                            // trailing rows
-        // 1. diagonal block -> LDS (identity padded)
-        for (int q = tid; q < DNB * DNB; q += NT) {
+    // One 16x16 block (ib, jb) of the trailing update A22 -= L21 L21^T, two at a time per wave so that the L2/HBM round trip of one
+    // block's accumulator overlaps the other's MFMAs.
+    auto update_pair = [&](const int (&ibs)[2], const int (&jbs)[2], const bool (&live)[2], int t0, int m) {
+        Acc acc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const T* cp = Ab + (size_t)(t0 + ibs[u] * 16) * n + t0 + jbs[u] * 16 + r;
+            const bool colok = live[u] && jbs[u] * 16 + r < m;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = Mf<T>::row(g, q);
+                acc[u][q] = (colok && ibs[u] * 16 + row < m) ? cp[(size_t)row * n] : T(0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!live[u]) continue;
+#pragma unroll
+            for (int c = 0; c < DNB / 4; ++c) {
+                const T a = -Pn[(size_t)(ibs[u] * 16 + r) * DLP + 4 * c + g];
+                const T b = Pn[(size_t)(jbs[u] * 16 + r) * DLP + 4 * c + g];
+                acc[u] = Mf<T>::mma(a, b, acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            T* cp = Ab + (size_t)(t0 + ibs[u] * 16) * n + t0 + jbs[u] * 16 + r;
+            const bool colok = live[u] && jbs[u] * 16 + r < m;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = Mf<T>::row(g, q);
+                if (colok && ibs[u] * 16 + row < m) cp[(size_t)row * n] = acc[u][q];
+            }
+        }
+    };
+    // diagonal block at k0 -> Ds (identity padded), by the threads [0, nthr)
+    auto load_diag = [&](int k0, int kb, int t, int nthr) {
+        for (int q = t; q < DNB * DNB; q += nthr) {
             const int rr = q / DNB, c = q - rr * DNB;
             T v = (rr == c) ? T(1) : T(0);
             if (rr < kb && c <= rr) v = Ab[(size_t)(k0 + rr) * n + k0 + c];
             Ds[rr][c] = v;
         }
+    };
+
+    // Look-ahead (round 3): the 32 x 32 diagonal block of panel k+1 is factored and inverted by wave 0 (10 us in fp64, registers
+    // only) WHILE the other waves run the bulk of panel k's trailing update, which is HBM-bound (16 bytes per 64 flops): the
+    // blocks of the next panel's own 32 columns are updated first by all waves, then wave 0 leaves.  (Before: one wave busy and
+    // fifteen idle for 0.18 of the 0.75 ms at n = 512.)  Per panel: 1. [prologue / previous iteration] diagonal block factored,
+    // 2. L11 and L11^-1 written back, 3. panel staged in LDS, 4. L21 = A21 L11^-T on the matrix cores, forward solve,
+    // 5a. trailing update of block columns 0-1, 5b. wave 0: next diagonal block | others: the remaining block columns.
+    {
+        const int kb0 = n < DNB ? n : DNB;
+        load_diag(0, kb0, tid, NT);
         __syncthreads();
-        CSTAMP(0);
-        // 2. wave 0: factor and invert the diagonal block
         if (tid < 64) {
             factor_invert_diag32<T>(Ds, Li, red + 32, red + 96, red + 16, tid);
-            if (tid < kb) logdet_part += t_log<T>(Ds[tid][tid]);
+            if (tid < kb0) logdet_part += t_log<T>(Ds[tid][tid]);
         }
         __syncthreads();
         CSTAMP(1);
+    }
+    for (int k0 = 0; k0 < n; k0 += DNB) {
+        const int kb = (n - k0 < DNB) ? (n - k0) : DNB;
+        const int t0 = k0 + kb, m = n - t0;                            // trailing rows
         // L11 -> lower triangle; the strictly-lower part of L11^-1 is kept, transposed, in the (otherwise unused) strictly
         // upper part of the diagonal block: the backward solve reads it from there (its diagonal is 1 / L11's diagonal)
         for (int q = tid; q < DNB * DNB; q += NT) {
@@ -298,61 +344,65 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
                 rv[t0 + rr] = sacc;
             }
             CSTAMP(4);
-            // 5. trailing update A22 -= L21 L21^T: the lower 16x16 blocks are dealt to the waves, two per step so that the
-            //    L2/HBM round trip of one block's accumulator overlaps the other's MFMAs
-            const int total = mb * (mb + 1) / 2;
-            for (int c0 = wave; c0 < total; c0 += 2 * NW) {
-                int ibs[2], jbs[2];
-                bool live[2];
+            // 5a. trailing update of the block columns 0 and 1 (the next panel's own 32 columns), by every wave:
+            //     q < mb -> block (q, 0); q >= mb -> block (q - mb + 1, 1)
+            {
+                const int first = 2 * mb - 1;
+                for (int c0 = wave; c0 < first; c0 += 2 * NW) {
+                    int ibs[2], jbs[2];
+                    bool live[2];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int c = c0 + u * NW;
-                    live[u] = c < total;
-                    int ib = (int)((sqrtf(8.0f * (float)c + 1.0f) - 1.0f) * 0.5f);
-                    while (ib * (ib + 1) / 2 > c) --ib;
-                    while ((ib + 1) * (ib + 2) / 2 <= c) ++ib;
-                    ibs[u] = ib; jbs[u] = c - ib * (ib + 1) / 2;
-                }
-                Acc acc[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const T* cp = Ab + (size_t)(t0 + ibs[u] * 16) * n + t0 + jbs[u] * 16 + r;
-                    const bool colok = live[u] && jbs[u] * 16 + r < m;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int row = Mf<T>::row(g, q);
-                        acc[u][q] = (colok && ibs[u] * 16 + row < m) ? cp[(size_t)row * n] : T(0);
+                    for (int u = 0; u < 2; ++u) {
+                        const int c = c0 + u * NW;
+                        live[u] = c < first;
+                        ibs[u] = c < mb ? c : c - mb + 1;
+                        jbs[u] = c < mb ? 0 : 1;
                     }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (!live[u]) continue;
-#pragma unroll
-                    for (int c = 0; c < DNB / 4; ++c) {
-                        const T a = -Pn[(size_t)(ibs[u] * 16 + r) * DLP + 4 * c + g];
-                        const T b = Pn[(size_t)(jbs[u] * 16 + r) * DLP + 4 * c + g];
-                        acc[u] = Mf<T>::mma(a, b, acc[u]);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    T* cp = Ab + (size_t)(t0 + ibs[u] * 16) * n + t0 + jbs[u] * 16 + r;
-                    const bool colok = live[u] && jbs[u] * 16 + r < m;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int row = Mf<T>::row(g, q);
-                        if (colok && ibs[u] * 16 + row < m) cp[(size_t)row * n] = acc[u][q];
-                    }
+                    update_pair(ibs, jbs, live, t0, m);
                 }
             }
+            __syncthreads();                                                 // (the stores above are read back below)
+            load_diag(t0, (n - t0 < DNB) ? (n - t0) : DNB, tid, NT);         // next diagonal block -> Ds: one element per thread,
+            __syncthreads();                                                 // one round trip (by wave 0 alone: sixteen in a row)
+            // 5b. wave 0: the next diagonal block, factored and inverted in registers | the other waves: block columns >= 2
+#ifdef PACOH_CHOL_STAMPS
+            const long long tb_ = wall_clock64();
+#endif
+            if (wave == 0) {
+                const int kbn = (n - t0 < DNB) ? (n - t0) : DNB;
+                factor_invert_diag32<T>(Ds, Li, red + 32, red + 96, red + 16, tid);
+                if (tid < kbn) logdet_part += t_log<T>(Ds[tid][tid]);
+            } else if (mb > 2) {
+                const int mr = mb - 2;                                       // lower triangle of the blocks (ib >= jb >= 2)
+                const int total = mr * (mr + 1) / 2;
+                for (int c0 = wave - 1; c0 < total; c0 += 2 * (NW - 1)) {
+                    int ibs[2], jbs[2];
+                    bool live[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int c = c0 + u * (NW - 1);
+                        live[u] = c < total;
+                        int ib = (int)((sqrtf(8.0f * (float)c + 1.0f) - 1.0f) * 0.5f);
+                        while (ib * (ib + 1) / 2 > c) --ib;
+                        while ((ib + 1) * (ib + 2) / 2 <= c) ++ib;
+                        ibs[u] = ib + 2; jbs[u] = c - ib * (ib + 1) / 2 + 2;
+                    }
+                    update_pair(ibs, jbs, live, t0, m);
+                }
+            }
+#ifdef PACOH_CHOL_STAMPS
+            if (tid == 0) ph_[6] += wall_clock64() - tb_;
+            if (tid == 64) red[100] += (T)(wall_clock64() - tb_);
+            if (tid == 960) red[101] += (T)(wall_clock64() - tb_);
+#endif
         }
         __syncthreads();
         CSTAMP(5);
     }
 #ifdef PACOH_CHOL_STAMPS
     if (tid == 0 && blockIdx.x == 0)
-        printf("chol phases (us): load diag %.1f | factor+invert %.1f | write L11, stage panel %.1f | panel solve %.1f | resid %.1f | trailing %.1f\n",
-               ph_[0] * 0.01, ph_[1] * 0.01, ph_[2] * 0.01, ph_[3] * 0.01, ph_[4] * 0.01, ph_[5] * 0.01);
+        printf("chol phases (us): load diag %.1f | factor+invert %.1f | write L11, stage panel %.1f | panel solve %.1f | resid %.1f | trailing %.1f (5b: wave 0 %.1f, wave 1 %.1f, wave 15 %.1f)\n",
+               ph_[0] * 0.01, ph_[1] * 0.01, ph_[2] * 0.01, ph_[3] * 0.01, ph_[4] * 0.01, ph_[5] * 0.01, ph_[6] * 0.01, (double)red[100] * 0.01, (double)red[101] * 0.01);
 #endif
 #undef CSTAMP
 
