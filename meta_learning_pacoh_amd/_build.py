@@ -78,6 +78,57 @@ def build_library(force=False, verbose=True, variant=None, extra_flags=()):
     return lib_path
 
 
+def build_asan_shim(verbose=False):
+    """Host-side AddressSanitizer build (sanitizers run on the CPU build only): every source compiled --cuda-host-only with
+    -fsanitize=address into lib/libpacoh_gp_asan_host.so (no device code: it cannot launch anything) and tests/asan/abi_shim.cpp
+    linked against it.  Returns the path of the shim executable (tests/test_abi.py runs it)."""
+    obj_dir = OBJ_DIR + '_asan_host'
+    os.makedirs(obj_dir, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    san = ['-O1', '-g', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '--cuda-host-only', '-fsanitize=address',
+           '-fno-omit-frame-pointer', '-Wno-pass-failed', '-Wno-unused-value', '-I', INCLUDE]
+    sources = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdr_m = _deps_mtime()
+
+    def compile_one(src):
+        sp, op = os.path.join(CSRC, src), os.path.join(obj_dir, src.replace('.hip', '.o'))
+        if os.path.exists(op) and os.path.getmtime(op) >= max(os.path.getmtime(sp), hdr_m):
+            return op
+        r = subprocess.run([hipcc] + san + ['-c', sp, '-o', op], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc (ASan host build) failed for %s:\n%s' % (sp, r.stdout[-4000:]))
+        return op
+
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        objs = list(ex.map(compile_one, sources))
+    # a host-only object still refers to its (absent) device code object as __hip_fatbin_<hash>: empty stand-ins, which the HIP
+    # runtime only records at load time (code objects are parsed on the first launch, and this library never launches)
+    nm = subprocess.run(['nm', '-u'] + objs, stdout=subprocess.PIPE, text=True).stdout
+    syms = sorted({ln.split()[-1] for ln in nm.splitlines() if '__hip_fatbin_' in ln})
+    stub_c = os.path.join(obj_dir, 'fatbin_stubs.c')
+    with open(stub_c, 'w') as fh:
+        fh.write(''.join('__attribute__((aligned(4096))) const char %s[64] = {0};\n' % sym for sym in syms))
+    stub_o = stub_c[:-2] + '.o'
+    subprocess.run(['gcc', '-fPIC', '-c', stub_c, '-o', stub_o], check=True)
+    objs = objs + [stub_o]
+    lib_path = os.path.join(LIB_DIR, 'libpacoh_gp_asan_host.so')
+    r = subprocess.run([hipcc, '-shared', '-fPIC', '-fsanitize=address', '-o', lib_path] + objs,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('ASan host link failed:\n%s' % r.stdout[-4000:])
+    shim_src = os.path.join(os.path.dirname(HERE), 'tests', 'asan', 'abi_shim.cpp')
+    shim = os.path.join(obj_dir, 'abi_shim')
+    r = subprocess.run([hipcc, '-x', 'c++', '-O1', '-g', '-std=c++17', '-fsanitize=address', '-fno-omit-frame-pointer', '-I', INCLUDE,
+                        shim_src, '-x', 'none', lib_path, '-Wl,-rpath,' + LIB_DIR, '-o', shim],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('ASan shim build failed:\n%s' % r.stdout[-4000:])
+    if verbose:
+        print('[pacoh build] ASan host shim:', shim, file=sys.stderr)
+    return shim
+
+
 if __name__ == '__main__':
     # python -m meta_learning_pacoh_amd._build [--force] [--variant NAME -DFLAG ...]
     argv = sys.argv[1:]

@@ -153,11 +153,40 @@ def _stream():
 PROFILE = None
 
 
+class _Roctx:
+    """roctx ranges around every C-ABI call (step_begin / mlp_fwd / gp_lml_fwdbwd / mlp_bwd / hyper_bwd / svgd_phi ... -- the names
+    of the per-kernel breakdown), so that `rocprofv3 --marker-trace --kernel-trace -- python3 bench.py` attributes the kernels of
+    a step to its phases.  No-ops unless PACOH_ROCTX=1; ranges are host-side, so the attributed pass is the eager one
+    (PACOH_NO_GRAPH=1 or bench.py's per-kernel pass) -- a graph replay is one host call.  The profiler's own marker library is
+    preferred (rocprofv3 intercepts it), the classic libroctx64 is the fallback."""
+    push = pop = None
+
+    @classmethod
+    def setup(cls):
+        if os.environ.get('PACOH_ROCTX', '0') != '1':
+            return
+        for name in ('librocprofiler-sdk-roctx.so', 'librocprofiler-sdk-roctx.so.1', 'libroctx64.so', 'libroctx64.so.4'):
+            try:
+                lib = ctypes.CDLL(name)
+                push, pop = lib.roctxRangePushA, lib.roctxRangePop
+            except (OSError, AttributeError):
+                continue
+            push.argtypes, push.restype, pop.argtypes, pop.restype = [ctypes.c_char_p], ctypes.c_int, [], ctypes.c_int
+            cls.push, cls.pop = push, pop
+            return
+        raise RuntimeError('PACOH_ROCTX=1 but neither librocprofiler-sdk-roctx nor libroctx64 could be loaded')
+
+
+_Roctx.setup()
+
+
 class _Timed:
     def __init__(self, name):
         self.name = name
 
     def __enter__(self):
+        if _Roctx.push is not None:
+            _Roctx.push(('pacoh:' + self.name).encode())
         if PROFILE is not None:
             self.start = torch.cuda.Event(enable_timing=True)
             self.end = torch.cuda.Event(enable_timing=True)
@@ -168,7 +197,32 @@ class _Timed:
         if PROFILE is not None:
             self.end.record()
             PROFILE.setdefault(self.name, []).append((self.start, self.end))
+        if _Roctx.pop is not None:
+            _Roctx.pop()
         return False
+
+
+class _Range:
+    def __init__(self, name=None):
+        self.name = name
+
+    def __enter__(self):
+        if self.name is not None:
+            _Roctx.push(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        if self.name is not None:
+            _Roctx.pop()
+        return False
+
+
+_NULL_CTX = _Range()
+
+
+def roctx_range(name):
+    """context manager: a named roctx range around a phase of a step (no-op unless PACOH_ROCTX=1)"""
+    return _Range(('pacoh:step:' + name).encode()) if _Roctx.push is not None else _NULL_CTX
 
 
 def profile_summary():

@@ -288,9 +288,12 @@ def run_step(graphs, graphed, body_likelihood, exchange, body_update):
             exchange()
             graphs[1].replay()
     else:
-        body_likelihood()
-        exchange()
-        body_update()
+        with L.roctx_range('likelihood'):                  # (no-ops unless PACOH_ROCTX=1)
+            body_likelihood()
+        with L.roctx_range('exchange'):
+            exchange()
+        with L.roctx_range('update'):
+            body_update()
 
 
 class StepMode:

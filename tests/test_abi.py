@@ -78,6 +78,21 @@ def test_argument_validation_returns_error_codes_without_launching(lib):
     assert lib.pacoh_mlp2_stash_bytes(20, 10, 20, 1, hidden, 4, 1, 2, 0) == 0
 
 
+def test_host_side_address_sanitizer_shim():
+    """SURVEY section 5, row 2 (sanitizers on the CPU build only): the library's HOST code compiled with -fsanitize=address
+    (--cuda-host-only, seconds) + tests/asan/abi_shim.cpp walking argument validation, limit checks, workspace / stash queries and
+    the MLP dispatchers' reads of the caller's hidden[] with exactly-sized heap arrays.  Clean run = no report; the self-check
+    (an array one element too short) must make AddressSanitizer abort, which proves the instrumentation is live."""
+    import subprocess
+    from meta_learning_pacoh_amd._build import build_asan_shim
+    shim = build_asan_shim()
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=0')
+    r = subprocess.run([shim], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0 and 'ASAN SHIM OK' in r.stdout and 'AddressSanitizer' not in r.stderr, r.stderr[-3000:]
+    r = subprocess.run([shim], env=dict(env, PACOH_ASAN_SELFCHECK='1'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and 'AddressSanitizer: heap-buffer-overflow' in r.stderr
+
+
 def test_no_cpu_fallback():
     """the product path must fail loudly without a HIP device"""
     import numpy as np
