@@ -51,7 +51,7 @@ extern "C" {
 #define PACOH_MAX_FEATURES 16  /* f (kernel input dim) <= 16                                     */
 #define PACOH_MLP_MAX_HIDDEN_LAYERS 63   /* per-particle MLP: any layer_sizes up to this depth ...          */
 #define PACOH_MLP_MAX_WIDTH 65536        /* ... and this width (the reference has no limit: models.py:328-349) */
-#define PACOH_SVGD_MAX_PARTICLES 1024    /* RBF-SVGD entry points (the reference has no limit; its sweeps use 10 / 50); IMQ: 64 */
+#define PACOH_SVGD_MAX_PARTICLES 1024    /* SVGD entry points, RBF and IMQ kernel (the reference has no limit; its sweeps use 10 / 50) */
 
 /* info[b] values written by the GP kernels (LAPACK-style): 0 = clean Cholesky; 1..3 = succeeded
  * after adding diagonal jitter base*10^(k-1), base = 1e-6 (f32) / 1e-8 (f64) -- the retry ladder of
@@ -299,7 +299,7 @@ int pacoh_svgd_update_dev(void* X, const void* score, const void* prior_mean, co
  * (required in that case); phi then also carries the derivative through h_d that the reference's autograd
  * produces (the bandwidth is built from the differentiable squared differences).
  * Replaces SVGD.phi + IMQSteinKernel (meta_learn/svgd.py:12-23, 63-97; selected at GPR_meta_svgd.py:176-177).
- * P <= 64.  workspace: pacoh_svgd_imq_workspace_bytes(). */
+ * P <= PACOH_SVGD_MAX_PARTICLES (round 3; the pair table of rounds 1-2 capped it at 64).  workspace: pacoh_svgd_imq_workspace_bytes(). */
 size_t pacoh_svgd_imq_workspace_bytes(int P, int D, int dtype);
 int pacoh_svgd_phi_imq(const void* X, const void* score, double alpha, double beta, double bandwidth,
                        int neg, void* phi, void* h_out, void* workspace, int P, int D, int dtype,

@@ -173,7 +173,7 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         if kernel not in ('RBF', 'IMQ'):                       # GPR_meta_svgd.py:173-179
             raise NotImplementedError
         self.kernel = kernel
-        assert num_particles <= (L.SVGD_MAX_PARTICLES if kernel == 'RBF' else 64), 'too many particles for the SVGD kernels'
+        assert num_particles <= L.SVGD_MAX_PARTICLES, 'too many particles for the SVGD kernels'
         self.num_iter_fit, self.prior_factor, self.feature_dim = num_iter_fit, prior_factor, feature_dim
         self.weight_prior_std, self.bias_prior_std = weight_prior_std, bias_prior_std
         self.num_particles, self.bandwidth, self.optimizer_name = num_particles, bandwidth, optimizer

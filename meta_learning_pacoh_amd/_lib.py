@@ -601,7 +601,7 @@ def svgd_update(X, score, prior_mean, prior_std, prior_factor, bandwidth, optimi
 
 
 SC_SCORE_SCALE, SC_LR, SC_ADAM, SC_COUNT = 0, 1, 4, 8          # PACOH_SC_* of include/pacoh_gp.h
-SVGD_MAX_PARTICLES = 1024                                      # PACOH_SVGD_MAX_PARTICLES (RBF kernel; IMQ: 64)
+SVGD_MAX_PARTICLES = 1024                                      # PACOH_SVGD_MAX_PARTICLES (RBF and IMQ kernel)
 
 
 def step_scalars(score_scale, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):

@@ -32,7 +32,9 @@ __device__ __forceinline__ double from_bits(uint64_t u) { return __longlong_as_d
 // ---- stage 1: per-dimension lower median over the P(P-1)/2 pairs --------------------------------------------
 // 16 dimensions per 256-thread workgroup, 16 lanes per dimension.  The k-th smallest of the (non-negative)
 // squared differences is found by bisection on the IEEE bit pattern (monotone for v >= 0): NB-1 rounds of
-// "count values below the candidate", each lane counting its share of the pairs, 4 shuffles per round.
+// "count values below the candidate", each lane counting the pairs (a, b > a) of its rows a = ln, ln + 16, ...
+// (enumerated on the fly: no pair table, so any P whose 16 coordinate columns fit in LDS -- 1024 particles and beyond),
+// 4 shuffles per round.
 template <typename T>
 __global__ void __launch_bounds__(256) imq_bw_kernel(const T* __restrict__ X, T* __restrict__ h, T* __restrict__ dh,
                                                      int32_t* __restrict__ bidx, T log_p1, int P, int D) {
@@ -40,48 +42,45 @@ __global__ void __launch_bounds__(256) imq_bw_kernel(const T* __restrict__ X, T*
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Pp = P | 1;
     T* xs = reinterpret_cast<T*>(smem_raw);                          // [16][Pp]
-    uint16_t* tab = reinterpret_cast<uint16_t*>(xs + 16 * Pp);       // [npairs]  (a << 8 | b), row-major a < b
-    const int npairs = P * (P - 1) / 2;
+    const long npairs = (long)P * (P - 1) / 2;
     const int d0 = blockIdx.x * 16;
     for (int idx = threadIdx.x; idx < P * 16; idx += 256) {
         const int p = idx >> 4, c = idx & 15;
         const int d = min(d0 + c, D - 1);
         xs[c * Pp + p] = X[(long)p * D + d];
     }
-    for (int a = threadIdx.x; a < P - 1; a += 256) {
-        int q = a * P - a * (a + 1) / 2;                            // index of pair (a, a+1)
-        for (int b = a + 1; b < P; ++b) tab[q++] = (uint16_t)((a << 8) | b);
-    }
     __syncthreads();
     const int dl = threadIdx.x >> 4, ln = threadIdx.x & 15;
     const T* xd = xs + dl * Pp;
-    const int k = (npairs - 1) / 2;
+    const long k = (npairs - 1) / 2;
     U result = 0;
     for (int bit = BitsOf<T>::NB - 2; bit >= 0; --bit) {
         const U cand = result | (U(1) << bit);
-        int cnt = 0;
-        for (int q = ln; q < npairs; q += 16) {
-            const int pr = tab[q];
-            const T df = xd[pr & 255] - xd[pr >> 8];
-            cnt += to_bits(df * df) < cand ? 1 : 0;
+        long cnt = 0;
+        for (int a = ln; a < P - 1; a += 16) {
+            const T xa = xd[a];
+            int c = 0;
+            for (int b = a + 1; b < P; ++b) { const T df = xd[b] - xa; c += to_bits(df * df) < cand ? 1 : 0; }
+            cnt += c;
         }
         cnt += __shfl_xor(cnt, 1, 64); cnt += __shfl_xor(cnt, 2, 64);
         cnt += __shfl_xor(cnt, 4, 64); cnt += __shfl_xor(cnt, 8, 64);
         if (cnt <= k) result = cand;
     }
-    // first pair (row-major) that attains the median
-    int qmin = 0x7fffffff;
-    for (int q = ln; q < npairs; q += 16) {
-        const int pr = tab[q];
-        const T df = xd[pr & 255] - xd[pr >> 8];
-        if (to_bits(df * df) == result) qmin = min(qmin, q);
+    // first pair (row-major over a < b: what torch.median's index refers to) that attains the median
+    long qmin = 0x7fffffffffffffffL;
+    for (int a = ln; a < P - 1 && qmin == 0x7fffffffffffffffL; a += 16) {       // (a lane's rows ascend: its first hit is its smallest)
+        const T xa = xd[a];
+        for (int b = a + 1; b < P; ++b) {
+            const T df = xd[b] - xa;
+            if (to_bits(df * df) == result) { qmin = (long)a * P + b; break; }   // (a P + b orders the pairs like the row-major index)
+        }
     }
     qmin = min(qmin, __shfl_xor(qmin, 1, 64)); qmin = min(qmin, __shfl_xor(qmin, 2, 64));
     qmin = min(qmin, __shfl_xor(qmin, 4, 64)); qmin = min(qmin, __shfl_xor(qmin, 8, 64));
     const int d = d0 + dl;
     if (ln == 0 && d < D) {
-        const int pr = tab[min(qmin, npairs - 1)];
-        const int a = pr >> 8, b = pr & 255;
+        const int a = (int)(qmin / P), b = (int)(qmin - (long)a * P);
         h[d] = from_bits(result) / log_p1;
         dh[d] = T(2) * (xd[b] - xd[a]) / log_p1;
         bidx[d] = b;
@@ -112,45 +111,53 @@ __global__ void __launch_bounds__(64) imq_kmat_kernel(const T* __restrict__ X, c
     }
 }
 
-// ---- stage 3: phi; one thread per dimension, particle columns staged in LDS -----------------------------------
+// ---- stage 3: phi; TD dimensions per 64-thread block (TD = 64 while the 2 P TD coordinates fit in LDS, fewer for many
+//      particles), particle columns staged in LDS; the 64 / TD thread groups of a block split the output particles j ----------
 template <typename T>
 __global__ void __launch_bounds__(64) imq_phi_kernel(const T* __restrict__ X, const T* __restrict__ score,
                                                      const T* __restrict__ Kmat, const T* __restrict__ Kb,
                                                      const T* __restrict__ h, const T* __restrict__ dh,
                                                      const int32_t* __restrict__ bidx, T h_fixed, int neg,
-                                                     T* __restrict__ phi, int P, int D) {
+                                                     T* __restrict__ phi, int P, int D, int TD) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* xs = reinterpret_cast<T*>(smem_raw);          // [P][64]
-    T* ss = xs + P * 64;                             // [P][64]
+    T* xs = reinterpret_cast<T*>(smem_raw);          // [P][TD]
+    T* ss = xs + (size_t)P * TD;                     // [P][TD]
+    T* Sred = ss + (size_t)P * TD;                   // [64]
     const int t = threadIdx.x;
-    const int d = blockIdx.x * 64 + t;
+    const int tl = t & (TD - 1), grp = t / TD, ngrp = 64 / TD;
+    const int d = blockIdx.x * TD + tl;
     const int dc = min(d, D - 1);
-    for (int p = 0; p < P; ++p) {
-        xs[p * 64 + t] = X[(long)p * D + dc];
-        ss[p * 64 + t] = score[(long)p * D + dc];
+    for (int p = grp; p < P; p += ngrp) {
+        xs[(size_t)p * TD + tl] = X[(long)p * D + dc];
+        ss[(size_t)p * TD + tl] = score[(long)p * D + dc];
     }
-    // lane-private columns: no barrier needed
+    __syncthreads();
     const T hd = h ? h[dc] : h_fixed;
     const T two_over_h = T(2) / hd;
     const T sgn = (neg ? T(-1) : T(1)) / T(P);
     T S = 0;
-    for (int j = 0; j < P; ++j) {
-        const T xj = xs[j * 64 + t];
-        const T* Kj = Kmat + j * P;                  // wave-uniform -> scalar loads
-        const T* Kbj = Kb + j * P;
+    for (int j = grp; j < P; j += ngrp) {
+        const T xj = xs[(size_t)j * TD + tl];
+        const T* Kj = Kmat + (size_t)j * P;
+        const T* Kbj = Kb + (size_t)j * P;
         T acc = 0, g = 0;
         for (int i = 0; i < P; ++i) {
-            const T df = xj - xs[i * 64 + t];
+            const T df = xj - xs[(size_t)i * TD + tl];
             const T kb = Kbj[i];
-            acc = fma(Kj[i], ss[i * 64 + t], acc);
+            acc = fma(Kj[i], ss[(size_t)i * TD + tl], acc);
             g = fma(kb, df, g);
             S = fma(kb * df, df, S);
         }
         if (d < D) phi[(long)j * D + d] = sgn * (acc - two_over_h * g);
     }
-    if (h && d < D) {
+    Sred[t] = S;
+    __syncthreads();                                 // (also: every phi row of this block's dimensions is written)
+    if (h && grp == 0 && d < D) {
+        T Sd = 0;
+        for (int q = 0; q < ngrp; ++q) Sd += Sred[q * TD + tl];     // fixed order
         const long q = (long)bidx[d] * D + d;
-        phi[q] += sgn * (S / (hd * hd)) * dh[d];
+        __threadfence_block();
+        phi[q] += sgn * (Sd / (hd * hd)) * dh[d];
     }
 }
 
@@ -158,22 +165,29 @@ template <typename T>
 int imq_launch(const void* X, const void* score, double alpha, double beta, double bandwidth, int neg, void* phi,
                void* h_out, void* workspace, int P, int D, hipStream_t s) {
     T* Kmat = (T*)workspace;
-    T* Kb = Kmat + P * P;
+    T* Kb = Kmat + (size_t)P * P;
     T* dh = Kb + P * P;
     int32_t* bidx = (int32_t*)(dh + D);
     T* harr = (T*)h_out;
     const bool median = !(bandwidth > 0.0);
     if (median) {
         const int Pp = P | 1;
-        size_t lds = (size_t)16 * Pp * sizeof(T) + (size_t)(P * (P - 1) / 2) * sizeof(uint16_t);
+        const size_t lds = (size_t)16 * Pp * sizeof(T);
+        if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(imq_bw_kernel<T>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PACOH_ELIMIT;
         hipLaunchKernelGGL(imq_bw_kernel<T>, dim3((D + 15) / 16), dim3(256), lds, s, (const T*)X, harr, dh, bidx,
                            (T)log((double)P + 1.0), P, D);
     }
     hipLaunchKernelGGL(imq_kmat_kernel<T>, dim3(P * P), dim3(64), 0, s, (const T*)X, median ? (const T*)harr : (const T*)nullptr,
                        (T)bandwidth, (T)alpha, (T)beta, Kmat, Kb, P, D);
-    hipLaunchKernelGGL(imq_phi_kernel<T>, dim3((D + 63) / 64), dim3(64), (size_t)2 * P * 64 * sizeof(T), s, (const T*)X,
+    int TD = 64;                                     // dimensions per block: the two [P][TD] column images within 96 KB of LDS
+    while (TD > 1 && (size_t)2 * P * TD * sizeof(T) > 96u * 1024u) TD >>= 1;
+    const size_t lds3 = (size_t)2 * P * TD * sizeof(T) + 64 * sizeof(T);
+    if (lds3 > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(imq_phi_kernel<T>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess) return PACOH_ELIMIT;
+    hipLaunchKernelGGL(imq_phi_kernel<T>, dim3((D + TD - 1) / TD), dim3(64), lds3, s, (const T*)X,
                        (const T*)score, (const T*)Kmat, (const T*)Kb, median ? (const T*)harr : (const T*)nullptr,
-                       (const T*)dh, (const int32_t*)bidx, (T)bandwidth, neg, (T*)phi, P, D);
+                       (const T*)dh, (const int32_t*)bidx, (T)bandwidth, neg, (T*)phi, P, D, TD);
     return launch_status();
 }
 
@@ -182,7 +196,7 @@ int imq_launch(const void* X, const void* score, double alpha, double beta, doub
 extern "C" size_t pacoh_svgd_imq_workspace_bytes(int P, int D, int dtype) {
     if (P <= 0 || D <= 0) return 0;
     const size_t e = dtype == PACOH_F64 ? 8 : 4;
-    return (size_t)(2 * P * P + D) * e + (size_t)D * sizeof(int32_t) + 16;
+    return ((size_t)2 * P * P + D) * e + (size_t)D * sizeof(int32_t) + 16;
 }
 
 extern "C" int pacoh_svgd_phi_imq(const void* X, const void* score, double alpha, double beta, double bandwidth,
@@ -193,7 +207,7 @@ extern "C" int pacoh_svgd_phi_imq(const void* X, const void* score, double alpha
     if (!(alpha > 0.0) || !(beta < 0.0)) return PACOH_EINVAL;        // svgd.py:72-73
     const bool median = !(bandwidth > 0.0);
     if (median && (!h_out || P < 2)) return PACOH_EINVAL;
-    if (P > 64) return PACOH_ELIMIT;
+    if (P > PACOH_SVGD_MAX_PARTICLES) return PACOH_ELIMIT;
     if (dtype == PACOH_F32)
         return imq_launch<float>(X, score, alpha, beta, bandwidth, neg, phi, h_out, workspace, P, D, (hipStream_t)stream);
     return imq_launch<double>(X, score, alpha, beta, bandwidth, neg, phi, h_out, workspace, P, D, (hipStream_t)stream);

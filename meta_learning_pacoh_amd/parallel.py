@@ -125,8 +125,10 @@ class RcclComm:
             buf.fill_(float(rank + 1))
             graph = torch.cuda.CUDAGraph()
             kw = {'capture_error_mode': 'thread_local'} if w > 1 else {}      # (torch.distributed's watchdog thread: see capture_graph)
-            with torch.cuda.graph(graph, **kw):
-                self.all_reduce_(buf)
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')            # (one rank: RCCL enqueues nothing for an in-place sum -> "graph is empty")
+                with torch.cuda.graph(graph, **kw):
+                    self.all_reduce_(buf)
             graph.replay()                                 # every rank: total
             graph.replay()                                 # every rank: w * total
             torch.cuda.synchronize()

@@ -199,7 +199,39 @@ def make_deep_mlp():
     print('deep_mlp_ref.npz written')
 
 
+def make_imq_large():
+    """IMQ-SVGD beyond 64 particles (round 3: the IMQ entry point takes up to 1024 like the RBF one): phi of the REAL
+    meta_learn/svgd.py (SVGD.phi + IMQSteinKernel, svgd.py:12-23,63-99), median and fixed bandwidth, fp32 and fp64
+        python tests/golden/make_golden.py imq_large"""
+    svgd = _load('ref_svgd', os.path.join(REF, 'meta_learn', 'svgd.py'))
+
+    class QuadLogProb:
+        def __init__(self, mu, s):
+            self.mu, self.s = mu, s
+
+        def log_prob(self, X):
+            return (-0.5 * ((X - self.mu) / self.s) ** 2).sum(-1)
+
+    fx = {}
+    for tag, (P, D, bw) in {'p80_median': (80, 150, None), 'p130_fixed': (130, 64, 1.2), 'p200_median': (200, 40, None),
+                            'p65_median_wide': (65, 260, None)}.items():
+        gen = torch.Generator().manual_seed(7 + P + D)
+        X = torch.randn(P, D, generator=gen) * 0.7
+        mu = torch.randn(D, generator=gen)
+        s = torch.rand(D, generator=gen) + 0.5
+        for sfx, dt in (('', torch.float32), ('64', torch.float64)):
+            Xd, mud, sd = X.to(dt), mu.to(dt), s.to(dt)
+            kern = svgd.IMQSteinKernel(bandwidth=bw)
+            phi = svgd.SVGD(QuadLogProb(mud, sd), kern, optimizer=None).phi(Xd)
+            fx[tag + '_phi' + sfx] = phi.detach().numpy()
+        fx[tag + '_X'], fx[tag + '_mu'], fx[tag + '_s'] = X.numpy(), mu.numpy(), s.numpy()   # score = -(X - mu) / s^2
+        fx[tag + '_bw_arg'] = np.array(-1.0 if bw is None else bw)
+    np.savez_compressed(os.path.join(OUT, 'svgd_imq_large_ref.npz'), **fx)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'imq_large':
+        return make_imq_large()
     if len(sys.argv) > 1 and sys.argv[1] == 'mixture_quantiles':
         return make_mixture_quantiles()
     if len(sys.argv) > 1 and sys.argv[1] == 'deep_mlp':

@@ -561,7 +561,35 @@ def test_svgd_phi_imq_other_exponents_and_limits(L):
     with pytest.raises(RuntimeError):
         L.svgd_phi_imq(X.cuda(), score.cuda(), -1.0, -0.5, None)           # alpha must be positive (svgd.py:72)
     with pytest.raises(RuntimeError):
-        L.svgd_phi_imq(torch.zeros(65, 8).cuda(), torch.zeros(65, 8).cuda())  # P <= 64
+        L.svgd_phi_imq(torch.zeros(1025, 8).cuda(), torch.zeros(1025, 8).cuda())  # P <= PACOH_SVGD_MAX_PARTICLES
+
+
+@pytest.mark.parametrize('tag', ['p80_median', 'p130_fixed', 'p200_median', 'p65_median_wide'])
+def test_svgd_phi_imq_beyond_64_particles_matches_reference_fixture(L, golden_dir, tag):
+    """IMQ-SVGD with 65 - 200 particles (the reference has no limit, svgd.py:63-99) vs phi of the REAL meta_learn/svgd.py
+    (svgd_imq_large_ref.npz, made by tests/golden/make_golden.py imq_large): pair enumeration on the fly instead of a pair table,
+    fewer dimensions per block in the phi kernel"""
+    fx = np.load(os.path.join(golden_dir, 'svgd_imq_large_ref.npz'))
+    bw_arg = float(fx[tag + '_bw_arg'])
+    bw = None if bw_arg < 0 else bw_arg
+    for dt, sfx, tol in ((torch.float32, '', 5e-5), (torch.float64, '64', 1e-11)):
+        X, mu, s = (torch.from_numpy(fx[tag + k]).to(dt).cuda() for k in ('_X', '_mu', '_s'))
+        score = (-(X - mu) / s ** 2).contiguous()
+        phi, h, _ = L.svgd_phi_imq(X, score, 0.5, -0.5, bw)
+        assert relerr(phi, torch.from_numpy(fx[tag + '_phi' + sfx])) < tol, (tag, dt)
+        if bw is None:
+            h_o, _, _ = O.svgd_imq_bandwidth(X.cpu())
+            assert relerr(h, h_o) < (1e-6 if dt == torch.float32 else 1e-14)
+
+
+def test_svgd_phi_imq_many_particles_vs_oracle(L):
+    """600 particles (fp64): the phi kernel runs 8 dimensions per block there; against the oracle's closed form"""
+    g = torch.Generator().manual_seed(8)
+    X = torch.randn(600, 37, generator=g, dtype=torch.float64)
+    score = torch.randn(600, 37, generator=g, dtype=torch.float64)
+    phi, h, _ = L.svgd_phi_imq(X.cuda(), score.cuda(), 0.5, -0.5, None)
+    phi_o, h_o = O.svgd_phi_imq_closed_form(X, score, 0.5, -0.5, None)
+    assert relerr(phi, phi_o) < 1e-10 and relerr(h, h_o) < 1e-13
 
 
 def test_vi_full_covariance_matches_reference_fixture(L, golden_dir):

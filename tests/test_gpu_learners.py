@@ -734,8 +734,21 @@ def test_svgd_with_more_than_64_particles(M, monkeypatch):
         mean, std = m.predict(*tasks[0], tasks[1][0])
         assert np.isfinite(mean).all() and (std > 0).all()
     assert torch.equal(runs[0], runs[1])
+    # the IMQ particle kernel takes the same particle counts since round 3 (its pair table used to cap it at 64): three steps of an
+    # 80-particle learner against the oracle's closed form on the same score
+    m = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=80, kernel='IMQ', task_batch_size=3, lr=1e-2, mean_nn_layers=(8, 8),
+                                      kernel_nn_layers=(8, 8), random_seed=5)
+    theta0 = m.particles.clone()
+    idx, pre = m._sample_task_batch()
+    _, score = m._log_prob_and_score(theta0, idx, pre)
+    from meta_learning_pacoh_amd import _lib as Lb
+    phi, _, _ = Lb.svgd_phi_imq(theta0, score)
+    phi_o, _ = O.svgd_phi_imq_closed_form(theta0.cpu().double(), score.cpu().double())
+    assert float((phi.cpu().double() - phi_o).norm() / phi_o.norm()) < 1e-4
+    m.meta_fit(verbose=False, n_iter=3)
+    assert bool(torch.isfinite(m.particles).all()) and not torch.equal(m.particles, theta0)
     with pytest.raises(AssertionError):
-        M.GPRegressionMetaLearnedSVGD(tasks, num_particles=80, kernel='IMQ', random_seed=5)
+        M.GPRegressionMetaLearnedSVGD(tasks, num_particles=1025, kernel='IMQ', random_seed=5)
 
 
 def test_vi_fused_update_equals_the_launch_sequence_it_replaces(M, monkeypatch):
