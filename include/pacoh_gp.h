@@ -192,6 +192,18 @@ int pacoh_mlp2_bwd(const void* x, int x_div, const void* theta, long theta_strid
                    const int32_t* hidden, int n_hidden, long off_a, int d_out_a, const void* g_a, long off_b,
                    int d_out_b, const void* g_b, void* d_theta, long d_theta_stride, int accumulate,
                    void* workspace, const void* stash, int B, int n, int dtype, void* stream);
+/* pacoh_mlp2_bwd followed by pacoh_hyper_bwd (below) on the same d_theta rows -- the whole gradient epilogue of a step
+ * (loss.backward() reaching the networks AND the raw GP hyper-parameters: GPR_meta_mll.py:115, svgd.py:16) in one call.  On the
+ * fused fp32 path the hyper-parameter reduction runs in extra workgroups of the backward's slab-reduction launch: one launch and one
+ * launch boundary less per step.  Arguments: those of pacoh_mlp2_bwd (accumulate must be 0), then those of pacoh_hyper_bwd with
+ * grad = d_theta. */
+int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
+                         const int32_t* hidden, int n_hidden, long off_a, int d_out_a, const void* g_a, long off_b,
+                         int d_out_b, const void* g_b, void* d_theta, long d_theta_stride, int accumulate,
+                         void* workspace, const void* stash, int B, int n,
+                         int T, int off_ls, int f, int off_os, int off_noise, int off_const, const void* d_lengthscale,
+                         const void* d_outputscale, const void* d_noise, const void* d_const, const void* lml, void* lik,
+                         double lik_scale, const int32_t* info, int32_t* fail_flag, int dtype, void* stream);
 
 /* ---- A3 + A7: parameter transforms, hyper-prior ------------------------------------------------
  * softplus with optional floor, forward:  out = log(1+exp(raw)) + floor            (random_gp.py:69-74;

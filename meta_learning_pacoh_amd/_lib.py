@@ -49,6 +49,8 @@ SIGNATURES = {
     'pacoh_mlp2_fwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_mlp2_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_mlp2_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp]),
+    'pacoh_mlp2_bwd_hyper': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _i,
+                                  _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _i, _vp]),
     'pacoh_softplus_fwd': (_i, [_vp, _vp, _d, _l, _i, _vp]),
     'pacoh_softplus_bwd': (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),
     'pacoh_hyper_fwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
@@ -504,6 +506,25 @@ def mlp2_bwd(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, g_a, off_b, d_out
         _check(lib.pacoh_mlp2_bwd(_ptr(x), x_div, _ptr(theta, x), theta.shape[1], P, d_in, harr, len(hidden), off_a, d_out_a,
                                   _ptr(g_a, x), off_b, d_out_b, _ptr(g_b, x), _ptr(d_theta, x), d_theta.shape[1],
                                   int(bool(accumulate)), _ptr(workspace), _ptr(stash), B, n, code, _stream()), 'pacoh_mlp2_bwd')
+    return workspace
+
+
+def mlp2_bwd_hyper(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, g_a, off_b, d_out_b, g_b, d_theta, B, n, T, off_ls, f, off_os,
+                   off_noise, off_const, d_ls, d_os, d_noise, d_const, lml=None, lik=None, lik_scale=1.0, info=None, fail_flag=None,
+                   workspace=None, stash=None):
+    """mlp2_bwd + hyper_bwd (grad = d_theta) in one C-ABI call: the gradient epilogue of a step; returns the workspace for reuse"""
+    lib = load_library()
+    harr, code = _hidden_arr(hidden), dtype_code(x)
+    need = lib.pacoh_mlp2_bwd_workspace_bytes(B, P, n, d_in, harr, len(hidden), d_out_a, d_out_b, code)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(max(1, need), dtype=torch.uint8, device=x.device)
+    with _Timed('mlp_bwd'):
+        _check(lib.pacoh_mlp2_bwd_hyper(_ptr(x), x_div, _ptr(theta, x), theta.shape[1], P, d_in, harr, len(hidden), off_a, d_out_a,
+                                        _ptr(g_a, x), off_b, d_out_b, _ptr(g_b, x), _ptr(d_theta, x), d_theta.shape[1], 0,
+                                        _ptr(workspace), _ptr(stash), B, n, T, off_ls, f, off_os, off_noise, off_const,
+                                        _ptr(d_ls, x), _ptr(d_os, x), _ptr(d_noise, x), _ptr(d_const, x), _ptr(lml, x), _ptr(lik, x),
+                                        float(lik_scale), _ptr(info if fail_flag is not None else None),
+                                        _ptr(fail_flag if info is not None else None), code, _stream()), 'pacoh_mlp2_bwd_hyper')
     return workspace
 
 

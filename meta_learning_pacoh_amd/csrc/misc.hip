@@ -3,6 +3,7 @@
 // D ~ 10^3 parameters); they exist so that a whole meta-training step stays on the device and can be
 // captured into one hipGraph.
 #include "common.h"
+#include "hyper_tail.h"
 
 namespace pacoh {
 
@@ -47,42 +48,9 @@ __global__ void hyper_fwd_kernel(const T* __restrict__ theta, long stride, int P
 // lik[p] = lik_scale * sum_t lml[t, p] (the likelihood term of the meta log-probability rides along: same loop over tasks).
 // One 256-thread workgroup per entry, fixed summation order (deterministic).
 template <typename T>
-__global__ void __launch_bounds__(256) hyper_bwd_kernel(const T* __restrict__ theta, long stride, int P, int Tt, int off_ls, int f,
-                                                        int off_os, int off_noise, int off_const, const T* __restrict__ d_ls,
-                                                        const T* __restrict__ d_os, const T* __restrict__ d_noise,
-                                                        const T* __restrict__ d_const, T* __restrict__ grad, long gstride,
-                                                        const T* __restrict__ lml, T* __restrict__ lik, T lik_scale,
-                                                        const int32_t* __restrict__ info, int32_t* __restrict__ fail_flag) {
+__global__ void __launch_bounds__(256) hyper_bwd_kernel(HyperBwdArgs<T> a) {
     __shared__ T red[4];
-    const int per = f + 4;
-    // the step's numerical status rides along: any problem whose jittered Cholesky failed (info < 0) raises the caller's flag
-    // (gpytorch's psd_safe_cholesky raises NotPSDError at that point; the host checks the flag at its next synchronisation)
-    if (info && fail_flag && blockIdx.x % per == f + 1) {
-        const int pp = blockIdx.x / per;
-        bool bad = false;
-        for (int t = threadIdx.x; t < Tt; t += 256) bad |= info[(long)t * P + pp] < 0;
-        if (bad) atomicOr(fail_flag, 1);
-    }
-    const int w = blockIdx.x;
-    const int p = w / per, e = w - p * per;
-    const T* src; int width, col, off;
-    if (e < f) { src = d_ls; width = f; col = e; off = off_ls + e; }
-    else if (e == f) { src = d_os; width = 1; col = 0; off = off_os; }
-    else if (e == f + 1) { src = d_noise; width = 1; col = 0; off = off_noise; }
-    else if (e == f + 2) { src = d_const; width = 1; col = 0; off = off_const; }
-    else { src = lml; width = 1; col = 0; off = 0; }
-    if (!src || off < 0) return;
-    T s = 0;
-    for (int t = threadIdx.x; t < Tt; t += 256) s += src[((long)t * P + p) * width + col];
-    s = subwave_sum<T>(s, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        s = (red[0] + red[1]) + (red[2] + red[3]);
-        if (e == f + 3) { if (lik) lik[p] = lik_scale * s; return; }
-        const T chain = (e == f + 2) ? T(1) : sigmoid_t<T>(theta[(long)p * stride + off]);
-        grad[(long)p * gstride + off] = s * chain;
-    }
+    hyper_bwd_block<T>(a, blockIdx.x, red);               // (hyper_tail.h: shared with the slab reduction of the fused MLP backward)
 }
 
 // ---- hyper-prior: independent Normals over all D entries ----------------------------------------
@@ -328,6 +296,23 @@ __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ 
     __shared__ T Ki[PACOH_SVGD_MAX_PARTICLES];
     __shared__ T gam_s, rowsum_s;
     const int i = blockIdx.y;
+    // The kernel is a chain of L2 round trips, not arithmetic (P x 2 loads per thread behind the bandwidth / kernel-row phase of
+    // wave 0: 11 us at P = 20 with four particles' loads in flight behind the barrier).  Everything that does not depend on that
+    // phase is requested BEFORE it: the first twenty particles' coordinates and scores, the own coordinate, the optimizer state.
+    constexpr int PF = 20;
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    const int dc = d < D ? d : D - 1;
+    const int npre = P < PF ? P : PF;
+    T xpre[PF], spre[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        xpre[u] = u < npre ? X[(long)u * D + dc] : T(0);
+        spre[u] = u < npre ? score[(long)u * D + dc] : T(0);
+    }
+    const long q = (long)i * D + dc;
+    const T xi = X[q];
+    const T md = mu ? mu[dc] : T(0), sdv = mu ? sd[dc] : T(1);
+    T mq = use_adam ? m[q] : T(0), vq0 = use_adam ? v[q] : T(0);
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         T bw = bandwidth;
@@ -348,14 +333,29 @@ __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ 
         if (lane == 0) { gam_s = gam; rowsum_s = rs; if (bw_out && blockIdx.x == 0 && i == 0) *bw_out = bw; }
     }
     __syncthreads();
-    const int d = blockIdx.x * 256 + threadIdx.x;
     if (d >= D) return;
     const T gam2 = T(2) * gam_s;
-    const T md = mu ? mu[d] : T(0), sdv = mu ? sd[d] : T(1);
     const T pscale = mu ? prior_factor / (sdv * sdv) : T(0);
     T acc = 0;
-    int j = 0;
-    for (; j + 4 <= P; j += 4) {                     // four particles' loads in flight (a rolled loop waited for each pair in turn)
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        if (u < npre) {
+            const T sj = score_scale * spre[u] - pscale * (xpre[u] - md);
+            acc = fma(Ki[u], sj - gam2 * xpre[u], acc);
+        }
+    }
+    int j = npre;
+    for (; j + 10 <= P; j += 10) {                  // ten particles' loads in flight per round
+        T xj[10], scv[10];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) { xj[u] = X[(long)(j + u) * D + d]; scv[u] = score[(long)(j + u) * D + d]; }
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+            const T sj = score_scale * scv[u] - pscale * (xj[u] - md);
+            acc = fma(Ki[j + u], sj - gam2 * xj[u], acc);
+        }
+    }
+    for (; j + 4 <= P; j += 4) {
         T xj[4], sc4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { xj[u] = X[(long)(j + u) * D + d]; sc4[u] = score[(long)(j + u) * D + d]; }
@@ -370,14 +370,11 @@ __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ 
         const T sj = score_scale * score[(long)j * D + d] - pscale * (xj - md);
         acc = fma(Ki[j], sj - gam2 * xj, acc);
     }
-    const T xi = X[(long)i * D + d];
     const T r = (acc + gam2 * xi * rowsum_s) / T(P);          // phi[i,d]
-    const long q = (long)i * D + d;
     if (use_adam) {
         const T g = -r;                                       // particles.grad = -phi (svgd.py:27)
-        T mq = m[q];
         mq = mq + (g - mq) * one_minus_b1;
-        const T vq = v[q] * b2 + one_minus_b2 * g * g;
+        const T vq = vq0 * b2 + one_minus_b2 * g * g;
         const T denom = t_sqrt<T>(vq) / bc2_sqrt + eps;
         X_out[q] = xi - step_size * (mq / denom);
         m[q] = mq; v[q] = vq;
@@ -740,14 +737,17 @@ extern "C" int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int 
     if (!theta || !grad || !d_ls || !d_noise || P <= 0 || T_ <= 0 || f <= 0) return PACOH_EINVAL;
     if ((lml == nullptr) != (lik == nullptr)) return PACOH_EINVAL;
     unsigned blocks = (unsigned)(P * (f + 4));
-    if (dtype == PACOH_F32)
-        hipLaunchKernelGGL(hyper_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)theta, theta_stride, P, T_,
-                           off_ls, f, off_os, off_noise, off_const, (const float*)d_ls, (const float*)d_os, (const float*)d_noise,
-                           (const float*)d_const, (float*)grad, grad_stride, (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag);
-    else
-        hipLaunchKernelGGL(hyper_bwd_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)theta, theta_stride, P, T_,
-                           off_ls, f, off_os, off_noise, off_const, (const double*)d_ls, (const double*)d_os, (const double*)d_noise,
-                           (const double*)d_const, (double*)grad, grad_stride, (const double*)lml, (double*)lik, lik_scale, info, fail_flag);
+    if (dtype == PACOH_F32) {
+        HyperBwdArgs<float> a = {(const float*)theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, (const float*)d_ls,
+                                 (const float*)d_os, (const float*)d_noise, (const float*)d_const, (float*)grad, grad_stride,
+                                 (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag};
+        hipLaunchKernelGGL(hyper_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        HyperBwdArgs<double> a = {(const double*)theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, (const double*)d_ls,
+                                  (const double*)d_os, (const double*)d_noise, (const double*)d_const, (double*)grad, grad_stride,
+                                  (const double*)lml, (double*)lik, lik_scale, info, fail_flag};
+        hipLaunchKernelGGL(hyper_bwd_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    }
     return launch_status();
 }
 

@@ -6,6 +6,7 @@
 //   layers  (mlp_layers.hip) everything else (any depth, any width, fp32/fp64): layer-by-layer MFMA GEMMs through a workspace
 // PACOH_MLP_PATH=fused|mfma|valu|layers restricts the choice to that path and the ones after it (tests, A/B timing).
 #include "common.h"
+#include "hyper_tail.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -30,7 +31,8 @@ size_t mlp_fused_stash_bytes(int B, int P, int n, int n_hidden, int nets);
 size_t mlp_fused_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int nets);
 int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
                   int n_hidden, int nets, const long* off, const int* d_out, const void* const* g_out, void* d_theta,
-                  long d_theta_stride, int accumulate, void* workspace, const void* stash, int B, int n, hipStream_t s);
+                  long d_theta_stride, int accumulate, void* workspace, const void* stash, int B, int n, hipStream_t s,
+                  const HyperBwdArgs<float>* tail);
 // mlp_layers.hip
 size_t mlp_layers_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype, int bwd);
 int mlp_layers_fwd(const void*, int, const void*, long, int, int, const int32_t*, int, int, void*, void*, int, int, int, hipStream_t);
@@ -161,7 +163,7 @@ extern "C" int pacoh_mlp_bwd(const void* x, int x_div, const void* theta, long t
         const long off = 0;
         const void* const gs[1] = {g_out};
         return mlp_fused_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 1, &off, &d_out, gs, d_theta, d_theta_stride,
-                             accumulate, workspace, nullptr, B, n, s);
+                             accumulate, workspace, nullptr, B, n, s, nullptr);
     }
     case PATH_MFMA:
         return mlp_mfma_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride,
@@ -223,10 +225,11 @@ extern "C" size_t pacoh_mlp2_bwd_workspace_bytes(int B, int P, int n, int d_in, 
     return align256(a > b ? a : b);
 }
 
-extern "C" int pacoh_mlp2_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
-                              const int32_t* hidden, int n_hidden, long off_a, int d_out_a, const void* g_a, long off_b,
-                              int d_out_b, const void* g_b, void* d_theta, long d_theta_stride, int accumulate,
-                              void* workspace, const void* stash, int B, int n, int dtype, void* stream) {
+static int mlp2_bwd_impl(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
+                         const int32_t* hidden, int n_hidden, long off_a, int d_out_a, const void* g_a, long off_b,
+                         int d_out_b, const void* g_b, void* d_theta, long d_theta_stride, int accumulate,
+                         void* workspace, const void* stash, int B, int n, int dtype, void* stream,
+                         const HyperBwdArgs<float>* tail, bool* tail_done) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!g_a || !g_b || !d_theta || !workspace || !x || !theta || x_div <= 0 || P <= 0 || B <= 0 || n <= 0 || B % P != 0 || off_a < 0 || off_b < 0)
         return PACOH_EINVAL;
@@ -237,8 +240,9 @@ extern "C" int pacoh_mlp2_bwd(const void* x, int x_div, const void* theta, long 
         const long off[2] = {off_a, off_b};
         const int dout[2] = {d_out_a, d_out_b};
         const void* const gs[2] = {g_a, g_b};
+        if (tail_done) *tail_done = tail != nullptr;
         return mlp_fused_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 2, off, dout, gs, d_theta, d_theta_stride,
-                             accumulate, workspace, stash, B, n, (hipStream_t)stream);
+                             accumulate, workspace, stash, B, n, (hipStream_t)stream, tail);
     }
     const size_t es = dtype == PACOH_F64 ? 8 : 4;
     rc = pacoh_mlp_bwd(x, x_div, (const char*)theta + off_a * es, theta_stride, P, d_in, hidden, n_hidden, d_out_a, g_a,
@@ -246,6 +250,42 @@ extern "C" int pacoh_mlp2_bwd(const void* x, int x_div, const void* theta, long 
     if (rc) return rc;
     return pacoh_mlp_bwd(x, x_div, (const char*)theta + off_b * es, theta_stride, P, d_in, hidden, n_hidden, d_out_b, g_b,
                          (char*)d_theta + off_b * es, d_theta_stride, accumulate, workspace, B, n, dtype, stream);
+}
+
+extern "C" int pacoh_mlp2_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
+                              const int32_t* hidden, int n_hidden, long off_a, int d_out_a, const void* g_a, long off_b,
+                              int d_out_b, const void* g_b, void* d_theta, long d_theta_stride, int accumulate,
+                              void* workspace, const void* stash, int B, int n, int dtype, void* stream) {
+    return mlp2_bwd_impl(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, off_a, d_out_a, g_a, off_b, d_out_b, g_b, d_theta,
+                         d_theta_stride, accumulate, workspace, stash, B, n, dtype, stream, nullptr, nullptr);
+}
+
+// pacoh_mlp2_bwd + pacoh_hyper_bwd: the whole gradient epilogue of a step.  On the fused fp32 path the hyper-parameter
+// reduction runs in extra workgroups of the slab-reduction launch (one launch less); elsewhere the two calls in sequence.
+extern "C" int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
+                                    const int32_t* hidden, int n_hidden, long off_a, int d_out_a, const void* g_a, long off_b,
+                                    int d_out_b, const void* g_b, void* d_theta, long d_theta_stride, int accumulate,
+                                    void* workspace, const void* stash, int B, int n,
+                                    int T_, int off_ls, int f, int off_os, int off_noise, int off_const, const void* d_ls,
+                                    const void* d_os, const void* d_noise, const void* d_const, const void* lml, void* lik,
+                                    double lik_scale, const int32_t* info, int32_t* fail_flag, int dtype, void* stream) {
+    if (!d_ls || !d_noise || T_ <= 0 || f <= 0 || (lml == nullptr) != (lik == nullptr)) return PACOH_EINVAL;
+    if (accumulate) return PACOH_EINVAL;              // (the tail writes its columns of d_theta; the blocks of the two networks are overwritten)
+    bool tail_done = false;
+    int rc;
+    if (dtype == PACOH_F32) {
+        HyperBwdArgs<float> tail = {(const float*)theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, (const float*)d_ls,
+                                    (const float*)d_os, (const float*)d_noise, (const float*)d_const, (float*)d_theta, d_theta_stride,
+                                    (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag};
+        rc = mlp2_bwd_impl(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, off_a, d_out_a, g_a, off_b, d_out_b, g_b, d_theta,
+                           d_theta_stride, accumulate, workspace, stash, B, n, dtype, stream, &tail, &tail_done);
+    } else {
+        rc = mlp2_bwd_impl(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, off_a, d_out_a, g_a, off_b, d_out_b, g_b, d_theta,
+                           d_theta_stride, accumulate, workspace, stash, B, n, dtype, stream, nullptr, nullptr);
+    }
+    if (rc || tail_done) return rc;
+    return pacoh_hyper_bwd(theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, d_theta,
+                           d_theta_stride, lml, lik, lik_scale, info, fail_flag, dtype, stream);
 }
 
 extern "C" int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, int T_, int P, int Wd,

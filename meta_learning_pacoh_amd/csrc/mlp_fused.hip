@@ -25,6 +25,7 @@
 // Replaces LinearVectorized / NeuralNetworkVectorized forward (meta_learn/models.py:295-317,343-349; the torch.bmm at
 // :313) and its autograd backward; P = 1 is NeuralNetwork.forward (models.py:211-217).
 #include "common.h"
+#include "hyper_tail.h"
 #include <stdlib.h>
 
 namespace pacoh {
@@ -488,7 +489,14 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
 // out[p, w] (+)= sum_c in[c, p, w] for up to two networks in one launch (blockIdx.y): 8 lanes per output element split the
 // slabs, fixed order -> deterministic
 struct SlabReduce { const float* in; float* out; int Wd; };
-__global__ void __launch_bounds__(256) fused_reduce_slab_kernel(SlabReduce s0, SlabReduce s1, long out_stride, int accumulate, int C, int P) {
+// (blockIdx.y == nets, tail_blocks > 0: the step's hyper-parameter reduction rides in this launch -- hyper_tail.h)
+__global__ void __launch_bounds__(256) fused_reduce_slab_kernel(SlabReduce s0, SlabReduce s1, long out_stride, int accumulate, int C, int P,
+                                                                int nets, HyperBwdArgs<float> tail, int tail_blocks) {
+    if ((int)blockIdx.y == nets) {
+        __shared__ float red[4];
+        if ((int)blockIdx.x < tail_blocks) hyper_bwd_block<float>(tail, blockIdx.x, red);
+        return;
+    }
     const SlabReduce& sr = blockIdx.y ? s1 : s0;
     const long tot = (long)P * sr.Wd;
     const long idx = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
@@ -645,7 +653,8 @@ size_t mlp_fused_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hid
 
 int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
                   int n_hidden, int nets, const long* off, const int* d_out, const void* const* g_out, void* d_theta,
-                  long d_theta_stride, int accumulate, void* workspace, const void* stash, int B, int n, hipStream_t s) {
+                  long d_theta_stride, int accumulate, void* workspace, const void* stash, int B, int n, hipStream_t s,
+                  const HyperBwdArgs<float>* tail) {
     FusedArgs a = {};
     fused_fill(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, B, n, stash, nets);
     const FusedBwdPlan pl = fused_bwd_plan(a.R, P, nets, n_hidden);
@@ -665,8 +674,11 @@ int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride
     PACOH_FUSED_DISPATCH(mlp_fused_bwd_kernel, n_hidden, pl.pb, PACOH_LAUNCH_BWD);
 #undef PACOH_LAUNCH_BWD
     const long tot = (long)P * wmax;
-    hipLaunchKernelGGL(fused_reduce_slab_kernel, dim3((unsigned)((tot * 8 + 255) / 256), nets), dim3(256), 0, s,
-                       sr[0], sr[1], d_theta_stride, accumulate, pl.chunks * 4, P);
+    unsigned gx = (unsigned)((tot * 8 + 255) / 256);
+    const int tail_blocks = tail ? tail->P * (tail->f + 4) : 0;
+    if ((unsigned)tail_blocks > gx) gx = (unsigned)tail_blocks;
+    hipLaunchKernelGGL(fused_reduce_slab_kernel, dim3(gx, nets + (tail ? 1 : 0)), dim3(256), 0, s,
+                       sr[0], sr[1], d_theta_stride, accumulate, pl.chunks * 4, P, nets, tail ? *tail : HyperBwdArgs<float>{}, tail_blocks);
     return launch_status();
 }
 

@@ -459,25 +459,28 @@ class GPEngine:
             n_valid=batch.n_valid if batch.ragged else None, g_lml=g, want_dz=(lay.covar_module == 'NN'))
         grad = grad_out if grad_out is not None else torch.empty(P, D, dtype=dt, device=dev)   # every block is written below
         pair = self._paired_nets()
-        if pair is not None:
-            self._ws['mk'] = L.mlp2_bwd(batch.x, P, theta, P, lay.input_dim, list(lay.mean_nn_layers), pair[0], 1,
-                                        d_mean.reshape(B, n, 1), pair[1], lay.feature_dim, d_z, grad, False, B, n, self._ws.get('mk'),
-                                        stash=self._ws.get(('stash', B, n)))
-        else:
-            if lay.covar_module == 'NN':
-                lo, _ = lay.block_range('kernel_nn.')
-                self._ws['k'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers),
-                                          lay.feature_dim, d_z, grad[:, lo:], D, False, B, n, self._ws.get('k'))
-            if lay.mean_module == 'NN':
-                lo, _ = lay.block_range('mean_nn.')
-                self._ws['m'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.mean_nn_layers), 1,
-                                          d_mean.reshape(B, n, 1), grad[:, lo:], D, False, B, n, self._ws.get('m'))
-        # hyper-parameters (+ constant mean): sum over tasks and softplus chain rule in one launch
         off_ls, f, off_os, off_noise, off_c = self._hyper_offsets()
+        hyper = dict(lml=lml if lik_out is not None else None, lik=lik_out, lik_scale=lik_scale,
+                     info=info if fail_flag is not None else None, fail_flag=fail_flag)
+        if pair is not None:
+            # both networks' backward + the hyper-parameter reduction (softplus chain rule, likelihood sums, failure flag): one call,
+            # on the fused path two launches
+            self._ws['mk'] = L.mlp2_bwd_hyper(batch.x, P, theta, P, lay.input_dim, list(lay.mean_nn_layers), pair[0], 1,
+                                              d_mean.reshape(B, n, 1), pair[1], lay.feature_dim, d_z, grad, B, n, T, off_ls, f, off_os,
+                                              off_noise, off_c, d_ls, d_os, d_noise, None, workspace=self._ws.get('mk'),
+                                              stash=self._ws.get(('stash', B, n)), **hyper)
+            return lml.reshape(T, P), grad, info
+        if lay.covar_module == 'NN':
+            lo, _ = lay.block_range('kernel_nn.')
+            self._ws['k'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers),
+                                      lay.feature_dim, d_z, grad[:, lo:], D, False, B, n, self._ws.get('k'))
+        if lay.mean_module == 'NN':
+            lo, _ = lay.block_range('mean_nn.')
+            self._ws['m'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.mean_nn_layers), 1,
+                                      d_mean.reshape(B, n, 1), grad[:, lo:], D, False, B, n, self._ws.get('m'))
+        # hyper-parameters (+ constant mean): sum over tasks and softplus chain rule in one launch
         L.hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_c, d_ls, d_os, d_noise,
-                    d_mean if lay.mean_module == 'constant' else None, grad,
-                    lml=lml if lik_out is not None else None, lik=lik_out, lik_scale=lik_scale,
-                    info=info if fail_flag is not None else None, fail_flag=fail_flag)
+                    d_mean if lay.mean_module == 'constant' else None, grad, **hyper)
         return lml.reshape(T, P), grad, info
 
     def predict(self, theta, ctx_x, ctx_y, tst_x, want_cov=False):
