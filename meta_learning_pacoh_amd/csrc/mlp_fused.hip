@@ -357,19 +357,13 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
     float* sc1 = tscr[wave] + TRS;
     const int twr = 4 * TLD * g + tskew(g) + r, trd = TLD * r + tskew(r >> 2) + 4 * g;
     const float* wo = wl + f_off_out(NH);
-    float w3r[2][2][4];
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-        for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) w3r[o][fb][s] = wo[o * 32 + fb * 16 + 4 * g + s];
 
     // accumulators (plain orientation: this lane = feature r of a block, partial sums over the points 4g+q of every block)
     f32x4 aW[NH > 1 ? NH - 1 : 1][2][2] = {};             // hidden weight gradients, accumulator layout [out 4g+s][in r]
     float aBh[NH > 1 ? NH - 1 : 1][2] = {};               // hidden bias gradients [layer][feature block]
     float aW1[2][4] = {}, aB1[2] = {};                    // first layer [feature block][k]
-    float aWo[2][2] = {}, aBo[2] = {};                    // output layer [o][feature block]
+    f32x4 aWoT[2][2] = {};                                // output layer, transposed orientation: [o][feature block][s] of this lane's point(s)
+    float aBoT[2] = {};
 
     constexpr int TP = 16 * PB;
     for (int tl = wave; tl < a.tiles_per_wg; tl += 4) {
@@ -387,27 +381,31 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
 #pragma unroll
         for (int l = 1; l < NH; ++l)
             if (l < NH - ns) f_hidden<PB>(wl + F_OFF_H + (l - 1) * HBLK, r, g, H[l - 1], H[l]);
-        // ---- output layer (VALU): dW_out, db_out in the plain orientation; delta of the last hidden layer over H[NH-1] ---
+        // ---- output layer (VALU).  dW_out, db_out are summed in the TRANSPOSED orientation the activations are in (a lane owns a
+        //      point and the features 4g+s: 16 + 2 lane-private accumulators, summed over the 16 lanes of a row once, at the very
+        //      end) -- no block transposes for this layer (round 3; rounds 1-2 turned both feature blocks of every 16-point block
+        //      through LDS: 8 of a tile's 32 round trips).  W_out comes from LDS per tile instead of living in 16 registers. ----
+        {
+            f32x4 w3[2][2];
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) {
-            const f32x4 Hp0 = f_turn(sc0, H[NH - 1][0][pb], twr, trd);
-            const f32x4 Hp1 = f_turn(sc1, H[NH - 1][1][pb], twr, trd);
+            for (int o = 0; o < 2; ++o)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float2 gp = *reinterpret_cast<const float2*>(st + (pb * 16 + 4 * g + q) * TSTRIDE + 4);
-                aWo[0][0] = fmaf(gp.x, Hp0[q], aWo[0][0]); aWo[0][1] = fmaf(gp.x, Hp1[q], aWo[0][1]);
-                aWo[1][0] = fmaf(gp.y, Hp0[q], aWo[1][0]); aWo[1][1] = fmaf(gp.y, Hp1[q], aWo[1][1]);
-                aBo[0] += gp.x; aBo[1] += gp.y;
+                for (int fb = 0; fb < 2; ++fb) w3[o][fb] = *reinterpret_cast<const f32x4*>(wo + o * 32 + fb * 16 + 4 * g);
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                const float2 gr = *reinterpret_cast<const float2*>(st + (pb * 16 + r) * TSTRIDE + 4);
+                aBoT[0] += gr.x; aBoT[1] += gr.y;
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const float h = H[NH - 1][fb][pb][s];
+                        aWoT[0][fb][s] = fmaf(gr.x, h, aWoT[0][fb][s]);
+                        aWoT[1][fb][s] = fmaf(gr.y, h, aWoT[1][fb][s]);
+                        const float d = fmaf(w3[1][fb][s], gr.y, w3[0][fb][s] * gr.x);
+                        H[NH - 1][fb][pb][s] = d * (1.0f - h * h);
+                    }
             }
-            const float2 gr = *reinterpret_cast<const float2*>(st + (pb * 16 + r) * TSTRIDE + 4);
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float h = H[NH - 1][fb][pb][s];
-                    const float d = fmaf(w3r[1][fb][s], gr.y, w3r[0][fb][s] * gr.x);
-                    H[NH - 1][fb][pb][s] = d * (1.0f - h * h);
-                }
         }
         // ---- hidden layers NH .. 2: H[l] holds delta_l^T, H[l-1] the activations below it ---------------------------------
 #pragma unroll
@@ -477,12 +475,24 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
         off += hl * (prev + 1);
         prev = hl;
     }
+    // output layer: sums over the 16 points (lanes) of a row; the four lane rows hold the point sums of one 16-block each in
+    // turn (every block's points sit in all four rows g with different FEATURES), so a row sum is the whole sum for its features
+    auto rs = [](float v) {
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        return v;
+    };
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
-        const float b = rg(aBo[o]);
+        const float b = rs(aBoT[o]);                       // (the same in every row: g(point r) does not depend on g)
         if (lane == 0 && o < nt.d_out) dst[off + o] = b;
 #pragma unroll
-        for (int fb = 0; fb < 2; ++fb) { const float v = rg(aWo[o][fb]); if (g == 0 && o < nt.d_out && fb * 16 + r < prev) dst[off + nt.d_out + o * prev + fb * 16 + r] = v; }
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float v = rs(aWoT[o][fb][s]);
+                const int k = fb * 16 + 4 * g + s;
+                if (r == 0 && o < nt.d_out && k < prev) dst[off + nt.d_out + o * prev + k] = v;
+            }
     }
 }
 
@@ -559,11 +569,15 @@ static int fused_chunks(int R, int P, int nets, int tp, int resident, double ove
     return (tiles + best_tpw - 1) / best_tpw;
 }
 
-// Hidden layers (counted from the top) whose activations the forward parks in HBM for the backward.  Default 1: the last hidden
-// layer (cfg #3, 2 x 32: backward 206 -> ?? us, forward +?? us for 2 x 335 MB of traffic); PACOH_MLP_STASH=0 recomputes everything
+// Hidden layers (counted from the top) whose activations the forward parks in HBM for the backward.  Default: all but the first
+// (whose recomputation is one MFMA per block on d_in <= 4 inputs) -- measured at the cfg #3 shape (1024 tasks x 20 particles x
+// 64 points, both networks; tools/mlp_time.py): 2 x 32: forward 88 -> 100 us, backward 207 -> 171 us (stashing the first layer too:
+// forward 141 us); 4 x 32: forward + backward 801 us without, 694 / 665 / 641 / 663 us with 1 / 2 / 3 / 4 layers stashed.
+// PACOH_MLP_STASH=k stashes k layers (0: recompute everything, as rounds 1-2 did).
 static int fused_n_stash(int n_hidden) {
-    const int want = fused_env("PACOH_MLP_STASH", 1);              // (read per call: tests and tools/mlp_time.py switch it)
-    return want < 0 ? 0 : (want > n_hidden ? n_hidden : want);
+    const int want = fused_env("PACOH_MLP_STASH", -1);             // (read per call: tests and tools/mlp_time.py switch it)
+    if (want < 0) return n_hidden > 1 ? n_hidden - 1 : 0;
+    return want > n_hidden ? n_hidden : want;
 }
 static int fused_nblk(int B, int P, int n) { return 4 * (int)(((long)(B / P) * n + 63) / 64); }
 

@@ -62,7 +62,7 @@ int main() {
     }
     {
         int32_t* h = heap_hidden({32, 32, 32, 32});
-        EXPECT(pacoh_mlp2_stash_bytes(20, 10, 20, 1, h, 4, 1, 2, PACOH_F32) == 2u * 10 * 4 * 2048);
+        EXPECT(pacoh_mlp2_stash_bytes(20, 10, 20, 1, h, 4, 1, 2, PACOH_F32) == 3u * 2 * 10 * 4 * 2048);
         EXPECT(pacoh_mlp2_stash_bytes(20, 10, 20, 1, h, 4, 1, 2, PACOH_F64) == 0);
         std::free(h);
         h = heap_hidden({1 << 20});
