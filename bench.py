@@ -286,14 +286,14 @@ def rooflines(wl, pp):
     return roofline, kernel_rooflines, sum(wl['flops'][k][0] for k in modelled)
 
 
-def other_config_leg(cfg, M, L, steps=100):
-    """one of BASELINE.json's other configurations, timed like the headline one but bounded (about 2-3 s): 64 untimed steps, `steps`
-    timed ones between synchronisations, then the eager per-kernel pass"""
+def other_config_leg(cfg, M, L, steps=256):
+    """one of BASELINE.json's other configurations, timed like the headline one but bounded (about 2-3 s): three untimed 64-step
+    calls (both looks of the learners at graph replay vs plain launches -- engine.StepMode -- happen there, not in the timed
+    region), `steps` timed ones between synchronisations (two 128-step noise chunks of PACOH-VI), then the eager per-kernel pass"""
     wl = WORKLOADS[cfg](1, 'weak', M, L)
-    wl['run'](64)
-    torch.cuda.synchronize()
-    wl['run'](32)
-    torch.cuda.synchronize()
+    for _ in range(3):
+        wl['run'](64)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     wl['run'](steps)
     torch.cuda.synchronize()

@@ -40,7 +40,8 @@ constexpr int F_OFF_B1 = 128;                 // b1 [32]
 constexpr int F_OFF_H = 160;                  // hidden layers 2..NH
 __host__ __device__ constexpr int f_off_out(int nh) { return F_OFF_H + (nh - 1) * HBLK; }      // W_out [2][32] | b_out [2] (+2 pad)
 __host__ __device__ constexpr int f_welems(int nh) { return f_off_out(nh) + 68; }
-constexpr int TSTRIDE = 8;                    // staged tile row: x[4] | g[2] | pad[2]
+constexpr int TSTRIDE = 4;                    // staged tile: x[point][4] (16-byte rows: conflict-free 16-byte writes and broadcast reads) ...
+constexpr int TSTAGE = 6;                     // ... followed by the upstream gradients feature-major, g[o][point]: TSTAGE floats per point
 constexpr int TLD = 17;                       // scratch row stride of a block transpose; row i sits tskew(i >> 2) words further on
 __host__ __device__ constexpr int tskew(int k) { return 12 * (k & 1) + 32 * (k >> 1); }
 constexpr int TRS = 320;                      // one transpose scratch block (16 * 17 + tskew(3) + 4, rounded)
@@ -111,8 +112,10 @@ __device__ void fused_load_weights(float* wl, const float* __restrict__ th, cons
     __syncthreads();
 }
 
-// Stage the tile's inputs (and upstream gradients) in the wave's LDS block: st[pt][0..3] = x (zero padded), st[pt][4..5] = g
-// (zero for rows past the end).  Returns the output row (problem*n + point) of this lane's point, or -1.
+// Stage the tile's inputs (and upstream gradients) in the wave's LDS block: st[pt * 4 + 0..3] = x (zero padded),
+// st[16 PB * 4 + o * 16 PB + pt] = g[pt][o] (zero for rows past the end; dword accesses of consecutive lanes: no bank conflicts --
+// as 8-byte fields of 32-byte rows the compiler's ds_read2_b64 pairs were 4-way conflicted).
+// Returns the output row (problem*n + point) of this lane's point, or -1.
 template <int PB, bool BWD>
 __device__ __forceinline__ long stage_tile(const FusedArgs& a, const FusedNet& nt, int p, int row0, float* st, int lane) {
     long orow = -1;
@@ -133,10 +136,8 @@ __device__ __forceinline__ long stage_tile(const FusedArgs& a, const FusedNet& n
         const long o = (long)bi * a.n + i;
         if (BWD) {
             const float* gq = nt.g_out + o * nt.d_out;
-            float2 gv;
-            gv.x = valid ? gq[0] : 0.0f;
-            gv.y = (valid && nt.d_out > 1) ? gq[1] : 0.0f;
-            *reinterpret_cast<float2*>(st + lane * TSTRIDE + 4) = gv;
+            st[16 * PB * TSTRIDE + lane] = valid ? gq[0] : 0.0f;
+            st[16 * PB * (TSTRIDE + 1) + lane] = (valid && nt.d_out > 1) ? gq[1] : 0.0f;
         }
         orow = valid ? o : -1;
     }
@@ -290,7 +291,7 @@ __device__ __forceinline__ void stash_get(const FusedArgs& a, const FusedNet& nt
 template <int NH, int PB, int MINW>
 __global__ void __launch_bounds__(256, MINW) mlp_fused_fwd_kernel(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) float wl[f_welems(NH)];
-    __shared__ __attribute__((aligned(16))) float stage[4][16 * PB * TSTRIDE];
+    __shared__ __attribute__((aligned(16))) float stage[4][16 * PB * TSTAGE];
     const FusedNet& nt = a.net[blockIdx.z];
     const int p = blockIdx.y;
     fused_load_weights<NH>(wl, a.theta + (long)p * a.theta_stride + nt.theta_off, a, nt.d_out);
@@ -345,7 +346,7 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_fwd_kernel(FusedArgs a) {
 template <int NH, int PB, int MINW>
 __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) float wl[f_welems(NH)];
-    __shared__ __attribute__((aligned(16))) float stage[4][16 * PB * TSTRIDE];
+    __shared__ __attribute__((aligned(16))) float stage[4][16 * PB * TSTAGE];
     __shared__ __attribute__((aligned(16))) float tscr[4][2 * TRS];
     const FusedNet& nt = a.net[blockIdx.z];
     const int p = blockIdx.y;
@@ -393,7 +394,9 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
                 for (int fb = 0; fb < 2; ++fb) w3[o][fb] = *reinterpret_cast<const f32x4*>(wo + o * 32 + fb * 16 + 4 * g);
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) {
-                const float2 gr = *reinterpret_cast<const float2*>(st + (pb * 16 + r) * TSTRIDE + 4);
+                float2 gr;                                 // upstream gradient of this lane's point
+                gr.x = st[16 * PB * TSTRIDE + pb * 16 + r];
+                gr.y = st[16 * PB * (TSTRIDE + 1) + pb * 16 + r];
                 aBoT[0] += gr.x; aBoT[1] += gr.y;
 #pragma unroll
                 for (int fb = 0; fb < 2; ++fb)
