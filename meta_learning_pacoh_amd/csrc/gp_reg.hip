@@ -229,6 +229,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     __shared__ __attribute__((aligned(16))) float av[NP];           // alpha
     __shared__ __attribute__((aligned(16))) float tv[16];           // column layout -> replicated layout of one 16-vector
     __shared__ __attribute__((aligned(16))) float fsc[128];         // factor16(): lane row k -> all lane rows
+    __shared__ __attribute__((aligned(16))) float tsc[320];         // one 16x16 block transpose (V_K = -L_KK^-T)
     __shared__ __attribute__((aligned(16))) float dzc[BWD ? NP * FP : 1];   // d_z before the chain-rule factors
     // W = K^-1, strictly upper block triangle, each block as the 64 lanes' accumulator registers (one 16-byte slot per lane): parked
     // here between the matrix-core phase that produces it and the gradient loop that consumes it, so that the two phases do not
@@ -341,7 +342,26 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
             // negated operand Vn = -L_KK^-T.
             factor16(U[uidx(NB, K, K)], Zd[K], dprod, nId, r, g, fsc);
             SCHED_FENCE();
+#ifndef PACOH_VN_LDS
+#define PACOH_VN_LDS 1
+#endif
+#if PACOH_VN_LDS
+            // -L_KK^-T: the block transposed through 1.25 KB of LDS (4 dword writes + 4 dword reads, the conflict-free skewed
+            // stride-17 layout of mlp_fused.hip's f_turn) instead of a product with the -identity block (4 MFMAs = 128 of the
+            // issue cycles the matrix cores and the vector units share)
+            f32x4 Vn;
+            {
+                const int twr = 68 * g + 12 * (g & 1) + 32 * (g >> 1) + r, trd = 17 * r + 12 * ((r >> 2) & 1) + 32 * (r >> 3) + 4 * g;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) tsc[twr + 17 * s] = -Zd[K][s];
+                WSYNC();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Vn[q] = tsc[trd + q];
+                WSYNC();
+            }
+#else
             const f32x4 Vn = mmT(Zd[K], nId, f32x4{0.f, 0.f, 0.f, 0.f});             // -L_KK^-T
+#endif
 #pragma unroll
             for (int J = K + 1; J < NB; ++J) U[uidx(NB, K, J)] = mmT(Vn, U[uidx(NB, K, J)], f32x4{0.f, 0.f, 0.f, 0.f});   // R[K][J] = L_KK^-1 A[K][J]
             SCHED_FENCE();
