@@ -227,7 +227,6 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     __shared__ __attribute__((aligned(16))) float zf[NP * FP];      // features / lengthscale
     __shared__ __attribute__((aligned(16))) float rv[NP];           // residual
     __shared__ __attribute__((aligned(16))) float av[NP];           // alpha
-    __shared__ __attribute__((aligned(16))) float tv[16];           // column layout -> replicated layout of one 16-vector
     __shared__ __attribute__((aligned(16))) float fsc[128];         // factor16(): lane row k -> all lane rows
     __shared__ __attribute__((aligned(16))) float tsc[320];         // one 16x16 block transpose (V_K = -L_KK^-T)
     __shared__ __attribute__((aligned(16))) float dzc[BWD ? NP * FP : 1];   // d_z before the chain-rule factors
@@ -365,20 +364,20 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
 #pragma unroll
             for (int J = K + 1; J < NB; ++J) U[uidx(NB, K, J)] = mmT(Vn, U[uidx(NB, K, J)], f32x4{0.f, 0.f, 0.f, 0.f});   // R[K][J] = L_KK^-1 A[K][J]
             SCHED_FENCE();
-            {   // u_K = L_KK^-1 (r_K - sum_m L[K][m] u_m), L[K][m] = R[m][K]^T: tn = -r_K + sum_m R[m][K]^T u_m on the vector
-                // units (mvT_), turned into the replicated layout through 64 bytes of LDS; the product with L_KK^-1 on the matrix cores
-                f32x4 tn = -*reinterpret_cast<const f32x4*>(rv + 16 * K + 4 * g);
+            {   // u_K = L_KK^-1 (r_K - sum_m L[K][m] u_m), L[K][m] = R[m][K]^T, all on the vector units: t = r_K - sum_m R[m][K]^T u_m
+                // comes out of mvT_ / xg_sum_ in column layout (lane (r, .) holds entry r), and row 4g+s of L_KK^-1 t is a sum over the
+                // 16 lanes of a lane row of Z[4g+s][r] t[r] -- four multiplies and 16 DPP adds, which leave u_K in the replicated layout
+                // the later products want.  (Rounds 1-2: a 16x16x16 product on the matrix cores for this one vector, 128 issue cycles,
+                // fed through an LDS round trip that turned t into the replicated layout.)
+                float tc = rv[16 * K + r];
                 if (K > 0) {
                     float tp = 0.0f;
 #pragma unroll
                     for (int m = 0; m < K; ++m) tp = mvT_(U[uidx(NB, m, K)], uB[m], tp);
-                    tp = xg_sum_(tp);
-                    if (g == 0) tv[r] = tp;
-                    WSYNC();
-                    tn += *reinterpret_cast<const f32x4*>(tv + 4 * g);
-                    WSYNC();
+                    tc -= xg_sum_(tp);
                 }
-                uB[K] = mmT(Vn, tn, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int s = 0; s < 4; ++s) uB[K][s] = row_sum_(Zd[K][s] * tc);
             }
             SCHED_FENCE();
             if (BWD) {
