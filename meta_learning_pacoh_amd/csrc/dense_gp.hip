@@ -602,8 +602,10 @@ __global__ void __launch_bounds__(256) dense_grad_cols_kernel(const T* __restric
             const T e = rbf_exp<T>(T(-0.5) * s);
             dos = fma(Gij, e, dos);
             const T M = Gij * os * e;
+            // (the lengthscale sums sum_j M_ij (z_j - z_i)_c^2 are not accumulated: M being symmetric, their total over i equals
+            //  -2 sum_i (z_i - z_0)_c dz_i[c] -- one multiply per row on the finished d_z sums below; round 3, as in gp_reg.hip)
 #pragma unroll
-            for (int c = 0; c < FP; ++c) { const T md = M * df[c]; dz[c] += md; dls[c] = fma(md, df[c], dls[c]); }
+            for (int c = 0; c < FP; ++c) dz[c] = fma(M, df[c], dz[c]);
             if (j == i) dnz = Gij;
         }
     }
@@ -620,9 +622,11 @@ __global__ void __launch_bounds__(256) dense_grad_cols_kernel(const T* __restric
         for (int w = 0; w < 3; ++w) {                 // fixed order: deterministic
             const T* r = red + ((size_t)w * 64 + lane) * NR;
 #pragma unroll
-            for (int c = 0; c < FP; ++c) { dz[c] += r[c]; dls[c] += r[FP + c]; }
+            for (int c = 0; c < FP; ++c) dz[c] += r[c];
             dos += r[2 * FP]; dnz += r[2 * FP + 1];
         }
+#pragma unroll
+        for (int c = 0; c < FP; ++c) dls[c] = c < f ? T(-2) * (zi[c] - zt[c * n]) * dz[c] : T(0);
         T* rp = rowpart + (b * n + i) * (long)W3;
         if (!live) {
             const T v = failed ? T(NAN) : T(0);
