@@ -19,7 +19,7 @@
 // the PLAIN orientation, where a lane owns a feature and sums over points: 10 + 6 accumulator registers per lane and
 // two cross-lane adds at the very end (the earlier formulation summed in the transposed orientation, where a lane owns
 // a point: 66 lane-private accumulators per lane, kept in 67 KB of LDS).  Hidden-layer bias gradients fall out of the
-// same plain-orientation deltas the weight gradient needs.  Every wave writes its own partial slab; slabs are summed in
+// same plain-orientation deltas the weight gradient needs.  Every workgroup (1-2 hidden layers; every wave for deeper networks) writes its own partial slab; slabs are summed in
 // fixed order (deterministic).
 //
 // Replaces LinearVectorized / NeuralNetworkVectorized forward (meta_learn/models.py:295-317,343-349; the torch.bmm at
@@ -40,6 +40,8 @@ constexpr int F_OFF_B1 = 128;                 // b1 [32]
 constexpr int F_OFF_H = 160;                  // hidden layers 2..NH
 __host__ __device__ constexpr int f_off_out(int nh) { return F_OFF_H + (nh - 1) * HBLK; }      // W_out [2][32] | b_out [2] (+2 pad)
 __host__ __device__ constexpr int f_welems(int nh) { return f_off_out(nh) + 68; }
+__host__ __device__ constexpr int f_dnet_max(int nh) { return 32 * 5 + (nh - 1) * 32 * 33 + 2 * 33; }   // parameters of a d_in 4 / width 32 / d_out 2 network
+__host__ __device__ constexpr bool bwd_wg_slab(int nh) { return nh <= 2; }     // backward: one gradient slab per workgroup (else per wave)
 constexpr int TSTRIDE = 4;                    // staged tile: x[point][4] (16-byte rows: conflict-free 16-byte writes and broadcast reads) ...
 constexpr int TSTAGE = 6;                     // ... followed by the upstream gradients feature-major, g[o][point]: TSTAGE floats per point
 constexpr int TLD = 17;                       // scratch row stride of a block transpose; row i sits tskew(i >> 2) words further on
@@ -345,17 +347,23 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_fwd_kernel(FusedArgs a) {
 // ---- backward -----------------------------------------------------------------------------------------------------
 template <int NH, int PB, int MINW>
 __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
-    __shared__ __attribute__((aligned(16))) float wl[f_welems(NH)];
-    __shared__ __attribute__((aligned(16))) float stage[4][16 * PB * TSTAGE];
-    __shared__ __attribute__((aligned(16))) float tscr[4][2 * TRS];
+    // one LDS block: weights | staged tiles | transpose scratch.  NH <= 2: once the tile loop is over the same bytes take the four
+    // waves' gradient slabs, which are summed there (fixed order) into ONE slab per workgroup -- a quarter of the partial slabs the
+    // reduction kernel has to read, written with coalesced stores (bwd_wg_slab; deeper networks keep a slab per wave: 4 D_net
+    // floats do not fit beside their larger weight image)
+    constexpr int L_WL = (f_welems(NH) + 3) & ~3, L_ST = 4 * 16 * PB * TSTAGE, L_TS = 4 * 2 * TRS;
+    constexpr int L_RED = bwd_wg_slab(NH) ? 4 * f_dnet_max(NH) : 0;
+    constexpr int L_ALL = (L_WL + L_ST + L_TS) > L_RED ? (L_WL + L_ST + L_TS) : L_RED;
+    __shared__ __attribute__((aligned(16))) float lds[L_ALL];
+    float* wl = lds;
     const FusedNet& nt = a.net[blockIdx.z];
     const int p = blockIdx.y;
     fused_load_weights<NH>(wl, a.theta + (long)p * a.theta_stride + nt.theta_off, a, nt.d_out);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    float* st = stage[wave];
-    float* sc0 = tscr[wave];
-    float* sc1 = tscr[wave] + TRS;
+    float* st = lds + L_WL + wave * (16 * PB * TSTAGE);
+    float* sc0 = lds + L_WL + L_ST + wave * (2 * TRS);
+    float* sc1 = sc0 + TRS;
     const int twr = 4 * TLD * g + tskew(g) + r, trd = TLD * r + tskew(r >> 2) + 4 * g;
     const float* wo = wl + f_off_out(NH);
 
@@ -445,7 +453,8 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
     }
     // ---- sums over the four point groups g, then this wave's slab in the reference's flattened layout -------------------
     auto rg = [](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
-    float* dst = nt.slab + ((long)(blockIdx.x * 4 + wave) * a.P + p) * nt.D_net;
+    if (bwd_wg_slab(NH)) __syncthreads();               // (every wave is done with the weights / tiles / scratch the slabs overwrite)
+    float* dst = bwd_wg_slab(NH) ? lds + wave * nt.D_net : nt.slab + ((long)(blockIdx.x * 4 + wave) * a.P + p) * nt.D_net;
     const int d_in = a.d_in, h0 = a.h[0];
     float unscale[NH];                                 // layer j+1's delta carries TSC^(NH-1-j) (see tanh_pre)
     unscale[NH - 1] = 1.0f;
@@ -496,6 +505,12 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
                 const int k = fb * 16 + 4 * g + s;
                 if (r == 0 && o < nt.d_out && k < prev) dst[off + nt.d_out + o * prev + k] = v;
             }
+    }
+    if (bwd_wg_slab(NH)) {
+        __syncthreads();
+        float* out = nt.slab + ((long)blockIdx.x * a.P + p) * nt.D_net;
+        for (int e = threadIdx.x; e < nt.D_net; e += 256)
+            out[e] = (lds[e] + lds[nt.D_net + e]) + (lds[2 * nt.D_net + e] + lds[3 * nt.D_net + e]);
     }
 }
 
@@ -665,7 +680,7 @@ static FusedBwdPlan fused_bwd_plan(int R, int P, int nets, int n_hidden) {
 // bytes of slab space for ONE network of a (possibly two-network) backward launch
 size_t mlp_fused_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int nets) {
     const FusedBwdPlan pl = fused_bwd_plan((B / P) * n, P, nets, n_hidden);
-    return (size_t)pl.chunks * 4 * P * fused_dnet(d_in, hidden, n_hidden, d_out) * sizeof(float);
+    return (size_t)pl.chunks * (bwd_wg_slab(n_hidden) ? 1 : 4) * P * fused_dnet(d_in, hidden, n_hidden, d_out) * sizeof(float);
 }
 
 int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
@@ -684,7 +699,7 @@ int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride
         a.net[k].D_net = fused_dnet(d_in, hidden, n_hidden, d_out[k]);
         a.net[k].slab = ws;
         sr[k].in = ws; sr[k].out = (float*)d_theta + off[k]; sr[k].Wd = a.net[k].D_net;
-        ws += (size_t)pl.chunks * 4 * P * a.net[k].D_net;
+        ws += (size_t)pl.chunks * (bwd_wg_slab(n_hidden) ? 1 : 4) * P * a.net[k].D_net;
         if (a.net[k].D_net > wmax) wmax = a.net[k].D_net;
     }
 #define PACOH_LAUNCH_BWD(K) hipLaunchKernelGGL(K, dim3(pl.chunks, P, nets), dim3(256), 0, s, a)
@@ -695,7 +710,8 @@ int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride
     const int tail_blocks = tail ? tail->P * (tail->f + 4) : 0;
     if ((unsigned)tail_blocks > gx) gx = (unsigned)tail_blocks;
     hipLaunchKernelGGL(fused_reduce_slab_kernel, dim3(gx, nets + (tail ? 1 : 0)), dim3(256), 0, s,
-                       sr[0], sr[1], d_theta_stride, accumulate, pl.chunks * 4, P, nets, tail ? *tail : HyperBwdArgs<float>{}, tail_blocks);
+                       sr[0], sr[1], d_theta_stride, accumulate, pl.chunks * (bwd_wg_slab(n_hidden) ? 1 : 4), P, nets,
+                       tail ? *tail : HyperBwdArgs<float>{}, tail_blocks);
     return launch_status();
 }
 
