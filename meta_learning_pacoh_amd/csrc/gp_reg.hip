@@ -99,8 +99,10 @@ __device__ __forceinline__ float wave_sum_(float v) {
 
 // Cholesky of the 16x16 block C = -Cn (accumulator layout, symmetric; handed over NEGATED, as the kernel stores the matrix) and
 // the inverse of its factor: on exit Z = L^-1 (accumulator layout, zeros above the diagonal).  nId = -identity.  The diagonal of L
-// is multiplied into `dprod` (lane (r, g = r>>2) takes L[r][r], the other lanes 1) for the log-determinant; a pivot that is not
-// positive turns its lane's product into NaN (q * rsq(q)), which is also how the caller notices the failure.
+// is multiplied into `dprod` as its RECIPROCAL, read off the finished inverse (1 / L[r][r] = Z[r][r]: register r & 3 of lane
+// (r, r >> 2); the other lanes multiply by 1) once per block -- round 3; rounds 1-2 picked L[r][r] out of the panel row with three
+// selects under exec-mask branches in each of the four elimination steps.  A pivot that is not positive turns its lane's product
+// into NaN (rsq), a zero pivot into infinity, which is also how the caller notices the failure.
 // What is NOT computed: the entries of L above the 4-column panel being eliminated are left as they fall out of the
 // substitution (garbage): they only ever produce rows of L Z that have been consumed already.
 #ifndef PACOH_F16_LDS
@@ -114,7 +116,6 @@ __device__ __forceinline__ float wave_sum_(float v) {
 // a scalar-operand instruction: 4.7 instead of 3.2 cycles).
 __device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const f32x4& nId, int r, int g, float* fs) {
     f32x4 Tn = nId;                                         // -E + L Z, built up by one rank-4 MFMA per step (see below)
-    float dsel = 1.0f;                                      // L[r][r] in the lanes g == r >> 2
     Z = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -170,8 +171,6 @@ __device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const
         }
         // rows 4k..4k+3 of L^-1: Lp Z_k = E_k - (L Z)[k-th block row]; the lanes g == k hold that block row of Tn = -E + L Z
         if (g == k) {
-            const int c = r & 3;
-            dsel = c == 0 ? x0 : (c == 1 ? x1 : (c == 2 ? x2 : x3));
             const float z0 = -Tn[0] * r0;
             const float z1 = fmaf(-z0, l10, -Tn[1]) * r1;
             const float z2 = fmaf(-z1, l21, fmaf(-z0, l20, -Tn[2])) * r2;
@@ -198,7 +197,10 @@ __device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const
             Tn = mfma_(xg, zb, Tn);
         }
     }
-    if (g == (r >> 2)) dprod *= dsel;
+    // 1 / L[r][r] = Z[r][r] sits in register r & 3 of lane (r, r >> 2)
+    const int c = r & 3;
+    const float zd = c == 0 ? Z[0] : (c == 1 ? Z[1] : (c == 2 ? Z[2] : Z[3]));
+    if (g == (r >> 2)) dprod *= zd;
 }
 
 // A kernel argument read where it is needed.  The compiler loads the whole argument struct into scalar registers at kernel
@@ -395,7 +397,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
 #pragma unroll
                 for (int J = I; J < NB; ++J) U[uidx(NB, I, J)] = mmT(U[uidx(NB, K, I)], U[uidx(NB, K, J)], U[uidx(NB, I, J)]);
         }
-        if (__builtin_amdgcn_ballot_w64(dprod > 0.0f) == ~0ull) { my_info = attempt; break; }   // every pivot positive (wave-uniform)
+        if (__builtin_amdgcn_ballot_w64(dprod > 0.0f && dprod < __builtin_huge_valf()) == ~0ull) { my_info = attempt; break; }   // every pivot positive
         jitter = 1e-6f;
         for (int q = 0; q < attempt; ++q) jitter *= 10.0f;
     }
@@ -406,7 +408,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
 #pragma unroll
     for (int K = 0; K < NB; ++K) q2 += (uB[K][0] * uB[K][0] + uB[K][1] * uB[K][1]) + (uB[K][2] * uB[K][2] + uB[K][3] * uB[K][3]);
     const float quad = wave_sum_(r == 0 ? q2 : 0.0f);
-    const float logdet = wave_sum_(logf(dprod));              // log det = 2 sum log L_ii; padding rows have pivot 1
+    const float logdet = -wave_sum_(logf(dprod));             // log det = 2 sum log L_ii (dprod: 1 / L_ii); padding rows have pivot 1
     float lml = nv > 0 ? -0.5f * (quad + 2.0f * logdet + (float)nv * 1.8378770664093453f) / (float)nv : 0.0f;
     if (!okf) lml = NAN;
     if (lane == 0) LATE(lml)[b] = lml;
