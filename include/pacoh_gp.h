@@ -49,6 +49,18 @@ extern "C" {
 #define PACOH_MEAN_CONST 2     /* mean[P]     (ConstantMeanLight, models.py:406-416)             */
 
 #define PACOH_MAX_FEATURES 16  /* f (kernel input dim) <= 16                                     */
+/* Kernel family of the GP entry points (round 3).  Default: ARD-RBF.  The family rides in the bits above the feature count of
+ * the `f` argument, f_arg = f | (PACOH_KERNEL_x << PACOH_KERNEL_SHIFT), of pacoh_gram_rbf_ard, pacoh_gp_lml_fwd / _fwdbwd /
+ * _predict, pacoh_gp_lml_dense / pacoh_gp_predict_dense, and of pacoh_hyper_fwd / pacoh_hyper_bwd / pacoh_step_begin, where it
+ * says that the family has ONE raw scale parameter shared by all f input dimensions.
+ *   PACOH_KERNEL_COSINE  k(x, x') = os * cos(pi * |x - x'| / period)   -- gpytorch.kernels.CosineKernel, which the reference's own
+ *                        suite hands to the single-task learner (tests/test_GPR.py:95-101; GPR_mll.py:66-78 takes any Kernel
+ *                        object): `lengthscale[p, 0..f)` all hold the period length; d_lengthscale[b, c] comes back per
+ *                        dimension and its sum over c is the gradient of the period.  General (LDS-resident / HBM-resident)
+ *                        kernels only: not a hot path. */
+#define PACOH_KERNEL_RBF 0
+#define PACOH_KERNEL_COSINE 1
+#define PACOH_KERNEL_SHIFT 8
 #define PACOH_MLP_MAX_HIDDEN_LAYERS 63   /* per-particle MLP: any layer_sizes up to this depth ...          */
 #define PACOH_MLP_MAX_WIDTH 65536        /* ... and this width (the reference has no limit: models.py:328-349) */
 #define PACOH_SVGD_MAX_PARTICLES 1024    /* SVGD entry points, RBF and IMQ kernel (the reference has no limit; its sweeps use 10 / 50) */

@@ -29,7 +29,7 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         # strings as the reference, or ZeroMean / ConstantMean / (Scale)RBFKernel objects (modules.py); other objects cannot run here
         mean_module, self._mean_init = resolve_mean_module(mean_module)
         covar_module, self._covar_init, self._learn_outputscale = resolve_covar_module(covar_module)
-        assert mean_module in ['NN', 'constant', 'zero'] and covar_module in ['NN', 'SE']
+        assert mean_module in ['NN', 'constant', 'zero'] and covar_module in ['NN', 'SE', 'COS']
         assert optimizer in ['Adam', 'SGD']
 
         self.lr_params, self.weight_decay, self.feature_dim = lr_params, weight_decay, feature_dim

@@ -44,7 +44,7 @@ class GPRegressionLearned:
         # strings as the reference, or ZeroMean / ConstantMean / (Scale)RBFKernel objects (modules.py); other objects cannot run here
         mean_module, mean_init = resolve_mean_module(mean_module)
         covar_module, covar_init, learn_os = resolve_covar_module(covar_module)
-        assert mean_module in ['NN', 'constant', 'zero'] and covar_module in ['NN', 'SE']
+        assert mean_module in ['NN', 'constant', 'zero'] and covar_module in ['NN', 'SE', 'COS']
         assert optimizer in ['Adam', 'SGD']
         self.normalize_data, self.logger = normalize_data, get_logger()
         self.device, self.dtype = get_device(), torch.float32

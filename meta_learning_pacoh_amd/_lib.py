@@ -14,6 +14,12 @@ LIB_PATH = os.environ.get('PACOH_LIB') or os.path.join(_HERE, 'lib', 'libpacoh_g
 
 F32, F64 = 0, 1
 MEAN_ZERO, MEAN_VECTOR, MEAN_CONST = 0, 1, 2
+KERNEL_RBF, KERNEL_COSINE, KERNEL_SHIFT = 0, 1, 8          # PACOH_KERNEL_* (pacoh_gp.h): the family rides in the bits above f
+
+
+def _kf(f, kernel):
+    """the `f` argument of a GP entry point: feature count | kernel family"""
+    return int(f) | (int(kernel) << KERNEL_SHIFT)
 ERRORS = {-1: 'PACOH_EINVAL (bad argument)', -2: 'PACOH_ELIMIT (shape outside kernel limits)',
           -3: 'PACOH_EDTYPE', -4: 'PACOH_ELAUNCH (HIP launch failed)', -5: 'PACOH_ENOCOMM (librccl not loadable)'}
 COMM_ID_BYTES = 128
@@ -249,14 +255,14 @@ def _hidden_arr(hidden):
 # thin typed wrappers (shapes are validated here, the C side validates limits)
 # ------------------------------------------------------------------------------------------------
 
-def gram_rbf_ard(z1, z1_div, z2, z2_div, lengthscale, outputscale, noise, add_noise_diag, B, P):
+def gram_rbf_ard(z1, z1_div, z2, z2_div, lengthscale, outputscale, noise, add_noise_diag, B, P, kernel=KERNEL_RBF):
     lib = load_library()
     n, f = z1.shape[-2], z1.shape[-1]
     m = z2.shape[-2]
     K = torch.empty(B, n, m, dtype=z1.dtype, device=z1.device)
     with _Timed('gram_rbf_ard'):
         _check(lib.pacoh_gram_rbf_ard(_ptr(z1), z1_div, _ptr(z2, z1), z2_div, _ptr(lengthscale, z1), _ptr(outputscale, z1),
-                                      _ptr(noise, z1), int(bool(add_noise_diag)), _ptr(K), B, P, n, m, f, dtype_code(z1),
+                                      _ptr(noise, z1), int(bool(add_noise_diag)), _ptr(K), B, P, n, m, _kf(f, kernel), dtype_code(z1),
                                       _stream()), 'pacoh_gram_rbf_ard')
     return K
 
@@ -269,7 +275,7 @@ def gp_small_max_n(dtype, want_grad):
 
 
 def gp_lml_fwd(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, B, P, n_valid=None,
-               want_alpha=False, want_L=False):
+               want_alpha=False, want_L=False, kernel=KERNEL_RBF):
     lib = load_library()
     n, f = z.shape[-2], z.shape[-1]
     dev, dt = z.device, z.dtype
@@ -280,12 +286,13 @@ def gp_lml_fwd(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, no
     if FORCE_DENSE or n > gp_small_max_n(dt, False):
         if want_alpha or want_L:
             raise RuntimeError('alpha / L outputs are only available on the small-n path (n <= %d)' % gp_small_max_n(dt, False))
-        lml = _gp_lml_dense(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, None, B, P, info, False)[0]
+        lml = _gp_lml_dense(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, None, B, P, info, False,
+                            kernel=kernel)[0]
         return lml, None, None, info
     with _Timed('gp_lml_fwd'):
         _check(lib.pacoh_gp_lml_fwd(_ptr(z), z_div, _ptr(mean, z), mean_mode, _ptr(y, z), y_div, _ptr(lengthscale, z),
                                     _ptr(outputscale, z), _ptr(noise, z), _ptr(n_valid), _ptr(lml), _ptr(alpha), _ptr(L),
-                                    _ptr(info), B, P, n, f, dtype_code(z), _stream()), 'pacoh_gp_lml_fwd')
+                                    _ptr(info), B, P, n, _kf(f, kernel), dtype_code(z), _stream()), 'pacoh_gp_lml_fwd')
     return lml, alpha, L, info
 
 
@@ -302,7 +309,7 @@ def _workspace(key, nbytes, device):
 
 
 def _gp_lml_dense(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, g_lml, B, P, info,
-                  want_grad, want_dz=True):
+                  want_grad, want_dz=True, kernel=KERNEL_RBF):
     """large-n path (matrices materialised in HBM): -> (lml, d_z, d_mean, d_ls, d_os, d_noise)"""
     lib = load_library()
     n, f = z.shape[-2], z.shape[-1]
@@ -344,12 +351,12 @@ def _gp_lml_dense(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale,
                                           _ptr(sl(n_valid, b0, b1, y_div)), _ptr(sl(g_lml, b0, b1), z), _ptr(sl(lml, b0, b1)),
                                           _ptr(sl(d_z, b0, b1)), _ptr(d_mean_c), _ptr(sl(d_ls, b0, b1)), _ptr(sl(d_os, b0, b1)),
                                           _ptr(sl(d_noise, b0, b1)), _ptr(sl(info, b0, b1)), _ptr(ws),
-                                          Bc, P, n, f, code, _stream()), 'pacoh_gp_lml_dense')
+                                          Bc, P, n, _kf(f, kernel), code, _stream()), 'pacoh_gp_lml_dense')
     return lml, d_z, d_mean, d_ls, d_os, d_noise
 
 
 def gp_lml_fwdbwd(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, B, P, n_valid=None,
-                  g_lml=None, want_dz=True):
+                  g_lml=None, want_dz=True, kernel=KERNEL_RBF):
     lib = load_library()
     n, f = z.shape[-2], z.shape[-1]
     dev, dt = z.device, z.dtype
@@ -367,17 +374,17 @@ def gp_lml_fwdbwd(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale,
     info = torch.empty(B, dtype=torch.int32, device=dev)
     if FORCE_DENSE or n > gp_small_max_n(dt, True):
         return _gp_lml_dense(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, g_lml, B, P, info,
-                             True, want_dz) + (info,)
+                             True, want_dz, kernel=kernel) + (info,)
     with _Timed('gp_lml_fwdbwd'):
         _check(lib.pacoh_gp_lml_fwdbwd(_ptr(z), z_div, _ptr(mean, z), mean_mode, _ptr(y, z), y_div, _ptr(lengthscale, z),
                                        _ptr(outputscale, z), _ptr(noise, z), _ptr(n_valid), _ptr(g_lml, z), _ptr(lml),
                                        _ptr(d_z), _ptr(d_mean), _ptr(d_ls), _ptr(d_os), _ptr(d_noise), _ptr(info),
-                                       B, P, n, f, dtype_code(z), _stream()), 'pacoh_gp_lml_fwdbwd')
+                                       B, P, n, _kf(f, kernel), dtype_code(z), _stream()), 'pacoh_gp_lml_fwdbwd')
     return lml, d_z, d_mean, d_ls, d_os, d_noise, info
 
 
 def gp_predict(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, z_tst, zt_div, mean_tst, lengthscale, outputscale, noise,
-               B, P, n_valid=None, want_cov=False):
+               B, P, n_valid=None, want_cov=False, kernel=KERNEL_RBF):
     lib = load_library()
     n, f = z_ctx.shape[-2], z_ctx.shape[-1]
     m = z_tst.shape[-2]
@@ -393,7 +400,7 @@ def gp_predict(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, z_tst, zt_div, mean_
             _check(lib.pacoh_gp_predict_dense(_ptr(z_ctx), z_div, _ptr(mean_ctx, z_ctx), mean_mode, _ptr(y, z_ctx), y_div,
                                               _ptr(z_tst, z_ctx), zt_div, _ptr(mean_tst, z_ctx), _ptr(lengthscale, z_ctx),
                                               _ptr(outputscale, z_ctx), _ptr(noise, z_ctx), _ptr(n_valid), _ptr(mu), _ptr(var),
-                                              _ptr(cov), _ptr(info), _ptr(ws), B, P, n, m, f, code, _stream()),
+                                              _ptr(cov), _ptr(info), _ptr(ws), B, P, n, m, _kf(f, kernel), code, _stream()),
                    'pacoh_gp_predict_dense')
         return mu, var, cov, info
     ws_bytes = lib.pacoh_gp_predict_workspace_bytes(B, n, m, code, int(want_cov))
@@ -402,7 +409,7 @@ def gp_predict(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, z_tst, zt_div, mean_
         _check(lib.pacoh_gp_predict(_ptr(z_ctx), z_div, _ptr(mean_ctx, z_ctx), mean_mode, _ptr(y, z_ctx), y_div,
                                     _ptr(z_tst, z_ctx), zt_div, _ptr(mean_tst, z_ctx), _ptr(lengthscale, z_ctx),
                                     _ptr(outputscale, z_ctx), _ptr(noise, z_ctx), _ptr(n_valid), _ptr(mu), _ptr(var),
-                                    _ptr(cov), _ptr(info), _ptr(ws), B, P, n, m, f, code, _stream()), 'pacoh_gp_predict')
+                                    _ptr(cov), _ptr(info), _ptr(ws), B, P, n, m, _kf(f, kernel), code, _stream()), 'pacoh_gp_predict')
     return mu, var, cov, info
 
 
@@ -548,26 +555,26 @@ def softplus_bwd(raw, g, d_raw=None, accumulate=False):
     return d_raw
 
 
-def hyper_fwd(theta, off_ls, f, off_os, off_noise, noise_floor):
+def hyper_fwd(theta, off_ls, f, off_os, off_noise, noise_floor, kernel=KERNEL_RBF):
     lib = load_library()
     P, D = theta.shape
     ls = torch.empty(P, f, dtype=theta.dtype, device=theta.device)
     os_ = torch.empty(P, dtype=theta.dtype, device=theta.device) if off_os >= 0 else None
     noise = torch.empty(P, dtype=theta.dtype, device=theta.device)
     with _Timed('hyper_fwd'):
-        _check(lib.pacoh_hyper_fwd(_ptr(theta), D, P, off_ls, f, off_os, off_noise, float(noise_floor), _ptr(ls), _ptr(os_),
+        _check(lib.pacoh_hyper_fwd(_ptr(theta), D, P, off_ls, _kf(f, kernel), off_os, off_noise, float(noise_floor), _ptr(ls), _ptr(os_),
                                    _ptr(noise), dtype_code(theta), _stream()), 'pacoh_hyper_fwd')
     return ls, os_, noise
 
 
 def hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, grad, lml=None, lik=None,
-              lik_scale=1.0, info=None, fail_flag=None):
+              lik_scale=1.0, info=None, fail_flag=None, kernel=KERNEL_RBF):
     """lml [T*P] and lik [P] (both or neither): lik[p] = lik_scale * sum_t lml[t, p] in the same launch;
     info [T*P] and fail_flag [1] (int32, both or neither): fail_flag |= any(info < 0)"""
     lib = load_library()
     P, D = theta.shape
     with _Timed('hyper_bwd'):
-        _check(lib.pacoh_hyper_bwd(_ptr(theta), D, P, T, off_ls, f, off_os, off_noise, off_const, _ptr(d_ls, theta),
+        _check(lib.pacoh_hyper_bwd(_ptr(theta), D, P, T, off_ls, _kf(f, kernel), off_os, off_noise, off_const, _ptr(d_ls, theta),
                                    _ptr(d_os, theta), _ptr(d_noise, theta), _ptr(d_const, theta), _ptr(grad, theta),
                                    grad.shape[1], _ptr(lml, theta), _ptr(lik, theta), float(lik_scale),
                                    _ptr(info if fail_flag is not None else None), _ptr(fail_flag if info is not None else None),
@@ -691,7 +698,8 @@ def step_begin(feed, tasks, out, theta=None, hyper=None, hyper_out=None, advance
     ls = os_ = noise = None
     P, stride = 0, 0
     if theta is not None:
-        off_ls, f, off_os, off_noise, floor = hyper
+        off_ls, f, off_os, off_noise, floor = hyper[:5]
+        f = _kf(f, hyper[5] if len(hyper) > 5 else KERNEL_RBF)
         ls, os_, noise = hyper_out
         P, stride = theta.shape
     with _Timed('step_begin'):

@@ -65,6 +65,28 @@ template <> __device__ __forceinline__ float rbf_exp<float>(float x) {
     return fmaf(e, lo * 0.6931471805599453f, e);
 }
 
+// ---- kernel families ---------------------------------------------------------------------------------------------------------
+// The `f` argument of the GP entry points carries the kernel family in the bits above the feature count (PACOH_KERNEL_* in
+// pacoh_gp.h): f_arg = f | (kernel << PACOH_KERNEL_SHIFT).  In scaled coordinates u = z / lengthscale, with s2 = |u_i - u_j|^2:
+//   RBF     k / os = exp(-s2 / 2)          -(d k / d u_ic) / ((u_i - u_j)_c os) = the same value
+//   COSINE  k / os = cos(pi sqrt(s2))      ... = pi sin(pi s) / s   (-> pi^2 for s -> 0)        [gpytorch.kernels.CosineKernel]
+// kern_eval returns both: every gradient of the LML is a contraction with one of the two (d/d outputscale with the first, d/d z
+// and d/d lengthscale with the second), so the kernels that evaluate the RBF family evaluate any family given this pair.
+__host__ __device__ inline int kernel_of(int f_arg) { return f_arg >> PACOH_KERNEL_SHIFT; }
+__host__ __device__ inline int features_of(int f_arg) { return f_arg & ((1 << PACOH_KERNEL_SHIFT) - 1); }
+template <typename T> __device__ __forceinline__ void sincospi_t(T x, T* s, T* c);
+template <> __device__ __forceinline__ void sincospi_t<float>(float x, float* s, float* c) { sincospif(x, s, c); }
+template <> __device__ __forceinline__ void sincospi_t<double>(double x, double* s, double* c) { sincospi(x, s, c); }
+template <typename T> __device__ __forceinline__ void kern_eval(int kind, T s2, T& kv, T& kd) {
+    if (kind == PACOH_KERNEL_RBF) { kv = kd = rbf_exp<T>(T(-0.5) * s2); return; }
+    const T s = t_sqrt<T>(s2);
+    T sn, cs;
+    sincospi_t<T>(s, &sn, &cs);
+    kv = cs;
+    kd = s > T(1e-12) ? T(3.141592653589793) * sn / s : T(9.869604401089358);
+}
+template <typename T> __device__ __forceinline__ T kern_val(int kind, T s2) { T kv, kd; kern_eval<T>(kind, s2, kv, kd); return kv; }
+
 // tanh for the MLP activations.  fp32: 1 - 2 / (1 + exp(2x)) on the hardware exp2 / rcp: five instructions, no branches,
 // correct limits for both signs (exp2 overflow -> rcp(inf) = 0 -> +1; exp2 underflow -> 1 - 2 = -1).  Its ABSOLUTE error is
 // ~1e-7 everywhere (one rounding of a value near 1); the relative error grows like 1e-7 / |x| for tiny |x|, which is

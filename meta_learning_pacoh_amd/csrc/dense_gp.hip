@@ -107,7 +107,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) regram_failed_kernel(const T* __restrict__ z, int z_div, const T* __restrict__ ls,
                                                             const T* __restrict__ os, const T* __restrict__ noise,
                                                             const int32_t* __restrict__ info, T jitter, T* __restrict__ A,
-                                                            int P, int n, int f) {
+                                                            int P, int n, int f, int kind) {
     const long b = blockIdx.y;
     if (info[b] >= 0) return;
     const int p = (int)(b % P);
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) regram_failed_kernel(const T* __restrict_
         for (int j = threadIdx.x; j < n; j += 256) {
             T s = 0;
             for (int c = 0; c < f; ++c) { const T d = zb[(long)i * f + c] / ls[(long)p * f + c] - zb[(long)j * f + c] / ls[(long)p * f + c]; s = fma(d, d, s); }
-            row[j] = osv * rbf_exp<T>(T(-0.5) * s) + (i == j ? dg : T(0));
+            row[j] = osv * kern_val<T>(kind, s) + (i == j ? dg : T(0));
         }
     }
 }
@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(256) dense_grad_rows_kernel(const T* __restric
                                                               int y_div, const T* __restrict__ g_lml, const T* __restrict__ alpha,
                                                               const T* __restrict__ Wm, const int32_t* __restrict__ info,
                                                               T* __restrict__ d_z, T* __restrict__ d_mean, int mean_mode,
-                                                              T* __restrict__ rowpart, int P, int n, int f, int rows) {
+                                                              T* __restrict__ rowpart, int P, int n, int f, int rows, int kind) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* zt = reinterpret_cast<T*>(smem_raw);          // [f][n]  (LDS only)
     T* al = zt + (size_t)f * n;                       // [n]
@@ -523,9 +523,10 @@ __global__ void __launch_bounds__(256) dense_grad_rows_kernel(const T* __restric
                 df[c] = c < f ? (LDS ? zt[c * n + j] : zb[(long)j * f + c]) - zi[c] : T(0);
                 s = fma(df[c], df[c], s);
             }
-            const T e = rbf_exp<T>(T(-0.5) * s);
+            T e, ed;                                   // k / os and the weight of (z_j - z_i) in its derivative (common.h: kern_eval)
+            kern_eval<T>(kind, s, e, ed);
             dos = fma(Gij, e, dos);
-            const T M = Gij * os * e;
+            const T M = Gij * os * ed;
 #pragma unroll
             for (int c = 0; c < FP; ++c) { const T md = M * df[c]; dz[c] += md; dls[c] = fma(md, df[c], dls[c]); }
             if (j == i) dnz = Gij;
@@ -558,7 +559,7 @@ __global__ void __launch_bounds__(256) dense_grad_cols_kernel(const T* __restric
                                                               int y_div, const T* __restrict__ g_lml, const T* __restrict__ alpha,
                                                               const T* __restrict__ Wm, const int32_t* __restrict__ info,
                                                               T* __restrict__ d_z, T* __restrict__ d_mean, int mean_mode,
-                                                              T* __restrict__ rowpart, int P, int n, int f) {
+                                                              T* __restrict__ rowpart, int P, int n, int f, int kind) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* zt = reinterpret_cast<T*>(smem_raw);          // [f][n]
     T* al = zt + (size_t)f * n;                       // [n]
@@ -599,9 +600,10 @@ __global__ void __launch_bounds__(256) dense_grad_cols_kernel(const T* __restric
                 df[c] = c < f ? zt[c * n + j] - zi[c] : T(0);
                 s = fma(df[c], df[c], s);
             }
-            const T e = rbf_exp<T>(T(-0.5) * s);
+            T e, ed;
+            kern_eval<T>(kind, s, e, ed);
             dos = fma(Gij, e, dos);
-            const T M = Gij * os * e;
+            const T M = Gij * os * ed;
             // (the lengthscale sums sum_j M_ij (z_j - z_i)_c^2 are not accumulated: M being symmetric, their total over i equals
             //  -2 sum_i (z_i - z_0)_c dz_i[c] -- one multiply per row on the finished d_z sums below; round 3, as in gp_reg.hip)
 #pragma unroll
@@ -761,7 +763,8 @@ template <typename T>
 int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, const void* y, int y_div, const void* ls,
                    const void* os, const void* noise, const int32_t* n_valid, const void* g_lml, void* lml, void* d_z,
                    void* d_mean, void* d_ls, void* d_os, void* d_noise, int32_t* info, void* workspace, int B, int P, int n,
-                   int f, int dtype, hipStream_t s) {
+                   int f_arg, int dtype, hipStream_t s) {
+    const int f = features_of(f_arg), kind = kernel_of(f_arg);
     const bool bwd = d_ls != nullptr;
     const size_t nn = (size_t)B * n * n;
     unsigned char* w = (unsigned char*)workspace;
@@ -782,13 +785,13 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
     const bool u_only = bwd && dense_chol_saves_inverse(n, dtype);          // alpha comes from Z afterwards (dense_alpha_kernel)
     for (int attempt = 0; attempt < 4; ++attempt) {
         if (attempt == 0) {
-            int rc = pacoh_gram_rbf_ard(z, z_div, z, z_div, ls, os, noise, 1, A, B, P, n, n, f, dtype, s);
+            int rc = pacoh_gram_rbf_ard(z, z_div, z, z_div, ls, os, noise, 1, A, B, P, n, n, f_arg, dtype, s);
             if (rc) return rc;
         } else {
             double jit = jitter_base;
             for (int q = 1; q < attempt; ++q) jit *= 10.0;
             hipLaunchKernelGGL(regram_failed_kernel<T>, dim3(n < 8 ? n : 8, B), dim3(256), 0, s, (const T*)z, z_div, (const T*)ls, (const T*)os,
-                               (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f);
+                               (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f, kind);
         }
         if (n_valid) hipLaunchKernelGGL(dense_mask_kernel<T>, dim3(n, B), dim3(256), 0, s, A, n_valid, y_div, (const int32_t*)info, attempt, n);
         int rc = dense_chol_launch(A, resid, logp, bwd ? alpha : nullptr, info, 1.0, B, n, dtype, attempt, s, u_only ? 1 : 0);
@@ -817,13 +820,13 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
         if (use_lds && cols_on && glds + 3 * 64 * (2 * fp + 2) * sizeof(T) <= 64u * 1024u) \
             hipLaunchKernelGGL((dense_grad_cols_kernel<T, fp>), dim3((n + 63) / 64, B), dim3(256), glds + 3 * 64 * (2 * fp + 2) * sizeof(T), s, \
             (const T*)zsc, (const T*)ls, (const T*)os, n_valid, y_div, (const T*)g_lml, (const T*)alpha, (const T*)Wm, \
-            (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f); \
+            (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f, kind); \
         else if (use_lds) hipLaunchKernelGGL((dense_grad_rows_kernel<T, fp, true>), dim3((n + rows - 1) / rows, B), dim3(256), glds, s, \
             (const T*)zsc, (const T*)ls, (const T*)os, n_valid, y_div, (const T*)g_lml, (const T*)alpha, (const T*)Wm, \
-            (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f, rows); \
+            (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f, rows, kind); \
         else hipLaunchKernelGGL((dense_grad_rows_kernel<T, fp, false>), dim3((n + rows - 1) / rows, B), dim3(256), 0, s, \
             (const T*)zsc, (const T*)ls, (const T*)os, n_valid, y_div, (const T*)g_lml, (const T*)alpha, (const T*)Wm, \
-            (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f, rows); \
+            (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f, rows, kind); \
         break;
         switch (FP) { PACOH_DG_CASE(2) PACOH_DG_CASE(4) PACOH_DG_CASE(8) default: PACOH_DG_CASE(16) }
 #undef PACOH_DG_CASE
@@ -838,7 +841,8 @@ template <typename T>
 int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int mean_mode, const void* y, int y_div,
                        const void* z_tst, int zt_div, const void* mean_tst, const void* ls, const void* os, const void* noise,
                        const int32_t* n_valid, void* mu, void* var, void* cov, int32_t* info, void* workspace, int B, int P,
-                       int n, int m, int f, int dtype, hipStream_t s) {
+                       int n, int m, int f_arg, int dtype, hipStream_t s) {
+    const int f = features_of(f_arg), kind = kernel_of(f_arg);
     const size_t nn = (size_t)B * n * n, nm = (size_t)B * n * m;
     unsigned char* w = (unsigned char*)workspace;
     T* A = (T*)w;                 w += align256(nn * sizeof(T));
@@ -856,13 +860,13 @@ int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int m
     const double jitter_base = dtype == PACOH_F32 ? 1e-6 : 1e-8;
     for (int attempt = 0; attempt < 4; ++attempt) {
         if (attempt == 0) {
-            int rc = pacoh_gram_rbf_ard(z_ctx, z_div, z_ctx, z_div, ls, os, noise, 1, A, B, P, n, n, f, dtype, s);
+            int rc = pacoh_gram_rbf_ard(z_ctx, z_div, z_ctx, z_div, ls, os, noise, 1, A, B, P, n, n, f_arg, dtype, s);
             if (rc) return rc;
         } else {
             double jit = jitter_base;
             for (int q = 1; q < attempt; ++q) jit *= 10.0;
             hipLaunchKernelGGL(regram_failed_kernel<T>, dim3(n < 8 ? n : 8, B), dim3(256), 0, s, (const T*)z_ctx, z_div, (const T*)ls,
-                               (const T*)os, (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f);
+                               (const T*)os, (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f, kind);
         }
         if (n_valid) hipLaunchKernelGGL(dense_mask_kernel<T>, dim3(n, B), dim3(256), 0, s, A, n_valid, y_div, (const int32_t*)info, attempt, n);
         int rc = dense_chol_launch(A, resid, logp, alpha, info, 1.0, B, n, dtype, attempt, s);
@@ -872,14 +876,14 @@ int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int m
         int rc = launch_trtri<T>(A, info, B, n, mpad, lds, dense_chol_saves_inverse(n, dtype) ? 1 : 0, s);
         if (rc) return rc;
     }
-    int rc = pacoh_gram_rbf_ard(z_ctx, z_div, z_tst, zt_div, ls, os, nullptr, 0, Kxs, B, P, n, m, f, dtype, s);
+    int rc = pacoh_gram_rbf_ard(z_ctx, z_div, z_tst, zt_div, ls, os, nullptr, 0, Kxs, B, P, n, m, f_arg, dtype, s);
     if (rc) return rc;
     // padded context rows carry no information: Z's identity rows would pass those rows of K_xs straight into V
     if (n_valid) hipLaunchKernelGGL(dense_zero_rows_kernel<T>, dim3(n, B), dim3(256), 0, s, Kxs, n_valid, y_div, n, m);
     GemmArgs gv = {A, Kxs, V, (long)n * n, (long)n * m, (long)n * m, n, m, m, n, m, n, 0, 0, 1, 0, 1.0, 0.0, info, 0};
     launch_bgemm<T>(gv, B, s);                                              // V = Z K_xs
     if (cov) {
-        rc = pacoh_gram_rbf_ard(z_tst, zt_div, z_tst, zt_div, ls, os, noise, 1, cov, B, P, m, m, f, dtype, s);
+        rc = pacoh_gram_rbf_ard(z_tst, zt_div, z_tst, zt_div, ls, os, noise, 1, cov, B, P, m, m, f_arg, dtype, s);
         if (rc) return rc;
         GemmArgs gc = {V, V, cov, (long)n * m, (long)n * m, (long)m * m, m, m, m, m, m, n, 1, 0, 0, 0, -1.0, 1.0, info, 1};
         launch_bgemm<T>(gc, B, s);                                          // cov = K_ss + noise I - V^T V
@@ -897,6 +901,7 @@ int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int m
 using namespace pacoh;
 
 extern "C" size_t pacoh_gp_lml_dense_workspace_bytes(int B, int n, int f, int dtype, int want_grad) {
+    f = features_of(f);
     if (B <= 0 || n <= 0 || f <= 0) return 0;
     const size_t e = dtype == PACOH_F64 ? 8 : 4;
     const size_t nn = (size_t)B * n * n;
@@ -915,7 +920,7 @@ extern "C" int pacoh_gp_lml_dense(const void* z, int z_div, const void* mean, in
         return PACOH_EINVAL;
     if (mean_mode != PACOH_MEAN_ZERO && !mean) return PACOH_EINVAL;
     if (d_lengthscale && !d_noise) return PACOH_EINVAL;
-    if (f > PACOH_MAX_FEATURES) return PACOH_ELIMIT;
+    if (features_of(f) > PACOH_MAX_FEATURES || features_of(f) <= 0 || kernel_of(f) > PACOH_KERNEL_COSINE) return PACOH_ELIMIT;
     if (dtype == PACOH_F32)
         return lml_dense_impl<float>(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, g_lml, lml, d_z,
                                      d_mean, d_lengthscale, d_outputscale, d_noise, info, workspace, B, P, n, f, dtype, (hipStream_t)stream);
@@ -940,7 +945,7 @@ extern "C" int pacoh_gp_predict_dense(const void* z_ctx, int z_div, const void* 
         m <= 0 || f <= 0 || z_div <= 0 || y_div <= 0 || zt_div <= 0)
         return PACOH_EINVAL;
     if (mean_mode != PACOH_MEAN_ZERO && (!mean_ctx || !mean_tst)) return PACOH_EINVAL;
-    if (f > PACOH_MAX_FEATURES) return PACOH_ELIMIT;
+    if (features_of(f) > PACOH_MAX_FEATURES || features_of(f) <= 0 || kernel_of(f) > PACOH_KERNEL_COSINE) return PACOH_ELIMIT;
     if (dtype == PACOH_F32)
         return predict_dense_impl<float>(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, z_tst, zt_div, mean_tst, lengthscale, outputscale,
                                          noise, n_valid, mu, var, cov, info, workspace, B, P, n, m, f, dtype, (hipStream_t)stream);

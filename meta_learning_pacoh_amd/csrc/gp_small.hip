@@ -28,6 +28,7 @@ struct GpArgs {
     T* d_z; T* d_mean; T* d_ls; T* d_os; T* d_noise;
     const T* z_tst; int zt_div; const T* mean_tst; T* mu; T* var; T* V_out; int m;
     int B, P, n, f, GS, G, LD;
+    int kind;             // kernel family (PACOH_KERNEL_*), decoded from the f argument of the entry point
     int nZ;               // rows of the second LDS matrix (Z / test-point tile)
     unsigned per_group;   // LDS elements per group
 };
@@ -127,7 +128,7 @@ __global__ void __launch_bounds__(256) gp_small_kernel(GpArgs<T> a) {
                     T s = 0;
 #pragma unroll
                     for (int c = 0; c < FP; ++c) { T d = zs[c] - zf[k * FP + c]; s = fma(d, d, s); }
-                    aik = os * rbf_exp<T>(T(-0.5) * s);
+                    aik = os * kern_val<T>(a.kind, s);
                     if (i == k) aik += noise + jitter;
                 } else {
                     aik = (i == k) ? T(1) : T(0);
@@ -210,9 +211,10 @@ __global__ void __launch_bounds__(256) gp_small_kernel(GpArgs<T> a) {
                     T df[FP];
 #pragma unroll
                     for (int c = 0; c < FP; ++c) { df[c] = zf[j * FP + c] - zs[c]; s = fma(df[c], df[c], s); }
-                    T e = rbf_exp<T>(T(-0.5) * s);
+                    T e, ed;                           // k / os and the weight of (z_i - z_j) in its derivative (RBF: the same)
+                    kern_eval<T>(a.kind, s, e, ed);
                     dos = fma(Gij, e, dos);
-                    T M = Gij * os * e;
+                    T M = Gij * os * ed;
 #pragma unroll
                     for (int c = 0; c < FP; ++c) { T md = M * df[c]; dz[c] += md; dls[c] = fma(md, df[c], dls[c]); }
                     if (j == i) dnz = Gij;
@@ -275,7 +277,7 @@ __global__ void __launch_bounds__(256) gp_small_kernel(GpArgs<T> a) {
                         T sd = 0;
 #pragma unroll
                         for (int c = 0; c < FP; ++c) { T d = zt[c] - zf[r * FP + c]; sd = fma(d, d, sd); }
-                        ks = os * rbf_exp<T>(T(-0.5) * sd);
+                        ks = os * kern_val<T>(a.kind, sd);
                     }
                     T acc = dot_rows<T>(Zmat + (size_t)i * LD, Lmat + (size_t)r * LD, 0, r);
                     T val = (ks - acc) * invd[r];
@@ -296,7 +298,7 @@ template <typename T>
 __global__ void gp_predict_cov_kernel(const T* __restrict__ z_tst, int zt_div, const T* __restrict__ V,
                                       const T* __restrict__ ls, const T* __restrict__ os,
                                       const T* __restrict__ noise, T* __restrict__ cov,
-                                      int B, int P, int n, int m, int f) {
+                                      int B, int P, int n, int m, int f, int kind) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long total = (long)B * m * m;
     if (idx >= total) return;
@@ -309,7 +311,7 @@ __global__ void gp_predict_cov_kernel(const T* __restrict__ z_tst, int zt_div, c
     T sd = 0;
     for (int c = 0; c < f; ++c) { T d = (za[c] - zb[c]) / ls[(long)p * f + c]; sd = fma(d, d, sd); }
     T osv = os ? os[p] : T(1);
-    T k = osv * rbf_exp<T>(T(-0.5) * sd);
+    T k = osv * kern_val<T>(kind, sd);
     const T* va = V + (b * m + s1) * (long)n;
     const T* vb = V + (b * m + s2) * (long)n;
     T acc = 0;
@@ -322,7 +324,7 @@ static inline int pow2ceil(int n) { int g = 8; while (g < n) g <<= 1; return g; 
 template <typename T, int MODE>
 static int launch_gp_small(GpArgs<T> a, hipStream_t stream) {
     if (a.B <= 0 || a.P <= 0 || a.n <= 0 || a.f <= 0 || a.z_div <= 0 || a.y_div <= 0) return PACOH_EINVAL;
-    if (a.f > PACOH_MAX_FEATURES) return PACOH_ELIMIT;
+    if (a.f > PACOH_MAX_FEATURES || a.kind < 0 || a.kind > PACOH_KERNEL_COSINE) return PACOH_ELIMIT;
     if (!a.z || !a.y || !a.ls || !a.noise) return PACOH_EINVAL;
     if (a.mean_mode != PACOH_MEAN_ZERO && !a.mean) return PACOH_EINVAL;
     const int FP = a.f <= 2 ? 2 : (a.f <= 4 ? 4 : (a.f <= 8 ? 8 : 16));
@@ -394,6 +396,7 @@ static bool mfma_enabled() {
     return on;
 }
 static int try_mfma(const GpArgs<float>& a, bool bwd, hipStream_t s) {
+    if (a.kind != PACOH_KERNEL_RBF) return 1;                  // (the register- / LDS-resident MFMA kernels evaluate the RBF family only)
     if (!mfma_enabled() || a.n > 128 || a.B <= 0 || a.P <= 0 || a.f <= 0 || a.f > PACOH_MAX_FEATURES ||
         a.z_div <= 0 || a.y_div <= 0 || !a.z || !a.y || !a.ls || !a.noise || (a.mean_mode != PACOH_MEAN_ZERO && !a.mean))
         return 1;
@@ -417,7 +420,7 @@ static GpArgs<T> make_args(const void* z, int z_div, const void* mean, int mean_
     GpArgs<T> a = {};
     a.z = (const T*)z; a.z_div = z_div; a.mean = (const T*)mean; a.mean_mode = mean_mode;
     a.y = (const T*)y; a.y_div = y_div; a.ls = (const T*)ls; a.os = (const T*)os; a.noise = (const T*)noise;
-    a.n_valid = n_valid; a.B = B; a.P = P; a.n = n; a.f = f;
+    a.n_valid = n_valid; a.B = B; a.P = P; a.n = n; a.f = features_of(f); a.kind = kernel_of(f);
     return a;
 }
 
@@ -485,7 +488,7 @@ extern "C" int pacoh_gp_predict(const void* z_ctx, int z_div, const void* mean_c
             hipLaunchKernelGGL(gp_predict_cov_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                                (hipStream_t)stream, (const float*)z_tst, zt_div, (const float*)workspace,
                                (const float*)lengthscale, (const float*)outputscale, (const float*)noise,
-                               (float*)cov, B, P, n, m, f);
+                               (float*)cov, B, P, n, m, features_of(f), kernel_of(f));
             rc = launch_status();
         }
         return rc;
@@ -499,7 +502,7 @@ extern "C" int pacoh_gp_predict(const void* z_ctx, int z_div, const void* mean_c
         hipLaunchKernelGGL(gp_predict_cov_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                            (hipStream_t)stream, (const double*)z_tst, zt_div, (const double*)workspace,
                            (const double*)lengthscale, (const double*)outputscale, (const double*)noise,
-                           (double*)cov, B, P, n, m, f);
+                           (double*)cov, B, P, n, m, features_of(f), kernel_of(f));
         rc = launch_status();
     }
     return rc;

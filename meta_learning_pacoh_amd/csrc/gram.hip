@@ -215,15 +215,50 @@ static int launch_gram(const void* z1, int z1_div, const void* z2, int z2_div, c
 
 using namespace pacoh;
 
+// Any kernel family (common.h: kern_eval), one thread per entry: the families other than ARD-RBF are capability, not hot path
+namespace pacoh {
+template <typename T>
+__global__ void __launch_bounds__(256) gram_family_kernel(const T* __restrict__ z1, int z1_div, const T* __restrict__ z2, int z2_div,
+                                                          const T* __restrict__ ls, const T* __restrict__ os, const T* __restrict__ noise,
+                                                          int add_noise, T* __restrict__ K, int B, int P, int n, int m, int f, int kind) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * n * m) return;
+    const int j = (int)(idx % m), i = (int)((idx / m) % n);
+    const long b = idx / ((long)n * m);
+    const int p = (int)(b % P);
+    const T* a = z1 + ((b / z1_div) * n + i) * (long)f;
+    const T* c2 = z2 + ((b / z2_div) * m + j) * (long)f;
+    T s = 0;
+    for (int c = 0; c < f; ++c) { const T d = a[c] / ls[(long)p * f + c] - c2[c] / ls[(long)p * f + c]; s = fma(d, d, s); }
+    T k = (os ? os[p] : T(1)) * kern_val<T>(kind, s);
+    if (add_noise && i == j) k += noise[p];
+    K[idx] = k;
+}
+}  // namespace pacoh
+
 extern "C" int pacoh_gram_rbf_ard(const void* z1, int z1_div, const void* z2, int z2_div,
                                   const void* lengthscale, const void* outputscale, const void* noise,
                                   int add_noise_diag, void* K,
                                   int B, int P, int n, int m, int f, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
+    const int kind = kernel_of(f);
+    f = features_of(f);
     if (!z1 || !z2 || !lengthscale || !K || B <= 0 || P <= 0 || n <= 0 || m <= 0 || f <= 0 || z1_div <= 0 || z2_div <= 0)
         return PACOH_EINVAL;
     if (add_noise_diag && !noise) return PACOH_EINVAL;
-    if (f > PACOH_MAX_FEATURES) return PACOH_ELIMIT;
+    if (f > PACOH_MAX_FEATURES || kind < 0 || kind > PACOH_KERNEL_COSINE) return PACOH_ELIMIT;
+    if (kind != PACOH_KERNEL_RBF) {
+        const long total = (long)B * n * m;
+        if (dtype == PACOH_F32)
+            hipLaunchKernelGGL(gram_family_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)z1,
+                               z1_div, (const float*)z2, z2_div, (const float*)lengthscale, (const float*)outputscale, (const float*)noise,
+                               add_noise_diag, (float*)K, B, P, n, m, f, kind);
+        else
+            hipLaunchKernelGGL(gram_family_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const double*)z1,
+                               z1_div, (const double*)z2, z2_div, (const double*)lengthscale, (const double*)outputscale, (const double*)noise,
+                               add_noise_diag, (double*)K, B, P, n, m, f, kind);
+        return launch_status();
+    }
     if (dtype == PACOH_F32)
         return launch_gram<float>(z1, z1_div, z2, z2_div, lengthscale, outputscale, noise, add_noise_diag, K, B, P, n, m, f, (hipStream_t)stream);
     return launch_gram<double>(z1, z1_div, z2, z2_div, lengthscale, outputscale, noise, add_noise_diag, K, B, P, n, m, f, (hipStream_t)stream);

@@ -14,6 +14,8 @@ struct HyperBwdArgs {
     T* grad; long gstride;
     const T* lml; T* lik; T lik_scale;
     const int32_t* info; int32_t* fail_flag;
+    int tie;                  // kernel families with ONE raw scale for all f dimensions (PACOH_KERNEL_COSINE): grad[off_ls] takes the
+                              // sum over the f per-dimension gradients, the entries behind it do not exist
 };
 
 template <typename T> __device__ __forceinline__ T hyper_sigmoid(T x) { return x > T(20) ? T(1) : T(1) / (T(1) + t_exp<T>(-x)); }
@@ -32,14 +34,19 @@ __device__ __forceinline__ void hyper_bwd_block(const HyperBwdArgs<T>& a, int w,
     }
     const int p = w / per, e = w - p * per;
     const T* src; int width, col, off;
-    if (e < a.f) { src = a.d_ls; width = a.f; col = e; off = a.off_ls + e; }
+    int ncol = 1;
+    if (e < a.f) {
+        src = a.d_ls; width = a.f; col = e; off = a.off_ls + e;
+        if (a.tie) { if (e > 0) return; ncol = a.f; }
+    }
     else if (e == a.f) { src = a.d_os; width = 1; col = 0; off = a.off_os; }
     else if (e == a.f + 1) { src = a.d_noise; width = 1; col = 0; off = a.off_noise; }
     else if (e == a.f + 2) { src = a.d_const; width = 1; col = 0; off = a.off_const; }
     else { src = a.lml; width = 1; col = 0; off = 0; }
     if (!src || off < 0) return;
     T s = 0;
-    for (int t = threadIdx.x; t < a.Tt; t += 256) s += src[((long)t * a.P + p) * width + col];
+    for (int t = threadIdx.x; t < a.Tt; t += 256)
+        for (int c = 0; c < ncol; ++c) s += src[((long)t * a.P + p) * width + col + c];
     s = subwave_sum<T>(s, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();

@@ -33,13 +33,13 @@ template <typename T> __device__ __forceinline__ T sigmoid_t(T x) { return x > T
 
 template <typename T>
 __global__ void hyper_fwd_kernel(const T* __restrict__ theta, long stride, int P, int off_ls, int f, int off_os, int off_noise,
-                                 T noise_floor, T* __restrict__ ls, T* __restrict__ os, T* __restrict__ noise) {
+                                 T noise_floor, T* __restrict__ ls, T* __restrict__ os, T* __restrict__ noise, int tie) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int per = f + 2;
     if (q >= P * per) return;
     const int p = q / per, e = q - p * per;
     const T* th = theta + (long)p * stride;
-    if (e < f) ls[p * f + e] = softplus_t<T>(th[off_ls + e]);
+    if (e < f) ls[p * f + e] = softplus_t<T>(th[off_ls + (tie ? 0 : e)]);     // (tie: one raw scale shared by all f dimensions)
     else if (e == f) { if (os && off_os >= 0) os[p] = softplus_t<T>(th[off_os]); }
     else noise[p] = softplus_t<T>(th[off_noise]) + noise_floor;
 }
@@ -583,6 +583,7 @@ struct StepBeginArgs {
     const T* theta; long stride; int P, off_ls, f, off_os, off_noise; T noise_floor; T* ls; T* os; T* noise;
     int aux_blocks;                                  // blocks [tb+2, tb+2+aux_blocks) copy the auxiliary payload
     const T* sv_X; T* sv_d2; T* sv_snap; int sv_P, sv_D;         // blocks behind them: SVGD pairwise distances + particle snapshot
+    int tie;                                         // one raw scale for all f dimensions (kernel families other than ARD-RBF)
 };
 
 template <typename T>
@@ -606,7 +607,7 @@ __global__ void __launch_bounds__(256) step_begin_kernel(StepBeginArgs<T> a) {
             for (int q = threadIdx.x; q < a.P * per; q += 256) {
                 const int p = q / per, e = q - p * per;
                 const T* th = a.theta + (long)p * a.stride;
-                if (e < a.f) a.ls[p * a.f + e] = softplus_t<T>(th[a.off_ls + e]);
+                if (e < a.f) a.ls[p * a.f + e] = softplus_t<T>(th[a.off_ls + (a.tie ? 0 : e)]);
                 else if (e == a.f) { if (a.os && a.off_os >= 0) a.os[p] = softplus_t<T>(th[a.off_os]); }
                 else a.noise[p] = softplus_t<T>(th[a.off_noise]) + a.noise_floor;
             }
@@ -660,8 +661,9 @@ static int step_begin_launch(const int64_t* idx_all, int tb, const void* sc_all,
     T* d2 = (T*)svgd_workspace;                       // (layout of pacoh_svgd_update_dev_workspace_bytes: distances | snapshot | median pair)
     StepBeginArgs<T> a = {(const long*)idx_all, tb, (const T*)sc_all, n_sc, (const T*)aux_all, n_aux, (long*)counter, ticket, (T*)sc_out,
                           (T*)aux_out, (const T*)x, (const T*)y, n_valid, (T*)out_x, (T*)out_y, out_n_valid, n * d, n, (const T*)theta,
-                          theta_stride, P, off_ls, f, off_os, off_noise, (T)noise_floor, (T*)ls, (T*)os, (T*)noise,
-                          (int)ab, (const T*)svgd_X, d2, svgd_X ? d2 + svgd_P * svgd_P : nullptr, svgd_P, svgd_D};
+                          theta_stride, P, off_ls, features_of(f), off_os, off_noise, (T)noise_floor, (T*)ls, (T*)os, (T*)noise,
+                          (int)ab, (const T*)svgd_X, d2, svgd_X ? d2 + svgd_P * svgd_P : nullptr, svgd_P, svgd_D,
+                          kernel_of(f) != PACOH_KERNEL_RBF};
     const long sb = svgd_X ? (long)svgd_P * svgd_P : 0;
     hipLaunchKernelGGL(step_begin_kernel<T>, dim3((unsigned)(tb + 2 + ab + sb)), dim3(256), 0, s, a);
     if (advance) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, (long*)counter);
@@ -678,7 +680,7 @@ extern "C" int pacoh_step_begin(const int64_t* idx_all, int tb, const void* sc_a
     if (!counter || !ticket || tb < 0 || n_sc < 0 || n_aux < 0 || (n_sc > 0 && (!sc_all || !sc_out)) || (n_aux > 0 && (!aux_all || !aux_out)))
         return PACOH_EINVAL;
     if (tb > 0 && (!idx_all || !x || !y || !out_x || !out_y || n <= 0 || d <= 0 || (n_valid == nullptr) != (out_n_valid == nullptr))) return PACOH_EINVAL;
-    if (theta && (!ls || !noise || P <= 0 || f <= 0)) return PACOH_EINVAL;
+    if (theta && (!ls || !noise || P <= 0 || features_of(f) <= 0)) return PACOH_EINVAL;
     if (svgd_X && (!svgd_workspace || svgd_P <= 0 || svgd_D <= 0)) return PACOH_EINVAL;
     if (svgd_X && svgd_P > PACOH_SVGD_MAX_PARTICLES) return PACOH_ELIMIT;
     if (dtype == PACOH_F32)
@@ -718,14 +720,16 @@ extern "C" int pacoh_abi_version(void) { return 4; }
 extern "C" int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise,
                                double noise_floor, void* ls, void* os, void* noise, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
+    const int tie = kernel_of(f) != PACOH_KERNEL_RBF;
+    f = features_of(f);
     if (!theta || !ls || !noise || P <= 0 || f <= 0 || off_ls < 0 || off_noise < 0) return PACOH_EINVAL;
     unsigned blocks = (unsigned)((P * (f + 2) + 255) / 256);
     if (dtype == PACOH_F32)
         hipLaunchKernelGGL(hyper_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)theta, theta_stride,
-                           P, off_ls, f, off_os, off_noise, (float)noise_floor, (float*)ls, (float*)os, (float*)noise);
+                           P, off_ls, f, off_os, off_noise, (float)noise_floor, (float*)ls, (float*)os, (float*)noise, tie);
     else
         hipLaunchKernelGGL(hyper_fwd_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)theta, theta_stride,
-                           P, off_ls, f, off_os, off_noise, noise_floor, (double*)ls, (double*)os, (double*)noise);
+                           P, off_ls, f, off_os, off_noise, noise_floor, (double*)ls, (double*)os, (double*)noise, tie);
     return launch_status();
 }
 
@@ -734,18 +738,20 @@ extern "C" int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int 
                                void* grad, long grad_stride, const void* lml, void* lik, double lik_scale,
                                const int32_t* info, int32_t* fail_flag, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
+    const int tie = kernel_of(f) != PACOH_KERNEL_RBF;
+    f = features_of(f);
     if (!theta || !grad || !d_ls || !d_noise || P <= 0 || T_ <= 0 || f <= 0) return PACOH_EINVAL;
     if ((lml == nullptr) != (lik == nullptr)) return PACOH_EINVAL;
     unsigned blocks = (unsigned)(P * (f + 4));
     if (dtype == PACOH_F32) {
         HyperBwdArgs<float> a = {(const float*)theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, (const float*)d_ls,
                                  (const float*)d_os, (const float*)d_noise, (const float*)d_const, (float*)grad, grad_stride,
-                                 (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag};
+                                 (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag, tie};
         hipLaunchKernelGGL(hyper_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     } else {
         HyperBwdArgs<double> a = {(const double*)theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, (const double*)d_ls,
                                   (const double*)d_os, (const double*)d_noise, (const double*)d_const, (double*)grad, grad_stride,
-                                  (const double*)lml, (double*)lik, lik_scale, info, fail_flag};
+                                  (const double*)lml, (double*)lik, lik_scale, info, fail_flag, tie};
         hipLaunchKernelGGL(hyper_bwd_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     }
     return launch_status();

@@ -269,14 +269,15 @@ extern "C" int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta,
                                     int T_, int off_ls, int f, int off_os, int off_noise, int off_const, const void* d_ls,
                                     const void* d_os, const void* d_noise, const void* d_const, const void* lml, void* lik,
                                     double lik_scale, const int32_t* info, int32_t* fail_flag, int dtype, void* stream) {
-    if (!d_ls || !d_noise || T_ <= 0 || f <= 0 || (lml == nullptr) != (lik == nullptr)) return PACOH_EINVAL;
+    if (!d_ls || !d_noise || T_ <= 0 || features_of(f) <= 0 || (lml == nullptr) != (lik == nullptr)) return PACOH_EINVAL;
     if (accumulate) return PACOH_EINVAL;              // (the tail writes its columns of d_theta; the blocks of the two networks are overwritten)
     bool tail_done = false;
     int rc;
     if (dtype == PACOH_F32) {
-        HyperBwdArgs<float> tail = {(const float*)theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, (const float*)d_ls,
-                                    (const float*)d_os, (const float*)d_noise, (const float*)d_const, (float*)d_theta, d_theta_stride,
-                                    (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag};
+        HyperBwdArgs<float> tail = {(const float*)theta, theta_stride, P, T_, off_ls, features_of(f), off_os, off_noise, off_const,
+                                    (const float*)d_ls, (const float*)d_os, (const float*)d_noise, (const float*)d_const, (float*)d_theta,
+                                    d_theta_stride, (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag,
+                                    kernel_of(f) != PACOH_KERNEL_RBF};
         rc = mlp2_bwd_impl(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, off_a, d_out_a, g_a, off_b, d_out_b, g_b, d_theta,
                            d_theta_stride, accumulate, workspace, stash, B, n, dtype, stream, &tail, &tail_done);
     } else {

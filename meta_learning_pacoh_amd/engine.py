@@ -36,8 +36,11 @@ class ParamLayout:
 
     def __init__(self, input_dim, mean_module='NN', covar_module='NN', mean_nn_layers=(32, 32),
                  kernel_nn_layers=(32, 32), feature_dim=2, with_outputscale=False):
-        assert mean_module in ('NN', 'constant', 'zero') and covar_module in ('NN', 'SE')
+        # 'COS': gpytorch.kernels.CosineKernel on the raw inputs (module objects only, modules.py) -- ONE raw period parameter, kept
+        # in the lengthscale slot; the device sees it replicated over the input dimensions (PACOH_KERNEL_COSINE in pacoh_gp.h)
+        assert mean_module in ('NN', 'constant', 'zero') and covar_module in ('NN', 'SE', 'COS')
         self.input_dim, self.mean_module, self.covar_module = input_dim, mean_module, covar_module
+        self.kernel_code = L.KERNEL_COSINE if covar_module == 'COS' else L.KERNEL_RBF
         self.mean_nn_layers, self.kernel_nn_layers = tuple(mean_nn_layers), tuple(kernel_nn_layers)
         self.feature_dim = feature_dim if covar_module == 'NN' else input_dim
         self.with_outputscale = with_outputscale
@@ -50,7 +53,7 @@ class ParamLayout:
         if covar_module == 'NN':
             for k, v in nn_param_layout(input_dim, feature_dim, kernel_nn_layers).items():
                 blocks['kernel_nn.' + k] = v
-        blocks['lengthscale_raw'] = self.feature_dim
+        blocks['lengthscale_raw'] = 1 if covar_module == 'COS' else self.feature_dim
         if with_outputscale:
             blocks['outputscale_raw'] = 1
         blocks['noise_raw'] = 1
@@ -217,7 +220,7 @@ class StepFeed:
             ls = torch.empty(P, f, dtype=theta.dtype, device=theta.device)
             os_ = torch.empty(P, dtype=theta.dtype, device=theta.device) if off_os >= 0 else None
             noise = torch.empty(P, dtype=theta.dtype, device=theta.device)
-            hyper, hyper_out = (off_ls, f, off_os, off_noise, engine.noise_floor), (ls, os_, noise)
+            hyper, hyper_out = (off_ls, f, off_os, off_noise, engine.noise_floor, engine.layout.kernel_code), (ls, os_, noise)
             hyp = hyper_out
         L.step_begin(self, tasks, out, theta if hyp is not None else None, hyper, hyper_out, advance=advance, svgd=svgd)
         return batch, hyp
@@ -376,7 +379,7 @@ class GPEngine:
 
     def _hypers(self, theta):
         off_ls, f, off_os, off_noise, _ = self._hyper_offsets()
-        return L.hyper_fwd(theta, off_ls, f, off_os, off_noise, self.noise_floor)
+        return L.hyper_fwd(theta, off_ls, f, off_os, off_noise, self.noise_floor, kernel=self.layout.kernel_code)
 
     def _paired_nets(self):
         """both networks present with the same hidden shape -> (mean block offset, kernel block offset), else None"""
@@ -430,7 +433,7 @@ class GPEngine:
         ls, os_, noise = self._hypers(theta)
         z, z_div, mean, mode = self._features(theta, batch.x, T, n)
         lml, _, _, info = L.gp_lml_fwd(z, z_div, mean, mode, batch.y, P, ls, os_, noise, T * P, P,
-                                       n_valid=batch.n_valid if batch.ragged else None)
+                                       n_valid=batch.n_valid if batch.ragged else None, kernel=self.layout.kernel_code)
         return lml.reshape(T, P), info
 
     def lml_and_grad(self, theta, batch, weight=1.0, lik_out=None, lik_scale=1.0, grad_out=None, fail_flag=None, hypers=None):
@@ -456,7 +459,7 @@ class GPEngine:
             g = ent[0]
         lml, d_z, d_mean, d_ls, d_os, d_noise, info = L.gp_lml_fwdbwd(
             z, z_div, mean, mode, batch.y, P, ls, os_, noise, B, P,
-            n_valid=batch.n_valid if batch.ragged else None, g_lml=g, want_dz=(lay.covar_module == 'NN'))
+            n_valid=batch.n_valid if batch.ragged else None, g_lml=g, want_dz=(lay.covar_module == 'NN'), kernel=lay.kernel_code)
         grad = grad_out if grad_out is not None else torch.empty(P, D, dtype=dt, device=dev)   # every block is written below
         pair = self._paired_nets()
         off_ls, f, off_os, off_noise, off_c = self._hyper_offsets()
@@ -480,7 +483,7 @@ class GPEngine:
                                       d_mean.reshape(B, n, 1), grad[:, lo:], D, False, B, n, self._ws.get('m'))
         # hyper-parameters (+ constant mean): sum over tasks and softplus chain rule in one launch
         L.hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_c, d_ls, d_os, d_noise,
-                    d_mean if lay.mean_module == 'constant' else None, grad, **hyper)
+                    d_mean if lay.mean_module == 'constant' else None, grad, kernel=lay.kernel_code, **hyper)
         return lml.reshape(T, P), grad, info
 
     def predict(self, theta, ctx_x, ctx_y, tst_x, want_cov=False):
@@ -499,4 +502,5 @@ class GPEngine:
         ls, os_, noise = self._hypers(theta)
         zc, zc_div, mc, mode = self._features(theta, ctx_x.contiguous(), T, n, theta_per_task)
         zt, zt_div, mt, _ = self._features(theta, tst_x.contiguous(), T, m, theta_per_task)
-        return L.gp_predict(zc, zc_div, mc, mode, ctx_y.contiguous(), P, zt, zt_div, mt, ls, os_, noise, T * P, rows, want_cov=want_cov)
+        return L.gp_predict(zc, zc_div, mc, mode, ctx_y.contiguous(), P, zt, zt_div, mt, ls, os_, noise, T * P, rows, want_cov=want_cov,
+                            kernel=self.layout.kernel_code)

@@ -234,6 +234,19 @@ def gram_rbf_ard(z1, z2, lengthscale, outputscale=1.0):
     return outputscale * torch.exp(-0.5 * sq_dist_scaled(z1, z2, lengthscale))
 
 
+def gram_cosine(z1, z2, period, outputscale=1.0):
+    """gpytorch.kernels.CosineKernel [gpytorch-upstream; absent here, restated from its documented definition]:
+    K_ij = os * cos(pi * |z_i - z_j| / period_length) -- the kernel object the reference's own suite hands to the single-task
+    learner (tests/test_GPR.py:95-101; GPR_mll.py:41 accepts any gpytorch.kernels.Kernel).  `period` broadcasts like a
+    lengthscale ([...,1,1] or [...,1,f] with equal entries)."""
+    d2 = sq_dist_scaled(z1, z2, period)
+    return outputscale * torch.cos(math.pi * torch.sqrt(d2.clamp_min(1e-30)))
+
+
+def gram_family(z1, z2, lengthscale, outputscale=1.0, kernel='rbf'):
+    return gram_cosine(z1, z2, lengthscale, outputscale) if kernel == 'cos' else gram_rbf_ard(z1, z2, lengthscale, outputscale)
+
+
 def _as_batched(v, like):
     v = torch.as_tensor(v, dtype=like.dtype)
     return v
@@ -254,7 +267,7 @@ def psd_safe_cholesky(A):
     raise RuntimeError('matrix not positive definite after jitter')
 
 
-def gp_mll(z, mean, y, lengthscale, outputscale, noise):
+def gp_mll(z, mean, y, lengthscale, outputscale, noise, kernel='rbf'):
     """A5+A6: per-datapoint exact log marginal likelihood
     (gpytorch.mlls.ExactMarginalLogLikelihood, call sites GPR_meta_mll.py:72,111-113 and
     random_gp.py:83-85):  MVN(mean, K + noise*I).log_prob(y) / n.
@@ -262,7 +275,7 @@ def gp_mll(z, mean, y, lengthscale, outputscale, noise):
     z [...,n,f]; mean,y [...,n]; lengthscale [...,1,f]; outputscale,noise [...] or scalars.
     Returns [...]."""
     n = z.shape[-2]
-    K = gram_rbf_ard(z, z, lengthscale, 1.0)
+    K = gram_family(z, z, lengthscale, 1.0, kernel)
     os_ = torch.as_tensor(outputscale, dtype=z.dtype)
     nz = torch.as_tensor(noise, dtype=z.dtype)
     if os_.ndim > 0:
@@ -540,7 +553,7 @@ def vi_full_grad(tril_cov, eps, score, prior_factor):
 # A11  posterior predictive + eval metrics
 # --------------------------------------------------------------------------------------
 
-def gp_predict(z_ctx, m_ctx, y_ctx, z_tst, m_tst, lengthscale, outputscale, noise):
+def gp_predict(z_ctx, m_ctx, y_ctx, z_tst, m_tst, lengthscale, outputscale, noise, kernel='rbf'):
     """Exact GP posterior predictive incl. observation noise (eval-mode ExactGP +
     likelihood [gpytorch-upstream]; call sites GPR_meta_mll.py:174-181, GPR_meta_svgd.py:203-212):
       mu* = m* + K*x (Kxx + s2 I)^-1 (y - mx);  S* = K** - K*x (Kxx + s2 I)^-1 Kx* + s2 I.
@@ -552,9 +565,9 @@ def gp_predict(z_ctx, m_ctx, y_ctx, z_tst, m_tst, lengthscale, outputscale, nois
         os_ = os_.reshape(os_.shape + (1, 1))
     if nz.ndim > 0:
         nz = nz.reshape(nz.shape + (1, 1))
-    Kxx = os_ * gram_rbf_ard(z_ctx, z_ctx, lengthscale) + nz * torch.eye(n, dtype=z_ctx.dtype)
-    Kxs = os_ * gram_rbf_ard(z_ctx, z_tst, lengthscale)
-    Kss = os_ * gram_rbf_ard(z_tst, z_tst, lengthscale)
+    Kxx = os_ * gram_family(z_ctx, z_ctx, lengthscale, 1.0, kernel) + nz * torch.eye(n, dtype=z_ctx.dtype)
+    Kxs = os_ * gram_family(z_ctx, z_tst, lengthscale, 1.0, kernel)
+    Kss = os_ * gram_family(z_tst, z_tst, lengthscale, 1.0, kernel)
     L = psd_safe_cholesky(Kxx)
     alpha = torch.cholesky_solve((y_ctx - m_ctx).unsqueeze(-1), L)
     mean = m_tst + (Kxs.transpose(-1, -2) @ alpha).squeeze(-1)
@@ -682,7 +695,8 @@ class MapOracle:
             for m in self.kernel_net: params += [m.weight, m.bias]
             ls_dim = feature_dim
         else:
-            self.kernel_net, ls_dim = None, self.input_dim
+            self.kernel_net, ls_dim = None, (1 if covar_module == 'COS' else self.input_dim)     # COS: one period_length
+        self.kernel = 'cos' if covar_module == 'COS' else 'rbf'
         if mean_module == 'NN':
             self.mean_net = make_net(1, mean_nn_layers)
             for m in self.mean_net: params += [m.weight, m.bias]
@@ -725,7 +739,7 @@ class MapOracle:
     def task_mll(self, x, y):
         z, m = self.features(x)
         ls, os_, noise = self.hypers()
-        return gp_mll(z, m, y, ls, os_, noise)
+        return gp_mll(z, m, y, ls, os_, noise, kernel=self.kernel)
 
     # ---- training loop ------------------------------------------------------------
     def meta_fit(self, valid_tuples=None, log_period=500, n_iter=None, log_fn=None):
@@ -760,7 +774,7 @@ class MapOracle:
             zc, mc = self.features(cx)
             zt, mt = self.features(tx)
             ls, os_, noise = self.hypers()
-            return gp_predict(zc, mc, cy, zt, mt, ls, os_, noise)
+            return gp_predict(zc, mc, cy, zt, mt, ls, os_, noise, kernel=self.kernel)
 
     def eval(self, cx, cy, tx, ty):
         mean, cov = self.predict_normalized(cx, cy, tx)

@@ -808,3 +808,73 @@ def test_launch_stream_follows_torch_current_stream(L):
     side.synchronize()
     assert float(y.sum()) == 2000.0
     assert (L._stream().value or 0) == torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------------------ kernel families (round 3)
+def _cos_problem(T, P, n, f, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    B = T * P
+    z = torch.randn(B, n, f, generator=g, dtype=torch.float64)
+    mean = 0.3 * torch.randn(B, n, generator=g, dtype=torch.float64)
+    y = torch.randn(T, n, generator=g, dtype=torch.float64)
+    ls = torch.rand(P, f, generator=g, dtype=torch.float64) + 0.8          # period lengths (per dimension: the device allows ARD)
+    # cos(pi |x - x'| / p) is positive semi-definite in one dimension only: beyond it the noise has to carry the matrix
+    # (|lambda_min(os K)| <= os n: with os <= 0.05 and n <= 33 below 1.65 < noise)
+    os_ = (0.2 + 0.3 * torch.rand(P, generator=g, dtype=torch.float64)) * (1.0 if f == 1 else 0.1)
+    noise = (0.2 if f == 1 else 2.0) + torch.rand(P, generator=g, dtype=torch.float64)
+    return [t.to(dtype) for t in (z, mean, y, ls, os_, noise)]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('case', [(2, 2, 20, 1, False), (1, 3, 33, 3, False), (2, 1, 150, 1, False), (1, 2, 24, 2, True)])
+def test_cosine_kernel_family_gram_lml_gradients_predict(L, dtype, case):
+    """PACOH_KERNEL_COSINE (gpytorch.kernels.CosineKernel: the kernel object of the reference's tests/test_GPR.py:95-101) through
+    the C ABI -- the family rides in the high bits of the `f` argument: Gram, LML, every gradient and the posterior predictive vs the
+    oracle's torch restatement and its autograd, on the LDS-resident general kernel (n <= 128) and the HBM-resident path (n = 150 or
+    forced)"""
+    T, P, n, f, force_dense = case
+    B = T * P
+    z, mean, y, ls, os_, noise = _cos_problem(T, P, n, f, dtype, seed=11 * n + f)
+    K = L.gram_rbf_ard(z.to(DEV), 1, z.to(DEV), 1, ls.to(DEV), os_.to(DEV), noise.to(DEV), True, B, P, kernel=L.KERNEL_COSINE)
+    lsb = ls.unsqueeze(0).expand(T, P, f).reshape(B, 1, f).double()
+    osb = os_.unsqueeze(0).expand(T, P).reshape(B).double()
+    nb = noise.unsqueeze(0).expand(T, P).reshape(B).double()
+    Kref = osb.reshape(B, 1, 1) * O.gram_cosine(z.double(), z.double(), lsb) + nb.reshape(B, 1, 1) * torch.eye(n, dtype=torch.float64)
+    assert relerr(K, Kref) < (2e-6 if dtype == torch.float32 else 1e-13)
+    gl = torch.rand(B, dtype=dtype) + 0.5
+    leaves = [t.double().clone().requires_grad_(True) for t in (z, mean, ls, os_, noise)]
+    yy = y.unsqueeze(1).expand(T, P, n).reshape(B, n).double()
+    ref = O.gp_mll(leaves[0], leaves[1], yy, leaves[2].unsqueeze(0).expand(T, P, f).reshape(B, 1, f),
+                   leaves[3].unsqueeze(0).expand(T, P).reshape(B), leaves[4].unsqueeze(0).expand(T, P).reshape(B), kernel='cos')
+    (ref * gl.double()).sum().backward()
+    old = L.FORCE_DENSE
+    L.FORCE_DENSE = force_dense
+    try:
+        out = L.gp_lml_fwdbwd(z.to(DEV), 1, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, ls.to(DEV), os_.to(DEV), noise.to(DEV), B, P,
+                              g_lml=gl.to(DEV), kernel=L.KERNEL_COSINE)
+        lml_f, _, _, info_f = L.gp_lml_fwd(z.to(DEV), 1, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, ls.to(DEV), os_.to(DEV), noise.to(DEV),
+                                           B, P, kernel=L.KERNEL_COSINE)
+        g = torch.Generator().manual_seed(5)
+        m = 9
+        zt = torch.randn(B, m, f, generator=g, dtype=dtype)
+        mt = 0.2 * torch.randn(B, m, generator=g, dtype=dtype)
+        mu, var, cov, info_p = L.gp_predict(z.to(DEV), 1, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, zt.to(DEV), 1, mt.to(DEV), ls.to(DEV),
+                                            os_.to(DEV), noise.to(DEV), B, P, want_cov=True, kernel=L.KERNEL_COSINE)
+    finally:
+        L.FORCE_DENSE = old
+    lml, d_z, d_mean, d_ls, d_os, d_noise, info = out
+    assert int(info.abs().max()) == 0 and int(info_f.abs().max()) == 0 and int(info_p.abs().max()) == 0
+    t_l, t_g = (2e-4, 5e-3) if dtype == torch.float32 else (1e-10, 1e-8)
+    assert maxrel(lml, ref) < t_l and maxrel(lml_f, ref) < t_l
+    assert relerr(d_z, leaves[0].grad * 1.0) < t_g
+    assert relerr(d_mean, leaves[1].grad) < t_g
+    assert relerr(d_ls.reshape(T, P, f).sum(0), leaves[2].grad) < t_g
+    assert relerr(d_os.reshape(T, P).sum(0), leaves[3].grad) < t_g
+    assert relerr(d_noise.reshape(T, P).sum(0), leaves[4].grad) < t_g
+    rm, rc = O.gp_predict(z.double(), mean.double(), yy, zt.double(), mt.double(), lsb, osb, nb, kernel='cos')
+    tol = 5e-3 if dtype == torch.float32 else 1e-9
+    assert relerr(mu, rm) < tol and relerr(var, torch.diagonal(rc, dim1=-2, dim2=-1)) < tol and relerr(cov, rc) < tol
+    # an unknown family is refused before anything is launched
+    lib = L.load_library()
+    assert lib.pacoh_gram_rbf_ard(z.to(DEV).data_ptr(), 1, z.to(DEV).data_ptr(), 1, ls.to(DEV).data_ptr(), None, None, 0, K.data_ptr(), B, P,
+                                  n, n, f | (2 << L.KERNEL_SHIFT), L.dtype_code(K), None) == -2

@@ -696,7 +696,7 @@ def test_module_objects_run_like_their_string_options(M):
         def __init__(self, base, raw=0.0):
             self.base_kernel, self.raw_outputscale = base, torch.nn.Parameter(torch.tensor(raw))
 
-    class CosineKernel:
+    class MaternKernel:
         pass
 
     tasks = O.sinusoid_tasks_nd(8, 12, 2, seed0=70)
@@ -712,7 +712,83 @@ def test_module_objects_run_like_their_string_options(M):
     assert abs(float(c.theta[0, lay.slices['outputscale_raw'][0]]) + 0.2) < 1e-7
     assert torch.allclose(c.theta[0, lay.slices['lengthscale_raw'][0]:lay.slices['lengthscale_raw'][1]].cpu(), torch.full((2,), 0.5))
     with pytest.raises(NotImplementedError):
-        M.GPRegressionMetaLearned(tasks, mean_module='constant', covar_module=CosineKernel())
+        M.GPRegressionMetaLearned(tasks, mean_module='constant', covar_module=MaternKernel())
+
+
+class _CosineKernel:
+    """stand-in for gpytorch.kernels.CosineKernel (recognised by class name, modules.py): one raw period_length, softplus-constrained"""
+
+    def __init__(self, raw=0.0):
+        self.raw_period_length = torch.nn.Parameter(torch.full((1, 1), raw))
+
+
+_CosineKernel.__name__ = 'CosineKernel'
+
+
+def test_cosine_kernel_object_single_task_learner_matches_oracle_and_learns(M):
+    """the reference's tests/test_GPR.py:95-120 (test_kernel_learning_COS): GPRegressionLearned(covar_module=CosineKernel()) -- (a) the
+    first iterations against the oracle's restatement with the same kernel, (b) the behaviour the reference asserts: learning the
+    period beats the vanilla model on sinusoidal targets"""
+    rs = np.random.RandomState(22)
+    x = rs.uniform(-2, 2, size=(40, 1))
+    y = np.sin(3.0 * x) + 0.05 * rs.randn(40, 1)
+    kw = dict(mean_module='constant', num_iter_fit=1)
+    m = M.GPRegressionLearned(x, y, learning_mode='learn_kernel', covar_module=_CosineKernel(), lr=1e-2, random_seed=4, **kw)
+    o = O.SingleTaskOracle(x, y, learning_mode='learn_kernel', covar_module='COS', lr=1e-2, random_seed=4, dtype=torch.float64, **kw)
+    assert m.layout.D == 4 and m.layout.blocks['lengthscale_raw'] == 1              # constant | period | outputscale | noise
+    # a plain CosineKernel has no learnable output scale: pin the oracle's at softplus^-1(1) and keep it out of the comparison
+    with torch.no_grad():
+        o.raw_outputscale.fill_(float(np.log(np.e - 1.0)))
+    o.raw_outputscale.requires_grad_(False)
+    losses = []
+    for _ in range(6):
+        losses.append(m.fit(verbose=False, n_iter=1))
+    ref = [rec[1] for rec in o.fit(n_iter=6, log_period=1)]
+    assert abs(losses[0] - ref[0]) < 2e-4 * max(1.0, abs(ref[0]))
+    lo = m.layout.slices['lengthscale_raw'][0]
+    assert abs(float(m.theta[0, lo]) - float(o.raw_lengthscale.reshape(-1)[0])) < 2e-3          # six AdamW steps of 1e-2 each
+    # (b) tests/test_GPR.py:95-120
+    vanilla = M.GPRegressionLearned(x, y, learning_mode='vanilla', num_iter_fit=1, mean_module='constant', covar_module=_CosineKernel(),
+                                    random_seed=4)
+    vanilla.fit(verbose=False)
+    learned = M.GPRegressionLearned(x, y, learning_mode='learn_kernel', num_iter_fit=500, mean_module='constant',
+                                    covar_module=_CosineKernel(), random_seed=4)
+    learned.fit(valid_x=x, valid_t=y, verbose=False)
+    ll_v, rmse_v, _ = vanilla.eval(x, y)
+    ll_k, rmse_k, _ = learned.eval(x, y)
+    assert ll_k > ll_v and rmse_k < rmse_v
+
+
+def test_cosine_kernel_object_meta_learner_ties_the_period_over_input_dimensions(M):
+    """GPRegressionMetaLearned(covar_module=ScaleKernel(CosineKernel())) on 2-d inputs: ONE period parameter, the device sees it
+    replicated over both dimensions and hands back their summed gradient; first iterations vs the oracle, graph replay included"""
+    class ScaleKernel:
+        def __init__(self, base, raw=0.0):
+            self.base_kernel, self.raw_outputscale = base, torch.nn.Parameter(torch.tensor(raw))
+
+    rs = np.random.RandomState(3)
+    tasks = []
+    for _ in range(6):
+        x = rs.uniform(-1, 1, size=(9, 2))
+        tasks.append((x, np.sin(2 * x[:, :1]) + 0.1 * rs.randn(9, 1)))
+    # (cos(pi |x - x'| / p) is positive semi-definite in one dimension only: in two the output scale is kept small against the noise,
+    #  |lambda_min(os K)| <= os n = 0.44 < 0.69)
+    m = M.GPRegressionMetaLearned(tasks, mean_module='constant', covar_module=ScaleKernel(_CosineKernel(0.3), -3.0), task_batch_size=6,
+                                  lr_params=5e-3, random_seed=2)
+    assert m.layout.blocks['lengthscale_raw'] == 1 and m.layout.feature_dim == 2
+    o = O.MapOracle(tasks, mean_module='constant', covar_module='COS', task_batch_size=6, lr_params=5e-3, random_seed=2, dtype=torch.float64)
+    with torch.no_grad():
+        o.raw_lengthscale.fill_(0.3)
+        o.raw_outputscale.fill_(-3.0)
+    m.meta_fit(verbose=False, n_iter=5)
+    o.meta_fit(n_iter=5)
+    lay = m.layout
+    got = m.theta[0].cpu().double()
+    assert abs(float(got[lay.slices['lengthscale_raw'][0]]) - float(o.raw_lengthscale.reshape(-1)[0])) < 5e-4
+    assert abs(float(got[lay.slices['outputscale_raw'][0]]) - float(o.raw_outputscale)) < 5e-4
+    assert abs(float(got[lay.slices['noise_raw'][0]]) - float(o.raw_noise.reshape(-1)[0])) < 5e-4
+    mean, std = m.predict(*tasks[0], tasks[1][0])
+    assert np.isfinite(mean).all() and (std > 0).all()
 
 
 def test_svgd_with_more_than_64_particles(M, monkeypatch):

@@ -163,6 +163,10 @@ def test_module_objects_are_resolved_by_class_name():
             self.base_kernel, self.raw_outputscale = base, torch.nn.Parameter(torch.tensor(raw))
 
     class CosineKernel(Kernel):
+        def __init__(self, raw=0.0):
+            self.raw_period_length = torch.nn.Parameter(torch.full((1, 1), raw))
+
+    class MaternKernel(Kernel):
         pass
 
     assert resolve_mean_module('NN') == ('NN', {}) and resolve_mean_module(ZeroMean()) == ('zero', {})
@@ -172,8 +176,15 @@ def test_module_objects_are_resolved_by_class_name():
     assert kind == 'SE' and learn and init == {'lengthscale_raw': [0.5, -1.0], 'outputscale_raw': 0.75}
     kind, init, learn = resolve_covar_module(RBFKernel([0.1]))
     assert kind == 'SE' and not learn and abs(np.log1p(np.exp(init['outputscale_raw'])) - 1.0) < 1e-12
+    # the cosine family (round 3; the kernel object of the reference's tests/test_GPR.py:95-101): one raw period in the lengthscale slot
+    kind, init, learn = resolve_covar_module(CosineKernel(0.4))
+    assert kind == 'COS' and not learn and init['lengthscale_raw'] == [pytest.approx(0.4)]
+    kind, init, learn = resolve_covar_module(ScaleKernel(CosineKernel(), -0.5))
+    assert kind == 'COS' and learn and init == {'lengthscale_raw': [0.0], 'outputscale_raw': -0.5}
+    lay_c = ParamLayout(3, 'zero', 'COS', with_outputscale=True)
+    assert lay_c.blocks['lengthscale_raw'] == 1 and lay_c.feature_dim == 3 and lay_c.D == 3 and lay_c.kernel_code == 1
     with pytest.raises(NotImplementedError):
-        resolve_covar_module(CosineKernel())
+        resolve_covar_module(MaternKernel())
     with pytest.raises(NotImplementedError):
         resolve_mean_module(Mean())
     lay = ParamLayout(2, 'constant', 'SE', with_outputscale=True)

@@ -130,3 +130,19 @@ def test_svgd_vi_flavour_restated_independently_with_numpy_and_scipy():
     got = O.meta_log_prob(theta, [(torch.from_numpy(x), torch.from_numpy(y)) for x, y in tasks], cfg, pm, ps, 0.01, loop=True)
     # (the pre-factor is a float32 quantity in the reference and in the oracle: random_gp.py:209-212)
     assert np.abs(got.numpy() - want).max() < 1e-6 * np.abs(want).max()
+
+
+def test_cosine_kernel_restatement_against_numpy():
+    """gpytorch.kernels.CosineKernel restated (k = os cos(pi |x - x'| / p)): plain numpy on the same points, symmetry, unit diagonal,
+    and the LML through scipy"""
+    rs = np.random.RandomState(1)
+    x = rs.randn(9, 1)
+    p, os_, s2 = 0.8, 0.6, 0.3
+    K = O.gram_cosine(torch.from_numpy(x), torch.from_numpy(x), torch.tensor([p], dtype=torch.float64), os_).numpy()
+    want = os_ * np.cos(np.pi * np.abs(x - x.T) / p)
+    assert np.abs(K - want).max() < 1e-12 and np.abs(np.diag(K) - os_).max() < 1e-12
+    y = rs.randn(9)
+    got = float(O.gp_mll(torch.from_numpy(x), torch.zeros(9, dtype=torch.float64), torch.from_numpy(y),
+                         torch.tensor([[p]], dtype=torch.float64), os_, s2, kernel='cos'))
+    ref = scipy.stats.multivariate_normal(np.zeros(9), want + s2 * np.eye(9)).logpdf(y) / 9
+    assert abs(got - ref) < 1e-10 * max(1.0, abs(ref))
