@@ -192,3 +192,29 @@ def test_module_objects_are_resolved_by_class_name():
     apply_initial_values(theta, lay, {'constant_mean': 0.25, 'lengthscale_raw': [0.5, -1.0], 'outputscale_raw': 0.75})
     assert theta[lay.slices['constant_mean'][0]] == 0.25 and theta[lay.slices['outputscale_raw'][0]] == 0.75
     assert theta[lay.slices['lengthscale_raw'][0]:lay.slices['lengthscale_raw'][1]].tolist() == [0.5, -1.0]
+
+
+def test_failed_cholesky_on_another_rank_raises_on_every_rank(monkeypatch):
+    """a rank whose shard hit a non-positive-definite matrix must not raise alone (the others would wait in the next
+    all-reduce).  Its NaN likelihood sums / loss reach every rank through the packed buffer; _check_numerics raises on a rank whose own
+    flag is clean when the reduced values are not finite -- and only in multi-rank runs"""
+    from types import SimpleNamespace
+    from meta_learning_pacoh_amd.engine import NotPSDError
+    from meta_learning_pacoh_amd.GPR_meta_mll import GPRegressionMetaLearned
+    from meta_learning_pacoh_amd.GPR_meta_svgd import _RandomGPLearner
+    clean = lambda: torch.zeros(1, dtype=torch.int32)
+    svgd = SimpleNamespace(_fail=clean(), _lik=torch.tensor([0.3, float('nan')]))
+    mapl = SimpleNamespace(_fail=clean(), _g_loss=torch.tensor([float('nan')]))
+    _RandomGPLearner._check_numerics(svgd)                     # world size 1: the local flag alone decides
+    GPRegressionMetaLearned._check_numerics(mapl)
+    monkeypatch.setattr(parallel, 'world', lambda: (1, 2))
+    with pytest.raises(NotPSDError):
+        _RandomGPLearner._check_numerics(svgd)
+    with pytest.raises(NotPSDError):
+        GPRegressionMetaLearned._check_numerics(mapl)
+    ok = SimpleNamespace(_fail=clean(), _lik=torch.tensor([0.3, 0.1]))
+    _RandomGPLearner._check_numerics(ok)
+    flagged = SimpleNamespace(_fail=torch.ones(1, dtype=torch.int32), _lik=torch.tensor([0.3, 0.1]))
+    with pytest.raises(NotPSDError):
+        _RandomGPLearner._check_numerics(flagged)
+    assert int(flagged._fail) == 0                             # (reset, as before)
