@@ -222,7 +222,10 @@ __host__ __device__ constexpr int uidx(int NB, int K, int J) { return K * NB - K
 // waves per SIMD the register allocation aims at: 4 (the n <= 64, f <= 2 backward kernel needs 122 registers and 7.7 KB of LDS);
 // with f <= 4 the n = 64 kernels need 168 - 186 registers (3 resp. 2 waves)
 #define GPR_MINW(NB, FP, BWD) ((NB) > 4 ? 1 : ((NB) == 4 && (FP) == 4 ? ((BWD) ? 2 : 3) : 4))
-template <int NB, int FP, bool BWD>
+// HAS_OS = false: the caller has no outputscale (SVGD / VI: SEKernelLight, models.py:418-446) -- os == 1 at compile time: the 40
+// multiplies of the Gram build and the 64 additions of the gradient loop that only feed d lml / d outputscale are not compiled in
+// (instantiated for the shapes of cfg #3 / #4 only: every instantiation costs build time)
+template <int NB, int FP, bool BWD, bool HAS_OS = true>
 __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfmaArgs a) {
     constexpr int NP = 16 * NB;
     constexpr int NU = NB * (NB + 1) / 2;
@@ -257,7 +260,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     float kls[FP];                                            // KAPPA / lengthscale
 #pragma unroll
     for (int c = 0; c < FP; ++c) kls[c] = (c < f) ? KAPPA / a.ls[(long)p * f + c] : 1.0f;
-    const float os = a.os ? a.os[p] : 1.0f;
+    const float os = HAS_OS ? (a.os ? a.os[p] : 1.0f) : 1.0f;
     const float noise = a.noise[p];
 
     // ---- features (pre-divided by the lengthscale) and residual, lane l = rows l, l + 64, ... --------------------------------
@@ -453,7 +456,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
 #pragma unroll
             for (int c = 0; c < FP; ++c) { df[c] = zi[c] - zc[c]; q = fmaf(df[c], df[c], q); }
             const float M = Gij * __builtin_amdgcn_exp2f(-q);
-            msum += M;
+            if (HAS_OS) msum += M;
 #pragma unroll
             for (int c = 0; c < FP; ++c) colacc[c] = fmaf(M, df[c], colacc[c]);
         }
@@ -567,8 +570,15 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
 
 template <int NB, bool BWD>
 static int launch_reg(const GpMfmaArgs& a, int FP, hipStream_t s) {
-    if (FP == 2) hipLaunchKernelGGL((gp_reg_kernel<NB, 2, BWD>), dim3((unsigned)a.B), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((gp_reg_kernel<NB, 4, BWD>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+    if (FP == 2) {
+        if constexpr (BWD && (NB == 4 || NB == 8)) {
+            if (!a.os && !a.d_os) {
+                hipLaunchKernelGGL((gp_reg_kernel<NB, 2, true, false>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+                return launch_status();
+            }
+        }
+        hipLaunchKernelGGL((gp_reg_kernel<NB, 2, BWD>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+    } else hipLaunchKernelGGL((gp_reg_kernel<NB, 4, BWD>), dim3((unsigned)a.B), dim3(64), 0, s, a);
     return launch_status();
 }
 
