@@ -206,7 +206,13 @@ def main():
     if rank == 0 and world == 1 and args.config == 3 and not args.no_other_configs:
         del wl
         torch.cuda.empty_cache()
-        others = {'cfg%d' % c: other_config_leg(c, M, L) for c in (2, 4, 5)}
+        others = {}
+        for c in (2, 4, 5):
+            try:
+                others['cfg%d' % c] = other_config_leg(c, M, L)
+            except Exception as exc:                     # (a side leg must never take the headline line down with it)
+                others['cfg%d' % c] = {'error': repr(exc)}
+                torch.cuda.empty_cache()
 
     if rank == 0:
         cpu = None if (args.no_cpu_baseline or world > 1 or args.config != 3) else cpu_baseline()
