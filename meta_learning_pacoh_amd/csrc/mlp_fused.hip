@@ -644,7 +644,18 @@ int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride
     for (int k = 0; k < nets; ++k) { a.net[k].theta_off = off[k]; a.net[k].out = (float*)out[k]; a.net[k].d_out = d_out[k]; }
     const int pb = fused_fwd_pb(n_hidden) == 2 ? 2 : 4;
     const int tiles = (a.R + 16 * pb - 1) / (16 * pb);
-    a.tiles_per_wg = fused_env("PACOH_FUSED_FWD_TPW", 16);         // 4 tiles per wave (4 / 8 / 16 / 32: 109 / 100 / 95 / 94 us at cfg #3)
+    // tiles per workgroup (a wave takes every 4th): 16 at cfg #3 (4 / 8 / 16 / 32: 109 / 100 / 95 / 94 us); small batches -- the 1/8
+    // strong-scaling shard -- want fewer, or a SIMD holds two four-tile waves while its neighbour idles: the count that minimises
+    // (waves per SIMD) x (tiles per wave + half a tile of fixed cost), larger counts winning ties
+    a.tiles_per_wg = fused_env("PACOH_FUSED_FWD_TPW", 0);
+    if (a.tiles_per_wg <= 0) {
+        double best = 1e30;
+        for (int tpw = 4; tpw <= 32; tpw *= 2) {
+            const long waves = (long)((tiles + tpw - 1) / tpw) * P * nets * 4;
+            const double cost = (double)((waves + 1023) / 1024) * (tpw / 4 + 0.5);
+            if (cost <= best * 1.02 || tpw == 4) { if (cost < best) best = cost; a.tiles_per_wg = tpw; }
+        }
+    }
     const int wgs = (tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
 #define PACOH_LAUNCH_FWD(K) hipLaunchKernelGGL((K), dim3(wgs, P, nets), dim3(256), 0, s, a)
     if (pb == 4) {
