@@ -317,6 +317,35 @@ int pacoh_svgd_update_dev(void* X, const void* score, const void* prior_mean, co
                           double beta2, void* exp_avg, void* exp_avg_sq, void* bw_out, void* workspace, int P, int D,
                           int dist_done, int64_t* step_counter, int dtype, void* stream);
 
+/* The pipelined SVGD step (round 3; csrc/step_tail.h): what pacoh_step_begin does for a step is spread over launches the step has
+ * anyway, so that a captured step is FIVE launches (forward, GP, backward, slab reduction, update) instead of six.
+ *   prologue of a chunk of steps (host): pacoh_step_begin on row 0 (sc_out = sc2 row 0, theta given, no svgd_X, advance = 0),
+ *     then *counter := -1;
+ *   pacoh_mlp2_fwd_svgd = pacoh_mlp2_fwd + pacoh_svgd_dist_advance: *counter += 1, the particles' squared distances and their
+ *     snapshot into svgd_workspace -- in extra workgroups of the forward launch on the fused fp32 path, as a launch behind it
+ *     elsewhere (pacoh_svgd_dist_advance alone: configurations without the two networks);
+ *   pacoh_svgd_update_next = pacoh_svgd_update_dev (dist_done) with the step scalars read from sc2[*counter & 1][n_sc]; its own
+ *     threads write softplus of the hyper-parameter entries they have just updated to ls[P,f] / os[P] / noise[P] (ls = NULL: not
+ *     wanted), and extra workgroups of the launch copy row *counter + 1 of sc_all into sc2[(*counter + 1) & 1] and gather that
+ *     row's tb tasks (idx_all[row, tb]; x[T,n,d], y[T,n], optional n_valid) into out_x / out_y / out_n_valid: idx_all and sc_all
+ *     must hold one valid row beyond the last step of the chunk.
+ * Replaces, together: the softplus transforms of the raw hyper-parameters (random_gp.py:69-74), the gather of the drawn task
+ * batch (GPR_meta_svgd.py:102) and the pairwise distances of SVGD.phi / RBF_Kernel (svgd.py:12-59) as separate launches. */
+int pacoh_svgd_dist_advance(const void* X, void* workspace, int P, int D, int64_t* counter, int dtype, void* stream);
+int pacoh_mlp2_fwd_svgd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
+                        const int32_t* hidden, int n_hidden, long off_a, int d_out_a, void* out_a, long off_b, int d_out_b,
+                        void* out_b, void* workspace, void* stash, int B, int n,
+                        const void* svgd_X, void* svgd_workspace, int svgd_P, int svgd_D, int64_t* counter,
+                        int dtype, void* stream);
+int pacoh_svgd_update_next(void* X, const void* score, const void* prior_mean, const void* prior_std, double prior_factor,
+                           double bandwidth, int use_adam, double beta1, double beta2, void* exp_avg, void* exp_avg_sq,
+                           void* bw_out, void* workspace, int P, int D,
+                           const int64_t* counter, void* sc2, int n_sc, const int64_t* idx_all, int tb, const void* sc_all,
+                           const void* x, const void* y, const int32_t* n_valid, void* out_x, void* out_y,
+                           int32_t* out_n_valid, int n, int d,
+                           int off_ls, int f, int off_os, int off_noise, double noise_floor, void* ls, void* os, void* noise,
+                           int dtype, void* stream);
+
 /* Same update direction with the IMQ particle kernel k_ij = (alpha + sum_d (X_jd - X_id)^2 / h_d)^beta
  * (alpha > 0, beta < 0).  bandwidth > 0: h_d = bandwidth for every d.  bandwidth <= 0: per-dimension median
  * heuristic h_d = lower-median_{a<b} (X_bd - X_ad)^2 / ln(P+1) (torch.median semantics), written to h_out[D]

@@ -203,9 +203,20 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         self._feed = StepFeed(self.device, self.dtype, tb_local, chunk=self.GRAPH_CHUNK)
         self._svgd_ws = L.svgd_update_workspace(self.particles, self._svgd_ws)
         self._graphs = None
+        # Five launches per step instead of six (csrc/step_tail.h): the distance matrix rides in the forward launch, the next step's
+        # scalars and task batch are fetched by the update launch.  A rank without tasks of its own has no forward launch: it keeps
+        # the step_begin launch.  PACOH_SVGD_PIPELINE=0: the round-2 launch sequence (A/B measurements, bit-identity tests)
+        self._pipelined = tb_local > 0 and os.environ.get('PACOH_SVGD_PIPELINE', '1') != '0'
+        if self._pipelined:
+            self._feed.pipeline(self.tasks, self.engine, self.particles)
 
     def _body_likelihood(self):
         """score[P,D] = d/d theta_p sum_t mll[t,p] over this rank's tasks (unscaled), lik[P] the sums themselves"""
+        if self._pipelined:
+            self.engine.lml_and_grad(self.particles, self._feed.batch, weight=1.0, lik_out=self._lik, lik_scale=1.0,
+                                     grad_out=self._score, fail_flag=self._fail, hypers=self._feed.hyp,
+                                     svgd_tail=(self.particles, self._svgd_ws, self._feed.ctr))
+            return
         # select + gather + hyper transforms + the particles' distance matrix: one launch; the counter is advanced by the update
         batch, hyp = self._feed.begin(self.tasks, self.engine, self.particles, advance=False, svgd=(self.particles, self._svgd_ws))
         if batch is None:
@@ -217,6 +228,12 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
     def _body_update(self):
         """prior score + pre-factor + bandwidth + phi + optimizer in one launch (distances: _body_likelihood), particles updated
         in place, step counter advanced"""
+        self.last_bandwidth = self._bw_out
+        if self._pipelined:
+            L.svgd_update_next(self.particles, self._score, self.prior_mean, self.prior_std, self.prior_factor, self.bandwidth,
+                               self.optimizer_name, self.exp_avg, self.exp_avg_sq, self._svgd_ws, self._bw_out, self._feed, self.tasks,
+                               self._feed.hyper)
+            return
         _, self._svgd_ws = L.svgd_update_dev(self.particles, self._score, self.prior_mean, self.prior_std, self.prior_factor,
                                              self.bandwidth, self.optimizer_name, self._feed.sc, self.exp_avg, self.exp_avg_sq,
                                              workspace=self._svgd_ws, bw_out=self._bw_out, dist_done=True,
@@ -234,6 +251,8 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
                                                            many_ok=self.tasks.n <= 128)
         for t, sv in zip(state, saved):
             t.copy_(sv)                                   # undo what the warm-up runs did
+        if self._pipelined:
+            self._feed.prologue()                         # (batch buffers, scalars and hyper-parameters of the restored particles)
 
     def _run_step(self, graphed):
         run_step(self._graphs, graphed, self._body_likelihood, self._exchange, self._body_update)
@@ -246,6 +265,8 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
             k = min(n_steps, self.GRAPH_CHUNK)
             idx_rows, sc_rows = self._draw_steps(k, self.lr_scheduler, self.opt_step + 1)
             self._feed.upload(idx_rows, sc_rows)
+            if self._pipelined:
+                self._feed.prologue()
             if graphed and self._graphs is None:
                 self._build_graphs()                      # (captured with real operands in the feed; state and counter are restored)
             if graphed:
@@ -267,6 +288,8 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
             self.opt_step += 1
             self._feed.upload(np.asarray(idx_local).reshape(1, -1) if len(idx_local) > 0 else None,
                               [L.step_scalars(pre_factor, self.lr_scheduler.lr, self.opt_step)])
+            if self._pipelined:
+                self._feed.prologue()
             self._run_step(False)
             return
         _, score = self._log_prob_and_score(self.particles, idx_local, pre_factor)

@@ -53,6 +53,8 @@ SIGNATURES = {
     'pacoh_mlp2_fwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_mlp2_stash_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_mlp2_fwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pacoh_mlp2_fwd_svgd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _vp, _i, _i,
+                                 _vp, _vp, _i, _i, _vp, _i, _vp]),
     'pacoh_mlp2_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_mlp2_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_mlp2_bwd_hyper': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _i,
@@ -67,6 +69,10 @@ SIGNATURES = {
                               _vp, _l, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_svgd_update_dev_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_update_dev': (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _vp, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    'pacoh_svgd_dist_advance': (_i, [_vp, _vp, _i, _i, _vp, _i, _vp]),
+    'pacoh_svgd_update_next': (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _d, _d, _vp, _vp, _vp, _vp, _i, _i,
+                                    _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                                    _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
     'pacoh_prior_logprob_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
     'pacoh_svgd_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_phi': (_i, [_vp, _vp, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -94,7 +100,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4              # pacoh_abi_version() of the library this table was written for
+ABI_VERSION = 5              # pacoh_abi_version() of the library this table was written for
 
 
 def load_library():
@@ -486,18 +492,25 @@ def mlp2_stash(x, P, d_in, hidden, d_out_a, d_out_b, B, n, stash=None):
     return stash
 
 
-def mlp2_fwd(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, off_b, d_out_b, B, n, ws_holder=None, stash=None):
+def mlp2_fwd(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, off_b, d_out_b, B, n, ws_holder=None, stash=None, svgd_tail=None):
     """two networks of the same hidden shape (blocks at element offsets off_a / off_b of the rows of theta[P, D]) on the
     same inputs: -> (out_a[B,n,d_out_a], out_b[B,n,d_out_b]); one launch on the fused fp32 path.  stash (mlp2_stash()) receives
-    the activations the matching mlp2_bwd(stash=...) would otherwise recompute"""
+    the activations the matching mlp2_bwd(stash=...) would otherwise recompute.  svgd_tail = (particles, workspace, counter): the
+    pipelined SVGD step's distance matrix + counter increment ride in the same launch (svgd_dist_advance)"""
     lib = load_library()
     out_a = torch.empty(B, n, d_out_a, dtype=x.dtype, device=x.device)
     out_b = torch.empty(B, n, d_out_b, dtype=x.dtype, device=x.device)
     harr, code = _hidden_arr(hidden), dtype_code(x)
     ws = _mlp_fwd_ws(lib.pacoh_mlp2_fwd_workspace_bytes(B, P, n, d_in, harr, len(hidden), d_out_a, d_out_b, code), x.device, ws_holder)
     with _Timed('mlp_fwd'):
-        _check(lib.pacoh_mlp2_fwd(_ptr(x), x_div, _ptr(theta, x), theta.shape[1], P, d_in, harr, len(hidden), off_a, d_out_a,
-                                  _ptr(out_a), off_b, d_out_b, _ptr(out_b), _ptr(ws), _ptr(stash), B, n, code, _stream()), 'pacoh_mlp2_fwd')
+        if svgd_tail is not None:
+            sv_X, sv_ws, ctr = svgd_tail
+            _check(lib.pacoh_mlp2_fwd_svgd(_ptr(x), x_div, _ptr(theta, x), theta.shape[1], P, d_in, harr, len(hidden), off_a, d_out_a,
+                                           _ptr(out_a), off_b, d_out_b, _ptr(out_b), _ptr(ws), _ptr(stash), B, n, _ptr(sv_X, x),
+                                           _ptr(sv_ws), sv_X.shape[0], sv_X.shape[1], _ptr(ctr), code, _stream()), 'pacoh_mlp2_fwd_svgd')
+        else:
+            _check(lib.pacoh_mlp2_fwd(_ptr(x), x_div, _ptr(theta, x), theta.shape[1], P, d_in, harr, len(hidden), off_a, d_out_a,
+                                      _ptr(out_a), off_b, d_out_b, _ptr(out_b), _ptr(ws), _ptr(stash), B, n, code, _stream()), 'pacoh_mlp2_fwd')
     return out_a, out_b
 
 
@@ -736,6 +749,39 @@ def svgd_update_dev(X, score, prior_mean, prior_std, prior_factor, bandwidth, op
                                          _ptr(step_counter), code, _stream()),
                'pacoh_svgd_update_dev')
     return bw_out, workspace
+
+
+def svgd_dist_advance(X, workspace, counter):
+    """pipelined SVGD step without a paired forward pass to ride in: *counter += 1, squared distances + snapshot of X -> workspace"""
+    with _Timed('svgd_dist'):
+        _check(load_library().pacoh_svgd_dist_advance(_ptr(X), _ptr(workspace), X.shape[0], X.shape[1], _ptr(counter), dtype_code(X),
+                                                      _stream()), 'pacoh_svgd_dist_advance')
+
+
+def svgd_update_next(X, score, prior_mean, prior_std, prior_factor, bandwidth, optimizer, exp_avg, exp_avg_sq, workspace, bw_out,
+                     feed, tasks, hyper, beta1=0.9, beta2=0.999):
+    """the update of a pipelined SVGD step (include/pacoh_gp.h, "The pipelined SVGD step"): svgd_update_dev(dist_done) with the
+    scalars of feed.sc2[counter & 1]; writes the updated particles' transformed hyper-parameters into feed.hyp with hyper =
+    (off_ls, f, off_os, off_noise, noise_floor, kernel) and fetches the next row's scalars and task batch into feed.sc2 / feed.batch"""
+    lib = load_library()
+    P, D = X.shape
+    bw = -1.0 if bandwidth is None else float(bandwidth)
+    x = y = nv = ox = oy = onv = None
+    n = d = 0
+    if feed.tb > 0:
+        x, y, nv = tasks.x, tasks.y, (tasks.n_valid if tasks.ragged else None)
+        ox, oy, onv = feed.batch.x, feed.batch.y, feed.batch.n_valid
+        n, d = x.shape[1], x.shape[2]
+    off_ls, f, off_os, off_noise, floor, kernel = hyper
+    ls, os_, noise = feed.hyp
+    with _Timed('svgd_phi'):
+        _check(lib.pacoh_svgd_update_next(_ptr(X), _ptr(score, X), _ptr(prior_mean, X), _ptr(prior_std, X), float(prior_factor), bw,
+                                          int(optimizer == 'Adam'), float(beta1), float(beta2), _ptr(exp_avg, X), _ptr(exp_avg_sq, X),
+                                          _ptr(bw_out), _ptr(workspace), P, D,
+                                          _ptr(feed.ctr), _ptr(feed.sc2, X), feed.sc2.shape[1], _ptr(feed.idx_all), feed.tb,
+                                          _ptr(feed.sc_all, X), _ptr(x, X), _ptr(y, X), _ptr(nv), _ptr(ox), _ptr(oy), _ptr(onv), n, d,
+                                          off_ls, _kf(f, kernel), off_os, off_noise, float(floor), _ptr(ls), _ptr(os_), _ptr(noise),
+                                          dtype_code(X), _stream()), 'pacoh_svgd_update_next')
 
 
 def svgd_phi_imq(X, score, alpha=0.5, beta=-0.5, bandwidth=None, neg=False, workspace=None):

@@ -4,6 +4,7 @@
 // captured into one hipGraph.
 #include "common.h"
 #include "hyper_tail.h"
+#include "step_tail.h"
 
 namespace pacoh {
 
@@ -82,30 +83,14 @@ __global__ void __launch_bounds__(1024) prior_kernel(const T* __restrict__ theta
 }
 
 // ---- SVGD ---------------------------------------------------------------------------------------
-// stage 1: squared distances, one 256-thread workgroup per (i,j) pair, direct differences
-template <typename T>
-__device__ __forceinline__ void svgd_dist_block(const T* __restrict__ X, T* __restrict__ d2, int P, int D, T* __restrict__ snap, int pair) {
-    __shared__ T red[4];
-    const int i = pair / P, j = pair - i * P;
-    if (j > i) return;
-    const T* xi = X + (long)i * D;
-    if (snap && i == j) {                       // the diagonal pairs copy their particle: the in-place update reads the snapshot
-        for (int d = threadIdx.x; d < D; d += 256) snap[(long)i * D + d] = xi[d];
-        if (threadIdx.x == 0) d2[i * P + i] = T(0);
-        return;
-    }
-    const T* xj = X + (long)j * D;
-    T acc = 0;
-    for (int d = threadIdx.x; d < D; d += 256) { T df = xi[d] - xj[d]; acc = fma(df, df, acc); }
-    acc = subwave_sum<T>(acc, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) { const T tot = (red[0] + red[1]) + (red[2] + red[3]); d2[i * P + j] = tot; d2[j * P + i] = tot; }
-}
+// stage 1: squared distances, one 256-thread workgroup per (i,j) pair, direct differences (svgd_dist_block: step_tail.h)
 template <typename T>
 __global__ void __launch_bounds__(256) svgd_dist_kernel(const T* __restrict__ X, T* __restrict__ d2, int P, int D, T* __restrict__ snap = nullptr) {
     svgd_dist_block<T>(X, d2, P, D, snap, (int)blockIdx.x);
 }
+// the same behind a forward pass that has no tail of its own (step_tail.h): distances + snapshot + the step counter's increment
+template <typename T>
+__global__ void __launch_bounds__(256) svgd_dist_advance_kernel(SvgdDistTail<T> t) { svgd_dist_tail<T>(t, (int)blockIdx.x, (int)gridDim.x); }
 
 // Median of the full PxP squared-distance matrix (numpy.median semantics) from its P(P-1)/2 distinct off-diagonal entries:
 // the sorted full matrix is P zeros followed by every pair value twice, so entry m of it is 0 for m < P and u[(m-P)/2]
@@ -289,12 +274,20 @@ __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ 
                                                           T one_minus_b2, T step_size, T bc2_sqrt, T eps,
                                                           T* __restrict__ m, T* __restrict__ v, T* __restrict__ X_out, int P, int D,
                                                           const T* __restrict__ sc = nullptr, const T* __restrict__ mids = nullptr,
-                                                          long* __restrict__ step_counter = nullptr) {
+                                                          long* __restrict__ step_counter = nullptr,
+                                                          StepNextArgs<T> nx = StepNextArgs<T>{}) {
+    if (nx.counter) {
+        // pipelined step (step_tail.h): rows blockIdx.y >= P of the grid fetch the next step's operands; the others find this step's
+        // scalars in the row of sc2 the step counter selects
+        if ((int)blockIdx.y >= P) {
+            step_next_tail<T>(nx, ((int)blockIdx.y - P) * (int)gridDim.x + (int)blockIdx.x, ((int)gridDim.y - P) * (int)gridDim.x);
+            return;
+        }
+    }
     if (step_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *step_counter += 1;   // (as in adam_dev_kernel)
-    T score_scale = T(1);
-    if (sc) { score_scale = sc[0]; lr = sc[1]; step_size = sc[5]; bc2_sqrt = sc[6]; eps = sc[7]; }     // PACOH_SC_* (pacoh_gp.h)
     __shared__ T Ki[PACOH_SVGD_MAX_PARTICLES];
     __shared__ T gam_s, rowsum_s;
+    __shared__ T sc_s[5];                                  // score scale, lr, Adam step size, sqrt of bias correction 2, eps
     const int i = blockIdx.y;
     // The kernel is a chain of L2 round trips, not arithmetic (P x 2 loads per thread behind the bandwidth / kernel-row phase of
     // wave 0: 11 us at P = 20 with four particles' loads in flight behind the barrier).  Everything that does not depend on that
@@ -331,9 +324,17 @@ __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ 
         for (int j = lane; j < P; j += 64) { const T kv = t_exp<T>(-gam * d2[i * P + j]); Ki[j] = kv; ksum += kv; }
         const T rs = subwave_sum<T>(ksum, 64);
         if (lane == 0) { gam_s = gam; rowsum_s = rs; if (bw_out && blockIdx.x == 0 && i == 0) *bw_out = bw; }
+    } else if (threadIdx.x == 64) {
+        // the step scalars, fetched by a wave that only waits for the bandwidth phase anyway: in the pipelined step their address
+        // hangs on the step counter (two dependent round trips, which would otherwise sit in front of the prefetch above)
+        const T* scp = nx.counter ? nx.sc2 + (*nx.counter & 1) * nx.n_sc : sc;
+        if (scp) { sc_s[0] = scp[0]; sc_s[1] = scp[1]; sc_s[2] = scp[5]; sc_s[3] = scp[6]; sc_s[4] = scp[7]; }     // PACOH_SC_* (pacoh_gp.h)
+        else { sc_s[0] = T(1); sc_s[1] = lr; sc_s[2] = step_size; sc_s[3] = bc2_sqrt; sc_s[4] = eps; }
     }
     __syncthreads();
     if (d >= D) return;
+    const T score_scale = sc_s[0];
+    lr = sc_s[1]; step_size = sc_s[2]; bc2_sqrt = sc_s[3]; eps = sc_s[4];
     const T gam2 = T(2) * gam_s;
     const T pscale = mu ? prior_factor / (sdv * sdv) : T(0);
     T acc = 0;
@@ -371,15 +372,25 @@ __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ 
         acc = fma(Ki[j], sj - gam2 * xj, acc);
     }
     const T r = (acc + gam2 * xi * rowsum_s) / T(P);          // phi[i,d]
+    T xn;
     if (use_adam) {
         const T g = -r;                                       // particles.grad = -phi (svgd.py:27)
         mq = mq + (g - mq) * one_minus_b1;
         const T vq = vq0 * b2 + one_minus_b2 * g * g;
         const T denom = t_sqrt<T>(vq) / bc2_sqrt + eps;
-        X_out[q] = xi - step_size * (mq / denom);
+        xn = xi - step_size * (mq / denom);
         m[q] = mq; v[q] = vq;
     } else {
-        X_out[q] = fma(lr, r, xi);
+        xn = fma(lr, r, xi);
+    }
+    X_out[q] = xn;
+    if (nx.counter && nx.ls) {
+        // the transformed hyper-parameters of the updated particle (what pacoh_step_begin computes from theta at the next step),
+        // by the threads that hold their raw values
+        if (d == nx.off_noise) nx.noise[i] = softplus_t<T>(xn) + nx.noise_floor;
+        else if (nx.os && d == nx.off_os) nx.os[i] = softplus_t<T>(xn);
+        else if (nx.tie) { if (d == nx.off_ls) { const T v1 = softplus_t<T>(xn); for (int e = 0; e < nx.f; ++e) nx.ls[i * nx.f + e] = v1; } }
+        else if (d >= nx.off_ls && d < nx.off_ls + nx.f) nx.ls[i * nx.f + (d - nx.off_ls)] = softplus_t<T>(xn);
     }
 }
 
@@ -715,7 +726,7 @@ extern "C" int pacoh_gather_tasks(const void* x, const void* y, const int32_t* n
     return launch_status();
 }
 
-extern "C" int pacoh_abi_version(void) { return 4; }
+extern "C" int pacoh_abi_version(void) { return 5; }
 
 extern "C" int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise,
                                double noise_floor, void* ls, void* os, void* noise, int dtype, void* stream) {
@@ -836,6 +847,77 @@ extern "C" int pacoh_svgd_update_dev(void* X, const void* score, const void* pri
                                              exp_avg, exp_avg_sq, bw_out, workspace, P, D, dist_done, step_counter, (hipStream_t)stream);
     return svgd_update_dev_launch<double>(X, score, prior_mean, prior_std, prior_factor, bandwidth, use_adam, scalars, beta1, beta2,
                                           exp_avg, exp_avg_sq, bw_out, workspace, P, D, dist_done, step_counter, (hipStream_t)stream);
+}
+
+extern "C" int pacoh_svgd_dist_advance(const void* X, void* workspace, int P, int D, int64_t* counter, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!X || !workspace || P <= 0 || D <= 0) return PACOH_EINVAL;
+    if (P > PACOH_SVGD_MAX_PARTICLES) return PACOH_ELIMIT;
+    if (dtype == PACOH_F32) {
+        float* d2 = (float*)workspace;
+        SvgdDistTail<float> t = {(const float*)X, d2, d2 + P * P, P, D, (long*)counter};
+        hipLaunchKernelGGL(svgd_dist_advance_kernel<float>, dim3(P * P), dim3(256), 0, (hipStream_t)stream, t);
+    } else {
+        double* d2 = (double*)workspace;
+        SvgdDistTail<double> t = {(const double*)X, d2, d2 + P * P, P, D, (long*)counter};
+        hipLaunchKernelGGL(svgd_dist_advance_kernel<double>, dim3(P * P), dim3(256), 0, (hipStream_t)stream, t);
+    }
+    return launch_status();
+}
+
+template <typename T>
+static int svgd_update_next_launch(void* X, const void* score, const void* mu, const void* sd, double prior_factor, double bandwidth,
+                                   int use_adam, double beta1, double beta2, void* m, void* v, void* bw_out, void* workspace, int P, int D,
+                                   const StepNextArgs<T>& nx, hipStream_t s) {
+    T* d2 = (T*)workspace;
+    T* snap = d2 + P * P;
+    T* mids = nullptr;
+    if (P > 64 && !(bandwidth > 0.0)) {
+        mids = snap + (long)P * D;
+        hipLaunchKernelGGL(svgd_median_large_kernel<T>, dim3(2), dim3(1024), 0, s, (const T*)d2, P, mids);
+    }
+    const int gx = (D + 255) / 256;
+    const int tail_rows = (nx.tb + 1 + gx - 1) / gx;                 // tb gathers + the scalars' row
+    hipLaunchKernelGGL(svgd_update_kernel<T>, dim3(gx, P + tail_rows), dim3(256), 0, s, (const T*)snap, (const T*)score, (const T*)mu,
+                       (const T*)sd, (T)prior_factor, (const T*)d2, (T)bandwidth, (T*)bw_out, use_adam, T(0),
+                       (T)(1.0 - beta1), (T)beta2, (T)(1.0 - beta2), T(0), T(1), T(0), (T*)m, (T*)v, (T*)X, P, D, (const T*)nullptr,
+                       (const T*)mids, (long*)nullptr, nx);
+    return launch_status();
+}
+
+// pacoh_svgd_update_dev for the pipelined step (step_tail.h): distances already in the workspace, scalars from the ping-pong rows
+// the counter selects, the updated particles' transformed hyper-parameters written by the update itself, and -- in extra workgroups
+// of the same launch -- the NEXT step's scalars and task batch fetched
+extern "C" int pacoh_svgd_update_next(void* X, const void* score, const void* prior_mean, const void* prior_std, double prior_factor,
+                                      double bandwidth, int use_adam, double beta1, double beta2, void* exp_avg, void* exp_avg_sq,
+                                      void* bw_out, void* workspace, int P, int D,
+                                      const int64_t* counter, void* sc2, int n_sc, const int64_t* idx_all, int tb, const void* sc_all,
+                                      const void* x, const void* y, const int32_t* n_valid, void* out_x, void* out_y,
+                                      int32_t* out_n_valid, int n, int d,
+                                      int off_ls, int f, int off_os, int off_noise, double noise_floor, void* ls, void* os, void* noise,
+                                      int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!X || !score || !workspace || P <= 0 || D <= 0 || !counter || !sc2 || !sc_all || n_sc < PACOH_SC_COUNT) return PACOH_EINVAL;
+    if ((prior_mean == nullptr) != (prior_std == nullptr)) return PACOH_EINVAL;
+    if (use_adam && (!exp_avg || !exp_avg_sq)) return PACOH_EINVAL;
+    if (tb < 0 || (tb > 0 && (!idx_all || !x || !y || !out_x || !out_y || n <= 0 || d <= 0 || (n_valid == nullptr) != (out_n_valid == nullptr))))
+        return PACOH_EINVAL;
+    const int fdim = features_of(f);
+    if (ls && (!noise || fdim <= 0 || off_ls < 0 || off_noise < 0 || off_noise >= D || off_ls + (kernel_of(f) != PACOH_KERNEL_RBF ? 1 : fdim) > D ||
+               off_os >= D)) return PACOH_EINVAL;
+    if (P > PACOH_SVGD_MAX_PARTICLES) return PACOH_ELIMIT;
+    if (dtype == PACOH_F32) {
+        StepNextArgs<float> nx = {(const long*)counter, (float*)sc2, n_sc, (const long*)idx_all, tb, (const float*)sc_all, (const float*)x,
+                                  (const float*)y, n_valid, (float*)out_x, (float*)out_y, out_n_valid, n * d, n, off_ls, fdim, off_os, off_noise,
+                                  kernel_of(f) != PACOH_KERNEL_RBF, (float)noise_floor, (float*)ls, (float*)os, (float*)noise};
+        return svgd_update_next_launch<float>(X, score, prior_mean, prior_std, prior_factor, bandwidth, use_adam, beta1, beta2, exp_avg,
+                                              exp_avg_sq, bw_out, workspace, P, D, nx, (hipStream_t)stream);
+    }
+    StepNextArgs<double> nx = {(const long*)counter, (double*)sc2, n_sc, (const long*)idx_all, tb, (const double*)sc_all, (const double*)x,
+                               (const double*)y, n_valid, (double*)out_x, (double*)out_y, out_n_valid, n * d, n, off_ls, fdim, off_os, off_noise,
+                               kernel_of(f) != PACOH_KERNEL_RBF, noise_floor, (double*)ls, (double*)os, (double*)noise};
+    return svgd_update_next_launch<double>(X, score, prior_mean, prior_std, prior_factor, bandwidth, use_adam, beta1, beta2, exp_avg,
+                                           exp_avg_sq, bw_out, workspace, P, D, nx, (hipStream_t)stream);
 }
 
 template <typename T>

@@ -7,6 +7,7 @@
 // PACOH_MLP_PATH=fused|mfma|valu|layers restricts the choice to that path and the ones after it (tests, A/B timing).
 #include "common.h"
 #include "hyper_tail.h"
+#include "step_tail.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -26,7 +27,7 @@ bool mlp_mfma_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_ou
 bool mlp_fused_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_out);
 int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
                   int n_hidden, int nets, const long* off, const int* d_out, void* const* out, void* stash, int B, int n,
-                  hipStream_t s);
+                  hipStream_t s, const SvgdDistTail<float>* tail = nullptr);
 size_t mlp_fused_stash_bytes(int B, int P, int n, int n_hidden, int nets);
 size_t mlp_fused_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int nets);
 int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
@@ -194,9 +195,10 @@ extern "C" size_t pacoh_mlp2_stash_bytes(int B, int P, int n, int d_in, const in
     return mlp_fused_stash_bytes(B, P, n, n_hidden, 2);
 }
 
-extern "C" int pacoh_mlp2_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
-                              const int32_t* hidden, int n_hidden, long off_a, int d_out_a, void* out_a, long off_b, int d_out_b,
-                              void* out_b, void* workspace, void* stash, int B, int n, int dtype, void* stream) {
+static int mlp2_fwd_impl(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
+                         const int32_t* hidden, int n_hidden, long off_a, int d_out_a, void* out_a, long off_b, int d_out_b,
+                         void* out_b, void* workspace, void* stash, int B, int n, int dtype, void* stream,
+                         const SvgdDistTail<float>* tail, bool* tail_done) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!out_a || !out_b || !x || !theta || x_div <= 0 || P <= 0 || B <= 0 || n <= 0 || B % P != 0 || off_a < 0 || off_b < 0) return PACOH_EINVAL;
     int rc = args_ok(d_in, hidden, n_hidden, d_out_a);
@@ -206,12 +208,47 @@ extern "C" int pacoh_mlp2_fwd(const void* x, int x_div, const void* theta, long 
         const long off[2] = {off_a, off_b};
         const int dout[2] = {d_out_a, d_out_b};
         void* const outs[2] = {out_a, out_b};
-        return mlp_fused_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 2, off, dout, outs, stash, B, n, (hipStream_t)stream);
+        if (tail_done) *tail_done = tail != nullptr;
+        return mlp_fused_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 2, off, dout, outs, stash, B, n, (hipStream_t)stream, tail);
     }
     const size_t es = dtype == PACOH_F64 ? 8 : 4;
     rc = pacoh_mlp_fwd(x, x_div, (const char*)theta + off_a * es, theta_stride, P, d_in, hidden, n_hidden, d_out_a, out_a, workspace, B, n, dtype, stream);
     if (rc) return rc;
     return pacoh_mlp_fwd(x, x_div, (const char*)theta + off_b * es, theta_stride, P, d_in, hidden, n_hidden, d_out_b, out_b, workspace, B, n, dtype, stream);
+}
+
+extern "C" int pacoh_mlp2_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
+                              const int32_t* hidden, int n_hidden, long off_a, int d_out_a, void* out_a, long off_b, int d_out_b,
+                              void* out_b, void* workspace, void* stash, int B, int n, int dtype, void* stream) {
+    return mlp2_fwd_impl(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, off_a, d_out_a, out_a, off_b, d_out_b, out_b, workspace,
+                         stash, B, n, dtype, stream, nullptr, nullptr);
+}
+
+extern "C" int pacoh_svgd_dist_advance(const void* X, void* workspace, int P, int D, int64_t* counter, int dtype, void* stream);
+
+// pacoh_mlp2_fwd + pacoh_svgd_dist_advance: the first launch of a pipelined SVGD step (step_tail.h).  On the fused fp32 path the
+// particles' distance matrix, their snapshot and the step counter's increment run in extra workgroups of the forward launch;
+// elsewhere the two calls in sequence.
+extern "C" int pacoh_mlp2_fwd_svgd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
+                                   const int32_t* hidden, int n_hidden, long off_a, int d_out_a, void* out_a, long off_b, int d_out_b,
+                                   void* out_b, void* workspace, void* stash, int B, int n,
+                                   const void* svgd_X, void* svgd_workspace, int svgd_P, int svgd_D, int64_t* counter,
+                                   int dtype, void* stream) {
+    if (!svgd_X || !svgd_workspace || svgd_P <= 0 || svgd_D <= 0) return PACOH_EINVAL;
+    if (svgd_P > PACOH_SVGD_MAX_PARTICLES) return PACOH_ELIMIT;
+    bool tail_done = false;
+    int rc;
+    if (dtype == PACOH_F32) {
+        float* d2 = (float*)svgd_workspace;
+        SvgdDistTail<float> tail = {(const float*)svgd_X, d2, d2 + svgd_P * svgd_P, svgd_P, svgd_D, (long*)counter};
+        rc = mlp2_fwd_impl(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, off_a, d_out_a, out_a, off_b, d_out_b, out_b,
+                           workspace, stash, B, n, dtype, stream, &tail, &tail_done);
+    } else {
+        rc = mlp2_fwd_impl(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, off_a, d_out_a, out_a, off_b, d_out_b, out_b,
+                           workspace, stash, B, n, dtype, stream, nullptr, nullptr);
+    }
+    if (rc || tail_done) return rc;
+    return pacoh_svgd_dist_advance(svgd_X, svgd_workspace, svgd_P, svgd_D, counter, dtype, stream);
 }
 
 extern "C" size_t pacoh_mlp2_bwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out_a,

@@ -26,6 +26,7 @@
 // :313) and its autograd backward; P = 1 is NeuralNetwork.forward (models.py:211-217).
 #include "common.h"
 #include "hyper_tail.h"
+#include "step_tail.h"
 #include <stdlib.h>
 
 namespace pacoh {
@@ -67,6 +68,8 @@ struct FusedArgs {
     int tiles_per_wg;
     int n_stash;               // the top n_stash hidden layers travel through FusedNet::stash (0 = recompute everything)
     int nblk;                  // 16-point blocks per particle in the stash (a multiple of 4)
+    int tail_z;                // forward only: workgroups with blockIdx.z == tail_z (> 0) run sv (step_tail.h) instead of a network
+    SvgdDistTail<float> sv;
 };
 
 // stash element (particle p, 16-point block blk, slot, feature block fb): 256 floats, lane-major f32x4
@@ -294,6 +297,10 @@ template <int NH, int PB, int MINW>
 __global__ void __launch_bounds__(256, MINW) mlp_fused_fwd_kernel(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) float wl[f_welems(NH)];
     __shared__ __attribute__((aligned(16))) float stage[4][16 * PB * TSTAGE];
+    if (a.tail_z > 0 && (int)blockIdx.z == a.tail_z) {    // the SVGD step's distance matrix rides in this launch
+        svgd_dist_tail<float>(a.sv, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+        return;
+    }
     const FusedNet& nt = a.net[blockIdx.z];
     const int p = blockIdx.y;
     fused_load_weights<NH>(wl, a.theta + (long)p * a.theta_stride + nt.theta_off, a, nt.d_out);
@@ -638,7 +645,7 @@ constexpr int BWD_MINW_PB2 = PACOH_BWD_MINW_PB2;
 // nets = 1 or 2 networks of the SAME hidden shape at element offsets off[k] of the theta rows
 int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
                   int n_hidden, int nets, const long* off, const int* d_out, void* const* out, void* stash, int B, int n,
-                  hipStream_t s) {
+                  hipStream_t s, const SvgdDistTail<float>* tail) {
     FusedArgs a = {};
     fused_fill(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, B, n, stash, nets);
     for (int k = 0; k < nets; ++k) { a.net[k].theta_off = off[k]; a.net[k].out = (float*)out[k]; a.net[k].d_out = d_out[k]; }
@@ -657,7 +664,8 @@ int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride
         }
     }
     const int wgs = (tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
-#define PACOH_LAUNCH_FWD(K) hipLaunchKernelGGL((K), dim3(wgs, P, nets), dim3(256), 0, s, a)
+    if (tail) { a.tail_z = nets; a.sv = *tail; }
+#define PACOH_LAUNCH_FWD(K) hipLaunchKernelGGL((K), dim3(wgs, P, nets + (tail ? 1 : 0)), dim3(256), 0, s, a)
     if (pb == 4) {
         if (n_hidden == 1) PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<1, 4, 4>)); else if (n_hidden == 2) PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<2, 4, 4>));
         else if (n_hidden == 3) PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<3, 4, 4>)); else PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<4, 4, 4>));

@@ -153,21 +153,23 @@ class StepFeed:
     def __init__(self, device, dtype, tb, chunk=1024, aux_shape=None):
         chunk = max(int(chunk), GRAPH_STEPS)              # (a several-steps graph reads GRAPH_STEPS consecutive rows)
         self.device, self.dtype, self.tb, self.chunk = device, dtype, int(tb), int(chunk)
-        self.idx_all = torch.zeros(chunk, tb, dtype=torch.int64, device=device) if tb > 0 else None
+        rows = chunk + 1                                  # (the pipelined SVGD step fetches one row ahead: pipeline())
+        self.idx_all = torch.zeros(rows, tb, dtype=torch.int64, device=device) if tb > 0 else None
         self.idx = torch.zeros(tb, dtype=torch.int64, device=device) if tb > 0 else None
-        self.sc_all = torch.zeros(chunk, L.SC_COUNT, dtype=dtype, device=device)
+        self.sc_all = torch.zeros(rows, L.SC_COUNT, dtype=dtype, device=device)
         self.sc = torch.zeros(L.SC_COUNT, dtype=dtype, device=device)
+        self.sc2 = self.batch = self.hyp = self._pipe = None
         self.ctr = torch.zeros(1, dtype=torch.int64, device=device)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=device)      # last-block ticket of pacoh_step_begin
         # two pinned staging sets, used alternately: the host prepares and enqueues chunk k+1 while the GPU still runs chunk k
         # (with one set it would have to wait for chunk k's upload, which sits in the stream behind chunk k-1's steps)
-        self._h_idx = [torch.zeros(chunk, max(tb, 1), dtype=torch.int64).pin_memory() for _ in range(2)]
-        self._h_sc = [torch.zeros(chunk, L.SC_COUNT, dtype=dtype).pin_memory() for _ in range(2)]
+        self._h_idx = [torch.zeros(rows, max(tb, 1), dtype=torch.int64).pin_memory() for _ in range(2)]
+        self._h_sc = [torch.zeros(rows, L.SC_COUNT, dtype=dtype).pin_memory() for _ in range(2)]
         self.aux_all = self.aux = self._h_aux = None
         if aux_shape is not None:
-            self.aux_all = torch.zeros((chunk,) + tuple(aux_shape), dtype=dtype, device=device)
+            self.aux_all = torch.zeros((rows,) + tuple(aux_shape), dtype=dtype, device=device)
             self.aux = torch.zeros(tuple(aux_shape), dtype=dtype, device=device)
-            self._h_aux = [torch.zeros((chunk,) + tuple(aux_shape), dtype=dtype).pin_memory() for _ in range(2)]
+            self._h_aux = [torch.zeros((rows,) + tuple(aux_shape), dtype=dtype).pin_memory() for _ in range(2)]
         self._ev, self._slot = [None, None], 0
 
     def upload(self, idx_rows, sc_rows, aux_rows=None):
@@ -178,10 +180,11 @@ class StepFeed:
         self._slot = 1 - q
         if self._ev[q] is not None:
             self._ev[q].synchronize()                    # the copies that last read this staging set have executed
-        # Rows k .. GRAPH_STEPS-1 repeat the last real row: the warm-up and capture runs of the several-steps graph read GRAPH_STEPS
-        # rows whatever k is (meta_fit's first chunk is ONE step), and must see valid task indices and step scalars there -- not
-        # stale rows, not the zeros of a fresh buffer (lr = 0 and bias correction 0 give NaN optimizer state)
-        kk = max(k, GRAPH_STEPS)
+        # Rows k .. GRAPH_STEPS repeat the last real row: the warm-up and capture runs of the several-steps graph read GRAPH_STEPS
+        # rows whatever k is (meta_fit's first chunk is ONE step), the pipelined SVGD step one more (its update fetches the row
+        # behind the one in flight), and they must see valid task indices and step scalars there -- not stale rows, not the zeros of a
+        # fresh buffer (lr = 0 and bias correction 0 give NaN optimizer state)
+        kk = max(k, GRAPH_STEPS) + 1
         self._h_sc[q][:k].copy_(torch.as_tensor(np.asarray(sc_rows, dtype=np.float64)))
         self._h_sc[q][k:kk] = self._h_sc[q][k - 1]
         self.sc_all[:kk].copy_(self._h_sc[q][:kk], non_blocking=True)
@@ -196,6 +199,38 @@ class StepFeed:
         self.ctr.zero_()
         self._ev[q] = self._ev[q] or torch.cuda.Event()
         self._ev[q].record()
+
+    def pipeline(self, tasks, engine, theta):
+        """switch the feed to the pipelined SVGD step (csrc/step_tail.h): persistent batch buffers, transformed hyper-parameters and
+        two rows of step scalars, filled one step ahead by the update launch.  prologue() after every upload()"""
+        assert self.tb > 0
+        dev, dt = tasks.x.device, tasks.x.dtype
+        batch = TaskBatch.__new__(TaskBatch)
+        batch.T, batch.n, batch.ragged, batch.sizes = self.tb, tasks.n, tasks.ragged, None
+        batch.x = torch.empty(self.tb, tasks.n, tasks.x.shape[2], dtype=dt, device=dev)
+        batch.y = torch.empty(self.tb, tasks.n, dtype=dt, device=dev)
+        batch.n_valid = torch.empty(self.tb, dtype=torch.int32, device=dev) if tasks.ragged else None
+        off_ls, f, off_os, off_noise, _ = engine._hyper_offsets()
+        P = theta.shape[0]
+        self.batch = batch
+        self.hyp = (torch.empty(P, f, dtype=theta.dtype, device=theta.device),
+                    torch.empty(P, dtype=theta.dtype, device=theta.device) if off_os >= 0 else None,
+                    torch.empty(P, dtype=theta.dtype, device=theta.device))
+        self.hyper = (off_ls, f, off_os, off_noise, engine.noise_floor, engine.layout.kernel_code)
+        self.sc2 = torch.zeros(2, L.SC_COUNT, dtype=self.dtype, device=self.device)
+        self._pipe = (tasks, theta)
+
+    def prologue(self):
+        """row 0 of the uploaded chunk into the batch buffers and sc2[0], the hyper-parameters of the particles as they are now,
+        counter = -1 (the forward of the first step makes it 0): one launch + one fill, once per chunk -- not part of the step"""
+        tasks, theta = self._pipe
+        self.ctr.zero_()
+        sc, self.sc = self.sc, self.sc2[0]
+        try:
+            L.step_begin(self, tasks, (self.batch.x, self.batch.y, self.batch.n_valid), theta, self.hyper, self.hyp, advance=False)
+        finally:
+            self.sc = sc
+        self.ctr.fill_(-1)
 
     def select(self):
         L.step_select(self.idx_all, self.sc_all, self.ctr, self.idx, self.sc, self.aux_all, self.aux)
@@ -269,7 +304,10 @@ def build_step_graphs(body_likelihood, exchange, body_update, feed, many_ok=True
     ((whole step,), four steps) when the exchange can be captured (world size 1, or RCCL on the compute stream:
     parallel.collective_in_graph()), else ((likelihood, update), None) around the eager torch.distributed call"""
     def rewind():
-        feed.ctr.zero_()
+        if feed.sc2 is not None:
+            feed.prologue()                               # pipelined SVGD step: row 0 fetched again, counter = -1
+        else:
+            feed.ctr.zero_()
     if parallel.collective_in_graph():
         def whole():
             body_likelihood()
@@ -388,7 +426,7 @@ class GPEngine:
             return lay.block_range('mean_nn.')[0], lay.block_range('kernel_nn.')[0]
         return None
 
-    def _features(self, theta, x, T, n, theta_per_task=False, keep=False):
+    def _features(self, theta, x, T, n, theta_per_task=False, keep=False, svgd_tail=None):
         """kernel inputs z (+ divisor) and mean (+ mode) for B = T*P problems (b = t*P + p: task t, parameter row p).
         theta_per_task: theta holds T*S rows, S of its own per task -- the same kernels with P = T*S parameter rows, ONE
         problem per row (B = T*S) and inputs shared by S consecutive problems.  keep: park the activations the backward of the
@@ -404,8 +442,10 @@ class GPEngine:
                 stash = self._ws[key] = L.mlp2_stash(x, P, lay.input_dim, list(lay.mean_nn_layers), 1, lay.feature_dim, B, n,
                                                      self._ws.get(key))
             mean, z = L.mlp2_fwd(x, x_div, theta, P, lay.input_dim, list(lay.mean_nn_layers), pair[0], 1, pair[1],
-                                 lay.feature_dim, B, n, ws_holder=self._ws, stash=stash)
+                                 lay.feature_dim, B, n, ws_holder=self._ws, stash=stash, svgd_tail=svgd_tail)
             return z, 1, mean.reshape(B, n), L.MEAN_VECTOR
+        if svgd_tail is not None:
+            L.svgd_dist_advance(*svgd_tail)                # (no paired forward launch to ride in)
         if lay.covar_module == 'NN':
             lo, _ = lay.block_range('kernel_nn.')
             z = L.mlp_fwd(x, x_div, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers), lay.feature_dim, B, n,
@@ -436,18 +476,21 @@ class GPEngine:
                                        n_valid=batch.n_valid if batch.ragged else None, kernel=self.layout.kernel_code)
         return lml.reshape(T, P), info
 
-    def lml_and_grad(self, theta, batch, weight=1.0, lik_out=None, lik_scale=1.0, grad_out=None, fail_flag=None, hypers=None):
+    def lml_and_grad(self, theta, batch, weight=1.0, lik_out=None, lik_scale=1.0, grad_out=None, fail_flag=None, hypers=None,
+                     svgd_tail=None):
         """returns (lml[T,P], grad[P,D]) with grad = d(weight * sum_t lml[t,p]) / d theta[p];
         lik_out[P] (optional) receives lik_scale * sum_t lml[t,p] from the same launch that reduces the hyper-gradients;
         grad_out[P,D] (optional, contiguous) is used for the gradient instead of a fresh tensor;
-        fail_flag (optional int32[1]) is raised by that launch if any problem's Cholesky failed even with jitter"""
+        fail_flag (optional int32[1]) is raised by that launch if any problem's Cholesky failed even with jitter;
+        svgd_tail = (particles, workspace, counter): the pipelined SVGD step's distance matrix and counter increment, in extra
+        workgroups of the forward launch where there is one (L.mlp2_fwd)"""
         lay = self.layout
         P, D = theta.shape
         T, n = batch.T, batch.n
         B = T * P
         dev, dt = theta.device, theta.dtype
         ls, os_, noise = hypers if hypers is not None else self._hypers(theta)      # (hypers: already transformed by pacoh_step_begin)
-        z, z_div, mean, mode = self._features(theta, batch.x, T, n, keep=True)
+        z, z_div, mean, mode = self._features(theta, batch.x, T, n, keep=True, svgd_tail=svgd_tail)
         g = None                                        # weight 1: the kernels take g_lml = NULL
         if float(weight) != 1.0:
             gkey = ('g', B, dt, dev)                    # ONE upstream-gradient vector per batch shape, refilled when the weight changes

@@ -633,6 +633,41 @@ def test_graph_replay_is_bit_identical_to_eager_launches(M, kind, layers, monkey
     assert m_e.opt_step == m_g.opt_step == 8 and m_e.lr_scheduler.epoch == 8
 
 
+@pytest.mark.parametrize('cfg', [
+    dict(),                                                                         # two fused 2 x 32 networks: tail of the forward launch
+    dict(mean_nn_layers=(32, 32, 32, 32), kernel_nn_layers=(32, 32, 32, 32)),
+    dict(mean_nn_layers=(16, 16), kernel_nn_layers=(16, 16)),                       # general MLP path: distance launch behind it
+    dict(mean_module='constant', covar_module='SE'),                                # no network at all
+    dict(mean_module='constant', covar_module='NN', feature_dim=3),                  # one network
+    dict(optimizer='SGD', bandwidth=0.7),
+    dict(num_particles=70),                                                         # median of > 64 particles: its own launch stays
+])
+@pytest.mark.parametrize('graph', ['0', '1'])
+def test_pipelined_svgd_step_equals_the_step_begin_sequence(M, cfg, graph, monkeypatch):
+    """csrc/step_tail.h: distance matrix in the forward launch, hyper-parameter transforms by the update's own threads, next step's
+    scalars and task batch fetched by the update launch -- the same bits as the six-launch sequence with pacoh_step_begin
+    (PACOH_SVGD_PIPELINE=0), eager and replayed, ragged tasks, decaying learning rate, chunks of 1 + 2 + 3 + ... steps"""
+    rs = np.random.RandomState(11)
+    tasks = []
+    for t in range(7):
+        n = 9 + 2 * (t % 3)
+        x = rs.uniform(-3, 3, size=(n, 2))
+        tasks.append((x, np.sin(x[:, :1]) + 0.3 * x[:, 1:] + 0.05 * rs.randn(n, 1)))
+    monkeypatch.setenv('PACOH_GRAPH', graph)
+    kw = dict(num_particles=5, task_batch_size=4, lr=1e-2, lr_decay=0.9, random_seed=3)
+    kw.update(cfg)
+    out = []
+    for pipe in ('0', '1'):
+        monkeypatch.setenv('PACOH_SVGD_PIPELINE', pipe)
+        m = M.GPRegressionMetaLearnedSVGD(tasks, **kw)
+        m.meta_fit(verbose=False, n_iter=13, log_period=3)
+        assert m._pipelined == (pipe == '1') and m.opt_step == 13
+        m.svgd_step(np.array([1, 5, 2]), 0.25)                     # explicit draw, other batch size: a fresh feed
+        out.append((m.particles.clone(), m.exp_avg.clone(), float(m.last_bandwidth)))
+    assert bool(torch.isfinite(out[1][0]).all())
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+
+
 def test_launcher_networks_run_through_the_learners(M):
     """experiments/meta_GPR_SVGD_base_exp.py:29-30,83 (4 x 32, 10 particles, bandwidth 0.1, prior_factor 0.1, 2 tasks per step) and
     experiments/meta_GPR_mll_base_exp.py:29-30 (4 x 128, 2 tasks x 5 points per step): construct, train a few steps, predict; the
