@@ -103,18 +103,41 @@ class RcclComm:
     def all_reduce_(self, buf):
         return L.allreduce_sum(buf, self.handle)
 
+    def _agree(self, ok, dev):
+        """the same verdict on every rank (MIN over ranks through torch.distributed): a rank must never replay a collective its
+        peers failed to capture -- it would wait for them forever"""
+        if self.world_size > 1:
+            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item() > 0)
+        return ok
+
     def _self_test(self):
-        """eager all-reduce, then the same call captured in a hipGraph and replayed twice, on values whose sums are known; every rank
-        must see every check pass (the verdicts are combined with a MIN all-reduce through torch.distributed)"""
+        """eager all-reduce, then the same call captured in a hipGraph and replayed twice, on values whose sums are known.  Three
+        phases (eager / capture / replay), each closed by an agreement of all ranks: the next phase only starts if every rank got
+        through the previous one"""
         w, rank = self.world_size, self.rank
         dev = torch.device('cuda', torch.cuda.current_device())
         total = w * (w + 1) / 2.0
-        ok = True
-        try:
+        buf = graph = None
+
+        def phase(fn):
+            try:
+                ok = bool(fn())
+            except Exception as exc:                       # a capture the RCCL build does not support, a launch error, ...
+                warnings.warn('pacoh: in-graph RCCL all-reduce self-test failed on rank %d: %r' % (rank, exc))
+                ok = False
+            return self._agree(ok, dev)
+
+        def eager():
+            nonlocal buf
             buf = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=dev)
             self.all_reduce_(buf)
             torch.cuda.synchronize()
-            ok = ok and bool((buf == total).all())
+            return (buf == total).all()
+
+        def capture():
+            nonlocal graph
             buf.fill_(float(rank + 1))
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -123,24 +146,23 @@ class RcclComm:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             buf.fill_(float(rank + 1))
-            graph = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph()
             kw = {'capture_error_mode': 'thread_local'} if w > 1 else {}      # (torch.distributed's watchdog thread: see capture_graph)
             with warnings.catch_warnings():
                 warnings.simplefilter('ignore')            # (one rank: RCCL enqueues nothing for an in-place sum -> "graph is empty")
-                with torch.cuda.graph(graph, **kw):
+                with torch.cuda.graph(g, **kw):
                     self.all_reduce_(buf)
+            graph = g
+            return True
+
+        def replay():
             graph.replay()                                 # every rank: total
             graph.replay()                                 # every rank: w * total
             torch.cuda.synchronize()
-            ok = ok and bool((buf == w * total).all())
-            del graph
-        except Exception as exc:                           # a capture the RCCL build does not support, a launch error, ...
-            warnings.warn('pacoh: in-graph RCCL all-reduce self-test failed on rank %d: %r' % (rank, exc))
-            ok = False
-        if w > 1:
-            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = bool(flag.item() > 0)
+            return (buf == w * total).all()
+
+        ok = phase(eager) and phase(capture) and phase(replay)
+        del graph
         return ok
 
     def close(self):
