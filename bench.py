@@ -157,7 +157,7 @@ def main():
 
     # (enough untimed steps for the learners' first look at graph replay vs plain launches -- engine.StepMode -- and, in the chunks
     #  below, their second: neither decision falls into the timed region)
-    wl['run'](max(32, args.warmup))
+    wl['run'](max(40, args.warmup))
     barrier()
     # A fresh box needs a second or two of the real launch path before it issues steps at its steady rate (first process after boot:
     # hipGraphLaunch measured at 0.18 ms per step against 0.03 ms a minute later, enough to starve a 0.5 ms step).  More untimed steps,

@@ -338,15 +338,18 @@ def run_step(graphs, graphed, body_likelihood, exchange, body_update):
 
 
 class StepMode:
-    """Replay the captured step graph(s) or issue the same launches one by one?  The graph wins when Python's ~10 us per launch
-    is what limits the step (PACOH-MAP, small batches, slow hosts); when the host keeps ahead anyway -- a 0.5 ms step issued in
-    0.1 ms -- plain launches are 1-3 % faster on this ROCm (the replay leaves a slightly larger gap between its kernel nodes).  Both
-    produce identical bits, so the choice is made by timing the real training steps: a first look after PROBE steps of each kind
-    (the first steps of a process are not representative: cold host, clocks ramping), a second, longer one once 4 * REPROBE more
-    steps have run; plain launches are only chosen when they win by 3 %.  PACOH_GRAPH=1 / 0 forces a mode."""
+    """Replay the captured step graph(s) or issue the same launches one by one?  Both produce identical bits.  The graph is the
+    default and nearly always stays: it costs the host 0.003-0.01 ms per step (four steps per replay) against 0.1-0.2 ms for plain
+    launches, so that a busy host cannot starve the GPU -- on the shared test hosts plain launches measured anywhere between 1 %
+    faster than the replay (quiet host: the replay leaves a slightly larger gap between its kernel nodes on this ROCm) and 30 %
+    slower (a neighbour's job on the same cores: 0.566 against 0.427 ms per cfg #3 step).  Plain launches are therefore chosen only
+    when they beat the replay by 10 % in both looks' samples, which means that the replay itself is in trouble (a pathological
+    graph launch).  The looks time the real training steps: a first one after PROBE steps of each kind (the first steps of a process
+    are not representative: cold host, clocks ramping), a second, longer one once 4 * REPROBE more steps have run.
+    PACOH_GRAPH=1 / 0 forces a mode."""
     PROBE = 6
     REPROBE = 12
-    MARGIN = 0.97        # eager launches must beat the replay by 3 %: the replay frees the host (0.01-0.03 ms per step against 0.1-0.2)
+    MARGIN = 0.90        # plain launches must beat the replay by 10 % (see above)
 
     def __init__(self):
         self.use_graph = None
@@ -374,18 +377,31 @@ class StepMode:
         done = 0
         if not self.forced:
             n = 0
-            if self._looks == 0 and n_steps >= 5 * self.PROBE:
+            if self._looks == 0:
                 n = self.PROBE
-            elif self._looks == 1 and self._since >= 4 * self.REPROBE and n_steps >= 4 * self.REPROBE:
+            elif self._looks == 1 and self._since >= 4 * self.REPROBE:
                 n = self.REPROBE
-            if n:
+            # the replay is timed the way it will be used: several steps per graph launch where the learner has such a graph (a
+            # single-step replay pays the launch of the graph once per step -- on a slow host that alone decided for plain launches)
+            ng = n if replay_many is None else -(-n // GRAPH_STEPS) * GRAPH_STEPS
+            cost = 2 * (n + ng + (GRAPH_STEPS if replay_many is not None else 0))
+            if n and n_steps >= max(cost, 5 * n):
+                def graph_time():
+                    if replay_many is None:
+                        return self._time(step, True, ng)
+                    replay_many(GRAPH_STEPS)               # (not timed: first-use effects)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    replay_many(ng)
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t0) / ng
                 # (each kind twice, interleaved, the faster sample counts: one hiccup of the host or the clocks during a handful of
                 #  steps must not decide the mode for the rest of the run)
-                t = [min(pair) for pair in zip(*[[self._time(step, graphed, n) for graphed in (False, True)] for _ in range(2)])]
+                t = [min(pair) for pair in zip(*[[self._time(step, False, n), graph_time()] for _ in range(2)])]
                 self.timings = {'eager_ms': t[0] * 1e3, 'graph_ms': t[1] * 1e3, 'steps_each': n}
                 self.use_graph = not (t[0] < self.MARGIN * t[1])
                 self._looks += 1
-                done = 4 * n
+                done = cost
         graphed = True if self.use_graph is None else self.use_graph
         if graphed and replay_many is not None:
             replay_many(n_steps - done)
