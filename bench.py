@@ -68,7 +68,9 @@ def cpu_baseline(budget_s=12.0):
     """The CPU oracle (plain torch restatement of the reference's arithmetic, oracle/pacoh_oracle.py) on
     the host cores, on a bounded sample of the config-3 workload.  Reported baseline only."""
     from oracle import pacoh_oracle as O
-    cores = os.cpu_count() or 1
+    from meta_learning_pacoh_amd.util import host_cpu_budget
+    cores = host_cpu_budget()                              # (what the cgroup lets this process use, not the cores it can see)
+    threads_before = torch.get_num_threads()
     T_s = 32
     tasks = make_tasks(T_s, N_CTX, DIM)
     stats = O.compute_normalization_stats(tasks)
@@ -88,15 +90,15 @@ def cpu_baseline(budget_s=12.0):
         return T_s * PARTICLES * reps / (time.time() - t0)
 
     # small batched LAPACK/BLAS calls do not scale to every core of a big host: probe a few thread counts
-    cands = sorted({1, min(8, cores), min(32, cores), cores})
+    cands = sorted({1, min(4, cores), min(8, cores), cores})
     probe = {th: rate(False, th, budget_s / 8) for th in cands}
     best = max(probe, key=probe.get)
     batched = rate(False, best, budget_s / 4)
     looped = rate(True, best, budget_s / 4)
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads_before)
     return {'value': round(batched, 1), 'unit': 'evals/s', 'cores': best, 'kind': 'port',
             'sample': '%d tasks x %d particles (n=%d, d=%d, NN/NN, fp32) LML+autograd score with the CPU oracle, fully '
-                      'batched over tasks x particles, best of torch threads %s on a %d-core host (%s evals/s); '
+                      'batched over tasks x particles, best of torch threads %s with %d usable CPUs (cgroup quota; %s evals/s); '
                       'reference-style python loop over tasks at %d threads: %.1f evals/s'
                       % (T_s, PARTICLES, N_CTX, DIM, cands, cores, {k: round(v) for k, v in probe.items()}, best, looped)}
 
@@ -137,6 +139,13 @@ def main():
     if backend != 'nccl':
         os.environ['PACOH_SHARE_DEVICE'] = '1'
     torch.cuda.set_device(dev_index)
+    # Host side of the GPU job: a handful of intra-op threads, never more than this process's share of the CPUs it may really use.  The
+    # test hosts show 256 cores behind a cgroup quota of 16; torch's default pool (128 spinning workers) burnt that quota on the
+    # per-chunk staging copies and the kernel froze the process for tens of milliseconds at a time -- 0.43 ms steps measured as 0.50-0.57
+    # whenever such a freeze left the GPU idle in front of a short timed region (util.host_cpu_budget, tools/short_region_probe.py)
+    from meta_learning_pacoh_amd.util import host_cpu_budget
+    budget = max(1, host_cpu_budget() // max(1, world if backend == 'nccl' else 1))
+    torch.set_num_threads(max(1, min(4, budget, torch.get_num_threads())))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -194,7 +203,7 @@ def main():
     exchange = None if world == 1 else ('pacoh_allreduce_sum (RCCL) on the compute stream, captured in the step graph' if comm is not None
                                         else 'torch.distributed.all_reduce between two graphs per step')
 
-    pp = profile_pass(wl, L, min(args.steps, 50))
+    pp = profile_pass(wl, L, 50)                         # (its own step count: --steps 20 would make the per-kernel averages noisy)
     kernel_ms, kernel_sum, prof_ms = pp['kernel_ms'], pp['kernel_sum'], pp['ms_per_step']
     roofline, kernel_rooflines, step_flops = rooflines(wl, pp)
 
@@ -249,7 +258,7 @@ def profile_pass(wl, L, prof_steps):
     """per-kernel times with HIP events on the launch stream: the SAME launch sequence issued eagerly (PACOH_NO_GRAPH=1), and the
     wall time per step of that very pass"""
     os.environ['PACOH_NO_GRAPH'] = '1'
-    wl['run'](2)
+    wl['run'](6)
     torch.cuda.synchronize()
     L.PROFILE = {}
     t0 = time.perf_counter()

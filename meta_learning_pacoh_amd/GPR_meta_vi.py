@@ -171,7 +171,7 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         while n_steps > 0:
             k = min(n_steps, self._feed.chunk)
             idx_rows, sc_rows = self._draw_steps(k, self.lr_scheduler, self.opt_step + 1)
-            eps = torch.stack([standard_normal(S, D) for _ in range(k)])        # the reference's stream: one rsample per step
+            eps = [standard_normal(S, D) for _ in range(k)]                     # the reference's stream: one rsample per step
             self._feed.upload(idx_rows, sc_rows, eps)
             if graphed and self._graphs is None:
                 self._build_graphs()                      # (captured with real operands in the feed; state and counter are restored)

@@ -7,6 +7,7 @@ stream and owns the parameter layout.
 """
 import os
 import time
+import warnings
 from collections import OrderedDict
 
 import numpy as np
@@ -150,7 +151,17 @@ class StepFeed:
     the first launch of the captured step -- moves the current row into the fixed buffers idx / sc / aux the kernels read and
     advances the device-side counter."""
 
+    _warned_threads = False
+
     def __init__(self, device, dtype, tb, chunk=1024, aux_shape=None):
+        if not StepFeed._warned_threads:
+            StepFeed._warned_threads = True
+            from .util import host_cpu_budget
+            if torch.get_num_threads() > host_cpu_budget():
+                warnings.warn('torch uses %d intra-op CPU threads but this process may only use %d CPUs (affinity / cgroup quota): '
+                              'the spinning pool can get the whole process throttled and starve the GPU of launches -- call '
+                              'torch.set_num_threads(%d) or set OMP_NUM_THREADS' % (torch.get_num_threads(), host_cpu_budget(),
+                                                                                  min(4, host_cpu_budget())))
         chunk = max(int(chunk), GRAPH_STEPS)              # (a several-steps graph reads GRAPH_STEPS consecutive rows)
         self.device, self.dtype, self.tb, self.chunk = device, dtype, int(tb), int(chunk)
         rows = chunk + 1                                  # (the pipelined SVGD step fetches one row ahead: pipeline())
@@ -171,9 +182,16 @@ class StepFeed:
             self.aux = torch.zeros(tuple(aux_shape), dtype=dtype, device=device)
             self._h_aux = [torch.zeros((rows,) + tuple(aux_shape), dtype=dtype).pin_memory() for _ in range(2)]
         self._ev, self._slot = [None, None], 0
+        # the staging sets are FILLED through numpy views: plain memcpy on the calling thread.  torch's copy_ fans a 64 x 1024 index
+        # block out over its intra-op pool (128 spinning workers on the 256-core test hosts, which have a CPU quota of 16: the
+        # process was throttled for tens of milliseconds per chunk -- util.host_cpu_budget)
+        self._n_idx = [t.numpy() for t in self._h_idx]
+        self._n_sc = [t.numpy() for t in self._h_sc]
+        self._n_aux = [t.numpy() for t in self._h_aux] if self._h_aux is not None else None
 
     def upload(self, idx_rows, sc_rows, aux_rows=None):
-        """idx_rows: int array [k, tb]; sc_rows: k rows of L.step_scalars(); aux_rows: tensor [k, ...] | None; resets the counter"""
+        """idx_rows: int array [k, tb]; sc_rows: k rows of L.step_scalars(); aux_rows: tensor [k, ...] or k tensors [...] | None;
+        resets the counter"""
         k = len(sc_rows)
         assert 0 < k <= self.chunk
         q = self._slot
@@ -185,16 +203,23 @@ class StepFeed:
         # behind the one in flight), and they must see valid task indices and step scalars there -- not stale rows, not the zeros of a
         # fresh buffer (lr = 0 and bias correction 0 give NaN optimizer state)
         kk = max(k, GRAPH_STEPS) + 1
-        self._h_sc[q][:k].copy_(torch.as_tensor(np.asarray(sc_rows, dtype=np.float64)))
-        self._h_sc[q][k:kk] = self._h_sc[q][k - 1]
+        hs = self._n_sc[q]
+        hs[:k] = np.asarray(sc_rows, dtype=np.float64)
+        hs[k:kk] = hs[k - 1]
         self.sc_all[:kk].copy_(self._h_sc[q][:kk], non_blocking=True)
         if self.tb > 0:
-            self._h_idx[q][:k].copy_(torch.from_numpy(np.ascontiguousarray(idx_rows)).reshape(k, self.tb))
-            self._h_idx[q][k:kk] = self._h_idx[q][k - 1]
+            hi = self._n_idx[q]
+            hi[:k] = np.asarray(idx_rows).reshape(k, self.tb)
+            hi[k:kk] = hi[k - 1]
             self.idx_all[:kk].copy_(self._h_idx[q][:kk], non_blocking=True)
         if self.aux_all is not None:
-            self._h_aux[q][:k].copy_(aux_rows)
-            self._h_aux[q][k:kk] = self._h_aux[q][k - 1]
+            ha = self._n_aux[q]
+            if torch.is_tensor(aux_rows):
+                ha[:k] = aux_rows.numpy()
+            else:                                        # one tensor per step
+                for j, row in enumerate(aux_rows):
+                    ha[j] = row.numpy()
+            ha[k:kk] = ha[k - 1]
             self.aux_all[:kk].copy_(self._h_aux[q][:kk], non_blocking=True)
         self.ctr.zero_()
         self._ev[q] = self._ev[q] or torch.cuda.Event()

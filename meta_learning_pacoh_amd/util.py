@@ -70,3 +70,32 @@ class StepLR:
         if self.gamma >= 1.0:
             return np.full(k, self.base_lr, dtype=np.float64)
         return self.base_lr * self.gamma ** ((self.epoch + np.arange(k)) // self.step_size).astype(np.float64)
+
+
+def host_cpu_budget():
+    """CPUs this process may really use: the smaller of its affinity mask and its cgroup CPU quota (containers commonly show every
+    core of the host -- 256 on the MI355X boxes -- behind a quota of 16).  torch sizes its intra-op pool by the visible cores; its
+    workers spin between parallel regions, so a few medium-sized host-side tensor copies per chunk of steps were enough to burn the
+    quota, and the kernel then froze the whole process for tens of milliseconds at a time (tools/short_region_probe.py: 11 of 11
+    scheduler periods throttled, the GPU starved)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:                      # cgroup v2: "<quota|max> <period>"
+            q, per = fh.read().split()[:2]
+            if q != 'max':
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as fq, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as fp:
+                q, per = float(fq.read()), float(fp.read())
+                if q > 0 and per > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            quota = None
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)

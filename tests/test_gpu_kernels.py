@@ -715,6 +715,67 @@ def test_svgd_many_particles(L, P):
         assert relerr(Xd, X + lr * phi_p) < tol
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('P,optimizer,kernel', [(7, 'Adam', 'RBF'), (70, 'SGD', 'RBF'), (5, 'Adam', 'COS')])
+def test_pipelined_step_entry_points(L, dtype, P, optimizer, kernel):
+    """pacoh_svgd_dist_advance + pacoh_svgd_update_next (csrc/step_tail.h) through the ABI: counter protocol, the update against the
+    oracle's phi + torch optimizer with the scalars of the row the counter selects, softplus of the updated hyper-parameter entries,
+    the NEXT row's scalars and gathered (ragged) task batch -- two consecutive steps"""
+    from types import SimpleNamespace
+    g = torch.Generator().manual_seed(23 + P)
+    D, pf, T, n, d, tb, f = 61, 0.3, 9, 6, 2, 4, 3
+    off_ls, off_os, off_noise, floor = 50, 57, 58, 1e-3
+    X = torch.randn(P, D, generator=g, dtype=torch.float64)
+    mu, sd = torch.randn(D, generator=g, dtype=torch.float64), torch.rand(D, generator=g, dtype=torch.float64) + 0.5
+    tasks = SimpleNamespace(x=torch.randn(T, n, d, generator=g, dtype=torch.float64).to(dtype).to(DEV),
+                            y=torch.randn(T, n, generator=g, dtype=torch.float64).to(dtype).to(DEV),
+                            n_valid=torch.randint(1, n + 1, (T,), generator=g).to(torch.int32).to(DEV), ragged=True)
+    rows = 3
+    idx_all = torch.randint(0, T, (rows, tb), generator=g).to(DEV)
+    sc_rows = [L.step_scalars(0.5 + 0.1 * k, 1e-2 * 0.9 ** k, k + 1) for k in range(rows)]
+    sc_all = torch.tensor(sc_rows, dtype=dtype, device=DEV)
+    feed = SimpleNamespace(tb=tb, idx_all=idx_all, sc_all=sc_all, ctr=torch.full((1,), -1, dtype=torch.int64, device=DEV),
+                           sc2=torch.zeros(2, L.SC_COUNT, dtype=dtype, device=DEV),
+                           batch=SimpleNamespace(x=torch.zeros(tb, n, d, dtype=dtype, device=DEV), y=torch.zeros(tb, n, dtype=dtype, device=DEV),
+                                                 n_valid=torch.zeros(tb, dtype=torch.int32, device=DEV)),
+                           hyp=(torch.zeros(P, f, dtype=dtype, device=DEV), torch.zeros(P, dtype=dtype, device=DEV),
+                                torch.zeros(P, dtype=dtype, device=DEV)))
+    feed.sc2[0] = sc_all[0]                                   # (what the chunk's prologue leaves)
+    hyper = (off_ls, f, off_os, off_noise, floor, L.KERNEL_COSINE if kernel == 'COS' else L.KERNEL_RBF)
+    Xo = X.clone().requires_grad_(True)
+    opt = torch.optim.Adam([Xo], lr=1.0) if optimizer == 'Adam' else torch.optim.SGD([Xo], lr=1.0)
+    Xd, m, v = X.to(dtype).to(DEV), torch.zeros(P, D, dtype=dtype, device=DEV), torch.zeros(P, D, dtype=dtype, device=DEV)
+    ws, bw_out = L.svgd_update_workspace(Xd), torch.zeros(1, dtype=dtype, device=DEV)
+    tol = 3e-4 if dtype == torch.float32 else 1e-10
+    for k in range(2):
+        score = torch.randn(P, D, generator=g, dtype=torch.float64)
+        L.svgd_dist_advance(Xd, ws, feed.ctr)
+        assert int(feed.ctr) == k
+        d2 = ws.view(dtype)[:P * P].reshape(P, P).double().cpu()
+        assert relerr(d2, torch.cdist(Xo.detach(), Xo.detach()) ** 2) < (1e-5 if dtype == torch.float32 else 1e-12)
+        s_tot = sc_rows[k][0] * score + pf * (-(Xo.detach() - mu) / sd ** 2)
+        phi, bw_o = O.svgd_phi_closed_form(Xo.detach(), s_tot, None)
+        for grp in opt.param_groups:
+            grp['lr'] = sc_rows[k][1]
+        Xo.grad = -phi
+        opt.step()
+        L.svgd_update_next(Xd, score.to(dtype).to(DEV), mu.to(dtype).to(DEV), sd.to(dtype).to(DEV), pf, None, optimizer, m, v, ws,
+                           bw_out, feed, tasks, hyper)
+        assert int(feed.ctr) == k                             # (the update reads the counter, the next forward advances it)
+        assert abs(float(bw_out) - float(bw_o)) < 1e-5 * float(bw_o)
+        assert relerr(Xd, Xo.detach()) < tol
+        # hyper-parameters of the UPDATED particles, from the very values the kernel stored
+        sp = torch.nn.functional.softplus
+        ls_ref = sp(Xd[:, off_ls:off_ls + 1]).expand(P, f) if kernel == 'COS' else sp(Xd[:, off_ls:off_ls + f])
+        assert relerr(feed.hyp[0], ls_ref) < 1e-6 and relerr(feed.hyp[1], sp(Xd[:, off_os])) < 1e-6
+        assert relerr(feed.hyp[2], sp(Xd[:, off_noise]) + floor) < 1e-6
+        # the next row: scalars in the other ping-pong row, tasks gathered
+        assert torch.equal(feed.sc2[(k + 1) & 1], sc_all[k + 1]) and torch.equal(feed.sc2[k & 1], sc_all[k])
+        nxt = idx_all[k + 1]
+        assert torch.equal(feed.batch.x, tasks.x[nxt]) and torch.equal(feed.batch.y, tasks.y[nxt])
+        assert torch.equal(feed.batch.n_valid, tasks.n_valid[nxt])
+
+
 # ------------------------------------------------------------------------------------------ predictive cdf / quantiles / calibration
 def test_mixture_cdf_icdf_calib_match_reference_fixture(L, golden_dir):
     """pacoh_mixture_cdf / _icdf / pacoh_calib_error vs EqualWeightedMixtureDist.cdf / .icdf, AffineTransformedDistribution and

@@ -218,3 +218,18 @@ def test_failed_cholesky_on_another_rank_raises_on_every_rank(monkeypatch):
     with pytest.raises(NotPSDError):
         _RandomGPLearner._check_numerics(flagged)
     assert int(flagged._fail) == 0                             # (reset, as before)
+
+
+def test_host_cpu_budget_is_within_the_visible_cores():
+    """util.host_cpu_budget: affinity mask capped by the cgroup quota -- what bench.py and the test session size torch's intra-op
+    pool by (256 visible cores behind a quota of 16 got the spinning pool throttled and the GPU starved)"""
+    import os
+    from meta_learning_pacoh_amd.util import host_cpu_budget
+    b = host_cpu_budget()
+    assert isinstance(b, int) and 1 <= b <= (os.cpu_count() or 1)
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            assert b <= max(1, int(float(q) / float(per)))
+    except OSError:
+        pass
