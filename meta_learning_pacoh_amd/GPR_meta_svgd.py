@@ -104,9 +104,14 @@ class _RandomGPLearner(RegressionModelMetaLearned):
         """task draws (this rank's shard) and step scalars of the next k steps, vectorised: one randint call of shape [k, B] consumes
         the numpy stream exactly like k calls of size B (GPR_meta_svgd.py:102 draws one batch per iteration)"""
         idx = self.rds_numpy.randint(0, self.tasks.T, size=(k, self.task_batch_size))
-        sizes = self.tasks.sizes[idx].astype(np.float32)                       # harmonic pre-factor per step (random_gp.py:209-212)
+        # harmonic pre-factor per step (random_gp.py:209-212); tasks of one size: every row is the same computation on the same
+        # numbers -- done once
+        rows = idx if self.tasks.ragged else idx[:1]
+        sizes = self.tasks.sizes[rows].astype(np.float32)
         hm = np.float32(1.0) / np.mean(np.float32(1.0) / sizes, axis=1, dtype=np.float32)
         pre = (hm / (hm + np.float32(self.task_batch_size))).astype(np.float64)
+        if not self.tasks.ragged:
+            pre = np.repeat(pre, k)
         sc_rows = L.step_scalar_rows(pre, lr_scheduler.lrs(k), first_step, weight_decay=weight_decay)
         rank, world = parallel.world()
         local = np.ascontiguousarray(idx[:, rank::world])

@@ -221,7 +221,7 @@ class StepFeed:
                     ha[j] = row.numpy()
             ha[k:kk] = ha[k - 1]
             self.aux_all[:kk].copy_(self._h_aux[q][:kk], non_blocking=True)
-        self.ctr.zero_()
+        self.ctr.fill_(-1 if self.sc2 is not None else 0)      # (pipelined step: the first forward makes it 0 -- prologue())
         self._ev[q] = self._ev[q] or torch.cuda.Event()
         self._ev[q].record()
 
@@ -243,19 +243,18 @@ class StepFeed:
                     torch.empty(P, dtype=theta.dtype, device=theta.device))
         self.hyper = (off_ls, f, off_os, off_noise, engine.noise_floor, engine.layout.kernel_code)
         self.sc2 = torch.zeros(2, L.SC_COUNT, dtype=self.dtype, device=self.device)
+        self._row0 = torch.zeros(1, dtype=torch.int64, device=self.device)      # constant: the prologue works on row 0
         self._pipe = (tasks, theta)
 
     def prologue(self):
-        """row 0 of the uploaded chunk into the batch buffers and sc2[0], the hyper-parameters of the particles as they are now,
-        counter = -1 (the forward of the first step makes it 0): one launch + one fill, once per chunk -- not part of the step"""
+        """row 0 of the uploaded chunk into the batch buffers and sc2[0], the hyper-parameters of the particles as they are now: one
+        launch, once per chunk -- not part of the step.  (upload() has left the counter at -1: the forward of the first step makes it 0)"""
         tasks, theta = self._pipe
-        self.ctr.zero_()
-        sc, self.sc = self.sc, self.sc2[0]
+        sc, ctr, self.sc, self.ctr = self.sc, self.ctr, self.sc2[0], self._row0     # (step_begin reads its row number from feed.ctr)
         try:
             L.step_begin(self, tasks, (self.batch.x, self.batch.y, self.batch.n_valid), theta, self.hyper, self.hyp, advance=False)
         finally:
-            self.sc = sc
-        self.ctr.fill_(-1)
+            self.sc, self.ctr = sc, ctr
 
     def select(self):
         L.step_select(self.idx_all, self.sc_all, self.ctr, self.idx, self.sc, self.aux_all, self.aux)
@@ -330,7 +329,8 @@ def build_step_graphs(body_likelihood, exchange, body_update, feed, many_ok=True
     parallel.collective_in_graph()), else ((likelihood, update), None) around the eager torch.distributed call"""
     def rewind():
         if feed.sc2 is not None:
-            feed.prologue()                               # pipelined SVGD step: row 0 fetched again, counter = -1
+            feed.ctr.fill_(-1)                            # pipelined SVGD step: row 0 fetched again, counter = -1
+            feed.prologue()
         else:
             feed.ctr.zero_()
     if parallel.collective_in_graph():
