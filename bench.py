@@ -174,7 +174,7 @@ def main():
     prev, t_warm = None, time.perf_counter()
     for _ in range(40):
         t_c = time.perf_counter()
-        wl['run'](64)
+        wl['run'](128)                                    # (16 + 112 steps: engine.first_chunk; the second look needs a chunk of >= 60)
         barrier()
         cur = time.perf_counter() - t_c
         stable = prev is not None and abs(cur - prev) <= 0.03 * prev and time.perf_counter() - t_warm >= 1.0
@@ -302,12 +302,12 @@ def rooflines(wl, pp):
 
 
 def other_config_leg(cfg, M, L, steps=256):
-    """one of BASELINE.json's other configurations, timed like the headline one but bounded (about 2-3 s): three untimed 64-step
+    """one of BASELINE.json's other configurations, timed like the headline one but bounded (about 2-3 s): three untimed (64 / 128 / 64-step)
     calls (both looks of the learners at graph replay vs plain launches -- engine.StepMode -- happen there, not in the timed
     region), `steps` timed ones between synchronisations (two 128-step noise chunks of PACOH-VI), then the eager per-kernel pass"""
     wl = WORKLOADS[cfg](1, 'weak', M, L)
-    for _ in range(3):
-        wl['run'](64)
+    for n in (64, 128, 64):
+        wl['run'](n)
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     wl['run'](steps)

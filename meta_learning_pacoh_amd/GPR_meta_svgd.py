@@ -12,7 +12,8 @@ from . import _lib as L
 from . import parallel
 from .abstract import RegressionModelMetaLearned
 from .distributions import GaussianPredictive
-from .engine import AsyncUploader, GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, build_step_graphs, replay_steps, run_step
+from .engine import (AsyncUploader, GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, build_step_graphs, first_chunk,
+                     replay_steps, run_step)
 from .util import StepLR
 
 
@@ -266,8 +267,10 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         """the next n_steps SVGD steps of the training loop (task draws from rds_numpy, lr from the scheduler)"""
         self._setup_step(self._local_batch_size())
         graphed = self._graphs_allowed()
+        first = True
         while n_steps > 0:
-            k = min(n_steps, self.GRAPH_CHUNK)
+            k = first_chunk(n_steps, self.GRAPH_CHUNK) if first else min(n_steps, self.GRAPH_CHUNK)
+            first = False
             idx_rows, sc_rows = self._draw_steps(k, self.lr_scheduler, self.opt_step + 1)
             self._feed.upload(idx_rows, sc_rows)
             if self._pipelined:

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib as L
 from . import parallel
-from .engine import AsyncUploader, StepFeed, StepMode, build_step_graphs, replay_steps, run_step
+from .engine import AsyncUploader, StepFeed, StepMode, build_step_graphs, first_chunk, replay_steps, run_step
 from .GPR_meta_svgd import _RandomGPLearner
 from .util import StepLR
 
@@ -168,8 +168,10 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         self._setup_step(self._local_batch_size())
         graphed = self._graphs_allowed()
         S, D = self.svi_batch_size, self.layout.D
+        first = True
         while n_steps > 0:
-            k = min(n_steps, self._feed.chunk)
+            k = first_chunk(n_steps, self._feed.chunk) if first else min(n_steps, self._feed.chunk)
+            first = False
             idx_rows, sc_rows = self._draw_steps(k, self.lr_scheduler, self.opt_step + 1)
             eps = [standard_normal(S, D) for _ in range(k)]                     # the reference's stream: one rsample per step
             self._feed.upload(idx_rows, sc_rows, eps)

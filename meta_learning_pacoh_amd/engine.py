@@ -290,6 +290,18 @@ GRAPH_STEPS = 4      # steps per graph of the second graph the learners capture 
                      # when the host is busy with somebody else's job; tools/graph_steps_probe.py)
 
 
+FIRST_CHUNK = 16     # steps in the first chunk of a call that has many more to issue (first_chunk)
+
+
+def first_chunk(n_steps, chunk):
+    """size of the FIRST chunk of a training call: the host prepares a chunk (task draws, step scalars, PACOH-VI's noise: 0.15 ms
+    per step) before it can issue any of its steps, and while it prepares chunk k + 1 the GPU runs chunk k -- except for the first
+    one, in front of which the GPU idles (meta_fit synchronises at every log line).  A small first chunk gets it started: 1.4 ms
+    (SVGD, 200 steps) / 19 ms (VI, 128 steps) of idle time become 0.1 / 2.4 ms at the price of one more upload"""
+    k = min(n_steps, chunk)
+    return FIRST_CHUNK if n_steps >= 4 * FIRST_CHUNK and k > FIRST_CHUNK else k
+
+
 def replay_steps(n, graph_one, graph_many):
     """n steps through graph_many (GRAPH_STEPS steps per replay) and graph_one (the remainder)"""
     if graph_many is not None:

@@ -668,6 +668,28 @@ def test_pipelined_svgd_step_equals_the_step_begin_sequence(M, cfg, graph, monke
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
 
 
+@pytest.mark.parametrize('kind', ['svgd', 'vi'])
+def test_small_first_chunk_does_not_change_the_run(M, kind, monkeypatch):
+    """engine.first_chunk: a training call with many steps to issue starts with a chunk of 16 (the GPU gets work while the host
+    prepares the rest); the task draws, PACOH-VI's noise and the schedule are consumed in the same order either way: same bits"""
+    from meta_learning_pacoh_amd import engine
+    rs = np.random.RandomState(5)
+    tasks = [(x, np.sin(x[:, :1]) + 0.3 * x[:, 1:] + 0.05 * rs.randn(10, 1)) for x in (rs.uniform(-3, 3, size=(10, 2)) for _ in range(6))]
+    out = []
+    for first in (16, 10 ** 9):
+        monkeypatch.setattr(engine, 'FIRST_CHUNK', first)
+        sizes = []
+        real = engine.StepFeed.upload
+        monkeypatch.setattr(engine.StepFeed, 'upload', lambda self, idx, sc, aux=None: (sizes.append(len(sc)), real(self, idx, sc, aux))[1])
+        m, res = _fit(M, kind, tasks, 80)                       # log_period 3 ... chunks of <= 3 steps
+        m._train_steps(90)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(engine.StepFeed, 'upload', real)
+        assert (sizes[-2:] == [16, 74]) if first == 16 else (sizes[-1] == 90)
+        out.append((m.particles if kind == 'svgd' else m.posterior).clone())
+    assert bool(torch.isfinite(out[0]).all()) and torch.equal(out[0], out[1])
+
+
 def test_launcher_networks_run_through_the_learners(M):
     """experiments/meta_GPR_SVGD_base_exp.py:29-30,83 (4 x 32, 10 particles, bandwidth 0.1, prior_factor 0.1, 2 tasks per step) and
     experiments/meta_GPR_mll_base_exp.py:29-30 (4 x 128, 2 tasks x 5 points per step): construct, train a few steps, predict; the
