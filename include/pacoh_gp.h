@@ -215,7 +215,8 @@ int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta, long theta
                          void* workspace, const void* stash, int B, int n,
                          int T, int off_ls, int f, int off_os, int off_noise, int off_const, const void* d_lengthscale,
                          const void* d_outputscale, const void* d_noise, const void* d_const, const void* lml, void* lik,
-                         double lik_scale, const int32_t* info, int32_t* fail_flag, int dtype, void* stream);
+                         double lik_scale, const int32_t* info, int32_t* fail_flag, void* svgd_workspace, int svgd_P, int svgd_D,
+                         int dtype, void* stream);
 
 /* ---- A3 + A7: parameter transforms, hyper-prior ------------------------------------------------
  * softplus with optional floor, forward:  out = log(1+exp(raw)) + floor            (random_gp.py:69-74;
@@ -238,11 +239,16 @@ int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int
  * Deterministic (fixed summation order).
  * info[T*P] / fail_flag (both or neither): the per-problem status of pacoh_gp_lml_fwdbwd rides along; *fail_flag |= 1 if any
  * problem's Cholesky failed even with jitter -- where gpytorch's psd_safe_cholesky raises NotPSDError; the host reads the flag
- * at its next synchronisation point and raises there. */
+ * at its next synchronisation point and raises there.
+ * svgd_workspace (optional; pacoh_svgd_update_dev_workspace_bytes(svgd_P, svgd_D), svgd_P <= 64): one more workgroup of this launch
+ * computes the SVGD step's median-heuristic bandwidth (svgd.py:45-51) from the particles' distance matrix at the head of that
+ * workspace into the workspace's bandwidth slot, where pacoh_svgd_update_next(bandwidth_ready = 1) picks it up: the register sort
+ * (7 us of the update's dependent chain, behind the all-reduce at N > 1) runs beside the reduction instead. */
 int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int T, int off_ls, int f, int off_os, int off_noise,
                     int off_const, const void* d_ls, const void* d_os, const void* d_noise, const void* d_const,
                     void* grad, long grad_stride, const void* lml, void* lik, double lik_scale,
-                    const int32_t* info, int32_t* fail_flag, int dtype, void* stream);
+                    const int32_t* info, int32_t* fail_flag, void* svgd_workspace, int svgd_P, int svgd_D,
+                    int dtype, void* stream);
 
 /* logp[p] = sum_d log N(theta[p,d]; prior_mean[d], prior_std[d]);  grad[p,d] (optional, += scaled):
  * grad += grad_scale * d logp / d theta.  Replaces CatDist.log_prob over the Normal blocks
@@ -328,7 +334,8 @@ int pacoh_svgd_update_dev(void* X, const void* score, const void* prior_mean, co
  *     threads write softplus of the hyper-parameter entries they have just updated to ls[P,f] / os[P] / noise[P] (ls = NULL: not
  *     wanted), and extra workgroups of the launch copy row *counter + 1 of sc_all into sc2[(*counter + 1) & 1] and gather that
  *     row's tb tasks (idx_all[row, tb]; x[T,n,d], y[T,n], optional n_valid) into out_x / out_y / out_n_valid: idx_all and sc_all
- *     must hold one valid row beyond the last step of the chunk.
+ *     must hold one valid row beyond the last step of the chunk.  bandwidth_ready != 0 (bandwidth <= 0, P <= 64): the median
+ *     bandwidth is read from the workspace's bandwidth slot (pacoh_hyper_bwd / pacoh_mlp2_bwd_hyper with svgd_workspace).
  * Replaces, together: the softplus transforms of the raw hyper-parameters (random_gp.py:69-74), the gather of the drawn task
  * batch (GPR_meta_svgd.py:102) and the pairwise distances of SVGD.phi / RBF_Kernel (svgd.py:12-59) as separate launches. */
 int pacoh_svgd_dist_advance(const void* X, void* workspace, int P, int D, int64_t* counter, int dtype, void* stream);
@@ -344,7 +351,7 @@ int pacoh_svgd_update_next(void* X, const void* score, const void* prior_mean, c
                            const void* x, const void* y, const int32_t* n_valid, void* out_x, void* out_y,
                            int32_t* out_n_valid, int n, int d,
                            int off_ls, int f, int off_os, int off_noise, double noise_floor, void* ls, void* os, void* noise,
-                           int dtype, void* stream);
+                           int bandwidth_ready, int dtype, void* stream);
 
 /* Same update direction with the IMQ particle kernel k_ij = (alpha + sum_d (X_jd - X_id)^2 / h_d)^beta
  * (alpha > 0, beta < 0).  bandwidth > 0: h_d = bandwidth for every d.  bandwidth <= 0: per-dimension median

@@ -215,13 +215,15 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         self._pipelined = tb_local > 0 and os.environ.get('PACOH_SVGD_PIPELINE', '1') != '0'
         if self._pipelined:
             self._feed.pipeline(self.tasks, self.engine, self.particles)
+        # median bandwidth computed beside the hyper-parameter reduction instead of inside the update (P <= 64: one wavefront's sort)
+        self._bw_ahead = self._pipelined and self.bandwidth is None and P <= 64 and os.environ.get('PACOH_SVGD_BW_AHEAD', '1') != '0'
 
     def _body_likelihood(self):
         """score[P,D] = d/d theta_p sum_t mll[t,p] over this rank's tasks (unscaled), lik[P] the sums themselves"""
         if self._pipelined:
             self.engine.lml_and_grad(self.particles, self._feed.batch, weight=1.0, lik_out=self._lik, lik_scale=1.0,
                                      grad_out=self._score, fail_flag=self._fail, hypers=self._feed.hyp,
-                                     svgd_tail=(self.particles, self._svgd_ws, self._feed.ctr))
+                                     svgd_tail=(self.particles, self._svgd_ws, self._feed.ctr, self._bw_ahead))
             return
         # select + gather + hyper transforms + the particles' distance matrix: one launch; the counter is advanced by the update
         batch, hyp = self._feed.begin(self.tasks, self.engine, self.particles, advance=False, svgd=(self.particles, self._svgd_ws))
@@ -238,7 +240,7 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         if self._pipelined:
             L.svgd_update_next(self.particles, self._score, self.prior_mean, self.prior_std, self.prior_factor, self.bandwidth,
                                self.optimizer_name, self.exp_avg, self.exp_avg_sq, self._svgd_ws, self._bw_out, self._feed, self.tasks,
-                               self._feed.hyper)
+                               self._feed.hyper, bandwidth_ready=self._bw_ahead)
             return
         _, self._svgd_ws = L.svgd_update_dev(self.particles, self._score, self.prior_mean, self.prior_std, self.prior_factor,
                                              self.bandwidth, self.optimizer_name, self._feed.sc, self.exp_avg, self.exp_avg_sq,

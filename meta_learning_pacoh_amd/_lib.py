@@ -58,11 +58,11 @@ SIGNATURES = {
     'pacoh_mlp2_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_mlp2_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_mlp2_bwd_hyper': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _i,
-                                  _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _i, _vp]),
+                                  _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_softplus_fwd': (_i, [_vp, _vp, _d, _l, _i, _vp]),
     'pacoh_softplus_bwd': (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),
     'pacoh_hyper_fwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
-    'pacoh_hyper_bwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _d, _vp, _vp, _i, _vp]),
+    'pacoh_hyper_bwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _d, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_step_select': (_i, [_vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _i, _vp]),
     'pacoh_scale_dev': (_i, [_vp, _vp, _l, _i, _vp]),
     'pacoh_step_begin': (_i, [_vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
@@ -72,7 +72,7 @@ SIGNATURES = {
     'pacoh_svgd_dist_advance': (_i, [_vp, _vp, _i, _i, _vp, _i, _vp]),
     'pacoh_svgd_update_next': (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _d, _d, _vp, _vp, _vp, _vp, _i, _i,
                                     _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
-                                    _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
+                                    _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _i, _vp]),
     'pacoh_prior_logprob_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
     'pacoh_svgd_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_phi': (_i, [_vp, _vp, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -100,7 +100,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 5              # pacoh_abi_version() of the library this table was written for
+ABI_VERSION = 6              # pacoh_abi_version() of the library this table was written for
 
 
 def load_library():
@@ -531,8 +531,9 @@ def mlp2_bwd(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, g_a, off_b, d_out
 
 def mlp2_bwd_hyper(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, g_a, off_b, d_out_b, g_b, d_theta, B, n, T, off_ls, f, off_os,
                    off_noise, off_const, d_ls, d_os, d_noise, d_const, lml=None, lik=None, lik_scale=1.0, info=None, fail_flag=None,
-                   workspace=None, stash=None):
-    """mlp2_bwd + hyper_bwd (grad = d_theta) in one C-ABI call: the gradient epilogue of a step; returns the workspace for reuse"""
+                   workspace=None, stash=None, svgd_bw=None):
+    """mlp2_bwd + hyper_bwd (grad = d_theta) in one C-ABI call: the gradient epilogue of a step; returns the workspace for reuse.
+    svgd_bw = (SVGD workspace, P, D): the step's median bandwidth is computed by one more workgroup (hyper_bwd)"""
     lib = load_library()
     harr, code = _hidden_arr(hidden), dtype_code(x)
     need = lib.pacoh_mlp2_bwd_workspace_bytes(B, P, n, d_in, harr, len(hidden), d_out_a, d_out_b, code)
@@ -544,8 +545,17 @@ def mlp2_bwd_hyper(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, g_a, off_b,
                                         _ptr(workspace), _ptr(stash), B, n, T, off_ls, f, off_os, off_noise, off_const,
                                         _ptr(d_ls, x), _ptr(d_os, x), _ptr(d_noise, x), _ptr(d_const, x), _ptr(lml, x), _ptr(lik, x),
                                         float(lik_scale), _ptr(info if fail_flag is not None else None),
-                                        _ptr(fail_flag if info is not None else None), code, _stream()), 'pacoh_mlp2_bwd_hyper')
+                                        _ptr(fail_flag if info is not None else None), *_svgd_bw(svgd_bw), code, _stream()),
+               'pacoh_mlp2_bwd_hyper')
     return workspace
+
+
+def _svgd_bw(svgd_bw):
+    """(workspace pointer, P, D) arguments of the optional bandwidth block"""
+    if svgd_bw is None:
+        return None, 0, 0
+    ws, P, D = svgd_bw
+    return _ptr(ws), int(P), int(D)
 
 
 def softplus_fwd(raw, floor=0.0):
@@ -581,9 +591,11 @@ def hyper_fwd(theta, off_ls, f, off_os, off_noise, noise_floor, kernel=KERNEL_RB
 
 
 def hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, grad, lml=None, lik=None,
-              lik_scale=1.0, info=None, fail_flag=None, kernel=KERNEL_RBF):
+              lik_scale=1.0, info=None, fail_flag=None, kernel=KERNEL_RBF, svgd_bw=None):
     """lml [T*P] and lik [P] (both or neither): lik[p] = lik_scale * sum_t lml[t, p] in the same launch;
-    info [T*P] and fail_flag [1] (int32, both or neither): fail_flag |= any(info < 0)"""
+    info [T*P] and fail_flag [1] (int32, both or neither): fail_flag |= any(info < 0);
+    svgd_bw = (SVGD workspace, P, D), P <= 64: one more workgroup computes the SVGD step's median bandwidth from the distance matrix
+    in that workspace into its bandwidth slot (svgd_update_next(bandwidth_ready=True))"""
     lib = load_library()
     P, D = theta.shape
     with _Timed('hyper_bwd'):
@@ -591,7 +603,7 @@ def hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_n
                                    _ptr(d_os, theta), _ptr(d_noise, theta), _ptr(d_const, theta), _ptr(grad, theta),
                                    grad.shape[1], _ptr(lml, theta), _ptr(lik, theta), float(lik_scale),
                                    _ptr(info if fail_flag is not None else None), _ptr(fail_flag if info is not None else None),
-                                   dtype_code(theta), _stream()), 'pacoh_hyper_bwd')
+                                   *_svgd_bw(svgd_bw), dtype_code(theta), _stream()), 'pacoh_hyper_bwd')
 
 
 def prior_logprob_grad(theta, prior_mean, prior_std, grad=None, grad_scale=1.0):
@@ -759,7 +771,7 @@ def svgd_dist_advance(X, workspace, counter):
 
 
 def svgd_update_next(X, score, prior_mean, prior_std, prior_factor, bandwidth, optimizer, exp_avg, exp_avg_sq, workspace, bw_out,
-                     feed, tasks, hyper, beta1=0.9, beta2=0.999):
+                     feed, tasks, hyper, beta1=0.9, beta2=0.999, bandwidth_ready=False):
     """the update of a pipelined SVGD step (include/pacoh_gp.h, "The pipelined SVGD step"): svgd_update_dev(dist_done) with the
     scalars of feed.sc2[counter & 1]; writes the updated particles' transformed hyper-parameters into feed.hyp with hyper =
     (off_ls, f, off_os, off_noise, noise_floor, kernel) and fetches the next row's scalars and task batch into feed.sc2 / feed.batch"""
@@ -781,7 +793,7 @@ def svgd_update_next(X, score, prior_mean, prior_std, prior_factor, bandwidth, o
                                           _ptr(feed.ctr), _ptr(feed.sc2, X), feed.sc2.shape[1], _ptr(feed.idx_all), feed.tb,
                                           _ptr(feed.sc_all, X), _ptr(x, X), _ptr(y, X), _ptr(nv), _ptr(ox), _ptr(oy), _ptr(onv), n, d,
                                           off_ls, _kf(f, kernel), off_os, off_noise, float(floor), _ptr(ls), _ptr(os_), _ptr(noise),
-                                          dtype_code(X), _stream()), 'pacoh_svgd_update_next')
+                                          int(bool(bandwidth_ready)), dtype_code(X), _stream()), 'pacoh_svgd_update_next')
 
 
 def svgd_phi_imq(X, score, alpha=0.5, beta=-0.5, bandwidth=None, neg=False, workspace=None):

@@ -4,6 +4,7 @@
 // workgroups of the MLP backward's slab reduction (mlp_fused.hip: one launch and one launch boundary less per step).
 #pragma once
 #include "common.h"
+#include "step_tail.h"
 
 namespace pacoh {
 
@@ -16,7 +17,13 @@ struct HyperBwdArgs {
     const int32_t* info; int32_t* fail_flag;
     int tie;                  // kernel families with ONE raw scale for all f dimensions (PACOH_KERNEL_COSINE): grad[off_ls] takes the
                               // sum over the f per-dimension gradients, the entries behind it do not exist
+    const T* sv_d2; int sv_P; T* sv_bw;      // SVGD: ONE more virtual block computes the step's median-heuristic bandwidth from the
+                                             // particles' distance matrix (step_tail.h, svgd_bandwidth_block) | sv_bw = nullptr
 };
+
+// virtual blocks of the reduction itself, and with the optional bandwidth block behind them
+template <typename T> __host__ __device__ inline int hyper_bwd_blocks(const HyperBwdArgs<T>& a) { return a.P * (a.f + 4); }
+template <typename T> __host__ __device__ inline int hyper_tail_blocks(const HyperBwdArgs<T>& a) { return hyper_bwd_blocks(a) + (a.sv_bw ? 1 : 0); }
 
 template <typename T> __device__ __forceinline__ T hyper_sigmoid(T x) { return x > T(20) ? T(1) : T(1) / (T(1) + t_exp<T>(-x)); }
 
@@ -56,6 +63,13 @@ __device__ __forceinline__ void hyper_bwd_block(const HyperBwdArgs<T>& a, int w,
         const T chain = (e == a.f + 2) ? T(1) : hyper_sigmoid<T>(a.theta[(long)p * a.stride + off]);
         a.grad[(long)p * a.gstride + off] = s * chain;
     }
+}
+
+// block w of hyper_tail_blocks(a): the reduction's blocks, then the bandwidth block
+template <typename T>
+__device__ __forceinline__ void hyper_tail_block(const HyperBwdArgs<T>& a, int w, T* red) {
+    if (w < hyper_bwd_blocks(a)) hyper_bwd_block<T>(a, w, red);
+    else if (a.sv_bw) svgd_bandwidth_block<T>(a.sv_d2, a.sv_P, a.sv_bw);
 }
 
 }  // namespace pacoh

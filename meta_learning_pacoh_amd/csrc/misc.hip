@@ -51,7 +51,7 @@ __global__ void hyper_fwd_kernel(const T* __restrict__ theta, long stride, int P
 template <typename T>
 __global__ void __launch_bounds__(256) hyper_bwd_kernel(HyperBwdArgs<T> a) {
     __shared__ T red[4];
-    hyper_bwd_block<T>(a, blockIdx.x, red);               // (hyper_tail.h: shared with the slab reduction of the fused MLP backward)
+    hyper_tail_block<T>(a, blockIdx.x, red);              // (hyper_tail.h: shared with the slab reduction of the fused MLP backward)
 }
 
 // ---- hyper-prior: independent Normals over all D entries ----------------------------------------
@@ -92,77 +92,8 @@ __global__ void __launch_bounds__(256) svgd_dist_kernel(const T* __restrict__ X,
 template <typename T>
 __global__ void __launch_bounds__(256) svgd_dist_advance_kernel(SvgdDistTail<T> t) { svgd_dist_tail<T>(t, (int)blockIdx.x, (int)gridDim.x); }
 
-// Median of the full PxP squared-distance matrix (numpy.median semantics) from its P(P-1)/2 distinct off-diagonal entries:
-// the sorted full matrix is P zeros followed by every pair value twice, so entry m of it is 0 for m < P and u[(m-P)/2]
-// otherwise (u = sorted pair values).  u is sorted by ONE wavefront entirely in registers: VPL values per lane, bitonic
-// network with lane exchanges by shuffle and register exchanges for strides >= 64 -- no LDS, no barriers (the 512-element LDS
-// bitonic sort this replaces spent 45 barrier rounds = 16.5 us on it at P = 20; this takes ~1.5 us).
-template <typename T, int VPL>
-__device__ __forceinline__ T wave_median_full_matrix(const T* __restrict__ d2, int P, int lane) {
-    constexpr int NV = 64 * VPL;
-    const int npairs = P * (P - 1) / 2;
-    T v[VPL];
-#pragma unroll
-    for (int q = 0; q < VPL; ++q) {
-        const int e = q * 64 + lane;
-        T val = T(INFINITY);
-        if (e < npairs) {
-            // pair index e -> (i, j), i < j, row-major over the strict upper triangle
-            int i = (int)((T(2 * P - 1) - t_sqrt<T>(T((2 * P - 1) * (2 * P - 1) - 8 * e))) * T(0.5));
-            while (i > 0 && i * (2 * P - i - 1) / 2 > e) --i;
-            while ((i + 1) * (2 * P - i - 2) / 2 <= e) ++i;
-            const int j = i + 1 + (e - i * (2 * P - i - 1) / 2);
-            val = d2[i * P + j];
-        }
-        v[q] = val;
-    }
-#pragma unroll
-    for (int k = 2; k <= NV; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 64) {                           // partner in another register of the same lane
-                const int dq = j >> 6;
-#pragma unroll
-                for (int q = 0; q < VPL; ++q) {
-                    if ((q & dq) == 0) {
-                        const bool up = (((q * 64) & k) == 0);           // e & k depends only on q here (k > j >= 64)
-                        const T a = v[q], c = v[q | dq];
-                        const bool sw = (a > c) == up;
-                        v[q] = sw ? c : a; v[q | dq] = sw ? a : c;
-                    }
-                }
-            } else {                                 // partner lane = lane ^ j
-#pragma unroll
-                for (int q = 0; q < VPL; ++q) {
-                    const int e = q * 64 + lane;
-                    const T other = shfl_xor_t<T>(v[q], j);
-                    const bool up = (e & k) == 0;
-                    const bool lower = (lane & j) == 0;
-                    const T mn = v[q] < other ? v[q] : other, mx = v[q] < other ? other : v[q];
-                    v[q] = (lower == up) ? mn : mx;
-                }
-            }
-        }
-    }
-    const int N = P * P;
-    T mids[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int m = h == 0 ? (N - 1) / 2 : N / 2;
-        T val = T(0);
-        if (m >= P) {
-            const int kidx = (m - P) >> 1;
-            const int src_lane = kidx & 63, src_q = kidx >> 6;
-            T pick = T(0);
-#pragma unroll
-            for (int q = 0; q < VPL; ++q) pick = (q == src_q) ? v[q] : pick;
-            val = __shfl(pick, src_lane, 64);
-        }
-        mids[h] = val;
-    }
-    return (mids[0] + mids[1]) * T(0.5);
-}
-
+// (wave_median_full_matrix -- the median of the full PxP matrix by one wavefront -- lives in step_tail.h: the step's bandwidth is
+// computed ahead of the update by a workgroup riding in the hyper-parameter reduction, svgd_bandwidth_block)
 // More than 64 particles (the register sort above holds 2048 pair values): the two middle order statistics of the full matrix by
 // bisection on the IEEE bit pattern (monotone for values >= 0), one 1024-thread workgroup per statistic: per round every thread
 // counts its share of the pairs below the candidate straight from d2 (L2-resident), 31 / 63 rounds.  mids[h] receives entry
@@ -310,14 +241,9 @@ __global__ void __launch_bounds__(256) svgd_update_kernel(const T* __restrict__ 
         const int lane = threadIdx.x;
         T bw = bandwidth;
         if (!(bandwidth > T(0))) {
-            const int npairs = P * (P - 1) / 2;
-            T med;
-            if (mids) med = (mids[0] + mids[1]) * T(0.5);                    // P > 64: svgd_median_large_kernel ran in front
-            else if (npairs <= 256) med = wave_median_full_matrix<T, 4>(d2, P, lane);
-            else if (npairs <= 512) med = wave_median_full_matrix<T, 8>(d2, P, lane);
-            else if (npairs <= 1024) med = wave_median_full_matrix<T, 16>(d2, P, lane);
-            else med = wave_median_full_matrix<T, 32>(d2, P, lane);
-            bw = t_sqrt<T>(med / (T(2) * t_log<T>(T(P + 1))));
+            if (nx.bw_pre) bw = *nx.bw_pre;                                  // computed ahead, beside the hyper-parameter reduction
+            else if (mids) bw = t_sqrt<T>(((mids[0] + mids[1]) * T(0.5)) / (T(2) * t_log<T>(T(P + 1))));   // P > 64: svgd_median_large_kernel ran in front
+            else bw = svgd_median_bandwidth<T>(d2, P, lane);
         }
         const T gam = T(1) / (T(1e-8) + T(2) * bw * bw);
         T ksum = 0;
@@ -726,7 +652,7 @@ extern "C" int pacoh_gather_tasks(const void* x, const void* y, const int32_t* n
     return launch_status();
 }
 
-extern "C" int pacoh_abi_version(void) { return 5; }
+extern "C" int pacoh_abi_version(void) { return 6; }
 
 extern "C" int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise,
                                double noise_floor, void* ls, void* os, void* noise, int dtype, void* stream) {
@@ -744,26 +670,34 @@ extern "C" int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int 
     return launch_status();
 }
 
+// svgd_workspace (optional; pacoh_svgd_update_dev_workspace_bytes(svgd_P, svgd_D)): one more workgroup of the launch computes the
+// median-heuristic bandwidth from the distance matrix at the head of that workspace into its bandwidth slot (P <= 64)
 extern "C" int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int T_, int off_ls, int f, int off_os, int off_noise,
                                int off_const, const void* d_ls, const void* d_os, const void* d_noise, const void* d_const,
                                void* grad, long grad_stride, const void* lml, void* lik, double lik_scale,
-                               const int32_t* info, int32_t* fail_flag, int dtype, void* stream) {
+                               const int32_t* info, int32_t* fail_flag, void* svgd_workspace, int svgd_P, int svgd_D,
+                               int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     const int tie = kernel_of(f) != PACOH_KERNEL_RBF;
     f = features_of(f);
     if (!theta || !grad || !d_ls || !d_noise || P <= 0 || T_ <= 0 || f <= 0) return PACOH_EINVAL;
     if ((lml == nullptr) != (lik == nullptr)) return PACOH_EINVAL;
-    unsigned blocks = (unsigned)(P * (f + 4));
+    if (svgd_workspace && (svgd_P <= 0 || svgd_D <= 0)) return PACOH_EINVAL;
+    if (svgd_workspace && svgd_P > 64) return PACOH_ELIMIT;
     if (dtype == PACOH_F32) {
+        float* ws = (float*)svgd_workspace;
         HyperBwdArgs<float> a = {(const float*)theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, (const float*)d_ls,
                                  (const float*)d_os, (const float*)d_noise, (const float*)d_const, (float*)grad, grad_stride,
-                                 (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag, tie};
-        hipLaunchKernelGGL(hyper_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+                                 (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag, tie,
+                                 ws, svgd_P, ws ? ws + svgd_bw_slot(svgd_P, svgd_D) : nullptr};
+        hipLaunchKernelGGL(hyper_bwd_kernel<float>, dim3((unsigned)hyper_tail_blocks(a)), dim3(256), 0, (hipStream_t)stream, a);
     } else {
+        double* ws = (double*)svgd_workspace;
         HyperBwdArgs<double> a = {(const double*)theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, (const double*)d_ls,
                                   (const double*)d_os, (const double*)d_noise, (const double*)d_const, (double*)grad, grad_stride,
-                                  (const double*)lml, (double*)lik, lik_scale, info, fail_flag, tie};
-        hipLaunchKernelGGL(hyper_bwd_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+                                  (const double*)lml, (double*)lik, lik_scale, info, fail_flag, tie,
+                                  ws, svgd_P, ws ? ws + svgd_bw_slot(svgd_P, svgd_D) : nullptr};
+        hipLaunchKernelGGL(hyper_bwd_kernel<double>, dim3((unsigned)hyper_tail_blocks(a)), dim3(256), 0, (hipStream_t)stream, a);
     }
     return launch_status();
 }
@@ -811,7 +745,7 @@ extern "C" size_t pacoh_svgd_workspace_bytes(int P, int D, int dtype) {
 
 extern "C" size_t pacoh_svgd_update_dev_workspace_bytes(int P, int D, int dtype) {
     if (P <= 0 || D <= 0) return 0;
-    return (size_t)(P * P + (long)P * D + 2) * (dtype == PACOH_F64 ? 8 : 4);      // distances + snapshot of the particles + median pair
+    return (size_t)(P * P + (long)P * D + 4) * (dtype == PACOH_F64 ? 8 : 4);      // distances + snapshot of the particles + median pair + bandwidth (svgd_bw_slot)
 }
 
 template <typename T>
@@ -895,8 +829,9 @@ extern "C" int pacoh_svgd_update_next(void* X, const void* score, const void* pr
                                       const void* x, const void* y, const int32_t* n_valid, void* out_x, void* out_y,
                                       int32_t* out_n_valid, int n, int d,
                                       int off_ls, int f, int off_os, int off_noise, double noise_floor, void* ls, void* os, void* noise,
-                                      int dtype, void* stream) {
+                                      int bandwidth_ready, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (bandwidth_ready && P > 64) return PACOH_ELIMIT;
     if (!X || !score || !workspace || P <= 0 || D <= 0 || !counter || !sc2 || !sc_all || n_sc < PACOH_SC_COUNT) return PACOH_EINVAL;
     if ((prior_mean == nullptr) != (prior_std == nullptr)) return PACOH_EINVAL;
     if (use_adam && (!exp_avg || !exp_avg_sq)) return PACOH_EINVAL;
@@ -909,13 +844,15 @@ extern "C" int pacoh_svgd_update_next(void* X, const void* score, const void* pr
     if (dtype == PACOH_F32) {
         StepNextArgs<float> nx = {(const long*)counter, (float*)sc2, n_sc, (const long*)idx_all, tb, (const float*)sc_all, (const float*)x,
                                   (const float*)y, n_valid, (float*)out_x, (float*)out_y, out_n_valid, n * d, n, off_ls, fdim, off_os, off_noise,
-                                  kernel_of(f) != PACOH_KERNEL_RBF, (float)noise_floor, (float*)ls, (float*)os, (float*)noise};
+                                  kernel_of(f) != PACOH_KERNEL_RBF, (float)noise_floor, (float*)ls, (float*)os, (float*)noise,
+                                  bandwidth_ready ? (const float*)workspace + svgd_bw_slot(P, D) : nullptr};
         return svgd_update_next_launch<float>(X, score, prior_mean, prior_std, prior_factor, bandwidth, use_adam, beta1, beta2, exp_avg,
                                               exp_avg_sq, bw_out, workspace, P, D, nx, (hipStream_t)stream);
     }
     StepNextArgs<double> nx = {(const long*)counter, (double*)sc2, n_sc, (const long*)idx_all, tb, (const double*)sc_all, (const double*)x,
                                (const double*)y, n_valid, (double*)out_x, (double*)out_y, out_n_valid, n * d, n, off_ls, fdim, off_os, off_noise,
-                               kernel_of(f) != PACOH_KERNEL_RBF, noise_floor, (double*)ls, (double*)os, (double*)noise};
+                               kernel_of(f) != PACOH_KERNEL_RBF, noise_floor, (double*)ls, (double*)os, (double*)noise,
+                               bandwidth_ready ? (const double*)workspace + svgd_bw_slot(P, D) : nullptr};
     return svgd_update_next_launch<double>(X, score, prior_mean, prior_std, prior_factor, bandwidth, use_adam, beta1, beta2, exp_avg,
                                            exp_avg_sq, bw_out, workspace, P, D, nx, (hipStream_t)stream);
 }

@@ -305,7 +305,10 @@ extern "C" int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta,
                                     void* workspace, const void* stash, int B, int n,
                                     int T_, int off_ls, int f, int off_os, int off_noise, int off_const, const void* d_ls,
                                     const void* d_os, const void* d_noise, const void* d_const, const void* lml, void* lik,
-                                    double lik_scale, const int32_t* info, int32_t* fail_flag, int dtype, void* stream) {
+                                    double lik_scale, const int32_t* info, int32_t* fail_flag,
+                                    void* svgd_workspace, int svgd_P, int svgd_D, int dtype, void* stream) {
+    if (svgd_workspace && (svgd_P <= 0 || svgd_D <= 0)) return PACOH_EINVAL;
+    if (svgd_workspace && svgd_P > 64) return PACOH_ELIMIT;
     if (!d_ls || !d_noise || T_ <= 0 || features_of(f) <= 0 || (lml == nullptr) != (lik == nullptr)) return PACOH_EINVAL;
     if (accumulate) return PACOH_EINVAL;              // (the tail writes its columns of d_theta; the blocks of the two networks are overwritten)
     bool tail_done = false;
@@ -314,7 +317,8 @@ extern "C" int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta,
         HyperBwdArgs<float> tail = {(const float*)theta, theta_stride, P, T_, off_ls, features_of(f), off_os, off_noise, off_const,
                                     (const float*)d_ls, (const float*)d_os, (const float*)d_noise, (const float*)d_const, (float*)d_theta,
                                     d_theta_stride, (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag,
-                                    kernel_of(f) != PACOH_KERNEL_RBF};
+                                    kernel_of(f) != PACOH_KERNEL_RBF, (const float*)svgd_workspace, svgd_P,
+                                    svgd_workspace ? (float*)svgd_workspace + svgd_bw_slot(svgd_P, svgd_D) : nullptr};
         rc = mlp2_bwd_impl(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, off_a, d_out_a, g_a, off_b, d_out_b, g_b, d_theta,
                            d_theta_stride, accumulate, workspace, stash, B, n, dtype, stream, &tail, &tail_done);
     } else {
@@ -323,7 +327,7 @@ extern "C" int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta,
     }
     if (rc || tail_done) return rc;
     return pacoh_hyper_bwd(theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, d_theta,
-                           d_theta_stride, lml, lik, lik_scale, info, fail_flag, dtype, stream);
+                           d_theta_stride, lml, lik, lik_scale, info, fail_flag, svgd_workspace, svgd_P, svgd_D, dtype, stream);
 }
 
 extern "C" int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, int T_, int P, int Wd,

@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(256) fused_reduce_slab_kernel(SlabReduce s0, S
                                                                 int nets, HyperBwdArgs<float> tail, int tail_blocks) {
     if ((int)blockIdx.y == nets) {
         __shared__ float red[4];
-        if ((int)blockIdx.x < tail_blocks) hyper_bwd_block<float>(tail, blockIdx.x, red);
+        if ((int)blockIdx.x < tail_blocks) hyper_tail_block<float>(tail, blockIdx.x, red);
         return;
     }
     const SlabReduce& sr = blockIdx.y ? s1 : s0;
@@ -726,7 +726,7 @@ int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride
 #undef PACOH_LAUNCH_BWD
     const long tot = (long)P * wmax;
     unsigned gx = (unsigned)((tot * 8 + 255) / 256);
-    const int tail_blocks = tail ? tail->P * (tail->f + 4) : 0;
+    const int tail_blocks = tail ? hyper_tail_blocks(*tail) : 0;
     if ((unsigned)tail_blocks > gx) gx = (unsigned)tail_blocks;
     hipLaunchKernelGGL(fused_reduce_slab_kernel, dim3(gx, nets + (tail ? 1 : 0)), dim3(256), 0, s,
                        sr[0], sr[1], d_theta_stride, accumulate, pl.chunks * (bwd_wg_slab(n_hidden) ? 1 : 4), P, nets,

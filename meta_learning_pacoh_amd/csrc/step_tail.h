@@ -37,6 +37,101 @@ __device__ __forceinline__ void svgd_dist_block(const T* __restrict__ X, T* __re
     if (threadIdx.x == 0) { const T tot = (red[0] + red[1]) + (red[2] + red[3]); d2[i * P + j] = tot; d2[j * P + i] = tot; }
 }
 
+// Median of the full PxP squared-distance matrix (numpy.median semantics) from its P(P-1)/2 distinct off-diagonal entries:
+// the sorted full matrix is P zeros followed by every pair value twice, so entry m of it is 0 for m < P and u[(m-P)/2]
+// otherwise (u = sorted pair values).  u is sorted by ONE wavefront entirely in registers: VPL values per lane, bitonic
+// network with lane exchanges by shuffle and register exchanges for strides >= 64 -- no LDS, no barriers (the 512-element LDS
+// bitonic sort this replaces spent 45 barrier rounds = 16.5 us on it at P = 20; this takes ~1.5 us).
+template <typename T, int VPL>
+__device__ __forceinline__ T wave_median_full_matrix(const T* __restrict__ d2, int P, int lane) {
+    constexpr int NV = 64 * VPL;
+    const int npairs = P * (P - 1) / 2;
+    T v[VPL];
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+        const int e = q * 64 + lane;
+        T val = T(INFINITY);
+        if (e < npairs) {
+            // pair index e -> (i, j), i < j, row-major over the strict upper triangle
+            int i = (int)((T(2 * P - 1) - t_sqrt<T>(T((2 * P - 1) * (2 * P - 1) - 8 * e))) * T(0.5));
+            while (i > 0 && i * (2 * P - i - 1) / 2 > e) --i;
+            while ((i + 1) * (2 * P - i - 2) / 2 <= e) ++i;
+            const int j = i + 1 + (e - i * (2 * P - i - 1) / 2);
+            val = d2[i * P + j];
+        }
+        v[q] = val;
+    }
+#pragma unroll
+    for (int k = 2; k <= NV; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {                           // partner in another register of the same lane
+                const int dq = j >> 6;
+#pragma unroll
+                for (int q = 0; q < VPL; ++q) {
+                    if ((q & dq) == 0) {
+                        const bool up = (((q * 64) & k) == 0);           // e & k depends only on q here (k > j >= 64)
+                        const T a = v[q], c = v[q | dq];
+                        const bool sw = (a > c) == up;
+                        v[q] = sw ? c : a; v[q | dq] = sw ? a : c;
+                    }
+                }
+            } else {                                 // partner lane = lane ^ j
+#pragma unroll
+                for (int q = 0; q < VPL; ++q) {
+                    const int e = q * 64 + lane;
+                    const T other = shfl_xor_t<T>(v[q], j);
+                    const bool up = (e & k) == 0;
+                    const bool lower = (lane & j) == 0;
+                    const T mn = v[q] < other ? v[q] : other, mx = v[q] < other ? other : v[q];
+                    v[q] = (lower == up) ? mn : mx;
+                }
+            }
+        }
+    }
+    const int N = P * P;
+    T mids[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int m = h == 0 ? (N - 1) / 2 : N / 2;
+        T val = T(0);
+        if (m >= P) {
+            const int kidx = (m - P) >> 1;
+            const int src_lane = kidx & 63, src_q = kidx >> 6;
+            T pick = T(0);
+#pragma unroll
+            for (int q = 0; q < VPL; ++q) pick = (q == src_q) ? v[q] : pick;
+            val = __shfl(pick, src_lane, 64);
+        }
+        mids[h] = val;
+    }
+    return (mids[0] + mids[1]) * T(0.5);
+}
+
+
+// The median-heuristic bandwidth of an SVGD step (svgd.py:45-51) ahead of its update: the distances are complete once the forward
+// launch has retired, the update only needs the scalar.  One wavefront (the first of the calling workgroup); P <= 64.
+template <typename T>
+__device__ __forceinline__ T svgd_median_bandwidth(const T* __restrict__ d2, int P, int lane) {
+    const int npairs = P * (P - 1) / 2;
+    T med;
+    if (npairs <= 256) med = wave_median_full_matrix<T, 4>(d2, P, lane);
+    else if (npairs <= 512) med = wave_median_full_matrix<T, 8>(d2, P, lane);
+    else if (npairs <= 1024) med = wave_median_full_matrix<T, 16>(d2, P, lane);
+    else med = wave_median_full_matrix<T, 32>(d2, P, lane);
+    return t_sqrt<T>(med / (T(2) * t_log<T>(T(P + 1))));
+}
+template <typename T>
+__device__ __forceinline__ void svgd_bandwidth_block(const T* __restrict__ d2, int P, T* __restrict__ bw_out) {
+    if (threadIdx.x < 64) {
+        const T bw = svgd_median_bandwidth<T>(d2, P, (int)threadIdx.x);
+        if (threadIdx.x == 0) *bw_out = bw;
+    }
+}
+
+// element index of the bandwidth slot in the workspace of pacoh_svgd_update_dev_workspace_bytes: distances | snapshot | median pair | bw
+__host__ __device__ inline long svgd_bw_slot(int P, int D) { return (long)P * P + (long)P * D + 2; }
+
 // the forward's tail: lin = index of this workgroup among the nlin tail workgroups
 template <typename T>
 struct SvgdDistTail {
@@ -60,6 +155,7 @@ struct StepNextArgs {
     const T* x; const T* y; const int32_t* n_valid;  // resident task table
     T* ox; T* oy; int32_t* onv; int nx, ny;          // the batch buffers of the next step
     int off_ls, f, off_os, off_noise, tie; T noise_floor; T* ls; T* os; T* noise;      // hyper-parameters of the UPDATED particles
+    const T* bw_pre;                                 // the step's bandwidth, computed ahead (svgd_bandwidth_block) | nullptr
 };
 
 template <typename T>

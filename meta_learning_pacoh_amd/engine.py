@@ -495,10 +495,11 @@ class GPEngine:
                 stash = self._ws[key] = L.mlp2_stash(x, P, lay.input_dim, list(lay.mean_nn_layers), 1, lay.feature_dim, B, n,
                                                      self._ws.get(key))
             mean, z = L.mlp2_fwd(x, x_div, theta, P, lay.input_dim, list(lay.mean_nn_layers), pair[0], 1, pair[1],
-                                 lay.feature_dim, B, n, ws_holder=self._ws, stash=stash, svgd_tail=svgd_tail)
+                                 lay.feature_dim, B, n, ws_holder=self._ws, stash=stash,
+                                 svgd_tail=svgd_tail[:3] if svgd_tail is not None else None)
             return z, 1, mean.reshape(B, n), L.MEAN_VECTOR
         if svgd_tail is not None:
-            L.svgd_dist_advance(*svgd_tail)                # (no paired forward launch to ride in)
+            L.svgd_dist_advance(*svgd_tail[:3])            # (no paired forward launch to ride in)
         if lay.covar_module == 'NN':
             lo, _ = lay.block_range('kernel_nn.')
             z = L.mlp_fwd(x, x_div, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers), lay.feature_dim, B, n,
@@ -535,8 +536,9 @@ class GPEngine:
         lik_out[P] (optional) receives lik_scale * sum_t lml[t,p] from the same launch that reduces the hyper-gradients;
         grad_out[P,D] (optional, contiguous) is used for the gradient instead of a fresh tensor;
         fail_flag (optional int32[1]) is raised by that launch if any problem's Cholesky failed even with jitter;
-        svgd_tail = (particles, workspace, counter): the pipelined SVGD step's distance matrix and counter increment, in extra
-        workgroups of the forward launch where there is one (L.mlp2_fwd)"""
+        svgd_tail = (particles, workspace, counter, want_bandwidth): the pipelined SVGD step's distance matrix and counter
+        increment, in extra workgroups of the forward launch where there is one (L.mlp2_fwd), and -- want_bandwidth -- its median
+        bandwidth by one more workgroup of the hyper-parameter reduction (L.hyper_bwd)"""
         lay = self.layout
         P, D = theta.shape
         T, n = batch.T, batch.n
@@ -561,6 +563,8 @@ class GPEngine:
         off_ls, f, off_os, off_noise, off_c = self._hyper_offsets()
         hyper = dict(lml=lml if lik_out is not None else None, lik=lik_out, lik_scale=lik_scale,
                      info=info if fail_flag is not None else None, fail_flag=fail_flag)
+        if svgd_tail is not None and svgd_tail[3]:
+            hyper['svgd_bw'] = (svgd_tail[1],) + tuple(svgd_tail[0].shape)
         if pair is not None:
             # both networks' backward + the hyper-parameter reduction (softplus chain rule, likelihood sums, failure flag): one call,
             # on the fused path two launches

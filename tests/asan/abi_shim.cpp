@@ -30,7 +30,7 @@ int main() {
         std::printf("%zu\n", pacoh_mlp_bwd_workspace_bytes(60, 3, 33, 2, h, 3, 2, PACOH_F32));
         return 0;
     }
-    EXPECT(pacoh_abi_version() == 5);
+    EXPECT(pacoh_abi_version() == 6);
     EXPECT(pacoh_gp_small_max_n(PACOH_F32, 0) >= 128 && pacoh_gp_small_max_n(PACOH_F64, 1) >= 64 && pacoh_gp_small_max_n(7, 0) == PACOH_EDTYPE);
     EXPECT(pacoh_svgd_workspace_bytes(20, 2534, PACOH_F32) == (2 * 400 + 20 + 8) * 4);
     EXPECT(pacoh_gp_predict_workspace_bytes(4, 64, 50, PACOH_F32, 1) == 4u * 50 * 64 * 4 && pacoh_gp_predict_workspace_bytes(4, 64, 50, PACOH_F32, 0) == 0);
@@ -87,10 +87,12 @@ int main() {
     EXPECT(pacoh_svgd_dist_advance(fake, fake, 1025, 10, nullptr, PACOH_F32, nullptr) == PACOH_ELIMIT);
     EXPECT(pacoh_svgd_update_next(fake, fake, nullptr, nullptr, 0.1, -1.0, 1, 0.9, 0.999, fake, fake, nullptr, fake, 5, 10,
                                   nullptr, fake, PACOH_SC_COUNT, nullptr, 0, fake, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0,
-                                  0, 2, -1, 2, 0.0, nullptr, nullptr, nullptr, PACOH_F32, nullptr) == PACOH_EINVAL);          // no counter
+                                  0, 2, -1, 2, 0.0, nullptr, nullptr, nullptr, 0, PACOH_F32, nullptr) == PACOH_EINVAL);       // no counter
     EXPECT(pacoh_svgd_update_next(fake, fake, nullptr, nullptr, 0.1, -1.0, 1, 0.9, 0.999, fake, fake, nullptr, fake, 5, 10,
                                   (const int64_t*)fake, fake, PACOH_SC_COUNT, nullptr, 0, fake, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                  nullptr, 0, 0, 8, 3, -1, 2, 0.0, fake, nullptr, fake, PACOH_F32, nullptr) == PACOH_EINVAL);   // ls beyond D
+                                  nullptr, 0, 0, 8, 3, -1, 2, 0.0, fake, nullptr, fake, 0, PACOH_F32, nullptr) == PACOH_EINVAL);   // ls beyond D
+    EXPECT(pacoh_hyper_bwd(fake, 10, 3, 2, 0, 2, -1, 2, -1, fake, nullptr, fake, nullptr, fake, 10, nullptr, nullptr, 1.0, nullptr, nullptr,
+                           fake, 65, 10, PACOH_F32, nullptr) == PACOH_ELIMIT);                     // bandwidth block: register sort, P <= 64
     {
         int32_t* h = (int32_t*)std::malloc(2 * sizeof(int32_t));
         h[0] = h[1] = 32;

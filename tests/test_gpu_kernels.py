@@ -759,8 +759,16 @@ def test_pipelined_step_entry_points(L, dtype, P, optimizer, kernel):
             grp['lr'] = sc_rows[k][1]
         Xo.grad = -phi
         opt.step()
+        ahead = P <= 64 and k == 1                             # second step: the bandwidth comes from the workgroup riding in hyper_bwd
+        if ahead:
+            Tt = 3
+            dl, dn = torch.randn(Tt, P, f, dtype=dtype, device=DEV), torch.randn(Tt, P, dtype=dtype, device=DEV)
+            L.hyper_bwd(Xd, Tt, off_ls, f, -1, off_noise, -1, dl, None, dn, None, torch.zeros(P, D, dtype=dtype, device=DEV),
+                        kernel=hyper[5], svgd_bw=(ws, P, D))
+            slot = ws.view(dtype)[P * P + P * D + 2]
+            assert abs(float(slot) - float(bw_o)) < 1e-5 * float(bw_o)
         L.svgd_update_next(Xd, score.to(dtype).to(DEV), mu.to(dtype).to(DEV), sd.to(dtype).to(DEV), pf, None, optimizer, m, v, ws,
-                           bw_out, feed, tasks, hyper)
+                           bw_out, feed, tasks, hyper, bandwidth_ready=ahead)
         assert int(feed.ctr) == k                             # (the update reads the counter, the next forward advances it)
         assert abs(float(bw_out) - float(bw_o)) < 1e-5 * float(bw_o)
         assert relerr(Xd, Xo.detach()) < tol
