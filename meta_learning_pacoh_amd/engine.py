@@ -299,7 +299,11 @@ def first_chunk(n_steps, chunk):
     one, in front of which the GPU idles (meta_fit synchronises at every log line).  A small first chunk gets it started: 1.4 ms
     (SVGD, 200 steps) / 19 ms (VI, 128 steps) of idle time become 0.1 / 2.4 ms at the price of one more upload"""
     k = min(n_steps, chunk)
-    return FIRST_CHUNK if n_steps >= 4 * FIRST_CHUNK and k > FIRST_CHUNK else k
+    if n_steps >= 4 * FIRST_CHUNK and k > FIRST_CHUNK:
+        return FIRST_CHUNK
+    if n_steps >= 2 * GRAPH_STEPS and k > GRAPH_STEPS and FIRST_CHUNK <= n_steps:      # short calls (the driver times 20 steps): one replay's worth
+        return GRAPH_STEPS
+    return k
 
 
 def replay_steps(n, graph_one, graph_many):
