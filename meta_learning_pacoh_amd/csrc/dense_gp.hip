@@ -403,6 +403,7 @@ __global__ void __launch_bounds__(256, 2) ztz_kernel(const T* __restrict__ Zall,
         for (int q = 0; q < 8; ++q) { As[buf][lr][lc + q] = ra[q]; Bs[buf][lr][lc + q] = rb[q]; }
     };
     const int kbeg = i0;                                           // (i0 >= j0: rows above the tile's first row contribute nothing)
+    const bool dead = tm == tn && wj > wi;                         // diagonal tile, sub-tile strictly above the diagonal
     T ra[8], rb[8];
     load_slab(kbeg, ra, rb);
     store_slab(0, ra, rb);
@@ -411,17 +412,22 @@ __global__ void __launch_bounds__(256, 2) ztz_kernel(const T* __restrict__ Zall,
     for (int k0 = kbeg; k0 < n; k0 += KS) {
         const bool more = k0 + KS < n;
         if (more) load_slab(k0 + KS, ra, rb);                      // global loads of the next slab fly under this slab's MFMAs
+        // this wave's rows start at i0 + wi: slabs that end above them hold only zeros of Z there, and in a diagonal tile the
+        // sub-tile above the diagonal is never stored -- a quarter of the launch's MFMAs; the matrix cores go to the other
+        // workgroup of the CU meanwhile
+        if (!dead && k0 + KS > i0 + wi) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            T av[4], bv[4];
+            for (int s = 0; s < 4; ++s) {
+                T av[4], bv[4];
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) av[ib] = As[buf][4 * g + s][wi + 16 * ib + r];
+                for (int ib = 0; ib < 4; ++ib) av[ib] = As[buf][4 * g + s][wi + 16 * ib + r];
 #pragma unroll
-            for (int jb = 0; jb < 4; ++jb) bv[jb] = Bs[buf][4 * g + s][wj + 16 * jb + r];
+                for (int jb = 0; jb < 4; ++jb) bv[jb] = Bs[buf][4 * g + s][wj + 16 * jb + r];
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib)
+                for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
-                for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = Mf<T>::mma(av[ib], bv[jb], acc[ib][jb]);
+                    for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = Mf<T>::mma(av[ib], bv[jb], acc[ib][jb]);
+            }
         }
         if (more) store_slab(buf ^ 1, ra, rb);
         __syncthreads();
