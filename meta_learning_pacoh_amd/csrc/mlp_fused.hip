@@ -68,8 +68,9 @@ struct FusedArgs {
     int tiles_per_wg;
     int n_stash;               // the top n_stash hidden layers travel through FusedNet::stash (0 = recompute everything)
     int nblk;                  // 16-point blocks per particle in the stash (a multiple of 4)
-    int tail_z;                // forward only: workgroups with blockIdx.z == tail_z (> 0) run sv (step_tail.h) instead of a network
-    SvgdDistTail<float> sv;
+    int tail_z;                // workgroups with blockIdx.z == tail_z (> 0) run a tail instead of a network: forward sv (step_tail.h),
+    SvgdDistTail<float> sv;    // backward the SVGD bandwidth block (svgd_bandwidth_block on bw_d2[bw_P, bw_P] -> bw_out)
+    const float* bw_d2; float* bw_out; int bw_P;
 };
 
 // stash element (particle p, 16-point block blk, slot, feature block fb): 256 floats, lane-major f32x4
@@ -362,6 +363,10 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
     constexpr int L_RED = bwd_wg_slab(NH) ? 4 * f_dnet_max(NH) : 0;
     constexpr int L_ALL = (L_WL + L_ST + L_TS) > L_RED ? (L_WL + L_ST + L_TS) : L_RED;
     __shared__ __attribute__((aligned(16))) float lds[L_ALL];
+    if (a.tail_z > 0 && (int)blockIdx.z == a.tail_z) {     // the SVGD step's median bandwidth rides in this launch (one workgroup)
+        if (blockIdx.x == 0 && blockIdx.y == 0) svgd_bandwidth_block<float>(a.bw_d2, a.bw_P, a.bw_out);
+        return;
+    }
     float* wl = lds;
     const FusedNet& nt = a.net[blockIdx.z];
     const int p = blockIdx.y;
@@ -721,16 +726,21 @@ int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride
         ws += (size_t)pl.chunks * (bwd_wg_slab(n_hidden) ? 1 : 4) * P * a.net[k].D_net;
         if (a.net[k].D_net > wmax) wmax = a.net[k].D_net;
     }
-#define PACOH_LAUNCH_BWD(K) hipLaunchKernelGGL(K, dim3(pl.chunks, P, nets), dim3(256), 0, s, a)
+    // the step's SVGD bandwidth (requested with the hyper-parameter tail) is computed by one workgroup of THIS launch, fully hidden
+    // behind the networks' workgroups; the tail handed to the reduction no longer carries it
+    HyperBwdArgs<float> rtail = tail ? *tail : HyperBwdArgs<float>{};
+    const bool bw_here = tail && tail->sv_bw;
+    if (bw_here) { a.tail_z = nets; a.bw_d2 = tail->sv_d2; a.bw_P = tail->sv_P; a.bw_out = tail->sv_bw; rtail.sv_bw = nullptr; }
+#define PACOH_LAUNCH_BWD(K) hipLaunchKernelGGL(K, dim3(pl.chunks, P, nets + (bw_here ? 1 : 0)), dim3(256), 0, s, a)
     PACOH_FUSED_DISPATCH(mlp_fused_bwd_kernel, n_hidden, pl.pb, PACOH_LAUNCH_BWD);
 #undef PACOH_LAUNCH_BWD
     const long tot = (long)P * wmax;
     unsigned gx = (unsigned)((tot * 8 + 255) / 256);
-    const int tail_blocks = tail ? hyper_tail_blocks(*tail) : 0;
+    const int tail_blocks = tail ? hyper_tail_blocks(rtail) : 0;
     if ((unsigned)tail_blocks > gx) gx = (unsigned)tail_blocks;
     hipLaunchKernelGGL(fused_reduce_slab_kernel, dim3(gx, nets + (tail ? 1 : 0)), dim3(256), 0, s,
                        sr[0], sr[1], d_theta_stride, accumulate, pl.chunks * (bwd_wg_slab(n_hidden) ? 1 : 4), P, nets,
-                       tail ? *tail : HyperBwdArgs<float>{}, tail_blocks);
+                       rtail, tail_blocks);
     return launch_status();
 }
 
