@@ -317,6 +317,17 @@ int pacoh_step_begin(const int64_t* idx_all, int tb, const void* sc_all, int n_s
                      const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise, double noise_floor,
                      void* ls, void* os, void* noise, int advance, const void* svgd_X, void* svgd_workspace, int svgd_P, int svgd_D,
                      int dtype, void* stream);
+/* pacoh_step_begin for a PACOH-VI step with a diagonal posterior (round 3): the same launch also draws the step's S samples
+ * theta[S,D] = loc + exp(scale) * eps from posterior[2,D] and the step's noise row (aux row of n_aux = S*D values), their log q[S]
+ * (pacoh_vi_sample: Normal(loc, scale.exp()).to_event(1).rsample / .log_prob, random_gp.py:244-248, GPR_meta_vi.py:220-221) and
+ * the samples' transformed hyper-parameters ls[S,f] / os[S] / noise[S] (pacoh_hyper_fwd, random_gp.py:69-74; ls = NULL: not
+ * wanted): two launches less per step. */
+int pacoh_step_begin_vi(const int64_t* idx_all, int tb, const void* sc_all, int n_sc, const void* aux_all, long n_aux,
+                        int64_t* counter, int32_t* ticket, void* sc_out, void* aux_out,
+                        const void* x, const void* y, const int32_t* n_valid, void* out_x, void* out_y, int32_t* out_n_valid, int n, int d,
+                        const void* posterior, int S, int D, void* theta_out, void* log_q_out,
+                        int off_ls, int f, int off_os, int off_noise, double noise_floor, void* ls, void* os, void* noise,
+                        int advance, int dtype, void* stream);
 size_t pacoh_svgd_update_dev_workspace_bytes(int P, int D, int dtype);
 int pacoh_svgd_update_dev(void* X, const void* score, const void* prior_mean, const void* prior_std,
                           double prior_factor, double bandwidth, int use_adam, const void* scalars, double beta1,

@@ -124,14 +124,19 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         self._graphs = None
 
     def _body_likelihood(self):
-        batch, _ = self._feed.begin(self.tasks, advance=False)    # select (incl. the step's noise) + task gather: one launch; the
-                                                                  # Adam launch at the end of the step advances the counter
-        self._theta, self._log_q = L.vi_sample(self.posterior, self._feed.aux, full=self.cov_type == 'full')
+        hyp = None
+        if self.cov_type == 'diag' and os.environ.get('PACOH_VI_UNFUSED') != '1':
+            # select (incl. the step's noise) + task gather + the step's samples, their log q and transformed hyper-parameters: one
+            # launch; the update launch at the end of the step advances the counter
+            batch, hyp, self._theta, self._log_q = self._feed.begin_vi(self.tasks, self.engine, self.posterior, self.svi_batch_size)
+        else:
+            batch, _ = self._feed.begin(self.tasks, advance=False)
+            self._theta, self._log_q = L.vi_sample(self.posterior, self._feed.aux, full=self.cov_type == 'full')
         if batch is None:
             self._packed.zero_()
             return
         self.engine.lml_and_grad(self._theta, batch, weight=1.0, lik_out=self._lik, lik_scale=1.0, grad_out=self._score,
-                                 fail_flag=self._fail)
+                                 fail_flag=self._fail, hypers=hyp)
 
     def _body_update(self):
         S = self.svi_batch_size

@@ -67,6 +67,8 @@ SIGNATURES = {
     'pacoh_scale_dev': (_i, [_vp, _vp, _l, _i, _vp]),
     'pacoh_step_begin': (_i, [_vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                               _vp, _l, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
+    'pacoh_step_begin_vi': (_i, [_vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                                 _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _i, _vp]),
     'pacoh_svgd_update_dev_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_update_dev': (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _vp, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     'pacoh_svgd_dist_advance': (_i, [_vp, _vp, _i, _i, _vp, _i, _vp]),
@@ -100,7 +102,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 6              # pacoh_abi_version() of the library this table was written for
+ABI_VERSION = 7              # pacoh_abi_version() of the library this table was written for
 
 
 def load_library():
@@ -734,6 +736,35 @@ def step_begin(feed, tasks, out, theta=None, hyper=None, hyper_out=None, advance
                                     _ptr(theta, feed.sc_all), stride, P, off_ls, f, off_os, off_noise, float(floor), _ptr(ls), _ptr(os_),
                                     _ptr(noise), int(bool(advance)), _ptr(sv_X, feed.sc_all), _ptr(sv_ws), sv_P, sv_D,
                                     dtype_code(feed.sc_all), _stream()), 'pacoh_step_begin')
+
+
+def step_begin_vi(feed, tasks, out, posterior, theta_out, log_q_out, hyper=None, hyper_out=None, advance=False):
+    """step_begin for a PACOH-VI step (diagonal posterior [2, D]): feed row -> feed.sc / feed.aux (the step's noise), task gather,
+    AND the step's samples theta_out[S, D], log_q_out[S] and their transformed hyper-parameters hyper_out = (ls, os | None, noise)
+    with hyper = (off_ls, f, off_os, off_noise, noise_floor, kernel): one launch instead of three"""
+    lib = load_library()
+    tb = feed.tb
+    S, D = theta_out.shape
+    x = y = nv = ox = oy = onv = None
+    n = d = 0
+    if tb > 0:
+        x, y, nv = tasks.x, tasks.y, (tasks.n_valid if tasks.ragged else None)
+        ox, oy, onv = out
+        n, d = x.shape[1], x.shape[2]
+    off_ls = f = off_os = off_noise = 0
+    floor = 0.0
+    ls = os_ = noise = None
+    if hyper is not None:
+        off_ls, f, off_os, off_noise, floor = hyper[:5]
+        f = _kf(f, hyper[5] if len(hyper) > 5 else KERNEL_RBF)
+        ls, os_, noise = hyper_out
+    with _Timed('step_begin'):
+        _check(lib.pacoh_step_begin_vi(_ptr(feed.idx_all), tb, _ptr(feed.sc_all), feed.sc_all.shape[1], _ptr(feed.aux_all, feed.sc_all),
+                                       feed.aux_all[0].numel(), _ptr(feed.ctr), _ptr(feed.ticket), _ptr(feed.sc), _ptr(feed.aux, feed.sc_all),
+                                       _ptr(x, feed.sc_all), _ptr(y, feed.sc_all), _ptr(nv), _ptr(ox), _ptr(oy), _ptr(onv), n, d,
+                                       _ptr(posterior, feed.sc_all), S, D, _ptr(theta_out, feed.sc_all), _ptr(log_q_out, feed.sc_all),
+                                       off_ls, f, off_os, off_noise, float(floor), _ptr(ls), _ptr(os_), _ptr(noise),
+                                       int(bool(advance)), dtype_code(feed.sc_all), _stream()), 'pacoh_step_begin_vi')
 
 
 def scale_dev(buf, scalar):

@@ -521,6 +521,10 @@ struct StepBeginArgs {
     int aux_blocks;                                  // blocks [tb+2, tb+2+aux_blocks) copy the auxiliary payload
     const T* sv_X; T* sv_d2; T* sv_snap; int sv_P, sv_D;         // blocks behind them: SVGD pairwise distances + particle snapshot
     int tie;                                         // one raw scale for all f dimensions (kernel families other than ARD-RBF)
+    // PACOH-VI (diagonal posterior): the blocks behind all others draw the step's samples theta[s] = loc + exp(scale) * eps[s] from
+    // the step's noise row (aux_all[row], NOT the copy another block of this launch is making), their log q, and the transformed
+    // hyper-parameters of the samples -- pacoh_vi_sample + pacoh_hyper_fwd without their launches
+    const T* vi_post; T* vi_theta; T* vi_logq; int vi_S, vi_D;
 };
 
 template <typename T>
@@ -552,10 +556,32 @@ __global__ void __launch_bounds__(256) step_begin_kernel(StepBeginArgs<T> a) {
     } else if (blk < a.tb + 2 + a.aux_blocks) {
         const int nb = a.aux_blocks;
         for (long q = (long)(blk - a.tb - 2) * 256 + threadIdx.x; q < a.n_aux; q += (long)nb * 256) a.aux_out[q] = a.aux_all[row * a.n_aux + q];
-    } else {
+    } else if (a.vi_post == nullptr || blk < a.tb + 2 + a.aux_blocks + (a.sv_X ? a.sv_P * a.sv_P : 0)) {
         // the particles do not change before the step's update: their distance matrix (and the snapshot the in-place update reads)
         // can be had here, a launch earlier and off the path behind the all-reduce
         svgd_dist_block<T>(a.sv_X, a.sv_d2, a.sv_P, a.sv_D, a.sv_snap, blk - (a.tb + 2 + a.aux_blocks));
+    } else {
+        __shared__ T red[4];                                     // (arithmetic and summation order of vi_sample_kernel / hyper_fwd_kernel)
+        const int s_ = blk - (a.tb + 2 + a.aux_blocks + (a.sv_X ? a.sv_P * a.sv_P : 0)), D = a.vi_D;
+        const T* eps = a.aux_all + row * a.n_aux + (long)s_ * D;
+        const T HALF_LOG2PI = T(0.9189385332046727);
+        T acc = 0;
+        for (int d = threadIdx.x; d < D; d += 256) {
+            const T e = eps[d], sc = a.vi_post[D + d];
+            const T th = a.vi_post[d] + t_exp<T>(sc) * e;
+            a.vi_theta[(long)s_ * D + d] = th;
+            acc += T(-0.5) * e * e - sc - HALF_LOG2PI;
+            if (a.ls) {
+                if (d == a.off_noise) a.noise[s_] = softplus_t<T>(th) + a.noise_floor;
+                else if (a.os && d == a.off_os) a.os[s_] = softplus_t<T>(th);
+                else if (a.tie) { if (d == a.off_ls) { const T v1 = softplus_t<T>(th); for (int e2 = 0; e2 < a.f; ++e2) a.ls[s_ * a.f + e2] = v1; } }
+                else if (d >= a.off_ls && d < a.off_ls + a.f) a.ls[s_ * a.f + (d - a.off_ls)] = softplus_t<T>(th);
+            }
+        }
+        acc = subwave_sum<T>(acc, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) a.vi_logq[s_] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -592,7 +618,8 @@ static int step_begin_launch(const int64_t* idx_all, int tb, const void* sc_all,
                              int32_t* ticket, void* sc_out, void* aux_out, const void* x, const void* y, const int32_t* n_valid, void* out_x,
                              void* out_y, int32_t* out_n_valid, int n, int d, const void* theta, long theta_stride, int P, int off_ls, int f,
                              int off_os, int off_noise, double noise_floor, void* ls, void* os, void* noise, int advance,
-                             const void* svgd_X, void* svgd_workspace, int svgd_P, int svgd_D, hipStream_t s) {
+                             const void* svgd_X, void* svgd_workspace, int svgd_P, int svgd_D, hipStream_t s,
+                             const void* vi_post = nullptr, void* vi_theta = nullptr, void* vi_logq = nullptr, int vi_S = 0, int vi_D = 0) {
     long ab = n_aux > 0 ? (n_aux + 2047) / 2048 : 0;
     if (ab > 256) ab = 256;
     T* d2 = (T*)svgd_workspace;                       // (layout of pacoh_svgd_update_dev_workspace_bytes: distances | snapshot | median pair)
@@ -600,9 +627,9 @@ static int step_begin_launch(const int64_t* idx_all, int tb, const void* sc_all,
                           (T*)aux_out, (const T*)x, (const T*)y, n_valid, (T*)out_x, (T*)out_y, out_n_valid, n * d, n, (const T*)theta,
                           theta_stride, P, off_ls, features_of(f), off_os, off_noise, (T)noise_floor, (T*)ls, (T*)os, (T*)noise,
                           (int)ab, (const T*)svgd_X, d2, svgd_X ? d2 + svgd_P * svgd_P : nullptr, svgd_P, svgd_D,
-                          kernel_of(f) != PACOH_KERNEL_RBF};
+                          kernel_of(f) != PACOH_KERNEL_RBF, (const T*)vi_post, (T*)vi_theta, (T*)vi_logq, vi_S, vi_D};
     const long sb = svgd_X ? (long)svgd_P * svgd_P : 0;
-    hipLaunchKernelGGL(step_begin_kernel<T>, dim3((unsigned)(tb + 2 + ab + sb)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(step_begin_kernel<T>, dim3((unsigned)(tb + 2 + ab + sb + (vi_post ? vi_S : 0))), dim3(256), 0, s, a);
     if (advance) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, (long*)counter);
     return launch_status();
 }
@@ -629,6 +656,29 @@ extern "C" int pacoh_step_begin(const int64_t* idx_all, int tb, const void* sc_a
                                      advance, svgd_X, svgd_workspace, svgd_P, svgd_D, (hipStream_t)stream);
 }
 
+// pacoh_step_begin for a PACOH-VI step with a diagonal posterior: additionally draws the step's S samples theta[S, D] = loc +
+// exp(scale) * eps from posterior[2, D] and the step's noise row (n_aux = S * D), their log q[S], and the samples' transformed
+// hyper-parameters ls[S, f] / os[S] / noise[S] -- pacoh_vi_sample and pacoh_hyper_fwd in extra workgroups of the same launch
+extern "C" int pacoh_step_begin_vi(const int64_t* idx_all, int tb, const void* sc_all, int n_sc, const void* aux_all, long n_aux,
+                                   int64_t* counter, int32_t* ticket, void* sc_out, void* aux_out,
+                                   const void* x, const void* y, const int32_t* n_valid, void* out_x, void* out_y, int32_t* out_n_valid, int n, int d,
+                                   const void* posterior, int S, int D, void* theta_out, void* log_q_out,
+                                   int off_ls, int f, int off_os, int off_noise, double noise_floor, void* ls, void* os, void* noise,
+                                   int advance, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!counter || !ticket || tb < 0 || n_sc <= 0 || !sc_all || !sc_out || !aux_all || !aux_out) return PACOH_EINVAL;
+    if (!posterior || !theta_out || !log_q_out || S <= 0 || D <= 0 || n_aux != (long)S * D) return PACOH_EINVAL;
+    if (tb > 0 && (!idx_all || !x || !y || !out_x || !out_y || n <= 0 || d <= 0 || (n_valid == nullptr) != (out_n_valid == nullptr))) return PACOH_EINVAL;
+    if (ls && (!noise || features_of(f) <= 0 || off_ls < 0 || off_noise < 0 || off_noise >= D || off_os >= D)) return PACOH_EINVAL;
+    if (dtype == PACOH_F32)
+        return step_begin_launch<float>(idx_all, tb, sc_all, n_sc, aux_all, n_aux, counter, ticket, sc_out, aux_out, x, y, n_valid, out_x, out_y,
+                                        out_n_valid, n, d, nullptr, 0, S, off_ls, f, off_os, off_noise, noise_floor, ls, os, noise,
+                                        advance, nullptr, nullptr, 0, 0, (hipStream_t)stream, posterior, theta_out, log_q_out, S, D);
+    return step_begin_launch<double>(idx_all, tb, sc_all, n_sc, aux_all, n_aux, counter, ticket, sc_out, aux_out, x, y, n_valid, out_x, out_y,
+                                     out_n_valid, n, d, nullptr, 0, S, off_ls, f, off_os, off_noise, noise_floor, ls, os, noise,
+                                     advance, nullptr, nullptr, 0, 0, (hipStream_t)stream, posterior, theta_out, log_q_out, S, D);
+}
+
 extern "C" int pacoh_scale_dev(void* buf, const void* scalar, long count, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!buf || !scalar || count <= 0) return PACOH_EINVAL;
@@ -652,7 +702,7 @@ extern "C" int pacoh_gather_tasks(const void* x, const void* y, const int32_t* n
     return launch_status();
 }
 
-extern "C" int pacoh_abi_version(void) { return 6; }
+extern "C" int pacoh_abi_version(void) { return 7; }
 
 extern "C" int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise,
                                double noise_floor, void* ls, void* os, void* noise, int dtype, void* stream) {

@@ -285,6 +285,31 @@ class StepFeed:
         return batch, hyp
 
 
+def _begin_vi(self, tasks, engine, posterior, S):
+    """StepFeed.begin for a PACOH-VI step with a diagonal posterior: select (incl. the step's noise) + task gather + the step's
+    samples, their log q and transformed hyper-parameters in ONE launch -> (TaskBatch | None, hypers, theta[S, D], log_q[S])"""
+    D = posterior.shape[1]
+    dev, dt = posterior.device, posterior.dtype
+    batch = out = None
+    if self.tb > 0:
+        batch = TaskBatch.__new__(TaskBatch)
+        batch.T, batch.n, batch.ragged, batch.sizes = self.tb, tasks.n, tasks.ragged, None
+        batch.x = torch.empty(self.tb, tasks.n, tasks.x.shape[2], dtype=tasks.x.dtype, device=tasks.x.device)
+        batch.y = torch.empty(self.tb, tasks.n, dtype=tasks.x.dtype, device=tasks.x.device)
+        batch.n_valid = torch.empty(self.tb, dtype=torch.int32, device=tasks.x.device) if tasks.ragged else None
+        out = (batch.x, batch.y, batch.n_valid)
+    off_ls, f, off_os, off_noise, _ = engine._hyper_offsets()
+    hyp = (torch.empty(S, f, dtype=dt, device=dev), torch.empty(S, dtype=dt, device=dev) if off_os >= 0 else None,
+           torch.empty(S, dtype=dt, device=dev))
+    theta, log_q = torch.empty(S, D, dtype=dt, device=dev), torch.empty(S, dtype=dt, device=dev)
+    L.step_begin_vi(self, tasks, out, posterior, theta, log_q, (off_ls, f, off_os, off_noise, engine.noise_floor, engine.layout.kernel_code),
+                    hyp, advance=False)
+    return batch, hyp, theta, log_q
+
+
+StepFeed.begin_vi = _begin_vi
+
+
 GRAPH_STEPS = 4      # steps per graph of the second graph the learners capture at world size 1 (hipGraphLaunch costs the host per
                      # launch, not per node: 0.006-0.012 ms per step with one step per graph, 0.003 with four -- what keeps the GPU fed
                      # when the host is busy with somebody else's job; tools/graph_steps_probe.py)

@@ -30,7 +30,7 @@ int main() {
         std::printf("%zu\n", pacoh_mlp_bwd_workspace_bytes(60, 3, 33, 2, h, 3, 2, PACOH_F32));
         return 0;
     }
-    EXPECT(pacoh_abi_version() == 6);
+    EXPECT(pacoh_abi_version() == 7);
     EXPECT(pacoh_gp_small_max_n(PACOH_F32, 0) >= 128 && pacoh_gp_small_max_n(PACOH_F64, 1) >= 64 && pacoh_gp_small_max_n(7, 0) == PACOH_EDTYPE);
     EXPECT(pacoh_svgd_workspace_bytes(20, 2534, PACOH_F32) == (2 * 400 + 20 + 8) * 4);
     EXPECT(pacoh_gp_predict_workspace_bytes(4, 64, 50, PACOH_F32, 1) == 4u * 50 * 64 * 4 && pacoh_gp_predict_workspace_bytes(4, 64, 50, PACOH_F32, 0) == 0);
@@ -100,6 +100,9 @@ int main() {
                                    PACOH_F32, nullptr) == PACOH_EINVAL);                                                       // no particles
         std::free(h);
     }
+    EXPECT(pacoh_step_begin_vi(nullptr, 0, fake, PACOH_SC_COUNT, fake, 59, (int64_t*)fake, (int32_t*)fake, fake, fake, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, nullptr, 0, 0, fake, 6, 10, fake, fake, 0, 2, -1, 2, 0.0, nullptr, nullptr, nullptr, 0,
+                               PACOH_F32, nullptr) == PACOH_EINVAL);                              // noise row is not S x D values
     EXPECT(pacoh_adam_step(nullptr, nullptr, nullptr, nullptr, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 10, PACOH_F32, nullptr) == PACOH_EINVAL);
     EXPECT(pacoh_allreduce_sum(nullptr, 4, PACOH_F32, fake, nullptr) == PACOH_EINVAL);
     EXPECT(pacoh_allreduce_sum(fake, 4, 7, fake, nullptr) == PACOH_EDTYPE);

@@ -784,6 +784,40 @@ def test_pipelined_step_entry_points(L, dtype, P, optimizer, kernel):
         assert torch.equal(feed.batch.n_valid, tasks.n_valid[nxt])
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('kernel', ['RBF', 'COS'])
+def test_step_begin_vi_equals_sample_plus_hyper_fwd(L, dtype, kernel):
+    """pacoh_step_begin_vi: the step's samples, log q and transformed hyper-parameters from the SAME launch that selects the step's
+    row and gathers its tasks -- bit for bit what pacoh_vi_sample + pacoh_hyper_fwd + pacoh_step_begin give, for row 0 and row 1"""
+    from types import SimpleNamespace
+    g = torch.Generator().manual_seed(41)
+    S, D, T, n, d, tb, f = 6, 300, 7, 5, 2, 3, 3
+    off_ls, off_noise, floor = 200, 290, 1e-3
+    code = L.KERNEL_COSINE if kernel == 'COS' else L.KERNEL_RBF
+    post = torch.randn(2, D, generator=g, dtype=torch.float64).to(dtype).to(DEV)
+    tasks = SimpleNamespace(x=torch.randn(T, n, d, generator=g, dtype=torch.float64).to(dtype).to(DEV),
+                            y=torch.randn(T, n, generator=g, dtype=torch.float64).to(dtype).to(DEV), n_valid=None, ragged=False)
+    rows = 2
+    feed = SimpleNamespace(tb=tb, idx_all=torch.randint(0, T, (rows, tb), generator=g).to(DEV),
+                           sc_all=torch.rand(rows, L.SC_COUNT, generator=g, dtype=torch.float64).to(dtype).to(DEV),
+                           aux_all=torch.randn(rows, S, D, generator=g, dtype=torch.float64).to(dtype).to(DEV),
+                           ctr=torch.zeros(1, dtype=torch.int64, device=DEV), ticket=torch.zeros(1, dtype=torch.int32, device=DEV),
+                           sc=torch.zeros(L.SC_COUNT, dtype=dtype, device=DEV), aux=torch.zeros(S, D, dtype=dtype, device=DEV))
+    for row in range(rows):
+        feed.ctr.fill_(row)
+        out = (torch.zeros(tb, n, d, dtype=dtype, device=DEV), torch.zeros(tb, n, dtype=dtype, device=DEV), None)
+        theta, log_q = torch.zeros(S, D, dtype=dtype, device=DEV), torch.zeros(S, dtype=dtype, device=DEV)
+        hyp = (torch.zeros(S, f, dtype=dtype, device=DEV), None, torch.zeros(S, dtype=dtype, device=DEV))
+        L.step_begin_vi(feed, tasks, out, post, theta, log_q, (off_ls, f, -1, off_noise, floor, code), hyp)
+        th_ref, lq_ref = L.vi_sample(post, feed.aux_all[row].contiguous())
+        ls_ref, _, noise_ref = L.hyper_fwd(th_ref, off_ls, f, -1, off_noise, floor, kernel=code)
+        assert torch.equal(theta, th_ref) and torch.equal(log_q, lq_ref)
+        assert torch.equal(hyp[0], ls_ref) and torch.equal(hyp[2], noise_ref)
+        assert torch.equal(feed.aux, feed.aux_all[row]) and torch.equal(feed.sc, feed.sc_all[row])
+        assert torch.equal(out[0], tasks.x[feed.idx_all[row]]) and torch.equal(out[1], tasks.y[feed.idx_all[row]])
+        assert int(feed.ctr) == row                           # (advance = False: the step's update launch advances the counter)
+
+
 # ------------------------------------------------------------------------------------------ predictive cdf / quantiles / calibration
 def test_mixture_cdf_icdf_calib_match_reference_fixture(L, golden_dir):
     """pacoh_mixture_cdf / _icdf / pacoh_calib_error vs EqualWeightedMixtureDist.cdf / .icdf, AffineTransformedDistribution and
