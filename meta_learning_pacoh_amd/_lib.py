@@ -50,6 +50,8 @@ SIGNATURES = {
     'pacoh_mlp_fwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_mlp_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i]),
     'pacoh_mlp_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _l, _i, _vp, _i, _i, _i, _vp]),
+    'pacoh_mlp_bwd_hyper': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _l, _vp, _i, _i,
+                                 _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_mlp2_fwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_mlp2_stash_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_mlp2_fwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -102,7 +104,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 7              # pacoh_abi_version() of the library this table was written for
+ABI_VERSION = 8              # pacoh_abi_version() of the library this table was written for
 
 
 def load_library():
@@ -477,6 +479,29 @@ def mlp_bwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, g_out, 
                                  len(hidden), d_out, _ptr(g_out, x), ctypes.c_void_p(d_theta_block.data_ptr()),
                                  d_theta_stride, int(bool(accumulate)), _ptr(workspace), B, n, code, _stream()),
                'pacoh_mlp_bwd')
+    return workspace
+
+
+def mlp_bwd_hyper(x, x_div, theta, lo, P, d_in, hidden, d_out, g_out, grad, B, n, T, off_ls, f, off_os, off_noise, off_const,
+                  d_ls, d_os, d_noise, d_const, lml=None, lik=None, lik_scale=1.0, info=None, fail_flag=None, kernel=KERNEL_RBF,
+                  workspace=None, svgd_bw=None):
+    """mlp_bwd of the ONE network whose block starts at column lo of theta[P, D] (gradient into grad[:, lo:]) + hyper_bwd on the
+    rows, in one C-ABI call (one launch less on the fused path); returns the workspace for reuse"""
+    lib = load_library()
+    code, harr = dtype_code(x), _hidden_arr(hidden)
+    D = theta.shape[1]
+    es = theta.element_size()
+    need = lib.pacoh_mlp_bwd_workspace_bytes(B, P, n, d_in, harr, len(hidden), d_out, code)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(max(1, need), dtype=torch.uint8, device=x.device)
+    with _Timed('mlp_bwd'):
+        _check(lib.pacoh_mlp_bwd_hyper(_ptr(x), x_div, ctypes.c_void_p(theta.data_ptr() + lo * es), D, P, d_in, harr, len(hidden), d_out,
+                                       _ptr(g_out, x), ctypes.c_void_p(grad.data_ptr() + lo * es), grad.shape[1], _ptr(workspace), B, n,
+                                       _ptr(theta, x), _ptr(grad, x), T, off_ls, _kf(f, kernel), off_os, off_noise, off_const,
+                                       _ptr(d_ls, x), _ptr(d_os, x), _ptr(d_noise, x), _ptr(d_const, x), _ptr(lml, x), _ptr(lik, x),
+                                       float(lik_scale), _ptr(info if fail_flag is not None else None),
+                                       _ptr(fail_flag if info is not None else None), *_svgd_bw(svgd_bw), code, _stream()),
+               'pacoh_mlp_bwd_hyper')
     return workspace
 
 

@@ -330,6 +330,42 @@ extern "C" int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta,
                            d_theta_stride, lml, lik, lik_scale, info, fail_flag, svgd_workspace, svgd_P, svgd_D, dtype, stream);
 }
 
+// pacoh_mlp_bwd + pacoh_hyper_bwd for configurations with ONE network (mean or kernel features): as pacoh_mlp2_bwd_hyper, the
+// hyper-parameter reduction rides in the slab reduction's launch on the fused fp32 path.  theta / d_theta: the NETWORK's block inside
+// the parameter rows; theta_rows / grad_rows: the rows themselves (what pacoh_hyper_bwd reads and writes).
+extern "C" int pacoh_mlp_bwd_hyper(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
+                                   const int32_t* hidden, int n_hidden, int d_out, const void* g_out, void* d_theta, long d_theta_stride,
+                                   void* workspace, int B, int n,
+                                   const void* theta_rows, void* grad_rows, int T_, int off_ls, int f, int off_os, int off_noise,
+                                   int off_const, const void* d_ls, const void* d_os, const void* d_noise, const void* d_const,
+                                   const void* lml, void* lik, double lik_scale, const int32_t* info, int32_t* fail_flag,
+                                   void* svgd_workspace, int svgd_P, int svgd_D, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!g_out || !d_theta || !workspace || !x || !theta || !theta_rows || !grad_rows || x_div <= 0 || P <= 0 || B <= 0 || n <= 0 || B % P != 0)
+        return PACOH_EINVAL;
+    if (!d_ls || !d_noise || T_ <= 0 || features_of(f) <= 0 || (lml == nullptr) != (lik == nullptr)) return PACOH_EINVAL;
+    if (svgd_workspace && (svgd_P <= 0 || svgd_D <= 0)) return PACOH_EINVAL;
+    if (svgd_workspace && svgd_P > 64) return PACOH_ELIMIT;
+    int rc = args_ok(d_in, hidden, n_hidden, d_out);
+    if (rc) return rc;
+    if (dtype == PACOH_F32 && pick_path(dtype, d_in, hidden, n_hidden, d_out, (long)B * n) == PATH_FUSED) {
+        HyperBwdArgs<float> tail = {(const float*)theta_rows, theta_stride, P, T_, off_ls, features_of(f), off_os, off_noise, off_const,
+                                    (const float*)d_ls, (const float*)d_os, (const float*)d_noise, (const float*)d_const, (float*)grad_rows,
+                                    d_theta_stride, (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag,
+                                    kernel_of(f) != PACOH_KERNEL_RBF, (const float*)svgd_workspace, svgd_P,
+                                    svgd_workspace ? (float*)svgd_workspace + svgd_bw_slot(svgd_P, svgd_D) : nullptr};
+        const long off = 0;
+        const void* const gs[1] = {g_out};
+        return mlp_fused_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 1, &off, &d_out, gs, d_theta, d_theta_stride,
+                             0, workspace, nullptr, B, n, (hipStream_t)stream, &tail);
+    }
+    rc = pacoh_mlp_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, 0, workspace, B, n,
+                       dtype, stream);
+    if (rc) return rc;
+    return pacoh_hyper_bwd(theta_rows, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, grad_rows,
+                           d_theta_stride, lml, lik, lik_scale, info, fail_flag, svgd_workspace, svgd_P, svgd_D, dtype, stream);
+}
+
 extern "C" int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, int T_, int P, int Wd,
                                   int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;

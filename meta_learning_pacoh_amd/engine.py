@@ -602,6 +602,17 @@ class GPEngine:
                                               off_noise, off_c, d_ls, d_os, d_noise, None, workspace=self._ws.get('mk'),
                                               stash=self._ws.get(('stash', B, n)), **hyper)
             return lml.reshape(T, P), grad, info
+        d_const = d_mean if lay.mean_module == 'constant' else None
+        if (lay.covar_module == 'NN') != (lay.mean_module == 'NN'):
+            # ONE network: its backward and the hyper-parameter reduction in one call (one launch less on the fused path)
+            if lay.covar_module == 'NN':
+                (lo, _), layers, d_out, g_net = lay.block_range('kernel_nn.'), lay.kernel_nn_layers, lay.feature_dim, d_z
+            else:
+                (lo, _), layers, d_out, g_net = lay.block_range('mean_nn.'), lay.mean_nn_layers, 1, d_mean.reshape(B, n, 1)
+            self._ws['k1'] = L.mlp_bwd_hyper(batch.x, P, theta, lo, P, lay.input_dim, list(layers), d_out, g_net, grad, B, n, T, off_ls, f,
+                                             off_os, off_noise, off_c, d_ls, d_os, d_noise, d_const, kernel=lay.kernel_code,
+                                             workspace=self._ws.get('k1'), **hyper)
+            return lml.reshape(T, P), grad, info
         if lay.covar_module == 'NN':
             lo, _ = lay.block_range('kernel_nn.')
             self._ws['k'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers),
@@ -611,8 +622,7 @@ class GPEngine:
             self._ws['m'] = L.mlp_bwd(batch.x, P, theta[:, lo:], D, P, lay.input_dim, list(lay.mean_nn_layers), 1,
                                       d_mean.reshape(B, n, 1), grad[:, lo:], D, False, B, n, self._ws.get('m'))
         # hyper-parameters (+ constant mean): sum over tasks and softplus chain rule in one launch
-        L.hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_c, d_ls, d_os, d_noise,
-                    d_mean if lay.mean_module == 'constant' else None, grad, kernel=lay.kernel_code, **hyper)
+        L.hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_c, d_ls, d_os, d_noise, d_const, grad, kernel=lay.kernel_code, **hyper)
         return lml.reshape(T, P), grad, info
 
     def predict(self, theta, ctx_x, ctx_y, tst_x, want_cov=False):
