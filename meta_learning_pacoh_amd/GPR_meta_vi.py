@@ -39,13 +39,20 @@ def init_vi_posterior_full(D, init_std=0.1):
 _NORMAL_ARGS = {}
 
 
-def standard_normal(n, D):
+def standard_normal(n, D, out=None):
     """the eps of Normal(loc, scale).rsample((n,)) (torch.distributions: _standard_normal): the same call, hence the same use of
-    the CPU generator, as the reference's; its two constant operands are kept between calls"""
+    the CPU generator, as the reference's; its two constant operands are kept between calls.  out (float32 [n, D], e.g. a row of
+    pinned staging memory): filled in place -- the same values from the same generator state, without the 100 KB allocation per
+    call that costs as much as the draw itself"""
     args = _NORMAL_ARGS.get((n, D))
     if args is None:
         args = _NORMAL_ARGS[(n, D)] = (torch.zeros(n, D), torch.ones(n, D))
-    return torch.normal(*args)
+    if out is not None and out.dtype == torch.float32:
+        return torch.normal(*args, out=out)
+    eps = torch.normal(*args)
+    if out is not None:
+        out.copy_(eps)
+    return eps
 
 
 class GPRegressionMetaLearnedVI(_RandomGPLearner):
@@ -175,12 +182,13 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         S, D = self.svi_batch_size, self.layout.D
         k = 0
         while n_steps > 0:
-            # chunk sizes 16, 32, 64, ...: the host draws 0.15 ms of noise per step, the GPU needs 0.4-0.5 ms per step -- a chunk may
-            # be at most ~3x the one the GPU is busy with, or the GPU runs dry while the host prepares it
-            k = first_chunk(n_steps, self._feed.chunk) if k == 0 else min(n_steps, self._feed.chunk, 2 * k)
+            # chunk sizes 16, 24, 36, 52, ...: the host draws 0.15-0.19 ms of noise per step, the GPU needs 0.4-0.5 ms per step -- a
+            # chunk must take the host less to prepare than the one in flight takes the GPU, or the GPU runs dry (growth 2 left a
+            # margin of 10 % on the slower hosts: cfg #4 read 0.42 or 0.49 ms per step depending on the box)
+            k = first_chunk(n_steps, self._feed.chunk) if k == 0 else min(n_steps, self._feed.chunk, (k + k // 2 + 3) // 4 * 4)
             idx_rows, sc_rows = self._draw_steps(k, self.lr_scheduler, self.opt_step + 1)
-            eps = [standard_normal(S, D) for _ in range(k)]                     # the reference's stream: one rsample per step
-            self._feed.upload(idx_rows, sc_rows, eps)
+            # the reference's stream: one rsample per step, drawn straight into the pinned staging rows
+            self._feed.upload(idx_rows, sc_rows, lambda j, out: standard_normal(S, D, out=out))
             if graphed and self._graphs is None:
                 self._build_graphs()                      # (captured with real operands in the feed; state and counter are restored)
             if graphed:

@@ -190,8 +190,8 @@ class StepFeed:
         self._n_aux = [t.numpy() for t in self._h_aux] if self._h_aux is not None else None
 
     def upload(self, idx_rows, sc_rows, aux_rows=None):
-        """idx_rows: int array [k, tb]; sc_rows: k rows of L.step_scalars(); aux_rows: tensor [k, ...] or k tensors [...] | None;
-        resets the counter"""
+        """idx_rows: int array [k, tb]; sc_rows: k rows of L.step_scalars(); aux_rows: tensor [k, ...], k tensors [...], a callable
+        (j, out_row) filling the pinned staging row of step j in place, or None; resets the counter"""
         k = len(sc_rows)
         assert 0 < k <= self.chunk
         q = self._slot
@@ -214,7 +214,10 @@ class StepFeed:
             self.idx_all[:kk].copy_(self._h_idx[q][:kk], non_blocking=True)
         if self.aux_all is not None:
             ha = self._n_aux[q]
-            if torch.is_tensor(aux_rows):
+            if callable(aux_rows):                       # aux_rows(j, out): writes step j's payload straight into the staging row
+                for j in range(k):
+                    aux_rows(j, self._h_aux[q][j])
+            elif torch.is_tensor(aux_rows):
                 ha[:k] = aux_rows.numpy()
             else:                                        # one tensor per step
                 for j, row in enumerate(aux_rows):

@@ -233,3 +233,22 @@ def test_host_cpu_budget_is_within_the_visible_cores():
             assert b <= max(1, int(float(q) / float(per)))
     except OSError:
         pass
+
+
+def test_standard_normal_into_a_buffer_is_the_same_draw():
+    """GPR_meta_vi.standard_normal(out=row): the values and the generator state after the call equal those of the plain call (the
+    reference's Normal(...).rsample, random_gp.py:244-248) -- PACOH-VI draws its per-step noise straight into pinned staging rows"""
+    import torch
+    torch.manual_seed(77)
+    a = [standard_normal(3, 50) for _ in range(4)]
+    state_a = torch.get_rng_state()
+    torch.manual_seed(77)
+    buf = torch.empty(4, 3, 50)
+    for j in range(4):
+        standard_normal(3, 50, out=buf[j])
+    assert torch.equal(torch.stack(a), buf) and torch.equal(state_a, torch.get_rng_state())
+    torch.manual_seed(77)
+    buf64 = torch.empty(4, 3, 50, dtype=torch.float64)
+    for j in range(4):
+        standard_normal(3, 50, out=buf64[j])
+    assert torch.equal(torch.stack(a).double(), buf64)
