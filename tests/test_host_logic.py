@@ -252,3 +252,18 @@ def test_standard_normal_into_a_buffer_is_the_same_draw():
     for j in range(4):
         standard_normal(3, 50, out=buf64[j])
     assert torch.equal(torch.stack(a).double(), buf64)
+
+
+def test_first_chunk_sizes():
+    """engine.first_chunk: a call with many steps starts with 16, a short one (the driver's 20-step region) with one replay's worth,
+    tiny calls and small feeds are left alone; the sizes always fit the request and the feed"""
+    from meta_learning_pacoh_amd import engine
+    fc = engine.first_chunk
+    assert fc(200, 1024) == 16 and fc(64, 1024) == 16 and fc(1000, 128) == 16
+    assert fc(20, 1024) == 4 and fc(63, 1024) == 4 and fc(16, 1024) == 4
+    assert fc(15, 1024) == 15 and fc(7, 1024) == 7 and fc(1, 1024) == 1
+    assert fc(200, 8) == 4 and fc(20, 4) == 4 and fc(20, 2) == 2
+    for n in range(1, 300):
+        for chunk in (1, 4, 16, 100, 1024):
+            k = fc(n, chunk)
+            assert 1 <= k <= min(n, chunk)
