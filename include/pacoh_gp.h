@@ -204,6 +204,21 @@ int pacoh_mlp2_bwd(const void* x, int x_div, const void* theta, long theta_strid
                    const int32_t* hidden, int n_hidden, long off_a, int d_out_a, const void* g_a, long off_b,
                    int d_out_b, const void* g_b, void* d_theta, long d_theta_stride, int accumulate,
                    void* workspace, const void* stash, int B, int n, int dtype, void* stream);
+/* The optimizer step of a PACOH-MAP iteration folded into the gradient epilogue (round 3): with ONE parameter row (P = 1) and no
+ * exchange between gradient and update (world size 1), pacoh_hyper_bwd / pacoh_mlp_bwd_hyper / pacoh_mlp2_bwd_hyper apply AdamW
+ * (torch.optim.AdamW's op order, as pacoh_adam_step_dev) to every gradient entry in the launch that finishes it -- the slab
+ * reduction's threads hold the networks' entries, the hyper-parameter reduction's blocks the rest -- restricted to the column
+ * ranges [seg_lo[k], seg_hi[k]) (learning_mode), advance *step_counter and add the loss (lik[0]) to *loss_cum: the AdamW launch
+ * of GPR_meta_mll.py:115-117 disappears.  Where the fused slab reduction does not apply the same calls issue pacoh_adam_step_dev
+ * per range behind the gradient, so that the caller never has to know.  scalars: the PACOH_SC_ADAM block (4 values, device). */
+typedef struct pacoh_adam_inline {
+    void* param; void* exp_avg; void* exp_avg_sq;
+    const void* scalars;
+    double beta1, beta2;
+    int n_seg; int seg_lo[4]; int seg_hi[4];
+    int64_t* step_counter; void* loss_cum;
+} pacoh_adam_inline;
+
 /* pacoh_mlp2_bwd followed by pacoh_hyper_bwd (below) on the same d_theta rows -- the whole gradient epilogue of a step
  * (loss.backward() reaching the networks AND the raw GP hyper-parameters: GPR_meta_mll.py:115, svgd.py:16) in one call.  On the
  * fused fp32 path the hyper-parameter reduction runs in extra workgroups of the backward's slab-reduction launch: one launch and one
@@ -216,7 +231,7 @@ int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta, long theta
                          int T, int off_ls, int f, int off_os, int off_noise, int off_const, const void* d_lengthscale,
                          const void* d_outputscale, const void* d_noise, const void* d_const, const void* lml, void* lik,
                          double lik_scale, const int32_t* info, int32_t* fail_flag, void* svgd_workspace, int svgd_P, int svgd_D,
-                         int dtype, void* stream);
+                         const pacoh_adam_inline* opt, int dtype, void* stream);
 
 /* The same for configurations with ONE network (NN mean with an SE kernel: BASELINE config #2; or NN kernel features with a
  * constant mean): pacoh_mlp_bwd (accumulate = 0) followed by pacoh_hyper_bwd, the reduction riding in the slab reduction's launch
@@ -227,7 +242,7 @@ int pacoh_mlp_bwd_hyper(const void* x, int x_div, const void* theta, long theta_
                         const void* theta_rows, void* grad_rows, int T, int off_ls, int f, int off_os, int off_noise,
                         int off_const, const void* d_lengthscale, const void* d_outputscale, const void* d_noise, const void* d_const,
                         const void* lml, void* lik, double lik_scale, const int32_t* info, int32_t* fail_flag,
-                        void* svgd_workspace, int svgd_P, int svgd_D, int dtype, void* stream);
+                        void* svgd_workspace, int svgd_P, int svgd_D, const pacoh_adam_inline* opt, int dtype, void* stream);
 
 /* ---- A3 + A7: parameter transforms, hyper-prior ------------------------------------------------
  * softplus with optional floor, forward:  out = log(1+exp(raw)) + floor            (random_gp.py:69-74;
@@ -259,7 +274,7 @@ int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int T, int off_
                     int off_const, const void* d_ls, const void* d_os, const void* d_noise, const void* d_const,
                     void* grad, long grad_stride, const void* lml, void* lik, double lik_scale,
                     const int32_t* info, int32_t* fail_flag, void* svgd_workspace, int svgd_P, int svgd_D,
-                    int dtype, void* stream);
+                    const pacoh_adam_inline* opt, int dtype, void* stream);
 
 /* logp[p] = sum_d log N(theta[p,d]; prior_mean[d], prior_std[d]);  grad[p,d] (optional, += scaled):
  * grad += grad_scale * d logp / d theta.  Replaces CatDist.log_prob over the Normal blocks

@@ -132,7 +132,7 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         self._g_cum = torch.zeros((), dtype=self.dtype, device=self.device)
         self._fail = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._feed = StepFeed(self.device, self.dtype, tb_local, chunk=self.GRAPH_CHUNK)
-        self._graphs = None
+        self._graphs = self._opt_blk = None
 
     def _body_likelihood(self):
         # select + gather + hyper transforms: one launch; with Adam the step's last launch advances the feed's counter
@@ -140,14 +140,30 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         if batch is None:                                  # more ranks than tasks in the batch: this rank contributes zeros
             self._packed.zero_()
             return
-        # loss = -sum_t mll_t rides in the hyper-parameter reduction (lik_out), the gradient of it in grad_out
+        # loss = -sum_t mll_t rides in the hyper-parameter reduction (lik_out), the gradient of it in grad_out; at world size 1 so does
+        # the AdamW step (_adam_inline): every gradient entry is updated by the thread that finishes it
         self.engine.lml_and_grad(self.theta, batch, weight=-1.0, lik_out=self._g_loss, lik_scale=-1.0, grad_out=self._grad,
-                                 fail_flag=self._fail, hypers=hyp)
+                                 fail_flag=self._fail, hypers=hyp, opt=self._opt_block() if self._adam_inline() else None)
 
     def _adam_advances(self):
         return self.optimizer_name == 'Adam' and len(self.train_segments) > 0
 
+    def _adam_inline(self):
+        """the AdamW launch folded into the gradient epilogue (include/pacoh_gp.h, pacoh_adam_inline): no exchange between gradient
+        and update, i.e. world size 1, and a task batch on this rank; PACOH_MAP_ADAM_INLINE=0 keeps the separate launch (A/B, tests)"""
+        return (self._adam_advances() and parallel.world()[1] == 1 and self._feed.tb > 0 and len(self.train_segments) <= 4
+                and os.environ.get('PACOH_MAP_ADAM_INLINE', '1') != '0')
+
+    def _opt_block(self):
+        blk = getattr(self, '_opt_blk', None)
+        if blk is None:
+            blk = self._opt_blk = L.adam_inline(self.theta, self.exp_avg, self.exp_avg_sq, self._feed.sc[L.SC_ADAM:L.SC_ADAM + 4],
+                                                self.train_segments, step_counter=self._feed.ctr, loss_cum=self._g_cum.reshape(1))
+        return blk
+
     def _body_update(self):
+        if self._adam_inline():
+            return                                        # (done inside _body_likelihood's last launch)
         if not self._adam_advances():
             L.axpy(self._g_cum.reshape(1), self._g_loss, 1.0)
         for k, (lo, hi) in enumerate(self.train_segments):

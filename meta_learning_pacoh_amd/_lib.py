@@ -51,7 +51,7 @@ SIGNATURES = {
     'pacoh_mlp_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i]),
     'pacoh_mlp_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _l, _i, _vp, _i, _i, _i, _vp]),
     'pacoh_mlp_bwd_hyper': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _l, _vp, _i, _i,
-                                 _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _i, _i, _vp]),
+                                 _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     'pacoh_mlp2_fwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_mlp2_stash_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_mlp2_fwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -60,11 +60,11 @@ SIGNATURES = {
     'pacoh_mlp2_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_mlp2_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_mlp2_bwd_hyper': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _i,
-                                  _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _i, _i, _vp]),
+                                  _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     'pacoh_softplus_fwd': (_i, [_vp, _vp, _d, _l, _i, _vp]),
     'pacoh_softplus_bwd': (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),
     'pacoh_hyper_fwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
-    'pacoh_hyper_bwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _d, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pacoh_hyper_bwd': (_i, [_vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _d, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     'pacoh_step_select': (_i, [_vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _i, _vp]),
     'pacoh_scale_dev': (_i, [_vp, _vp, _l, _i, _vp]),
     'pacoh_step_begin': (_i, [_vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
@@ -104,7 +104,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 8              # pacoh_abi_version() of the library this table was written for
+ABI_VERSION = 9              # pacoh_abi_version() of the library this table was written for
 
 
 def load_library():
@@ -484,7 +484,7 @@ def mlp_bwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, g_out, 
 
 def mlp_bwd_hyper(x, x_div, theta, lo, P, d_in, hidden, d_out, g_out, grad, B, n, T, off_ls, f, off_os, off_noise, off_const,
                   d_ls, d_os, d_noise, d_const, lml=None, lik=None, lik_scale=1.0, info=None, fail_flag=None, kernel=KERNEL_RBF,
-                  workspace=None, svgd_bw=None):
+                  workspace=None, svgd_bw=None, opt=None):
     """mlp_bwd of the ONE network whose block starts at column lo of theta[P, D] (gradient into grad[:, lo:]) + hyper_bwd on the
     rows, in one C-ABI call (one launch less on the fused path); returns the workspace for reuse"""
     lib = load_library()
@@ -500,7 +500,7 @@ def mlp_bwd_hyper(x, x_div, theta, lo, P, d_in, hidden, d_out, g_out, grad, B, n
                                        _ptr(theta, x), _ptr(grad, x), T, off_ls, _kf(f, kernel), off_os, off_noise, off_const,
                                        _ptr(d_ls, x), _ptr(d_os, x), _ptr(d_noise, x), _ptr(d_const, x), _ptr(lml, x), _ptr(lik, x),
                                        float(lik_scale), _ptr(info if fail_flag is not None else None),
-                                       _ptr(fail_flag if info is not None else None), *_svgd_bw(svgd_bw), code, _stream()),
+                                       _ptr(fail_flag if info is not None else None), *_svgd_bw(svgd_bw), _opt_ptr(opt), code, _stream()),
                'pacoh_mlp_bwd_hyper')
     return workspace
 
@@ -558,7 +558,7 @@ def mlp2_bwd(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, g_a, off_b, d_out
 
 def mlp2_bwd_hyper(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, g_a, off_b, d_out_b, g_b, d_theta, B, n, T, off_ls, f, off_os,
                    off_noise, off_const, d_ls, d_os, d_noise, d_const, lml=None, lik=None, lik_scale=1.0, info=None, fail_flag=None,
-                   workspace=None, stash=None, svgd_bw=None):
+                   workspace=None, stash=None, svgd_bw=None, opt=None):
     """mlp2_bwd + hyper_bwd (grad = d_theta) in one C-ABI call: the gradient epilogue of a step; returns the workspace for reuse.
     svgd_bw = (SVGD workspace, P, D): the step's median bandwidth is computed by one more workgroup (hyper_bwd)"""
     lib = load_library()
@@ -572,9 +572,35 @@ def mlp2_bwd_hyper(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, g_a, off_b,
                                         _ptr(workspace), _ptr(stash), B, n, T, off_ls, f, off_os, off_noise, off_const,
                                         _ptr(d_ls, x), _ptr(d_os, x), _ptr(d_noise, x), _ptr(d_const, x), _ptr(lml, x), _ptr(lik, x),
                                         float(lik_scale), _ptr(info if fail_flag is not None else None),
-                                        _ptr(fail_flag if info is not None else None), *_svgd_bw(svgd_bw), code, _stream()),
+                                        _ptr(fail_flag if info is not None else None), *_svgd_bw(svgd_bw), _opt_ptr(opt), code, _stream()),
                'pacoh_mlp2_bwd_hyper')
     return workspace
+
+
+class AdamInline(ctypes.Structure):
+    """pacoh_adam_inline (include/pacoh_gp.h): the AdamW step of a PACOH-MAP iteration folded into the gradient epilogue"""
+    _fields_ = [('param', _vp), ('exp_avg', _vp), ('exp_avg_sq', _vp), ('scalars', _vp), ('beta1', _d), ('beta2', _d),
+                ('n_seg', _i), ('seg_lo', _i * 4), ('seg_hi', _i * 4), ('step_counter', _vp), ('loss_cum', _vp)]
+
+
+def adam_inline(param, exp_avg, exp_avg_sq, scalars, segments, step_counter=None, loss_cum=None, beta1=0.9, beta2=0.999):
+    """argument block for hyper_bwd / mlp_bwd_hyper / mlp2_bwd_hyper(opt=...): param / exp_avg / exp_avg_sq [1, D], scalars = the
+    PACOH_SC_ADAM block of the step's scalar row (device), segments = trained column ranges [(lo, hi), ...] (at most 4).  The
+    object keeps references to the tensors: it holds raw pointers"""
+    assert 1 <= len(segments) <= 4 and param.shape[0] == 1
+    o = AdamInline()
+    o.param, o.exp_avg, o.exp_avg_sq, o.scalars = (t.data_ptr() for t in (param, exp_avg, exp_avg_sq, scalars))
+    o.beta1, o.beta2, o.n_seg = float(beta1), float(beta2), len(segments)
+    for k, (lo, hi) in enumerate(segments):
+        o.seg_lo[k], o.seg_hi[k] = int(lo), int(hi)
+    o.step_counter = step_counter.data_ptr() if step_counter is not None else None
+    o.loss_cum = loss_cum.data_ptr() if loss_cum is not None else None
+    o._keep = (param, exp_avg, exp_avg_sq, scalars, step_counter, loss_cum)
+    return o
+
+
+def _opt_ptr(opt):
+    return ctypes.cast(ctypes.pointer(opt), _vp) if opt is not None else None
 
 
 def _svgd_bw(svgd_bw):
@@ -618,7 +644,7 @@ def hyper_fwd(theta, off_ls, f, off_os, off_noise, noise_floor, kernel=KERNEL_RB
 
 
 def hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, grad, lml=None, lik=None,
-              lik_scale=1.0, info=None, fail_flag=None, kernel=KERNEL_RBF, svgd_bw=None):
+              lik_scale=1.0, info=None, fail_flag=None, kernel=KERNEL_RBF, svgd_bw=None, opt=None):
     """lml [T*P] and lik [P] (both or neither): lik[p] = lik_scale * sum_t lml[t, p] in the same launch;
     info [T*P] and fail_flag [1] (int32, both or neither): fail_flag |= any(info < 0);
     svgd_bw = (SVGD workspace, P, D), P <= 64: one more workgroup computes the SVGD step's median bandwidth from the distance matrix
@@ -630,7 +656,7 @@ def hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_n
                                    _ptr(d_os, theta), _ptr(d_noise, theta), _ptr(d_const, theta), _ptr(grad, theta),
                                    grad.shape[1], _ptr(lml, theta), _ptr(lik, theta), float(lik_scale),
                                    _ptr(info if fail_flag is not None else None), _ptr(fail_flag if info is not None else None),
-                                   *_svgd_bw(svgd_bw), dtype_code(theta), _stream()), 'pacoh_hyper_bwd')
+                                   *_svgd_bw(svgd_bw), _opt_ptr(opt), dtype_code(theta), _stream()), 'pacoh_hyper_bwd')
 
 
 def prior_logprob_grad(theta, prior_mean, prior_std, grad=None, grad_scale=1.0):

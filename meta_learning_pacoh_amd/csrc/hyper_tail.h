@@ -8,6 +8,49 @@
 
 namespace pacoh {
 
+// The optimizer step of a PACOH-MAP iteration applied by the threads that FINISH a gradient entry (round 3): Adam is elementwise, the
+// slab reduction's threads hold the networks' gradient entries and the hyper-parameter reduction's blocks the rest, so at world size
+// 1 (no exchange between gradient and update) the AdamW launch disappears.  One parameter row (P = 1); op order of adam_dev_kernel.
+template <typename T>
+struct AdamInline {
+    T* param; T* m; T* v;                     // param == nullptr: off
+    const T* sc;                              // {1 - lr * weight_decay, lr / (1 - beta1^t), sqrt(1 - beta2^t), eps} in device memory
+    T one_minus_b1, b2, one_minus_b2;
+    int nseg; int lo[4], hi[4];               // trained column ranges (learning_mode)
+    long* step_counter; T* cum;               // the feed's counter (+1 per step) and the running sum of the logged loss, by the likelihood block
+};
+// One AdamW update, every operation rounded on its own in the order of torch.optim._single_tensor_adam (mul_(1 - lr wd); lerp_;
+// mul_(beta2).addcmul_; sqrt / bias correction + eps; addcdiv_).  No fused multiply-adds: which of `a * b + c * d`'s products the
+// compiler folds into the addition depends on the code around it, and the separate AdamW launch (adam_dev_kernel) and the update
+// folded into the gradient epilogue (adam_inline) must give the same bits.
+template <typename T>
+__device__ __forceinline__ void adam_update(T& p, T g, T& m, T& v, T decay_mul, T one_minus_b1, T b2, T one_minus_b2, T step_size,
+                                            T bc2_sqrt, T eps) {
+#pragma clang fp contract(off)
+    T pp = p * decay_mul;
+    T d1 = g - m;
+    T d2 = d1 * one_minus_b1;
+    T mq = m + d2;
+    T v1 = v * b2;
+    T g1 = one_minus_b2 * g;
+    T g2 = g1 * g;
+    T vq = v1 + g2;
+    T denom = t_sqrt<T>(vq) / bc2_sqrt + eps;
+    T r = mq / denom;
+    T u = step_size * r;
+    p = pp - u; m = mq; v = vq;
+}
+template <typename T>
+__device__ __forceinline__ void adam_inline(const AdamInline<T>& o, long q, T g) {
+    if (!o.param) return;
+    bool in = false;
+    for (int s = 0; s < o.nseg; ++s) in |= q >= o.lo[s] && q < o.hi[s];
+    if (!in) return;
+    T p = o.param[q], mq = o.m[q], vq = o.v[q];
+    adam_update<T>(p, g, mq, vq, o.sc[0], o.one_minus_b1, o.b2, o.one_minus_b2, o.sc[1], o.sc[2], o.sc[3]);
+    o.param[q] = p; o.m[q] = mq; o.v[q] = vq;
+}
+
 template <typename T>
 struct HyperBwdArgs {
     const T* theta; long stride; int P, Tt, off_ls, f, off_os, off_noise, off_const;
@@ -19,6 +62,7 @@ struct HyperBwdArgs {
                               // sum over the f per-dimension gradients, the entries behind it do not exist
     const T* sv_d2; int sv_P; T* sv_bw;      // SVGD: ONE more virtual block computes the step's median-heuristic bandwidth from the
                                              // particles' distance matrix (step_tail.h, svgd_bandwidth_block) | sv_bw = nullptr
+    AdamInline<T> opt;                       // PACOH-MAP at world size 1: the AdamW step on every entry this reduction finishes
 };
 
 // virtual blocks of the reduction itself, and with the optional bandwidth block behind them
@@ -59,9 +103,18 @@ __device__ __forceinline__ void hyper_bwd_block(const HyperBwdArgs<T>& a, int w,
     __syncthreads();
     if (threadIdx.x == 0) {
         s = (red[0] + red[1]) + (red[2] + red[3]);
-        if (e == a.f + 3) { if (a.lik) a.lik[p] = a.lik_scale * s; return; }
-        const T chain = (e == a.f + 2) ? T(1) : hyper_sigmoid<T>(a.theta[(long)p * a.stride + off]);
-        a.grad[(long)p * a.gstride + off] = s * chain;
+        if (e == a.f + 3) {
+            if (a.lik) a.lik[p] = a.lik_scale * s;
+            if (a.opt.param) {                             // (as adam_dev_kernel's first thread: feed counter, running loss sum)
+                if (a.opt.step_counter) *a.opt.step_counter += 1;
+                if (a.opt.cum) *a.opt.cum += a.lik_scale * s;
+            }
+            return;
+        }
+        const T chain = (e == a.f + 2) ? T(1) : hyper_sigmoid<T>(a.theta[(long)p * a.stride + off]);      // (read BEFORE the update below)
+        const T gv = s * chain;
+        a.grad[(long)p * a.gstride + off] = gv;
+        adam_inline<T>(a.opt, off, gv);
     }
 }
 

@@ -347,14 +347,8 @@ __global__ void adam_dev_kernel(T* __restrict__ param, const T* __restrict__ gra
     if (q == 0 && step_counter) *step_counter += 1;  // the step's last launch also advances the feed (pacoh_step_begin, advance = 0)
     if (q == 0 && cum) *cum += *loss;                // ... and keeps the running sum of the logged loss (GPR_meta_mll.py:119-125)
     if (q >= count) return;
-    const T decay_mul = sc[0], step_size = sc[1], bc2_sqrt = sc[2], eps = sc[3];
-    T g = grad[q];
-    T p = param[q] * decay_mul;
-    T mq = m[q];
-    mq = mq + (g - mq) * one_minus_b1;
-    T vq = v[q] * b2 + one_minus_b2 * g * g;
-    T denom = t_sqrt<T>(vq) / bc2_sqrt + eps;
-    p = p - step_size * (mq / denom);
+    T p = param[q], mq = m[q], vq = v[q];
+    adam_update<T>(p, grad[q], mq, vq, sc[0], one_minus_b1, b2, one_minus_b2, sc[1], sc[2], sc[3]);          // (hyper_tail.h)
     param[q] = p; m[q] = mq; v[q] = vq;
 }
 
@@ -702,7 +696,7 @@ extern "C" int pacoh_gather_tasks(const void* x, const void* y, const int32_t* n
     return launch_status();
 }
 
-extern "C" int pacoh_abi_version(void) { return 8; }
+extern "C" int pacoh_abi_version(void) { return 9; }
 
 extern "C" int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise,
                                double noise_floor, void* ls, void* os, void* noise, int dtype, void* stream) {
@@ -726,8 +720,10 @@ extern "C" int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int 
                                int off_const, const void* d_ls, const void* d_os, const void* d_noise, const void* d_const,
                                void* grad, long grad_stride, const void* lml, void* lik, double lik_scale,
                                const int32_t* info, int32_t* fail_flag, void* svgd_workspace, int svgd_P, int svgd_D,
-                               int dtype, void* stream) {
+                               const pacoh_adam_inline* opt, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (opt && (!opt->param || !opt->exp_avg || !opt->exp_avg_sq || !opt->scalars || opt->n_seg < 1 || opt->n_seg > 4 || P != 1 || !lml))
+        return PACOH_EINVAL;
     const int tie = kernel_of(f) != PACOH_KERNEL_RBF;
     f = features_of(f);
     if (!theta || !grad || !d_ls || !d_noise || P <= 0 || T_ <= 0 || f <= 0) return PACOH_EINVAL;
@@ -739,14 +735,24 @@ extern "C" int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int 
         HyperBwdArgs<float> a = {(const float*)theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, (const float*)d_ls,
                                  (const float*)d_os, (const float*)d_noise, (const float*)d_const, (float*)grad, grad_stride,
                                  (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag, tie,
-                                 ws, svgd_P, ws ? ws + svgd_bw_slot(svgd_P, svgd_D) : nullptr};
+                                 ws, svgd_P, ws ? ws + svgd_bw_slot(svgd_P, svgd_D) : nullptr, AdamInline<float>{}};
+        if (opt) {
+            a.opt = {(float*)opt->param, (float*)opt->exp_avg, (float*)opt->exp_avg_sq, (const float*)opt->scalars, (float)(1.0 - opt->beta1),
+                     (float)opt->beta2, (float)(1.0 - opt->beta2), opt->n_seg, {0, 0, 0, 0}, {0, 0, 0, 0}, (long*)opt->step_counter, (float*)opt->loss_cum};
+            for (int k = 0; k < opt->n_seg; ++k) { a.opt.lo[k] = opt->seg_lo[k]; a.opt.hi[k] = opt->seg_hi[k]; }
+        }
         hipLaunchKernelGGL(hyper_bwd_kernel<float>, dim3((unsigned)hyper_tail_blocks(a)), dim3(256), 0, (hipStream_t)stream, a);
     } else {
         double* ws = (double*)svgd_workspace;
         HyperBwdArgs<double> a = {(const double*)theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, (const double*)d_ls,
                                   (const double*)d_os, (const double*)d_noise, (const double*)d_const, (double*)grad, grad_stride,
                                   (const double*)lml, (double*)lik, lik_scale, info, fail_flag, tie,
-                                  ws, svgd_P, ws ? ws + svgd_bw_slot(svgd_P, svgd_D) : nullptr};
+                                  ws, svgd_P, ws ? ws + svgd_bw_slot(svgd_P, svgd_D) : nullptr, AdamInline<double>{}};
+        if (opt) {
+            a.opt = {(double*)opt->param, (double*)opt->exp_avg, (double*)opt->exp_avg_sq, (const double*)opt->scalars, 1.0 - opt->beta1,
+                     opt->beta2, 1.0 - opt->beta2, opt->n_seg, {0, 0, 0, 0}, {0, 0, 0, 0}, (long*)opt->step_counter, (double*)opt->loss_cum};
+            for (int k = 0; k < opt->n_seg; ++k) { a.opt.lo[k] = opt->seg_lo[k]; a.opt.hi[k] = opt->seg_hi[k]; }
+        }
         hipLaunchKernelGGL(hyper_bwd_kernel<double>, dim3((unsigned)hyper_tail_blocks(a)), dim3(256), 0, (hipStream_t)stream, a);
     }
     return launch_status();

@@ -33,7 +33,7 @@ size_t mlp_fused_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hid
 int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
                   int n_hidden, int nets, const long* off, const int* d_out, const void* const* g_out, void* d_theta,
                   long d_theta_stride, int accumulate, void* workspace, const void* stash, int B, int n, hipStream_t s,
-                  const HyperBwdArgs<float>* tail);
+                  const HyperBwdArgs<float>* tail, long col_base = 0);
 // mlp_layers.hip
 size_t mlp_layers_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype, int bwd);
 int mlp_layers_fwd(const void*, int, const void*, long, int, int, const int32_t*, int, int, void*, void*, int, int, int, hipStream_t);
@@ -262,6 +262,32 @@ extern "C" size_t pacoh_mlp2_bwd_workspace_bytes(int B, int P, int n, int d_in, 
     return align256(a > b ? a : b);
 }
 
+// pacoh_adam_inline (include/pacoh_gp.h) -> the device-side struct of the fused path
+static bool adam_inline_ok(const pacoh_adam_inline* o, int P, const void* lml) {
+    return o->param && o->exp_avg && o->exp_avg_sq && o->scalars && o->n_seg >= 0 && o->n_seg <= 4 && P == 1 && lml != nullptr;
+}
+static AdamInline<float> adam_inline_f32(const pacoh_adam_inline* o) {
+    AdamInline<float> a = {(float*)o->param, (float*)o->exp_avg, (float*)o->exp_avg_sq, (const float*)o->scalars, (float)(1.0 - o->beta1),
+                           (float)o->beta2, (float)(1.0 - o->beta2), o->n_seg, {0, 0, 0, 0}, {0, 0, 0, 0}, (long*)o->step_counter, (float*)o->loss_cum};
+    for (int k = 0; k < o->n_seg; ++k) { a.lo[k] = o->seg_lo[k]; a.hi[k] = o->seg_hi[k]; }
+    return a;
+}
+// the same step as separate launches (paths without the fused slab reduction): one pacoh_adam_step_dev per trained segment, the last
+// one advancing the feed's counter and adding the loss to its running sum
+static int adam_inline_fallback(const pacoh_adam_inline* o, const void* grad_rows, const void* loss, int dtype, void* stream) {
+    const size_t es = dtype == PACOH_F64 ? 8 : 4;
+    for (int k = 0; k < o->n_seg; ++k) {
+        const bool last = k == o->n_seg - 1;
+        const long lo = o->seg_lo[k], cnt = o->seg_hi[k] - lo;
+        if (cnt <= 0) continue;
+        const int rc = pacoh_adam_step_dev((char*)o->param + lo * es, (const char*)grad_rows + lo * es, (char*)o->exp_avg + lo * es,
+                                           (char*)o->exp_avg_sq + lo * es, o->scalars, o->beta1, o->beta2, cnt,
+                                           last ? o->step_counter : nullptr, last ? o->loss_cum : nullptr, last ? loss : nullptr, dtype, stream);
+        if (rc) return rc;
+    }
+    return PACOH_OK;
+}
+
 static int mlp2_bwd_impl(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
                          const int32_t* hidden, int n_hidden, long off_a, int d_out_a, const void* g_a, long off_b,
                          int d_out_b, const void* g_b, void* d_theta, long d_theta_stride, int accumulate,
@@ -306,9 +332,10 @@ extern "C" int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta,
                                     int T_, int off_ls, int f, int off_os, int off_noise, int off_const, const void* d_ls,
                                     const void* d_os, const void* d_noise, const void* d_const, const void* lml, void* lik,
                                     double lik_scale, const int32_t* info, int32_t* fail_flag,
-                                    void* svgd_workspace, int svgd_P, int svgd_D, int dtype, void* stream) {
+                                    void* svgd_workspace, int svgd_P, int svgd_D, const pacoh_adam_inline* opt, int dtype, void* stream) {
     if (svgd_workspace && (svgd_P <= 0 || svgd_D <= 0)) return PACOH_EINVAL;
     if (svgd_workspace && svgd_P > 64) return PACOH_ELIMIT;
+    if (opt && (!adam_inline_ok(opt, P, lml) || opt->n_seg < 1)) return PACOH_EINVAL;
     if (!d_ls || !d_noise || T_ <= 0 || features_of(f) <= 0 || (lml == nullptr) != (lik == nullptr)) return PACOH_EINVAL;
     if (accumulate) return PACOH_EINVAL;              // (the tail writes its columns of d_theta; the blocks of the two networks are overwritten)
     bool tail_done = false;
@@ -318,7 +345,8 @@ extern "C" int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta,
                                     (const float*)d_ls, (const float*)d_os, (const float*)d_noise, (const float*)d_const, (float*)d_theta,
                                     d_theta_stride, (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag,
                                     kernel_of(f) != PACOH_KERNEL_RBF, (const float*)svgd_workspace, svgd_P,
-                                    svgd_workspace ? (float*)svgd_workspace + svgd_bw_slot(svgd_P, svgd_D) : nullptr};
+                                    svgd_workspace ? (float*)svgd_workspace + svgd_bw_slot(svgd_P, svgd_D) : nullptr,
+                                    opt ? adam_inline_f32(opt) : AdamInline<float>{}};
         rc = mlp2_bwd_impl(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, off_a, d_out_a, g_a, off_b, d_out_b, g_b, d_theta,
                            d_theta_stride, accumulate, workspace, stash, B, n, dtype, stream, &tail, &tail_done);
     } else {
@@ -326,8 +354,10 @@ extern "C" int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta,
                            d_theta_stride, accumulate, workspace, stash, B, n, dtype, stream, nullptr, nullptr);
     }
     if (rc || tail_done) return rc;
-    return pacoh_hyper_bwd(theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, d_theta,
-                           d_theta_stride, lml, lik, lik_scale, info, fail_flag, svgd_workspace, svgd_P, svgd_D, dtype, stream);
+    rc = pacoh_hyper_bwd(theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, d_theta,
+                         d_theta_stride, lml, lik, lik_scale, info, fail_flag, svgd_workspace, svgd_P, svgd_D, nullptr, dtype, stream);
+    if (rc || !opt) return rc;
+    return adam_inline_fallback(opt, d_theta, lik, dtype, stream);
 }
 
 // pacoh_mlp_bwd + pacoh_hyper_bwd for configurations with ONE network (mean or kernel features): as pacoh_mlp2_bwd_hyper, the
@@ -339,8 +369,9 @@ extern "C" int pacoh_mlp_bwd_hyper(const void* x, int x_div, const void* theta, 
                                    const void* theta_rows, void* grad_rows, int T_, int off_ls, int f, int off_os, int off_noise,
                                    int off_const, const void* d_ls, const void* d_os, const void* d_noise, const void* d_const,
                                    const void* lml, void* lik, double lik_scale, const int32_t* info, int32_t* fail_flag,
-                                   void* svgd_workspace, int svgd_P, int svgd_D, int dtype, void* stream) {
+                                   void* svgd_workspace, int svgd_P, int svgd_D, const pacoh_adam_inline* opt, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (opt && (!adam_inline_ok(opt, P, lml) || opt->n_seg < 1)) return PACOH_EINVAL;
     if (!g_out || !d_theta || !workspace || !x || !theta || !theta_rows || !grad_rows || x_div <= 0 || P <= 0 || B <= 0 || n <= 0 || B % P != 0)
         return PACOH_EINVAL;
     if (!d_ls || !d_noise || T_ <= 0 || features_of(f) <= 0 || (lml == nullptr) != (lik == nullptr)) return PACOH_EINVAL;
@@ -353,17 +384,20 @@ extern "C" int pacoh_mlp_bwd_hyper(const void* x, int x_div, const void* theta, 
                                     (const float*)d_ls, (const float*)d_os, (const float*)d_noise, (const float*)d_const, (float*)grad_rows,
                                     d_theta_stride, (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag,
                                     kernel_of(f) != PACOH_KERNEL_RBF, (const float*)svgd_workspace, svgd_P,
-                                    svgd_workspace ? (float*)svgd_workspace + svgd_bw_slot(svgd_P, svgd_D) : nullptr};
+                                    svgd_workspace ? (float*)svgd_workspace + svgd_bw_slot(svgd_P, svgd_D) : nullptr,
+                                    opt ? adam_inline_f32(opt) : AdamInline<float>{}};
         const long off = 0;
         const void* const gs[1] = {g_out};
         return mlp_fused_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 1, &off, &d_out, gs, d_theta, d_theta_stride,
-                             0, workspace, nullptr, B, n, (hipStream_t)stream, &tail);
+                             0, workspace, nullptr, B, n, (hipStream_t)stream, &tail, (long)((const float*)d_theta - (const float*)grad_rows));
     }
     rc = pacoh_mlp_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, 0, workspace, B, n,
                        dtype, stream);
     if (rc) return rc;
-    return pacoh_hyper_bwd(theta_rows, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, grad_rows,
-                           d_theta_stride, lml, lik, lik_scale, info, fail_flag, svgd_workspace, svgd_P, svgd_D, dtype, stream);
+    rc = pacoh_hyper_bwd(theta_rows, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, grad_rows,
+                         d_theta_stride, lml, lik, lik_scale, info, fail_flag, svgd_workspace, svgd_P, svgd_D, nullptr, dtype, stream);
+    if (rc || !opt) return rc;
+    return adam_inline_fallback(opt, grad_rows, lik, dtype, stream);
 }
 
 extern "C" int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, int T_, int P, int Wd,

@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
 
 // out[p, w] (+)= sum_c in[c, p, w] for up to two networks in one launch (blockIdx.y): 8 lanes per output element split the
 // slabs, fixed order -> deterministic
-struct SlabReduce { const float* in; float* out; int Wd; };
+struct SlabReduce { const float* in; float* out; int Wd; int col0; };    // col0: the network block's first column in the parameter row
 // (blockIdx.y == nets, tail_blocks > 0: the step's hyper-parameter reduction rides in this launch -- hyper_tail.h)
 __global__ void __launch_bounds__(256) fused_reduce_slab_kernel(SlabReduce s0, SlabReduce s1, long out_stride, int accumulate, int C, int P,
                                                                 int nets, HyperBwdArgs<float> tail, int tail_blocks) {
@@ -547,7 +547,9 @@ __global__ void __launch_bounds__(256) fused_reduce_slab_kernel(SlabReduce s0, S
     if (idx < tot && part == 0) {
         const int p = (int)(idx / sr.Wd), w = (int)(idx - (long)p * sr.Wd);
         float* o = sr.out + (long)p * out_stride + w;
-        *o = accumulate ? *o + s : s;
+        const float gv = accumulate ? *o + s : s;
+        *o = gv;
+        if (P == 1) adam_inline<float>(tail.opt, sr.col0 + w, gv);         // PACOH-MAP: the AdamW step on this entry (hyper_tail.h)
     }
 }
 
@@ -710,7 +712,7 @@ size_t mlp_fused_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hid
 int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
                   int n_hidden, int nets, const long* off, const int* d_out, const void* const* g_out, void* d_theta,
                   long d_theta_stride, int accumulate, void* workspace, const void* stash, int B, int n, hipStream_t s,
-                  const HyperBwdArgs<float>* tail) {
+                  const HyperBwdArgs<float>* tail, long col_base) {
     FusedArgs a = {};
     fused_fill(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, B, n, stash, nets);
     const FusedBwdPlan pl = fused_bwd_plan(a.R, P, nets, n_hidden);
@@ -722,7 +724,7 @@ int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride
         a.net[k].theta_off = off[k]; a.net[k].g_out = (const float*)g_out[k]; a.net[k].d_out = d_out[k];
         a.net[k].D_net = fused_dnet(d_in, hidden, n_hidden, d_out[k]);
         a.net[k].slab = ws;
-        sr[k].in = ws; sr[k].out = (float*)d_theta + off[k]; sr[k].Wd = a.net[k].D_net;
+        sr[k].in = ws; sr[k].out = (float*)d_theta + off[k]; sr[k].Wd = a.net[k].D_net; sr[k].col0 = (int)(col_base + off[k]);
         ws += (size_t)pl.chunks * (bwd_wg_slab(n_hidden) ? 1 : 4) * P * a.net[k].D_net;
         if (a.net[k].D_net > wmax) wmax = a.net[k].D_net;
     }

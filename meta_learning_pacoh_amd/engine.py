@@ -563,14 +563,15 @@ class GPEngine:
         return lml.reshape(T, P), info
 
     def lml_and_grad(self, theta, batch, weight=1.0, lik_out=None, lik_scale=1.0, grad_out=None, fail_flag=None, hypers=None,
-                     svgd_tail=None):
+                     svgd_tail=None, opt=None):
         """returns (lml[T,P], grad[P,D]) with grad = d(weight * sum_t lml[t,p]) / d theta[p];
         lik_out[P] (optional) receives lik_scale * sum_t lml[t,p] from the same launch that reduces the hyper-gradients;
         grad_out[P,D] (optional, contiguous) is used for the gradient instead of a fresh tensor;
         fail_flag (optional int32[1]) is raised by that launch if any problem's Cholesky failed even with jitter;
         svgd_tail = (particles, workspace, counter, want_bandwidth): the pipelined SVGD step's distance matrix and counter
         increment, in extra workgroups of the forward launch where there is one (L.mlp2_fwd), and -- want_bandwidth -- its median
-        bandwidth by one more workgroup of the hyper-parameter reduction (L.hyper_bwd)"""
+        bandwidth by one more workgroup of the hyper-parameter reduction (L.hyper_bwd);
+        opt (L.adam_inline(...), one parameter row): the AdamW step is applied to every gradient entry where it is finished"""
         lay = self.layout
         P, D = theta.shape
         T, n = batch.T, batch.n
@@ -597,6 +598,8 @@ class GPEngine:
                      info=info if fail_flag is not None else None, fail_flag=fail_flag)
         if svgd_tail is not None and svgd_tail[3]:
             hyper['svgd_bw'] = (svgd_tail[1],) + tuple(svgd_tail[0].shape)
+        if opt is not None:                                 # PACOH-MAP at world size 1: the AdamW step rides in the gradient epilogue
+            hyper['opt'] = opt
         if pair is not None:
             # both networks' backward + the hyper-parameter reduction (softplus chain rule, likelihood sums, failure flag): one call,
             # on the fused path two launches

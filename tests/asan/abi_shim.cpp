@@ -30,7 +30,7 @@ int main() {
         std::printf("%zu\n", pacoh_mlp_bwd_workspace_bytes(60, 3, 33, 2, h, 3, 2, PACOH_F32));
         return 0;
     }
-    EXPECT(pacoh_abi_version() == 8);
+    EXPECT(pacoh_abi_version() == 9);
     EXPECT(pacoh_gp_small_max_n(PACOH_F32, 0) >= 128 && pacoh_gp_small_max_n(PACOH_F64, 1) >= 64 && pacoh_gp_small_max_n(7, 0) == PACOH_EDTYPE);
     EXPECT(pacoh_svgd_workspace_bytes(20, 2534, PACOH_F32) == (2 * 400 + 20 + 8) * 4);
     EXPECT(pacoh_gp_predict_workspace_bytes(4, 64, 50, PACOH_F32, 1) == 4u * 50 * 64 * 4 && pacoh_gp_predict_workspace_bytes(4, 64, 50, PACOH_F32, 0) == 0);
@@ -92,7 +92,7 @@ int main() {
                                   (const int64_t*)fake, fake, PACOH_SC_COUNT, nullptr, 0, fake, nullptr, nullptr, nullptr, nullptr, nullptr,
                                   nullptr, 0, 0, 8, 3, -1, 2, 0.0, fake, nullptr, fake, 0, PACOH_F32, nullptr) == PACOH_EINVAL);   // ls beyond D
     EXPECT(pacoh_hyper_bwd(fake, 10, 3, 2, 0, 2, -1, 2, -1, fake, nullptr, fake, nullptr, fake, 10, nullptr, nullptr, 1.0, nullptr, nullptr,
-                           fake, 65, 10, PACOH_F32, nullptr) == PACOH_ELIMIT);                     // bandwidth block: register sort, P <= 64
+                           fake, 65, 10, nullptr, PACOH_F32, nullptr) == PACOH_ELIMIT);                     // bandwidth block: register sort, P <= 64
     {
         int32_t* h = (int32_t*)std::malloc(2 * sizeof(int32_t));
         h[0] = h[1] = 32;
@@ -103,6 +103,13 @@ int main() {
     EXPECT(pacoh_step_begin_vi(nullptr, 0, fake, PACOH_SC_COUNT, fake, 59, (int64_t*)fake, (int32_t*)fake, fake, fake, nullptr, nullptr, nullptr,
                                nullptr, nullptr, nullptr, 0, 0, fake, 6, 10, fake, fake, 0, 2, -1, 2, 0.0, nullptr, nullptr, nullptr, 0,
                                PACOH_F32, nullptr) == PACOH_EINVAL);                              // noise row is not S x D values
+    {   // the AdamW step folded into the gradient epilogue: one parameter row only, and the likelihood sums must be requested
+        pacoh_adam_inline opt = {fake, fake, fake, fake, 0.9, 0.999, 1, {0, 0, 0, 0}, {5, 0, 0, 0}, nullptr, nullptr};
+        EXPECT(pacoh_hyper_bwd(fake, 10, 3, 2, 0, 2, -1, 2, -1, fake, nullptr, fake, nullptr, fake, 10, fake, fake, 1.0, nullptr, nullptr,
+                               nullptr, 0, 0, &opt, PACOH_F32, nullptr) == PACOH_EINVAL);           // P = 3
+        EXPECT(pacoh_hyper_bwd(fake, 10, 1, 2, 0, 2, -1, 2, -1, fake, nullptr, fake, nullptr, fake, 10, nullptr, nullptr, 1.0, nullptr, nullptr,
+                               nullptr, 0, 0, &opt, PACOH_F32, nullptr) == PACOH_EINVAL);           // no likelihood block to count the step
+    }
     EXPECT(pacoh_adam_step(nullptr, nullptr, nullptr, nullptr, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 10, PACOH_F32, nullptr) == PACOH_EINVAL);
     EXPECT(pacoh_allreduce_sum(nullptr, 4, PACOH_F32, fake, nullptr) == PACOH_EINVAL);
     EXPECT(pacoh_allreduce_sum(fake, 4, 7, fake, nullptr) == PACOH_EDTYPE);

@@ -691,6 +691,40 @@ def test_small_first_chunk_does_not_change_the_run(M, kind, monkeypatch):
     assert bool(torch.isfinite(out[0]).all()) and torch.equal(out[0], out[1])
 
 
+@pytest.mark.parametrize('cfg', [
+    dict(),                                                                         # two fused networks: slab reduction + tail
+    dict(covar_module='SE', mean_module='NN'),                                      # one network (BASELINE config #2)
+    dict(covar_module='NN', mean_module='constant', feature_dim=3),
+    dict(covar_module='SE', mean_module='constant'),                                # no network: pacoh_hyper_bwd alone
+    dict(mean_nn_layers=(16, 16), kernel_nn_layers=(16, 16)),                       # general MLP path: AdamW launches behind the gradient
+    dict(learning_mode='learn_mean', covar_module='SE'), dict(learning_mode='learn_kernel', mean_module='constant'),   # trained column ranges
+    dict(mean_nn_layers=(32, 32, 32, 32), kernel_nn_layers=(32, 32, 32, 32), weight_decay=0.0),
+])
+@pytest.mark.parametrize('graph', ['0', '1'])
+def test_map_adam_folded_into_the_gradient_epilogue(M, cfg, graph, monkeypatch):
+    """pacoh_adam_inline: the AdamW step applied by the threads that finish a gradient entry (slab reduction, hyper-parameter
+    reduction) -- the same bits as the separate pacoh_adam_step_dev launch (PACOH_MAP_ADAM_INLINE=0): parameters, optimizer state,
+    logged loss; weight decay on every group, decaying learning rate, ragged tasks, eager and replayed"""
+    rs = np.random.RandomState(13)
+    tasks = []
+    for t in range(7):
+        n = 8 + 2 * (t % 3)
+        x = rs.uniform(-3, 3, size=(n, 2))
+        tasks.append((x, np.sin(x[:, :1]) + 0.3 * x[:, 1:] + 0.05 * rs.randn(n, 1)))
+    monkeypatch.setenv('PACOH_GRAPH', graph)
+    kw = dict(task_batch_size=4, lr_params=1e-2, weight_decay=0.05, lr_decay=0.9, random_seed=3)
+    kw.update(cfg)
+    out = []
+    for inline in ('0', '1'):
+        monkeypatch.setenv('PACOH_MAP_ADAM_INLINE', inline)
+        m = M.GPRegressionMetaLearned(tasks, **kw)
+        loss = m.meta_fit(verbose=False, n_iter=14, log_period=4)
+        assert m._adam_inline() == (inline == '1') and m.opt_step == 14
+        out.append((m.theta.clone(), m.exp_avg.clone(), m.exp_avg_sq.clone(), float(loss)))
+    assert bool(torch.isfinite(out[1][0]).all())
+    assert all(torch.equal(a, b) for a, b in zip(out[0][:3], out[1][:3])) and out[0][3] == out[1][3]
+
+
 def test_launcher_networks_run_through_the_learners(M):
     """experiments/meta_GPR_SVGD_base_exp.py:29-30,83 (4 x 32, 10 particles, bandwidth 0.1, prior_factor 0.1, 2 tasks per step) and
     experiments/meta_GPR_mll_base_exp.py:29-30 (4 x 128, 2 tasks x 5 points per step): construct, train a few steps, predict; the
