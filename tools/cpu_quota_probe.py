@@ -1,5 +1,14 @@
-import os, sys, time, torch
-sys.path.insert(0, '/root/repo')
+"""Is the host side being throttled by the container's CPU quota?  Prints the cgroup quota, the cores torch sizes its intra-op pool
+by, then runs 24 chunks of 64 training steps and reports per chunk the wall time per step, the host's issue time and the GPU-event
+time per step, and finally the cgroup's cpu.stat delta (nr_throttled, throttled_usec).
+    python tools/cpu_quota_probe.py [torch threads]        (no argument: torch's default pool)"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def stat():
     for p in ('/sys/fs/cgroup/cpu.stat', '/sys/fs/cgroup/cpu/cpu.stat'):
         if os.path.exists(p):
