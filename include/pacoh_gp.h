@@ -211,13 +211,28 @@ int pacoh_mlp2_bwd(const void* x, int x_div, const void* theta, long theta_strid
  * ranges [seg_lo[k], seg_hi[k]) (learning_mode), advance *step_counter and add the loss (lik[0]) to *loss_cum: the AdamW launch
  * of GPR_meta_mll.py:115-117 disappears.  Where the fused slab reduction does not apply the same calls issue pacoh_adam_step_dev
  * per range behind the gradient, so that the caller never has to know.  scalars: the PACOH_SC_ADAM block (4 values, device). */
+/* next (optional; fused fp32 networks only -- pacoh_mlp_fused_path(); PACOH_ELIMIT otherwise): the pipelined feed of "The pipelined
+ * SVGD step" below for PACOH-MAP.  The backward launch of the call advances *counter, the slab-reduction launch behind it reads the
+ * step's scalars from sc2[*counter & 1] (`scalars` and `step_counter` above are then unused), publishes softplus of the raw
+ * hyper-parameters it has just updated to ls[1,f] / os[1] / noise[1] (+ noise_floor), copies row *counter + 1 of sc_all into the other
+ * row of sc2 and gathers that row's tb tasks into out_x / out_y / out_n_valid: an iteration is FOUR launches (forward, GP, backward,
+ * reduction); pacoh_step_begin runs once per chunk of iterations (row 0, then *counter := -1). */
+typedef struct pacoh_step_next {
+    int64_t* counter; void* sc2; int n_sc;
+    const int64_t* idx_all; int tb; const void* sc_all;
+    const void* x; const void* y; const int32_t* n_valid; void* out_x; void* out_y; int32_t* out_n_valid; int n, d;
+    double noise_floor; void* ls; void* os; void* noise;
+} pacoh_step_next;
 typedef struct pacoh_adam_inline {
     void* param; void* exp_avg; void* exp_avg_sq;
     const void* scalars;
     double beta1, beta2;
     int n_seg; int seg_lo[4]; int seg_hi[4];
     int64_t* step_counter; void* loss_cum;
+    const pacoh_step_next* next;
 } pacoh_adam_inline;
+/* 1 if these network shapes run on the fused fp32 kernels, else 0 (host-side query) */
+int pacoh_mlp_fused_path(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype);
 
 /* pacoh_mlp2_bwd followed by pacoh_hyper_bwd (below) on the same d_theta rows -- the whole gradient epilogue of a step
  * (loss.backward() reaching the networks AND the raw GP hyper-parameters: GPR_meta_mll.py:115, svgd.py:16) in one call.  On the

@@ -133,8 +133,26 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         self._fail = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._feed = StepFeed(self.device, self.dtype, tb_local, chunk=self.GRAPH_CHUNK)
         self._graphs = self._opt_blk = None
+        # Four launches per iteration (forward, GP, backward, slab reduction) where the AdamW step rides in the gradient epilogue
+        # (_adam_inline) AND the networks run on the fused kernels: the epilogue then also fetches the next iteration's operands and
+        # publishes the updated hyper-parameters' transforms (include/pacoh_gp.h, pacoh_step_next) -- no step_begin launch.
+        # PACOH_MAP_PIPELINE=0: keep it
+        self._pipelined = self._adam_inline() and self._nets_fused(tb_local) and os.environ.get('PACOH_MAP_PIPELINE', '1') != '0'
+        if self._pipelined:
+            self._feed.pipeline(self.tasks, self.engine, self.theta)
+
+    def _nets_fused(self, tb_local):
+        lay = self.layout
+        nets = ([(lay.mean_nn_layers, 1)] if lay.mean_module == 'NN' else []) + \
+               ([(lay.kernel_nn_layers, lay.feature_dim)] if lay.covar_module == 'NN' else [])
+        return (len(nets) > 0 and tb_local > 0 and (len(nets) == 1 or lay.mean_nn_layers == lay.kernel_nn_layers) and
+                all(L.mlp_fused_path(tb_local, 1, self.tasks.n, lay.input_dim, list(h), d_out, self.dtype) for h, d_out in nets))
 
     def _body_likelihood(self):
+        if getattr(self, '_pipelined', False):
+            self.engine.lml_and_grad(self.theta, self._feed.batch, weight=-1.0, lik_out=self._g_loss, lik_scale=-1.0,
+                                     grad_out=self._grad, fail_flag=self._fail, hypers=self._feed.hyp, opt=self._opt_block())
+            return
         # select + gather + hyper transforms: one launch; with Adam the step's last launch advances the feed's counter
         batch, hyp = self._feed.begin(self.tasks, self.engine, self.theta, advance=not self._adam_advances())
         if batch is None:                                  # more ranks than tasks in the batch: this rank contributes zeros
@@ -151,14 +169,19 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
     def _adam_inline(self):
         """the AdamW launch folded into the gradient epilogue (include/pacoh_gp.h, pacoh_adam_inline): no exchange between gradient
         and update, i.e. world size 1, and a task batch on this rank; PACOH_MAP_ADAM_INLINE=0 keeps the separate launch (A/B, tests)"""
-        return (self._adam_advances() and parallel.world()[1] == 1 and self._feed.tb > 0 and len(self.train_segments) <= 4
+        lay = self.layout
+        one_call = not (lay.mean_module == 'NN' and lay.covar_module == 'NN' and lay.mean_nn_layers != lay.kernel_nn_layers)
+        # (two networks of different shapes: two backward calls and a separate reduction -- no single launch finishes every entry)
+        return (self._adam_advances() and parallel.world()[1] == 1 and self._feed.tb > 0 and len(self.train_segments) <= 4 and one_call
                 and os.environ.get('PACOH_MAP_ADAM_INLINE', '1') != '0')
 
     def _opt_block(self):
         blk = getattr(self, '_opt_blk', None)
         if blk is None:
+            nxt = L.step_next(self._feed, self.tasks, self.engine.noise_floor) if getattr(self, '_pipelined', False) else None
             blk = self._opt_blk = L.adam_inline(self.theta, self.exp_avg, self.exp_avg_sq, self._feed.sc[L.SC_ADAM:L.SC_ADAM + 4],
-                                                self.train_segments, step_counter=self._feed.ctr, loss_cum=self._g_cum.reshape(1))
+                                                self.train_segments, step_counter=self._feed.ctr, loss_cum=self._g_cum.reshape(1),
+                                                next_feed=nxt)
         return blk
 
     def _body_update(self):
@@ -186,6 +209,8 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
                                                            many_ok=self.tasks.n <= 128)
         for t, sv in zip(state, saved):
             t.copy_(sv)
+        if self._pipelined:
+            self._feed.prologue()                         # (batch buffers, scalars and hyper-parameters of the restored parameters)
 
     def _run_step(self, graphed):
         run_step(self._graphs, graphed, self._body_likelihood, self._all_reduce, self._body_update)
@@ -208,6 +233,8 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
             local = np.ascontiguousarray(idx[:, rank::world])
             parallel.check_same_draws(local, sc_rows)
             self._feed.upload(local if self._feed.tb > 0 else None, sc_rows)
+            if self._pipelined:
+                self._feed.prologue()
             if graphed and self._graphs is None:
                 self._build_graphs()
             if graphed:

@@ -52,6 +52,7 @@ SIGNATURES = {
     'pacoh_mlp_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _l, _i, _vp, _i, _i, _i, _vp]),
     'pacoh_mlp_bwd_hyper': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _l, _vp, _i, _i,
                                  _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    'pacoh_mlp_fused_path': (_i, [_i, _i, _i, _i, _ip, _i, _i, _i]),
     'pacoh_mlp2_fwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_mlp2_stash_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_mlp2_fwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _l, _i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -104,7 +105,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 9              # pacoh_abi_version() of the library this table was written for
+ABI_VERSION = 10              # pacoh_abi_version() of the library this table was written for
 
 
 def load_library():
@@ -577,18 +578,52 @@ def mlp2_bwd_hyper(x, x_div, theta, P, d_in, hidden, off_a, d_out_a, g_a, off_b,
     return workspace
 
 
+class StepNext(ctypes.Structure):
+    """pacoh_step_next (include/pacoh_gp.h): the pipelined feed carried by the gradient epilogue of a PACOH-MAP iteration"""
+    _fields_ = [('counter', _vp), ('sc2', _vp), ('n_sc', _i), ('idx_all', _vp), ('tb', _i), ('sc_all', _vp), ('x', _vp), ('y', _vp),
+                ('n_valid', _vp), ('out_x', _vp), ('out_y', _vp), ('out_n_valid', _vp), ('n', _i), ('d', _i), ('noise_floor', _d),
+                ('ls', _vp), ('os', _vp), ('noise', _vp)]
+
+
 class AdamInline(ctypes.Structure):
     """pacoh_adam_inline (include/pacoh_gp.h): the AdamW step of a PACOH-MAP iteration folded into the gradient epilogue"""
     _fields_ = [('param', _vp), ('exp_avg', _vp), ('exp_avg_sq', _vp), ('scalars', _vp), ('beta1', _d), ('beta2', _d),
-                ('n_seg', _i), ('seg_lo', _i * 4), ('seg_hi', _i * 4), ('step_counter', _vp), ('loss_cum', _vp)]
+                ('n_seg', _i), ('seg_lo', _i * 4), ('seg_hi', _i * 4), ('step_counter', _vp), ('loss_cum', _vp),
+                ('next', ctypes.POINTER(StepNext))]
 
 
-def adam_inline(param, exp_avg, exp_avg_sq, scalars, segments, step_counter=None, loss_cum=None, beta1=0.9, beta2=0.999):
+def mlp_fused_path(B, P, n, d_in, hidden, d_out, dtype):
+    """do networks of this shape run on the fused fp32 kernels? (host-side query)"""
+    code = F32 if dtype == torch.float32 else F64
+    return bool(load_library().pacoh_mlp_fused_path(B, P, n, d_in, _hidden_arr(hidden), len(hidden), d_out, code))
+
+
+def step_next(feed, tasks, noise_floor):
+    """pacoh_step_next of a pipelined engine.StepFeed (feed.pipeline() has run): the next step's operands are fetched, and the
+    transformed hyper-parameters published into feed.hyp, by the gradient epilogue that carries this block"""
+    o = StepNext()
+    ls, os_, noise = feed.hyp
+    nv, onv = (tasks.n_valid, feed.batch.n_valid) if tasks.ragged else (None, None)
+    keep = (feed.ctr, feed.sc2, feed.idx_all, feed.sc_all, tasks.x, tasks.y, nv, feed.batch.x, feed.batch.y, onv, ls, os_, noise)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    o.counter, o.sc2, o.n_sc = ptr(feed.ctr), ptr(feed.sc2), feed.sc2.shape[1]
+    o.idx_all, o.tb, o.sc_all = ptr(feed.idx_all), feed.tb, ptr(feed.sc_all)
+    o.x, o.y, o.n_valid, o.out_x, o.out_y, o.out_n_valid = ptr(tasks.x), ptr(tasks.y), ptr(nv), ptr(feed.batch.x), ptr(feed.batch.y), ptr(onv)
+    o.n, o.d, o.noise_floor = tasks.x.shape[1], tasks.x.shape[2], float(noise_floor)
+    o.ls, o.os, o.noise = ptr(ls), ptr(os_), ptr(noise)
+    o._keep = keep
+    return o
+
+
+def adam_inline(param, exp_avg, exp_avg_sq, scalars, segments, step_counter=None, loss_cum=None, beta1=0.9, beta2=0.999, next_feed=None):
     """argument block for hyper_bwd / mlp_bwd_hyper / mlp2_bwd_hyper(opt=...): param / exp_avg / exp_avg_sq [1, D], scalars = the
-    PACOH_SC_ADAM block of the step's scalar row (device), segments = trained column ranges [(lo, hi), ...] (at most 4).  The
-    object keeps references to the tensors: it holds raw pointers"""
+    PACOH_SC_ADAM block of the step's scalar row (device), segments = trained column ranges [(lo, hi), ...] (at most 4);
+    next_feed = step_next(...): the pipelined feed rides along (fused networks only).  The object keeps references to the
+    tensors: it holds raw pointers"""
     assert 1 <= len(segments) <= 4 and param.shape[0] == 1
     o = AdamInline()
+    o.next = ctypes.pointer(next_feed) if next_feed is not None else None
+    o._next = next_feed
     o.param, o.exp_avg, o.exp_avg_sq, o.scalars = (t.data_ptr() for t in (param, exp_avg, exp_avg_sq, scalars))
     o.beta1, o.beta2, o.n_seg = float(beta1), float(beta2), len(segments)
     for k, (lo, hi) in enumerate(segments):

@@ -162,4 +162,7 @@ inline int launch_status() {
     return (e == hipSuccess || e == hipErrorNotReady) ? PACOH_OK : PACOH_ELAUNCH;
 }
 
+// softplus with torch's threshold (F.softplus: x for x > 20)
+template <typename T> __device__ __forceinline__ T softplus_t(T x) { return x > T(20) ? x : t_log1p<T>(t_exp<T>(x)); }
+
 }  // namespace pacoh

@@ -18,6 +18,7 @@ struct AdamInline {
     T one_minus_b1, b2, one_minus_b2;
     int nseg; int lo[4], hi[4];               // trained column ranges (learning_mode)
     long* step_counter; T* cum;               // the feed's counter (+1 per step) and the running sum of the logged loss, by the likelihood block
+    const long* counter; const T* sc2; int n_sc;   // pipelined feed (step_tail.h): the scalars are those of row sc2[*counter & 1] instead of sc
 };
 // One AdamW update, every operation rounded on its own in the order of torch.optim._single_tensor_adam (mul_(1 - lr wd); lerp_;
 // mul_(beta2).addcmul_; sqrt / bias correction + eps; addcdiv_).  No fused multiply-adds: which of `a * b + c * d`'s products the
@@ -40,15 +41,19 @@ __device__ __forceinline__ void adam_update(T& p, T g, T& m, T& v, T decay_mul, 
     T u = step_size * r;
     p = pp - u; m = mq; v = vq;
 }
+// -> the entry's value after the call (unchanged where it is not trained)
 template <typename T>
-__device__ __forceinline__ void adam_inline(const AdamInline<T>& o, long q, T g) {
-    if (!o.param) return;
+__device__ __forceinline__ T adam_inline(const AdamInline<T>& o, long q, T g) {
+    if (!o.param) return T(0);
     bool in = false;
     for (int s = 0; s < o.nseg; ++s) in |= q >= o.lo[s] && q < o.hi[s];
-    if (!in) return;
-    T p = o.param[q], mq = o.m[q], vq = o.v[q];
-    adam_update<T>(p, g, mq, vq, o.sc[0], o.one_minus_b1, o.b2, o.one_minus_b2, o.sc[1], o.sc[2], o.sc[3]);
+    T p = o.param[q];
+    if (!in) return p;
+    const T* sc = o.counter ? o.sc2 + (*o.counter & 1) * o.n_sc + PACOH_SC_ADAM : o.sc;
+    T mq = o.m[q], vq = o.v[q];
+    adam_update<T>(p, g, mq, vq, sc[0], o.one_minus_b1, o.b2, o.one_minus_b2, sc[1], sc[2], sc[3]);
     o.param[q] = p; o.m[q] = mq; o.v[q] = vq;
+    return p;
 }
 
 template <typename T>
@@ -63,11 +68,15 @@ struct HyperBwdArgs {
     const T* sv_d2; int sv_P; T* sv_bw;      // SVGD: ONE more virtual block computes the step's median-heuristic bandwidth from the
                                              // particles' distance matrix (step_tail.h, svgd_bandwidth_block) | sv_bw = nullptr
     AdamInline<T> opt;                       // PACOH-MAP at world size 1: the AdamW step on every entry this reduction finishes
+    StepNextArgs<T> nx;                      // ... and the pipelined feed: the updated hyper-parameters' transforms are published by the
+                                             // blocks that update them, tb + 1 more virtual blocks fetch the next step's operands
 };
 
 // virtual blocks of the reduction itself, and with the optional bandwidth block behind them
 template <typename T> __host__ __device__ inline int hyper_bwd_blocks(const HyperBwdArgs<T>& a) { return a.P * (a.f + 4); }
-template <typename T> __host__ __device__ inline int hyper_tail_blocks(const HyperBwdArgs<T>& a) { return hyper_bwd_blocks(a) + (a.sv_bw ? 1 : 0); }
+template <typename T> __host__ __device__ inline int hyper_tail_blocks(const HyperBwdArgs<T>& a) {
+    return hyper_bwd_blocks(a) + (a.sv_bw ? 1 : 0) + (a.nx.counter ? a.nx.tb + 1 : 0);
+}
 
 template <typename T> __device__ __forceinline__ T hyper_sigmoid(T x) { return x > T(20) ? T(1) : T(1) / (T(1) + t_exp<T>(-x)); }
 
@@ -114,15 +123,22 @@ __device__ __forceinline__ void hyper_bwd_block(const HyperBwdArgs<T>& a, int w,
         const T chain = (e == a.f + 2) ? T(1) : hyper_sigmoid<T>(a.theta[(long)p * a.stride + off]);      // (read BEFORE the update below)
         const T gv = s * chain;
         a.grad[(long)p * a.gstride + off] = gv;
-        adam_inline<T>(a.opt, off, gv);
+        const T now = adam_inline<T>(a.opt, off, gv);
+        if (a.opt.param && a.nx.counter && a.nx.ls) {       // the next step's transformed hyper-parameters, from the value just stored
+            if (e < a.f) { const T v1 = softplus_t<T>(now); for (int c = 0; c < ncol; ++c) a.nx.ls[p * a.f + e + c] = v1; }
+            else if (e == a.f) { if (a.nx.os) a.nx.os[p] = softplus_t<T>(now); }
+            else if (e == a.f + 1) a.nx.noise[p] = softplus_t<T>(now) + a.nx.noise_floor;
+        }
     }
 }
 
 // block w of hyper_tail_blocks(a): the reduction's blocks, then the bandwidth block
 template <typename T>
 __device__ __forceinline__ void hyper_tail_block(const HyperBwdArgs<T>& a, int w, T* red) {
-    if (w < hyper_bwd_blocks(a)) hyper_bwd_block<T>(a, w, red);
-    else if (a.sv_bw) svgd_bandwidth_block<T>(a.sv_d2, a.sv_P, a.sv_bw);
+    const int hb = hyper_bwd_blocks(a);
+    if (w < hb) hyper_bwd_block<T>(a, w, red);
+    else if (a.sv_bw && w == hb) svgd_bandwidth_block<T>(a.sv_d2, a.sv_P, a.sv_bw);
+    else if (a.nx.counter) step_next_tail<T>(a.nx, w - hb - (a.sv_bw ? 1 : 0), a.nx.tb + 1);
 }
 
 }  // namespace pacoh

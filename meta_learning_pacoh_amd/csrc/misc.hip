@@ -29,7 +29,7 @@ __global__ void softplus_bwd_kernel(const T* __restrict__ raw, const T* __restri
 }
 
 // ---- all GP hyper-parameter transforms of one step in one launch (A3) -------------------------------
-template <typename T> __device__ __forceinline__ T softplus_t(T x) { return x > T(20) ? x : t_log1p<T>(t_exp<T>(x)); }
+// (softplus_t: common.h)
 template <typename T> __device__ __forceinline__ T sigmoid_t(T x) { return x > T(20) ? T(1) : T(1) / (T(1) + t_exp<T>(-x)); }
 
 template <typename T>
@@ -696,7 +696,7 @@ extern "C" int pacoh_gather_tasks(const void* x, const void* y, const int32_t* n
     return launch_status();
 }
 
-extern "C" int pacoh_abi_version(void) { return 9; }
+extern "C" int pacoh_abi_version(void) { return 10; }
 
 extern "C" int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise,
                                double noise_floor, void* ls, void* os, void* noise, int dtype, void* stream) {
@@ -724,6 +724,7 @@ extern "C" int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int 
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (opt && (!opt->param || !opt->exp_avg || !opt->exp_avg_sq || !opt->scalars || opt->n_seg < 1 || opt->n_seg > 4 || P != 1 || !lml))
         return PACOH_EINVAL;
+    if (opt && opt->next) return PACOH_ELIMIT;         // (the pipelined feed's counter is advanced by the fused MLP backward launch)
     const int tie = kernel_of(f) != PACOH_KERNEL_RBF;
     f = features_of(f);
     if (!theta || !grad || !d_ls || !d_noise || P <= 0 || T_ <= 0 || f <= 0) return PACOH_EINVAL;
@@ -735,10 +736,11 @@ extern "C" int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int 
         HyperBwdArgs<float> a = {(const float*)theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, (const float*)d_ls,
                                  (const float*)d_os, (const float*)d_noise, (const float*)d_const, (float*)grad, grad_stride,
                                  (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag, tie,
-                                 ws, svgd_P, ws ? ws + svgd_bw_slot(svgd_P, svgd_D) : nullptr, AdamInline<float>{}};
+                                 ws, svgd_P, ws ? ws + svgd_bw_slot(svgd_P, svgd_D) : nullptr, AdamInline<float>{}, StepNextArgs<float>{}};
         if (opt) {
             a.opt = {(float*)opt->param, (float*)opt->exp_avg, (float*)opt->exp_avg_sq, (const float*)opt->scalars, (float)(1.0 - opt->beta1),
-                     (float)opt->beta2, (float)(1.0 - opt->beta2), opt->n_seg, {0, 0, 0, 0}, {0, 0, 0, 0}, (long*)opt->step_counter, (float*)opt->loss_cum};
+                     (float)opt->beta2, (float)(1.0 - opt->beta2), opt->n_seg, {0, 0, 0, 0}, {0, 0, 0, 0}, (long*)opt->step_counter, (float*)opt->loss_cum,
+                     nullptr, nullptr, 0};
             for (int k = 0; k < opt->n_seg; ++k) { a.opt.lo[k] = opt->seg_lo[k]; a.opt.hi[k] = opt->seg_hi[k]; }
         }
         hipLaunchKernelGGL(hyper_bwd_kernel<float>, dim3((unsigned)hyper_tail_blocks(a)), dim3(256), 0, (hipStream_t)stream, a);
@@ -747,10 +749,11 @@ extern "C" int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int 
         HyperBwdArgs<double> a = {(const double*)theta, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, (const double*)d_ls,
                                   (const double*)d_os, (const double*)d_noise, (const double*)d_const, (double*)grad, grad_stride,
                                   (const double*)lml, (double*)lik, lik_scale, info, fail_flag, tie,
-                                  ws, svgd_P, ws ? ws + svgd_bw_slot(svgd_P, svgd_D) : nullptr, AdamInline<double>{}};
+                                  ws, svgd_P, ws ? ws + svgd_bw_slot(svgd_P, svgd_D) : nullptr, AdamInline<double>{}, StepNextArgs<double>{}};
         if (opt) {
             a.opt = {(double*)opt->param, (double*)opt->exp_avg, (double*)opt->exp_avg_sq, (const double*)opt->scalars, 1.0 - opt->beta1,
-                     opt->beta2, 1.0 - opt->beta2, opt->n_seg, {0, 0, 0, 0}, {0, 0, 0, 0}, (long*)opt->step_counter, (double*)opt->loss_cum};
+                     opt->beta2, 1.0 - opt->beta2, opt->n_seg, {0, 0, 0, 0}, {0, 0, 0, 0}, (long*)opt->step_counter, (double*)opt->loss_cum,
+                     nullptr, nullptr, 0};
             for (int k = 0; k < opt->n_seg; ++k) { a.opt.lo[k] = opt->seg_lo[k]; a.opt.hi[k] = opt->seg_hi[k]; }
         }
         hipLaunchKernelGGL(hyper_bwd_kernel<double>, dim3((unsigned)hyper_tail_blocks(a)), dim3(256), 0, (hipStream_t)stream, a);

@@ -268,9 +268,25 @@ static bool adam_inline_ok(const pacoh_adam_inline* o, int P, const void* lml) {
 }
 static AdamInline<float> adam_inline_f32(const pacoh_adam_inline* o) {
     AdamInline<float> a = {(float*)o->param, (float*)o->exp_avg, (float*)o->exp_avg_sq, (const float*)o->scalars, (float)(1.0 - o->beta1),
-                           (float)o->beta2, (float)(1.0 - o->beta2), o->n_seg, {0, 0, 0, 0}, {0, 0, 0, 0}, (long*)o->step_counter, (float*)o->loss_cum};
+                           (float)o->beta2, (float)(1.0 - o->beta2), o->n_seg, {0, 0, 0, 0}, {0, 0, 0, 0}, (long*)o->step_counter, (float*)o->loss_cum,
+                           nullptr, nullptr, 0};
     for (int k = 0; k < o->n_seg; ++k) { a.lo[k] = o->seg_lo[k]; a.hi[k] = o->seg_hi[k]; }
+    if (o->next) {                                   // pipelined feed: scalars by the counter, which the backward launch advances
+        a.counter = (const long*)o->next->counter; a.sc2 = (const float*)o->next->sc2; a.n_sc = o->next->n_sc;
+        a.step_counter = nullptr;
+    }
     return a;
+}
+static bool step_next_ok(const pacoh_step_next* x) {
+    return x->counter && x->sc2 && x->sc_all && x->n_sc >= PACOH_SC_COUNT && x->tb > 0 && x->idx_all && x->x && x->y && x->out_x && x->out_y &&
+           x->n > 0 && x->d > 0 && (x->n_valid == nullptr) == (x->out_n_valid == nullptr) && (x->ls == nullptr || x->noise != nullptr);
+}
+// off_ls .. off_noise: the hyper-parameter layout of the call (the transforms the next step needs are of the entries this call updates)
+static StepNextArgs<float> step_next_f32(const pacoh_step_next* x, int off_ls, int f, int off_os, int off_noise) {
+    return StepNextArgs<float>{(const long*)x->counter, (float*)x->sc2, x->n_sc, (const long*)x->idx_all, x->tb, (const float*)x->sc_all,
+                               (const float*)x->x, (const float*)x->y, x->n_valid, (float*)x->out_x, (float*)x->out_y, x->out_n_valid,
+                               x->n * x->d, x->n, off_ls, features_of(f), off_os, off_noise, kernel_of(f) != PACOH_KERNEL_RBF,
+                               (float)x->noise_floor, (float*)x->ls, (float*)x->os, (float*)x->noise, nullptr};
 }
 // the same step as separate launches (paths without the fused slab reduction): one pacoh_adam_step_dev per trained segment, the last
 // one advancing the feed's counter and adding the loss to its running sum
@@ -336,6 +352,12 @@ extern "C" int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta,
     if (svgd_workspace && (svgd_P <= 0 || svgd_D <= 0)) return PACOH_EINVAL;
     if (svgd_workspace && svgd_P > 64) return PACOH_ELIMIT;
     if (opt && (!adam_inline_ok(opt, P, lml) || opt->n_seg < 1)) return PACOH_EINVAL;
+    if (opt && opt->next) {
+        if (!step_next_ok(opt->next)) return PACOH_EINVAL;
+        if (dtype != PACOH_F32 || args_ok(d_in, hidden, n_hidden, d_out_a) || args_ok(d_in, hidden, n_hidden, d_out_b) ||
+            pick_path(dtype, d_in, hidden, n_hidden, d_out_a, (long)B * n) != PATH_FUSED ||
+            pick_path(dtype, d_in, hidden, n_hidden, d_out_b, (long)B * n) != PATH_FUSED) return PACOH_ELIMIT;     // (pacoh_mlp_fused_path)
+    }
     if (!d_ls || !d_noise || T_ <= 0 || features_of(f) <= 0 || (lml == nullptr) != (lik == nullptr)) return PACOH_EINVAL;
     if (accumulate) return PACOH_EINVAL;              // (the tail writes its columns of d_theta; the blocks of the two networks are overwritten)
     bool tail_done = false;
@@ -346,7 +368,8 @@ extern "C" int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta,
                                     d_theta_stride, (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag,
                                     kernel_of(f) != PACOH_KERNEL_RBF, (const float*)svgd_workspace, svgd_P,
                                     svgd_workspace ? (float*)svgd_workspace + svgd_bw_slot(svgd_P, svgd_D) : nullptr,
-                                    opt ? adam_inline_f32(opt) : AdamInline<float>{}};
+                                    opt ? adam_inline_f32(opt) : AdamInline<float>{},
+                                    (opt && opt->next) ? step_next_f32(opt->next, off_ls, f, off_os, off_noise) : StepNextArgs<float>{}};
         rc = mlp2_bwd_impl(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, off_a, d_out_a, g_a, off_b, d_out_b, g_b, d_theta,
                            d_theta_stride, accumulate, workspace, stash, B, n, dtype, stream, &tail, &tail_done);
     } else {
@@ -372,6 +395,11 @@ extern "C" int pacoh_mlp_bwd_hyper(const void* x, int x_div, const void* theta, 
                                    void* svgd_workspace, int svgd_P, int svgd_D, const pacoh_adam_inline* opt, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (opt && (!adam_inline_ok(opt, P, lml) || opt->n_seg < 1)) return PACOH_EINVAL;
+    if (opt && opt->next) {
+        if (!step_next_ok(opt->next)) return PACOH_EINVAL;
+        if (dtype != PACOH_F32 || args_ok(d_in, hidden, n_hidden, d_out) ||
+            pick_path(dtype, d_in, hidden, n_hidden, d_out, (long)B * n) != PATH_FUSED) return PACOH_ELIMIT;       // (pacoh_mlp_fused_path)
+    }
     if (!g_out || !d_theta || !workspace || !x || !theta || !theta_rows || !grad_rows || x_div <= 0 || P <= 0 || B <= 0 || n <= 0 || B % P != 0)
         return PACOH_EINVAL;
     if (!d_ls || !d_noise || T_ <= 0 || features_of(f) <= 0 || (lml == nullptr) != (lik == nullptr)) return PACOH_EINVAL;
@@ -385,7 +413,8 @@ extern "C" int pacoh_mlp_bwd_hyper(const void* x, int x_div, const void* theta, 
                                     d_theta_stride, (const float*)lml, (float*)lik, (float)lik_scale, info, fail_flag,
                                     kernel_of(f) != PACOH_KERNEL_RBF, (const float*)svgd_workspace, svgd_P,
                                     svgd_workspace ? (float*)svgd_workspace + svgd_bw_slot(svgd_P, svgd_D) : nullptr,
-                                    opt ? adam_inline_f32(opt) : AdamInline<float>{}};
+                                    opt ? adam_inline_f32(opt) : AdamInline<float>{},
+                                    (opt && opt->next) ? step_next_f32(opt->next, off_ls, f, off_os, off_noise) : StepNextArgs<float>{}};
         const long off = 0;
         const void* const gs[1] = {g_out};
         return mlp_fused_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 1, &off, &d_out, gs, d_theta, d_theta_stride,
@@ -398,6 +427,13 @@ extern "C" int pacoh_mlp_bwd_hyper(const void* x, int x_div, const void* theta, 
                          d_theta_stride, lml, lik, lik_scale, info, fail_flag, svgd_workspace, svgd_P, svgd_D, nullptr, dtype, stream);
     if (rc || !opt) return rc;
     return adam_inline_fallback(opt, grad_rows, lik, dtype, stream);
+}
+
+// 1 if these network shapes run on the fused fp32 kernels (mlp_fused.hip) -- where the gradient epilogue can carry the optimizer
+// step's pipelined feed (pacoh_adam_inline.next) --, else 0
+extern "C" int pacoh_mlp_fused_path(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype) {
+    if (check_dtype(dtype) || P <= 0 || B <= 0 || n <= 0 || B % P != 0 || args_ok(d_in, hidden, n_hidden, d_out)) return 0;
+    return dtype == PACOH_F32 && pick_path(dtype, d_in, hidden, n_hidden, d_out, (long)B * n) == PATH_FUSED;
 }
 
 extern "C" int pacoh_reduce_tasks(const void* in, void* out, double scale, int accumulate, int T_, int P, int Wd,

@@ -71,6 +71,8 @@ struct FusedArgs {
     int tail_z;                // workgroups with blockIdx.z == tail_z (> 0) run a tail instead of a network: forward sv (step_tail.h),
     SvgdDistTail<float> sv;    // backward the SVGD bandwidth block (svgd_bandwidth_block on bw_d2[bw_P, bw_P] -> bw_out)
     const float* bw_d2; float* bw_out; int bw_P;
+    long* adv_counter;         // backward: the same workgroup advances the pipelined feed's step counter (PACOH-MAP; the slab reduction
+                               // behind this launch reads it)
 };
 
 // stash element (particle p, 16-point block blk, slot, feature block fb): 256 floats, lane-major f32x4
@@ -364,7 +366,10 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
     constexpr int L_ALL = (L_WL + L_ST + L_TS) > L_RED ? (L_WL + L_ST + L_TS) : L_RED;
     __shared__ __attribute__((aligned(16))) float lds[L_ALL];
     if (a.tail_z > 0 && (int)blockIdx.z == a.tail_z) {     // the SVGD step's median bandwidth rides in this launch (one workgroup)
-        if (blockIdx.x == 0 && blockIdx.y == 0) svgd_bandwidth_block<float>(a.bw_d2, a.bw_P, a.bw_out);
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            if (a.bw_out) svgd_bandwidth_block<float>(a.bw_d2, a.bw_P, a.bw_out);
+            if (a.adv_counter && threadIdx.x == 0) *a.adv_counter += 1;
+        }
         return;
     }
     float* wl = lds;
@@ -731,9 +736,11 @@ int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride
     // the step's SVGD bandwidth (requested with the hyper-parameter tail) is computed by one workgroup of THIS launch, fully hidden
     // behind the networks' workgroups; the tail handed to the reduction no longer carries it
     HyperBwdArgs<float> rtail = tail ? *tail : HyperBwdArgs<float>{};
-    const bool bw_here = tail && tail->sv_bw;
-    if (bw_here) { a.tail_z = nets; a.bw_d2 = tail->sv_d2; a.bw_P = tail->sv_P; a.bw_out = tail->sv_bw; rtail.sv_bw = nullptr; }
-#define PACOH_LAUNCH_BWD(K) hipLaunchKernelGGL(K, dim3(pl.chunks, P, nets + (bw_here ? 1 : 0)), dim3(256), 0, s, a)
+    const bool bw_here = tail && tail->sv_bw, adv_here = tail && tail->nx.counter;
+    if (bw_here) { a.bw_d2 = tail->sv_d2; a.bw_P = tail->sv_P; a.bw_out = tail->sv_bw; rtail.sv_bw = nullptr; }
+    if (adv_here) a.adv_counter = const_cast<long*>(tail->nx.counter);
+    if (bw_here || adv_here) a.tail_z = nets;
+#define PACOH_LAUNCH_BWD(K) hipLaunchKernelGGL(K, dim3(pl.chunks, P, nets + ((bw_here || adv_here) ? 1 : 0)), dim3(256), 0, s, a)
     PACOH_FUSED_DISPATCH(mlp_fused_bwd_kernel, n_hidden, pl.pb, PACOH_LAUNCH_BWD);
 #undef PACOH_LAUNCH_BWD
     const long tot = (long)P * wmax;

@@ -30,7 +30,7 @@ int main() {
         std::printf("%zu\n", pacoh_mlp_bwd_workspace_bytes(60, 3, 33, 2, h, 3, 2, PACOH_F32));
         return 0;
     }
-    EXPECT(pacoh_abi_version() == 9);
+    EXPECT(pacoh_abi_version() == 10);
     EXPECT(pacoh_gp_small_max_n(PACOH_F32, 0) >= 128 && pacoh_gp_small_max_n(PACOH_F64, 1) >= 64 && pacoh_gp_small_max_n(7, 0) == PACOH_EDTYPE);
     EXPECT(pacoh_svgd_workspace_bytes(20, 2534, PACOH_F32) == (2 * 400 + 20 + 8) * 4);
     EXPECT(pacoh_gp_predict_workspace_bytes(4, 64, 50, PACOH_F32, 1) == 4u * 50 * 64 * 4 && pacoh_gp_predict_workspace_bytes(4, 64, 50, PACOH_F32, 0) == 0);
@@ -104,7 +104,7 @@ int main() {
                                nullptr, nullptr, nullptr, 0, 0, fake, 6, 10, fake, fake, 0, 2, -1, 2, 0.0, nullptr, nullptr, nullptr, 0,
                                PACOH_F32, nullptr) == PACOH_EINVAL);                              // noise row is not S x D values
     {   // the AdamW step folded into the gradient epilogue: one parameter row only, and the likelihood sums must be requested
-        pacoh_adam_inline opt = {fake, fake, fake, fake, 0.9, 0.999, 1, {0, 0, 0, 0}, {5, 0, 0, 0}, nullptr, nullptr};
+        pacoh_adam_inline opt = {fake, fake, fake, fake, 0.9, 0.999, 1, {0, 0, 0, 0}, {5, 0, 0, 0}, nullptr, nullptr, nullptr};
         EXPECT(pacoh_hyper_bwd(fake, 10, 3, 2, 0, 2, -1, 2, -1, fake, nullptr, fake, nullptr, fake, 10, fake, fake, 1.0, nullptr, nullptr,
                                nullptr, 0, 0, &opt, PACOH_F32, nullptr) == PACOH_EINVAL);           // P = 3
         EXPECT(pacoh_hyper_bwd(fake, 10, 1, 2, 0, 2, -1, 2, -1, fake, nullptr, fake, nullptr, fake, 10, nullptr, nullptr, 1.0, nullptr, nullptr,

@@ -699,6 +699,7 @@ def test_small_first_chunk_does_not_change_the_run(M, kind, monkeypatch):
     dict(mean_nn_layers=(16, 16), kernel_nn_layers=(16, 16)),                       # general MLP path: AdamW launches behind the gradient
     dict(learning_mode='learn_mean', covar_module='SE'), dict(learning_mode='learn_kernel', mean_module='constant'),   # trained column ranges
     dict(mean_nn_layers=(32, 32, 32, 32), kernel_nn_layers=(32, 32, 32, 32), weight_decay=0.0),
+    dict(mean_nn_layers=(32, 32), kernel_nn_layers=(16,)),                         # two shapes: no single call finishes every entry
 ])
 @pytest.mark.parametrize('graph', ['0', '1'])
 def test_map_adam_folded_into_the_gradient_epilogue(M, cfg, graph, monkeypatch):
@@ -719,10 +720,49 @@ def test_map_adam_folded_into_the_gradient_epilogue(M, cfg, graph, monkeypatch):
         monkeypatch.setenv('PACOH_MAP_ADAM_INLINE', inline)
         m = M.GPRegressionMetaLearned(tasks, **kw)
         loss = m.meta_fit(verbose=False, n_iter=14, log_period=4)
-        assert m._adam_inline() == (inline == '1') and m.opt_step == 14
+        two_shapes = 'kernel_nn_layers' in cfg and cfg['kernel_nn_layers'] != cfg['mean_nn_layers']
+        assert m._adam_inline() == (inline == '1' and not two_shapes) and m.opt_step == 14
         out.append((m.theta.clone(), m.exp_avg.clone(), m.exp_avg_sq.clone(), float(loss)))
     assert bool(torch.isfinite(out[1][0]).all())
     assert all(torch.equal(a, b) for a, b in zip(out[0][:3], out[1][:3])) and out[0][3] == out[1][3]
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(),                                                                         # two fused networks
+    dict(covar_module='SE', mean_module='NN'),                                      # one network (BASELINE config #2)
+    dict(covar_module='NN', mean_module='constant', feature_dim=2),
+    dict(learning_mode='learn_mean', covar_module='SE'),
+    dict(mean_nn_layers=(32, 32, 32, 32), kernel_nn_layers=(32, 32, 32, 32)),
+    dict(mean_nn_layers=(16, 16), kernel_nn_layers=(16, 16)),
+    dict(mean_nn_layers=(64, 64), kernel_nn_layers=(64, 64)),                       # not on the fused kernels: stays with step_begin
+    dict(covar_module='NN', mean_module='constant', feature_dim=3),                 # (three outputs: neither)
+])
+@pytest.mark.parametrize('graph', ['0', '1'])
+def test_map_iteration_in_four_launches_equals_the_step_begin_sequence(M, cfg, graph, monkeypatch):
+    """pacoh_step_next: the gradient epilogue of a PACOH-MAP iteration (with the AdamW step in it) also fetches the next iteration's
+    scalars and task batch and publishes the updated hyper-parameters' transforms; the backward launch advances the feed -- the same
+    bits as with the step_begin launch (PACOH_MAP_PIPELINE=0), eager and replayed, ragged tasks, chunks of 1 + 3 + 4 + ... steps"""
+    rs = np.random.RandomState(17)
+    tasks = []
+    for t in range(7):
+        n = 8 + 2 * (t % 3)
+        x = rs.uniform(-3, 3, size=(n, 2))
+        tasks.append((x, np.sin(x[:, :1]) + 0.3 * x[:, 1:] + 0.05 * rs.randn(n, 1)))
+    monkeypatch.setenv('PACOH_GRAPH', graph)
+    kw = dict(task_batch_size=4, lr_params=1e-2, weight_decay=0.05, lr_decay=0.9, random_seed=3)
+    kw.update(cfg)
+    out = []
+    for pipe in ('0', '1'):
+        monkeypatch.setenv('PACOH_MAP_PIPELINE', pipe)
+        m = M.GPRegressionMetaLearned(tasks, **kw)
+        loss = m.meta_fit(verbose=False, n_iter=14, log_period=4)
+        fused = cfg.get('mean_nn_layers', (32, 32))[0] <= 32 and cfg.get('feature_dim', 2) <= 2
+        assert m._pipelined == (pipe == '1' and fused) and m.opt_step == 14
+        mean, std = m.predict(*tasks[0], tasks[1][0])
+        out.append((m.theta.clone(), m.exp_avg.clone(), m.exp_avg_sq.clone(), float(loss), mean, std))
+    assert bool(torch.isfinite(out[1][0]).all())
+    assert all(torch.equal(a, b) for a, b in zip(out[0][:3], out[1][:3])) and out[0][3] == out[1][3]
+    assert np.array_equal(out[0][4], out[1][4]) and np.array_equal(out[0][5], out[1][5])
 
 
 def test_launcher_networks_run_through_the_learners(M):
