@@ -577,8 +577,13 @@ static int fused_dnet(int d_in, const int32_t* hidden, int n_hidden, int d_out) 
     return c + d_out * (prev + 1);
 }
 
-static int fused_bwd_pb(int n_hidden) { return fused_env("PACOH_FUSED_BWD_PB", n_hidden <= 2 ? 4 : 2); }
-static int fused_fwd_pb(int) { return fused_env("PACOH_FUSED_FWD_PB", 4); }
+// point blocks (of 16) per tile.  Small launches -- fewer 64-point tiles than the chip has wave slots, e.g. PACOH-MAP's 256 tasks x 32
+// points x one parameter row -- are one tile per wave either way and pure latency: 32-point tiles halve that latency
+static bool fused_small(int R, int P, int nets) { return (long)((R + 63) / 64) * P * nets <= 512; }
+static int fused_bwd_pb(int n_hidden, int R, int P, int nets) {
+    return fused_env("PACOH_FUSED_BWD_PB", (n_hidden <= 2 && !fused_small(R, P, nets)) ? 4 : 2);
+}
+static int fused_fwd_pb(int, int R, int P, int nets) { return fused_env("PACOH_FUSED_FWD_PB", fused_small(R, P, nets) ? 2 : 4); }
 
 // resident workgroups of a kernel on the whole chip (occupancy query, cached per kernel)
 template <typename K> static int resident_wgs(K kern) {
@@ -661,7 +666,7 @@ int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride
     FusedArgs a = {};
     fused_fill(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, B, n, stash, nets);
     for (int k = 0; k < nets; ++k) { a.net[k].theta_off = off[k]; a.net[k].out = (float*)out[k]; a.net[k].d_out = d_out[k]; }
-    const int pb = fused_fwd_pb(n_hidden) == 2 ? 2 : 4;
+    const int pb = fused_fwd_pb(n_hidden, a.R, P, nets) == 2 ? 2 : 4;
     const int tiles = (a.R + 16 * pb - 1) / (16 * pb);
     // tiles per workgroup (a wave takes every 4th): 16 at cfg #3 (4 / 8 / 16 / 32: 109 / 100 / 95 / 94 us); small batches -- the 1/8
     // strong-scaling shard -- want fewer, or a SIMD holds two four-tile waves while its neighbour idles: the count that minimises
@@ -693,7 +698,7 @@ struct FusedBwdPlan { int pb, chunks, tiles_per_wg; };
 
 static FusedBwdPlan fused_bwd_plan(int R, int P, int nets, int n_hidden) {
     FusedBwdPlan pl;
-    pl.pb = fused_bwd_pb(n_hidden) == 2 ? 2 : 4;
+    pl.pb = fused_bwd_pb(n_hidden, R, P, nets) == 2 ? 2 : 4;
     static int resident[FMAXNH + 1][2] = {};
     int& res = resident[n_hidden][pl.pb == 4];
     if (res == 0) {
