@@ -250,10 +250,16 @@ int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta, long theta
 
 /* The same for configurations with ONE network (NN mean with an SE kernel: BASELINE config #2; or NN kernel features with a
  * constant mean): pacoh_mlp_bwd (accumulate = 0) followed by pacoh_hyper_bwd, the reduction riding in the slab reduction's launch
- * on the fused fp32 path.  theta / d_theta point at the network's block inside the rows, theta_rows / grad_rows at the rows. */
+ * on the fused fp32 path.  theta / d_theta point at the network's block inside the rows, theta_rows / grad_rows at the rows.
+ * stash (optional): the activation stash as for the two-network calls -- pacoh_mlp_stash_bytes() bytes, filled by
+ * pacoh_mlp_fwd_stash (= pacoh_mlp_fwd with that one argument more) on the same inputs. */
+size_t pacoh_mlp_stash_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype);
+int pacoh_mlp_fwd_stash(const void* x, int x_div, const void* theta, long theta_stride, int P,
+                        int d_in, const int32_t* hidden, int n_hidden, int d_out, void* out, void* workspace, void* stash,
+                        int B, int n, int dtype, void* stream);
 int pacoh_mlp_bwd_hyper(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
                         const int32_t* hidden, int n_hidden, int d_out, const void* g_out, void* d_theta, long d_theta_stride,
-                        void* workspace, int B, int n,
+                        void* workspace, const void* stash, int B, int n,
                         const void* theta_rows, void* grad_rows, int T, int off_ls, int f, int off_os, int off_noise,
                         int off_const, const void* d_lengthscale, const void* d_outputscale, const void* d_noise, const void* d_const,
                         const void* lml, void* lik, double lik_scale, const int32_t* info, int32_t* fail_flag,

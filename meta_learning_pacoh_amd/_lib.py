@@ -50,8 +50,10 @@ SIGNATURES = {
     'pacoh_mlp_fwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_mlp_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i]),
     'pacoh_mlp_bwd': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _l, _i, _vp, _i, _i, _i, _vp]),
-    'pacoh_mlp_bwd_hyper': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _l, _vp, _i, _i,
+    'pacoh_mlp_bwd_hyper': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _l, _vp, _vp, _i, _i,
                                  _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    'pacoh_mlp_stash_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i]),
+    'pacoh_mlp_fwd_stash': (_i, [_vp, _i, _vp, _l, _i, _i, _ip, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_mlp_fused_path': (_i, [_i, _i, _i, _i, _ip, _i, _i, _i]),
     'pacoh_mlp2_fwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_mlp2_stash_bytes': (_sz, [_i, _i, _i, _i, _ip, _i, _i, _i, _i]),
@@ -105,7 +107,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 10              # pacoh_abi_version() of the library this table was written for
+ABI_VERSION = 11              # pacoh_abi_version() of the library this table was written for
 
 
 def load_library():
@@ -455,16 +457,33 @@ def _mlp_fwd_ws(need, device, holder):
     return ws
 
 
-def mlp_fwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, B, n, ws_holder=None):
+def mlp_fwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, B, n, ws_holder=None, stash=None):
+    """stash (mlp_stash()): receives the activations the matching mlp_bwd_hyper(stash=...) would otherwise recompute"""
     lib = load_library()
     out = torch.empty(B, n, d_out, dtype=x.dtype, device=x.device)
     harr, code = _hidden_arr(hidden), dtype_code(x)
     ws = _mlp_fwd_ws(lib.pacoh_mlp_fwd_workspace_bytes(B, P, n, d_in, harr, len(hidden), d_out, code), x.device, ws_holder)
     with _Timed('mlp_fwd'):
-        _check(lib.pacoh_mlp_fwd(_ptr(x), x_div, ctypes.c_void_p(theta_block.data_ptr()), theta_stride, P, d_in,
-                                 harr, len(hidden), d_out, _ptr(out), _ptr(ws), B, n, code, _stream()),
-               'pacoh_mlp_fwd')
+        if stash is not None:
+            _check(lib.pacoh_mlp_fwd_stash(_ptr(x), x_div, ctypes.c_void_p(theta_block.data_ptr()), theta_stride, P, d_in,
+                                           harr, len(hidden), d_out, _ptr(out), _ptr(ws), _ptr(stash), B, n, code, _stream()),
+                   'pacoh_mlp_fwd_stash')
+        else:
+            _check(lib.pacoh_mlp_fwd(_ptr(x), x_div, ctypes.c_void_p(theta_block.data_ptr()), theta_stride, P, d_in,
+                                     harr, len(hidden), d_out, _ptr(out), _ptr(ws), B, n, code, _stream()),
+                   'pacoh_mlp_fwd')
     return out
+
+
+def mlp_stash(x, P, d_in, hidden, d_out, B, n, stash=None):
+    """activation stash for a mlp_fwd / mlp_bwd_hyper pair of ONE network of this shape (reused if large enough) | None"""
+    lib = load_library()
+    need = lib.pacoh_mlp_stash_bytes(B, P, n, d_in, _hidden_arr(hidden), len(hidden), d_out, dtype_code(x))
+    if need == 0 or need > MLP_STASH_MAX_BYTES:
+        return None
+    if stash is None or stash.numel() < need:
+        stash = torch.empty(need, dtype=torch.uint8, device=x.device)
+    return stash
 
 
 def mlp_bwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, g_out, d_theta_block, d_theta_stride,
@@ -485,7 +504,7 @@ def mlp_bwd(x, x_div, theta_block, theta_stride, P, d_in, hidden, d_out, g_out, 
 
 def mlp_bwd_hyper(x, x_div, theta, lo, P, d_in, hidden, d_out, g_out, grad, B, n, T, off_ls, f, off_os, off_noise, off_const,
                   d_ls, d_os, d_noise, d_const, lml=None, lik=None, lik_scale=1.0, info=None, fail_flag=None, kernel=KERNEL_RBF,
-                  workspace=None, svgd_bw=None, opt=None):
+                  workspace=None, svgd_bw=None, opt=None, stash=None):
     """mlp_bwd of the ONE network whose block starts at column lo of theta[P, D] (gradient into grad[:, lo:]) + hyper_bwd on the
     rows, in one C-ABI call (one launch less on the fused path); returns the workspace for reuse"""
     lib = load_library()
@@ -497,8 +516,8 @@ def mlp_bwd_hyper(x, x_div, theta, lo, P, d_in, hidden, d_out, g_out, grad, B, n
         workspace = torch.empty(max(1, need), dtype=torch.uint8, device=x.device)
     with _Timed('mlp_bwd'):
         _check(lib.pacoh_mlp_bwd_hyper(_ptr(x), x_div, ctypes.c_void_p(theta.data_ptr() + lo * es), D, P, d_in, harr, len(hidden), d_out,
-                                       _ptr(g_out, x), ctypes.c_void_p(grad.data_ptr() + lo * es), grad.shape[1], _ptr(workspace), B, n,
-                                       _ptr(theta, x), _ptr(grad, x), T, off_ls, _kf(f, kernel), off_os, off_noise, off_const,
+                                       _ptr(g_out, x), ctypes.c_void_p(grad.data_ptr() + lo * es), grad.shape[1], _ptr(workspace),
+                                       _ptr(stash), B, n, _ptr(theta, x), _ptr(grad, x), T, off_ls, _kf(f, kernel), off_os, off_noise, off_const,
                                        _ptr(d_ls, x), _ptr(d_os, x), _ptr(d_noise, x), _ptr(d_const, x), _ptr(lml, x), _ptr(lik, x),
                                        float(lik_scale), _ptr(info if fail_flag is not None else None),
                                        _ptr(fail_flag if info is not None else None), *_svgd_bw(svgd_bw), _opt_ptr(opt), code, _stream()),

@@ -115,9 +115,9 @@ extern "C" size_t pacoh_mlp_fwd_workspace_bytes(int B, int P, int n, int d_in, c
     return mlp_layers_workspace(B, P, n, d_in, hidden, n_hidden, d_out, dtype, 0);
 }
 
-extern "C" int pacoh_mlp_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P,
-                             int d_in, const int32_t* hidden, int n_hidden, int d_out, void* out, void* workspace,
-                             int B, int n, int dtype, void* stream) {
+static int mlp_fwd_impl(const void* x, int x_div, const void* theta, long theta_stride, int P,
+                        int d_in, const int32_t* hidden, int n_hidden, int d_out, void* out, void* workspace, void* stash,
+                        int B, int n, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!out || !x || !theta || x_div <= 0 || P <= 0 || B <= 0 || n <= 0 || B % P != 0) return PACOH_EINVAL;
     int rc = args_ok(d_in, hidden, n_hidden, d_out);
@@ -127,7 +127,7 @@ extern "C" int pacoh_mlp_fwd(const void* x, int x_div, const void* theta, long t
     case PATH_FUSED: {
         const long off = 0;
         void* const outs[1] = {out};
-        return mlp_fused_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 1, &off, &d_out, outs, nullptr, B, n, s);
+        return mlp_fused_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 1, &off, &d_out, outs, stash, B, n, s);
     }
     case PATH_MFMA:
         return mlp_mfma_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, s);
@@ -137,6 +137,25 @@ extern "C" int pacoh_mlp_fwd(const void* x, int x_div, const void* theta, long t
     default:
         return mlp_layers_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, workspace, B, n, dtype, s);
     }
+}
+
+
+extern "C" int pacoh_mlp_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P,
+                             int d_in, const int32_t* hidden, int n_hidden, int d_out, void* out, void* workspace,
+                             int B, int n, int dtype, void* stream) {
+    return mlp_fwd_impl(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, workspace, nullptr, B, n, dtype, stream);
+}
+
+// the activation stash of pacoh_mlp2_fwd / pacoh_mlp2_bwd for ONE network: bytes (0: this shape keeps none), and the forward that fills it
+extern "C" size_t pacoh_mlp_stash_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype) {
+    if (P <= 0 || B <= 0 || n <= 0 || B % P != 0 || args_ok(d_in, hidden, n_hidden, d_out)) return 0;
+    if (pick_path(dtype, d_in, hidden, n_hidden, d_out, (long)B * n) != PATH_FUSED) return 0;
+    return mlp_fused_stash_bytes(B, P, n, n_hidden, 1);
+}
+extern "C" int pacoh_mlp_fwd_stash(const void* x, int x_div, const void* theta, long theta_stride, int P,
+                                   int d_in, const int32_t* hidden, int n_hidden, int d_out, void* out, void* workspace, void* stash,
+                                   int B, int n, int dtype, void* stream) {
+    return mlp_fwd_impl(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, workspace, stash, B, n, dtype, stream);
 }
 
 extern "C" size_t pacoh_mlp_bwd_workspace_bytes(int B, int P, int n, int d_in, const int32_t* hidden,
@@ -388,7 +407,7 @@ extern "C" int pacoh_mlp2_bwd_hyper(const void* x, int x_div, const void* theta,
 // the parameter rows; theta_rows / grad_rows: the rows themselves (what pacoh_hyper_bwd reads and writes).
 extern "C" int pacoh_mlp_bwd_hyper(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
                                    const int32_t* hidden, int n_hidden, int d_out, const void* g_out, void* d_theta, long d_theta_stride,
-                                   void* workspace, int B, int n,
+                                   void* workspace, const void* stash, int B, int n,
                                    const void* theta_rows, void* grad_rows, int T_, int off_ls, int f, int off_os, int off_noise,
                                    int off_const, const void* d_ls, const void* d_os, const void* d_noise, const void* d_const,
                                    const void* lml, void* lik, double lik_scale, const int32_t* info, int32_t* fail_flag,
@@ -418,7 +437,7 @@ extern "C" int pacoh_mlp_bwd_hyper(const void* x, int x_div, const void* theta, 
         const long off = 0;
         const void* const gs[1] = {g_out};
         return mlp_fused_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 1, &off, &d_out, gs, d_theta, d_theta_stride,
-                             0, workspace, nullptr, B, n, (hipStream_t)stream, &tail, (long)((const float*)d_theta - (const float*)grad_rows));
+                             0, workspace, stash, B, n, (hipStream_t)stream, &tail, (long)((const float*)d_theta - (const float*)grad_rows));
     }
     rc = pacoh_mlp_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, 0, workspace, B, n,
                        dtype, stream);

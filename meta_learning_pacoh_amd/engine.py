@@ -532,17 +532,26 @@ class GPEngine:
             return z, 1, mean.reshape(B, n), L.MEAN_VECTOR
         if svgd_tail is not None:
             L.svgd_dist_advance(*svgd_tail[:3])            # (no paired forward launch to ride in)
+        one_net = (lay.covar_module == 'NN') != (lay.mean_module == 'NN')      # the backward of ONE network can read a stash too
         if lay.covar_module == 'NN':
             lo, _ = lay.block_range('kernel_nn.')
+            stash = None
+            if keep and one_net:
+                stash = self._ws[('stash1', B, n)] = L.mlp_stash(x, P, lay.input_dim, list(lay.kernel_nn_layers), lay.feature_dim, B, n,
+                                                                 self._ws.get(('stash1', B, n)))
             z = L.mlp_fwd(x, x_div, theta[:, lo:], D, P, lay.input_dim, list(lay.kernel_nn_layers), lay.feature_dim, B, n,
-                          ws_holder=self._ws)
+                          ws_holder=self._ws, stash=stash)
             z_div = 1
         else:
             z, z_div = x, x_div
         if lay.mean_module == 'NN':
             lo, _ = lay.block_range('mean_nn.')
+            stash = None
+            if keep and one_net:
+                stash = self._ws[('stash1', B, n)] = L.mlp_stash(x, P, lay.input_dim, list(lay.mean_nn_layers), 1, B, n,
+                                                                 self._ws.get(('stash1', B, n)))
             mean = L.mlp_fwd(x, x_div, theta[:, lo:], D, P, lay.input_dim, list(lay.mean_nn_layers), 1, B, n,
-                             ws_holder=self._ws).reshape(B, n)
+                             ws_holder=self._ws, stash=stash).reshape(B, n)
             mode = L.MEAN_VECTOR
         elif lay.mean_module == 'constant':
             lo, hi = lay.slices['constant_mean']
@@ -617,7 +626,7 @@ class GPEngine:
                 (lo, _), layers, d_out, g_net = lay.block_range('mean_nn.'), lay.mean_nn_layers, 1, d_mean.reshape(B, n, 1)
             self._ws['k1'] = L.mlp_bwd_hyper(batch.x, P, theta, lo, P, lay.input_dim, list(layers), d_out, g_net, grad, B, n, T, off_ls, f,
                                              off_os, off_noise, off_c, d_ls, d_os, d_noise, d_const, kernel=lay.kernel_code,
-                                             workspace=self._ws.get('k1'), **hyper)
+                                             workspace=self._ws.get('k1'), stash=self._ws.get(('stash1', B, n)), **hyper)
             return lml.reshape(T, P), grad, info
         if lay.covar_module == 'NN':
             lo, _ = lay.block_range('kernel_nn.')

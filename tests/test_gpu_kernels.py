@@ -402,6 +402,25 @@ def test_mlp2_mean_and_kernel_network_in_one_call(L, dtype, case):
     m1 = L.mlp_fwd(x_dev, x_div, th_dev, D, P, d_in, list(hidden), 1, B, n)
     z1 = L.mlp_fwd(x_dev, x_div, th_dev[:, Dm:], D, P, d_in, list(hidden), 2, B, n)
     assert relerr(m1, mean) < 1e-6 and relerr(z1, z) < 1e-6
+    # ... and with their own activation stash (ONE network: pacoh_mlp_fwd_stash -> pacoh_mlp_bwd_hyper(stash)): same output, the kernel
+    # network's gradient block as above, the hyper-parameter columns behind it reduced by the same call
+    st1 = L.mlp_stash(x_dev, P, d_in, list(hidden), 2, B, n)
+    assert (st1 is not None) == (fused and len(hidden) > 1)
+    T_h = B // P
+    d_ls, d_nz = torch.randn(T_h, P, 2, generator=g, dtype=dtype).to(DEV), torch.randn(T_h, P, generator=g, dtype=dtype).to(DEV)
+    for stash1 in ([None, st1] if st1 is not None else [None]):
+        if stash1 is not None:
+            stash1.fill_(0xff)
+        z2 = L.mlp_fwd(x_dev, x_div, th_dev[:, Dm:], D, P, d_in, list(hidden), 2, B, n, stash=stash1)
+        assert torch.equal(z2, z1)
+        grad1 = torch.full((P, D), 5.0, dtype=dtype, device=DEV)
+        L.mlp_bwd_hyper(x_dev, x_div, th_dev, Dm, P, d_in, list(hidden), 2, g_k.to(DEV), grad1, B, n, T_h, Dm + Dk, 2, -1, Dm + Dk + 2, -1,
+                        d_ls, None, d_nz, None, stash=stash1)
+        assert bool(torch.isfinite(grad1).all()) and float((grad1[:, :Dm] - 5).abs().max()) == 0
+        assert relerr(grad1[:, Dm:Dm + Dk], th.grad[:, Dm:Dm + Dk]) < tol_b
+        sig = torch.sigmoid(th_dev[:, Dm + Dk:].double())
+        assert relerr(grad1[:, Dm + Dk:Dm + Dk + 2], d_ls.double().sum(0) * sig[:, :2]) < tol_b
+        assert relerr(grad1[:, Dm + Dk + 2], d_nz.double().sum(0) * sig[:, 2]) < tol_b
 
 
 @pytest.mark.parametrize('tag', ['v4x32_d1_o2', 'v4x32_d4_o1', 'v3x32_d2_o2', 'v4x128_d2_o2', 'v_irregular_d3_o3', 's4x128'])
