@@ -765,6 +765,39 @@ def test_map_iteration_in_four_launches_equals_the_step_begin_sequence(M, cfg, g
     assert np.array_equal(out[0][4], out[1][4]) and np.array_equal(out[0][5], out[1][5])
 
 
+@pytest.mark.parametrize('seed', range(8))
+def test_pipelined_steps_on_random_shapes(M, seed, monkeypatch):
+    """the pipelined SVGD / PACOH-MAP steps against their launch sequences on random shapes: 1-70 particles (64 / 65: register sort
+    vs bisection median), 1-6 tasks per step, 3-20 points, one or two input dimensions, ragged or not, 1-3 hidden layers"""
+    rs = np.random.RandomState(100 + seed)
+    d = int(rs.randint(1, 3))
+    ragged = bool(rs.randint(0, 2))
+    n_tasks = int(rs.randint(2, 8))
+    tasks = []
+    for t in range(n_tasks):
+        n = int(rs.randint(3, 21)) if ragged or t == 0 else tasks[0][0].shape[0]
+        x = rs.uniform(-3, 3, size=(n, d))
+        tasks.append((x, np.sin(x[:, :1]) + 0.05 * rs.randn(n, 1)))
+    layers = tuple([32] * int(rs.randint(1, 4)))
+    tb = int(rs.randint(1, 7))
+    P = int([1, 2, 5, 20, 64, 65, 70, 3][seed])
+    monkeypatch.setenv('PACOH_GRAPH', str(seed % 2))
+    out = []
+    for pipe in ('0', '1'):
+        monkeypatch.setenv('PACOH_SVGD_PIPELINE', pipe)
+        monkeypatch.setenv('PACOH_MAP_PIPELINE', pipe)
+        m = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=P, task_batch_size=tb, lr=5e-3, lr_decay=0.95, mean_nn_layers=layers,
+                                          kernel_nn_layers=layers, random_seed=seed)
+        m.meta_fit(verbose=False, n_iter=9, log_period=4)
+        mm = M.GPRegressionMetaLearned(tasks, task_batch_size=tb, lr_params=5e-3, weight_decay=0.01, mean_nn_layers=layers,
+                                       kernel_nn_layers=layers, random_seed=seed)
+        mm.meta_fit(verbose=False, n_iter=9, log_period=4)
+        assert m._pipelined == (pipe == '1') and mm._pipelined == (pipe == '1')
+        out.append((m.particles.clone(), mm.theta.clone()))
+    assert bool(torch.isfinite(out[1][0]).all()) and bool(torch.isfinite(out[1][1]).all())
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 def test_launcher_networks_run_through_the_learners(M):
     """experiments/meta_GPR_SVGD_base_exp.py:29-30,83 (4 x 32, 10 particles, bandwidth 0.1, prior_factor 0.1, 2 tasks per step) and
     experiments/meta_GPR_mll_base_exp.py:29-30 (4 x 128, 2 tasks x 5 points per step): construct, train a few steps, predict; the
