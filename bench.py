@@ -123,7 +123,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)     # 0.12 s of GPU time at config 3
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
-    ap.add_argument('--config', type=int, choices=[2, 3, 4, 5], default=3)
+    ap.add_argument('--config', type=int, choices=[1, 2, 3, 4, 5], default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
     args = ap.parse_args()
@@ -216,7 +216,7 @@ def main():
         del wl
         torch.cuda.empty_cache()
         others = {}
-        for c in (2, 4, 5):
+        for c in (1, 2, 4, 5):
             try:
                 others['cfg%d' % c] = other_config_leg(c, M, L)
             except Exception as exc:                     # (a side leg must never take the headline line down with it)
@@ -352,7 +352,7 @@ def other_config_leg(cfg, M, L, steps=256):
     ms = (time.perf_counter() - t0) / steps * 1e3
     pp = profile_pass(wl, L, min(steps, 30))
     roofline, _, step_flops = rooflines(wl, pp)
-    out = {'metric': wl['metric'], 'workload': wl['describe'], 'dtype': wl['dtype'], 'steps': steps, 'ms_per_step': round(ms, 4),
+    out = {'metric': wl['metric'], 'workload': wl['describe'], 'dtype': wl['dtype'], 'steps': steps, 'ms_per_step': round(ms, 5),
            'value': round(wl['evals_per_step'] / (ms * 1e-3), 1), 'unit': 'evals/s', 'finite': wl['finite'](),
            'step_algorithmic_tflops': round(step_flops / (ms * 1e-3) / 1e12, 3),
            'dominant_kernel': None if roofline is None else {k: roofline[k] for k in ('kernel', 'achieved', 'peak', 'unit', 'algorithmic_frac', 'ms_per_step')},
@@ -420,6 +420,19 @@ def wl_cfg3(world, scaling, M, L):
                 extra={'tasks_total': T_global, 'particles': PARTICLES, 'n_ctx': N_CTX, 'd': DIM})
 
 
+def wl_cfg1(world, scaling, M, L):
+    """BASELINE.json configs[0], the reference's demo (demo.py:14-26): PACOH-MAP on 20 sinusoid tasks x 5 points, 5 tasks per iteration,
+    NN(32,32) mean + kernel features, AdamW with weight decay 0.2 -- a latency-sized iteration (four launches)"""
+    model = M.GPRegressionMetaLearned(_rand_tasks(20, 5, 1, 26), task_batch_size=5, weight_decay=0.2, random_seed=30)
+    w = net_macs(1, (32, 32), 1) + net_macs(1, (32, 32), 2)
+    ev = 5 / world
+    return dict(run=model._train_steps, evals_per_step=5, dtype='f32', finite=lambda: bool(torch.isfinite(model.theta).all()), mode=lambda: _mode(model),
+                metric='task-GP LML+grad evals/sec (PACOH-MAP demo: 20 tasks x 5 points, 5 per iteration)',
+                flops={'gp_lml_fwdbwd': (gp_flops(5, 2) * ev,) * 2, 'mlp_fwd': (2 * 5 * w * ev,) * 2, 'mlp_bwd': (4 * 5 * w * ev, 6 * 5 * w * ev)},
+                describe='PACOH-MAP iteration (hipGraph replay), cfg#1 = the reference\'s demo: 20 tasks x 5 points, 5 tasks per iteration, NN(32,32) mean + kernel, AdamW',
+                extra={'tasks_total': 20, 'n_ctx': 5, 'd': 1})
+
+
 def wl_cfg2(world, scaling, M, L):
     """PACOH-MAP, 256 sinusoid-like tasks, n_ctx = 32, d = 1, SE kernel + NN(32,32) mean, the full task batch every iteration"""
     T = 256 * world if scaling == 'weak' else 256
@@ -472,7 +485,7 @@ def wl_cfg5(world, scaling, M, L):
                 extra={'problems_per_gpu': B, 'n_ctx': n, 'd': d})
 
 
-WORKLOADS = {2: wl_cfg2, 3: wl_cfg3, 4: wl_cfg4, 5: wl_cfg5}
+WORKLOADS = {1: wl_cfg1, 2: wl_cfg2, 3: wl_cfg3, 4: wl_cfg4, 5: wl_cfg5}
 
 if __name__ == '__main__':
     main()

@@ -190,9 +190,9 @@ def test_bench_line_contract():
     assert abs(sum(d['kernel_ms_per_step'].values()) - d['kernel_sum_ms_per_step']) < 1e-2
     # the other BASELINE configurations ride along, bounded, so that the driver sees them too
     oc = d['other_configs']
-    assert set(oc) == {'cfg2', 'cfg4', 'cfg5'}
+    assert set(oc) == {'cfg1', 'cfg2', 'cfg4', 'cfg5'}
     for leg in oc.values():
         assert leg['finite'] is True and leg['value'] > 0 and leg['ms_per_step'] > 0
-        assert abs(leg['value'] - {'cfg2': 256, 'cfg4': 5120, 'cfg5': 256}[[k for k, v in oc.items() if v is leg][0]] / (leg['ms_per_step'] * 1e-3)) <= 2e-3 * leg['value']
+        assert abs(leg['value'] - {'cfg1': 5, 'cfg2': 256, 'cfg4': 5120, 'cfg5': 256}[[k for k, v in oc.items() if v is leg][0]] / (leg['ms_per_step'] * 1e-3)) <= 2e-3 * leg['value']
         assert 0 < leg['dominant_kernel']['algorithmic_frac'] < 1
-    assert oc['cfg5']['dtype'] == 'f64' and oc['cfg2']['dtype'] == oc['cfg4']['dtype'] == 'f32'
+    assert oc['cfg5']['dtype'] == 'f64' and oc['cfg1']['dtype'] == oc['cfg2']['dtype'] == oc['cfg4']['dtype'] == 'f32'
