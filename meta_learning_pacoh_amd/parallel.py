@@ -92,6 +92,8 @@ class RcclComm:
     """pacoh_comm_* handle of this rank (include/pacoh_gp.h, section 8e): created collectively by every rank.  graph_ok: the
     all-reduce survived capture into a hipGraph and two replays with the right sums on EVERY rank (self_test)"""
 
+    SELF_TEST_TIMEOUT_S = 180
+
     def __init__(self, self_test=True):
         rank, w = world()
         self.rank, self.world_size = rank, w
@@ -161,7 +163,24 @@ class RcclComm:
             torch.cuda.synchronize()
             return (buf == w * total).all()
 
-        ok = phase(eager) and phase(capture) and phase(replay)
+        # A collective that one rank never joins cannot be cancelled: if the test does not finish, say so and end the process (the
+        # launcher then ends the job) instead of leaving a silent hang for the caller's own timeout to find
+        def gave_up():
+            import sys
+            sys.stderr.write('pacoh: the in-graph RCCL all-reduce self-test did not finish within %d s on rank %d of %d -- rerun with '
+                             'PACOH_COMM=torch (torch.distributed carries the exchange between two graphs per step)\n'
+                             % (self.SELF_TEST_TIMEOUT_S, rank, w))
+            sys.stderr.flush()
+            os._exit(13)
+        import threading
+        dog = threading.Timer(self.SELF_TEST_TIMEOUT_S, gave_up)
+        dog.daemon = True
+        if w > 1:
+            dog.start()
+        try:
+            ok = phase(eager) and phase(capture) and phase(replay)
+        finally:
+            dog.cancel()
         del graph
         return ok
 
