@@ -216,15 +216,28 @@ int dense_mfma_try(void* A, const void* resid, void* logp, void* alpha_out, int3
 // Cholesky + solves + log-density of B materialised matrices; attempt > 0 re-runs only problems with info[b] < 0
 // (and then writes info[b] = attempt on success): the psd_safe_cholesky ladder of the dense path.
 // true when dense_chol_launch() takes the MFMA kernel, which leaves the inverses of the diagonal blocks in the upper triangle
+bool dense_ll_fits(int n, int dtype);                      // dense_ll.hip
+int dense_ll_try(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n, int dtype,
+                 int attempt, int u_only, hipStream_t s);                    // dense_ll.hip; returns 1 if n is outside its plan
+constexpr int LL_MIN_N = 97;                               // below: the right-looking kernel with fewer waves
+static bool ll_enabled() {
+    static const bool on = []() { const char* e = getenv("PACOH_CHOL_LL"); return !(e && e[0] == '0'); }();
+    return on;
+}
 bool dense_chol_saves_inverse(int n, int dtype) {
     const char* e = getenv("PACOH_DISABLE_MFMA");
-    return !(e && e[0] == '1') && dense_mfma_fits(n, dtype);
+    if (e && e[0] == '1') return false;
+    return (ll_enabled() && n >= LL_MIN_N && dense_ll_fits(n, dtype)) || dense_mfma_fits(n, dtype);
 }
 
 // u_only (only honoured on the MFMA path, i.e. when dense_chol_saves_inverse()): alpha_out receives u = L^-1 r instead of alpha
 int dense_chol_launch(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
                       int dtype, int attempt, hipStream_t stream, int u_only) {
     static const bool mfma_on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
+    if (mfma_on && ll_enabled() && n >= LL_MIN_N) {
+        int rc = dense_ll_try(A, resid, logp, alpha_out, info, scale, B, n, dtype, attempt, u_only, stream);
+        if (rc != 1) return rc;
+    }
     if (mfma_on) {
         int rc = dense_mfma_try(A, resid, logp, alpha_out, info, scale, B, n, dtype, attempt, u_only, stream);
         if (rc != 1) return rc;
