@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
     constexpr int ES = sizeof(T), BLK = 256 * ES;
     using Acc = typename Mf<T>::acc;
     unsigned char* const Dimg = sm;                               // next / current diagonal block, 10 block images (C^T layout)
-    unsigned char* const Zimg = Dimg + 10 * BLK;                  // -Z00 | +L10 | -Z11 as MFMA A-operand images
+    unsigned char* const Zimg = Dimg + 10 * BLK;                  // Z00 | -L10 | Z11 as MFMA A-operand images
     const int npad = (n + 63) & ~63;
     T* const uvec = reinterpret_cast<T*>(Zimg + 10 * BLK);        // [npad]  u = L^-1 r
     T* const tmpv = uvec + npad;                                  // [64]
@@ -93,6 +93,13 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     T* const Ab = A + (size_t)blockIdx.x * n * n;
+#ifdef PACOH_LL_STAMPS
+    if (blockIdx.x == 0 && lane == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        printf("wave %d: HW_ID %08x  simd %u  cu %u  wave_slot %u\n", wave, hwid, (hwid >> 4) & 3, (hwid >> 8) & 15, hwid & 15);
+    }
+#endif
     const int ncol = (n + LLW - 1) / LLW;
     if (tid < 32) flg[tid] = T(0);
     for (int q = tid; q < npad; q += LL_NT) uvec[q] = T(0);
@@ -121,14 +128,15 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
     LL_BAR();
 
     // ---- pieces shared by the bulk waves and (first column) the helpers -------------------------------------------------------
-    // accumulator blocks are TRANSPOSED (register q of lane (r, g) = element [row 16 ib + r][column 16 cb + row(g, q)]) and hold
-    // MINUS the updated panel: they start as -A (loaded while the first slab is in flight) and collect + L L^T
-    auto load_neg = [&](Acc (&X)[4], int c0, int ib) __attribute__((always_inline)) {
+    // accumulator blocks are TRANSPOSED (register q of lane (r, g) = element [row 16 ib + r][column 16 cb + row(g, q)]); they start
+    // as A -- loads that nothing waits for until the first MFMA: they fly under the first slab's fetch -- and collect - L L^T
+    // (the top-row operand is negated on its way into the MFMA: four sign flips per eight MFMAs)
+    auto load_a = [&](Acc (&X)[4], int c0, int ib) __attribute__((always_inline)) {
         const int row = c0 + 16 * ib + r;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) X[cb][q] = row < n ? -Ab[(size_t)row * n + c0 + 16 * cb + Mf<T>::row(g, q)] : T(0);
+            for (int q = 0; q < 4; ++q) X[cb][q] = row < n ? Ab[(size_t)row * n + c0 + 16 * cb + Mf<T>::row(g, q)] : T(0);
     };
     auto zmul = [&](int av, int b, const Acc& X, Acc o) __attribute__((always_inline)) -> Acc {
         const T* zp = reinterpret_cast<const T*>(Zimg + tri_idx(av, b) * BLK) + lane;
@@ -136,15 +144,15 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
         for (int s = 0; s < 4; ++s) o = Mf<T>::mma(zp[s * 64], X[s], o);
         return o;
     };
-    // panel solve on X = -(panel) (4 blocks = 64 columns x 16 rows, transposed): X := L21^T = Z_jj (panel), through the 2 x 2
-    // structure of Z_jj with the images -Z00 | +L10 | -Z11
+    // panel solve (4 blocks = 64 columns x 16 rows, transposed): X := L21^T = Z_jj X, through the 2 x 2 structure of Z_jj with the
+    // images Z00 | -L10 | Z11
     auto solve = [&](Acc (&X)[4]) __attribute__((always_inline)) {
         const Acc z = {0, 0, 0, 0};
         Acc t1 = zmul(1, 0, X[0], z);
         t1 = zmul(1, 1, X[1], t1);
         const Acc t0 = zmul(0, 0, X[0], z);
         X[0] = t0; X[1] = t1;
-        X[2] = zmul(2, 0, X[0], X[2]); X[2] = zmul(2, 1, X[1], X[2]);      // -(panel_hi - L10 Y_lo)
+        X[2] = zmul(2, 0, X[0], X[2]); X[2] = zmul(2, 1, X[1], X[2]);      // panel_hi - L10 Y_lo
         X[3] = zmul(3, 0, X[0], X[3]); X[3] = zmul(3, 1, X[1], X[3]);
         Acc t3 = zmul(3, 2, X[2], z);
         t3 = zmul(3, 3, X[3], t3);
@@ -190,24 +198,28 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                     a[cc] = v;
                 }
             };
-            auto after_elim = [&](int h, int rr, int lane, int n, int c0) __attribute__((always_inline)) {                        // L(h,h) -> global, log-determinant
-                const int row = c0 + 32 * h + rr;
-                if (lane < 32 && row < n) {
+            // The chain writes nothing to global memory (its scattered 8-byte stores queued behind the bulk waves' panel stores and
+            // stalled the elimination): L(h,h) goes back into the Dimg images its rows came from, Z(h,h) and L10 are in Zimg anyway,
+            // and helper waves 1 / 2 copy all of it out behind X1.
+            auto after_elim = [&](int h, int rr, int lane, int n, int c0) __attribute__((always_inline)) {      // L(h,h) -> Dimg, log-determinant
+                if (lane < 32) {
+                    const int ibv = 2 * h + (rr >> 4);
+                    const int base = tri_idx(ibv, 0) * BLK;
 #pragma unroll
-                    for (int cc = 0; cc < DNB; ++cc)
-                        if (cc <= rr) Ab[(size_t)row * n + c0 + 32 * h + cc] = a[cc];
-                    logdet_part -= t_log<T>(invd[32 * h + rr]);
+                    for (int cc = 0; cc < DNB; ++cc) {
+                        const int cb = 2 * h + (cc >> 4);
+                        if (cb <= ibv) *reinterpret_cast<T*>(Dimg + base + cb * BLK + img_off<T>(cc & 15, rr & 15)) = a[cc];
+                    }
+                    if (c0 + 32 * h + rr < n) logdet_part -= t_log<T>(invd[32 * h + rr]);
                 }
             };
-            auto after_inv = [&](int h, int rr, int lane, int n, int c0) __attribute__((always_inline)) {                         // Z(h,h) -> operand images and (transposed) the upper triangle
+            auto after_inv = [&](int h, int rr, int lane, int n, int c0) __attribute__((always_inline)) {       // Z(h,h) -> operand images
                 if (lane < 32) {
                     const int av = 2 * h + (rr >> 4);
 #pragma unroll
                     for (int cc = 0; cc < DNB; ++cc) {
                         const int b = 2 * h + (cc >> 4);
-                        if (b <= av) *reinterpret_cast<T*>(Zimg + tri_idx(av, b) * BLK + img_off<T>(cc & 15, rr & 15)) = -a[cc];
-                        const int row = c0 + 32 * h + cc, col = c0 + 32 * h + rr;
-                        if (cc < rr && col < n) Ab[(size_t)row * n + col] = a[cc];
+                        if (b <= av) *reinterpret_cast<T*>(Zimg + tri_idx(av, b) * BLK + img_off<T>(cc & 15, rr & 15)) = a[cc];
                     }
                 }
             };
@@ -227,19 +239,16 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                             for (int s = 0; s < 4; ++s)
                                 o = Mf<T>::mma(*reinterpret_cast<const T*>(Zimg + tri_idx(av, b) * BLK + (s * 64 + lane) * ES),
                                                *reinterpret_cast<const T*>(Dimg + tri_idx(2 + ibr, b) * BLK + (s * 64 + lane) * ES), o);
-                        const int row = c0 + 32 + 16 * ibr + r;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            *reinterpret_cast<T*>(Zimg + tri_idx(2 + ibr, av) * BLK + (q * 64 + lane) * ES) = -o[q];      // (o = -L10^T: the image is +L10)
-                            if (row < n) Ab[(size_t)row * n + c0 + 16 * av + Mf<T>::row(g, q)] = -o[q];
-                        }
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<T*>(Zimg + tri_idx(2 + ibr, av) * BLK + (q * 64 + lane) * ES) = -o[q];      // (the image is -L10)
                     }
                 LL_LDSWAIT();
 #pragma unroll
                 for (int ibr = 0; ibr < 2; ++ibr)
 #pragma unroll
                     for (int cbr = 0; cbr <= ibr; ++cbr) {
-                        Acc sacc = {0, 0, 0, 0};                  // L10 L10^T from the two images
+                        Acc sacc = {0, 0, 0, 0};                  // (-L10)(-L10)^T from the two images
 #pragma unroll
                         for (int av = 0; av < 2; ++av)
 #pragma unroll
@@ -254,7 +263,7 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
             };
             // The factorisation is straight-line code (one definition chain for the 32 row registers: as a switch inside a loop
             // every quantum boundary was a 27-way merge of all of them and the allocator spilled); after each quantum the barriers
-            // of the slots that end there are executed.  Slot 0 ends at P0 (<= quantum 11: Zimg still belongs to the previous
+            // of the slots that end there are executed.  Slot 0 ends at P0 (quanta 0..11: Zimg still belongs to the previous
             // column's panel solve), slot 1 at P1, slot 2 + s at slab s's barrier(s).
             const int nslots = cf.ns + 2;
             int slot = 0;
@@ -266,8 +275,9 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                 { const long long d_ = wall_clock64() - s0_; st_q += d_; st_qc[j & 7] += d_; }
 #endif
                 while (slot < nslots) {
-                    int qe = (slot + 1) * LL_NQ / nslots;
-                    if (slot == 0 && qe > 12) qe = 12;
+                    // the chain is the kernel's critical path: everything Zimg's hand-over allows goes in front of P0 (the bulk waves
+                    // are in the previous column's panel solve meanwhile), the rest is spread over P1 and the slabs
+                    const int qe = slot <= 1 ? 12 : 12 + (slot - 1) * (LL_NQ - 12) / (nslots - 2);
                     if (qe > qdone) break;
                     LL_BAR();
                     if (slot >= 2 && !cf.dbl) LL_BAR();
@@ -282,33 +292,28 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
 #define LL_OPAQUE() int lane = threadIdx.x & 63; asm volatile("" : "+v"(lane)); const int rr = lane & 31; int nq = n, c0q = c0; \
             asm volatile("" : "+s"(nq), "+s"(c0q)); (void)rr; (void)nq; (void)c0q
             sync_point(0);
-            { LL_OPAQUE(); load_rows(0, rr); ElimRange<T, 0, 4>::run(a, invd, bad, lane); } sync_point(1);
-            { LL_OPAQUE(); ElimRange<T, 4, 8>::run(a, invd, bad, lane); } sync_point(2);
-            { LL_OPAQUE(); ElimRange<T, 8, 12>::run(a, invd, bad, lane); } sync_point(3);
-            { LL_OPAQUE(); ElimRange<T, 12, 16>::run(a, invd, bad, lane); } sync_point(4);
-            { LL_OPAQUE(); ElimRange<T, 16, 20>::run(a, invd, bad, lane); } sync_point(5);
-            { LL_OPAQUE(); ElimRange<T, 20, 24>::run(a, invd, bad, lane); } sync_point(6);
-            { LL_OPAQUE(); ElimRange<T, 24, 28>::run(a, invd, bad, lane); } sync_point(7);
-            { LL_OPAQUE(); ElimRange<T, 28, 32>::run(a, invd, bad, lane); } sync_point(8);
-            { LL_OPAQUE(); LL_LDSWAIT(); after_elim(0, rr, lane, nq, c0q); InvRange<T, 31, 24>::run(a, invd, rr); } sync_point(9);
-            { LL_OPAQUE(); InvRange<T, 23, 16>::run(a, invd, rr); } sync_point(10);
-            { LL_OPAQUE(); InvRange<T, 15, 8>::run(a, invd, rr); } sync_point(11);
-            { LL_OPAQUE(); InvRange<T, 7, 0>::run(a, invd, rr); } sync_point(12);
-            { LL_OPAQUE(); after_inv(0, rr, lane, nq, c0q); } sync_point(13);
-            if (two) { LL_OPAQUE(); mid(lane, nq, c0q); } sync_point(14);
-            if (two) { LL_OPAQUE(); load_rows(1, rr); ElimRange<T, 0, 4>::run(a, invd + 32, bad, lane); } sync_point(15);
-            if (two) { LL_OPAQUE(); ElimRange<T, 4, 8>::run(a, invd + 32, bad, lane); } sync_point(16);
-            if (two) { LL_OPAQUE(); ElimRange<T, 8, 12>::run(a, invd + 32, bad, lane); } sync_point(17);
-            if (two) { LL_OPAQUE(); ElimRange<T, 12, 16>::run(a, invd + 32, bad, lane); } sync_point(18);
-            if (two) { LL_OPAQUE(); ElimRange<T, 16, 20>::run(a, invd + 32, bad, lane); } sync_point(19);
-            if (two) { LL_OPAQUE(); ElimRange<T, 20, 24>::run(a, invd + 32, bad, lane); } sync_point(20);
-            if (two) { LL_OPAQUE(); ElimRange<T, 24, 28>::run(a, invd + 32, bad, lane); } sync_point(21);
-            if (two) { LL_OPAQUE(); ElimRange<T, 28, 32>::run(a, invd + 32, bad, lane); } sync_point(22);
-            if (two) { LL_OPAQUE(); LL_LDSWAIT(); after_elim(1, rr, lane, nq, c0q); InvRange<T, 31, 24>::run(a, invd + 32, rr); } sync_point(23);
-            if (two) { LL_OPAQUE(); InvRange<T, 23, 16>::run(a, invd + 32, rr); } sync_point(24);
-            if (two) { LL_OPAQUE(); InvRange<T, 15, 8>::run(a, invd + 32, rr); } sync_point(25);
-            if (two) { LL_OPAQUE(); InvRange<T, 7, 0>::run(a, invd + 32, rr); } sync_point(26);
-            if (two) { LL_OPAQUE(); after_inv(1, rr, lane, nq, c0q); } sync_point(27);
+            // quanta 0..12: first 32-block (8 x elimination, 4 x inverse, images), 13: L10 and the update of D11, 14..26: second block.
+            // (ONE copy of the unrolled elimination / inverse for both blocks: 56 KB of straight-line code per pass as it is)
+#pragma nounroll
+            for (int h = 0; h < 2; ++h) {
+                const int qb = 14 * h;
+                const bool act = h == 0 || two;
+                T* const iv = invd + 32 * h;
+                if (act) { LL_OPAQUE(); load_rows(h, rr); ElimRange<T, 0, 4>::run(a, iv, bad, lane); } sync_point(qb + 1);
+                if (act) { LL_OPAQUE(); ElimRange<T, 4, 8>::run(a, iv, bad, lane); } sync_point(qb + 2);
+                if (act) { LL_OPAQUE(); ElimRange<T, 8, 12>::run(a, iv, bad, lane); } sync_point(qb + 3);
+                if (act) { LL_OPAQUE(); ElimRange<T, 12, 16>::run(a, iv, bad, lane); } sync_point(qb + 4);
+                if (act) { LL_OPAQUE(); ElimRange<T, 16, 20>::run(a, iv, bad, lane); } sync_point(qb + 5);
+                if (act) { LL_OPAQUE(); ElimRange<T, 20, 24>::run(a, iv, bad, lane); } sync_point(qb + 6);
+                if (act) { LL_OPAQUE(); ElimRange<T, 24, 28>::run(a, iv, bad, lane); } sync_point(qb + 7);
+                if (act) { LL_OPAQUE(); ElimRange<T, 28, 32>::run(a, iv, bad, lane); } sync_point(qb + 8);
+                if (act) { LL_OPAQUE(); LL_LDSWAIT(); after_elim(h, rr, lane, nq, c0q); InvRange<T, 31, 24>::run(a, iv, rr); } sync_point(qb + 9);
+                if (act) { LL_OPAQUE(); InvRange<T, 23, 16>::run(a, iv, rr); } sync_point(qb + 10);
+                if (act) { LL_OPAQUE(); InvRange<T, 15, 8>::run(a, iv, rr); } sync_point(qb + 11);
+                if (act) { LL_OPAQUE(); InvRange<T, 7, 0>::run(a, iv, rr); } sync_point(qb + 12);
+                if (act) { LL_OPAQUE(); after_inv(h, rr, lane, nq, c0q); } sync_point(qb + 13);
+                if (h == 0) { if (two) { LL_OPAQUE(); mid(lane, nq, c0q); } sync_point(14); }
+            }
 #undef LL_OPAQUE
             LL_BAR();                                             // X1: Zimg complete
             LL_BAR();                                             // X2
@@ -385,6 +390,55 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                     glds16(reinterpret_cast<const unsigned char*>(Ab + (size_t)(cn.c0 + ic) * n) + ((pp ^ sig) << 4), slab0 + v * 1024);
                 }
             }
+            // Only what must leave Dimg before the look-ahead owners overwrite it (behind X2) happens in front of X2 -- the priority
+            // row blocks' solve is 2 us, and every wave of the workgroup waits here: helper h' = hidx - 1 takes the three blocks of
+            // L(h',h') into registers.  Everything else (copy-out of Z and L10, forward solve, first-column row blocks) reads Zimg,
+            // which the chain rewrites only behind the next P0.
+            // (lane ids made opaque inside the column loop, as in the chain: the ~100 LDS addresses of the unrolled code below are
+            //  loop invariant and would be hoisted and spilled -- 87 registers, reloaded next to every slab barrier)
+            int lane = threadIdx.x & 63;
+            asm volatile("" : "+v"(lane));
+            const int r = lane & 15, g = lane >> 4;
+            T lreg[3][4];
+            if (hidx != 0) {
+                const int hh = hidx - 1;
+#pragma unroll
+                for (int av = 0; av < 2; ++av)
+#pragma unroll
+                    for (int b = 0; b <= av; ++b) {
+                        const T* lp = reinterpret_cast<const T*>(Dimg + tri_idx(2 * hh + av, 2 * hh + b) * BLK) + lane;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) lreg[av + b][q] = lp[q * 64];
+                    }
+            }
+            LL_BAR();                                             // X2
+            LL_BAR();                                             // X3
+            if (hidx != 0) {
+                // L(h',h'), the strictly lower part of Z(h',h') transposed into the block's upper triangle, half of L10
+                const int hh = hidx - 1;
+                const int k0 = c0 + 32 * hh;
+#pragma unroll
+                for (int av = 0; av < 2; ++av)
+#pragma unroll
+                    for (int b = 0; b <= av; ++b) {
+                        const T* zp = reinterpret_cast<const T*>(Zimg + tri_idx(2 * hh + av, 2 * hh + b) * BLK) + lane;
+                        const int i = 16 * av + r;                // row inside the 32-block
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c = 16 * b + Mf<T>::row(g, q);
+                            if (c <= i && k0 + i < n) Ab[(size_t)(k0 + i) * n + k0 + c] = lreg[av + b][q];
+                            if (c < i && k0 + i < n) Ab[(size_t)(k0 + c) * n + k0 + i] = zp[q * 64];
+                        }
+                    }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {                     // L10 block (hh, b): rows c0 + 32 + 16 hh + r
+                    const T* lp = reinterpret_cast<const T*>(Zimg + tri_idx(2 + hh, b) * BLK) + lane;
+                    const int row = c0 + 32 + 16 * hh + r;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (row < n) Ab[(size_t)row * n + c0 + 16 * b + Mf<T>::row(g, q)] = -lp[q * 64];
+                }
+            }
             if (hidx == 0) {                                      // u_j = Z_jj (r_j - L[j, 0:j] u)
                 const int row = c0 + lane;
                 const T rhs = row < n ? resid[(size_t)blockIdx.x * n + row] - sacc : T(0);
@@ -396,11 +450,11 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
 #pragma unroll
                     for (int c = 0; c < 32; ++c)
                         if ((c >> 4) <= av) u = fma(*reinterpret_cast<const T*>(Zimg + tri_idx(av, c >> 4) * BLK + img_off<T>(c & 15, li & 15)), tmpv[c], u);
-                    uvec[c0 + lane] = -u;                         // (the image is -Z00)
+                    uvec[c0 + lane] = u;
                 }
                 LL_LDSWAIT();
                 if (lane >= 32) {
-                    T t = -tmpv[lane];                            // -(r_hi - L10 u_lo), to meet the image -Z11
+                    T t = tmpv[lane];                             // r_hi - L10 u_lo
 #pragma unroll
                     for (int c = 0; c < 32; ++c)
                         t = fma(*reinterpret_cast<const T*>(Zimg + tri_idx(2 + av, c >> 4) * BLK + img_off<T>(c & 15, li & 15)), uvec[c0 + c], t);
@@ -414,18 +468,6 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                     uvec[c0 + lane] = row < n ? u : T(0);
                 }
             }
-            // first column (nothing to accumulate, 28 row blocks at n = 512 against the bulk waves' 24 slots): the helpers solve the
-            // row blocks beyond those slots -- the chain, whose SIMD they share, idles until X3
-            if (cf.ns == 0) {
-                for (int rho = 2 * LL_NBULK + hidx; rho < cf.R; rho += 3) {
-                    Acc X[4];
-                    load_neg(X, c0, 4 + rho);
-                    solve(X);
-                    store_l(X, c0, 4 + rho);
-                }
-            }
-            LL_BAR();                                             // X2
-            LL_BAR();                                             // X3
         }
 #ifdef LL_X_BULK
     } else if (false) {
@@ -438,7 +480,7 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
         int lacb = 4, laib = 4;
         if (la_owner) { int cbr, ibr; la_coords(bw - 2, cbr, ibr); lacb = 4 + cbr; laib = 4 + ibr; }
 #ifdef PACOH_LL_STAMPS
-        long long sb_[6] = {0, 0, 0, 0, 0, 0}, sb_t = wall_clock64();
+        long long sb_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sb_t = wall_clock64();
 #define BST(k) do { const long long t_ = wall_clock64(); sb_[k] += t_ - sb_t; sb_t = t_; } while (0)
 #else
 #define BST(k) do {} while (0)
@@ -453,13 +495,13 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) { acc0[cb] = Acc{0, 0, 0, 0}; acc1[cb] = Acc{0, 0, 0, 0}; }
             la = Acc{0, 0, 0, 0};
-            // -A into the accumulators: the loads fly while the column's first slab is fetched (P0 / P1)
-            if (v0) load_neg(acc0, c0, ib0);
-            if (v1) load_neg(acc1, c0, ib1);
+            // A into the accumulators: the loads fly while the column's first slab is fetched (P0 / P1)
+            if (v0) load_a(acc0, c0, ib0);
+            if (v1) load_a(acc1, c0, ib1);
             if (do_la) {
                 const int row = c0 + 16 * laib + r;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) la[q] = -a_padded(row, c0 + 16 * lacb + Mf<T>::row(g, q));
+                for (int q = 0; q < 4; ++q) la[q] = a_padded(row, c0 + 16 * lacb + Mf<T>::row(g, q));
             }
             // P += (top rows) (own rows)^T over one slab
             auto slab_mma = [&](const unsigned char* buf) __attribute__((always_inline)) {
@@ -479,7 +521,7 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                         if (v0) {
                             T av[4];
 #pragma unroll
-                            for (int cb = 0; cb < 4; ++cb) av[cb] = *reinterpret_cast<const T*>(buf + cb * 16 * RB + xo);
+                            for (int cb = 0; cb < 4; ++cb) av[cb] = -*reinterpret_cast<const T*>(buf + cb * 16 * RB + xo);
                             const T b0 = *reinterpret_cast<const T*>(buf + ib0 * 16 * RB + xo);
 #pragma unroll
                             for (int cb = 0; cb < 4; ++cb) acc0[cb] = Mf<T>::mma(av[cb], b0, acc0[cb]);
@@ -490,7 +532,7 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                             }
                         }
                         if (do_la) {
-                            const T aa = *reinterpret_cast<const T*>(buf + lacb * 16 * RB + xo);
+                            const T aa = -*reinterpret_cast<const T*>(buf + lacb * 16 * RB + xo);
                             const T bb = *reinterpret_cast<const T*>(buf + laib * 16 * RB + xo);
                             la = Mf<T>::mma(aa, bb, la);
                         }
@@ -499,8 +541,9 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
             };
             BST(5);
             LL_BAR();                                             // P0
-            LL_BAR();                                             // P1
             BST(0);
+            LL_BAR();                                             // P1
+            BST(6);
             for (int s = 0; s < cf.ns; ++s) {
                 slab_mma((cf.dbl && (s & 1)) ? slab1 : slab0);
                 BST(1);
@@ -520,9 +563,11 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
             // pass 0: the rows of the next diagonal block (they gate the chain), pass 1: everything else
             const bool pr0 = v0 && ib0 < 8;                       // (ib1 >= 16: never a priority block)
             if (pr0) { solve(acc0); publish(acc0, ib0); }
+            BST(7);
             LL_BAR();                                             // X2: Limg complete
-            if (do_la) {                                          // next diagonal block = -(la + L21 L21^T over this column's 64 columns)
-                Acc sacc = la;
+            BST(8);
+            if (do_la) {                                          // next diagonal block = la - L21 L21^T over this column's 64 columns
+                Acc sacc = {0, 0, 0, 0};
                 const T* pa = reinterpret_cast<const T*>(Limg + (lacb - 4) * 4 * BLK) + lane;
                 const T* pb = reinterpret_cast<const T*>(Limg + (laib - 4) * 4 * BLK) + lane;
 #pragma unroll
@@ -533,20 +578,29 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int col = c0 + 16 * lacb + Mf<T>::row(g, q);
-                    const T v = (row < n && col < n) ? -sacc[q] : (row == col ? T(1) : T(0));
+                    const T v = (row < n && col < n) ? la[q] - sacc[q] : (row == col ? T(1) : T(0));
                     *reinterpret_cast<T*>(Dimg + tri_idx(laib - 4, lacb - 4) * BLK + (q * 64 + lane) * ES) = v;
                 }
             }
+            BST(9);
             LL_BAR();                                             // X3: Dimg holds the next diagonal block
+            BST(10);
             if (pr0) store_l(acc0, c0, ib0);
             if (v0 && !pr0) { solve(acc0); store_l(acc0, c0, ib0); }
             if (v1) { solve(acc1); store_l(acc1, c0, ib1); }
+            // first column (nothing accumulated: 28 row blocks at n = 512 against 24 slots): a third row block for the first waves
+            if (cf.ns == 0 && bw + 2 * LL_NBULK < cf.R) {
+                load_a(acc0, c0, ib1 + LL_NBULK);
+                solve(acc0);
+                store_l(acc0, c0, ib1 + LL_NBULK);
+            }
+            BST(11);
         }
 #ifdef PACOH_LL_STAMPS
         BST(5);
         if ((bw == 0 || bw == 11) && lane == 0 && blockIdx.x == 0)
-            printf("bulk %d (us): P0+P1 wait %.1f | slab mma %.1f | slab barrier %.1f | load X %.1f | X1 wait %.1f | phase B + stores %.1f\n", bw,
-                   sb_[0] * 0.01, sb_[1] * 0.01, sb_[2] * 0.01, sb_[3] * 0.01, sb_[4] * 0.01, sb_[5] * 0.01);
+            printf("bulk %d (us): load -A issue %.1f | P0 wait %.1f | P1 wait %.1f | slab mma %.1f | slab barrier %.1f | X1 wait %.1f | pass 0 %.1f | X2 wait %.1f | LA %.1f | X3 wait %.1f | pass 1 + stores %.1f\n", bw,
+                   sb_[5] * 0.01, sb_[0] * 0.01, sb_[6] * 0.01, sb_[1] * 0.01, sb_[2] * 0.01, (sb_[3] + sb_[4]) * 0.01, sb_[7] * 0.01, sb_[8] * 0.01, sb_[9] * 0.01, sb_[10] * 0.01, sb_[11] * 0.01);
 #endif
 #undef BST
     }
