@@ -28,6 +28,7 @@
 // (random_gp.py:83-85 at the large-context configuration; joint test log-likelihood of abstract.py:134-163).
 #include "common.h"
 #include "dense_diag.h"
+#include <type_traits>
 
 namespace pacoh {
 namespace {
@@ -35,22 +36,28 @@ namespace {
 constexpr int LLW = 64;              // block-column width
 constexpr int LL_NT = 1024;
 constexpr int LL_NBULK = 12;
-constexpr int LL_NQ = 27;            // quanta of the chain per block column
+constexpr int LL_NQ = 28;            // quanta of the chain per block column
 
 __host__ __device__ constexpr int tri_idx(int a, int b) { return a * (a + 1) / 2 + b; }
 
-struct ColCfg { int c0, m, mb, R, RB, KS, ns, dbl, mrows; };
+struct ColCfg { int c0, m, mb, R, RB, KS, ns, nb, bsz, mrows; };
 
 template <typename T>
 __host__ __device__ inline ColCfg col_cfg(int j, int n, int S0, int S1) {
     ColCfg c;
     c.c0 = j * LLW; c.m = n - c.c0; c.mb = (c.m + 15) >> 4;
     c.R = c.mb > 4 ? c.mb - 4 : 0;
-    int RB = 256, mrows = (c.m + 3) & ~3;                    // 4 rows per DMA instruction at 256-byte rows, 8 at 128
-    if (mrows * 256 > S1 || mrows * 256 > S0) { RB = 128; mrows = (c.m + 7) & ~7; }
-    c.RB = RB; c.mrows = mrows; c.KS = RB / (int)sizeof(T);
-    c.ns = c.c0 / c.KS;
-    c.dbl = mrows * RB <= S1 ? 1 : 0;
+    // the slabs of a column go through a ring of up to four buffers in the S0 + S1 bytes behind the fixed LDS areas (prefetch
+    // distance = buffers - 1); 256-byte rows (half as many slabs and barriers) when three of those fit, else 128-byte rows.
+    // A DMA instruction fills 1 KiB: 4 rows of 256 bytes or 8 of 128.
+    const int tot = S0 + S1;
+    const int m256 = (c.m + 3) & ~3, m128 = (c.m + 7) & ~7;
+    int nb256 = tot / (m256 * 256), nb128 = tot / (m128 * 128);
+    nb256 = nb256 > 4 ? 4 : nb256; nb128 = nb128 > 4 ? 4 : nb128;
+    if (nb256 >= 3) { c.RB = 256; c.mrows = m256; c.nb = nb256; } else { c.RB = 128; c.mrows = m128; c.nb = nb128; }
+    c.bsz = c.mrows * c.RB;
+    c.KS = c.RB / (int)sizeof(T);
+    c.ns = c.R > 0 ? c.c0 / c.KS : 0;                         // (a last column with nothing below its diagonal block: no slabs)
     return c;
 }
 
@@ -66,6 +73,21 @@ template <typename T> __device__ __forceinline__ constexpr int img_off(int c15, 
 __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// s_waitcnt vmcnt(n) for a run-time n (the instruction takes an immediate); n > 63 waits for less than asked: never here
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define LL_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        LL_VMC(0) LL_VMC(1) LL_VMC(2) LL_VMC(3) LL_VMC(4) LL_VMC(5) LL_VMC(6) LL_VMC(7) LL_VMC(8) LL_VMC(9) LL_VMC(10) LL_VMC(11) LL_VMC(12)
+        LL_VMC(13) LL_VMC(14) LL_VMC(15) LL_VMC(16) LL_VMC(17) LL_VMC(18) LL_VMC(19) LL_VMC(20) LL_VMC(21) LL_VMC(22) LL_VMC(23) LL_VMC(24)
+        LL_VMC(25) LL_VMC(26) LL_VMC(27) LL_VMC(28) LL_VMC(29) LL_VMC(30) LL_VMC(31) LL_VMC(32) LL_VMC(33) LL_VMC(34) LL_VMC(35) LL_VMC(36)
+        LL_VMC(37) LL_VMC(38) LL_VMC(39) LL_VMC(40) LL_VMC(41) LL_VMC(42) LL_VMC(43) LL_VMC(44) LL_VMC(45) LL_VMC(46) LL_VMC(47) LL_VMC(48)
+        LL_VMC(49) LL_VMC(50) LL_VMC(51) LL_VMC(52) LL_VMC(53) LL_VMC(54) LL_VMC(55) LL_VMC(56) LL_VMC(57) LL_VMC(58) LL_VMC(59) LL_VMC(60)
+        LL_VMC(61) LL_VMC(62)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef LL_VMC
 }
 
 #define LL_BAR() __syncthreads()
@@ -133,10 +155,12 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
     // (the top-row operand is negated on its way into the MFMA: four sign flips per eight MFMAs)
     auto load_a = [&](Acc (&X)[4], int c0, int ib) __attribute__((always_inline)) {
         const int row = c0 + 16 * ib + r;
+        const int rowc = row < n ? row : n - 1;                   // (rows beyond the matrix: a copy of the last row, never stored -- a
+                                                                  //  select on the loaded value would make every load wait where it is issued)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) X[cb][q] = row < n ? Ab[(size_t)row * n + c0 + 16 * cb + Mf<T>::row(g, q)] : T(0);
+            for (int q = 0; q < 4; ++q) X[cb][q] = Ab[(size_t)rowc * n + c0 + 16 * cb + Mf<T>::row(g, q)];
     };
     auto zmul = [&](int av, int b, const Acc& X, Acc o) __attribute__((always_inline)) -> Acc {
         const T* zp = reinterpret_cast<const T*>(Zimg + tri_idx(av, b) * BLK) + lane;
@@ -186,32 +210,38 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
             const int c0 = cf.c0;
             const int kbw = cf.m < LLW ? cf.m : LLW;
             const bool two = kbw > 32;
-            // one quantum of the factorisation of the 64 x 64 block in Dimg; h = 0 / 1: its first / second 32 x 32 diagonal block
-            auto load_rows = [&](int h, int rr) __attribute__((always_inline)) {
-                const int ibv = 2 * h + (rr >> 4);
+            // Pieces of the factorisation of the 64 x 64 block in Dimg.  h = 0: the 64 x 32 PANEL [D00; D10], a row per lane (all 64 lanes
+            // carry distinct rows: the elimination of D00 yields L10 = D10 L00^-T in the same instructions); h = 1: the 32 x 32 block
+            // D11 - L10 L10^T (both half-waves carry the same rows).
+            auto load_rows = [&](int h, int lane) __attribute__((always_inline)) {          // h = 2: L00 back from Dimg, for its inverse
+                const int row = h == 1 ? 32 + (lane & 31) : (h == 2 ? (lane & 31) : lane);
+                if (h == 2) h = 0;
+                const int ibv = row >> 4;
                 const int base = tri_idx(ibv, 0) * BLK;
 #pragma unroll
                 for (int cc = 0; cc < DNB; ++cc) {
                     const int cb = 2 * h + (cc >> 4);
                     T v = T(0);
-                    if (cb <= ibv) v = *reinterpret_cast<const T*>(Dimg + base + cb * BLK + img_off<T>(cc & 15, rr & 15));
+                    if (cb <= ibv) v = *reinterpret_cast<const T*>(Dimg + base + cb * BLK + img_off<T>(cc & 15, row & 15));
                     a[cc] = v;
                 }
             };
             // The chain writes nothing to global memory (its scattered 8-byte stores queued behind the bulk waves' panel stores and
-            // stalled the elimination): L(h,h) goes back into the Dimg images its rows came from, Z(h,h) and L10 are in Zimg anyway,
-            // and helper waves 1 / 2 copy all of it out behind X1.
-            auto after_elim = [&](int h, int rr, int lane, int n, int c0) __attribute__((always_inline)) {      // L(h,h) -> Dimg, log-determinant
-                if (lane < 32) {
-                    const int ibv = 2 * h + (rr >> 4);
-                    const int base = tri_idx(ibv, 0) * BLK;
+            // stalled the elimination): L(h,h) goes back into the Dimg images its rows came from, -L10 into its Zimg operand images,
+            // and helper waves 1 / 2 copy all of it out behind X3.
+            auto after_elim = [&](int h, int lane, int n, int c0) __attribute__((always_inline)) {
+                const int row = h ? 32 + (lane & 31) : lane;
+                const int ibv = row >> 4;
+                const bool is_l10 = h == 0 && lane >= 32;
+                unsigned char* const dst = (is_l10 ? Zimg : Dimg) + tri_idx(ibv, 0) * BLK;
+                if (h == 0 || lane < 32) {
 #pragma unroll
                     for (int cc = 0; cc < DNB; ++cc) {
                         const int cb = 2 * h + (cc >> 4);
-                        if (cb <= ibv) *reinterpret_cast<T*>(Dimg + base + cb * BLK + img_off<T>(cc & 15, rr & 15)) = a[cc];
+                        if (cb <= ibv) *reinterpret_cast<T*>(dst + cb * BLK + img_off<T>(cc & 15, row & 15)) = is_l10 ? -a[cc] : a[cc];
                     }
-                    if (c0 + 32 * h + rr < n) logdet_part -= t_log<T>(invd[32 * h + rr]);
                 }
+                if (lane < 32 && c0 + 32 * h + lane < n) logdet_part -= t_log<T>(invd[32 * h + lane]);
             };
             auto after_inv = [&](int h, int rr, int lane, int n, int c0) __attribute__((always_inline)) {       // Z(h,h) -> operand images
                 if (lane < 32) {
@@ -223,32 +253,13 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                     }
                 }
             };
-            auto mid = [&](int lane, int n, int c0) __attribute__((always_inline)) {      // L10^T = Z00 D10^T, D11 -= L10 L10^T
-                const int r = lane & 15, g = lane >> 4;
-                LL_LDSWAIT();
-                // (one 16 x 16 block of L10^T at a time, handed on through its operand image: the 32 x 32 row block `a` stays live
-                //  across this quantum, and four result blocks beside it do not fit in 128 registers)
-#pragma unroll
-                for (int av = 0; av < 2; ++av)
-#pragma unroll
-                    for (int ibr = 0; ibr < 2; ++ibr) {
-                        Acc o = {0, 0, 0, 0};
-#pragma unroll
-                        for (int b = 0; b <= av; ++b)
-#pragma unroll
-                            for (int s = 0; s < 4; ++s)
-                                o = Mf<T>::mma(*reinterpret_cast<const T*>(Zimg + tri_idx(av, b) * BLK + (s * 64 + lane) * ES),
-                                               *reinterpret_cast<const T*>(Dimg + tri_idx(2 + ibr, b) * BLK + (s * 64 + lane) * ES), o);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            *reinterpret_cast<T*>(Zimg + tri_idx(2 + ibr, av) * BLK + (q * 64 + lane) * ES) = -o[q];      // (the image is -L10)
-                    }
+            auto upd11 = [&](int lane) __attribute__((always_inline)) {      // D11 -= L10 L10^T, both operands from the -L10 images
                 LL_LDSWAIT();
 #pragma unroll
                 for (int ibr = 0; ibr < 2; ++ibr)
 #pragma unroll
                     for (int cbr = 0; cbr <= ibr; ++cbr) {
-                        Acc sacc = {0, 0, 0, 0};                  // (-L10)(-L10)^T from the two images
+                        Acc sacc = {0, 0, 0, 0};
 #pragma unroll
                         for (int av = 0; av < 2; ++av)
 #pragma unroll
@@ -263,7 +274,7 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
             };
             // The factorisation is straight-line code (one definition chain for the 32 row registers: as a switch inside a loop
             // every quantum boundary was a 27-way merge of all of them and the allocator spilled); after each quantum the barriers
-            // of the slots that end there are executed.  Slot 0 ends at P0 (quanta 0..11: Zimg still belongs to the previous
+            // of the slots that end there are executed.  Slot 0 ends at P0 (quanta 0..7: Zimg still belongs to the previous
             // column's panel solve), slot 1 at P1, slot 2 + s at slab s's barrier(s).
             const int nslots = cf.ns + 2;
             int slot = 0;
@@ -277,10 +288,10 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                 while (slot < nslots) {
                     // the chain is the kernel's critical path: everything Zimg's hand-over allows goes in front of P0 (the bulk waves
                     // are in the previous column's panel solve meanwhile), the rest is spread over P1 and the slabs
-                    const int qe = slot <= 1 ? 12 : 12 + (slot - 1) * (LL_NQ - 12) / (nslots - 2);
+                    const int qe = slot <= 1 ? 8 : 8 + (slot - 1) * (LL_NQ - 8) / (nslots - 2);
                     if (qe > qdone) break;
                     LL_BAR();
-                    if (slot >= 2 && !cf.dbl) LL_BAR();
+                    if (slot >= 2 && cf.nb == 1) LL_BAR();
                     ++slot;
                 }
 #ifdef PACOH_LL_STAMPS
@@ -292,28 +303,38 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
 #define LL_OPAQUE() int lane = threadIdx.x & 63; asm volatile("" : "+v"(lane)); const int rr = lane & 31; int nq = n, c0q = c0; \
             asm volatile("" : "+s"(nq), "+s"(c0q)); (void)rr; (void)nq; (void)c0q
             sync_point(0);
-            // quanta 0..12: first 32-block (8 x elimination, 4 x inverse, images), 13: L10 and the update of D11, 14..26: second block.
-            // (ONE copy of the unrolled elimination / inverse for both blocks: 56 KB of straight-line code per pass as it is)
-#pragma nounroll
-            for (int h = 0; h < 2; ++h) {
-                const int qb = 14 * h;
-                const bool act = h == 0 || two;
-                T* const iv = invd + 32 * h;
-                if (act) { LL_OPAQUE(); load_rows(h, rr); ElimRange<T, 0, 4>::run(a, iv, bad, lane); } sync_point(qb + 1);
-                if (act) { LL_OPAQUE(); ElimRange<T, 4, 8>::run(a, iv, bad, lane); } sync_point(qb + 2);
-                if (act) { LL_OPAQUE(); ElimRange<T, 8, 12>::run(a, iv, bad, lane); } sync_point(qb + 3);
-                if (act) { LL_OPAQUE(); ElimRange<T, 12, 16>::run(a, iv, bad, lane); } sync_point(qb + 4);
-                if (act) { LL_OPAQUE(); ElimRange<T, 16, 20>::run(a, iv, bad, lane); } sync_point(qb + 5);
-                if (act) { LL_OPAQUE(); ElimRange<T, 20, 24>::run(a, iv, bad, lane); } sync_point(qb + 6);
-                if (act) { LL_OPAQUE(); ElimRange<T, 24, 28>::run(a, iv, bad, lane); } sync_point(qb + 7);
-                if (act) { LL_OPAQUE(); ElimRange<T, 28, 32>::run(a, iv, bad, lane); } sync_point(qb + 8);
-                if (act) { LL_OPAQUE(); LL_LDSWAIT(); after_elim(h, rr, lane, nq, c0q); InvRange<T, 31, 24>::run(a, iv, rr); } sync_point(qb + 9);
-                if (act) { LL_OPAQUE(); InvRange<T, 23, 16>::run(a, iv, rr); } sync_point(qb + 10);
-                if (act) { LL_OPAQUE(); InvRange<T, 15, 8>::run(a, iv, rr); } sync_point(qb + 11);
-                if (act) { LL_OPAQUE(); InvRange<T, 7, 0>::run(a, iv, rr); } sync_point(qb + 12);
-                if (act) { LL_OPAQUE(); after_inv(h, rr, lane, nq, c0q); } sync_point(qb + 13);
-                if (h == 0) { if (two) { LL_OPAQUE(); mid(lane, nq, c0q); } sync_point(14); }
-            }
+            // quanta 0..7: elimination of the panel, 8: L00 / -L10 images, 9: update of D11, 10..17: elimination of D11,
+            // 18..21: its inverse, 22: images, 23..27: inverse of L00 and images
+            { LL_OPAQUE(); load_rows(0, lane); ElimRange<T, 0, 4>::run(a, invd, bad, lane); } sync_point(1);
+            { LL_OPAQUE(); ElimRange<T, 4, 8>::run(a, invd, bad, lane); } sync_point(2);
+            { LL_OPAQUE(); ElimRange<T, 8, 12>::run(a, invd, bad, lane); } sync_point(3);
+            { LL_OPAQUE(); ElimRange<T, 12, 16>::run(a, invd, bad, lane); } sync_point(4);
+            { LL_OPAQUE(); ElimRange<T, 16, 20>::run(a, invd, bad, lane); } sync_point(5);
+            { LL_OPAQUE(); ElimRange<T, 20, 24>::run(a, invd, bad, lane); } sync_point(6);
+            { LL_OPAQUE(); ElimRange<T, 24, 28>::run(a, invd, bad, lane); } sync_point(7);
+            { LL_OPAQUE(); ElimRange<T, 28, 32>::run(a, invd, bad, lane); } sync_point(8);
+            { LL_OPAQUE(); LL_LDSWAIT(); after_elim(0, lane, nq, c0q); LL_LDSWAIT(); } sync_point(9);
+            if (two) { LL_OPAQUE(); upd11(lane); } sync_point(10);
+            if (two) { LL_OPAQUE(); load_rows(1, lane); ElimRange<T, 0, 4>::run(a, invd + 32, bad, lane); } sync_point(11);
+            if (two) { LL_OPAQUE(); ElimRange<T, 4, 8>::run(a, invd + 32, bad, lane); } sync_point(12);
+            if (two) { LL_OPAQUE(); ElimRange<T, 8, 12>::run(a, invd + 32, bad, lane); } sync_point(13);
+            if (two) { LL_OPAQUE(); ElimRange<T, 12, 16>::run(a, invd + 32, bad, lane); } sync_point(14);
+            if (two) { LL_OPAQUE(); ElimRange<T, 16, 20>::run(a, invd + 32, bad, lane); } sync_point(15);
+            if (two) { LL_OPAQUE(); ElimRange<T, 20, 24>::run(a, invd + 32, bad, lane); } sync_point(16);
+            if (two) { LL_OPAQUE(); ElimRange<T, 24, 28>::run(a, invd + 32, bad, lane); } sync_point(17);
+            if (two) { LL_OPAQUE(); ElimRange<T, 28, 32>::run(a, invd + 32, bad, lane); } sync_point(18);
+            if (two) { LL_OPAQUE(); LL_LDSWAIT(); after_elim(1, lane, nq, c0q); InvRange<T, 31, 24>::run(a, invd + 32, rr); } sync_point(19);
+            if (two) { LL_OPAQUE(); InvRange<T, 23, 16>::run(a, invd + 32, rr); } sync_point(20);
+            if (two) { LL_OPAQUE(); InvRange<T, 15, 8>::run(a, invd + 32, rr); } sync_point(21);
+            if (two) { LL_OPAQUE(); InvRange<T, 7, 0>::run(a, invd + 32, rr); } sync_point(22);
+            if (two) { LL_OPAQUE(); after_inv(1, rr, lane, nq, c0q); } sync_point(23);
+            // the inverse of L00 last: nothing on this wave's path needs it (L10 came out of the panel elimination), the bulk waves need
+            // it at X1 -- and since the panel elimination this wave is no longer the kernel's critical path
+            { LL_OPAQUE(); load_rows(2, lane); InvRange<T, 31, 24>::run(a, invd, rr); } sync_point(24);
+            { LL_OPAQUE(); InvRange<T, 23, 16>::run(a, invd, rr); } sync_point(25);
+            { LL_OPAQUE(); InvRange<T, 15, 8>::run(a, invd, rr); } sync_point(26);
+            { LL_OPAQUE(); InvRange<T, 7, 0>::run(a, invd, rr); } sync_point(27);
+            { LL_OPAQUE(); after_inv(0, rr, lane, nq, c0q); } sync_point(28);
 #undef LL_OPAQUE
             LL_BAR();                                             // X1: Zimg complete
             LL_BAR();                                             // X2
@@ -333,22 +354,43 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
 #endif
         // =========================================================== HELPERS =========================================================
         T sacc = 0;                                               // wave 4: (L[j, 0:j] u)_lane
+#ifdef PACOH_LL_STAMPS
+        long long sh_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sh_t = wall_clock64();
+#define HST(k) do { const long long t_ = wall_clock64(); sh_[k] += t_ - sh_t; sh_t = t_; } while (0)
+#else
+#define HST(k) do {} while (0)
+#endif
         for (int j = 0; j < ncol; ++j) {
             const ColCfg cf = col_cfg<T>(j, n, S0, S1);
             const int c0 = cf.c0;
             const int ppr_sh = cf.RB == 128 ? 3 : 4;              // log2(pieces per row)
-            auto issue = [&](int s, unsigned char* buf) __attribute__((always_inline)) {         // LDS-DMA of slab s: rows c0.., columns s KS .. + KS
-                const int ni = (cf.mrows << ppr_sh) >> 6;
-                const int k0 = s * cf.KS;
-                for (int v = hidx; v < ni; v += 3) {
-                    const int e = v * 64 + lane;
-                    const int i = e >> ppr_sh, pp = e & ((1 << ppr_sh) - 1);
-                    const int sig = cf.RB == 128 ? ((i >> 1) & 7) : (i & 15);
-                    const int ic = i < cf.m ? i : cf.m - 1;
-                    const unsigned char* src = reinterpret_cast<const unsigned char*>(Ab + (size_t)(c0 + ic) * n + k0) + ((pp ^ sig) << 4);
-                    glds16(src, buf + v * 1024);
+            // LDS-DMA of slab s: rows c0.., columns s KS .. + KS.  Instruction v fills rows v * rpi .. + rpi (rpi = 8 at 128-byte rows, 4 at
+            // 256).  Its per-lane source address = a wave-uniform base (row block, slab column) + a lane offset that depends on v only
+            // through the low bits of v in the XOR swizzle: one v_xor and a 64-bit add per instruction (the general index arithmetic
+            // cost 1 us per slab and helper -- more than the bulk waves' MFMA work per slab from column 3 on).
+            // The helpers split the instructions 1 : 2 : 2 -- helper 0 also takes the forward solve's dot products.
+            const int rpi = 64 >> ppr_sh;
+            const int lrow = lane >> ppr_sh, lpp = lane & ((1 << ppr_sh) - 1);
+            const int lsig = cf.RB == 128 ? (lrow >> 1) : lrow;
+            const unsigned voff0 = (unsigned)lrow * (unsigned)n * ES + (unsigned)((lpp ^ lsig) << 4);
+            const int ni_all = (cf.mrows << ppr_sh) >> 6;
+            const bool ragged = (cf.m & (rpi - 1)) != 0;          // last instruction reaches beyond the matrix: clamp its rows
+            auto mine = [&](int v) __attribute__((always_inline)) -> bool { const int q5 = v % 5; return hidx == 0 ? q5 == 0 : (hidx == 1 ? (q5 == 1 || q5 == 2) : q5 >= 3); };
+            auto issue_cfg = [&](int s, unsigned char* buf, int cc0, int KS, int ni, int mm, bool rag, unsigned vo0, int rb) __attribute__((always_inline)) {
+                const unsigned char* const colb = reinterpret_cast<const unsigned char*>(Ab + (size_t)cc0 * n + (size_t)s * KS);
+                const int vmask = rb == 128 ? 1 : 3;
+                const int rp = rb == 128 ? 8 : 4;
+                for (int v = 0; v < ni; ++v) {
+                    if (!mine(v)) continue;
+                    unsigned vo = vo0 ^ (unsigned)((v & vmask) << 6);
+                    if (rag && v == ni - 1) {                     // rows beyond the matrix read the last row (never stored)
+                        const int i = v * rp + (rb == 128 ? (lane >> 3) : (lane >> 4));
+                        if (i >= mm) vo -= (unsigned)(i - (mm - 1)) * (unsigned)n * ES;
+                    }
+                    glds16(colb + (size_t)v * rp * n * ES + vo, buf + v * 1024);
                 }
             };
+            auto issue = [&](int s, unsigned char* buf) __attribute__((always_inline)) { issue_cfg(s, buf, c0, cf.KS, ni_all, cf.m, ragged, voff0, cf.RB); };
             auto dot = [&](int s, const unsigned char* buf) __attribute__((always_inline)) {     // wave 4: sacc += slab row `lane` . u[k0 ..]
                 if (hidx != 0) return;
                 const int sig = cf.RB == 128 ? ((lane >> 1) & 7) : (lane & 15);
@@ -363,14 +405,32 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
             };
             sacc = 0;
             LL_BAR();                                             // P0
-            if (cf.ns > 0 && j < 2) issue(0, slab0);              // (columns >= 2: issued behind the previous column's X1)
+            // ring of cf.nb slab buffers, prefetch distance D = nb - 1.  The helpers' barrier inside the loop is a RAW s_barrier behind a
+            // COUNTED vmcnt: __syncthreads() would drain every DMA in flight, i.e. wait out the fetch latency of the slab issued a moment
+            // ago in every iteration (cdna_hip_programming.md, "Pipelining across barriers") -- at the thin late columns an iteration's
+            // MFMA work is shorter than that latency
+            const int D = cf.nb > 1 ? cf.nb - 1 : 0;
+            int per = 0;                                          // this helper's DMA instructions per slab
+            for (int v = 0; v < ni_all; ++v) per += mine(v) ? 1 : 0;
+            for (int s = (j < 2 ? 0 : 1); s < D && s < cf.ns; ++s) issue(s, slab0 + s * cf.bsz);   // (slab 0 of columns >= 2: behind the previous X1)
+            if (D == 0 && cf.ns > 0 && j < 2) issue(0, slab0);
             LL_BAR();                                             // P1
             for (int s = 0; s < cf.ns; ++s) {
-                unsigned char* cur = (cf.dbl && (s & 1)) ? slab1 : slab0;
-                if (cf.dbl) {
-                    if (s + 1 < cf.ns) issue(s + 1, (s & 1) ? slab0 : slab1);
+                unsigned char* cur = slab0 + (s % cf.nb) * cf.bsz;
+                if (cf.nb > 1) {
+                    HST(0);
+                    if (s + D < cf.ns) issue(s + D, slab0 + ((s + D) % cf.nb) * cf.bsz);
+                    HST(1);
                     dot(s, cur);
-                    LL_BAR();
+                    HST(2);
+                    int keep = cf.ns - 2 - s;                     // slabs s + 2 .. s + D may stay in flight across the barrier
+                    keep = keep > D - 1 ? D - 1 : keep;
+                    wait_vmcnt(keep > 0 ? keep * per : 0);
+                    HST(3);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    HST(4);
                 } else {
                     dot(s, cur);
                     LL_BAR();
@@ -381,13 +441,11 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
             LL_BAR();                                             // X1
             if (j >= 1 && j + 1 < ncol) {                         // slab 0 of column j + 1 (slab0 is free from here on; its rows: a subset)
                 const ColCfg cn = col_cfg<T>(j + 1, n, S0, S1);
-                const int sh = cn.RB == 128 ? 3 : 4, ni = (cn.mrows << sh) >> 6;
-                for (int v = hidx; v < ni; v += 3) {
-                    const int e = v * 64 + lane;
-                    const int i = e >> sh, pp = e & ((1 << sh) - 1);
-                    const int sig = cn.RB == 128 ? ((i >> 1) & 7) : (i & 15);
-                    const int ic = i < cn.m ? i : cn.m - 1;
-                    glds16(reinterpret_cast<const unsigned char*>(Ab + (size_t)(cn.c0 + ic) * n) + ((pp ^ sig) << 4), slab0 + v * 1024);
+                if (cn.ns > 0) {
+                    const int sh = cn.RB == 128 ? 3 : 4, rp = 64 >> sh;
+                    const int lr = lane >> sh, lp = lane & ((1 << sh) - 1), ls_ = cn.RB == 128 ? (lr >> 1) : lr;
+                    issue_cfg(0, slab0, cn.c0, cn.KS, (cn.mrows << sh) >> 6, cn.m, (cn.m & (rp - 1)) != 0,
+                              (unsigned)lr * (unsigned)n * ES + (unsigned)((lp ^ ls_) << 4), cn.RB);
                 }
             }
             // Only what must leave Dimg before the look-ahead owners overwrite it (behind X2) happens in front of X2 -- the priority
@@ -439,6 +497,16 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                         if (row < n) Ab[(size_t)row * n + c0 + 16 * b + Mf<T>::row(g, q)] = -lp[q * 64];
                 }
             }
+            if (hidx == 0 && cf.ns == 0 && c0 > 0) {              // no slabs in this column: L[j, 0:j] u straight from the rows in global memory
+                const int row = c0 + lane;
+                const T* lp = Ab + (size_t)(row < n ? row : n - 1) * n;
+                T s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                for (int k = 0; k < c0; k += 4) {
+                    s0 = fma(lp[k], uvec[k], s0); s1 = fma(lp[k + 1], uvec[k + 1], s1);
+                    s2 = fma(lp[k + 2], uvec[k + 2], s2); s3 = fma(lp[k + 3], uvec[k + 3], s3);
+                }
+                sacc = (s0 + s1) + (s2 + s3);
+            }
             if (hidx == 0) {                                      // u_j = Z_jj (r_j - L[j, 0:j] u)
                 const int row = c0 + lane;
                 const T rhs = row < n ? resid[(size_t)blockIdx.x * n + row] - sacc : T(0);
@@ -469,6 +537,12 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                 }
             }
         }
+#ifdef PACOH_LL_STAMPS
+        HST(0);
+        if (lane == 0 && blockIdx.x == 0)
+            printf("helper %d (us): outside slab loop %.1f | DMA issue %.1f | dot %.1f | vmcnt wait %.1f | barrier wait %.1f\n", hidx, sh_[0] * 0.01, sh_[1] * 0.01, sh_[2] * 0.01, sh_[3] * 0.01, sh_[4] * 0.01);
+#endif
+#undef HST
 #ifdef LL_X_BULK
     } else if (false) {
 #else
@@ -501,43 +575,71 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
             if (do_la) {
                 const int row = c0 + 16 * laib + r;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) la[q] = a_padded(row, c0 + 16 * lacb + Mf<T>::row(g, q));
+                for (int q = 0; q < 4; ++q) {                   // (clamped, not padded: the padding is applied when the block is handed on)
+                    const int col = c0 + 16 * lacb + Mf<T>::row(g, q);
+                    la[q] = Ab[(size_t)(row < n ? row : n - 1) * n + (col < n ? col : n - 1)];
+                }
             }
-            // P += (top rows) (own rows)^T over one slab
-            auto slab_mma = [&](const unsigned char* buf) __attribute__((always_inline)) {
+            // accumulators -= (top rows) (own rows)^T over one slab.  The wave's shape (second row block? look-ahead block?) is a pair of
+            // compile-time flags chosen once per slab: as wave-uniform branches inside the k loop they cut every step's ds_read / MFMA
+            // stream into three basic blocks, and the waves with a look-ahead block ran 30 % longer for 12 % more MFMAs
+            auto slab_body = [&](auto v1c, auto lac, const unsigned char* buf) __attribute__((always_inline)) {
+                constexpr bool V1 = decltype(v1c)::value, LA = decltype(lac)::value;
                 const int RB = cf.RB;
                 const int sig = RB == 128 ? ((r >> 1) & 7) : r;
                 // piece index of element kk = 16 t + row(g, s) is const(t, s) | lane bits; see the file header
                 const int lbits = (ES == 8) ? ((g >> 1) ^ sig) : (g ^ sig);
                 const int lx = (lbits << 4) | (ES == 8 ? (g & 1) * 8 : 0);
-                const int rowb = r * RB;
+                const unsigned char* const pa = buf + r * RB;                     // top rows (A operands): + cb * 16 * RB
+                const unsigned char* const pb0 = pa + ib0 * 16 * RB;
+                const unsigned char* const pb1 = pa + ib1 * 16 * RB;
+                const unsigned char* const pla = pa + lacb * 16 * RB;
+                const unsigned char* const plb = pa + laib * 16 * RB;
                 const int nchunk = cf.KS >> 4;
                 for (int t = 0; t < nchunk; ++t) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         const int cst = (ES == 8) ? ((8 * t + 2 * s) << 4) : ((4 * t) << 4);
-                        const int imm = (ES == 8) ? 0 : 4 * s;
-                        const int xo = rowb + (lx ^ cst) + imm;
-                        if (v0) {
-                            T av[4];
+                        const int xo = (lx ^ cst) + ((ES == 8) ? 0 : 4 * s);
+                        T av[4];
 #pragma unroll
-                            for (int cb = 0; cb < 4; ++cb) av[cb] = -*reinterpret_cast<const T*>(buf + cb * 16 * RB + xo);
-                            const T b0 = *reinterpret_cast<const T*>(buf + ib0 * 16 * RB + xo);
+                        for (int cb = 0; cb < 4; ++cb) av[cb] = -*reinterpret_cast<const T*>(pa + cb * 16 * RB + xo);
+                        const T b0 = *reinterpret_cast<const T*>(pb0 + xo);
+                        T b1 = 0, aa = 0, bb = 0;
+                        if constexpr (V1) b1 = *reinterpret_cast<const T*>(pb1 + xo);
+                        if constexpr (LA) { aa = -*reinterpret_cast<const T*>(pla + xo); bb = *reinterpret_cast<const T*>(plb + xo); }
 #pragma unroll
-                            for (int cb = 0; cb < 4; ++cb) acc0[cb] = Mf<T>::mma(av[cb], b0, acc0[cb]);
-                            if (v1) {
-                                const T b1 = *reinterpret_cast<const T*>(buf + ib1 * 16 * RB + xo);
+                        for (int cb = 0; cb < 4; ++cb) acc0[cb] = Mf<T>::mma(av[cb], b0, acc0[cb]);
+                        if constexpr (V1) {
 #pragma unroll
-                                for (int cb = 0; cb < 4; ++cb) acc1[cb] = Mf<T>::mma(av[cb], b1, acc1[cb]);
-                            }
+                            for (int cb = 0; cb < 4; ++cb) acc1[cb] = Mf<T>::mma(av[cb], b1, acc1[cb]);
                         }
-                        if (do_la) {
-                            const T aa = -*reinterpret_cast<const T*>(buf + lacb * 16 * RB + xo);
-                            const T bb = *reinterpret_cast<const T*>(buf + laib * 16 * RB + xo);
-                            la = Mf<T>::mma(aa, bb, la);
-                        }
+                        if constexpr (LA) la = Mf<T>::mma(aa, bb, la);
                     }
                 }
+            };
+            auto slab_la_only = [&](const unsigned char* buf) __attribute__((always_inline)) {      // (a wave without row blocks: thin columns)
+                const int RB = cf.RB;
+                const int sig = RB == 128 ? ((r >> 1) & 7) : r;
+                const int lbits = (ES == 8) ? ((g >> 1) ^ sig) : (g ^ sig);
+                const int lx = (lbits << 4) | (ES == 8 ? (g & 1) * 8 : 0);
+                const unsigned char* const pla = buf + (lacb * 16 + r) * RB;
+                const unsigned char* const plb = buf + (laib * 16 + r) * RB;
+                const int nchunk = cf.KS >> 4;
+                for (int t = 0; t < nchunk; ++t) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int cst = (ES == 8) ? ((8 * t + 2 * s) << 4) : ((4 * t) << 4);
+                        const int xo = (lx ^ cst) + ((ES == 8) ? 0 : 4 * s);
+                        la = Mf<T>::mma(-*reinterpret_cast<const T*>(pla + xo), *reinterpret_cast<const T*>(plb + xo), la);
+                    }
+                }
+            };
+            auto slab_mma = [&](const unsigned char* buf) __attribute__((always_inline)) {
+                if (v0) {
+                    if (v1) { if (do_la) slab_body(std::true_type{}, std::true_type{}, buf); else slab_body(std::true_type{}, std::false_type{}, buf); }
+                    else { if (do_la) slab_body(std::false_type{}, std::true_type{}, buf); else slab_body(std::false_type{}, std::false_type{}, buf); }
+                } else if (do_la) slab_la_only(buf);
             };
             BST(5);
             LL_BAR();                                             // P0
@@ -545,10 +647,10 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
             LL_BAR();                                             // P1
             BST(6);
             for (int s = 0; s < cf.ns; ++s) {
-                slab_mma((cf.dbl && (s & 1)) ? slab1 : slab0);
+                slab_mma(slab0 + (s % cf.nb) * cf.bsz);
                 BST(1);
                 LL_BAR();
-                if (!cf.dbl) LL_BAR();
+                if (cf.nb == 1) LL_BAR();
                 BST(2);
             }
             BST(3);
