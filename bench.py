@@ -117,6 +117,39 @@ def pmc_traffic(substr):
     return None
 
 
+def assemble_line(metric, value, world, steps, warmup, ms_per_step, scaling, dtype, backend, world_size_seen, leg, legs, host_ms,
+                  step_mode, config, roofline, kernel_rooflines, step_flops, gram, pp, others, cpu):
+    """the ONE JSON line of the driver's contract (tests/test_host_logic.py asserts its shape without a GPU).  At N > 1 on the
+    headline configuration `legs` holds both scaling modes -- {'weak': {...}, 'strong': {...}}, each with ms_per_step, value,
+    exchange, world_size_seen, all_reduce_us -- and the top-level value / ms_per_step are those of the `scaling` leg"""
+    kernel_sum, prof_ms = pp['kernel_sum'], pp['ms_per_step']
+    return {
+        'metric': metric,
+        'value': round(value, 1), 'unit': 'evals/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': scaling,
+        'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
+        'backend': backend, 'world_size_seen': world_size_seen,
+        'exchange': leg.get('exchange'), 'all_reduce_us': leg.get('all_reduce_us'), 'legs': legs,
+        'host_ms_per_step': round(host_ms, 4), 'step_mode': step_mode,
+        'config': config,
+        'roofline': roofline, 'kernel_rooflines': kernel_rooflines,
+        'step_algorithmic_tflops': round(step_flops / (ms_per_step * 1e-3) / 1e12, 3),
+        'gram_roofline': gram,
+        # per-kernel HIP-event times come from a SEPARATE pass that issues the same launch sequence eagerly (events cannot be
+        # read out of a graph replay); that pass's own wall time per step is printed next to them: kernel_sum <= profile pass.
+        # kernel_ms_per_step_events_raw: the intervals as measured; kernel_ms_per_step: less the event pair's own overhead
+        # (schema 2, round 3 on: round-2 lines carry the raw values under kernel_ms_per_step)
+        'schema': 2,
+        'kernel_ms_per_step': pp['kernel_ms'],
+        'kernel_ms_per_step_events_raw': pp['kernel_ms_raw'], 'event_overhead_us': round(pp['event_overhead_ms'] * 1e3, 2),
+        'kernel_sum_ms_per_step': round(kernel_sum, 4),
+        'profile_pass_ms_per_step': round(prof_ms, 4),
+        'launch_gaps_ms_per_step': round(prof_ms - kernel_sum, 4),
+        'other_configs': others,
+        'cpu_baseline': cpu,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -157,55 +190,93 @@ def main():
     import meta_learning_pacoh_amd as M
     from meta_learning_pacoh_amd import _lib as L
 
-    wl = WORKLOADS[args.config](world, args.scaling, M, L)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # (enough untimed steps for the learners' first look at graph replay vs plain launches -- engine.StepMode -- and, in the chunks
-    #  below, their second: neither decision falls into the timed region)
-    wl['run'](max(40, args.warmup))
-    barrier()
-    # A fresh box needs a second or two of the real launch path before it issues steps at its steady rate (first process after boot:
-    # hipGraphLaunch measured at 0.18 ms per step against 0.03 ms a minute later, enough to starve a 0.5 ms step).  More untimed steps,
-    # in chunks, until two consecutive chunks take the same time (or 5 s have passed); every rank runs the same number of chunks.
-    prev, t_warm = None, time.perf_counter()
-    for _ in range(40):
-        t_c = time.perf_counter()
-        wl['run'](128)                                    # (16 + 112 steps: engine.first_chunk; the second look needs a chunk of >= 60)
+    def exchange_name():
+        if world == 1:
+            return None
+        from meta_learning_pacoh_amd import parallel
+        comm = parallel._direct_comm()
+        return ('pacoh_allreduce_sum (RCCL) on the compute stream, captured in the step graph' if comm is not None
+                else 'torch.distributed.all_reduce between two graphs per step')
+
+    def timed_leg(scaling, primary):
+        """build the workload, warm it up, time EXACTLY args.steps steps between barrier + synchronize, MAX over ranks"""
+        wl = WORKLOADS[args.config](world, scaling, M, L)
+        # (enough untimed steps for the learners' first look at graph replay vs plain launches -- engine.StepMode -- and, in the
+        #  chunks below, their second: neither decision falls into the timed region)
+        wl['run'](max(40, args.warmup))
         barrier()
-        cur = time.perf_counter() - t_c
-        stable = prev is not None and abs(cur - prev) <= 0.03 * prev and time.perf_counter() - t_warm >= 1.0
-        flag = torch.tensor([1.0 if (stable or time.perf_counter() - t_warm > 5.0) else 0.0], device='cuda')
+        # A fresh box needs a second or two of the real launch path before it issues steps at its steady rate (first process after
+        # boot: hipGraphLaunch measured at 0.18 ms per step against 0.03 ms a minute later, enough to starve a 0.5 ms step).  More
+        # untimed steps, in chunks, until two consecutive chunks take the same time (or 5 s have passed); every rank runs the same
+        # number of chunks.
+        prev, t_warm = None, time.perf_counter()
+        for _ in range(40):
+            t_c = time.perf_counter()
+            wl['run'](128)                                # (16 + 112 steps: engine.first_chunk; the second look needs a chunk of >= 60)
+            barrier()
+            cur = time.perf_counter() - t_c
+            stable = prev is not None and abs(cur - prev) <= 0.03 * prev and time.perf_counter() - t_warm >= 1.0
+            flag = torch.tensor([1.0 if (stable or time.perf_counter() - t_warm > 5.0) else 0.0], device='cuda')
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) > 0:
+                break
+            prev = cur
+        t0 = time.perf_counter()
+        wl['run'](args.steps)
+        t_issued = time.perf_counter()                   # the host has issued every step (nothing synchronises inside)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        host_ms = (t_issued - t0) / args.steps * 1e3
         if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if float(flag.item()) > 0:
-            break
-        prev = cur
-    t0 = time.perf_counter()
-    wl['run'](args.steps)
-    t_issued = time.perf_counter()                       # the host has issued every step (nothing synchronises inside)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    host_ms = (t_issued - t0) / args.steps * 1e3
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    finite = wl['finite']()
+            tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        leg = {'scaling': scaling, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+               'value': round(wl['evals_per_step'] * args.steps / elapsed, 1), 'unit': 'evals/s',
+               'evals_per_step': wl['evals_per_step'], 'host_ms_per_step': round(host_ms, 4), 'finite': wl['finite'](),
+               'exchange': exchange_name(), 'world_size_seen': (dist.get_world_size() if world > 1 else 1),
+               'step_mode': wl.get('mode', lambda: None)(), 'tasks_total': wl.get('extra', {}).get('tasks_total')}
+        return leg, wl, elapsed
+
+    leg, wl, elapsed = timed_leg(args.scaling, True)
+    finite = leg['finite']
     ms_per_step = elapsed / args.steps * 1e3
+    host_ms = leg['host_ms_per_step']
     evals_per_step, metric, dtype, describe, extra = wl['evals_per_step'], wl.get('metric'), wl['dtype'], wl['describe'], wl.get('extra', {})
-    step_mode = wl.get('mode', lambda: None)()
-    from meta_learning_pacoh_amd import parallel
-    comm = parallel._direct_comm() if world > 1 else None
-    exchange = None if world == 1 else ('pacoh_allreduce_sum (RCCL) on the compute stream, captured in the step graph' if comm is not None
-                                        else 'torch.distributed.all_reduce between two graphs per step')
+    step_mode = leg['step_mode']
+    exchange = leg['exchange']
 
     pp = profile_pass(wl, L, 50)                         # (its own step count: --steps 20 would make the per-kernel averages noisy)
     kernel_ms, kernel_sum, prof_ms = pp['kernel_ms'], pp['kernel_sum'], pp['ms_per_step']
     roofline, kernel_rooflines, step_flops = rooflines(wl, pp)
+
+    def all_reduce_us(pp_):
+        """HIP-event time of the step's one exchange in the eager per-kernel pass (the in-graph collective cannot be timed from
+        outside the graph): RCCL's kernel on the compute stream, or torch.distributed's call"""
+        for key in ('allreduce_sum', 'allreduce_torch'):
+            if key in pp_['kernel_ms_raw']:
+                return round(pp_['kernel_ms_raw'][key] * 1e3, 2)
+        return None
+    leg['all_reduce_us'] = all_reduce_us(pp) if world > 1 else None
+
+    # N > 1, headline configuration: BOTH scaling modes from the one invocation the driver makes -- weak (1024 tasks per GPU) and
+    # strong (1024 tasks in total: cfg #3 as BASELINE.json words it).  The line's own value / ms_per_step are the --scaling leg's.
+    legs = None
+    if world > 1 and args.config == 3:
+        legs = {args.scaling: leg}
+        other = 'strong' if args.scaling == 'weak' else 'weak'
+        del wl
+        torch.cuda.empty_cache()
+        leg2, wl2, _ = timed_leg(other, False)
+        leg2['all_reduce_us'] = all_reduce_us(profile_pass(wl2, L, 20))
+        legs[other] = leg2
+        wl = wl2
 
     gram = gram_leg(L) if (rank == 0 and args.config == 3) else None
 
@@ -226,29 +297,14 @@ def main():
     if rank == 0:
         cpu = None if (args.no_cpu_baseline or world > 1 or args.config != 3) else cpu_baseline()
         value = evals_per_step * args.steps / elapsed
-        out = {
-            'metric': 'task-GP LML+grad evals/sec (n_ctx=64, d=4, 20 particles)' if args.config == 3 else metric,
-            'value': round(value, 1), 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': args.scaling,
-            'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
-            'backend': (backend if world > 1 else None), 'world_size_seen': (dist.get_world_size() if world > 1 else 1),
-            'exchange': exchange,
-            'host_ms_per_step': round(host_ms, 4), 'step_mode': step_mode,
-            'config': dict({'workload': describe, 'evals_per_step': evals_per_step,
-                            'parallelism': 'task-shard x%d' % world, 'finite': finite}, **extra),
-            'roofline': roofline, 'kernel_rooflines': kernel_rooflines,
-            'step_algorithmic_tflops': round(step_flops / (ms_per_step * 1e-3) / 1e12, 3),
-            'gram_roofline': gram,
-            # per-kernel HIP-event times come from a SEPARATE pass that issues the same launch sequence eagerly (events cannot be
-            # read out of a graph replay); that pass's own wall time per step is printed next to them: kernel_sum <= profile pass
-            'kernel_ms_per_step': kernel_ms,
-            'kernel_ms_per_step_events_raw': pp['kernel_ms_raw'], 'event_overhead_us': round(pp['event_overhead_ms'] * 1e3, 2),
-            'kernel_sum_ms_per_step': round(kernel_sum, 4),
-            'profile_pass_ms_per_step': round(prof_ms, 4),
-            'launch_gaps_ms_per_step': round(prof_ms - kernel_sum, 4),
-            'other_configs': others,
-            'cpu_baseline': cpu,
-        }
+        out = assemble_line(
+            metric='task-GP LML+grad evals/sec (n_ctx=64, d=4, 20 particles)' if args.config == 3 else metric, value=value,
+            world=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, scaling=args.scaling, dtype=dtype,
+            backend=(backend if world > 1 else None), world_size_seen=(dist.get_world_size() if world > 1 else 1), leg=leg, legs=legs,
+            host_ms=host_ms, step_mode=step_mode,
+            config=dict({'workload': describe, 'evals_per_step': evals_per_step, 'parallelism': 'task-shard x%d' % world,
+                         'finite': finite}, **extra),
+            roofline=roofline, kernel_rooflines=kernel_rooflines, step_flops=step_flops, gram=gram, pp=pp, others=others, cpu=cpu)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

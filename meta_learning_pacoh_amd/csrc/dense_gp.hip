@@ -21,6 +21,8 @@ namespace pacoh {
 int dense_chol_launch(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
                       int dtype, int attempt, hipStream_t stream, int u_only = 0);                  // dense.hip
 bool dense_chol_saves_inverse(int n, int dtype);                                                     // dense.hip
+int gram_rbf_for_chol(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
+                      int dtype, hipStream_t s, int lower);                                          // gram.hip
 
 namespace {
 
@@ -804,7 +806,9 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
     const bool u_only = bwd && dense_chol_saves_inverse(n, dtype);          // alpha comes from Z afterwards (dense_alpha_kernel)
     for (int attempt = 0; attempt < 4; ++attempt) {
         if (attempt == 0) {
-            int rc = pacoh_gram_rbf_ard(z, z_div, z, z_div, ls, os, noise, 1, A, B, P, n, n, f_arg, dtype, s);
+            // (RBF family: the tiles above the diagonal are skipped -- nothing downstream reads A's upper triangle)
+            int rc = kind == PACOH_KERNEL_RBF ? gram_rbf_for_chol(z, z_div, ls, os, noise, A, B, P, n, f, dtype, s, 1)
+                                              : pacoh_gram_rbf_ard(z, z_div, z, z_div, ls, os, noise, 1, A, B, P, n, n, f_arg, dtype, s);
             if (rc) return rc;
         } else {
             double jit = jitter_base;
@@ -879,7 +883,8 @@ int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int m
     const double jitter_base = dtype == PACOH_F32 ? 1e-6 : 1e-8;
     for (int attempt = 0; attempt < 4; ++attempt) {
         if (attempt == 0) {
-            int rc = pacoh_gram_rbf_ard(z_ctx, z_div, z_ctx, z_div, ls, os, noise, 1, A, B, P, n, n, f_arg, dtype, s);
+            int rc = kind == PACOH_KERNEL_RBF ? gram_rbf_for_chol(z_ctx, z_div, ls, os, noise, A, B, P, n, f, dtype, s, 1)
+                                              : pacoh_gram_rbf_ard(z_ctx, z_div, z_ctx, z_div, ls, os, noise, 1, A, B, P, n, n, f_arg, dtype, s);
             if (rc) return rc;
         } else {
             double jit = jitter_base;

@@ -36,7 +36,8 @@ namespace {
 constexpr int LLW = 64;              // block-column width
 constexpr int LL_NT = 1024;
 constexpr int LL_NBULK = 12;
-constexpr int LL_NQ = 28;            // quanta of the chain per block column
+constexpr int LL_NQ = 29;            // quanta of the chain per block column
+constexpr int LL_QCAP = 12;          // ... of which in front of P0 (none of them touches Zimg; about what the bulk waves' pass 1 takes)            // quanta of the chain per block column
 
 __host__ __device__ constexpr int tri_idx(int a, int b) { return a * (a + 1) / 2 + b; }
 
@@ -232,8 +233,8 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
             auto after_elim = [&](int h, int lane, int n, int c0) __attribute__((always_inline)) {
                 const int row = h ? 32 + (lane & 31) : lane;
                 const int ibv = row >> 4;
-                const bool is_l10 = h == 0 && lane >= 32;
-                unsigned char* const dst = (is_l10 ? Zimg : Dimg) + tri_idx(ibv, 0) * BLK;
+                const bool is_l10 = h == 0 && lane >= 32;         // (-L10 goes into the Dimg slots D10 came from: Zimg still belongs to the
+                unsigned char* const dst = Dimg + tri_idx(ibv, 0) * BLK;      //  previous column's panel solve when this runs in front of P0)
                 if (h == 0 || lane < 32) {
 #pragma unroll
                     for (int cc = 0; cc < DNB; ++cc) {
@@ -264,8 +265,8 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                         for (int av = 0; av < 2; ++av)
 #pragma unroll
                             for (int s = 0; s < 4; ++s)
-                                sacc = Mf<T>::mma(*reinterpret_cast<const T*>(Zimg + tri_idx(2 + cbr, av) * BLK + (s * 64 + lane) * ES),
-                                                  *reinterpret_cast<const T*>(Zimg + tri_idx(2 + ibr, av) * BLK + (s * 64 + lane) * ES), sacc);
+                                sacc = Mf<T>::mma(*reinterpret_cast<const T*>(Dimg + tri_idx(2 + cbr, av) * BLK + (s * 64 + lane) * ES),
+                                                  *reinterpret_cast<const T*>(Dimg + tri_idx(2 + ibr, av) * BLK + (s * 64 + lane) * ES), sacc);
                         T* dp = reinterpret_cast<T*>(Dimg + tri_idx(2 + ibr, 2 + cbr) * BLK);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) dp[q * 64 + lane] -= sacc[q];
@@ -274,8 +275,8 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
             };
             // The factorisation is straight-line code (one definition chain for the 32 row registers: as a switch inside a loop
             // every quantum boundary was a 27-way merge of all of them and the allocator spilled); after each quantum the barriers
-            // of the slots that end there are executed.  Slot 0 ends at P0 (quanta 0..7: Zimg still belongs to the previous
-            // column's panel solve), slot 1 at P1, slot 2 + s at slab s's barrier(s).
+            // of the slots that end there are executed.  Slot 0 ends at P0 (quanta 0..11: Zimg still belongs to the previous
+            // column's panel solve, and none of them touches it), slot 1 at P1, slot 2 + s at slab s's barrier(s).
             const int nslots = cf.ns + 2;
             int slot = 0;
 #ifdef PACOH_LL_STAMPS
@@ -288,7 +289,7 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                 while (slot < nslots) {
                     // the chain is the kernel's critical path: everything Zimg's hand-over allows goes in front of P0 (the bulk waves
                     // are in the previous column's panel solve meanwhile), the rest is spread over P1 and the slabs
-                    const int qe = slot <= 1 ? 8 : 8 + (slot - 1) * (LL_NQ - 8) / (nslots - 2);
+                    const int qe = slot <= 1 ? LL_QCAP : LL_QCAP + (slot - 1) * (LL_NQ - LL_QCAP) / (nslots - 2);
                     if (qe > qdone) break;
                     LL_BAR();
                     if (slot >= 2 && cf.nb == 1) LL_BAR();
@@ -303,8 +304,8 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
 #define LL_OPAQUE() int lane = threadIdx.x & 63; asm volatile("" : "+v"(lane)); const int rr = lane & 31; int nq = n, c0q = c0; \
             asm volatile("" : "+s"(nq), "+s"(c0q)); (void)rr; (void)nq; (void)c0q
             sync_point(0);
-            // quanta 0..7: elimination of the panel, 8: L00 / -L10 images, 9: update of D11, 10..17: elimination of D11,
-            // 18..21: its inverse, 22: images, 23..27: inverse of L00 and images
+            // quanta 0..7: elimination of the panel, 8: L00 / -L10 images (in Dimg), 9: update of D11, 10..17: elimination of D11,
+            // 18: -L10 into Zimg, 19..22: inverse of L11, 23: images, 24..28: inverse of L00 and images
             { LL_OPAQUE(); load_rows(0, lane); ElimRange<T, 0, 4>::run(a, invd, bad, lane); } sync_point(1);
             { LL_OPAQUE(); ElimRange<T, 4, 8>::run(a, invd, bad, lane); } sync_point(2);
             { LL_OPAQUE(); ElimRange<T, 8, 12>::run(a, invd, bad, lane); } sync_point(3);
@@ -323,18 +324,28 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
             if (two) { LL_OPAQUE(); ElimRange<T, 20, 24>::run(a, invd + 32, bad, lane); } sync_point(16);
             if (two) { LL_OPAQUE(); ElimRange<T, 24, 28>::run(a, invd + 32, bad, lane); } sync_point(17);
             if (two) { LL_OPAQUE(); ElimRange<T, 28, 32>::run(a, invd + 32, bad, lane); } sync_point(18);
-            if (two) { LL_OPAQUE(); LL_LDSWAIT(); after_elim(1, lane, nq, c0q); InvRange<T, 31, 24>::run(a, invd + 32, rr); } sync_point(19);
-            if (two) { LL_OPAQUE(); InvRange<T, 23, 16>::run(a, invd + 32, rr); } sync_point(20);
-            if (two) { LL_OPAQUE(); InvRange<T, 15, 8>::run(a, invd + 32, rr); } sync_point(21);
-            if (two) { LL_OPAQUE(); InvRange<T, 7, 0>::run(a, invd + 32, rr); } sync_point(22);
-            if (two) { LL_OPAQUE(); after_inv(1, rr, lane, nq, c0q); } sync_point(23);
+            {   // the -L10 images move from Dimg into their Zimg operand slots (always behind P0: quantum 18 >= the slot-0 cap)
+                LL_OPAQUE();
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) {
+                    const int off = tri_idx(2 + (blk >> 1), blk & 1) * BLK;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<T*>(Zimg + off + (q * 64 + lane) * ES) = *reinterpret_cast<const T*>(Dimg + off + (q * 64 + lane) * ES);
+                }
+            } sync_point(19);
+            if (two) { LL_OPAQUE(); LL_LDSWAIT(); after_elim(1, lane, nq, c0q); InvRange<T, 31, 24>::run(a, invd + 32, rr); } sync_point(20);
+            if (two) { LL_OPAQUE(); InvRange<T, 23, 16>::run(a, invd + 32, rr); } sync_point(21);
+            if (two) { LL_OPAQUE(); InvRange<T, 15, 8>::run(a, invd + 32, rr); } sync_point(22);
+            if (two) { LL_OPAQUE(); InvRange<T, 7, 0>::run(a, invd + 32, rr); } sync_point(23);
+            if (two) { LL_OPAQUE(); after_inv(1, rr, lane, nq, c0q); } sync_point(24);
             // the inverse of L00 last: nothing on this wave's path needs it (L10 came out of the panel elimination), the bulk waves need
             // it at X1 -- and since the panel elimination this wave is no longer the kernel's critical path
-            { LL_OPAQUE(); load_rows(2, lane); InvRange<T, 31, 24>::run(a, invd, rr); } sync_point(24);
-            { LL_OPAQUE(); InvRange<T, 23, 16>::run(a, invd, rr); } sync_point(25);
-            { LL_OPAQUE(); InvRange<T, 15, 8>::run(a, invd, rr); } sync_point(26);
-            { LL_OPAQUE(); InvRange<T, 7, 0>::run(a, invd, rr); } sync_point(27);
-            { LL_OPAQUE(); after_inv(0, rr, lane, nq, c0q); } sync_point(28);
+            { LL_OPAQUE(); load_rows(2, lane); InvRange<T, 31, 24>::run(a, invd, rr); } sync_point(25);
+            { LL_OPAQUE(); InvRange<T, 23, 16>::run(a, invd, rr); } sync_point(26);
+            { LL_OPAQUE(); InvRange<T, 15, 8>::run(a, invd, rr); } sync_point(27);
+            { LL_OPAQUE(); InvRange<T, 7, 0>::run(a, invd, rr); } sync_point(28);
+            { LL_OPAQUE(); after_inv(0, rr, lane, nq, c0q); } sync_point(29);
 #undef LL_OPAQUE
             LL_BAR();                                             // X1: Zimg complete
             LL_BAR();                                             // X2
@@ -367,22 +378,21 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
             // LDS-DMA of slab s: rows c0.., columns s KS .. + KS.  Instruction v fills rows v * rpi .. + rpi (rpi = 8 at 128-byte rows, 4 at
             // 256).  Its per-lane source address = a wave-uniform base (row block, slab column) + a lane offset that depends on v only
             // through the low bits of v in the XOR swizzle: one v_xor and a 64-bit add per instruction (the general index arithmetic
-            // cost 1 us per slab and helper -- more than the bulk waves' MFMA work per slab from column 3 on).
-            // The helpers split the instructions 1 : 2 : 2 -- helper 0 also takes the forward solve's dot products.
+            // cost as much again as the instructions' own issue, 60-185 cycles each: MI355X_MICROARCH.md).  Dealing the instructions to
+            // all fifteen waves beside the chain was measured and lost: inside the MFMA loop an issue costs the bulk waves more than
+            // the helpers' waiting costs them (slab loop 245 -> 270 us).
             const int rpi = 64 >> ppr_sh;
             const int lrow = lane >> ppr_sh, lpp = lane & ((1 << ppr_sh) - 1);
             const int lsig = cf.RB == 128 ? (lrow >> 1) : lrow;
-            const unsigned voff0 = (unsigned)lrow * (unsigned)n * ES + (unsigned)((lpp ^ lsig) << 4);
+            const unsigned vrow0 = (unsigned)lrow * (unsigned)n * ES, vpc0 = (unsigned)((lpp ^ lsig) << 4);
             const int ni_all = (cf.mrows << ppr_sh) >> 6;
             const bool ragged = (cf.m & (rpi - 1)) != 0;          // last instruction reaches beyond the matrix: clamp its rows
-            auto mine = [&](int v) __attribute__((always_inline)) -> bool { const int q5 = v % 5; return hidx == 0 ? q5 == 0 : (hidx == 1 ? (q5 == 1 || q5 == 2) : q5 >= 3); };
-            auto issue_cfg = [&](int s, unsigned char* buf, int cc0, int KS, int ni, int mm, bool rag, unsigned vo0, int rb) __attribute__((always_inline)) {
+            auto issue_cfg = [&](int s, unsigned char* buf, int cc0, int KS, int ni, int mm, bool rag, unsigned vr0, unsigned vp0, int rb) __attribute__((always_inline)) {
                 const unsigned char* const colb = reinterpret_cast<const unsigned char*>(Ab + (size_t)cc0 * n + (size_t)s * KS);
                 const int vmask = rb == 128 ? 1 : 3;
                 const int rp = rb == 128 ? 8 : 4;
-                for (int v = 0; v < ni; ++v) {
-                    if (!mine(v)) continue;
-                    unsigned vo = vo0 ^ (unsigned)((v & vmask) << 6);
+                for (int v = hidx; v < ni; v += 3) {
+                    unsigned vo = vr0 + (vp0 ^ (unsigned)((v & vmask) << 6));
                     if (rag && v == ni - 1) {                     // rows beyond the matrix read the last row (never stored)
                         const int i = v * rp + (rb == 128 ? (lane >> 3) : (lane >> 4));
                         if (i >= mm) vo -= (unsigned)(i - (mm - 1)) * (unsigned)n * ES;
@@ -390,7 +400,7 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                     glds16(colb + (size_t)v * rp * n * ES + vo, buf + v * 1024);
                 }
             };
-            auto issue = [&](int s, unsigned char* buf) __attribute__((always_inline)) { issue_cfg(s, buf, c0, cf.KS, ni_all, cf.m, ragged, voff0, cf.RB); };
+            auto issue = [&](int s, unsigned char* buf) __attribute__((always_inline)) { issue_cfg(s, buf, c0, cf.KS, ni_all, cf.m, ragged, vrow0, vpc0, cf.RB); };
             auto dot = [&](int s, const unsigned char* buf) __attribute__((always_inline)) {     // wave 4: sacc += slab row `lane` . u[k0 ..]
                 if (hidx != 0) return;
                 const int sig = cf.RB == 128 ? ((lane >> 1) & 7) : (lane & 15);
@@ -410,8 +420,7 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
             // ago in every iteration (cdna_hip_programming.md, "Pipelining across barriers") -- at the thin late columns an iteration's
             // MFMA work is shorter than that latency
             const int D = cf.nb > 1 ? cf.nb - 1 : 0;
-            int per = 0;                                          // this helper's DMA instructions per slab
-            for (int v = 0; v < ni_all; ++v) per += mine(v) ? 1 : 0;
+            const int per = ni_all > hidx ? (ni_all - hidx + 2) / 3 : 0;        // this helper's DMA instructions per slab
             for (int s = (j < 2 ? 0 : 1); s < D && s < cf.ns; ++s) issue(s, slab0 + s * cf.bsz);   // (slab 0 of columns >= 2: behind the previous X1)
             if (D == 0 && cf.ns > 0 && j < 2) issue(0, slab0);
             LL_BAR();                                             // P1
@@ -445,7 +454,7 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
                     const int sh = cn.RB == 128 ? 3 : 4, rp = 64 >> sh;
                     const int lr = lane >> sh, lp = lane & ((1 << sh) - 1), ls_ = cn.RB == 128 ? (lr >> 1) : lr;
                     issue_cfg(0, slab0, cn.c0, cn.KS, (cn.mrows << sh) >> 6, cn.m, (cn.m & (rp - 1)) != 0,
-                              (unsigned)lr * (unsigned)n * ES + (unsigned)((lp ^ ls_) << 4), cn.RB);
+                              (unsigned)lr * (unsigned)n * ES, (unsigned)((lp ^ ls_) << 4), cn.RB);
                 }
             }
             // Only what must leave Dimg before the look-ahead owners overwrite it (behind X2) happens in front of X2 -- the priority

@@ -87,15 +87,31 @@ __global__ void __launch_bounds__(256) gram_kernel(const T* __restrict__ z1, int
                                                    const T* __restrict__ ls, const T* __restrict__ os,
                                                    const T* __restrict__ noise, int add_noise, T* __restrict__ K,
                                                    int P, int n, int m, int f, int tjq_shift, int tiles_i, int tiles_j,
-                                                   int total_units) {
+                                                   int total_units, int lower) {
     constexpr int VW = VecOf<T>::W;
+    // lower != 0 (square Grams feeding the Cholesky of the dense path, which reads the lower triangle only; G == 1): tiles that lie
+    // entirely above the diagonal are neither evaluated nor written -- 48 of 128 tiles at n = 512 in fp64 (16 x 128 tiles)
+    // The grid holds only the kept tiles (`lower` = their number per problem; the launch is dispatch-bound -- one 16 KB tile per
+    // workgroup -- so skipped workgroups that merely exit early bought nothing): unit index -> (problem, tile row, tile column).
+    int unit_remap = -1;
+    if (lower) {
+        const int TIl = (QPT * 256) >> tjq_shift, TJl = VW << tjq_shift;
+        int t = blockIdx.x % lower, ti = 0;
+        for (;; ++ti) {
+            int cnt = (ti * TIl + TIl - 1) / TJl + 1;
+            cnt = cnt > tiles_j ? tiles_j : cnt;
+            if (t < cnt) break;
+            t -= cnt;
+        }
+        unit_remap = ((blockIdx.x / lower) * tiles_i + ti) * tiles_j + t;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int TJ = VW << tjq_shift;                  // tile columns
     const int TI = (QPT * 256) >> tjq_shift;         // tile rows
     const int E1 = TI * FP, E = (TI + TJ) * FP;      // staged elements per unit: z1 rows, then z2 rows
     T* lds0 = reinterpret_cast<T*>(smem_raw);
     const bool mvec = (m % VW) == 0;
-    const int u0 = blockIdx.x * G;
+    const int u0 = lower ? unit_remap : blockIdx.x * G;
     // decompose the first unit once; the others follow by incrementing
     int tjs[G], tis[G], bs[G], ps[G];
     {
@@ -176,7 +192,7 @@ __global__ void __launch_bounds__(256) gram_kernel(const T* __restrict__ z1, int
 
 template <typename T>
 static int launch_gram(const void* z1, int z1_div, const void* z2, int z2_div, const void* ls, const void* os,
-                       const void* noise, int add_noise, void* K, int B, int P, int n, int m, int f, hipStream_t s) {
+                       const void* noise, int add_noise, void* K, int B, int P, int n, int m, int f, hipStream_t s, int lower = 0) {
     constexpr int VW = VecOf<T>::W;
     const int mq = (m + VW - 1) / VW;
     int tjq_shift = 0;
@@ -190,15 +206,21 @@ static int launch_gram(const void* z1, int z1_div, const void* z2, int z2_div, c
     const int R = (E + 255) / 256;                                    // staged elements per thread and unit: 1..65
     int G = R <= 4 ? 2 : 1;                                           // units per workgroup (measured: 2 best at n=64; 1, 4 within 10 %)
     while (G > 1 && units / G < 2048) G >>= 1;                        // keep >= 8 workgroups per CU
-    if (R > 4) G = 1;
+    if (R > 4 || lower) G = 1;
     const size_t lds = (size_t)G * E * sizeof(T);
-    const long blocks = (units + G - 1) / G;
+    long blocks = (units + G - 1) / G;
+    if (lower) {                                                      // `lower` becomes the number of kept tiles per problem
+        int kept = 0;
+        for (int ti = 0; ti < tiles_i; ++ti) { const int c = (ti * TI + TI - 1) / TJ + 1; kept += c > tiles_j ? tiles_j : c; }
+        lower = kept;
+        blocks = (long)B * kept;
+    }
     // every tile interior and every workgroup complete: the kernel variant without any bounds-checked code
-    const bool allfull = (n % TI) == 0 && (m % TJ) == 0 && f == FP && (units % G) == 0;
+    const bool allfull = (n % TI) == 0 && (m % TJ) == 0 && f == FP && (units % G) == 0;      // (G == 1 with `lower`)
 #define PACOH_GRAM_LAUNCH(fp, r, g) if (allfull) PACOH_GRAM_LAUNCH2(fp, r, g, true); else PACOH_GRAM_LAUNCH2(fp, r, g, false)
 #define PACOH_GRAM_LAUNCH2(fp, r, g, af) hipLaunchKernelGGL((gram_kernel<T, fp, r, g, af>), dim3((unsigned)blocks), dim3(256), lds, s, \
         (const T*)z1, z1_div, (const T*)z2, z2_div, (const T*)ls, (const T*)os, (const T*)noise, add_noise, (T*)K, P, n, m, f, \
-        tjq_shift, tiles_i, tiles_j, (int)units)
+        tjq_shift, tiles_i, tiles_j, (int)units, lower)
 #define PACOH_GRAM_RG(fp, r) do { if (G >= 2) { PACOH_GRAM_LAUNCH(fp, r, 2); } else { PACOH_GRAM_LAUNCH(fp, r, 1); } } while (0)
 #define PACOH_GRAM_CASE(fp) case fp: \
         if (R <= 1) PACOH_GRAM_RG(fp, 1); else if (R <= 2) PACOH_GRAM_RG(fp, 2); else if (R <= 4) PACOH_GRAM_RG(fp, 4); \
@@ -209,6 +231,14 @@ static int launch_gram(const void* z1, int z1_div, const void* z2, int z2_div, c
 #undef PACOH_GRAM_LAUNCH
 #undef PACOH_GRAM_LAUNCH2
     return launch_status();
+}
+
+// the dense path's own Gram call (dense_gp.hip): lower != 0 -> only the tiles that touch the lower triangle (A = os K + noise I is
+// about to be factorised in place, and every Cholesky kernel of the path reads the lower triangle only)
+int gram_rbf_for_chol(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
+                      int dtype, hipStream_t s, int lower) {
+    if (dtype == PACOH_F32) return launch_gram<float>(z, z_div, z, z_div, ls, os, noise, 1, K, B, P, n, n, f, s, lower);
+    return launch_gram<double>(z, z_div, z, z_div, ls, os, noise, 1, K, B, P, n, n, f, s, lower);
 }
 
 }  // namespace pacoh

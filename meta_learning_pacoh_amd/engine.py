@@ -217,11 +217,11 @@ class StepFeed:
             if callable(aux_rows):                       # aux_rows(j, out): writes step j's payload straight into the staging row
                 for j in range(k):
                     aux_rows(j, self._h_aux[q][j])
-            elif torch.is_tensor(aux_rows):
-                ha[:k] = aux_rows.numpy()
+            elif torch.is_tensor(aux_rows):              # (any device / dtype / requires_grad: what copy_ used to accept)
+                ha[:k] = aux_rows.detach().to('cpu', self._h_aux[q].dtype).numpy().reshape(ha[:k].shape)
             else:                                        # one tensor per step
                 for j, row in enumerate(aux_rows):
-                    ha[j] = row.numpy()
+                    ha[j] = row.detach().to('cpu', self._h_aux[q].dtype).numpy().reshape(ha[j].shape)
             ha[k:kk] = ha[k - 1]
             self.aux_all[:kk].copy_(self._h_aux[q][:kk], non_blocking=True)
         self.ctr.fill_(-1 if self.sc2 is not None else 0)      # (pipelined step: the first forward makes it 0 -- prologue())
@@ -469,6 +469,13 @@ class StepMode:
                 t = [min(pair) for pair in zip(*[[self._time(step, False, n), graph_time()] for _ in range(2)])]
                 self.timings = {'eager_ms': t[0] * 1e3, 'graph_ms': t[1] * 1e3, 'steps_each': n}
                 self.use_graph = not (t[0] < self.MARGIN * t[1])
+                # one decision for all ranks: with the collective captured in the step graph a rank that replays while a peer issues
+                # eagerly still matches call for call, but the run would no longer be reproducible per rank -- and with
+                # torch.distributed between two graphs the two modes must not mix at all.  Graph mode wins unless every rank prefers
+                # plain launches.
+                from . import parallel
+                if parallel.world()[1] > 1:
+                    self.use_graph = not parallel.agree_all(not self.use_graph)
                 self._looks += 1
                 done = cost
         graphed = True if self.use_graph is None else self.use_graph

@@ -66,6 +66,47 @@ def check_same_draws(idx_rows, sc_rows):
 _comm_serial = 0
 
 
+def agree_all(ok):
+    """the same verdict on every rank: MIN over ranks of `ok` through torch.distributed (a host-side tensor on gloo, a device tensor on
+    nccl).  Used wherever a per-rank decision would change which collectives a rank issues -- a rank must never issue (or replay) a
+    collective its peers do not"""
+    _, w = world()
+    if w == 1:
+        return bool(ok)
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() > 0)
+
+
+class _Watchdog:
+    """ends the process (exit code 13, no re-exec) if the block it guards does not finish: a collective that one rank never joins --
+    ncclCommInitRank, the self-test's all-reduce -- cannot be cancelled, and the launcher ends the job when a rank exits"""
+
+    def __init__(self, seconds, what):
+        import threading
+        rank, w = world()
+        self.active = w > 1
+
+        def gave_up():
+            import sys
+            sys.stderr.write('pacoh: %s did not finish within %d s on rank %d of %d -- rerun with PACOH_COMM=torch '
+                             '(torch.distributed carries the exchange between two graphs per step)\n' % (what, seconds, rank, w))
+            sys.stderr.flush()
+            os._exit(13)
+        self.timer = threading.Timer(seconds, gave_up)
+        self.timer.daemon = True
+
+    def __enter__(self):
+        if self.active:
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
 def _exchange_unique_id(rank, w):
     """rank 0's fresh RCCL communicator id on every rank: through the c10d key-value store (host side, no collective, no device
     traffic) when torch.distributed has one, else as a broadcast object"""
@@ -97,22 +138,21 @@ class RcclComm:
     def __init__(self, self_test=True):
         rank, w = world()
         self.rank, self.world_size = rank, w
-        self.handle = L.comm_init(_exchange_unique_id(rank, w), rank, w)
+        self.handle = None
         self.graph_ok = False
+        # (the watchdog starts BEFORE the id exchange and ncclCommInitRank: both block until every rank has joined)
+        with _Watchdog(self.SELF_TEST_TIMEOUT_S, 'creating the RCCL communicator'):
+            self.handle = L.comm_init(_exchange_unique_id(rank, w), rank, w)
         if self_test:
             self.graph_ok = self._self_test()
 
     def all_reduce_(self, buf):
         return L.allreduce_sum(buf, self.handle)
 
-    def _agree(self, ok, dev):
-        """the same verdict on every rank (MIN over ranks through torch.distributed): a rank must never replay a collective its
-        peers failed to capture -- it would wait for them forever"""
-        if self.world_size > 1:
-            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = bool(flag.item() > 0)
-        return ok
+    def _agree(self, ok, dev=None):
+        """the same verdict on every rank: a rank must never replay a collective its peers failed to capture -- it would wait for
+        them forever"""
+        return agree_all(ok)
 
     def _self_test(self):
         """eager all-reduce, then the same call captured in a hipGraph and replayed twice, on values whose sums are known.  Three
@@ -165,22 +205,8 @@ class RcclComm:
 
         # A collective that one rank never joins cannot be cancelled: if the test does not finish, say so and end the process (the
         # launcher then ends the job) instead of leaving a silent hang for the caller's own timeout to find
-        def gave_up():
-            import sys
-            sys.stderr.write('pacoh: the in-graph RCCL all-reduce self-test did not finish within %d s on rank %d of %d -- rerun with '
-                             'PACOH_COMM=torch (torch.distributed carries the exchange between two graphs per step)\n'
-                             % (self.SELF_TEST_TIMEOUT_S, rank, w))
-            sys.stderr.flush()
-            os._exit(13)
-        import threading
-        dog = threading.Timer(self.SELF_TEST_TIMEOUT_S, gave_up)
-        dog.daemon = True
-        if w > 1:
-            dog.start()
-        try:
+        with _Watchdog(self.SELF_TEST_TIMEOUT_S, 'the in-graph RCCL all-reduce self-test'):
             ok = phase(eager) and phase(capture) and phase(replay)
-        finally:
-            dog.cancel()
         del graph
         return ok
 
@@ -220,15 +246,28 @@ def _direct_comm():
     reaches it at the same point of the program (the learners call collective_in_graph() when they set up their step)"""
     global _direct
     if _direct is None and _want_direct():
+        comm, ok = None, True
         try:
-            _direct = RcclComm()
+            comm = RcclComm(self_test=False)
         except Exception as exc:
-            warnings.warn('pacoh: RCCL communicator could not be created (%r): torch.distributed carries the all-reduce' % (exc,))
-            _direct = False
-        if _direct and world()[1] > 1 and not _direct.graph_ok:
-            # the communicator exists but does not survive graph capture here: use it eagerly?  No -- one code path less to
-            # trust on hardware this build never saw: fall back to torch.distributed between two graphs
-            _direct.close()
+            warnings.warn('pacoh: RCCL communicator could not be created on rank %d (%r)' % (world()[0], exc))
+            ok = False
+        # EVERY rank reports, and all ranks take the same branch: one rank falling back to torch.distributed while its peers sit in
+        # the communicator's self-test would build different step graphs and hang the first exchange
+        if agree_all(ok):
+            comm.graph_ok = comm._self_test()              # (its three phases are agreed on by all ranks themselves)
+            ok = comm.graph_ok or world()[1] == 1
+        else:
+            ok = False
+        if ok:
+            _direct = comm
+        else:
+            # the communicator does not exist everywhere, or does not survive graph capture here: use it eagerly?  No -- one code
+            # path less to trust on hardware this build never saw: torch.distributed between two graphs per step
+            if comm is not None:
+                comm.close()
+            if world()[0] == 0:
+                warnings.warn('pacoh: torch.distributed carries the all-reduce (no usable in-graph RCCL communicator)')
             _direct = False
     return _direct or None
 
@@ -255,7 +294,8 @@ def all_reduce_buffer_(buf):
     if comm is not None:
         comm.all_reduce_(buf)
     elif world()[1] > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        with L._Timed('allreduce_torch'):
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 
 

@@ -104,3 +104,27 @@ def test_two_ranks_on_one_gpu_match_single_process(kind):
         else:
             assert np.abs(r0 - ref).max() < 2e-3 * max(1.0, np.abs(ref).max())
             assert np.linalg.norm(r0 - ref) < 1e-3 * np.linalg.norm(ref)
+
+
+def test_bench_two_ranks_prints_both_scaling_legs():
+    """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` (gloo transport: two ranks on the box's one GPU) prints ONE JSON
+    line whose `legs` holds the weak and the strong scaling mode, each timed with the exchange in place"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PACOH_BENCH_BACKEND='gloo')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2'],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['world_size_seen'] == 2 and out['scaling'] == 'weak'
+    assert set(out['legs']) == {'weak', 'strong'}
+    assert out['legs']['weak']['tasks_total'] == 2048 and out['legs']['strong']['tasks_total'] == 1024
+    for leg in out['legs'].values():
+        assert leg['finite'] and leg['ms_per_step'] > 0 and leg['world_size_seen'] == 2
+        assert 'torch.distributed' in leg['exchange'] and leg['all_reduce_us'] is not None and leg['all_reduce_us'] > 0
+    assert out['value'] == out['legs']['weak']['value']

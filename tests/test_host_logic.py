@@ -267,3 +267,34 @@ def test_first_chunk_sizes():
         for chunk in (1, 4, 16, 100, 1024):
             k = fc(n, chunk)
             assert 1 <= k <= min(n, chunk)
+
+
+def test_bench_line_shape_with_both_scaling_legs():
+    """bench.py's JSON line at N > 1: `legs` carries the weak AND the strong scaling mode of the one invocation the driver makes,
+    each with ms_per_step / value / exchange / world_size_seen / all_reduce_us; the top-level numbers are the --scaling leg's"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('pacoh_bench', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    def leg(scaling, ms, evals):
+        return {'scaling': scaling, 'ms_per_step': ms, 'value': evals / (ms * 1e-3), 'unit': 'evals/s', 'evals_per_step': evals,
+                'host_ms_per_step': 0.01, 'finite': True, 'exchange': 'torch.distributed.all_reduce between two graphs per step',
+                'world_size_seen': 2, 'step_mode': {'graph': True}, 'tasks_total': 2048 if scaling == 'weak' else 1024, 'all_reduce_us': 31.5}
+    legs = {'weak': leg('weak', 0.45, 40960), 'strong': leg('strong', 0.25, 20480)}
+    pp = {'kernel_sum': 0.4, 'ms_per_step': 0.47, 'kernel_ms': {'mlp_bwd': 0.17}, 'kernel_ms_raw': {'mlp_bwd': 0.18}, 'event_overhead_ms': 0.009}
+    out = bench.assemble_line(metric='task-GP LML+grad evals/sec (n_ctx=64, d=4, 20 particles)', value=legs['weak']['value'], world=2, steps=20,
+                              warmup=5, ms_per_step=0.45, scaling='weak', dtype='f32', backend='gloo', world_size_seen=2, leg=legs['weak'],
+                              legs=legs, host_ms=0.01, step_mode={'graph': True}, config={'workload': 'x'}, roofline=None,
+                              kernel_rooflines={}, step_flops=2.6e10, gram=None, pp=pp, others=None, cpu=None)
+    json.loads(json.dumps(out))                                  # one serialisable line
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+                'data', 'config', 'roofline', 'cpu_baseline', 'legs', 'exchange', 'all_reduce_us', 'world_size_seen', 'schema'):
+        assert key in out, key
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] == round(legs['weak']['value'], 1)
+    assert set(out['legs']) == {'weak', 'strong'}
+    for l in out['legs'].values():
+        for key in ('ms_per_step', 'value', 'exchange', 'world_size_seen', 'all_reduce_us'):
+            assert key in l, key
+    assert out['all_reduce_us'] == 31.5 and out['vs_baseline'] is None
