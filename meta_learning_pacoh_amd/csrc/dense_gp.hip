@@ -21,6 +21,7 @@ namespace pacoh {
 int dense_chol_launch(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
                       int dtype, int attempt, hipStream_t stream, int u_only = 0);                  // dense.hip
 bool dense_chol_saves_inverse(int n, int dtype);                                                     // dense.hip
+int trtri_ll_try(void* A, const int32_t* info, int B, int n, int dtype, hipStream_t s);            // dense_trtri_ll.hip (1: not in its plan)
 int gram_rbf_for_chol(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
                       int dtype, hipStream_t s, int lower);                                          // gram.hip
 
@@ -762,6 +763,12 @@ __global__ void __launch_bounds__(256) dense_alpha_kernel(const T* __restrict__ 
 
 template <typename T>
 int launch_trtri(T* A, const int32_t* info, int B, int n, int mpad, size_t lds, int saved_inv, hipStream_t s) {
+    // the left-looking kernel (dense_trtri_ll.hip) needs the inverse diagonal blocks the MFMA Cholesky kernels leave behind
+    static const bool ll_on = []() { const char* e = getenv("PACOH_TRTRI_LL"); return !(e && e[0] == '0'); }();
+    if (ll_on && saved_inv && n >= 97) {
+        const int rc = trtri_ll_try(A, info, B, n, sizeof(T) == 4 ? PACOH_F32 : PACOH_F64, s);
+        if (rc != 1) return rc;
+    }
 #define PACOH_TRTRI_LAUNCH(nt) do { auto kern = trtri_dense_kernel<T, nt>; \
         if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return PACOH_ELIMIT; \

@@ -1,0 +1,464 @@
+// Z = L^-1 in place (lower triangle) for the large-context path, LEFT-LOOKING by 64-row panels (round 4): one 1024-thread
+// workgroup per matrix, the companion of dense_ll.hip (which leaves the inverse of every 32 x 32 diagonal block of L transposed
+// in that block's upper triangle).
+//
+//   panel I (rows c0 = 64 I .. + 64):   Z[I, 0:I] = - Z_II * ( L[I, 0:I] * Z[0:I, 0:I] ),      Z[I, I] = Z_II = L[I,I]^-1
+//
+// The 64 x c0 product lives in MFMA accumulators (<= 8 blocks of 16 x 16 per wave, 14 waves); the finished rows of Z stream
+// through LDS once per panel as ROW slabs of 16 rows (contiguous in memory: full-line DMA, and a slab only brings the columns
+// up to its own diagonal), next to the 64 x 16 slab of the panel's own L columns; nothing is written inside the loop.  There is
+// no dependency chain at all -- Z_II is assembled from what the Cholesky left behind (two 32 x 32 inverses + L10) -- so every
+// SIMD runs MFMAs.  The right-looking kernel this replaces (trtri_dense_kernel) re-read the inverted trailing matrix from
+// L2 / HBM for every 32-column panel with per-lane 8-byte loads: 1.9 GB per 256 x 512^2 fp64 launch, 0.46 ms.
+// Slabs are taken in DESCENDING k order: the heavy ones (long rows, many column blocks) first, so that the DMA of the next
+// slab always hides behind more MFMA work than it needs.
+// Roles: waves 0 and 1 = helpers (LDS-DMA issue; wave 1 also assembles Z_II's operand images and writes the diagonal block),
+// waves 2..15 = MFMA waves; MFMA wave w owns column blocks w and NB - 1 - w of the panel (Z is lower triangular: column block
+// q only meets the slabs k >= q, so the pair's work is the same for every w).
+// Reference semantics: the explicit inverse gpytorch's inv_quad_logdet / torch.cholesky_inverse produce on the way to K^-1
+// (meta_learn/random_gp.py:83-85 backward at the large-context configuration).
+#include "common.h"
+#include "dense_diag.h"
+#include <type_traits>
+
+namespace pacoh {
+namespace {
+
+constexpr int TL_NT = 1024;
+constexpr int TL_NMMA = 14;
+
+__host__ __device__ constexpr int tl_tri(int a, int b) { return a * (a + 1) / 2 + b; }
+
+__device__ __forceinline__ void tl_glds16(const void* src, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+__device__ __forceinline__ void tl_wait_vmcnt(int n) {
+#define TL_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        TL_VMC(0) TL_VMC(1) TL_VMC(2) TL_VMC(3) TL_VMC(4) TL_VMC(5) TL_VMC(6) TL_VMC(7) TL_VMC(8) TL_VMC(9) TL_VMC(10) TL_VMC(11) TL_VMC(12)
+        TL_VMC(13) TL_VMC(14) TL_VMC(15) TL_VMC(16) TL_VMC(17) TL_VMC(18) TL_VMC(19) TL_VMC(20) TL_VMC(21) TL_VMC(22) TL_VMC(23) TL_VMC(24)
+        TL_VMC(25) TL_VMC(26) TL_VMC(27) TL_VMC(28) TL_VMC(29) TL_VMC(30) TL_VMC(31) TL_VMC(32) TL_VMC(33) TL_VMC(34) TL_VMC(35) TL_VMC(36)
+        TL_VMC(37) TL_VMC(38) TL_VMC(39) TL_VMC(40)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef TL_VMC
+}
+
+template <typename T> __device__ __forceinline__ constexpr int tl_img_off(int c15, int r) {
+    return (Mf<T>::q_of(c15) * 64 + 16 * Mf<T>::g_of(c15) + r) * (int)sizeof(T);
+}
+
+// LDS: Zd images (10 blocks) | ring of nb x { Z slab: 16 rows x RS bytes | L slab: 64 rows x 128 bytes (XOR-swizzled pieces) }
+template <typename T>
+__global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, const int32_t* __restrict__ info, int n, int ring_bytes) {
+    if (info && info[blockIdx.x] < 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    constexpr int ES = sizeof(T), BLK = 256 * ES;
+    constexpr int KS = 16;                                        // rows of a Z slab = columns of an L slab
+    constexpr int LRB = KS * ES;                                  // bytes per L slab row (128 fp64 / 64 fp32)
+    using Acc = typename Mf<T>::acc;
+    unsigned char* const Zdimg = sm;                              // -Z00 | +L10 | -Z11 operand images of the panel's diagonal block
+    unsigned char* const ring = sm + 10 * BLK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    T* const Ab = A + (size_t)blockIdx.x * n * n;
+    const int npan = (n + 63) >> 6;
+    const bool is_helper = wave < 2;
+    const int mw = wave - 2;                                      // MFMA wave 0..13
+
+    // Waves 0 / 1 assemble the operand images of Z_II = [Z00 0; Z10 Z11] from what the Cholesky left (two inverse 32-blocks,
+    // transposed, in the upper triangles; 1 / diagonal; L10): -Z00 | +L10 | -Z11, one 32-block and one row block of L10 each.  The
+    // loads for panel I + 1 are issued at the start of panel I's loop and sit in registers until that panel's epilogue has read the
+    // images of panel I (these waves have no accumulators): loaded where they are needed they cost 20 us per panel, with every
+    // other wave waiting at the barrier.
+    auto run = [&](auto imgc) __attribute__((always_inline)) {
+    constexpr bool IMG = decltype(imgc)::value;
+    T pre[IMG ? 5 : 1][4];
+    const int hw = wave & 1;                                      // helper wave hw: inverse block Z(hw,hw), row block hw of L10, column block hw of Z10
+    auto img_load = [&](int I) __attribute__((always_inline)) {
+        const int c0 = I << 6;
+        const int last = n - 1;
+        {
+            const int k0 = c0 + 32 * hw;
+#pragma unroll
+            for (int av = 0; av < 2; ++av)
+#pragma unroll
+                for (int b = 0; b <= av; ++b) {
+                    const int i = 16 * av + r;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = 16 * b + Mf<T>::row(g, q);
+                        int row = k0 + (c < i ? c : i), col = k0 + i;             // (c < i: the transposed entry; else the diagonal)
+                        row = row < last ? row : last; col = col < last ? col : last;
+                        pre[av + b][q] = Ab[(size_t)row * n + col];
+                    }
+                }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            int row = c0 + 32 + 16 * hw + r;
+            row = row < last ? row : last;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int col = c0 + 16 * b + Mf<T>::row(g, q);
+                col = col < last ? col : last;
+                pre[3 + b][q] = Ab[(size_t)row * n + col];
+            }
+        }
+    };
+    auto img_write = [&](int I) __attribute__((always_inline)) {
+        const int c0 = I << 6;
+        {
+            const int k0 = c0 + 32 * hw;
+#pragma unroll
+            for (int av = 0; av < 2; ++av)
+#pragma unroll
+                for (int b = 0; b <= av; ++b) {
+                    T* const zp = reinterpret_cast<T*>(Zdimg + tl_tri(2 * hw + av, 2 * hw + b) * BLK) + lane;
+                    const int i = 16 * av + r;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = 16 * b + Mf<T>::row(g, q);
+                        const T x = pre[av + b][q];
+                        T v = T(0);
+                        if (k0 + i < n) v = c < i ? x : (c == i ? T(1) / x : T(0));
+                        else if (c == i) v = T(1);                // (rows beyond the matrix: identity)
+                        zp[q * 64] = -v;
+                    }
+                }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            T* const lp = reinterpret_cast<T*>(Zdimg + tl_tri(2 + hw, b) * BLK) + lane;
+            const int row = c0 + 32 + 16 * hw + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lp[q * 64] = row < n ? pre[3 + b][q] : T(0);
+        }
+    };
+    if constexpr (IMG) img_load(0);
+#ifdef PACOH_LL_STAMPS
+    long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = wall_clock64();
+#define TST(k) do { const long long t_ = wall_clock64(); st_[k] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define TST(k) do {} while (0)
+#endif
+    // Slab order of a panel with ns k-blocks: the blocks of the panels before the previous one first (descending), then the previous
+    // panel's four -- those rows were stored a moment ago; everything in front of them can be fetched while that panel's epilogue
+    // still runs.
+    auto kb_of = [](int ns, int t) -> int { return ns <= 4 ? ns - 1 - t : (t < ns - 4 ? ns - 5 - t : 2 * ns - 5 - t); };
+    int pre_issued = 0;                                           // slabs of the coming panel already in flight
+    // byte-ring allocator (wave-uniform scalars): offsets of the last eight slabs issued, end of the newest one
+    int rq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rhead = 0;
+    auto rq_get = [&](int i) __attribute__((always_inline)) -> int {
+        int v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v = (i & 7) == k ? rq[k] : v;
+        return v;
+    };
+    auto rq_set = [&](int i, int v) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rq[k] = (i & 7) == k ? v : rq[k];
+    };
+    for (int I = 0; I < npan; ++I) {
+        const int c0 = I << 6;
+        const int NBq = c0 >> 4;                                  // column blocks of the panel's product
+        const int ns = NBq;                                       // slabs (16 rows of Z each)
+        const int pm = (n - c0) < 64 ? (n - c0) : 64;             // rows of this panel inside the matrix
+
+        // ---- The slabs live in a BYTE ring: slab t (k block kb) takes 16 rows of exactly its own length (16 kb + 16 columns) plus the
+        // 64 x 16 L slab, placed behind its predecessor (wrapping to 0 when it does not fit).  With entries of the widest slab's size
+        // only two fit at the big panels, and one slab in flight per CU is latency-bound (64 KB / 2.5 us = 26 GB/s): every slab
+        // waited 2-3 us for its data.  Tight entries let the smaller slabs run three or four deep.
+        // DMA: EVERY wave issues -- wave w brings row w of the Z slab (ceil(pieces / 64) instructions of 64 x 16 bytes, the last one
+        // partial = EXEC-masked), the first waves one instruction of the L slab each; two dedicated helper waves needed 350 us for
+        // the launch's 4096 instructions.  Bank layout of a Z slab row: rows of a multiple of 256 bytes store piece p of row k' at
+        // position p ^ (8 (k' & 1)) -- the two rows a 32-lane read group touches (k' = 4 s + g, g = 0 / 1) then sit in different
+        // 128-byte halves of the 256-byte bank row; rows of an odd multiple of 128 bytes do so by themselves.
+        constexpr int PPR = LRB / 16;                             // L slab: pieces per row, 8 (fp64) / 4 (fp32)
+        constexpr int RPI = 64 / PPR;                             // ... rows per instruction
+        constexpr int NLI = 64 / RPI;                             // ... instructions per slab
+        constexpr int DMAX = 4;                                   // slabs in flight beyond the one being consumed
+        auto esize = [&](int ns_, int u) __attribute__((always_inline)) -> int { return KS * (16 * kb_of(ns_, u) + 16) * ES + 64 * LRB; };
+        // place slab u of a panel with ns_ slabs beside the live slabs oldest .. u - 1 (none live: oldest == u): its offset, or -1
+        auto place = [&](int ns_, int u, int oldest) __attribute__((always_inline)) -> int {
+            if (u >= ns_ || u > oldest + DMAX) return -1;
+            const int sz = esize(ns_, u);
+            if (oldest == u) { rhead = sz; return 0; }            // empty ring
+            const int tail = rq_get(oldest);
+            int off = -1;
+            if (rhead > tail) {                                   // live bytes [tail, rhead): room behind them, or in front after a wrap
+                if (rhead + sz <= ring_bytes) off = rhead;
+                else if (sz <= tail) off = 0;
+            } else if (rhead + sz <= tail) off = rhead;           // wrapped: live bytes [tail, end) and [0, rhead)
+            if (off >= 0) rhead = off + sz;
+            return off;
+        };
+        auto dma_p = [&](int I_, int t, int off) __attribute__((always_inline)) {  // slab t of panel I_ at ring offset off
+            const int c0_ = I_ << 6, ns_ = c0_ >> 4;
+            const int pm_ = (n - c0_) < 64 ? (n - c0_) : 64;
+            const int kb = kb_of(ns_, t);
+            const int RS_ = (16 * kb + 16) * ES;
+            unsigned char* const zb = ring + off;
+            const int pieces = RS_ / 16;
+            const int ipr = (pieces + 63) >> 6;                   // instructions per row
+            const int lxx = (RS_ & 255) == 0 ? (lane ^ (8 * (wave & 1))) : lane;
+            const unsigned char* const rowp = reinterpret_cast<const unsigned char*>(Ab + (size_t)(16 * kb + wave) * n);
+            for (int ch = 0; ch < ipr; ++ch)
+                if (ch * 64 + lane < pieces) tl_glds16(rowp + (ch * 64 + lxx) * 16, zb + wave * RS_ + ch * 1024);
+            if (wave < NLI) {                                     // L rows c0 .. + 64 (clamped to the matrix), columns 16 kb .. + 16
+                const int i = wave * RPI + lane / PPR, pp = lane % PPR;
+                const int sig = (ES == 8) ? ((i >> 1) & 7) : ((i >> 2) & 3);
+                const int ic = i < pm_ ? i : pm_ - 1;
+                tl_glds16(reinterpret_cast<const unsigned char*>(Ab + (size_t)(c0_ + ic) * n + 16 * kb) + ((pp ^ sig) << 4),
+                          zb + KS * RS_ + wave * 1024);
+            }
+        };
+        auto dma_count = [&](int t) __attribute__((always_inline)) -> int {      // this wave's instructions for slab t
+            const int pieces = (16 * kb_of(ns, t) + 16) * ES / 16;
+            return ((pieces + 63) >> 6) + (wave < NLI ? 1 : 0);
+        };
+        int nxt = pre_issued;                                     // next slab to issue
+        // the loop's barrier: a RAW s_barrier behind a COUNTED vmcnt (the slabs beyond t + 1 stay in flight across it)
+        auto slab_barrier = [&](int t) __attribute__((always_inline)) {
+            int pend = 0;
+            for (int u = t + 2; u < nxt; ++u) pend += dma_count(u);
+            tl_wait_vmcnt(pend);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+
+        TST(0);
+        __syncthreads();                                          // previous panel's stores are visible, its LDS reads are over
+        TST(1);
+        for (;;) { const int o = place(ns, nxt, 0); if (o < 0) break; rq_set(nxt, o); dma_p(I, nxt, o); ++nxt; }
+        if constexpr (IMG) img_write(I);
+        TST(2);
+        __syncthreads();                                          // images written, first slab(s) landed
+        TST(3);
+        if constexpr (IMG) { if (I + 1 < npan) img_load(I + 1); }           // (rows of L / inverse blocks no panel before I + 1 writes)
+
+        Acc acc0[IMG ? 1 : 4], acc1[IMG ? 1 : 4];
+        if constexpr (!IMG) {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) { acc0[ib] = Acc{0, 0, 0, 0}; acc1[ib] = Acc{0, 0, 0, 0}; }
+        }
+        const int qb0 = mw, qb1 = NBq - 1 - mw;                   // this wave's column blocks (qb1 > qb0 when it has two)
+        const bool v0 = !is_helper && mw < (NBq + 1) / 2, v1 = v0 && qb1 > qb0;
+
+        for (int t = 0; t < ns; ++t) {
+            const int kb = kb_of(ns, t);
+            const int RS = (16 * kb + 16) * ES;
+            const unsigned char* const zb = ring + rq_get(t);
+            const unsigned char* const lb = zb + KS * RS;
+            const bool zswz = (RS & 255) == 0;
+            for (;;) { const int o = place(ns, nxt, t); if (o < 0) break; rq_set(nxt, o); dma_p(I, nxt, o); ++nxt; }
+            TST(7);
+            // out[i][q] += L[c0 + i][16 kb + k] Z[16 kb + k][q]: column block qb takes part iff qb <= kb; in the diagonal block
+            // (qb == kb) the entries above Z's diagonal are not Z (the Cholesky's inverse blocks live there): masked to zero
+            const bool d0 = v0 && qb0 <= kb, d1 = v1 && qb1 <= kb;
+            if constexpr (!IMG) {
+                // (the wave's shape in this slab -- one or two column blocks -- as compile-time flags: wave-uniform branches inside
+                //  the k loop cut each step's read / MFMA stream apart; the diagonal-block mask is a multiplication by 0 / 1)
+                auto body = [&](auto c0c, auto c1c) __attribute__((always_inline)) {
+                    constexpr bool C0 = decltype(c0c)::value, C1 = decltype(c1c)::value;
+                    const int lsig = (ES == 8) ? ((r >> 1) & 7) : ((r >> 2) & 3);
+                    T av[4][4], b0[4], b1[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int kk = Mf<T>::row(g, s);          // k inside the slab for this lane at step s
+                        const int piece = (kk * ES) >> 4, lo = (kk * ES) & 15;
+#pragma unroll
+                        for (int ib = 0; ib < 4; ++ib)
+                            av[s][ib] = *reinterpret_cast<const T*>(lb + (16 * ib + r) * LRB + ((piece ^ lsig) << 4) + lo);
+                        const unsigned char* const zrow = zb + kk * RS;
+                        const int zx = zswz ? 8 * (kk & 1) : 0;
+                        if constexpr (C0) {
+                            const int q = 16 * qb0 + r;
+                            b0[s] = *reinterpret_cast<const T*>(zrow + ((((q * ES) >> 4) ^ zx) << 4) + ((q * ES) & 15)) * ((qb0 == kb && r > kk) ? T(0) : T(1));
+                        }
+                        if constexpr (C1) {
+                            const int q = 16 * qb1 + r;
+                            b1[s] = *reinterpret_cast<const T*>(zrow + ((((q * ES) >> 4) ^ zx) << 4) + ((q * ES) & 15)) * ((qb1 == kb && r > kk) ? T(0) : T(1));
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        if constexpr (C0) {
+#pragma unroll
+                            for (int ib = 0; ib < 4; ++ib) acc0[ib] = Mf<T>::mma(av[s][ib], b0[s], acc0[ib]);
+                        }
+                        if constexpr (C1) {
+#pragma unroll
+                            for (int ib = 0; ib < 4; ++ib) acc1[ib] = Mf<T>::mma(av[s][ib], b1[s], acc1[ib]);
+                        }
+                    }
+                };
+                if (d0 && d1) body(std::true_type{}, std::true_type{});
+                else if (d0) body(std::true_type{}, std::false_type{});
+                else if (d1) body(std::false_type{}, std::true_type{});
+            }
+            TST(4);
+            if (nxt > t + 1 || t + 1 >= ns) slab_barrier(t);
+            else {                                                // (the next slab did not fit beside this one: fetch it between two barriers)
+                __syncthreads();
+                { const int o = place(ns, nxt, nxt); rq_set(nxt, o); dma_p(I, nxt, o); ++nxt; }
+                __syncthreads();
+            }
+            TST(5);
+        }
+
+        // the ring is free from here on: the coming panel's first slabs that do not depend on this panel's rows (its old k blocks)
+        pre_issued = 0;
+        if (I + 1 < npan) {
+            const int ns2 = (I + 1) << 2;
+            for (;;) {
+                if (pre_issued >= ns2 - 4) break;
+                const int o = place(ns2, pre_issued, 0);
+                if (o < 0) break;
+                rq_set(pre_issued, o); dma_p(I + 1, pre_issued, o); ++pre_issued;
+            }
+        }
+        // ---- epilogue: Z[I, q-block] = -Z_II out, through the 2 x 2 structure of Z_II (images -Z00 | L10 | -Z11), from registers
+        auto zmul = [&](int av, int b, const Acc& X, Acc o) __attribute__((always_inline)) -> Acc {
+            const T* zp = reinterpret_cast<const T*>(Zdimg + tl_tri(av, b) * BLK) + lane;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) o = Mf<T>::mma(zp[s * 64], X[s], o);
+            return o;
+        };
+        auto finish = [&](Acc (&X)[IMG ? 1 : 4], int qb) __attribute__((always_inline)) {
+            if constexpr (!IMG) {
+            const Acc z = {0, 0, 0, 0};
+            Acc t1 = zmul(1, 0, X[0], z);
+            t1 = zmul(1, 1, X[1], t1);
+            const Acc t0 = zmul(0, 0, X[0], z);
+            X[0] = t0; X[1] = t1;                                 // R_lo = -Z00 X_lo
+            X[2] = zmul(2, 0, X[0], X[2]); X[2] = zmul(2, 1, X[1], X[2]);      // X_hi + L10 R_lo
+            X[3] = zmul(3, 0, X[0], X[3]); X[3] = zmul(3, 1, X[1], X[3]);
+            Acc t3 = zmul(3, 2, X[2], z);
+            t3 = zmul(3, 3, X[3], t3);
+            const Acc t2 = zmul(2, 2, X[2], z);
+            X[2] = t2; X[3] = t3;                                 // R_hi = -Z11 (X_hi + L10 R_lo)
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = c0 + 16 * ib + Mf<T>::row(g, q);
+                    if (row < n) Ab[(size_t)row * n + 16 * qb + r] = X[ib][q];
+                }
+            }
+        };
+        if constexpr (!IMG) {
+            if (v0) finish(acc0, qb0);
+            if (v1) finish(acc1, qb1);
+        }
+        TST(6);
+        // ---- helper 1: the diagonal block itself.  Z00, Z11 (lower parts) from the images; Z10 = (-Z11) (L10 Z00)
+        if constexpr (IMG) {
+            {
+                const int h = hw;
+                const int k0 = c0 + 32 * h;
+#pragma unroll
+                for (int av = 0; av < 2; ++av)
+#pragma unroll
+                    for (int b = 0; b <= av; ++b) {
+                        const T* const zp = reinterpret_cast<const T*>(Zdimg + tl_tri(2 * h + av, 2 * h + b) * BLK) + lane;
+                        const int i = 16 * av + r;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c = 16 * b + Mf<T>::row(g, q);
+                            if (c <= i && k0 + i < n) Ab[(size_t)(k0 + i) * n + k0 + c] = -zp[q * 64];
+                        }
+                    }
+            }
+            if (pm > 32) {
+                // T = L10 Z00 (A = the L10 image; B[k][c] = Z00[k][c] read out of the image of -Z00, whose element (i', c') sits at
+                // img_off(c', i')), then Z10 = (-Z11) T with T's accumulator blocks as B operands
+                {
+                    const int cb = hw;
+                    Acc tt[2];
+#pragma unroll
+                    for (int ibr = 0; ibr < 2; ++ibr) {
+                        Acc o = {0, 0, 0, 0};
+#pragma unroll
+                        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                if (kb2 < cb) continue;
+                                const T a = *(reinterpret_cast<const T*>(Zdimg + tl_tri(2 + ibr, kb2) * BLK) + s * 64 + lane);
+                                const T b = -*reinterpret_cast<const T*>(Zdimg + tl_tri(kb2, cb) * BLK + tl_img_off<T>(r, Mf<T>::row(g, s)));
+                                o = Mf<T>::mma(a, b, o);
+                            }
+                        tt[ibr] = o;
+                    }
+#pragma unroll
+                    for (int ibp = 0; ibp < 2; ++ibp) {
+                        Acc zz = {0, 0, 0, 0};
+#pragma unroll
+                        for (int ibr = 0; ibr <= ibp; ++ibr)
+#pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                                zz = Mf<T>::mma(*(reinterpret_cast<const T*>(Zdimg + tl_tri(2 + ibp, 2 + ibr) * BLK) + s * 64 + lane), tt[ibr][s], zz);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int row = c0 + 32 + 16 * ibp + Mf<T>::row(g, q);
+                            if (row < n) Ab[(size_t)row * n + c0 + 16 * cb + r] = zz[q];
+                        }
+                    }
+                }
+            }
+        }
+    }
+#ifdef PACOH_LL_STAMPS
+    TST(0);
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 1 || wave == 2 || wave == 15))
+        printf("trtri wave %d (us): tail+diag %.1f | panel barrier %.1f | prologue dma / images %.1f | barrier %.1f | loop work %.1f | loop barrier %.1f | finish %.1f | dma issue %.1f\n",
+               wave, st_[0] * 0.01, st_[1] * 0.01, st_[2] * 0.01, st_[3] * 0.01, st_[4] * 0.01, st_[5] * 0.01, st_[6] * 0.01, st_[7] * 0.01);
+#endif
+    };
+    // (two instantiations of the panel loop: waves 0 / 1 hold twenty prefetched image entries each in registers and no accumulators,
+    //  the other waves hold accumulators and no image entries -- one allocation for the union of both would spill 165 registers)
+    if (wave < 2) run(std::true_type{}); else run(std::false_type{});
+#undef TST
+}
+
+template <typename T>
+bool tl_plan(int n, int* ring_bytes, size_t* lds) {
+    const int ES = sizeof(T), BLK = 256 * ES;
+    if (n < 1 || n > 512 || ((size_t)n * ES) % 16 != 0) return false;
+    const size_t cap = 160u * 1024u;
+    const int npan = (n + 63) / 64;
+    const int c0max = (npan - 1) * 64;
+    const size_t bmax = (size_t)16 * c0max * ES + 64 * 16 * ES;     // largest ring entry
+    size_t ring = cap - 10 * BLK;
+    if (bmax > ring) return false;
+    *ring_bytes = (int)ring; *lds = cap;
+    return true;
+}
+
+}  // namespace
+
+bool trtri_ll_fits(int n, int dtype) {
+    int rb; size_t lds;
+    return dtype == PACOH_F32 ? tl_plan<float>(n, &rb, &lds) : tl_plan<double>(n, &rb, &lds);
+}
+
+// returns 1 when n is outside this kernel's plan (caller: trtri_dense_kernel)
+int trtri_ll_try(void* A, const int32_t* info, int B, int n, int dtype, hipStream_t s) {
+    int rb = 0; size_t lds = 0;
+    if (dtype == PACOH_F32) {
+        if (!tl_plan<float>(n, &rb, &lds)) return 1;
+        auto kern = trtri_ll_kernel<float>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        hipLaunchKernelGGL(kern, dim3(B), dim3(TL_NT), lds, s, (float*)A, info, n, rb);
+    } else {
+        if (!tl_plan<double>(n, &rb, &lds)) return 1;
+        auto kern = trtri_ll_kernel<double>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        hipLaunchKernelGGL(kern, dim3(B), dim3(TL_NT), lds, s, (double*)A, info, n, rb);
+    }
+    return launch_status();
+}
+
+}  // namespace pacoh

@@ -15,8 +15,8 @@ def main(src, out):
     for path in glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True):
         with open(path) as fh:
             for row in csv.DictReader(fh):
-                name = re.sub(r'^void ', '', row['Kernel_Name'])
-                name = re.sub(r'\(.*$', '', name).replace('pacoh::', '').replace('(anonymous namespace)::', '')
+                name = re.sub(r'^void ', '', row['Kernel_Name']).replace('(anonymous namespace)::', '').replace('pacoh::', '')
+                name = re.sub(r'\(.*$', '', name)
                 d = acc.setdefault(name, {})
                 c = d.setdefault(row['Counter_Name'], [0.0, set()])
                 c[0] += float(row['Counter_Value'])
