@@ -34,6 +34,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 FP32_PEAK_TFLOPS = 157.3       # fp32 vector peak == fp32-input MFMA peak (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6        # fp64 matrix peak: AMD's MI355X figure; tools/mfma_peak.hip measures what v_mfma_f64_16x16x4 sustains
 PMC_PROFILE = os.path.join('profiles', 'r03_pmc_hbm_traffic.json')
+DENSE_PMC_PROFILE = os.path.join('profiles', 'r04_dense_pmc_hbm_traffic.json')
 
 
 def make_tasks(n_tasks, n, d, seed0=1000):
@@ -394,6 +395,114 @@ def rooflines(wl, pp):
     return roofline, kernel_rooflines, sum(wl['flops'][k][0] for k in modelled)
 
 
+def cpu_baseline_other(cfg, budget_s=2.5):
+    """bounded CPU baseline (<= ~3 s) beside configurations #2 / #4 / #5, with the oracle (kind "port"): the same LML + gradient arithmetic
+    in plain torch on the host cores.  #2: PACOH-MAP loss + autograd over the 256 sinusoid tasks, batched over tasks and as the
+    reference's python loop; #4: the [S, D] score of a 16-task sample at n = 128; #5: fp64 batched LAPACK Cholesky LML + autograd
+    gradients on a 4-problem sample (n = 512, d = 8)."""
+    from oracle import pacoh_oracle as O
+    from meta_learning_pacoh_amd.util import host_cpu_budget
+    cores = host_cpu_budget()
+    threads = max(1, min(8, cores))
+    before = torch.get_num_threads()
+    torch.set_num_threads(threads)
+
+    def rate(fn, units):
+        fn()                                               # warm-up
+        t0, reps = time.time(), 0
+        while time.time() - t0 < budget_s / 2:
+            fn()
+            reps += 1
+        return units * reps / (time.time() - t0)
+    try:
+        if cfg == 2:
+            tasks = sinusoid_tasks(27, 256, 32)
+            orc = O.MapOracle(tasks, covar_module='SE', mean_module='NN', task_batch_size=256, random_seed=1)
+            xs = torch.stack([x for x, _ in orc.tasks]); ys = torch.stack([y for _, y in orc.tasks])
+
+            def batched():
+                orc.optimizer.zero_grad()
+                (-orc.task_mll(xs, ys).sum()).backward()
+
+            def looped():
+                orc.optimizer.zero_grad()
+                loss = 0.0
+                for x, y in orc.tasks:
+                    loss = loss - orc.task_mll(x, y)
+                loss.backward()
+            vb, vl = rate(batched, 256), rate(looped, 256)
+            sample = '256 sinusoid tasks x n=32 (SinusoidDataset(RandomState(27))), SE kernel + NN(32,32) mean, fp32 loss + autograd: batched over tasks %.0f evals/s, reference-style python loop %.0f evals/s' % (vb, vl)
+            value = vb
+        elif cfg == 4:
+            T_s, S = 16, 10
+            tasks = _rand_tasks(T_s, 128, 1, 28)
+            stats = O.compute_normalization_stats(tasks)
+            otasks = [O.prepare_task(x, y, stats, torch.float32) for x, y in tasks]
+            gcfg = O.GPConfig(1, 'NN', 'NN')
+            pm, ps = O.hyperprior_mean_std(gcfg.layout, 0.5, 3.0)
+            torch.manual_seed(0)
+            theta = O.hyperprior_sample(gcfg.layout, pm, ps, S)
+            vb = rate(lambda: O.meta_score(theta, otasks, gcfg, pm, ps, 0.01, loop=False), T_s * S)
+            vl = rate(lambda: O.meta_score(theta, otasks, gcfg, pm, ps, 0.01, loop=True), T_s * S)
+            sample = '%d tasks x %d samples (n=128, d=1, NN/NN, fp32) LML + autograd score: batched %.0f evals/s, python loop over tasks %.0f evals/s' % (T_s, S, vb, vl)
+            value = vb
+        else:
+            Bs, n, d = 4, 512, 8
+            g = torch.Generator().manual_seed(5)
+            X = torch.randn(Bs, n, d, dtype=torch.float64, generator=g).requires_grad_(True)
+            Y = torch.randn(Bs, n, dtype=torch.float64, generator=g)
+            ls = torch.full((1, 1, d), 0.6931, dtype=torch.float64, requires_grad=True)
+            nz = torch.tensor(0.313, dtype=torch.float64, requires_grad=True)
+
+            def lml():
+                for v in (X, ls, nz):
+                    v.grad = None
+                O.gp_mll(X, torch.zeros(Bs, n, dtype=torch.float64), Y, ls, 1.0, nz).sum().backward()
+            value = rate(lml, Bs)
+            sample = '%d problems (n=512, d=8, fp64): Gram + batched LAPACK Cholesky LML + autograd gradients' % Bs
+        return {'value': round(value, 1), 'unit': 'evals/s', 'cores': threads, 'kind': 'port', 'sample': sample}
+    finally:
+        torch.set_num_threads(before)
+
+
+def cfg5_hbm_report(L):
+    """BASELINE config #5's HBM-roofline report: the fp64 Gram leg at n = 512, d = 8 measured here (HIP events, the public entry point:
+    full matrices, 2.13 MB per Gram), the lower-triangle-tiles launch the path itself uses, and the factorisation kernels' HBM
+    traffic against one pass over the matrices from the COMMITTED PMC profile (not measured in this run)."""
+    B, n, d = 256, 512, 8
+    z = torch.randn(B, n, d, dtype=torch.float64, device='cuda')
+    ls = torch.full((1, d), 0.6931, dtype=torch.float64, device='cuda')
+    nz = torch.tensor([0.313], dtype=torch.float64, device='cuda')
+    K = torch.empty(B, n, n, dtype=torch.float64, device='cuda')
+    lib = L.load_library()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        lib.pacoh_gram_rbf_ard(z.data_ptr(), 1, z.data_ptr(), 1, ls.data_ptr(), None, nz.data_ptr(), 1, K.data_ptr(), B, 1, n, n, d, 1, st)
+    for _ in range(5):
+        run()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        run()
+    e.record()
+    torch.cuda.synchronize()
+    t_k = s.elapsed_time(e) / 20 * 1e-3
+    alg = B * (n * d * 8 + n * n * 8)
+    out = {'gram': {'kernel': 'gram_rbf_ard fp64 n=512 d=8 (full matrices)', 'bound': 'hbm', 'algorithmic_bytes': alg, 'bytes_per_gram': n * d * 8 + n * n * 8,
+                    'us_per_launch': round(t_k * 1e6, 1), 'achieved': round(alg / t_k / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(alg / t_k / 1e9 / HBM_PEAK_GBS, 4)}}
+    try:
+        with open(os.path.join(ROOT, DENSE_PMC_PROFILE)) as fh:
+            prof = json.load(fh)
+        one_pass = B * n * n * 8
+        out['traffic'] = {'source': 'committed PMC profile %s (not measured in this run)' % DENSE_PMC_PROFILE, 'one_pass_over_the_matrices_bytes': one_pass,
+                          'kernels': {k: {'hbm_bytes_per_factorisation': v, 'ratio_to_one_pass': round(v / one_pass, 2)} for k, v in prof['per_pass'].items()}}
+    except Exception:
+        out['traffic'] = None
+    return out
+
+
 def other_config_leg(cfg, M, L, steps=256):
     """one of BASELINE.json's other configurations, timed like the headline one but bounded (about 2-3 s): three untimed (64 / 128 / 64-step)
     calls (both looks of the learners at graph replay vs plain launches -- engine.StepMode -- happen there, not in the timed
@@ -415,6 +524,13 @@ def other_config_leg(cfg, M, L, steps=256):
            'kernel_ms_per_step': pp['kernel_ms'], 'profile_pass_ms_per_step': round(pp['ms_per_step'], 4)}
     del wl
     torch.cuda.empty_cache()
+    if cfg == 5:
+        out['hbm'] = cfg5_hbm_report(L)
+    if cfg in (2, 4, 5):
+        try:
+            out['cpu_baseline'] = cpu_baseline_other(cfg)
+        except Exception as exc:
+            out['cpu_baseline'] = {'error': repr(exc)}
     return out
 
 
@@ -452,6 +568,22 @@ def _rand_tasks(T, n, d, seed):
     return [(rs.uniform(-5, 5, (n, d)), rs.normal(size=(n, 1))) for _ in range(T)]
 
 
+def sinusoid_tasks(seed, n_tasks, n_samples):
+    """the reference's SinusoidDataset(RandomState(seed)).generate_meta_train_data(n_tasks, n_samples) (experiments/data_sim.py:203-248,
+    same RNG call order: amplitude, x shift, y shift, slope, period, then X, then the noise): the tasks SURVEY.md 8d names for
+    configurations #1 (seed 26, 20 x 5 = demo.py:17) and #2 (seed 27, 256 x 32)"""
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n_tasks):
+        amp, x_shift = rs.uniform(0.7, 1.3), rs.normal(loc=0.0, scale=0.1)
+        y_shift, slope = rs.normal(loc=5.0, scale=0.1), rs.normal(loc=0.5, scale=0.2)
+        period = rs.uniform(1.5, 1.5)
+        X = rs.uniform(-5, 5, size=(n_samples, 1))
+        f = slope * X + amp * np.sin(period * (X - x_shift)) + y_shift
+        out.append((X, f + 0.1 * rs.normal(size=f.shape)))
+    return out
+
+
 def _mode(model):
     """how the learner ended up issuing its steps: {'graph': bool, 'eager_ms': .., 'graph_ms': ..} (engine.StepMode)"""
     sm = model._step_mode
@@ -479,20 +611,21 @@ def wl_cfg3(world, scaling, M, L):
 def wl_cfg1(world, scaling, M, L):
     """BASELINE.json configs[0], the reference's demo (demo.py:14-26): PACOH-MAP on 20 sinusoid tasks x 5 points, 5 tasks per iteration,
     NN(32,32) mean + kernel features, AdamW with weight decay 0.2 -- a latency-sized iteration (four launches)"""
-    model = M.GPRegressionMetaLearned(_rand_tasks(20, 5, 1, 26), task_batch_size=5, weight_decay=0.2, random_seed=30)
+    model = M.GPRegressionMetaLearned(sinusoid_tasks(26, 20, 5), task_batch_size=5, weight_decay=0.2, random_seed=30)
     w = net_macs(1, (32, 32), 1) + net_macs(1, (32, 32), 2)
     ev = 5 / world
     return dict(run=model._train_steps, evals_per_step=5, dtype='f32', finite=lambda: bool(torch.isfinite(model.theta).all()), mode=lambda: _mode(model),
                 metric='task-GP LML+grad evals/sec (PACOH-MAP demo: 20 tasks x 5 points, 5 per iteration)',
                 flops={'gp_lml_fwdbwd': (gp_flops(5, 2) * ev,) * 2, 'mlp_fwd': (2 * 5 * w * ev,) * 2, 'mlp_bwd': (4 * 5 * w * ev, 6 * 5 * w * ev)},
-                describe='PACOH-MAP iteration (hipGraph replay), cfg#1 = the reference\'s demo: 20 tasks x 5 points, 5 tasks per iteration, NN(32,32) mean + kernel, AdamW',
+                describe='PACOH-MAP iteration (hipGraph replay), cfg#1 = the reference\'s demo: SinusoidDataset(RandomState(26)) 20 tasks x 5 points, 5 tasks per iteration, NN(32,32) mean + kernel, AdamW',
                 extra={'tasks_total': 20, 'n_ctx': 5, 'd': 1})
 
 
 def wl_cfg2(world, scaling, M, L):
-    """PACOH-MAP, 256 sinusoid-like tasks, n_ctx = 32, d = 1, SE kernel + NN(32,32) mean, the full task batch every iteration"""
+    """PACOH-MAP, 256 sinusoid tasks (SinusoidDataset(RandomState(27))), n_ctx = 32, d = 1, SE kernel + NN(32,32) mean, the full
+    task batch every iteration"""
     T = 256 * world if scaling == 'weak' else 256
-    model = M.GPRegressionMetaLearned(_rand_tasks(T, 32, 1, 27), covar_module='SE', mean_module='NN', task_batch_size=T, random_seed=1)
+    model = M.GPRegressionMetaLearned(sinusoid_tasks(27, T, 32), covar_module='SE', mean_module='NN', task_batch_size=T, random_seed=1)
     ev = T / world
     w = net_macs(1, (32, 32), 1)
     return dict(run=model._train_steps, evals_per_step=T, dtype='f32', finite=lambda: bool(torch.isfinite(model.theta).all()), mode=lambda: _mode(model),

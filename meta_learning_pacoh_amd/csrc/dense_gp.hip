@@ -21,7 +21,7 @@ namespace pacoh {
 int dense_chol_launch(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
                       int dtype, int attempt, hipStream_t stream, int u_only = 0);                  // dense.hip
 bool dense_chol_saves_inverse(int n, int dtype);                                                     // dense.hip
-int trtri_ll_try(void* A, const int32_t* info, int B, int n, int dtype, hipStream_t s);            // dense_trtri_ll.hip (1: not in its plan)
+int trtri_ll_try(void* A, const int32_t* info, int B, int n, int dtype, hipStream_t s, const void* u, void* alpha);            // dense_trtri_ll.hip (1: not in its plan)
 int gram_rbf_for_chol(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
                       int dtype, hipStream_t s, int lower);                                          // gram.hip
 
@@ -110,9 +110,11 @@ template <typename T>
 __global__ void __launch_bounds__(256) regram_failed_kernel(const T* __restrict__ z, int z_div, const T* __restrict__ ls,
                                                             const T* __restrict__ os, const T* __restrict__ noise,
                                                             const int32_t* __restrict__ info, T jitter, T* __restrict__ A,
-                                                            int P, int n, int f, int kind) {
-    const long b = blockIdx.y;
-    if (info[b] >= 0) return;
+                                                            int P, int n, int f, int kind, int B) {
+    // a SMALL grid that walks over the problems (the usual case is "nothing failed": 2048 workgroups that only exit cost 5 us per
+    // rung of the ladder, three rungs per evaluation)
+    for (long b = blockIdx.y; b < B; b += gridDim.y) {
+    if (info[b] >= 0) continue;
     const int p = (int)(b % P);
     const T* zb = z + (b / z_div) * (long)n * f;
     const T osv = os ? os[p] : T(1);
@@ -124,6 +126,7 @@ __global__ void __launch_bounds__(256) regram_failed_kernel(const T* __restrict_
             for (int c = 0; c < f; ++c) { const T d = zb[(long)i * f + c] / ls[(long)p * f + c] - zb[(long)j * f + c] / ls[(long)p * f + c]; s = fma(d, d, s); }
             row[j] = osv * kern_val<T>(kind, s) + (i == j ? dg : T(0));
         }
+    }
     }
 }
 
@@ -762,12 +765,13 @@ __global__ void __launch_bounds__(256) dense_alpha_kernel(const T* __restrict__ 
 }
 
 template <typename T>
-int launch_trtri(T* A, const int32_t* info, int B, int n, int mpad, size_t lds, int saved_inv, hipStream_t s) {
+int launch_trtri(T* A, const int32_t* info, int B, int n, int mpad, size_t lds, int saved_inv, hipStream_t s, const T* u = nullptr,
+                 T* alpha = nullptr, int* did_alpha = nullptr) {
     // the left-looking kernel (dense_trtri_ll.hip) needs the inverse diagonal blocks the MFMA Cholesky kernels leave behind
     static const bool ll_on = []() { const char* e = getenv("PACOH_TRTRI_LL"); return !(e && e[0] == '0'); }();
     if (ll_on && saved_inv && n >= 97) {
-        const int rc = trtri_ll_try(A, info, B, n, sizeof(T) == 4 ? PACOH_F32 : PACOH_F64, s);
-        if (rc != 1) return rc;
+        const int rc = trtri_ll_try(A, info, B, n, sizeof(T) == 4 ? PACOH_F32 : PACOH_F64, s, u, alpha);
+        if (rc != 1) { if (did_alpha && u && alpha) *did_alpha = 1; return rc; }
     }
 #define PACOH_TRTRI_LAUNCH(nt) do { auto kern = trtri_dense_kernel<T, nt>; \
         if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
@@ -820,19 +824,22 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
         } else {
             double jit = jitter_base;
             for (int q = 1; q < attempt; ++q) jit *= 10.0;
-            hipLaunchKernelGGL(regram_failed_kernel<T>, dim3(n < 8 ? n : 8, B), dim3(256), 0, s, (const T*)z, z_div, (const T*)ls, (const T*)os,
-                               (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f, kind);
+            hipLaunchKernelGGL(regram_failed_kernel<T>, dim3(n < 8 ? n : 8, B < 32 ? B : 32), dim3(256), 0, s, (const T*)z, z_div, (const T*)ls, (const T*)os,
+                               (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f, kind, B);
         }
         if (n_valid) hipLaunchKernelGGL(dense_mask_kernel<T>, dim3(n, B), dim3(256), 0, s, A, n_valid, y_div, (const int32_t*)info, attempt, n);
         int rc = dense_chol_launch(A, resid, logp, bwd ? alpha : nullptr, info, 1.0, B, n, dtype, attempt, s, u_only ? 1 : 0);
         if (rc) return rc;
     }
     if (bwd) {
-        int rc = launch_trtri<T>(A, info, B, n, mpad, lds, dense_chol_saves_inverse(n, dtype) ? 1 : 0, s);
+        int did_alpha = 0;                             // (the left-looking inverse produces alpha = Z^T u on the way)
+        int rc = launch_trtri<T>(A, info, B, n, mpad, lds, dense_chol_saves_inverse(n, dtype) ? 1 : 0, s, u_only ? alpha : nullptr,
+                                 u_only ? resid : nullptr, &did_alpha);
         if (rc) return rc;
         if (u_only) {                                  // alpha = Z^T u into the residual buffer (free after the last factorisation attempt)
-            hipLaunchKernelGGL(dense_alpha_kernel<T>, dim3((n + 63) / 64, B), dim3(256), 0, s, (const T*)A, (const T*)alpha, resid,
-                               (const int32_t*)info, n);
+            if (!did_alpha)
+                hipLaunchKernelGGL(dense_alpha_kernel<T>, dim3((n + 63) / 64, B), dim3(256), 0, s, (const T*)A, (const T*)alpha, resid,
+                                   (const int32_t*)info, n);
             T* t = alpha; alpha = resid; resid = t;
         }
         GemmArgs ga = {A, A, Wm, (long)n * n, (long)n * n, (long)n * n, n, n, n, n, n, n, 1, 0, 1, 1, 1.0, 0.0, info, 1};
@@ -896,8 +903,8 @@ int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int m
         } else {
             double jit = jitter_base;
             for (int q = 1; q < attempt; ++q) jit *= 10.0;
-            hipLaunchKernelGGL(regram_failed_kernel<T>, dim3(n < 8 ? n : 8, B), dim3(256), 0, s, (const T*)z_ctx, z_div, (const T*)ls,
-                               (const T*)os, (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f, kind);
+            hipLaunchKernelGGL(regram_failed_kernel<T>, dim3(n < 8 ? n : 8, B < 32 ? B : 32), dim3(256), 0, s, (const T*)z_ctx, z_div, (const T*)ls,
+                               (const T*)os, (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f, kind, B);
         }
         if (n_valid) hipLaunchKernelGGL(dense_mask_kernel<T>, dim3(n, B), dim3(256), 0, s, A, n_valid, y_div, (const int32_t*)info, attempt, n);
         int rc = dense_chol_launch(A, resid, logp, alpha, info, 1.0, B, n, dtype, attempt, s);

@@ -51,21 +51,35 @@ template <typename T> __device__ __forceinline__ constexpr int tl_img_off(int c1
 
 // LDS: Zd images (10 blocks) | ring of nb x { Z slab: 16 rows x RS bytes | L slab: 64 rows x 128 bytes (XOR-swizzled pieces) }
 template <typename T>
-__global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, const int32_t* __restrict__ info, int n, int ring_bytes) {
-    if (info && info[blockIdx.x] < 0) return;
+__global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, const int32_t* __restrict__ info, int n, int ring_bytes,
+                                                         const T* __restrict__ u, T* __restrict__ alpha) {
+    // u / alpha (optional): alpha = Z^T u = A^-1 r on the fly -- every finished row block of Z is in registers once; the separate
+    // pass over Z that computed it (dense_alpha_kernel) read the whole inverse again: 0.28 GB and 84 us per 256 x 512^2 launch
+    if (info && info[blockIdx.x] < 0) {
+        if (alpha) for (int q = threadIdx.x; q < n; q += TL_NT) alpha[(size_t)blockIdx.x * n + q] = T(NAN);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     constexpr int ES = sizeof(T), BLK = 256 * ES;
     constexpr int KS = 16;                                        // rows of a Z slab = columns of an L slab
     constexpr int LRB = KS * ES;                                  // bytes per L slab row (128 fp64 / 64 fp32)
     using Acc = typename Mf<T>::acc;
     unsigned char* const Zdimg = sm;                              // -Z00 | +L10 | -Z11 operand images of the panel's diagonal block
-    unsigned char* const ring = sm + 10 * BLK;
+    const int npad = (n + 63) & ~63;
+    T* const uv = reinterpret_cast<T*>(sm + 10 * BLK);            // [npad] u (zero beyond n)
+    T* const al_a = uv + npad;                                    // [npad] alpha: the panels' off-diagonal rows and the inverse 32-blocks
+    T* const al_b = al_a + npad;                                  // [npad] ... the Z10 blocks (a writer of its own per entry: no races)
+    unsigned char* const ring = reinterpret_cast<unsigned char*>(al_b + npad);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     T* const Ab = A + (size_t)blockIdx.x * n * n;
     const int npan = (n + 63) >> 6;
     const bool is_helper = wave < 2;
     const int mw = wave - 2;                                      // MFMA wave 0..13
+    for (int q = tid; q < npad; q += TL_NT) {
+        uv[q] = (u && q < n) ? u[(size_t)blockIdx.x * n + q] : T(0);
+        al_a[q] = T(0); al_b[q] = T(0);
+    }
 
     // Waves 0 / 1 assemble the operand images of Z_II = [Z00 0; Z10 Z11] from what the Cholesky left (two inverse 32-blocks,
     // transposed, in the upper triangles; 1 / diagonal; L10): -Z00 | +L10 | -Z11, one 32-block and one row block of L10 each.  The
@@ -340,13 +354,18 @@ __global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, cons
             t3 = zmul(3, 3, X[3], t3);
             const Acc t2 = zmul(2, 2, X[2], z);
             X[2] = t2; X[3] = t3;                                 // R_hi = -Z11 (X_hi + L10 R_lo)
+            T part = 0;                                           // sum_i Z[i][16 qb + r] u[i] over the panel's rows held by this lane
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = c0 + 16 * ib + Mf<T>::row(g, q);
                     if (row < n) Ab[(size_t)row * n + 16 * qb + r] = X[ib][q];
+                    part = fma(X[ib][q], uv[row], part);
                 }
+            part += shfl_xor_t<T>(part, 16);
+            part += shfl_xor_t<T>(part, 32);
+            if (g == 0) al_a[16 * qb + r] += part;                // (this wave is the column block's only writer in this panel)
             }
         };
         if constexpr (!IMG) {
@@ -371,12 +390,26 @@ __global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, cons
                             if (c <= i && k0 + i < n) Ab[(size_t)(k0 + i) * n + k0 + c] = -zp[q * 64];
                         }
                     }
+                // alpha[k0 + c] += sum_i Z(h,h)[i][c] u[k0 + i]: per column block b the two row blocks, then over the 16 rows (lanes r)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        T sacc = 0;
+#pragma unroll
+                        for (int av = b; av < 2; ++av)
+                            sacc = fma(-*(reinterpret_cast<const T*>(Zdimg + tl_tri(2 * h + av, 2 * h + b) * BLK) + q * 64 + lane), uv[k0 + 16 * av + r], sacc);
+                        sacc += shfl_xor_t<T>(sacc, 1); sacc += shfl_xor_t<T>(sacc, 2);
+                        sacc += shfl_xor_t<T>(sacc, 4); sacc += shfl_xor_t<T>(sacc, 8);
+                        if (r == 0) al_a[k0 + 16 * b + Mf<T>::row(g, q)] += sacc;
+                    }
             }
             if (pm > 32) {
                 // T = L10 Z00 (A = the L10 image; B[k][c] = Z00[k][c] read out of the image of -Z00, whose element (i', c') sits at
                 // img_off(c', i')), then Z10 = (-Z11) T with T's accumulator blocks as B operands
                 {
                     const int cb = hw;
+                    T zpart = 0;
                     Acc tt[2];
 #pragma unroll
                     for (int ibr = 0; ibr < 2; ++ibr) {
@@ -404,8 +437,12 @@ __global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, cons
                         for (int q = 0; q < 4; ++q) {
                             const int row = c0 + 32 + 16 * ibp + Mf<T>::row(g, q);
                             if (row < n) Ab[(size_t)row * n + c0 + 16 * cb + r] = zz[q];
+                            zpart = fma(zz[q], uv[row], zpart);
                         }
                     }
+                    zpart += shfl_xor_t<T>(zpart, 16);
+                    zpart += shfl_xor_t<T>(zpart, 32);
+                    if (g == 0) al_b[c0 + 16 * cb + r] = zpart;
                 }
             }
         }
@@ -420,6 +457,10 @@ __global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, cons
     // (two instantiations of the panel loop: waves 0 / 1 hold twenty prefetched image entries each in registers and no accumulators,
     //  the other waves hold accumulators and no image entries -- one allocation for the union of both would spill 165 registers)
     if (wave < 2) run(std::true_type{}); else run(std::false_type{});
+    if (alpha) {
+        __syncthreads();
+        for (int q = tid; q < n; q += TL_NT) alpha[(size_t)blockIdx.x * n + q] = al_a[q] + al_b[q];
+    }
 #undef TST
 }
 
@@ -431,7 +472,7 @@ bool tl_plan(int n, int* ring_bytes, size_t* lds) {
     const int npan = (n + 63) / 64;
     const int c0max = (npan - 1) * 64;
     const size_t bmax = (size_t)16 * c0max * ES + 64 * 16 * ES;     // largest ring entry
-    size_t ring = cap - 10 * BLK;
+    size_t ring = cap - 10 * BLK - 3 * (size_t)((n + 63) & ~63) * ES;
     if (bmax > ring) return false;
     *ring_bytes = (int)ring; *lds = cap;
     return true;
@@ -444,19 +485,19 @@ bool trtri_ll_fits(int n, int dtype) {
     return dtype == PACOH_F32 ? tl_plan<float>(n, &rb, &lds) : tl_plan<double>(n, &rb, &lds);
 }
 
-// returns 1 when n is outside this kernel's plan (caller: trtri_dense_kernel)
-int trtri_ll_try(void* A, const int32_t* info, int B, int n, int dtype, hipStream_t s) {
+// returns 1 when n is outside this kernel's plan (caller: trtri_dense_kernel).  u / alpha (optional): alpha = Z^T u as well
+int trtri_ll_try(void* A, const int32_t* info, int B, int n, int dtype, hipStream_t s, const void* u, void* alpha) {
     int rb = 0; size_t lds = 0;
     if (dtype == PACOH_F32) {
         if (!tl_plan<float>(n, &rb, &lds)) return 1;
         auto kern = trtri_ll_kernel<float>;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-        hipLaunchKernelGGL(kern, dim3(B), dim3(TL_NT), lds, s, (float*)A, info, n, rb);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(TL_NT), lds, s, (float*)A, info, n, rb, (const float*)u, (float*)alpha);
     } else {
         if (!tl_plan<double>(n, &rb, &lds)) return 1;
         auto kern = trtri_ll_kernel<double>;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-        hipLaunchKernelGGL(kern, dim3(B), dim3(TL_NT), lds, s, (double*)A, info, n, rb);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(TL_NT), lds, s, (double*)A, info, n, rb, (const double*)u, (double*)alpha);
     }
     return launch_status();
 }

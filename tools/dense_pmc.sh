@@ -4,5 +4,5 @@ tag=${1:-rXX}; out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}" || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/dpmc/fetch -- python3 tools/dense_profile.py f64 4 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/dpmc/write -- python3 tools/dense_profile.py f64 4 > /dev/null 2>&1
-python tools/pmc_summary.py $out/dpmc $out/dense_pmc_hbm_traffic.json > $out/dense_pmc_hbm_traffic.txt
+python tools/pmc_summary.py $out/dpmc $out/dense_pmc_hbm_traffic.json 4 > $out/dense_pmc_hbm_traffic.txt
 rm -rf $out/dpmc; cat $out/dense_pmc_hbm_traffic.txt

@@ -10,7 +10,7 @@ import re
 import sys
 
 
-def main(src, out):
+def main(src, out, passes=0):
     acc = {}
     for path in glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True):
         with open(path) as fh:
@@ -30,14 +30,20 @@ def main(src, out):
         fk, wk = f[0] / max(1, len(f[1])), w[0] / max(1, len(w[1]))
         kernels[name] = {'FETCH_SIZE_KB': round(fk, 2), 'WRITE_SIZE_KB': round(wk, 2), 'launches': max(len(f[1]), len(w[1])),
                          'hbm_bytes_per_launch': int((2 * fk + wk) * 1024)}
+    per_pass = {}
+    if passes:      # bytes per pass of the profiled program (a kernel launched several times per pass, e.g. the jitter-ladder retries that
+                    # exit at once, is summed: what one LML + gradient evaluation of the batch moves)
+        for name, d in acc.items():
+            if 'FETCH_SIZE' in d or 'WRITE_SIZE' in d:
+                per_pass[name] = int((2 * d.get('FETCH_SIZE', [0.0])[0] + d.get('WRITE_SIZE', [0.0])[0]) * 1024 / passes)
     note = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) of `bench.py --steps 3 --warmup 1 '
             '--no-cpu-baseline`, averaged per launch; raw counters are in KB. hbm_bytes applies the gfx950 correction of '
             'MI355X_MICROARCH.md (FETCH_SIZE reports half of a wide coalesced read stream): hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.')
     with open(out, 'w') as fh:
-        json.dump({'note': note, 'kernels': kernels}, fh, indent=1)
+        json.dump({'note': note, 'kernels': kernels, 'per_pass': per_pass, 'passes': passes}, fh, indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'])[:12]:
         print('%-60s %12d B/launch' % (k[:60], v['hbm_bytes_per_launch']))
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0)
