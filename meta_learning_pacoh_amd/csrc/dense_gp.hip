@@ -21,7 +21,10 @@ namespace pacoh {
 int dense_chol_launch(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
                       int dtype, int attempt, hipStream_t stream, int u_only = 0);                  // dense.hip
 bool dense_chol_saves_inverse(int n, int dtype);                                                     // dense.hip
-int trtri_ll_try(void* A, const int32_t* info, int B, int n, int dtype, hipStream_t s, const void* u, void* alpha);            // dense_trtri_ll.hip (1: not in its plan)
+int trtri_ll_try(void* A, const int32_t* info, int B, int n, int dtype, hipStream_t s, const void* u, void* alpha);
+int dense_grad_mfma_try(const void* zs, const void* ls, const void* os, const int32_t* n_valid, int y_div, const void* g_lml,
+                        const void* alpha, const void* Wm, const int32_t* info, void* d_z, void* d_mean, int mean_mode, void* rowpart,
+                        void* scratch, size_t scratch_bytes, int B, int P, int n, int f, int kind, int dtype, hipStream_t s);   // dense_grad_mfma.hip            // dense_trtri_ll.hip (1: not in its plan)
 int gram_rbf_for_chol(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
                       int dtype, hipStream_t s, int lower);                                          // gram.hip
 
@@ -847,6 +850,11 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
         const long tz = (long)B * n * f;
         hipLaunchKernelGGL(dense_scale_kernel<T>, dim3((unsigned)((tz + 255) / 256)), dim3(256), 0, s, (const T*)z, z_div, (const T*)ls, zsc,
                            P, n, f, tz);
+        // fp64 ARD-RBF: the symmetric MFMA contraction (dense_grad_mfma.hip); its scratch is the factor's buffer, free once W = Z^T Z exists
+        static const bool gm_on = []() { const char* e = getenv("PACOH_GRAD_MFMA"); return !(e && e[0] == '0'); }();
+        const int grc = gm_on ? dense_grad_mfma_try(zsc, ls, os, n_valid, y_div, g_lml, alpha, Wm, (const int32_t*)info, d_z, d_mean, mean_mode,
+                                                    rowpart, A, nn * sizeof(T), B, P, n, f, kind, dtype, s) : 1;
+        if (grc != 0 && grc != 1) return grc;
         const int FP = f <= 2 ? 2 : (f <= 4 ? 4 : (f <= 8 ? 8 : 16));
         // 16 rows per workgroup with the coordinates staged in LDS when they fit, else 4 rows per workgroup from L1/L2
         const size_t glds = ((size_t)n * f + n) * sizeof(T);
@@ -865,7 +873,7 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
             (const T*)zsc, (const T*)ls, (const T*)os, n_valid, y_div, (const T*)g_lml, (const T*)alpha, (const T*)Wm, \
             (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f, rows, kind); \
         break;
-        switch (FP) { PACOH_DG_CASE(2) PACOH_DG_CASE(4) PACOH_DG_CASE(8) default: PACOH_DG_CASE(16) }
+        if (grc == 1) switch (FP) { PACOH_DG_CASE(2) PACOH_DG_CASE(4) PACOH_DG_CASE(8) default: PACOH_DG_CASE(16) }
 #undef PACOH_DG_CASE
     }
     hipLaunchKernelGGL(dense_finish_kernel<T>, dim3(B), dim3(64), 0, s, (const T*)logp, (const T*)rowpart, (const T*)ls, n_valid,

@@ -1,0 +1,254 @@
+// Gradient contractions of the large-context path on the matrix cores, fp64, ARD-RBF, f <= 8 (round 4).
+//
+//   G = (alpha alpha^T - W) / 2n,  M = G o (os K),   d_z_i = sum_j M_ij (z_j - z_i),   d_os = sum_ij G_ij K_ij / os,  d_noise = sum_i G_ii
+//
+// dense_grad_cols_kernel evaluated every ORDERED pair (i, j) on the vector units: eight coordinate differences, an fp64 exp of
+// ~25 instructions and eight more fmas per pair -- 0.33 ms per 256 x 512^2 launch, bound by the fp64 vector rate.  Here
+//   * M is symmetric, so only the tiles on and below the block diagonal are evaluated (half the exps, half of W read): a 64 x 64
+//     tile (I, J), J < I, feeds the rows of I with M Z_J and the rows of J with M^T Z_I;
+//   * the squared distances come from ONE MFMA product per 16 x 16 block (|z_i|^2 + |z_j|^2 - 2 z_i . z_j; fp64: the
+//     cancellation costs ~1e-16 |z|^2, far below the path's 1e-8 parity bar -- fp32 keeps the direct differences of the old kernel),
+//     and both contractions with the coordinates are MFMA products as well: the accumulator block of M is directly the A operand
+//     of M^T Z_I (register index = k), and goes through a 16 x 17 LDS scratch once for M Z_J.  A column of ones appended to the
+//     coordinate images delivers the row / column sums of M (the -z_i sum_j M_ij term and d_os) from the same products.
+// Per tile and wave: 40 MFMAs and 64 exps per lane, where the vector kernel spent ~3500 fp64 instructions per lane.
+// One workgroup per (problem, row block I), four waves = the four 16-column strips of a tile.  The column-side sums of the tiles
+// J < I land in a partial buffer [problem][tile][64][9] and are added in fixed order by dense_grad_combine_kernel (deterministic).
+// Reference: the backward of ExactMarginalLogLikelihood through the RBF kernel (meta_learn/random_gp.py:83-85, models.py:428-446).
+#include "common.h"
+#include "dense_diag.h"
+
+namespace pacoh {
+namespace {
+
+constexpr int GT = 64;               // tile edge
+constexpr int GZL = 17;              // leading dimension of the coordinate images [64][16 (+1)]: 8 coordinates | 1 | zeros
+using Acc = f64x4_t;
+
+__device__ __forceinline__ int gm_row(int g, int q) { return g + 4 * q; }      // fp64 16x16x4 accumulator row = k index of step q
+
+// a - b * c with the product ROUNDED first (no fused multiply-add): sum_j M_ij z_j - z_i sum_j M_ij is exactly zero for a task of one
+// point (and for coincident points) only if both products are rounded alike -- the direct-difference kernel returned exact zeros there
+__device__ __forceinline__ double sub_rounded_product(double a, double b, double c) {
+#pragma clang fp contract(off)
+    const double p = b * c;
+    return a - p;
+}
+
+__device__ __forceinline__ int clamp_nv2(const int32_t* n_valid, long ty, int n) {
+    int nv = n_valid ? n_valid[ty] : n;
+    nv = nv < n ? nv : n;
+    return nv < 0 ? 0 : nv;
+}
+
+// number of tiles (I, J), J < I, in front of row block I
+__host__ __device__ inline int tiles_before(int I) { return I * (I - 1) / 2; }
+
+__global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* __restrict__ zs, const double* __restrict__ osp,
+                                                              const int32_t* __restrict__ n_valid, int y_div,
+                                                              const double* __restrict__ alpha, const double* __restrict__ Wm,
+                                                              const int32_t* __restrict__ info, double* __restrict__ rowside,
+                                                              double* __restrict__ colpart, double* __restrict__ gdiag, int P, int n,
+                                                              int f) {
+    __shared__ double ZI[GT][GZL], ZJ[2][GT][GZL], n2I[GT], n2J[2][GT], aI[GT], aJ[2][GT];
+    __shared__ double Tr[4][16][17];
+    __shared__ double Rows[GT][GZL];
+    const long b = blockIdx.y;
+    const int I = blockIdx.x, I0 = I * GT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int nI = (n + GT - 1) / GT;
+    if (info[b] < 0) return;                               // (the combine kernel writes the NaNs)
+    const int nv = clamp_nv2(n_valid, b / y_div, n);
+    const double os = osp ? osp[b % P] : 1.0;
+    const double inv2n = nv > 0 ? 0.5 / (double)nv : 0.0;
+    const double* zb = zs + b * (long)n * f;
+    const double* ab = alpha + b * (long)n;
+    const double* Wb = Wm + b * (long)n * n;
+
+    auto stage = [&](double (*Z)[GZL], double* n2, double* al, int R0) {
+        // rows R0 .. R0 + 64 of the scaled coordinates: [c < f] coordinates, [8] = 1, rest 0; rows beyond nv: all zero (no weight)
+        for (int e = tid; e < GT * 16; e += 256) {
+            const int i = e >> 4, c = e & 15;
+            const int row = R0 + i;
+            double v = 0.0;
+            if (row < nv) v = c < f ? zb[(long)row * f + c] : (c == 8 ? 1.0 : 0.0);
+            Z[i][c] = v;
+        }
+        if (tid < GT) {
+            const int row = R0 + tid;
+            double s = 0.0;
+            if (row < nv) for (int c = 0; c < f; ++c) { const double v = zb[(long)row * f + c]; s = fma(v, v, s); }
+            n2[tid] = s;
+            al[tid] = row < nv ? ab[row] : 0.0;
+        }
+    };
+    stage(ZI, n2I, aI, I0);
+    stage(ZJ[0], n2J[0], aJ[0], 0);
+    Acc rowacc[4];
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) rowacc[ib] = Acc{0, 0, 0, 0};
+    const int j = 16 * w + r;                              // this lane's column inside a tile
+    // this lane's entries of W for one 16 x 16 block: unconditional loads at clamped addresses, requested one block ahead
+    auto load_w = [&](int J0, int ib, double (&wv)[4]) __attribute__((always_inline)) {
+        const int jc = J0 + j < n ? J0 + j : n - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ic = I0 + 16 * ib + gm_row(g, q);
+            wv[q] = Wb[(long)(ic < n ? ic : n - 1) * n + jc];
+        }
+    };
+
+    for (int J = 0; J <= I; ++J) {
+        const int J0 = J * GT, cur = J & 1;
+        __syncthreads();                                   // tile J's coordinates are staged; the other buffer's readers are done
+        if (J < I) stage(ZJ[cur ^ 1], n2J[cur ^ 1], aJ[cur ^ 1], J0 + GT);      // next tile's coordinates fly under this tile's work
+        double (*Zj)[GZL] = ZJ[cur];
+        const double* n2j = n2J[cur];
+        const double* aj = aJ[cur];
+        const bool diag = J == I;
+        Acc oj = {0, 0, 0, 0};
+        double wv[2][4];
+        load_w(J0, 0, wv[0]);
+        // one 16 x 16 block of the tile at a time (the four blocks of M need not be alive together: 128 registers, 4 waves per SIMD)
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            if (ib < 3) load_w(J0, ib + 1, wv[(ib + 1) & 1]);
+            Acc s = {0, 0, 0, 0};
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+                s = __builtin_amdgcn_mfma_f64_16x16x4f64(ZI[16 * ib + r][4 * st + g], Zj[16 * w + r][4 * st + g], s, 0, 0, 0);
+            Acc M;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * ib + gm_row(g, q);
+                const bool ok = I0 + i < nv && J0 + j < nv;
+                double d2 = n2I[i] + n2j[j] - 2.0 * s[q];
+                d2 = d2 > 0.0 ? d2 : 0.0;
+                const double e = rbf_exp<double>(-0.5 * d2);
+                const double G = ok ? (aI[i] * aj[j] - wv[ib & 1][q]) * inv2n : 0.0;
+                if (diag && i == j && ok) gdiag[b * (long)n + I0 + i] = G;
+                M[q] = G * os * e;
+            }
+            // rows of J <- M^T [Z_I | 1] (tiles below the block diagonal only): the accumulator block of M as A operand = its transpose
+            if (!diag) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+                    oj = __builtin_amdgcn_mfma_f64_16x16x4f64(M[st], ZI[16 * ib + gm_row(g, st)][r], oj, 0, 0, 0);
+            }
+            // rows of I <- M [Z_J | 1]: M's block through the wave's 16 x 17 scratch (A operand = M itself)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Tr[w][gm_row(g, q)][r] = M[q];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+                rowacc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(Tr[w][r][gm_row(g, st)], Zj[16 * w + gm_row(g, st)][r], rowacc[ib], 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!diag) {
+            // oj: lane (r, g) register q = sum_i M[i][jj] [Z_I | 1][i][c = r], jj = 16 w + row(g, q)
+            double* cp = colpart + ((b * (long)(nI * (nI - 1) / 2) + tiles_before(I) + J) * GT) * 9;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int jj = 16 * w + gm_row(g, q);
+                const double cs = __shfl(oj[q], 16 * g + 8, 64);          // column sum of M (the ones column, c = 8)
+                if (r < 8) cp[(long)jj * 9 + r] = sub_rounded_product(oj[q], Zj[jj][r], cs);
+                else if (r == 8) cp[(long)jj * 9 + 8] = cs;
+            }
+        }
+    }
+    // the four strips' row sums, added in wave order (fixed: deterministic)
+    for (int ww = 0; ww < 4; ++ww) {
+        __syncthreads();
+        if (w == ww) {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double* p = &Rows[16 * ib + gm_row(g, q)][r];
+                    *p = (ww == 0 ? 0.0 : *p) + rowacc[ib][q];
+                }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < GT * 9; e += 256) {
+        const int i = e / 9, c = e - i * 9;
+        if (I0 + i < n) rowside[(b * (long)n + I0 + i) * 9 + c] = c < 8 ? sub_rounded_product(Rows[i][c], ZI[i][c], Rows[i][8]) : Rows[i][8];
+    }
+}
+
+// per row: the row-side sums + the column-side partial sums of the tiles below it (fixed order), then the outputs of
+// dense_grad_cols_kernel: d_z, d_mean, rowpart = {lengthscale terms, d_os term, G_ii, alpha_i}
+__global__ void __launch_bounds__(256) dense_grad_combine_kernel(const double* __restrict__ zs, const double* __restrict__ lsp,
+                                                                 const double* __restrict__ osp, const int32_t* __restrict__ n_valid,
+                                                                 int y_div, const double* __restrict__ g_lml,
+                                                                 const double* __restrict__ alpha, const int32_t* __restrict__ info,
+                                                                 const double* __restrict__ rowside, const double* __restrict__ colpart,
+                                                                 const double* __restrict__ gdiag, double* __restrict__ d_z,
+                                                                 double* __restrict__ d_mean, int mean_mode, double* __restrict__ rowpart,
+                                                                 int P, int n, int f) {
+    const long b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int p = (int)(b % P);
+    const int nv = clamp_nv2(n_valid, b / y_div, n);
+    const bool failed = info[b] < 0;
+    const double gup = g_lml ? g_lml[b] : 1.0;
+    const int W3 = f + 3;
+    double* rp = rowpart + (b * n + i) * (long)W3;
+    if (failed || i >= nv) {
+        const double v = failed ? (double)NAN : 0.0;
+        if (d_z) for (int c = 0; c < f; ++c) d_z[(b * n + i) * (long)f + c] = v;
+        if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = v;
+        for (int c = 0; c < W3; ++c) rp[c] = v;
+        return;
+    }
+    const int nI = (n + GT - 1) / GT, Ji = i / GT, il = i - Ji * GT;
+    double acc[9];
+    for (int c = 0; c < 9; ++c) acc[c] = rowside[(b * (long)n + i) * 9 + c];
+    for (int I = Ji + 1; I < nI; ++I) {
+        const double* cp = colpart + ((b * (long)(nI * (nI - 1) / 2) + tiles_before(I) + Ji) * GT + il) * 9;
+        for (int c = 0; c < 9; ++c) acc[c] += cp[c];
+    }
+    const double os = osp ? osp[p] : 1.0;
+    const double* zb = zs + b * (long)n * f;
+    for (int c = 0; c < f; ++c) {
+        if (d_z) d_z[(b * n + i) * (long)f + c] = 2.0 * gup * acc[c] / lsp[(long)p * f + c];
+        rp[c] = -2.0 * (zb[(long)i * f + c] - zb[c]) * acc[c];        // (lengthscale sums from the finished d_z sums, as dense_grad_cols_kernel)
+    }
+    const double ai = alpha[b * (long)n + i];
+    rp[f] = acc[8] / os;                                   // sum_j G_ij K_ij / os = sum_j M_ij / os
+    rp[f + 1] = gdiag[b * (long)n + i];
+    rp[f + 2] = ai;
+    if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = gup * ai / (double)nv;
+}
+
+}  // namespace
+
+// scratch the two kernels need (bytes): rowside [B][n][9] | column-side partials [B][tiles][64][9] | G_ii [B][n]
+size_t dense_grad_mfma_scratch(int B, int n) {
+    const size_t nI = (n + GT - 1) / GT;
+    return ((size_t)B * n * 9 + (size_t)B * (nI * (nI - 1) / 2) * GT * 9 + (size_t)B * n) * sizeof(double);
+}
+
+// fp64, ARD-RBF, f <= 8: the MFMA contraction; returns 1 when outside its plan (caller: dense_grad_cols / rows kernels)
+int dense_grad_mfma_try(const void* zs, const void* ls, const void* os, const int32_t* n_valid, int y_div, const void* g_lml,
+                        const void* alpha, const void* Wm, const int32_t* info, void* d_z, void* d_mean, int mean_mode, void* rowpart,
+                        void* scratch, size_t scratch_bytes, int B, int P, int n, int f, int kind, int dtype, hipStream_t s) {
+    if (dtype != PACOH_F64 || kind != PACOH_KERNEL_RBF || f > 8 || n < GT) return 1;
+    if (dense_grad_mfma_scratch(B, n) > scratch_bytes) return 1;
+    const int nI = (n + GT - 1) / GT;
+    double* rowside = (double*)scratch;
+    double* colpart = rowside + (size_t)B * n * 9;
+    double* gdiag = colpart + (size_t)B * ((size_t)nI * (nI - 1) / 2) * GT * 9;
+    hipLaunchKernelGGL(dense_grad_tile_kernel, dim3(nI, B), dim3(256), 0, s, (const double*)zs, (const double*)os, n_valid, y_div,
+                       (const double*)alpha, (const double*)Wm, info, rowside, colpart, gdiag, P, n, f);
+    hipLaunchKernelGGL(dense_grad_combine_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, (const double*)zs, (const double*)ls,
+                       (const double*)os, n_valid, y_div, (const double*)g_lml, (const double*)alpha, info, rowside, colpart, gdiag,
+                       (double*)d_z, (double*)d_mean, mean_mode, (double*)rowpart, P, n, f);
+    return launch_status();
+}
+
+}  // namespace pacoh
