@@ -216,7 +216,7 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         if self._pipelined:
             self._feed.pipeline(self.tasks, self.engine, self.particles)
         # median bandwidth computed beside the hyper-parameter reduction instead of inside the update (P <= 64: one wavefront's sort)
-        self._bw_ahead = self._pipelined and self.bandwidth is None and P <= 64 and os.environ.get('PACOH_SVGD_BW_AHEAD', '1') != '0'
+        self._bw_ahead = self._pipelined and self.bandwidth is None and P <= 64
 
     def _body_likelihood(self):
         """score[P,D] = d/d theta_p sum_t mll[t,p] over this rank's tasks (unscaled), lik[P] the sums themselves"""

@@ -372,19 +372,53 @@ __global__ void __launch_bounds__(256) bgemm_kernel(GemmArgs ga) {
 // holds a 64 x 64 sub-tile as 4 x 4 accumulator blocks.  Against the direct-from-L2 bgemm_kernel above (one wave per 32 x 32
 // tile, every wave fetching its own operands: ~55 B/clk/CU of L2 traffic, the kernel's bound) this moves 4x fewer bytes per MFMA.
 // k runs from the tile's first row (Z[k][i] = 0 for k < i) to n.  Tiles above the diagonal are mirrored from below.
+// Round 4: (a) the blocks a wave multiplies in a slab are a compile-time mask (ztz_slab<MASK>: the rows the slab has reached x the
+// wave's pattern in a diagonal tile) instead of sixteen tested bits around sixteen MFMAs; (b) slabs below the tile's own diagonal
+// range are staged by 16-byte loads without the triangle test; (c) the tiles of one matrix run on ONE XCD (workgroup ids are dealt
+// round-robin to the eight XCDs, each with its own L2: with a plain (tile, matrix) grid the ten tiles of a matrix fetched the same
+// rows of Z from HBM up to eight times).
+template <typename T, unsigned MASK, int LDT>
+__device__ __forceinline__ void ztz_slab(const T (*__restrict__ Asb)[LDT], const T (*__restrict__ Bsb)[LDT], typename Mf<T>::acc (&acc)[4][4],
+                                         int ca, int cb, int g) {
+    constexpr unsigned rows = ((MASK & 0xFu) ? 1u : 0u) | ((MASK & 0xF0u) ? 2u : 0u) | ((MASK & 0xF00u) ? 4u : 0u) | ((MASK & 0xF000u) ? 8u : 0u);
+    constexpr unsigned cols = (MASK | MASK >> 4 | MASK >> 8 | MASK >> 12) & 0xFu;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        T av[4], bv[4];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) if (rows >> ib & 1u) av[ib] = Asb[4 * g + s][ca + 32 * ib];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) if (cols >> jb & 1u) bv[jb] = Bsb[4 * g + s][cb + 32 * jb];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+                if (MASK >> (4 * ib + jb) & 1u) acc[ib][jb] = Mf<T>::mma(av[ib], bv[jb], acc[ib][jb]);
+    }
+}
+
 template <typename T>
-__global__ void __launch_bounds__(256, 2) ztz_kernel(const T* __restrict__ Zall, T* __restrict__ Wall, int n, const int32_t* __restrict__ info) {
+__global__ void __launch_bounds__(256, 2) ztz_kernel(const T* __restrict__ Zall, T* __restrict__ Wall, int n, const int32_t* __restrict__ info,
+                                                     int nt, int Bn) {
     using Acc = typename Mf<T>::acc;
     constexpr int TS = 128, KS = 16, LDT = TS + 4;
+    constexpr int VE = 16 / (int)sizeof(T);                        // elements per 16-byte chunk
+    typedef T VT __attribute__((ext_vector_type(VE)));
     __shared__ __attribute__((aligned(16))) T As[2][KS][LDT];
     __shared__ __attribute__((aligned(16))) T Bs[2][KS][LDT];
-    const int b = blockIdx.y;
+    // workgroup id -> (matrix, tile): ids L, L + 8, L + 16, ... (one XCD) walk the tiles of one matrix
+    int b, tile;
+    {
+        const int L = blockIdx.x, B8 = Bn & ~7;
+        if (L < nt * B8) { const int slot = L >> 3; b = (L & 7) + 8 * (slot / nt); tile = slot % nt; }
+        else { const int Lr = L - nt * B8; b = B8 + Lr / nt; tile = Lr % nt; }
+    }
     if (info && info[b] < 0) return;
     // lower-triangle tile index -> (tm, tn), tn <= tm
-    int tm = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
-    while (tm * (tm + 1) / 2 > (int)blockIdx.x) --tm;
-    while ((tm + 1) * (tm + 2) / 2 <= (int)blockIdx.x) ++tm;
-    const int tn = blockIdx.x - tm * (tm + 1) / 2;
+    int tm = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+    while (tm * (tm + 1) / 2 > tile) --tm;
+    while ((tm + 1) * (tm + 2) / 2 <= tile) ++tm;
+    const int tn = tile - tm * (tm + 1) / 2;
     const int i0 = tm * TS, j0 = tn * TS;
     const T* Z = Zall + (long)b * n * n;
     T* W = Wall + (long)b * n * n;
@@ -394,36 +428,55 @@ __global__ void __launch_bounds__(256, 2) ztz_kernel(const T* __restrict__ Zall,
     // (row blocks wr, wr+2, wr+4, wr+6; column blocks wc, wc+2, ...).  Interleaved, not a 64 x 64 quadrant: Z is lower triangular,
     // a row block contributes only from the slab that reaches its first row on, and in a diagonal tile the blocks above the
     // diagonal are never stored -- with quadrants the wave holding the top-left one did every MFMA and paced the workgroup
-    // (0.61 -> 0.55 ms by skipping in the others); interleaved, all four skip alike
+    // (0.61 -> 0.55 ms by skipping in the others); interleaved, all four skip alike.  In a diagonal tile block (ib, jb) is on or
+    // below the diagonal iff wc + 2 jb <= wr + 2 ib: jb <= ib for three of the waves, jb < ib for wave (0, 1).
     const int wr = wave >> 1, wc = wave & 1;
+    const int pat = tm != tn ? 0 : (wr == 0 && wc == 1 ? 2 : 1);
     Acc acc[4][4];
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = Acc{0, 0, 0, 0};
-    unsigned need = 0;                                             // bit 4 ib + jb: block (ib, jb) is on or below the diagonal
+    // staging: a slab operand is KS rows of TS elements = KS * CPR 16-byte chunks; thread t moves chunks t, t + 256, ...: a wave
+    // reads and writes one whole row segment per instruction (1 KiB contiguous in HBM, conflict-free in LDS; the first version gave
+    // each thread eight consecutive elements of a row -- its LDS writes were 4-way bank-conflicted: SQ_LDS_BANK_CONFLICT three
+    // times SQ_ACTIVE_INST_LDS)
+    constexpr int CPR = TS / VE, NCH = KS * CPR / 256;
+    const bool vec_ok = ((long)n * sizeof(T)) % 16 == 0 && i0 + TS <= n;     // (j0 + TS <= i0 + TS)
+    auto load_slab = [&](int k0, VT (&ra)[NCH], VT (&rb)[NCH]) __attribute__((always_inline)) {
+        if (vec_ok && k0 >= i0 + TS) {                             // below the tile's diagonal range: whole rows, no triangle
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib)
+            for (int v = 0; v < NCH; ++v) {
+                const int c = (int)threadIdx.x + 256 * v, k = k0 + c / CPR, col = (c % CPR) * VE;
+                const int kc = k < n ? k : n - 1;
+                const VT xa = *(const VT*)(Z + (long)kc * n + i0 + col), xb = *(const VT*)(Z + (long)kc * n + j0 + col);
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
-            if (tm != tn || wc + 2 * jb <= wr + 2 * ib) need |= 1u << (4 * ib + jb);
-    // staging: thread t loads slab row t / 16, columns 8 * (t % 16) .. + 8 of both operands
-    const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 8;
-    auto load_slab = [&](int k0, T (&ra)[8], T (&rb)[8]) {
-        const int k = k0 + lr;
+                for (int e = 0; e < VE; ++e) { ra[v][e] = k < n ? xa[e] : T(0); rb[v][e] = k < n ? xb[e] : T(0); }
+            }
+            return;
+        }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int ci = i0 + lc + q, cj = j0 + lc + q;
-            ra[q] = (k < n && ci < n && ci <= k) ? Z[(long)k * n + ci] : T(0);
-            rb[q] = (k < n && cj < n && cj <= k) ? Z[(long)k * n + cj] : T(0);
+        for (int v = 0; v < NCH; ++v) {
+            const int c = (int)threadIdx.x + 256 * v, k = k0 + c / CPR, col = (c % CPR) * VE;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const int ci = i0 + col + e, cj = j0 + col + e;
+                ra[v][e] = (k < n && ci < n && ci <= k) ? Z[(long)k * n + ci] : T(0);
+                rb[v][e] = (k < n && cj < n && cj <= k) ? Z[(long)k * n + cj] : T(0);
+            }
         }
     };
-    auto store_slab = [&](int buf, const T (&ra)[8], const T (&rb)[8]) {
+    auto store_slab = [&](int buf, const VT (&ra)[NCH], const VT (&rb)[NCH]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { As[buf][lr][lc + q] = ra[q]; Bs[buf][lr][lc + q] = rb[q]; }
+        for (int v = 0; v < NCH; ++v) {
+            const int c = (int)threadIdx.x + 256 * v, row = c / CPR, col = (c % CPR) * VE;
+            *(VT*)&As[buf][row][col] = ra[v];
+            *(VT*)&Bs[buf][row][col] = rb[v];
+        }
     };
     const int kbeg = i0;                                           // (i0 >= j0: rows above the tile's first row contribute nothing)
-    T ra[8], rb[8];
+    const int ca = 16 * wr + r, cb = 16 * wc + r;
+    VT ra[NCH], rb[NCH];
     load_slab(kbeg, ra, rb);
     store_slab(0, ra, rb);
     __syncthreads();
@@ -431,26 +484,20 @@ __global__ void __launch_bounds__(256, 2) ztz_kernel(const T* __restrict__ Zall,
     for (int k0 = kbeg; k0 < n; k0 += KS) {
         const bool more = k0 + KS < n;
         if (more) load_slab(k0 + KS, ra, rb);                      // global loads of the next slab fly under this slab's MFMAs
-        // row blocks this slab reaches (slab rows k0 .. k0+15 against the block's first row i0 + 16 (wr + 2 ib)): a prefix
-        const int reach = (k0 + KS - 1 - i0) / 16;                 // last block row of the tile with a nonzero in this slab
-        unsigned live = 0;
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib) if (wr + 2 * ib <= reach) live |= (need >> (4 * ib) & 15u) << (4 * ib);
-        if (live) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                T av[4], bv[4];
-#pragma unroll
-                for (int ib = 0; ib < 4; ++ib) av[ib] = As[buf][4 * g + s][16 * (wr + 2 * ib) + r];
-#pragma unroll
-                for (int jb = 0; jb < 4; ++jb) bv[jb] = Bs[buf][4 * g + s][16 * (wc + 2 * jb) + r];
-#pragma unroll
-                for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-                    for (int jb = 0; jb < 4; ++jb)
-                        if (live >> (4 * ib + jb) & 1u) acc[ib][jb] = Mf<T>::mma(av[ib], bv[jb], acc[ib][jb]);
-            }
+        // row blocks this slab reaches (slab rows k0 .. k0+15 against the block's first row i0 + 16 (wr + 2 ib)): a prefix of nl
+        const int reach = (k0 - i0) / 16 - wr;
+        const int nl = reach < 0 ? 0 : (reach >= 6 ? 4 : reach / 2 + 1);
+#define PACOH_ZTZ(M) ztz_slab<T, M, LDT>(As[buf], Bs[buf], acc, ca, cb, g)
+#define PACOH_ZTZ_NL(F, TRI, STR) do { if (pat == 0) PACOH_ZTZ(F); else if (pat == 1) PACOH_ZTZ(TRI); else PACOH_ZTZ(STR); } while (0)
+        switch (nl) {
+            case 4: PACOH_ZTZ_NL(0xFFFFu, 0xF731u, 0x7310u); break;
+            case 3: PACOH_ZTZ_NL(0x0FFFu, 0x0731u, 0x0310u); break;
+            case 2: PACOH_ZTZ_NL(0x00FFu, 0x0031u, 0x0010u); break;
+            case 1: if (pat == 0) PACOH_ZTZ(0x000Fu); else if (pat == 1) PACOH_ZTZ(0x0001u); break;
+            default: break;
         }
+#undef PACOH_ZTZ_NL
+#undef PACOH_ZTZ
         if (more) store_slab(buf ^ 1, ra, rb);
         __syncthreads();
         buf ^= 1;
@@ -471,14 +518,13 @@ __global__ void __launch_bounds__(256, 2) ztz_kernel(const T* __restrict__ Zall,
 
 template <typename T>
 void launch_ztz(const T* Z, T* W, int n, const int32_t* info, int Bn, hipStream_t s) {
-    const int t = (n + 127) / 128;
-    hipLaunchKernelGGL(ztz_kernel<T>, dim3(t * (t + 1) / 2, Bn), dim3(256), 0, s, Z, W, n, info);
+    const int t = (n + 127) / 128, nt = t * (t + 1) / 2;
+    hipLaunchKernelGGL(ztz_kernel<T>, dim3((unsigned)(nt * Bn)), dim3(256), 0, s, Z, W, n, info, nt, Bn);
 }
 
 template <typename T>
 void launch_bgemm(const GemmArgs& ga, int Bn, hipStream_t s) {
-    static const bool tiled = []() { const char* e = getenv("PACOH_ZTZ_TILED"); return !(e && e[0] == '0'); }();
-    if (tiled && ga.A == ga.B && ga.transA && !ga.transB && ga.lowerA && ga.lowerB && ga.symC && ga.M == ga.N && ga.M == ga.K &&
+    if (ga.A == ga.B && ga.transA && !ga.transB && ga.lowerA && ga.lowerB && ga.symC && ga.M == ga.N && ga.M == ga.K &&
         ga.lda == ga.M && ga.ldb == ga.M && ga.ldc == ga.M && ga.alpha == 1.0 && ga.beta == 0.0 && ga.M >= 128) {
         launch_ztz<T>((const T*)ga.A, (T*)ga.C, ga.M, ga.info, Bn, s);
         return;
@@ -860,9 +906,8 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
         const size_t glds = ((size_t)n * f + n) * sizeof(T);
         const bool use_lds = glds <= 60u * 1024u;
         const int rows = use_lds ? 16 : 4;
-        static const bool cols_on = []() { const char* e = getenv("PACOH_GRAD_COLS"); return !(e && e[0] == '0'); }();
 #define PACOH_DG_CASE(fp) case fp: \
-        if (use_lds && cols_on && glds + 3 * 64 * (2 * fp + 2) * sizeof(T) <= 64u * 1024u) \
+        if (use_lds && glds + 3 * 64 * (2 * fp + 2) * sizeof(T) <= 64u * 1024u) \
             hipLaunchKernelGGL((dense_grad_cols_kernel<T, fp>), dim3((n + 63) / 64, B), dim3(256), glds + 3 * 64 * (2 * fp + 2) * sizeof(T), s, \
             (const T*)zsc, (const T*)ls, (const T*)os, n_valid, y_div, (const T*)g_lml, (const T*)alpha, (const T*)Wm, \
             (const int32_t*)info, (T*)d_z, (T*)d_mean, mean_mode, rowpart, P, n, f, kind); \

@@ -105,9 +105,6 @@ __device__ __forceinline__ float wave_sum_(float v) {
 // into NaN (rsq), a zero pivot into infinity, which is also how the caller notices the failure.
 // What is NOT computed: the entries of L above the 4-column panel being eliminated are left as they fall out of the
 // substitution (garbage): they only ever produce rows of L Z that have been consumed already.
-#ifndef PACOH_F16_LDS
-#define PACOH_F16_LDS 2
-#endif
 // fs: 128 floats of per-wave LDS.  The four registers of the lane row g == k (rows 4k..4k+3 of the block, one column per lane) have
 // to reach all four lane rows twice per step (the panel rows of C, then the fresh rows of Z).  As four ds_bpermute each that is
 // 8 x 24 issue cycles per step (tools/valu_rates.hip); as one 16-lane ds_write_b128 + one ds_read_b128 (the four lanes of equal r
@@ -122,33 +119,16 @@ __device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const
         // pivot block P[c][j] = C[4k+c][4k+j] = register c of lane (r = 4k+j, g = k): wave-uniform
         const float c0 = Cn[0], c1 = Cn[1], c2 = Cn[2], c3 = Cn[3];
         const int src = (16 * k + r) * 4;
-#if PACOH_F16_LDS >= 1
         if (g == k) *reinterpret_cast<f32x4*>(fs + 4 * r) = Cn;
         asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
         const f32x4 rtv = *reinterpret_cast<const f32x4*>(fs + 4 * r);
         const float rt0 = -rtv[0], rt1 = -rtv[1], rt2 = -rtv[2], rt3 = -rtv[3];
-#else
-        // rt[c] = C[4k+c][r] = register c of lane (r, g = k)
-        const float rt0 = -__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c0)));
-        const float rt1 = -__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c1)));
-        const float rt2 = -__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c2)));
-        const float rt3 = -__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(c3)));
-#endif
-#if PACOH_F16_LDS >= 2
         const f32x4 pc0 = *reinterpret_cast<const f32x4*>(fs + 16 * k), pc1 = *reinterpret_cast<const f32x4*>(fs + 16 * k + 4);
         const f32x4 pc2 = *reinterpret_cast<const f32x4*>(fs + 16 * k + 8), pc3 = *reinterpret_cast<const f32x4*>(fs + 16 * k + 12);
         const float p00 = -pc0[0], p10 = -pc0[1], p20 = -pc0[2], p30 = -pc0[3];
         const float p11 = -pc1[1], p21 = -pc1[2], p31 = -pc1[3];
         const float p22 = -pc2[2], p32 = -pc2[3], p33 = -pc3[3];
-#else
-        const int l0 = 20 * k;
-        const float p00 = -readlane_(c0, l0), p10 = -readlane_(c1, l0), p20 = -readlane_(c2, l0), p30 = -readlane_(c3, l0);
-        const float p11 = -readlane_(c1, l0 + 1), p21 = -readlane_(c2, l0 + 1), p31 = -readlane_(c3, l0 + 1);
-        const float p22 = -readlane_(c2, l0 + 2), p32 = -readlane_(c3, l0 + 2), p33 = -readlane_(c3, l0 + 3);
-#endif
-#if PACOH_F16_LDS >= 1
         asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
-#endif
         const float r0 = __builtin_amdgcn_rsqf(p00);
         const float l10 = p10 * r0, l20 = p20 * r0, l30 = p30 * r0;
         const float q11 = fmaf(-l10, l10, p11);
@@ -181,18 +161,11 @@ __device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const
             // Tn += L[:, 4k..4k+3] Z[4k..4k+3, :]: ONE MFMA (k index = the four new columns) -- A[i][kk] = L[i][4k+kk] is xg of lane
             // (i, kk); B[kk][j] = Z[4k+kk][j] lives in register kk of lane (j, k) and reaches lane (j, kk) by four lane reads.  (Forming
             // the block row of L Z as a full product with L^T kept in registers took four MFMAs per step for a 4-row result.)
-#if PACOH_F16_LDS >= 1
             if (g == k) *reinterpret_cast<f32x4*>(fs + 64 + 4 * r) = Z;
             asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
             const f32x4 wv = *reinterpret_cast<const f32x4*>(fs + 64 + 4 * r);
             asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
             const float w0 = wv[0], w1 = wv[1], w2 = wv[2], w3 = wv[3];
-#else
-            const float w0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(Z[0])));
-            const float w1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(Z[1])));
-            const float w2 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(Z[2])));
-            const float w3 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(Z[3])));
-#endif
             const float zb = g == 0 ? w0 : (g == 1 ? w1 : (g == 2 ? w2 : w3));
             Tn = mfma_(xg, zb, Tn);
         }
@@ -346,10 +319,6 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
             // negated operand Vn = -L_KK^-T.
             factor16(U[uidx(NB, K, K)], Zd[K], dprod, nId, r, g, fsc);
             SCHED_FENCE();
-#ifndef PACOH_VN_LDS
-#define PACOH_VN_LDS 1
-#endif
-#if PACOH_VN_LDS
             // -L_KK^-T: the block transposed through 1.25 KB of LDS (4 dword writes + 4 dword reads, the conflict-free skewed
             // stride-17 layout of mlp_fused.hip's f_turn) instead of a product with the -identity block (4 MFMAs = 128 of the
             // issue cycles the matrix cores and the vector units share)
@@ -363,9 +332,6 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
                 for (int q = 0; q < 4; ++q) Vn[q] = tsc[trd + q];
                 WSYNC();
             }
-#else
-            const f32x4 Vn = mmT(Zd[K], nId, f32x4{0.f, 0.f, 0.f, 0.f});             // -L_KK^-T
-#endif
 #pragma unroll
             for (int J = K + 1; J < NB; ++J) U[uidx(NB, K, J)] = mmT(Vn, U[uidx(NB, K, J)], f32x4{0.f, 0.f, 0.f, 0.f});   // R[K][J] = L_KK^-1 A[K][J]
             SCHED_FENCE();

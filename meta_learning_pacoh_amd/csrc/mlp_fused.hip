@@ -253,22 +253,11 @@ __device__ __forceinline__ void f_wgrad(f32x4& acc, const f32x4& Ap, const f32x4
     acc = fmfma(Ap[2], Bp[2], acc); acc = fmfma(Ap[3], Bp[3], acc);
 }
 
-#ifndef PACOH_STASH_NT
-#define PACOH_STASH_NT 1
-#endif
 __device__ __forceinline__ void stash_st(const f32x4& v, f32x4* q) {
-#if PACOH_STASH_NT & 1
     __builtin_nontemporal_store(v, q);
-#else
-    *q = v;
-#endif
 }
 __device__ __forceinline__ f32x4 stash_ld(const f32x4* q) {
-#if PACOH_STASH_NT & 2
-    return __builtin_nontemporal_load(q);
-#else
     return *q;
-#endif
 }
 
 template <int PB>
@@ -639,14 +628,8 @@ static void fused_fill(FusedArgs& a, const void* x, int x_div, const void* theta
     for (int k = 0; k < 2; ++k) a.net[k].stash = (a.n_stash > 0 && k < nets) ? (float*)stash + k * per_net : nullptr;
 }
 
-#ifndef PACOH_BWD_MINW
-#define PACOH_BWD_MINW 3
-#endif
-constexpr int BWD_MINW = PACOH_BWD_MINW;      // NH <= 2, 64-point tiles: three waves per SIMD (168 registers; forcing 128 spills)
-#ifndef PACOH_BWD_MINW_PB2
-#define PACOH_BWD_MINW_PB2 2
-#endif
-constexpr int BWD_MINW_PB2 = PACOH_BWD_MINW_PB2;
+constexpr int BWD_MINW = 3;      // NH <= 2, 64-point tiles: three waves per SIMD (168 registers; forcing 128 spills)
+constexpr int BWD_MINW_PB2 = 2;
 // M is applied to the parenthesised kernel instantiation (the commas of the template arguments must not split macro arguments)
 #define PACOH_FUSED_DISPATCH(KERNEL, nh, pb, M)                                                          \
     do {                                                                                                 \

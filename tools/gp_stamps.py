@@ -34,6 +34,6 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 16)()
 fn(buf, 0)
 tot = sum(buf[:10])
-print('PACOH_GP_PG=%s  n=%d: %.0f cycles per problem (s_memtime domain)' % (os.environ.get('PACOH_GP_PG', '1'), n, tot / (B * reps)))
+print('n=%d: %.0f cycles per problem (s_memtime domain)' % (n, tot / (B * reps)))
 for k, name in enumerate(NAMES):
     print('   %-28s %8.0f cycles  %5.1f %%' % (name, buf[k] / (B * reps), 100.0 * buf[k] / tot))

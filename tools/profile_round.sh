@@ -32,3 +32,5 @@ python tools/host_issue_time.py 128 >> $out/host_issue.txt 2>/dev/null
 rm -rf $out/stats $out/pmc $out/sq $out/dense64 $out/dense32
 ls -la $out
 head -c 1500 $out/bench.json; echo; cat $out/mfma_peak.txt; head -12 $out/bench_kernel_stats.csv; head -8 $out/dense_kernel_stats_fp64.csv; cat $out/host_issue.txt
+# HBM traffic of the large-context path's kernels (what bench.py's other_configs.cfg5.hbm block reads)
+bash tools/dense_pmc.sh $tag
