@@ -442,31 +442,48 @@ __global__ void __launch_bounds__(256, 2) ztz_kernel(const T* __restrict__ Zall,
     // each thread eight consecutive elements of a row -- its LDS writes were 4-way bank-conflicted: SQ_LDS_BANK_CONFLICT three
     // times SQ_ACTIVE_INST_LDS)
     constexpr int CPR = TS / VE, NCH = KS * CPR / 256;
+    // Loads are unconditional, from clamped addresses, and nothing touches the loaded values before store_slab (a select or a
+    // conditional load makes the compiler wait for the data where it is requested, i.e. before the slab's MFMAs instead of
+    // after them: 418 -> 390 us); the triangle / edge mask is applied when the slab is written to LDS, and only in the slabs that
+    // need one.  (Staging a diagonal tile's one operand once -- B fragments read from the A image -- was slower: 426 us.  With
+    // the staging compiled out the kernel takes 311 us, without its barriers 297: the loads cost 55 us, the LDS writes 24.)
     const bool vec_ok = ((long)n * sizeof(T)) % 16 == 0 && i0 + TS <= n;     // (j0 + TS <= i0 + TS)
     auto load_slab = [&](int k0, VT (&ra)[NCH], VT (&rb)[NCH]) __attribute__((always_inline)) {
-        if (vec_ok && k0 >= i0 + TS) {                             // below the tile's diagonal range: whole rows, no triangle
+        if (vec_ok) {
 #pragma unroll
             for (int v = 0; v < NCH; ++v) {
                 const int c = (int)threadIdx.x + 256 * v, k = k0 + c / CPR, col = (c % CPR) * VE;
                 const int kc = k < n ? k : n - 1;
-                const VT xa = *(const VT*)(Z + (long)kc * n + i0 + col), xb = *(const VT*)(Z + (long)kc * n + j0 + col);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) { ra[v][e] = k < n ? xa[e] : T(0); rb[v][e] = k < n ? xb[e] : T(0); }
+                ra[v] = *(const VT*)(Z + (long)kc * n + i0 + col);
+                rb[v] = *(const VT*)(Z + (long)kc * n + j0 + col);
             }
-            return;
-        }
+        } else {
 #pragma unroll
-        for (int v = 0; v < NCH; ++v) {
-            const int c = (int)threadIdx.x + 256 * v, k = k0 + c / CPR, col = (c % CPR) * VE;
+            for (int v = 0; v < NCH; ++v) {
+                const int c = (int)threadIdx.x + 256 * v, k = k0 + c / CPR, col = (c % CPR) * VE;
+                const int kc = k < n ? k : n - 1;
 #pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                const int ci = i0 + col + e, cj = j0 + col + e;
-                ra[v][e] = (k < n && ci < n && ci <= k) ? Z[(long)k * n + ci] : T(0);
-                rb[v][e] = (k < n && cj < n && cj <= k) ? Z[(long)k * n + cj] : T(0);
+                for (int e = 0; e < VE; ++e) {
+                    const int ci = i0 + col + e, cj = j0 + col + e;
+                    ra[v][e] = Z[(long)kc * n + (ci < n ? ci : n - 1)];
+                    rb[v][e] = Z[(long)kc * n + (cj < n ? cj : n - 1)];
+                }
             }
         }
     };
-    auto store_slab = [&](int buf, const VT (&ra)[NCH], const VT (&rb)[NCH]) __attribute__((always_inline)) {
+    auto store_slab = [&](int buf, int k0, VT (&ra)[NCH], VT (&rb)[NCH]) __attribute__((always_inline)) {
+        if (!vec_ok || k0 < i0 + TS || k0 + KS > n) {
+#pragma unroll
+            for (int v = 0; v < NCH; ++v) {
+                const int c = (int)threadIdx.x + 256 * v, k = k0 + c / CPR, col = (c % CPR) * VE;
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const int ci = i0 + col + e, cj = j0 + col + e;
+                    ra[v][e] = (k < n && ci < n && ci <= k) ? ra[v][e] : T(0);
+                    rb[v][e] = (k < n && cj < n && cj <= k) ? rb[v][e] : T(0);
+                }
+            }
+        }
 #pragma unroll
         for (int v = 0; v < NCH; ++v) {
             const int c = (int)threadIdx.x + 256 * v, row = c / CPR, col = (c % CPR) * VE;
@@ -478,7 +495,7 @@ __global__ void __launch_bounds__(256, 2) ztz_kernel(const T* __restrict__ Zall,
     const int ca = 16 * wr + r, cb = 16 * wc + r;
     VT ra[NCH], rb[NCH];
     load_slab(kbeg, ra, rb);
-    store_slab(0, ra, rb);
+    store_slab(0, kbeg, ra, rb);
     __syncthreads();
     int buf = 0;
     for (int k0 = kbeg; k0 < n; k0 += KS) {
@@ -498,7 +515,7 @@ __global__ void __launch_bounds__(256, 2) ztz_kernel(const T* __restrict__ Zall,
         }
 #undef PACOH_ZTZ_NL
 #undef PACOH_ZTZ
-        if (more) store_slab(buf ^ 1, ra, rb);
+        if (more) store_slab(buf ^ 1, k0 + KS, ra, rb);
         __syncthreads();
         buf ^= 1;
     }
