@@ -212,7 +212,13 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         # Five launches per step instead of six (csrc/step_tail.h): the distance matrix rides in the forward launch, the next step's
         # scalars and task batch are fetched by the update launch.  A rank without tasks of its own has no forward launch: it keeps
         # the step_begin launch.  PACOH_SVGD_PIPELINE=0: the round-2 launch sequence (A/B measurements, bit-identity tests)
-        self._pipelined = tb_local > 0 and os.environ.get('PACOH_SVGD_PIPELINE', '1') != '0'
+        # (the IMQ particle kernel has its own launch sequence: _body_update_imq)
+        self._pipelined = tb_local > 0 and self.kernel == 'RBF' and os.environ.get('PACOH_SVGD_PIPELINE', '1') != '0'
+        if self.kernel == 'IMQ':
+            self._imq_phi = torch.empty_like(self.particles)
+            self._imq_h = torch.empty(D, dtype=self.dtype, device=self.device) if self.bandwidth is None else None
+            self._imq_logp = torch.empty(P, dtype=self.dtype, device=self.device)
+            self._imq_ws = L.svgd_imq_workspace(self.particles)
         if self._pipelined:
             self._feed.pipeline(self.tasks, self.engine, self.particles)
         # median bandwidth computed beside the hyper-parameter reduction instead of inside the update (P <= 64: one wavefront's sort)
@@ -226,7 +232,11 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
                                      svgd_tail=(self.particles, self._svgd_ws, self._feed.ctr, self._bw_ahead))
             return
         # select + gather + hyper transforms + the particles' distance matrix: one launch; the counter is advanced by the update
-        batch, hyp = self._feed.begin(self.tasks, self.engine, self.particles, advance=False, svgd=(self.particles, self._svgd_ws))
+        # (IMQ: no distance matrix -- its bandwidths are per-dimension medians --, the counter is advanced behind this launch)
+        if self.kernel == 'IMQ':
+            batch, hyp = self._feed.begin(self.tasks, self.engine, self.particles, advance=True)
+        else:
+            batch, hyp = self._feed.begin(self.tasks, self.engine, self.particles, advance=False, svgd=(self.particles, self._svgd_ws))
         if batch is None:
             self._packed.zero_()
             return
@@ -236,6 +246,8 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
     def _body_update(self):
         """prior score + pre-factor + bandwidth + phi + optimizer in one launch (distances: _body_likelihood), particles updated
         in place, step counter advanced"""
+        if self.kernel == 'IMQ':
+            return self._body_update_imq()
         self.last_bandwidth = self._bw_out
         if self._pipelined:
             L.svgd_update_next(self.particles, self._score, self.prior_mean, self.prior_std, self.prior_factor, self.bandwidth,
@@ -247,6 +259,22 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
                                              workspace=self._svgd_ws, bw_out=self._bw_out, dist_done=True,
                                              step_counter=self._feed.ctr)
         self.last_bandwidth = self._bw_out
+
+    def _body_update_imq(self):
+        """SVGD.step with the IMQ particle kernel (svgd.py:12-28, 58-77) on the step feed: every step-dependent scalar (pre-factor,
+        learning rate, Adam's bias corrections) is read from the feed's selected row in device memory, so that the launch
+        sequence is captured and replayed like the RBF one.  score <- pre * score + prior_factor * d log prior (random_gp.py:
+        204-222), -phi from pacoh_svgd_phi_imq (per-dimension median bandwidths incl. the gradient through them), optimizer step."""
+        sc = self._feed.sc
+        L.scale_dev(self._score, sc[L.SC_SCORE_SCALE:L.SC_SCORE_SCALE + 1])
+        L.prior_logprob_grad(self.particles, self.prior_mean, self.prior_std, self._score, self.prior_factor, logp_out=self._imq_logp)
+        neg_phi, self.last_bandwidth, self._imq_ws = L.svgd_phi_imq(self.particles, self._score, bandwidth=self.bandwidth, neg=True,
+                                                                    workspace=self._imq_ws, phi_out=self._imq_phi, h_out=self._imq_h)
+        if self.optimizer_name == 'Adam':
+            L.adam_step_dev(self.particles, neg_phi, self.exp_avg, self.exp_avg_sq, sc[L.SC_ADAM:L.SC_ADAM + 4])
+        else:
+            L.scale_dev(neg_phi, sc[L.SC_LR:L.SC_LR + 1])          # particles -= lr * (-phi)
+            L.axpy(self.particles, neg_phi, -1.0)
 
     def _exchange(self):
         parallel.all_reduce_buffer_(self._packed)         # ONE exchange per step: score [P, D] | lik [P], in place
@@ -293,24 +321,13 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
 
     def svgd_step(self, idx_local, pre_factor):
         """SVGD.step (meta_learn/svgd.py:25-28) on an explicit task draw: particles.grad = -phi; optimizer.step()"""
-        if self.kernel == 'RBF':
-            self._setup_step(len(idx_local))
-            self.opt_step += 1
-            self._feed.upload(np.asarray(idx_local).reshape(1, -1) if len(idx_local) > 0 else None,
-                              [L.step_scalars(pre_factor, self.lr_scheduler.lr, self.opt_step)])
-            if self._pipelined:
-                self._feed.prologue()
-            self._run_step(False)
-            return
-        _, score = self._log_prob_and_score(self.particles, idx_local, pre_factor)
-        phi_fn = L.svgd_phi_imq                                             # IMQ: alpha=0.5, beta=-0.5 (svgd.py:70)
-        neg_phi, self.last_bandwidth, self._svgd_ws = phi_fn(self.particles, score, bandwidth=self.bandwidth, neg=True,
-                                                             workspace=self._svgd_ws)
+        self._setup_step(len(idx_local))
         self.opt_step += 1
-        if self.optimizer_name == 'Adam':
-            L.adam_step(self.particles, neg_phi, self.exp_avg, self.exp_avg_sq, self.lr_scheduler.lr, self.opt_step)
-        else:
-            L.axpy(self.particles, neg_phi, -self.lr_scheduler.lr)
+        self._feed.upload(np.asarray(idx_local).reshape(1, -1) if len(idx_local) > 0 else None,
+                          [L.step_scalars(pre_factor, self.lr_scheduler.lr, self.opt_step)])
+        if self._pipelined:
+            self._feed.prologue()
+        self._run_step(False)
 
     def meta_fit(self, valid_tuples=None, verbose=True, log_period=500, n_iter=None):
         """GPR_meta_svgd.py:82-121"""
@@ -321,13 +338,7 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         itr = 0
         while itr < n_iter:
             nxt = 1 if itr == 0 else min(n_iter, (itr // log_period + 1) * log_period)      # up to the next log line
-            if self.kernel == 'RBF':
-                self._train_steps(nxt - itr)
-            else:
-                for _ in range(nxt - itr):
-                    idx_local, pre = self._sample_task_batch()
-                    self.svgd_step(idx_local, pre)
-                    self.lr_scheduler.step()
+            self._train_steps(nxt - itr)                  # (both particle kernels: steps replayed from captured graphs)
             itr = nxt
             if itr == 1 or itr % log_period == 0:
                 torch.cuda.synchronize()

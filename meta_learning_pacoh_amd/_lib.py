@@ -713,10 +713,10 @@ def hyper_bwd(theta, T, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_n
                                    *_svgd_bw(svgd_bw), _opt_ptr(opt), dtype_code(theta), _stream()), 'pacoh_hyper_bwd')
 
 
-def prior_logprob_grad(theta, prior_mean, prior_std, grad=None, grad_scale=1.0):
+def prior_logprob_grad(theta, prior_mean, prior_std, grad=None, grad_scale=1.0, logp_out=None):
     lib = load_library()
     P, D = theta.shape
-    logp = torch.empty(P, dtype=theta.dtype, device=theta.device)
+    logp = logp_out if logp_out is not None else torch.empty(P, dtype=theta.dtype, device=theta.device)
     with _Timed('prior_logprob_grad'):
         _check(lib.pacoh_prior_logprob_grad(_ptr(theta), _ptr(prior_mean, theta), _ptr(prior_std, theta), _ptr(logp),
                                             _ptr(grad, theta), float(grad_scale), P, D, dtype_code(theta), _stream()),
@@ -932,16 +932,27 @@ def svgd_update_next(X, score, prior_mean, prior_std, prior_factor, bandwidth, o
                                           int(bool(bandwidth_ready)), dtype_code(X), _stream()), 'pacoh_svgd_update_next')
 
 
-def svgd_phi_imq(X, score, alpha=0.5, beta=-0.5, bandwidth=None, neg=False, workspace=None):
-    """-> (phi[P,D], h[D] | None (fixed bandwidth), workspace)"""
+def svgd_imq_workspace(X, workspace=None):
+    """scratch of pacoh_svgd_phi_imq for particles X[P, D] (uint8 tensor; an existing one is kept when it is large enough)"""
+    need = load_library().pacoh_svgd_imq_workspace_bytes(X.shape[0], X.shape[1], dtype_code(X))
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=X.device)
+    return workspace
+
+
+def svgd_phi_imq(X, score, alpha=0.5, beta=-0.5, bandwidth=None, neg=False, workspace=None, phi_out=None, h_out=None):
+    """-> (phi[P,D], h[D] | None (fixed bandwidth), workspace); phi_out / h_out: caller-owned result buffers (a captured step)"""
     lib = load_library()
     P, D = X.shape
     code = dtype_code(X)
     need = lib.pacoh_svgd_imq_workspace_bytes(P, D, code)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=X.device)
-    phi = torch.empty_like(X)
-    h_out = torch.empty(D, dtype=X.dtype, device=X.device) if bandwidth is None else None
+    phi = phi_out if phi_out is not None else torch.empty_like(X)
+    if bandwidth is not None:
+        h_out = None
+    elif h_out is None:
+        h_out = torch.empty(D, dtype=X.dtype, device=X.device)
     bw = -1.0 if bandwidth is None else float(bandwidth)
     with _Timed('svgd_phi'):
         _check(lib.pacoh_svgd_phi_imq(_ptr(X), _ptr(score, X), float(alpha), float(beta), bw, int(bool(neg)), _ptr(phi),

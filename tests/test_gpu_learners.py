@@ -386,6 +386,52 @@ def test_svgd_imq_kernel_steps_match_oracle(M):
         M.GPRegressionMetaLearnedSVGD(tasks, num_particles=P, kernel='laplace')
 
 
+@pytest.mark.parametrize('opt', ['Adam', 'SGD'])
+def test_svgd_imq_steps_run_from_the_step_feed_and_replay_bit_identically(M, opt, monkeypatch):
+    """the IMQ particle kernel takes the RBF kernel's route through meta_fit since round 4: task draws and step scalars from the
+    device-side feed, the launch sequence captured once and replayed -- the same bits as the launches issued one by one
+    (PACOH_NO_GRAPH=1), ragged tasks (per-step pre-factor), decaying learning rate; and the trajectory of meta_fit against the
+    oracle's closed-form phi (svgd.py:58-77) driven by the same task draws with torch's optimizers"""
+    rs = np.random.RandomState(13)
+    tasks = []
+    for t in range(6):
+        n = 9 + 2 * (t % 3)
+        x = rs.uniform(-3, 3, size=(n, 2))
+        tasks.append((x, np.sin(x[:, :1]) + 0.3 * x[:, 1:] + 0.05 * rs.randn(n, 1)))
+    kw = dict(num_particles=6, task_batch_size=4, lr=5e-3, lr_decay=0.95, random_seed=3, kernel='IMQ', optimizer=opt,
+              mean_nn_layers=(8, 8), kernel_nn_layers=(8, 8))
+    monkeypatch.setenv('PACOH_NO_GRAPH', '1')
+    m_e = M.GPRegressionMetaLearnedSVGD(tasks, **kw)
+    theta0 = m_e.particles.cpu().double().clone()
+    m_e.meta_fit(verbose=False, n_iter=7, log_period=3)
+    assert m_e._graphs is None
+    monkeypatch.delenv('PACOH_NO_GRAPH')
+    monkeypatch.setenv('PACOH_GRAPH', '1')
+    m_g = M.GPRegressionMetaLearnedSVGD(tasks, **kw)
+    m_g.meta_fit(verbose=False, n_iter=7, log_period=3)
+    assert m_g._graphs is not None and len(m_g._graphs) == 1
+    assert bool(torch.isfinite(m_g.particles).all()) and torch.equal(m_e.particles, m_g.particles)
+    assert m_e.opt_step == m_g.opt_step == 7 and m_g.last_bandwidth.shape == (m_g.particles.shape[1],)
+    # oracle trajectory on the same draws (numpy stream of the learner's seed: GPR_meta_svgd.py:102)
+    cfg = O.GPConfig(2, 'NN', 'NN', mean_nn_layers=(8, 8), kernel_nn_layers=(8, 8))
+    pm, ps = O.hyperprior_mean_std(cfg.layout, 0.5, 3.0)
+    stats = O.compute_normalization_stats(tasks)
+    otasks = [O.prepare_task(x, y, stats, torch.float64) for x, y in tasks]
+    m_r = M.GPRegressionMetaLearnedSVGD(tasks, **kw)              # a third learner only to read the draws its stream produces
+    X = theta0.clone()
+    optim = torch.optim.Adam([X], lr=5e-3) if opt == 'Adam' else torch.optim.SGD([X], lr=5e-3)
+    sched = torch.optim.lr_scheduler.StepLR(optim, 1000, gamma=0.95)
+    for _ in range(7):
+        idx = m_r.rds_numpy.randint(0, len(tasks), size=4)
+        sel = [otasks[i] for i in idx]
+        _, s = O.meta_score(X, sel, cfg, pm, ps, 0.01)          # (pre-factor from the batch's sizes: random_gp.py:209-212)
+        phi, _ = O.svgd_phi_imq_closed_form(X.detach(), s)
+        X.grad = -phi
+        optim.step()
+        sched.step()
+    assert relerr(m_g.particles, X) < 2e-3
+
+
 def test_vi_full_covariance_steps_match_oracle(M):
     """GPRegressionMetaLearnedVI(cov_type='full') (random_gp.py:249-251): init stream and three Adam steps vs the oracle"""
     T, n, d, S = 4, 12, 2, 3
