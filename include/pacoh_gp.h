@@ -303,6 +303,11 @@ int pacoh_hyper_bwd(const void* theta, long theta_stride, int P, int T, int off_
 int pacoh_prior_logprob_grad(const void* theta, const void* prior_mean, const void* prior_std,
                              void* logp, void* grad, double grad_scale, int P, int D, int dtype,
                              void* stream);
+/* The same for a captured step (round 4, the IMQ-SVGD update): score[p,d] := *score_scale * score[p,d] + prior_factor * d logp / d theta
+ * with the likelihood pre-factor (random_gp.py:209-212, 221-222) read from device memory (a step-scalar row's
+ * PACOH_SC_SCORE_SCALE entry): pacoh_scale_dev + pacoh_prior_logprob_grad in one launch. */
+int pacoh_prior_score_dev(const void* theta, const void* prior_mean, const void* prior_std, void* score,
+                          double prior_factor, const void* score_scale, int P, int D, int dtype, void* stream);
 
 /* ---- A9: SVGD update direction -----------------------------------------------------------------
  * phi[i,:] = ( sum_j k_ij score[j,:] + 2 gamma sum_j k_ij (X[i,:] - X[j,:]) ) / P,

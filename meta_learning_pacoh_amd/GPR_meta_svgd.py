@@ -217,7 +217,6 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         if self.kernel == 'IMQ':
             self._imq_phi = torch.empty_like(self.particles)
             self._imq_h = torch.empty(D, dtype=self.dtype, device=self.device) if self.bandwidth is None else None
-            self._imq_logp = torch.empty(P, dtype=self.dtype, device=self.device)
             self._imq_ws = L.svgd_imq_workspace(self.particles)
         if self._pipelined:
             self._feed.pipeline(self.tasks, self.engine, self.particles)
@@ -232,9 +231,10 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
                                      svgd_tail=(self.particles, self._svgd_ws, self._feed.ctr, self._bw_ahead))
             return
         # select + gather + hyper transforms + the particles' distance matrix: one launch; the counter is advanced by the update
-        # (IMQ: no distance matrix -- its bandwidths are per-dimension medians --, the counter is advanced behind this launch)
+        # (IMQ: no distance matrix -- its bandwidths are per-dimension medians; the counter is advanced by the Adam launch, or
+        # behind this one for SGD)
         if self.kernel == 'IMQ':
-            batch, hyp = self._feed.begin(self.tasks, self.engine, self.particles, advance=True)
+            batch, hyp = self._feed.begin(self.tasks, self.engine, self.particles, advance=self.optimizer_name != 'Adam')
         else:
             batch, hyp = self._feed.begin(self.tasks, self.engine, self.particles, advance=False, svgd=(self.particles, self._svgd_ws))
         if batch is None:
@@ -266,12 +266,13 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         sequence is captured and replayed like the RBF one.  score <- pre * score + prior_factor * d log prior (random_gp.py:
         204-222), -phi from pacoh_svgd_phi_imq (per-dimension median bandwidths incl. the gradient through them), optimizer step."""
         sc = self._feed.sc
-        L.scale_dev(self._score, sc[L.SC_SCORE_SCALE:L.SC_SCORE_SCALE + 1])
-        L.prior_logprob_grad(self.particles, self.prior_mean, self.prior_std, self._score, self.prior_factor, logp_out=self._imq_logp)
+        L.prior_score_dev(self.particles, self.prior_mean, self.prior_std, self._score, self.prior_factor,
+                          sc[L.SC_SCORE_SCALE:L.SC_SCORE_SCALE + 1])
         neg_phi, self.last_bandwidth, self._imq_ws = L.svgd_phi_imq(self.particles, self._score, bandwidth=self.bandwidth, neg=True,
                                                                     workspace=self._imq_ws, phi_out=self._imq_phi, h_out=self._imq_h)
         if self.optimizer_name == 'Adam':
-            L.adam_step_dev(self.particles, neg_phi, self.exp_avg, self.exp_avg_sq, sc[L.SC_ADAM:L.SC_ADAM + 4])
+            L.adam_step_dev(self.particles, neg_phi, self.exp_avg, self.exp_avg_sq, sc[L.SC_ADAM:L.SC_ADAM + 4],
+                            step_counter=self._feed.ctr)
         else:
             L.scale_dev(neg_phi, sc[L.SC_LR:L.SC_LR + 1])          # particles -= lr * (-phi)
             L.axpy(self.particles, neg_phi, -1.0)

@@ -81,6 +81,7 @@ SIGNATURES = {
                                     _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                                     _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _i, _vp]),
     'pacoh_prior_logprob_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
+    'pacoh_prior_score_dev': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _i, _i, _i, _vp]),
     'pacoh_svgd_workspace_bytes': (_sz, [_i, _i, _i]),
     'pacoh_svgd_phi': (_i, [_vp, _vp, _d, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pacoh_svgd_update': (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _d, _d, _d, _d, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -107,7 +108,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 11              # pacoh_abi_version() of the library this table was written for
+ABI_VERSION = 12              # pacoh_abi_version() of the library this table was written for
 
 
 def load_library():
@@ -722,6 +723,15 @@ def prior_logprob_grad(theta, prior_mean, prior_std, grad=None, grad_scale=1.0, 
                                             _ptr(grad, theta), float(grad_scale), P, D, dtype_code(theta), _stream()),
                'pacoh_prior_logprob_grad')
     return logp
+
+
+def prior_score_dev(theta, prior_mean, prior_std, score, prior_factor, score_scale):
+    """score := score_scale[0] * score + prior_factor * d log prior / d theta, the pre-factor in device memory (a captured step)"""
+    P, D = theta.shape
+    with _Timed('prior_logprob_grad'):
+        _check(load_library().pacoh_prior_score_dev(_ptr(theta), _ptr(prior_mean, theta), _ptr(prior_std, theta), _ptr(score, theta),
+                                                    float(prior_factor), _ptr(score_scale, theta), P, D, dtype_code(theta), _stream()),
+               'pacoh_prior_score_dev')
 
 
 def svgd_phi(X, score, bandwidth=None, neg=False, workspace=None):

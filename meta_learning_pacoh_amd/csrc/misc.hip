@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) hyper_bwd_kernel(HyperBwdArgs<T> a) {
 template <typename T>
 __global__ void __launch_bounds__(1024) prior_kernel(const T* __restrict__ theta, const T* __restrict__ mu,
                                                      const T* __restrict__ sd, T* __restrict__ logp,
-                                                     T* __restrict__ grad, T grad_scale, int D) {
+                                                     T* __restrict__ grad, T grad_scale, int D, const T* __restrict__ in_scale = nullptr) {
     // one 1024-thread workgroup per parameter row: only P (= particles) rows exist, so the kernel is pure latency; 16 waves
     // per row keep the dependent load -> log -> store chain to 2-3 trips (8.2 -> ~4 us at P = 20, D = 2534)
     __shared__ T red[16];
@@ -66,11 +66,12 @@ __global__ void __launch_bounds__(1024) prior_kernel(const T* __restrict__ theta
     const T* th = theta + (long)p * D;
     const T HALF_LOG2PI = T(0.9189385332046727);
     T acc = 0;
+    const T gin = in_scale ? in_scale[0] : T(1);                    // (pacoh_prior_score_dev: the incoming score's factor, device-side)
     for (int d = threadIdx.x; d < D; d += 1024) {
         T s = sd[d];
         T zv = (th[d] - mu[d]) / s;
         acc += T(-0.5) * zv * zv - t_log<T>(s) - HALF_LOG2PI;
-        if (grad) grad[(long)p * D + d] += grad_scale * (-zv / s);
+        if (grad) grad[(long)p * D + d] = (in_scale ? gin * grad[(long)p * D + d] : grad[(long)p * D + d]) + grad_scale * (-zv / s);
     }
     acc = subwave_sum<T>(acc, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -696,7 +697,7 @@ extern "C" int pacoh_gather_tasks(const void* x, const void* y, const int32_t* n
     return launch_status();
 }
 
-extern "C" int pacoh_abi_version(void) { return 11; }
+extern "C" int pacoh_abi_version(void) { return 12; }
 
 extern "C" int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise,
                                double noise_floor, void* ls, void* os, void* noise, int dtype, void* stream) {
@@ -793,6 +794,21 @@ extern "C" int pacoh_prior_logprob_grad(const void* theta, const void* prior_mea
     else
         hipLaunchKernelGGL(prior_kernel<double>, dim3(P), dim3(1024), 0, (hipStream_t)stream, (const double*)theta,
                            (const double*)prior_mean, (const double*)prior_std, (double*)logp, (double*)grad, grad_scale, D);
+    return launch_status();
+}
+
+extern "C" int pacoh_prior_score_dev(const void* theta, const void* prior_mean, const void* prior_std, void* score,
+                                     double prior_factor, const void* score_scale, int P, int D, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (!theta || !prior_mean || !prior_std || !score || !score_scale || P <= 0 || D <= 0) return PACOH_EINVAL;
+    if (dtype == PACOH_F32)
+        hipLaunchKernelGGL(prior_kernel<float>, dim3(P), dim3(1024), 0, (hipStream_t)stream, (const float*)theta,
+                           (const float*)prior_mean, (const float*)prior_std, (float*)nullptr, (float*)score, (float)prior_factor, D,
+                           (const float*)score_scale);
+    else
+        hipLaunchKernelGGL(prior_kernel<double>, dim3(P), dim3(1024), 0, (hipStream_t)stream, (const double*)theta,
+                           (const double*)prior_mean, (const double*)prior_std, (double*)nullptr, (double*)score, prior_factor, D,
+                           (const double*)score_scale);
     return launch_status();
 }
 

@@ -87,22 +87,101 @@ __global__ void __launch_bounds__(256) imq_bw_kernel(const T* __restrict__ X, T*
     }
 }
 
-// ---- stage 2: base_ij, k_ij, kb_ij; one wave per pair j <= i -------------------------------------------------
+// sum / min over the 16 lanes of a DPP row, result in every lane: quad xor 1, quad xor 2, mirror within 8, mirror within 16 (vector-rate
+// moves; the __shfl_xor form goes through the LDS crossbar: 4 x ~100 cycles per bisection round, 3/4 of the small kernel's time)
+__device__ __forceinline__ int row16_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+    return v;
+}
+__device__ __forceinline__ int row16_min(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false));
+    return v;
+}
+
+// The same for P <= 32 (the reference's sweeps use 10 / 50 particles, BASELINE config #3 20): a lane keeps its <= 31 pair values
+// in registers -- pair q = ln + 16 m in row-major order over a < b --, so that a bisection round is 31 compares and 4 shuffles
+// instead of a loop over LDS (41 -> 5 us at P = 20, D = 2534: the kernel is one round of workgroups, i.e. pure latency).  Same
+// values, same bit patterns, same first-pair rule as the general kernel above.
 template <typename T>
-__global__ void __launch_bounds__(64) imq_kmat_kernel(const T* __restrict__ X, const T* __restrict__ h, T h_fixed,
+__global__ void __launch_bounds__(256) imq_bw_small_kernel(const T* __restrict__ X, T* __restrict__ h, T* __restrict__ dh,
+                                                           int32_t* __restrict__ bidx, T log_p1, int P, int D) {
+    using U = typename BitsOf<T>::U;
+    constexpr int M = 31;                                            // ceil(32 * 31 / 2 / 16)
+    __shared__ T xs[16][33];
+    const int npairs = P * (P - 1) / 2;
+    const int d0 = blockIdx.x * 16;
+    for (int idx = threadIdx.x; idx < P * 16; idx += 256) {
+        const int p = idx >> 4, c = idx & 15;
+        xs[c][p] = X[(long)p * D + min(d0 + c, D - 1)];
+    }
+    __syncthreads();
+    const int dl = threadIdx.x >> 4, ln = threadIdx.x & 15;
+    const T* xd = xs[dl];
+    U vals[M];
+    {
+        // pair q -> (a, b): rows a hold P - 1 - a pairs each; walk the rows once (q ascends by 16 per step)
+        int a = 0, row0 = 0;                                         // row0 = index of pair (a, a + 1)
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int q = ln + 16 * m;
+            while (a < P - 2 && q >= row0 + (P - 1 - a)) { row0 += P - 1 - a; ++a; }
+            const int b = a + 1 + (q - row0);
+            const bool ok = q < npairs;
+            const T df = xd[ok ? b : 0] - xd[ok ? a : 0];
+            vals[m] = ok ? to_bits(df * df) : ~U(0);                 // (never below a candidate: the sign bit of a candidate is clear)
+        }
+    }
+    const int k = (npairs - 1) / 2;
+    U result = 0;
+    for (int bit = BitsOf<T>::NB - 2; bit >= 0; --bit) {
+        const U cand = result | (U(1) << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int m = 0; m < M; ++m) cnt += vals[m] < cand ? 1 : 0;
+        cnt = row16_sum(cnt);
+        if (cnt <= k) result = cand;
+    }
+    int qmin = 0x7fffffff;                                           // first pair in row-major order that attains the median
+#pragma unroll
+    for (int m = M - 1; m >= 0; --m) if (vals[m] == result) qmin = ln + 16 * m;
+    qmin = row16_min(qmin);
+    const int d = d0 + dl;
+    if (ln == 0 && d < D) {
+        int a = 0, row0 = 0;
+        while (a < P - 2 && qmin >= row0 + (P - 1 - a)) { row0 += P - 1 - a; ++a; }
+        const int b = a + 1 + (qmin - row0);
+        h[d] = from_bits(result) / log_p1;
+        dh[d] = T(2) * (xd[b] - xd[a]) / log_p1;
+        bidx[d] = b;
+    }
+}
+
+// ---- stage 2: base_ij, k_ij, kb_ij; one workgroup per pair j <= i ---------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) imq_kmat_kernel(const T* __restrict__ X, const T* __restrict__ h, T h_fixed,
                                                       T alpha, T beta, T* __restrict__ Kmat, T* __restrict__ Kb,
                                                       int P, int D) {
     const int i = blockIdx.x / P, j = blockIdx.x - i * P;
     if (j > i) return;
     const T* xi = X + (long)i * D;
     const T* xj = X + (long)j * D;
+    __shared__ T part[4];
     T acc = 0;
-    for (int d = threadIdx.x; d < D; d += 64) {
+    for (int d = threadIdx.x; d < D; d += 256) {
         const T df = xi[d] - xj[d];
         acc += df * df / (h ? h[d] : h_fixed);
     }
     acc = subwave_sum<T>(acc, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
     if (threadIdx.x == 0) {
+        acc = (part[0] + part[1]) + (part[2] + part[3]);             // fixed order
         const T base = alpha + acc;
         const T kv = t_exp<T>(beta * t_log<T>(base));
         const T kb = beta * kv / base;
@@ -175,13 +254,18 @@ int imq_launch(const void* X, const void* score, double alpha, double beta, doub
         const size_t lds = (size_t)16 * Pp * sizeof(T);
         if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(imq_bw_kernel<T>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PACOH_ELIMIT;
-        hipLaunchKernelGGL(imq_bw_kernel<T>, dim3((D + 15) / 16), dim3(256), lds, s, (const T*)X, harr, dh, bidx,
-                           (T)log((double)P + 1.0), P, D);
+        if (P <= 32)
+            hipLaunchKernelGGL(imq_bw_small_kernel<T>, dim3((D + 15) / 16), dim3(256), 0, s, (const T*)X, harr, dh, bidx,
+                               (T)log((double)P + 1.0), P, D);
+        else
+            hipLaunchKernelGGL(imq_bw_kernel<T>, dim3((D + 15) / 16), dim3(256), lds, s, (const T*)X, harr, dh, bidx,
+                               (T)log((double)P + 1.0), P, D);
     }
-    hipLaunchKernelGGL(imq_kmat_kernel<T>, dim3(P * P), dim3(64), 0, s, (const T*)X, median ? (const T*)harr : (const T*)nullptr,
+    hipLaunchKernelGGL(imq_kmat_kernel<T>, dim3(P * P), dim3(256), 0, s, (const T*)X, median ? (const T*)harr : (const T*)nullptr,
                        (T)bandwidth, (T)alpha, (T)beta, Kmat, Kb, P, D);
     int TD = 64;                                     // dimensions per block: the two [P][TD] column images within 96 KB of LDS
     while (TD > 1 && (size_t)2 * P * TD * sizeof(T) > 96u * 1024u) TD >>= 1;
+    while (TD > 16 && (D + TD - 1) / TD < 256) TD >>= 1;            // (40 one-wave blocks for D = 2534 were pure latency: 26 -> 8 us)
     const size_t lds3 = (size_t)2 * P * TD * sizeof(T) + 64 * sizeof(T);
     if (lds3 > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(imq_phi_kernel<T>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess) return PACOH_ELIMIT;

@@ -485,6 +485,11 @@ def test_softplus_prior_adam(L, dtype):
     lp = L.prior_logprob_grad(theta.to(DEV), pm.to(dtype).to(DEV), ps.to(dtype).to(DEV), grad, 0.01)
     assert maxrel(lp, ref) < (1e-5 if dtype == torch.float32 else 1e-12)
     assert relerr(grad.cpu() - 2.0, 0.01 * th.grad) < (1e-5 if dtype == torch.float32 else 1e-12)
+    # the captured-step form: score := scale[0] * score + prior_factor * d log prior, the scale read from device memory
+    sc0 = torch.randn(7, cfg.D, generator=g, dtype=dtype)
+    sc = sc0.to(DEV)
+    L.prior_score_dev(theta.to(DEV), pm.to(dtype).to(DEV), ps.to(dtype).to(DEV), sc, 0.01, torch.tensor([0.37], dtype=dtype, device=DEV))
+    assert relerr(sc, 0.37 * sc0.double() + 0.01 * th.grad) < (1e-5 if dtype == torch.float32 else 1e-12)
 
     # AdamW: 5 steps against torch.optim.AdamW
     p0 = torch.randn(300, generator=g, dtype=dtype)
