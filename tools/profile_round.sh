@@ -34,3 +34,6 @@ ls -la $out
 head -c 1500 $out/bench.json; echo; cat $out/mfma_peak.txt; head -12 $out/bench_kernel_stats.csv; head -8 $out/dense_kernel_stats_fp64.csv; cat $out/host_issue.txt
 # HBM traffic of the large-context path's kernels (what bench.py's other_configs.cfg5.hbm block reads)
 bash tools/dense_pmc.sh $tag
+# SQ counters of the large-context path's kernels
+bash tools/dense_sq.sh $tag > /dev/null 2>&1
+python tools/imq_time.py 1024 200 2> /dev/null | grep "ms per step" > $out/imq_step.txt
