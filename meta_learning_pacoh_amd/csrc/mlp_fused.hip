@@ -625,7 +625,11 @@ static void fused_fill(FusedArgs& a, const void* x, int x_div, const void* theta
     a.n_stash = stash ? fused_n_stash(n_hidden) : 0;
     a.nblk = fused_nblk(B, P, n);
     const size_t per_net = (size_t)P * a.nblk * a.n_stash * 2 * 256;
+#ifdef PACOH_EXP_STASH_NETS      // experiment build (VERDICT r3 #4a): only the first PACOH_EXP_STASH_NETS networks use the stash, the others recompute
+    for (int k = 0; k < 2; ++k) a.net[k].stash = (a.n_stash > 0 && k < nets && k < PACOH_EXP_STASH_NETS) ? (float*)stash + k * per_net : nullptr;
+#else
     for (int k = 0; k < 2; ++k) a.net[k].stash = (a.n_stash > 0 && k < nets) ? (float*)stash + k * per_net : nullptr;
+#endif
 }
 
 constexpr int BWD_MINW = 3;      // NH <= 2, 64-point tiles: three waves per SIMD (168 registers; forcing 128 spills)
