@@ -27,6 +27,14 @@ int dense_grad_mfma_try(const void* zs, const void* ls, const void* os, const in
                         void* scratch, size_t scratch_bytes, int B, int P, int n, int f, int kind, int dtype, hipStream_t s);   // dense_grad_mfma.hip            // dense_trtri_ll.hip (1: not in its plan)
 int gram_rbf_for_chol(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
                       int dtype, hipStream_t s, int lower);                                          // gram.hip
+int dense_gram_mfma_try(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
+                        int dtype, hipStream_t s);                                                   // dense_grad_mfma.hip (1: not in its plan)
+// A = os K + noise I for the factorisation (lower block triangle): fp64 distances on the matrix cores where that kernel applies
+static int gram_for_chol(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
+                         int dtype, hipStream_t s) {
+    const int rc = dense_gram_mfma_try(z, z_div, ls, os, noise, K, B, P, n, f, dtype, s);
+    return rc == 1 ? gram_rbf_for_chol(z, z_div, ls, os, noise, K, B, P, n, f, dtype, s, 1) : rc;
+}
 
 namespace {
 
@@ -884,7 +892,7 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
     for (int attempt = 0; attempt < 4; ++attempt) {
         if (attempt == 0) {
             // (RBF family: the tiles above the diagonal are skipped -- nothing downstream reads A's upper triangle)
-            int rc = kind == PACOH_KERNEL_RBF ? gram_rbf_for_chol(z, z_div, ls, os, noise, A, B, P, n, f, dtype, s, 1)
+            int rc = kind == PACOH_KERNEL_RBF ? gram_for_chol(z, z_div, ls, os, noise, A, B, P, n, f, dtype, s)
                                               : pacoh_gram_rbf_ard(z, z_div, z, z_div, ls, os, noise, 1, A, B, P, n, n, f_arg, dtype, s);
             if (rc) return rc;
         } else {
@@ -967,7 +975,7 @@ int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int m
     const double jitter_base = dtype == PACOH_F32 ? 1e-6 : 1e-8;
     for (int attempt = 0; attempt < 4; ++attempt) {
         if (attempt == 0) {
-            int rc = kind == PACOH_KERNEL_RBF ? gram_rbf_for_chol(z_ctx, z_div, ls, os, noise, A, B, P, n, f, dtype, s, 1)
+            int rc = kind == PACOH_KERNEL_RBF ? gram_for_chol(z_ctx, z_div, ls, os, noise, A, B, P, n, f, dtype, s)
                                               : pacoh_gram_rbf_ard(z_ctx, z_div, z_ctx, z_div, ls, os, noise, 1, A, B, P, n, n, f_arg, dtype, s);
             if (rc) return rc;
         } else {

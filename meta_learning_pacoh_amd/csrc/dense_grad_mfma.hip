@@ -110,7 +110,9 @@ __global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* _
         Acc oj = {0, 0, 0, 0};
         double wv[2][4];
         load_w(J0, 0, wv[0]);
-        // one 16 x 16 block of the tile at a time (the four blocks of M need not be alive together: 128 registers, 4 waves per SIMD)
+        // one 16 x 16 block of the tile at a time, W requested one block ahead.  (Requesting the WHOLE next tile a tile ahead -- 16 loads
+        // per lane in flight instead of 4 -- needs 223 registers, two waves per SIMD instead of three: 268 -> 306 us.  The kernel
+        // waits on its own LDS / MFMA chain per block, not on HBM.)
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) {
             if (ib < 3) load_w(J0, ib + 1, wv[(ib + 1) & 1]);
@@ -225,7 +227,77 @@ __global__ void __launch_bounds__(256) dense_grad_combine_kernel(const double* _
     if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = gup * ai / (double)nv;
 }
 
+// ---- the Gram matrix for the factorisation, same idea -----------------------------------------------------------------------------
+// A = os exp(-|u_i - u_j|^2 / 2) + noise I, u = z / lengthscale, tiles (I, J) with J <= I only (every Cholesky kernel of the path reads
+// the lower triangle; diagonal tiles are written whole).  gram_kernel spends 8 subtractions + 8 fmas + the 20-instruction exp per
+// entry on the fp64 vector units and is bound by them at d = 8 (241 us for the full 256 x 512^2 matrix against 113 us at d = 2, the same
+// bytes); here the distances are |u_i|^2 + |u_j|^2 - 2 u_i . u_j with the product on the matrix cores.  The coordinates are taken
+// relative to the problem's first point before scaling, which keeps |u|^2 -- and with it the cancellation error ~1e-16 |u|^2 -- small;
+// the diagonal is exact by construction (d2 = 0), the result is symmetric bit for bit (S_ij and S_ji are the same products).
+__global__ void __launch_bounds__(256, 4) dense_gram_tile_kernel(const double* __restrict__ z, int z_div, const double* __restrict__ lsp,
+                                                                 const double* __restrict__ osp, const double* __restrict__ noisep,
+                                                                 double* __restrict__ K, int P, int n, int f) {
+    __shared__ double ZI[GT][GZL], ZJ[GT][GZL], n2I[GT], n2J[GT];
+    const long b = blockIdx.y;
+    int I = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+    while (I * (I + 1) / 2 > (int)blockIdx.x) --I;
+    while ((I + 1) * (I + 2) / 2 <= (int)blockIdx.x) ++I;
+    const int J = blockIdx.x - I * (I + 1) / 2;
+    const int I0 = I * GT, J0 = J * GT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int p = (int)(b % P);
+    const double* zb = z + (b / z_div) * (long)n * f;
+    const double* ls = lsp + (long)p * f;
+    auto stage = [&](double (*Z)[GZL], double* n2, int R0) {
+        for (int e = tid; e < GT * 8; e += 256) {
+            const int i = e >> 3, c = e & 7;
+            const int row = R0 + i;
+            Z[i][c] = (row < n && c < f) ? (zb[(long)row * f + c] - zb[c]) / ls[c] : 0.0;
+        }
+        __syncthreads();
+        if (tid < GT) {
+            double s = 0.0;
+            for (int c = 0; c < 8; ++c) s = fma(Z[tid][c], Z[tid][c], s);
+            n2[tid] = s;
+        }
+    };
+    stage(ZI, n2I, I0);
+    stage(ZJ, n2J, J0);
+    __syncthreads();
+    const double os = osp ? osp[p] : 1.0, noise = noisep[p];
+    const int j = 16 * w + r, gj = J0 + j;
+    double* Kb = K + b * (long)n * n;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+        Acc s = {0, 0, 0, 0};
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+            s = __builtin_amdgcn_mfma_f64_16x16x4f64(ZI[16 * ib + r][4 * st + g], ZJ[j][4 * st + g], s, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = 16 * ib + gm_row(g, q), gi = I0 + i;
+            double d2 = n2I[i] + n2J[j] - 2.0 * s[q];
+            d2 = (d2 > 0.0 && gi != gj) ? d2 : 0.0;
+            double k = os * rbf_exp<double>(-0.5 * d2);
+            if (gi == gj) k += noise;
+            if (gi < n && gj < n) Kb[(long)gi * n + gj] = k;
+        }
+    }
+}
+
 }  // namespace
+
+// fp64 ARD-RBF Gram + noise for the factorisation, lower block triangle only; returns 1 when outside its plan (caller: gram_kernel)
+int dense_gram_mfma_try(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
+                        int dtype, hipStream_t s) {
+    static const bool on = []() { const char* e = getenv("PACOH_GRAM_MFMA"); return !(e && e[0] == '0'); }();
+    if (!on || dtype != PACOH_F64 || f > 8 || n < GT || !noise) return 1;
+    const int nI = (n + GT - 1) / GT;
+    hipLaunchKernelGGL(dense_gram_tile_kernel, dim3(nI * (nI + 1) / 2, B), dim3(256), 0, s, (const double*)z, z_div, (const double*)ls,
+                       (const double*)os, (const double*)noise, (double*)K, P, n, f);
+    return launch_status();
+}
 
 // scratch the two kernels need (bytes): rowside [B][n][9] | column-side partials [B][tiles][64][9] | G_ii [B][n]
 size_t dense_grad_mfma_scratch(int B, int n) {
