@@ -25,6 +25,7 @@ int trtri_ll_try(void* A, const int32_t* info, int B, int n, int dtype, hipStrea
 int dense_grad_mfma_try(const void* zs, const void* ls, const void* os, const int32_t* n_valid, int y_div, const void* g_lml,
                         const void* alpha, const void* Wm, const int32_t* info, void* d_z, void* d_mean, int mean_mode, void* rowpart,
                         void* scratch, size_t scratch_bytes, int B, int P, int n, int f, int kind, int dtype, hipStream_t s);   // dense_grad_mfma.hip            // dense_trtri_ll.hip (1: not in its plan)
+bool dense_grad_mfma_plan(int B, int n, int f, int kind, int dtype, size_t scratch_bytes);             // dense_grad_mfma.hip
 int gram_rbf_for_chol(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
                       int dtype, hipStream_t s, int lower);                                          // gram.hip
 int dense_gram_mfma_try(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
@@ -407,7 +408,7 @@ __device__ __forceinline__ void ztz_slab(const T (*__restrict__ Asb)[LDT], const
 
 template <typename T>
 __global__ void __launch_bounds__(256, 2) ztz_kernel(const T* __restrict__ Zall, T* __restrict__ Wall, int n, const int32_t* __restrict__ info,
-                                                     int nt, int Bn) {
+                                                     int nt, int Bn, int mirror) {
     using Acc = typename Mf<T>::acc;
     constexpr int TS = 128, KS = 16, LDT = TS + 4;
     constexpr int VE = 16 / (int)sizeof(T);                        // elements per 16-byte chunk
@@ -536,22 +537,22 @@ __global__ void __launch_bounds__(256, 2) ztz_kernel(const T* __restrict__ Zall,
                 const int i = i0 + 16 * (wr + 2 * ib) + Mf<T>::row(g, q), j = j0 + 16 * (wc + 2 * jb) + r;
                 if (i < n && j < n && (tm != tn || j <= i)) {
                     W[(long)i * n + j] = acc[ib][jb][q];
-                    W[(long)j * n + i] = acc[ib][jb][q];
+                    if (mirror || tm == tn) W[(long)j * n + i] = acc[ib][jb][q];      // (mirror == 0: the reader takes the lower block triangle only)
                 }
             }
 }
 
 template <typename T>
-void launch_ztz(const T* Z, T* W, int n, const int32_t* info, int Bn, hipStream_t s) {
+void launch_ztz(const T* Z, T* W, int n, const int32_t* info, int Bn, hipStream_t s, int mirror) {
     const int t = (n + 127) / 128, nt = t * (t + 1) / 2;
-    hipLaunchKernelGGL(ztz_kernel<T>, dim3((unsigned)(nt * Bn)), dim3(256), 0, s, Z, W, n, info, nt, Bn);
+    hipLaunchKernelGGL(ztz_kernel<T>, dim3((unsigned)(nt * Bn)), dim3(256), 0, s, Z, W, n, info, nt, Bn, mirror);
 }
 
 template <typename T>
-void launch_bgemm(const GemmArgs& ga, int Bn, hipStream_t s) {
+void launch_bgemm(const GemmArgs& ga, int Bn, hipStream_t s, int mirror = 1) {
     if (ga.A == ga.B && ga.transA && !ga.transB && ga.lowerA && ga.lowerB && ga.symC && ga.M == ga.N && ga.M == ga.K &&
         ga.lda == ga.M && ga.ldb == ga.M && ga.ldc == ga.M && ga.alpha == 1.0 && ga.beta == 0.0 && ga.M >= 128) {
-        launch_ztz<T>((const T*)ga.A, (T*)ga.C, ga.M, ga.info, Bn, s);
+        launch_ztz<T>((const T*)ga.A, (T*)ga.C, ga.M, ga.info, Bn, s, mirror);
         return;
     }
     const int tiles = ((ga.M + 63) / 64) * ((ga.N + 63) / 64);
@@ -917,13 +918,16 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
             T* t = alpha; alpha = resid; resid = t;
         }
         GemmArgs ga = {A, A, Wm, (long)n * n, (long)n * n, (long)n * n, n, n, n, n, n, n, 1, 0, 1, 1, 1.0, 0.0, info, 1};
-        launch_bgemm<T>(ga, B, s);                                          // W = Z^T Z
+        // fp64 ARD-RBF: the symmetric MFMA contraction (dense_grad_mfma.hip) reads the lower 64-tiles of W only -- the 128-tiles of
+        // Z^T Z below the block diagonal are then not mirrored (268 MB of 32-byte-segment stores less per 256 x 512^2 launch)
+        static const bool gm_on = []() { const char* e = getenv("PACOH_GRAD_MFMA"); return !(e && e[0] == '0'); }();
+        const bool gm_plan = gm_on && dense_grad_mfma_plan(B, n, f, kind, dtype, nn * sizeof(T));
+        launch_bgemm<T>(ga, B, s, gm_plan ? 0 : 1);                         // W = Z^T Z
         const long tz = (long)B * n * f;
         hipLaunchKernelGGL(dense_scale_kernel<T>, dim3((unsigned)((tz + 255) / 256)), dim3(256), 0, s, (const T*)z, z_div, (const T*)ls, zsc,
                            P, n, f, tz);
-        // fp64 ARD-RBF: the symmetric MFMA contraction (dense_grad_mfma.hip); its scratch is the factor's buffer, free once W = Z^T Z exists
-        static const bool gm_on = []() { const char* e = getenv("PACOH_GRAD_MFMA"); return !(e && e[0] == '0'); }();
-        const int grc = gm_on ? dense_grad_mfma_try(zsc, ls, os, n_valid, y_div, g_lml, alpha, Wm, (const int32_t*)info, d_z, d_mean, mean_mode,
+        // (its scratch is the factor's buffer, free once W = Z^T Z exists)
+        const int grc = gm_plan ? dense_grad_mfma_try(zsc, ls, os, n_valid, y_div, g_lml, alpha, Wm, (const int32_t*)info, d_z, d_mean, mean_mode,
                                                     rowpart, A, nn * sizeof(T), B, P, n, f, kind, dtype, s) : 1;
         if (grc != 0 && grc != 1) return grc;
         const int FP = f <= 2 ? 2 : (f <= 4 ? 4 : (f <= 8 ? 8 : 16));

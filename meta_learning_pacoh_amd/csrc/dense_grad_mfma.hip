@@ -305,12 +305,16 @@ size_t dense_grad_mfma_scratch(int B, int n) {
     return ((size_t)B * n * 9 + (size_t)B * (nI * (nI - 1) / 2) * GT * 9 + (size_t)B * n) * sizeof(double);
 }
 
+// does the MFMA contraction take this call?  (the caller asks before it builds W: the tile kernel reads W's lower 64-tiles only)
+bool dense_grad_mfma_plan(int B, int n, int f, int kind, int dtype, size_t scratch_bytes) {
+    return dtype == PACOH_F64 && kind == PACOH_KERNEL_RBF && f <= 8 && n >= GT && dense_grad_mfma_scratch(B, n) <= scratch_bytes;
+}
+
 // fp64, ARD-RBF, f <= 8: the MFMA contraction; returns 1 when outside its plan (caller: dense_grad_cols / rows kernels)
 int dense_grad_mfma_try(const void* zs, const void* ls, const void* os, const int32_t* n_valid, int y_div, const void* g_lml,
                         const void* alpha, const void* Wm, const int32_t* info, void* d_z, void* d_mean, int mean_mode, void* rowpart,
                         void* scratch, size_t scratch_bytes, int B, int P, int n, int f, int kind, int dtype, hipStream_t s) {
-    if (dtype != PACOH_F64 || kind != PACOH_KERNEL_RBF || f > 8 || n < GT) return 1;
-    if (dense_grad_mfma_scratch(B, n) > scratch_bytes) return 1;
+    if (!dense_grad_mfma_plan(B, n, f, kind, dtype, scratch_bytes)) return 1;
     const int nI = (n + GT - 1) / GT;
     double* rowside = (double*)scratch;
     double* colpart = rowside + (size_t)B * n * 9;
