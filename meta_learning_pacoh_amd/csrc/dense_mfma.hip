@@ -75,7 +75,11 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     T* Ab = A + (size_t)blockIdx.x * n * n;
-    if (tid == 0) { red[16] = 0; red[100] = 0; red[101] = 0; }
+    if (tid == 0) red[16] = 0;
+#ifdef PACOH_CHOL_STAMPS
+    __shared__ double stamp_wait[2];                   // (own storage: red[96..128) is the reciprocal-pivot scratch of factor_invert_diag32)
+    if (tid == 0) { stamp_wait[0] = 0; stamp_wait[1] = 0; }
+#endif
     for (int q = tid; q < n; q += NT) rv[q] = resid[(size_t)blockIdx.x * n + q];
     T logdet_part = 0;
     __syncthreads();
@@ -256,8 +260,8 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
             }
 #ifdef PACOH_CHOL_STAMPS
             if (tid == 0) ph_[6] += wall_clock64() - tb_;
-            if (tid == 64) red[100] += (T)(wall_clock64() - tb_);
-            if (tid == 960) red[101] += (T)(wall_clock64() - tb_);
+            if (tid == 64) stamp_wait[0] += (double)(wall_clock64() - tb_);
+            if (tid == 960) stamp_wait[1] += (double)(wall_clock64() - tb_);
 #endif
         }
         __syncthreads();
@@ -266,7 +270,7 @@ __global__ void __launch_bounds__(NT) chol_dense_mfma_kernel(T* __restrict__ A, 
 #ifdef PACOH_CHOL_STAMPS
     if (tid == 0 && blockIdx.x == 0)
         printf("chol phases (us): load diag %.1f | factor+invert %.1f | write L11, stage panel %.1f | panel solve %.1f | resid %.1f | trailing %.1f (5b: wave 0 %.1f, wave 1 %.1f, wave 15 %.1f)\n",
-               ph_[0] * 0.01, ph_[1] * 0.01, ph_[2] * 0.01, ph_[3] * 0.01, ph_[4] * 0.01, ph_[5] * 0.01, ph_[6] * 0.01, (double)red[100] * 0.01, (double)red[101] * 0.01);
+               ph_[0] * 0.01, ph_[1] * 0.01, ph_[2] * 0.01, ph_[3] * 0.01, ph_[4] * 0.01, ph_[5] * 0.01, ph_[6] * 0.01, stamp_wait[0] * 0.01, stamp_wait[1] * 0.01);
 #endif
 #undef CSTAMP
 

@@ -432,6 +432,38 @@ def test_svgd_imq_steps_run_from_the_step_feed_and_replay_bit_identically(M, opt
     assert relerr(m_g.particles, X) < 2e-3
 
 
+def test_step_feed_upload_accepts_tensors_lists_and_callables(M):
+    """engine.StepFeed.upload: the per-step payload as ONE tensor [k, ...] (any device, dtype, requires_grad), a list of k tensors, or
+    a callable filling the pinned staging rows -- the same rows reach the device; select() hands them out in order"""
+    from meta_learning_pacoh_amd import _lib as Lb
+    from meta_learning_pacoh_amd.engine import StepFeed
+    dev = torch.device('cuda')
+    k, tb, S, D = 5, 3, 2, 7
+    g = torch.Generator().manual_seed(0)
+    payload = torch.randn(k, S, D, generator=g)
+    idx = np.arange(k * tb).reshape(k, tb) % 4
+    sc = [Lb.step_scalars(0.1 * (j + 1), 1e-3, j + 1) for j in range(k)]
+    forms = {
+        'cpu tensor': payload.clone(),
+        'cuda tensor': payload.to(dev),
+        'fp64 tensor that requires grad': payload.double().requires_grad_(True),
+        'list of tensors': [payload[j].clone() for j in range(k)],
+        'list of cuda tensors': [payload[j].to(dev) for j in range(k)],
+        'callable': lambda j, out: out.copy_(payload[j]),
+    }
+    for name, aux in forms.items():
+        feed = StepFeed(dev, torch.float32, tb, chunk=16, aux_shape=(S, D))
+        feed.upload(idx, sc, aux)
+        torch.cuda.synchronize()
+        assert torch.equal(feed.aux_all[:k].cpu(), payload), name
+        assert torch.equal(feed.idx_all[:k].cpu(), torch.from_numpy(idx)), name
+        for j in range(k):
+            feed.select()
+            torch.cuda.synchronize()
+            assert torch.equal(feed.aux.cpu(), payload[j]) and torch.equal(feed.idx.cpu(), torch.from_numpy(idx[j])), (name, j)
+            assert abs(float(feed.sc[Lb.SC_SCORE_SCALE]) - 0.1 * (j + 1)) < 1e-6
+
+
 def test_vi_full_covariance_steps_match_oracle(M):
     """GPRegressionMetaLearnedVI(cov_type='full') (random_gp.py:249-251): init stream and three Adam steps vs the oracle"""
     T, n, d, S = 4, 12, 2, 3
