@@ -158,98 +158,54 @@ __global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, cons
 #define TST(k) do {} while (0)
 #endif
     // Slab order of a panel with ns k-blocks: the blocks of the panels before the previous one first (descending), then the previous
-    // panel's four -- those rows were stored a moment ago; everything in front of them can be fetched while that panel's epilogue
-    // still runs.
+    // panel's four -- those rows were stored a moment ago.
     auto kb_of = [](int ns, int t) -> int { return ns <= 4 ? ns - 1 - t : (t < ns - 4 ? ns - 5 - t : 2 * ns - 5 - t); };
-    int pre_issued = 0;                                           // slabs of the coming panel already in flight
-    // byte-ring allocator (wave-uniform scalars): offsets of the last eight slabs issued, end of the newest one
-    int rq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rhead = 0;
-    auto rq_get = [&](int i) __attribute__((always_inline)) -> int {
-        int v = 0;
+    // ---- Operands.  The A operand of a slab -- the 64 x 16 piece L[c0 .. c0 + 64, 16 kb .. + 16] every wave multiplies with -- goes
+    // through LDS: NLI LDS-DMA instructions per slab, issued by the two helper waves into a ring of NSLOT fixed slots; L is pure input
+    // (a panel overwrites only its own rows), so the helpers run ONE continuous pipeline over all panels' slabs.  The B operand --
+    // the 16 x 16 block Z[16 kb .. + 16, 16 qb .. + 16] of a finished panel -- is needed by exactly ONE wave (the owner of column
+    // block qb): it loads its fragments straight into registers, one slab ahead, with plain 8-byte loads (16 lanes = 128 bytes of a
+    // row).  The first left-looking version streamed the Z rows through LDS as well: 3 200 of its 4 096 DMA instructions per matrix,
+    // and LDS-DMA turned out to cost 85-750 ns PER INSTRUCTION on the issuing wave (stamps: 77-196 us of "DMA issue" per wave, twice
+    // the time the waves spent on MFMAs) -- the kernel was bound by the DMA path, not by the matrix cores.
+    constexpr int PPR = LRB / 16;                                 // L slab: 16-byte pieces per row, 8 (fp64) / 4 (fp32)
+    constexpr int RPI = 64 / PPR;                                 // ... rows per instruction
+    constexpr int NLI = 64 / RPI;                                 // ... instructions per slab
+    constexpr int LSB = 64 * LRB;                                 // ... bytes
+    constexpr int HPI = NLI / 2;                                  // instructions per slab and helper wave
+    const int nslot = (ring_bytes / LSB) < 16 ? (ring_bytes / LSB) : 16;
+    // issue pointer over the global slab sequence (panel iI, slab it, global index gi); consume pointer gs
+    int iI = 1, it = 0, gi = 0, gs = 0;
+    auto issue_upto = [&](int lim) __attribute__((always_inline)) {          // helpers: bring slabs gi .. lim - 1
+        while (gi < lim && iI < npan) {
+            const int c0_ = iI << 6, ns_ = c0_ >> 4;
+            const int pm_ = (n - c0_) < 64 ? (n - c0_) : 64;
+            const int kb = kb_of(ns_, it);
+            unsigned char* const dst = ring + (gi % nslot) * LSB;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v = (i & 7) == k ? rq[k] : v;
-        return v;
-    };
-    auto rq_set = [&](int i, int v) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) rq[k] = (i & 7) == k ? v : rq[k];
+            for (int h = 0; h < HPI; ++h) {
+                const int v = 2 * h + hw;
+                const int i = v * RPI + lane / PPR, pp = lane % PPR;
+                const int sig = (ES == 8) ? ((i >> 1) & 7) : ((i >> 2) & 3);
+                const int ic = i < pm_ ? i : pm_ - 1;
+                tl_glds16(reinterpret_cast<const unsigned char*>(Ab + (size_t)(c0_ + ic) * n + 16 * kb) + ((pp ^ sig) << 4), dst + v * 1024);
+            }
+            ++gi;
+            if (++it == ns_) { it = 0; ++iI; }
+        }
     };
     for (int I = 0; I < npan; ++I) {
         const int c0 = I << 6;
         const int NBq = c0 >> 4;                                  // column blocks of the panel's product
-        const int ns = NBq;                                       // slabs (16 rows of Z each)
+        const int ns = NBq;                                       // slabs (16 columns of L x 16 rows of Z each)
         const int pm = (n - c0) < 64 ? (n - c0) : 64;             // rows of this panel inside the matrix
 
-        // ---- The slabs live in a BYTE ring: slab t (k block kb) takes 16 rows of exactly its own length (16 kb + 16 columns) plus the
-        // 64 x 16 L slab, placed behind its predecessor (wrapping to 0 when it does not fit).  With entries of the widest slab's size
-        // only two fit at the big panels, and one slab in flight per CU is latency-bound (64 KB / 2.5 us = 26 GB/s): every slab
-        // waited 2-3 us for its data.  Tight entries let the smaller slabs run three or four deep.
-        // DMA: EVERY wave issues -- wave w brings row w of the Z slab (ceil(pieces / 64) instructions of 64 x 16 bytes, the last one
-        // partial = EXEC-masked), the first waves one instruction of the L slab each; two dedicated helper waves needed 350 us for
-        // the launch's 4096 instructions.  Bank layout of a Z slab row: rows of a multiple of 256 bytes store piece p of row k' at
-        // position p ^ (8 (k' & 1)) -- the two rows a 32-lane read group touches (k' = 4 s + g, g = 0 / 1) then sit in different
-        // 128-byte halves of the 256-byte bank row; rows of an odd multiple of 128 bytes do so by themselves.
-        constexpr int PPR = LRB / 16;                             // L slab: pieces per row, 8 (fp64) / 4 (fp32)
-        constexpr int RPI = 64 / PPR;                             // ... rows per instruction
-        constexpr int NLI = 64 / RPI;                             // ... instructions per slab
-        constexpr int DMAX = 4;                                   // slabs in flight beyond the one being consumed
-        auto esize = [&](int ns_, int u) __attribute__((always_inline)) -> int { return KS * (16 * kb_of(ns_, u) + 16) * ES + 64 * LRB; };
-        // place slab u of a panel with ns_ slabs beside the live slabs oldest .. u - 1 (none live: oldest == u): its offset, or -1
-        auto place = [&](int ns_, int u, int oldest) __attribute__((always_inline)) -> int {
-            if (u >= ns_ || u > oldest + DMAX) return -1;
-            const int sz = esize(ns_, u);
-            if (oldest == u) { rhead = sz; return 0; }            // empty ring
-            const int tail = rq_get(oldest);
-            int off = -1;
-            if (rhead > tail) {                                   // live bytes [tail, rhead): room behind them, or in front after a wrap
-                if (rhead + sz <= ring_bytes) off = rhead;
-                else if (sz <= tail) off = 0;
-            } else if (rhead + sz <= tail) off = rhead;           // wrapped: live bytes [tail, end) and [0, rhead)
-            if (off >= 0) rhead = off + sz;
-            return off;
-        };
-        auto dma_p = [&](int I_, int t, int off) __attribute__((always_inline)) {  // slab t of panel I_ at ring offset off
-            const int c0_ = I_ << 6, ns_ = c0_ >> 4;
-            const int pm_ = (n - c0_) < 64 ? (n - c0_) : 64;
-            const int kb = kb_of(ns_, t);
-            const int RS_ = (16 * kb + 16) * ES;
-            unsigned char* const zb = ring + off;
-            const int pieces = RS_ / 16;
-            const int ipr = (pieces + 63) >> 6;                   // instructions per row
-            const int lxx = (RS_ & 255) == 0 ? (lane ^ (8 * (wave & 1))) : lane;
-            const unsigned char* const rowp = reinterpret_cast<const unsigned char*>(Ab + (size_t)(16 * kb + wave) * n);
-            for (int ch = 0; ch < ipr; ++ch)
-                if (ch * 64 + lane < pieces) tl_glds16(rowp + (ch * 64 + lxx) * 16, zb + wave * RS_ + ch * 1024);
-            if (wave < NLI) {                                     // L rows c0 .. + 64 (clamped to the matrix), columns 16 kb .. + 16
-                const int i = wave * RPI + lane / PPR, pp = lane % PPR;
-                const int sig = (ES == 8) ? ((i >> 1) & 7) : ((i >> 2) & 3);
-                const int ic = i < pm_ ? i : pm_ - 1;
-                tl_glds16(reinterpret_cast<const unsigned char*>(Ab + (size_t)(c0_ + ic) * n + 16 * kb) + ((pp ^ sig) << 4),
-                          zb + KS * RS_ + wave * 1024);
-            }
-        };
-        auto dma_count = [&](int t) __attribute__((always_inline)) -> int {      // this wave's instructions for slab t
-            const int pieces = (16 * kb_of(ns, t) + 16) * ES / 16;
-            return ((pieces + 63) >> 6) + (wave < NLI ? 1 : 0);
-        };
-        int nxt = pre_issued;                                     // next slab to issue
-        // the loop's barrier: a RAW s_barrier behind a COUNTED vmcnt (the slabs beyond t + 1 stay in flight across it)
-        auto slab_barrier = [&](int t) __attribute__((always_inline)) {
-            int pend = 0;
-            for (int u = t + 2; u < nxt; ++u) pend += dma_count(u);
-            tl_wait_vmcnt(pend);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        };
-
         TST(0);
-        __syncthreads();                                          // previous panel's stores are visible, its LDS reads are over
+        __syncthreads();                                          // previous panel's stores are visible, its image reads are over
         TST(1);
-        for (;;) { const int o = place(ns, nxt, 0); if (o < 0) break; rq_set(nxt, o); dma_p(I, nxt, o); ++nxt; }
-        if constexpr (IMG) img_write(I);
+        if constexpr (IMG) { issue_upto(gs + nslot); img_write(I); }
         TST(2);
-        __syncthreads();                                          // images written, first slab(s) landed
+        __syncthreads();                                          // images written; (vmcnt(0): the slabs issued so far have landed)
         TST(3);
         if constexpr (IMG) { if (I + 1 < npan) img_load(I + 1); }           // (rows of L / inverse blocks no panel before I + 1 writes)
 
@@ -260,52 +216,52 @@ __global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, cons
         }
         const int qb0 = mw, qb1 = NBq - 1 - mw;                   // this wave's column blocks (qb1 > qb0 when it has two)
         const bool v0 = !is_helper && mw < (NBq + 1) / 2, v1 = v0 && qb1 > qb0;
-
-        for (int t = 0; t < ns; ++t) {
+        // B fragments of slab kb for this wave's column blocks: unconditional loads at clamped (always valid) addresses -- whether a
+        // block takes part is decided where the values are used
+        auto load_b = [&](int kb, T (&b0)[IMG ? 1 : 4], T (&b1)[IMG ? 1 : 4]) __attribute__((always_inline)) {
+            if constexpr (!IMG) {
+                const int q0 = qb0 <= kb ? qb0 : kb, q1 = (v1 && qb1 <= kb) ? qb1 : kb;
+                // (32-bit element offsets from the wave-uniform matrix base: no 64-bit address per fragment in vector registers)
+                const int ob = 16 * kb * n + r;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int orow = ob + Mf<T>::row(g, s) * n;
+                    b0[s] = Ab[orow + 16 * q0];
+                    b1[s] = Ab[orow + 16 * q1];
+                }
+            }
+        };
+        // one slab: MFMAs with the fragments bc, the next slab's fragments requested into bn first
+        auto slab = [&](int t, T (&bc0)[IMG ? 1 : 4], T (&bc1)[IMG ? 1 : 4], T (&bn0)[IMG ? 1 : 4], T (&bn1)[IMG ? 1 : 4]) __attribute__((always_inline)) {
             const int kb = kb_of(ns, t);
-            const int RS = (16 * kb + 16) * ES;
-            const unsigned char* const zb = ring + rq_get(t);
-            const unsigned char* const lb = zb + KS * RS;
-            const bool zswz = (RS & 255) == 0;
-            for (;;) { const int o = place(ns, nxt, t); if (o < 0) break; rq_set(nxt, o); dma_p(I, nxt, o); ++nxt; }
+            const unsigned char* const lb = ring + (gs % nslot) * LSB;
+            if constexpr (IMG) issue_upto(gs + nslot);
+            if (t + 1 < ns) load_b(kb_of(ns, t + 1), bn0, bn1);
             TST(7);
             // out[i][q] += L[c0 + i][16 kb + k] Z[16 kb + k][q]: column block qb takes part iff qb <= kb; in the diagonal block
             // (qb == kb) the entries above Z's diagonal are not Z (the Cholesky's inverse blocks live there): masked to zero
             const bool d0 = v0 && qb0 <= kb, d1 = v1 && qb1 <= kb;
             if constexpr (!IMG) {
-                // (the wave's shape in this slab -- one or two column blocks -- as compile-time flags: wave-uniform branches inside
-                //  the k loop cut each step's read / MFMA stream apart; the diagonal-block mask is a multiplication by 0 / 1)
                 auto body = [&](auto c0c, auto c1c) __attribute__((always_inline)) {
                     constexpr bool C0 = decltype(c0c)::value, C1 = decltype(c1c)::value;
                     const int lsig = (ES == 8) ? ((r >> 1) & 7) : ((r >> 2) & 3);
-                    T av[4][4], b0[4], b1[4];
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         const int kk = Mf<T>::row(g, s);          // k inside the slab for this lane at step s
                         const int piece = (kk * ES) >> 4, lo = (kk * ES) & 15;
+                        T av[4];
 #pragma unroll
                         for (int ib = 0; ib < 4; ++ib)
-                            av[s][ib] = *reinterpret_cast<const T*>(lb + (16 * ib + r) * LRB + ((piece ^ lsig) << 4) + lo);
-                        const unsigned char* const zrow = zb + kk * RS;
-                        const int zx = zswz ? 8 * (kk & 1) : 0;
+                            av[ib] = *reinterpret_cast<const T*>(lb + (16 * ib + r) * LRB + ((piece ^ lsig) << 4) + lo);
                         if constexpr (C0) {
-                            const int q = 16 * qb0 + r;
-                            b0[s] = *reinterpret_cast<const T*>(zrow + ((((q * ES) >> 4) ^ zx) << 4) + ((q * ES) & 15)) * ((qb0 == kb && r > kk) ? T(0) : T(1));
+                            const T b = bc0[s] * ((qb0 == kb && r > kk) ? T(0) : T(1));
+#pragma unroll
+                            for (int ib = 0; ib < 4; ++ib) acc0[ib] = Mf<T>::mma(av[ib], b, acc0[ib]);
                         }
                         if constexpr (C1) {
-                            const int q = 16 * qb1 + r;
-                            b1[s] = *reinterpret_cast<const T*>(zrow + ((((q * ES) >> 4) ^ zx) << 4) + ((q * ES) & 15)) * ((qb1 == kb && r > kk) ? T(0) : T(1));
-                        }
-                    }
+                            const T b = bc1[s] * ((qb1 == kb && r > kk) ? T(0) : T(1));
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        if constexpr (C0) {
-#pragma unroll
-                            for (int ib = 0; ib < 4; ++ib) acc0[ib] = Mf<T>::mma(av[s][ib], b0[s], acc0[ib]);
-                        }
-                        if constexpr (C1) {
-#pragma unroll
-                            for (int ib = 0; ib < 4; ++ib) acc1[ib] = Mf<T>::mma(av[s][ib], b1[s], acc1[ib]);
+                            for (int ib = 0; ib < 4; ++ib) acc1[ib] = Mf<T>::mma(av[ib], b, acc1[ib]);
                         }
                     }
                 };
@@ -314,24 +270,24 @@ __global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, cons
                 else if (d1) body(std::false_type{}, std::true_type{});
             }
             TST(4);
-            if (nxt > t + 1 || t + 1 >= ns) slab_barrier(t);
-            else {                                                // (the next slab did not fit beside this one: fetch it between two barriers)
-                __syncthreads();
-                { const int o = place(ns, nxt, nxt); rq_set(nxt, o); dma_p(I, nxt, o); ++nxt; }
-                __syncthreads();
+            // the loop's barrier: a RAW s_barrier; the helpers wait for THEIR instructions of the next slab first (counted: the slabs
+            // beyond it stay in flight), the MFMA waves' fragment loads stay in flight across it
+            if constexpr (IMG) {
+                const int later = gi - (gs + 2);                  // slabs issued behind the next one
+                tl_wait_vmcnt(later > 0 ? later * HPI : 0);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            ++gs;
             TST(5);
-        }
-
-        // the ring is free from here on: the coming panel's first slabs that do not depend on this panel's rows (its old k blocks)
-        pre_issued = 0;
-        if (I + 1 < npan) {
-            const int ns2 = (I + 1) << 2;
-            for (;;) {
-                if (pre_issued >= ns2 - 4) break;
-                const int o = place(ns2, pre_issued, 0);
-                if (o < 0) break;
-                rq_set(pre_issued, o); dma_p(I + 1, pre_issued, o); ++pre_issued;
+        };
+        {
+            T ba0[IMG ? 1 : 4], ba1[IMG ? 1 : 4], bb0[IMG ? 1 : 4], bb1[IMG ? 1 : 4];
+            if (ns > 0) load_b(kb_of(ns, 0), ba0, ba1);
+            for (int t = 0; t < ns; t += 2) {
+                slab(t, ba0, ba1, bb0, bb1);
+                if (t + 1 < ns) slab(t + 1, bb0, bb1, ba0, ba1);
             }
         }
         // ---- epilogue: Z[I, q-block] = -Z_II out, through the 2 x 2 structure of Z_II (images -Z00 | L10 | -Z11), from registers
