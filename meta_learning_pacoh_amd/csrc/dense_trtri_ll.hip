@@ -217,26 +217,27 @@ __global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, cons
         const int qb0 = mw, qb1 = NBq - 1 - mw;                   // this wave's column blocks (qb1 > qb0 when it has two)
         const bool v0 = !is_helper && mw < (NBq + 1) / 2, v1 = v0 && qb1 > qb0;
         // B fragments of slab kb for this wave's column blocks: unconditional loads at clamped (always valid) addresses -- whether a
-        // block takes part is decided where the values are used
-        auto load_b = [&](int kb, T (&b0)[IMG ? 1 : 4], T (&b1)[IMG ? 1 : 4]) __attribute__((always_inline)) {
-            if constexpr (!IMG) {
-                const int q0 = qb0 <= kb ? qb0 : kb, q1 = (v1 && qb1 <= kb) ? qb1 : kb;
-                // (32-bit element offsets from the wave-uniform matrix base: no 64-bit address per fragment in vector registers)
-                const int ob = 16 * kb * n + r;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int orow = ob + Mf<T>::row(g, s) * n;
-                    b0[s] = Ab[orow + 16 * q0];
-                    b1[s] = Ab[orow + 16 * q1];
-                }
-            }
+        // block takes part is decided where the values are used.  ONE register set: fragment s of the NEXT slab is requested into the
+        // register of fragment s of this slab right behind the MFMAs that read it, so every fragment has a whole slab's time to arrive
+        // (a second set for ping-pong spilled 52 registers at the 128 this 1024-thread kernel has: the "load issue" phase then read
+        // 249 us on the stamps -- scratch traffic).
+        T bf0[IMG ? 1 : 4], bf1[IMG ? 1 : 4];
+        auto frag_off = [&](int kb, int s, int& o0, int& o1) __attribute__((always_inline)) {
+            const int q0 = qb0 <= kb ? qb0 : kb, q1 = (v1 && qb1 <= kb) ? qb1 : kb;
+            const int orow = (16 * kb + Mf<T>::row(g, s)) * n + r;           // (32-bit element offsets from the wave-uniform base)
+            o0 = orow + 16 * q0; o1 = orow + 16 * q1;
         };
-        // one slab: MFMAs with the fragments bc, the next slab's fragments requested into bn first
-        auto slab = [&](int t, T (&bc0)[IMG ? 1 : 4], T (&bc1)[IMG ? 1 : 4], T (&bn0)[IMG ? 1 : 4], T (&bn1)[IMG ? 1 : 4]) __attribute__((always_inline)) {
+        if constexpr (!IMG) {
+            if (ns > 0) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { int o0, o1; frag_off(kb_of(ns, 0), s, o0, o1); bf0[s] = Ab[o0]; bf1[s] = Ab[o1]; }
+            }
+        }
+        for (int t = 0; t < ns; ++t) {
             const int kb = kb_of(ns, t);
+            const int kbn = t + 1 < ns ? kb_of(ns, t + 1) : kb;   // (last slab: a harmless reload of itself)
             const unsigned char* const lb = ring + (gs % nslot) * LSB;
             if constexpr (IMG) issue_upto(gs + nslot);
-            if (t + 1 < ns) load_b(kb_of(ns, t + 1), bn0, bn1);
             TST(7);
             // out[i][q] += L[c0 + i][16 kb + k] Z[16 kb + k][q]: column block qb takes part iff qb <= kb; in the diagonal block
             // (qb == kb) the entries above Z's diagonal are not Z (the Cholesky's inverse blocks live there): masked to zero
@@ -248,26 +249,32 @@ __global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, cons
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         const int kk = Mf<T>::row(g, s);          // k inside the slab for this lane at step s
-                        const int piece = (kk * ES) >> 4, lo = (kk * ES) & 15;
-                        T av[4];
+                        if constexpr (C0 || C1) {
+                            const int piece = (kk * ES) >> 4, lo = (kk * ES) & 15;
+                            T av[4];
 #pragma unroll
-                        for (int ib = 0; ib < 4; ++ib)
-                            av[ib] = *reinterpret_cast<const T*>(lb + (16 * ib + r) * LRB + ((piece ^ lsig) << 4) + lo);
-                        if constexpr (C0) {
-                            const T b = bc0[s] * ((qb0 == kb && r > kk) ? T(0) : T(1));
+                            for (int ib = 0; ib < 4; ++ib)
+                                av[ib] = *reinterpret_cast<const T*>(lb + (16 * ib + r) * LRB + ((piece ^ lsig) << 4) + lo);
+                            if constexpr (C0) {
+                                const T bv = bf0[s] * ((qb0 == kb && r > kk) ? T(0) : T(1));
 #pragma unroll
-                            for (int ib = 0; ib < 4; ++ib) acc0[ib] = Mf<T>::mma(av[ib], b, acc0[ib]);
+                                for (int ib = 0; ib < 4; ++ib) acc0[ib] = Mf<T>::mma(av[ib], bv, acc0[ib]);
+                            }
+                            if constexpr (C1) {
+                                const T bv = bf1[s] * ((qb1 == kb && r > kk) ? T(0) : T(1));
+#pragma unroll
+                                for (int ib = 0; ib < 4; ++ib) acc1[ib] = Mf<T>::mma(av[ib], bv, acc1[ib]);
+                            }
                         }
-                        if constexpr (C1) {
-                            const T b = bc1[s] * ((qb1 == kb && r > kk) ? T(0) : T(1));
-#pragma unroll
-                            for (int ib = 0; ib < 4; ++ib) acc1[ib] = Mf<T>::mma(av[ib], b, acc1[ib]);
-                        }
+                        int o0, o1;
+                        frag_off(kbn, s, o0, o1);
+                        bf0[s] = Ab[o0]; bf1[s] = Ab[o1];
                     }
                 };
                 if (d0 && d1) body(std::true_type{}, std::true_type{});
                 else if (d0) body(std::true_type{}, std::false_type{});
                 else if (d1) body(std::false_type{}, std::true_type{});
+                else body(std::false_type{}, std::false_type{});
             }
             TST(4);
             // the loop's barrier: a RAW s_barrier; the helpers wait for THEIR instructions of the next slab first (counted: the slabs
@@ -281,14 +288,6 @@ __global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, cons
             asm volatile("" ::: "memory");
             ++gs;
             TST(5);
-        };
-        {
-            T ba0[IMG ? 1 : 4], ba1[IMG ? 1 : 4], bb0[IMG ? 1 : 4], bb1[IMG ? 1 : 4];
-            if (ns > 0) load_b(kb_of(ns, 0), ba0, ba1);
-            for (int t = 0; t < ns; t += 2) {
-                slab(t, ba0, ba1, bb0, bb1);
-                if (t + 1 < ns) slab(t + 1, bb0, bb1, ba0, ba1);
-            }
         }
         // ---- epilogue: Z[I, q-block] = -Z_II out, through the 2 x 2 structure of Z_II (images -Z00 | L10 | -Z11), from registers
         auto zmul = [&](int av, int b, const Acc& X, Acc o) __attribute__((always_inline)) -> Acc {
