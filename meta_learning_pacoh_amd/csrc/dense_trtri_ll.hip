@@ -26,6 +26,7 @@ namespace {
 
 constexpr int TL_NT = 1024;
 constexpr int TL_NMMA = 14;
+constexpr int TL_G = 2;              // slabs per barrier of the slab loop (1: 409 us, 2: 392 us, 4: 493 us at 256 x 512^2 fp64)
 
 __host__ __device__ constexpr int tl_tri(int a, int b) { return a * (a + 1) / 2 + b; }
 
@@ -237,7 +238,8 @@ __global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, cons
             const int kb = kb_of(ns, t);
             const int kbn = t + 1 < ns ? kb_of(ns, t + 1) : kb;   // (last slab: a harmless reload of itself)
             const unsigned char* const lb = ring + (gs % nslot) * LSB;
-            if constexpr (IMG) issue_upto(gs + nslot);
+            // (slabs are handed over in groups of TL_G: one barrier per group -- the ring is sixteen slabs deep)
+            if constexpr (IMG) { if ((t & (TL_G - 1)) == 0) issue_upto(gs + nslot); }
             TST(7);
             // out[i][q] += L[c0 + i][16 kb + k] Z[16 kb + k][q]: column block qb takes part iff qb <= kb; in the diagonal block
             // (qb == kb) the entries above Z's diagonal are not Z (the Cholesky's inverse blocks live there): masked to zero
@@ -279,13 +281,15 @@ __global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, cons
             TST(4);
             // the loop's barrier: a RAW s_barrier; the helpers wait for THEIR instructions of the next slab first (counted: the slabs
             // beyond it stay in flight), the MFMA waves' fragment loads stay in flight across it
-            if constexpr (IMG) {
-                const int later = gi - (gs + 2);                  // slabs issued behind the next one
-                tl_wait_vmcnt(later > 0 ? later * HPI : 0);
+            if (((t + 1) & (TL_G - 1)) == 0 || t + 1 == ns) {
+                if constexpr (IMG) {
+                    const int later = gi - (gs + 1 + TL_G);       // slabs issued behind the next group
+                    tl_wait_vmcnt(later > 0 ? later * HPI : 0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
             ++gs;
             TST(5);
         }
