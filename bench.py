@@ -466,9 +466,9 @@ def cpu_baseline_other(cfg, budget_s=2.5):
 
 
 def cfg5_hbm_report(L):
-    """BASELINE config #5's HBM-roofline report: the fp64 Gram leg at n = 512, d = 8 measured here (HIP events, the public entry point:
-    full matrices, 2.13 MB per Gram), the lower-triangle-tiles launch the path itself uses, and the factorisation kernels' HBM
-    traffic against one pass over the matrices from the COMMITTED PMC profile (not measured in this run)."""
+    """BASELINE config #5's HBM-roofline report: the fp64 Gram leg at n = 512, d = 8 measured here (HIP events, the public entry point on
+    one point set: full symmetric matrices, 2.13 MB per Gram; the path itself launches the lower block triangle only), and the
+    large-context kernels' HBM traffic against one pass over the matrices from the COMMITTED PMC profile (not measured in this run)."""
     B, n, d = 256, 512, 8
     z = torch.randn(B, n, d, dtype=torch.float64, device='cuda')
     ls = torch.full((1, d), 0.6931, dtype=torch.float64, device='cuda')
@@ -489,7 +489,7 @@ def cfg5_hbm_report(L):
     torch.cuda.synchronize()
     t_k = s.elapsed_time(e) / 20 * 1e-3
     alg = B * (n * d * 8 + n * n * 8)
-    out = {'gram': {'kernel': 'gram_rbf_ard fp64 n=512 d=8 (full matrices)', 'bound': 'hbm', 'algorithmic_bytes': alg, 'bytes_per_gram': n * d * 8 + n * n * 8,
+    out = {'gram': {'kernel': 'gram_rbf_ard fp64 n=512 d=8 (full matrices, one point set)', 'bound': 'hbm', 'algorithmic_bytes': alg, 'bytes_per_gram': n * d * 8 + n * n * 8,
                     'us_per_launch': round(t_k * 1e6, 1), 'achieved': round(alg / t_k / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(alg / t_k / 1e9 / HBM_PEAK_GBS, 4)}}
     try:

@@ -234,10 +234,14 @@ __global__ void __launch_bounds__(256) dense_grad_combine_kernel(const double* _
 // bytes); here the distances are |u_i|^2 + |u_j|^2 - 2 u_i . u_j with the product on the matrix cores.  The coordinates are taken
 // relative to the problem's first point before scaling, which keeps |u|^2 -- and with it the cancellation error ~1e-16 |u|^2 -- small;
 // the diagonal is exact by construction (d2 = 0), the result is symmetric bit for bit (S_ij and S_ji are the same products).
+// MIRROR (pacoh_gram_rbf_ard on one point set): the tiles below the block diagonal are also written transposed, through a 16 x 17
+// LDS scratch per wave so that both stores are 128-byte row segments -- half the exps of the full matrix, all of its bytes.
+template <bool MIRROR>
 __global__ void __launch_bounds__(256, 4) dense_gram_tile_kernel(const double* __restrict__ z, int z_div, const double* __restrict__ lsp,
                                                                  const double* __restrict__ osp, const double* __restrict__ noisep,
                                                                  double* __restrict__ K, int P, int n, int f) {
     __shared__ double ZI[GT][GZL], ZJ[GT][GZL], n2I[GT], n2J[GT];
+    __shared__ double Tr[MIRROR ? 4 : 1][16][17];
     const long b = blockIdx.y;
     int I = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
     while (I * (I + 1) / 2 > (int)blockIdx.x) --I;
@@ -265,7 +269,7 @@ __global__ void __launch_bounds__(256, 4) dense_gram_tile_kernel(const double* _
     stage(ZI, n2I, I0);
     stage(ZJ, n2J, J0);
     __syncthreads();
-    const double os = osp ? osp[p] : 1.0, noise = noisep[p];
+    const double os = osp ? osp[p] : 1.0, noise = noisep ? noisep[p] : 0.0;
     const int j = 16 * w + r, gj = J0 + j;
     double* Kb = K + b * (long)n * n;
 #pragma unroll
@@ -282,6 +286,20 @@ __global__ void __launch_bounds__(256, 4) dense_gram_tile_kernel(const double* _
             double k = os * rbf_exp<double>(-0.5 * d2);
             if (gi == gj) k += noise;
             if (gi < n && gj < n) Kb[(long)gi * n + gj] = k;
+            if constexpr (MIRROR) Tr[w][gm_row(g, q)][r] = k;
+        }
+        if constexpr (MIRROR) {
+            if (I != J) {                                          // (wave-uniform) K[J0 + 16 w + jj][I0 + 16 ib + ii], ii = r: rows of 128 bytes
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int jj = gm_row(g, q), mj = J0 + 16 * w + jj, mi = I0 + 16 * ib + r;
+                    if (mj < n && mi < n) Kb[(long)mj * n + mi] = Tr[w][r][jj];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
 }
@@ -294,7 +312,18 @@ int dense_gram_mfma_try(const void* z, int z_div, const void* ls, const void* os
     static const bool on = []() { const char* e = getenv("PACOH_GRAM_MFMA"); return !(e && e[0] == '0'); }();
     if (!on || dtype != PACOH_F64 || f > 8 || n < GT || !noise) return 1;
     const int nI = (n + GT - 1) / GT;
-    hipLaunchKernelGGL(dense_gram_tile_kernel, dim3(nI * (nI + 1) / 2, B), dim3(256), 0, s, (const double*)z, z_div, (const double*)ls,
+    hipLaunchKernelGGL(dense_gram_tile_kernel<false>, dim3(nI * (nI + 1) / 2, B), dim3(256), 0, s, (const double*)z, z_div, (const double*)ls,
+                       (const double*)os, (const double*)noise, (double*)K, P, n, f);
+    return launch_status();
+}
+
+// pacoh_gram_rbf_ard with z1 == z2 (one point set, square, fp64, f <= 8, n >= 64): the whole symmetric matrix from its lower tiles
+int dense_gram_mfma_full(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
+                         hipStream_t s) {
+    static const bool on = []() { const char* e = getenv("PACOH_GRAM_MFMA"); return !(e && e[0] == '0'); }();
+    if (!on || f > 8 || n < GT) return 1;
+    const int nI = (n + GT - 1) / GT;
+    hipLaunchKernelGGL(dense_gram_tile_kernel<true>, dim3(nI * (nI + 1) / 2, B), dim3(256), 0, s, (const double*)z, z_div, (const double*)ls,
                        (const double*)os, (const double*)noise, (double*)K, P, n, f);
     return launch_status();
 }

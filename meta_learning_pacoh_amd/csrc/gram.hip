@@ -245,6 +245,11 @@ int gram_rbf_for_chol(const void* z, int z_div, const void* ls, const void* os, 
 
 using namespace pacoh;
 
+namespace pacoh {
+int dense_gram_mfma_full(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
+                         hipStream_t s);                                                     // dense_grad_mfma.hip (1: not in its plan)
+}
+
 // Any kernel family (common.h: kern_eval), one thread per entry: the families other than ARD-RBF are capability, not hot path
 namespace pacoh {
 template <typename T>
@@ -291,5 +296,9 @@ extern "C" int pacoh_gram_rbf_ard(const void* z1, int z1_div, const void* z2, in
     }
     if (dtype == PACOH_F32)
         return launch_gram<float>(z1, z1_div, z2, z2_div, lengthscale, outputscale, noise, add_noise_diag, K, B, P, n, m, f, (hipStream_t)stream);
+    if (z1 == z2 && z1_div == z2_div && n == m) {            // one point set: symmetric, distances on the matrix cores (dense_grad_mfma.hip)
+        const int rc = dense_gram_mfma_full(z1, z1_div, lengthscale, outputscale, add_noise_diag ? noise : nullptr, K, B, P, n, f, (hipStream_t)stream);
+        if (rc != 1) return rc;
+    }
     return launch_gram<double>(z1, z1_div, z2, z2_div, lengthscale, outputscale, noise, add_noise_diag, K, B, P, n, m, f, (hipStream_t)stream);
 }

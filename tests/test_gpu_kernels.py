@@ -86,6 +86,26 @@ def test_gram_square_with_noise(L):
     assert maxrel(K, ref) < 1e-12
 
 
+@pytest.mark.parametrize('case', [(2, 3, 64, 8), (1, 2, 130, 5), (2, 1, 512, 8), (1, 1, 200, 1)])
+def test_gram_one_point_set_fp64_symmetric_path(L, case):
+    """pacoh_gram_rbf_ard with z1 and z2 the SAME buffer (fp64, f <= 8, n >= 64): lower tiles with the distances on the matrix cores,
+    mirrored through LDS -- against the direct-difference oracle, symmetric bit for bit, with and without the noise diagonal"""
+    T, P, n, f = case
+    B = T * P
+    g = torch.Generator().manual_seed(n)
+    z = (3.0 * torch.randn(B, n, f, generator=g, dtype=torch.float64)).to(DEV)
+    ls = (torch.rand(P, f, generator=g, dtype=torch.float64) + 0.5).to(DEV)
+    os_ = (torch.rand(P, generator=g, dtype=torch.float64) + 0.5).to(DEV)
+    noise = (torch.rand(P, generator=g, dtype=torch.float64) * 0.1 + 0.01).to(DEV)
+    lsb = ls.cpu().unsqueeze(0).expand(T, P, f).reshape(B, 1, f)
+    ref = os_.cpu().unsqueeze(0).expand(T, P).reshape(B, 1, 1) * O.gram_rbf_ard(z.cpu(), z.cpu(), lsb)
+    K = L.gram_rbf_ard(z, 1, z, 1, ls, os_, None, False, B, P)
+    assert maxrel(K, ref) < 1e-12 and torch.equal(K, K.transpose(-1, -2))
+    Kn = L.gram_rbf_ard(z, 1, z, 1, ls, os_, noise, True, B, P)
+    refn = ref + torch.diag_embed(noise.cpu().unsqueeze(0).expand(T, P).reshape(B, 1).expand(B, n))
+    assert maxrel(Kn, refn) < 1e-12 and torch.equal(Kn, Kn.transpose(-1, -2))
+
+
 # ------------------------------------------------------------------------------------------ lml fwd
 CASES = [  # T, P, n, f, per_eval_z
     (4, 3, 5, 2, True),        # cfg #1 shape (demo)
