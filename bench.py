@@ -33,7 +33,7 @@ TASKS, N_CTX, DIM, PARTICLES = 1024, 64, 4, 20
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy peak)
 FP32_PEAK_TFLOPS = 157.3       # fp32 vector peak == fp32-input MFMA peak (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6        # fp64 matrix peak: AMD's MI355X figure; tools/mfma_peak.hip measures what v_mfma_f64_16x16x4 sustains
-PMC_PROFILE = os.path.join('profiles', 'r03_pmc_hbm_traffic.json')
+PMC_PROFILE = os.path.join('profiles', 'r04_pmc_hbm_traffic.json')
 DENSE_PMC_PROFILE = os.path.join('profiles', 'r04_dense_pmc_hbm_traffic.json')
 
 
