@@ -110,6 +110,8 @@ __global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* _
         Acc oj = {0, 0, 0, 0};
         double wv[2][4];
         load_w(J0, 0, wv[0]);
+        // (Also measured and dropped: eight waves per workgroup sharing an LDS image of the M tile -- one accumulator per side and wave,
+        //  128 registers, four waves per SIMD, two workgroup barriers per tile instead of eight wave-level waits: 336 us.)
         // one 16 x 16 block of the tile at a time, W requested one block ahead.  (Requesting the WHOLE next tile a tile ahead -- 16 loads
         // per lane in flight instead of 4 -- needs 223 registers, two waves per SIMD instead of three: 268 -> 306 us.  The kernel
         // waits on its own LDS / MFMA chain per block, not on HBM.)
