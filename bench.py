@@ -497,7 +497,8 @@ def cfg5_hbm_report(L):
             prof = json.load(fh)
         one_pass = B * n * n * 8
         out['traffic'] = {'source': 'committed PMC profile %s (not measured in this run)' % DENSE_PMC_PROFILE, 'one_pass_over_the_matrices_bytes': one_pass,
-                          'kernels': {k: {'hbm_bytes_per_factorisation': v, 'ratio_to_one_pass': round(v / one_pass, 2)} for k, v in prof['per_pass'].items()}}
+                          'kernels': {k: {'hbm_bytes_per_pass': v, 'ratio_to_one_pass': round(v / one_pass, 2)} for k, v in prof['per_pass'].items()
+                                      if not k.startswith(('at::', '__amd'))}}
     except Exception:
         out['traffic'] = None
     return out
