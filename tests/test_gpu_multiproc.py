@@ -31,7 +31,12 @@ def _run(world_rank, world, port, out_dir, kind):
     torch.cuda.set_device(0)
     import meta_learning_pacoh_amd as M
     tasks = O.sinusoid_tasks_nd(9, 16, 2, seed0=300)
-    if kind in ('svgd', 'svgd_unseeded'):
+    if kind == 'svgd_imq':
+        # the IMQ particle kernel's update (round 4: on the step feed / in the step graphs) behind the same exchange
+        model = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=4, task_batch_size=6, lr=1e-2, random_seed=11, kernel='IMQ', optimizer='SGD')
+        model.meta_fit(verbose=False, n_iter=3)
+        state = model.particles
+    elif kind in ('svgd', 'svgd_unseeded'):
         # unseeded: rank 0's seed is broadcast (parallel.broadcast_seed), so the ranks still draw the same task batches
         model = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=4, task_batch_size=6, lr=1e-2,
                                               random_seed=11 if kind == 'svgd' else None)
@@ -76,7 +81,7 @@ def test_unseeded_two_rank_run_stays_in_step():
         assert np.isfinite(r0).all() and np.array_equal(r0, r1)
 
 
-@pytest.mark.parametrize('kind', ['svgd', 'vi', 'map', 'map_sgd'])
+@pytest.mark.parametrize('kind', ['svgd', 'svgd_imq', 'vi', 'map', 'map_sgd'])
 def test_two_ranks_on_one_gpu_match_single_process(kind):
     if not torch.cuda.is_available():
         pytest.skip('needs a HIP device')
