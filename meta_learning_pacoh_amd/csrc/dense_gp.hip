@@ -749,14 +749,17 @@ __global__ void __launch_bounds__(256) dense_grad_cols_kernel(const T* __restric
     }
 }
 
-// ---- per-problem results: lml and the reduced hyper-parameter gradients; one wave per problem ---------------------------------
+// ---- per-problem results: lml and the reduced hyper-parameter gradients; one 256-thread workgroup per problem, a thread per row (its
+// f + 3 values are contiguous), wave sums then the four waves in order (fixed: deterministic).  One wave reading column by column
+// with an 88-byte stride took 19 us per 256 x 512 launch -- as long as the 256 x 512^2 Gram kernel's tail.
 template <typename T>
-__global__ void __launch_bounds__(64) dense_finish_kernel(const T* __restrict__ logp, const T* __restrict__ rowpart,
+__global__ void __launch_bounds__(256) dense_finish_kernel(const T* __restrict__ logp, const T* __restrict__ rowpart,
                                                           const T* __restrict__ lsp, const int32_t* __restrict__ n_valid, int y_div,
                                                           const T* __restrict__ g_lml, const int32_t* __restrict__ info,
                                                           T* __restrict__ lml, T* __restrict__ d_mean, int mean_mode,
                                                           T* __restrict__ d_ls, T* __restrict__ d_os, T* __restrict__ d_noise,
                                                           int P, int n, int f, int bwd) {
+    __shared__ T red[4][PACOH_MAX_FEATURES + 3];
     const long b = blockIdx.x;
     const int lane = threadIdx.x;
     const int p = (int)(b % P);
@@ -771,11 +774,26 @@ __global__ void __launch_bounds__(64) dense_finish_kernel(const T* __restrict__ 
     if (!bwd) return;
     const T gup = g_lml ? g_lml[b] : T(1);
     const int W3 = f + 3;
-    for (int c = 0; c < W3; ++c) {
-        T s = 0;
-        for (int i = lane; i < n; i += 64) s += rowpart[(b * n + i) * (long)W3 + c];
-        s = subwave_sum<T>(s, 64);
-        if (lane == 0) {
+    T part[PACOH_MAX_FEATURES + 3];
+#pragma unroll
+    for (int c = 0; c < PACOH_MAX_FEATURES + 3; ++c) part[c] = 0;
+    for (int i = lane; i < n; i += 256) {
+        const T* rp = rowpart + (b * n + i) * (long)W3;
+#pragma unroll
+        for (int c = 0; c < PACOH_MAX_FEATURES + 3; ++c) if (c < W3) part[c] += rp[c];
+    }
+#pragma unroll
+    for (int c = 0; c < PACOH_MAX_FEATURES + 3; ++c) {
+        if (c < W3) {
+            const T s = subwave_sum<T>(part[c], 64);
+            if ((lane & 63) == 0) red[lane >> 6][c] = s;
+        }
+    }
+    __syncthreads();
+    if (lane < W3) {
+        const int c = lane;
+        T s = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+        {
             if (failed) s = T(NAN);
             if (c < f) d_ls[b * f + c] = gup * s / lsp[(long)p * f + c];
             else if (c == f) { if (d_os) d_os[b] = gup * s; }
@@ -950,7 +968,7 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
         if (grc == 1) switch (FP) { PACOH_DG_CASE(2) PACOH_DG_CASE(4) PACOH_DG_CASE(8) default: PACOH_DG_CASE(16) }
 #undef PACOH_DG_CASE
     }
-    hipLaunchKernelGGL(dense_finish_kernel<T>, dim3(B), dim3(64), 0, s, (const T*)logp, (const T*)rowpart, (const T*)ls, n_valid,
+    hipLaunchKernelGGL(dense_finish_kernel<T>, dim3(B), dim3(256), 0, s, (const T*)logp, (const T*)rowpart, (const T*)ls, n_valid,
                        y_div, (const T*)g_lml, (const int32_t*)info, (T*)lml, (T*)d_mean, mean_mode, (T*)d_ls, (T*)d_os,
                        (T*)d_noise, P, n, f, bwd ? 1 : 0);
     return launch_status();
