@@ -217,6 +217,9 @@ int dense_mfma_try(void* A, const void* resid, void* logp, void* alpha_out, int3
 // (and then writes info[b] = attempt on success): the psd_safe_cholesky ladder of the dense path.
 // true when dense_chol_launch() takes the MFMA kernel, which leaves the inverses of the diagonal blocks in the upper triangle
 bool dense_ll_fits(int n, int dtype);                      // dense_ll.hip
+int dense_ll_retry_try(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n, int dtype,
+                       int att_lo, int att_hi, int u_only, const void* z, int z_div, const void* ls, const void* os, const void* noise,
+                       const int32_t* n_valid, int y_div, double jitter_base, int P, int f, int kind, hipStream_t s);   // dense_ll.hip
 int dense_ll_try(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n, int dtype,
                  int attempt, int u_only, hipStream_t s);                    // dense_ll.hip; returns 1 if n is outside its plan
 constexpr int LL_MIN_N = 97;                               // below: the right-looking kernel with fewer waves
@@ -228,6 +231,18 @@ bool dense_chol_saves_inverse(int n, int dtype) {
     const char* e = getenv("PACOH_DISABLE_MFMA");
     if (e && e[0] == '1') return false;
     return (ll_enabled() && n >= LL_MIN_N && dense_ll_fits(n, dtype)) || dense_mfma_fits(n, dtype);
+}
+
+// rungs 1 .. 3 of the jitter ladder in one launch where the left-looking kernel factors this size (dense_ll.hip); 1: not here --
+// the caller issues the re-Gram and factorisation launches rung by rung
+int dense_chol_retry_fused(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n, int dtype,
+                           int u_only, const void* z, int z_div, const void* ls, const void* os, const void* noise, const int32_t* n_valid,
+                           int y_div, double jitter_base, int P, int f, int kind, hipStream_t stream) {
+    static const bool mfma_on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
+    static const bool fused_on = []() { const char* e = getenv("PACOH_RETRY_FUSED"); return !(e && e[0] == '0'); }();
+    if (!(mfma_on && fused_on && ll_enabled() && n >= LL_MIN_N)) return 1;
+    return dense_ll_retry_try(A, resid, logp, alpha_out, info, scale, B, n, dtype, 1, 3, u_only, z, z_div, ls, os, noise, n_valid, y_div,
+                              jitter_base, P, f, kind, stream);
 }
 
 // u_only (only honoured on the MFMA path, i.e. when dense_chol_saves_inverse()): alpha_out receives u = L^-1 r instead of alpha

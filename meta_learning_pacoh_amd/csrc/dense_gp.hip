@@ -21,6 +21,9 @@ namespace pacoh {
 int dense_chol_launch(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
                       int dtype, int attempt, hipStream_t stream, int u_only = 0);                  // dense.hip
 bool dense_chol_saves_inverse(int n, int dtype);                                                     // dense.hip
+int dense_chol_retry_fused(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n, int dtype,
+                           int u_only, const void* z, int z_div, const void* ls, const void* os, const void* noise, const int32_t* n_valid,
+                           int y_div, double jitter_base, int P, int f, int kind, hipStream_t stream);           // dense.hip (1: not fused)
 int trtri_ll_try(void* A, const int32_t* info, int B, int n, int dtype, hipStream_t s, const void* u, void* alpha);
 int dense_grad_mfma_try(const void* zs, const void* ls, const void* os, const int32_t* n_valid, int y_div, const void* g_lml,
                         const void* alpha, const void* Wm, const int32_t* info, void* d_z, void* d_mean, int mean_mode, void* rowpart,
@@ -915,6 +918,12 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
                                               : pacoh_gram_rbf_ard(z, z_div, z, z_div, ls, os, noise, 1, A, B, P, n, n, f_arg, dtype, s);
             if (rc) return rc;
         } else {
+            if (attempt == 1) {                        // the whole ladder in one launch where the left-looking kernel factors this size
+                const int rf = dense_chol_retry_fused(A, resid, logp, bwd ? alpha : nullptr, info, 1.0, B, n, dtype, u_only ? 1 : 0, z, z_div, ls, os,
+                                                      noise, n_valid, y_div, jitter_base, P, f, kind, s);
+                if (rf == 0) break;
+                if (rf != 1) return rf;
+            }
             double jit = jitter_base;
             for (int q = 1; q < attempt; ++q) jit *= 10.0;
             hipLaunchKernelGGL(regram_failed_kernel<T>, dim3(n < 8 ? n : 8, B < 32 ? B : 32), dim3(256), 0, s, (const T*)z, z_div, (const T*)ls, (const T*)os,
@@ -1001,6 +1010,12 @@ int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int m
                                               : pacoh_gram_rbf_ard(z_ctx, z_div, z_ctx, z_div, ls, os, noise, 1, A, B, P, n, n, f_arg, dtype, s);
             if (rc) return rc;
         } else {
+            if (attempt == 1) {
+                const int rf = dense_chol_retry_fused(A, resid, logp, alpha, info, 1.0, B, n, dtype, 0, z_ctx, z_div, ls, os, noise, n_valid, y_div,
+                                                      jitter_base, P, f, kind, s);
+                if (rf == 0) break;
+                if (rf != 1) return rf;
+            }
             double jit = jitter_base;
             for (int q = 1; q < attempt; ++q) jit *= 10.0;
             hipLaunchKernelGGL(regram_failed_kernel<T>, dim3(n < 8 ? n : 8, B < 32 ? B : 32), dim3(256), 0, s, (const T*)z_ctx, z_div, (const T*)ls,

@@ -95,10 +95,9 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #define LL_LDSWAIT() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 template <typename T>
-__global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const T* __restrict__ resid, T* __restrict__ logp,
-                                                         T* __restrict__ alpha_out, int32_t* __restrict__ info, T scale, int n,
-                                                         int attempt, int u_only, int S0, int S1) {
-    if (attempt > 0 && info && info[blockIdx.x] >= 0) return;      // jitter-ladder retry: only the failed problems
+__device__ __forceinline__ void chol_ll_body(T* __restrict__ A, const T* __restrict__ resid, T* __restrict__ logp,
+                                             T* __restrict__ alpha_out, int32_t* __restrict__ info, T scale, int n,
+                                             int attempt, int u_only, int S0, int S1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     constexpr int ES = sizeof(T), BLK = 256 * ES;
     using Acc = typename Mf<T>::acc;
@@ -794,6 +793,67 @@ __global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const
 
 // LDS plan for matrices of size n: slab areas S0 / S1 (S1 also holds the 16 look-ahead operand images).  false: not eligible.
 template <typename T>
+__global__ void __launch_bounds__(LL_NT) chol_ll_kernel(T* __restrict__ A, const T* __restrict__ resid, T* __restrict__ logp,
+                                                         T* __restrict__ alpha_out, int32_t* __restrict__ info, T scale, int n,
+                                                         int attempt, int u_only, int S0, int S1) {
+    if (attempt > 0 && info && info[blockIdx.x] >= 0) return;      // jitter-ladder retry: only the failed problems
+    chol_ll_body<T>(A, resid, logp, alpha_out, info, scale, n, attempt, u_only, S0, S1);
+}
+
+// ---- the WHOLE jitter ladder in one launch (the large-context GP path; dense_gp.hip) -----------------------------------------------
+// gpytorch's psd_safe_cholesky retries a failed factorisation with 1e-6 / 1e-8 * 10^k added to the diagonal.  As separate launches
+// that is, per call, three re-Gram launches and three factorisation launches that exit at once when nothing failed -- 6 x 4.5-5.9 us.
+// Here a failed problem's workgroup rebuilds its own matrix (what regram_failed_kernel + dense_mask_kernel wrote: direct
+// differences, kern_val) and factors it again, rung after rung; a problem that did not fail costs one early exit.
+struct LLRegen {
+    const void* z; const void* ls; const void* os; const void* noise; const int32_t* n_valid;
+    double jitter_base;
+    int z_div, y_div, P, f, kind;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(LL_NT) chol_ll_retry_kernel(T* __restrict__ A, const T* __restrict__ resid, T* __restrict__ logp,
+                                                               T* __restrict__ alpha_out, int32_t* __restrict__ info, T scale, int n,
+                                                               int att_lo, int att_hi, int u_only, int S0, int S1, LLRegen rg) {
+    const long b = blockIdx.x;
+    for (int attempt = att_lo; attempt <= att_hi; ++attempt) {
+        // (info[b] of the previous rung was written by this workgroup a moment ago: read it past the L1)
+        if (__hip_atomic_load(&info[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) return;
+        {
+            const int p = (int)(b % rg.P), f = rg.f;
+            const T* zb = (const T*)rg.z + (b / rg.z_div) * (long)n * f;
+            const T* ls = (const T*)rg.ls + (long)p * f;
+            const T osv = rg.os ? ((const T*)rg.os)[p] : T(1);
+            double jit = rg.jitter_base;
+            for (int q = 1; q < attempt; ++q) jit *= 10.0;
+            const T dg = ((const T*)rg.noise)[p] + (T)jit;
+            int nv = n;
+            if (rg.n_valid) { nv = rg.n_valid[b / rg.y_div]; nv = nv < 0 ? 0 : (nv > n ? n : nv); }
+            T* const Ab = A + (size_t)b * n * n;
+            for (int i = threadIdx.x >> 6; i < n; i += LL_NT / 64) {
+                T* row = Ab + (size_t)i * n;
+                for (int j = threadIdx.x & 63; j < n; j += 64) {
+                    T s = 0;
+                    for (int c = 0; c < f; ++c) { const T d = zb[(long)i * f + c] / ls[c] - zb[(long)j * f + c] / ls[c]; s = fma(d, d, s); }
+                    T v = osv * kern_val<T>(rg.kind, s) + (i == j ? dg : T(0));
+                    if (i >= nv || j >= nv) v = (i == j) ? T(1) : T(0);
+                    row[j] = v;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");         // the rebuilt matrix is in L2, this CU's L1 holds no stale lines of it
+        __syncthreads();
+        // (the body's loop-invariant addresses must not be hoisted out of the rung loop: 134 spilled registers, and a kernel with a
+        //  large scratch segment takes 16 us to launch and exit where this one should take 4)
+        int nq = n, s0q = S0, s1q = S1, uq = u_only;
+        asm volatile("" : "+s"(nq), "+s"(s0q), "+s"(s1q), "+s"(uq));
+        chol_ll_body<T>(A, resid, logp, alpha_out, info, scale, nq, attempt, uq, s0q, s1q);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        __syncthreads();
+    }
+}
+
+template <typename T>
 bool ll_plan(int n, int* S0, int* S1, size_t* lds) {
     const int ES = sizeof(T), BLK = 256 * ES;
     if (n < 1 || ((size_t)n * ES) % 16 != 0) return false;          // 16-byte DMA pieces: rows must start 16-byte aligned
@@ -834,6 +894,30 @@ bool dense_ll_fits(int n, int dtype) {
     int S0, S1;
     size_t lds;
     return dtype == PACOH_F32 ? ll_plan<float>(n, &S0, &S1, &lds) : ll_plan<double>(n, &S0, &S1, &lds);
+}
+
+// the rungs att_lo .. att_hi of the jitter ladder in ONE launch (see chol_ll_retry_kernel); 1: outside the plan
+int dense_ll_retry_try(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n, int dtype,
+                       int att_lo, int att_hi, int u_only, const void* z, int z_div, const void* ls, const void* os, const void* noise,
+                       const int32_t* n_valid, int y_div, double jitter_base, int P, int f, int kind, hipStream_t s) {
+    if (!info) return 1;
+    const LLRegen rg = {z, ls, os, noise, n_valid, jitter_base, z_div, y_div, P, f, kind};
+    int S0 = 0, S1 = 0;
+    size_t lds = 0;
+    if (dtype == PACOH_F32) {
+        if (!ll_plan<float>(n, &S0, &S1, &lds)) return 1;
+        auto kern = chol_ll_retry_kernel<float>;
+        if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        hipLaunchKernelGGL(kern, dim3(B), dim3(LL_NT), lds, s, (float*)A, (const float*)resid, (float*)logp, (float*)alpha_out, info, (float)scale, n,
+                           att_lo, att_hi, u_only, S0, S1, rg);
+    } else {
+        if (!ll_plan<double>(n, &S0, &S1, &lds)) return 1;
+        auto kern = chol_ll_retry_kernel<double>;
+        if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        hipLaunchKernelGGL(kern, dim3(B), dim3(LL_NT), lds, s, (double*)A, (const double*)resid, (double*)logp, (double*)alpha_out, info, scale, n,
+                           att_lo, att_hi, u_only, S0, S1, rg);
+    }
+    return launch_status();
 }
 
 // returns 1 when the matrix size is outside this kernel's plan (caller falls back to dense_mfma.hip / dense.hip)

@@ -135,6 +135,31 @@ def test_dense_jitter_ladder(L):
     assert abs(float(lml[0]) - float(ref0)) < 0.2 * abs(float(ref0))     # fp32 at condition ~1e8: loose by nature
 
 
+@pytest.mark.parametrize('ragged', [False, True])
+def test_dense_jitter_ladder_fp64_all_rungs_in_one_launch(L, ragged):
+    """fp64, n = 200 (the left-looking kernel's sizes: the ladder's three rungs are ONE launch there -- a failed problem's workgroup
+    rebuilds its own matrix with the jitter and factors it again): identical points with noise 1e-20 fail, succeed with jitter 1e-8
+    and report attempt 1; the healthy problem beside it is untouched; with ragged tasks the padded rows stay identity rows"""
+    n, f = 200, 3
+    gen = torch.Generator().manual_seed(5)
+    z = torch.zeros(2, n, f, dtype=torch.float64)
+    z[1] = torch.randn(n, f, generator=gen, dtype=torch.float64)
+    y = torch.randn(1, n, dtype=torch.float64, generator=gen)
+    ls = torch.ones(2, f, dtype=torch.float64)
+    noise = torch.tensor([1e-20, 0.3], dtype=torch.float64)
+    nv = 170 if ragged else n
+    n_valid = torch.tensor([nv], dtype=torch.int32, device=DEV) if ragged else None
+    out = L.gp_lml_fwdbwd(z.to(DEV), 1, None, L.MEAN_ZERO, y.to(DEV), 2, ls.to(DEV), None, noise.to(DEV), 2, 2, n_valid=n_valid)
+    lml, info = out[0].cpu(), out[-1].cpu()
+    assert info.tolist() == [1, 0]
+    assert bool(torch.isfinite(lml).all()) and all(bool(torch.isfinite(o).all()) for o in out[1:-1] if o is not None)
+    ref1 = O.gp_mll(z[1, :nv], torch.zeros(nv, dtype=torch.float64), y[0, :nv], ls[1], torch.tensor(1.0, dtype=torch.float64), noise[1])
+    assert abs(float(lml[1]) - float(ref1)) < 1e-9 * abs(float(ref1))
+    K = torch.ones(nv, nv, dtype=torch.float64) + (1e-20 + 1e-8) * torch.eye(nv, dtype=torch.float64)
+    ref0 = torch.distributions.MultivariateNormal(torch.zeros(nv, dtype=torch.float64), K).log_prob(y[0, :nv]) / nv
+    assert abs(float(lml[0]) - float(ref0)) < 1e-4 * abs(float(ref0))      # (condition number 2e10: the factorisation itself is the error)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
 @pytest.mark.parametrize('case', [(2, 2, 64, 130, 4), (1, 2, 200, 50, 2), (1, 1, 300, 7, 3)])
 def test_dense_predict(L, dtype, case):
