@@ -4,15 +4,18 @@
 //
 //   panel I (rows c0 = 64 I .. + 64):   Z[I, 0:I] = - Z_II * ( L[I, 0:I] * Z[0:I, 0:I] ),      Z[I, I] = Z_II = L[I,I]^-1
 //
-// The 64 x c0 product lives in MFMA accumulators (<= 8 blocks of 16 x 16 per wave, 14 waves); the finished rows of Z stream
-// through LDS once per panel as ROW slabs of 16 rows (contiguous in memory: full-line DMA, and a slab only brings the columns
-// up to its own diagonal), next to the 64 x 16 slab of the panel's own L columns; nothing is written inside the loop.  There is
-// no dependency chain at all -- Z_II is assembled from what the Cholesky left behind (two 32 x 32 inverses + L10) -- so every
+// The 64 x c0 product lives in MFMA accumulators (<= 8 blocks of 16 x 16 per wave, 14 waves) and is taken in slabs of 16 along k:
+//   * the A operand of a slab -- the 64 x 16 piece of the panel's own L rows, which EVERY wave multiplies with -- goes through a ring
+//     of fixed LDS slots by LDS-DMA from the two helper waves (L is pure input: one pipeline over all panels' slabs);
+//   * the B operand -- a 16 x 16 block of a finished panel of Z -- is needed by exactly ONE wave, which loads its fragments straight
+//     into registers a slab ahead (one register set, refreshed in place behind the MFMAs that read it).
+// (The first version streamed the finished rows of Z through LDS too; LDS-DMA costs its issuing wave 85-750 ns per instruction, and
+// the 3 200 instructions per matrix that took bounded the kernel: 511 us against 392 now.)  Nothing is written inside the loop.  There
+// is no dependency chain at all -- Z_II is assembled from what the Cholesky left behind (two 32 x 32 inverses + L10) -- so every
 // SIMD runs MFMAs.  The right-looking kernel this replaces (trtri_dense_kernel) re-read the inverted trailing matrix from
 // L2 / HBM for every 32-column panel with per-lane 8-byte loads: 1.9 GB per 256 x 512^2 fp64 launch, 0.46 ms.
-// Slabs are taken in DESCENDING k order: the heavy ones (long rows, many column blocks) first, so that the DMA of the next
-// slab always hides behind more MFMA work than it needs.
-// Roles: waves 0 and 1 = helpers (LDS-DMA issue; wave 1 also assembles Z_II's operand images and writes the diagonal block),
+// Slabs are taken in DESCENDING k order, the previous panel's four blocks last (those rows were stored a moment ago).
+// Roles: waves 0 and 1 = helpers (LDS-DMA issue, the operand images of Z_II, the diagonal block itself),
 // waves 2..15 = MFMA waves; MFMA wave w owns column blocks w and NB - 1 - w of the panel (Z is lower triangular: column block
 // q only meets the slabs k >= q, so the pair's work is the same for every w).
 // Reference semantics: the explicit inverse gpytorch's inv_quad_logdet / torch.cholesky_inverse produce on the way to K^-1
@@ -50,7 +53,7 @@ template <typename T> __device__ __forceinline__ constexpr int tl_img_off(int c1
     return (Mf<T>::q_of(c15) * 64 + 16 * Mf<T>::g_of(c15) + r) * (int)sizeof(T);
 }
 
-// LDS: Zd images (10 blocks) | ring of nb x { Z slab: 16 rows x RS bytes | L slab: 64 rows x 128 bytes (XOR-swizzled pieces) }
+// LDS: Zd images (10 blocks) | u, alpha partial sums | ring of <= 16 L slabs: 64 rows x 128 bytes (fp32: 64) each, XOR-swizzled pieces
 template <typename T>
 __global__ void __launch_bounds__(TL_NT) trtri_ll_kernel(T* __restrict__ A, const int32_t* __restrict__ info, int n, int ring_bytes,
                                                          const T* __restrict__ u, T* __restrict__ alpha) {
@@ -430,9 +433,9 @@ bool tl_plan(int n, int* ring_bytes, size_t* lds) {
     const size_t cap = 160u * 1024u;
     const int npan = (n + 63) / 64;
     const int c0max = (npan - 1) * 64;
-    const size_t bmax = (size_t)16 * c0max * ES + 64 * 16 * ES;     // largest ring entry
+    (void)c0max;
     size_t ring = cap - 10 * BLK - 3 * (size_t)((n + 63) & ~63) * ES;
-    if (bmax > ring) return false;
+    if (ring < (size_t)4 * 64 * 16 * ES) return false;              // at least four L slabs in flight
     *ring_bytes = (int)ring; *lds = cap;
     return true;
 }
