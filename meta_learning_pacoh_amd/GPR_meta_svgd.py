@@ -9,11 +9,12 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import engine as _engine
 from . import parallel
 from .abstract import RegressionModelMetaLearned
 from .distributions import GaussianPredictive
-from .engine import (AsyncUploader, GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, build_step_graphs, first_chunk,
-                     replay_steps, run_step)
+from .engine import (GRAPH_STEPS, AsyncUploader, GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, build_step_graphs,
+                     first_chunk, replay_steps, run_step)
 from .util import StepLR
 
 
@@ -78,10 +79,23 @@ class _RandomGPLearner(RegressionModelMetaLearned):
     def _setup_tasks(self, meta_train_data):
         tasks = [self._prepare_data_per_task(x, y) for x, y in meta_train_data]
         self.tasks = TaskBatch(tasks, self.device, self.dtype)
+        self._idx_ahead = None                            # task draws taken from the numpy stream ahead of their use (SVGD: _prefetch)
+
+    def _take_idx(self, k):
+        """the next k global task draws, int64 [k, B]: rows drawn ahead first, then the numpy stream -- one randint call of shape
+        [k, B] consumes it exactly like k calls of size B (GPR_meta_svgd.py:102 draws one batch per iteration)"""
+        q = getattr(self, '_idx_ahead', None)
+        if q is None or len(q) == 0:
+            return self.rds_numpy.randint(0, self.tasks.T, size=(k, self.task_batch_size))
+        take, rest = q[:k], q[k:]
+        self._idx_ahead = rest if len(rest) > 0 else None
+        if len(take) < k:
+            take = np.concatenate([take, self.rds_numpy.randint(0, self.tasks.T, size=(k - len(take), self.task_batch_size))], 0)
+        return take
 
     def _sample_task_batch(self):
         """global with-replacement draw from the shared seed (GPR_meta_svgd.py:102), then this rank's shard"""
-        idx = self.rds_numpy.randint(0, self.tasks.T, size=self.task_batch_size)
+        idx = self._take_idx(1)[0]
         pre = harmonic_pre_factor(self.tasks.sizes[idx])
         local = parallel.shard(idx)
         return local, pre
@@ -104,7 +118,11 @@ class _RandomGPLearner(RegressionModelMetaLearned):
     def _draw_steps(self, k, lr_scheduler, first_step, weight_decay=0.0):
         """task draws (this rank's shard) and step scalars of the next k steps, vectorised: one randint call of shape [k, B] consumes
         the numpy stream exactly like k calls of size B (GPR_meta_svgd.py:102 draws one batch per iteration)"""
-        idx = self.rds_numpy.randint(0, self.tasks.T, size=(k, self.task_batch_size))
+        return self._rows_to_feed(self._take_idx(k), lr_scheduler, first_step, weight_decay)
+
+    def _rows_to_feed(self, idx, lr_scheduler, first_step, weight_decay=0.0):
+        """task draws idx [k, B] -> (this rank's shard of them, the steps' scalar rows)"""
+        k = idx.shape[0]
         # harmonic pre-factor per step (random_gp.py:209-212); tasks of one size: every row is the same computation on the same
         # numbers -- done once
         rows = idx if self.tasks.ragged else idx[:1]
@@ -298,12 +316,27 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         """the next n_steps SVGD steps of the training loop (task draws from rds_numpy, lr from the scheduler)"""
         self._setup_step(self._local_batch_size())
         graphed = self._graphs_allowed()
-        first = True
+        first = ramp = True
+        used_ahead = False
+        ahead, self._ahead = getattr(self, '_ahead', None), None
         while n_steps > 0:
-            k = first_chunk(n_steps, self.GRAPH_CHUNK) if first else min(n_steps, self.GRAPH_CHUNK)
+            # a chunk uploaded at the end of the previous call (_prefetch) is this call's first chunk if nobody has touched the feed
+            # since and its scalars still hold (same step count, same learning rates): no draw, no upload in front of the first replay
+            use_ahead = (first and ahead is not None and ahead['feed'] is self._feed and ahead['serial'] == self._feed.serial
+                         and self._graphs is not None)
+            if use_ahead:
+                k = min(n_steps, ahead['k'])
+                used_ahead = True
+            elif ramp and used_ahead:                     # behind the chunk prepared ahead: 16 steps if many more follow, else the rest
+                k = _engine.FIRST_CHUNK if n_steps >= 4 * _engine.FIRST_CHUNK else min(n_steps, self.GRAPH_CHUNK)
+                ramp = False
+            else:
+                k = first_chunk(n_steps, self.GRAPH_CHUNK) if ramp else min(n_steps, self.GRAPH_CHUNK)
+                ramp = False
             first = False
             idx_rows, sc_rows = self._draw_steps(k, self.lr_scheduler, self.opt_step + 1)
-            self._feed.upload(idx_rows, sc_rows)
+            if not (use_ahead and np.array_equal(sc_rows, ahead['sc'][:k])):
+                self._feed.upload(idx_rows, sc_rows)
             if self._pipelined:
                 self._feed.prologue()
             if graphed and self._graphs is None:
@@ -319,6 +352,24 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
             for _ in range(k):
                 self.lr_scheduler.step()
             n_steps -= k
+        if graphed and self._graphs is not None and os.environ.get('PACOH_PREFETCH', '1') != '0':
+            self._prefetch()
+
+    def _prefetch(self):
+        """The NEXT call's first chunk, prepared now: one replay's worth of task draws taken from the numpy stream (kept in
+        _idx_ahead until they are used: the sequence of draws is the one without prefetching), their scalars, the upload.  A training
+        call otherwise starts with the host preparing a chunk while the GPU idles -- 0.2-0.9 ms on a busy host, i.e. 2-10 % of the
+        20-step region the benchmark driver times.  The chunk is used only if the feed is untouched and the scalars still hold."""
+        k = GRAPH_STEPS
+        q = getattr(self, '_idx_ahead', None)
+        have = 0 if q is None else len(q)
+        if have < k:
+            more = self.rds_numpy.randint(0, self.tasks.T, size=(k - have, self.task_batch_size))
+            q = more if have == 0 else np.concatenate([q, more], 0)
+            self._idx_ahead = q
+        idx_rows, sc_rows = self._rows_to_feed(q[:k], self.lr_scheduler, self.opt_step + 1)
+        self._feed.upload(idx_rows, sc_rows)
+        self._ahead = dict(k=k, sc=np.array(sc_rows, copy=True), feed=self._feed, serial=self._feed.serial)
 
     def svgd_step(self, idx_local, pre_factor):
         """SVGD.step (meta_learn/svgd.py:25-28) on an explicit task draw: particles.grad = -phi; optimizer.step()"""

@@ -194,6 +194,7 @@ class StepFeed:
         (j, out_row) filling the pinned staging row of step j in place, or None; resets the counter"""
         k = len(sc_rows)
         assert 0 < k <= self.chunk
+        self.serial = getattr(self, 'serial', 0) + 1     # (a learner that uploaded a chunk AHEAD checks that nobody has uploaded since)
         q = self._slot
         self._slot = 1 - q
         if self._ev[q] is not None:

@@ -763,8 +763,10 @@ def test_small_first_chunk_does_not_change_the_run(M, kind, monkeypatch):
         m._train_steps(90)
         torch.cuda.synchronize()
         monkeypatch.setattr(engine.StepFeed, 'upload', real)
-        ramp = [16, 74] if kind == 'svgd' else [16, 24, 36, 14]  # (PACOH-VI grows by half: its chunks cost the host 0.15 ms of noise per step)
-        assert (sizes[-len(ramp):] == ramp) if first == 16 else (sizes[-1] == 90)
+        # PACOH-SVGD: the call's first four steps were prepared (drawn, uploaded) at the end of the previous call -- no upload --, and
+        # it ends by preparing the next call's; PACOH-VI grows by half (its chunks cost the host 0.15 ms of noise per step)
+        ramp = [16, 70, 4] if kind == 'svgd' else [16, 24, 36, 14]
+        assert (sizes[-len(ramp):] == ramp) if first == 16 else (sizes[-2:] == [86, 4] if kind == 'svgd' else sizes[-1] == 90)
         out.append((m.particles if kind == 'svgd' else m.posterior).clone())
     assert bool(torch.isfinite(out[0]).all()) and torch.equal(out[0], out[1])
 
