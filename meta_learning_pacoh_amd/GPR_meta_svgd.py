@@ -335,7 +335,10 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
                 ramp = False
             first = False
             idx_rows, sc_rows = self._draw_steps(k, self.lr_scheduler, self.opt_step + 1)
-            if not (use_ahead and np.array_equal(sc_rows, ahead['sc'][:k])):
+            same = use_ahead and np.array_equal(sc_rows, ahead['sc'][:k]) and (
+                (idx_rows is None and ahead['idx'] is None) or
+                (idx_rows is not None and ahead['idx'] is not None and np.array_equal(idx_rows, ahead['idx'][:k])))
+            if not same:                                  # (e.g. _sample_task_batch() took a row of the queue in between)
                 self._feed.upload(idx_rows, sc_rows)
             if self._pipelined:
                 self._feed.prologue()
@@ -359,7 +362,8 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         """The NEXT call's first chunk, prepared now: one replay's worth of task draws taken from the numpy stream (kept in
         _idx_ahead until they are used: the sequence of draws is the one without prefetching), their scalars, the upload.  A training
         call otherwise starts with the host preparing a chunk while the GPU idles -- 0.2-0.9 ms on a busy host, i.e. 2-10 % of the
-        20-step region the benchmark driver times.  The chunk is used only if the feed is untouched and the scalars still hold."""
+        20-step region the benchmark driver times.  The chunk is used only if the feed is untouched and both the draws at the head of
+        the queue and the scalars are still the ones that were uploaded."""
         k = GRAPH_STEPS
         q = getattr(self, '_idx_ahead', None)
         have = 0 if q is None else len(q)
@@ -369,7 +373,8 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
             self._idx_ahead = q
         idx_rows, sc_rows = self._rows_to_feed(q[:k], self.lr_scheduler, self.opt_step + 1)
         self._feed.upload(idx_rows, sc_rows)
-        self._ahead = dict(k=k, sc=np.array(sc_rows, copy=True), feed=self._feed, serial=self._feed.serial)
+        self._ahead = dict(k=k, sc=np.array(sc_rows, copy=True), idx=None if idx_rows is None else np.array(idx_rows, copy=True),
+                           feed=self._feed, serial=self._feed.serial)
 
     def svgd_step(self, idx_local, pre_factor):
         """SVGD.step (meta_learn/svgd.py:25-28) on an explicit task draw: particles.grad = -phi; optimizer.step()"""

@@ -432,6 +432,33 @@ def test_svgd_imq_steps_run_from_the_step_feed_and_replay_bit_identically(M, opt
     assert relerr(m_g.particles, X) < 2e-3
 
 
+def test_prefetched_task_draws_keep_the_numpy_stream_in_order(M, monkeypatch):
+    """PACOH-SVGD prepares the next call's first chunk at the end of a training call: the task draws it takes from the numpy stream
+    ahead of time are queued and handed out first, so every consumer -- the next training call, an explicit _sample_task_batch()
+    -- sees the sequence RandomState(seed + 1) produces without prefetching; and the run equals the one with PACOH_PREFETCH=0"""
+    tasks = tasks_nd(7, 12, 2)
+    kw = dict(num_particles=4, task_batch_size=5, lr=1e-2, random_seed=21, mean_nn_layers=(8, 8), kernel_nn_layers=(8, 8))
+    m = M.GPRegressionMetaLearnedSVGD(tasks, **kw)
+    m.meta_fit(verbose=False, n_iter=6, log_period=4)
+    assert m._idx_ahead is not None and len(m._idx_ahead) == 4 and m._ahead is not None      # four steps' draws are waiting
+    ref = np.random.RandomState(21 + 1)
+    for _ in range(6):
+        ref.randint(0, 7, size=5)
+    idx, _ = m._sample_task_batch()                              # the 7th draw of the stream, from the queue
+    assert np.array_equal(np.sort(idx), np.sort(ref.randint(0, 7, size=5)))
+    m.meta_fit(verbose=False, n_iter=5, log_period=100)          # (the uploaded chunk's first row is gone: re-uploaded, same bits below)
+    ref_draws = [ref.randint(0, 7, size=5) for _ in range(5)]
+    monkeypatch.setenv('PACOH_PREFETCH', '0')
+    m2 = M.GPRegressionMetaLearnedSVGD(tasks, **kw)
+    m2.meta_fit(verbose=False, n_iter=6, log_period=4)
+    assert m2._idx_ahead is None
+    m2._sample_task_batch()
+    m2.meta_fit(verbose=False, n_iter=5, log_period=100)
+    assert torch.equal(m.particles, m2.particles) and m.opt_step == m2.opt_step == 11
+    assert np.array_equal(m2.rds_numpy.randint(0, 7, size=5), np.random.RandomState(22).randint(0, 7, size=(13, 5))[12])
+    del ref_draws
+
+
 def test_step_feed_upload_accepts_tensors_lists_and_callables(M):
     """engine.StepFeed.upload: the per-step payload as ONE tensor [k, ...] (any device, dtype, requires_grad), a list of k tensors, or
     a callable filling the pinned staging rows -- the same rows reach the device; select() hands them out in order"""
