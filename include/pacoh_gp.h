@@ -515,6 +515,35 @@ int pacoh_mixture_icdf(const void* mu, const void* var, const void* quantile, vo
                        double hi, double eps, int max_iter, int closed_form, int P, int m, int dtype, void* stream);
 int pacoh_calib_error(const void* cdf, void* out, int T, int m, int dtype, void* stream);
 
+/* ---- K whole PACOH-MAP iterations per launch (round 5) ------------------------------------------
+ * The reference's own regime -- a handful of small tasks per iteration (demo.py:14-26: 5 tasks x 5 points) -- is pure launch
+ * latency as a sequence of launches.  pacoh_map_persist runs K iterations of the loop body of GPRegressionMetaLearned.meta_fit
+ * (GPR_meta_mll.py:104-117: sample the task batch, per task LearnedGPRegressionModel.forward + ExactMarginalLogLikelihood
+ * (models.py:505-519), loss = -sum_t mll_t, backward, AdamW step) in ONE launch of ONE workgroup that keeps parameters, Adam
+ * moments and activations in LDS (csrc/map_persist.hip).  fp32, one parameter row (P = 1), world size 1.
+ *   theta / exp_avg / exp_avg_sq [D]: read at the start, trained entries written back at the end;
+ *   x [T, n, d], y [T, n], n_valid [T] | NULL: the resident task table; idx_rows [K, tb] (int64) the task draws and sc_rows [K, n_sc]
+ *   the step scalars of the K iterations (rows of engine.StepFeed: PACOH_SC_ADAM block used);
+ *   mean_mode PACOH_MEAN_ZERO / _VECTOR (NN at theta[off_mean ..), hidden widths mean_hidden[n_mean_hidden]) / _CONST (theta[off_mean]);
+ *   kernel_nn != 0: features = NN at theta[off_kernel ..) with f outputs, else the raw inputs (f == d); ARD-RBF kernel with
+ *   lengthscales softplus(theta[off_ls .. +f)), outputscale softplus(theta[off_os]) (off_os < 0: none), noise
+ *   softplus(theta[off_noise]) + noise_floor; networks as models.py:319-323 (per layer bias before weight, tanh);
+ *   seg_lo / seg_hi [n_seg <= 4]: trained column ranges (learning_mode); beta1 / beta2: Adam;
+ *   *loss_last := loss of the last iteration, *loss_cum += sum of the K losses, *fail_flag |= 1 if a Cholesky failed even with the
+ *   jitter ladder in any iteration (the parameters then hold NaN, as after the launch sequence).
+ * Limits (PACOH_ELIMIT otherwise; pacoh_map_persist_supported answers without launching): n <= 32, d <= 4, f <= 4, tb <= 16,
+ * tb n (d + 1) <= 1024, hidden widths <= 32, <= 4 hidden layers, K <= 1024, the LDS plan <= 160 KB.  Results equal the launch
+ * sequence's to rounding (other summation order), not bit for bit. */
+int pacoh_map_persist_supported(int n, int d, int tb, int mean_mode, const int32_t* mean_hidden, int n_mean_hidden, int kernel_nn,
+                                const int32_t* kernel_hidden, int n_kernel_hidden, int f, int dtype);
+int pacoh_map_persist(void* theta, void* exp_avg, void* exp_avg_sq, int D, const void* x, const void* y, const int32_t* n_valid,
+                      int n, int d, const int64_t* idx_rows, int tb, const void* sc_rows, int n_sc, int K,
+                      int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
+                      int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
+                      int off_ls, int off_os, int off_noise, double noise_floor,
+                      const int32_t* seg_lo, const int32_t* seg_hi, int n_seg, double beta1, double beta2,
+                      void* loss_last, void* loss_cum, int32_t* fail_flag, int dtype, void* stream);
+
 /* ---- 8e: the step's one exchange ----------------------------------------------------------------------------------
  * buf[0..count) := sum over ranks of buf (in place), enqueued on the caller's stream: RCCL ncclAllReduce(ncclSum) over xGMI.
  * Sums the per-rank partial  sum_t mll[t,:]  and partial score [P,D] of the task-sharded objective

@@ -133,6 +133,18 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         self._fail = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._feed = StepFeed(self.device, self.dtype, tb_local, chunk=self.GRAPH_CHUNK)
         self._graphs = self._opt_blk = None
+        # The reference's own regime -- a handful of small tasks per iteration -- runs K whole iterations per launch in one
+        # workgroup (include/pacoh_gp.h, pacoh_map_persist): world size 1, Adam, a shape the kernel takes.  PACOH_MAP_PERSIST=0: the
+        # launch sequence below (tests compare the two)
+        self._persist = None
+        if (self._adam_advances() and parallel.world()[1] == 1 and tb_local > 0 and os.environ.get('PACOH_MAP_PERSIST', '1') != '0'
+                and not L.FORCE_DENSE):
+            plan = L.MapPersistPlan(self.layout, self.tasks, tb_local, self.engine.noise_floor, self.train_segments, self.dtype)
+            if plan.supported():
+                self._persist = plan
+        if self._persist is not None:
+            self._pipelined = False
+            return
         # Four launches per iteration (forward, GP, backward, slab reduction) where the AdamW step rides in the gradient epilogue
         # (_adam_inline) AND the networks run on the fused kernels: the epilogue then also fetches the next iteration's operands and
         # publishes the updated hyper-parameters' transforms (include/pacoh_gp.h, pacoh_step_next) -- no step_begin launch.
@@ -220,8 +232,25 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         return (self.optimizer_name == 'Adam' and os.environ.get('PACOH_NO_GRAPH', '0') != '1'
                 and self.tasks.n <= L.gp_small_max_n(self.dtype, True) and not L.FORCE_DENSE)
 
+    def _train_steps_persist(self, n_steps):
+        """K iterations per launch: the task draws and step scalars of a chunk go up in one copy each (engine.StepFeed), one
+        launch runs the chunk.  Same draws from rds_numpy, same scalars as the launch sequence."""
+        while n_steps > 0:
+            k = min(n_steps, self.GRAPH_CHUNK)
+            idx = self.rds_numpy.randint(0, self.tasks.T, size=(k, self.task_batch_size))
+            sc_rows = L.step_scalar_rows(1.0, self.lr_scheduler.lrs(k), self.opt_step + 1, weight_decay=self.weight_decay)
+            self._feed.upload(idx, sc_rows)
+            L.map_persist(self._persist, self.theta, self.exp_avg, self.exp_avg_sq, self.tasks, self._feed.idx_all, self._feed.sc_all, k,
+                          self._g_loss, self._g_cum.reshape(1), self._fail)
+            self.opt_step += k
+            for _ in range(k):
+                self.lr_scheduler.step()
+            n_steps -= k
+
     def _train_steps(self, n_steps):
         self._setup_step()
+        if self._persist is not None:
+            return self._train_steps_persist(n_steps)
         graphed = self._use_graph()
         while n_steps > 0:
             k = min(n_steps, self.GRAPH_CHUNK) if self.optimizer_name == 'Adam' else 1     # SGD reads the host-side learning rate

@@ -101,6 +101,9 @@ SIGNATURES = {
     'pacoh_mixture_cdf': (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _i, _i, _i, _vp]),
     'pacoh_mixture_icdf': (_i, [_vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _i, _i, _i, _i, _i, _vp]),
     'pacoh_calib_error': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'pacoh_map_persist_supported': (_i, [_i, _i, _i, _i, _ip, _i, _i, _ip, _i, _i, _i]),
+    'pacoh_map_persist': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _ip, _i, _i, _i, _ip, _i, _i,
+                               _i, _i, _i, _d, _ip, _ip, _i, _d, _d, _vp, _vp, _vp, _i, _vp]),
     'pacoh_comm_unique_id': (_i, [_vp]),
     'pacoh_comm_init': (_i, [_vp, _i, _i, _c.POINTER(_vp)]),
     'pacoh_allreduce_sum': (_i, [_vp, _l, _i, _vp, _vp]),
@@ -108,7 +111,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 12              # pacoh_abi_version() of the library this table was written for
+ABI_VERSION = 13              # pacoh_abi_version() of the library this table was written for
 
 
 def load_library():
@@ -610,6 +613,58 @@ class AdamInline(ctypes.Structure):
     _fields_ = [('param', _vp), ('exp_avg', _vp), ('exp_avg_sq', _vp), ('scalars', _vp), ('beta1', _d), ('beta2', _d),
                 ('n_seg', _i), ('seg_lo', _i * 4), ('seg_hi', _i * 4), ('step_counter', _vp), ('loss_cum', _vp),
                 ('next', ctypes.POINTER(StepNext))]
+
+
+class MapPersistPlan:
+    """argument block of pacoh_map_persist for one learner (include/pacoh_gp.h, "K whole PACOH-MAP iterations per launch"): the
+    parameter layout of the learner's engine.ParamLayout in the entry point's terms.  supported(): does the persistent kernel
+    take this shape?"""
+
+    def __init__(self, layout, tasks, tb, noise_floor, segments, dtype):
+        lay = layout
+        self.n, self.d, self.tb, self.dtype = int(tasks.n), int(tasks.x.shape[2]), int(tb), dtype
+        self.mean_mode = {'NN': MEAN_VECTOR, 'constant': MEAN_CONST, 'zero': MEAN_ZERO}[lay.mean_module]
+        self.off_mean = (lay.block_range('mean_nn.')[0] if lay.mean_module == 'NN'
+                         else (lay.slices['constant_mean'][0] if lay.mean_module == 'constant' else -1))
+        self.mean_hidden = list(lay.mean_nn_layers) if lay.mean_module == 'NN' else []
+        self.kernel_nn = int(lay.covar_module == 'NN')
+        self.off_kernel = lay.block_range('kernel_nn.')[0] if self.kernel_nn else -1
+        self.kernel_hidden = list(lay.kernel_nn_layers) if self.kernel_nn else []
+        self.f = int(lay.feature_dim)
+        self.off_ls = lay.slices['lengthscale_raw'][0]
+        self.off_os = lay.slices['outputscale_raw'][0] if lay.with_outputscale else -1
+        self.off_noise = lay.slices['noise_raw'][0]
+        self.noise_floor = float(noise_floor)
+        self.rbf = lay.kernel_code == KERNEL_RBF
+        self.D = lay.D
+        k = len(segments)
+        self.n_seg = k
+        self.seg_lo = (ctypes.c_int32 * 4)(*([int(lo) for lo, _ in segments] + [0] * (4 - k))) if k <= 4 else None
+        self.seg_hi = (ctypes.c_int32 * 4)(*([int(hi) for _, hi in segments] + [0] * (4 - k))) if k <= 4 else None
+        self._mh, self._kh = _hidden_arr(self.mean_hidden), _hidden_arr(self.kernel_hidden)
+
+    def supported(self):
+        if not self.rbf or self.n_seg > 4 or self.n_seg < 1:
+            return False
+        code = F32 if self.dtype == torch.float32 else F64
+        return bool(load_library().pacoh_map_persist_supported(self.n, self.d, self.tb, self.mean_mode, self._mh, len(self.mean_hidden),
+                                                               self.kernel_nn, self._kh, len(self.kernel_hidden), self.f, code))
+
+
+def map_persist(plan, theta, exp_avg, exp_avg_sq, tasks, idx_rows, sc_rows, K, loss_last, loss_cum, fail_flag, beta1=0.9, beta2=0.999):
+    """K PACOH-MAP iterations in one launch (pacoh_map_persist): rows 0..K-1 of idx_rows [>= K, tb] (int64, device) / sc_rows [>= K, SC_COUNT]"""
+    lib = load_library()
+    assert theta.shape[0] == 1 and idx_rows.dtype == torch.int64 and idx_rows.shape[1] == plan.tb
+    with _Timed('map_persist'):
+        _check(lib.pacoh_map_persist(_ptr(theta), _ptr(exp_avg, theta), _ptr(exp_avg_sq, theta), plan.D, _ptr(tasks.x, theta), _ptr(tasks.y, theta),
+                                     _ptr(tasks.n_valid) if tasks.ragged else None, plan.n, plan.d, _ptr(idx_rows), plan.tb,
+                                     _ptr(sc_rows, theta), sc_rows.shape[1], int(K),
+                                     plan.mean_mode, plan.off_mean, plan._mh, len(plan.mean_hidden),
+                                     plan.kernel_nn, plan.off_kernel, plan._kh, len(plan.kernel_hidden), plan.f,
+                                     plan.off_ls, plan.off_os, plan.off_noise, plan.noise_floor,
+                                     plan.seg_lo, plan.seg_hi, plan.n_seg, float(beta1), float(beta2),
+                                     _ptr(loss_last, theta), _ptr(loss_cum, theta), _ptr(fail_flag), dtype_code(theta), _stream()),
+               'pacoh_map_persist')
 
 
 def mlp_fused_path(B, P, n, d_in, hidden, d_out, dtype):

@@ -697,7 +697,7 @@ extern "C" int pacoh_gather_tasks(const void* x, const void* y, const int32_t* n
     return launch_status();
 }
 
-extern "C" int pacoh_abi_version(void) { return 12; }
+extern "C" int pacoh_abi_version(void) { return 13; }
 
 extern "C" int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise,
                                double noise_floor, void* ls, void* os, void* noise, int dtype, void* stream) {

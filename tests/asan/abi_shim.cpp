@@ -30,7 +30,7 @@ int main() {
         std::printf("%zu\n", pacoh_mlp_bwd_workspace_bytes(60, 3, 33, 2, h, 3, 2, PACOH_F32));
         return 0;
     }
-    EXPECT(pacoh_abi_version() == 12);
+    EXPECT(pacoh_abi_version() == 13);
     EXPECT(pacoh_gp_small_max_n(PACOH_F32, 0) >= 128 && pacoh_gp_small_max_n(PACOH_F64, 1) >= 64 && pacoh_gp_small_max_n(7, 0) == PACOH_EDTYPE);
     EXPECT(pacoh_svgd_workspace_bytes(20, 2534, PACOH_F32) == (2 * 400 + 20 + 8) * 4);
     EXPECT(pacoh_gp_predict_workspace_bytes(4, 64, 50, PACOH_F32, 1) == 4u * 50 * 64 * 4 && pacoh_gp_predict_workspace_bytes(4, 64, 50, PACOH_F32, 0) == 0);
@@ -72,6 +72,21 @@ int main() {
         EXPECT(pacoh_mlp_fwd_workspace_bytes(10, 1, 5, 1, h, 4, 2, PACOH_F32) > 0);
         EXPECT(pacoh_mlp_fwd(fake, 1, fake, 10, 1, 1, h, 4, 2, fake, nullptr, 10, 5, PACOH_F32, nullptr) == PACOH_EINVAL);   // needs a workspace
         std::free(h);
+    }
+    {   // the persistent PACOH-MAP kernel's host-side plan reads mean_hidden[] / kernel_hidden[] of exactly n entries (round 5)
+        int32_t* hm = heap_hidden({32, 32});
+        int32_t* hk = heap_hidden({16});
+        EXPECT(pacoh_map_persist_supported(5, 1, 5, PACOH_MEAN_VECTOR, hm, 2, 1, hk, 1, 2, PACOH_F32) == 1);
+        EXPECT(pacoh_map_persist_supported(5, 1, 17, PACOH_MEAN_VECTOR, hm, 2, 1, hk, 1, 2, PACOH_F32) == 0);     // more tasks than waves
+        EXPECT(pacoh_map_persist_supported(5, 1, 5, PACOH_MEAN_VECTOR, hm, 2, 0, nullptr, 0, 1, PACOH_F64) == 0);
+        int32_t seg[4] = {0, 0, 0, 0};
+        EXPECT(pacoh_map_persist(fake, fake, fake, 8, fake, fake, nullptr, 33, 1, (const int64_t*)fake, 5, fake, PACOH_SC_COUNT, 1, PACOH_MEAN_ZERO, -1,
+                                 nullptr, 0, 0, -1, nullptr, 0, 1, 0, 1, 2, 1e-3, seg, seg, 1, 0.9, 0.999, nullptr, nullptr, nullptr, PACOH_F32,
+                                 nullptr) == PACOH_ELIMIT);                                                                          // n > 32
+        EXPECT(pacoh_map_persist(nullptr, fake, fake, 8, fake, fake, nullptr, 5, 1, (const int64_t*)fake, 5, fake, PACOH_SC_COUNT, 1, PACOH_MEAN_ZERO, -1,
+                                 nullptr, 0, 0, -1, nullptr, 0, 1, 0, 1, 2, 1e-3, seg, seg, 1, 0.9, 0.999, nullptr, nullptr, nullptr, PACOH_F32,
+                                 nullptr) == PACOH_EINVAL);
+        std::free(hm); std::free(hk);
     }
     EXPECT(pacoh_gp_lml_fwd(nullptr, 1, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 4, 1, 16, 2,
                             PACOH_F32, nullptr) == PACOH_EINVAL);

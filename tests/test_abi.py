@@ -36,7 +36,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 def test_abi_version_and_host_side_queries(lib):
     from meta_learning_pacoh_amd import _lib
-    assert lib.pacoh_abi_version() == _lib.ABI_VERSION == 12
+    assert lib.pacoh_abi_version() == _lib.ABI_VERSION == 13
     assert lib.pacoh_gp_small_max_n(0, 0) >= 128 and lib.pacoh_gp_small_max_n(0, 1) >= 128      # fp32: cfg #4 fits
     assert lib.pacoh_gp_small_max_n(1, 1) >= 64                                                  # fp64: cfg #3 fits
     assert lib.pacoh_gp_small_max_n(7, 0) == -3
@@ -46,6 +46,10 @@ def test_abi_version_and_host_side_queries(lib):
     assert nbytes % (20 * (32 * 5 + 32 * 33 + 2 * 33) * 4) == 0 and nbytes > 0
     assert lib.pacoh_gp_predict_workspace_bytes(4, 64, 50, 0, 1) == 4 * 50 * 64 * 4
     assert lib.pacoh_gp_predict_workspace_bytes(4, 64, 50, 0, 0) == 0
+    # the persistent PACOH-MAP kernel's shape query (host side: the LDS plan): demo.py's shape fits, n = 33 and fp64 do not
+    assert lib.pacoh_map_persist_supported(5, 1, 5, 1, hidden, 2, 1, hidden, 2, 2, 0) == 1
+    assert lib.pacoh_map_persist_supported(33, 1, 5, 1, hidden, 2, 1, hidden, 2, 2, 0) == 0
+    assert lib.pacoh_map_persist_supported(5, 1, 5, 1, hidden, 2, 1, hidden, 2, 2, 1) == 0
 
 
 def test_argument_validation_returns_error_codes_without_launching(lib):

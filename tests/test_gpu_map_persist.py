@@ -1,0 +1,173 @@
+"""pacoh_map_persist -- K whole PACOH-MAP iterations per launch in one workgroup (csrc/map_persist.hip; reference loop body:
+meta_learn/GPR_meta_mll.py:104-117, models.py:505-519) -- against the four-launch iteration of the same learner on the same task draws,
+against the CPU oracle, and at its limits.  The two device paths sum in different orders, so they agree to rounding, not bit for
+bit; one parameter is excluded from the comparison on purpose: the kernel network's OUTPUT BIAS has an exactly-zero derivative (a
+stationary kernel sees feature differences only), its gradient is rounding noise, and AdamW turns the sign of that noise into
+steps of +-lr -- on either path, and on the reference."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pacoh_oracle as O
+
+
+@pytest.fixture(scope='module')
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    import meta_learning_pacoh_amd as m
+    return m
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def make_tasks(seed, T, ragged, d=2):
+    rs = np.random.RandomState(seed)
+    tasks = []
+    for t in range(T):
+        n = 8 + 2 * (t % 3) if ragged else 12
+        x = rs.uniform(-3, 3, size=(n, d))
+        tasks.append((x, np.sin(x[:, :1]) + 0.3 * x[:, -1:] + 0.05 * rs.randn(n, 1)))
+    return tasks
+
+
+def fit_both(M, monkeypatch, tasks, n_iter, log_period, **kw):
+    out = []
+    for persist in ('0', '1'):
+        monkeypatch.setenv('PACOH_MAP_PERSIST', persist)
+        m = M.GPRegressionMetaLearned(tasks, **kw)
+        loss = m.meta_fit(verbose=False, n_iter=n_iter, log_period=log_period)
+        out.append((m, float(loss)))
+    return out
+
+
+def keep_mask(m):
+    keep = torch.ones_like(m.theta, dtype=torch.bool)
+    sl = m.layout.slices.get('kernel_nn.out.bias')
+    if sl is not None:
+        keep[0, sl[0]:sl[1]] = False
+    return keep
+
+
+CFGS = [
+    dict(),                                                                         # two 32-wide networks: the compile-time chains
+    dict(covar_module='SE', mean_module='NN'),                                      # one network (BASELINE config #2's modules)
+    dict(covar_module='NN', mean_module='constant', feature_dim=3),                 # three features: the f <= 4 GP instantiation
+    dict(covar_module='SE', mean_module='constant'),                                # no network: GP + hyper-parameters only
+    dict(covar_module='SE', mean_module='zero', learning_mode='learn_kernel'),
+    dict(mean_nn_layers=(16, 16), kernel_nn_layers=(16, 16)),                       # generic chains: one quad group + remainder
+    dict(mean_nn_layers=(20, 12), kernel_nn_layers=(24,)),                          # widths that are no multiple of 16, different depths
+    dict(mean_nn_layers=(32, 32, 32), kernel_nn_layers=(32, 32, 32), weight_decay=0.0, task_batch_size=2),   # (three hidden layers: 2 x 12 points fit the LDS plan)
+    dict(learning_mode='learn_mean', covar_module='SE'), dict(learning_mode='learn_kernel', mean_module='constant'),   # frozen column ranges
+    dict(mean_nn_layers=(32, 32), kernel_nn_layers=(16,)),
+]
+
+
+@pytest.mark.parametrize('cfg', CFGS)
+@pytest.mark.parametrize('ragged', [True, False])
+def test_persistent_iterations_equal_the_launch_sequence(M, cfg, ragged, monkeypatch):
+    """14 iterations as chunks of 1 + 3 + 4 + 4 + 2 (meta_fit's log periods): parameters, both Adam moments, the last loss and the
+    logged running loss; weight decay on every group, decaying learning rate, ragged tasks (zero-padded rows) and full ones"""
+    tasks = make_tasks(13, 7, ragged)
+    kw = dict(task_batch_size=4, lr_params=1e-2, weight_decay=0.05, lr_decay=0.9, random_seed=3)
+    kw.update(cfg)
+    (m0, l0), (m1, l1) = fit_both(M, monkeypatch, tasks, 14, 4, **kw)
+    assert m0._persist is None and m1._persist is not None and m1.opt_step == 14 and m1.lr_scheduler.epoch == 14
+    keep = keep_mask(m1)
+    assert bool(torch.isfinite(m1.theta).all())
+    assert rel(m1.theta[keep], m0.theta[keep]) < 2e-5
+    assert rel(m1.exp_avg[keep], m0.exp_avg[keep]) < 2e-5 and rel(m1.exp_avg_sq[keep], m0.exp_avg_sq[keep]) < 2e-5
+    assert abs(l1 - l0) < 1e-5 * max(1.0, abs(l0)) and abs(float(m1._g_cum) - float(m0._g_cum)) < 1e-4
+    frozen = torch.ones_like(keep)
+    for lo, hi in m1.train_segments:
+        frozen[0, lo:hi] = False
+    assert torch.equal(m1.theta[frozen], m0.theta[frozen]) and float(m1.exp_avg[frozen].abs().sum()) == 0.0     # untrained entries untouched
+    mean0, std0 = m0.predict(*tasks[0], tasks[1][0])
+    mean1, std1 = m1.predict(*tasks[0], tasks[1][0])
+    assert np.allclose(mean0, mean1, rtol=2e-4, atol=2e-5) and np.allclose(std0, std1, rtol=2e-4, atol=2e-5)
+
+
+def test_persistent_path_matches_the_oracle_on_the_demo(M, monkeypatch):
+    """BASELINE config #1 (demo.py:14-26): 50 AdamW iterations against the CPU oracle's MapOracle on the same draws"""
+    env = O.SinusoidDataset(np.random.RandomState(26))
+    train, test = env.generate_meta_train_data(20, 5), env.generate_meta_test_data(20, 5, 50)
+    monkeypatch.setenv('PACOH_MAP_PERSIST', '1')
+    model = M.GPRegressionMetaLearned(train, weight_decay=0.2, num_iter_fit=50, random_seed=30)
+    orc = O.MapOracle(train, weight_decay=0.2, num_iter_fit=50, random_seed=30)
+    log_o = orc.meta_fit(test, log_period=50, n_iter=50)
+    model.meta_fit(test, log_period=50, n_iter=50, verbose=False)
+    assert model._persist is not None
+    ll, rmse, calib = model.eval_datasets(test)
+    assert abs(ll - log_o[-1][2]) < 2e-3 and abs(rmse - log_o[-1][3]) < 2e-3 and abs(calib - log_o[-1][4]) < 5e-3
+    lay = model.layout
+    lo, hi = lay.slices['kernel_nn.fc_2.weight']
+    assert rel(model.theta[0, lo:hi], orc.kernel_net[1].weight.reshape(-1)) < 1e-3
+    lo, hi = lay.slices['mean_nn.fc_1.bias']
+    assert rel(model.theta[0, lo:hi], orc.mean_net[0].bias.reshape(-1)) < 1e-3
+
+
+@pytest.mark.parametrize('n,d,tb,T', [(1, 1, 1, 3), (5, 1, 5, 20), (16, 3, 4, 9), (17, 4, 3, 7), (32, 1, 2, 40), (32, 4, 2, 8), (3, 2, 16, 16), (4, 1, 16, 20)])
+def test_persistent_kernel_at_the_edges_of_its_shape_range(M, n, d, tb, T, monkeypatch):
+    """one point per task, one task per iteration, 16 tasks (every wave a GP), 32 points (two 16-row blocks), four input dimensions
+    (the f <= 4 instantiation when the kernel has no network), point counts that leave a tile nearly empty.  (What bounds tasks x
+    points is the LDS plan: ~68 floats per point, hidden layer and network beside 4 x the parameter image.)"""
+    rs = np.random.RandomState(100 * n + tb)
+    tasks = []
+    for t in range(T):
+        x = rs.uniform(-2, 2, size=(n, d))
+        tasks.append((x, np.sin(x.sum(1, keepdims=True)) + 0.05 * rs.randn(n, 1)))
+    for cfg in (dict(), dict(covar_module='SE', mean_module='NN')):
+        kw = dict(task_batch_size=tb, lr_params=5e-3, weight_decay=0.01, random_seed=5)
+        kw.update(cfg)
+        (m0, l0), (m1, l1) = fit_both(M, monkeypatch, tasks, 6, 3, **kw)
+        assert m1._persist is not None, (n, d, tb, cfg)
+        keep = keep_mask(m1)
+        assert bool(torch.isfinite(m1.theta).all())
+        assert rel(m1.theta[keep], m0.theta[keep]) < 5e-5 and abs(l1 - l0) < 2e-5 * max(1.0, abs(l0))
+
+
+def test_shapes_outside_the_plan_take_the_launch_sequence(M, monkeypatch):
+    monkeypatch.setenv('PACOH_MAP_PERSIST', '1')
+    cases = [dict(tasks=make_tasks(1, 20, False), task_batch_size=17),                           # more tasks per iteration than waves
+             dict(tasks=[(np.random.RandomState(2).randn(40, 1), np.random.RandomState(3).randn(40, 1))] * 4, task_batch_size=2),   # n > 32
+             dict(tasks=make_tasks(4, 6, False), task_batch_size=3, mean_nn_layers=(64, 64), kernel_nn_layers=(64, 64)),
+             dict(tasks=make_tasks(5, 6, False), task_batch_size=3, optimizer='SGD'),
+             dict(tasks=make_tasks(6, 6, False, d=5), task_batch_size=3)]
+    for c in cases:
+        tasks = c.pop('tasks')
+        m = M.GPRegressionMetaLearned(tasks, random_seed=1, **c)
+        m.meta_fit(verbose=False, n_iter=3, log_period=2)
+        assert m._persist is None and bool(torch.isfinite(m.theta).all())
+    from meta_learning_pacoh_amd import _lib as L
+    lib = L.load_library()
+    h = L._hidden_arr([32, 32])
+    assert lib.pacoh_map_persist_supported(5, 1, 5, L.MEAN_VECTOR, h, 2, 1, h, 2, 2, L.F32) == 1
+    assert lib.pacoh_map_persist_supported(5, 1, 5, L.MEAN_VECTOR, h, 2, 1, h, 2, 2, L.F64) == 0          # fp32 only
+    assert lib.pacoh_map_persist_supported(33, 1, 5, L.MEAN_VECTOR, h, 2, 1, h, 2, 2, L.F32) == 0
+    # the entry point itself refuses what the plan refuses (no launch, no partial work)
+    t = torch.zeros(8, device='cuda')
+    idx = torch.zeros(1, 5, dtype=torch.int64, device='cuda')
+    seg = (L.ctypes.c_int32 * 4)(0, 0, 0, 0)
+    rc = lib.pacoh_map_persist(t.data_ptr(), t.data_ptr(), t.data_ptr(), 8, t.data_ptr(), t.data_ptr(), None, 33, 1, idx.data_ptr(), 5,
+                               t.data_ptr(), 8, 1, L.MEAN_ZERO, -1, h, 0, 0, -1, h, 0, 1, 0, 1, 2, 1e-3, seg, seg, 1, 0.9, 0.999,
+                               None, None, None, L.F32, None)
+    assert rc == -2                                                                                   # PACOH_ELIMIT
+
+
+def test_a_failed_cholesky_raises_like_the_launch_sequence(M, monkeypatch):
+    """a NaN noise parameter makes every jittered Cholesky fail (info = -1): gpytorch raises NotPSDError inside the loss evaluation,
+    meta_fit raises at its next synchronisation -- on both paths, the persistent one through the failure flag of its last wave"""
+    from meta_learning_pacoh_amd.engine import NotPSDError
+    tasks = O.sinusoid_tasks_nd(5, 8, 1, seed0=50)
+    for persist in ('0', '1'):
+        monkeypatch.setenv('PACOH_MAP_PERSIST', persist)
+        m = M.GPRegressionMetaLearned(tasks, task_batch_size=3, random_seed=1)
+        m.theta[0, m.layout.slices['noise_raw'][0]] = float('nan')
+        with pytest.raises(NotPSDError):
+            m.meta_fit(verbose=False, n_iter=2)
+        assert (m._persist is not None) == (persist == '1')
