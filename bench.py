@@ -33,6 +33,7 @@ TASKS, N_CTX, DIM, PARTICLES = 1024, 64, 4, 20
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy peak)
 FP32_PEAK_TFLOPS = 157.3       # fp32 vector peak == fp32-input MFMA peak (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6        # fp64 matrix peak: AMD's MI355X figure; tools/mfma_peak.hip measures what v_mfma_f64_16x16x4 sustains
+STEADY_STEPS = 200            # the extra region behind the timed one (the line's `steady` object)
 PMC_PROFILE = os.path.join('profiles', 'r04_pmc_hbm_traffic.json')
 DENSE_PMC_PROFILE = os.path.join('profiles', 'r04_dense_pmc_hbm_traffic.json')
 
@@ -131,6 +132,7 @@ def assemble_line(metric, value, world, steps, warmup, ms_per_step, scaling, dty
         'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
         'backend': backend, 'world_size_seen': world_size_seen,
         'exchange': leg.get('exchange'), 'all_reduce_us': leg.get('all_reduce_us'), 'legs': legs,
+        'steady': leg.get('steady'),
         'host_ms_per_step': round(host_ms, 4), 'step_mode': step_mode,
         'config': config,
         'roofline': roofline, 'kernel_rooflines': kernel_rooflines,
@@ -238,7 +240,20 @@ def main():
             tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
+        # the steady state, driver-visible: one more region of STEADY_STEPS steps right behind the --steps region (same workload, same
+        # bracketing).  The top-level value stays the --steps region's; short regions also pay the clock ramp after the idle barrier
+        # (tools/README.md), which this one dilutes.
+        t1 = time.perf_counter()
+        wl['run'](STEADY_STEPS)
+        barrier()
+        steady_s = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([steady_s], dtype=torch.float64, device='cuda')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            steady_s = float(tt.item())
         leg = {'scaling': scaling, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+               'steady': {'steps': STEADY_STEPS, 'ms_per_step': round(steady_s / STEADY_STEPS * 1e3, 4),
+                          'value': round(wl['evals_per_step'] * STEADY_STEPS / steady_s, 1)},
                'value': round(wl['evals_per_step'] * args.steps / elapsed, 1), 'unit': 'evals/s',
                'evals_per_step': wl['evals_per_step'], 'host_ms_per_step': round(host_ms, 4), 'finite': wl['finite'](),
                'exchange': exchange_name(), 'world_size_seen': (dist.get_world_size() if world > 1 else 1),
@@ -277,6 +292,10 @@ def main():
         leg2, wl2, _ = timed_leg(other, False)
         leg2['all_reduce_us'] = all_reduce_us(profile_pass(wl2, L, 20))
         legs[other] = leg2
+        # what the first real record needs to explain its own efficiency: a rank of the weak leg does the N = 1 job's work, so the
+        # strong leg's ideal step is that time / N; what is above it is the one-round-of-workgroups floor of a small shard plus the exchange
+        legs['strong']['ideal_ms_per_step'] = round(legs['weak']['ms_per_step'] / world, 4)
+        legs['strong']['ideal_source'] = 'legs.weak.ms_per_step (1024 tasks per GPU = the N = 1 job) / %d' % world
         wl = wl2
 
     gram = gram_leg(L) if (rank == 0 and args.config == 3) else None
@@ -617,8 +636,9 @@ def wl_cfg1(world, scaling, M, L):
     ev = 5 / world
     return dict(run=model._train_steps, evals_per_step=5, dtype='f32', finite=lambda: bool(torch.isfinite(model.theta).all()), mode=lambda: _mode(model),
                 metric='task-GP LML+grad evals/sec (PACOH-MAP demo: 20 tasks x 5 points, 5 per iteration)',
-                flops={'gp_lml_fwdbwd': (gp_flops(5, 2) * ev,) * 2, 'mlp_fwd': (2 * 5 * w * ev,) * 2, 'mlp_bwd': (4 * 5 * w * ev, 6 * 5 * w * ev)},
-                describe='PACOH-MAP iteration (hipGraph replay), cfg#1 = the reference\'s demo: SinusoidDataset(RandomState(26)) 20 tasks x 5 points, 5 tasks per iteration, NN(32,32) mean + kernel, AdamW',
+                flops={'gp_lml_fwdbwd': (gp_flops(5, 2) * ev,) * 2, 'mlp_fwd': (2 * 5 * w * ev,) * 2, 'mlp_bwd': (4 * 5 * w * ev, 6 * 5 * w * ev),
+                       'map_persist': ((gp_flops(5, 2) + 6 * 5 * w) * ev,) * 2},        # (the whole iteration is one kernel: pacoh_map_persist)
+                describe='PACOH-MAP iteration (K iterations per launch of the persistent kernel where the shape fits, else hipGraph replay), cfg#1 = the reference\'s demo: SinusoidDataset(RandomState(26)) 20 tasks x 5 points, 5 tasks per iteration, NN(32,32) mean + kernel, AdamW',
                 extra={'tasks_total': 20, 'n_ctx': 5, 'd': 1})
 
 

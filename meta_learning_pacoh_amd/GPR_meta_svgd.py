@@ -9,11 +9,10 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from . import engine as _engine
 from . import parallel
 from .abstract import RegressionModelMetaLearned
 from .distributions import GaussianPredictive
-from .engine import (GRAPH_STEPS, AsyncUploader, GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, build_step_graphs,
+from .engine import (AsyncUploader, GPEngine, NotPSDError, ParamLayout, StepFeed, StepMode, TaskBatch, build_step_graphs,
                      first_chunk, replay_steps, run_step)
 from .util import StepLR
 
@@ -79,19 +78,11 @@ class _RandomGPLearner(RegressionModelMetaLearned):
     def _setup_tasks(self, meta_train_data):
         tasks = [self._prepare_data_per_task(x, y) for x, y in meta_train_data]
         self.tasks = TaskBatch(tasks, self.device, self.dtype)
-        self._idx_ahead = None                            # task draws taken from the numpy stream ahead of their use (SVGD: _prefetch)
 
     def _take_idx(self, k):
-        """the next k global task draws, int64 [k, B]: rows drawn ahead first, then the numpy stream -- one randint call of shape
-        [k, B] consumes it exactly like k calls of size B (GPR_meta_svgd.py:102 draws one batch per iteration)"""
-        q = getattr(self, '_idx_ahead', None)
-        if q is None or len(q) == 0:
-            return self.rds_numpy.randint(0, self.tasks.T, size=(k, self.task_batch_size))
-        take, rest = q[:k], q[k:]
-        self._idx_ahead = rest if len(rest) > 0 else None
-        if len(take) < k:
-            take = np.concatenate([take, self.rds_numpy.randint(0, self.tasks.T, size=(k - len(take), self.task_batch_size))], 0)
-        return take
+        """the next k global task draws, int64 [k, B]: one randint call of shape [k, B] consumes the numpy stream exactly like k calls
+        of size B (GPR_meta_svgd.py:102 draws one batch per iteration)"""
+        return self.rds_numpy.randint(0, self.tasks.T, size=(k, self.task_batch_size))
 
     def _sample_task_batch(self):
         """global with-replacement draw from the shared seed (GPR_meta_svgd.py:102), then this rank's shard"""
@@ -316,30 +307,12 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         """the next n_steps SVGD steps of the training loop (task draws from rds_numpy, lr from the scheduler)"""
         self._setup_step(self._local_batch_size())
         graphed = self._graphs_allowed()
-        first = ramp = True
-        used_ahead = False
-        ahead, self._ahead = getattr(self, '_ahead', None), None
+        ramp = True
         while n_steps > 0:
-            # a chunk uploaded at the end of the previous call (_prefetch) is this call's first chunk if nobody has touched the feed
-            # since and its scalars still hold (same step count, same learning rates): no draw, no upload in front of the first replay
-            use_ahead = (first and ahead is not None and ahead['feed'] is self._feed and ahead['serial'] == self._feed.serial
-                         and self._graphs is not None)
-            if use_ahead:
-                k = min(n_steps, ahead['k'])
-                used_ahead = True
-            elif ramp and used_ahead:                     # behind the chunk prepared ahead: 16 steps if many more follow, else the rest
-                k = _engine.FIRST_CHUNK if n_steps >= 4 * _engine.FIRST_CHUNK else min(n_steps, self.GRAPH_CHUNK)
-                ramp = False
-            else:
-                k = first_chunk(n_steps, self.GRAPH_CHUNK) if ramp else min(n_steps, self.GRAPH_CHUNK)
-                ramp = False
-            first = False
+            k = first_chunk(n_steps, self.GRAPH_CHUNK) if ramp else min(n_steps, self.GRAPH_CHUNK)
+            ramp = False
             idx_rows, sc_rows = self._draw_steps(k, self.lr_scheduler, self.opt_step + 1)
-            same = use_ahead and np.array_equal(sc_rows, ahead['sc'][:k]) and (
-                (idx_rows is None and ahead['idx'] is None) or
-                (idx_rows is not None and ahead['idx'] is not None and np.array_equal(idx_rows, ahead['idx'][:k])))
-            if not same:                                  # (e.g. _sample_task_batch() took a row of the queue in between)
-                self._feed.upload(idx_rows, sc_rows)
+            self._feed.upload(idx_rows, sc_rows)
             if self._pipelined:
                 self._feed.prologue()
             if graphed and self._graphs is None:
@@ -355,26 +328,6 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
             for _ in range(k):
                 self.lr_scheduler.step()
             n_steps -= k
-        if graphed and self._graphs is not None and os.environ.get('PACOH_PREFETCH', '1') != '0':
-            self._prefetch()
-
-    def _prefetch(self):
-        """The NEXT call's first chunk, prepared now: one replay's worth of task draws taken from the numpy stream (kept in
-        _idx_ahead until they are used: the sequence of draws is the one without prefetching), their scalars, the upload.  A training
-        call otherwise starts with the host preparing a chunk while the GPU idles -- 0.2-0.9 ms on a busy host, i.e. 2-10 % of the
-        20-step region the benchmark driver times.  The chunk is used only if the feed is untouched and both the draws at the head of
-        the queue and the scalars are still the ones that were uploaded."""
-        k = GRAPH_STEPS
-        q = getattr(self, '_idx_ahead', None)
-        have = 0 if q is None else len(q)
-        if have < k:
-            more = self.rds_numpy.randint(0, self.tasks.T, size=(k - have, self.task_batch_size))
-            q = more if have == 0 else np.concatenate([q, more], 0)
-            self._idx_ahead = q
-        idx_rows, sc_rows = self._rows_to_feed(q[:k], self.lr_scheduler, self.opt_step + 1)
-        self._feed.upload(idx_rows, sc_rows)
-        self._ahead = dict(k=k, sc=np.array(sc_rows, copy=True), idx=None if idx_rows is None else np.array(idx_rows, copy=True),
-                           feed=self._feed, serial=self._feed.serial)
 
     def svgd_step(self, idx_local, pre_factor):
         """SVGD.step (meta_learn/svgd.py:25-28) on an explicit task draw: particles.grad = -phi; optimizer.step()"""

@@ -885,8 +885,12 @@ int launch_ll(void* A, const void* resid, void* logp, void* alpha_out, int32_t* 
     if (!ll_plan<T>(n, &S0, &S1, &lds)) return 1;
     auto kern = chol_ll_kernel<T>;
     if (lds > 64u * 1024u &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return 1;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        // NOT "outside the plan" (1): the caller has already routed on dense_chol_saves_inverse(), which answers from ll_plan alone --
+        // the fallback kernels ignore u_only and leave no inverse diagonal blocks, the gradients would be silently wrong
+        (void)hipGetLastError();
+        return PACOH_ELIMIT;
+    }
     hipLaunchKernelGGL(kern, dim3(B), dim3(LL_NT), lds, s, (T*)A, (const T*)resid, (T*)logp, (T*)alpha_out, info, (T)scale, n, attempt,
                        u_only, S0, S1);
     return launch_status();
@@ -911,13 +915,13 @@ int dense_ll_retry_try(void* A, const void* resid, void* logp, void* alpha_out, 
     if (dtype == PACOH_F32) {
         if (!ll_plan<float>(n, &S0, &S1, &lds)) return 1;
         auto kern = chol_ll_retry_kernel<float>;
-        if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return PACOH_ELIMIT; }
         hipLaunchKernelGGL(kern, dim3(B), dim3(LL_NT), lds, s, (float*)A, (const float*)resid, (float*)logp, (float*)alpha_out, info, (float)scale, n,
                            att_lo, att_hi, u_only, S0, S1, rg);
     } else {
         if (!ll_plan<double>(n, &S0, &S1, &lds)) return 1;
         auto kern = chol_ll_retry_kernel<double>;
-        if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return PACOH_ELIMIT; }
         hipLaunchKernelGGL(kern, dim3(B), dim3(LL_NT), lds, s, (double*)A, (const double*)resid, (double*)logp, (double*)alpha_out, info, scale, n,
                            att_lo, att_hi, u_only, S0, S1, rg);
     }

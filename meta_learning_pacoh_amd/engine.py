@@ -194,7 +194,6 @@ class StepFeed:
         (j, out_row) filling the pinned staging row of step j in place, or None; resets the counter"""
         k = len(sc_rows)
         assert 0 < k <= self.chunk
-        self.serial = getattr(self, 'serial', 0) + 1     # (a learner that uploaded a chunk AHEAD checks that nobody has uploaded since)
         q = self._slot
         self._slot = 1 - q
         if self._ev[q] is not None:
@@ -330,8 +329,6 @@ def first_chunk(n_steps, chunk):
     k = min(n_steps, chunk)
     if n_steps >= 4 * FIRST_CHUNK and k > FIRST_CHUNK:
         return FIRST_CHUNK
-    if n_steps >= 2 * GRAPH_STEPS and k > GRAPH_STEPS and FIRST_CHUNK <= n_steps:      # short calls (the driver times 20 steps): one replay's worth
-        return GRAPH_STEPS
     return k
 
 

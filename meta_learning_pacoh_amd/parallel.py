@@ -247,14 +247,26 @@ def _direct_comm():
     global _direct
     if _direct is None and _want_direct():
         comm, ok = None, True
+        # Preconditions FIRST, agreed by all ranks, before anybody enters the blocking ncclCommInitRank: what can fail on ONE rank
+        # alone (librccl not loadable there, a symbol missing, no id obtainable) would otherwise leave its healthy peers inside
+        # pacoh_comm_init until their watchdog ends the job -- instead of the fallback to torch.distributed this function promises
+        # (ADVICE r4).  pacoh_comm_unique_id exercises exactly that: dlopen + symbol binding + ncclGetUniqueId, no peer involved.
         try:
-            comm = RcclComm(self_test=False)
+            L.comm_unique_id()
         except Exception as exc:
-            warnings.warn('pacoh: RCCL communicator could not be created on rank %d (%r)' % (world()[0], exc))
+            warnings.warn('pacoh: rank %d cannot use RCCL directly (%r); all ranks fall back to torch.distributed' % (world()[0], exc))
             ok = False
+        if not agree_all(ok):
+            ok = False
+        else:
+            try:
+                comm = RcclComm(self_test=False)
+            except Exception as exc:
+                warnings.warn('pacoh: RCCL communicator could not be created on rank %d (%r)' % (world()[0], exc))
+                ok = False
         # EVERY rank reports, and all ranks take the same branch: one rank falling back to torch.distributed while its peers sit in
         # the communicator's self-test would build different step graphs and hang the first exchange
-        if agree_all(ok):
+        if agree_all(ok) and comm is not None:
             comm.graph_ok = comm._self_test()              # (its three phases are agreed on by all ranks themselves)
             ok = comm.graph_ok or world()[1] == 1
         else:

@@ -432,31 +432,32 @@ def test_svgd_imq_steps_run_from_the_step_feed_and_replay_bit_identically(M, opt
     assert relerr(m_g.particles, X) < 2e-3
 
 
-def test_prefetched_task_draws_keep_the_numpy_stream_in_order(M, monkeypatch):
-    """PACOH-SVGD prepares the next call's first chunk at the end of a training call: the task draws it takes from the numpy stream
-    ahead of time are queued and handed out first, so every consumer -- the next training call, an explicit _sample_task_batch()
-    -- sees the sequence RandomState(seed + 1) produces without prefetching; and the run equals the one with PACOH_PREFETCH=0"""
+def test_task_draws_consume_the_numpy_stream_like_the_reference(M):
+    """one randint call per iteration, nothing drawn ahead (GPR_meta_svgd.py:102): after n iterations and an explicit
+    _sample_task_batch() the learner's RandomState(seed + 1) stands exactly n + 1 draws into its stream -- also for the global
+    np.random stream of an unseeded learner, which anything the caller draws afterwards depends on (the round-4 prefetch,
+    removed in round 5, left it four batches further along)"""
     tasks = tasks_nd(7, 12, 2)
-    kw = dict(num_particles=4, task_batch_size=5, lr=1e-2, random_seed=21, mean_nn_layers=(8, 8), kernel_nn_layers=(8, 8))
-    m = M.GPRegressionMetaLearnedSVGD(tasks, **kw)
+    kw = dict(num_particles=4, task_batch_size=5, lr=1e-2, mean_nn_layers=(8, 8), kernel_nn_layers=(8, 8))
+    m = M.GPRegressionMetaLearnedSVGD(tasks, random_seed=21, **kw)
     m.meta_fit(verbose=False, n_iter=6, log_period=4)
-    assert m._idx_ahead is not None and len(m._idx_ahead) == 4 and m._ahead is not None      # four steps' draws are waiting
     ref = np.random.RandomState(21 + 1)
     for _ in range(6):
         ref.randint(0, 7, size=5)
-    idx, _ = m._sample_task_batch()                              # the 7th draw of the stream, from the queue
+    idx, _ = m._sample_task_batch()                              # the 7th draw of the stream
     assert np.array_equal(np.sort(idx), np.sort(ref.randint(0, 7, size=5)))
-    m.meta_fit(verbose=False, n_iter=5, log_period=100)          # (the uploaded chunk's first row is gone: re-uploaded, same bits below)
-    ref_draws = [ref.randint(0, 7, size=5) for _ in range(5)]
-    monkeypatch.setenv('PACOH_PREFETCH', '0')
-    m2 = M.GPRegressionMetaLearnedSVGD(tasks, **kw)
-    m2.meta_fit(verbose=False, n_iter=6, log_period=4)
-    assert m2._idx_ahead is None
-    m2._sample_task_batch()
-    m2.meta_fit(verbose=False, n_iter=5, log_period=100)
-    assert torch.equal(m.particles, m2.particles) and m.opt_step == m2.opt_step == 11
-    assert np.array_equal(m2.rds_numpy.randint(0, 7, size=5), np.random.RandomState(22).randint(0, 7, size=(13, 5))[12])
-    del ref_draws
+    m.meta_fit(verbose=False, n_iter=5, log_period=100)
+    assert np.array_equal(m.rds_numpy.randint(0, 7, size=5), np.random.RandomState(22).randint(0, 7, size=(13, 5))[12]) and m.opt_step == 11
+    for cls, extra in ((M.GPRegressionMetaLearnedSVGD, kw), (M.GPRegressionMetaLearned, dict(task_batch_size=5))):
+        np.random.seed(77)
+        mu = cls(tasks, random_seed=None, **extra)               # unseeded: draws from the process-wide numpy stream
+        assert mu.rds_numpy is np.random
+        np.random.seed(78)
+        mu.meta_fit(verbose=False, n_iter=9, log_period=4)
+        after = np.random.randint(0, 1000, size=4)
+        np.random.seed(78)
+        np.random.randint(0, 7, size=(9, 5))
+        assert np.array_equal(after, np.random.randint(0, 1000, size=4))
 
 
 def test_step_feed_upload_accepts_tensors_lists_and_callables(M):
@@ -792,10 +793,9 @@ def test_small_first_chunk_does_not_change_the_run(M, kind, monkeypatch):
         m._train_steps(90)
         torch.cuda.synchronize()
         monkeypatch.setattr(engine.StepFeed, 'upload', real)
-        # PACOH-SVGD: the call's first four steps were prepared (drawn, uploaded) at the end of the previous call -- no upload --, and
-        # it ends by preparing the next call's; PACOH-VI grows by half (its chunks cost the host 0.15 ms of noise per step)
-        ramp = [16, 70, 4] if kind == 'svgd' else [16, 24, 36, 14]
-        assert (sizes[-len(ramp):] == ramp) if first == 16 else (sizes[-2:] == [86, 4] if kind == 'svgd' else sizes[-1] == 90)
+        # PACOH-SVGD: 16, then the rest; PACOH-VI grows by half (its chunks cost the host 0.15 ms of noise per step)
+        ramp = [16, 74] if kind == 'svgd' else [16, 24, 36, 14]
+        assert (sizes[-len(ramp):] == ramp) if first == 16 else sizes[-1] == 90
         out.append((m.particles if kind == 'svgd' else m.posterior).clone())
     assert bool(torch.isfinite(out[0]).all()) and torch.equal(out[0], out[1])
 

@@ -133,3 +133,4 @@ def test_bench_two_ranks_prints_both_scaling_legs():
         assert leg['finite'] and leg['ms_per_step'] > 0 and leg['world_size_seen'] == 2
         assert 'torch.distributed' in leg['exchange'] and leg['all_reduce_us'] is not None and leg['all_reduce_us'] > 0
     assert out['value'] == out['legs']['weak']['value']
+    assert out['legs']['strong']['ideal_ms_per_step'] == round(out['legs']['weak']['ms_per_step'] / 2, 4) and out['steady']['steps'] == 200

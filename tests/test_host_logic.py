@@ -255,14 +255,15 @@ def test_standard_normal_into_a_buffer_is_the_same_draw():
 
 
 def test_first_chunk_sizes():
-    """engine.first_chunk: a call with many steps starts with 16, a short one (the driver's 20-step region) with one replay's worth,
-    tiny calls and small feeds are left alone; the sizes always fit the request and the feed"""
+    """engine.first_chunk: a call with many steps starts with 16 so that the host's chunk preparation hides behind the GPU; shorter
+    calls and small feeds are one chunk (round 5: the round-4 rule for the driver's 20-step window is gone -- profiles/r05_prefetch_ab.txt);
+    the sizes always fit the request and the feed"""
     from meta_learning_pacoh_amd import engine
     fc = engine.first_chunk
     assert fc(200, 1024) == 16 and fc(64, 1024) == 16 and fc(1000, 128) == 16
-    assert fc(20, 1024) == 4 and fc(63, 1024) == 4 and fc(16, 1024) == 4
+    assert fc(20, 1024) == 20 and fc(63, 1024) == 63 and fc(16, 1024) == 16
     assert fc(15, 1024) == 15 and fc(7, 1024) == 7 and fc(1, 1024) == 1
-    assert fc(200, 8) == 4 and fc(20, 4) == 4 and fc(20, 2) == 2
+    assert fc(200, 8) == 8 and fc(20, 4) == 4 and fc(20, 2) == 2
     for n in range(1, 300):
         for chunk in (1, 4, 16, 100, 1024):
             k = fc(n, chunk)
@@ -281,7 +282,8 @@ def test_bench_line_shape_with_both_scaling_legs():
     def leg(scaling, ms, evals):
         return {'scaling': scaling, 'ms_per_step': ms, 'value': evals / (ms * 1e-3), 'unit': 'evals/s', 'evals_per_step': evals,
                 'host_ms_per_step': 0.01, 'finite': True, 'exchange': 'torch.distributed.all_reduce between two graphs per step',
-                'world_size_seen': 2, 'step_mode': {'graph': True}, 'tasks_total': 2048 if scaling == 'weak' else 1024, 'all_reduce_us': 31.5}
+                'world_size_seen': 2, 'step_mode': {'graph': True}, 'tasks_total': 2048 if scaling == 'weak' else 1024, 'all_reduce_us': 31.5,
+                'steady': {'steps': 200, 'ms_per_step': ms * 0.97, 'value': evals / (ms * 0.97e-3)}}
     legs = {'weak': leg('weak', 0.45, 40960), 'strong': leg('strong', 0.25, 20480)}
     pp = {'kernel_sum': 0.4, 'ms_per_step': 0.47, 'kernel_ms': {'mlp_bwd': 0.17}, 'kernel_ms_raw': {'mlp_bwd': 0.18}, 'event_overhead_ms': 0.009}
     out = bench.assemble_line(metric='task-GP LML+grad evals/sec (n_ctx=64, d=4, 20 particles)', value=legs['weak']['value'], world=2, steps=20,
@@ -290,7 +292,7 @@ def test_bench_line_shape_with_both_scaling_legs():
                               kernel_rooflines={}, step_flops=2.6e10, gram=None, pp=pp, others=None, cpu=None)
     json.loads(json.dumps(out))                                  # one serialisable line
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
-                'data', 'config', 'roofline', 'cpu_baseline', 'legs', 'exchange', 'all_reduce_us', 'world_size_seen', 'schema'):
+                'data', 'config', 'roofline', 'cpu_baseline', 'legs', 'exchange', 'all_reduce_us', 'world_size_seen', 'schema', 'steady'):
         assert key in out, key
     assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] == round(legs['weak']['value'], 1)
     assert set(out['legs']) == {'weak', 'strong'}
@@ -298,3 +300,4 @@ def test_bench_line_shape_with_both_scaling_legs():
         for key in ('ms_per_step', 'value', 'exchange', 'world_size_seen', 'all_reduce_us'):
             assert key in l, key
     assert out['all_reduce_us'] == 31.5 and out['vs_baseline'] is None
+    assert set(out['steady']) == {'steps', 'ms_per_step', 'value'} and out['steady']['steps'] == 200       # the steady-state region behind the timed one

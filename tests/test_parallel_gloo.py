@@ -71,6 +71,26 @@ def _worker(rank, world, port, out_dir):
         ok = False
     except AssertionError:
         pass
+    # one rank cannot use RCCL directly (library / symbol / id): ALL ranks agree on that before anybody enters the blocking
+    # communicator creation, and torch.distributed carries the exchange
+    import warnings
+    from meta_learning_pacoh_amd import _lib as L
+    made = []
+
+    def fake_uid():
+        if rank == 1:
+            raise RuntimeError('librccl not loadable on this rank')
+        return b'x' * L.COMM_ID_BYTES
+    real_uid, real_comm = L.comm_unique_id, parallel.RcclComm
+    L.comm_unique_id, parallel.RcclComm = fake_uid, (lambda **kw: made.append(1))
+    os.environ['PACOH_COMM'] = 'rccl'
+    parallel._direct = None
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        comm = parallel._direct_comm()
+    ok = ok and comm is None and not made and parallel._direct is False
+    os.environ.pop('PACOH_COMM')
+    L.comm_unique_id, parallel.RcclComm, parallel._direct = real_uid, real_comm, None
     with open(os.path.join(out_dir, 'rank%d.txt' % rank), 'w') as f:
         f.write('ok' if ok else 'mismatch')
     dist.destroy_process_group()
