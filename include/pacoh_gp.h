@@ -544,6 +544,34 @@ int pacoh_map_persist(void* theta, void* exp_avg, void* exp_avg_sq, int D, const
                       const int32_t* seg_lo, const int32_t* seg_hi, int n_seg, double beta1, double beta2,
                       void* loss_last, void* loss_cum, int32_t* fail_flag, int dtype, void* stream);
 
+/* The same loop body for task batches too LARGE for one workgroup (BASELINE config #2: 256 tasks x 32 points per iteration), as TWO
+ * launches per iteration instead of four (round 5, csrc/map_task.hip): pacoh_map_task_step runs
+ *   (1) forward of the networks, GP LML and its gradient, backward of the networks for every task -- one workgroup per task (several
+ *       tasks per workgroup when they fit one 16-point tile), the task's activations staying in LDS between the stages --, writing one
+ *       gradient slab per workgroup and network;
+ *   (2) the slab reduction with the step's tail: sums over tasks into d_theta[1, D], hyper-parameter reduction with the softplus chain
+ *       rule, *lik = lik_scale * sum_t lml_t, the failure flag, and -- opt / opt->next as for pacoh_mlp2_bwd_hyper -- the AdamW step on
+ *       every entry, the next iteration's scalars, task gather and hyper-parameter transforms.
+ * batch_x [tb, n, d] / batch_y [tb, n] / batch_n_valid [tb] | NULL: the iteration's gathered tasks (pacoh_step_begin / the previous
+ * call's opt->next); ls [f] / os [1] | NULL / noise [1]: the transformed hyper-parameters of the ONE parameter row theta[1, D]; the
+ * networks as for pacoh_map_persist (D = the length of the parameter row).  workspace: pacoh_map_task_workspace_bytes() bytes (0: shape outside the plan -> PACOH_ELIMIT
+ * from the call).  Limits: fp32, n <= 32, d <= 4, f <= 4, at least one network, hidden widths <= 32, <= 4 hidden layers.  The step
+ * counter of opt->next is advanced by launch (1).
+ * pacoh_map_task_setup: the workspace also holds the networks' parameters in the padded layout launch (1) keeps them in (its prologue
+ * copies them instead of decoding theta) -- written by this call from theta, kept current by launch (2)'s AdamW step.  Call it before the
+ * first pacoh_map_task_step on a workspace and whenever theta was changed by anything else. */
+int pacoh_map_task_setup(const void* theta, int D, int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
+                         int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
+                         void* workspace, size_t workspace_bytes, int dtype, void* stream);
+size_t pacoh_map_task_workspace_bytes(int D, int n, int d, int tb, int mean_mode, const int32_t* mean_hidden, int n_mean_hidden, int kernel_nn,
+                                      const int32_t* kernel_hidden, int n_kernel_hidden, int f, int dtype);
+int pacoh_map_task_step(const void* theta, long theta_stride, const void* batch_x, const void* batch_y, const int32_t* batch_n_valid,
+                        int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
+                        int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
+                        const void* ls, const void* os, const void* noise, int off_ls, int off_os, int off_noise,
+                        void* d_theta, long d_theta_stride, void* lik, double lik_scale, int32_t* fail_flag,
+                        void* workspace, size_t workspace_bytes, const pacoh_adam_inline* opt, int dtype, void* stream);
+
 /* ---- 8e: the step's one exchange ----------------------------------------------------------------------------------
  * buf[0..count) := sum over ranks of buf (in place), enqueued on the caller's stream: RCCL ncclAllReduce(ncclSum) over xGMI.
  * Sums the per-rank partial  sum_t mll[t,:]  and partial score [P,D] of the task-sharded objective

@@ -144,6 +144,7 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
                 self._persist = plan
         if self._persist is not None:
             self._pipelined = False
+            self._task_ws = None
             return
         # Four launches per iteration (forward, GP, backward, slab reduction) where the AdamW step rides in the gradient epilogue
         # (_adam_inline) AND the networks run on the fused kernels: the epilogue then also fetches the next iteration's operands and
@@ -152,6 +153,13 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         self._pipelined = self._adam_inline() and self._nets_fused(tb_local) and os.environ.get('PACOH_MAP_PIPELINE', '1') != '0'
         if self._pipelined:
             self._feed.pipeline(self.tasks, self.engine, self.theta)
+        # ... and TWO where the whole task batch's forward + GP + backward is one launch (include/pacoh_gp.h, pacoh_map_task_step: one
+        # workgroup per task, BASELINE config #2's regime) in front of the slab reduction.  PACOH_MAP_TASK_FUSED=0: the four launches
+        self._task_ws = None
+        if self._pipelined and os.environ.get('PACOH_MAP_TASK_FUSED', '1') != '0' and not L.FORCE_DENSE:
+            plan = L.MapPersistPlan(self.layout, self.tasks, tb_local, self.engine.noise_floor, self.train_segments, self.dtype)
+            self._task_ws = L.map_task_workspace(plan, tb_local, self.device)
+            self._task_plan = plan
 
     def _nets_fused(self, tb_local):
         lay = self.layout
@@ -162,6 +170,10 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
 
     def _body_likelihood(self):
         if getattr(self, '_pipelined', False):
+            if self._task_ws is not None:
+                L.map_task_step(self._task_plan, self.theta, self._feed.batch, self._feed.hyp, self._grad, self._g_loss, -1.0, self._fail,
+                                self._task_ws, self._opt_block())
+                return
             self.engine.lml_and_grad(self.theta, self._feed.batch, weight=-1.0, lik_out=self._g_loss, lik_scale=-1.0,
                                      grad_out=self._grad, fail_flag=self._fail, hypers=self._feed.hyp, opt=self._opt_block())
             return
@@ -264,8 +276,12 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
             self._feed.upload(local if self._feed.tb > 0 else None, sc_rows)
             if self._pipelined:
                 self._feed.prologue()
+            if self._task_ws is not None:                # (theta may have been set from outside since the last call)
+                L.map_task_setup(self._task_plan, self.theta, self._feed.tb, self._task_ws)
             if graphed and self._graphs is None:
                 self._build_graphs()
+                if self._task_ws is not None:            # (the capture runs stepped the image along with theta; theta was restored)
+                    L.map_task_setup(self._task_plan, self.theta, self._feed.tb, self._task_ws)
             if graphed:
                 # replay or eager launches, whichever is faster here (engine.StepMode); several steps per replay where possible
                 many = (lambda n: replay_steps(n, self._graphs[0], self._graph_many)) if len(self._graphs) == 1 else None

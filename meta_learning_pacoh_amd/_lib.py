@@ -104,6 +104,10 @@ SIGNATURES = {
     'pacoh_map_persist_supported': (_i, [_i, _i, _i, _i, _ip, _i, _i, _ip, _i, _i, _i]),
     'pacoh_map_persist': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _ip, _i, _i, _i, _ip, _i, _i,
                                _i, _i, _i, _d, _ip, _ip, _i, _d, _d, _vp, _vp, _vp, _i, _vp]),
+    'pacoh_map_task_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _ip, _i, _i, _ip, _i, _i, _i]),
+    'pacoh_map_task_setup': (_i, [_vp, _i, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip, _i, _i, _vp, _sz, _i, _vp]),
+    'pacoh_map_task_step': (_i, [_vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip, _i, _i, _vp, _vp, _vp, _i, _i, _i,
+                                 _vp, _l, _vp, _d, _vp, _vp, _sz, _vp, _i, _vp]),
     'pacoh_comm_unique_id': (_i, [_vp]),
     'pacoh_comm_init': (_i, [_vp, _i, _i, _c.POINTER(_vp)]),
     'pacoh_allreduce_sum': (_i, [_vp, _l, _i, _vp, _vp]),
@@ -665,6 +669,43 @@ def map_persist(plan, theta, exp_avg, exp_avg_sq, tasks, idx_rows, sc_rows, K, l
                                      plan.seg_lo, plan.seg_hi, plan.n_seg, float(beta1), float(beta2),
                                      _ptr(loss_last, theta), _ptr(loss_cum, theta), _ptr(fail_flag), dtype_code(theta), _stream()),
                'pacoh_map_persist')
+
+
+def map_task_workspace(plan, tb, device, workspace=None):
+    """workspace of map_task_step for a batch of tb tasks (None: the task-fused kernel does not take this shape)"""
+    need = load_library().pacoh_map_task_workspace_bytes(plan.D, plan.n, plan.d, int(tb), plan.mean_mode, plan._mh, len(plan.mean_hidden), plan.kernel_nn,
+                                                        plan._kh, len(plan.kernel_hidden), plan.f, F32 if plan.dtype == torch.float32 else F64)
+    if need == 0 or not plan.rbf:
+        return None
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=device)
+    return workspace
+
+
+def map_task_setup(plan, theta, tb, workspace):
+    """(re)build the parameter image of map_task_step's workspace from theta: before the first step on it and after any change of theta
+    that did not come from map_task_step itself (pacoh_map_task_setup)"""
+    lib = load_library()
+    with _Timed('map_task_setup'):
+        _check(lib.pacoh_map_task_setup(_ptr(theta), plan.D, plan.n, plan.d, int(tb), plan.mean_mode, plan.off_mean, plan._mh, len(plan.mean_hidden),
+                                        plan.kernel_nn, plan.off_kernel, plan._kh, len(plan.kernel_hidden), plan.f, _ptr(workspace),
+                                        workspace.numel(), dtype_code(theta), _stream()), 'pacoh_map_task_setup')
+
+
+def map_task_step(plan, theta, batch, hypers, grad, lik, lik_scale, fail_flag, workspace, opt):
+    """one PACOH-MAP iteration's likelihood, gradient and update as two launches (pacoh_map_task_step): batch = the gathered TaskBatch,
+    hypers = (ls [1, f], os [1] | None, noise [1]) transformed, grad [1, D], lik [1]; opt = adam_inline(...) with its step_next"""
+    lib = load_library()
+    ls, os_, noise = hypers
+    with _Timed('map_task_step'):
+        _check(lib.pacoh_map_task_step(_ptr(theta), theta.shape[1], _ptr(batch.x, theta), _ptr(batch.y, theta),
+                                       _ptr(batch.n_valid) if batch.n_valid is not None else None, plan.n, plan.d, int(batch.T),
+                                       plan.mean_mode, plan.off_mean, plan._mh, len(plan.mean_hidden),
+                                       plan.kernel_nn, plan.off_kernel, plan._kh, len(plan.kernel_hidden), plan.f,
+                                       _ptr(ls, theta), _ptr(os_, theta), _ptr(noise, theta), plan.off_ls, plan.off_os, plan.off_noise,
+                                       _ptr(grad, theta), grad.shape[1], _ptr(lik, theta), float(lik_scale), _ptr(fail_flag),
+                                       _ptr(workspace), workspace.numel(), _opt_ptr(opt), dtype_code(theta), _stream()),
+               'pacoh_map_task_step')
 
 
 def mlp_fused_path(B, P, n, d_in, hidden, d_out, dtype):

@@ -1,0 +1,358 @@
+// Task-fused PACOH-MAP iteration (round 5): forward of the networks, Gram / Cholesky / LML and its gradient, and the networks'
+// backward pass of ONE task per workgroup in ONE launch, for task batches too large for the persistent one-workgroup kernel
+// (map_persist.hip) -- BASELINE config #2: 256 tasks x 32 points per iteration.  As separate launches that iteration was
+// forward (6.7 us) -> GP (8.0) -> backward (10.5) -> slab reduction + AdamW (5.0): four kernel latencies, each kernel a few hundred
+// instructions per wave.  Here a workgroup keeps its task's activations in LDS between the three stages (map_net.h: the parameter
+// image, the in-register MFMA chains, gp_reg_body.h for the GP) and writes ONE gradient slab per network in the layout the existing
+// slab reduction reads (mlp_fused.hip, fused_reduce_slab_kernel: sum over tasks + AdamW + next batch + hyper-parameter transforms in its
+// tail) -- an iteration is two launches.
+// Reference lines replaced: GPR_meta_mll.py:104-117 (the task loop and backward), models.py:505-519, models.py:206-217.
+#include "map_net.h"
+
+namespace pacoh {
+
+// mlp_fused.hip: the slab reduction as a launch of its own (what mlp_fused_bwd issues behind its backward kernel)
+int fused_reduce_launch(const float* slab0, int wd0, long off0, const float* slab1, int wd1, long off1, int nets, float* d_theta,
+                        long d_theta_stride, int slabs, const HyperBwdArgs<float>* tail, float* img_th, const int* img_map, hipStream_t s);
+
+namespace {
+
+constexpr int MT_NT = 512;           // 8 waves: 256 registers per lane (the two-block GP needs 90-112), cheaper barriers
+constexpr int MT_MAXTASKS = 36;      // task descriptors that fit the kernel-argument segment beside the layer table
+
+struct MtArgs {
+    MpArgs p;                        // (first: mp_layer_karg reads the layer table at its offset in the kernel-argument segment)
+    const float* bx; const float* by; const int32_t* bnv;            // the gathered batch [tb_total, n, d] / [tb_total, n] / [tb_total] | null
+    const float* hyp_ls; const float* hyp_os; const float* hyp_noise;   // transformed hyper-parameters of the one parameter row
+    float* slab[2]; int dnet[2]; int flat0[2];                       // per network: slabs [workgroups][dnet], first column of its block in theta
+    float* lml_g; int32_t* info_g; float* dls_g; float* dos_g; float* dnz_g; float* dc_g;   // per-task GP outputs [tb_total (, f)]
+    long* adv_counter;               // the pipelined feed's step counter: advanced by workgroup 0 (as mlp_fused_bwd_kernel does)
+    const float* thimg;              // the parameter image in memory (map_task_setup_kernel; kept current by the slab reduction's AdamW)
+    int tb_total;
+    int ntask[3];                    // tasks per phase of a FULL workgroup, planned by the host (mt_plan) ...
+    MpTask plan[MT_MAXTASKS];        // ... phase 0 = plan[0 .. ntask[0]), phase 2 = plan[ntask[0] ..): the delta chains are phase 0's tasks again
+};
+static_assert(sizeof(MtArgs) <= 4096, "the kernel-argument segment holds 4 KB");
+
+// The task descriptors of a workgroup, planned ONCE on the host and handed over in the kernel arguments (planned inside the kernel
+// -- by one thread, then by 64 in parallel -- the plan cost 2-4 us of a 7 us kernel in every launch).  Chains (network, point tile)
+// first: they are phase 0 and, as delta chains, phase 1; then per layer its weight tiles and its bias task.  The slab fields of a
+// weight tile: dst = its first entry relative to the network's block, s_dst = in (row stride in theta), kmax = the bias entries of its
+// rows, pad1 = the tile column that is the bias (none if >= 16), pad0 = the network.  A workgroup with fewer tasks than a full one
+// skips the chains of point tiles it does not have; the MFMA steps of a weight tile follow from its own point count.
+int mt_plan(MtArgs& ka) {
+    const MpArgs& a = ka.p;
+    const int nPt = (a.pts + 15) >> 4;
+    int q = 0;
+    for (int k = 0; k < a.nets; ++k)
+        for (int Pt = 0; Pt < nPt; ++Pt) {
+            if (q >= MT_MAXTASKS) return PACOH_ELIMIT;
+            MpTask tk = {};
+            tk.kind = MP_FWD; tk.w = k; tk.src = Pt; tk.n1 = a.nl[k];
+            bool w32 = a.L[k][0].S <= 8 && a.L[k][a.nl[k] - 1].out <= 4;
+            for (int l = 0; l + 1 < a.nl[k]; ++l) w32 = w32 && a.L[k][l].out == 32;
+            tk.flags = w32 ? 4 : 0;
+            ka.plan[q++] = tk;
+        }
+    ka.ntask[0] = ka.ntask[1] = q;
+    for (int k = 0; k < a.nets; ++k)
+        for (int l = 0; l < a.nl[k]; ++l) {
+            const MpLayer& L = a.L[k][l];
+            for (int J = 0; J < (L.out + 15) >> 4; ++J)
+                for (int I = 0; I < (L.in + 15) >> 4; ++I) {
+                    if (q >= MT_MAXTASKS) return PACOH_ELIMIT;
+                    MpTask tk = {};
+                    tk.kind = MP_WGRAD; tk.S = L.S; tk.pad0 = k; tk.w = L.w_lds + 16 * J * L.S + 16 * I;
+                    tk.src = L.d_out + 16 * J; tk.s_src = L.s_d; tk.aux = (l == 0 ? 0 : L.a_in) + 16 * I; tk.flags = l == 0 ? 2 : 0;
+                    tk.lim_a = L.out - 16 * J; tk.lim_b = L.S - 16 * I; tk.n2 = L.s_d - 16 * J;
+                    tk.dst = (L.w_flat - ka.flat0[k]) + 16 * J * L.in + 16 * I; tk.s_dst = L.in;
+                    tk.kmax = (L.b_flat - ka.flat0[k]) + 16 * J; tk.pad1 = L.in - 16 * I;
+                    ka.plan[q++] = tk;
+                }
+            if ((L.in & 15) == 0) {
+                if (q >= MT_MAXTASKS) return PACOH_ELIMIT;
+                MpTask tk = {};
+                tk.kind = MP_BIAS; tk.S = L.S; tk.pad0 = k; tk.w = L.w_lds + L.in; tk.src = L.d_out; tk.s_src = L.s_d; tk.lim_a = L.out;
+                tk.dst = L.b_flat - ka.flat0[k];
+                ka.plan[q++] = tk;
+            }
+        }
+    ka.ntask[2] = q - ka.ntask[0];
+    return PACOH_OK;
+}
+
+// The parameter image in MEMORY (once per training call, and whenever theta was changed from outside): thimg[DP] as the kernels keep it
+// in LDS, and for every network entry of theta its place in the image (-1 elsewhere) -- with it the slab reduction's AdamW step writes
+// each updated entry into the image too, so that the task kernel's prologue is a copy.
+__global__ void __launch_bounds__(MT_NT) map_task_setup_kernel(MtArgs ka, float* thimg, int* img_map, int Dmax) {
+    const MpArgs& a = ka.p;
+    const int t = threadIdx.x;
+    for (int q = t; q < a.DP; q += MT_NT) thimg[q] = 0.0f;
+    for (int q = t; q < Dmax; q += MT_NT) img_map[q] = -1;
+    __syncthreads();
+    for (int k = 0; k < a.nets; ++k)
+        for (int l = 0; l < a.nl[k]; ++l) {
+            const MpLayer L = mp_layer_karg(k, l);
+            for (int e = t; e < L.out * (L.in + 1); e += MT_NT) {
+                const int j = e / (L.in + 1), i = e - j * (L.in + 1);
+                const int q = i < L.in ? L.w_flat + j * L.in + i : L.b_flat + j;
+                const int li = L.w_lds + j * L.S + i;
+                thimg[li] = a.theta[q];
+                img_map[q] = li;
+            }
+        }
+}
+
+template <int NB, int FP>
+__global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ __attribute__((aligned(16))) int ltab[2 * MP_MAXL * 16];
+    const MpArgs& a = ka.p;
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lane = t & 63, r16 = t & 15, g4 = (t >> 4) & 3;
+    constexpr int NW = MT_NT / 64;
+    const int n = a.n, d = a.d, f = a.f;
+    const int task0 = blockIdx.x * a.tb;
+    const int tb = ka.tb_total - task0 < a.tb ? ka.tb_total - task0 : a.tb;      // tasks of this workgroup
+    const int pts = tb * n;
+    float* th = lds + a.o_th;
+    float* hp = lds + a.o_hp;
+    MpTask* tasks = reinterpret_cast<MpTask*>(lds + a.o_tasks);
+
+#ifdef PACOH_MP_STAMPS
+    if (t == 0) { mp_st_on = 1; mp_st_n[0] = mp_st_n[1] = 0; }
+    __syncthreads();
+    MP_STAMP();
+#endif
+    // ---- prologue (every launch pays it: 18 000 cycles in the first version, a third of the kernel): the layer table from the
+    //      kernel-argument segment, LDS zeroed 16 bytes per store; then ONE memory round trip for everything else -- the parameter
+    //      image as a flat loop over image entries (layer found by comparison, row by a float division: no per-layer loops with their
+    //      dependent scalar loads), the task's points, the hyper-parameters -- while the last wave plans the tasks -------------------
+    typedef const int __attribute__((address_space(4))) * kint_t;
+    if (t < 2 * MP_MAXL * 16) {
+        kint_t kt = (kint_t)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(MpArgs, L));
+        ltab[t] = kt[t];
+    }
+    const int nchain = ka.ntask[0], nweight = ka.ntask[2];
+    {
+        float4* l4 = reinterpret_cast<float4*>(lds);
+        for (int q = t; q < (a.total + 3) >> 2; q += MT_NT) l4[q] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    MP_STAMP();
+    // (every global load of the prologue is issued before the first one is waited for: theta was written by the previous
+    //  iteration's reduction on other XCDs -- a load of it is a fabric round trip of ~2 000 cycles, and three of them in a row per
+    //  thread were most of the second version's prologue)
+    const int epl = n * (d + 1);
+    const bool mover = t < tb * epl;
+    const int mv_s = mover ? t / epl : 0, mv_r = mover ? t - mv_s * epl : 0;
+    float mv_val = 0.0f, hp_val = 0.0f;
+    int nv_val = 0;
+    if (mover) mv_val = mv_r < n * d ? ka.bx[(long)(task0 + mv_s) * (n * d) + mv_r] : ka.by[(long)(task0 + mv_s) * n + (mv_r - n * d)];
+    if (t < tb && ka.bnv) nv_val = ka.bnv[task0 + t];
+    if (t < 7) {
+        if (t < f) hp_val = ka.hyp_ls[t];
+        else if (t == 4) { if (ka.hyp_os) hp_val = ka.hyp_os[0]; }
+        else if (t == 5) hp_val = ka.hyp_noise[0];
+        else if (t == 6 && a.off_const >= 0) hp_val = a.theta[a.off_const];
+    }
+    if (wave == NW - 1) {                               // the last wave copies the plan out of the kernel arguments
+        kint_t kt = (kint_t)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(MtArgs, plan));
+        int* dst = reinterpret_cast<int*>(tasks);
+        constexpr int PW = MT_MAXTASKS * 16 / 64;        // words per lane: all loads first, then the stores (ONE memory round trip)
+        int w[PW];
+        const int nw = (nchain + nweight) * 16;
+#pragma unroll
+        for (int u = 0; u < PW; ++u) { const int q = (t & 63) + 64 * u; w[u] = q < nw ? kt[q] : 0; }
+#pragma unroll
+        for (int u = 0; u < PW; ++u) { const int q = (t & 63) + 64 * u; if (q < nw) dst[q] = w[u]; }
+    } else {
+        const MpLayer* lt = reinterpret_cast<const MpLayer*>(ltab);
+        const int nl0 = a.nets > 0 ? a.nl[0] : 0, nl1 = a.nets > 1 ? a.nl[1] : 0;
+        constexpr int IT = MT_NT - 64;
+        // the parameter image, 16 bytes per lane from its copy in memory (decoding it from theta's layout cost every workgroup ~300
+        // instructions per launch: 5 000 cycles)
+        {
+            const float4* src = reinterpret_cast<const float4*>(ka.thimg);
+            float4* dst = reinterpret_cast<float4*>(th);
+            for (int q = t; q < a.DP >> 2; q += IT) dst[q] = src[q];
+        }
+        for (int q = 0; q < nl0 + nl1; ++q) {                  // the constant-1 column of every layer's input activations
+            const MpLayer& L = lt[q < nl0 ? q : MP_MAXL + (q - nl0)];
+            const bool first = q == 0 || q == nl0;
+            for (int p = t; p < pts; p += IT) lds[(first ? a.o_a0 : L.a_in) + p * L.S + L.in] = 1.0f;
+        }
+    }
+    MP_STAMP();
+    if (t < 7 && (t < f || t >= 4)) hp[t] = hp_val;
+    if (t < tb) lds[a.o_gl + t] = -1.0f;               // loss = -sum_t mll_t (GPR_meta_mll.py:109-113)
+    if (mover) {
+        if (mv_r < n * d) {
+            const int i = mv_r / d, c = mv_r - i * d;
+            lds[a.o_a0 + (mv_s * n + i) * a.S0 + c] = mv_val; lds[a.o_xs + (mv_s * n + i) * d + c] = mv_val;
+        } else lds[a.o_y + mv_s * n + (mv_r - n * d)] = mv_val;
+    }
+    if (t < tb && ka.bnv) reinterpret_cast<int*>(lds + a.o_nv)[t] = nv_val;
+    if (blockIdx.x == 0 && t == 0 && ka.adv_counter) *ka.adv_counter += 1;
+    MP_STAMP();
+    __syncthreads();
+
+    const int a0_off = a.o_a0;
+    auto run_phase = [&](int ph) {
+        const int nt = ph == 2 ? nweight : nchain, first = ph == 2 ? nchain : 0;
+        for (int q = wave; q < nt; q += NW) {
+            const int4* e = reinterpret_cast<const int4*>(tasks + first + q);
+            const int4 d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3];
+            const int kind = ph == 1 ? MP_DELTA : sgi(d0.x);          // (phase 1 = the chains of phase 0, backwards)
+            const bool w32 = sgi(d3.x) & 4;
+            if (kind != MP_WGRAD && kind != MP_BIAS && 16 * sgi(d0.w) >= pts) continue;      // (a point tile this workgroup's tasks do not reach)
+            if (kind == MP_FWD) { if (w32) mp_fwd_chain32(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, a0_off, r16, g4); else mp_fwd_chain(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, a0_off, r16, g4); }
+            else if (kind == MP_DELTA) { if (w32) mp_delta_chain32(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, r16, g4); else mp_delta_chain(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, r16, g4); }
+            else if (kind == MP_WGRAD) {
+                // the tile's 16 x 16 block of the weight-and-bias gradient into this workgroup's slab, in theta's own layout: weight
+                // [j][i] row-major, then the bias column where the tile covers it (lane (r, g): row r, columns 4 g .. 4 g + 3)
+                const f32x4 acc = mp_wgrad_acc(d0, d1, d2, d3, lds, a0_off, pts, r16, g4);
+                const int k = sgi(d3.z);
+                float* sl = ka.slab[k] + (long)blockIdx.x * ka.dnet[k];
+                if (r16 < d2.x) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int c = 4 * g4 + s;
+                        if (c < d3.w) sl[d1.z + r16 * d1.w + c] = acc[s];
+                        else if (c == d3.w) sl[d3.y + r16] = acc[s];
+                    }
+                }
+            } else if (kind == MP_BIAS) {
+                const float sum = mp_bias_sum(d0, d1, d2, lds, pts, lane);
+                const int k = sgi(d3.z);
+                if (lane < 32 && lane < d2.x) ka.slab[k][(long)blockIdx.x * ka.dnet[k] + d1.z + lane] = sum;
+            }
+        }
+    };
+
+    MP_STAMP();
+    if (a.nets > 0) { run_phase(0); __syncthreads(); }
+    MP_STAMP();
+
+    // ---- GP: one wave per task of the workgroup; its per-task outputs go straight to the arrays the hyper-parameter reduction reads --
+    if (wave < tb) {
+        GpMfmaArgs g;
+        const int mean_mode = sg(a.mean_mode), kernel_nn = sg(a.kernel_nn), has_os = ka.hyp_os != nullptr;
+        // the body indexes everything by b = the wave (the workgroup's LDS arrays); the global per-task arrays are handed over
+        // already offset to this workgroup's first task
+        g.z = sp(kernel_nn ? lds + a.o_zk : lds + a.o_xs); g.z_div = 1;
+        g.mean = sp(mean_mode == PACOH_MEAN_VECTOR ? lds + a.o_mn : (mean_mode == PACOH_MEAN_CONST ? hp + 6 : nullptr));
+        g.mean_mode = mean_mode;
+        g.y = sp(lds + a.o_y); g.y_div = 1;
+        g.ls = sp(hp); g.os = sp(has_os ? hp + 4 : nullptr); g.noise = sp(hp + 5);
+        g.n_valid = sp(ka.bnv ? reinterpret_cast<int*>(lds + a.o_nv) : nullptr);
+        g.g_lml = sp(lds + a.o_gl);
+        g.lml = ka.lml_g + task0; g.info = ka.info_g + task0;
+        g.d_z = sp(kernel_nn ? lds + a.o_dzk : nullptr);
+        g.d_mean = mean_mode == PACOH_MEAN_VECTOR ? sp(lds + a.o_dmn) : (mean_mode == PACOH_MEAN_CONST ? ka.dc_g + task0 : nullptr);
+        g.d_ls = ka.dls_g + (long)task0 * f; g.d_os = has_os ? ka.dos_g + task0 : nullptr; g.d_noise = ka.dnz_g + task0;
+        g.B = ka.tb_total; g.P = 1; g.n = sg(n); g.f = sg(f);
+        constexpr int NP = 16 * NB;
+        float* ws = lds + sg(a.o_gp) + wave * sg(a.gpw);
+        gpreg::gp_reg_body<NB, FP, true, true>(g, gpreg::WaveCtx{(unsigned)wave}, ws, ws + NP * FP, ws + NP * FP + NP,
+                                               ws + NP * FP + 2 * NP, ws + NP * FP + 2 * NP + 128, ws + NP * FP + 2 * NP + 448,
+                                               ws + 2 * NP * FP + 2 * NP + 448);
+    }
+    MP_STAMP();
+    if (a.nets > 0) {
+        __syncthreads();
+        MP_STAMP();
+        run_phase(1);
+        __syncthreads();
+        MP_STAMP();
+        run_phase(2);
+    }
+    MP_STAMP();
+#ifdef PACOH_MP_STAMPS
+    if (t == 0 && blockIdx.x == 7 && ka.adv_counter && *ka.adv_counter == 3)
+        for (int q = 1; q < mp_st_n[0]; ++q) printf("mt stamp %d: +%lld cycles\n", q, mp_st[0][q] - mp_st[0][q - 1]);
+#endif
+}
+
+}  // namespace
+
+// The launch pair of one iteration's likelihood + gradient + update: the task kernel, then the slab reduction with the step's tail
+// (hyper-parameter reduction, AdamW, next batch).  -> PACOH_ELIMIT when the shape is outside the plan.
+int map_task_launch(const void* theta, const void* bx, const void* by, const int32_t* bnv, int n, int d, int tb_total,
+                    int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
+                    int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
+                    const void* hyp_ls, const void* hyp_os, const void* hyp_noise, void* workspace, size_t workspace_bytes,
+                    void* d_theta, long d_theta_stride, const HyperBwdArgs<float>* tail_in, int plan_only, size_t* need_bytes, int D, hipStream_t stream) {
+    MtArgs ka;
+    memset(&ka, 0, sizeof(ka));
+    MpArgs& a = ka.p;
+    int NB, FP;
+    // tasks per workgroup: as many whole tasks as fit ONE 16-point tile (a chain per network and tile), at least one
+    int tpw = n > 0 ? 16 / n : 1;
+    if (tpw < 1) tpw = 1;
+    if (tpw > MT_NT / 64) tpw = MT_NT / 64;
+    if (tpw > tb_total) tpw = tb_total;
+    const int rc = map_persist_plan(a, n, d, tpw, 1, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel, kernel_hidden,
+                                    n_kernel_hidden, f, &NB, &FP);
+    if (rc != PACOH_OK) return rc;
+    if (a.nets < 1 || tpw * n * (d + 1) > MT_NT) return PACOH_ELIMIT;
+    const int wgs = (tb_total + tpw - 1) / tpw;
+    // workspace: slabs [wgs][dnet] per network, then lml / d_ls (f) / d_os / d_noise / d_const [tb_total] and info
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    size_t o_slab[2] = {0, 0};
+    for (int k = 0; k < a.nets; ++k) {
+        const MpLayer& L0 = a.L[k][0]; const MpLayer& Ll = a.L[k][a.nl[k] - 1];
+        ka.flat0[k] = L0.b_flat;
+        ka.dnet[k] = Ll.w_flat + Ll.out * Ll.in - L0.b_flat;
+        o_slab[k] = carve((size_t)wgs * ka.dnet[k] * sizeof(float));
+    }
+    if (mt_plan(ka) != PACOH_OK) return PACOH_ELIMIT;        // (needs flat0[]: the slab-relative entries)
+    const int Dmax = D;                                 // (the index map covers the whole parameter row)
+    for (int k = 0; k < a.nets; ++k) if (plan_only != 1 && ka.flat0[k] + ka.dnet[k] > D) return PACOH_EINVAL;
+    const size_t o_img = carve((size_t)a.DP * 4), o_map = carve((size_t)Dmax * 4);
+    const size_t o_lml = carve((size_t)tb_total * 4), o_dls = carve((size_t)tb_total * f * 4), o_dos = carve((size_t)tb_total * 4),
+                 o_dnz = carve((size_t)tb_total * 4), o_dc = carve((size_t)tb_total * 4), o_info = carve((size_t)tb_total * 4);
+    if (need_bytes) *need_bytes = off;
+    if (plan_only == 1) return PACOH_OK;
+    if (!workspace || workspace_bytes < off) return PACOH_EINVAL;
+    char* ws = (char*)workspace;
+    a.theta = (float*)const_cast<void*>(theta);
+    a.off_const = mean_mode == PACOH_MEAN_CONST ? off_mean : -1;
+    ka.bx = (const float*)bx; ka.by = (const float*)by; ka.bnv = bnv;
+    ka.hyp_ls = (const float*)hyp_ls; ka.hyp_os = (const float*)hyp_os; ka.hyp_noise = (const float*)hyp_noise;
+    for (int k = 0; k < a.nets; ++k) ka.slab[k] = (float*)(ws + o_slab[k]);
+    ka.lml_g = (float*)(ws + o_lml); ka.dls_g = (float*)(ws + o_dls); ka.dos_g = (float*)(ws + o_dos); ka.dnz_g = (float*)(ws + o_dnz);
+    ka.dc_g = (float*)(ws + o_dc); ka.info_g = (int32_t*)(ws + o_info);
+    ka.tb_total = tb_total;
+    ka.thimg = (const float*)(ws + o_img);
+    if (plan_only == 2) {                               // the image and its index map (pacoh_map_task_setup)
+        hipLaunchKernelGGL(map_task_setup_kernel, dim3(1), dim3(MT_NT), 0, stream, ka, (float*)(ws + o_img), (int*)(ws + o_map), Dmax);
+        return launch_status();
+    }
+    HyperBwdArgs<float> tail = *tail_in;
+    tail.d_ls = ka.dls_g; tail.d_os = hyp_os ? ka.dos_g : nullptr; tail.d_noise = ka.dnz_g; tail.d_const = mean_mode == PACOH_MEAN_CONST ? ka.dc_g : nullptr;
+    tail.lml = tail.lik ? ka.lml_g : nullptr; tail.info = tail.fail_flag ? ka.info_g : nullptr;
+    ka.adv_counter = const_cast<long*>(tail.nx.counter);
+    const size_t bytes = (size_t)a.total * sizeof(float);
+#define PACOH_MT_LAUNCH(nb, fp) do { \
+        static bool attr_done = false; \
+        if (!attr_done) { \
+            if (hipFuncSetAttribute((const void*)map_task_kernel<nb, fp>, hipFuncAttributeMaxDynamicSharedMemorySize, MP_LDS_BYTES) != hipSuccess) { \
+                (void)hipGetLastError(); return PACOH_ELIMIT; } \
+            attr_done = true; \
+        } \
+        hipLaunchKernelGGL((map_task_kernel<nb, fp>), dim3((unsigned)wgs), dim3(MT_NT), bytes, stream, ka); } while (0)
+    if (NB == 1 && FP == 2) PACOH_MT_LAUNCH(1, 2);
+    else if (NB == 1) PACOH_MT_LAUNCH(1, 4);
+    else if (FP == 2) PACOH_MT_LAUNCH(2, 2);
+    else PACOH_MT_LAUNCH(2, 4);
+#undef PACOH_MT_LAUNCH
+    if (launch_status() != PACOH_OK) return PACOH_ELAUNCH;
+    return fused_reduce_launch(ka.slab[0], ka.dnet[0], ka.flat0[0], a.nets > 1 ? ka.slab[1] : nullptr, a.nets > 1 ? ka.dnet[1] : 0,
+                               a.nets > 1 ? ka.flat0[1] : 0, a.nets, (float*)d_theta, d_theta_stride, wgs, &tail, (float*)(ws + o_img),
+                               (const int*)(ws + o_map), stream);
+}
+
+}  // namespace pacoh

@@ -448,6 +448,56 @@ extern "C" int pacoh_mlp_bwd_hyper(const void* x, int x_div, const void* theta, 
     return adam_inline_fallback(opt, grad_rows, lik, dtype, stream);
 }
 
+// ---- the task-fused PACOH-MAP iteration (map_task.hip): forward + GP + backward of every task in one launch, slab reduction + tail --
+namespace pacoh {
+int map_task_launch(const void* theta, const void* bx, const void* by, const int32_t* bnv, int n, int d, int tb_total,
+                    int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
+                    int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
+                    const void* hyp_ls, const void* hyp_os, const void* hyp_noise, void* workspace, size_t workspace_bytes,
+                    void* d_theta, long d_theta_stride, const HyperBwdArgs<float>* tail_in, int plan_only, size_t* need_bytes, int D, hipStream_t stream);
+}
+extern "C" size_t pacoh_map_task_workspace_bytes(int D, int n, int d, int tb, int mean_mode, const int32_t* mean_hidden, int n_mean_hidden, int kernel_nn,
+                                                 const int32_t* kernel_hidden, int n_kernel_hidden, int f, int dtype) {
+    if (dtype != PACOH_F32 || tb <= 0 || D <= 0) return 0;
+    size_t need = 0;
+    HyperBwdArgs<float> none = {};
+    const int rc = map_task_launch(nullptr, nullptr, nullptr, nullptr, n, d, tb, mean_mode, 0, mean_hidden, n_mean_hidden, kernel_nn, 0, kernel_hidden,
+                                   n_kernel_hidden, f, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, &none, 1, &need, D, nullptr);
+    return rc == PACOH_OK ? need : 0;
+}
+extern "C" int pacoh_map_task_setup(const void* theta, int D, int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
+                                    int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
+                                    void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (dtype != PACOH_F32) return PACOH_ELIMIT;
+    if (!theta || !workspace || tb <= 0 || D <= 0) return PACOH_EINVAL;
+    HyperBwdArgs<float> none = {};
+    return map_task_launch(theta, nullptr, nullptr, nullptr, n, d, tb, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel,
+                           kernel_hidden, n_kernel_hidden, features_of(f), nullptr, nullptr, nullptr, workspace, workspace_bytes, nullptr, 0, &none, 2,
+                           nullptr, D, (hipStream_t)stream);
+}
+extern "C" int pacoh_map_task_step(const void* theta, long theta_stride, const void* batch_x, const void* batch_y, const int32_t* batch_n_valid,
+                                   int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
+                                   int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
+                                   const void* ls, const void* os, const void* noise, int off_ls, int off_os, int off_noise,
+                                   void* d_theta, long d_theta_stride, void* lik, double lik_scale, int32_t* fail_flag,
+                                   void* workspace, size_t workspace_bytes, const pacoh_adam_inline* opt, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (dtype != PACOH_F32) return PACOH_ELIMIT;
+    if (!theta || !batch_x || !batch_y || !ls || !noise || !d_theta || !workspace || tb <= 0 || off_ls < 0 || off_noise < 0 || (os == nullptr) != (off_os < 0))
+        return PACOH_EINVAL;
+    if (opt && (!adam_inline_ok(opt, 1, lik) || opt->n_seg < 1)) return PACOH_EINVAL;
+    if (opt && opt->next && !step_next_ok(opt->next)) return PACOH_EINVAL;
+    HyperBwdArgs<float> tail = {(const float*)theta, theta_stride, 1, tb, off_ls, features_of(f), off_os, off_noise,
+                                mean_mode == PACOH_MEAN_CONST ? off_mean : -1, nullptr, nullptr, nullptr, nullptr, (float*)d_theta, d_theta_stride,
+                                nullptr, (float*)lik, (float)lik_scale, nullptr, fail_flag, 0, nullptr, 0, nullptr,
+                                opt ? adam_inline_f32(opt) : AdamInline<float>{},
+                                (opt && opt->next) ? step_next_f32(opt->next, off_ls, f, off_os, off_noise) : StepNextArgs<float>{}};
+    return map_task_launch(theta, batch_x, batch_y, batch_n_valid, n, d, tb, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel,
+                           kernel_hidden, n_kernel_hidden, features_of(f), ls, os, noise, workspace, workspace_bytes, d_theta, d_theta_stride, &tail, 0,
+                           nullptr, (int)theta_stride, (hipStream_t)stream);
+}
+
 // 1 if these network shapes run on the fused fp32 kernels (mlp_fused.hip) -- where the gradient epilogue can carry the optimizer
 // step's pipelined feed (pacoh_adam_inline.next) --, else 0
 extern "C" int pacoh_mlp_fused_path(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype) {

@@ -524,8 +524,12 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
 // slabs, fixed order -> deterministic
 struct SlabReduce { const float* in; float* out; int Wd; int col0; };    // col0: the network block's first column in the parameter row
 // (blockIdx.y == nets, tail_blocks > 0: the step's hyper-parameter reduction rides in this launch -- hyper_tail.h)
+// LSH: log2 of the lanes that share an output element -- 3 (8 lanes) behind the fused backward kernel (a few dozen slabs); 5 behind the
+// task-fused PACOH-MAP kernel, whose 256 slabs (one per task) cost 8 lanes 32 dependent-latency loads each: 12 us for a 5 us kernel
+template <int LSH>
 __global__ void __launch_bounds__(256) fused_reduce_slab_kernel(SlabReduce s0, SlabReduce s1, long out_stride, int accumulate, int C, int P,
-                                                                int nets, HyperBwdArgs<float> tail, int tail_blocks) {
+                                                                int nets, HyperBwdArgs<float> tail, int tail_blocks, float* img_th, const int* img_map) {
+    constexpr int LANES = 1 << LSH;
     if ((int)blockIdx.y == nets) {
         __shared__ float red[4];
         if ((int)blockIdx.x < tail_blocks) hyper_tail_block<float>(tail, blockIdx.x, red);
@@ -533,17 +537,22 @@ __global__ void __launch_bounds__(256) fused_reduce_slab_kernel(SlabReduce s0, S
     }
     const SlabReduce& sr = blockIdx.y ? s1 : s0;
     const long tot = (long)P * sr.Wd;
-    const long idx = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
-    const int part = threadIdx.x & 7;
+    const long idx = ((long)blockIdx.x * 256 + threadIdx.x) >> LSH;
+    const int part = threadIdx.x & (LANES - 1);
     float s = 0;
-    if (idx < tot) for (int c = part; c < C; c += 8) s += sr.in[(long)c * tot + idx];
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (idx < tot) for (int c = part; c < C; c += LANES) s += sr.in[(long)c * tot + idx];
+#pragma unroll
+    for (int m = 1; m < LANES; m <<= 1) s += __shfl_xor(s, m, 64);
     if (idx < tot && part == 0) {
         const int p = (int)(idx / sr.Wd), w = (int)(idx - (long)p * sr.Wd);
         float* o = sr.out + (long)p * out_stride + w;
         const float gv = accumulate ? *o + s : s;
         *o = gv;
-        if (P == 1) adam_inline<float>(tail.opt, sr.col0 + w, gv);         // PACOH-MAP: the AdamW step on this entry (hyper_tail.h)
+        if (P == 1) {                                                      // PACOH-MAP: the AdamW step on this entry (hyper_tail.h)
+            const float now = adam_inline<float>(tail.opt, sr.col0 + w, gv);
+            // (behind the task-fused kernel, map_task.hip: the entry's copy in the parameter image that kernel's prologue reads)
+            if (img_th && tail.opt.param) { const int li = img_map[sr.col0 + w]; if (li >= 0) img_th[li] = now; }
+        }
     }
 }
 
@@ -739,9 +748,23 @@ int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride
     unsigned gx = (unsigned)((tot * 8 + 255) / 256);
     const int tail_blocks = tail ? hyper_tail_blocks(rtail) : 0;
     if ((unsigned)tail_blocks > gx) gx = (unsigned)tail_blocks;
-    hipLaunchKernelGGL(fused_reduce_slab_kernel, dim3(gx, nets + (tail ? 1 : 0)), dim3(256), 0, s,
+    hipLaunchKernelGGL(fused_reduce_slab_kernel<3>, dim3(gx, nets + (tail ? 1 : 0)), dim3(256), 0, s,
                        sr[0], sr[1], d_theta_stride, accumulate, pl.chunks * (bwd_wg_slab(n_hidden) ? 1 : 4), P, nets,
-                       rtail, tail_blocks);
+                       rtail, tail_blocks, (float*)nullptr, (const int*)nullptr);
+    return launch_status();
+}
+
+// The slab reduction as a launch of its own: the task-fused PACOH-MAP kernel (map_task.hip) writes one slab per workgroup and
+// network in theta's layout; this sums them into d_theta and runs the step's tail (hyper-parameter reduction, AdamW, next batch).
+int fused_reduce_launch(const float* slab0, int wd0, long off0, const float* slab1, int wd1, long off1, int nets, float* d_theta,
+                        long d_theta_stride, int slabs, const HyperBwdArgs<float>* tail, float* img_th, const int* img_map, hipStream_t s) {
+    SlabReduce sr[2] = {{slab0, d_theta + off0, wd0, (int)off0}, {slab1, d_theta + off1, wd1, (int)off1}};
+    const int wmax = wd0 > wd1 ? wd0 : wd1;
+    unsigned gx = (unsigned)(((long)wmax * 32 + 255) / 256);
+    const int tail_blocks = tail ? hyper_tail_blocks(*tail) : 0;
+    if ((unsigned)tail_blocks > gx) gx = (unsigned)tail_blocks;
+    hipLaunchKernelGGL(fused_reduce_slab_kernel<5>, dim3(gx, nets + (tail ? 1 : 0)), dim3(256), 0, s, sr[0], sr[1], d_theta_stride, 0, slabs, 1, nets,
+                       tail ? *tail : HyperBwdArgs<float>{}, tail_blocks, img_th, img_map);
     return launch_status();
 }
 

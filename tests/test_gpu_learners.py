@@ -691,7 +691,8 @@ def test_step_graph_with_the_captured_rccl_all_reduce(M, kind, monkeypatch):
     """the multi-rank step as ONE hipGraph: PACOH_COMM=rccl puts the step's exchange -- pacoh_allreduce_sum on the compute stream, a
     world-size-1 RCCL communicator on this one-GPU box -- INSIDE the captured step (and the four-steps-per-replay graph); the
     communicator's own capture self-test must pass, and the replayed run must equal the run without any collective bit for bit"""
-    monkeypatch.setenv('PACOH_MAP_PERSIST', '0')      # (the launch sequence is the subject here; test_gpu_map_persist.py covers the other path)
+    monkeypatch.setenv('PACOH_MAP_PERSIST', '0')      # (the launch sequence is the subject here; test_gpu_map_persist.py covers the other paths)
+    monkeypatch.setenv('PACOH_MAP_TASK_FUSED', '0')
     from meta_learning_pacoh_amd import parallel
     rs = np.random.RandomState(7)
     tasks = [(x, np.sin(x[:, :1]) + 0.3 * x[:, 1:] + 0.05 * rs.randn(12, 1)) for x in (rs.uniform(-3, 3, size=(12, 2)) for _ in range(6))]
@@ -721,7 +722,8 @@ def test_step_graph_with_the_captured_rccl_all_reduce(M, kind, monkeypatch):
 def test_graph_replay_is_bit_identical_to_eager_launches(M, kind, layers, monkeypatch):
     """meta_fit replays captured step graphs; PACOH_NO_GRAPH=1 issues the same launches one by one: identical bits, also for the
     launchers' 4 x 32 / 4 x 128 networks, ragged tasks (per-step pre-factor from the device scalars) and a decaying learning rate"""
-    monkeypatch.setenv('PACOH_MAP_PERSIST', '0')      # (the launch sequence is the subject here; test_gpu_map_persist.py covers the other path)
+    monkeypatch.setenv('PACOH_MAP_PERSIST', '0')      # (the launch sequence is the subject here; test_gpu_map_persist.py covers the other paths)
+    monkeypatch.setenv('PACOH_MAP_TASK_FUSED', '0')
     if kind != 'map' and layers[0] == 128:
         pytest.skip('4 x 128 is the PACOH-MAP launcher configuration')
     rs = np.random.RandomState(7)
@@ -815,7 +817,8 @@ def test_map_adam_folded_into_the_gradient_epilogue(M, cfg, graph, monkeypatch):
     """pacoh_adam_inline: the AdamW step applied by the threads that finish a gradient entry (slab reduction, hyper-parameter
     reduction) -- the same bits as the separate pacoh_adam_step_dev launch (PACOH_MAP_ADAM_INLINE=0): parameters, optimizer state,
     logged loss; weight decay on every group, decaying learning rate, ragged tasks, eager and replayed"""
-    monkeypatch.setenv('PACOH_MAP_PERSIST', '0')      # (the launch sequence is the subject here; test_gpu_map_persist.py covers the other path)
+    monkeypatch.setenv('PACOH_MAP_PERSIST', '0')      # (the launch sequence is the subject here; test_gpu_map_persist.py covers the other paths)
+    monkeypatch.setenv('PACOH_MAP_TASK_FUSED', '0')
     rs = np.random.RandomState(13)
     tasks = []
     for t in range(7):
@@ -852,7 +855,8 @@ def test_map_iteration_in_four_launches_equals_the_step_begin_sequence(M, cfg, g
     """pacoh_step_next: the gradient epilogue of a PACOH-MAP iteration (with the AdamW step in it) also fetches the next iteration's
     scalars and task batch and publishes the updated hyper-parameters' transforms; the backward launch advances the feed -- the same
     bits as with the step_begin launch (PACOH_MAP_PIPELINE=0), eager and replayed, ragged tasks, chunks of 1 + 3 + 4 + ... steps"""
-    monkeypatch.setenv('PACOH_MAP_PERSIST', '0')      # (the launch sequence is the subject here; test_gpu_map_persist.py covers the other path)
+    monkeypatch.setenv('PACOH_MAP_PERSIST', '0')      # (the launch sequence is the subject here; test_gpu_map_persist.py covers the other paths)
+    monkeypatch.setenv('PACOH_MAP_TASK_FUSED', '0')
     rs = np.random.RandomState(17)
     tasks = []
     for t in range(7):
@@ -880,7 +884,8 @@ def test_map_iteration_in_four_launches_equals_the_step_begin_sequence(M, cfg, g
 def test_pipelined_steps_on_random_shapes(M, seed, monkeypatch):
     """the pipelined SVGD / PACOH-MAP steps against their launch sequences on random shapes: 1-70 particles (64 / 65: register sort
     vs bisection median), 1-6 tasks per step, 3-20 points, one or two input dimensions, ragged or not, 1-3 hidden layers"""
-    monkeypatch.setenv('PACOH_MAP_PERSIST', '0')      # (the launch sequence is the subject here; test_gpu_map_persist.py covers the other path)
+    monkeypatch.setenv('PACOH_MAP_PERSIST', '0')      # (the launch sequence is the subject here; test_gpu_map_persist.py covers the other paths)
+    monkeypatch.setenv('PACOH_MAP_TASK_FUSED', '0')
     rs = np.random.RandomState(100 + seed)
     d = int(rs.randint(1, 3))
     ragged = bool(rs.randint(0, 2))

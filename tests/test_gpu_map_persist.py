@@ -38,6 +38,7 @@ def make_tasks(seed, T, ragged, d=2):
 
 def fit_both(M, monkeypatch, tasks, n_iter, log_period, **kw):
     out = []
+    monkeypatch.setenv('PACOH_MAP_TASK_FUSED', '0')             # (the reference run: the four-launch iteration)
     for persist in ('0', '1'):
         monkeypatch.setenv('PACOH_MAP_PERSIST', persist)
         m = M.GPRegressionMetaLearned(tasks, **kw)
@@ -171,3 +172,64 @@ def test_a_failed_cholesky_raises_like_the_launch_sequence(M, monkeypatch):
         with pytest.raises(NotPSDError):
             m.meta_fit(verbose=False, n_iter=2)
         assert (m._persist is not None) == (persist == '1')
+
+
+# ---- the task-fused iteration (pacoh_map_task_step: forward + GP + backward of every task in one launch, then the slab reduction) ----
+TASK_CFGS = [
+    dict(covar_module='SE', mean_module='NN'),                                      # BASELINE config #2's modules
+    dict(),                                                                         # two networks
+    dict(mean_nn_layers=(16, 16), kernel_nn_layers=(16, 16)),                       # generic chains
+    dict(covar_module='NN', mean_module='constant'),                                # constant mean: d_const through the GP's per-task output
+    dict(learning_mode='learn_mean', covar_module='SE'),
+    dict(mean_nn_layers=(32, 32, 32), kernel_nn_layers=(32, 32, 32)),
+]
+
+
+@pytest.mark.parametrize('cfg', TASK_CFGS)
+@pytest.mark.parametrize('shape', [(24, 32, 1, 24), (40, 12, 2, 21), (9, 5, 1, 40), (6, 17, 3, 5)])
+@pytest.mark.parametrize('graph', ['0', '1'])
+def test_task_fused_iteration_equals_the_four_launch_iteration(M, cfg, shape, graph, monkeypatch):
+    """T tasks of n points, a batch of tb per iteration (more than one workgroup's worth: the persistent kernel does not take it):
+    one workgroup per task (several tasks per workgroup at n = 5), ragged batches, 14 iterations eagerly and as replayed graphs"""
+    T, n, d, tb = shape
+    rs = np.random.RandomState(7 * T + n)
+    tasks = []
+    for t in range(T):
+        m = n - (t % 3) if n > 4 else n
+        x = rs.uniform(-3, 3, size=(m, d))
+        tasks.append((x, np.sin(x[:, :1]) + 0.3 * x[:, -1:] + 0.05 * rs.randn(m, 1)))
+    kw = dict(task_batch_size=tb, lr_params=1e-2, weight_decay=0.05, lr_decay=0.9, random_seed=3)
+    kw.update(cfg)
+    monkeypatch.setenv('PACOH_MAP_PERSIST', '0')
+    monkeypatch.setenv('PACOH_GRAPH', graph)
+    out = []
+    for fused in ('0', '1'):
+        monkeypatch.setenv('PACOH_MAP_TASK_FUSED', fused)
+        m = M.GPRegressionMetaLearned(tasks, **kw)
+        loss = m.meta_fit(verbose=False, n_iter=14, log_period=4)
+        assert m._pipelined and (m._task_ws is not None) == (fused == '1') and m.opt_step == 14
+        out.append((m, float(loss)))
+    (m0, l0), (m1, l1) = out
+    keep = keep_mask(m1)
+    assert bool(torch.isfinite(m1.theta).all())
+    assert rel(m1.theta[keep], m0.theta[keep]) < 2e-5 and rel(m1.exp_avg[keep], m0.exp_avg[keep]) < 2e-5
+    assert rel(m1.exp_avg_sq[keep], m0.exp_avg_sq[keep]) < 2e-5
+    assert abs(l1 - l0) < 1e-5 * max(1.0, abs(l0)) and abs(float(m1._g_cum) - float(m0._g_cum)) < 1e-4 * max(1.0, abs(float(m0._g_cum)))
+
+
+def test_task_fused_step_failure_flag_and_limits(M, monkeypatch):
+    from meta_learning_pacoh_amd.engine import NotPSDError
+    from meta_learning_pacoh_amd import _lib as L
+    monkeypatch.setenv('PACOH_MAP_PERSIST', '0')
+    tasks = O.sinusoid_tasks_nd(30, 8, 1, seed0=50)
+    m = M.GPRegressionMetaLearned(tasks, task_batch_size=20, random_seed=1)
+    m.theta[0, m.layout.slices['noise_raw'][0]] = float('nan')
+    with pytest.raises(NotPSDError):
+        m.meta_fit(verbose=False, n_iter=2)
+    assert m._task_ws is not None
+    h = L._hidden_arr([32, 32])
+    lib = L.load_library()
+    assert lib.pacoh_map_task_workspace_bytes(2000, 32, 1, 256, L.MEAN_VECTOR, h, 2, 0, h, 0, 1, L.F32) > 0
+    assert lib.pacoh_map_task_workspace_bytes(2000, 33, 1, 256, L.MEAN_VECTOR, h, 2, 0, h, 0, 1, L.F32) == 0       # n > 32
+    assert lib.pacoh_map_task_workspace_bytes(2000, 32, 1, 256, L.MEAN_ZERO, h, 0, 0, h, 0, 1, L.F32) == 0         # no network: nothing to fuse
+    assert lib.pacoh_map_task_workspace_bytes(2000, 32, 1, 256, L.MEAN_VECTOR, h, 2, 0, h, 0, 1, L.F64) == 0

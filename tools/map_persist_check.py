@@ -37,6 +37,7 @@ def compare():
             kw = dict(task_batch_size=4, lr_params=1e-2, weight_decay=0.05, lr_decay=0.9, random_seed=3)
             kw.update(cfg)
             out = []
+            os.environ['PACOH_MAP_TASK_FUSED'] = '0'
             for persist in ('0', '1'):
                 os.environ['PACOH_MAP_PERSIST'] = persist
                 m = M.GPRegressionMetaLearned(tasks, **kw)
@@ -63,7 +64,7 @@ def timing():
     from meta_learning_pacoh_amd import _lib as L
     for cfg in (1, 2):
         for persist in ('0', '1'):
-            os.environ['PACOH_MAP_PERSIST'] = persist
+            os.environ['PACOH_MAP_PERSIST'] = os.environ['PACOH_MAP_TASK_FUSED'] = persist
             wl = bench.WORKLOADS[cfg](1, 'weak', M, L)
             for k in (64, 128, 64, 1024):
                 wl['run'](k)
@@ -72,8 +73,9 @@ def timing():
             wl['run'](4096)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / 4096 * 1e3
-            print('cfg #%d PACOH_MAP_PERSIST=%s: %.5f ms per iteration (finite %s)' % (cfg, persist, ms, wl['finite']()), flush=True)
+            print('cfg #%d PACOH_MAP_PERSIST=PACOH_MAP_TASK_FUSED=%s: %.5f ms per iteration (finite %s)' % (cfg, persist, ms, wl['finite']()), flush=True)
     os.environ.pop('PACOH_MAP_PERSIST')
+    os.environ.pop('PACOH_MAP_TASK_FUSED')
 
 
 if __name__ == '__main__':
