@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 FP32_PEAK_TFLOPS = 157.3       # fp32 vector peak == fp32-input MFMA peak (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6        # fp64 matrix peak: AMD's MI355X figure; tools/mfma_peak.hip measures what v_mfma_f64_16x16x4 sustains
 STEADY_STEPS = 200            # the extra region behind the timed one (the line's `steady` object)
-PMC_PROFILE = os.path.join('profiles', 'r04_pmc_hbm_traffic.json')
-DENSE_PMC_PROFILE = os.path.join('profiles', 'r04_dense_pmc_hbm_traffic.json')
+PMC_PROFILE = os.path.join('profiles', 'r05_pmc_hbm_traffic.json')
+DENSE_PMC_PROFILE = os.path.join('profiles', 'r05_dense_pmc_hbm_traffic.json')
 
 
 def make_tasks(n_tasks, n, d, seed0=1000):
@@ -652,8 +652,9 @@ def wl_cfg2(world, scaling, M, L):
     return dict(run=model._train_steps, evals_per_step=T, dtype='f32', finite=lambda: bool(torch.isfinite(model.theta).all()), mode=lambda: _mode(model),
                 metric='task-GP LML+grad evals/sec (PACOH-MAP, 256 tasks, n_ctx=32, d=1, SE kernel)',
                 flops={'gp_lml_fwdbwd': (gp_flops(32, 1) * ev,) * 2, 'mlp_fwd': (2 * 32 * w * ev,) * 2,
-                       'mlp_bwd': (4 * 32 * w * ev, 6 * 32 * w * ev)},
-                describe='PACOH-MAP iteration (hipGraph replay), cfg#2: %d tasks x n_ctx=32, d=1, SE kernel + NN(32,32) mean, AdamW' % T,
+                       'mlp_bwd': (4 * 32 * w * ev, 6 * 32 * w * ev),
+                       'map_task_step': ((gp_flops(32, 1) + 6 * 32 * w) * ev,) * 2},    # (forward + GP + backward in one launch + the slab reduction)
+                describe='PACOH-MAP iteration (hipGraph replay; two launches per iteration: pacoh_map_task_step), cfg#2: %d tasks x n_ctx=32, d=1, SE kernel + NN(32,32) mean, AdamW' % T,
                 extra={'tasks_total': T, 'n_ctx': 32, 'd': 1})
 
 

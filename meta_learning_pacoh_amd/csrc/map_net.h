@@ -130,7 +130,7 @@ __device__ __forceinline__ void mp_stamp_() {           // (diagnostic build: wa
 // the row (one ds_read_b128 each, four MFMA steps per read), and a remainder quad is one more step with element g per lane.
 // Rows / columns outside a matrix (tile padding) read whatever follows in LDS: they only reach output rows / columns that are not
 // stored -- except in the weight-gradient tile, where padding POINTS would enter every sum and are masked to zero.
-enum { MP_NONE = 0, MP_FWD = 1, MP_DELTA = 2, MP_WGRAD = 3, MP_BIAS = 4 };
+enum { MP_NONE = 0, MP_FWD = 1, MP_DELTA = 2, MP_WGRAD = 3 };
 struct MpTask {                      // 16 ints; offsets in floats from the start of dynamic LDS unless stated
     int kind, S;
     int w;                           // FWD / DELTA chain: the network; WGRAD: parameter-image offset (from th / m / v / flat) of entry (16 J, 16 I); BIAS: of column `in`
@@ -139,7 +139,7 @@ struct MpTask {                      // 16 ints; offsets in floats from the star
     int dst, s_dst;
     int lim_a, lim_b;                // WGRAD / BIAS: valid rows j, columns i of the tile
     int n1, n2;                      // FWD / DELTA chain: layers of the network; WGRAD: MFMA steps = ceil(pts / 4), valid d_out columns
-    int flags;                       // bit 1: aux (WGRAD) is relative to the current A0 buffer
+    int flags;                       // bit 1: aux (WGRAD) is relative to the current A0 buffer; bit 2: 32-wide chains; bit 3: the tile sums the bias too
     int kmax;
     int pad0, pad1;                  // pad0: mp_plan's sort key
 };
@@ -379,25 +379,41 @@ __device__ __forceinline__ void mp_adam_entry(float* __restrict__ th, float* __r
 // (r, g) then holds columns 4 g .. 4 g + 3 of row r -- four consecutive entries of the parameter image, so that parameters, both
 // moments and the trained-flags move as one 16-byte LDS access each and the update runs without a branch per entry (a tile's
 // AdamW was 28 dword accesses and four exec-mask branches per lane in the row-per-register orientation).
+// bias (out): flags bit 3 -- this tile also sums the layer's bias gradient of its 16 rows, sum_p d_out[p][j]: a second accumulator
+// with the constant 1 as the A operand and the SAME B operand, so every lane (r, .) ends up holding the sum of row j = r.  (A task of
+// its own per layer -- a wave reading the column again, one entry per lane -- made 20 tasks of 16 at demo.py's shape: a second round.)
 __device__ __forceinline__ f32x4 mp_wgrad_acc(const int4 d0, const int4 d1, const int4 d2, const int4 d3, const float* __restrict__ lds,
-                                              int a0_off, int pts, int r, int g) {
+                                              int a0_off, int pts, int r, int g, float& bias) {
     const int S = d0.y, steps = (pts + 3) >> 2, s_d = d1.x;      // (pts: the caller's actual point count, wave-uniform)
     const bool jok = r < d2.w;
+    const bool with_bias = sgi(d3.x) & 8;
     const float* dp = lds + d0.w + (jok ? r : 0) + g * s_d;                              // d_out[4 ks + g][16 J + r]
     const float* ap = lds + d1.y + ((d3.x & 2) ? a0_off : 0) + r + g * S;               // a[4 ks + g][16 I + r]
     const int dstep = 4 * s_d, astep = 4 * S;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     MP_STAMP();
     // every step but the last has four valid points; the last is clamped and masked (padding points would enter the sums)
+    if (with_bias) {
 #pragma unroll 4
-    for (int ks = 0; ks + 1 < steps; ++ks) { acc = mfma_(*ap, jok ? *dp : 0.0f, acc); ap += astep; dp += dstep; }
+        for (int ks = 0; ks + 1 < steps; ++ks) {
+            const float dv = jok ? *dp : 0.0f;
+            acc = mfma_(*ap, dv, acc); acc1 = mfma_(1.0f, dv, acc1);
+            ap += astep; dp += dstep;
+        }
+    } else {
+#pragma unroll 4
+        for (int ks = 0; ks + 1 < steps; ++ks) { acc = mfma_(*ap, jok ? *dp : 0.0f, acc); ap += astep; dp += dstep; }
+    }
     {
         const int back = 4 * (steps - 1) + g - (pts - 1);                                  // > 0: this lane's point does not exist
         const bool ok = back <= 0;
         const float av = ap[ok ? 0 : -back * S], dv = dp[ok ? 0 : -back * s_d];
-        acc = mfma_(ok ? av : 0.0f, ok && jok ? dv : 0.0f, acc);
+        const float dm = ok && jok ? dv : 0.0f;
+        acc = mfma_(ok ? av : 0.0f, dm, acc);
+        if (with_bias) acc1 = mfma_(1.0f, dm, acc1);
     }
     MP_STAMP();
+    bias = acc1[0];
     return acc;
 }
 
@@ -405,7 +421,9 @@ __device__ __forceinline__ void mp_wgrad_tile(const int4 d0, const int4 d1, cons
                                               float* __restrict__ mm, float* __restrict__ vv, const int* __restrict__ flat,
                                               const float* __restrict__ lds, int a0_off, int pts, int r, int g, const MpAdam& o) {
     const int S = d0.y;
-    const f32x4 acc = mp_wgrad_acc(d0, d1, d2, d3, lds, a0_off, pts, r, g);
+    float bias;
+    const f32x4 acc = mp_wgrad_acc(d0, d1, d2, d3, lds, a0_off, pts, r, g, bias);
+    if ((d3.x & 8) && g == 0 && r < d2.x) mp_adam_entry(th, mm, vv, flat, d3.y + r * S, bias, o);      // (kmax: the bias entry of row 0 of the tile)
     if (r < d2.x && 4 * g < d2.y) {
         const int li = d0.z + r * S + 4 * g;
         const int4 fq = *reinterpret_cast<const int4*>(flat + li);
@@ -423,30 +441,6 @@ __device__ __forceinline__ void mp_wgrad_tile(const int4 d0, const int4 d1, cons
         }
         *reinterpret_cast<f32x4*>(th + li) = pw; *reinterpret_cast<f32x4*>(mm + li) = pm; *reinterpret_cast<f32x4*>(vv + li) = pv;
     }
-}
-
-// bias entries of a layer whose bias column no weight tile covers (in a multiple of 16): lane j sums d_out[.][j]
-__device__ __forceinline__ float mp_bias_sum(const int4 d0, const int4 d1, const int4 d2, const float* __restrict__ lds, int pts, int lane) {
-    // lanes j and 32 + j take the even / odd points of column j, eight independent loads at a time
-    const int j = lane & 31, half = lane >> 5;
-    const bool jok = j < d2.x;
-    const float* dcol = lds + d0.w + (jok ? j : 0);
-    const int s_d = d1.x;
-    float sum = 0.0f;
-    for (int p0 = half; p0 < pts; p0 += 16) {
-        float part[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int p = p0 + 2 * u; part[u] = dcol[(p < pts ? p : 0) * s_d]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (p0 + 2 * u < pts) sum += part[u];
-    }
-    return sum + __shfl_xor(sum, 32, 64);
-}
-__device__ __forceinline__ void mp_bias_task(const int4 d0, const int4 d1, const int4 d2, float* __restrict__ th, float* __restrict__ mm,
-                                             float* __restrict__ vv, const int* __restrict__ flat, const float* __restrict__ lds, int pts,
-                                             int lane, const MpAdam& o) {
-    const float sum = mp_bias_sum(d0, d1, d2, lds, pts, lane);
-    if ((lane & 31) < d2.x && lane < 32) mp_adam_entry(th, mm, vv, flat, d0.z + (lane & 31) * d0.y, sum, o);
 }
 
 // The launch's task table, written by ONE thread.  Phase 0: forward chains (network, point tile); phase 1: delta chains; phase 2: the
@@ -477,15 +471,11 @@ __device__ void mp_plan(const MpArgs& a, const int* __restrict__ ltab, MpTask* _
                     tk.kind = MP_WGRAD; tk.S = L.S; tk.w = L.w_lds + 16 * J * L.S + 16 * I;
                     tk.src = L.d_out + 16 * J; tk.s_src = L.s_d; tk.aux = (l == 0 ? 0 : L.a_in) + 16 * I; tk.flags = l == 0 ? 2 : 0;
                     tk.lim_a = L.out - 16 * J; tk.lim_b = L.S - 16 * I; tk.n1 = (pts + 3) >> 2; tk.n2 = L.s_d - 16 * J;
+                    if (I == 0 && (L.in & 15) == 0) { tk.flags |= 8; tk.kmax = L.w_lds + 16 * J * L.S + L.in; }     // (no tile covers the bias column)
                     const int ja = tk.lim_a < 16 ? tk.lim_a : 16, ib = tk.lim_b < 16 ? tk.lim_b : 16;
                     tk.pad0 = ja * ib;                       // (sort key)
                     put(2, tk);
                 }
-            if ((L.in & 15) == 0) {
-                MpTask tk = {};
-                tk.kind = MP_BIAS; tk.S = L.S; tk.w = L.w_lds + L.in; tk.src = L.d_out; tk.s_src = L.s_d; tk.lim_a = L.out; tk.pad0 = 1;
-                put(2, tk);
-            }
         }
     MpTask* w = tasks + 2 * slots;
     for (int i = 0; i < ntask[2]; ++i) {

@@ -137,7 +137,6 @@ __global__ void __launch_bounds__(MP_NT) map_persist_kernel(MpArgs a) {
             if (kind == MP_FWD) { if (w32) mp_fwd_chain32(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, a0_off, r16, g4); else mp_fwd_chain(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, a0_off, r16, g4); }
             else if (kind == MP_DELTA) { if (w32) mp_delta_chain32(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, r16, g4); else mp_delta_chain(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, r16, g4); }
             else if (kind == MP_WGRAD) mp_wgrad_tile(d0, d1, d2, d3, th, mm, vv, flat, lds, a0_off, pts, r16, g4, ad);
-            else if (kind == MP_BIAS) mp_bias_task(d0, d1, d2, th, mm, vv, flat, lds, pts, lane, ad);
         }
     };
 
@@ -171,7 +170,9 @@ __global__ void __launch_bounds__(MP_NT) map_persist_kernel(MpArgs a) {
             MP_STAMP();
         }
 
-        // ---- GP: one wave per task of the batch ----------------------------------------------------------------------------
+        // ---- GP: one wave per task of the batch.  (Tried: several whole tasks per wave as ONE block-diagonal 16 x 16 problem -- three of
+        //      demo.py's 5-point tasks per wave, two GP waves instead of five.  The body is ~1 850 instructions per wave whatever its
+        //      neighbours do, the per-task sums and masks added 25 %: 10 700 cycles against 8 400 + 1 300 of barrier wait.  Dropped.) ----
         if (wave < tb) {
             GpMfmaArgs g;
             const int mean_mode = sg(a.mean_mode), kernel_nn = sg(a.kernel_nn), has_os = sg(a.off_os) >= 0;

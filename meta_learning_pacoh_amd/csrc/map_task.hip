@@ -36,7 +36,7 @@ static_assert(sizeof(MtArgs) <= 4096, "the kernel-argument segment holds 4 KB");
 
 // The task descriptors of a workgroup, planned ONCE on the host and handed over in the kernel arguments (planned inside the kernel
 // -- by one thread, then by 64 in parallel -- the plan cost 2-4 us of a 7 us kernel in every launch).  Chains (network, point tile)
-// first: they are phase 0 and, as delta chains, phase 1; then per layer its weight tiles and its bias task.  The slab fields of a
+// first: they are phase 0 and, as delta chains, phase 1; then per layer its weight tiles (flags bit 3: the tile also sums the bias).  The slab fields of a
 // weight tile: dst = its first entry relative to the network's block, s_dst = in (row stride in theta), kmax = the bias entries of its
 // rows, pad1 = the tile column that is the bias (none if >= 16), pad0 = the network.  A workgroup with fewer tasks than a full one
 // skips the chains of point tiles it does not have; the MFMA steps of a weight tile follow from its own point count.
@@ -67,15 +67,9 @@ int mt_plan(MtArgs& ka) {
                     tk.lim_a = L.out - 16 * J; tk.lim_b = L.S - 16 * I; tk.n2 = L.s_d - 16 * J;
                     tk.dst = (L.w_flat - ka.flat0[k]) + 16 * J * L.in + 16 * I; tk.s_dst = L.in;
                     tk.kmax = (L.b_flat - ka.flat0[k]) + 16 * J; tk.pad1 = L.in - 16 * I;
+                    if (I == 0 && (L.in & 15) == 0) tk.flags |= 8;      // (no tile covers the bias column: this one sums it alongside)
                     ka.plan[q++] = tk;
                 }
-            if ((L.in & 15) == 0) {
-                if (q >= MT_MAXTASKS) return PACOH_ELIMIT;
-                MpTask tk = {};
-                tk.kind = MP_BIAS; tk.S = L.S; tk.pad0 = k; tk.w = L.w_lds + L.in; tk.src = L.d_out; tk.s_src = L.s_d; tk.lim_a = L.out;
-                tk.dst = L.b_flat - ka.flat0[k];
-                ka.plan[q++] = tk;
-            }
         }
     ka.ntask[2] = q - ka.ntask[0];
     return PACOH_OK;
@@ -206,15 +200,17 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
             const int4 d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3];
             const int kind = ph == 1 ? MP_DELTA : sgi(d0.x);          // (phase 1 = the chains of phase 0, backwards)
             const bool w32 = sgi(d3.x) & 4;
-            if (kind != MP_WGRAD && kind != MP_BIAS && 16 * sgi(d0.w) >= pts) continue;      // (a point tile this workgroup's tasks do not reach)
+            if (kind != MP_WGRAD && 16 * sgi(d0.w) >= pts) continue;      // (a point tile this workgroup's tasks do not reach)
             if (kind == MP_FWD) { if (w32) mp_fwd_chain32(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, a0_off, r16, g4); else mp_fwd_chain(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, a0_off, r16, g4); }
             else if (kind == MP_DELTA) { if (w32) mp_delta_chain32(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, r16, g4); else mp_delta_chain(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, r16, g4); }
             else if (kind == MP_WGRAD) {
                 // the tile's 16 x 16 block of the weight-and-bias gradient into this workgroup's slab, in theta's own layout: weight
                 // [j][i] row-major, then the bias column where the tile covers it (lane (r, g): row r, columns 4 g .. 4 g + 3)
-                const f32x4 acc = mp_wgrad_acc(d0, d1, d2, d3, lds, a0_off, pts, r16, g4);
+                float bias;
+                const f32x4 acc = mp_wgrad_acc(d0, d1, d2, d3, lds, a0_off, pts, r16, g4, bias);
                 const int k = sgi(d3.z);
                 float* sl = ka.slab[k] + (long)blockIdx.x * ka.dnet[k];
+                if ((d3.x & 8) && g4 == 0 && r16 < d2.x) sl[d3.y + r16] = bias;
                 if (r16 < d2.x) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
@@ -223,10 +219,6 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
                         else if (c == d3.w) sl[d3.y + r16] = acc[s];
                     }
                 }
-            } else if (kind == MP_BIAS) {
-                const float sum = mp_bias_sum(d0, d1, d2, lds, pts, lane);
-                const int k = sgi(d3.z);
-                if (lane < 32 && lane < d2.x) ka.slab[k][(long)blockIdx.x * ka.dnet[k] + d1.z + lane] = sum;
             }
         }
     };

@@ -1,10 +1,11 @@
-// C-ABI entry points of the per-particle MLP.  Four implementations, picked per call by shape and dtype:
+// C-ABI entry points of the per-particle MLP.  Three implementations, picked per call by shape and dtype (round 5 removed the fourth, a
+// thread-per-point VALU kernel: on the 18 shapes of tests/test_gpu_kernels.py it was never the fastest where anything else applied but
+// a network without hidden layers, and the dispatcher's order cost fp64 networks 2-6x against `layers`: profiles/r05_mlp_paths.txt):
 //   fused   (mlp_fused.hip)  fp32, 1-4 hidden layers of width <= 32, d_in <= 4, d_out <= 2: register-resident MFMA kernels,
 //                            one launch for the mean AND the kernel-feature network (pacoh_mlp2_*)
 //   mfma    (mlp_mfma.hip)   fp32, 1-2 hidden layers of width <= 32, d_in <= 16, d_out <= 8: the same idea with padded io layers
-//   valu    (mlp_impl.h)     fp32/fp64, 0-3 hidden layers of width <= 64: thread per data point, weights in LDS
 //   layers  (mlp_layers.hip) everything else (any depth, any width, fp32/fp64): layer-by-layer MFMA GEMMs through a workspace
-// PACOH_MLP_PATH=fused|mfma|valu|layers restricts the choice to that path and the ones after it (tests, A/B timing).
+// PACOH_MLP_PATH=fused|mfma|layers restricts the choice to that path and the ones after it (tests, A/B timing).
 #include "common.h"
 #include "hyper_tail.h"
 #include "step_tail.h"
@@ -12,12 +13,6 @@
 #include <string.h>
 
 namespace pacoh {
-#define PACOH_MLP_DECL(sfx) \
-int mlp_fwd_##sfx(const void*, int, const void*, long, int, int, const int32_t*, int, int, void*, int, int, hipStream_t); \
-int mlp_bwd_##sfx(const void*, int, const void*, long, int, int, const int32_t*, int, int, const void*, void*, long, int, void*, int, int, hipStream_t);
-PACOH_MLP_DECL(f32)
-PACOH_MLP_DECL(f64)
-#undef PACOH_MLP_DECL
 // mlp_mfma.hip; return 1 if not applicable
 int mlp_mfma_fwd(const void*, int, const void*, long, int, int, const int32_t*, int, int, void*, int, int, hipStream_t);
 size_t mlp_mfma_bwd_workspace(int, int, int, int, const int32_t*, int, int);
@@ -53,21 +48,14 @@ __global__ void __launch_bounds__(256) reduce_tasks_kernel(const T* __restrict__
     if (lane == 0) out[idx] = accumulate ? out[idx] + scale * s : scale * s;
 }
 
-enum MlpPath { PATH_FUSED = 0, PATH_MFMA = 1, PATH_VALU = 2, PATH_LAYERS = 3 };
+enum MlpPath { PATH_FUSED = 0, PATH_MFMA = 1, PATH_LAYERS = 3 };
 
 static int first_allowed_path() {          // read on every call (a getenv): tests switch paths inside one process
     const char* e = getenv("PACOH_MLP_PATH");
     if (!e) return (int)PATH_FUSED;
     if (!strcmp(e, "mfma")) return (int)PATH_MFMA;
-    if (!strcmp(e, "valu")) return (int)PATH_VALU;
     if (!strcmp(e, "layers")) return (int)PATH_LAYERS;
     return (int)PATH_FUSED;
-}
-
-static bool valu_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_out) {
-    if (n_hidden > 3 || d_in > 16 || d_out > 8) return false;
-    for (int l = 0; l < n_hidden; ++l) if (hidden[l] > 64) return false;
-    return true;
 }
 
 static int args_ok(int d_in, const int32_t* hidden, int n_hidden, int d_out) {
@@ -85,22 +73,7 @@ static MlpPath pick_path(int dtype, int d_in, const int32_t* hidden, int n_hidde
     const bool f32 = dtype == PACOH_F32 && rows_total <= 0x3fffffffL;
     if (first <= PATH_FUSED && f32 && mlp_fused_applicable(d_in, hidden, n_hidden, d_out)) return PATH_FUSED;
     if (first <= PATH_MFMA && f32 && mlp_mfma_applicable(d_in, hidden, n_hidden, d_out)) return PATH_MFMA;
-    if (first <= PATH_VALU && valu_applicable(d_in, hidden, n_hidden, d_out)) return PATH_VALU;
     return PATH_LAYERS;
-}
-
-static size_t valu_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype) {
-    int prev = d_in, mx = 0;
-    long params = 0;
-    for (int l = 0; l < n_hidden; ++l) { params += (long)hidden[l] * (prev + 1); prev = hidden[l]; mx = hidden[l] > mx ? hidden[l] : mx; }
-    params += (long)d_out * (prev + 1);
-    const int tile = (mx <= 32 ? 256 : 128) / (dtype == PACOH_F64 ? 2 : 1);     // = bwd_tile<T>(HP) in mlp_impl.h
-    long rows = (long)(B / P) * n;
-    long tiles = (rows + tile - 1) / tile;
-    long want = (2048 + P - 1) / P;
-    long chunks = tiles < want ? tiles : want;
-    if (chunks < 1) chunks = 1;
-    return (size_t)chunks * P * params * (dtype == PACOH_F64 ? 8 : 4);
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -131,9 +104,6 @@ static int mlp_fwd_impl(const void* x, int x_div, const void* theta, long theta_
     }
     case PATH_MFMA:
         return mlp_mfma_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, s);
-    case PATH_VALU:
-        return dtype == PACOH_F32 ? mlp_fwd_f32(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, s)
-                                  : mlp_fwd_f64(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, s);
     default:
         return mlp_layers_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, workspace, B, n, dtype, s);
     }
@@ -164,7 +134,6 @@ extern "C" size_t pacoh_mlp_bwd_workspace_bytes(int B, int P, int n, int d_in, c
     switch (pick_path(dtype, d_in, hidden, n_hidden, d_out, (long)B * n)) {
     case PATH_FUSED: return mlp_fused_bwd_workspace(B, P, n, d_in, hidden, n_hidden, d_out, 1);
     case PATH_MFMA: return mlp_mfma_bwd_workspace(B, P, n, d_in, hidden, n_hidden, d_out);
-    case PATH_VALU: return valu_bwd_workspace(B, P, n, d_in, hidden, n_hidden, d_out, dtype);
     default: return mlp_layers_workspace(B, P, n, d_in, hidden, n_hidden, d_out, dtype, 1);
     }
 }
@@ -188,10 +157,6 @@ extern "C" int pacoh_mlp_bwd(const void* x, int x_div, const void* theta, long t
     case PATH_MFMA:
         return mlp_mfma_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride,
                             accumulate, workspace, B, n, s);
-    case PATH_VALU:
-        return dtype == PACOH_F32
-            ? mlp_bwd_f32(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, accumulate, workspace, B, n, s)
-            : mlp_bwd_f64(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, accumulate, workspace, B, n, s);
     default:
         return mlp_layers_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride,
                               accumulate, workspace, B, n, dtype, s);

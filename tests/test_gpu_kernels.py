@@ -313,7 +313,7 @@ MLP_CASES = [  # P, T, n, d_in, hidden, d_out
     (2, 2, 40, 20, (48,), 11),               # wide io
     (1, 3, 300, 2, (), 1),
 ]
-MLP_PATHS = [None, 'mfma', 'valu', 'layers']      # PACOH_MLP_PATH: first implementation the dispatcher may pick
+MLP_PATHS = [None, 'mfma', 'layers']      # PACOH_MLP_PATH: first implementation the dispatcher may pick (round 5: the VALU path is gone)
 
 
 @pytest.fixture
