@@ -336,6 +336,24 @@ def _gp_lml_dense(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale,
     n, f = z.shape[-2], z.shape[-1]
     dev, dt = z.device, z.dtype
     code = dtype_code(z)
+    # The left-looking factorisation / inverse kernels (csrc/dense_ll.hip, dense_trtri_ll.hip: 97 <= n <= 512) need matrix rows that are a
+    # multiple of 16 bytes; an odd context size would drop to the right-looking generation (1.3-1.5x slower at these sizes).  Such a
+    # batch is handed over as a RAGGED one of the next aligned size -- the padded rows become identity rows of the matrices, exactly what
+    # the kernels do for tasks of unequal length -- and the outputs are cut back (round 5; PACOH_DENSE_PAD=0: as before).
+    align = 4 if dt == torch.float32 else 2
+    if 97 <= n < 512 and n % align != 0 and os.environ.get('PACOH_DENSE_PAD', '1') != '0' and os.environ.get('PACOH_CHOL_LL', '1') != '0':
+        npad = (n + align - 1) // align * align
+        pad_rows = lambda t: torch.nn.functional.pad(t, (0, 0, 0, npad - n))              # [.., n, f] -> [.., npad, f]
+        pad_last = lambda t: torch.nn.functional.pad(t, (0, npad - n))                    # [.., n] -> [.., npad]
+        nv = (torch.full((y.shape[0],), n, dtype=torch.int32, device=dev) if n_valid is None else n_valid.clamp(max=n))
+        out = _gp_lml_dense(pad_rows(z), z_div, pad_last(mean) if mean_mode == MEAN_VECTOR else mean, mean_mode, pad_last(y), y_div, lengthscale,
+                            outputscale, noise, nv, g_lml, B, P, info, want_grad, want_dz, kernel)
+        lml, d_z, d_mean, d_ls, d_os, d_noise = out
+        if d_z is not None:
+            d_z = d_z[:, :n].contiguous()
+        if d_mean is not None and mean_mode == MEAN_VECTOR:
+            d_mean = d_mean[:, :n].contiguous()
+        return lml, d_z, d_mean, d_ls, d_os, d_noise
     lml = torch.empty(B, dtype=dt, device=dev)
     d_z = d_mean = d_ls = d_os = d_noise = None
     if want_grad:
