@@ -201,6 +201,10 @@ struct WaveCtx {
     __device__ __forceinline__ T late(T value, unsigned) const { return value; }
 };
 
+// 1 / x on the hardware reciprocal plus one Newton step (3 instructions, <= 1 ulp) instead of the IEEE division sequence (11): round 5's
+// part of the instruction diet -- six divisions and one logf per problem were ~85 of the kernel's ~2 200 vector instructions
+__device__ __forceinline__ float rcp_(float x) { const float r = __builtin_amdgcn_rcpf(x); return r * fmaf(-x, r, 2.0f); }
+
 __host__ __device__ constexpr int uidx(int NB, int K, int J) { return K * NB - K * (K - 1) / 2 + (J - K); }   // upper block (K <= J)
 
 
@@ -242,7 +246,7 @@ __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, 
     constexpr float KAPPA = 0.8493218002880191f, INV_KAPPA2 = 1.3862943611198906f;
     float kls[FP];                                            // KAPPA / lengthscale
 #pragma unroll
-    for (int c = 0; c < FP; ++c) kls[c] = (c < f) ? KAPPA / a.ls[(long)p * f + c] : 1.0f;
+    for (int c = 0; c < FP; ++c) kls[c] = (c < f) ? KAPPA * rcp_(a.ls[(long)p * f + c]) : 1.0f;
     const float os = HAS_OS ? (a.os ? a.os[p] : 1.0f) : 1.0f;
     const float noise = a.noise[p];
 
@@ -387,8 +391,10 @@ __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, 
 #pragma unroll
     for (int K = 0; K < NB; ++K) q2 += (uB[K][0] * uB[K][0] + uB[K][1] * uB[K][1]) + (uB[K][2] * uB[K][2] + uB[K][3] * uB[K][3]);
     const float quad = wave_sum_(r == 0 ? q2 : 0.0f);
-    const float logdet = -wave_sum_(logf(dprod));             // log det = 2 sum log L_ii (dprod: 1 / L_ii); padding rows have pivot 1
-    float lml = nv > 0 ? -0.5f * (quad + 2.0f * logdet + (float)nv * 1.8378770664093453f) / (float)nv : 0.0f;
+    // (hardware log2: its ~1e-7 relative error on a lane's share is far below what the sum's own rounding moves)
+    const float logdet = -0.6931471805599453f * wave_sum_(__builtin_amdgcn_logf(dprod));   // log det = 2 sum log L_ii (dprod: 1 / L_ii); padding rows have pivot 1
+    const float inv_nv = nv > 0 ? rcp_((float)nv) : 0.0f;
+    float lml = -0.5f * (quad + 2.0f * logdet + (float)nv * 1.8378770664093453f) * inv_nv;
     if (!okf) lml = NAN;
     if (lane == 0) GPR_LATE(lml)[b] = lml;
     if (!BWD) return;
@@ -407,7 +413,7 @@ __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, 
     // ---- gradient sums ---------------------------------------------------------------------------------------------------------------
     const float* g_lml_p = GPR_LATE(g_lml);
     const float gup = g_lml_p ? g_lml_p[b] : 1.0f;
-    const float osn = nv > 0 ? 0.5f * os / (float)nv : 0.0f;   // the outputscale rides on the 1/(2 n) factor: M_ij = G_ij os e_ij
+    const float osn = 0.5f * os * inv_nv;   // the outputscale rides on the 1/(2 n) factor: M_ij = G_ij os e_ij
     float msum = 0.0f, dnz = 0.0f;                              // sum of M (= os d lml/d os), os x trace part (= os d lml/d noise); x osn at the end
     // Every ordered pair (i, j) is visited, column block by column block: lane (r, g) holds the entries (i = 16I + 4g+s, j = 16J + r),
     // so everything destined for point j -- d_z[j] = sum_i M_ij (z_i - z_j) -- accumulates in the lane over s and I and needs only
@@ -516,14 +522,14 @@ __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, 
         }
         if (a.mean_mode == PACOH_MEAN_VECTOR) {
             float* d_mean_p = GPR_LATE(d_mean);
-            if (d_mean_p && i < n) d_mean_p[b * n + i] = (i < nv) ? gup * ai / (float)nv + bad : 0.0f;
+            if (d_mean_p && i < n) d_mean_p[b * n + i] = (i < nv) ? gup * ai * inv_nv + bad : 0.0f;
         }
         asum += (i < nv) ? ai : 0.0f;
     }
     if (a.mean_mode == PACOH_MEAN_CONST) {
         const float sa = wave_sum_(asum);
         float* d_mean_p = GPR_LATE(d_mean);
-        if (d_mean_p && lane == 0) d_mean_p[b] = nv > 0 ? gup * sa / (float)nv + bad : 0.0f;
+        if (d_mean_p && lane == 0) d_mean_p[b] = gup * sa * inv_nv + bad;
     }
 #pragma unroll
     for (int c = 0; c < FP; ++c) {
@@ -537,8 +543,9 @@ __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, 
     const float sdos = osn * wave_sum_(msum) + padc, sdnz = padc - osn * wave_sum_(dnz);
     if (lane == 0) {
         float* d_os_p = GPR_LATE(d_os);
-        if (d_os_p) d_os_p[b] = gup * sdos / os + bad;
-        GPR_LATE(d_noise)[b] = gup * sdnz / os + bad;
+        const float inv_os = rcp_(os);
+        if (d_os_p) d_os_p[b] = gup * sdos * inv_os + bad;
+        GPR_LATE(d_noise)[b] = gup * sdnz * inv_os + bad;
     }
 #undef WSYNC
 #undef SCHED_FENCE
