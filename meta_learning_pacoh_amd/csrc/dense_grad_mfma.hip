@@ -53,11 +53,14 @@ __global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* _
     __shared__ double ZI[GT][GZL], ZJ[2][GT][GZL], n2I[GT], n2J[2][GT], aI[GT], aJ[2][GT];
     __shared__ double Tr[4][16][17];
     __shared__ double Rows[GT][GZL];
-    const long b = blockIdx.y;
-    const int I = blockIdx.x, I0 = I * GT;
+    // grid (problems, row blocks), LONGEST row block first.  Workgroups go to the eight XCDs round-robin in linear-id order: with the
+    // row block as the fast index and eight row blocks (n = 512) XCD k received every workgroup of row block k -- 1 tile each on XCD
+    // 0, 8 tiles each on XCD 7, which then ran 1.8 x the balanced time (267 us; this order: see profiles/r05_dense_kernel_stats_fp64.csv).
+    const long b = blockIdx.x;
+    const int nI = (n + GT - 1) / GT;
+    const int I = nI - 1 - (int)blockIdx.y, I0 = I * GT;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int nI = (n + GT - 1) / GT;
     if (info[b] < 0) return;                               // (the combine kernel writes the NaNs)
     const int nv = clamp_nv2(n_valid, b / y_div, n);
     const double os = osp ? osp[b % P] : 1.0;
@@ -350,7 +353,7 @@ int dense_grad_mfma_try(const void* zs, const void* ls, const void* os, const in
     double* rowside = (double*)scratch;
     double* colpart = rowside + (size_t)B * n * 9;
     double* gdiag = colpart + (size_t)B * ((size_t)nI * (nI - 1) / 2) * GT * 9;
-    hipLaunchKernelGGL(dense_grad_tile_kernel, dim3(nI, B), dim3(256), 0, s, (const double*)zs, (const double*)os, n_valid, y_div,
+    hipLaunchKernelGGL(dense_grad_tile_kernel, dim3(B, nI), dim3(256), 0, s, (const double*)zs, (const double*)os, n_valid, y_div,
                        (const double*)alpha, (const double*)Wm, info, rowside, colpart, gdiag, P, n, f);
     hipLaunchKernelGGL(dense_grad_combine_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, (const double*)zs, (const double*)ls,
                        (const double*)os, n_valid, y_div, (const double*)g_lml, (const double*)alpha, info, rowside, colpart, gdiag,

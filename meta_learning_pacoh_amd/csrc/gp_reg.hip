@@ -8,8 +8,12 @@
 namespace pacoh {
 
 // waves per SIMD the register allocation aims at: 4 (the n <= 64, f <= 2 backward kernel needs 122 registers and 7.7 KB of LDS);
-// with f <= 4 the n = 64 kernels need 168 - 186 registers (3 resp. 2 waves)
-#define GPR_MINW(NB, FP, BWD) ((NB) > 4 ? 1 : ((NB) == 4 && (FP) == 4 ? ((BWD) ? 2 : 3) : 4))
+// with f <= 4 the n = 64 kernels need 168 - 186 registers (3 resp. 2 waves).  n > 64: TWO (round 5) -- the live set of the
+// algorithm is 44 blocks = 176 registers + temporaries, it was the 28 KB of parked W blocks per problem that held the kernel at one
+// wave per SIMD, and the compiler, knowing that, spread over 396 registers.  With the blocks consumed where they are produced
+// (gp_reg_body.h) the n = 128, f <= 2 kernel takes 244 registers and 4.8 KB: 0.982 -> 0.682 ms per 20 480 problems
+// (profiles/r05_gp_two_waves.txt).  f <= 4 at n = 128 would spill 200 registers at that budget and stays at one wave.
+#define GPR_MINW(NB, FP, BWD) ((NB) > 4 ? ((FP) == 2 || (NB) == 6 ? 2 : 1) : ((NB) == 4 && (FP) == 4 ? ((BWD) ? 2 : 3) : 4))
 template <int NB, int FP, bool BWD, bool HAS_OS = true>
 __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfmaArgs a) {
     constexpr int NP = 16 * NB;
@@ -23,7 +27,7 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     // W = K^-1, strictly upper block triangle, each block as the 64 lanes' accumulator registers (one 16-byte slot per lane): parked
     // here between the matrix-core phase that produces it and the gradient loop that consumes it, so that the two phases do not
     // have to share the register file (1 KB per block; with it a problem holds 7.7 KB of LDS = 20 problems per CU)
-    __shared__ __attribute__((aligned(16))) float Wl[BWD && NB > 1 ? (NU - NB) * 256 : 4];
+    __shared__ __attribute__((aligned(16))) float Wl[BWD && NB > 1 && NB <= 4 ? (NU - NB) * 256 : 4];   // (n > 64: no parking, see gp_reg_body.h)
     gpreg::gp_reg_body<NB, FP, BWD, HAS_OS>(a, gpreg::KernelCtx{}, zf, rv, av, fsc, tsc, dzc, Wl);
 }
 
@@ -45,8 +49,8 @@ static int launch_reg(const GpMfmaArgs& a, int FP, hipStream_t s) {
 int gp_reg_try(const GpMfmaArgs& a, bool bwd, hipStream_t s) {
     const char* e = getenv("PACOH_GP_REG");
     if (e && e[0] == '0') return 1;
-    // (n > 64: one wave still holds the whole matrix -- 240 registers + 148 accumulation registers at n = 128, one wave per SIMD --
-    //  and beats the LDS-resident kernel, which also runs one wave per SIMD there but moves every block through LDS: 2.4x at n = 128)
+    // (n > 64: one wave still holds the whole matrix -- 244 registers at n = 128, two waves per SIMD -- and beats the LDS-resident
+    //  kernel, which runs one wave per SIMD there and moves every block through LDS)
     static const int max_n = []() { const char* m = getenv("PACOH_GP_REG_MAX_N"); return m && m[0] ? atoi(m) : 128; }();
     if (a.n > max_n || a.n > 128 || a.f > 4 || a.n < 1) return 1;
     const int NB = (a.n + 15) / 16;

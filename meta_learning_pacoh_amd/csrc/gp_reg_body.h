@@ -443,9 +443,70 @@ __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, 
             for (int c = 0; c < FP; ++c) colacc[c] = fmaf(M, df[c], colacc[c]);
         }
     };
-    // ---- W = K^-1, upper block triangle: W[I][J] = sum_{m >= J} Linv[m][I]^T Linv[m][J].  A diagonal block is consumed where it
-    //      is produced; the strictly upper blocks are parked in LDS for the loop below, which needs each of them twice (as block
-    //      (I,J) and, transposed, as block (J,I)) -------------------------------------------------------------------------------------
+    // ---- W = K^-1, upper block triangle: W[I][J] = sum_{m >= J} Linv[m][I]^T Linv[m][J] ------------------------------------------------
+    // n <= 64 (PARK): a diagonal block is consumed where it is produced; the strictly upper blocks are parked in LDS for the loop
+    // below, which needs each of them twice (as block (I,J) and, transposed, as block (J,I)) -- the two phases do not share the
+    // register file, which is what keeps the n = 64 kernel at four waves per SIMD.
+    // n > 64: parking costs 1 KB per block -- 28 KB per problem at n = 128, which alone held the kernel at ONE wave per SIMD (four
+    // problems per CU), where a lone wave issues a vector instruction every ~7 cycles instead of every 4.  There every block is
+    // consumed where it is produced, once as it is and once transposed through the 1.25 KB transpose scratch, with the column sums
+    // of all NB column blocks live (NB x FP registers): 4.8 KB of LDS per problem, 2 waves per SIMD.
+    constexpr bool PARK = NB <= 4;
+    if constexpr (!PARK) {
+        float colacc[NB][FP];
+#pragma unroll
+        for (int J = 0; J < NB; ++J)
+#pragma unroll
+            for (int c = 0; c < FP; ++c) colacc[J][c] = 0.0f;
+        const int twr = 68 * g + 12 * (g & 1) + 32 * (g >> 1) + r, trd = 17 * r + 12 * ((r >> 2) & 1) + 32 * (r >> 3) + 4 * g;
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+#pragma unroll
+            for (int J = I; J < NB; ++J) {
+                // (pure arithmetic floats freely across SCHED_FENCE when the instruction stream is first laid out: left alone, all 36
+                //  block products come first -- their results spilled -- and the 4 608 entries after them.  The volatile asm
+                //  statements pass the accumulator's zero and the running sums through: block (I,J)'s products start behind the
+                //  previous block's last entry.)
+                f32x4 Wb = {0.f, 0.f, 0.f, 0.f};
+                asm volatile("" : "+v"(Wb));
+                Wb = mmT(I == J ? Zd[J] : G[J][I], Zd[J], Wb);
+#pragma unroll
+                for (int m = J + 1; m < NB; ++m) Wb = mmT(G[m][I], G[m][J], Wb);
+                {
+                    float zc[FP];
+#pragma unroll
+                    for (int c = 0; c < FP; ++c) zc[c] = zf[(16 * J + r) * FP + c];
+                    block_entries(Wb, I, zc, av[16 * J + r], colacc[J], I == J);
+                }
+                if (I != J) {                                  // ... and as block (J, I): the transpose
+                    f32x4 Wt;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) tsc[twr + 17 * s] = Wb[s];
+                    WSYNC();
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Wt[q] = tsc[trd + q];
+                    WSYNC();
+                    float zc[FP];
+#pragma unroll
+                    for (int c = 0; c < FP; ++c) zc[c] = zf[(16 * I + r) * FP + c];
+                    block_entries(Wt, J, zc, av[16 * I + r], colacc[I], false);
+#pragma unroll
+                    for (int c = 0; c < FP; ++c) asm volatile("" : "+v"(colacc[I][c]));
+                }
+#pragma unroll
+                for (int c = 0; c < FP; ++c) asm volatile("" : "+v"(colacc[J][c]));
+                SCHED_FENCE();
+            }
+        }
+#pragma unroll
+        for (int J = 0; J < NB; ++J)
+#pragma unroll
+            for (int c = 0; c < FP; ++c) {
+                float v = colacc[J][c];
+                v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                if (g == 0) dzc[(16 * J + r) * FP + c] = v;
+            }
+    } else {
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
 #pragma unroll
@@ -497,6 +558,7 @@ __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, 
             v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
             if (g == 0) dzc[(16 * J + r) * FP + c] += v;
         }
+    }
     }
     WSYNC();
     const float bad = okf ? 0.0f : NAN;
