@@ -113,6 +113,10 @@ CASES = [  # T, P, n, f, per_eval_z
     (3, 4, 64, 2, True),       # cfg #3 NN features
     (3, 4, 64, 4, False),      # cfg #3 SE on d=4 inputs
     (2, 2, 128, 2, True),      # cfg #4
+    (2, 2, 80, 2, False),      # n > 64 (round 5: two waves per SIMD, W blocks consumed where they are produced): 6 blocks, f <= 2
+    (2, 2, 96, 4, True),       # ... 6 blocks, f <= 4
+    (1, 3, 112, 3, True),      # ... 8 blocks (7 used), f <= 4 (one wave per SIMD)
+    (2, 2, 128, 4, True),      # ... 8 blocks, f <= 4
     (2, 2, 47, 3, True),       # odd n
     (1, 2, 9, 16, True),       # max feature dim
 ]

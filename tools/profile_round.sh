@@ -14,6 +14,11 @@ tools/mfma_peak > $out/mfma_peak.txt 2>&1
 # per-kernel times of the default bench command (graph replays + the eager instrumented pass)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline --no-other-configs > $out/bench_under_rocprof.json 2>/dev/null
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/bench_kernel_stats.csv
+# ... and of BASELINE configs #2 (the task-fused MAP kernel) and #4 (the n = 128 GP kernel)
+for c in 2 4; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats$c -- python3 bench.py --config $c --no-cpu-baseline > /dev/null 2>&1
+  cp $(ls $out/stats$c/*/*kernel_stats.csv | head -1) $out/cfg${c}_kernel_stats.csv; rm -rf $out/stats$c
+done
 # HBM traffic: separate FETCH_SIZE / WRITE_SIZE passes
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
