@@ -187,7 +187,10 @@ __global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* _
 }
 
 // per row: the row-side sums + the column-side partial sums of the tiles below it (fixed order), then the outputs of
-// dense_grad_cols_kernel: d_z, d_mean, rowpart = {lengthscale terms, d_os term, G_ii, alpha_i}
+// dense_grad_cols_kernel: d_z, d_mean, rowpart = {lengthscale terms, d_os term, G_ii, alpha_i}.
+// One thread per (row, sum c = 0..8): consecutive threads read consecutive doubles of rowside [row][9] and of a tile's partials
+// [64][9] (round 5; one thread per row walking its nine sums read 72-byte strides and took 36.5 us per 256 x 512 launch).
+constexpr int GC_ROWS = 28;          // rows per 256-thread workgroup (252 threads busy)
 __global__ void __launch_bounds__(256) dense_grad_combine_kernel(const double* __restrict__ zs, const double* __restrict__ lsp,
                                                                  const double* __restrict__ osp, const int32_t* __restrict__ n_valid,
                                                                  int y_div, const double* __restrict__ g_lml,
@@ -197,8 +200,9 @@ __global__ void __launch_bounds__(256) dense_grad_combine_kernel(const double* _
                                                                  double* __restrict__ d_mean, int mean_mode, double* __restrict__ rowpart,
                                                                  int P, int n, int f) {
     const long b = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const int t = threadIdx.x, lr = t / 9, c = t - 9 * lr;
+    const int i = blockIdx.x * GC_ROWS + lr;
+    if (lr >= GC_ROWS || i >= n) return;
     const int p = (int)(b % P);
     const int nv = clamp_nv2(n_valid, b / y_div, n);
     const bool failed = info[b] < 0;
@@ -207,29 +211,29 @@ __global__ void __launch_bounds__(256) dense_grad_combine_kernel(const double* _
     double* rp = rowpart + (b * n + i) * (long)W3;
     if (failed || i >= nv) {
         const double v = failed ? (double)NAN : 0.0;
-        if (d_z) for (int c = 0; c < f; ++c) d_z[(b * n + i) * (long)f + c] = v;
-        if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = v;
-        for (int c = 0; c < W3; ++c) rp[c] = v;
+        if (c < f) { if (d_z) d_z[(b * n + i) * (long)f + c] = v; rp[c] = v; }
+        if (c == 8) {
+            if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = v;
+            rp[f] = v; rp[f + 1] = v; rp[f + 2] = v;
+        }
         return;
     }
     const int nI = (n + GT - 1) / GT, Ji = i / GT, il = i - Ji * GT;
-    double acc[9];
-    for (int c = 0; c < 9; ++c) acc[c] = rowside[(b * (long)n + i) * 9 + c];
-    for (int I = Ji + 1; I < nI; ++I) {
-        const double* cp = colpart + ((b * (long)(nI * (nI - 1) / 2) + tiles_before(I) + Ji) * GT + il) * 9;
-        for (int c = 0; c < 9; ++c) acc[c] += cp[c];
+    double acc = rowside[(b * (long)n + i) * 9 + c];
+    for (int I = Ji + 1; I < nI; ++I)
+        acc += colpart[((b * (long)(nI * (nI - 1) / 2) + tiles_before(I) + Ji) * GT + il) * 9 + c];
+    if (c < f) {
+        const double* zb = zs + b * (long)n * f;
+        if (d_z) d_z[(b * n + i) * (long)f + c] = 2.0 * gup * acc / lsp[(long)p * f + c];
+        rp[c] = -2.0 * (zb[(long)i * f + c] - zb[c]) * acc;            // (lengthscale sums from the finished d_z sums, as dense_grad_cols_kernel)
+    } else if (c == 8) {
+        const double os = osp ? osp[p] : 1.0;
+        const double ai = alpha[b * (long)n + i];
+        rp[f] = acc / os;                                  // sum_j G_ij K_ij / os = sum_j M_ij / os
+        rp[f + 1] = gdiag[b * (long)n + i];
+        rp[f + 2] = ai;
+        if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = gup * ai / (double)nv;
     }
-    const double os = osp ? osp[p] : 1.0;
-    const double* zb = zs + b * (long)n * f;
-    for (int c = 0; c < f; ++c) {
-        if (d_z) d_z[(b * n + i) * (long)f + c] = 2.0 * gup * acc[c] / lsp[(long)p * f + c];
-        rp[c] = -2.0 * (zb[(long)i * f + c] - zb[c]) * acc[c];        // (lengthscale sums from the finished d_z sums, as dense_grad_cols_kernel)
-    }
-    const double ai = alpha[b * (long)n + i];
-    rp[f] = acc[8] / os;                                   // sum_j G_ij K_ij / os = sum_j M_ij / os
-    rp[f + 1] = gdiag[b * (long)n + i];
-    rp[f + 2] = ai;
-    if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = gup * ai / (double)nv;
 }
 
 // ---- the Gram matrix for the factorisation, same idea -----------------------------------------------------------------------------
@@ -355,7 +359,7 @@ int dense_grad_mfma_try(const void* zs, const void* ls, const void* os, const in
     double* gdiag = colpart + (size_t)B * ((size_t)nI * (nI - 1) / 2) * GT * 9;
     hipLaunchKernelGGL(dense_grad_tile_kernel, dim3(B, nI), dim3(256), 0, s, (const double*)zs, (const double*)os, n_valid, y_div,
                        (const double*)alpha, (const double*)Wm, info, rowside, colpart, gdiag, P, n, f);
-    hipLaunchKernelGGL(dense_grad_combine_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, (const double*)zs, (const double*)ls,
+    hipLaunchKernelGGL(dense_grad_combine_kernel, dim3((n + GC_ROWS - 1) / GC_ROWS, B), dim3(256), 0, s, (const double*)zs, (const double*)ls,
                        (const double*)os, n_valid, y_div, (const double*)g_lml, (const double*)alpha, info, rowside, colpart, gdiag,
                        (double*)d_z, (double*)d_mean, mean_mode, (double*)rowpart, P, n, f);
     return launch_status();
