@@ -112,11 +112,22 @@ __device__ __forceinline__ float wave_sum_(float v) {
 // read one address: a broadcast) it is 2 x (13 + 4) -- and the pivot block comes out of the same 256 bytes by four uniform
 // ds_read_b128 instead of ten v_readlane (4.7 cycles each, and their scalar results make every instruction of the 4x4 Cholesky
 // a scalar-operand instruction: 4.7 instead of 3.2 cycles).
-__device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const f32x4& nId, int r, int g, float* fs) {
+// SKIP (round 5; n <= 32, where the last block is often mostly padding -- the 5-point tasks of cfg #1 pay for a 16 x 16 block; in the
+// 6- / 8-block kernels, which also serve 5 and 7 blocks, the branches cost 12 registers and the n = 128 kernel its second wave per
+// SIMD): `rows` = rows of this block inside the problem (wave-uniform).  A step
+// whose four columns are all padding is not run: the padding rows are rows of the identity, exactly (their off-diagonal kernel
+// entries are exp2(-1e20) = 0), so the step would produce x = 0, Z rows = identity rows and a pivot of 1 -- which is what is set.
+template <bool SKIP = false>
+__device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const f32x4& nId, int r, int g, float* fs, int rows = 16) {
     f32x4 Tn = nId;                                         // -E + L Z, built up by one rank-4 MFMA per step (see below)
     Z = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int rows_u = SKIP ? __builtin_amdgcn_readfirstlane(rows) : 16;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+        if (SKIP && 4 * k >= rows_u) {
+            if (g == k) { Z[0] = -nId[0]; Z[1] = -nId[1]; Z[2] = -nId[2]; Z[3] = -nId[3]; }
+            continue;
+        }
         // pivot block P[c][j] = C[4k+c][4k+j] = register c of lane (r = 4k+j, g = k): wave-uniform
         const float c0 = Cn[0], c1 = Cn[1], c2 = Cn[2], c3 = Cn[3];
         const int src = (16 * k + r) * 4;
@@ -331,7 +342,7 @@ __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, 
             // registers per product.  So the blocks not yet eliminated are kept NEGATED (Un = -A): the trailing update becomes
             // Un[I][J] += R[K][I]^T R[K][J] with both operands as they are, and every other product of the step takes the one
             // negated operand Vn = -L_KK^-T.
-            factor16(U[uidx(NB, K, K)], Zd[K], dprod, nId, r, g, fsc);
+            factor16<(NB <= 2)>(U[uidx(NB, K, K)], Zd[K], dprod, nId, r, g, fsc, nv - 16 * K);
             SCHED_FENCE();
             // -L_KK^-T: the block transposed through 1.25 KB of LDS (4 dword writes + 4 dword reads, the conflict-free skewed
             // stride-17 layout of mlp_fused.hip's f_turn) instead of a product with the -identity block (4 MFMAs = 128 of the
