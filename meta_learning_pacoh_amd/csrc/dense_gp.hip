@@ -551,11 +551,155 @@ void launch_ztz(const T* Z, T* W, int n, const int32_t* info, int Bn, hipStream_
     hipLaunchKernelGGL(ztz_kernel<T>, dim3((unsigned)(nt * Bn)), dim3(256), 0, s, Z, W, n, info, nt, Bn, mirror);
 }
 
+// ---- the general batched GEMM, LDS-tiled (round 5) ---------------------------------------------------------------------------
+// ztz_kernel's tile scheme for ANY op(A) op(B) of GemmArgs: one workgroup per 128 x 128 tile of C, k in slabs of 16, both operands of
+// a slab through a double-buffered LDS image [k][128] read by four waves of 4 x 4 accumulator blocks each (ztz_slab), the next
+// slab's global loads in flight under this slab's MFMAs.  An operand stored k-major (transA / !transB: a slab row is contiguous) is
+// staged by 16-byte loads and 16-byte LDS stores; stored i-major (!transA / transB: 16 bytes = 4 / 2 consecutive k of one row) it
+// is transposed on the way into LDS (consecutive lanes = consecutive rows: conflict-free scalar stores).  Stored-lower operands
+// clip the tile's k range and are masked where a slab crosses their diagonal.  bgemm_kernel above -- one wave per 32 x 32 tile,
+// operands straight from L2 -- ran the predictive's V = Z K_xs at 18 TFLOP/s in fp32; it stays for outputs narrower than a tile.
+template <typename T>
+__global__ void __launch_bounds__(256, 2) gemm_tile_kernel(GemmArgs ga, int tiles_n, int nt, int Bn) {
+    using Acc = typename Mf<T>::acc;
+    constexpr int TS = 128, KS = 16, LDT = TS + 4;
+    constexpr int VE = 16 / (int)sizeof(T);
+    typedef T VT __attribute__((ext_vector_type(VE)));
+    __shared__ __attribute__((aligned(16))) T As[2][KS][LDT];
+    __shared__ __attribute__((aligned(16))) T Bs[2][KS][LDT];
+    int b, tile;                                                   // ids L, L + 8, ... (one XCD) walk the tiles of one matrix
+    {
+        const int L = blockIdx.x, B8 = Bn & ~7;
+        if (L < nt * B8) { const int slot = L >> 3; b = (L & 7) + 8 * (slot / nt); tile = slot % nt; }
+        else { const int Lr = L - nt * B8; b = B8 + Lr / nt; tile = Lr % nt; }
+    }
+    if (ga.info && ga.info[b] < 0) return;
+    int tm, tn;
+    if (ga.symC) {
+        tm = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+        while (tm * (tm + 1) / 2 > tile) --tm;
+        while ((tm + 1) * (tm + 2) / 2 <= tile) ++tm;
+        tn = tile - tm * (tm + 1) / 2;
+    } else { tm = tile / tiles_n; tn = tile - tm * tiles_n; }
+    const int i0 = tm * TS, j0 = tn * TS;
+    const T* A = (const T*)ga.A + (long)b * ga.sA;
+    const T* Bm = (const T*)ga.B + (long)b * ga.sB;
+    T* C = (T*)ga.C + (long)b * ga.sC;
+    const int M = ga.M, N = ga.N, K = ga.K, lda = ga.lda, ldb = ga.ldb;
+    const bool tA = ga.transA != 0, tB = ga.transB != 0, lA = ga.lowerA != 0, lB = ga.lowerB != 0;
+    int klo = 0, khi = K;
+    if (lA) { if (tA) klo = max(klo, i0); else khi = min(khi, i0 + TS); }
+    if (lB) { if (tB) khi = min(khi, j0 + TS); else klo = max(klo, j0); }
+    klo &= ~(KS - 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    Acc acc[4][4];
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = Acc{0, 0, 0, 0};
+    constexpr int NCH = KS * TS / VE / 256;                          // 16-byte chunks per thread, slab and operand
+    // chunk c of a slab: k-major storage -> (k = c / CPR, columns (c % CPR) VE ..); i-major -> (row c % TS, k = (c / TS) VE ..)
+    constexpr int CPR = TS / VE;
+    const bool vecA = ((long)lda * sizeof(T)) % 16 == 0 && ((size_t)A % 16) == 0 && (tA ? i0 + TS <= M : true);
+    const bool vecB = ((long)ldb * sizeof(T)) % 16 == 0 && ((size_t)Bm % 16) == 0 && (tB ? true : j0 + TS <= N);
+    // unconditional loads from clamped addresses (nothing tests the loaded values before the slab is written to LDS: ztz_kernel's note)
+    auto load_op = [&](const T* X, int ld, bool kmajor, int dim, int o0, bool vec, int k0, VT (&rg)[NCH]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < NCH; ++v) {
+            const int c = (int)threadIdx.x + 256 * v;
+            if (kmajor) {
+                const int k = k0 + c / CPR, col = o0 + (c % CPR) * VE;
+                const int kc = k < K ? k : K - 1;
+                if (vec) rg[v] = *(const VT*)(X + (long)kc * ld + col);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) rg[v][e] = X[(long)kc * ld + (col + e < dim ? col + e : dim - 1)];
+                }
+            } else {
+                const int row = o0 + c % TS, k = k0 + (c / TS) * VE;
+                const int rc = row < dim ? row : dim - 1;
+                if (vec && k + VE <= K) rg[v] = *(const VT*)(X + (long)rc * ld + k);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) rg[v][e] = X[(long)rc * ld + (k + e < K ? k + e : K - 1)];
+                }
+            }
+        }
+    };
+    // lower: (idx, k) is stored iff  kmajor ? idx <= k : k <= idx
+    auto store_op = [&](T (*Xs)[LDT], bool kmajor, int dim, int o0, bool lower, int k0, VT (&rg)[NCH]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < NCH; ++v) {
+            const int c = (int)threadIdx.x + 256 * v;
+            if (kmajor) {
+                const int kl = c / CPR, cl = (c % CPR) * VE, k = k0 + kl;
+                VT x = rg[v];
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const int idx = o0 + cl + e;
+                    if (k >= K || idx >= dim || (lower && idx > k)) x[e] = T(0);
+                }
+                *(VT*)&Xs[kl][cl] = x;
+            } else {
+                const int rl = c % TS, kl = (c / TS) * VE, idx = o0 + rl;
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const int k = k0 + kl + e;
+                    Xs[kl + e][rl] = (k >= K || idx >= dim || (lower && k > idx)) ? T(0) : rg[v][e];
+                }
+            }
+        }
+    };
+    const int ca = 16 * wr + r, cb = 16 * wc + r;
+    VT ra[NCH], rb[NCH];
+    if (klo < khi) {
+        load_op(A, lda, tA, M, i0, vecA, klo, ra);
+        load_op(Bm, ldb, !tB, N, j0, vecB, klo, rb);
+        store_op(As[0], tA, M, i0, lA, klo, ra);
+        store_op(Bs[0], !tB, N, j0, lB, klo, rb);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = klo; k0 < khi; k0 += KS) {
+        const bool more = k0 + KS < khi;
+        if (more) { load_op(A, lda, tA, M, i0, vecA, k0 + KS, ra); load_op(Bm, ldb, !tB, N, j0, vecB, k0 + KS, rb); }
+        ztz_slab<T, 0xFFFFu, LDT>(As[buf], Bs[buf], acc, ca, cb, g);
+        if (more) { store_op(As[buf ^ 1], tA, M, i0, lA, k0 + KS, ra); store_op(Bs[buf ^ 1], !tB, N, j0, lB, k0 + KS, rb); }
+        __syncthreads();
+        buf ^= 1;
+    }
+    const T alpha = (T)ga.alpha, beta = (T)ga.beta;
+    const int ldc = ga.ldc;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + 16 * (wr + 2 * ib) + Mf<T>::row(g, q), j = j0 + 16 * (wc + 2 * jb) + r;
+                if (i < M && j < N) {
+                    T* cp = C + (long)i * ldc + j;
+                    const T v = beta == T(0) ? alpha * acc[ib][jb][q] : fma(alpha, acc[ib][jb][q], beta * *cp);
+                    *cp = v;
+                    if (ga.symC && tm != tn) C[(long)j * ldc + i] = v;
+                }
+            }
+}
+
 template <typename T>
 void launch_bgemm(const GemmArgs& ga, int Bn, hipStream_t s, int mirror = 1) {
     if (ga.A == ga.B && ga.transA && !ga.transB && ga.lowerA && ga.lowerB && ga.symC && ga.M == ga.N && ga.M == ga.K &&
         ga.lda == ga.M && ga.ldb == ga.M && ga.ldc == ga.M && ga.alpha == 1.0 && ga.beta == 0.0 && ga.M >= 128) {
         launch_ztz<T>((const T*)ga.A, (T*)ga.C, ga.M, ga.info, Bn, s, mirror);
+        return;
+    }
+    static const bool tile_on = []() { const char* e = getenv("PACOH_GEMM_TILE"); return !(e && e[0] == '0'); }();
+    if (tile_on && ga.M >= 96 && ga.N >= 96 && ga.K >= 32 && (const void*)ga.C != ga.A && (const void*)ga.C != ga.B) {
+        const int tm = (ga.M + 127) / 128, tn = (ga.N + 127) / 128;
+        const int nt = ga.symC ? tm * (tm + 1) / 2 : tm * tn;
+        hipLaunchKernelGGL(gemm_tile_kernel<T>, dim3((unsigned)(nt * Bn)), dim3(256), 0, s, ga, tn, nt, Bn);
         return;
     }
     const int tiles = ((ga.M + 63) / 64) * ((ga.N + 63) / 64);
