@@ -25,6 +25,10 @@ int dense_chol_retry_fused(void* A, const void* resid, void* logp, void* alpha_o
                            int u_only, const void* z, int z_div, const void* ls, const void* os, const void* noise, const int32_t* n_valid,
                            int y_div, double jitter_base, int P, int f, int kind, hipStream_t stream);           // dense.hip (1: not fused)
 int trtri_ll_try(void* A, const int32_t* info, int B, int n, int dtype, hipStream_t s, const void* u, void* alpha);
+bool trtri_ll_fits(int n, int dtype);
+bool dense_ll_fits(int n, int dtype);                                                                // dense_ll.hip
+int dense_ll_try(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n, int dtype,
+                 int attempt, int u_only, hipStream_t s);                                            // dense_ll.hip (1: not in its plan)
 int dense_grad_mfma_try(const void* zs, const void* ls, const void* os, const int32_t* n_valid, int y_div, const void* g_lml,
                         const void* alpha, const void* Wm, const int32_t* info, void* d_z, void* d_mean, int mean_mode, void* rowpart,
                         void* scratch, size_t scratch_bytes, int B, int P, int n, int f, int kind, int dtype, hipStream_t s);   // dense_grad_mfma.hip            // dense_trtri_ll.hip (1: not in its plan)
@@ -1004,14 +1008,186 @@ __global__ void __launch_bounds__(256) dense_alpha_kernel(const T* __restrict__ 
     }
 }
 
+// rows x cols sub-matrices of a batch, 16 bytes per thread where both sides allow it
+template <typename T>
+__global__ void __launch_bounds__(256) sub_copy_kernel(const T* __restrict__ src, long ss, int lds_, T* __restrict__ dst, long sd, int ldd,
+                                                       int rows, int cols, int vec) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    typedef T VT __attribute__((ext_vector_type(VE)));
+    const long b = blockIdx.y;
+    const T* S = src + b * ss;
+    T* D = dst + b * sd;
+    if (vec) {
+        const int cpr = cols / VE;
+        const long total = (long)rows * cpr;
+        for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+            const int i = (int)(q / cpr), j = (int)(q - (long)i * cpr) * VE;
+            *(VT*)(D + (long)i * ldd + j) = *(const VT*)(S + (long)i * lds_ + j);
+        }
+    } else {
+        const long total = (long)rows * cols;
+        for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+            const int i = (int)(q / cols), j = (int)(q - (long)i * cols);
+            D[(long)i * ldd + j] = S[(long)i * lds_ + j];
+        }
+    }
+}
+template <typename T>
+void launch_sub_copy(const T* src, long ss, int lds_, T* dst, long sd, int ldd, int rows, int cols, int B, hipStream_t s) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const bool vec = cols % VE == 0 && lds_ % VE == 0 && ldd % VE == 0 && ss % VE == 0 && sd % VE == 0 && ((size_t)src % 16) == 0 && ((size_t)dst % 16) == 0;
+    long chunks = ((long)rows * (vec ? cols / VE : cols) + 255) / 256;
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(sub_copy_kernel<T>, dim3((unsigned)chunks, B), dim3(256), 0, s, src, ss, lds_, dst, sd, ldd, rows, cols, vec ? 1 : 0);
+}
+
+// Z = L^-1 for 512 < n <= 1024 (round 5), two-level: Z = [Z11 0; -Z22 L21 Z11, Z22].  The diagonal sub-blocks (n1 = a multiple of 64,
+// both <= 512) go through the left-looking kernel as compact copies -- it takes the leading dimension = the size -- and the
+// off-diagonal block is two products on the LDS-tiled GEMM; the right-looking kernel this replaces there runs ONE workgroup per
+// matrix at 16-17 TFLOP/s in fp32 (profiles/r05_dense_big_n.txt: 1.22 ms of a 3.34 ms call at n = 784, 128 problems).
+// scratch: B (n1^2 + n2^2 + n1 n2) elements.  1: outside the plan.
+template <typename T>
+int trtri_blocked(T* A, const int32_t* info, int B, int n, T* scratch, size_t scratch_elems, hipStream_t s) {
+    static const bool on = []() { const char* e = getenv("PACOH_TRTRI_BLOCKED"); return !(e && e[0] == '0'); }();
+    const int dtype = sizeof(T) == 4 ? PACOH_F32 : PACOH_F64;
+    if (!on || !scratch || n <= 512 || n > 1024) return 1;
+    const int n1 = 64 * ((n + 127) / 128), n2 = n - n1;
+    if (n2 < 1 || !trtri_ll_fits(n1, dtype) || !trtri_ll_fits(n2, dtype)) return 1;
+    const size_t e1 = (size_t)B * n1 * n1, e2 = (size_t)B * n2 * n2, ex = (size_t)B * n2 * n1;
+    if (e1 + e2 + ex > scratch_elems) return 1;
+    T* C1 = scratch; T* C2 = C1 + e1; T* X = C2 + e2;
+    const long sA = (long)n * n;
+    launch_sub_copy<T>(A, sA, n, C1, (long)n1 * n1, n1, n1, n1, B, s);
+    launch_sub_copy<T>(A + (long)n1 * n + n1, sA, n, C2, (long)n2 * n2, n2, n2, n2, B, s);
+    int rc = trtri_ll_try(C1, info, B, n1, dtype, s, nullptr, nullptr);
+    if (rc) return rc == 1 ? PACOH_ELIMIT : rc;
+    rc = trtri_ll_try(C2, info, B, n2, dtype, s, nullptr, nullptr);
+    if (rc) return rc == 1 ? PACOH_ELIMIT : rc;
+    // X = L21 Z11;  Z21 = -Z22 X (into A's off-diagonal block)
+    GemmArgs g1 = {A + (long)n1 * n, C1, X, sA, (long)n1 * n1, (long)n2 * n1, n, n1, n1, n2, n1, n1, 0, 0, 0, 1, 1.0, 0.0, info, 0};
+    launch_bgemm<T>(g1, B, s, 1);
+    GemmArgs g2 = {C2, X, A + (long)n1 * n, (long)n2 * n2, (long)n2 * n1, sA, n2, n1, n, n2, n1, n2, 0, 0, 1, 0, -1.0, 0.0, info, 0};
+    launch_bgemm<T>(g2, B, s, 1);
+    launch_sub_copy<T>(C1, (long)n1 * n1, n1, A, sA, n, n1, n1, B, s);
+    launch_sub_copy<T>(C2, (long)n2 * n2, n2, A + (long)n1 * n + n1, sA, n, n2, n2, B, s);
+    return launch_status();
+}
+
+// r2[b][i] = r[b][n1 + i] - sum_k L21[b][i][k] u1[b][k]: one wave per row of the second sub-block
+template <typename T>
+__global__ void __launch_bounds__(256) blocked_resid2_kernel(const T* __restrict__ resid, const T* __restrict__ L21, const T* __restrict__ u1,
+                                                             T* __restrict__ r2, int n, int n1, int n2) {
+    const long b = blockIdx.y;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n2) return;
+    const T* Lr = L21 + (b * n2 + i) * (long)n1;
+    const T* ub = u1 + b * (long)n1;
+    T acc = 0;
+    for (int k = lane; k < n1; k += 64) acc = fma(Lr[k], ub[k], acc);
+    acc = subwave_sum<T>(acc, 64);
+    if (lane == 0) r2[b * (long)n2 + i] = resid[b * (long)n + n1 + i] - acc;
+}
+
+// the two sub-factorisations' verdicts, log-densities and u = L^-1 r as ONE problem's (attempt 0 of the jitter ladder)
+template <typename T>
+__global__ void __launch_bounds__(256) blocked_combine_kernel(const int32_t* __restrict__ info1, const int32_t* __restrict__ info2,
+                                                              const T* __restrict__ logp1, const T* __restrict__ logp2,
+                                                              const T* __restrict__ u1, const T* __restrict__ u2, int32_t* __restrict__ info,
+                                                              T* __restrict__ logp, T* __restrict__ u, int n, int n1) {
+    const long b = blockIdx.x;
+    const bool ok = info1[b] == 0 && info2[b] == 0;
+    if (threadIdx.x == 0) { info[b] = ok ? 0 : -1; logp[b] = ok ? logp1[b] + logp2[b] : T(NAN); }
+    if (u) {
+        const int n2 = n - n1;
+        for (int q = threadIdx.x; q < n; q += 256) u[b * (long)n + q] = !ok ? T(NAN) : (q < n1 ? u1[b * (long)n1 + q] : u2[b * (long)n2 + (q - n1)]);
+    }
+}
+
+// Cholesky + log-density + u = L^-1 r for 512 < n <= 1024 (round 5), rung 0 of the jitter ladder, two-level:
+//   L11 = chol(A11), Z11 = L11^-1;  L21 = A21 Z11^T;  L22 = chol(A22 - L21 L21^T);  u1 = L11^-1 r1, u2 = L22^-1 (r2 - L21 u1)
+// with the diagonal sub-blocks (n1 a multiple of 64, both <= 512) as compact copies through the left-looking kernels and the rest on
+// the LDS-tiled GEMM.  The right-looking kernel this replaces at these sizes runs one workgroup per matrix for ~1.3 ms at n = 784
+// however few matrices there are -- and the reference's MNIST tasks come a handful at a time.  A is left in the layout every
+// Cholesky kernel of the path leaves (L below, the inverse 32-blocks above the diagonal); a problem that fails either
+// sub-factorisation gets info = -1 and goes through the ladder's later rungs on the right-looking kernel, like everybody else's failures.
+// scratch: B (n1^2 + n2^2 + n1 n2 + 2 n + 4) elements + 2 B int32.  1: outside the plan.
+template <typename T>
+size_t chol_blocked_scratch(int B, int n) {
+    const int n1 = 64 * ((n + 127) / 128), n2 = n - n1;
+    return (size_t)B * ((size_t)n1 * n1 + (size_t)n2 * n2 + (size_t)n1 * n2 + 2 * (size_t)n + 8) + 64;
+}
+template <typename T>
+bool chol_blocked_plan(int B, int n, size_t scratch_elems) {
+    static const bool on = []() { const char* e = getenv("PACOH_CHOL_BLOCKED"); return !(e && e[0] == '0'); }();
+    static const bool mfma_on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
+    static const bool ll_on = []() { const char* e = getenv("PACOH_CHOL_LL"); return !(e && e[0] == '0'); }();
+    const int dtype = sizeof(T) == 4 ? PACOH_F32 : PACOH_F64;
+    if (!on || !mfma_on || !ll_on || n <= 512 || n > 1024) return false;
+    const int n1 = 64 * ((n + 127) / 128), n2 = n - n1;
+    return n2 >= 97 && dense_ll_fits(n1, dtype) && dense_ll_fits(n2, dtype) && trtri_ll_fits(n1, dtype) && chol_blocked_scratch<T>(B, n) <= scratch_elems;
+}
+// want_inv: go on to Z = L^-1 for the problems both sub-factorisations solved -- Z11 exists already, Z22 = L22^-1 in place,
+// Z21 = -Z22 (L21 Z11) -- and leave Z in A instead of L (no factor is written back: four of the block copies and the second
+// inversion of L11 that a separate inverse stage would need).  Without it (forward-only call) nothing reads A afterwards.
+template <typename T>
+int chol_blocked(T* A, const T* resid, T* logp, T* u_out, int32_t* info, int B, int n, T* scratch, bool want_inv, hipStream_t s) {
+    const int dtype = sizeof(T) == 4 ? PACOH_F32 : PACOH_F64;
+    const int n1 = 64 * ((n + 127) / 128), n2 = n - n1;
+    const size_t e1 = (size_t)B * n1 * n1, e2 = (size_t)B * n2 * n2, ex = (size_t)B * n2 * n1;
+    // scratch: C1 | C2 | T21 | r1 | r2 | u1 | u2 | logp1 | logp2 | info1, info2
+    T* C1 = scratch; T* C2 = C1 + e1; T* T21 = C2 + e2;
+    T* r1 = T21 + ex; T* r2 = r1 + (size_t)B * n1;
+    T* const u1v = r2 + (size_t)B * n2; T* const u2v = u1v + (size_t)B * n1;
+    T* lp1 = u2v + (size_t)B * n2; T* lp2 = lp1 + B;
+    int32_t* i1 = reinterpret_cast<int32_t*>(lp2 + B); int32_t* i2 = i1 + B;
+    const long sA = (long)n * n, s1 = (long)n1 * n1, s2 = (long)n2 * n2, sx = (long)n2 * n1;
+    T* const A21 = A + (long)n1 * n; T* const A22 = A21 + n1;
+    launch_sub_copy<T>(A, sA, n, C1, s1, n1, n1, n1, B, s);
+    launch_sub_copy<T>(resid, n, n, r1, n1, n1, 1, n1, B, s);
+    int rc = dense_ll_try(C1, r1, lp1, u1v, i1, 1.0, B, n1, dtype, 0, 1, s);
+    if (rc) return rc == 1 ? PACOH_ELIMIT : rc;
+    rc = trtri_ll_try(C1, i1, B, n1, dtype, s, nullptr, nullptr);                            // C1 = Z11
+    if (rc) return rc == 1 ? PACOH_ELIMIT : rc;
+    GemmArgs g1 = {A21, C1, T21, sA, s1, sx, n, n1, n1, n2, n1, n1, 0, 1, 0, 1, 1.0, 0.0, i1, 0};      // L21 = A21 Z11^T
+    launch_bgemm<T>(g1, B, s, 1);
+    launch_sub_copy<T>(A22, sA, n, C2, s2, n2, n2, n2, B, s);
+    GemmArgs g2 = {T21, T21, C2, sx, sx, s2, n1, n1, n2, n2, n2, n1, 0, 1, 0, 0, -1.0, 1.0, i1, 1};    // C2 = A22 - L21 L21^T
+    launch_bgemm<T>(g2, B, s, 1);
+    hipLaunchKernelGGL(blocked_resid2_kernel<T>, dim3((n2 + 3) / 4, B), dim3(256), 0, s, resid, (const T*)T21, (const T*)u1v, r2, n, n1, n2);
+    rc = dense_ll_try(C2, r2, lp2, u2v, i2, 1.0, B, n2, dtype, 0, 1, s);
+    if (rc) return rc == 1 ? PACOH_ELIMIT : rc;
+    hipLaunchKernelGGL(blocked_combine_kernel<T>, dim3(B), dim3(256), 0, s, (const int32_t*)i1, (const int32_t*)i2, (const T*)lp1, (const T*)lp2,
+                       (const T*)u1v, (const T*)u2v, info, logp, u_out, n, n1);
+    if (want_inv) {
+        rc = trtri_ll_try(C2, info, B, n2, dtype, s, nullptr, nullptr);                      // C2 = Z22
+        if (rc) return rc == 1 ? PACOH_ELIMIT : rc;
+        GemmArgs g3 = {T21, C1, A21, sx, s1, sA, n1, n1, n, n2, n1, n1, 0, 0, 0, 1, 1.0, 0.0, info, 0};        // X = L21 Z11 (into A's dead A21)
+        launch_bgemm<T>(g3, B, s, 1);
+        GemmArgs g4 = {C2, A21, T21, s2, sA, sx, n2, n, n1, n2, n1, n2, 0, 0, 1, 0, -1.0, 0.0, info, 0};       // Z21 = -Z22 X
+        launch_bgemm<T>(g4, B, s, 1);
+        launch_sub_copy<T>(T21, sx, n1, A21, sA, n, n2, n1, B, s);
+        launch_sub_copy<T>(C1, s1, n1, A, sA, n, n1, n1, B, s);
+        launch_sub_copy<T>(C2, s2, n2, A22, sA, n, n2, n2, B, s);
+    }
+    return launch_status();
+}
+
+// late[b] = the problems a LATER rung of the ladder solved (info > 0): the inverse stage's mask after chol_blocked(want_inv)
+__global__ void late_mask_kernel(const int32_t* __restrict__ info, int32_t* __restrict__ late, int B) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) late[b] = info[b] > 0 ? info[b] : -1;
+}
+
 template <typename T>
 int launch_trtri(T* A, const int32_t* info, int B, int n, int mpad, size_t lds, int saved_inv, hipStream_t s, const T* u = nullptr,
-                 T* alpha = nullptr, int* did_alpha = nullptr) {
+                 T* alpha = nullptr, int* did_alpha = nullptr, T* scratch = nullptr, size_t scratch_elems = 0) {
     // the left-looking kernel (dense_trtri_ll.hip) needs the inverse diagonal blocks the MFMA Cholesky kernels leave behind
     static const bool ll_on = []() { const char* e = getenv("PACOH_TRTRI_LL"); return !(e && e[0] == '0'); }();
     if (ll_on && saved_inv && n >= 97) {
         const int rc = trtri_ll_try(A, info, B, n, sizeof(T) == 4 ? PACOH_F32 : PACOH_F64, s, u, alpha);
         if (rc != 1) { if (did_alpha && u && alpha) *did_alpha = 1; return rc; }
+        const int rb = trtri_blocked<T>(A, info, B, n, scratch, scratch_elems, s);
+        if (rb != 1) return rb;
     }
 #define PACOH_TRTRI_LAUNCH(nt) do { auto kern = trtri_dense_kernel<T, nt>; \
         if (lds > 64u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
@@ -1055,6 +1231,10 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
                        (const T*)mean, mean_mode, n_valid, resid, P, n, total);
     const double jitter_base = dtype == PACOH_F32 ? 1e-6 : 1e-8;            // psd_safe_cholesky [gpytorch-upstream]
     const bool u_only = bwd && dense_chol_saves_inverse(n, dtype);          // alpha comes from Z afterwards (dense_alpha_kernel)
+    // 512 < n <= 1024: rung 0 of the ladder two-level on the left-looking kernels + the tiled GEMM (chol_blocked; its scratch is W's
+    // buffer, which only a call with gradients has); failures take the later rungs on the right-looking kernel as before
+    T* const cb_scratch = bwd ? Wm : (T*)((unsigned char*)zsc + align256((size_t)B * n * f * sizeof(T)));    // (forward only: its own region, see the workspace query)
+    const bool blocked = dense_chol_saves_inverse(n, dtype) && chol_blocked_plan<T>(B, n, bwd ? nn : chol_blocked_scratch<T>(B, n));
     for (int attempt = 0; attempt < 4; ++attempt) {
         if (attempt == 0) {
             // (RBF family: the tiles above the diagonal are skipped -- nothing downstream reads A's upper triangle)
@@ -1074,13 +1254,22 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
                                (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f, kind, B);
         }
         if (n_valid) hipLaunchKernelGGL(dense_mask_kernel<T>, dim3(n, B), dim3(256), 0, s, A, n_valid, y_div, (const int32_t*)info, attempt, n);
-        int rc = dense_chol_launch(A, resid, logp, bwd ? alpha : nullptr, info, 1.0, B, n, dtype, attempt, s, u_only ? 1 : 0);
+        int rc = (attempt == 0 && blocked) ? chol_blocked<T>(A, resid, logp, bwd ? alpha : nullptr, info, B, n, cb_scratch, bwd, s)
+                                           : dense_chol_launch(A, resid, logp, bwd ? alpha : nullptr, info, 1.0, B, n, dtype, attempt, s, u_only ? 1 : 0);
         if (rc) return rc;
     }
     if (bwd) {
         int did_alpha = 0;                             // (the left-looking inverse produces alpha = Z^T u on the way)
-        int rc = launch_trtri<T>(A, info, B, n, mpad, lds, dense_chol_saves_inverse(n, dtype) ? 1 : 0, s, u_only ? alpha : nullptr,
-                                 u_only ? resid : nullptr, &did_alpha);
+        int rc;
+        if (blocked) {
+            // the two-level factorisation left Z for what rung 0 solved; only what a later rung solved is still a factor (rare: the
+            // right-looking inverse, which exits at once for everybody else).  The mask lives at the head of rowpart, which the contraction kernels write later.
+            int32_t* late = reinterpret_cast<int32_t*>(rowpart);
+            hipLaunchKernelGGL(late_mask_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const int32_t*)info, late, B);
+            rc = launch_trtri<T>(A, late, B, n, mpad, lds, 1, s);
+        } else
+            rc = launch_trtri<T>(A, info, B, n, mpad, lds, dense_chol_saves_inverse(n, dtype) ? 1 : 0, s, u_only ? alpha : nullptr,
+                                 u_only ? resid : nullptr, &did_alpha, Wm, nn);                 // (W's buffer: free until W = Z^T Z)
         if (rc) return rc;
         if (u_only) {                                  // alpha = Z^T u into the residual buffer (free after the last factorisation attempt)
             if (!did_alpha)
@@ -1170,7 +1359,7 @@ int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int m
         if (rc) return rc;
     }
     {
-        int rc = launch_trtri<T>(A, info, B, n, mpad, lds, dense_chol_saves_inverse(n, dtype) ? 1 : 0, s);
+        int rc = launch_trtri<T>(A, info, B, n, mpad, lds, dense_chol_saves_inverse(n, dtype) ? 1 : 0, s, nullptr, nullptr, nullptr, V, nm);
         if (rc) return rc;
     }
     int rc = pacoh_gram_rbf_ard(z_ctx, z_div, z_tst, zt_div, ls, os, nullptr, 0, Kxs, B, P, n, m, f_arg, dtype, s);
@@ -1202,8 +1391,10 @@ extern "C" size_t pacoh_gp_lml_dense_workspace_bytes(int B, int n, int f, int dt
     if (B <= 0 || n <= 0 || f <= 0) return 0;
     const size_t e = dtype == PACOH_F64 ? 8 : 4;
     const size_t nn = (size_t)B * n * n;
+    // (forward only, 512 < n <= 1024: the two-level Cholesky's scratch, which a call with gradients finds in W's buffer)
+    const size_t cb = (!want_grad && n > 512 && n <= 1024) ? align256((dtype == PACOH_F64 ? chol_blocked_scratch<double>(B, n) : chol_blocked_scratch<float>(B, n)) * e) : 0;
     return align256(nn * e) * (want_grad ? 2 : 1) + 2 * align256((size_t)B * n * e) + align256((size_t)B * e) +
-           align256((size_t)B * n * (f + 3) * e) + align256((size_t)B * n * f * e) + 256;
+           align256((size_t)B * n * (f + 3) * e) + align256((size_t)B * n * f * e) + cb + 256;
 }
 
 extern "C" int pacoh_gp_lml_dense(const void* z, int z_div, const void* mean, int mean_mode, const void* y, int y_div,

@@ -205,6 +205,43 @@ def test_dense_jitter_ladder_fp64_all_rungs_in_one_launch(L, ragged):
 
 
 @pytest.mark.parametrize('ragged', [False, True])
+@pytest.mark.parametrize('n', [640, 1000])
+def test_dense_two_level_path_ladder_and_healthy_neighbours(L, n, ragged):
+    """512 < n <= 1024, fp32 (round 5): rung 0 of the ladder is the two-level factorisation + inverse on the left-looking kernels and
+    the tiled GEMM; a problem either sub-factorisation rejects takes the later rungs on the right-looking kernel and its inverse
+    through the late mask.  Identical points with a negative noise term are indefinite until the jitter exceeds |noise|: -5e-6 needs
+    rung 2 (1e-5), -1e-2 fails every rung.  info = [2, -1, 0, 0]; the healthy problems (one with the failing ones in its launch, one
+    alone) agree bit for bit and with the oracle; gradients finite where info >= 0, NaN for the failure"""
+    f = 3
+    gen = torch.Generator().manual_seed(n)
+    z = torch.zeros(4, n, f)
+    z[2] = torch.randn(n, f, generator=gen)
+    z[3] = z[2]
+    y = torch.randn(1, n, generator=gen)
+    ls = torch.ones(4, f)
+    noise = torch.tensor([-5e-6, -1e-2, 0.3, 0.3])
+    nv = n - 77 if ragged else n
+    n_valid = torch.tensor([nv], dtype=torch.int32, device=DEV) if ragged else None
+    out = L.gp_lml_fwdbwd(z.to(DEV), 1, None, L.MEAN_ZERO, y.to(DEV), 4, ls.to(DEV), None, noise.to(DEV), 4, 4, n_valid=n_valid, want_dz=True)
+    lml, info = out[0].cpu(), out[-1].cpu()
+    assert info.tolist() == [2, -1, 0, 0]
+    grads = [o.cpu() for o in out[1:-1] if o is not None]
+    for b in (0, 2, 3):
+        assert bool(torch.isfinite(lml[b])) and all(bool(torch.isfinite(gr[b]).all()) for gr in grads), b
+    assert bool(torch.isnan(lml[1]))
+    assert torch.equal(lml[2], lml[3]) and all(torch.equal(gr[2], gr[3]) for gr in grads)
+    ref = O.gp_mll(z[2, :nv].double(), torch.zeros(nv, dtype=torch.float64), y[0, :nv].double(), ls[2].double(),
+                   torch.tensor(1.0, dtype=torch.float64), noise[2].double())
+    assert abs(float(lml[2]) - float(ref)) < 5e-3 * abs(float(ref))
+    alone = L.gp_lml_fwdbwd(z[3:].to(DEV), 1, None, L.MEAN_ZERO, y.to(DEV), 1, ls[3:].to(DEV), None, noise[3:].to(DEV), 1, 1, n_valid=n_valid, want_dz=True)
+    assert torch.equal(alone[0].cpu()[0], lml[3])
+    # the jittered rank-one problem: log-density of 1 1^T + (noise + 1e-5) I (condition number ~1e8 in fp32: the factorisation is the error)
+    K = torch.ones(nv, nv, dtype=torch.float64) + (float(noise[0]) + 1e-5) * torch.eye(nv, dtype=torch.float64)
+    ref0 = torch.distributions.MultivariateNormal(torch.zeros(nv, dtype=torch.float64), K).log_prob(y[0, :nv].double()) / nv
+    assert abs(float(lml[0]) - float(ref0)) < 0.2 * abs(float(ref0))
+
+
+@pytest.mark.parametrize('ragged', [False, True])
 def test_dense_jitter_ladder_fp64_every_rung_and_the_failure_exit(L, ragged):
     """the fused ladder (chol_ll_retry_kernel: up to three more factorisations inside ONE launch, the matrix rebuilt in the
     workgroup before each) beyond its first rung: identical points with a NEGATIVE noise term make K = 1 1^T + (noise +
