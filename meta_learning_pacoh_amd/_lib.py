@@ -341,8 +341,8 @@ def _gp_lml_dense(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale,
     # batch is handed over as a RAGGED one of the next aligned size -- the padded rows become identity rows of the matrices, exactly what
     # the kernels do for tasks of unequal length -- and the outputs are cut back (round 5; PACOH_DENSE_PAD=0: as before).
     align = 4 if dt == torch.float32 else 2
-    # (512 < n < 1024, fp32: the two-level factorisation of round 5 wants the same alignment for its second sub-block)
-    if (97 <= n < 512 or (512 < n < 1024 and dt == torch.float32)) and n % align != 0 and os.environ.get('PACOH_DENSE_PAD', '1') != '0' \
+    # (512 < n < 1024: the two-level factorisation of round 5 wants the same alignment for its second sub-block)
+    if (97 <= n < 512 or 512 < n < 1024) and n % align != 0 and os.environ.get('PACOH_DENSE_PAD', '1') != '0' \
             and os.environ.get('PACOH_CHOL_LL', '1') != '0':
         npad = (n + align - 1) // align * align
         pad_rows = lambda t: torch.nn.functional.pad(t, (0, 0, 0, npad - n))              # [.., n, f] -> [.., npad, f]

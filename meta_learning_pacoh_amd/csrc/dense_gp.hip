@@ -1011,10 +1011,11 @@ __global__ void __launch_bounds__(256) dense_alpha_kernel(const T* __restrict__ 
 // rows x cols sub-matrices of a batch, 16 bytes per thread where both sides allow it
 template <typename T>
 __global__ void __launch_bounds__(256) sub_copy_kernel(const T* __restrict__ src, long ss, int lds_, T* __restrict__ dst, long sd, int ldd,
-                                                       int rows, int cols, int vec) {
+                                                       int rows, int cols, int vec, const int32_t* __restrict__ mask) {
     constexpr int VE = 16 / (int)sizeof(T);
     typedef T VT __attribute__((ext_vector_type(VE)));
     const long b = blockIdx.y;
+    if (mask && mask[b] < 0) return;
     const T* S = src + b * ss;
     T* D = dst + b * sd;
     if (vec) {
@@ -1033,12 +1034,13 @@ __global__ void __launch_bounds__(256) sub_copy_kernel(const T* __restrict__ src
     }
 }
 template <typename T>
-void launch_sub_copy(const T* src, long ss, int lds_, T* dst, long sd, int ldd, int rows, int cols, int B, hipStream_t s) {
+void launch_sub_copy(const T* src, long ss, int lds_, T* dst, long sd, int ldd, int rows, int cols, int B, hipStream_t s,
+                     const int32_t* mask = nullptr) {
     constexpr int VE = 16 / (int)sizeof(T);
     const bool vec = cols % VE == 0 && lds_ % VE == 0 && ldd % VE == 0 && ss % VE == 0 && sd % VE == 0 && ((size_t)src % 16) == 0 && ((size_t)dst % 16) == 0;
     long chunks = ((long)rows * (vec ? cols / VE : cols) + 255) / 256;
     if (chunks > 64) chunks = 64;
-    hipLaunchKernelGGL(sub_copy_kernel<T>, dim3((unsigned)chunks, B), dim3(256), 0, s, src, ss, lds_, dst, sd, ldd, rows, cols, vec ? 1 : 0);
+    hipLaunchKernelGGL(sub_copy_kernel<T>, dim3((unsigned)chunks, B), dim3(256), 0, s, src, ss, lds_, dst, sd, ldd, rows, cols, vec ? 1 : 0, mask);
 }
 
 // Z = L^-1 for 512 < n <= 1024 (round 5), two-level: Z = [Z11 0; -Z22 L21 Z11, Z22].  The diagonal sub-blocks (n1 = a multiple of 64,
@@ -1088,19 +1090,36 @@ __global__ void __launch_bounds__(256) blocked_resid2_kernel(const T* __restrict
     if (lane == 0) r2[b * (long)n2 + i] = resid[b * (long)n + n1 + i] - acc;
 }
 
-// the two sub-factorisations' verdicts, log-densities and u = L^-1 r as ONE problem's (attempt 0 of the jitter ladder)
+// the two sub-factorisations' verdicts, log-densities and u = L^-1 r as ONE problem's, at rung `rung` of the jitter ladder (rung > 0:
+// only the problems still marked failed take part -- info1 / info2 read `rung` where a sub-factorisation of this rung succeeded)
 template <typename T>
 __global__ void __launch_bounds__(256) blocked_combine_kernel(const int32_t* __restrict__ info1, const int32_t* __restrict__ info2,
                                                               const T* __restrict__ logp1, const T* __restrict__ logp2,
                                                               const T* __restrict__ u1, const T* __restrict__ u2, int32_t* __restrict__ info,
-                                                              T* __restrict__ logp, T* __restrict__ u, int n, int n1) {
+                                                              T* __restrict__ logp, T* __restrict__ u, int n, int n1, int rung,
+                                                              int32_t* __restrict__ act) {
     const long b = blockIdx.x;
-    const bool ok = info1[b] == 0 && info2[b] == 0;
-    if (threadIdx.x == 0) { info[b] = ok ? 0 : -1; logp[b] = ok ? logp1[b] + logp2[b] : T(NAN); }
+    if (rung > 0 && info[b] >= 0) { if (threadIdx.x == 0 && act) act[b] = -1; return; }     // solved at an earlier rung
+    const bool ok = info1[b] == rung && info2[b] == rung;
+    __syncthreads();
+    if (threadIdx.x == 0) { info[b] = ok ? rung : -1; logp[b] = ok ? logp1[b] + logp2[b] : T(NAN); if (act) act[b] = ok ? 0 : -1; }
     if (u) {
         const int n2 = n - n1;
         for (int q = threadIdx.x; q < n; q += 256) u[b * (long)n + q] = !ok ? T(NAN) : (q < n1 ? u1[b * (long)n1 + q] : u2[b * (long)n2 + (q - n1)]);
     }
+}
+
+// rung > 0: which problems run (info < 0).  run[b] = 0 / -1 (the "skip if negative" convention of the copies, products and inverses),
+// pre1 / pre2[b] = -1 / 0 (the factorisation kernels' own: at a rung > 0 they skip what reads >= 0)
+__global__ void blocked_need_kernel(const int32_t* __restrict__ info, int32_t* __restrict__ run, int32_t* __restrict__ pre1,
+                                    int32_t* __restrict__ pre2, int B) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) { const bool need = info[b] < 0; run[b] = need ? 0 : -1; pre1[b] = need ? -1 : 0; pre2[b] = need ? -1 : 0; }
+}
+// run1[b] = 0 where the first sub-factorisation of this rung succeeded for a problem that runs
+__global__ void blocked_stage_kernel(const int32_t* __restrict__ run, const int32_t* __restrict__ i1, int32_t* __restrict__ run1, int rung, int B) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) run1[b] = (run[b] == 0 && i1[b] == rung) ? 0 : -1;
 }
 
 // Cholesky + log-density + u = L^-1 r for 512 < n <= 1024 (round 5), rung 0 of the jitter ladder, two-level:
@@ -1129,50 +1148,61 @@ bool chol_blocked_plan(int B, int n, size_t scratch_elems) {
 // want_inv: go on to Z = L^-1 for the problems both sub-factorisations solved -- Z11 exists already, Z22 = L22^-1 in place,
 // Z21 = -Z22 (L21 Z11) -- and leave Z in A instead of L (no factor is written back: four of the block copies and the second
 // inversion of L11 that a separate inverse stage would need).  Without it (forward-only call) nothing reads A afterwards.
+// rung > 0: the same on the problems still marked failed (their A rebuilt with the rung's jitter by the caller), everybody else's
+// blocks, vectors and verdicts untouched: the copies, products and inverses take a run mask, the factorisation kernels their own
+// "skip what is solved" convention.  Used where no right-looking kernel exists for the later rungs (fp64 above n ~ 520).
 template <typename T>
-int chol_blocked(T* A, const T* resid, T* logp, T* u_out, int32_t* info, int B, int n, T* scratch, bool want_inv, hipStream_t s) {
+int chol_blocked(T* A, const T* resid, T* logp, T* u_out, int32_t* info, int B, int n, T* scratch, bool want_inv, int rung, hipStream_t s) {
     const int dtype = sizeof(T) == 4 ? PACOH_F32 : PACOH_F64;
     const int n1 = 64 * ((n + 127) / 128), n2 = n - n1;
     const size_t e1 = (size_t)B * n1 * n1, e2 = (size_t)B * n2 * n2, ex = (size_t)B * n2 * n1;
-    // scratch: C1 | C2 | T21 | r1 | r2 | u1 | u2 | logp1 | logp2 | info1, info2
+    // scratch: C1 | C2 | T21 | r1 | r2 | u1 | u2 | logp1 | logp2 | info1, info2 | run, run1, act
     T* C1 = scratch; T* C2 = C1 + e1; T* T21 = C2 + e2;
     T* r1 = T21 + ex; T* r2 = r1 + (size_t)B * n1;
     T* const u1v = r2 + (size_t)B * n2; T* const u2v = u1v + (size_t)B * n1;
     T* lp1 = u2v + (size_t)B * n2; T* lp2 = lp1 + B;
     int32_t* i1 = reinterpret_cast<int32_t*>(lp2 + B); int32_t* i2 = i1 + B;
+    int32_t* run = i2 + B; int32_t* run1 = run + B; int32_t* act = run1 + B;
     const long sA = (long)n * n, s1 = (long)n1 * n1, s2 = (long)n2 * n2, sx = (long)n2 * n1;
     T* const A21 = A + (long)n1 * n; T* const A22 = A21 + n1;
-    launch_sub_copy<T>(A, sA, n, C1, s1, n1, n1, n1, B, s);
-    launch_sub_copy<T>(resid, n, n, r1, n1, n1, 1, n1, B, s);
-    int rc = dense_ll_try(C1, r1, lp1, u1v, i1, 1.0, B, n1, dtype, 0, 1, s);
+    const unsigned gb = (unsigned)((B + 255) / 256);
+    const int32_t* m0 = nullptr;                      // who runs at all
+    if (rung > 0) { hipLaunchKernelGGL(blocked_need_kernel, dim3(gb), dim3(256), 0, s, (const int32_t*)info, run, i1, i2, B); m0 = run; }
+    launch_sub_copy<T>(A, sA, n, C1, s1, n1, n1, n1, B, s, m0);
+    launch_sub_copy<T>(resid, n, n, r1, n1, n1, 1, n1, B, s, m0);
+    int rc = dense_ll_try(C1, r1, lp1, u1v, i1, 1.0, B, n1, dtype, rung, 1, s);
     if (rc) return rc == 1 ? PACOH_ELIMIT : rc;
-    rc = trtri_ll_try(C1, i1, B, n1, dtype, s, nullptr, nullptr);                            // C1 = Z11
+    const int32_t* m1 = i1;                           // ... and got through the first sub-factorisation (rung 0: info1 = 0 / -1 is that mask)
+    if (rung > 0) { hipLaunchKernelGGL(blocked_stage_kernel, dim3(gb), dim3(256), 0, s, (const int32_t*)run, (const int32_t*)i1, run1, rung, B); m1 = run1; }
+    rc = trtri_ll_try(C1, m1, B, n1, dtype, s, nullptr, nullptr);                            // C1 = Z11
     if (rc) return rc == 1 ? PACOH_ELIMIT : rc;
-    GemmArgs g1 = {A21, C1, T21, sA, s1, sx, n, n1, n1, n2, n1, n1, 0, 1, 0, 1, 1.0, 0.0, i1, 0};      // L21 = A21 Z11^T
+    GemmArgs g1 = {A21, C1, T21, sA, s1, sx, n, n1, n1, n2, n1, n1, 0, 1, 0, 1, 1.0, 0.0, m1, 0};      // L21 = A21 Z11^T
     launch_bgemm<T>(g1, B, s, 1);
-    launch_sub_copy<T>(A22, sA, n, C2, s2, n2, n2, n2, B, s);
-    GemmArgs g2 = {T21, T21, C2, sx, sx, s2, n1, n1, n2, n2, n2, n1, 0, 1, 0, 0, -1.0, 1.0, i1, 1};    // C2 = A22 - L21 L21^T
+    launch_sub_copy<T>(A22, sA, n, C2, s2, n2, n2, n2, B, s, m0);
+    GemmArgs g2 = {T21, T21, C2, sx, sx, s2, n1, n1, n2, n2, n2, n1, 0, 1, 0, 0, -1.0, 1.0, m1, 1};    // C2 = A22 - L21 L21^T
     launch_bgemm<T>(g2, B, s, 1);
     hipLaunchKernelGGL(blocked_resid2_kernel<T>, dim3((n2 + 3) / 4, B), dim3(256), 0, s, resid, (const T*)T21, (const T*)u1v, r2, n, n1, n2);
-    rc = dense_ll_try(C2, r2, lp2, u2v, i2, 1.0, B, n2, dtype, 0, 1, s);
+    rc = dense_ll_try(C2, r2, lp2, u2v, i2, 1.0, B, n2, dtype, rung, 1, s);
     if (rc) return rc == 1 ? PACOH_ELIMIT : rc;
     hipLaunchKernelGGL(blocked_combine_kernel<T>, dim3(B), dim3(256), 0, s, (const int32_t*)i1, (const int32_t*)i2, (const T*)lp1, (const T*)lp2,
-                       (const T*)u1v, (const T*)u2v, info, logp, u_out, n, n1);
+                       (const T*)u1v, (const T*)u2v, info, logp, u_out, n, n1, rung, rung > 0 ? act : nullptr);
     if (want_inv) {
-        rc = trtri_ll_try(C2, info, B, n2, dtype, s, nullptr, nullptr);                      // C2 = Z22
+        const int32_t* m2 = rung > 0 ? act : info;    // ... and were solved at this rung (rung 0: info = 0 / -1 is that mask)
+        rc = trtri_ll_try(C2, m2, B, n2, dtype, s, nullptr, nullptr);                        // C2 = Z22
         if (rc) return rc == 1 ? PACOH_ELIMIT : rc;
-        GemmArgs g3 = {T21, C1, A21, sx, s1, sA, n1, n1, n, n2, n1, n1, 0, 0, 0, 1, 1.0, 0.0, info, 0};        // X = L21 Z11 (into A's dead A21)
+        GemmArgs g3 = {T21, C1, A21, sx, s1, sA, n1, n1, n, n2, n1, n1, 0, 0, 0, 1, 1.0, 0.0, m2, 0};          // X = L21 Z11 (into A's dead A21)
         launch_bgemm<T>(g3, B, s, 1);
-        GemmArgs g4 = {C2, A21, T21, s2, sA, sx, n2, n, n1, n2, n1, n2, 0, 0, 1, 0, -1.0, 0.0, info, 0};       // Z21 = -Z22 X
+        GemmArgs g4 = {C2, A21, T21, s2, sA, sx, n2, n, n1, n2, n1, n2, 0, 0, 1, 0, -1.0, 0.0, m2, 0};         // Z21 = -Z22 X
         launch_bgemm<T>(g4, B, s, 1);
-        launch_sub_copy<T>(T21, sx, n1, A21, sA, n, n2, n1, B, s);
-        launch_sub_copy<T>(C1, s1, n1, A, sA, n, n1, n1, B, s);
-        launch_sub_copy<T>(C2, s2, n2, A22, sA, n, n2, n2, B, s);
+        launch_sub_copy<T>(T21, sx, n1, A21, sA, n, n2, n1, B, s, m2);
+        launch_sub_copy<T>(C1, s1, n1, A, sA, n, n1, n1, B, s, m2);
+        launch_sub_copy<T>(C2, s2, n2, A22, sA, n, n2, n2, B, s, m2);
     }
     return launch_status();
 }
 
-// late[b] = the problems a LATER rung of the ladder solved (info > 0): the inverse stage's mask after chol_blocked(want_inv)
+// late[b] = the problems a LATER rung of the ladder solved on the right-looking kernel (info > 0): what is still a factor after
+// chol_blocked(want_inv) at rung 0
 __global__ void late_mask_kernel(const int32_t* __restrict__ info, int32_t* __restrict__ late, int B) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b < B) late[b] = info[b] > 0 ? info[b] : -1;
@@ -1225,16 +1255,19 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
     T* zsc = (T*)w;
     int mpad = 0;
     const size_t lds = trtri_lds<T>(n, &mpad);
-    if (bwd && lds > 160u * 1024u) return PACOH_ELIMIT;
     const long total = (long)B * n;
     hipLaunchKernelGGL(dense_resid_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T*)y, y_div,
                        (const T*)mean, mean_mode, n_valid, resid, P, n, total);
     const double jitter_base = dtype == PACOH_F32 ? 1e-6 : 1e-8;            // psd_safe_cholesky [gpytorch-upstream]
-    const bool u_only = bwd && dense_chol_saves_inverse(n, dtype);          // alpha comes from Z afterwards (dense_alpha_kernel)
     // 512 < n <= 1024: rung 0 of the ladder two-level on the left-looking kernels + the tiled GEMM (chol_blocked; its scratch is W's
-    // buffer, which only a call with gradients has); failures take the later rungs on the right-looking kernel as before
+    // buffer in a call with gradients).  Failures take the later rungs on the right-looking kernel where one exists for the size
+    // (two early-exit launches per rung when nothing failed); where none does -- fp64 above n ~ 520, which returned PACOH_ELIMIT for
+    // a call with gradients until round 5 -- the later rungs are two-level as well (ladder_blocked).
     T* const cb_scratch = bwd ? Wm : (T*)((unsigned char*)zsc + align256((size_t)B * n * f * sizeof(T)));    // (forward only: its own region, see the workspace query)
-    const bool blocked = dense_chol_saves_inverse(n, dtype) && chol_blocked_plan<T>(B, n, bwd ? nn : chol_blocked_scratch<T>(B, n));
+    const bool blocked = chol_blocked_plan<T>(B, n, bwd ? nn : chol_blocked_scratch<T>(B, n));
+    const bool ladder_blocked = blocked && !dense_chol_saves_inverse(n, dtype);
+    if (bwd && !ladder_blocked && lds > 160u * 1024u) return PACOH_ELIMIT;
+    const bool u_only = bwd && (blocked || dense_chol_saves_inverse(n, dtype));     // alpha comes from Z afterwards (dense_alpha_kernel)
     for (int attempt = 0; attempt < 4; ++attempt) {
         if (attempt == 0) {
             // (RBF family: the tiles above the diagonal are skipped -- nothing downstream reads A's upper triangle)
@@ -1254,16 +1287,18 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
                                (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f, kind, B);
         }
         if (n_valid) hipLaunchKernelGGL(dense_mask_kernel<T>, dim3(n, B), dim3(256), 0, s, A, n_valid, y_div, (const int32_t*)info, attempt, n);
-        int rc = (attempt == 0 && blocked) ? chol_blocked<T>(A, resid, logp, bwd ? alpha : nullptr, info, B, n, cb_scratch, bwd, s)
+        int rc = (blocked && (attempt == 0 || ladder_blocked)) ? chol_blocked<T>(A, resid, logp, bwd ? alpha : nullptr, info, B, n, cb_scratch, bwd, attempt, s)
                                            : dense_chol_launch(A, resid, logp, bwd ? alpha : nullptr, info, 1.0, B, n, dtype, attempt, s, u_only ? 1 : 0);
         if (rc) return rc;
     }
     if (bwd) {
         int did_alpha = 0;                             // (the left-looking inverse produces alpha = Z^T u on the way)
         int rc;
-        if (blocked) {
+        if (ladder_blocked) rc = 0;                    // (every rung left Z)
+        else if (blocked) {
             // the two-level factorisation left Z for what rung 0 solved; only what a later rung solved is still a factor (rare: the
-            // right-looking inverse, which exits at once for everybody else).  The mask lives at the head of rowpart, which the contraction kernels write later.
+            // right-looking inverse, which exits at once for everybody else).  The mask lives at the head of rowpart, which the
+            // contraction kernels write later.
             int32_t* late = reinterpret_cast<int32_t*>(rowpart);
             hipLaunchKernelGGL(late_mask_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const int32_t*)info, late, B);
             rc = launch_trtri<T>(A, late, B, n, mpad, lds, 1, s);
