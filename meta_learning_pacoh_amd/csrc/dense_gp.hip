@@ -1364,10 +1364,14 @@ int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int m
     T* V = (T*)w;                 w += align256(nm * sizeof(T));
     T* resid = (T*)w;             w += align256((size_t)B * n * sizeof(T));
     T* alpha = (T*)w;             w += align256((size_t)B * n * sizeof(T));
-    T* logp = (T*)w;
+    T* logp = (T*)w;              w += align256((size_t)B * sizeof(T));
+    T* const cb_scratch = (T*)w;                                           // (512 < n <= 1024 only, see the workspace query)
     int mpad = 0;
     const size_t lds = trtri_lds<T>(n, &mpad);
-    if (lds > 160u * 1024u) return PACOH_ELIMIT;
+    // 512 < n <= 1024: the two-level factorisation + inverse of lml_dense_impl (u = L^-1 r and Z come out of it, alpha = Z^T u)
+    const bool blocked = chol_blocked_plan<T>(B, n, chol_blocked_scratch<T>(B, n));
+    const bool ladder_blocked = blocked && !dense_chol_saves_inverse(n, dtype);
+    if (!ladder_blocked && lds > 160u * 1024u) return PACOH_ELIMIT;
     const long total = (long)B * n;
     hipLaunchKernelGGL(dense_resid_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T*)y, y_div,
                        (const T*)mean_ctx, mean_mode, n_valid, resid, P, n, total);
@@ -1378,7 +1382,7 @@ int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int m
                                               : pacoh_gram_rbf_ard(z_ctx, z_div, z_ctx, z_div, ls, os, noise, 1, A, B, P, n, n, f_arg, dtype, s);
             if (rc) return rc;
         } else {
-            if (attempt == 1) {
+            if (attempt == 1 && !blocked) {
                 const int rf = dense_chol_retry_fused(A, resid, logp, alpha, info, 1.0, B, n, dtype, 0, z_ctx, z_div, ls, os, noise, n_valid, y_div,
                                                       jitter_base, P, f, kind, s);
                 if (rf == 0) break;
@@ -1390,10 +1394,20 @@ int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int m
                                (const T*)os, (const T*)noise, (const int32_t*)info, (T)jit, A, P, n, f, kind, B);
         }
         if (n_valid) hipLaunchKernelGGL(dense_mask_kernel<T>, dim3(n, B), dim3(256), 0, s, A, n_valid, y_div, (const int32_t*)info, attempt, n);
-        int rc = dense_chol_launch(A, resid, logp, alpha, info, 1.0, B, n, dtype, attempt, s);
+        int rc = (blocked && (attempt == 0 || ladder_blocked)) ? chol_blocked<T>(A, resid, logp, alpha, info, B, n, cb_scratch, true, attempt, s)
+                                                               : dense_chol_launch(A, resid, logp, alpha, info, 1.0, B, n, dtype, attempt, s, blocked ? 1 : 0);
         if (rc) return rc;
     }
-    {
+    if (blocked) {
+        if (!ladder_blocked) {                         // what a later rung solved on the right-looking kernel is still a factor
+            int32_t* late = reinterpret_cast<int32_t*>(V);
+            hipLaunchKernelGGL(late_mask_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const int32_t*)info, late, B);
+            int rc = launch_trtri<T>(A, late, B, n, mpad, lds, 1, s);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(dense_alpha_kernel<T>, dim3((n + 63) / 64, B), dim3(256), 0, s, (const T*)A, (const T*)alpha, resid, (const int32_t*)info, n);
+        T* t = alpha; alpha = resid; resid = t;         // alpha = Z^T u (the two-level path hands over u)
+    } else {
         int rc = launch_trtri<T>(A, info, B, n, mpad, lds, dense_chol_saves_inverse(n, dtype) ? 1 : 0, s, nullptr, nullptr, nullptr, V, nm);
         if (rc) return rc;
     }
@@ -1454,8 +1468,9 @@ extern "C" int pacoh_gp_lml_dense(const void* z, int z_div, const void* mean, in
 extern "C" size_t pacoh_gp_predict_dense_workspace_bytes(int B, int n, int m, int dtype) {
     if (B <= 0 || n <= 0 || m <= 0) return 0;
     const size_t e = dtype == PACOH_F64 ? 8 : 4;
+    const size_t cb = (n > 512 && n <= 1024) ? align256((dtype == PACOH_F64 ? chol_blocked_scratch<double>(B, n) : chol_blocked_scratch<float>(B, n)) * e) : 0;
     return align256((size_t)B * n * n * e) + 2 * align256((size_t)B * n * m * e) + 2 * align256((size_t)B * n * e) +
-           align256((size_t)B * e) + 256;
+           align256((size_t)B * e) + cb + 256;
 }
 
 extern "C" int pacoh_gp_predict_dense(const void* z_ctx, int z_div, const void* mean_ctx, int mean_mode, const void* y, int y_div,

@@ -291,7 +291,9 @@ def test_dense_jitter_ladder_fp64_every_rung_and_the_failure_exit(L, ragged):
 @pytest.mark.parametrize('case', [(2, 2, 64, 130, 4), (1, 2, 200, 50, 2), (1, 1, 300, 7, 3),
                                   # m >= 96: V = Z K_xs and cov = K_ss - V^T V on the LDS-tiled GEMM (round 5) -- aligned rows (16-byte
                                   # staging loads), misaligned rows and ragged tile edges (scalar staging), more than one tile each way
-                                  (1, 2, 384, 128, 4), (1, 1, 333, 257, 2), (1, 2, 200, 130, 3)])
+                                  (1, 2, 384, 128, 4), (1, 1, 333, 257, 2), (1, 2, 200, 130, 3),
+                                  # 512 < n <= 1024: the two-level factorisation + inverse (fp64 had no path with an inverse here)
+                                  (1, 2, 640, 100, 3), (1, 1, 904, 40, 2)])
 def test_dense_predict(L, dtype, case):
     T, P, n, m, f = case
     B = T * P
