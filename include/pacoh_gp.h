@@ -140,7 +140,10 @@ int pacoh_mvn_logprob_dense(void* A, const void* resid, void* logp, void* alpha_
  * reference lines), for context sets beyond pacoh_gp_small_max_n(): Gram build -> MFMA-panel Cholesky -> in-place
  * triangular inverse -> K^-1 = Z^T Z (batched MFMA GEMM) -> gradient contractions.  d_lengthscale == NULL selects
  * forward only (lml, info).  workspace: the *_workspace_bytes() queries (O(B n^2)).
- * Limit: the 32-column factorisation panel must fit in LDS (n <= ~1000 fp32, ~520 fp64), else PACOH_ELIMIT. */
+ * Sizes: n <= 512 runs the left-looking Cholesky / inverse (one workgroup per matrix, rows of a multiple of 16 bytes); 512 < n <= 1024
+ * (same alignment) a two-level factorisation + inverse -- diagonal sub-blocks <= 512 on those kernels, the off-diagonal block on an
+ * LDS-tiled batched GEMM -- in both dtypes; other sizes the right-looking kernels of rounds 1-3, whose 32-column panel must fit in LDS
+ * (n <= ~1000 fp32, ~520 fp64), else PACOH_ELIMIT for a call that needs the inverse (gradients, predictive). */
 size_t pacoh_gp_lml_dense_workspace_bytes(int B, int n, int f, int dtype, int want_grad);
 int pacoh_gp_lml_dense(const void* z, int z_div, const void* mean, int mean_mode, const void* y, int y_div,
                        const void* lengthscale, const void* outputscale, const void* noise,
