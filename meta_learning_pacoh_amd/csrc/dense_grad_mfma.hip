@@ -1,4 +1,4 @@
-// Gradient contractions of the large-context path on the matrix cores, fp64, ARD-RBF, f <= 8 (round 4).
+// Gradient contractions of the large-context path on the matrix cores, ARD-RBF, f <= 8 (round 4: fp64; round 5: fp32 as well).
 //
 //   G = (alpha alpha^T - W) / 2n,  M = G o (os K),   d_z_i = sum_j M_ij (z_j - z_i),   d_os = sum_ij G_ij K_ij / os,  d_noise = sum_i G_ii
 //
@@ -23,15 +23,14 @@ namespace {
 
 constexpr int GT = 64;               // tile edge
 constexpr int GZL = 17;              // leading dimension of the coordinate images [64][16 (+1)]: 8 coordinates | 1 | zeros
-using Acc = f64x4_t;
 
-__device__ __forceinline__ int gm_row(int g, int q) { return g + 4 * q; }      // fp64 16x16x4 accumulator row = k index of step q
 
 // a - b * c with the product ROUNDED first (no fused multiply-add): sum_j M_ij z_j - z_i sum_j M_ij is exactly zero for a task of one
 // point (and for coincident points) only if both products are rounded alike -- the direct-difference kernel returned exact zeros there
-__device__ __forceinline__ double sub_rounded_product(double a, double b, double c) {
+template <typename T>
+__device__ __forceinline__ T sub_rounded_product(T a, T b, T c) {
 #pragma clang fp contract(off)
-    const double p = b * c;
+    const T p = b * c;
     return a - p;
 }
 
@@ -44,15 +43,18 @@ __device__ __forceinline__ int clamp_nv2(const int32_t* n_valid, long ty, int n)
 // number of tiles (I, J), J < I, in front of row block I
 __host__ __device__ inline int tiles_before(int I) { return I * (I - 1) / 2; }
 
-__global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* __restrict__ zs, const double* __restrict__ osp,
+template <typename T>
+__global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const T* __restrict__ zs, const T* __restrict__ osp,
                                                               const int32_t* __restrict__ n_valid, int y_div,
-                                                              const double* __restrict__ alpha, const double* __restrict__ Wm,
-                                                              const int32_t* __restrict__ info, double* __restrict__ rowside,
-                                                              double* __restrict__ colpart, double* __restrict__ gdiag, int P, int n,
+                                                              const T* __restrict__ alpha, const T* __restrict__ Wm,
+                                                              const int32_t* __restrict__ info, T* __restrict__ rowside,
+                                                              T* __restrict__ colpart, T* __restrict__ gdiag, int P, int n,
                                                               int f) {
-    __shared__ double ZI[GT][GZL], ZJ[2][GT][GZL], n2I[GT], n2J[2][GT], aI[GT], aJ[2][GT];
-    __shared__ double Tr[4][16][17];
-    __shared__ double Rows[GT][GZL];
+    using Acc = typename Mf<T>::acc;
+    auto gm_row = [](int g_, int q_) { return Mf<T>::row(g_, q_); };       // accumulator row of register q = the k index of step q
+    __shared__ T ZI[GT][GZL], ZJ[2][GT][GZL], n2I[GT], n2J[2][GT], aI[GT], aJ[2][GT];
+    __shared__ T Tr[4][16][17];
+    __shared__ T Rows[GT][GZL];
     // grid (problems, row blocks), LONGEST row block first.  Workgroups go to the eight XCDs round-robin in linear-id order: with the
     // row block as the fast index and eight row blocks (n = 512) XCD k received every workgroup of row block k -- 1 tile each on XCD
     // 0, 8 tiles each on XCD 7, which then ran 1.8 x the balanced time (267 us; this order: see profiles/r05_dense_kernel_stats_fp64.csv).
@@ -63,25 +65,25 @@ __global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* _
     const int r = lane & 15, g = lane >> 4;
     if (info[b] < 0) return;                               // (the combine kernel writes the NaNs)
     const int nv = clamp_nv2(n_valid, b / y_div, n);
-    const double os = osp ? osp[b % P] : 1.0;
-    const double inv2n = nv > 0 ? 0.5 / (double)nv : 0.0;
-    const double* zb = zs + b * (long)n * f;
-    const double* ab = alpha + b * (long)n;
-    const double* Wb = Wm + b * (long)n * n;
+    const T os = osp ? osp[b % P] : 1.0;
+    const T inv2n = nv > 0 ? T(0.5) / (T)nv : 0.0;
+    const T* zb = zs + b * (long)n * f;
+    const T* ab = alpha + b * (long)n;
+    const T* Wb = Wm + b * (long)n * n;
 
-    auto stage = [&](double (*Z)[GZL], double* n2, double* al, int R0) {
+    auto stage = [&](T (*Z)[GZL], T* n2, T* al, int R0) {
         // rows R0 .. R0 + 64 of the scaled coordinates: [c < f] coordinates, [8] = 1, rest 0; rows beyond nv: all zero (no weight)
         for (int e = tid; e < GT * 16; e += 256) {
             const int i = e >> 4, c = e & 15;
             const int row = R0 + i;
-            double v = 0.0;
+            T v = 0.0;
             if (row < nv) v = c < f ? zb[(long)row * f + c] : (c == 8 ? 1.0 : 0.0);
             Z[i][c] = v;
         }
         if (tid < GT) {
             const int row = R0 + tid;
-            double s = 0.0;
-            if (row < nv) for (int c = 0; c < f; ++c) { const double v = zb[(long)row * f + c]; s = fma(v, v, s); }
+            T s = 0.0;
+            if (row < nv) for (int c = 0; c < f; ++c) { const T v = zb[(long)row * f + c]; s = fma(v, v, s); }
             n2[tid] = s;
             al[tid] = row < nv ? ab[row] : 0.0;
         }
@@ -93,7 +95,7 @@ __global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* _
     for (int ib = 0; ib < 4; ++ib) rowacc[ib] = Acc{0, 0, 0, 0};
     const int j = 16 * w + r;                              // this lane's column inside a tile
     // this lane's entries of W for one 16 x 16 block: unconditional loads at clamped addresses, requested one block ahead
-    auto load_w = [&](int J0, int ib, double (&wv)[4]) __attribute__((always_inline)) {
+    auto load_w = [&](int J0, int ib, T (&wv)[4]) __attribute__((always_inline)) {
         const int jc = J0 + j < n ? J0 + j : n - 1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -106,12 +108,12 @@ __global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* _
         const int J0 = J * GT, cur = J & 1;
         __syncthreads();                                   // tile J's coordinates are staged; the other buffer's readers are done
         if (J < I) stage(ZJ[cur ^ 1], n2J[cur ^ 1], aJ[cur ^ 1], J0 + GT);      // next tile's coordinates fly under this tile's work
-        double (*Zj)[GZL] = ZJ[cur];
-        const double* n2j = n2J[cur];
-        const double* aj = aJ[cur];
+        T (*Zj)[GZL] = ZJ[cur];
+        const T* n2j = n2J[cur];
+        const T* aj = aJ[cur];
         const bool diag = J == I;
         Acc oj = {0, 0, 0, 0};
-        double wv[2][4];
+        T wv[2][4];
         load_w(J0, 0, wv[0]);
         // (Also measured and dropped: eight waves per workgroup sharing an LDS image of the M tile -- one accumulator per side and wave,
         //  128 registers, four waves per SIMD, two workgroup barriers per tile instead of eight wave-level waits: 336 us.)
@@ -124,16 +126,16 @@ __global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* _
             Acc s = {0, 0, 0, 0};
 #pragma unroll
             for (int st = 0; st < 2; ++st)
-                s = __builtin_amdgcn_mfma_f64_16x16x4f64(ZI[16 * ib + r][4 * st + g], Zj[16 * w + r][4 * st + g], s, 0, 0, 0);
+                s = Mf<T>::mma(ZI[16 * ib + r][4 * st + g], Zj[16 * w + r][4 * st + g], s);
             Acc M;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = 16 * ib + gm_row(g, q);
                 const bool ok = I0 + i < nv && J0 + j < nv;
-                double d2 = n2I[i] + n2j[j] - 2.0 * s[q];
+                T d2 = n2I[i] + n2j[j] - 2.0 * s[q];
                 d2 = d2 > 0.0 ? d2 : 0.0;
-                const double e = rbf_exp<double>(-0.5 * d2);
-                const double G = ok ? (aI[i] * aj[j] - wv[ib & 1][q]) * inv2n : 0.0;
+                const T e = rbf_exp<T>(-0.5 * d2);
+                const T G = ok ? (aI[i] * aj[j] - wv[ib & 1][q]) * inv2n : 0.0;
                 if (diag && i == j && ok) gdiag[b * (long)n + I0 + i] = G;
                 M[q] = G * os * e;
             }
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* _
             if (!diag) {
 #pragma unroll
                 for (int st = 0; st < 4; ++st)
-                    oj = __builtin_amdgcn_mfma_f64_16x16x4f64(M[st], ZI[16 * ib + gm_row(g, st)][r], oj, 0, 0, 0);
+                    oj = Mf<T>::mma(M[st], ZI[16 * ib + gm_row(g, st)][r], oj);
             }
             // rows of I <- M [Z_J | 1]: M's block through the wave's 16 x 17 scratch (A operand = M itself)
 #pragma unroll
@@ -150,18 +152,18 @@ __global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* _
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int st = 0; st < 4; ++st)
-                rowacc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(Tr[w][r][gm_row(g, st)], Zj[16 * w + gm_row(g, st)][r], rowacc[ib], 0, 0, 0);
+                rowacc[ib] = Mf<T>::mma(Tr[w][r][gm_row(g, st)], Zj[16 * w + gm_row(g, st)][r], rowacc[ib]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
         if (!diag) {
             // oj: lane (r, g) register q = sum_i M[i][jj] [Z_I | 1][i][c = r], jj = 16 w + row(g, q)
-            double* cp = colpart + ((b * (long)(nI * (nI - 1) / 2) + tiles_before(I) + J) * GT) * 9;
+            T* cp = colpart + ((b * (long)(nI * (nI - 1) / 2) + tiles_before(I) + J) * GT) * 9;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int jj = 16 * w + gm_row(g, q);
-                const double cs = __shfl(oj[q], 16 * g + 8, 64);          // column sum of M (the ones column, c = 8)
-                if (r < 8) cp[(long)jj * 9 + r] = sub_rounded_product(oj[q], Zj[jj][r], cs);
+                const T cs = __shfl(oj[q], 16 * g + 8, 64);          // column sum of M (the ones column, c = 8)
+                if (r < 8) cp[(long)jj * 9 + r] = sub_rounded_product<T>(oj[q], Zj[jj][r], cs);
                 else if (r == 8) cp[(long)jj * 9 + 8] = cs;
             }
         }
@@ -174,7 +176,7 @@ __global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* _
             for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    double* p = &Rows[16 * ib + gm_row(g, q)][r];
+                    T* p = &Rows[16 * ib + gm_row(g, q)][r];
                     *p = (ww == 0 ? 0.0 : *p) + rowacc[ib][q];
                 }
         }
@@ -182,7 +184,7 @@ __global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* _
     __syncthreads();
     for (int e = tid; e < GT * 9; e += 256) {
         const int i = e / 9, c = e - i * 9;
-        if (I0 + i < n) rowside[(b * (long)n + I0 + i) * 9 + c] = c < 8 ? sub_rounded_product(Rows[i][c], ZI[i][c], Rows[i][8]) : Rows[i][8];
+        if (I0 + i < n) rowside[(b * (long)n + I0 + i) * 9 + c] = c < 8 ? sub_rounded_product<T>(Rows[i][c], ZI[i][c], Rows[i][8]) : Rows[i][8];
     }
 }
 
@@ -191,13 +193,14 @@ __global__ void __launch_bounds__(256, 3) dense_grad_tile_kernel(const double* _
 // One thread per (row, sum c = 0..8): consecutive threads read consecutive doubles of rowside [row][9] and of a tile's partials
 // [64][9] (round 5; one thread per row walking its nine sums read 72-byte strides and took 36.5 us per 256 x 512 launch).
 constexpr int GC_ROWS = 28;          // rows per 256-thread workgroup (252 threads busy)
-__global__ void __launch_bounds__(256) dense_grad_combine_kernel(const double* __restrict__ zs, const double* __restrict__ lsp,
-                                                                 const double* __restrict__ osp, const int32_t* __restrict__ n_valid,
-                                                                 int y_div, const double* __restrict__ g_lml,
-                                                                 const double* __restrict__ alpha, const int32_t* __restrict__ info,
-                                                                 const double* __restrict__ rowside, const double* __restrict__ colpart,
-                                                                 const double* __restrict__ gdiag, double* __restrict__ d_z,
-                                                                 double* __restrict__ d_mean, int mean_mode, double* __restrict__ rowpart,
+template <typename T>
+__global__ void __launch_bounds__(256) dense_grad_combine_kernel(const T* __restrict__ zs, const T* __restrict__ lsp,
+                                                                 const T* __restrict__ osp, const int32_t* __restrict__ n_valid,
+                                                                 int y_div, const T* __restrict__ g_lml,
+                                                                 const T* __restrict__ alpha, const int32_t* __restrict__ info,
+                                                                 const T* __restrict__ rowside, const T* __restrict__ colpart,
+                                                                 const T* __restrict__ gdiag, T* __restrict__ d_z,
+                                                                 T* __restrict__ d_mean, int mean_mode, T* __restrict__ rowpart,
                                                                  int P, int n, int f) {
     const long b = blockIdx.y;
     const int t = threadIdx.x, lr = t / 9, c = t - 9 * lr;
@@ -206,11 +209,11 @@ __global__ void __launch_bounds__(256) dense_grad_combine_kernel(const double* _
     const int p = (int)(b % P);
     const int nv = clamp_nv2(n_valid, b / y_div, n);
     const bool failed = info[b] < 0;
-    const double gup = g_lml ? g_lml[b] : 1.0;
+    const T gup = g_lml ? g_lml[b] : 1.0;
     const int W3 = f + 3;
-    double* rp = rowpart + (b * n + i) * (long)W3;
+    T* rp = rowpart + (b * n + i) * (long)W3;
     if (failed || i >= nv) {
-        const double v = failed ? (double)NAN : 0.0;
+        const T v = failed ? T(NAN) : 0.0;
         if (c < f) { if (d_z) d_z[(b * n + i) * (long)f + c] = v; rp[c] = v; }
         if (c == 8) {
             if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = v;
@@ -219,20 +222,20 @@ __global__ void __launch_bounds__(256) dense_grad_combine_kernel(const double* _
         return;
     }
     const int nI = (n + GT - 1) / GT, Ji = i / GT, il = i - Ji * GT;
-    double acc = rowside[(b * (long)n + i) * 9 + c];
+    T acc = rowside[(b * (long)n + i) * 9 + c];
     for (int I = Ji + 1; I < nI; ++I)
         acc += colpart[((b * (long)(nI * (nI - 1) / 2) + tiles_before(I) + Ji) * GT + il) * 9 + c];
     if (c < f) {
-        const double* zb = zs + b * (long)n * f;
+        const T* zb = zs + b * (long)n * f;
         if (d_z) d_z[(b * n + i) * (long)f + c] = 2.0 * gup * acc / lsp[(long)p * f + c];
         rp[c] = -2.0 * (zb[(long)i * f + c] - zb[c]) * acc;            // (lengthscale sums from the finished d_z sums, as dense_grad_cols_kernel)
     } else if (c == 8) {
-        const double os = osp ? osp[p] : 1.0;
-        const double ai = alpha[b * (long)n + i];
+        const T os = osp ? osp[p] : 1.0;
+        const T ai = alpha[b * (long)n + i];
         rp[f] = acc / os;                                  // sum_j G_ij K_ij / os = sum_j M_ij / os
         rp[f + 1] = gdiag[b * (long)n + i];
         rp[f + 2] = ai;
-        if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = gup * ai / (double)nv;
+        if (d_mean && mean_mode == PACOH_MEAN_VECTOR) d_mean[b * n + i] = gup * ai / (T)nv;
     }
 }
 
@@ -249,6 +252,8 @@ template <bool MIRROR>
 __global__ void __launch_bounds__(256, 4) dense_gram_tile_kernel(const double* __restrict__ z, int z_div, const double* __restrict__ lsp,
                                                                  const double* __restrict__ osp, const double* __restrict__ noisep,
                                                                  double* __restrict__ K, int P, int n, int f) {
+    using Acc = f64x4_t;
+    auto gm_row = [](int g_, int q_) { return Mf<double>::row(g_, q_); };
     __shared__ double ZI[GT][GZL], ZJ[GT][GZL], n2I[GT], n2J[GT];
     __shared__ double Tr[MIRROR ? 4 : 1][16][17];
     const long b = blockIdx.y;
@@ -338,31 +343,42 @@ int dense_gram_mfma_full(const void* z, int z_div, const void* ls, const void* o
 }
 
 // scratch the two kernels need (bytes): rowside [B][n][9] | column-side partials [B][tiles][64][9] | G_ii [B][n]
-size_t dense_grad_mfma_scratch(int B, int n) {
+size_t dense_grad_mfma_scratch(int B, int n, int dtype) {
     const size_t nI = (n + GT - 1) / GT;
-    return ((size_t)B * n * 9 + (size_t)B * (nI * (nI - 1) / 2) * GT * 9 + (size_t)B * n) * sizeof(double);
+    return ((size_t)B * n * 9 + (size_t)B * (nI * (nI - 1) / 2) * GT * 9 + (size_t)B * n) * (dtype == PACOH_F64 ? 8 : 4);
 }
 
 // does the MFMA contraction take this call?  (the caller asks before it builds W: the tile kernel reads W's lower 64-tiles only)
+// fp32 since round 5: the squared distances from one product cost ~1e-7 |z|^2 there -- harmless in the contraction, whose kernel
+// entries only weight sums (the Gram matrix that is FACTORED keeps its direct differences in fp32: dense_gram_mfma_try)
 bool dense_grad_mfma_plan(int B, int n, int f, int kind, int dtype, size_t scratch_bytes) {
-    return dtype == PACOH_F64 && kind == PACOH_KERNEL_RBF && f <= 8 && n >= GT && dense_grad_mfma_scratch(B, n) <= scratch_bytes;
+    static const bool f32_on = []() { const char* e = getenv("PACOH_GRAD_MFMA_F32"); return !(e && e[0] == '0'); }();
+    return (dtype == PACOH_F64 || f32_on) && kind == PACOH_KERNEL_RBF && f <= 8 && n >= GT && dense_grad_mfma_scratch(B, n, dtype) <= scratch_bytes;
 }
 
-// fp64, ARD-RBF, f <= 8: the MFMA contraction; returns 1 when outside its plan (caller: dense_grad_cols / rows kernels)
+template <typename T>
+static int grad_mfma_launch(const void* zs, const void* ls, const void* os, const int32_t* n_valid, int y_div, const void* g_lml,
+                            const void* alpha, const void* Wm, const int32_t* info, void* d_z, void* d_mean, int mean_mode, void* rowpart,
+                            void* scratch, int B, int P, int n, int f, hipStream_t s) {
+    const int nI = (n + GT - 1) / GT;
+    T* rowside = (T*)scratch;
+    T* colpart = rowside + (size_t)B * n * 9;
+    T* gdiag = colpart + (size_t)B * ((size_t)nI * (nI - 1) / 2) * GT * 9;
+    hipLaunchKernelGGL(dense_grad_tile_kernel<T>, dim3(B, nI), dim3(256), 0, s, (const T*)zs, (const T*)os, n_valid, y_div,
+                       (const T*)alpha, (const T*)Wm, info, rowside, colpart, gdiag, P, n, f);
+    hipLaunchKernelGGL(dense_grad_combine_kernel<T>, dim3((n + GC_ROWS - 1) / GC_ROWS, B), dim3(256), 0, s, (const T*)zs, (const T*)ls,
+                       (const T*)os, n_valid, y_div, (const T*)g_lml, (const T*)alpha, info, rowside, colpart, gdiag,
+                       (T*)d_z, (T*)d_mean, mean_mode, (T*)rowpart, P, n, f);
+    return launch_status();
+}
+
+// ARD-RBF, f <= 8: the MFMA contraction; returns 1 when outside its plan (caller: dense_grad_cols / rows kernels)
 int dense_grad_mfma_try(const void* zs, const void* ls, const void* os, const int32_t* n_valid, int y_div, const void* g_lml,
                         const void* alpha, const void* Wm, const int32_t* info, void* d_z, void* d_mean, int mean_mode, void* rowpart,
                         void* scratch, size_t scratch_bytes, int B, int P, int n, int f, int kind, int dtype, hipStream_t s) {
     if (!dense_grad_mfma_plan(B, n, f, kind, dtype, scratch_bytes)) return 1;
-    const int nI = (n + GT - 1) / GT;
-    double* rowside = (double*)scratch;
-    double* colpart = rowside + (size_t)B * n * 9;
-    double* gdiag = colpart + (size_t)B * ((size_t)nI * (nI - 1) / 2) * GT * 9;
-    hipLaunchKernelGGL(dense_grad_tile_kernel, dim3(B, nI), dim3(256), 0, s, (const double*)zs, (const double*)os, n_valid, y_div,
-                       (const double*)alpha, (const double*)Wm, info, rowside, colpart, gdiag, P, n, f);
-    hipLaunchKernelGGL(dense_grad_combine_kernel, dim3((n + GC_ROWS - 1) / GC_ROWS, B), dim3(256), 0, s, (const double*)zs, (const double*)ls,
-                       (const double*)os, n_valid, y_div, (const double*)g_lml, (const double*)alpha, info, rowside, colpart, gdiag,
-                       (double*)d_z, (double*)d_mean, mean_mode, (double*)rowpart, P, n, f);
-    return launch_status();
+    return dtype == PACOH_F64 ? grad_mfma_launch<double>(zs, ls, os, n_valid, y_div, g_lml, alpha, Wm, info, d_z, d_mean, mean_mode, rowpart, scratch, B, P, n, f, s)
+                              : grad_mfma_launch<float>(zs, ls, os, n_valid, y_div, g_lml, alpha, Wm, info, d_z, d_mean, mean_mode, rowpart, scratch, B, P, n, f, s);
 }
 
 }  // namespace pacoh
