@@ -561,7 +561,10 @@ void launch_ztz(const T* Z, T* W, int n, const int32_t* info, int Bn, hipStream_
 // slab's global loads in flight under this slab's MFMAs.  An operand stored k-major (transA / !transB: a slab row is contiguous) is
 // staged by 16-byte loads and 16-byte LDS stores; stored i-major (!transA / transB: 16 bytes = 4 / 2 consecutive k of one row) it
 // is transposed on the way into LDS (consecutive lanes = consecutive rows: conflict-free scalar stores).  Stored-lower operands
-// clip the tile's k range and are masked where a slab crosses their diagonal.  bgemm_kernel above -- one wave per 32 x 32 tile,
+// clip the tile's k range and are masked where a slab crosses their diagonal.  (Tried on the n = 784 fp32 two-level call: loads two
+// slabs ahead through a second register set -- 256 registers, two workgroups per CU: 2.34 -> 2.48 ms at 128 problems, 1.20 -> 1.19 at
+// 16; edge tiles that multiply only the row blocks inside the matrix, as a switch over seven ztz_slab masks -- 206 registers in
+// fp32, 347 spilled in fp64: not measured.)  bgemm_kernel above -- one wave per 32 x 32 tile,
 // operands straight from L2 -- ran the predictive's V = Z K_xs at 18 TFLOP/s in fp32; it stays for outputs narrower than a tile.
 template <typename T>
 __global__ void __launch_bounds__(256, 2) gemm_tile_kernel(GemmArgs ga, int tiles_n, int nt, int Bn) {
