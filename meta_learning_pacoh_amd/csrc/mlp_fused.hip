@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_fwd_kernel(FusedArgs a) {
     const FusedNet& nt = a.net[blockIdx.z];
     const int p = blockIdx.y;
     fused_load_weights<NH>(wl, a.theta + (long)p * a.theta_stride + nt.theta_off, a, nt.d_out);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (uniform: the tile loop and every stash address on the scalar unit)
     const int r = lane & 15, g = lane >> 4;
     float* st = stage[wave];
     const float* wo = wl + f_off_out(NH);
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(256, MINW) mlp_fused_bwd_kernel(FusedArgs a) {
     const FusedNet& nt = a.net[blockIdx.z];
     const int p = blockIdx.y;
     fused_load_weights<NH>(wl, a.theta + (long)p * a.theta_stride + nt.theta_off, a, nt.d_out);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
     float* st = lds + L_WL + wave * (16 * PB * TSTAGE);
     float* sc0 = lds + L_WL + L_ST + wave * (2 * TRS);
