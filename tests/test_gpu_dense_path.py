@@ -1,6 +1,8 @@
 """Large-n GP path (every n x n matrix materialised in HBM: gram -> MFMA-panel Cholesky -> triangular inverse -> batched MFMA
 GEMM -> gradient contractions; csrc/dense_gp.hip) against the CPU oracle: same checks as the LDS-resident kernels, at sizes
 beyond their limit and -- with the routing forced -- at small sizes where both device paths must agree."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -249,6 +251,29 @@ def test_dense_two_level_path_ladder_and_healthy_neighbours(L, n, dtype, ragged)
     K = torch.ones(nv, nv, dtype=torch.float64) + (float(noise[0]) + jit2) * torch.eye(nv, dtype=torch.float64)
     ref0 = torch.distributions.MultivariateNormal(torch.zeros(nv, dtype=torch.float64), K).log_prob(y[0, :nv].double()) / nv
     assert abs(float(lml[0]) - float(ref0)) < (1e-3 if f64 else 0.2) * abs(float(ref0))
+
+
+def test_two_level_path_is_what_ran(L):
+    """PACOH_CHOL_BLOCKED=0 PACOH_TRTRI_BLOCKED=0 select the right-looking kernels at n = 640 fp32: the two runs must agree to rounding
+    AND differ in the last bits, or the switch (and with it the claim that the two-level path ran in the tests above) is dead.  (The
+    tiled GEMM has no such test: it accumulates k in the order of the kernel it replaces and returns the same bits --
+    profiles/r05_dense_big_n.txt shows it by name.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch, sys; sys.path.insert(0, '.'); from meta_learning_pacoh_amd import _lib as L\n"
+            "g = torch.Generator().manual_seed(5)\n"
+            "n = 640; z = torch.randn(2, n, 3, generator=g).cuda(); y = torch.randn(1, n, generator=g).cuda()\n"
+            "ls = torch.ones(2, 3).cuda(); nz = torch.tensor([0.3, 0.2]).cuda()\n"
+            "out = L.gp_lml_fwdbwd(z, 1, None, L.MEAN_ZERO, y, 2, ls, None, nz, 2, 2, want_dz=True); torch.cuda.synchronize()\n"
+            "print(repr(float(out[0][0])), repr(float(out[1][1, 17, 2])), repr(float(out[3][0, 1])))\n")
+    outs = []
+    for env in (dict(os.environ), dict(os.environ, PACOH_CHOL_BLOCKED='0', PACOH_TRTRI_BLOCKED='0')):
+        res = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, check=True)
+        outs.append([float(v) for v in res.stdout.split()])
+    a, b = outs
+    assert all(abs(x - y) <= 2e-3 * max(abs(y), 1e-3) for x, y in zip(a, b)), (a, b)
+    assert a != b, a
 
 
 @pytest.mark.parametrize('ragged', [False, True])
