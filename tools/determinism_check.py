@@ -17,7 +17,7 @@ def rep(name, fn, n=30):
 
 g = torch.Generator().manual_seed(3)
 total = 0
-for n, T, P, dt in ((64, 256, 20, torch.float32), (48, 256, 20, torch.float32), (128, 64, 10, torch.float32), (96, 64, 10, torch.float32), (512, 32, 1, torch.float64), (300, 32, 2, torch.float32)):
+for n, T, P, dt in ((64, 256, 20, torch.float32), (48, 256, 20, torch.float32), (128, 64, 10, torch.float32), (96, 64, 10, torch.float32), (512, 32, 1, torch.float64), (300, 32, 2, torch.float32), (784, 8, 2, torch.float32)):
     f = 2
     B = T * P
     z = torch.randn(B, n, f, generator=g, dtype=dt).cuda(); mean = (0.3 * torch.randn(B, n, generator=g, dtype=dt)).cuda()
