@@ -44,6 +44,15 @@ struct GpMfmaArgs {            // (same struct as in gp_small.hip / gp_mfma.hip)
     int B, P, n, f;
 };
 
+// the test side of a posterior-predictive call (gp_reg_predict_kernel): test inputs [B / zt_div, m, f], the prior mean at them
+// (mean_mode of GpMfmaArgs: [B, m] or [P]), outputs mu / var [B, m]
+struct GpPredArgs {
+    const float* zt; int zt_div;
+    const float* mean_tst;
+    float* mu; float* var;
+    int m;
+};
+
 namespace gpreg {
 
 
@@ -229,10 +238,16 @@ __host__ __device__ constexpr int uidx(int NB, int K, int J) { return K * NB - K
 // Ctx: lane() = lane of the wave, block() = problem index b, late<T>(a.field, offset of it) = that field, read late.
 // zf [16 NB FP], rv / av [16 NB], fsc [128], tsc [320], dzc [BWD ? 16 NB FP : 1], Wl [BWD && NB > 1 ? (NU - NB) 256 : 4]: per-wave
 // LDS scratch (16-byte aligned).
-template <int NB, int FP, bool BWD, bool HAS_OS, class Ctx>
+// PRED (round 5): the posterior predictive instead of the gradients -- mu_s = m_s + k_s^T alpha, var_s = os + noise - k_s^T K^-1 k_s for
+// the m test points of *pa, 16 at a time: the kernel entries K_xs of a test block against every context block (accumulator layout:
+// context rows x test columns), T = K^-1 K_xs as NB^2 block products with the blocks of W = K^-1 parked in LDS (all NU of them: Wl
+// [NU 256]), the two contractions with K_xs on the vector units.  n <= 64 (the parked form).  The LDS-resident general kernel it
+// replaces for these shapes ran 20 480 problems of n = m = 64 in 1.85 ms; the LML + gradient kernel takes 0.14 for the same batch.
+template <int NB, int FP, bool BWD, bool HAS_OS, class Ctx, bool PRED = false>
 __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, float* zf, float* rv,
                                             float* av, float* fsc, float* tsc,
-                                            float* dzc, float* Wl) {
+                                            float* dzc, float* Wl, const GpPredArgs* pa = nullptr) {
+    static_assert(!PRED || (BWD && NB <= 4), "the predictive runs on the parked form (n <= 64) of the backward instantiation");
     constexpr int NP = 16 * NB;
     constexpr int NU = NB * (NB + 1) / 2;
 #define GPR_LATE(field) cx.template late<decltype(GpMfmaArgs::field)>(a.field, (unsigned)__builtin_offsetof(GpMfmaArgs, field))
@@ -407,7 +422,7 @@ __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, 
     const float inv_nv = nv > 0 ? rcp_((float)nv) : 0.0f;
     float lml = -0.5f * (quad + 2.0f * logdet + (float)nv * 1.8378770664093453f) * inv_nv;
     if (!okf) lml = NAN;
-    if (lane == 0) GPR_LATE(lml)[b] = lml;
+    if (!PRED && lane == 0) GPR_LATE(lml)[b] = lml;
     if (!BWD) return;
 
     SCHED_FENCE();
@@ -421,6 +436,75 @@ __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, 
         if (g == 0) av[16 * K + r] = ap;
     }
     SCHED_FENCE();
+    if constexpr (PRED) {
+        // ---- W = K^-1, every block of the upper block triangle into LDS ----------------------------------------------------------------
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+#pragma unroll
+            for (int J = I; J < NB; ++J) {
+                f32x4 Wb = mmT(I == J ? Zd[J] : G[J][I], Zd[J], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int m = J + 1; m < NB; ++m) Wb = mmT(G[m][I], G[m][J], Wb);
+                *reinterpret_cast<f32x4*>(Wl + uidx(NB, I, J) * 256 + lane * 4) = Wb;
+                SCHED_FENCE();
+            }
+        }
+        WSYNC();
+        const int m_tst = pa->m;
+        const float* ztp = pa->zt + (long)(blk / (unsigned)pa->zt_div) * m_tst * (long)f;
+        const float bad = okf ? 0.0f : NAN;
+        const float prior_var = os + noise;
+#pragma unroll 1
+        for (int s0 = 0; s0 < m_tst; s0 += 16) {
+            const int sidx = s0 + r;                            // this lane's test point (column r of the block)
+            float zt[FP];
+#pragma unroll
+            for (int c = 0; c < FP; ++c) zt[c] = (sidx < m_tst && c < f) ? ztp[(long)sidx * f + c] * kls[c] : 0.0f;
+            f32x4 Ks[NB];
+            float mu_p = 0.0f;
+#pragma unroll
+            for (int I = 0; I < NB; ++I) {
+                const f32x4 ai4 = *reinterpret_cast<const f32x4*>(av + 16 * I + 4 * g);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float q = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < FP; ++c) { const float d = zf[(16 * I + 4 * g + s) * FP + c] - zt[c]; q = fmaf(d, d, q); }
+                    const float k = os * __builtin_amdgcn_exp2f(-q);      // (a padding row sits 1e10 away: exactly 0)
+                    Ks[I][s] = k;
+                    mu_p = fmaf(k, ai4[s], mu_p);
+                }
+            }
+            float vv = 0.0f;
+#pragma unroll
+            for (int J = 0; J < NB; ++J) {
+                f32x4 Tj = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int I = 0; I < NB; ++I) {                  // T_J += W[J][I] K_I = X^T K_I with X = W[I][J]
+                    f32x4 X;
+                    if (I <= J) X = *reinterpret_cast<const f32x4*>(Wl + (I * NB - I * (I - 1) / 2 + (J - I)) * 256 + lane * 4);
+                    else {                                       // the transpose of the stored block (J, I): element (r, 4g+s) of it
+                        const float* wt = Wl + (J * NB - J * (J - 1) / 2 + (I - J)) * 256 + (16 * (r >> 2)) * 4 + (r & 3);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) X[s] = wt[(4 * g + s) * 4];
+                    }
+                    Tj = mmT(X, Ks[I], Tj);
+                }
+                vv = fmaf(Ks[J][0], Tj[0], vv); vv = fmaf(Ks[J][1], Tj[1], vv); vv = fmaf(Ks[J][2], Tj[2], vv); vv = fmaf(Ks[J][3], Tj[3], vv);
+                SCHED_FENCE();
+            }
+            mu_p = xg_sum_(mu_p);
+            vv = xg_sum_(vv);
+            if (g == 0 && sidx < m_tst) {
+                float mt = 0.0f;
+                if (a.mean_mode == PACOH_MEAN_VECTOR) mt = pa->mean_tst[b * m_tst + sidx];
+                else if (a.mean_mode == PACOH_MEAN_CONST) mt = pa->mean_tst[p];
+                pa->mu[b * m_tst + sidx] = mt + mu_p + bad;
+                pa->var[b * m_tst + sidx] = prior_var - vv + bad;
+            }
+        }
+        return;
+    }
     // ---- gradient sums ---------------------------------------------------------------------------------------------------------------
     const float* g_lml_p = GPR_LATE(g_lml);
     const float gup = g_lml_p ? g_lml_p[b] : 1.0f;

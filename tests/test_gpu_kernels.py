@@ -263,6 +263,66 @@ def test_predict(L, dtype, case):
     assert relerr(cov, rc) < tol
 
 
+@pytest.mark.parametrize('case', [  # T, P, n, m, f, ragged, shared test set, mean mode
+    (3, 2, 5, 50, 2, False, False, 'vector'),      # the demo's shape (one block, 5 of 16 rows)
+    (2, 3, 20, 37, 1, True, False, 'vector'),      # two blocks, ragged tasks, m not a multiple of 16
+    (2, 2, 47, 16, 3, False, True, 'const'),       # three blocks, f <= 4, one test set per task shared by its particles
+    (3, 4, 64, 130, 2, True, False, 'zero'),       # cfg #3's context size, four blocks
+    (2, 2, 64, 64, 4, False, False, 'vector'),     # ... with four feature dimensions
+])
+def test_predict_marginal_register_resident(L, case):
+    """the marginal posterior predictive (no covariance) of an fp32 RBF GP at n <= 64, f <= 4 runs gp_reg_predict_kernel (round 5: the
+    body of the LML kernel with the predictive in place of the gradients): mean and variance against the oracle over block counts,
+    ragged tasks, mean modes and shared test sets; equal to the general kernel's answer (which want_cov selects) to fp32 rounding"""
+    T, P, n, m, f, ragged, shared, mm = case
+    B = T * P
+    dtype = torch.float32
+    z, mean, y, ls, os_, noise = make_problem(T, P, n, f, dtype, seed=3 * n + m)
+    g = torch.Generator().manual_seed(7)
+    zt = torch.randn(T if shared else B, m, f, generator=g, dtype=dtype)
+    sizes = [max(1, n - 7 * t) for t in range(T)] if ragged else [n] * T
+    nv = torch.tensor(sizes, dtype=torch.int32, device=DEV) if ragged else None
+    if mm == 'vector':
+        mean_ctx, mode, mt = mean, L.MEAN_VECTOR, 0.2 * torch.randn(B, m, generator=g, dtype=dtype)
+    elif mm == 'const':
+        c = torch.tensor([0.3, -0.7, 0.1, 0.5][:P], dtype=dtype)
+        mean_ctx, mode, mt = c, L.MEAN_CONST, c
+    else:
+        mean_ctx, mode, mt = None, L.MEAN_ZERO, None
+    dev = lambda t: None if t is None else t.to(DEV)
+    mu, var, cov, info = L.gp_predict(dev(z), 1, dev(mean_ctx), mode, dev(y), P, dev(zt), P if shared else 1, dev(mt), dev(ls), dev(os_), dev(noise),
+                                      B, P, n_valid=nv)
+    assert cov is None and int(info.abs().max()) == 0
+    mu2, var2, _, _ = L.gp_predict(dev(z), 1, dev(mean_ctx), mode, dev(y), P, dev(zt), P if shared else 1, dev(mt), dev(ls), dev(os_), dev(noise),
+                                   B, P, n_valid=nv, want_cov=True)
+    assert relerr(mu, mu2) < 2e-4 and relerr(var, var2) < 2e-4
+    for b in range(B):
+        t, p = b // P, b % P
+        k = sizes[t]
+        mc = mean[b, :k] if mm == 'vector' else (mt[p].expand(k) if mm == 'const' else torch.zeros(k))
+        ms = mt[b] if mm == 'vector' else (mt[p].expand(m) if mm == 'const' else torch.zeros(m))
+        ztb = zt[t] if shared else zt[b]
+        rm, rc = O.gp_predict(z[b:b + 1, :k].double(), mc.unsqueeze(0).double(), y[t:t + 1, :k].double(), ztb.unsqueeze(0).double(),
+                              ms.unsqueeze(0).double(), ls[p].double().reshape(1, 1, f), os_[p].double().reshape(1), noise[p].double().reshape(1))
+        assert relerr(mu[b], rm[0]) < 5e-3, (b, relerr(mu[b], rm[0]))
+        assert relerr(var[b], torch.diagonal(rc[0])) < 5e-3, (b,)
+
+
+def test_predict_marginal_register_resident_failure_is_nan(L):
+    """identical points with a noise term no rung of the ladder repairs: info = -1 and NaN mean / variance for that problem only"""
+    n, m, f = 32, 20, 2
+    z = torch.zeros(2, n, f)
+    z[1] = torch.randn(n, f, generator=torch.Generator().manual_seed(1))
+    y = torch.randn(1, n)
+    zt = torch.randn(2, m, f)
+    ls = torch.ones(2, f)
+    noise = torch.tensor([-1e-2, 0.3])
+    mu, var, _, info = L.gp_predict(z.to(DEV), 1, None, L.MEAN_ZERO, y.to(DEV), 2, zt.to(DEV), 1, None, ls.to(DEV), None, noise.to(DEV), 2, 2)
+    assert info.cpu().tolist() == [-1, 0]
+    assert bool(torch.isnan(mu[0]).all()) and bool(torch.isnan(var[0]).all())
+    assert bool(torch.isfinite(mu[1]).all()) and bool((var[1] > 0).all())
+
+
 # ------------------------------------------------------------------------------------------ dense
 @pytest.mark.parametrize('dtype,n,B', [(torch.float32, 50, 5), (torch.float64, 50, 3), (torch.float64, 512, 4),
                                        (torch.float64, 77, 2), (torch.float32, 200, 2)])
