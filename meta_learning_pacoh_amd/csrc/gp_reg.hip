@@ -31,19 +31,19 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     gpreg::gp_reg_body<NB, FP, BWD, HAS_OS>(a, gpreg::KernelCtx{}, zf, rv, av, fsc, tsc, dzc, Wl);
 }
 
-// the posterior predictive on the same body (PRED): mu / var at m test points per problem, n <= 64, f <= 4; all NU blocks of K^-1 parked
-// in LDS (13.8 KB per problem at n = 64: eleven problems per CU)
+// the posterior predictive on the same body (PRED): mu / var at m test points per problem, n <= 128, f <= 4; V = L^-1 K_xs from the
+// registers, nothing parked in LDS
 template <int NB, int FP>
-__global__ void __launch_bounds__(64, NB >= 4 ? (FP == 4 ? 2 : 3) : (NB == 3 && FP == 4 ? 3 : 4)) gp_reg_predict_kernel(GpMfmaArgs a, GpPredArgs pa) {
+__global__ void __launch_bounds__(64, NB > 4 ? (FP == 2 || NB == 6 ? 2 : 1) : (NB >= 3 && FP == 4 ? 3 : 4))
+gp_reg_predict_kernel(GpMfmaArgs a, GpPredArgs pa) {
     constexpr int NP = 16 * NB;
-    constexpr int NU = NB * (NB + 1) / 2;
     __shared__ __attribute__((aligned(16))) float zf[NP * FP];
     __shared__ __attribute__((aligned(16))) float rv[NP];
     __shared__ __attribute__((aligned(16))) float av[NP];
     __shared__ __attribute__((aligned(16))) float fsc[128];
     __shared__ __attribute__((aligned(16))) float tsc[320];
     __shared__ __attribute__((aligned(16))) float dzc[4];
-    __shared__ __attribute__((aligned(16))) float Wl[NU * 256];
+    __shared__ __attribute__((aligned(16))) float Wl[4];
     gpreg::gp_reg_body<NB, FP, true, true, gpreg::KernelCtx, true>(a, gpreg::KernelCtx{}, zf, rv, av, fsc, tsc, dzc, Wl, &pa);
 }
 
@@ -54,19 +54,21 @@ static int launch_reg_predict(const GpMfmaArgs& a, const GpPredArgs& pa, int FP,
     return launch_status();
 }
 
-// returns 1 if this path does not apply (n > 64, f > 4, or PACOH_GP_REG=0 / PACOH_GP_REG_PREDICT=0)
+// returns 1 if this path does not apply (n > 128, f > 4, or PACOH_GP_REG=0 / PACOH_GP_REG_PREDICT=0)
 int gp_reg_predict_try(const GpMfmaArgs& a, const GpPredArgs& pa, hipStream_t s) {
     const char* e = getenv("PACOH_GP_REG");
     if (e && e[0] == '0') return 1;
     static const bool on = []() { const char* q = getenv("PACOH_GP_REG_PREDICT"); return !(q && q[0] == '0'); }();
-    if (!on || a.n > 64 || a.f > 4 || a.n < 1 || pa.m < 1) return 1;
+    if (!on || a.n > 128 || a.f > 4 || a.n < 1 || pa.m < 1) return 1;
     const int NB = (a.n + 15) / 16;
     const int FP = a.f <= 2 ? 2 : 4;
     switch (NB) {
         case 1: return launch_reg_predict<1>(a, pa, FP, s);
         case 2: return launch_reg_predict<2>(a, pa, FP, s);
         case 3: return launch_reg_predict<3>(a, pa, FP, s);
-        default: return launch_reg_predict<4>(a, pa, FP, s);
+        case 4: return launch_reg_predict<4>(a, pa, FP, s);
+        case 5: case 6: return launch_reg_predict<6>(a, pa, FP, s);
+        default: return launch_reg_predict<8>(a, pa, FP, s);
     }
 }
 

@@ -238,16 +238,16 @@ __host__ __device__ constexpr int uidx(int NB, int K, int J) { return K * NB - K
 // Ctx: lane() = lane of the wave, block() = problem index b, late<T>(a.field, offset of it) = that field, read late.
 // zf [16 NB FP], rv / av [16 NB], fsc [128], tsc [320], dzc [BWD ? 16 NB FP : 1], Wl [BWD && NB > 1 ? (NU - NB) 256 : 4]: per-wave
 // LDS scratch (16-byte aligned).
-// PRED (round 5): the posterior predictive instead of the gradients -- mu_s = m_s + k_s^T alpha, var_s = os + noise - k_s^T K^-1 k_s for
+// PRED (round 5): the posterior predictive instead of the gradients -- mu_s = m_s + k_s^T alpha, var_s = os + noise - |L^-1 k_s|^2 for
 // the m test points of *pa, 16 at a time: the kernel entries K_xs of a test block against every context block (accumulator layout:
-// context rows x test columns), T = K^-1 K_xs as NB^2 block products with the blocks of W = K^-1 parked in LDS (all NU of them: Wl
-// [NU 256]), the two contractions with K_xs on the vector units.  n <= 64 (the parked form).  The LDS-resident general kernel it
-// replaces for these shapes ran 20 480 problems of n = m = 64 in 1.85 ms; the LML + gradient kernel takes 0.14 for the same batch.
+// context rows x test columns), V = L^-1 K_xs as block products with the blocks of L^-1 the backward instantiation keeps in registers,
+// the contractions with K_xs / V on the vector units.  The LDS-resident general kernel it replaces for these shapes ran 20 480
+// problems of n = m = 64 in 1.85 ms; the LML + gradient kernel takes 0.14 for the same batch.
 template <int NB, int FP, bool BWD, bool HAS_OS, class Ctx, bool PRED = false>
 __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, float* zf, float* rv,
                                             float* av, float* fsc, float* tsc,
                                             float* dzc, float* Wl, const GpPredArgs* pa = nullptr) {
-    static_assert(!PRED || (BWD && NB <= 4), "the predictive runs on the parked form (n <= 64) of the backward instantiation");
+    static_assert(!PRED || BWD, "the predictive runs on the backward instantiation (it needs the blocks of L^-1)");
     constexpr int NP = 16 * NB;
     constexpr int NU = NB * (NB + 1) / 2;
 #define GPR_LATE(field) cx.template late<decltype(GpMfmaArgs::field)>(a.field, (unsigned)__builtin_offsetof(GpMfmaArgs, field))
@@ -437,26 +437,33 @@ __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, 
     }
     SCHED_FENCE();
     if constexpr (PRED) {
-        // ---- W = K^-1, every block of the upper block triangle into LDS ----------------------------------------------------------------
+        // ---- V = L^-1 K_xs block by block from registers -- var_s = os + noise - |V_s|^2 -- with the blocks of L^-1 TRANSPOSED once, in
+        //      place (mmT(X, Y) = X^T Y is the only product the layout offers: L^-1[I][J] K_J = mmT(L^-1[I][J]^T, K_J)).  No K^-1 at all:
+        //      NB (NB + 1) / 2 block products per test block instead of NB^2 with K^-1, none to form it, nothing parked in LDS (the first
+        //      version, through K^-1 parked in LDS, took 0.26 ms for 20 480 problems of n = m = 64; this one: see gp_reg.hip)
+        const int twr = 68 * g + 12 * (g & 1) + 32 * (g >> 1) + r, trd = 17 * r + 12 * ((r >> 2) & 1) + 32 * (r >> 3) + 4 * g;
+        auto turn = [&](f32x4& X) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) tsc[twr + 17 * s] = X[s];
+            WSYNC();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) X[q] = tsc[trd + q];
+            WSYNC();
+        };
 #pragma unroll
         for (int I = 0; I < NB; ++I) {
+            turn(Zd[I]);
 #pragma unroll
-            for (int J = I; J < NB; ++J) {
-                f32x4 Wb = mmT(I == J ? Zd[J] : G[J][I], Zd[J], f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-                for (int m = J + 1; m < NB; ++m) Wb = mmT(G[m][I], G[m][J], Wb);
-                *reinterpret_cast<f32x4*>(Wl + uidx(NB, I, J) * 256 + lane * 4) = Wb;
-                SCHED_FENCE();
-            }
+            for (int J = 0; J < I; ++J) turn(G[I][J]);
+            SCHED_FENCE();
         }
-        WSYNC();
         const int m_tst = pa->m;
         const float* ztp = pa->zt + (long)(blk / (unsigned)pa->zt_div) * m_tst * (long)f;
         const float bad = okf ? 0.0f : NAN;
         const float prior_var = os + noise;
 #pragma unroll 1
         for (int s0 = 0; s0 < m_tst; s0 += 16) {
-            const int sidx = s0 + r;                            // this lane's test point (column r of the block)
+            const int sidx = s0 + r;
             float zt[FP];
 #pragma unroll
             for (int c = 0; c < FP; ++c) zt[c] = (sidx < m_tst && c < f) ? ztp[(long)sidx * f + c] * kls[c] : 0.0f;
@@ -470,27 +477,22 @@ __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, 
                     float q = 0.0f;
 #pragma unroll
                     for (int c = 0; c < FP; ++c) { const float d = zf[(16 * I + 4 * g + s) * FP + c] - zt[c]; q = fmaf(d, d, q); }
-                    const float k = os * __builtin_amdgcn_exp2f(-q);      // (a padding row sits 1e10 away: exactly 0)
+                    const float k = os * __builtin_amdgcn_exp2f(-q);
                     Ks[I][s] = k;
                     mu_p = fmaf(k, ai4[s], mu_p);
                 }
+                SCHED_FENCE();
             }
             float vv = 0.0f;
 #pragma unroll
-            for (int J = 0; J < NB; ++J) {
-                f32x4 Tj = {0.f, 0.f, 0.f, 0.f};
+            for (int I = 0; I < NB; ++I) {
+                f32x4 Vi = {0.f, 0.f, 0.f, 0.f};
+                asm volatile("" : "+v"(Vi));                     // (keeps block row I's products behind block row I - 1's sums: see the W loop)
 #pragma unroll
-                for (int I = 0; I < NB; ++I) {                  // T_J += W[J][I] K_I = X^T K_I with X = W[I][J]
-                    f32x4 X;
-                    if (I <= J) X = *reinterpret_cast<const f32x4*>(Wl + (I * NB - I * (I - 1) / 2 + (J - I)) * 256 + lane * 4);
-                    else {                                       // the transpose of the stored block (J, I): element (r, 4g+s) of it
-                        const float* wt = Wl + (J * NB - J * (J - 1) / 2 + (I - J)) * 256 + (16 * (r >> 2)) * 4 + (r & 3);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) X[s] = wt[(4 * g + s) * 4];
-                    }
-                    Tj = mmT(X, Ks[I], Tj);
-                }
-                vv = fmaf(Ks[J][0], Tj[0], vv); vv = fmaf(Ks[J][1], Tj[1], vv); vv = fmaf(Ks[J][2], Tj[2], vv); vv = fmaf(Ks[J][3], Tj[3], vv);
+                for (int J = 0; J < I; ++J) Vi = mmT(G[I][J], Ks[J], Vi);
+                Vi = mmT(Zd[I], Ks[I], Vi);
+                vv = fmaf(Vi[0], Vi[0], vv); vv = fmaf(Vi[1], Vi[1], vv); vv = fmaf(Vi[2], Vi[2], vv); vv = fmaf(Vi[3], Vi[3], vv);
+                asm volatile("" : "+v"(vv));
                 SCHED_FENCE();
             }
             mu_p = xg_sum_(mu_p);

@@ -489,8 +489,8 @@ extern "C" int pacoh_gp_predict(const void* z_ctx, int z_div, const void* mean_c
         auto a = make_args<float>(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, B, P, n, f);
         a.z_tst = (const float*)z_tst; a.zt_div = zt_div; a.mean_tst = (const float*)mean_tst;
         a.mu = (float*)mu; a.var = (float*)var; a.V_out = cov ? (float*)workspace : nullptr; a.m = m; a.info = info;
-        // marginal predictive of an RBF-family GP at n <= 64, f <= 4: the register-resident MFMA kernel (round 5)
-        if (!cov && a.kind == PACOH_KERNEL_RBF && mfma_enabled() && a.n <= 64 && a.f <= 4 && info && B > 0 && P > 0 && z_div > 0 && y_div > 0 && z_ctx && y &&
+        // marginal predictive of an RBF-family GP at n <= 128, f <= 4: the register-resident MFMA kernel (round 5)
+        if (!cov && a.kind == PACOH_KERNEL_RBF && mfma_enabled() && a.n <= 128 && a.f <= 4 && info && B > 0 && P > 0 && z_div > 0 && y_div > 0 && z_ctx && y &&
             lengthscale && noise && (mean_mode == PACOH_MEAN_ZERO || mean_ctx)) {
             GpMfmaArgs ma = {a.z, a.z_div, a.mean, a.mean_mode, a.y, a.y_div, a.ls, a.os, a.noise, a.n_valid, nullptr,
                              nullptr, info, nullptr, nullptr, nullptr, nullptr, nullptr, a.B, a.P, a.n, a.f};

@@ -269,9 +269,12 @@ def test_predict(L, dtype, case):
     (2, 2, 47, 16, 3, False, True, 'const'),       # three blocks, f <= 4, one test set per task shared by its particles
     (3, 4, 64, 130, 2, True, False, 'zero'),       # cfg #3's context size, four blocks
     (2, 2, 64, 64, 4, False, False, 'vector'),     # ... with four feature dimensions
+    (2, 2, 80, 40, 2, False, False, 'vector'),     # n > 64: V = L^-1 K_xs from the registers (six-block kernel, five used)
+    (1, 3, 128, 130, 2, True, True, 'const'),      # cfg #4's context size, ragged, shared test set
+    (2, 2, 100, 33, 4, False, False, 'zero'),      # eight-block kernel, seven used, f <= 4
 ])
 def test_predict_marginal_register_resident(L, case):
-    """the marginal posterior predictive (no covariance) of an fp32 RBF GP at n <= 64, f <= 4 runs gp_reg_predict_kernel (round 5: the
+    """the marginal posterior predictive (no covariance) of an fp32 RBF GP at n <= 128, f <= 4 runs gp_reg_predict_kernel (round 5: the
     body of the LML kernel with the predictive in place of the gradients): mean and variance against the oracle over block counts,
     ragged tasks, mean modes and shared test sets; equal to the general kernel's answer (which want_cov selects) to fp32 rounding"""
     T, P, n, m, f, ragged, shared, mm = case
