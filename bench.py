@@ -313,6 +313,10 @@ def main():
             except Exception as exc:                     # (a side leg must never take the headline line down with it)
                 others['cfg%d' % c] = {'error': repr(exc)}
                 torch.cuda.empty_cache()
+        try:
+            others['predictive'] = predictive_leg(L)
+        except Exception as exc:
+            others['predictive'] = {'error': repr(exc)}
 
     if rank == 0:
         cpu = None if (args.no_cpu_baseline or world > 1 or args.config != 3) else cpu_baseline()
@@ -329,6 +333,33 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def predictive_leg(L, reps=20):
+    """SURVEY 8 row A11 beside the LML: the marginal posterior predictive (mean + variance at m test points per problem) at the
+    context sizes of cfg #3 and cfg #4, fp32, NN-feature dimension 2 -- pacoh_gp_predict, inputs resident, HIP events"""
+    out = {}
+    for tag, B, n, m in (('cfg3_shape', 20480, 64, 64), ('cfg4_shape', 5120, 128, 128)):
+        f = 2
+        g = torch.Generator().manual_seed(n)
+        X = torch.randn(B, n, f, generator=g).cuda(); Y = torch.randn(B, n, generator=g).cuda(); Xs = torch.randn(B, m, f, generator=g).cuda()
+        ls = torch.full((1, f), 0.6931).cuda(); nz = torch.tensor([0.313]).cuda()
+        run = lambda: L.gp_predict(X, 1, None, L.MEAN_ZERO, Y, 1, Xs, 1, None, ls, None, nz, B, 1)
+        for _ in range(3):
+            res = run()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            res = run()
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / reps
+        out[tag] = {'problems': B, 'n_ctx': n, 'm_test': m, 'ms_per_call': round(ms, 4), 'value': round(B / (ms * 1e-3), 1),
+                    'unit': 'predictive evals/s', 'finite': bool(torch.isfinite(res[0]).all() and torch.isfinite(res[1]).all()),
+                    'info_max': int(res[3].abs().max())}
+        del X, Y, Xs
+    return out
 
 
 def event_overhead_ms(L, reps=64):
