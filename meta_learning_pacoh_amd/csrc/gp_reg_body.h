@@ -51,6 +51,7 @@ struct GpPredArgs {
     const float* mean_tst;
     float* mu; float* var;
     int m;
+    float* V_out;              // optional [B, m, n]: V = L^-1 K_xs, test point major (what gp_predict_cov_kernel builds the covariance from)
 };
 
 namespace gpreg {
@@ -491,6 +492,11 @@ __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, 
 #pragma unroll
                 for (int J = 0; J < I; ++J) Vi = mmT(G[I][J], Ks[J], Vi);
                 Vi = mmT(Zd[I], Ks[I], Vi);
+                if (pa->V_out && sidx < m_tst) {                 // rows 16 I + 4 g .. + 3 of column sidx: four consecutive floats
+                    float* vp = pa->V_out + (b * m_tst + sidx) * (long)n + 16 * I + 4 * g;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (16 * I + 4 * g + q < n) vp[q] = okf ? Vi[q] : NAN;
+                }
                 vv = fmaf(Vi[0], Vi[0], vv); vv = fmaf(Vi[1], Vi[1], vv); vv = fmaf(Vi[2], Vi[2], vv); vv = fmaf(Vi[3], Vi[3], vv);
                 asm volatile("" : "+v"(vv));
                 SCHED_FENCE();

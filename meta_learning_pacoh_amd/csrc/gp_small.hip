@@ -395,6 +395,7 @@ struct GpPredArgs {            // (same struct as in gp_reg_body.h)
     const float* mean_tst;
     float* mu; float* var;
     int m;
+    float* V_out;
 };
 int gp_reg_predict_try(const GpMfmaArgs& a, const GpPredArgs& pa, hipStream_t s);      // ... its predictive form (n <= 64, no covariance)
 }
@@ -490,15 +491,16 @@ extern "C" int pacoh_gp_predict(const void* z_ctx, int z_div, const void* mean_c
         a.z_tst = (const float*)z_tst; a.zt_div = zt_div; a.mean_tst = (const float*)mean_tst;
         a.mu = (float*)mu; a.var = (float*)var; a.V_out = cov ? (float*)workspace : nullptr; a.m = m; a.info = info;
         // marginal predictive of an RBF-family GP at n <= 128, f <= 4: the register-resident MFMA kernel (round 5)
-        if (!cov && a.kind == PACOH_KERNEL_RBF && mfma_enabled() && a.n <= 128 && a.f <= 4 && info && B > 0 && P > 0 && z_div > 0 && y_div > 0 && z_ctx && y &&
+        rc = 1;
+        if (a.kind == PACOH_KERNEL_RBF && mfma_enabled() && a.n <= 128 && a.f <= 4 && info && B > 0 && P > 0 && z_div > 0 && y_div > 0 && z_ctx && y &&
             lengthscale && noise && (mean_mode == PACOH_MEAN_ZERO || mean_ctx)) {
             GpMfmaArgs ma = {a.z, a.z_div, a.mean, a.mean_mode, a.y, a.y_div, a.ls, a.os, a.noise, a.n_valid, nullptr,
                              nullptr, info, nullptr, nullptr, nullptr, nullptr, nullptr, a.B, a.P, a.n, a.f};
-            GpPredArgs pa = {(const float*)z_tst, zt_div, (const float*)mean_tst, (float*)mu, (float*)var, m};
-            const int rr = gp_reg_predict_try(ma, pa, (hipStream_t)stream);
-            if (rr != 1) return rr;
+            GpPredArgs pa = {(const float*)z_tst, zt_div, (const float*)mean_tst, (float*)mu, (float*)var, m, a.V_out};
+            rc = gp_reg_predict_try(ma, pa, (hipStream_t)stream);         // (1: not its shape)
+            if (rc != 0 && rc != 1) return rc;
         }
-        rc = launch_gp_small<float, MODE_PREDICT>(a, (hipStream_t)stream);
+        if (rc == 1) rc = launch_gp_small<float, MODE_PREDICT>(a, (hipStream_t)stream);
         if (rc == PACOH_OK && cov) {
             long total = (long)B * m * m;
             hipLaunchKernelGGL(gp_predict_cov_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,

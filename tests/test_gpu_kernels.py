@@ -276,7 +276,7 @@ def test_predict(L, dtype, case):
 def test_predict_marginal_register_resident(L, case):
     """the marginal posterior predictive (no covariance) of an fp32 RBF GP at n <= 128, f <= 4 runs gp_reg_predict_kernel (round 5: the
     body of the LML kernel with the predictive in place of the gradients): mean and variance against the oracle over block counts,
-    ragged tasks, mean modes and shared test sets; equal to the general kernel's answer (which want_cov selects) to fp32 rounding"""
+    ragged tasks, mean modes and shared test sets; with the covariance requested the same kernel hands V = L^-1 K_xs to the covariance kernel"""
     T, P, n, m, f, ragged, shared, mm = case
     B = T * P
     dtype = torch.float32
@@ -296,9 +296,10 @@ def test_predict_marginal_register_resident(L, case):
     mu, var, cov, info = L.gp_predict(dev(z), 1, dev(mean_ctx), mode, dev(y), P, dev(zt), P if shared else 1, dev(mt), dev(ls), dev(os_), dev(noise),
                                       B, P, n_valid=nv)
     assert cov is None and int(info.abs().max()) == 0
-    mu2, var2, _, _ = L.gp_predict(dev(z), 1, dev(mean_ctx), mode, dev(y), P, dev(zt), P if shared else 1, dev(mt), dev(ls), dev(os_), dev(noise),
-                                   B, P, n_valid=nv, want_cov=True)
-    assert relerr(mu, mu2) < 2e-4 and relerr(var, var2) < 2e-4
+    mu2, var2, cov2, _ = L.gp_predict(dev(z), 1, dev(mean_ctx), mode, dev(y), P, dev(zt), P if shared else 1, dev(mt), dev(ls), dev(os_), dev(noise),
+                                      B, P, n_valid=nv, want_cov=True)                # (the same kernel handing V = L^-1 K_xs to the covariance kernel)
+    assert torch.equal(mu, mu2) and torch.equal(var, var2)
+    assert relerr(torch.diagonal(cov2, dim1=-2, dim2=-1), var) < 2e-4
     for b in range(B):
         t, p = b // P, b % P
         k = sizes[t]
@@ -309,6 +310,7 @@ def test_predict_marginal_register_resident(L, case):
                               ms.unsqueeze(0).double(), ls[p].double().reshape(1, 1, f), os_[p].double().reshape(1), noise[p].double().reshape(1))
         assert relerr(mu[b], rm[0]) < 5e-3, (b, relerr(mu[b], rm[0]))
         assert relerr(var[b], torch.diagonal(rc[0])) < 5e-3, (b,)
+        assert relerr(cov2[b], rc[0]) < 5e-3, (b,)
 
 
 def test_predict_marginal_register_resident_failure_is_nan(L):
