@@ -302,7 +302,7 @@ def main():
 
     # the other BASELINE configurations (parity-test cases, not the headline): bounded legs on the same box so that their numbers
     # are driver-visible too -- N = 1, default config only
-    others = None
+    others = predictive = None
     if rank == 0 and world == 1 and args.config == 3 and not args.no_other_configs:
         del wl
         torch.cuda.empty_cache()
@@ -314,9 +314,9 @@ def main():
                 others['cfg%d' % c] = {'error': repr(exc)}
                 torch.cuda.empty_cache()
         try:
-            others['predictive'] = predictive_leg(L)
+            predictive = predictive_leg(L)
         except Exception as exc:
-            others['predictive'] = {'error': repr(exc)}
+            predictive = {'error': repr(exc)}
 
     if rank == 0:
         cpu = None if (args.no_cpu_baseline or world > 1 or args.config != 3) else cpu_baseline()
@@ -329,6 +329,7 @@ def main():
             config=dict({'workload': describe, 'evals_per_step': evals_per_step, 'parallelism': 'task-shard x%d' % world,
                          'finite': finite}, **extra),
             roofline=roofline, kernel_rooflines=kernel_rooflines, step_flops=step_flops, gram=gram, pp=pp, others=others, cpu=cpu)
+        out['predictive'] = predictive                    # (row A11 beside the LML: predictive_leg; None outside the default N = 1 run)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -196,3 +196,8 @@ def test_bench_line_contract():
         assert abs(leg['value'] - {'cfg1': 5, 'cfg2': 256, 'cfg4': 5120, 'cfg5': 256}[[k for k, v in oc.items() if v is leg][0]] / (leg['ms_per_step'] * 1e-3)) <= 2e-3 * leg['value']
         assert 0 < leg['dominant_kernel']['algorithmic_frac'] < 1
     assert oc['cfg5']['dtype'] == 'f64' and oc['cfg1']['dtype'] == oc['cfg2']['dtype'] == oc['cfg4']['dtype'] == 'f32'
+    # ... and the marginal posterior predictive at the context sizes of cfg #3 / cfg #4 (row A11)
+    pr = d['predictive']
+    assert set(pr) == {'cfg3_shape', 'cfg4_shape'}
+    for leg in pr.values():
+        assert leg['finite'] is True and leg['info_max'] == 0 and abs(leg['value'] - leg['problems'] / (leg['ms_per_call'] * 1e-3)) <= 2e-3 * leg['value']
