@@ -253,6 +253,28 @@ def test_dense_two_level_path_ladder_and_healthy_neighbours(L, n, dtype, ragged)
     assert abs(float(lml[0]) - float(ref0)) < (1e-3 if f64 else 0.2) * abs(float(ref0))
 
 
+@pytest.mark.parametrize('dtype,n,B', [(torch.float32, 1024, 1), (torch.float64, 1024, 2), (torch.float32, 516, 9), (torch.float64, 514, 3)])
+def test_two_level_path_edges(L, dtype, n, B):
+    """the ends of the two-level range: n = 1024 (two sub-blocks of 512), n = 514 / 516 (the smallest second sub-block the split
+    produces: 194 / 196 rows), batches of 1 / 2 / 3 / 9 problems (the tiled GEMM deals workgroups to the XCDs in groups of eight
+    problems: the remainder path) -- LML and the gradients the call returns against the oracle, forward-only bit-equal"""
+    f, P = 2, 1
+    z, mean, y, ls, os_, noise = make_problem(B, P, n, f, dtype, seed=n + B, per_eval_z=True, noise_lo=0.05)
+    leaves = [t.double().clone().requires_grad_(True) for t in (z, mean, ls, os_, noise)]
+    ref = oracle_mll(leaves[0], leaves[1], y.double(), leaves[2], leaves[3], leaves[4], B, P, True)
+    ref.sum().backward()
+    out = L.gp_lml_fwdbwd(z.to(DEV), 1, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, ls.to(DEV), os_.to(DEV), noise.to(DEV), B * P, P, want_dz=True)
+    lml, d_z, d_mean, d_ls, d_os, d_noise, info = out
+    assert int(info.abs().max()) == 0
+    assert maxrel(lml, ref) < (5e-3 if dtype == torch.float32 else 1e-9)
+    gtol = 2e-2 if dtype == torch.float32 else 1e-7
+    assert relerr(d_z, leaves[0].grad) < gtol and relerr(d_mean, leaves[1].grad) < gtol
+    assert relerr(d_ls.reshape(B, P, f).sum(0), leaves[2].grad) < gtol
+    assert relerr(d_os.reshape(B, P).sum(0), leaves[3].grad) < gtol and relerr(d_noise.reshape(B, P).sum(0), leaves[4].grad) < gtol
+    lml2, _, _, info2 = L.gp_lml_fwd(z.to(DEV), 1, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, ls.to(DEV), os_.to(DEV), noise.to(DEV), B * P, P)
+    assert torch.equal(lml2, lml) and int(info2.abs().max()) == 0
+
+
 def test_two_level_path_is_what_ran(L):
     """PACOH_CHOL_BLOCKED=0 PACOH_TRTRI_BLOCKED=0 select the right-looking kernels at n = 640 fp32: the two runs must agree to rounding
     AND differ in the last bits, or the switch (and with it the claim that the two-level path ran in the tests above) is dead.  (The

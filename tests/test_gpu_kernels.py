@@ -272,6 +272,9 @@ def test_predict(L, dtype, case):
     (2, 2, 80, 40, 2, False, False, 'vector'),     # n > 64: V = L^-1 K_xs from the registers (six-block kernel, five used)
     (1, 3, 128, 130, 2, True, True, 'const'),      # cfg #4's context size, ragged, shared test set
     (2, 2, 100, 33, 4, False, False, 'zero'),      # eight-block kernel, seven used, f <= 4
+    (1, 1, 1, 1, 1, False, False, 'zero'),         # one context point, one test point
+    (3, 1, 17, 1, 2, True, True, 'vector'),        # one test point per task, the second block holds one row
+    (1, 5, 128, 16, 4, False, False, 'const'),     # eight blocks, f <= 4 (one wave per SIMD), five parameter rows
 ])
 def test_predict_marginal_register_resident(L, case):
     """the marginal posterior predictive (no covariance) of an fp32 RBF GP at n <= 128, f <= 4 runs gp_reg_predict_kernel (round 5: the
@@ -288,7 +291,7 @@ def test_predict_marginal_register_resident(L, case):
     if mm == 'vector':
         mean_ctx, mode, mt = mean, L.MEAN_VECTOR, 0.2 * torch.randn(B, m, generator=g, dtype=dtype)
     elif mm == 'const':
-        c = torch.tensor([0.3, -0.7, 0.1, 0.5][:P], dtype=dtype)
+        c = torch.tensor([0.3, -0.7, 0.1, 0.5, -0.2][:P], dtype=dtype)
         mean_ctx, mode, mt = c, L.MEAN_CONST, c
     else:
         mean_ctx, mode, mt = None, L.MEAN_ZERO, None
