@@ -318,6 +318,67 @@ __global__ void __launch_bounds__(256, 4) dense_gram_tile_kernel(const double* _
     }
 }
 
+// The same tiles for the factorisation's Gram matrix (lower block triangle, no mirror), a ROW of tiles per workgroup (round 5): row
+// block I's coordinates are staged once and the tiles J = 0 .. I walked with tile J + 1's coordinates staged under tile J's work --
+// one barrier per tile instead of a whole prologue (two global round trips and three barriers) per tile; grid (problem, row block),
+// longest row first (the XCD lesson of dense_grad_tile_kernel).
+__global__ void __launch_bounds__(256, 4) dense_gram_row_kernel(const double* __restrict__ z, int z_div, const double* __restrict__ lsp,
+                                                                const double* __restrict__ osp, const double* __restrict__ noisep,
+                                                                double* __restrict__ K, int P, int n, int f) {
+    using Acc = f64x4_t;
+    auto gm_row = [](int g_, int q_) { return Mf<double>::row(g_, q_); };
+    __shared__ double ZI[GT][GZL], ZJ[2][GT][GZL], n2I[GT], n2J[2][GT];
+    const long b = blockIdx.x;
+    const int nI = (n + GT - 1) / GT;
+    const int I = nI - 1 - (int)blockIdx.y, I0 = I * GT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int p = (int)(b % P);
+    const double* zb = z + (b / z_div) * (long)n * f;
+    const double* ls = lsp + (long)p * f;
+    // scaled coordinates relative to the problem's first point (columns 0..7, zero beyond f) and their squared norms: a thread owns
+    // whole rows' quarter -- 64 rows x 4 threads -- so that the norm is a sum over its own registers and one lane exchange
+    auto stage = [&](double (*Z)[GZL], double* n2, int R0) {
+        const int i = tid >> 2, c0 = (tid & 3) * 2;
+        const int row = R0 + i;
+        double v0 = 0.0, v1 = 0.0;
+        if (row < n) {
+            if (c0 < f) v0 = (zb[(long)row * f + c0] - zb[c0]) / ls[c0];
+            if (c0 + 1 < f) v1 = (zb[(long)row * f + c0 + 1] - zb[c0 + 1]) / ls[c0 + 1];
+        }
+        Z[i][c0] = v0; Z[i][c0 + 1] = v1;
+        double s = fma(v0, v0, v1 * v1);
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+        if ((tid & 3) == 0) n2[i] = s;
+    };
+    stage(ZI, n2I, I0);
+    stage(ZJ[0], n2J[0], 0);
+    const double os = osp ? osp[p] : 1.0, noise = noisep ? noisep[p] : 0.0;
+    double* Kb = K + b * (long)n * n;
+    for (int J = 0; J <= I; ++J) {
+        const int J0 = J * GT, cur = J & 1;
+        __syncthreads();                                   // tile J's coordinates are staged; the other buffer's readers are done
+        if (J < I) stage(ZJ[cur ^ 1], n2J[cur ^ 1], J0 + GT);
+        const int j = 16 * w + r, gj = J0 + j;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            Acc s = {0, 0, 0, 0};
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+                s = __builtin_amdgcn_mfma_f64_16x16x4f64(ZI[16 * ib + r][4 * st + g], ZJ[cur][j][4 * st + g], s, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * ib + gm_row(g, q), gi = I0 + i;
+                double d2 = n2I[i] + n2J[cur][j] - 2.0 * s[q];
+                d2 = (d2 > 0.0 && gi != gj) ? d2 : 0.0;
+                double k = os * rbf_exp<double>(-0.5 * d2);
+                if (gi == gj) k += noise;
+                if (gi < n && gj < n) Kb[(long)gi * n + gj] = k;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // fp64 ARD-RBF Gram + noise for the factorisation, lower block triangle only; returns 1 when outside its plan (caller: gram_kernel)
@@ -326,7 +387,8 @@ int dense_gram_mfma_try(const void* z, int z_div, const void* ls, const void* os
     static const bool on = []() { const char* e = getenv("PACOH_GRAM_MFMA"); return !(e && e[0] == '0'); }();
     if (!on || dtype != PACOH_F64 || f > 8 || n < GT || !noise) return 1;
     const int nI = (n + GT - 1) / GT;
-    hipLaunchKernelGGL(dense_gram_tile_kernel<false>, dim3(nI * (nI + 1) / 2, B), dim3(256), 0, s, (const double*)z, z_div, (const double*)ls,
+    // (one workgroup per tile -- dense_gram_tile_kernel<false> -- took 91 us per 256 x 512^2 launch, a row of tiles per workgroup 78)
+    hipLaunchKernelGGL(dense_gram_row_kernel, dim3(B, nI), dim3(256), 0, s, (const double*)z, z_div, (const double*)ls,
                        (const double*)os, (const double*)noise, (double*)K, P, n, f);
     return launch_status();
 }
