@@ -363,8 +363,8 @@ __device__ __forceinline__ void gp_reg_body(const GpMfmaArgs& a, const Ctx& cx, 
             // -L_KK^-T: the block transposed through 1.25 KB of LDS (4 dword writes + 4 dword reads, the conflict-free skewed
             // stride-17 layout of mlp_fused.hip's f_turn) instead of a product with the -identity block (4 MFMAs = 128 of the
             // issue cycles the matrix cores and the vector units share)
-            f32x4 Vn;
-            {
+            f32x4 Vn = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (NB > 1) {                             // (one block: no panel and no off-diagonal block of L^-1 reads it)
                 const int twr = 68 * g + 12 * (g & 1) + 32 * (g >> 1) + r, trd = 17 * r + 12 * ((r >> 2) & 1) + 32 * (r >> 3) + 4 * g;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) tsc[twr + 17 * s] = -Zd[K][s];
