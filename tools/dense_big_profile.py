@@ -10,7 +10,9 @@ dt = torch.float64 if (len(sys.argv) > 2 and sys.argv[2] == 'f64') else torch.fl
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 passes = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 d = 8
-X = torch.randn(B, n, d, dtype=dt, device='cuda'); Y = torch.randn(B, n, dtype=dt, device='cuda')
+# seeded inputs: the `lml mean` column of two builds is comparable only on the same draws
+gen = torch.Generator().manual_seed(1000 * n + B)
+X = torch.randn(B, n, d, dtype=dt, generator=gen).cuda(); Y = torch.randn(B, n, dtype=dt, generator=gen).cuda()
 ls = torch.full((1, d), 0.6931, dtype=dt, device='cuda'); nz = torch.tensor([0.313], dtype=dt, device='cuda')
 os1 = torch.ones(1, dtype=dt, device='cuda')
 for _ in range(3):
