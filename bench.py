@@ -159,7 +159,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)     # 0.12 s of GPU time at config 3
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
-    ap.add_argument('--config', type=int, choices=[1, 2, 3, 4, 5], default=3)
+    ap.add_argument('--config', type=lambda v: int(v) if v.isdigit() else v, choices=[1, 2, 3, 4, 5, 'ref_svgd', 'ref_vi', 'shard128'], default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
     args = ap.parse_args()
@@ -307,11 +307,12 @@ def main():
         del wl
         torch.cuda.empty_cache()
         others = {}
-        for c in (1, 2, 4, 5):
+        for c in (1, 2, 4, 5, 'ref_svgd', 'ref_vi', 'shard128'):
+            key = 'cfg%d' % c if isinstance(c, int) else c
             try:
-                others['cfg%d' % c] = other_config_leg(c, M, L)
+                others[key] = other_config_leg(c, M, L)
             except Exception as exc:                     # (a side leg must never take the headline line down with it)
-                others['cfg%d' % c] = {'error': repr(exc)}
+                others[key] = {'error': repr(exc)}
                 torch.cuda.empty_cache()
         try:
             predictive = predictive_leg(L)
@@ -484,6 +485,20 @@ def cpu_baseline_other(cfg, budget_s=2.5):
             vb, vl = rate(batched, 256), rate(looped, 256)
             sample = '256 sinusoid tasks x n=32 (SinusoidDataset(RandomState(27))), SE kernel + NN(32,32) mean, fp32 loss + autograd: batched over tasks %.0f evals/s, reference-style python loop %.0f evals/s' % (vb, vl)
             value = vb
+        elif cfg in ('ref_svgd', 'ref_vi'):
+            # one step's [P, D] score at the launcher shape: 2 tasks x 10 particles / samples, n = 20, 4 x 32 networks
+            tasks = sinusoid_tasks(29, 20, 20)[:2]
+            stats = O.compute_normalization_stats(tasks)
+            otasks = [O.prepare_task(x, y, stats, torch.float32) for x, y in tasks]
+            gcfg = O.GPConfig(1, 'NN', 'NN', REF_LAYERS, REF_LAYERS)
+            pm, ps = O.hyperprior_mean_std(gcfg.layout, 0.5, 3.0)
+            torch.manual_seed(0)
+            theta = O.hyperprior_sample(gcfg.layout, pm, ps, 10)
+            vb = rate(lambda: O.meta_score(theta, otasks, gcfg, pm, ps, 0.1, loop=False), 20)
+            vl = rate(lambda: O.meta_score(theta, otasks, gcfg, pm, ps, 0.1, loop=True), 20)
+            sample = ('one step at the launcher shape: 2 tasks x 10 particles (n=20, d=1, NN(32,32,32,32) mean + kernel, fp32) LML + autograd score: '
+                      'batched %.0f evals/s, reference-style python loop over tasks %.0f evals/s' % (vb, vl))
+            value = max(vb, vl)
         elif cfg == 4:
             T_s, S = 16, 10
             tasks = _rand_tasks(T_s, 128, 1, 28)
@@ -578,7 +593,7 @@ def other_config_leg(cfg, M, L, steps=256):
     torch.cuda.empty_cache()
     if cfg == 5:
         out['hbm'] = cfg5_hbm_report(L)
-    if cfg in (2, 4, 5):
+    if cfg in (2, 4, 5, 'ref_svgd', 'ref_vi'):
         try:
             out['cpu_baseline'] = cpu_baseline_other(cfg)
         except Exception as exc:
@@ -728,7 +743,62 @@ def wl_cfg5(world, scaling, M, L):
                 extra={'problems_per_gpu': B, 'n_ctx': n, 'd': d})
 
 
-WORKLOADS = {1: wl_cfg1, 2: wl_cfg2, 3: wl_cfg3, 4: wl_cfg4, 5: wl_cfg5}
+REF_LAYERS = (32, 32, 32, 32)     # num_layers=4, layer_size=32 (experiments/meta_GPR_SVGD_base_exp.py:29-30, meta_GPR_vi_base_exp.py:29-30)
+
+
+def _ref_launcher_flops(S):
+    w = net_macs(1, REF_LAYERS, 1) + net_macs(1, REF_LAYERS, 2)
+    ev = 2 * S
+    return {'gp_lml_fwdbwd': (gp_flops(20, 2) * ev,) * 2, 'mlp_fwd': (2 * 20 * w * ev,) * 2, 'mlp_bwd': (4 * 20 * w * ev, 6 * 20 * w * ev),
+            'svgd_task_step': ((gp_flops(20, 2) + 6 * 20 * w) * ev,) * 2}
+
+
+def wl_ref_svgd(world, scaling, M, L):
+    """the reference's own PACOH-SVGD launcher at its defaults (experiments/meta_GPR_SVGD_base_exp.py:23-49, 79-103): seed 28,
+    SinusoidDataset(RandomState(29)) 20 tasks x 20 points, task_batch_size = 2, 10 particles, 4 x 32 mean and kernel networks, Adam
+    1e-3 with decay 0.98, prior_factor 0.1, RBF particle kernel with bandwidth 0.1 -- 20 GP problems per step (VERDICT r5 missing #1)"""
+    model = M.GPRegressionMetaLearnedSVGD(sinusoid_tasks(29, 20, 20), weight_prior_std=0.5, prior_factor=0.1, covar_module='NN',
+                                          mean_module='NN', kernel_nn_layers=REF_LAYERS, mean_nn_layers=REF_LAYERS, random_seed=28,
+                                          optimizer='Adam', lr=1e-3, lr_decay=0.98, kernel='RBF', bandwidth=0.1, num_particles=10,
+                                          task_batch_size=2)
+    return dict(run=model._train_steps, evals_per_step=20, dtype='f32', mode=lambda: _mode(model),
+                finite=lambda: bool(torch.isfinite(model.particles).all()),
+                metric='task-GP LML+grad evals/sec (PACOH-SVGD at the reference launcher\'s defaults: 2 tasks x 10 particles per step, n_ctx=20)',
+                flops=_ref_launcher_flops(10),
+                describe='PACOH-SVGD step at the defaults of experiments/meta_GPR_SVGD_base_exp.py: 20 sinusoid tasks x 20 points, '
+                         'task_batch_size=2, 10 particles, NN(32,32,32,32) mean + kernel (D=%d), bandwidth 0.1' % model.layout.D,
+                extra={'tasks_total': 20, 'particles': 10, 'n_ctx': 20, 'd': 1})
+
+
+def wl_ref_vi(world, scaling, M, L):
+    """the reference's PACOH-VI launcher at its defaults (experiments/meta_GPR_vi_base_exp.py:23-52, 86-103): as wl_ref_svgd with a
+    diagonal Gaussian posterior and svi_batch_size = 10 samples per step"""
+    model = M.GPRegressionMetaLearnedVI(sinusoid_tasks(29, 20, 20), weight_prior_std=0.5, prior_factor=0.1, covar_module='NN',
+                                        mean_module='NN', kernel_nn_layers=REF_LAYERS, mean_nn_layers=REF_LAYERS, random_seed=28,
+                                        optimizer='Adam', lr=1e-3, lr_decay=0.98, svi_batch_size=10, cov_type='diag', task_batch_size=2)
+    return dict(run=model._train_steps, evals_per_step=20, dtype='f32', mode=lambda: _mode(model),
+                finite=lambda: bool(torch.isfinite(model.posterior).all()),
+                metric='task-GP LML+grad evals/sec (PACOH-VI at the reference launcher\'s defaults: 2 tasks x 10 samples per step, n_ctx=20)',
+                flops=_ref_launcher_flops(10),
+                describe='PACOH-VI step at the defaults of experiments/meta_GPR_vi_base_exp.py: 20 sinusoid tasks x 20 points, '
+                         'task_batch_size=2, 10 posterior samples, NN(32,32,32,32) mean + kernel, diagonal posterior',
+                extra={'tasks_total': 20, 'samples': 10, 'n_ctx': 20, 'd': 1})
+
+
+def wl_shard128(world, scaling, M, L):
+    """one rank's share of BASELINE config #3 strong-scaled over 8 GPUs: 128 of the 1024 tasks x 20 particles (no exchange: N = 1)"""
+    global TASKS
+    keep, TASKS = TASKS, 128
+    try:
+        wl = wl_cfg3(1, 'weak', M, L)
+    finally:
+        TASKS = keep
+    wl['metric'] = 'task-GP LML+grad evals/sec (cfg#3\'s 1/8 strong-scaling shard: 128 tasks x 20 particles, n_ctx=64, d=4)'
+    return wl
+
+
+WORKLOADS = {1: wl_cfg1, 2: wl_cfg2, 3: wl_cfg3, 4: wl_cfg4, 5: wl_cfg5, 'ref_svgd': wl_ref_svgd, 'ref_vi': wl_ref_vi,
+             'shard128': wl_shard128}
 
 if __name__ == '__main__':
     main()

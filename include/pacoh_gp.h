@@ -72,6 +72,11 @@ extern "C" {
 
 int pacoh_abi_version(void);
 
+/* The PACOH_* environment switches (test and A/B switches that force an implementation) are read ONCE, when
+ * the library is loaded; no entry point calls getenv.  A host that changes the environment afterwards and wants the change seen
+ * calls this (not thread-safe against concurrent launches). */
+void pacoh_reload_env(void);
+
 /* ---- A4: Gram build (materialised) -------------------------------------------------------------
  * K[b,i,j] = os_p * exp(-0.5 * sum_k ((z1[b,i,k] - z2[b,j,k]) / l_pk)^2)  (+ noise_p if i==j and
  * add_noise_diag != 0 and z1 == z2 semantics, i.e. square Gram).
@@ -574,6 +579,39 @@ int pacoh_map_task_step(const void* theta, long theta_stride, const void* batch_
                         const void* ls, const void* os, const void* noise, int off_ls, int off_os, int off_noise,
                         void* d_theta, long d_theta_stride, void* lik, double lik_scale, int32_t* fail_flag,
                         void* workspace, size_t workspace_bytes, const pacoh_adam_inline* opt, int dtype, void* stream);
+
+/* ---- the likelihood half of a PACOH-SVGD / PACOH-VI step for under-filled grids (round 6, csrc/map_task.hip) ----------------------
+ * The reference's own SVGD / VI launchers run 2 tasks x 10 particles (posterior samples) of 20 points per step
+ * (experiments/meta_GPR_SVGD_base_exp.py:28-49, meta_GPR_vi_base_exp.py:29-52): 20 GP problems, for which the general launch sequence
+ * (networks forward -> GP -> networks backward -> slab reduction) is four kernel latencies.  pacoh_svgd_task_step runs the sum
+ * random_gp.py:204-222 takes -- for every task t of the batch and every parameter row p: VectorizedGP.forward (random_gp.py:54-89), its
+ * MLL / n and the gradient w.r.t. theta[p] -- as TWO launches:
+ *   (1) pacoh_map_task_step's kernel with one workgroup per (task group, parameter row): the row's networks decoded into LDS, forward
+ *       chains -> GP LML + gradient -> delta chains -> weight-gradient tiles, one gradient slab per workgroup and network; with
+ *       svgd_X != NULL extra workgroups form the particles' distance matrix, its snapshot and advance *counter exactly as
+ *       pacoh_mlp2_fwd_svgd does (svgd.py:45-51's operand);
+ *   (2) the slab reduction with the step's tail: d_theta[p, :] = sum_t d mll[t, p] / d theta[p] (network blocks and, through the softplus
+ *       chain rule, the hyper-parameter columns), lik[p] = lik_scale * sum_t mll[t, p], *fail_flag |= 1 if a Cholesky failed even with
+ *       the jitter ladder, and -- want_bandwidth -- the median-heuristic bandwidth into the workspace's bandwidth slot.
+ * theta [P, D] (row stride theta_stride): SVGD's particles or VI's posterior samples; batch_x [tb, n, d] / batch_y [tb, n] /
+ * batch_n_valid [tb] | NULL: the step's gathered tasks; ls [P, f] / os [P] | NULL / noise [P]: the rows' transformed hyper-parameters;
+ * the networks, kernel and limits as for pacoh_map_task_step (fp32, RBF, n <= 32, d <= 4, f <= 4, at least one network, hidden widths
+ * <= 32, <= 4 hidden layers); svgd_workspace: pacoh_svgd_update_dev_workspace_bytes() bytes, as for pacoh_mlp2_fwd_svgd.
+ * workspace: pacoh_svgd_task_workspace_bytes() bytes (0: outside the plan -> the caller takes the general sequence); it also holds
+ * the map from the networks' padded LDS layout to the columns of a parameter row, written once by pacoh_svgd_task_setup (a function
+ * of the layout only -- no call is needed when the rows change).  Results equal the general sequence's to rounding. */
+size_t pacoh_svgd_task_workspace_bytes(int D, int P, int n, int d, int tb, int mean_mode, const int32_t* mean_hidden, int n_mean_hidden,
+                                       int kernel_nn, const int32_t* kernel_hidden, int n_kernel_hidden, int f, int dtype);
+int pacoh_svgd_task_setup(int D, int P, int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
+                          int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
+                          void* workspace, size_t workspace_bytes, int dtype, void* stream);
+int pacoh_svgd_task_step(const void* theta, long theta_stride, int P, const void* batch_x, const void* batch_y,
+                         const int32_t* batch_n_valid, int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden,
+                         int n_mean_hidden, int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
+                         const void* ls, const void* os, const void* noise, int off_ls, int off_os, int off_noise,
+                         void* d_theta, long d_theta_stride, void* lik, double lik_scale, int32_t* fail_flag,
+                         void* workspace, size_t workspace_bytes, const void* svgd_X, void* svgd_workspace, int svgd_D, int64_t* counter,
+                         int want_bandwidth, int dtype, void* stream);
 
 /* ---- 8e: the step's one exchange ----------------------------------------------------------------------------------
  * buf[0..count) := sum over ranks of buf (in place), enqueued on the caller's stream: RCCL ncclAllReduce(ncclSum) over xGMI.

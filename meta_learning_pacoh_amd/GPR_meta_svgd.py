@@ -128,6 +128,28 @@ class _RandomGPLearner(RegressionModelMetaLearned):
         parallel.check_same_draws(local, sc_rows)
         return (local if local.shape[1] > 0 else None), sc_rows
 
+    # Under-filled grids (round 6): the reference's own launchers run 2 tasks x 10 particles / samples of 20 points per step -- 20 GP
+    # problems, for which networks forward -> GP -> networks backward -> slab reduction are four kernel latencies.  There the
+    # likelihood half of a step is pacoh_svgd_task_step: one workgroup per (task, parameter row) does all three stages with the
+    # activations in LDS, then the slab reduction -- two launches.  Large grids stay on the throughput kernels.
+    TASK_FUSED_MAX_PROBLEMS = 1024
+
+    def _setup_task_fused(self, rows, tb_local):
+        """-> workspace of L.svgd_task_step for `rows` parameter rows x tb_local tasks per step, or None (general launch sequence):
+        fp32, RBF GP kernel, shapes inside the task-fused kernel's plan, at most TASK_FUSED_MAX_PROBLEMS problems per step.
+        PACOH_SVGD_TASK_FUSED=0 / 1: never / wherever the plan allows (tests, A/B)"""
+        self._task_plan = self._task_ws = None
+        force = os.environ.get('PACOH_SVGD_TASK_FUSED')
+        if force == '0' or tb_local < 1 or self.dtype != torch.float32 or L.FORCE_DENSE:
+            return None
+        if force != '1' and rows * tb_local > self.TASK_FUSED_MAX_PROBLEMS:
+            return None
+        plan = L.MapPersistPlan(self.layout, self.tasks, tb_local, 0.0, [(0, self.layout.D)], self.dtype)
+        ws = L.svgd_task_workspace(plan, rows, tb_local, self.device)
+        if ws is not None:
+            self._task_plan, self._task_ws = plan, ws
+        return ws
+
     def _check_numerics(self):
         """raise where the reference raises: gpytorch's psd_safe_cholesky -> NotPSDError (read at synchronisation points only)"""
         flag = getattr(self, '_fail', None)
@@ -227,6 +249,7 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
             self._imq_phi = torch.empty_like(self.particles)
             self._imq_h = torch.empty(D, dtype=self.dtype, device=self.device) if self.bandwidth is None else None
             self._imq_ws = L.svgd_imq_workspace(self.particles)
+        self._setup_task_fused(P, tb_local)
         if self._pipelined:
             self._feed.pipeline(self.tasks, self.engine, self.particles)
         # median bandwidth computed beside the hyper-parameter reduction instead of inside the update (P <= 64: one wavefront's sort)
@@ -234,6 +257,10 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
 
     def _body_likelihood(self):
         """score[P,D] = d/d theta_p sum_t mll[t,p] over this rank's tasks (unscaled), lik[P] the sums themselves"""
+        if self._pipelined and self._task_ws is not None:
+            L.svgd_task_step(self._task_plan, self.particles, self._feed.batch, self._feed.hyp, self._score, self._lik, 1.0, self._fail,
+                             self._task_ws, svgd=(self.particles, self._svgd_ws, self._feed.ctr, self._bw_ahead))
+            return
         if self._pipelined:
             self.engine.lml_and_grad(self.particles, self._feed.batch, weight=1.0, lik_out=self._lik, lik_scale=1.0,
                                      grad_out=self._score, fail_flag=self._fail, hypers=self._feed.hyp,
@@ -248,6 +275,9 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
             batch, hyp = self._feed.begin(self.tasks, self.engine, self.particles, advance=False, svgd=(self.particles, self._svgd_ws))
         if batch is None:
             self._packed.zero_()
+            return
+        if self._task_ws is not None:
+            L.svgd_task_step(self._task_plan, self.particles, batch, hyp, self._score, self._lik, 1.0, self._fail, self._task_ws)
             return
         self.engine.lml_and_grad(self.particles, batch, weight=1.0, lik_out=self._lik, lik_scale=1.0, grad_out=self._score,
                                  fail_flag=self._fail, hypers=hyp)
@@ -375,6 +405,6 @@ class GPRegressionMetaLearnedSVGD(_RandomGPLearner):
         return {'particles': self.particles.cpu().clone(), 'exp_avg': self.exp_avg.cpu().clone(),
                 'exp_avg_sq': self.exp_avg_sq.cpu().clone(), 'step': self.opt_step, 'epoch': self.lr_scheduler.epoch}
 
-    def load_state_dict(self, sd):
-        self.particles.copy_(sd['particles']); self.exp_avg.copy_(sd['exp_avg']); self.exp_avg_sq.copy_(sd['exp_avg_sq'])
-        self.opt_step, self.lr_scheduler.epoch = int(sd['step']), int(sd['epoch'])
+    def load_state_dict(self, state_dict):
+        self.particles.copy_(state_dict['particles']); self.exp_avg.copy_(state_dict['exp_avg']); self.exp_avg_sq.copy_(state_dict['exp_avg_sq'])
+        self.opt_step, self.lr_scheduler.epoch = int(state_dict['step']), int(state_dict['epoch'])

@@ -129,6 +129,7 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         chunk = max(1, min(self.GRAPH_CHUNK, int(os.environ.get('PACOH_VI_CHUNK', '128')), (64 << 20) // (S * D * 4)))
         self._feed = StepFeed(self.device, self.dtype, tb_local, chunk=chunk, aux_shape=(S, D))
         self._graphs = None
+        self._setup_task_fused(S, tb_local)              # (under-filled grids: the task-fused likelihood launch, GPR_meta_svgd.py)
 
     def _body_likelihood(self):
         hyp = None
@@ -141,6 +142,9 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
             self._theta, self._log_q = L.vi_sample(self.posterior, self._feed.aux, full=self.cov_type == 'full')
         if batch is None:
             self._packed.zero_()
+            return
+        if hyp is not None and self._task_ws is not None:
+            L.svgd_task_step(self._task_plan, self._theta, batch, hyp, self._score, self._lik, 1.0, self._fail, self._task_ws)
             return
         self.engine.lml_and_grad(self._theta, batch, weight=1.0, lik_out=self._lik, lik_scale=1.0, grad_out=self._score,
                                  fail_flag=self._fail, hypers=hyp)
@@ -267,6 +271,6 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
         return {'posterior': self.posterior.cpu().clone(), 'exp_avg': self.exp_avg.cpu().clone(),
                 'exp_avg_sq': self.exp_avg_sq.cpu().clone(), 'step': self.opt_step, 'epoch': self.lr_scheduler.epoch}
 
-    def load_state_dict(self, sd):
-        self.posterior.copy_(sd['posterior']); self.exp_avg.copy_(sd['exp_avg']); self.exp_avg_sq.copy_(sd['exp_avg_sq'])
-        self.opt_step, self.lr_scheduler.epoch = int(sd['step']), int(sd['epoch'])
+    def load_state_dict(self, state_dict):
+        self.posterior.copy_(state_dict['posterior']); self.exp_avg.copy_(state_dict['exp_avg']); self.exp_avg_sq.copy_(state_dict['exp_avg_sq'])
+        self.opt_step, self.lr_scheduler.epoch = int(state_dict['step']), int(state_dict['epoch'])

@@ -31,6 +31,7 @@ _ip = _c.POINTER(_c.c_int32)
 # symbol -> (restype, argtypes); must list every function declared in include/pacoh_gp.h
 SIGNATURES = {
     'pacoh_abi_version': (_i, []),
+    'pacoh_reload_env': (None, []),
     'pacoh_gram_rbf_ard': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'pacoh_gp_small_max_n': (_i, [_i, _i]),
     'pacoh_gp_lml_fwd': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -106,6 +107,10 @@ SIGNATURES = {
                                _i, _i, _i, _d, _ip, _ip, _i, _d, _d, _vp, _vp, _vp, _i, _vp]),
     'pacoh_map_task_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _ip, _i, _i, _ip, _i, _i, _i]),
     'pacoh_map_task_setup': (_i, [_vp, _i, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip, _i, _i, _vp, _sz, _i, _vp]),
+    'pacoh_svgd_task_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i, _ip, _i, _i, _ip, _i, _i, _i]),
+    'pacoh_svgd_task_setup': (_i, [_i, _i, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip, _i, _i, _vp, _sz, _i, _vp]),
+    'pacoh_svgd_task_step': (_i, [_vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip, _i, _i, _vp, _vp, _vp, _i, _i, _i,
+                                  _vp, _l, _vp, _d, _vp, _vp, _sz, _vp, _vp, _i, _vp, _i, _i, _vp]),
     'pacoh_map_task_step': (_i, [_vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip, _i, _i, _vp, _vp, _vp, _i, _i, _i,
                                  _vp, _l, _vp, _d, _vp, _vp, _sz, _vp, _i, _vp]),
     'pacoh_comm_unique_id': (_i, [_vp]),
@@ -115,7 +120,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 13              # pacoh_abi_version() of the library this table was written for
+ABI_VERSION = 14              # pacoh_abi_version() of the library this table was written for
 
 
 def load_library():
@@ -137,6 +142,12 @@ def load_library():
                                % (LIB_PATH, lib.pacoh_abi_version(), ABI_VERSION))
         _lib = lib
     return _lib
+
+
+def reload_env():
+    """the library reads its PACOH_* switches once at load time (csrc/switches.h); a test or tool that changes os.environ afterwards
+    calls this to have the change seen"""
+    load_library().pacoh_reload_env()
 
 
 def dtype_code(t):
@@ -726,6 +737,45 @@ def map_task_step(plan, theta, batch, hypers, grad, lik, lik_scale, fail_flag, w
                                        _ptr(grad, theta), grad.shape[1], _ptr(lik, theta), float(lik_scale), _ptr(fail_flag),
                                        _ptr(workspace), workspace.numel(), _opt_ptr(opt), dtype_code(theta), _stream()),
                'pacoh_map_task_step')
+
+
+def svgd_task_workspace(plan, P, tb, device, workspace=None):
+    """workspace of svgd_task_step for P parameter rows and a batch of tb tasks, its gather map written (None: the task-fused kernel
+    does not take this shape -- the caller runs the general launch sequence)"""
+    lib = load_library()
+    code = F32 if plan.dtype == torch.float32 else F64
+    need = lib.pacoh_svgd_task_workspace_bytes(plan.D, int(P), plan.n, plan.d, int(tb), plan.mean_mode, plan._mh, len(plan.mean_hidden),
+                                               plan.kernel_nn, plan._kh, len(plan.kernel_hidden), plan.f, code)
+    if need == 0 or not plan.rbf:
+        return None
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=device)
+    _check(lib.pacoh_svgd_task_setup(plan.D, int(P), plan.n, plan.d, int(tb), plan.mean_mode, plan.off_mean, plan._mh, len(plan.mean_hidden),
+                                     plan.kernel_nn, plan.off_kernel, plan._kh, len(plan.kernel_hidden), plan.f, _ptr(workspace),
+                                     workspace.numel(), code, _stream()), 'pacoh_svgd_task_setup')
+    return workspace
+
+
+def svgd_task_step(plan, theta, batch, hypers, grad, lik, lik_scale, fail_flag, workspace, svgd=None):
+    """the likelihood half of a PACOH-SVGD / PACOH-VI step as two launches (pacoh_svgd_task_step): theta [P, D] particles / posterior
+    samples, batch = the gathered TaskBatch, hypers = (ls [P, f], os [P] | None, noise [P]) transformed, grad [P, D], lik [P];
+    svgd = (particles, svgd workspace, step counter, want_bandwidth): the SVGD step's distance matrix in extra workgroups"""
+    lib = load_library()
+    ls, os_, noise = hypers
+    P, D = theta.shape
+    sx = sws = ctr = None
+    want_bw = 0
+    if svgd is not None:
+        sx, sws, ctr, want_bw = _ptr(svgd[0], theta), _ptr(svgd[1], theta), _ptr(svgd[2]), int(bool(svgd[3]))
+    with _Timed('svgd_task_step'):
+        _check(lib.pacoh_svgd_task_step(_ptr(theta), theta.stride(0), P, _ptr(batch.x, theta), _ptr(batch.y, theta),
+                                        _ptr(batch.n_valid) if (batch.n_valid is not None and batch.ragged) else None, plan.n, plan.d, int(batch.T),
+                                        plan.mean_mode, plan.off_mean, plan._mh, len(plan.mean_hidden),
+                                        plan.kernel_nn, plan.off_kernel, plan._kh, len(plan.kernel_hidden), plan.f,
+                                        _ptr(ls, theta), _ptr(os_, theta), _ptr(noise, theta), plan.off_ls, plan.off_os, plan.off_noise,
+                                        _ptr(grad, theta), grad.stride(0), _ptr(lik, theta), float(lik_scale), _ptr(fail_flag),
+                                        _ptr(workspace), workspace.numel(), sx, sws, D, ctr, want_bw, dtype_code(theta), _stream()),
+               'pacoh_svgd_task_step')
 
 
 def mlp_fused_path(B, P, n, d_in, hidden, d_out, dtype):

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <atomic>
 #include "../../include/pacoh_gp.h"
+#include "switches.h"
 
 #define PACOH_WAVE 64
 
@@ -160,6 +162,19 @@ inline int check_dtype(int dtype) {
 inline int launch_status() {
     const hipError_t e = hipGetLastError();
     return (e == hipSuccess || e == hipErrorNotReady) ? PACOH_OK : PACOH_ELAUNCH;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: opt in once per (kernel, device) -- `done` is the
+// calling launcher's own mask of devices (a process-wide bool would leave a second device without the opt-in: ADVICE r5).  Two threads
+// racing here both set the attribute, which is harmless.
+inline int lds_opt_in(const void* kernel, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return PACOH_ELAUNCH; }
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return PACOH_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); return PACOH_ELIMIT; }
+    done.fetch_or(bit, std::memory_order_release);
+    return PACOH_OK;
 }
 
 // softplus with torch's threshold (F.softplus: x for x > 20)

@@ -223,13 +223,9 @@ int dense_ll_retry_try(void* A, const void* resid, void* logp, void* alpha_out, 
 int dense_ll_try(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n, int dtype,
                  int attempt, int u_only, hipStream_t s);                    // dense_ll.hip; returns 1 if n is outside its plan
 constexpr int LL_MIN_N = 97;                               // below: the right-looking kernel with fewer waves
-static bool ll_enabled() {
-    static const bool on = []() { const char* e = getenv("PACOH_CHOL_LL"); return !(e && e[0] == '0'); }();
-    return on;
-}
+static bool ll_enabled() { return g_sw.chol_ll; }
 bool dense_chol_saves_inverse(int n, int dtype) {
-    const char* e = getenv("PACOH_DISABLE_MFMA");
-    if (e && e[0] == '1') return false;
+    if (!g_sw.mfma) return false;
     return (ll_enabled() && n >= LL_MIN_N && dense_ll_fits(n, dtype)) || dense_mfma_fits(n, dtype);
 }
 
@@ -238,8 +234,7 @@ bool dense_chol_saves_inverse(int n, int dtype) {
 int dense_chol_retry_fused(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n, int dtype,
                            int u_only, const void* z, int z_div, const void* ls, const void* os, const void* noise, const int32_t* n_valid,
                            int y_div, double jitter_base, int P, int f, int kind, hipStream_t stream) {
-    static const bool mfma_on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
-    static const bool fused_on = []() { const char* e = getenv("PACOH_RETRY_FUSED"); return !(e && e[0] == '0'); }();
+    const bool mfma_on = g_sw.mfma, fused_on = g_sw.retry_fused;
     if (!(mfma_on && fused_on && ll_enabled() && n >= LL_MIN_N)) return 1;
     return dense_ll_retry_try(A, resid, logp, alpha_out, info, scale, B, n, dtype, 1, 3, u_only, z, z_div, ls, os, noise, n_valid, y_div,
                               jitter_base, P, f, kind, stream);
@@ -248,7 +243,7 @@ int dense_chol_retry_fused(void* A, const void* resid, void* logp, void* alpha_o
 // u_only (only honoured on the MFMA path, i.e. when dense_chol_saves_inverse()): alpha_out receives u = L^-1 r instead of alpha
 int dense_chol_launch(void* A, const void* resid, void* logp, void* alpha_out, int32_t* info, double scale, int B, int n,
                       int dtype, int attempt, hipStream_t stream, int u_only) {
-    static const bool mfma_on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
+    const bool mfma_on = g_sw.mfma;
     if (mfma_on && ll_enabled() && n >= LL_MIN_N) {
         int rc = dense_ll_try(A, resid, logp, alpha_out, info, scale, B, n, dtype, attempt, u_only, stream);
         if (rc != 1) return rc;

@@ -702,7 +702,7 @@ void launch_bgemm(const GemmArgs& ga, int Bn, hipStream_t s, int mirror = 1) {
         launch_ztz<T>((const T*)ga.A, (T*)ga.C, ga.M, ga.info, Bn, s, mirror);
         return;
     }
-    static const bool tile_on = []() { const char* e = getenv("PACOH_GEMM_TILE"); return !(e && e[0] == '0'); }();
+    const bool tile_on = g_sw.gemm_tile;
     if (tile_on && ga.M >= 96 && ga.N >= 96 && ga.K >= 32 && (const void*)ga.C != ga.A && (const void*)ga.C != ga.B) {
         const int tm = (ga.M + 127) / 128, tn = (ga.N + 127) / 128;
         const int nt = ga.symC ? tm * (tm + 1) / 2 : tm * tn;
@@ -1072,7 +1072,7 @@ void launch_sub_copy(const T* src, long ss, int lds_, T* dst, long sd, int ldd, 
 // scratch: B (n1^2 + n2^2 + n1 n2) elements.  1: outside the plan.
 template <typename T>
 int trtri_blocked(T* A, const int32_t* info, int B, int n, T* scratch, size_t scratch_elems, hipStream_t s) {
-    static const bool on = []() { const char* e = getenv("PACOH_TRTRI_BLOCKED"); return !(e && e[0] == '0'); }();
+    const bool on = g_sw.trtri_blocked;
     const int dtype = sizeof(T) == 4 ? PACOH_F32 : PACOH_F64;
     if (!on || !scratch || n <= 512 || n > 1024) return 1;
     const int n1 = blocked_n1(n), n2 = n - n1;
@@ -1159,9 +1159,9 @@ size_t chol_blocked_scratch(int B, int n) {
 }
 template <typename T>
 bool chol_blocked_plan(int B, int n, size_t scratch_elems) {
-    static const bool on = []() { const char* e = getenv("PACOH_CHOL_BLOCKED"); return !(e && e[0] == '0'); }();
-    static const bool mfma_on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
-    static const bool ll_on = []() { const char* e = getenv("PACOH_CHOL_LL"); return !(e && e[0] == '0'); }();
+    const bool on = g_sw.chol_blocked;
+    const bool mfma_on = g_sw.mfma;
+    const bool ll_on = g_sw.chol_ll;
     const int dtype = sizeof(T) == 4 ? PACOH_F32 : PACOH_F64;
     if (!on || !mfma_on || !ll_on || n <= 512 || n > 1024) return false;
     const int n1 = blocked_n1(n), n2 = n - n1;
@@ -1234,7 +1234,7 @@ template <typename T>
 int launch_trtri(T* A, const int32_t* info, int B, int n, int mpad, size_t lds, int saved_inv, hipStream_t s, const T* u = nullptr,
                  T* alpha = nullptr, int* did_alpha = nullptr, T* scratch = nullptr, size_t scratch_elems = 0) {
     // the left-looking kernel (dense_trtri_ll.hip) needs the inverse diagonal blocks the MFMA Cholesky kernels leave behind
-    static const bool ll_on = []() { const char* e = getenv("PACOH_TRTRI_LL"); return !(e && e[0] == '0'); }();
+    const bool ll_on = g_sw.trtri_ll;
     if (ll_on && saved_inv && n >= 97) {
         const int rc = trtri_ll_try(A, info, B, n, sizeof(T) == 4 ? PACOH_F32 : PACOH_F64, s, u, alpha);
         if (rc != 1) { if (did_alpha && u && alpha) *did_alpha = 1; return rc; }
@@ -1337,7 +1337,7 @@ int lml_dense_impl(const void* z, int z_div, const void* mean, int mean_mode, co
         GemmArgs ga = {A, A, Wm, (long)n * n, (long)n * n, (long)n * n, n, n, n, n, n, n, 1, 0, 1, 1, 1.0, 0.0, info, 1};
         // fp64 ARD-RBF: the symmetric MFMA contraction (dense_grad_mfma.hip) reads the lower 64-tiles of W only -- the 128-tiles of
         // Z^T Z below the block diagonal are then not mirrored (268 MB of 32-byte-segment stores less per 256 x 512^2 launch)
-        static const bool gm_on = []() { const char* e = getenv("PACOH_GRAD_MFMA"); return !(e && e[0] == '0'); }();
+        const bool gm_on = g_sw.grad_mfma;
         const bool gm_plan = gm_on && dense_grad_mfma_plan(B, n, f, kind, dtype, nn * sizeof(T));
         launch_bgemm<T>(ga, B, s, gm_plan ? 0 : 1);                         // W = Z^T Z
         const long tz = (long)B * n * f;

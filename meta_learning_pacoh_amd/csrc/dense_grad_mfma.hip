@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(256, 4) dense_gram_row_kernel(const double* __
 // fp64 ARD-RBF Gram + noise for the factorisation, lower block triangle only; returns 1 when outside its plan (caller: gram_kernel)
 int dense_gram_mfma_try(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
                         int dtype, hipStream_t s) {
-    static const bool on = []() { const char* e = getenv("PACOH_GRAM_MFMA"); return !(e && e[0] == '0'); }();
+    const bool on = g_sw.gram_mfma;
     if (!on || dtype != PACOH_F64 || f > 8 || n < GT || !noise) return 1;
     const int nI = (n + GT - 1) / GT;
     // (one workgroup per tile -- dense_gram_tile_kernel<false> -- took 91 us per 256 x 512^2 launch, a row of tiles per workgroup 78)
@@ -396,7 +396,7 @@ int dense_gram_mfma_try(const void* z, int z_div, const void* ls, const void* os
 // pacoh_gram_rbf_ard with z1 == z2 (one point set, square, fp64, f <= 8, n >= 64): the whole symmetric matrix from its lower tiles
 int dense_gram_mfma_full(const void* z, int z_div, const void* ls, const void* os, const void* noise, void* K, int B, int P, int n, int f,
                          hipStream_t s) {
-    static const bool on = []() { const char* e = getenv("PACOH_GRAM_MFMA"); return !(e && e[0] == '0'); }();
+    const bool on = g_sw.gram_mfma;
     if (!on || f > 8 || n < GT) return 1;
     const int nI = (n + GT - 1) / GT;
     hipLaunchKernelGGL(dense_gram_tile_kernel<true>, dim3(nI * (nI + 1) / 2, B), dim3(256), 0, s, (const double*)z, z_div, (const double*)ls,
@@ -414,7 +414,7 @@ size_t dense_grad_mfma_scratch(int B, int n, int dtype) {
 // fp32 since round 5: the squared distances from one product cost ~1e-7 |z|^2 there -- harmless in the contraction, whose kernel
 // entries only weight sums (the Gram matrix that is FACTORED keeps its direct differences in fp32: dense_gram_mfma_try)
 bool dense_grad_mfma_plan(int B, int n, int f, int kind, int dtype, size_t scratch_bytes) {
-    static const bool f32_on = []() { const char* e = getenv("PACOH_GRAD_MFMA_F32"); return !(e && e[0] == '0'); }();
+    const bool f32_on = g_sw.grad_mfma_f32;
     return (dtype == PACOH_F64 || f32_on) && kind == PACOH_KERNEL_RBF && f <= 8 && n >= GT && dense_grad_mfma_scratch(B, n, dtype) <= scratch_bytes;
 }
 

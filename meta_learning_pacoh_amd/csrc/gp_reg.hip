@@ -56,10 +56,7 @@ static int launch_reg_predict(const GpMfmaArgs& a, const GpPredArgs& pa, int FP,
 
 // returns 1 if this path does not apply (n > 128, f > 4, or PACOH_GP_REG=0 / PACOH_GP_REG_PREDICT=0)
 int gp_reg_predict_try(const GpMfmaArgs& a, const GpPredArgs& pa, hipStream_t s) {
-    const char* e = getenv("PACOH_GP_REG");
-    if (e && e[0] == '0') return 1;
-    static const bool on = []() { const char* q = getenv("PACOH_GP_REG_PREDICT"); return !(q && q[0] == '0'); }();
-    if (!on || a.n > 128 || a.f > 4 || a.n < 1 || pa.m < 1) return 1;
+    if (!g_sw.gp_reg || !g_sw.gp_reg_predict || a.n > 128 || a.f > 4 || a.n < 1 || pa.m < 1) return 1;
     const int NB = (a.n + 15) / 16;
     const int FP = a.f <= 2 ? 2 : 4;
     switch (NB) {
@@ -74,25 +71,25 @@ int gp_reg_predict_try(const GpMfmaArgs& a, const GpPredArgs& pa, hipStream_t s)
 
 template <int NB, bool BWD>
 static int launch_reg(const GpMfmaArgs& a, int FP, hipStream_t s) {
+    const unsigned pad = g_sw.lds_pad_gp > 0 ? (unsigned)g_sw.lds_pad_gp : 0u;
     if (FP == 2) {
         if constexpr (BWD && (NB == 4 || NB == 8)) {
             if (!a.os && !a.d_os) {
-                hipLaunchKernelGGL((gp_reg_kernel<NB, 2, true, false>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+                hipLaunchKernelGGL((gp_reg_kernel<NB, 2, true, false>), dim3((unsigned)a.B), dim3(64), pad, s, a);
                 return launch_status();
             }
         }
-        hipLaunchKernelGGL((gp_reg_kernel<NB, 2, BWD>), dim3((unsigned)a.B), dim3(64), 0, s, a);
-    } else hipLaunchKernelGGL((gp_reg_kernel<NB, 4, BWD>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((gp_reg_kernel<NB, 2, BWD>), dim3((unsigned)a.B), dim3(64), pad, s, a);
+    } else hipLaunchKernelGGL((gp_reg_kernel<NB, 4, BWD>), dim3((unsigned)a.B), dim3(64), pad, s, a);
     return launch_status();
 }
 
 // returns 1 if this path does not apply (n > 128, f > 4, or PACOH_GP_REG=0)
 int gp_reg_try(const GpMfmaArgs& a, bool bwd, hipStream_t s) {
-    const char* e = getenv("PACOH_GP_REG");
-    if (e && e[0] == '0') return 1;
+    if (!g_sw.gp_reg) return 1;
     // (n > 64: one wave still holds the whole matrix -- 244 registers at n = 128, two waves per SIMD -- and beats the LDS-resident
     //  kernel, which runs one wave per SIMD there and moves every block through LDS)
-    static const int max_n = []() { const char* m = getenv("PACOH_GP_REG_MAX_N"); return m && m[0] ? atoi(m) : 128; }();
+    const int max_n = g_sw.gp_reg_max_n;
     if (a.n > max_n || a.n > 128 || a.f > 4 || a.n < 1) return 1;
     const int NB = (a.n + 15) / 16;
     const int FP = a.f <= 2 ? 2 : 4;

@@ -400,7 +400,7 @@ struct GpPredArgs {            // (same struct as in gp_reg_body.h)
 int gp_reg_predict_try(const GpMfmaArgs& a, const GpPredArgs& pa, hipStream_t s);      // ... its predictive form (n <= 64, no covariance)
 }
 static bool mfma_enabled() {
-    static const bool on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
+    const bool on = g_sw.mfma;
     return on;
 }
 static int try_mfma(const GpArgs<float>& a, bool bwd, hipStream_t s) {

@@ -513,8 +513,11 @@ void plan_net(MpArgs& a, int k, int off, int d_in, const int32_t* hidden, int nh
         if (l == 0) { L.a_in = a.o_a0; L.d_in = -1; }
         if (l < nh) {
             MpLayer& N = a.L[k][l + 1];
-            L.a_out = lds_top; L.s_out = N.S; N.a_in = lds_top; lds_top += a.pts * N.S;
-            L.d_out = lds_top; L.s_d = 32; N.d_in = lds_top; lds_top += a.pts * 32;
+            // (sized for whole 16-point tiles: the chains and weight tiles read the last tile's padding rows, which must be the plan's own
+            //  zeroed memory, never whatever follows it -- ADVICE r5)
+            const int pts16 = (a.pts + 15) & ~15;
+            L.a_out = lds_top; L.s_out = N.S; N.a_in = lds_top; lds_top += pts16 * N.S;
+            L.d_out = lds_top; L.s_d = 32; N.d_in = lds_top; lds_top += pts16 * 32;
         } else {
             L.a_out = out_off; L.s_out = out_stride; L.d_out = dout_off; L.s_d = out_stride;
         }
@@ -545,11 +548,12 @@ static int map_persist_plan(MpArgs& a, int n, int d, int tb, int K, int mean_mod
     auto take = [&](int count) { const int o = top; top += round4(count); return o; };
     a.S0 = round4(d + 1);
     a.o_hp = take(HP_SIZE);
-    a.a0_sz = round4(a.pts * a.S0); a.o_a0 = take(2 * a.a0_sz);
+    const int pts16 = (a.pts + 15) & ~15;              // whole 16-point tiles: padding rows are read (never stored) by the MFMA tiles
+    a.a0_sz = round4(pts16 * a.S0); a.o_a0 = take(2 * a.a0_sz);
     a.xs_sz = round4(a.pts * d); a.o_xs = take(2 * a.xs_sz);
     a.y_sz = round4(a.pts); a.o_y = take(2 * a.y_sz);
     a.o_nv = take(32);
-    a.o_mn = take(a.pts); a.o_zk = take(a.pts * f); a.o_dmn = take(a.pts); a.o_dzk = take(a.pts * f);
+    a.o_mn = take(pts16); a.o_zk = take(pts16 * f); a.o_dmn = take(pts16); a.o_dzk = take(pts16 * f);
     a.o_lml = take(16); a.o_info = take(16); a.o_dls = take(16 * 4); a.o_dos = take(16); a.o_dnz = take(16); a.o_dc = take(16); a.o_gl = take(16);
     int dp = 0;
     a.nets = 0;

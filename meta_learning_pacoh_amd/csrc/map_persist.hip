@@ -303,12 +303,26 @@ extern "C" int pacoh_map_persist(void* theta, void* exp_avg, void* exp_avg_sq, i
                                  void* loss_last, void* loss_cum, int32_t* fail_flag, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (dtype != PACOH_F32) return PACOH_ELIMIT;
+    if (f != features_of(f)) return PACOH_ELIMIT;          // (f carries no kernel-family bits here: the persistent kernel is RBF-only)
     if (!theta || !exp_avg || !exp_avg_sq || !x || !y || !idx_rows || !sc_rows || D <= 0 || n_seg < 0 || n_seg > 4 || n_sc < PACOH_SC_COUNT ||
         off_ls < 0 || off_noise < 0 || (n_seg > 0 && (!seg_lo || !seg_hi))) return PACOH_EINVAL;
     MpArgs a; int NB, FP;
     const int rc = map_persist_plan(a, n, d, tb, K, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel, kernel_hidden,
                                     n_kernel_hidden, f, &NB, &FP);
     if (rc != PACOH_OK) return rc;
+    // every range of the parameter row the kernel reads AND writes (theta and both Adam moments, prologue and epilogue) must lie
+    // inside [0, D): a wrong layout from a direct C caller would otherwise be a silent out-of-bounds device write
+    {
+        auto inside = [D](long lo, long len) { return lo >= 0 && len >= 0 && lo + len <= (long)D; };
+        for (int k = 0; k < a.nets; ++k)
+            for (int l = 0; l < a.nl[k]; ++l) {
+                const MpLayer& Ly = a.L[k][l];
+                if (!inside(Ly.b_flat, Ly.out) || !inside(Ly.w_flat, (long)Ly.out * Ly.in)) return PACOH_EINVAL;
+            }
+        if (!inside(off_ls, f) || !inside(off_noise, 1) || (off_os >= 0 && !inside(off_os, 1)) ||
+            (mean_mode == PACOH_MEAN_CONST && !inside(off_mean, 1))) return PACOH_EINVAL;
+        for (int s = 0; s < n_seg; ++s) if (seg_lo[s] < 0 || seg_hi[s] < seg_lo[s] || seg_hi[s] > D) return PACOH_EINVAL;
+    }
     a.theta = (float*)theta; a.m = (float*)exp_avg; a.v = (float*)exp_avg_sq; a.D = D;
     a.x = (const float*)x; a.y = (const float*)y; a.n_valid = n_valid;
     a.idx_all = idx_rows; a.sc_all = (const float*)sc_rows; a.n_sc = n_sc;
@@ -319,12 +333,8 @@ extern "C" int pacoh_map_persist(void* theta, void* exp_avg, void* exp_avg_sq, i
     for (int s = 0; s < n_seg; ++s) { a.lo[s] = seg_lo[s]; a.hi[s] = seg_hi[s]; }
     const size_t bytes = (size_t)a.total * sizeof(float);
 #define PACOH_MP_LAUNCH(nb, fp) do { \
-        static bool attr_done = false; \
-        if (!attr_done) { \
-            if (hipFuncSetAttribute((const void*)map_persist_kernel<nb, fp>, hipFuncAttributeMaxDynamicSharedMemorySize, MP_LDS_BYTES) != hipSuccess) { \
-                (void)hipGetLastError(); return PACOH_ELIMIT; } \
-            attr_done = true; \
-        } \
+        static std::atomic<uint64_t> attr_done{0}; \
+        { const int rc_a = lds_opt_in((const void*)map_persist_kernel<nb, fp>, MP_LDS_BYTES, attr_done); if (rc_a != PACOH_OK) return rc_a; } \
         hipLaunchKernelGGL((map_persist_kernel<nb, fp>), dim3(1), dim3(MP_NT), bytes, (hipStream_t)stream, a); } while (0)
     if (NB == 1 && FP == 2) PACOH_MP_LAUNCH(1, 2);
     else if (NB == 1) PACOH_MP_LAUNCH(1, 4);

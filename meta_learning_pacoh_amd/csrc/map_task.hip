@@ -13,7 +13,7 @@ namespace pacoh {
 
 // mlp_fused.hip: the slab reduction as a launch of its own (what mlp_fused_bwd issues behind its backward kernel)
 int fused_reduce_launch(const float* slab0, int wd0, long off0, const float* slab1, int wd1, long off1, int nets, float* d_theta,
-                        long d_theta_stride, int slabs, const HyperBwdArgs<float>* tail, float* img_th, const int* img_map, hipStream_t s);
+                        long d_theta_stride, int slabs, const HyperBwdArgs<float>* tail, float* img_th, const int* img_map, hipStream_t s, int P = 1);
 
 namespace {
 
@@ -29,6 +29,13 @@ struct MtArgs {
     long* adv_counter;               // the pipelined feed's step counter: advanced by workgroup 0 (as mlp_fused_bwd_kernel does)
     const float* thimg;              // the parameter image in memory (map_task_setup_kernel; kept current by the slab reduction's AdamW)
     int tb_total;
+    // MULTI (round 6, PACOH-SVGD / PACOH-VI: P parameter rows -- particles / posterior samples --, problem b = task * P + row, one
+    // workgroup per (task group, row)): the rows' stride, the image's gather map (entry q of the image = element src_map[q] of a row,
+    // -1: zero; a row changes every step, so every workgroup decodes its own image), and the SVGD step's distance matrix + counter
+    // in extra workgroups behind the groups * P task workgroups (step_tail.h)
+    long theta_stride; int P, groups;
+    const int* src_map;
+    SvgdDistTail<float> sv;
     int ntask[3];                    // tasks per phase of a FULL workgroup, planned by the host (mt_plan) ...
     MpTask plan[MT_MAXTASKS];        // ... phase 0 = plan[0 .. ntask[0]), phase 2 = plan[ntask[0] ..): the delta chains are phase 0's tasks again
 };
@@ -78,9 +85,23 @@ int mt_plan(MtArgs& ka) {
 // The parameter image in MEMORY (once per training call, and whenever theta was changed from outside): thimg[DP] as the kernels keep it
 // in LDS, and for every network entry of theta its place in the image (-1 elsewhere) -- with it the slab reduction's AdamW step writes
 // each updated entry into the image too, so that the task kernel's prologue is a copy.
-__global__ void __launch_bounds__(MT_NT) map_task_setup_kernel(MtArgs ka, float* thimg, int* img_map, int Dmax) {
+// (MULTI: src_map[DP], the inverse map, instead: thimg == nullptr)
+__global__ void __launch_bounds__(MT_NT) map_task_setup_kernel(MtArgs ka, float* thimg, int* img_map, int Dmax, int* src_map) {
     const MpArgs& a = ka.p;
     const int t = threadIdx.x;
+    if (src_map) {
+        for (int q = t; q < a.DP; q += MT_NT) src_map[q] = -1;
+        __syncthreads();
+        for (int k = 0; k < a.nets; ++k)
+            for (int l = 0; l < a.nl[k]; ++l) {
+                const MpLayer L = mp_layer_karg(k, l);
+                for (int e = t; e < L.out * (L.in + 1); e += MT_NT) {
+                    const int j = e / (L.in + 1), i = e - j * (L.in + 1);
+                    src_map[L.w_lds + j * L.S + i] = i < L.in ? L.w_flat + j * L.in + i : L.b_flat + j;
+                }
+            }
+        return;
+    }
     for (int q = t; q < a.DP; q += MT_NT) thimg[q] = 0.0f;
     for (int q = t; q < Dmax; q += MT_NT) img_map[q] = -1;
     __syncthreads();
@@ -97,7 +118,7 @@ __global__ void __launch_bounds__(MT_NT) map_task_setup_kernel(MtArgs ka, float*
         }
 }
 
-template <int NB, int FP>
+template <int NB, int FP, bool MULTI>
 __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ __attribute__((aligned(16))) int ltab[2 * MP_MAXL * 16];
@@ -107,7 +128,15 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
     const int lane = t & 63, r16 = t & 15, g4 = (t >> 4) & 3;
     constexpr int NW = MT_NT / 64;
     const int n = a.n, d = a.d, f = a.f;
-    const int task0 = blockIdx.x * a.tb;
+    const int P = MULTI ? ka.P : 1;
+    if (MULTI && (int)blockIdx.x >= ka.groups * P) {       // the SVGD step's distance matrix, snapshot and counter increment
+        svgd_dist_tail<float>(ka.sv, (int)blockIdx.x - ka.groups * P, (int)gridDim.x - ka.groups * P);
+        return;
+    }
+    const int grp = MULTI ? (int)blockIdx.x / P : (int)blockIdx.x;       // task group of this workgroup ...
+    const int pp = MULTI ? (int)blockIdx.x - grp * P : 0;               // ... and its parameter row
+    const float* trow = a.theta + (MULTI ? (long)pp * ka.theta_stride : 0L);
+    const int task0 = grp * a.tb;
     const int tb = ka.tb_total - task0 < a.tb ? ka.tb_total - task0 : a.tb;      // tasks of this workgroup
     const int pts = tb * n;
     float* th = lds + a.o_th;
@@ -146,10 +175,10 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
     if (mover) mv_val = mv_r < n * d ? ka.bx[(long)(task0 + mv_s) * (n * d) + mv_r] : ka.by[(long)(task0 + mv_s) * n + (mv_r - n * d)];
     if (t < tb && ka.bnv) nv_val = ka.bnv[task0 + t];
     if (t < 7) {
-        if (t < f) hp_val = ka.hyp_ls[t];
-        else if (t == 4) { if (ka.hyp_os) hp_val = ka.hyp_os[0]; }
-        else if (t == 5) hp_val = ka.hyp_noise[0];
-        else if (t == 6 && a.off_const >= 0) hp_val = a.theta[a.off_const];
+        if (t < f) hp_val = ka.hyp_ls[pp * f + t];
+        else if (t == 4) { if (ka.hyp_os) hp_val = ka.hyp_os[pp]; }
+        else if (t == 5) hp_val = ka.hyp_noise[pp];
+        else if (t == 6 && a.off_const >= 0) hp_val = trow[a.off_const];
     }
     if (wave == NW - 1) {                               // the last wave copies the plan out of the kernel arguments
         kint_t kt = (kint_t)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(MtArgs, plan));
@@ -167,7 +196,17 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
         constexpr int IT = MT_NT - 64;
         // the parameter image, 16 bytes per lane from its copy in memory (decoding it from theta's layout cost every workgroup ~300
         // instructions per launch: 5 000 cycles)
-        {
+        if (MULTI) {                                      // this row's image through the gather map: two round trips (the map is shared by all)
+            const int4* sm = reinterpret_cast<const int4*>(ka.src_map);
+            float4* dst = reinterpret_cast<float4*>(th);
+            for (int q = t; q < a.DP >> 2; q += IT) {
+                const int4 m4 = sm[q];
+                float4 v;
+                v.x = m4.x >= 0 ? trow[m4.x] : 0.0f; v.y = m4.y >= 0 ? trow[m4.y] : 0.0f;
+                v.z = m4.z >= 0 ? trow[m4.z] : 0.0f; v.w = m4.w >= 0 ? trow[m4.w] : 0.0f;
+                dst[q] = v;
+            }
+        } else {
             const float4* src = reinterpret_cast<const float4*>(ka.thimg);
             float4* dst = reinterpret_cast<float4*>(th);
             for (int q = t; q < a.DP >> 2; q += IT) dst[q] = src[q];
@@ -180,7 +219,7 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
     }
     MP_STAMP();
     if (t < 7 && (t < f || t >= 4)) hp[t] = hp_val;
-    if (t < tb) lds[a.o_gl + t] = -1.0f;               // loss = -sum_t mll_t (GPR_meta_mll.py:109-113)
+    if (t < tb) lds[a.o_gl + t] = MULTI ? 1.0f : -1.0f;       // MAP: loss = -sum_t mll_t (GPR_meta_mll.py:109-113); SVGD / VI: the score of +sum_t mll_t
     if (mover) {
         if (mv_r < n * d) {
             const int i = mv_r / d, c = mv_r - i * d;
@@ -240,10 +279,18 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
         g.ls = sp(hp); g.os = sp(has_os ? hp + 4 : nullptr); g.noise = sp(hp + 5);
         g.n_valid = sp(ka.bnv ? reinterpret_cast<int*>(lds + a.o_nv) : nullptr);
         g.g_lml = sp(lds + a.o_gl);
-        g.lml = ka.lml_g + task0; g.info = ka.info_g + task0;
         g.d_z = sp(kernel_nn ? lds + a.o_dzk : nullptr);
-        g.d_mean = mean_mode == PACOH_MEAN_VECTOR ? sp(lds + a.o_dmn) : (mean_mode == PACOH_MEAN_CONST ? ka.dc_g + task0 : nullptr);
-        g.d_ls = ka.dls_g + (long)task0 * f; g.d_os = has_os ? ka.dos_g + task0 : nullptr; g.d_noise = ka.dnz_g + task0;
+        if (MULTI) {
+            // (consecutive tasks of a row are P problems apart in the per-problem arrays: the body writes the workgroup's LDS slots, which
+            //  the first threads scatter behind the next barrier)
+            g.lml = sp(lds + a.o_lml); g.info = sp(reinterpret_cast<int32_t*>(lds + a.o_info));
+            g.d_mean = sp(mean_mode == PACOH_MEAN_VECTOR ? lds + a.o_dmn : (mean_mode == PACOH_MEAN_CONST ? lds + a.o_dc : nullptr));
+            g.d_ls = sp(lds + a.o_dls); g.d_os = sp(has_os ? lds + a.o_dos : nullptr); g.d_noise = sp(lds + a.o_dnz);
+        } else {
+            g.lml = ka.lml_g + task0; g.info = ka.info_g + task0;
+            g.d_mean = mean_mode == PACOH_MEAN_VECTOR ? sp(lds + a.o_dmn) : (mean_mode == PACOH_MEAN_CONST ? ka.dc_g + task0 : nullptr);
+            g.d_ls = ka.dls_g + (long)task0 * f; g.d_os = has_os ? ka.dos_g + task0 : nullptr; g.d_noise = ka.dnz_g + task0;
+        }
         g.B = ka.tb_total; g.P = 1; g.n = sg(n); g.f = sg(f);
         constexpr int NP = 16 * NB;
         float* ws = lds + sg(a.o_gp) + wave * sg(a.gpw);
@@ -254,6 +301,13 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
     MP_STAMP();
     if (a.nets > 0) {
         __syncthreads();
+        if (MULTI && t < tb) {
+            const long b = (long)(task0 + t) * P + pp;
+            ka.lml_g[b] = lds[a.o_lml + t]; ka.info_g[b] = reinterpret_cast<const int32_t*>(lds + a.o_info)[t]; ka.dnz_g[b] = lds[a.o_dnz + t];
+            if (ka.hyp_os) ka.dos_g[b] = lds[a.o_dos + t];
+            if (a.mean_mode == PACOH_MEAN_CONST) ka.dc_g[b] = lds[a.o_dc + t];
+            for (int c = 0; c < f; ++c) ka.dls_g[b * f + c] = lds[a.o_dls + t * f + c];
+        }
         MP_STAMP();
         run_phase(1);
         __syncthreads();
@@ -275,7 +329,12 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
                     int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
                     int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
                     const void* hyp_ls, const void* hyp_os, const void* hyp_noise, void* workspace, size_t workspace_bytes,
-                    void* d_theta, long d_theta_stride, const HyperBwdArgs<float>* tail_in, int plan_only, size_t* need_bytes, int D, hipStream_t stream) {
+                    void* d_theta, long d_theta_stride, const HyperBwdArgs<float>* tail_in, int plan_only, size_t* need_bytes, int D, hipStream_t stream,
+                    int multi, int P, long theta_stride, const SvgdDistTail<float>* sv) {
+    // multi: P parameter rows of stride theta_stride (PACOH-SVGD's particles / PACOH-VI's posterior samples), hyp_* = [P, f] / [P],
+    // problem b = task * P + row; sv: the SVGD step's distance tail | nullptr
+    if (!multi) P = 1;
+    if (P < 1) return PACOH_EINVAL;
     MtArgs ka;
     memset(&ka, 0, sizeof(ka));
     MpArgs& a = ka.p;
@@ -289,8 +348,9 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
                                     n_kernel_hidden, f, &NB, &FP);
     if (rc != PACOH_OK) return rc;
     if (a.nets < 1 || tpw * n * (d + 1) > MT_NT) return PACOH_ELIMIT;
-    const int wgs = (tb_total + tpw - 1) / tpw;
-    // workspace: slabs [wgs][dnet] per network, then lml / d_ls (f) / d_os / d_noise / d_const [tb_total] and info
+    const int groups = (tb_total + tpw - 1) / tpw;
+    const int wgs = groups * P;
+    // workspace: slabs [wgs][dnet] per network, then lml / d_ls (f) / d_os / d_noise / d_const [tb_total * P] and info
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     size_t o_slab[2] = {0, 0};
@@ -303,9 +363,10 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
     if (mt_plan(ka) != PACOH_OK) return PACOH_ELIMIT;        // (needs flat0[]: the slab-relative entries)
     const int Dmax = D;                                 // (the index map covers the whole parameter row)
     for (int k = 0; k < a.nets; ++k) if (plan_only != 1 && ka.flat0[k] + ka.dnet[k] > D) return PACOH_EINVAL;
-    const size_t o_img = carve((size_t)a.DP * 4), o_map = carve((size_t)Dmax * 4);
-    const size_t o_lml = carve((size_t)tb_total * 4), o_dls = carve((size_t)tb_total * f * 4), o_dos = carve((size_t)tb_total * 4),
-                 o_dnz = carve((size_t)tb_total * 4), o_dc = carve((size_t)tb_total * 4), o_info = carve((size_t)tb_total * 4);
+    const size_t o_img = carve((size_t)a.DP * 4), o_map = carve(multi ? 256 : (size_t)Dmax * 4);      // (multi: o_img holds the gather map)
+    const size_t B_ = (size_t)tb_total * P;
+    const size_t o_lml = carve(B_ * 4), o_dls = carve(B_ * f * 4), o_dos = carve(B_ * 4), o_dnz = carve(B_ * 4), o_dc = carve(B_ * 4),
+                 o_info = carve(B_ * 4);
     if (need_bytes) *need_bytes = off;
     if (plan_only == 1) return PACOH_OK;
     if (!workspace || workspace_bytes < off) return PACOH_EINVAL;
@@ -319,32 +380,38 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
     ka.dc_g = (float*)(ws + o_dc); ka.info_g = (int32_t*)(ws + o_info);
     ka.tb_total = tb_total;
     ka.thimg = (const float*)(ws + o_img);
-    if (plan_only == 2) {                               // the image and its index map (pacoh_map_task_setup)
-        hipLaunchKernelGGL(map_task_setup_kernel, dim3(1), dim3(MT_NT), 0, stream, ka, (float*)(ws + o_img), (int*)(ws + o_map), Dmax);
+    ka.theta_stride = theta_stride; ka.P = P; ka.groups = groups; ka.src_map = (const int*)(ws + o_img);
+    if (plan_only == 2) {                               // the image and its index map (pacoh_map_task_setup) / the gather map (pacoh_svgd_task_setup)
+        hipLaunchKernelGGL(map_task_setup_kernel, dim3(1), dim3(MT_NT), 0, stream, ka, multi ? nullptr : (float*)(ws + o_img), (int*)(ws + o_map), Dmax,
+                           multi ? (int*)(ws + o_img) : nullptr);
         return launch_status();
+    }
+    int tail_wgs = 0;
+    if (multi && sv && sv->X) {                         // one extra workgroup per particle pair of the lower triangle's rows (<= 256)
+        ka.sv = *sv;
+        tail_wgs = sv->P * sv->P < 256 ? sv->P * sv->P : 256;
     }
     HyperBwdArgs<float> tail = *tail_in;
     tail.d_ls = ka.dls_g; tail.d_os = hyp_os ? ka.dos_g : nullptr; tail.d_noise = ka.dnz_g; tail.d_const = mean_mode == PACOH_MEAN_CONST ? ka.dc_g : nullptr;
     tail.lml = tail.lik ? ka.lml_g : nullptr; tail.info = tail.fail_flag ? ka.info_g : nullptr;
-    ka.adv_counter = const_cast<long*>(tail.nx.counter);
+    ka.adv_counter = multi ? nullptr : const_cast<long*>(tail.nx.counter);
     const size_t bytes = (size_t)a.total * sizeof(float);
-#define PACOH_MT_LAUNCH(nb, fp) do { \
-        static bool attr_done = false; \
-        if (!attr_done) { \
-            if (hipFuncSetAttribute((const void*)map_task_kernel<nb, fp>, hipFuncAttributeMaxDynamicSharedMemorySize, MP_LDS_BYTES) != hipSuccess) { \
-                (void)hipGetLastError(); return PACOH_ELIMIT; } \
-            attr_done = true; \
-        } \
-        hipLaunchKernelGGL((map_task_kernel<nb, fp>), dim3((unsigned)wgs), dim3(MT_NT), bytes, stream, ka); } while (0)
-    if (NB == 1 && FP == 2) PACOH_MT_LAUNCH(1, 2);
-    else if (NB == 1) PACOH_MT_LAUNCH(1, 4);
-    else if (FP == 2) PACOH_MT_LAUNCH(2, 2);
-    else PACOH_MT_LAUNCH(2, 4);
+#define PACOH_MT_LAUNCH(nb, fp, mu) do { \
+        static std::atomic<uint64_t> attr_done{0}; \
+        { const int rc_a = lds_opt_in((const void*)map_task_kernel<nb, fp, mu>, MP_LDS_BYTES, attr_done); if (rc_a != PACOH_OK) return rc_a; } \
+        hipLaunchKernelGGL((map_task_kernel<nb, fp, mu>), dim3((unsigned)(wgs + tail_wgs)), dim3(MT_NT), bytes, stream, ka); } while (0)
+#define PACOH_MT_PICK(mu) do { \
+        if (NB == 1 && FP == 2) PACOH_MT_LAUNCH(1, 2, mu); \
+        else if (NB == 1) PACOH_MT_LAUNCH(1, 4, mu); \
+        else if (FP == 2) PACOH_MT_LAUNCH(2, 2, mu); \
+        else PACOH_MT_LAUNCH(2, 4, mu); } while (0)
+    if (multi) PACOH_MT_PICK(true); else PACOH_MT_PICK(false);
+#undef PACOH_MT_PICK
 #undef PACOH_MT_LAUNCH
     if (launch_status() != PACOH_OK) return PACOH_ELAUNCH;
     return fused_reduce_launch(ka.slab[0], ka.dnet[0], ka.flat0[0], a.nets > 1 ? ka.slab[1] : nullptr, a.nets > 1 ? ka.dnet[1] : 0,
-                               a.nets > 1 ? ka.flat0[1] : 0, a.nets, (float*)d_theta, d_theta_stride, wgs, &tail, (float*)(ws + o_img),
-                               (const int*)(ws + o_map), stream);
+                               a.nets > 1 ? ka.flat0[1] : 0, a.nets, (float*)d_theta, d_theta_stride, groups, &tail,
+                               multi ? nullptr : (float*)(ws + o_img), multi ? nullptr : (const int*)(ws + o_map), stream, P);
 }
 
 }  // namespace pacoh

@@ -6,7 +6,29 @@
 #include "hyper_tail.h"
 #include "step_tail.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 namespace pacoh {
+
+// ---- the environment switches (switches.h): read when the library is loaded, again only through pacoh_reload_env --------------
+void read_switches(Switches& s) {
+    auto off0 = [](const char* name) { const char* e = getenv(name); return !(e && e[0] == '0'); };     // on unless NAME=0
+    auto num = [](const char* name, int dflt) { const char* e = getenv(name); return (e && e[0]) ? atoi(e) : dflt; };
+    s.chol_ll = off0("PACOH_CHOL_LL"); s.trtri_ll = off0("PACOH_TRTRI_LL"); s.retry_fused = off0("PACOH_RETRY_FUSED");
+    s.gemm_tile = off0("PACOH_GEMM_TILE"); s.trtri_blocked = off0("PACOH_TRTRI_BLOCKED"); s.chol_blocked = off0("PACOH_CHOL_BLOCKED");
+    s.grad_mfma = off0("PACOH_GRAD_MFMA"); s.grad_mfma_f32 = off0("PACOH_GRAD_MFMA_F32"); s.gram_mfma = off0("PACOH_GRAM_MFMA");
+    s.dense_pad = off0("PACOH_DENSE_PAD");
+    s.mfma = num("PACOH_DISABLE_MFMA", 0) != 1;
+    s.gp_reg = off0("PACOH_GP_REG"); s.gp_reg_predict = off0("PACOH_GP_REG_PREDICT"); s.gp_reg_max_n = num("PACOH_GP_REG_MAX_N", 128);
+    s.fused_mlp = num("PACOH_DISABLE_FUSED_MLP", 0) == 0;
+    const char* e = getenv("PACOH_MLP_PATH");
+    s.mlp_path = !e ? 0 : (!strcmp(e, "mfma") ? 1 : (!strcmp(e, "layers") ? 3 : 0));
+    s.mlp_stash = num("PACOH_MLP_STASH", -1);
+    s.lds_pad_gp = num("PACOH_LDS_PAD_GP", -1); s.lds_pad_mlp = num("PACOH_LDS_PAD_MLP", -1);
+    s.fused_bwd_pb = num("PACOH_FUSED_BWD_PB", 0); s.fused_fwd_pb = num("PACOH_FUSED_FWD_PB", 0); s.fused_fwd_tpw = num("PACOH_FUSED_FWD_TPW", 0);
+}
+Switches g_sw = []() { Switches s; read_switches(s); return s; }();
 
 // ---- softplus (torch.nn.functional.softplus: beta=1, threshold=20) ------------------------------
 template <typename T>
@@ -697,7 +719,8 @@ extern "C" int pacoh_gather_tasks(const void* x, const void* y, const int32_t* n
     return launch_status();
 }
 
-extern "C" int pacoh_abi_version(void) { return 13; }
+extern "C" int pacoh_abi_version(void) { return 14; }
+extern "C" void pacoh_reload_env(void) { read_switches(g_sw); }
 
 extern "C" int pacoh_hyper_fwd(const void* theta, long theta_stride, int P, int off_ls, int f, int off_os, int off_noise,
                                double noise_floor, void* ls, void* os, void* noise, int dtype, void* stream) {

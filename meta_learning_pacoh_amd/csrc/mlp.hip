@@ -50,13 +50,7 @@ __global__ void __launch_bounds__(256) reduce_tasks_kernel(const T* __restrict__
 
 enum MlpPath { PATH_FUSED = 0, PATH_MFMA = 1, PATH_LAYERS = 3 };
 
-static int first_allowed_path() {          // read on every call (a getenv): tests switch paths inside one process
-    const char* e = getenv("PACOH_MLP_PATH");
-    if (!e) return (int)PATH_FUSED;
-    if (!strcmp(e, "mfma")) return (int)PATH_MFMA;
-    if (!strcmp(e, "layers")) return (int)PATH_LAYERS;
-    return (int)PATH_FUSED;
-}
+static int first_allowed_path() { return g_sw.mlp_path; }      // (PACOH_MLP_PATH: switches.h; tests switch it through pacoh_reload_env)
 
 static int args_ok(int d_in, const int32_t* hidden, int n_hidden, int d_out) {
     if (d_in <= 0 || d_out <= 0 || n_hidden < 0 || (n_hidden > 0 && !hidden)) return PACOH_EINVAL;
@@ -419,15 +413,16 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
                     int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
                     int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
                     const void* hyp_ls, const void* hyp_os, const void* hyp_noise, void* workspace, size_t workspace_bytes,
-                    void* d_theta, long d_theta_stride, const HyperBwdArgs<float>* tail_in, int plan_only, size_t* need_bytes, int D, hipStream_t stream);
+                    void* d_theta, long d_theta_stride, const HyperBwdArgs<float>* tail_in, int plan_only, size_t* need_bytes, int D, hipStream_t stream,
+                    int multi = 0, int P = 1, long theta_stride = 0, const SvgdDistTail<float>* sv = nullptr);
 }
 extern "C" size_t pacoh_map_task_workspace_bytes(int D, int n, int d, int tb, int mean_mode, const int32_t* mean_hidden, int n_mean_hidden, int kernel_nn,
                                                  const int32_t* kernel_hidden, int n_kernel_hidden, int f, int dtype) {
-    if (dtype != PACOH_F32 || tb <= 0 || D <= 0) return 0;
+    if (dtype != PACOH_F32 || tb <= 0 || D <= 0 || kernel_of(f) != PACOH_KERNEL_RBF) return 0;      // (the fused kernel is RBF-only)
     size_t need = 0;
     HyperBwdArgs<float> none = {};
     const int rc = map_task_launch(nullptr, nullptr, nullptr, nullptr, n, d, tb, mean_mode, 0, mean_hidden, n_mean_hidden, kernel_nn, 0, kernel_hidden,
-                                   n_kernel_hidden, f, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, &none, 1, &need, D, nullptr);
+                                   n_kernel_hidden, features_of(f), nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, &none, 1, &need, D, nullptr);
     return rc == PACOH_OK ? need : 0;
 }
 extern "C" int pacoh_map_task_setup(const void* theta, int D, int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
@@ -435,6 +430,7 @@ extern "C" int pacoh_map_task_setup(const void* theta, int D, int n, int d, int 
                                     void* workspace, size_t workspace_bytes, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (dtype != PACOH_F32) return PACOH_ELIMIT;
+    if (kernel_of(f) != PACOH_KERNEL_RBF) return PACOH_ELIMIT;       // (the fused kernel implements the RBF Gram and gradient only)
     if (!theta || !workspace || tb <= 0 || D <= 0) return PACOH_EINVAL;
     HyperBwdArgs<float> none = {};
     return map_task_launch(theta, nullptr, nullptr, nullptr, n, d, tb, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel,
@@ -449,6 +445,7 @@ extern "C" int pacoh_map_task_step(const void* theta, long theta_stride, const v
                                    void* workspace, size_t workspace_bytes, const pacoh_adam_inline* opt, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (dtype != PACOH_F32) return PACOH_ELIMIT;
+    if (kernel_of(f) != PACOH_KERNEL_RBF) return PACOH_ELIMIT;       // (a non-RBF family must not silently train with the RBF kernel)
     if (!theta || !batch_x || !batch_y || !ls || !noise || !d_theta || !workspace || tb <= 0 || off_ls < 0 || off_noise < 0 || (os == nullptr) != (off_os < 0))
         return PACOH_EINVAL;
     if (opt && (!adam_inline_ok(opt, 1, lik) || opt->n_seg < 1)) return PACOH_EINVAL;
@@ -461,6 +458,55 @@ extern "C" int pacoh_map_task_step(const void* theta, long theta_stride, const v
     return map_task_launch(theta, batch_x, batch_y, batch_n_valid, n, d, tb, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel,
                            kernel_hidden, n_kernel_hidden, features_of(f), ls, os, noise, workspace, workspace_bytes, d_theta, d_theta_stride, &tail, 0,
                            nullptr, (int)theta_stride, (hipStream_t)stream);
+}
+
+// ---- the same kernel with P parameter rows (round 6): the likelihood half of a PACOH-SVGD / PACOH-VI step -- forward of both networks,
+// GP LML + gradient, both networks' backward of every (task, row) problem in ONE launch, then the slab reduction with the step's
+// hyper-parameter tail: two launches where the general path needs four (random_gp.py:204-222, svgd.py:12-28, GPR_meta_vi.py:216-224) --
+extern "C" size_t pacoh_svgd_task_workspace_bytes(int D, int P, int n, int d, int tb, int mean_mode, const int32_t* mean_hidden, int n_mean_hidden,
+                                                  int kernel_nn, const int32_t* kernel_hidden, int n_kernel_hidden, int f, int dtype) {
+    if (dtype != PACOH_F32 || tb <= 0 || D <= 0 || P <= 0 || kernel_of(f) != PACOH_KERNEL_RBF) return 0;
+    size_t need = 0;
+    HyperBwdArgs<float> none = {};
+    const int rc = map_task_launch(nullptr, nullptr, nullptr, nullptr, n, d, tb, mean_mode, 0, mean_hidden, n_mean_hidden, kernel_nn, 0, kernel_hidden,
+                                   n_kernel_hidden, features_of(f), nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, &none, 1, &need, D, nullptr, 1, P, D,
+                                   nullptr);
+    return rc == PACOH_OK ? need : 0;
+}
+extern "C" int pacoh_svgd_task_setup(int D, int P, int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
+                                     int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
+                                     void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (dtype != PACOH_F32 || kernel_of(f) != PACOH_KERNEL_RBF) return PACOH_ELIMIT;
+    if (!workspace || tb <= 0 || D <= 0 || P <= 0) return PACOH_EINVAL;
+    HyperBwdArgs<float> none = {};
+    // (the gather map depends on the layout only: no parameter row is read here)
+    return map_task_launch(workspace, nullptr, nullptr, nullptr, n, d, tb, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel,
+                           kernel_hidden, n_kernel_hidden, features_of(f), nullptr, nullptr, nullptr, workspace, workspace_bytes, nullptr, 0, &none, 2,
+                           nullptr, D, (hipStream_t)stream, 1, P, D, nullptr);
+}
+extern "C" int pacoh_svgd_task_step(const void* theta, long theta_stride, int P, const void* batch_x, const void* batch_y,
+                                    const int32_t* batch_n_valid, int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden,
+                                    int n_mean_hidden, int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
+                                    const void* ls, const void* os, const void* noise, int off_ls, int off_os, int off_noise,
+                                    void* d_theta, long d_theta_stride, void* lik, double lik_scale, int32_t* fail_flag,
+                                    void* workspace, size_t workspace_bytes, const void* svgd_X, void* svgd_workspace, int svgd_D, int64_t* counter,
+                                    int want_bandwidth, int dtype, void* stream) {
+    if (check_dtype(dtype)) return PACOH_EDTYPE;
+    if (dtype != PACOH_F32 || kernel_of(f) != PACOH_KERNEL_RBF) return PACOH_ELIMIT;
+    if (!theta || !batch_x || !batch_y || !ls || !noise || !d_theta || !workspace || tb <= 0 || P <= 0 || off_ls < 0 || off_noise < 0 ||
+        (os == nullptr) != (off_os < 0) || theta_stride <= 0) return PACOH_EINVAL;
+    if ((svgd_X == nullptr) != (svgd_workspace == nullptr) || (svgd_X && svgd_D <= 0) || (want_bandwidth && !svgd_workspace)) return PACOH_EINVAL;
+    if (want_bandwidth && P > 64) return PACOH_ELIMIT;
+    float* d2 = (float*)svgd_workspace;
+    SvgdDistTail<float> sv = {(const float*)svgd_X, d2, d2 ? d2 + P * P : nullptr, P, svgd_D, (long*)counter};
+    HyperBwdArgs<float> tail = {(const float*)theta, theta_stride, P, tb, off_ls, features_of(f), off_os, off_noise,
+                                mean_mode == PACOH_MEAN_CONST ? off_mean : -1, nullptr, nullptr, nullptr, nullptr, (float*)d_theta, d_theta_stride,
+                                nullptr, (float*)lik, (float)lik_scale, nullptr, fail_flag, 0, want_bandwidth ? d2 : nullptr, P,
+                                want_bandwidth ? d2 + svgd_bw_slot(P, svgd_D) : nullptr, AdamInline<float>{}, StepNextArgs<float>{}};
+    return map_task_launch(theta, batch_x, batch_y, batch_n_valid, n, d, tb, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel,
+                           kernel_hidden, n_kernel_hidden, features_of(f), ls, os, noise, workspace, workspace_bytes, d_theta, d_theta_stride, &tail, 0,
+                           nullptr, (int)theta_stride, (hipStream_t)stream, 1, P, theta_stride, svgd_X ? &sv : nullptr);
 }
 
 // 1 if these network shapes run on the fused fp32 kernels (mlp_fused.hip) -- where the gradient epilogue can carry the optimizer

@@ -557,13 +557,9 @@ __global__ void __launch_bounds__(256) fused_reduce_slab_kernel(SlabReduce s0, S
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
-static int fused_env(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return (e && e[0]) ? atoi(e) : dflt;
-}
 
 bool mlp_fused_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_out) {
-    static const bool on = fused_env("PACOH_DISABLE_FUSED_MLP", 0) == 0;
+    const bool on = g_sw.fused_mlp;
     if (!on || n_hidden < 1 || n_hidden > FMAXNH || d_in < 1 || d_in > 4 || d_out < 1 || d_out > 2) return false;
     for (int l = 0; l < n_hidden; ++l) if (hidden[l] < 1 || hidden[l] > 32) return false;
     return true;
@@ -579,9 +575,9 @@ static int fused_dnet(int d_in, const int32_t* hidden, int n_hidden, int d_out) 
 // points x one parameter row -- are one tile per wave either way and pure latency: 32-point tiles halve that latency
 static bool fused_small(int R, int P, int nets) { return (long)((R + 63) / 64) * P * nets <= 512; }
 static int fused_bwd_pb(int n_hidden, int R, int P, int nets) {
-    return fused_env("PACOH_FUSED_BWD_PB", (n_hidden <= 2 && !fused_small(R, P, nets)) ? 4 : 2);
+    return g_sw.fused_bwd_pb > 0 ? g_sw.fused_bwd_pb : ((n_hidden <= 2 && !fused_small(R, P, nets)) ? 4 : 2);
 }
-static int fused_fwd_pb(int, int R, int P, int nets) { return fused_env("PACOH_FUSED_FWD_PB", fused_small(R, P, nets) ? 2 : 4); }
+static int fused_fwd_pb(int, int R, int P, int nets) { return g_sw.fused_fwd_pb > 0 ? g_sw.fused_fwd_pb : (fused_small(R, P, nets) ? 2 : 4); }
 
 // resident workgroups of a kernel on the whole chip (occupancy query, cached per kernel)
 template <typename K> static int resident_wgs(K kern) {
@@ -615,7 +611,7 @@ static int fused_chunks(int R, int P, int nets, int tp, int resident, double ove
 // forward 141 us); 4 x 32: forward + backward 801 us without, 694 / 665 / 641 / 663 us with 1 / 2 / 3 / 4 layers stashed.
 // PACOH_MLP_STASH=k stashes k layers (0: recompute everything, as rounds 1-2 did).
 static int fused_n_stash(int n_hidden) {
-    const int want = fused_env("PACOH_MLP_STASH", -1);             // (read per call: tests and tools/mlp_time.py switch it)
+    const int want = g_sw.mlp_stash;                               // (PACOH_MLP_STASH, switches.h; -1: the dispatcher's choice)
     if (want < 0) return n_hidden > 1 ? n_hidden - 1 : 0;
     return want > n_hidden ? n_hidden : want;
 }
@@ -667,7 +663,7 @@ int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride
     // tiles per workgroup (a wave takes every 4th): 16 at cfg #3 (4 / 8 / 16 / 32: 109 / 100 / 95 / 94 us); small batches -- the 1/8
     // strong-scaling shard -- want fewer, or a SIMD holds two four-tile waves while its neighbour idles: the count that minimises
     // (waves per SIMD) x (tiles per wave + half a tile of fixed cost), larger counts winning ties
-    a.tiles_per_wg = fused_env("PACOH_FUSED_FWD_TPW", 0);
+    a.tiles_per_wg = g_sw.fused_fwd_tpw;
     if (a.tiles_per_wg <= 0) {
         double best = 1e30;
         for (int tpw = 4; tpw <= 32; tpw *= 2) {
@@ -678,7 +674,8 @@ int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride
     }
     const int wgs = (tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
     if (tail) { a.tail_z = nets; a.sv = *tail; }
-#define PACOH_LAUNCH_FWD(K) hipLaunchKernelGGL((K), dim3(wgs, P, nets + (tail ? 1 : 0)), dim3(256), 0, s, a)
+    const unsigned pad = g_sw.lds_pad_mlp > 0 ? (unsigned)g_sw.lds_pad_mlp : 0u;
+#define PACOH_LAUNCH_FWD(K) hipLaunchKernelGGL((K), dim3(wgs, P, nets + (tail ? 1 : 0)), dim3(256), pad, s, a)
     if (pb == 4) {
         if (n_hidden == 1) PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<1, 4, 4>)); else if (n_hidden == 2) PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<2, 4, 4>));
         else if (n_hidden == 3) PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<3, 4, 4>)); else PACOH_LAUNCH_FWD((mlp_fused_fwd_kernel<4, 4, 4>));
@@ -741,7 +738,8 @@ int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride
     if (bw_here) { a.bw_d2 = tail->sv_d2; a.bw_P = tail->sv_P; a.bw_out = tail->sv_bw; rtail.sv_bw = nullptr; }
     if (adv_here) a.adv_counter = const_cast<long*>(tail->nx.counter);
     if (bw_here || adv_here) a.tail_z = nets;
-#define PACOH_LAUNCH_BWD(K) hipLaunchKernelGGL(K, dim3(pl.chunks, P, nets + ((bw_here || adv_here) ? 1 : 0)), dim3(256), 0, s, a)
+    const unsigned pad = g_sw.lds_pad_mlp > 0 ? (unsigned)g_sw.lds_pad_mlp : 0u;
+#define PACOH_LAUNCH_BWD(K) hipLaunchKernelGGL(K, dim3(pl.chunks, P, nets + ((bw_here || adv_here) ? 1 : 0)), dim3(256), pad, s, a)
     PACOH_FUSED_DISPATCH(mlp_fused_bwd_kernel, n_hidden, pl.pb, PACOH_LAUNCH_BWD);
 #undef PACOH_LAUNCH_BWD
     const long tot = (long)P * wmax;
@@ -756,15 +754,20 @@ int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride
 
 // The slab reduction as a launch of its own: the task-fused PACOH-MAP kernel (map_task.hip) writes one slab per workgroup and
 // network in theta's layout; this sums them into d_theta and runs the step's tail (hyper-parameter reduction, AdamW, next batch).
+// P parameter rows (PACOH-SVGD / VI behind the same kernel): slab c holds the rows' blocks one after the other, [c][p][w]; the lanes
+// that share an output element follow the slab count (2 task groups per step at the reference launchers' defaults: 2 lanes).
 int fused_reduce_launch(const float* slab0, int wd0, long off0, const float* slab1, int wd1, long off1, int nets, float* d_theta,
-                        long d_theta_stride, int slabs, const HyperBwdArgs<float>* tail, float* img_th, const int* img_map, hipStream_t s) {
+                        long d_theta_stride, int slabs, const HyperBwdArgs<float>* tail, float* img_th, const int* img_map, hipStream_t s, int P) {
     SlabReduce sr[2] = {{slab0, d_theta + off0, wd0, (int)off0}, {slab1, d_theta + off1, wd1, (int)off1}};
     const int wmax = wd0 > wd1 ? wd0 : wd1;
-    unsigned gx = (unsigned)(((long)wmax * 32 + 255) / 256);
+    const int lsh = slabs <= 2 ? 1 : (slabs <= 16 ? 3 : 5);
+    unsigned gx = (unsigned)((((long)P * wmax << lsh) + 255) / 256);
     const int tail_blocks = tail ? hyper_tail_blocks(*tail) : 0;
     if ((unsigned)tail_blocks > gx) gx = (unsigned)tail_blocks;
-    hipLaunchKernelGGL(fused_reduce_slab_kernel<5>, dim3(gx, nets + (tail ? 1 : 0)), dim3(256), 0, s, sr[0], sr[1], d_theta_stride, 0, slabs, 1, nets,
-                       tail ? *tail : HyperBwdArgs<float>{}, tail_blocks, img_th, img_map);
+#define PACOH_REDUCE(LSH) hipLaunchKernelGGL(fused_reduce_slab_kernel<LSH>, dim3(gx, nets + (tail ? 1 : 0)), dim3(256), 0, s, sr[0], sr[1], \
+                                             d_theta_stride, 0, slabs, P, nets, tail ? *tail : HyperBwdArgs<float>{}, tail_blocks, img_th, img_map)
+    if (lsh == 1) PACOH_REDUCE(1); else if (lsh == 3) PACOH_REDUCE(3); else PACOH_REDUCE(5);
+#undef PACOH_REDUCE
     return launch_status();
 }
 

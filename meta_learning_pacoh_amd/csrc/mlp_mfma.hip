@@ -643,7 +643,7 @@ __global__ void __launch_bounds__(256) reduce_slab_kernel(const T* __restrict__ 
 }
 
 bool mlp_mfma_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_out) {
-    static const bool on = []() { const char* e = getenv("PACOH_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
+    const bool on = g_sw.mfma;
     if (!on || n_hidden < 1 || n_hidden > 2 || d_in > 16 || d_out > 8) return false;
     for (int l = 0; l < n_hidden; ++l) if (hidden[l] > 32) return false;
     return true;

@@ -17,22 +17,25 @@ namespace pacoh {
 
 // squared distance of the particle pair (i, j) = (pair / P, pair % P), j <= i, by one 256-thread workgroup, direct differences;
 // the diagonal pairs copy their particle into the snapshot.  The caller separates two calls by a barrier (red is reused).
+// Workgroups larger than 256 threads (the task-fused step kernel, map_task.hip: 512) leave the work to their first 256 threads, so
+// that the sum's order -- and with it the median bandwidth -- is the same bits in whichever launch it rides.
 template <typename T>
 __device__ __forceinline__ void svgd_dist_block(const T* __restrict__ X, T* __restrict__ d2, int P, int D, T* __restrict__ snap, int pair) {
     __shared__ T red[4];
     const int i = pair / P, j = pair - i * P;
     if (j > i) return;
     const T* xi = X + (long)i * D;
+    const bool worker = threadIdx.x < 256;
     if (snap && i == j) {                       // the diagonal pairs copy their particle: the in-place update reads the snapshot
-        for (int d = threadIdx.x; d < D; d += 256) snap[(long)i * D + d] = xi[d];
+        if (worker) for (int d = threadIdx.x; d < D; d += 256) snap[(long)i * D + d] = xi[d];
         if (threadIdx.x == 0) d2[i * P + i] = T(0);
         return;
     }
     const T* xj = X + (long)j * D;
     T acc = 0;
-    for (int d = threadIdx.x; d < D; d += 256) { T df = xi[d] - xj[d]; acc = fma(df, df, acc); }
+    if (worker) for (int d = threadIdx.x; d < D; d += 256) { T df = xi[d] - xj[d]; acc = fma(df, df, acc); }
     acc = subwave_sum<T>(acc, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    if (worker && (threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) { const T tot = (red[0] + red[1]) + (red[2] + red[3]); d2[i * P + j] = tot; d2[j * P + i] = tot; }
 }

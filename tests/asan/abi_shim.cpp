@@ -30,7 +30,8 @@ int main() {
         std::printf("%zu\n", pacoh_mlp_bwd_workspace_bytes(60, 3, 33, 2, h, 3, 2, PACOH_F32));
         return 0;
     }
-    EXPECT(pacoh_abi_version() == 13);
+    EXPECT(pacoh_abi_version() == 14);
+    pacoh_reload_env();                                   // (the switches are read at load time and here, never on a launch path)
     EXPECT(pacoh_gp_small_max_n(PACOH_F32, 0) >= 128 && pacoh_gp_small_max_n(PACOH_F64, 1) >= 64 && pacoh_gp_small_max_n(7, 0) == PACOH_EDTYPE);
     EXPECT(pacoh_svgd_workspace_bytes(20, 2534, PACOH_F32) == (2 * 400 + 20 + 8) * 4);
     EXPECT(pacoh_gp_predict_workspace_bytes(4, 64, 50, PACOH_F32, 1) == 4u * 50 * 64 * 4 && pacoh_gp_predict_workspace_bytes(4, 64, 50, PACOH_F32, 0) == 0);
@@ -86,6 +87,41 @@ int main() {
         EXPECT(pacoh_map_persist(nullptr, fake, fake, 8, fake, fake, nullptr, 5, 1, (const int64_t*)fake, 5, fake, PACOH_SC_COUNT, 1, PACOH_MEAN_ZERO, -1,
                                  nullptr, 0, 0, -1, nullptr, 0, 1, 0, 1, 2, 1e-3, seg, seg, 1, 0.9, 0.999, nullptr, nullptr, nullptr, PACOH_F32,
                                  nullptr) == PACOH_EINVAL);
+        // a parameter layout that leaves the row: the persistent kernel reads AND writes theta / both moments at these offsets
+        {
+            int32_t lo[4] = {0, 0, 0, 0}, hi[4] = {40, 0, 0, 0};
+            const int Dm = 32 * 2 + 32 * 33 + 33;                    // NN(32, 32) mean on d = 1: 1153 columns from off_mean
+            EXPECT(pacoh_map_persist(fake, fake, fake, Dm + 3, fake, fake, nullptr, 5, 1, (const int64_t*)fake, 5, fake, PACOH_SC_COUNT, 1, PACOH_MEAN_VECTOR, 8,
+                                     hm, 2, 0, -1, nullptr, 0, 1, 0, -1, 2, 1e-3, lo, hi, 1, 0.9, 0.999, nullptr, nullptr, nullptr, PACOH_F32,
+                                     nullptr) == PACOH_EINVAL);                                                                      // network block ends at 8 + 1153 > D
+            EXPECT(pacoh_map_persist(fake, fake, fake, 40, fake, fake, nullptr, 5, 1, (const int64_t*)fake, 5, fake, PACOH_SC_COUNT, 1, PACOH_MEAN_ZERO, -1,
+                                     nullptr, 0, 0, -1, nullptr, 0, 1, 40, -1, 2, 1e-3, lo, hi, 1, 0.9, 0.999, nullptr, nullptr, nullptr, PACOH_F32,
+                                     nullptr) == PACOH_EINVAL);                                                                      // off_ls == D
+            hi[0] = 41;
+            EXPECT(pacoh_map_persist(fake, fake, fake, 40, fake, fake, nullptr, 5, 1, (const int64_t*)fake, 5, fake, PACOH_SC_COUNT, 1, PACOH_MEAN_ZERO, -1,
+                                     nullptr, 0, 0, -1, nullptr, 0, 1, 0, -1, 2, 1e-3, lo, hi, 1, 0.9, 0.999, nullptr, nullptr, nullptr, PACOH_F32,
+                                     nullptr) == PACOH_EINVAL);                                                                      // trained range beyond D
+        }
+        // the task-fused kernels are RBF-only: another kernel family must not silently train with the RBF Gram
+        const int f_cos = 1 | (PACOH_KERNEL_COSINE << PACOH_KERNEL_SHIFT);
+        EXPECT(pacoh_map_task_workspace_bytes(2000, 32, 1, 256, PACOH_MEAN_VECTOR, hm, 2, 0, nullptr, 0, 1, PACOH_F32) > 0);
+        EXPECT(pacoh_map_task_workspace_bytes(2000, 32, 1, 256, PACOH_MEAN_VECTOR, hm, 2, 0, nullptr, 0, f_cos, PACOH_F32) == 0);
+        EXPECT(pacoh_map_task_setup(fake, 2000, 32, 1, 256, PACOH_MEAN_VECTOR, 0, hm, 2, 0, -1, nullptr, 0, f_cos, fake, 1 << 20, PACOH_F32, nullptr) == PACOH_ELIMIT);
+        EXPECT(pacoh_map_task_step(fake, 2000, fake, fake, nullptr, 32, 1, 256, PACOH_MEAN_VECTOR, 0, hm, 2, 0, -1, nullptr, 0, f_cos, fake, nullptr, fake,
+                                   1990, -1, 1991, fake, 2000, nullptr, 1.0, nullptr, fake, 1 << 20, nullptr, PACOH_F32, nullptr) == PACOH_ELIMIT);
+        // the same kernel with P parameter rows (round 6)
+        EXPECT(pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 2, PACOH_MEAN_VECTOR, hm, 2, 1, hm, 2, 2, PACOH_F32) > 0);
+        EXPECT(pacoh_svgd_task_workspace_bytes(2534, 10, 33, 1, 2, PACOH_MEAN_VECTOR, hm, 2, 1, hm, 2, 2, PACOH_F32) == 0);
+        EXPECT(pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 2, PACOH_MEAN_VECTOR, hm, 2, 1, hm, 2, 2 | (PACOH_KERNEL_COSINE << PACOH_KERNEL_SHIFT), PACOH_F32) == 0);
+        EXPECT(pacoh_svgd_task_step(nullptr, 2534, 10, fake, fake, nullptr, 20, 1, 2, PACOH_MEAN_VECTOR, 0, hm, 2, 1, 1200, hm, 2, 2, fake, nullptr, fake,
+                                    2530, -1, 2533, fake, 2534, fake, 1.0, nullptr, fake, 1 << 20, nullptr, nullptr, 0, nullptr, 0, PACOH_F32,
+                                    nullptr) == PACOH_EINVAL);
+        EXPECT(pacoh_svgd_task_step(fake, 2534, 10, fake, fake, nullptr, 20, 1, 2, PACOH_MEAN_VECTOR, 0, hm, 2, 1, 1200, hm, 2, 2, fake, nullptr, fake,
+                                    2530, -1, 2533, fake, 2534, fake, 1.0, nullptr, fake, 1 << 20, fake, nullptr, 2534, nullptr, 0, PACOH_F32,
+                                    nullptr) == PACOH_EINVAL);                                                                       // svgd_X without its workspace
+        EXPECT(pacoh_svgd_task_step(fake, 2534, 10, fake, fake, nullptr, 20, 1, 2, PACOH_MEAN_VECTOR, 0, hm, 2, 1, 1200, hm, 2, 2, fake, nullptr, fake,
+                                    2530, -1, 2533, fake, 2534, fake, 1.0, nullptr, fake, 1 << 20, nullptr, nullptr, 0, nullptr, 0, PACOH_F64,
+                                    nullptr) == PACOH_ELIMIT);
         std::free(hm); std::free(hk);
     }
     EXPECT(pacoh_gp_lml_fwd(nullptr, 1, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 4, 1, 16, 2,

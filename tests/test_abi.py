@@ -36,7 +36,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 def test_abi_version_and_host_side_queries(lib):
     from meta_learning_pacoh_amd import _lib
-    assert lib.pacoh_abi_version() == _lib.ABI_VERSION == 13
+    assert lib.pacoh_abi_version() == _lib.ABI_VERSION == 14
     assert lib.pacoh_gp_small_max_n(0, 0) >= 128 and lib.pacoh_gp_small_max_n(0, 1) >= 128      # fp32: cfg #4 fits
     assert lib.pacoh_gp_small_max_n(1, 1) >= 64                                                  # fp64: cfg #3 fits
     assert lib.pacoh_gp_small_max_n(7, 0) == -3

@@ -82,8 +82,11 @@ def test_dense_lml_fwdbwd_at_odd_and_large_contexts(L, dtype, n):
                           g_lml=gl.to(DEV), want_dz=True)
     lml, d_z, d_mean, d_ls, d_os, d_noise, info = out
     assert int(info.abs().max()) == 0
-    assert maxrel(lml, ref) < (5e-3 if dtype == torch.float32 else 1e-9)
-    gtol = 2e-2 if dtype == torch.float32 else 1e-7
+    # fp32 bars (north star: 1e-2 rel).  Measured on these very problems, norm-wise against the fp64 oracle (tests/dense_fp32_errors.py ->
+    # profiles/r06_dense_fp32_errors.txt): LML <= 6e-7, every gradient <= 1.5e-5 at n = 129 ... 1000 -- within 1-12x of what plain torch
+    # fp32 autograd on the CPU loses on the same expression (<= 6e-6).  Asserted with a margin of ~20x on the worst measured entry
+    assert maxrel(lml, ref) < (1e-4 if dtype == torch.float32 else 1e-9)
+    gtol = 5e-4 if dtype == torch.float32 else 1e-7
     assert relerr(d_z, leaves[0].grad) < gtol and relerr(d_mean, leaves[1].grad) < gtol
     assert relerr(d_ls.reshape(T, P, f).sum(0), leaves[2].grad) < gtol
     assert relerr(d_os.reshape(T, P).sum(0), leaves[3].grad) < gtol and relerr(d_noise.reshape(T, P).sum(0), leaves[4].grad) < gtol
@@ -239,9 +242,9 @@ def test_dense_two_level_path_ladder_and_healthy_neighbours(L, n, dtype, ragged)
     leaves = [z[2, :nv].double().clone().requires_grad_(True), ls[2].double().clone().requires_grad_(True), noise[2].double().clone().requires_grad_(True)]
     ref = O.gp_mll(leaves[0], torch.zeros(nv, dtype=torch.float64), y[0, :nv].double(), leaves[1], torch.tensor(1.0, dtype=torch.float64), leaves[2])
     ref.backward()
-    assert abs(float(lml[2]) - float(ref)) < (1e-9 if f64 else 5e-3) * abs(float(ref))
+    assert abs(float(lml[2]) - float(ref)) < (1e-9 if f64 else 1e-4) * abs(float(ref))
     d_z, d_ls, d_noise = out[1].cpu(), out[3].cpu(), out[5].cpu()
-    gtol = 1e-7 if f64 else 2e-2
+    gtol = 1e-7 if f64 else 1e-3                     # (fp32: profiles/r06_dense_fp32_errors.txt, rows `ladder`)
     assert relerr(d_z[2, :nv], leaves[0].grad) < gtol and relerr(d_ls[2], leaves[1].grad) < gtol and relerr(d_noise[2], leaves[2].grad) < gtol
     alone = L.gp_lml_fwdbwd(z[3:].to(DEV), 1, None, L.MEAN_ZERO, y.to(DEV), 1, ls[3:].to(DEV), None, noise[3:].to(DEV), 1, 1, n_valid=n_valid, want_dz=True)
     assert torch.equal(alone[0].cpu()[0], lml[3])
@@ -266,8 +269,10 @@ def test_two_level_path_edges(L, dtype, n, B):
     out = L.gp_lml_fwdbwd(z.to(DEV), 1, mean.to(DEV), L.MEAN_VECTOR, y.to(DEV), P, ls.to(DEV), os_.to(DEV), noise.to(DEV), B * P, P, want_dz=True)
     lml, d_z, d_mean, d_ls, d_os, d_noise, info = out
     assert int(info.abs().max()) == 0
-    assert maxrel(lml, ref) < (5e-3 if dtype == torch.float32 else 1e-9)
-    gtol = 2e-2 if dtype == torch.float32 else 1e-7
+    # (fp32, measured: LML <= 1.4e-7, gradients <= 6.2e-5 -- d_ls at n = 1024, where torch fp32 itself is at 5.5e-6;
+    #  profiles/r06_dense_fp32_errors.txt, rows `edge`)
+    assert maxrel(lml, ref) < (1e-4 if dtype == torch.float32 else 1e-9)
+    gtol = 1e-3 if dtype == torch.float32 else 1e-7
     assert relerr(d_z, leaves[0].grad) < gtol and relerr(d_mean, leaves[1].grad) < gtol
     assert relerr(d_ls.reshape(B, P, f).sum(0), leaves[2].grad) < gtol
     assert relerr(d_os.reshape(B, P).sum(0), leaves[3].grad) < gtol and relerr(d_noise.reshape(B, P).sum(0), leaves[4].grad) < gtol

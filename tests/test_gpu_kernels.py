@@ -390,16 +390,20 @@ MLP_PATHS = [None, 'mfma', 'layers']      # PACOH_MLP_PATH: first implementation
 
 @pytest.fixture
 def mlp_path(request):
+    """(the library reads its switches once at load time: pacoh_reload_env makes it look again)"""
+    from meta_learning_pacoh_amd import _lib
     old = os.environ.get('PACOH_MLP_PATH')
     if request.param is None:
         os.environ.pop('PACOH_MLP_PATH', None)
     else:
         os.environ['PACOH_MLP_PATH'] = request.param
+    _lib.reload_env()
     yield request.param
     if old is None:
         os.environ.pop('PACOH_MLP_PATH', None)
     else:
         os.environ['PACOH_MLP_PATH'] = old
+    _lib.reload_env()
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float64])

@@ -49,7 +49,12 @@ def _run(world_rank, world, port, out_dir, kind):
         model = M.GPRegressionMetaLearned(tasks, task_batch_size=5, lr_params=1e-2, weight_decay=0.1, random_seed=11,
                                           optimizer='Adam' if kind == 'map' else 'SGD')
         model.meta_fit(verbose=False, n_iter=4)
-        state = model.theta
+        state = model.theta.clone()
+        # one parameter is left out of the comparison: the kernel network's OUTPUT BIAS has an exactly-zero derivative (a stationary
+        # kernel sees feature differences only), its gradient is rounding noise and AdamW turns the sign of that noise into steps of
+        # +-lr on every path, the reference's included (tests/test_gpu_map_persist.py: keep_mask)
+        lo, hi = model.layout.slices['kernel_nn.out.bias']
+        state[0, lo:hi] = 0.0
     else:
         model = M.GPRegressionMetaLearnedVI(tasks, svi_batch_size=3, task_batch_size=6, lr=1e-2, random_seed=11,
                                             mean_module='constant', covar_module='SE')
@@ -102,13 +107,10 @@ def test_two_ranks_on_one_gpu_match_single_process(kind):
         r1 = np.load(os.path.join(out, '%s_w2_r1.npy' % kind))
         assert np.array_equal(r0, r1)                                  # replicas stay bit-identical
         assert np.isfinite(ref).all()
-        # sharding only changes the order of the sum over tasks (fp32 re-association), amplified by the Adam steps
-        if kind == 'map':
-            assert np.abs(r0 - ref).max() <= 4 * 2 * 1e-2                  # at most a sign flip of every one of the 4 steps
-            assert np.linalg.norm(r0 - ref) < 2e-2 * np.linalg.norm(ref)
-        else:
-            assert np.abs(r0 - ref).max() < 2e-3 * max(1.0, np.abs(ref).max())
-            assert np.linalg.norm(r0 - ref) < 1e-3 * np.linalg.norm(ref)
+        # sharding only changes the order of the sum over tasks (fp32 re-association) -- for AdamW too, once the one parameter whose
+        # gradient is pure rounding noise is left out (see _run)
+        assert np.abs(r0 - ref).max() < 2e-3 * max(1.0, np.abs(ref).max())
+        assert np.linalg.norm(r0 - ref) < 1e-3 * np.linalg.norm(ref)
 
 
 def test_bench_two_ranks_prints_both_scaling_legs():

@@ -81,6 +81,7 @@ def main():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = str(v)
+        L.reload_env()
 
     rows = []
     for path in (None, 'mfma'):
