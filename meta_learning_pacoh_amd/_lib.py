@@ -766,7 +766,7 @@ def svgd_task_step(plan, theta, batch, hypers, grad, lik, lik_scale, fail_flag, 
     sx = sws = ctr = None
     want_bw = 0
     if svgd is not None:
-        sx, sws, ctr, want_bw = _ptr(svgd[0], theta), _ptr(svgd[1], theta), _ptr(svgd[2]), int(bool(svgd[3]))
+        sx, sws, ctr, want_bw = _ptr(svgd[0], theta), _ptr(svgd[1]), _ptr(svgd[2]), int(bool(svgd[3]))
     with _Timed('svgd_task_step'):
         _check(lib.pacoh_svgd_task_step(_ptr(theta), theta.stride(0), P, _ptr(batch.x, theta), _ptr(batch.y, theta),
                                         _ptr(batch.n_valid) if (batch.n_valid is not None and batch.ragged) else None, plan.n, plan.d, int(batch.T),

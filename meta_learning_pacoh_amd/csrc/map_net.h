@@ -530,7 +530,11 @@ void plan_net(MpArgs& a, int k, int off, int d_in, const int32_t* hidden, int nh
 // -> 0 and the filled plan, or PACOH_ELIMIT when the shape is outside what the persistent kernel takes (the caller then runs the
 // four-launch iteration)
 static int map_persist_plan(MpArgs& a, int n, int d, int tb, int K, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
-                            int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f, int* nb_out, int* fp_out) {
+                            int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f, int* nb_out, int* fp_out,
+                            bool with_moments = true) {
+    // with_moments: the persistent kernel keeps both Adam moments and the image-to-theta index beside the parameter image (four
+    // copies of its size); the task-fused kernels only read the image -- with four copies two 4 x 32 networks (the reference
+    // launchers' default) did not fit the plan
     memset(&a, 0, sizeof(a));
     if (n < 1 || n > 32 || d < 1 || d > 4 || tb < 1 || tb > MP_NT / 64 || K < 1 || K > 1024 || f < 1 || f > 4) return PACOH_ELIMIT;
     if (tb * n * (d + 1) > MP_NT) return PACOH_ELIMIT;
@@ -560,7 +564,9 @@ static int map_persist_plan(MpArgs& a, int n, int d, int tb, int K, int mean_mod
     if (mean_mode == PACOH_MEAN_VECTOR) { plan_net(a, a.nets, off_mean, d, mean_hidden, n_mean_hidden, 1, a.o_mn, 1, a.o_dmn, top, dp); a.nets++; }
     if (kernel_nn) { plan_net(a, a.nets, off_kernel, d, kernel_hidden, n_kernel_hidden, f, a.o_zk, f, a.o_dzk, top, dp); a.nets++; }
     a.DP = round4(dp > 0 ? dp : 4);
-    a.o_th = take(a.DP); a.o_m = take(a.DP); a.o_v = take(a.DP); a.o_flat = take(a.DP);
+    a.o_th = take(a.DP);
+    if (with_moments) { a.o_m = take(a.DP); a.o_v = take(a.DP); a.o_flat = take(a.DP); }
+    else a.o_m = a.o_v = a.o_flat = a.o_th;
     for (int k = 0; k < a.nets; ++k) for (int l = 0; l < a.nl[k]; ++l) a.L[k][l].w_lds += 0;      // (image offsets are relative to o_th / o_m / o_v)
     const int NP = 16 * NB, NU = NB * (NB + 1) / 2;
     a.gpw = round4(2 * NP * FP + 2 * NP + 448 + (NB > 1 ? (NU - NB) * 256 : 4));

@@ -345,7 +345,7 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
     if (tpw > MT_NT / 64) tpw = MT_NT / 64;
     if (tpw > tb_total) tpw = tb_total;
     const int rc = map_persist_plan(a, n, d, tpw, 1, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel, kernel_hidden,
-                                    n_kernel_hidden, f, &NB, &FP);
+                                    n_kernel_hidden, f, &NB, &FP, false);
     if (rc != PACOH_OK) return rc;
     if (a.nets < 1 || tpw * n * (d + 1) > MT_NT) return PACOH_ELIMIT;
     const int groups = (tb_total + tpw - 1) / tpw;

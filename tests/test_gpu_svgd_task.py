@@ -52,7 +52,7 @@ CFGS = [
     dict(mean_nn_layers=(32, 32, 32, 32), kernel_nn_layers=(32, 32, 32, 32)),       # the reference launchers' networks
     dict(covar_module='SE', mean_module='NN'),                                      # one network, kernel on the raw inputs
     dict(covar_module='NN', mean_module='constant'),                                # constant mean: d_const through the per-problem output
-    dict(covar_module='NN', mean_module='zero', kernel_nn_layers=(16, 16)),         # generic chains
+    dict(covar_module='NN', mean_module='constant', kernel_nn_layers=(16, 16)),     # generic chains
     dict(mean_nn_layers=(20, 12), kernel_nn_layers=(24,)),                          # widths that are no multiple of 16, different depths
 ]
 SHAPES = [(6, 20, 1, 2, 10), (9, 12, 2, 5, 4), (7, 5, 1, 7, 3), (5, 32, 3, 3, 6), (4, 17, 4, 4, 1)]      # (T, n, d, tasks per step, rows)
