@@ -261,6 +261,7 @@ def main():
         return leg, wl, elapsed
 
     leg, wl, elapsed = timed_leg(args.scaling, True)
+    gpu_only = wl['gpu_only']() if ('gpu_only' in wl and world == 1) else None
     finite = leg['finite']
     ms_per_step = elapsed / args.steps * 1e3
     host_ms = leg['host_ms_per_step']
@@ -330,6 +331,8 @@ def main():
             config=dict({'workload': describe, 'evals_per_step': evals_per_step, 'parallelism': 'task-shard x%d' % world,
                          'finite': finite}, **extra),
             roofline=roofline, kernel_rooflines=kernel_rooflines, step_flops=step_flops, gram=gram, pp=pp, others=others, cpu=cpu)
+        if gpu_only is not None:
+            out['gpu_ms_per_step_noise_resident'] = gpu_only      # (PACOH-VI: the step without the host's noise draw, _vi_gpu_only)
         out['predictive'] = predictive                    # (row A11 beside the LML: predictive_leg; None outside the default N = 1 run)
         print(json.dumps(out))
     if world > 1:
@@ -582,6 +585,7 @@ def other_config_leg(cfg, M, L, steps=256):
     wl['run'](steps)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    gpu_only = wl['gpu_only']() if 'gpu_only' in wl else None
     pp = profile_pass(wl, L, min(steps, 30))
     roofline, _, step_flops = rooflines(wl, pp)
     out = {'metric': wl['metric'], 'workload': wl['describe'], 'dtype': wl['dtype'], 'steps': steps, 'ms_per_step': round(ms, 5),
@@ -589,6 +593,10 @@ def other_config_leg(cfg, M, L, steps=256):
            'step_algorithmic_tflops': round(step_flops / (ms * 1e-3) / 1e12, 3),
            'dominant_kernel': None if roofline is None else {k: roofline[k] for k in ('kernel', 'achieved', 'peak', 'unit', 'algorithmic_frac', 'ms_per_step')},
            'kernel_ms_per_step': pp['kernel_ms'], 'profile_pass_ms_per_step': round(pp['ms_per_step'], 4)}
+    if gpu_only is not None:
+        # (ms_per_step above includes the host's per-step noise draw from torch's CPU generator -- the reference's stream; this is the
+        #  same step replayed with the noise already resident: _vi_gpu_only)
+        out['gpu_ms_per_step_noise_resident'] = gpu_only
     del wl
     torch.cuda.empty_cache()
     if cfg == 5:
@@ -712,6 +720,7 @@ def wl_cfg4(world, scaling, M, L):
     ev = T * S / world
     w = net_macs(1, (32, 32), 1) + net_macs(1, (32, 32), 2)
     return dict(run=model._train_steps, evals_per_step=T * S, dtype='f32', finite=lambda: bool(torch.isfinite(model.posterior).all()), mode=lambda: _mode(model),
+                gpu_only=_vi_gpu_only(model),
                 metric='task-GP LML+grad evals/sec (PACOH-VI, 512 tasks, n_ctx=128, 10 posterior samples)',
                 flops={'gp_lml_fwdbwd': (gp_flops(128, 2) * ev,) * 2, 'mlp_fwd': (2 * 128 * w * ev,) * 2,
                        'mlp_bwd': (4 * 128 * w * ev, (4 * w + 2 * 2 * 32) * 128 * ev)},
@@ -753,6 +762,29 @@ def _ref_launcher_flops(S):
             'svgd_task_step': ((gp_flops(20, 2) + 6 * 20 * w) * ev,) * 2}
 
 
+def _vi_gpu_only(model):
+    """PACOH-VI draws S x D standard normals per step from torch's CPU generator (the reference's stream, GPR_meta_vi.py:216-224 through
+    Normal.rsample): ~3 ns per number on one host thread, which at the launchers' shape (10 x 6566) is 0.2 ms per step -- several times what
+    the GPU needs.  This times the GPU's share alone: 16 rows of the chunk uploaded last (noise resident) replayed 8 times from the
+    captured step graphs, nothing drawn in between.  The optimizer state moves on: a timing, not training."""
+    def go():
+        from meta_learning_pacoh_amd.engine import replay_steps
+        graphs = getattr(model, '_graphs', None)
+        if not graphs or len(graphs) != 1:
+            return None
+        def burst():
+            model._feed.ctr.zero_()
+            replay_steps(16, graphs[0], model._graph_many)
+        burst()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            burst()
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / 128 * 1e3, 5)
+    return go
+
+
 def wl_ref_svgd(world, scaling, M, L):
     """the reference's own PACOH-SVGD launcher at its defaults (experiments/meta_GPR_SVGD_base_exp.py:23-49, 79-103): seed 28,
     SinusoidDataset(RandomState(29)) 20 tasks x 20 points, task_batch_size = 2, 10 particles, 4 x 32 mean and kernel networks, Adam
@@ -776,7 +808,7 @@ def wl_ref_vi(world, scaling, M, L):
     model = M.GPRegressionMetaLearnedVI(sinusoid_tasks(29, 20, 20), weight_prior_std=0.5, prior_factor=0.1, covar_module='NN',
                                         mean_module='NN', kernel_nn_layers=REF_LAYERS, mean_nn_layers=REF_LAYERS, random_seed=28,
                                         optimizer='Adam', lr=1e-3, lr_decay=0.98, svi_batch_size=10, cov_type='diag', task_batch_size=2)
-    return dict(run=model._train_steps, evals_per_step=20, dtype='f32', mode=lambda: _mode(model),
+    return dict(run=model._train_steps, evals_per_step=20, dtype='f32', mode=lambda: _mode(model), gpu_only=_vi_gpu_only(model),
                 finite=lambda: bool(torch.isfinite(model.posterior).all()),
                 metric='task-GP LML+grad evals/sec (PACOH-VI at the reference launcher\'s defaults: 2 tasks x 10 samples per step, n_ctx=20)',
                 flops=_ref_launcher_flops(10),

@@ -158,6 +158,18 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
         ltab[t] = kt[t];
     }
     const int nchain = ka.ntask[0], nweight = ka.ntask[2];
+    // MULTI: this row's image is gathered through a map (two dependent round trips).  The map words are requested HERE, in front of
+    // the LDS zeroing and its barrier, and the row entries right behind that barrier in one burst: as a loop of load / gather / store
+    // per 16 bytes the compiler made six dependent round trips of it -- 10 000-11 000 of the kernel's 52 000 cycles
+    constexpr int GI = 7;                                  // 7 x 448 lanes x 4 = 12 544 image entries >= two networks of five 32 x 36 layers
+    constexpr int IT = MT_NT - 64;                         // (the last wave copies the plan instead)
+    const int ng = a.DP >> 2;
+    int4 m4[GI];
+    if (MULTI && wave != NW - 1) {
+        const int4* sm = reinterpret_cast<const int4*>(ka.src_map);
+#pragma unroll
+        for (int u = 0; u < GI; ++u) { const int q = t + u * IT; m4[u] = sm[q < ng ? q : 0]; }
+    }
     {
         float4* l4 = reinterpret_cast<float4*>(lds);
         for (int q = t; q < (a.total + 3) >> 2; q += MT_NT) l4[q] = float4{0.f, 0.f, 0.f, 0.f};
@@ -174,11 +186,11 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
     int nv_val = 0;
     if (mover) mv_val = mv_r < n * d ? ka.bx[(long)(task0 + mv_s) * (n * d) + mv_r] : ka.by[(long)(task0 + mv_s) * n + (mv_r - n * d)];
     if (t < tb && ka.bnv) nv_val = ka.bnv[task0 + t];
-    if (t < 7) {
-        if (t < f) hp_val = ka.hyp_ls[pp * f + t];
-        else if (t == 4) { if (ka.hyp_os) hp_val = ka.hyp_os[pp]; }
-        else if (t == 5) hp_val = ka.hyp_noise[pp];
-        else if (t == 6 && a.off_const >= 0) hp_val = trow[a.off_const];
+    {   // (ONE load through a selected pointer: as a chain of branches each arm waited for the loads in flight before it)
+        const float* hsrc = t < f ? ka.hyp_ls + pp * f + t
+                          : (t == 4 ? (ka.hyp_os ? ka.hyp_os + pp : nullptr)
+                          : (t == 5 ? ka.hyp_noise + pp : ((t == 6 && a.off_const >= 0) ? trow + a.off_const : nullptr)));
+        if (t < 7 && hsrc) hp_val = *hsrc;
     }
     if (wave == NW - 1) {                               // the last wave copies the plan out of the kernel arguments
         kint_t kt = (kint_t)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(MtArgs, plan));
@@ -193,29 +205,56 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
     } else {
         const MpLayer* lt = reinterpret_cast<const MpLayer*>(ltab);
         const int nl0 = a.nets > 0 ? a.nl[0] : 0, nl1 = a.nets > 1 ? a.nl[1] : 0;
-        constexpr int IT = MT_NT - 64;
+        // the constant-1 column of every layer's input activations, one (layer, point) per lane (pts <= 32): as a loop over the layers
+        // with the points on the lanes it was ten dependent reads of the layer table, 4 000 cycles of every workgroup's prologue
+        auto ones_columns = [&]() {
+            for (int e = t; e < (nl0 + nl1) * 32; e += IT) {
+                const int q = e >> 5, p = e & 31;
+                if (p < pts) {
+                    const MpLayer& L = lt[q < nl0 ? q : MP_MAXL + (q - nl0)];
+                    const bool first = q == 0 || q == nl0;
+                    lds[(first ? a.o_a0 : L.a_in) + p * L.S + L.in] = 1.0f;
+                }
+            }
+        };
         // the parameter image, 16 bytes per lane from its copy in memory (decoding it from theta's layout cost every workgroup ~300
         // instructions per launch: 5 000 cycles)
         if (MULTI) {                                      // this row's image through the gather map: two round trips (the map is shared by all)
-            const int4* sm = reinterpret_cast<const int4*>(ka.src_map);
             float4* dst = reinterpret_cast<float4*>(th);
-            for (int q = t; q < a.DP >> 2; q += IT) {
-                const int4 m4 = sm[q];
-                float4 v;
-                v.x = m4.x >= 0 ? trow[m4.x] : 0.0f; v.y = m4.y >= 0 ? trow[m4.y] : 0.0f;
-                v.z = m4.z >= 0 ? trow[m4.z] : 0.0f; v.w = m4.w >= 0 ? trow[m4.w] : 0.0f;
-                dst[q] = v;
+            float4 v[GI];
+#pragma unroll
+            for (int u = 0; u < GI; ++u) {
+                v[u].x = trow[m4[u].x >= 0 ? m4[u].x : 0]; v[u].y = trow[m4[u].y >= 0 ? m4[u].y : 0];
+                v[u].z = trow[m4[u].z >= 0 ? m4[u].z : 0]; v[u].w = trow[m4[u].w >= 0 ? m4[u].w : 0];
+            }
+            MP_STAMP();
+            ones_columns();                               // (LDS-only work under the gather's round trip)
+            MP_STAMP();
+#pragma unroll
+            for (int u = 0; u < GI; ++u) {
+                const int q = t + u * IT;
+                if (q < ng) {
+                    float4 w;
+                    w.x = m4[u].x >= 0 ? v[u].x : 0.0f; w.y = m4[u].y >= 0 ? v[u].y : 0.0f;
+                    w.z = m4[u].z >= 0 ? v[u].z : 0.0f; w.w = m4[u].w >= 0 ? v[u].w : 0.0f;
+                    dst[q] = w;
+                }
+            }
+            MP_STAMP();
+            const int4* sm = reinterpret_cast<const int4*>(ka.src_map);
+            for (int q = t + GI * IT; q < ng; q += IT) {   // (never at the plan's sizes)
+                const int4 mm = sm[q];
+                float4 w;
+                w.x = mm.x >= 0 ? trow[mm.x] : 0.0f; w.y = mm.y >= 0 ? trow[mm.y] : 0.0f;
+                w.z = mm.z >= 0 ? trow[mm.z] : 0.0f; w.w = mm.w >= 0 ? trow[mm.w] : 0.0f;
+                dst[q] = w;
             }
         } else {
             const float4* src = reinterpret_cast<const float4*>(ka.thimg);
             float4* dst = reinterpret_cast<float4*>(th);
             for (int q = t; q < a.DP >> 2; q += IT) dst[q] = src[q];
         }
-        for (int q = 0; q < nl0 + nl1; ++q) {                  // the constant-1 column of every layer's input activations
-            const MpLayer& L = lt[q < nl0 ? q : MP_MAXL + (q - nl0)];
-            const bool first = q == 0 || q == nl0;
-            for (int p = t; p < pts; p += IT) lds[(first ? a.o_a0 : L.a_in) + p * L.S + L.in] = 1.0f;
-        }
+        if (!MULTI) ones_columns();
     }
     MP_STAMP();
     if (t < 7 && (t < f || t >= 4)) hp[t] = hp_val;
@@ -251,11 +290,17 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
                 float* sl = ka.slab[k] + (long)blockIdx.x * ka.dnet[k];
                 if ((d3.x & 8) && g4 == 0 && r16 < d2.x) sl[d3.y + r16] = bias;
                 if (r16 < d2.x) {
+                    float* row = sl + d1.z + r16 * d1.w + 4 * g4;
+                    if (4 * g4 + 3 < d3.w) {                // four consecutive entries of a weight row: one 16-byte store (4-byte aligned)
+                        typedef float __attribute__((ext_vector_type(4), aligned(4))) f4u;
+                        *reinterpret_cast<f4u*>(row) = f4u{acc[0], acc[1], acc[2], acc[3]};
+                    } else {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const int c = 4 * g4 + s;
-                        if (c < d3.w) sl[d1.z + r16 * d1.w + c] = acc[s];
-                        else if (c == d3.w) sl[d3.y + r16] = acc[s];
+                        for (int s = 0; s < 4; ++s) {
+                            const int c = 4 * g4 + s;
+                            if (c < d3.w) row[s] = acc[s];
+                            else if (c == d3.w) sl[d3.y + r16] = acc[s];
+                        }
                     }
                 }
             }
@@ -316,7 +361,7 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
     }
     MP_STAMP();
 #ifdef PACOH_MP_STAMPS
-    if (t == 0 && blockIdx.x == 7 && ka.adv_counter && *ka.adv_counter == 3)
+    if (t == 0 && blockIdx.x == 7 && ((ka.adv_counter && *ka.adv_counter == 3) || (MULTI && ka.sv.counter && *ka.sv.counter == 3)))
         for (int q = 1; q < mp_st_n[0]; ++q) printf("mt stamp %d: +%lld cycles\n", q, mp_st[0][q] - mp_st[0][q - 1]);
 #endif
 }

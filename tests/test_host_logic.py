@@ -252,6 +252,15 @@ def test_standard_normal_into_a_buffer_is_the_same_draw():
     for j in range(4):
         standard_normal(3, 50, out=buf64[j])
     assert torch.equal(torch.stack(a).double(), buf64)
+    # ... and they are the reference's own call, torch.distributions' _standard_normal = torch.normal(zeros, ones), value for value and
+    # generator state for generator state -- at sizes on both sides of the generator's 16-element blocks and at the launchers' size
+    for n, D in ((3, 50), (1, 1), (1, 15), (2, 8), (3, 7), (10, 6566)):
+        torch.manual_seed(5)
+        ref = [torch.normal(torch.zeros(n, D), torch.ones(n, D)) for _ in range(2)]
+        state_ref = torch.get_rng_state()
+        torch.manual_seed(5)
+        got = [standard_normal(n, D), standard_normal(n, D, out=torch.empty(n, D))]
+        assert all(torch.equal(g, r) for g, r in zip(got, ref)) and torch.equal(state_ref, torch.get_rng_state()), (n, D)
 
 
 def test_first_chunk_sizes():
