@@ -144,7 +144,12 @@ int pacoh_mvn_logprob_dense(void* A, const void* resid, void* logp, void* alpha_
  * Same arguments, outputs, jitter ladder and ragged-task rules as pacoh_gp_lml_fwdbwd / pacoh_gp_predict (and the same
  * reference lines), for context sets beyond pacoh_gp_small_max_n(): Gram build -> MFMA-panel Cholesky -> in-place
  * triangular inverse -> K^-1 = Z^T Z (batched MFMA GEMM) -> gradient contractions.  d_lengthscale == NULL selects
- * forward only (lml, info).  workspace: the *_workspace_bytes() queries (O(B n^2)).
+ * forward only (lml, info).  workspace: the *_workspace_bytes() queries (O(B n^2)).  pacoh_gp_lml_dense takes the size of what it was
+ * given: a workspace smaller than the query's answer for B problems makes it run the batch in slabs of whole tasks (problem b = t P + p,
+ * z_div / y_div in {1, P}; at least the query's answer for P problems, else PACOH_EINVAL) -- a host bounds the O(B n^2) scratch that way.
+ * Context sizes whose rows are not a multiple of 16 bytes (odd n; n mod 4 != 0 in fp32) between 97 and 1024 are run as a ragged batch
+ * of the next aligned size inside the call (the padded rows are identity rows; the workspace queries include the padded copies), so
+ * that they reach the left-looking / two-level kernels as well (round 6: this lived in the Python binding before).
  * Sizes: n <= 512 runs the left-looking Cholesky / inverse (one workgroup per matrix, rows of a multiple of 16 bytes); 512 < n <= 1024
  * (same alignment) a two-level factorisation + inverse -- diagonal sub-blocks <= 512 on those kernels, the off-diagonal block on an
  * LDS-tiled batched GEMM -- in both dtypes; other sizes the right-looking kernels of rounds 1-3, whose 32-column panel must fit in LDS
@@ -154,7 +159,7 @@ int pacoh_gp_lml_dense(const void* z, int z_div, const void* mean, int mean_mode
                        const void* lengthscale, const void* outputscale, const void* noise,
                        const int32_t* n_valid, const void* g_lml, void* lml, void* d_z, void* d_mean,
                        void* d_lengthscale, void* d_outputscale, void* d_noise, int32_t* info,
-                       void* workspace, int B, int P, int n, int f, int dtype, void* stream);
+                       void* workspace, size_t workspace_bytes, int B, int P, int n, int f, int dtype, void* stream);
 size_t pacoh_gp_predict_dense_workspace_bytes(int B, int n, int m, int dtype);
 int pacoh_gp_predict_dense(const void* z_ctx, int z_div, const void* mean_ctx, int mean_mode, const void* y,
                            int y_div, const void* z_tst, int zt_div, const void* mean_tst,

@@ -41,7 +41,7 @@ SIGNATURES = {
     'pacoh_gp_predict': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _i, _i, _i, _i, _i, _i, _vp]),
     'pacoh_gp_lml_dense_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
-    'pacoh_gp_lml_dense': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    'pacoh_gp_lml_dense': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                 _i, _i, _i, _i, _i, _vp]),
     'pacoh_gp_predict_dense_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pacoh_gp_predict_dense': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -347,26 +347,6 @@ def _gp_lml_dense(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale,
     n, f = z.shape[-2], z.shape[-1]
     dev, dt = z.device, z.dtype
     code = dtype_code(z)
-    # The left-looking factorisation / inverse kernels (csrc/dense_ll.hip, dense_trtri_ll.hip: 97 <= n <= 512) need matrix rows that are a
-    # multiple of 16 bytes; an odd context size would drop to the right-looking generation (1.3-1.5x slower at these sizes).  Such a
-    # batch is handed over as a RAGGED one of the next aligned size -- the padded rows become identity rows of the matrices, exactly what
-    # the kernels do for tasks of unequal length -- and the outputs are cut back (round 5; PACOH_DENSE_PAD=0: as before).
-    align = 4 if dt == torch.float32 else 2
-    # (512 < n < 1024: the two-level factorisation of round 5 wants the same alignment for its second sub-block)
-    if (97 <= n < 512 or 512 < n < 1024) and n % align != 0 and os.environ.get('PACOH_DENSE_PAD', '1') != '0' \
-            and os.environ.get('PACOH_CHOL_LL', '1') != '0':
-        npad = (n + align - 1) // align * align
-        pad_rows = lambda t: torch.nn.functional.pad(t, (0, 0, 0, npad - n))              # [.., n, f] -> [.., npad, f]
-        pad_last = lambda t: torch.nn.functional.pad(t, (0, npad - n))                    # [.., n] -> [.., npad]
-        nv = (torch.full((y.shape[0],), n, dtype=torch.int32, device=dev) if n_valid is None else n_valid.clamp(max=n))
-        out = _gp_lml_dense(pad_rows(z), z_div, pad_last(mean) if mean_mode == MEAN_VECTOR else mean, mean_mode, pad_last(y), y_div, lengthscale,
-                            outputscale, noise, nv, g_lml, B, P, info, want_grad, want_dz, kernel)
-        lml, d_z, d_mean, d_ls, d_os, d_noise = out
-        if d_z is not None:
-            d_z = d_z[:, :n].contiguous()
-        if d_mean is not None and mean_mode == MEAN_VECTOR:
-            d_mean = d_mean[:, :n].contiguous()
-        return lml, d_z, d_mean, d_ls, d_os, d_noise
     lml = torch.empty(B, dtype=dt, device=dev)
     d_z = d_mean = d_ls = d_os = d_noise = None
     if want_grad:
@@ -378,32 +358,19 @@ def _gp_lml_dense(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale,
         d_ls = torch.empty(B, f, dtype=dt, device=dev)
         d_os = torch.empty(B, dtype=dt, device=dev) if outputscale is not None else None
         d_noise = torch.empty(B, dtype=dt, device=dev)
-    # The scratch is O(B n^2): whole tasks (all their P problems) are processed in slabs that keep it under DENSE_WS_BYTES.
-    T_ = B // P
-    per_task = max(1, lib.pacoh_gp_lml_dense_workspace_bytes(P, n, f, code, int(want_grad)))
-    tb = T_
-    if B == T_ * P and z_div in (1, P) and y_div in (1, P) and T_ > 1:
-        tb = max(1, min(T_, DENSE_WS_BYTES // per_task))
-
-    def sl(t, b0, b1, div=1):
-        return None if t is None else t[b0 // div:(b1 + div - 1) // div]
-
+    # The scratch is O(B n^2).  The entry point itself runs the batch in slabs of whole tasks when it is handed less than the whole
+    # batch needs, and pads context sizes with misaligned rows onto the left-looking kernels (round 6: both lived here before): the
+    # binding only bounds the buffer -- DENSE_WS_BYTES, but never less than one task's share
+    need = lib.pacoh_gp_lml_dense_workspace_bytes(B, n, _kf(f, kernel), code, int(want_grad))
+    if need > DENSE_WS_BYTES and B % P == 0 and B > P:
+        one = max(1, lib.pacoh_gp_lml_dense_workspace_bytes(P, n, _kf(f, kernel), code, int(want_grad)))
+        need = min(need, max(one, DENSE_WS_BYTES // one * one))
+    ws = _workspace('lml', need, dev)
     with _Timed('gp_lml_dense'):
-        for t0 in range(0, T_ if tb < T_ else 1, tb):
-            if tb >= T_:
-                b0, b1 = 0, B
-            else:
-                b0, b1 = t0 * P, min(T_, t0 + tb) * P
-            Bc = b1 - b0
-            ws = _workspace('lml', lib.pacoh_gp_lml_dense_workspace_bytes(Bc, n, f, code, int(want_grad)), dev)
-            mean_c = sl(mean, b0, b1) if mean_mode == MEAN_VECTOR else mean
-            d_mean_c = sl(d_mean, b0, b1) if d_mean is not None else None          # [B,n] (vector) or [B] (const): both per problem
-            _check(lib.pacoh_gp_lml_dense(_ptr(sl(z, b0, b1, z_div)), z_div, _ptr(mean_c, z), mean_mode, _ptr(sl(y, b0, b1, y_div), z),
-                                          y_div, _ptr(lengthscale, z), _ptr(outputscale, z), _ptr(noise, z),
-                                          _ptr(sl(n_valid, b0, b1, y_div)), _ptr(sl(g_lml, b0, b1), z), _ptr(sl(lml, b0, b1)),
-                                          _ptr(sl(d_z, b0, b1)), _ptr(d_mean_c), _ptr(sl(d_ls, b0, b1)), _ptr(sl(d_os, b0, b1)),
-                                          _ptr(sl(d_noise, b0, b1)), _ptr(sl(info, b0, b1)), _ptr(ws),
-                                          Bc, P, n, _kf(f, kernel), code, _stream()), 'pacoh_gp_lml_dense')
+        _check(lib.pacoh_gp_lml_dense(_ptr(z), z_div, _ptr(mean, z), mean_mode, _ptr(y, z), y_div, _ptr(lengthscale, z),
+                                      _ptr(outputscale, z), _ptr(noise, z), _ptr(n_valid), _ptr(g_lml, z), _ptr(lml), _ptr(d_z),
+                                      _ptr(d_mean), _ptr(d_ls), _ptr(d_os), _ptr(d_noise), _ptr(info), _ptr(ws), need,
+                                      B, P, n, _kf(f, kernel), code, _stream()), 'pacoh_gp_lml_dense')
     return lml, d_z, d_mean, d_ls, d_os, d_noise
 
 

@@ -1456,9 +1456,43 @@ int predict_dense_impl(const void* z_ctx, int z_div, const void* mean_ctx, int m
 
 using namespace pacoh;
 
-extern "C" size_t pacoh_gp_lml_dense_workspace_bytes(int B, int n, int f, int dtype, int want_grad) {
-    f = features_of(f);
-    if (B <= 0 || n <= 0 || f <= 0) return 0;
+// ---- what the C ABI carries itself since round 6 (it lived in the Python binding): contexts whose rows are not a multiple
+//      of 16 bytes reach the left-looking kernels as a RAGGED batch of the next aligned size, and a workspace smaller than the whole
+//      batch needs runs the batch in slabs of whole tasks ------------------------------------------------------------------------------
+// dst[r][i][c] = i < n_src ? src[r][i][c] : 0 for i < n_dst (pad: n_dst > n_src; crop: n_dst < n_src), rows of w elements
+template <typename T>
+__global__ void __launch_bounds__(256) dense_rows_copy_kernel(const T* __restrict__ src, T* __restrict__ dst, long rows, int n_src, int n_dst, int w) {
+    const long per = (long)n_dst * w, tot = rows * per;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < tot; q += (long)gridDim.x * 256) {
+        const long rr = q / per; const int rem = (int)(q - rr * per), i = rem / w, c = rem - i * w;
+        dst[q] = i < n_src ? src[(rr * n_src + i) * w + c] : T(0);
+    }
+}
+__global__ void __launch_bounds__(256) dense_nv_kernel(const int32_t* __restrict__ nv_in, int32_t* __restrict__ nv_out, int count, int n) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q < count) { const int v = nv_in ? nv_in[q] : n; nv_out[q] = v < n ? v : n; }
+}
+template <typename T>
+static void rows_copy(const void* src, void* dst, long rows, int n_src, int n_dst, int w, hipStream_t s) {
+    const long tot = rows * n_dst * w;
+    if (tot <= 0) return;
+    long blocks = (tot + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(dense_rows_copy_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, (const T*)src, (T*)dst, rows, n_src, n_dst, w);
+}
+
+// the context size a problem of n points is factored at: n itself, or -- 97 <= n < 1024 with rows that are no multiple of 16 bytes,
+// where the left-looking kernels (n <= 512) / the two-level path (<= 1024) would otherwise hand the size to the right-looking
+// generation (1.022 vs 0.788 ms at n = 509 fp32, profiles/r05_dense_pad_ab.txt) -- the next aligned size: the padded rows are identity
+// rows of the matrices, exactly what the kernels do for tasks of unequal length.  PACOH_DENSE_PAD=0 / PACOH_CHOL_LL=0: never.
+static int dense_padded_n(int n, int dtype) {
+    const int align = dtype == PACOH_F32 ? 4 : 2;
+    if (!g_sw.dense_pad || !g_sw.chol_ll || n % align == 0) return n;
+    if ((n >= 97 && n < 512) || (n > 512 && n < 1024)) return (n + align - 1) / align * align;
+    return n;
+}
+
+static size_t lml_core_bytes(int B, int n, int f, int dtype, int want_grad) {
     const size_t e = dtype == PACOH_F64 ? 8 : 4;
     const size_t nn = (size_t)B * n * n;
     // (forward only, 512 < n <= 1024: the two-level Cholesky's scratch, which a call with gradients finds in W's buffer)
@@ -1466,12 +1500,101 @@ extern "C" size_t pacoh_gp_lml_dense_workspace_bytes(int B, int n, int f, int dt
     return align256(nn * e) * (want_grad ? 2 : 1) + 2 * align256((size_t)B * n * e) + align256((size_t)B * e) +
            align256((size_t)B * n * (f + 3) * e) + align256((size_t)B * n * f * e) + cb + 256;
 }
+// the padded copies of a slab of B problems: z, mean, y in; n_valid; d_z, d_mean out (upper bounds: every problem its own inputs)
+static size_t lml_pad_bytes(int B, int npad, int f, int dtype) {
+    const size_t e = dtype == PACOH_F64 ? 8 : 4;
+    return 2 * align256((size_t)B * npad * f * e) + 3 * align256((size_t)B * npad * e) + align256((size_t)B * 4);
+}
+static size_t lml_slab_bytes(int B, int n, int f, int dtype, int want_grad) {
+    const int npad = dense_padded_n(n, dtype);
+    return lml_core_bytes(B, npad, f, dtype, want_grad) + (npad != n ? lml_pad_bytes(B, npad, f, dtype) : 0);
+}
+
+extern "C" size_t pacoh_gp_lml_dense_workspace_bytes(int B, int n, int f, int dtype, int want_grad) {
+    f = features_of(f);
+    if (B <= 0 || n <= 0 || f <= 0) return 0;
+    return lml_slab_bytes(B, n, f, dtype, want_grad);
+}
+
+// one slab of Bc whole problems starting at problem b0 of the call: pointer offsets, the padded copies where the size asks for them
+template <typename T>
+static int lml_dense_slab(const void* z, int z_div, const void* mean, int mean_mode, const void* y, int y_div, const void* ls,
+                          const void* os, const void* noise, const int32_t* n_valid, const void* g_lml, void* lml, void* d_z,
+                          void* d_mean, void* d_ls, void* d_os, void* d_noise, int32_t* info, void* workspace, long b0, int Bc, int P, int n,
+                          int f_arg, int dtype, hipStream_t s) {
+    const int f = features_of(f_arg);
+    auto at = [](const void* p, long elems) -> const T* { return p ? (const T*)p + elems : nullptr; };
+    auto atw = [](void* p, long elems) -> T* { return p ? (T*)p + elems : nullptr; };
+    const long zr0 = b0 / z_div, yr0 = b0 / y_div;
+    const long zrows = (b0 + Bc + z_div - 1) / z_div - zr0, yrows = (b0 + Bc + y_div - 1) / y_div - yr0;
+    const T* zs = at(z, zr0 * n * f);
+    const T* ms = mean_mode == PACOH_MEAN_VECTOR ? at(mean, b0 * n) : (const T*)mean;
+    const T* ys = at(y, yr0 * n);
+    const int32_t* nvs = n_valid ? n_valid + yr0 : nullptr;
+    T* dzs = atw(d_z, b0 * n * f);
+    T* dms = mean_mode == PACOH_MEAN_VECTOR ? atw(d_mean, b0 * n) : atw(d_mean, b0);
+    const int npad = dense_padded_n(n, dtype);
+    unsigned char* w = (unsigned char*)workspace;
+    T* dz_p = nullptr; T* dm_p = nullptr;
+    if (npad != n) {
+        const size_t e = sizeof(T);
+        T* z_p = (T*)w;  w += align256((size_t)Bc * npad * f * e);
+        T* m_p = (T*)w;  w += align256((size_t)Bc * npad * e);
+        T* y_p = (T*)w;  w += align256((size_t)Bc * npad * e);
+        int32_t* nv_p = (int32_t*)w; w += align256((size_t)Bc * 4);
+        dz_p = (T*)w;    w += align256((size_t)Bc * npad * f * e);
+        dm_p = (T*)w;    w += align256((size_t)Bc * npad * e);
+        rows_copy<T>(zs, z_p, zrows, n, npad, f, s);
+        if (mean_mode == PACOH_MEAN_VECTOR) rows_copy<T>(ms, m_p, Bc, n, npad, 1, s);
+        rows_copy<T>(ys, y_p, yrows, n, npad, 1, s);
+        hipLaunchKernelGGL(dense_nv_kernel, dim3((unsigned)((yrows + 255) / 256)), dim3(256), 0, s, nvs, nv_p, (int)yrows, n);
+        zs = z_p; ys = y_p; nvs = nv_p;
+        if (mean_mode == PACOH_MEAN_VECTOR) ms = m_p;
+    }
+    const bool padded = npad != n;
+    int rc = lml_dense_impl<T>(zs, z_div, ms, mean_mode, ys, y_div, ls, os, noise, nvs, at(g_lml, b0), atw(lml, b0),
+                               padded && d_z ? dz_p : dzs, (padded && d_mean && mean_mode == PACOH_MEAN_VECTOR) ? dm_p : dms,
+                               atw(d_ls, b0 * f), atw(d_os, b0), atw(d_noise, b0), info + b0, w, Bc, P, npad, f_arg, dtype, s);
+    if (rc) return rc;
+    if (padded && d_ls) {                               // cut the padded gradients back
+        if (d_z) rows_copy<T>(dz_p, dzs, Bc, npad, n, f, s);
+        if (d_mean && mean_mode == PACOH_MEAN_VECTOR) rows_copy<T>(dm_p, dms, Bc, npad, n, 1, s);
+    }
+    return launch_status();
+}
+
+template <typename T>
+static int lml_dense_slabs(const void* z, int z_div, const void* mean, int mean_mode, const void* y, int y_div, const void* ls,
+                           const void* os, const void* noise, const int32_t* n_valid, const void* g_lml, void* lml, void* d_z,
+                           void* d_mean, void* d_ls, void* d_os, void* d_noise, int32_t* info, void* workspace, size_t workspace_bytes,
+                           int B, int P, int n, int f_arg, int dtype, hipStream_t s) {
+    const int f = features_of(f_arg), want_grad = d_ls != nullptr;
+    int tb = 0;                                          // tasks per slab; 0: the whole call at once
+    if (lml_slab_bytes(B, n, f, dtype, want_grad) > workspace_bytes) {
+        // slabs of WHOLE tasks (all P problems of a task share its inputs): needs the task-major layout b = t * P + p
+        if (B % P != 0 || (z_div != 1 && z_div != P) || (y_div != 1 && y_div != P)) return PACOH_EINVAL;
+        const size_t one = lml_slab_bytes(P, n, f, dtype, want_grad);
+        if (one == 0 || one > workspace_bytes) return PACOH_EINVAL;
+        tb = (int)(workspace_bytes / one);
+        while (tb > 1 && lml_slab_bytes(tb * P, n, f, dtype, want_grad) > workspace_bytes) --tb;
+    }
+    if (tb == 0) return lml_dense_slab<T>(z, z_div, mean, mean_mode, y, y_div, ls, os, noise, n_valid, g_lml, lml, d_z, d_mean, d_ls, d_os,
+                                          d_noise, info, workspace, 0, B, P, n, f_arg, dtype, s);
+    const int T_ = B / P;
+    for (int t0 = 0; t0 < T_; t0 += tb) {
+        const int tc = T_ - t0 < tb ? T_ - t0 : tb;
+        const int rc = lml_dense_slab<T>(z, z_div, mean, mean_mode, y, y_div, ls, os, noise, n_valid, g_lml, lml, d_z, d_mean, d_ls, d_os,
+                                         d_noise, info, workspace, (long)t0 * P, tc * P, P, n, f_arg, dtype, s);
+        if (rc) return rc;
+    }
+    return PACOH_OK;
+}
 
 extern "C" int pacoh_gp_lml_dense(const void* z, int z_div, const void* mean, int mean_mode, const void* y, int y_div,
                                   const void* lengthscale, const void* outputscale, const void* noise, const int32_t* n_valid,
                                   const void* g_lml, void* lml, void* d_z, void* d_mean, void* d_lengthscale, void* d_outputscale,
-                                  void* d_noise, int32_t* info, void* workspace, int B, int P, int n, int f, int dtype,
-                                  void* stream) {
+                                  void* d_noise, int32_t* info, void* workspace, size_t workspace_bytes, int B, int P, int n, int f,
+                                  int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!z || !y || !lengthscale || !noise || !lml || !info || !workspace || B <= 0 || P <= 0 || n <= 0 || f <= 0 || z_div <= 0 ||
         y_div <= 0)
@@ -1480,18 +1603,49 @@ extern "C" int pacoh_gp_lml_dense(const void* z, int z_div, const void* mean, in
     if (d_lengthscale && !d_noise) return PACOH_EINVAL;
     if (features_of(f) > PACOH_MAX_FEATURES || features_of(f) <= 0 || kernel_of(f) > PACOH_KERNEL_COSINE) return PACOH_ELIMIT;
     if (dtype == PACOH_F32)
-        return lml_dense_impl<float>(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, g_lml, lml, d_z,
-                                     d_mean, d_lengthscale, d_outputscale, d_noise, info, workspace, B, P, n, f, dtype, (hipStream_t)stream);
-    return lml_dense_impl<double>(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, g_lml, lml, d_z,
-                                  d_mean, d_lengthscale, d_outputscale, d_noise, info, workspace, B, P, n, f, dtype, (hipStream_t)stream);
+        return lml_dense_slabs<float>(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, g_lml, lml, d_z, d_mean,
+                                      d_lengthscale, d_outputscale, d_noise, info, workspace, workspace_bytes, B, P, n, f, dtype, (hipStream_t)stream);
+    return lml_dense_slabs<double>(z, z_div, mean, mean_mode, y, y_div, lengthscale, outputscale, noise, n_valid, g_lml, lml, d_z, d_mean,
+                                   d_lengthscale, d_outputscale, d_noise, info, workspace, workspace_bytes, B, P, n, f, dtype, (hipStream_t)stream);
 }
 
-extern "C" size_t pacoh_gp_predict_dense_workspace_bytes(int B, int n, int m, int dtype) {
-    if (B <= 0 || n <= 0 || m <= 0) return 0;
+static size_t predict_core_bytes(int B, int n, int m, int dtype) {
     const size_t e = dtype == PACOH_F64 ? 8 : 4;
     const size_t cb = (n > 512 && n <= 1024) ? align256((dtype == PACOH_F64 ? chol_blocked_scratch<double>(B, n) : chol_blocked_scratch<float>(B, n)) * e) : 0;
     return align256((size_t)B * n * n * e) + 2 * align256((size_t)B * n * m * e) + 2 * align256((size_t)B * n * e) +
            align256((size_t)B * e) + cb + 256;
+}
+// (the query does not know f: the padded copy of the context inputs is sized for PACOH_MAX_FEATURES -- 16 / n of the matrix buffer)
+extern "C" size_t pacoh_gp_predict_dense_workspace_bytes(int B, int n, int m, int dtype) {
+    if (B <= 0 || n <= 0 || m <= 0) return 0;
+    const size_t e = dtype == PACOH_F64 ? 8 : 4;
+    const int npad = dense_padded_n(n, dtype);
+    return predict_core_bytes(B, npad, m, dtype) +
+           (npad != n ? align256((size_t)B * npad * PACOH_MAX_FEATURES * e) + 2 * align256((size_t)B * npad * e) + align256((size_t)B * 4) : 0);
+}
+// the context side padded as for the LML (dense_padded_n); the test side and the outputs have m points and are untouched
+template <typename T>
+static int predict_dense_padded(const void* z_ctx, int z_div, const void* mean_ctx, int mean_mode, const void* y, int y_div,
+                                const void* z_tst, int zt_div, const void* mean_tst, const void* ls, const void* os, const void* noise,
+                                const int32_t* n_valid, void* mu, void* var, void* cov, int32_t* info, void* workspace, int B, int P,
+                                int n, int m, int f_arg, int dtype, hipStream_t s) {
+    const int f = features_of(f_arg), npad = dense_padded_n(n, dtype);
+    if (npad == n)
+        return predict_dense_impl<T>(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, z_tst, zt_div, mean_tst, ls, os, noise, n_valid, mu, var,
+                                     cov, info, workspace, B, P, n, m, f_arg, dtype, s);
+    const size_t e = sizeof(T);
+    unsigned char* w = (unsigned char*)workspace;
+    T* z_p = (T*)w;  w += align256((size_t)B * npad * PACOH_MAX_FEATURES * e);
+    T* m_p = (T*)w;  w += align256((size_t)B * npad * e);
+    T* y_p = (T*)w;  w += align256((size_t)B * npad * e);
+    int32_t* nv_p = (int32_t*)w; w += align256((size_t)B * 4);
+    const long zrows = (B + z_div - 1) / z_div, yrows = (B + y_div - 1) / y_div;
+    rows_copy<T>(z_ctx, z_p, zrows, n, npad, f, s);
+    if (mean_mode == PACOH_MEAN_VECTOR) rows_copy<T>(mean_ctx, m_p, B, n, npad, 1, s);
+    rows_copy<T>(y, y_p, yrows, n, npad, 1, s);
+    hipLaunchKernelGGL(dense_nv_kernel, dim3((unsigned)((yrows + 255) / 256)), dim3(256), 0, s, n_valid, nv_p, (int)yrows, n);
+    return predict_dense_impl<T>(z_p, z_div, mean_mode == PACOH_MEAN_VECTOR ? (const void*)m_p : mean_ctx, mean_mode, y_p, y_div, z_tst, zt_div,
+                                 mean_tst, ls, os, noise, nv_p, mu, var, cov, info, w, B, P, npad, m, f_arg, dtype, s);
 }
 
 extern "C" int pacoh_gp_predict_dense(const void* z_ctx, int z_div, const void* mean_ctx, int mean_mode, const void* y, int y_div,
@@ -1506,8 +1660,8 @@ extern "C" int pacoh_gp_predict_dense(const void* z_ctx, int z_div, const void* 
     if (mean_mode != PACOH_MEAN_ZERO && (!mean_ctx || !mean_tst)) return PACOH_EINVAL;
     if (features_of(f) > PACOH_MAX_FEATURES || features_of(f) <= 0 || kernel_of(f) > PACOH_KERNEL_COSINE) return PACOH_ELIMIT;
     if (dtype == PACOH_F32)
-        return predict_dense_impl<float>(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, z_tst, zt_div, mean_tst, lengthscale, outputscale,
-                                         noise, n_valid, mu, var, cov, info, workspace, B, P, n, m, f, dtype, (hipStream_t)stream);
-    return predict_dense_impl<double>(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, z_tst, zt_div, mean_tst, lengthscale, outputscale,
-                                      noise, n_valid, mu, var, cov, info, workspace, B, P, n, m, f, dtype, (hipStream_t)stream);
+        return predict_dense_padded<float>(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, z_tst, zt_div, mean_tst, lengthscale, outputscale,
+                                           noise, n_valid, mu, var, cov, info, workspace, B, P, n, m, f, dtype, (hipStream_t)stream);
+    return predict_dense_padded<double>(z_ctx, z_div, mean_ctx, mean_mode, y, y_div, z_tst, zt_div, mean_tst, lengthscale, outputscale,
+                                        noise, n_valid, mu, var, cov, info, workspace, B, P, n, m, f, dtype, (hipStream_t)stream);
 }

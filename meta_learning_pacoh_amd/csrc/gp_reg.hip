@@ -21,8 +21,11 @@ __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfm
     __shared__ __attribute__((aligned(16))) float zf[NP * FP];      // features / lengthscale
     __shared__ __attribute__((aligned(16))) float rv[NP];           // residual
     __shared__ __attribute__((aligned(16))) float av[NP];           // alpha
-    __shared__ __attribute__((aligned(16))) float fsc[128];         // factor16(): lane row k -> all lane rows
-    __shared__ __attribute__((aligned(16))) float tsc[320];         // one 16x16 block transpose (V_K = -L_KK^-T)
+    // factor16(): every lane row's registers -> all lane rows; the SAME memory is the 16x16 block transpose scratch (tsc, 320 floats:
+    // V_K = -L_KK^-T and the transposes of the gradient loop) -- one wave, in-order LDS, and no transpose is in flight across a
+    // factor16() call.  (As two arrays the round-6 factor16 slots made a problem 10.75 KB: 14 instead of 16 problems per CU, +11 %.)
+    __shared__ __attribute__((aligned(16))) float fsc[gpreg::GPR_SCR];
+    float* tsc = fsc;
     __shared__ __attribute__((aligned(16))) float dzc[BWD ? NP * FP : 1];   // d_z before the chain-rule factors
     // W = K^-1, strictly upper block triangle, each block as the 64 lanes' accumulator registers (one 16-byte slot per lane): parked
     // here between the matrix-core phase that produces it and the gradient loop that consumes it, so that the two phases do not
@@ -40,8 +43,8 @@ gp_reg_predict_kernel(GpMfmaArgs a, GpPredArgs pa) {
     __shared__ __attribute__((aligned(16))) float zf[NP * FP];
     __shared__ __attribute__((aligned(16))) float rv[NP];
     __shared__ __attribute__((aligned(16))) float av[NP];
-    __shared__ __attribute__((aligned(16))) float fsc[128];
-    __shared__ __attribute__((aligned(16))) float tsc[320];
+    __shared__ __attribute__((aligned(16))) float fsc[gpreg::GPR_SCR];
+    float* tsc = fsc;                                               // (shared with the transpose scratch: gp_reg_kernel)
     __shared__ __attribute__((aligned(16))) float dzc[4];
     __shared__ __attribute__((aligned(16))) float Wl[4];
     gpreg::gp_reg_body<NB, FP, true, true, gpreg::KernelCtx, true>(a, gpreg::KernelCtx{}, zf, rv, av, fsc, tsc, dzc, Wl, &pa);

@@ -116,7 +116,7 @@ __device__ __forceinline__ float wave_sum_(float v) {
 // into NaN (rsq), a zero pivot into infinity, which is also how the caller notices the failure.
 // What is NOT computed: the entries of L above the 4-column panel being eliminated are left as they fall out of the
 // substitution (garbage): they only ever produce rows of L Z that have been consumed already.
-// fs: 128 floats of per-wave LDS.  The four registers of the lane row g == k (rows 4k..4k+3 of the block, one column per lane) have
+// fs: per-wave LDS (GPR_FSC floats, see below).  The four registers of the lane row g == k (rows 4k..4k+3 of the block, one column per lane) have
 // to reach all four lane rows twice per step (the panel rows of C, then the fresh rows of Z).  As four ds_bpermute each that is
 // 8 x 24 issue cycles per step (tools/valu_rates.hip); as one 16-lane ds_write_b128 + one ds_read_b128 (the four lanes of equal r
 // read one address: a broadcast) it is 2 x (13 + 4) -- and the pivot block comes out of the same 256 bytes by four uniform
@@ -127,6 +127,22 @@ __device__ __forceinline__ float wave_sum_(float v) {
 // SIMD): `rows` = rows of this block inside the problem (wave-uniform).  A step
 // whose four columns are all padding is not run: the padding rows are rows of the identity, exactly (their off-diagonal kernel
 // entries are exp2(-1e20) = 0), so the step would produce x = 0, Z rows = identity rows and a pivot of 1 -- which is what is set.
+// Round 6 (groups 1 and 2 of profiles/r05_gp_reg_isa_histogram.txt), -DPACOH_F16_BRANCHFREE=1: the two stores of a step
+// are `if (g == k)` regions (s_and_saveexec / s_cbranch_execz / s_or per region, 32 regions per block); in the branch-free form EVERY
+// lane row stores its registers to a slot of its own (fs + 64 g, fs + 256 + 64 g) and the readers address lane row k's slot -- no
+// exec-mask code around a store -- and the Z entry a lane needs for the rank-4 update is read as ONE float (fs[.. + 4 r + g]) instead
+// of a 16-byte read and three selects.  Same bits; measured on the cfg #3 step, same box, two runs each
+// (profiles/r06_gp_factor16_ab.txt): 0.1449 / 0.1461 ms against 0.1452 / 0.1466 -- nothing, like round 5's permlane swap: the kernel
+// does not respond to a 3 % instruction diet.  It does respond to occupancy: the same build with the slots in a scratch array of
+// their own (10.75 KB of LDS per problem: 14 problems per CU instead of 16) ran 0.157 ms, +11 %.  Not the default.
+// GPR_FSC: floats of per-wave LDS factor16() uses; GPR_SCR: the scratch it shares with the 16x16 transpose (tsc, 320 floats: one
+// wave, in-order LDS, and no transpose is in flight across a factor16() call).
+#ifdef PACOH_F16_BRANCHFREE
+constexpr int GPR_FSC = 512;
+#else
+constexpr int GPR_FSC = 128;
+#endif
+constexpr int GPR_SCR = GPR_FSC > 320 ? GPR_FSC : 320;
 template <bool SKIP = false>
 __device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const f32x4& nId, int r, int g, float* fs, int rows = 16) {
     f32x4 Tn = nId;                                         // -E + L Z, built up by one rank-4 MFMA per step (see below)
@@ -141,12 +157,18 @@ __device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const
         // pivot block P[c][j] = C[4k+c][4k+j] = register c of lane (r = 4k+j, g = k): wave-uniform
         const float c0 = Cn[0], c1 = Cn[1], c2 = Cn[2], c3 = Cn[3];
         const int src = (16 * k + r) * 4;
+#ifndef PACOH_F16_BRANCHFREE
         if (g == k) *reinterpret_cast<f32x4*>(fs + 4 * r) = Cn;
+        const float* fk = fs;
+#else
+        *reinterpret_cast<f32x4*>(fs + 64 * g + 4 * r) = Cn;
+        const float* fk = fs + 64 * k;
+#endif
         asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
-        const f32x4 rtv = *reinterpret_cast<const f32x4*>(fs + 4 * r);
+        const f32x4 rtv = *reinterpret_cast<const f32x4*>(fk + 4 * r);
         const float rt0 = -rtv[0], rt1 = -rtv[1], rt2 = -rtv[2], rt3 = -rtv[3];
-        const f32x4 pc0 = *reinterpret_cast<const f32x4*>(fs + 16 * k), pc1 = *reinterpret_cast<const f32x4*>(fs + 16 * k + 4);
-        const f32x4 pc2 = *reinterpret_cast<const f32x4*>(fs + 16 * k + 8), pc3 = *reinterpret_cast<const f32x4*>(fs + 16 * k + 12);
+        const f32x4 pc0 = *reinterpret_cast<const f32x4*>(fk + 16 * k), pc1 = *reinterpret_cast<const f32x4*>(fk + 16 * k + 4);
+        const f32x4 pc2 = *reinterpret_cast<const f32x4*>(fk + 16 * k + 8), pc3 = *reinterpret_cast<const f32x4*>(fk + 16 * k + 12);
         const float p00 = -pc0[0], p10 = -pc0[1], p20 = -pc0[2], p30 = -pc0[3];
         const float p11 = -pc1[1], p21 = -pc1[2], p31 = -pc1[3];
         const float p22 = -pc2[2], p32 = -pc2[3], p33 = -pc3[3];
@@ -183,12 +205,19 @@ __device__ __forceinline__ void factor16(f32x4 Cn, f32x4& Z, float& dprod, const
             // Tn += L[:, 4k..4k+3] Z[4k..4k+3, :]: ONE MFMA (k index = the four new columns) -- A[i][kk] = L[i][4k+kk] is xg of lane
             // (i, kk); B[kk][j] = Z[4k+kk][j] lives in register kk of lane (j, k) and reaches lane (j, kk) by four lane reads.  (Forming
             // the block row of L Z as a full product with L^T kept in registers took four MFMAs per step for a 4-row result.)
+#ifndef PACOH_F16_BRANCHFREE
             if (g == k) *reinterpret_cast<f32x4*>(fs + 64 + 4 * r) = Z;
             asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
             const f32x4 wv = *reinterpret_cast<const f32x4*>(fs + 64 + 4 * r);
             asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
             const float w0 = wv[0], w1 = wv[1], w2 = wv[2], w3 = wv[3];
             const float zb = g == 0 ? w0 : (g == 1 ? w1 : (g == 2 ? w2 : w3));
+#else
+            *reinterpret_cast<f32x4*>(fs + 256 + 64 * g + 4 * r) = Z;      // (lane rows g != k store what they hold: nobody reads it)
+            asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
+            const float zb = fs[256 + 64 * k + 4 * r + g];
+            asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
+#endif
             Tn = mfma_(xg, zb, Tn);
         }
     }
@@ -237,7 +266,7 @@ __host__ __device__ constexpr int uidx(int NB, int K, int J) { return K * NB - K
 // one problem per 64-thread workgroup, arguments read late from the kernel-argument segment) and the persistent PACOH-MAP
 // iteration kernel (map_persist.hip: one wave per task of the batch inside a 1024-thread workgroup, every operand in LDS).
 // Ctx: lane() = lane of the wave, block() = problem index b, late<T>(a.field, offset of it) = that field, read late.
-// zf [16 NB FP], rv / av [16 NB], fsc [128], tsc [320], dzc [BWD ? 16 NB FP : 1], Wl [BWD && NB > 1 ? (NU - NB) 256 : 4]: per-wave
+// zf [16 NB FP], rv / av [16 NB], fsc / tsc [GPR_SCR, shared], dzc [BWD ? 16 NB FP : 1], Wl [BWD && NB > 1 ? (NU - NB) 256 : 4]: per-wave
 // LDS scratch (16-byte aligned).
 // PRED (round 5): the posterior predictive instead of the gradients -- mu_s = m_s + k_s^T alpha, var_s = os + noise - |L^-1 k_s|^2 for
 // the m test points of *pa, 16 at a time: the kernel entries K_xs of a test block against every context block (accumulator layout:

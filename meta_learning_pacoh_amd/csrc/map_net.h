@@ -569,7 +569,7 @@ static int map_persist_plan(MpArgs& a, int n, int d, int tb, int K, int mean_mod
     else a.o_m = a.o_v = a.o_flat = a.o_th;
     for (int k = 0; k < a.nets; ++k) for (int l = 0; l < a.nl[k]; ++l) a.L[k][l].w_lds += 0;      // (image offsets are relative to o_th / o_m / o_v)
     const int NP = 16 * NB, NU = NB * (NB + 1) / 2;
-    a.gpw = round4(2 * NP * FP + 2 * NP + 448 + (NB > 1 ? (NU - NB) * 256 : 4));
+    a.gpw = round4(2 * NP * FP + 2 * NP + gpreg::GPR_SCR + (NB > 1 ? (NU - NB) * 256 : 4));
     a.o_gp = take(a.gpw * tb);
     {   // tasks per phase as mp_plan emits them -> slots (the table's row length)
         const int nPt = (a.pts + 15) / 16;

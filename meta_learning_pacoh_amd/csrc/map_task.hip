@@ -340,8 +340,8 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
         constexpr int NP = 16 * NB;
         float* ws = lds + sg(a.o_gp) + wave * sg(a.gpw);
         gpreg::gp_reg_body<NB, FP, true, true>(g, gpreg::WaveCtx{(unsigned)wave}, ws, ws + NP * FP, ws + NP * FP + NP,
-                                               ws + NP * FP + 2 * NP, ws + NP * FP + 2 * NP + 128, ws + NP * FP + 2 * NP + 448,
-                                               ws + 2 * NP * FP + 2 * NP + 448);
+                                               ws + NP * FP + 2 * NP, ws + NP * FP + 2 * NP, ws + NP * FP + 2 * NP + gpreg::GPR_SCR,
+                                               ws + 2 * NP * FP + 2 * NP + gpreg::GPR_SCR);
     }
     MP_STAMP();
     if (a.nets > 0) {

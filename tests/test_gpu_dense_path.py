@@ -390,3 +390,54 @@ def test_dense_path_slabs_match_single_pass(L):
         assert torch.equal(a, b)
     for a, b in zip(shared_full, shared):
         assert (a is None and b is None) or torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dtype,n', [(torch.float32, 509), (torch.float64, 255), (torch.float32, 641)])
+def test_raw_c_abi_call_pads_and_slabs_by_itself(L, dtype, n):
+    """a host that binds pacoh_gp_lml_dense directly gets what the Python binding gives -- a
+    context size with misaligned rows is run as a ragged batch of the next aligned size INSIDE the call (left-looking kernels:
+    profiles/r06_raw_abi_n509_kernels.txt shows them by name), and a workspace that holds fewer problems than the batch makes the call
+    loop over slabs of whole tasks.  Raw ctypes call, no helper of _lib in between; against the oracle and bit-equal across slab sizes"""
+    import ctypes
+    lib = L.load_library()
+    T, P, f = 3, 2, 3
+    B = T * P
+    code = L.F32 if dtype == torch.float32 else L.F64
+    z, mean, y, ls, os_, noise = [t.to(DEV) for t in make_problem(T, P, n, f, dtype, seed=n, per_eval_z=True, noise_lo=0.05)]
+    nv = torch.tensor([n, n - 30, n], dtype=torch.int32, device=DEV)
+
+    def call(ws_bytes):
+        out = dict(lml=torch.empty(B, dtype=dtype, device=DEV), d_z=torch.full((B, n, f), float('nan'), dtype=dtype, device=DEV),
+                   d_mean=torch.full((B, n), float('nan'), dtype=dtype, device=DEV), d_ls=torch.empty(B, f, dtype=dtype, device=DEV),
+                   d_os=torch.empty(B, dtype=dtype, device=DEV), d_noise=torch.empty(B, dtype=dtype, device=DEV),
+                   info=torch.empty(B, dtype=torch.int32, device=DEV))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        rc = lib.pacoh_gp_lml_dense(p(z), 1, p(mean), L.MEAN_VECTOR, p(y), P, p(ls), p(os_), p(noise), p(nv), None, p(out['lml']), p(out['d_z']),
+                                    p(out['d_mean']), p(out['d_ls']), p(out['d_os']), p(out['d_noise']), p(out['info']), p(ws), ws_bytes,
+                                    B, P, n, f, code, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        return rc, out
+    need_all = lib.pacoh_gp_lml_dense_workspace_bytes(B, n, f, code, 1)
+    need_one = lib.pacoh_gp_lml_dense_workspace_bytes(P, n, f, code, 1)
+    assert 0 < need_one < need_all
+    rc, whole = call(need_all)
+    assert rc == 0 and int(whole['info'].abs().max()) == 0
+    rc1, one_task = call(need_one)                       # three slabs
+    rc2, two_tasks = call(2 * need_one)                  # two slabs (2 + 1 tasks)
+    assert rc1 == 0 and rc2 == 0
+    for k in whole:
+        assert torch.equal(whole[k], one_task[k]) and torch.equal(whole[k], two_tasks[k]), k
+    assert call(need_one - 1)[0] == -1                   # PACOH_EINVAL: not even one task fits
+    # the oracle on the ragged tasks (rows >= n_valid are ignored: their gradients are exact zeros)
+    tol_l, tol_g = (1e-4, 1e-3) if dtype == torch.float32 else (1e-9, 1e-7)
+    for t in range(T):
+        m_ = int(nv[t])
+        for p_ in range(P):
+            b = t * P + p_
+            lv = [z[b, :m_].double().cpu().requires_grad_(True), mean[b, :m_].double().cpu().requires_grad_(True)]
+            ref = O.gp_mll(lv[0], lv[1], y[t, :m_].double().cpu(), ls[p_].double().cpu(), os_[p_].double().cpu(), noise[p_].double().cpu())
+            ref.backward()
+            assert abs(float(whole['lml'][b]) - float(ref)) < tol_l * abs(float(ref))
+            assert relerr(whole['d_z'][b, :m_], lv[0].grad) < tol_g and relerr(whole['d_mean'][b, :m_], lv[1].grad) < tol_g
+            assert float(whole['d_z'][b, m_:].abs().max() if m_ < n else 0.0) == 0.0

@@ -1,15 +1,16 @@
-mkdir -p gpurun_out/r06e; export TMPDIR=/tmp
-PACOH_LIB=$PWD/meta_learning_pacoh_amd/lib/libpacoh_gp_mpst.so PACOH_NO_GRAPH=1 python tools/svgd_task_stamps.py 2>&1 | grep "mt stamp" | head -20 | tr '\n' ' '; echo
-for c in ref_svgd ref_vi 2; do
-  python bench.py --config $c --no-cpu-baseline > gpurun_out/r06e/bench_$c.json 2> gpurun_out/r06e/bench_$c.err
-done
+mkdir -p gpurun_out/r06g; export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_gpu_dense_path.py tests/test_gpu_chol_ll.py tests/test_gpu_fullsize.py tests/test_gpu_kernels.py tests/test_gpu_fuzz.py tests/test_gpu_map_persist.py tests/test_gpu_svgd_task.py -q -x 2>&1 | tail -6
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r06g/raw -- python3 tools/raw_abi_dense.py 509 f32 > gpurun_out/r06g/raw_abi.txt 2>&1
 python - <<'PY'
-import json
-for c in ('ref_svgd', 'ref_vi', '2'):
-    try:
-        d = json.load(open('gpurun_out/r06e/bench_%s.json' % c))
-        print(c, d['ms_per_step'], d['steady']['ms_per_step'], d.get('gpu_ms_per_step_noise_resident'), d['kernel_ms_per_step'], d['config'].get('finite'))
-    except Exception as e:
-        print(c, 'ERR', e)
+import csv, glob
+f = glob.glob('gpurun_out/r06g/raw/*/*kernel_stats.csv')[0]
+rows = list(csv.reader(open(f)))
+with open('gpurun_out/r06g/raw_abi_n509_kernels.txt', 'w') as fh:
+    fh.write('# rocprofv3 --kernel-trace --stats -- python3 tools/raw_abi_dense.py 509 f32  (pacoh_gp_lml_dense through raw ctypes, 5 calls of 16 problems)\n')
+    for r in rows[:14]:
+        fh.write('%-110s calls %s avg_ns %s\n' % (r[0][:110], r[1], r[3]))
+print(open('gpurun_out/r06g/raw_abi_n509_kernels.txt').read())
 PY
-timeout 900 python -m pytest tests/test_gpu_svgd_task.py tests/test_gpu_map_persist.py -q 2>&1 | tail -4
+tail -2 gpurun_out/r06g/raw_abi.txt; rm -rf gpurun_out/r06g/raw
+python tools/dense_pad_ab.py 2>&1 | tail -5
+python tools/determinism_check.py 2>&1 | tail -3

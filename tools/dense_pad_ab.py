@@ -20,6 +20,7 @@ for dtype, n in ((torch.float64, 255), (torch.float64, 401), (torch.float32, 255
     res = {}
     for pad in ('0', '1'):
         os.environ['PACOH_DENSE_PAD'] = pad
+        L.reload_env()
         for _ in range(3):
             out = L.gp_lml_fwdbwd(X, 1, None, L.MEAN_ZERO, Y, 1, ls, os1, nz, B, 1)
         torch.cuda.synchronize()
