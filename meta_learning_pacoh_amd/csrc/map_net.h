@@ -6,6 +6,7 @@
 // models.py:505-519, GPR_meta_mll.py:104-117.
 #pragma once
 #include "gp_reg_body.h"
+#include "gp8_body.h"
 #include "hyper_tail.h"
 #include <stdlib.h>
 #include <string.h>
@@ -51,6 +52,7 @@ struct MpArgs {
     int o_th, o_m, o_v, o_flat, o_a0, a0_sz, S0, o_xs, xs_sz, o_y, y_sz, o_nv, o_mn, o_zk, o_dmn, o_dzk;
     int o_lml, o_info, o_dls, o_dos, o_dnz, o_dc, o_gl, o_hp, o_gp, gpw, total;
     int pts;
+    int gp8;                         // n <= 8: the GP runs gp8_body (one matrix entry per lane) instead of the 16 x 16-block body (PACOH_GP8=0: never)
     int o_tasks, slots;              // the task table: [3 phases][slots] descriptors of 16 ints (mp_plan)
 };
 
@@ -548,6 +550,7 @@ static int map_persist_plan(MpArgs& a, int n, int d, int tb, int K, int mean_mod
     *nb_out = NB; *fp_out = FP;
     a.n = n; a.d = d; a.tb = tb; a.K = K; a.f = f; a.mean_mode = mean_mode; a.kernel_nn = kernel_nn;
     a.pts = tb * n;
+    a.gp8 = (n <= 8 && g_sw.gp8) ? 1 : 0;
     int top = 0;
     auto take = [&](int count) { const int o = top; top += round4(count); return o; };
     a.S0 = round4(d + 1);

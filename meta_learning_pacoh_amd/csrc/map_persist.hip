@@ -188,11 +188,17 @@ __global__ void __launch_bounds__(MP_NT) map_persist_kernel(MpArgs a) {
             g.d_mean = sp(mean_mode == PACOH_MEAN_VECTOR ? lds + a.o_dmn : (mean_mode == PACOH_MEAN_CONST ? lds + a.o_dc : nullptr));
             g.d_ls = sp(lds + a.o_dls); g.d_os = sp(has_os ? lds + a.o_dos : nullptr); g.d_noise = sp(lds + a.o_dnz);
             g.B = sg(tb); g.P = 1; g.n = sg(n); g.f = sg(f);
-            constexpr int NP = 16 * NB;
-            float* ws = lds + sg(a.o_gp) + wave * sg(a.gpw);
-            gpreg::gp_reg_body<NB, FP, true, true>(g, gpreg::WaveCtx{(unsigned)wave}, ws, ws + NP * FP, ws + NP * FP + NP,
-                                                   ws + NP * FP + 2 * NP, ws + NP * FP + 2 * NP, ws + NP * FP + 2 * NP + gpreg::GPR_SCR,
-                                                   ws + 2 * NP * FP + 2 * NP + gpreg::GPR_SCR);
+            // contexts of <= 8 points (the reference's demo: 5): one matrix entry per lane, no 16 x 16 blocks (gp8_body.h)
+            bool small8 = false;
+            if constexpr (NB == 1) small8 = sg(a.gp8) != 0;
+            if (small8) gpreg::gp8_body<FP>(g, gpreg::WaveCtx{(unsigned)wave});
+            else {
+                constexpr int NP = 16 * NB;
+                float* ws = lds + sg(a.o_gp) + wave * sg(a.gpw);
+                gpreg::gp_reg_body<NB, FP, true, true>(g, gpreg::WaveCtx{(unsigned)wave}, ws, ws + NP * FP, ws + NP * FP + NP,
+                                                       ws + NP * FP + 2 * NP, ws + NP * FP + 2 * NP, ws + NP * FP + 2 * NP + gpreg::GPR_SCR,
+                                                       ws + 2 * NP * FP + 2 * NP + gpreg::GPR_SCR);
+            }
         }
         MP_STAMP();
         __syncthreads();

@@ -337,11 +337,17 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
             g.d_ls = ka.dls_g + (long)task0 * f; g.d_os = has_os ? ka.dos_g + task0 : nullptr; g.d_noise = ka.dnz_g + task0;
         }
         g.B = ka.tb_total; g.P = 1; g.n = sg(n); g.f = sg(f);
-        constexpr int NP = 16 * NB;
-        float* ws = lds + sg(a.o_gp) + wave * sg(a.gpw);
-        gpreg::gp_reg_body<NB, FP, true, true>(g, gpreg::WaveCtx{(unsigned)wave}, ws, ws + NP * FP, ws + NP * FP + NP,
-                                               ws + NP * FP + 2 * NP, ws + NP * FP + 2 * NP, ws + NP * FP + 2 * NP + gpreg::GPR_SCR,
-                                               ws + 2 * NP * FP + 2 * NP + gpreg::GPR_SCR);
+        // contexts of <= 8 points (the reference's demo: 5): one matrix entry per lane, no 16 x 16 blocks (gp8_body.h)
+        bool small8 = false;
+        if constexpr (NB == 1) small8 = sg(a.gp8) != 0;
+        if (small8) gpreg::gp8_body<FP>(g, gpreg::WaveCtx{(unsigned)wave});
+        else {
+            constexpr int NP = 16 * NB;
+            float* ws = lds + sg(a.o_gp) + wave * sg(a.gpw);
+            gpreg::gp_reg_body<NB, FP, true, true>(g, gpreg::WaveCtx{(unsigned)wave}, ws, ws + NP * FP, ws + NP * FP + NP,
+                                                   ws + NP * FP + 2 * NP, ws + NP * FP + 2 * NP, ws + NP * FP + 2 * NP + gpreg::GPR_SCR,
+                                                   ws + 2 * NP * FP + 2 * NP + gpreg::GPR_SCR);
+        }
     }
     MP_STAMP();
     if (a.nets > 0) {

@@ -20,6 +20,7 @@ void read_switches(Switches& s) {
     s.grad_mfma = off0("PACOH_GRAD_MFMA"); s.grad_mfma_f32 = off0("PACOH_GRAD_MFMA_F32"); s.gram_mfma = off0("PACOH_GRAM_MFMA");
     s.dense_pad = off0("PACOH_DENSE_PAD");
     s.mfma = num("PACOH_DISABLE_MFMA", 0) != 1;
+    s.gp8 = off0("PACOH_GP8");
     s.gp_reg = off0("PACOH_GP_REG"); s.gp_reg_predict = off0("PACOH_GP_REG_PREDICT"); s.gp_reg_max_n = num("PACOH_GP_REG_MAX_N", 128);
     s.fused_mlp = num("PACOH_DISABLE_FUSED_MLP", 0) == 0;
     const char* e = getenv("PACOH_MLP_PATH");

@@ -11,6 +11,7 @@ struct Switches {
     bool mfma;                 // PACOH_DISABLE_MFMA=1 -> false: the next GP / Cholesky / MLP implementation (fallback coverage)
     // register-resident GP kernels
     bool gp_reg, gp_reg_predict;
+    bool gp8;                  // PACOH_GP8=0: the task-fused / persistent kernels run contexts of <= 8 points on the block body too (A/B, tests)
     int gp_reg_max_n;
     // per-particle MLP
     bool fused_mlp;

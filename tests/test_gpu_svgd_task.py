@@ -55,7 +55,8 @@ CFGS = [
     dict(covar_module='NN', mean_module='constant', kernel_nn_layers=(16, 16)),     # generic chains
     dict(mean_nn_layers=(20, 12), kernel_nn_layers=(24,)),                          # widths that are no multiple of 16, different depths
 ]
-SHAPES = [(6, 20, 1, 2, 10), (9, 12, 2, 5, 4), (7, 5, 1, 7, 3), (5, 32, 3, 3, 6), (4, 17, 4, 4, 1)]      # (T, n, d, tasks per step, rows)
+SHAPES = [(6, 20, 1, 2, 10), (9, 12, 2, 5, 4), (7, 5, 1, 7, 3), (5, 32, 3, 3, 6), (4, 17, 4, 4, 1),     # (T, n, d, tasks per step, rows)
+          (6, 8, 2, 3, 2), (5, 1, 1, 2, 2), (6, 7, 4, 4, 3)]      # n <= 8: the one-entry-per-lane GP body (csrc/gp8_body.h), n = 1, f = d = 4
 
 
 @pytest.mark.parametrize('cfg', CFGS)
@@ -87,6 +88,53 @@ def test_task_fused_score_equals_the_general_sequence(M, cfg, shape, ragged):
     assert rel(score1[:, keep], score0[:, keep]) < 5e-5
     for p in range(P):                                    # every row on its own (a swapped row would hide in the norm of all)
         assert rel(score1[p, keep], score0[p, keep]) < 2e-4, p
+
+
+@pytest.mark.parametrize('n', [2, 5, 8])
+def test_small_context_body_takes_the_jitter_ladder(M, n):
+    """gp8_body (contexts of <= 8 points: Gauss-Jordan sweeps, one matrix entry per lane): two identical points under a noise of 1e-9
+    make the second pivot vanish in fp32 -- rung 1 of gpytorch's ladder (jitter 1e-6) succeeds; the general sequence's kernels climb the
+    same ladder on the same problem, and a noise of -1 fails every rung on both (flag raised, NaN sums).  PACOH_GP8=0 (the 16 x 16-block
+    body inside the same kernel) must agree too"""
+    import os
+    from meta_learning_pacoh_amd import _lib as L
+    tasks = make_tasks(3, 4, n, 1, False)
+    for t in range(4):
+        tasks[t][0][1 % n] = tasks[t][0][0]                 # a duplicated point (n = 1: nothing to duplicate, the ladder is not needed)
+    m = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=3, task_batch_size=2, random_seed=5, covar_module='SE', mean_module='NN')
+    batch = m.tasks.select(torch.tensor([0, 2], device=m.device))
+    D, P = m.layout.D, 3
+    ls = torch.ones(P, 1, device=m.device)
+    res = {}
+    for tag, nz in (('ladder', 1e-9), ('fail', -1.0)):
+        noise = torch.full((P,), nz, device=m.device)
+        score0, lik0 = torch.zeros(P, D, device=m.device), torch.zeros(P, device=m.device)
+        fail0 = torch.zeros(1, dtype=torch.int32, device=m.device)
+        m.engine.lml_and_grad(m.particles, batch, weight=1.0, lik_out=lik0, lik_scale=1.0, grad_out=score0, fail_flag=fail0, hypers=(ls, None, noise))
+        out = []
+        for gp8 in ('1', '0'):
+            os.environ['PACOH_GP8'] = gp8
+            L.reload_env()
+            try:
+                ws = m._setup_task_fused(P, 2)
+                score1, lik1 = torch.zeros(P, D, device=m.device), torch.zeros(P, device=m.device)
+                fail1 = torch.zeros(1, dtype=torch.int32, device=m.device)
+                L.svgd_task_step(m._task_plan, m.particles, batch, (ls, None, noise), score1, lik1, 1.0, fail1, ws)
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop('PACOH_GP8', None)
+                L.reload_env()
+            out.append((score1, lik1, int(fail1)))
+        res[tag] = (lik0, int(fail0), out)
+    lik0, fail0, out = res['ladder']
+    assert fail0 == 0 and bool(torch.isfinite(lik0).all())
+    for score1, lik1, fail1 in out:
+        assert fail1 == 0 and bool(torch.isfinite(lik1).all()) and bool(torch.isfinite(score1).all())
+        assert rel(lik1, lik0) < (1e-2 if n > 1 else 1e-5)     # (condition number ~1e6 after the jitter: the factorisation is the error)
+    lik0, fail0, out = res['fail']
+    assert fail0 == 1
+    for score1, lik1, fail1 in out:
+        assert fail1 == 1 and bool(torch.isnan(lik1).all())
 
 
 def test_task_fused_score_against_the_oracle_at_the_launcher_shape(M):
