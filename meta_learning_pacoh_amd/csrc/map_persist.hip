@@ -174,25 +174,31 @@ __global__ void __launch_bounds__(MP_NT) map_persist_kernel(MpArgs a) {
         //      demo.py's 5-point tasks per wave, two GP waves instead of five.  The body is ~1 850 instructions per wave whatever its
         //      neighbours do, the per-task sums and masks added 25 %: 10 700 cycles against 8 400 + 1 300 of barrier wait.  Dropped.) ----
         if (wave < tb) {
-            GpMfmaArgs g;
             const int mean_mode = sg(a.mean_mode), kernel_nn = sg(a.kernel_nn), has_os = sg(a.off_os) >= 0;
-            g.z = sp(kernel_nn ? lds + a.o_zk : lds + a.o_xs + buf * a.xs_sz); g.z_div = 1;
-            g.mean = sp(mean_mode == PACOH_MEAN_VECTOR ? lds + a.o_mn : (mean_mode == PACOH_MEAN_CONST ? hp + 6 : nullptr));
-            g.mean_mode = mean_mode;
-            g.y = sp(lds + a.o_y + buf * a.y_sz); g.y_div = 1;
-            g.ls = sp(hp); g.os = sp(has_os ? hp + 4 : nullptr); g.noise = sp(hp + 5);
-            g.n_valid = sp(a.n_valid ? nv_l + buf * 16 : nullptr);
-            g.g_lml = sp(lds + a.o_gl);
-            g.lml = sp(lds + a.o_lml); g.info = sp(info_l);
-            g.d_z = sp(kernel_nn ? lds + a.o_dzk : nullptr);
-            g.d_mean = sp(mean_mode == PACOH_MEAN_VECTOR ? lds + a.o_dmn : (mean_mode == PACOH_MEAN_CONST ? lds + a.o_dc : nullptr));
-            g.d_ls = sp(lds + a.o_dls); g.d_os = sp(has_os ? lds + a.o_dos : nullptr); g.d_noise = sp(lds + a.o_dnz);
-            g.B = sg(tb); g.P = 1; g.n = sg(n); g.f = sg(f);
+            // (wrap: the block body wants its 17 pointers in scalar registers -- sp(); the small-context body addresses per lane anyway,
+            //  and the scalar copies cost it ~100 v_readlane of spilled scalars)
+            auto gp_args = [&](auto wrap) {
+                GpMfmaArgs g;
+                g.z = wrap(kernel_nn ? lds + a.o_zk : lds + a.o_xs + buf * a.xs_sz); g.z_div = 1;
+                g.mean = wrap(mean_mode == PACOH_MEAN_VECTOR ? lds + a.o_mn : (mean_mode == PACOH_MEAN_CONST ? hp + 6 : (float*)nullptr));
+                g.mean_mode = mean_mode;
+                g.y = wrap(lds + a.o_y + buf * a.y_sz); g.y_div = 1;
+                g.ls = wrap(hp); g.os = wrap(has_os ? hp + 4 : (float*)nullptr); g.noise = wrap(hp + 5);
+                g.n_valid = wrap(a.n_valid ? nv_l + buf * 16 : (int*)nullptr);
+                g.g_lml = wrap(lds + a.o_gl);
+                g.lml = wrap(lds + a.o_lml); g.info = wrap(info_l);
+                g.d_z = wrap(kernel_nn ? lds + a.o_dzk : (float*)nullptr);
+                g.d_mean = wrap(mean_mode == PACOH_MEAN_VECTOR ? lds + a.o_dmn : (mean_mode == PACOH_MEAN_CONST ? lds + a.o_dc : (float*)nullptr));
+                g.d_ls = wrap(lds + a.o_dls); g.d_os = wrap(has_os ? lds + a.o_dos : (float*)nullptr); g.d_noise = wrap(lds + a.o_dnz);
+                g.B = sg(tb); g.P = 1; g.n = sg(n); g.f = sg(f);
+                return g;
+            };
             // contexts of <= 8 points (the reference's demo: 5): one matrix entry per lane, no 16 x 16 blocks (gp8_body.h)
             bool small8 = false;
             if constexpr (NB == 1) small8 = sg(a.gp8) != 0;
-            if (small8) gpreg::gp8_body<FP>(g, gpreg::WaveCtx{(unsigned)wave});
+            if (small8) gpreg::gp8_body<FP>(gp_args([](auto* q) { return q; }), gpreg::WaveCtx{(unsigned)wave});
             else {
+                const GpMfmaArgs g = gp_args([](auto* q) { return sp(q); });
                 constexpr int NP = 16 * NB;
                 float* ws = lds + sg(a.o_gp) + wave * sg(a.gpw);
                 gpreg::gp_reg_body<NB, FP, true, true>(g, gpreg::WaveCtx{(unsigned)wave}, ws, ws + NP * FP, ws + NP * FP + NP,
