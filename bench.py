@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 FP32_PEAK_TFLOPS = 157.3       # fp32 vector peak == fp32-input MFMA peak (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6        # fp64 matrix peak: AMD's MI355X figure; tools/mfma_peak.hip measures what v_mfma_f64_16x16x4 sustains
 STEADY_STEPS = 200            # the extra region behind the timed one (the line's `steady` object)
-PMC_PROFILE = os.path.join('profiles', 'r05_pmc_hbm_traffic.json')
-DENSE_PMC_PROFILE = os.path.join('profiles', 'r05_dense_pmc_hbm_traffic.json')
+PMC_PROFILE = os.path.join('profiles', 'r06_pmc_hbm_traffic.json')
+DENSE_PMC_PROFILE = os.path.join('profiles', 'r06_dense_pmc_hbm_traffic.json')
 
 
 def make_tasks(n_tasks, n, d, seed0=1000):
@@ -103,6 +103,20 @@ def cpu_baseline(budget_s=12.0):
                       'batched over tasks x particles, best of torch threads %s with %d usable CPUs (cgroup quota; %s evals/s); '
                       'reference-style python loop over tasks at %d threads: %.1f evals/s'
                       % (T_s, PARTICLES, N_CTX, DIM, cands, cores, {k: round(v) for k, v in probe.items()}, best, looped)}
+
+
+def pmc_profile_state(path):
+    """{'profile': path, 'profile_source_hash': ..., 'current_source_hash': ..., 'stale': bool}: is the committed PMC profile the
+    `traffic` figures are read from still a profile of THESE kernel sources?  (a kernel change without
+    tools/profile_round.sh used to leave stale traffic in the line silently)"""
+    from meta_learning_pacoh_amd._build import source_hash
+    cur, rec = source_hash(), None
+    try:
+        with open(os.path.join(ROOT, path)) as fh:
+            rec = json.load(fh).get('source_hash')
+    except Exception:
+        pass
+    return {'profile': path, 'profile_source_hash': rec, 'current_source_hash': cur, 'stale': rec != cur}
 
 
 def pmc_traffic(substr):
@@ -434,6 +448,7 @@ def rooflines(wl, pp):
                 'ms_per_step': round(per_step_s * 1e3, 4), 'launches_per_step': launches / prof_steps,
                 'traffic': pmc_traffic(key) if key else None,
                 'traffic_source': 'committed PMC profile %s (not measured in this run)' % PMC_PROFILE,
+                'traffic_profile': pmc_profile_state(PMC_PROFILE),
                 'ms_per_step_events_raw': round(raw_ms[name] / prof_steps, 4), 'event_overhead_us': round(pp['event_overhead_ms'] * 1e3, 2),
                 'note': 'algorithmic flops per step and GPU (SURVEY 8d model; MLP backward = 4 n W, the part of the forward it still '
                         'recomputes -- the first layer, the rest comes from the activation stash -- is counted only in executed_frac) '
@@ -565,7 +580,8 @@ def cfg5_hbm_report(L):
         with open(os.path.join(ROOT, DENSE_PMC_PROFILE)) as fh:
             prof = json.load(fh)
         one_pass = B * n * n * 8
-        out['traffic'] = {'source': 'committed PMC profile %s (not measured in this run)' % DENSE_PMC_PROFILE, 'one_pass_over_the_matrices_bytes': one_pass,
+        out['traffic'] = {'source': 'committed PMC profile %s (not measured in this run)' % DENSE_PMC_PROFILE, 'profile_state': pmc_profile_state(DENSE_PMC_PROFILE),
+                          'one_pass_over_the_matrices_bytes': one_pass,
                           'kernels': {k: {'hbm_bytes_per_pass': v, 'ratio_to_one_pass': round(v / one_pass, 2)} for k, v in prof['per_pass'].items()
                                       if not k.startswith(('at::', '__amd'))}}
     except Exception:
@@ -633,6 +649,7 @@ def gram_leg(L):
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(alg_bytes / t_k / 1e9 / HBM_PEAK_GBS, 4),
             'traffic': pmc_traffic('gram_kernel<float, 2'),
             'traffic_source': 'committed PMC profile %s (not measured in this run)' % PMC_PROFILE,
+            'traffic_profile': pmc_profile_state(PMC_PROFILE),
             'algorithmic_bytes': alg_bytes, 'bytes_per_gram': N_CTX * 2 * 4 + N_CTX * N_CTX * 4, 'grams': B,
             'us_per_launch': round(t_k * 1e6, 2)}
 

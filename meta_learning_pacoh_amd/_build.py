@@ -31,6 +31,19 @@ def _hipcc():
     raise RuntimeError('hipcc not found: libpacoh_gp.so cannot be built')
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources (csrc/*.hip, *.h, include/pacoh_gp.h): the committed PMC traffic profiles
+    record the hash of the sources they were taken on, and bench.py marks a `traffic` figure stale when the sources have moved on"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h', '.inc')))
+    for path in files + [os.path.join(INCLUDE, 'pacoh_gp.h')]:
+        h.update(os.path.basename(path).encode())
+        with open(path, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _deps_mtime():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.inc'))]
     hdrs.append(os.path.join(INCLUDE, 'pacoh_gp.h'))

@@ -22,7 +22,7 @@ bool mlp_mfma_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_ou
 bool mlp_fused_applicable(int d_in, const int32_t* hidden, int n_hidden, int d_out);
 int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
                   int n_hidden, int nets, const long* off, const int* d_out, void* const* out, void* stash, int B, int n,
-                  hipStream_t s, const SvgdDistTail<float>* tail = nullptr);
+                  hipStream_t s, const SvgdDistTail<float>* tail = nullptr, bool* tail_taken = nullptr);
 size_t mlp_fused_stash_bytes(int B, int P, int n, int n_hidden, int nets);
 size_t mlp_fused_bwd_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int nets);
 int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
@@ -186,8 +186,8 @@ static int mlp2_fwd_impl(const void* x, int x_div, const void* theta, long theta
         const long off[2] = {off_a, off_b};
         const int dout[2] = {d_out_a, d_out_b};
         void* const outs[2] = {out_a, out_b};
-        if (tail_done) *tail_done = tail != nullptr;
-        return mlp_fused_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 2, off, dout, outs, stash, B, n, (hipStream_t)stream, tail);
+        return mlp_fused_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 2, off, dout, outs, stash, B, n, (hipStream_t)stream, tail,
+                             tail_done);
     }
     const size_t es = dtype == PACOH_F64 ? 8 : 4;
     rc = pacoh_mlp_fwd(x, x_div, (const char*)theta + off_a * es, theta_stride, P, d_in, hidden, n_hidden, d_out_a, out_a, workspace, B, n, dtype, stream);

@@ -654,7 +654,7 @@ constexpr int BWD_MINW_PB2 = 2;
 // nets = 1 or 2 networks of the SAME hidden shape at element offsets off[k] of the theta rows
 int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
                   int n_hidden, int nets, const long* off, const int* d_out, void* const* out, void* stash, int B, int n,
-                  hipStream_t s, const SvgdDistTail<float>* tail) {
+                  hipStream_t s, const SvgdDistTail<float>* tail, bool* tail_taken) {
     FusedArgs a = {};
     fused_fill(a, x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, B, n, stash, nets);
     for (int k = 0; k < nets; ++k) { a.net[k].theta_off = off[k]; a.net[k].out = (float*)out[k]; a.net[k].d_out = d_out[k]; }
@@ -673,6 +673,12 @@ int mlp_fused_fwd(const void* x, int x_div, const void* theta, long theta_stride
         }
     }
     const int wgs = (tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    // The tail slice of the grid has wgs x P workgroups for the P (P + 1) / 2 particle pairs (+ the snapshot rows).  A thin slice walks
+    // several pairs per workgroup one after the other, each a dependent chain of loads and a barrier: at the reference launcher's shape
+    // (10 particles of D = 6566, ONE tile workgroup per particle) the forward launch took 51 us, 40 of them the tail's.  Then the
+    // distances get a launch of their own (the caller's pacoh_svgd_dist_advance: P x P workgroups, ~5 us).
+    if (tail && (long)wgs * P * 2 < (long)tail->P * (tail->P + 1) / 2) tail = nullptr;
+    if (tail_taken) *tail_taken = tail != nullptr;
     if (tail) { a.tail_z = nets; a.sv = *tail; }
     const unsigned pad = g_sw.lds_pad_mlp > 0 ? (unsigned)g_sw.lds_pad_mlp : 0u;
 #define PACOH_LAUNCH_FWD(K) hipLaunchKernelGGL((K), dim3(wgs, P, nets + (tail ? 1 : 0)), dim3(256), pad, s, a)

@@ -39,8 +39,11 @@ def main(src, out, passes=0):
     note = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) of `bench.py --steps 3 --warmup 1 '
             '--no-cpu-baseline`, averaged per launch; raw counters are in KB. hbm_bytes applies the gfx950 correction of '
             'MI355X_MICROARCH.md (FETCH_SIZE reports half of a wide coalesced read stream): hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.')
+    # the kernel sources this profile was taken on (bench.py marks its `traffic` figures stale when they have changed since)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from meta_learning_pacoh_amd._build import source_hash
     with open(out, 'w') as fh:
-        json.dump({'note': note, 'kernels': kernels, 'per_pass': per_pass, 'passes': passes}, fh, indent=1)
+        json.dump({'note': note, 'source_hash': source_hash(), 'kernels': kernels, 'per_pass': per_pass, 'passes': passes}, fh, indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'])[:12]:
         print('%-60s %12d B/launch' % (k[:60], v['hbm_bytes_per_launch']))
 
