@@ -602,11 +602,13 @@ int pacoh_map_task_step(const void* theta, long theta_stride, const void* batch_
  * batch_n_valid [tb] | NULL: the step's gathered tasks; ls [P, f] / os [P] | NULL / noise [P]: the rows' transformed hyper-parameters;
  * the networks, kernel and limits as for pacoh_map_task_step (fp32, RBF, n <= 32, d <= 4, f <= 4, at least one network, hidden widths
  * <= 32, <= 4 hidden layers); svgd_workspace: pacoh_svgd_update_dev_workspace_bytes() bytes, as for pacoh_mlp2_fwd_svgd.
- * workspace: pacoh_svgd_task_workspace_bytes() bytes (0: outside the plan -> the caller takes the general sequence); it also holds
+ * workspace: pacoh_svgd_task_workspace_bytes() bytes; 0 = the caller takes the general sequence: the shape is outside the plan, or --
+ * any_size == 0 -- the tb x P workgroups would not all be resident at once (CUs x the occupancy of the kernel with its LDS plan), beyond
+ * which the throughput kernels win (profiles/r06_task_fused_crossover.txt); any_size != 0: wherever the plan allows.  It also holds
  * the map from the networks' padded LDS layout to the columns of a parameter row, written once by pacoh_svgd_task_setup (a function
  * of the layout only -- no call is needed when the rows change).  Results equal the general sequence's to rounding. */
 size_t pacoh_svgd_task_workspace_bytes(int D, int P, int n, int d, int tb, int mean_mode, const int32_t* mean_hidden, int n_mean_hidden,
-                                       int kernel_nn, const int32_t* kernel_hidden, int n_kernel_hidden, int f, int dtype);
+                                       int kernel_nn, const int32_t* kernel_hidden, int n_kernel_hidden, int f, int any_size, int dtype);
 int pacoh_svgd_task_setup(int D, int P, int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
                           int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
                           void* workspace, size_t workspace_bytes, int dtype, void* stream);

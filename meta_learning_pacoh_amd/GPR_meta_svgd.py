@@ -131,21 +131,20 @@ class _RandomGPLearner(RegressionModelMetaLearned):
     # Under-filled grids (round 6): the reference's own launchers run 2 tasks x 10 particles / samples of 20 points per step -- 20 GP
     # problems, for which networks forward -> GP -> networks backward -> slab reduction are four kernel latencies.  There the
     # likelihood half of a step is pacoh_svgd_task_step: one workgroup per (task, parameter row) does all three stages with the
-    # activations in LDS, then the slab reduction -- two launches.  Large grids stay on the throughput kernels.
-    TASK_FUSED_MAX_PROBLEMS = 1024
+    # activations in LDS, then the slab reduction -- two launches.  It wins while all its workgroups are resident at once (one round of
+    # ~20 us latency chains: up to 256-768 problems by network size, profiles/r06_task_fused_crossover.txt); the library's workspace
+    # query answers that question for the device at hand, larger grids stay on the throughput kernels.
 
     def _setup_task_fused(self, rows, tb_local):
         """-> workspace of L.svgd_task_step for `rows` parameter rows x tb_local tasks per step, or None (general launch sequence):
-        fp32, RBF GP kernel, shapes inside the task-fused kernel's plan, at most TASK_FUSED_MAX_PROBLEMS problems per step.
+        fp32, RBF GP kernel, a shape inside the task-fused kernel's plan whose workgroups are all resident at once.
         PACOH_SVGD_TASK_FUSED=0 / 1: never / wherever the plan allows (tests, A/B)"""
         self._task_plan = self._task_ws = None
         force = os.environ.get('PACOH_SVGD_TASK_FUSED')
         if force == '0' or tb_local < 1 or self.dtype != torch.float32 or L.FORCE_DENSE:
             return None
-        if force != '1' and rows * tb_local > self.TASK_FUSED_MAX_PROBLEMS:
-            return None
         plan = L.MapPersistPlan(self.layout, self.tasks, tb_local, 0.0, [(0, self.layout.D)], self.dtype)
-        ws = L.svgd_task_workspace(plan, rows, tb_local, self.device)
+        ws = L.svgd_task_workspace(plan, rows, tb_local, self.device, any_size=force == '1')
         if ws is not None:
             self._task_plan, self._task_ws = plan, ws
         return ws

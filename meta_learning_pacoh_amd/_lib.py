@@ -107,7 +107,7 @@ SIGNATURES = {
                                _i, _i, _i, _d, _ip, _ip, _i, _d, _d, _vp, _vp, _vp, _i, _vp]),
     'pacoh_map_task_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _ip, _i, _i, _ip, _i, _i, _i]),
     'pacoh_map_task_setup': (_i, [_vp, _i, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip, _i, _i, _vp, _sz, _i, _vp]),
-    'pacoh_svgd_task_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i, _ip, _i, _i, _ip, _i, _i, _i]),
+    'pacoh_svgd_task_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i, _ip, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_svgd_task_setup': (_i, [_i, _i, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip, _i, _i, _vp, _sz, _i, _vp]),
     'pacoh_svgd_task_step': (_i, [_vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip, _i, _i, _vp, _vp, _vp, _i, _i, _i,
                                   _vp, _l, _vp, _d, _vp, _vp, _sz, _vp, _vp, _i, _vp, _i, _i, _vp]),
@@ -706,13 +706,14 @@ def map_task_step(plan, theta, batch, hypers, grad, lik, lik_scale, fail_flag, w
                'pacoh_map_task_step')
 
 
-def svgd_task_workspace(plan, P, tb, device, workspace=None):
-    """workspace of svgd_task_step for P parameter rows and a batch of tb tasks, its gather map written (None: the task-fused kernel
-    does not take this shape -- the caller runs the general launch sequence)"""
+def svgd_task_workspace(plan, P, tb, device, workspace=None, any_size=False):
+    """workspace of svgd_task_step for P parameter rows and a batch of tb tasks, its gather map written (None: the caller runs the
+    general launch sequence -- the shape is outside the task-fused kernel's plan or, unless any_size, its workgroups would not all be
+    resident at once, beyond which the throughput kernels win)"""
     lib = load_library()
     code = F32 if plan.dtype == torch.float32 else F64
     need = lib.pacoh_svgd_task_workspace_bytes(plan.D, int(P), plan.n, plan.d, int(tb), plan.mean_mode, plan._mh, len(plan.mean_hidden),
-                                               plan.kernel_nn, plan._kh, len(plan.kernel_hidden), plan.f, code)
+                                               plan.kernel_nn, plan._kh, len(plan.kernel_hidden), plan.f, int(bool(any_size)), code)
     if need == 0 or not plan.rbf:
         return None
     if workspace is None or workspace.numel() < need:

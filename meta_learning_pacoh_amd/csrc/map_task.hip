@@ -381,7 +381,7 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
                     int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
                     const void* hyp_ls, const void* hyp_os, const void* hyp_noise, void* workspace, size_t workspace_bytes,
                     void* d_theta, long d_theta_stride, const HyperBwdArgs<float>* tail_in, int plan_only, size_t* need_bytes, int D, hipStream_t stream,
-                    int multi, int P, long theta_stride, const SvgdDistTail<float>* sv) {
+                    int multi, int P, long theta_stride, const SvgdDistTail<float>* sv, int one_round_only) {
     // multi: P parameter rows of stride theta_stride (PACOH-SVGD's particles / PACOH-VI's posterior samples), hyp_* = [P, f] / [P],
     // problem b = task * P + row; sv: the SVGD step's distance tail | nullptr
     if (!multi) P = 1;
@@ -419,6 +419,27 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
     const size_t o_lml = carve(B_ * 4), o_dls = carve(B_ * f * 4), o_dos = carve(B_ * 4), o_dnz = carve(B_ * 4), o_dc = carve(B_ * 4),
                  o_info = carve(B_ * 4);
     if (need_bytes) *need_bytes = off;
+    if (plan_only == 1 && one_round_only) {
+        // The task-fused launch wins while every workgroup is resident at once -- ONE round of workgroups, each a latency chain of ~20 us --
+        // and loses to the throughput kernels as soon as a second round starts (profiles/r06_task_fused_crossover.txt: 4 x 32 networks at
+        // n = 20, 139 KB of LDS = one workgroup per CU: 0.034 vs 0.069 ms at 160 problems, 0.061 vs 0.054 at 320).  Resident workgroups =
+        // CUs x what the occupancy calculator says for this instantiation and LDS plan; no device (build host): no verdict, the plan decides.
+        int dev = 0, cus = 0, per_cu = 0;
+        const size_t lds_bytes = (size_t)a.total * sizeof(float);
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+#define PACOH_MT_OCC(nb, fp, mu) do { \
+            static std::atomic<uint64_t> attr_done{0}; \
+            if (lds_opt_in((const void*)map_task_kernel<nb, fp, mu>, MP_LDS_BYTES, attr_done) != PACOH_OK) e = hipErrorUnknown; \
+            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_task_kernel<nb, fp, mu>, MT_NT, lds_bytes); } while (0)
+        if (e == hipSuccess) {
+            if (multi) { if (NB == 1 && FP == 2) PACOH_MT_OCC(1, 2, true); else if (NB == 1) PACOH_MT_OCC(1, 4, true); else if (FP == 2) PACOH_MT_OCC(2, 2, true); else PACOH_MT_OCC(2, 4, true); }
+            else { if (NB == 1 && FP == 2) PACOH_MT_OCC(1, 2, false); else if (NB == 1) PACOH_MT_OCC(1, 4, false); else if (FP == 2) PACOH_MT_OCC(2, 2, false); else PACOH_MT_OCC(2, 4, false); }
+        }
+#undef PACOH_MT_OCC
+        (void)hipGetLastError();
+        if (e == hipSuccess && cus > 0 && per_cu > 0 && (long)wgs > (long)cus * per_cu) return PACOH_ELIMIT;
+    }
     if (plan_only == 1) return PACOH_OK;
     if (!workspace || workspace_bytes < off) return PACOH_EINVAL;
     char* ws = (char*)workspace;

@@ -414,7 +414,7 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
                     int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
                     const void* hyp_ls, const void* hyp_os, const void* hyp_noise, void* workspace, size_t workspace_bytes,
                     void* d_theta, long d_theta_stride, const HyperBwdArgs<float>* tail_in, int plan_only, size_t* need_bytes, int D, hipStream_t stream,
-                    int multi = 0, int P = 1, long theta_stride = 0, const SvgdDistTail<float>* sv = nullptr);
+                    int multi = 0, int P = 1, long theta_stride = 0, const SvgdDistTail<float>* sv = nullptr, int one_round_only = 0);
 }
 extern "C" size_t pacoh_map_task_workspace_bytes(int D, int n, int d, int tb, int mean_mode, const int32_t* mean_hidden, int n_mean_hidden, int kernel_nn,
                                                  const int32_t* kernel_hidden, int n_kernel_hidden, int f, int dtype) {
@@ -464,13 +464,13 @@ extern "C" int pacoh_map_task_step(const void* theta, long theta_stride, const v
 // GP LML + gradient, both networks' backward of every (task, row) problem in ONE launch, then the slab reduction with the step's
 // hyper-parameter tail: two launches where the general path needs four (random_gp.py:204-222, svgd.py:12-28, GPR_meta_vi.py:216-224) --
 extern "C" size_t pacoh_svgd_task_workspace_bytes(int D, int P, int n, int d, int tb, int mean_mode, const int32_t* mean_hidden, int n_mean_hidden,
-                                                  int kernel_nn, const int32_t* kernel_hidden, int n_kernel_hidden, int f, int dtype) {
+                                                  int kernel_nn, const int32_t* kernel_hidden, int n_kernel_hidden, int f, int any_size, int dtype) {
     if (dtype != PACOH_F32 || tb <= 0 || D <= 0 || P <= 0 || kernel_of(f) != PACOH_KERNEL_RBF) return 0;
     size_t need = 0;
     HyperBwdArgs<float> none = {};
     const int rc = map_task_launch(nullptr, nullptr, nullptr, nullptr, n, d, tb, mean_mode, 0, mean_hidden, n_mean_hidden, kernel_nn, 0, kernel_hidden,
                                    n_kernel_hidden, features_of(f), nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, &none, 1, &need, D, nullptr, 1, P, D,
-                                   nullptr);
+                                   nullptr, any_size ? 0 : 1);
     return rc == PACOH_OK ? need : 0;
 }
 extern "C" int pacoh_svgd_task_setup(int D, int P, int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,

@@ -110,9 +110,9 @@ int main() {
         EXPECT(pacoh_map_task_step(fake, 2000, fake, fake, nullptr, 32, 1, 256, PACOH_MEAN_VECTOR, 0, hm, 2, 0, -1, nullptr, 0, f_cos, fake, nullptr, fake,
                                    1990, -1, 1991, fake, 2000, nullptr, 1.0, nullptr, fake, 1 << 20, nullptr, PACOH_F32, nullptr) == PACOH_ELIMIT);
         // the same kernel with P parameter rows (round 6)
-        EXPECT(pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 2, PACOH_MEAN_VECTOR, hm, 2, 1, hm, 2, 2, PACOH_F32) > 0);
-        EXPECT(pacoh_svgd_task_workspace_bytes(2534, 10, 33, 1, 2, PACOH_MEAN_VECTOR, hm, 2, 1, hm, 2, 2, PACOH_F32) == 0);
-        EXPECT(pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 2, PACOH_MEAN_VECTOR, hm, 2, 1, hm, 2, 2 | (PACOH_KERNEL_COSINE << PACOH_KERNEL_SHIFT), PACOH_F32) == 0);
+        EXPECT(pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 2, PACOH_MEAN_VECTOR, hm, 2, 1, hm, 2, 2, 0, PACOH_F32) > 0);     // (no device: the plan alone decides)
+        EXPECT(pacoh_svgd_task_workspace_bytes(2534, 10, 33, 1, 2, PACOH_MEAN_VECTOR, hm, 2, 1, hm, 2, 2, 0, PACOH_F32) == 0);
+        EXPECT(pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 2, PACOH_MEAN_VECTOR, hm, 2, 1, hm, 2, 2 | (PACOH_KERNEL_COSINE << PACOH_KERNEL_SHIFT), 1, PACOH_F32) == 0);
         EXPECT(pacoh_svgd_task_step(nullptr, 2534, 10, fake, fake, nullptr, 20, 1, 2, PACOH_MEAN_VECTOR, 0, hm, 2, 1, 1200, hm, 2, 2, fake, nullptr, fake,
                                     2530, -1, 2533, fake, 2534, fake, 1.0, nullptr, fake, 1 << 20, nullptr, nullptr, 0, nullptr, 0, PACOH_F32,
                                     nullptr) == PACOH_EINVAL);

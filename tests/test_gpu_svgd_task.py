@@ -236,12 +236,14 @@ def test_task_fused_step_limits_and_failure_flag(M, monkeypatch):
     from meta_learning_pacoh_amd import _lib as L
     h = L._hidden_arr([32, 32])
     lib = L.load_library()
-    assert lib.pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 2, L.MEAN_VECTOR, h, 2, 1, h, 2, 2, L.F32) > 0
-    assert lib.pacoh_svgd_task_workspace_bytes(2534, 10, 33, 1, 2, L.MEAN_VECTOR, h, 2, 1, h, 2, 2, L.F32) == 0        # n > 32
-    assert lib.pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 2, L.MEAN_ZERO, h, 0, 0, h, 0, 1, L.F32) == 0          # no network: nothing to fuse
-    assert lib.pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 2, L.MEAN_VECTOR, h, 2, 1, h, 2, 2, L.F64) == 0        # fp32 only
-    assert lib.pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 2, L.MEAN_VECTOR, h, 2, 1, h, 2, L._kf(2, L.KERNEL_COSINE), L.F32) == 0
-    # a grid the throughput kernels fill stays on them
+    assert lib.pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 2, L.MEAN_VECTOR, h, 2, 1, h, 2, 2, 0, L.F32) > 0
+    assert lib.pacoh_svgd_task_workspace_bytes(2534, 10, 33, 1, 2, L.MEAN_VECTOR, h, 2, 1, h, 2, 2, 0, L.F32) == 0        # n > 32
+    assert lib.pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 2, L.MEAN_ZERO, h, 0, 0, h, 0, 1, 0, L.F32) == 0          # no network: nothing to fuse
+    assert lib.pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 2, L.MEAN_VECTOR, h, 2, 1, h, 2, 2, 0, L.F64) == 0        # fp32 only
+    assert lib.pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 2, L.MEAN_VECTOR, h, 2, 1, h, 2, L._kf(2, L.KERNEL_COSINE), 0, L.F32) == 0
+    # more workgroups than are resident at once (a second round of ~20 us latency chains): the throughput kernels -- unless any_size
+    assert lib.pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 400, L.MEAN_VECTOR, h, 2, 1, h, 2, 2, 0, L.F32) == 0
+    assert lib.pacoh_svgd_task_workspace_bytes(2534, 10, 20, 1, 400, L.MEAN_VECTOR, h, 2, 1, h, 2, 2, 1, L.F32) > 0
     m = M.GPRegressionMetaLearnedSVGD(make_tasks(1, 300, 12, 1, False), num_particles=10, task_batch_size=200, random_seed=1)
     m.meta_fit(verbose=False, n_iter=2)
     assert m._task_ws is None

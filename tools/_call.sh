@@ -1,4 +1,3 @@
-export TMPDIR=/tmp
-bash tools/profile_round.sh r06 > gpurun_out/profile_round_r06.log 2>&1
-tail -40 gpurun_out/profile_round_r06.log
-timeout 1800 python -m pytest tests -m gpu -q > gpurun_out/r06/gputests.log 2>&1; grep -E "passed|failed" gpurun_out/r06/gputests.log | tail -2
+export TMPDIR=/tmp; mkdir -p gpurun_out/r06h
+(python tools/task_fused_crossover.py 20 10 4; python tools/task_fused_crossover.py 32 10 2; python tools/task_fused_crossover.py 8 10 2) 2>&1 | tee gpurun_out/r06h/crossover.txt
+timeout 900 python -m pytest tests/test_gpu_svgd_task.py tests/test_gpu_map_persist.py tests/test_gpu_multiproc.py -q 2>&1 | grep -E "passed|failed"
