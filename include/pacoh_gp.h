@@ -568,7 +568,8 @@ int pacoh_map_persist(void* theta, void* exp_avg, void* exp_avg_sq, int D, const
  * batch_x [tb, n, d] / batch_y [tb, n] / batch_n_valid [tb] | NULL: the iteration's gathered tasks (pacoh_step_begin / the previous
  * call's opt->next); ls [f] / os [1] | NULL / noise [1]: the transformed hyper-parameters of the ONE parameter row theta[1, D]; the
  * networks as for pacoh_map_persist (D = the length of the parameter row).  workspace: pacoh_map_task_workspace_bytes() bytes (0: shape outside the plan -> PACOH_ELIMIT
- * from the call).  Limits: fp32, n <= 32, d <= 4, f <= 4, at least one network, hidden widths <= 32, <= 4 hidden layers.  The step
+ * from the call -- or, any_size == 0, more workgroups than are resident at once: from the second round of workgroups on the four-launch
+ * sequence is faster, 2048 tasks x 32 points 0.088 vs 0.053 ms per iteration, profiles/r06_task_fused_crossover.txt).  Limits: fp32, n <= 32, d <= 4, f <= 4, at least one network, hidden widths <= 32, <= 4 hidden layers.  The step
  * counter of opt->next is advanced by launch (1).
  * pacoh_map_task_setup: the workspace also holds the networks' parameters in the padded layout launch (1) keeps them in (its prologue
  * copies them instead of decoding theta) -- written by this call from theta, kept current by launch (2)'s AdamW step.  Call it before the
@@ -577,7 +578,7 @@ int pacoh_map_task_setup(const void* theta, int D, int n, int d, int tb, int mea
                          int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
                          void* workspace, size_t workspace_bytes, int dtype, void* stream);
 size_t pacoh_map_task_workspace_bytes(int D, int n, int d, int tb, int mean_mode, const int32_t* mean_hidden, int n_mean_hidden, int kernel_nn,
-                                      const int32_t* kernel_hidden, int n_kernel_hidden, int f, int dtype);
+                                      const int32_t* kernel_hidden, int n_kernel_hidden, int f, int any_size, int dtype);
 int pacoh_map_task_step(const void* theta, long theta_stride, const void* batch_x, const void* batch_y, const int32_t* batch_n_valid,
                         int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
                         int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,

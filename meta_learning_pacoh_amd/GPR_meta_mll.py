@@ -158,7 +158,7 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         self._task_ws = None
         if self._pipelined and os.environ.get('PACOH_MAP_TASK_FUSED', '1') != '0' and not L.FORCE_DENSE:
             plan = L.MapPersistPlan(self.layout, self.tasks, tb_local, self.engine.noise_floor, self.train_segments, self.dtype)
-            self._task_ws = L.map_task_workspace(plan, tb_local, self.device)
+            self._task_ws = L.map_task_workspace(plan, tb_local, self.device, any_size=os.environ.get('PACOH_MAP_TASK_FUSED') == '1')
             self._task_plan = plan
 
     def _nets_fused(self, tb_local):

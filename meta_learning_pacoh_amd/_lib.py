@@ -105,7 +105,7 @@ SIGNATURES = {
     'pacoh_map_persist_supported': (_i, [_i, _i, _i, _i, _ip, _i, _i, _ip, _i, _i, _i]),
     'pacoh_map_persist': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _ip, _i, _i, _i, _ip, _i, _i,
                                _i, _i, _i, _d, _ip, _ip, _i, _d, _d, _vp, _vp, _vp, _i, _vp]),
-    'pacoh_map_task_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _ip, _i, _i, _ip, _i, _i, _i]),
+    'pacoh_map_task_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _ip, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_map_task_setup': (_i, [_vp, _i, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip, _i, _i, _vp, _sz, _i, _vp]),
     'pacoh_svgd_task_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i, _ip, _i, _i, _ip, _i, _i, _i, _i]),
     'pacoh_svgd_task_setup': (_i, [_i, _i, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip, _i, _i, _vp, _sz, _i, _vp]),
@@ -669,10 +669,12 @@ def map_persist(plan, theta, exp_avg, exp_avg_sq, tasks, idx_rows, sc_rows, K, l
                'pacoh_map_persist')
 
 
-def map_task_workspace(plan, tb, device, workspace=None):
-    """workspace of map_task_step for a batch of tb tasks (None: the task-fused kernel does not take this shape)"""
+def map_task_workspace(plan, tb, device, workspace=None, any_size=False):
+    """workspace of map_task_step for a batch of tb tasks (None: the task-fused kernel does not take this shape, or -- unless any_size --
+    its workgroups would not all be resident at once, where the four-launch iteration is faster)"""
     need = load_library().pacoh_map_task_workspace_bytes(plan.D, plan.n, plan.d, int(tb), plan.mean_mode, plan._mh, len(plan.mean_hidden), plan.kernel_nn,
-                                                        plan._kh, len(plan.kernel_hidden), plan.f, F32 if plan.dtype == torch.float32 else F64)
+                                                        plan._kh, len(plan.kernel_hidden), plan.f, int(bool(any_size)),
+                                                        F32 if plan.dtype == torch.float32 else F64)
     if need == 0 or not plan.rbf:
         return None
     if workspace is None or workspace.numel() < need:

@@ -417,12 +417,13 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
                     int multi = 0, int P = 1, long theta_stride = 0, const SvgdDistTail<float>* sv = nullptr, int one_round_only = 0);
 }
 extern "C" size_t pacoh_map_task_workspace_bytes(int D, int n, int d, int tb, int mean_mode, const int32_t* mean_hidden, int n_mean_hidden, int kernel_nn,
-                                                 const int32_t* kernel_hidden, int n_kernel_hidden, int f, int dtype) {
+                                                 const int32_t* kernel_hidden, int n_kernel_hidden, int f, int any_size, int dtype) {
     if (dtype != PACOH_F32 || tb <= 0 || D <= 0 || kernel_of(f) != PACOH_KERNEL_RBF) return 0;      // (the fused kernel is RBF-only)
     size_t need = 0;
     HyperBwdArgs<float> none = {};
     const int rc = map_task_launch(nullptr, nullptr, nullptr, nullptr, n, d, tb, mean_mode, 0, mean_hidden, n_mean_hidden, kernel_nn, 0, kernel_hidden,
-                                   n_kernel_hidden, features_of(f), nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, &none, 1, &need, D, nullptr);
+                                   n_kernel_hidden, features_of(f), nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, &none, 1, &need, D, nullptr,
+                                   0, 1, 0, nullptr, any_size ? 0 : 1);
     return rc == PACOH_OK ? need : 0;
 }
 extern "C" int pacoh_map_task_setup(const void* theta, int D, int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,

@@ -104,8 +104,8 @@ int main() {
         }
         // the task-fused kernels are RBF-only: another kernel family must not silently train with the RBF Gram
         const int f_cos = 1 | (PACOH_KERNEL_COSINE << PACOH_KERNEL_SHIFT);
-        EXPECT(pacoh_map_task_workspace_bytes(2000, 32, 1, 256, PACOH_MEAN_VECTOR, hm, 2, 0, nullptr, 0, 1, PACOH_F32) > 0);
-        EXPECT(pacoh_map_task_workspace_bytes(2000, 32, 1, 256, PACOH_MEAN_VECTOR, hm, 2, 0, nullptr, 0, f_cos, PACOH_F32) == 0);
+        EXPECT(pacoh_map_task_workspace_bytes(2000, 32, 1, 256, PACOH_MEAN_VECTOR, hm, 2, 0, nullptr, 0, 1, 0, PACOH_F32) > 0);
+        EXPECT(pacoh_map_task_workspace_bytes(2000, 32, 1, 256, PACOH_MEAN_VECTOR, hm, 2, 0, nullptr, 0, f_cos, 1, PACOH_F32) == 0);
         EXPECT(pacoh_map_task_setup(fake, 2000, 32, 1, 256, PACOH_MEAN_VECTOR, 0, hm, 2, 0, -1, nullptr, 0, f_cos, fake, 1 << 20, PACOH_F32, nullptr) == PACOH_ELIMIT);
         EXPECT(pacoh_map_task_step(fake, 2000, fake, fake, nullptr, 32, 1, 256, PACOH_MEAN_VECTOR, 0, hm, 2, 0, -1, nullptr, 0, f_cos, fake, nullptr, fake,
                                    1990, -1, 1991, fake, 2000, nullptr, 1.0, nullptr, fake, 1 << 20, nullptr, PACOH_F32, nullptr) == PACOH_ELIMIT);

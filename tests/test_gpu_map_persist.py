@@ -229,7 +229,10 @@ def test_task_fused_step_failure_flag_and_limits(M, monkeypatch):
     assert m._task_ws is not None
     h = L._hidden_arr([32, 32])
     lib = L.load_library()
-    assert lib.pacoh_map_task_workspace_bytes(2000, 32, 1, 256, L.MEAN_VECTOR, h, 2, 0, h, 0, 1, L.F32) > 0
-    assert lib.pacoh_map_task_workspace_bytes(2000, 33, 1, 256, L.MEAN_VECTOR, h, 2, 0, h, 0, 1, L.F32) == 0       # n > 32
-    assert lib.pacoh_map_task_workspace_bytes(2000, 32, 1, 256, L.MEAN_ZERO, h, 0, 0, h, 0, 1, L.F32) == 0         # no network: nothing to fuse
-    assert lib.pacoh_map_task_workspace_bytes(2000, 32, 1, 256, L.MEAN_VECTOR, h, 2, 0, h, 0, 1, L.F64) == 0
+    assert lib.pacoh_map_task_workspace_bytes(2000, 32, 1, 256, L.MEAN_VECTOR, h, 2, 0, h, 0, 1, 0, L.F32) > 0
+    assert lib.pacoh_map_task_workspace_bytes(2000, 33, 1, 256, L.MEAN_VECTOR, h, 2, 0, h, 0, 1, 0, L.F32) == 0       # n > 32
+    assert lib.pacoh_map_task_workspace_bytes(2000, 32, 1, 256, L.MEAN_ZERO, h, 0, 0, h, 0, 1, 0, L.F32) == 0         # no network: nothing to fuse
+    assert lib.pacoh_map_task_workspace_bytes(2000, 32, 1, 256, L.MEAN_VECTOR, h, 2, 0, h, 0, 1, 0, L.F64) == 0
+    # (round 6) more workgroups than are resident at once: the four-launch iteration, unless any_size
+    assert lib.pacoh_map_task_workspace_bytes(2000, 32, 1, 4096, L.MEAN_VECTOR, h, 2, 0, h, 0, 1, 0, L.F32) == 0
+    assert lib.pacoh_map_task_workspace_bytes(2000, 32, 1, 4096, L.MEAN_VECTOR, h, 2, 0, h, 0, 1, 1, L.F32) > 0
