@@ -173,7 +173,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)     # 0.12 s of GPU time at config 3
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
-    ap.add_argument('--config', type=lambda v: int(v) if v.isdigit() else v, choices=[1, 2, 3, 4, 5, 'ref_svgd', 'ref_vi', 'shard128'], default=3)
+    ap.add_argument('--config', type=lambda v: int(v) if v.isdigit() else v, choices=[1, 2, 3, 4, 5, 'ref_svgd', 'ref_vi', 'shard128', 'ref_map'], default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
     args = ap.parse_args()
@@ -834,6 +834,23 @@ def wl_ref_vi(world, scaling, M, L):
                 extra={'tasks_total': 20, 'samples': 10, 'n_ctx': 20, 'd': 1})
 
 
+def wl_ref_map(world, scaling, M, L):
+    """the reference's PACOH-MAP launcher at its defaults (experiments/meta_GPR_mll_base_exp.py:22-47, 79-99): seed 28,
+    SinusoidDataset(RandomState(29)) 20 tasks x 5 points, 2 tasks per iteration, 4 x 128 mean and kernel networks, AdamW 1e-3 with decay
+    0.98 and weight_decay 0 -- ten points through 128-wide layers per iteration: launch latency and nothing else"""
+    layers = (128, 128, 128, 128)
+    model = M.GPRegressionMetaLearned(sinusoid_tasks(29, 20, 5), learning_mode='both', covar_module='NN', mean_module='NN', mean_nn_layers=layers,
+                                      kernel_nn_layers=layers, weight_decay=0.0, lr_params=1e-3, lr_decay=0.98, task_batch_size=2, random_seed=28,
+                                      optimizer='Adam')
+    w = net_macs(1, layers, 1) + net_macs(1, layers, 2)
+    return dict(run=model._train_steps, evals_per_step=2, dtype='f32', finite=lambda: bool(torch.isfinite(model.theta).all()), mode=lambda: _mode(model),
+                metric='task-GP LML+grad evals/sec (PACOH-MAP at the reference launcher\'s defaults: 2 tasks x 5 points per iteration, 4 x 128 networks)',
+                flops={'gp_lml_fwdbwd': (gp_flops(5, 2) * 2,) * 2, 'mlp_fwd': (2 * 5 * w * 2,) * 2, 'mlp_bwd': (4 * 5 * w * 2, 6 * 5 * w * 2)},
+                describe='PACOH-MAP iteration at the defaults of experiments/meta_GPR_mll_base_exp.py: 20 sinusoid tasks x 5 points, batch_size=2, '
+                         'NN(128,128,128,128) mean + kernel (D=%d), AdamW' % model.layout.D,
+                extra={'tasks_total': 20, 'n_ctx': 5, 'd': 1})
+
+
 def wl_shard128(world, scaling, M, L):
     """one rank's share of BASELINE config #3 strong-scaled over 8 GPUs: 128 of the 1024 tasks x 20 particles (no exchange: N = 1)"""
     global TASKS
@@ -847,7 +864,7 @@ def wl_shard128(world, scaling, M, L):
 
 
 WORKLOADS = {1: wl_cfg1, 2: wl_cfg2, 3: wl_cfg3, 4: wl_cfg4, 5: wl_cfg5, 'ref_svgd': wl_ref_svgd, 'ref_vi': wl_ref_vi,
-             'shard128': wl_shard128}
+             'shard128': wl_shard128, 'ref_map': wl_ref_map}
 
 if __name__ == '__main__':
     main()

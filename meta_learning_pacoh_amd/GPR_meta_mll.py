@@ -150,16 +150,19 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         # (_adam_inline) AND the networks run on the fused kernels: the epilogue then also fetches the next iteration's operands and
         # publishes the updated hyper-parameters' transforms (include/pacoh_gp.h, pacoh_step_next) -- no step_begin launch.
         # PACOH_MAP_PIPELINE=0: keep it
-        self._pipelined = self._adam_inline() and self._nets_fused(tb_local) and os.environ.get('PACOH_MAP_PIPELINE', '1') != '0'
+        pipe = os.environ.get('PACOH_MAP_PIPELINE', '1') != '0'
+        inline = self._adam_inline() and pipe
+        # ... and TWO where the whole task batch's forward + GP + backward is one launch (include/pacoh_gp.h, pacoh_map_task_step: one
+        # workgroup per task, BASELINE config #2's regime; round 6: one workgroup for the whole batch with networks up to 128 wide, the
+        # reference's PACOH-MAP launcher) in front of the slab reduction.  PACOH_MAP_TASK_FUSED=0: the four launches
+        task_ws = plan = None
+        if self._adam_inline(task_fused=True) and pipe and tb_local > 0 and os.environ.get('PACOH_MAP_TASK_FUSED', '1') != '0' and not L.FORCE_DENSE:
+            plan = L.MapPersistPlan(self.layout, self.tasks, tb_local, self.engine.noise_floor, self.train_segments, self.dtype)
+            task_ws = L.map_task_workspace(plan, tb_local, self.device, any_size=os.environ.get('PACOH_MAP_TASK_FUSED') == '1')
+        self._pipelined = task_ws is not None or (inline and self._nets_fused(tb_local))
         if self._pipelined:
             self._feed.pipeline(self.tasks, self.engine, self.theta)
-        # ... and TWO where the whole task batch's forward + GP + backward is one launch (include/pacoh_gp.h, pacoh_map_task_step: one
-        # workgroup per task, BASELINE config #2's regime) in front of the slab reduction.  PACOH_MAP_TASK_FUSED=0: the four launches
-        self._task_ws = None
-        if self._pipelined and os.environ.get('PACOH_MAP_TASK_FUSED', '1') != '0' and not L.FORCE_DENSE:
-            plan = L.MapPersistPlan(self.layout, self.tasks, tb_local, self.engine.noise_floor, self.train_segments, self.dtype)
-            self._task_ws = L.map_task_workspace(plan, tb_local, self.device, any_size=os.environ.get('PACOH_MAP_TASK_FUSED') == '1')
-            self._task_plan = plan
+        self._task_ws, self._task_plan = (task_ws, plan) if self._pipelined else (None, None)
 
     def _nets_fused(self, tb_local):
         lay = self.layout
@@ -190,12 +193,14 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
     def _adam_advances(self):
         return self.optimizer_name == 'Adam' and len(self.train_segments) > 0
 
-    def _adam_inline(self):
+    def _adam_inline(self, task_fused=False):
         """the AdamW launch folded into the gradient epilogue (include/pacoh_gp.h, pacoh_adam_inline): no exchange between gradient
-        and update, i.e. world size 1, and a task batch on this rank; PACOH_MAP_ADAM_INLINE=0 keeps the separate launch (A/B, tests)"""
+        and update, i.e. world size 1, and a task batch on this rank; PACOH_MAP_ADAM_INLINE=0 keeps the separate launch (A/B, tests).
+        task_fused: behind pacoh_map_task_step, whose one slab reduction finishes every entry whatever the networks' shapes"""
         lay = self.layout
-        one_call = not (lay.mean_module == 'NN' and lay.covar_module == 'NN' and lay.mean_nn_layers != lay.kernel_nn_layers)
-        # (two networks of different shapes: two backward calls and a separate reduction -- no single launch finishes every entry)
+        one_call = task_fused or not (lay.mean_module == 'NN' and lay.covar_module == 'NN' and lay.mean_nn_layers != lay.kernel_nn_layers)
+        # (two networks of different shapes on the general path: two backward calls and a separate reduction -- no single launch
+        #  finishes every entry)
         return (self._adam_advances() and parallel.world()[1] == 1 and self._feed.tb > 0 and len(self.train_segments) <= 4 and one_call
                 and os.environ.get('PACOH_MAP_ADAM_INLINE', '1') != '0')
 
@@ -209,7 +214,7 @@ class GPRegressionMetaLearned(RegressionModelMetaLearned):
         return blk
 
     def _body_update(self):
-        if self._adam_inline():
+        if self._adam_inline(task_fused=getattr(self, '_task_ws', None) is not None):
             return                                        # (done inside _body_likelihood's last launch)
         if not self._adam_advances():
             L.axpy(self._g_cum.reshape(1), self._g_loss, 1.0)

@@ -15,7 +15,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 OBJ_DIR = os.path.join(HERE, 'build')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpacoh_gp.so')
-SOURCES = ['gp_small.hip', 'gp_mfma.hip', 'gp_reg.hip', 'map_persist.hip', 'map_task.hip', 'gram.hip', 'dense.hip', 'dense_mfma.hip', 'dense_ll.hip', 'dense_trtri_ll.hip', 'dense_grad_mfma.hip', 'dense_gp.hip', 'mlp.hip', 'mlp_mfma.hip', 'mlp_fused.hip', 'mlp_layers.hip', 'misc.hip', 'svgd_imq.hip', 'vi_full.hip', 'comm.hip', 'predictive.hip']
+SOURCES = ['gp_small.hip', 'gp_mfma.hip', 'gp_reg.hip', 'map_persist.hip', 'map_task.hip', 'map_wide.hip', 'gram.hip', 'dense.hip', 'dense_mfma.hip', 'dense_ll.hip', 'dense_trtri_ll.hip', 'dense_grad_mfma.hip', 'dense_gp.hip', 'mlp.hip', 'mlp_mfma.hip', 'mlp_fused.hip', 'mlp_layers.hip', 'misc.hip', 'svgd_imq.hip', 'vi_full.hip', 'comm.hip', 'predictive.hip']
 ARCH = 'gfx950'
 # per-source flags.  mlp_fused.hip: the compiler's automatic v_pk_fma_f32 / v_pk_add_f32 pairing costs the MFMA-paced backward
 # kernel 11-13 % (240 -> 213 us at cfg #3; packed fp32 issues at half rate and needs extra moves) -- the GP kernel is the

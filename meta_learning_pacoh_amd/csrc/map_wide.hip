@@ -1,0 +1,375 @@
+// PACOH-MAP iteration with WIDE networks at a tiny batch (round 6): forward of the networks, GP LML + gradient and the networks'
+// backward of ALL tasks of an iteration in ONE workgroup, for hidden widths up to 128 -- the reference's own PACOH-MAP launcher runs
+// 2 tasks x 5 points per iteration through two 4 x 128 networks (experiments/meta_GPR_mll_base_exp.py:29-47).  The general path takes
+// ~62 launches for that iteration (layer by layer: repack, GEMM, delta, weight gradient per layer and network: 0.21 ms, all of it
+// launch latency); the task-fused kernel of round 5 (map_task.hip) keeps a network as an LDS image, which two 128-wide networks
+// (400 KB) cannot be.  Here the weights stay where they are -- theta, L2-resident -- and stream through the matrix cores:
+//   * a hidden layer of one network is computed by NWN = 16 / nets waves, one 16-unit output tile per wave and round: the lane's row
+//     of the weight matrix as 16-byte loads along k, the activations of the <= 16 points of the batch from LDS as the B operand under
+//     the same quad permutation of k (map_net.h), bias + tanh in the epilogue, the result back to LDS for the next layer (one
+//     workgroup barrier per layer);
+//   * the GP is gp8_body / gp_reg_body of map_net.h, one wave per task;
+//   * backwards, layer by layer: the delta recursion as the transposed product (four strided loads per MFMA group), the weight
+//     gradient tiles as products over the points, written straight into ONE gradient slab per network in theta's own layout --
+//     which the slab reduction of map_task.hip / mlp_fused.hip (fused_reduce_launch) turns into the AdamW step, the hyper-parameter
+//     tail and the next iteration's batch: an iteration is two launches.
+// Limits: fp32, RBF, tb x n <= 16 points per iteration, d <= 4, f <= 4, 1 .. 4 hidden layers of equal or different widths that are
+// multiples of 16 and <= 128 (narrower networks take map_task.hip / map_persist.hip).
+// Reference lines replaced: GPR_meta_mll.py:104-117, models.py:206-217, 505-519.
+#include "map_net.h"
+
+namespace pacoh {
+
+int fused_reduce_launch(const float* slab0, int wd0, long off0, const float* slab1, int wd1, long off1, int nets, float* d_theta,
+                        long d_theta_stride, int slabs, const HyperBwdArgs<float>* tail, float* img_th, const int* img_map, hipStream_t s, int P = 1);
+
+namespace {
+
+constexpr int MW_NT = 1024;
+constexpr int MW_MAXL = 5;           // up to 4 hidden layers + the output layer
+constexpr int MW_MAXW = 128;
+constexpr int MW_PT = 16;            // points per iteration (one MFMA tile)
+
+struct MwLayer { int in, out, w_flat, b_flat; };
+struct MwNet {
+    int nl; MwLayer L[MW_MAXL];
+    int flat0, dnet; float* slab;
+    int o_act;                       // LDS: activations of the hidden layers [nl - 1][MW_PT][S]
+    int o_out, s_out;                // LDS: the network's outputs [pts][s_out] (mean: 1, features: f)
+    int o_gout;                      // LDS: upstream gradients [pts][s_out]
+    int o_del;                       // LDS: delta ping-pong [2][MW_PT][S]
+};
+struct MwArgs {
+    const float* theta; const float* bx; const float* by; const int32_t* bnv;
+    const float* hyp_ls; const float* hyp_os; const float* hyp_noise;
+    MwNet net[2]; int nets;
+    int n, d, f, tb, pts, mean_mode, kernel_nn, off_const, gp8, S;
+    float* lml_g; int32_t* info_g; float* dls_g; float* dos_g; float* dnz_g; float* dc_g;
+    long* adv_counter;
+    int o_hp, o_x, o_xs, o_y, o_nv, o_gl, o_gp, gpw, total;
+};
+
+typedef float __attribute__((ext_vector_type(4), aligned(4))) f4u;      // 16 bytes at 4-byte alignment (rows of theta)
+
+// out[p][u] = tanh(b[u] + sum_c W[u][c] x[p][c]) of the first layer (in = d <= 4): one (point, unit) per thread and round
+__device__ __forceinline__ void mw_first_layer(const MwArgs& a, const MwNet& N, float* lds, int tl, int nthr) {
+    const MwLayer& L = N.L[0];
+    const float* W = a.theta + L.w_flat; const float* b = a.theta + L.b_flat;
+    for (int e = tl; e < a.pts * L.out; e += nthr) {
+        const int p = e / L.out, u = e - p * L.out;
+        float v = b[u];
+        for (int c = 0; c < L.in; ++c) v = fmaf(W[u * L.in + c], lds[a.o_x + p * 4 + c], v);
+        lds[N.o_act + p * a.S + u] = act_tanh<float>(v);
+    }
+}
+
+// hidden layer l >= 1 (in, out multiples of 16): wave wl of the network's nw waves takes the output tiles U = wl, wl + nw, ...
+__device__ __forceinline__ void mw_hidden_layer(const MwArgs& a, const MwNet& N, int l, float* lds, int wl, int nw, int r, int g) {
+    const MwLayer& L = N.L[l];
+    const int S = a.S, nc = L.in >> 4;
+    const float* ain = lds + N.o_act + (l - 1) * MW_PT * S + r * S + 4 * g;
+    float* aout = lds + N.o_act + l * MW_PT * S + r * S + 4 * g;
+    for (int U = wl; U < (L.out >> 4); U += nw) {
+        const float* wrow = a.theta + L.w_flat + (long)(16 * U + r) * L.in + 4 * g;
+        f4u wq[MW_MAXW / 16];
+#pragma unroll
+        for (int c = 0; c < MW_MAXW / 16; ++c) wq[c] = c < nc ? *reinterpret_cast<const f4u*>(wrow + 16 * c) : f4u{0.f, 0.f, 0.f, 0.f};
+        const f4u bq = *reinterpret_cast<const f4u*>(a.theta + L.b_flat + 16 * U + 4 * g);
+        gpreg::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < MW_MAXW / 16; ++c) {
+            if (c < nc) {
+                const float4 av = *reinterpret_cast<const float4*>(ain + 16 * c);
+                acc = gpreg::mfma_(wq[c][0], av.x, acc); acc = gpreg::mfma_(wq[c][1], av.y, acc);
+                acc = gpreg::mfma_(wq[c][2], av.z, acc); acc = gpreg::mfma_(wq[c][3], av.w, acc);
+            }
+        }
+        // lane (r, g) holds units 16 U + 4 g + s of point r
+        float4 v;
+        v.x = act_tanh<float>(acc[0] + bq[0]); v.y = act_tanh<float>(acc[1] + bq[1]);
+        v.z = act_tanh<float>(acc[2] + bq[2]); v.w = act_tanh<float>(acc[3] + bq[3]);
+        if (r < a.pts) *reinterpret_cast<float4*>(aout + 16 * U) = v;
+    }
+}
+
+// the output layer (out <= 4): out[p][o] = b[o] + W[o][:] . h[p][:], 16 lanes per (p, o) entry
+__device__ __forceinline__ void mw_output_layer(const MwArgs& a, const MwNet& N, float* lds, int tl, int nthr) {
+    const MwLayer& L = N.L[N.nl - 1];
+    const int sub = tl & 15, S = a.S;
+    const float* h = lds + N.o_act + (N.nl - 2) * MW_PT * S;
+    for (int e = tl >> 4; e < a.pts * L.out; e += nthr >> 4) {
+        const int p = e / L.out, o = e - p * L.out;
+        float v = 0.0f;
+        for (int k4 = sub; k4 < (L.in >> 2); k4 += 16) {
+            const f4u w = *reinterpret_cast<const f4u*>(a.theta + L.w_flat + o * L.in + 4 * k4);
+            const float4 hv = *reinterpret_cast<const float4*>(h + p * S + 4 * k4);
+            v = fmaf(w[0], hv.x, v); v = fmaf(w[1], hv.y, v); v = fmaf(w[2], hv.z, v); v = fmaf(w[3], hv.w, v);
+        }
+        v = gpreg::row_sum_(v);
+        if (sub == 0) lds[N.o_out + p * N.s_out + o] = v + a.theta[L.b_flat + o];
+    }
+}
+
+__global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = t & 15, g = (t >> 4) & 3;
+    const int n = a.n, d = a.d, f = a.f, tb = a.tb, pts = a.pts, S = a.S;
+    float* hp = lds + a.o_hp;
+
+    // ---- prologue: everything requested first, LDS zeroed (padding points and columns must read 0), then landed -----------------------
+    const int epl = n * (d + 1);
+    const bool mover = t < tb * epl;
+    const int mv_s = mover ? t / epl : 0, mv_r = mover ? t - mv_s * epl : 0;
+    float mv_val = 0.0f, hp_val = 0.0f;
+    int nv_val = 0;
+    if (mover) mv_val = mv_r < n * d ? a.bx[(long)mv_s * (n * d) + mv_r] : a.by[(long)mv_s * n + (mv_r - n * d)];
+    if (t < tb && a.bnv) nv_val = a.bnv[t];
+    {
+        const float* hsrc = t < f ? a.hyp_ls + t
+                          : (t == 4 ? a.hyp_os : (t == 5 ? a.hyp_noise : ((t == 6 && a.off_const >= 0) ? a.theta + a.off_const : nullptr)));
+        if (t < 7 && hsrc) hp_val = *hsrc;
+    }
+    {
+        float4* l4 = reinterpret_cast<float4*>(lds);
+        for (int q = t; q < (a.total + 3) >> 2; q += MW_NT) l4[q] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (t < 7 && (t < f || t >= 4)) hp[t] = hp_val;
+    if (t < tb) lds[a.o_gl + t] = -1.0f;               // loss = -sum_t mll_t (GPR_meta_mll.py:109-113)
+    if (mover) {
+        if (mv_r < n * d) {
+            const int i = mv_r / d, c = mv_r - i * d;
+            lds[a.o_x + (mv_s * n + i) * 4 + c] = mv_val; lds[a.o_xs + (mv_s * n + i) * d + c] = mv_val;
+        } else lds[a.o_y + mv_s * n + (mv_r - n * d)] = mv_val;
+    }
+    if (t < tb && a.bnv) reinterpret_cast<int*>(lds + a.o_nv)[t] = nv_val;
+    if (t == 0 && a.adv_counter) *a.adv_counter += 1;
+    __syncthreads();
+
+    // the waves of a network: net k takes waves k * nw .. (k + 1) * nw - 1
+    const int nw = (MW_NT / 64) / a.nets;
+    const int k_net = wave / nw < a.nets ? wave / nw : a.nets - 1;
+    const int wl = wave - k_net * nw, tl = t - k_net * nw * 64, nthr = nw * 64;
+    const MwNet& N = a.net[k_net];
+    int max_nl = a.net[0].nl;
+    if (a.nets > 1 && a.net[1].nl > max_nl) max_nl = a.net[1].nl;
+
+    // ---- forward ---------------------------------------------------------------------------------------------------------------------
+    mw_first_layer(a, N, lds, tl, nthr);
+    __syncthreads();
+    for (int l = 1; l + 1 < max_nl; ++l) {
+        if (l + 1 < N.nl) mw_hidden_layer(a, N, l, lds, wl, nw, r, g);
+        __syncthreads();
+    }
+    mw_output_layer(a, N, lds, tl, nthr);
+    __syncthreads();
+
+    // ---- GP: one wave per task ----------------------------------------------------------------------------------------------------------
+    if (wave < tb) {
+        GpMfmaArgs gq;
+        const int mean_mode = sg(a.mean_mode), kernel_nn = sg(a.kernel_nn), has_os = a.hyp_os != nullptr;
+        const MwNet& Nm = a.net[0];
+        const MwNet& Nk = a.net[a.nets - 1];
+        gq.z = kernel_nn ? lds + Nk.o_out : lds + a.o_xs; gq.z_div = 1;
+        gq.mean = mean_mode == PACOH_MEAN_VECTOR ? lds + Nm.o_out : (mean_mode == PACOH_MEAN_CONST ? hp + 6 : nullptr);
+        gq.mean_mode = mean_mode;
+        gq.y = lds + a.o_y; gq.y_div = 1;
+        gq.ls = hp; gq.os = has_os ? hp + 4 : nullptr; gq.noise = hp + 5;
+        gq.n_valid = a.bnv ? reinterpret_cast<int*>(lds + a.o_nv) : nullptr;
+        gq.g_lml = lds + a.o_gl;
+        gq.lml = a.lml_g; gq.info = a.info_g;
+        gq.d_z = kernel_nn ? lds + Nk.o_gout : nullptr;
+        gq.d_mean = mean_mode == PACOH_MEAN_VECTOR ? lds + Nm.o_gout : (mean_mode == PACOH_MEAN_CONST ? a.dc_g : nullptr);
+        gq.d_ls = a.dls_g; gq.d_os = has_os ? a.dos_g : nullptr; gq.d_noise = a.dnz_g;
+        gq.B = tb; gq.P = 1; gq.n = sg(n); gq.f = sg(f);
+        if (sg(a.gp8)) {
+            if (f <= 2) gpreg::gp8_body<2>(gq, gpreg::WaveCtx{(unsigned)wave}); else gpreg::gp8_body<4>(gq, gpreg::WaveCtx{(unsigned)wave});
+        } else {
+            float* ws = lds + sg(a.o_gp) + wave * sg(a.gpw);
+            constexpr int NP = 16;
+            if (f <= 2) gpreg::gp_reg_body<1, 2, true, true>(gq, gpreg::WaveCtx{(unsigned)wave}, ws, ws + NP * 2, ws + NP * 2 + NP, ws + NP * 2 + 2 * NP,
+                                                             ws + NP * 2 + 2 * NP, ws + NP * 2 + 2 * NP + gpreg::GPR_SCR, ws + 2 * NP * 2 + 2 * NP + gpreg::GPR_SCR);
+            else gpreg::gp_reg_body<1, 4, true, true>(gq, gpreg::WaveCtx{(unsigned)wave}, ws, ws + NP * 4, ws + NP * 4 + NP, ws + NP * 4 + 2 * NP,
+                                                      ws + NP * 4 + 2 * NP, ws + NP * 4 + 2 * NP + gpreg::GPR_SCR, ws + 2 * NP * 4 + 2 * NP + gpreg::GPR_SCR);
+        }
+    }
+    __syncthreads();
+
+    // ---- backward.  Top: the output layer's gradients (slab) and the delta of the last hidden layer, on the vector units ----------------
+    float* slab = N.slab;
+    {
+        const MwLayer& L = N.L[N.nl - 1];
+        const float* h = lds + N.o_act + (N.nl - 2) * MW_PT * S;
+        const float* gout = lds + N.o_gout;
+        // d W_out[o][k] = sum_p g[p][o] h[p][k], d b_out[o] = sum_p g[p][o]
+        for (int e = tl; e < L.out * (L.in + 1); e += nthr) {
+            const int o = e / (L.in + 1), k = e - o * (L.in + 1);
+            float v = 0.0f;
+            for (int p = 0; p < pts; ++p) v = fmaf(gout[p * N.s_out + o], k < L.in ? h[p * S + k] : 1.0f, v);
+            slab[(k < L.in ? L.w_flat + o * L.in + k : L.b_flat + o) - N.flat0] = v;
+        }
+        // delta of the last hidden layer: (sum_o W_out[o][i] g[p][o]) (1 - h[p][i]^2) -> delta buffer 0
+        float* del = lds + N.o_del;
+        for (int e = tl; e < pts * L.in; e += nthr) {
+            const int p = e / L.in, i = e - p * L.in;
+            float v = 0.0f;
+            for (int o = 0; o < L.out; ++o) v = fmaf(a.theta[L.w_flat + o * L.in + i], gout[p * N.s_out + o], v);
+            const float hv = h[p * S + i];
+            del[p * S + i] = v * fmaf(-hv, hv, 1.0f);
+        }
+    }
+    __syncthreads();
+    // hidden layers l = nl - 2 .. 1: weight gradient tiles of layer l (its delta x the activations below) and the delta of layer l - 1
+    for (int step = 0; step + 2 < max_nl; ++step) {
+        const int l = N.nl - 2 - step;                   // this network's layer of the step (networks of different depth: the shallower one idles)
+        if (l >= 1) {
+            const MwLayer& L = N.L[l];
+            const float* del = lds + N.o_del + (step & 1) * MW_PT * S;           // delta of layer l [pts][out]
+            float* dnx = lds + N.o_del + ((step + 1) & 1) * MW_PT * S;           // delta of layer l - 1 [pts][in]
+            const float* ain = lds + N.o_act + (l - 1) * MW_PT * S;             // activations below [pts][in]
+            const int nJ = L.out >> 4, nI = L.in >> 4;
+            // weight tiles (J, I): D[j][i] = sum_p delta[p][16 J + j] a[p][16 I + i]; lane (r, g) holds rows 4 g + s, column r
+            for (int q = wl; q < nJ * nI; q += nw) {
+                const int J = q / nI, I = q - J * nI;
+                gpreg::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < MW_PT / 4; ++ks) {
+                    const int p = 4 * ks + g;
+                    acc = gpreg::mfma_(del[p * S + 16 * J + r], ain[p * S + 16 * I + r], acc);
+                }
+                float* dst = slab + (L.w_flat - N.flat0) + (long)(16 * J + 4 * g) * L.in + 16 * I + r;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dst[(long)s * L.in] = acc[s];
+            }
+            for (int j = tl; j < L.out; j += nthr) {       // bias gradient: sum over the points
+                float v = 0.0f;
+                for (int p = 0; p < pts; ++p) v += del[p * S + j];
+                slab[L.b_flat - N.flat0 + j] = v;
+            }
+            // delta of the layer below: D[i][p] = sum_j W[j][16 I + i] delta[p][j], times (1 - a^2); wave wl takes the tiles I = wl, wl + nw ..
+            for (int I = wl; I < nI; I += nw) {
+                gpreg::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float* wcol = a.theta + L.w_flat + 16 * I + r;
+                for (int c = 0; c < nJ; ++c) {
+                    const float4 dv = *reinterpret_cast<const float4*>(del + r * S + 16 * c + 4 * g);
+                    const float* wp = wcol + (long)(16 * c + 4 * g) * L.in;
+                    const float w0 = wp[0], w1 = wp[L.in], w2 = wp[2 * (long)L.in], w3 = wp[3 * (long)L.in];
+                    acc = gpreg::mfma_(w0, dv.x, acc); acc = gpreg::mfma_(w1, dv.y, acc);
+                    acc = gpreg::mfma_(w2, dv.z, acc); acc = gpreg::mfma_(w3, dv.w, acc);
+                }
+                const float4 hv = *reinterpret_cast<const float4*>(ain + r * S + 16 * I + 4 * g);
+                float4 o4;
+                o4.x = acc[0] * fmaf(-hv.x, hv.x, 1.0f); o4.y = acc[1] * fmaf(-hv.y, hv.y, 1.0f);
+                o4.z = acc[2] * fmaf(-hv.z, hv.z, 1.0f); o4.w = acc[3] * fmaf(-hv.w, hv.w, 1.0f);
+                if (r < pts) *reinterpret_cast<float4*>(dnx + r * S + 16 * I + 4 * g) = o4;
+            }
+        }
+        __syncthreads();
+    }
+    // the first layer: d W_0[j][c] = sum_p delta_0[p][j] x[p][c], d b_0[j] = sum_p delta_0[p][j]
+    {
+        const MwLayer& L = N.L[0];
+        const float* del = lds + N.o_del + ((N.nl - 2) & 1) * MW_PT * S;
+        for (int e = tl; e < L.out * (L.in + 1); e += nthr) {
+            const int j = e / (L.in + 1), c = e - j * (L.in + 1);
+            float v = 0.0f;
+            for (int p = 0; p < pts; ++p) v = fmaf(del[p * S + j], c < L.in ? lds[a.o_x + p * 4 + c] : 1.0f, v);
+            slab[(c < L.in ? L.w_flat + j * L.in + c : L.b_flat + j) - N.flat0] = v;
+        }
+    }
+}
+
+// -> PACOH_OK and the filled arguments, or PACOH_ELIMIT when the shape is outside this kernel's plan
+int mw_plan(MwArgs& a, int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden, int kernel_nn,
+            int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f) {
+    memset(&a, 0, sizeof(a));
+    if (n < 1 || d < 1 || d > 4 || f < 1 || f > 4 || tb < 1 || tb > MW_NT / 64 || tb * n > MW_PT || tb * n * (d + 1) > MW_NT) return PACOH_ELIMIT;
+    if (!kernel_nn && f != d) return PACOH_EINVAL;
+    a.n = n; a.d = d; a.f = f; a.tb = tb; a.pts = tb * n; a.mean_mode = mean_mode; a.kernel_nn = kernel_nn;
+    a.gp8 = (n <= 8 && g_sw.gp8) ? 1 : 0;
+    int maxw = 16;
+    auto net = [&](int k, int off, const int32_t* hidden, int nh, int d_out) -> int {
+        if (nh < 1 || nh > MW_MAXL - 1) return PACOH_ELIMIT;
+        MwNet& N = a.net[k];
+        N.nl = nh + 1;
+        int prev = d, q = off;
+        for (int l = 0; l <= nh; ++l) {
+            const int out = l < nh ? hidden[l] : d_out;
+            if (l < nh && (out < 16 || out > MW_MAXW || (out & 15))) return PACOH_ELIMIT;
+            N.L[l].in = prev; N.L[l].out = out; N.L[l].b_flat = q; N.L[l].w_flat = q + out; q += out * (prev + 1);
+            if (l < nh && out > maxw) maxw = out;
+            prev = out;
+        }
+        N.flat0 = off; N.dnet = q - off;
+        return PACOH_OK;
+    };
+    a.nets = 0;
+    if (mean_mode == PACOH_MEAN_VECTOR) { const int rc = net(a.nets, off_mean, mean_hidden, n_mean_hidden, 1); if (rc) return rc; a.net[a.nets].s_out = 1; a.nets++; }
+    if (kernel_nn) { const int rc = net(a.nets, off_kernel, kernel_hidden, n_kernel_hidden, f); if (rc) return rc; a.net[a.nets].s_out = f; a.nets++; }
+    if (a.nets < 1) return PACOH_ELIMIT;
+    bool wide = false;                                   // (networks of <= 32 units per layer belong to map_task.hip / map_persist.hip)
+    for (int k = 0; k < a.nets; ++k) for (int l = 0; l + 1 < a.net[k].nl; ++l) wide = wide || a.net[k].L[l].out > 32;
+    if (!wide) return PACOH_ELIMIT;
+    a.S = maxw + 4;                                      // row stride of the activation / delta images: 16-byte rows, 4 (odd) quads off a bank period
+    int top = 0;
+    auto take = [&](int count) { const int o = top; top += (count + 3) & ~3; return o; };
+    a.o_hp = take(8);
+    a.o_x = take(MW_PT * 4); a.o_xs = take(MW_PT * d); a.o_y = take(MW_PT); a.o_nv = take(16); a.o_gl = take(16);
+    for (int k = 0; k < a.nets; ++k) {
+        MwNet& N = a.net[k];
+        N.o_act = take((N.nl - 1) * MW_PT * a.S);
+        N.o_out = take(MW_PT * N.s_out); N.o_gout = take(MW_PT * N.s_out);
+        N.o_del = take(2 * MW_PT * a.S);
+    }
+    const int FPp = f <= 2 ? 2 : 4;
+    a.gpw = (2 * 16 * FPp + 2 * 16 + gpreg::GPR_SCR + 4 + 3) & ~3;
+    a.o_gp = take(a.gp8 ? 4 : a.gpw * tb);
+    a.total = top;
+    if ((size_t)top * sizeof(float) > (size_t)MP_LDS_BYTES) return PACOH_ELIMIT;
+    return PACOH_OK;
+}
+
+}  // namespace
+
+// the launch pair of map_task_launch for wide networks: plan_only 1 -> *need_bytes only; 2 -> nothing to set up (no parameter image)
+int map_wide_launch(const void* theta, const void* bx, const void* by, const int32_t* bnv, int n, int d, int tb_total,
+                    int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
+                    int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
+                    const void* hyp_ls, const void* hyp_os, const void* hyp_noise, void* workspace, size_t workspace_bytes,
+                    void* d_theta, long d_theta_stride, const HyperBwdArgs<float>* tail_in, int plan_only, size_t* need_bytes, int D, hipStream_t stream) {
+    MwArgs a;
+    const int rc = mw_plan(a, n, d, tb_total, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel, kernel_hidden, n_kernel_hidden, f);
+    if (rc != PACOH_OK) return rc;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    size_t o_slab[2] = {0, 0};
+    for (int k = 0; k < a.nets; ++k) o_slab[k] = carve((size_t)a.net[k].dnet * sizeof(float));
+    const size_t B_ = (size_t)tb_total;
+    const size_t o_lml = carve(B_ * 4), o_dls = carve(B_ * f * 4), o_dos = carve(B_ * 4), o_dnz = carve(B_ * 4), o_dc = carve(B_ * 4), o_info = carve(B_ * 4);
+    if (need_bytes) *need_bytes = off;
+    if (plan_only == 1 || plan_only == 2) return PACOH_OK;
+    for (int k = 0; k < a.nets; ++k) if (a.net[k].flat0 + a.net[k].dnet > D) return PACOH_EINVAL;
+    if (!workspace || workspace_bytes < off) return PACOH_EINVAL;
+    char* ws = (char*)workspace;
+    a.theta = (const float*)theta;
+    a.off_const = mean_mode == PACOH_MEAN_CONST ? off_mean : -1;
+    a.bx = (const float*)bx; a.by = (const float*)by; a.bnv = bnv;
+    a.hyp_ls = (const float*)hyp_ls; a.hyp_os = (const float*)hyp_os; a.hyp_noise = (const float*)hyp_noise;
+    for (int k = 0; k < a.nets; ++k) a.net[k].slab = (float*)(ws + o_slab[k]);
+    a.lml_g = (float*)(ws + o_lml); a.dls_g = (float*)(ws + o_dls); a.dos_g = (float*)(ws + o_dos); a.dnz_g = (float*)(ws + o_dnz);
+    a.dc_g = (float*)(ws + o_dc); a.info_g = (int32_t*)(ws + o_info);
+    HyperBwdArgs<float> tail = *tail_in;
+    tail.d_ls = a.dls_g; tail.d_os = hyp_os ? a.dos_g : nullptr; tail.d_noise = a.dnz_g; tail.d_const = mean_mode == PACOH_MEAN_CONST ? a.dc_g : nullptr;
+    tail.lml = tail.lik ? a.lml_g : nullptr; tail.info = tail.fail_flag ? a.info_g : nullptr;
+    a.adv_counter = const_cast<long*>(tail.nx.counter);
+    static std::atomic<uint64_t> attr_done{0};
+    { const int rc_a = lds_opt_in((const void*)map_wide_kernel, MP_LDS_BYTES, attr_done); if (rc_a != PACOH_OK) return rc_a; }
+    hipLaunchKernelGGL(map_wide_kernel, dim3(1), dim3(MW_NT), (size_t)a.total * sizeof(float), stream, a);
+    if (launch_status() != PACOH_OK) return PACOH_ELAUNCH;
+    return fused_reduce_launch(a.net[0].slab, a.net[0].dnet, a.net[0].flat0, a.nets > 1 ? a.net[1].slab : nullptr, a.nets > 1 ? a.net[1].dnet : 0,
+                               a.nets > 1 ? a.net[1].flat0 : 0, a.nets, (float*)d_theta, d_theta_stride, 1, &tail, nullptr, nullptr, stream, 1);
+}
+
+}  // namespace pacoh

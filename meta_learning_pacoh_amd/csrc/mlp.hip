@@ -415,6 +415,12 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
                     const void* hyp_ls, const void* hyp_os, const void* hyp_noise, void* workspace, size_t workspace_bytes,
                     void* d_theta, long d_theta_stride, const HyperBwdArgs<float>* tail_in, int plan_only, size_t* need_bytes, int D, hipStream_t stream,
                     int multi = 0, int P = 1, long theta_stride = 0, const SvgdDistTail<float>* sv = nullptr, int one_round_only = 0);
+// map_wide.hip: the same launch pair for hidden widths up to 128 at <= 16 points per iteration (weights streamed from theta)
+int map_wide_launch(const void* theta, const void* bx, const void* by, const int32_t* bnv, int n, int d, int tb_total,
+                    int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
+                    int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
+                    const void* hyp_ls, const void* hyp_os, const void* hyp_noise, void* workspace, size_t workspace_bytes,
+                    void* d_theta, long d_theta_stride, const HyperBwdArgs<float>* tail_in, int plan_only, size_t* need_bytes, int D, hipStream_t stream);
 }
 extern "C" size_t pacoh_map_task_workspace_bytes(int D, int n, int d, int tb, int mean_mode, const int32_t* mean_hidden, int n_mean_hidden, int kernel_nn,
                                                  const int32_t* kernel_hidden, int n_kernel_hidden, int f, int any_size, int dtype) {
@@ -424,7 +430,11 @@ extern "C" size_t pacoh_map_task_workspace_bytes(int D, int n, int d, int tb, in
     const int rc = map_task_launch(nullptr, nullptr, nullptr, nullptr, n, d, tb, mean_mode, 0, mean_hidden, n_mean_hidden, kernel_nn, 0, kernel_hidden,
                                    n_kernel_hidden, features_of(f), nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, &none, 1, &need, D, nullptr,
                                    0, 1, 0, nullptr, any_size ? 0 : 1);
-    return rc == PACOH_OK ? need : 0;
+    if (rc == PACOH_OK) return need;
+    // networks wider than the LDS image takes: the weights-from-theta kernel (map_wide.hip), <= 16 points per iteration
+    const int rcw = map_wide_launch(nullptr, nullptr, nullptr, nullptr, n, d, tb, mean_mode, 0, mean_hidden, n_mean_hidden, kernel_nn, 0, kernel_hidden,
+                                    n_kernel_hidden, features_of(f), nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, &none, 1, &need, D, nullptr);
+    return rcw == PACOH_OK ? need : 0;
 }
 extern "C" int pacoh_map_task_setup(const void* theta, int D, int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
                                     int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
@@ -434,9 +444,13 @@ extern "C" int pacoh_map_task_setup(const void* theta, int D, int n, int d, int 
     if (kernel_of(f) != PACOH_KERNEL_RBF) return PACOH_ELIMIT;       // (the fused kernel implements the RBF Gram and gradient only)
     if (!theta || !workspace || tb <= 0 || D <= 0) return PACOH_EINVAL;
     HyperBwdArgs<float> none = {};
-    return map_task_launch(theta, nullptr, nullptr, nullptr, n, d, tb, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel,
+    const int rc = map_task_launch(theta, nullptr, nullptr, nullptr, n, d, tb, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel,
+                                   kernel_hidden, n_kernel_hidden, features_of(f), nullptr, nullptr, nullptr, workspace, workspace_bytes, nullptr, 0, &none, 2,
+                                   nullptr, D, (hipStream_t)stream);
+    if (rc != PACOH_ELIMIT) return rc;
+    return map_wide_launch(theta, nullptr, nullptr, nullptr, n, d, tb, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel,
                            kernel_hidden, n_kernel_hidden, features_of(f), nullptr, nullptr, nullptr, workspace, workspace_bytes, nullptr, 0, &none, 2,
-                           nullptr, D, (hipStream_t)stream);
+                           nullptr, D, (hipStream_t)stream);      // (no parameter image to build: the wide kernel reads theta itself)
 }
 extern "C" int pacoh_map_task_step(const void* theta, long theta_stride, const void* batch_x, const void* batch_y, const int32_t* batch_n_valid,
                                    int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
@@ -456,7 +470,11 @@ extern "C" int pacoh_map_task_step(const void* theta, long theta_stride, const v
                                 nullptr, (float*)lik, (float)lik_scale, nullptr, fail_flag, 0, nullptr, 0, nullptr,
                                 opt ? adam_inline_f32(opt) : AdamInline<float>{},
                                 (opt && opt->next) ? step_next_f32(opt->next, off_ls, f, off_os, off_noise) : StepNextArgs<float>{}};
-    return map_task_launch(theta, batch_x, batch_y, batch_n_valid, n, d, tb, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel,
+    const int rc = map_task_launch(theta, batch_x, batch_y, batch_n_valid, n, d, tb, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel,
+                                   kernel_hidden, n_kernel_hidden, features_of(f), ls, os, noise, workspace, workspace_bytes, d_theta, d_theta_stride, &tail, 0,
+                                   nullptr, (int)theta_stride, (hipStream_t)stream);
+    if (rc != PACOH_ELIMIT) return rc;
+    return map_wide_launch(theta, batch_x, batch_y, batch_n_valid, n, d, tb, mean_mode, off_mean, mean_hidden, n_mean_hidden, kernel_nn, off_kernel,
                            kernel_hidden, n_kernel_hidden, features_of(f), ls, os, noise, workspace, workspace_bytes, d_theta, d_theta_stride, &tail, 0,
                            nullptr, (int)theta_stride, (hipStream_t)stream);
 }

@@ -236,3 +236,85 @@ def test_task_fused_step_failure_flag_and_limits(M, monkeypatch):
     # (round 6) more workgroups than are resident at once: the four-launch iteration, unless any_size
     assert lib.pacoh_map_task_workspace_bytes(2000, 32, 1, 4096, L.MEAN_VECTOR, h, 2, 0, h, 0, 1, 0, L.F32) == 0
     assert lib.pacoh_map_task_workspace_bytes(2000, 32, 1, 4096, L.MEAN_VECTOR, h, 2, 0, h, 0, 1, 1, L.F32) > 0
+
+
+# ---- wide networks at a tiny batch (round 6, csrc/map_wide.hip): the reference's PACOH-MAP launcher runs 2 tasks x 5 points per iteration
+#      through two 4 x 128 networks (experiments/meta_GPR_mll_base_exp.py:29-47) ------------------------------------------------------------
+WIDE_CFGS = [
+    dict(mean_nn_layers=(128,) * 4, kernel_nn_layers=(128,) * 4),                   # the launcher's networks
+    dict(mean_nn_layers=(64, 64), kernel_nn_layers=(128, 64, 32)),                  # different depths and widths per network
+    dict(covar_module='SE', mean_module='NN', mean_nn_layers=(128, 128)),           # one network, kernel on the raw inputs
+    dict(covar_module='NN', mean_module='constant', kernel_nn_layers=(48, 80)),     # constant mean; widths that are multiples of 16 only
+    dict(learning_mode='learn_kernel', mean_module='constant', kernel_nn_layers=(64,)),   # one hidden layer; the frozen mean column untouched
+]
+
+
+@pytest.mark.parametrize('cfg', WIDE_CFGS)
+@pytest.mark.parametrize('shape', [(20, 5, 1, 2), (8, 8, 2, 2), (6, 16, 1, 1), (7, 3, 4, 5), (9, 10, 3, 1)])
+@pytest.mark.parametrize('graph', ['0', '1'])
+def test_wide_network_iteration_equals_the_general_sequence(M, cfg, shape, graph, monkeypatch):
+    """T tasks of n points (ragged), tb per iteration with tb x n <= 16: forward, GP and backward of the whole batch in ONE workgroup that
+    streams the weights from theta (map_wide_kernel) + the slab reduction, against the layer-by-layer general sequence (~60 launches)
+    on the same draws: parameters, both Adam moments, losses after 12 iterations, eagerly and as replayed graphs"""
+    T, n, d, tb = shape
+    if cfg.get('covar_module') == 'SE' and d > 4:
+        pytest.skip('f = d <= 4')
+    rs = np.random.RandomState(5 * T + n)
+    tasks = []
+    for t in range(T):
+        m = n - (t % 3) if n > 4 else n
+        x = rs.uniform(-3, 3, size=(m, d))
+        tasks.append((x, np.sin(x[:, :1]) + 0.3 * x[:, -1:] + 0.05 * rs.randn(m, 1)))
+    kw = dict(task_batch_size=tb, lr_params=2e-3, weight_decay=0.02, lr_decay=0.9, random_seed=3)
+    kw.update(cfg)
+    monkeypatch.setenv('PACOH_MAP_PERSIST', '0')
+    monkeypatch.setenv('PACOH_GRAPH', graph)
+    out = []
+    for fused in ('0', '1'):
+        monkeypatch.setenv('PACOH_MAP_TASK_FUSED', fused)
+        m = M.GPRegressionMetaLearned(tasks, **kw)
+        loss = m.meta_fit(verbose=False, n_iter=12, log_period=5)
+        assert (m._task_ws is not None) == (fused == '1') and m.opt_step == 12
+        out.append((m, float(loss)))
+    (m0, l0), (m1, l1) = out
+    keep = keep_mask(m1)
+    assert bool(torch.isfinite(m1.theta).all())
+    assert rel(m1.theta[keep], m0.theta[keep]) < 2e-5 and rel(m1.exp_avg[keep], m0.exp_avg[keep]) < 2e-4
+    assert rel(m1.exp_avg_sq[keep], m0.exp_avg_sq[keep]) < 2e-4
+    assert abs(l1 - l0) < 1e-5 * max(1.0, abs(l0))
+    if cfg.get('learning_mode') == 'learn_kernel':       # frozen column ranges: bit for bit the initial values on both paths
+        lo, hi = m1.layout.slices['constant_mean']
+        assert torch.equal(m1.theta[:, lo:hi], m0.theta[:, lo:hi])
+
+
+def test_wide_network_iteration_against_the_oracle_at_the_launcher_shape(M, monkeypatch):
+    """experiments/meta_GPR_mll_base_exp.py's defaults (20 sinusoid tasks x 5 points, 2 per iteration, 4 x 128 networks): the first 25
+    iterations of the oracle's PACOH-MAP on the same task draws (oracle/pacoh_oracle.py: MapOracle, pinned to the recorded demo run)"""
+    import bench
+    monkeypatch.setenv('PACOH_MAP_PERSIST', '0')
+    tasks = bench.sinusoid_tasks(29, 20, 5)
+    layers = (128,) * 4
+    kw = dict(mean_nn_layers=layers, kernel_nn_layers=layers, task_batch_size=2, weight_decay=0.0, lr_decay=0.98, random_seed=28, lr_params=1e-3)
+    m = M.GPRegressionMetaLearned(tasks, **kw)
+    m.meta_fit(verbose=False, n_iter=25, log_period=100)
+    assert m._task_ws is not None
+    orc = O.MapOracle(tasks, num_iter_fit=25, **kw)
+    orc.meta_fit(None, log_period=100, n_iter=25)
+    lay = m.layout
+    for name, ref in (('kernel_nn.fc_2.weight', orc.kernel_net[1].weight), ('kernel_nn.fc_4.weight', orc.kernel_net[3].weight),
+                      ('mean_nn.fc_1.bias', orc.mean_net[0].bias), ('mean_nn.fc_3.weight', orc.mean_net[2].weight),
+                      ('mean_nn.out.weight', orc.mean_net[4].weight)):
+        lo, hi = lay.slices[name]
+        assert rel(m.theta[0, lo:hi], ref.detach().reshape(-1)) < 1e-3, name
+
+
+def test_wide_network_limits(M):
+    from meta_learning_pacoh_amd import _lib as L
+    lib = L.load_library()
+    h128, h32, h40 = L._hidden_arr([128] * 4), L._hidden_arr([32, 32]), L._hidden_arr([40, 40])
+    D = 200000
+    assert lib.pacoh_map_task_workspace_bytes(D, 5, 1, 2, L.MEAN_VECTOR, h128, 4, 1, h128, 4, 2, 0, L.F32) > 0
+    assert lib.pacoh_map_task_workspace_bytes(D, 5, 1, 4, L.MEAN_VECTOR, h128, 4, 1, h128, 4, 2, 0, L.F32) == 0        # 20 points > one tile
+    assert lib.pacoh_map_task_workspace_bytes(D, 5, 1, 2, L.MEAN_VECTOR, h40, 2, 1, h40, 2, 2, 0, L.F32) == 0          # width no multiple of 16
+    assert lib.pacoh_map_task_workspace_bytes(D, 5, 1, 2, L.MEAN_VECTOR, h32, 2, 1, h32, 2, 2, 0, L.F32) > 0           # narrow: the LDS-image kernel
+    assert lib.pacoh_map_task_workspace_bytes(D, 5, 1, 2, L.MEAN_VECTOR, h128, 4, 1, h128, 4, 2, 0, L.F64) == 0
