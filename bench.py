@@ -322,7 +322,7 @@ def main():
         del wl
         torch.cuda.empty_cache()
         others = {}
-        for c in (1, 2, 4, 5, 'ref_svgd', 'ref_vi', 'shard128'):
+        for c in (1, 2, 4, 5, 'ref_svgd', 'ref_vi', 'ref_map', 'shard128'):
             key = 'cfg%d' % c if isinstance(c, int) else c
             try:
                 others[key] = other_config_leg(c, M, L)
@@ -503,6 +503,14 @@ def cpu_baseline_other(cfg, budget_s=2.5):
             vb, vl = rate(batched, 256), rate(looped, 256)
             sample = '256 sinusoid tasks x n=32 (SinusoidDataset(RandomState(27))), SE kernel + NN(32,32) mean, fp32 loss + autograd: batched over tasks %.0f evals/s, reference-style python loop %.0f evals/s' % (vb, vl)
             value = vb
+        elif cfg == 'ref_map':
+            # the reference's PACOH-MAP launcher defaults restated: 2 tasks x 5 points per iteration through two 4 x 128 networks, AdamW
+            layers = (128, 128, 128, 128)
+            orc = O.MapOracle(sinusoid_tasks(29, 20, 5), mean_nn_layers=layers, kernel_nn_layers=layers, task_batch_size=2, weight_decay=0.0,
+                              lr_decay=0.98, lr_params=1e-3, random_seed=28, num_iter_fit=10)
+            value = rate(lambda: orc.meta_fit(None, log_period=1000, n_iter=10), 2 * 10)
+            sample = ('10 PACOH-MAP iterations at the launcher shape per sample (2 tasks x 5 points, NN(128,128,128,128) mean + kernel, fp32): '
+                      'loss + autograd + AdamW with the oracle')
         elif cfg in ('ref_svgd', 'ref_vi'):
             # one step's [P, D] score at the launcher shape: 2 tasks x 10 particles / samples, n = 20, 4 x 32 networks
             tasks = sinusoid_tasks(29, 20, 20)[:2]
@@ -617,7 +625,7 @@ def other_config_leg(cfg, M, L, steps=256):
     torch.cuda.empty_cache()
     if cfg == 5:
         out['hbm'] = cfg5_hbm_report(L)
-    if cfg in (2, 4, 5, 'ref_svgd', 'ref_vi'):
+    if cfg in (2, 4, 5, 'ref_svgd', 'ref_vi', 'ref_map'):
         try:
             out['cpu_baseline'] = cpu_baseline_other(cfg)
         except Exception as exc:
@@ -845,7 +853,8 @@ def wl_ref_map(world, scaling, M, L):
     w = net_macs(1, layers, 1) + net_macs(1, layers, 2)
     return dict(run=model._train_steps, evals_per_step=2, dtype='f32', finite=lambda: bool(torch.isfinite(model.theta).all()), mode=lambda: _mode(model),
                 metric='task-GP LML+grad evals/sec (PACOH-MAP at the reference launcher\'s defaults: 2 tasks x 5 points per iteration, 4 x 128 networks)',
-                flops={'gp_lml_fwdbwd': (gp_flops(5, 2) * 2,) * 2, 'mlp_fwd': (2 * 5 * w * 2,) * 2, 'mlp_bwd': (4 * 5 * w * 2, 6 * 5 * w * 2)},
+                flops={'gp_lml_fwdbwd': (gp_flops(5, 2) * 2,) * 2, 'mlp_fwd': (2 * 5 * w * 2,) * 2, 'mlp_bwd': (4 * 5 * w * 2, 6 * 5 * w * 2),
+                       'map_task_step': ((gp_flops(5, 2) + 6 * 5 * w) * 2,) * 2},      # (forward + GP + backward in one workgroup: map_wide_kernel)
                 describe='PACOH-MAP iteration at the defaults of experiments/meta_GPR_mll_base_exp.py: 20 sinusoid tasks x 5 points, batch_size=2, '
                          'NN(128,128,128,128) mean + kernel (D=%d), AdamW' % model.layout.D,
                 extra={'tasks_total': 20, 'n_ctx': 5, 'd': 1})

@@ -13,6 +13,12 @@
 //     gradient tiles as products over the points, written straight into ONE gradient slab per network in theta's own layout --
 //     which the slab reduction of map_task.hip / mlp_fused.hip (fused_reduce_launch) turns into the AdamW step, the hyper-parameter
 //     tail and the next iteration's batch: an iteration is two launches.
+// What bounds it (in-kernel stamps, tools/svgd_task_stamps.py ref_map; 4 x 128 networks, 10 points): ONE compute unit's matrix cores.  A
+// 128 x 128 layer of both networks is 512 v_mfma_f32_16x16x4_f32 (the point tile is 16 wide whatever the batch), 128 per SIMD at 32 cycles:
+// 4 100 cycles per layer forward, per delta product and per weight-gradient layer -- 6 000-7 000 measured with the barrier and the
+// epilogues, 10 000-12 000 where the layer's weights are also still in flight (they are requested a layer ahead; warming the XCD's L2
+// from helper workgroups changed nothing: tried, measured, removed).  112 000 cycles = 46 us per iteration against ~62 launches = 210 us
+// on the general path.  Next step if it matters: one workgroup per network with a two-workgroup barrier around the GP.
 // Limits: fp32, RBF, tb x n <= 16 points per iteration, d <= 4, f <= 4, 1 .. 4 hidden layers of equal or different widths that are
 // multiples of 16 and <= 128 (narrower networks take map_task.hip / map_persist.hip).
 // Reference lines replaced: GPR_meta_mll.py:104-117, models.py:206-217, 505-519.
@@ -63,33 +69,39 @@ __device__ __forceinline__ void mw_first_layer(const MwArgs& a, const MwNet& N, 
     }
 }
 
-// hidden layer l >= 1 (in, out multiples of 16): wave wl of the network's nw waves takes the output tiles U = wl, wl + nw, ...
-__device__ __forceinline__ void mw_hidden_layer(const MwArgs& a, const MwNet& N, int l, float* lds, int wl, int nw, int r, int g) {
+// hidden layer l >= 1 (in, out multiples of 16, <= 128: at most eight 16-unit output tiles, one per wave of the network's nw >= 8 waves).
+// The lane's row of the weight matrix is REQUESTED a layer ahead (mw_load_w: the weights were written by the previous iteration's
+// AdamW on other XCDs -- an L2 miss of ~2 000 cycles per layer if it were waited for where it is used) and applied behind the barrier.
+struct MwW { f4u wq[MW_MAXW / 16]; f4u bq; };
+__device__ __forceinline__ void mw_load_w(const MwArgs& a, const MwNet& N, int l, int wl, int r, int g, MwW& w) {
     const MwLayer& L = N.L[l];
+    const int nc = L.in >> 4;
+    const bool mine = l >= 1 && l + 1 < N.nl && wl < (L.out >> 4);
+    const float* wrow = a.theta + L.w_flat + (long)(16 * wl + r) * L.in + 4 * g;
+#pragma unroll
+    for (int c = 0; c < MW_MAXW / 16; ++c) w.wq[c] = (mine && c < nc) ? *reinterpret_cast<const f4u*>(wrow + 16 * c) : f4u{0.f, 0.f, 0.f, 0.f};
+    w.bq = mine ? *reinterpret_cast<const f4u*>(a.theta + L.b_flat + 16 * wl + 4 * g) : f4u{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void mw_hidden_layer(const MwArgs& a, const MwNet& N, int l, float* lds, int wl, int r, int g, const MwW& w) {
+    const MwLayer& L = N.L[l];
+    if (wl >= (L.out >> 4)) return;
     const int S = a.S, nc = L.in >> 4;
     const float* ain = lds + N.o_act + (l - 1) * MW_PT * S + r * S + 4 * g;
     float* aout = lds + N.o_act + l * MW_PT * S + r * S + 4 * g;
-    for (int U = wl; U < (L.out >> 4); U += nw) {
-        const float* wrow = a.theta + L.w_flat + (long)(16 * U + r) * L.in + 4 * g;
-        f4u wq[MW_MAXW / 16];
+    gpreg::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < MW_MAXW / 16; ++c) wq[c] = c < nc ? *reinterpret_cast<const f4u*>(wrow + 16 * c) : f4u{0.f, 0.f, 0.f, 0.f};
-        const f4u bq = *reinterpret_cast<const f4u*>(a.theta + L.b_flat + 16 * U + 4 * g);
-        gpreg::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < MW_MAXW / 16; ++c) {
-            if (c < nc) {
-                const float4 av = *reinterpret_cast<const float4*>(ain + 16 * c);
-                acc = gpreg::mfma_(wq[c][0], av.x, acc); acc = gpreg::mfma_(wq[c][1], av.y, acc);
-                acc = gpreg::mfma_(wq[c][2], av.z, acc); acc = gpreg::mfma_(wq[c][3], av.w, acc);
-            }
+    for (int c = 0; c < MW_MAXW / 16; ++c) {
+        if (c < nc) {
+            const float4 av = *reinterpret_cast<const float4*>(ain + 16 * c);
+            acc = gpreg::mfma_(w.wq[c][0], av.x, acc); acc = gpreg::mfma_(w.wq[c][1], av.y, acc);
+            acc = gpreg::mfma_(w.wq[c][2], av.z, acc); acc = gpreg::mfma_(w.wq[c][3], av.w, acc);
         }
-        // lane (r, g) holds units 16 U + 4 g + s of point r
-        float4 v;
-        v.x = act_tanh<float>(acc[0] + bq[0]); v.y = act_tanh<float>(acc[1] + bq[1]);
-        v.z = act_tanh<float>(acc[2] + bq[2]); v.w = act_tanh<float>(acc[3] + bq[3]);
-        if (r < a.pts) *reinterpret_cast<float4*>(aout + 16 * U) = v;
     }
+    // lane (r, g) holds units 16 wl + 4 g + s of point r
+    float4 v;
+    v.x = act_tanh<float>(acc[0] + w.bq[0]); v.y = act_tanh<float>(acc[1] + w.bq[1]);
+    v.z = act_tanh<float>(acc[2] + w.bq[2]); v.w = act_tanh<float>(acc[3] + w.bq[3]);
+    if (r < a.pts) *reinterpret_cast<float4*>(aout + 16 * wl) = v;
 }
 
 // the output layer (out <= 4): out[p][o] = b[o] + W[o][:] . h[p][:], 16 lanes per (p, o) entry
@@ -117,6 +129,11 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
     const int r = t & 15, g = (t >> 4) & 3;
     const int n = a.n, d = a.d, f = a.f, tb = a.tb, pts = a.pts, S = a.S;
     float* hp = lds + a.o_hp;
+#ifdef PACOH_MP_STAMPS
+    if (t == 0) { mp_st_on = 1; mp_st_n[0] = mp_st_n[1] = 0; }
+    __syncthreads();
+    MP_STAMP();
+#endif
 
     // ---- prologue: everything requested first, LDS zeroed (padding points and columns must read 0), then landed -----------------------
     const int epl = n * (d + 1);
@@ -147,6 +164,7 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
     if (t < tb && a.bnv) reinterpret_cast<int*>(lds + a.o_nv)[t] = nv_val;
     if (t == 0 && a.adv_counter) *a.adv_counter += 1;
     __syncthreads();
+    MP_STAMP();
 
     // the waves of a network: net k takes waves k * nw .. (k + 1) * nw - 1
     const int nw = (MW_NT / 64) / a.nets;
@@ -157,14 +175,24 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
     if (a.nets > 1 && a.net[1].nl > max_nl) max_nl = a.net[1].nl;
 
     // ---- forward ---------------------------------------------------------------------------------------------------------------------
+    MwW wcur;
+    mw_load_w(a, N, 1, wl, r, g, wcur);                  // (layer 1's weights under the first layer's work)
+    asm volatile("" ::: "memory");                       // (the loads are issued HERE; the compiler would sink them to their use)
     mw_first_layer(a, N, lds, tl, nthr);
     __syncthreads();
+    MP_STAMP();
     for (int l = 1; l + 1 < max_nl; ++l) {
-        if (l + 1 < N.nl) mw_hidden_layer(a, N, l, lds, wl, nw, r, g);
+        MwW wnext;
+        mw_load_w(a, N, l + 1 < MW_MAXL ? l + 1 : l, wl, r, g, wnext);
+        asm volatile("" ::: "memory");
+        if (l + 1 < N.nl) mw_hidden_layer(a, N, l, lds, wl, r, g, wcur);
+        wcur = wnext;
         __syncthreads();
+        MP_STAMP();
     }
     mw_output_layer(a, N, lds, tl, nthr);
     __syncthreads();
+    MP_STAMP();
 
     // ---- GP: one wave per task ----------------------------------------------------------------------------------------------------------
     if (wave < tb) {
@@ -196,6 +224,7 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
         }
     }
     __syncthreads();
+    MP_STAMP();
 
     // ---- backward.  Top: the output layer's gradients (slab) and the delta of the last hidden layer, on the vector units ----------------
     float* slab = N.slab;
@@ -221,6 +250,7 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
         }
     }
     __syncthreads();
+    MP_STAMP();
     // hidden layers l = nl - 2 .. 1: weight gradient tiles of layer l (its delta x the activations below) and the delta of layer l - 1
     for (int step = 0; step + 2 < max_nl; ++step) {
         const int l = N.nl - 2 - step;                   // this network's layer of the step (networks of different depth: the shallower one idles)
@@ -230,43 +260,63 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
             float* dnx = lds + N.o_del + ((step + 1) & 1) * MW_PT * S;           // delta of layer l - 1 [pts][in]
             const float* ain = lds + N.o_act + (l - 1) * MW_PT * S;             // activations below [pts][in]
             const int nJ = L.out >> 4, nI = L.in >> 4;
-            // weight tiles (J, I): D[j][i] = sum_p delta[p][16 J + j] a[p][16 I + i]; lane (r, g) holds rows 4 g + s, column r
-            for (int q = wl; q < nJ * nI; q += nw) {
-                const int J = q / nI, I = q - J * nI;
-                gpreg::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // the transposed weights of the delta product (wave wl: input tile I = wl) are requested FIRST: W[16 c + 4 g + s][16 wl + r],
+            // four strided loads per group of 16 outputs, under the weight-gradient tiles' LDS work
+            float wt[MW_MAXW / 16][4];
+            const bool dmine = wl < nI;
+            {
+                const float* wcol = a.theta + L.w_flat + 16 * wl + r + (long)(4 * g) * L.in;
 #pragma unroll
-                for (int ks = 0; ks < MW_PT / 4; ++ks) {
-                    const int p = 4 * ks + g;
-                    acc = gpreg::mfma_(del[p * S + 16 * J + r], ain[p * S + 16 * I + r], acc);
-                }
-                float* dst = slab + (L.w_flat - N.flat0) + (long)(16 * J + 4 * g) * L.in + 16 * I + r;
+                for (int c = 0; c < MW_MAXW / 16; ++c)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) dst[(long)s * L.in] = acc[s];
+                    for (int s = 0; s < 4; ++s) wt[c][s] = (dmine && c < nJ) ? wcol[(long)(16 * c + s) * L.in] : 0.0f;
+                asm volatile("" ::: "memory");           // (issued here, used behind the weight tiles)
             }
+            // weight tiles: wave wl takes row block J = wl (its delta operand is read once), every column block I;
+            // D[j][i] = sum_p delta[p][16 J + j] a[p][16 I + i]; lane (r, g) holds rows 4 g + s, column r
+            if (wl < nJ) {
+                const int nks = (pts + 3) >> 2;          // MFMA steps the points fill (the rows behind them are zero: nothing to add)
+                float dj[MW_PT / 4];
+#pragma unroll
+                for (int ks = 0; ks < MW_PT / 4; ++ks) dj[ks] = ks < nks ? del[(4 * ks + g) * S + 16 * wl + r] : 0.0f;
+                float* dst0 = slab + (L.w_flat - N.flat0) + (long)(16 * wl + 4 * g) * L.in + r;
+#pragma unroll 2
+                for (int I = 0; I < nI; ++I) {
+                    gpreg::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < MW_PT / 4; ++ks) if (ks < nks) acc = gpreg::mfma_(dj[ks], ain[(4 * ks + g) * S + 16 * I + r], acc);
+                    float* dst = dst0 + 16 * I;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) dst[(long)s * L.in] = acc[s];
+                }
+            }
+            MP_STAMP();
             for (int j = tl; j < L.out; j += nthr) {       // bias gradient: sum over the points
                 float v = 0.0f;
                 for (int p = 0; p < pts; ++p) v += del[p * S + j];
                 slab[L.b_flat - N.flat0 + j] = v;
             }
-            // delta of the layer below: D[i][p] = sum_j W[j][16 I + i] delta[p][j], times (1 - a^2); wave wl takes the tiles I = wl, wl + nw ..
-            for (int I = wl; I < nI; I += nw) {
+            MP_STAMP();
+            // delta of the layer below: D[i][p] = sum_j W[j][16 I + i] delta[p][j], times (1 - a^2)
+            if (dmine) {
                 gpreg::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                const float* wcol = a.theta + L.w_flat + 16 * I + r;
-                for (int c = 0; c < nJ; ++c) {
-                    const float4 dv = *reinterpret_cast<const float4*>(del + r * S + 16 * c + 4 * g);
-                    const float* wp = wcol + (long)(16 * c + 4 * g) * L.in;
-                    const float w0 = wp[0], w1 = wp[L.in], w2 = wp[2 * (long)L.in], w3 = wp[3 * (long)L.in];
-                    acc = gpreg::mfma_(w0, dv.x, acc); acc = gpreg::mfma_(w1, dv.y, acc);
-                    acc = gpreg::mfma_(w2, dv.z, acc); acc = gpreg::mfma_(w3, dv.w, acc);
+#pragma unroll
+                for (int c = 0; c < MW_MAXW / 16; ++c) {
+                    if (c < nJ) {
+                        const float4 dv = *reinterpret_cast<const float4*>(del + r * S + 16 * c + 4 * g);
+                        acc = gpreg::mfma_(wt[c][0], dv.x, acc); acc = gpreg::mfma_(wt[c][1], dv.y, acc);
+                        acc = gpreg::mfma_(wt[c][2], dv.z, acc); acc = gpreg::mfma_(wt[c][3], dv.w, acc);
+                    }
                 }
-                const float4 hv = *reinterpret_cast<const float4*>(ain + r * S + 16 * I + 4 * g);
+                const float4 hv = *reinterpret_cast<const float4*>(ain + r * S + 16 * wl + 4 * g);
                 float4 o4;
                 o4.x = acc[0] * fmaf(-hv.x, hv.x, 1.0f); o4.y = acc[1] * fmaf(-hv.y, hv.y, 1.0f);
                 o4.z = acc[2] * fmaf(-hv.z, hv.z, 1.0f); o4.w = acc[3] * fmaf(-hv.w, hv.w, 1.0f);
-                if (r < pts) *reinterpret_cast<float4*>(dnx + r * S + 16 * I + 4 * g) = o4;
+                if (r < pts) *reinterpret_cast<float4*>(dnx + r * S + 16 * wl + 4 * g) = o4;
             }
         }
         __syncthreads();
+        MP_STAMP();
     }
     // the first layer: d W_0[j][c] = sum_p delta_0[p][j] x[p][c], d b_0[j] = sum_p delta_0[p][j]
     {
@@ -279,6 +329,12 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
             slab[(c < L.in ? L.w_flat + j * L.in + c : L.b_flat + j) - N.flat0] = v;
         }
     }
+#ifdef PACOH_MP_STAMPS
+    MP_STAMP();
+    __syncthreads();
+    if (t == 0 && a.adv_counter && *a.adv_counter == 3)
+        for (int q = 1; q < mp_st_n[0]; ++q) printf("mw stamp %d: +%lld cycles\n", q, mp_st[0][q] - mp_st[0][q - 1]);
+#endif
 }
 
 // -> PACOH_OK and the filled arguments, or PACOH_ELIMIT when the shape is outside this kernel's plan

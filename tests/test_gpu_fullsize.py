@@ -191,13 +191,13 @@ def test_bench_line_contract():
     # the other BASELINE configurations ride along, bounded, so that the driver sees them too
     oc = d['other_configs']
     # (round 6: the reference launchers' own SVGD / VI shape -- 2 tasks x 10 particles / samples per step -- and cfg #3's 1/8 shard)
-    evals_of = {'cfg1': 5, 'cfg2': 256, 'cfg4': 5120, 'cfg5': 256, 'ref_svgd': 20, 'ref_vi': 20, 'shard128': 2560}
+    evals_of = {'cfg1': 5, 'cfg2': 256, 'cfg4': 5120, 'cfg5': 256, 'ref_svgd': 20, 'ref_vi': 20, 'ref_map': 2, 'shard128': 2560}
     assert set(oc) == set(evals_of)
     for key, leg in oc.items():
         assert leg['finite'] is True and leg['value'] > 0 and leg['ms_per_step'] > 0, key
         assert abs(leg['value'] - evals_of[key] / (leg['ms_per_step'] * 1e-3)) <= 2e-3 * leg['value'], key
         assert 0 < leg['dominant_kernel']['algorithmic_frac'] < 1, key
-    assert oc['ref_svgd']['cpu_baseline']['value'] > 0 and oc['ref_vi']['cpu_baseline']['value'] > 0
+    assert oc['ref_svgd']['cpu_baseline']['value'] > 0 and oc['ref_vi']['cpu_baseline']['value'] > 0 and oc['ref_map']['cpu_baseline']['value'] > 0
     assert oc['cfg5']['dtype'] == 'f64' and oc['cfg1']['dtype'] == oc['cfg2']['dtype'] == oc['cfg4']['dtype'] == 'f32'
     # ... and the marginal posterior predictive at the context sizes of cfg #3 / cfg #4 (row A11)
     pr = d['predictive']
