@@ -1,24 +1,30 @@
 // PACOH-MAP iteration with WIDE networks at a tiny batch (round 6): forward of the networks, GP LML + gradient and the networks'
-// backward of ALL tasks of an iteration in ONE workgroup, for hidden widths up to 128 -- the reference's own PACOH-MAP launcher runs
-// 2 tasks x 5 points per iteration through two 4 x 128 networks (experiments/meta_GPR_mll_base_exp.py:29-47).  The general path takes
-// ~62 launches for that iteration (layer by layer: repack, GEMM, delta, weight gradient per layer and network: 0.21 ms, all of it
-// launch latency); the task-fused kernel of round 5 (map_task.hip) keeps a network as an LDS image, which two 128-wide networks
-// (400 KB) cannot be.  Here the weights stay where they are -- theta, L2-resident -- and stream through the matrix cores:
-//   * a hidden layer of one network is computed by NWN = 16 / nets waves, one 16-unit output tile per wave and round: the lane's row
-//     of the weight matrix as 16-byte loads along k, the activations of the <= 16 points of the batch from LDS as the B operand under
-//     the same quad permutation of k (map_net.h), bias + tanh in the epilogue, the result back to LDS for the next layer (one
-//     workgroup barrier per layer);
-//   * the GP is gp8_body / gp_reg_body of map_net.h, one wave per task;
-//   * backwards, layer by layer: the delta recursion as the transposed product (four strided loads per MFMA group), the weight
-//     gradient tiles as products over the points, written straight into ONE gradient slab per network in theta's own layout --
-//     which the slab reduction of map_task.hip / mlp_fused.hip (fused_reduce_launch) turns into the AdamW step, the hyper-parameter
-//     tail and the next iteration's batch: an iteration is two launches.
-// What bounds it (in-kernel stamps, tools/svgd_task_stamps.py ref_map; 4 x 128 networks, 10 points): ONE compute unit's matrix cores.  A
-// 128 x 128 layer of both networks is 512 v_mfma_f32_16x16x4_f32 (the point tile is 16 wide whatever the batch), 128 per SIMD at 32 cycles:
-// 4 100 cycles per layer forward, per delta product and per weight-gradient layer -- 6 000-7 000 measured with the barrier and the
-// epilogues, 10 000-12 000 where the layer's weights are also still in flight (they are requested a layer ahead; warming the XCD's L2
-// from helper workgroups changed nothing: tried, measured, removed).  112 000 cycles = 46 us per iteration against ~62 launches = 210 us
-// on the general path.  Next step if it matters: one workgroup per network with a two-workgroup barrier around the GP.
+// backward of ALL tasks of an iteration in ONE launch of one workgroup per network, for hidden widths up to 128 -- the reference's own
+// PACOH-MAP launcher runs 2 tasks x 5 points per iteration through two 4 x 128 networks (experiments/meta_GPR_mll_base_exp.py:29-47).  The
+// general path takes ~62 launches for that iteration (layer by layer: repack, GEMM, delta, weight gradient per layer and network:
+// 0.21 ms, all of it launch latency); the task-fused kernel of round 5 (map_task.hip) keeps a network as an LDS image, which two
+// 128-wide networks (400 KB) cannot be.  Here the weights stay where they are -- theta -- and stream through the matrix cores:
+//   * a hidden layer is at most eight 16-unit output tiles, one per wave: the lane's row of the weight matrix as 16-byte loads along k
+//     (requested a layer AHEAD, into a register set of its own), the activations of the <= 16 points of the batch from LDS as the B
+//     operand under the same quad permutation of k (map_net.h), bias + tanh in the epilogue, the result back to LDS for the next layer
+//     (one workgroup barrier per layer);
+//   * the two networks' workgroups meet once, in front of the GP, which needs the mean AND the features: an exchange of <= 64 floats
+//     through write-through atomic stores and a pair of arrival counts (see the kernel); both then run the GP (gp8_body / gp_reg_body of
+//     map_net.h, one wave per task) on the same operands, and each takes its own network's gradient back down;
+//   * backwards, layer by layer: the delta recursion as the transposed product (four strided loads per MFMA group, requested under the
+//     weight-gradient tiles), the weight gradient tiles as products over the points (as many MFMA steps as the points fill), written
+//     straight into ONE gradient slab per network in theta's own layout -- which the slab reduction of map_task.hip / mlp_fused.hip
+//     (fused_reduce_launch) turns into the AdamW step, the hyper-parameter tail and the next iteration's batch: an iteration is two
+//     launches.
+// How it got to 31 us per launch (in-kernel stamps, tools/svgd_task_stamps.py ref_map; 4 x 128 networks, 10 points): both networks in ONE
+// workgroup 112 000 cycles = 46 us -- one compute unit's matrix cores were the bound: a 128 x 128 layer of the pair is 512
+// v_mfma_f32_16x16x4_f32, 128 per SIMD at 32 cycles = 4 100 cycles per layer forward, per delta product and per weight-gradient layer
+// (warming the XCD's L2 from helper workgroups changed nothing: tried, measured, removed) --; one workgroup per network with
+// __threadfence() on either side of the wait 104 000 (the hand-off alone 18 000); payload as agent-scope atomic stores, one
+// thread's release: 90 000; a weight register set per layer instead of a rotating pair (whose copy waited for the loads just
+// issued): 72 000 = 30 us.  What is left per workgroup: prologue 4 400, first layer 6 400, hidden layers 5 900 / 5 700 / 3 100, output
+// layer + hand-off 5 400, GP 5 400, top of the backward pass 3 800, three backward steps of 5 700 (weight tiles) + 2 500 (bias sums)
+// + 2 500 (delta), first layer's gradient 2 000.
 // Limits: fp32, RBF, tb x n <= 16 points per iteration, d <= 4, f <= 4, 1 .. 4 hidden layers of equal or different widths that are
 // multiples of 16 and <= 128 (narrower networks take map_task.hip / map_persist.hip).
 // Reference lines replaced: GPR_meta_mll.py:104-117, models.py:206-217, 505-519.
@@ -52,7 +58,8 @@ struct MwArgs {
     int n, d, f, tb, pts, mean_mode, kernel_nn, off_const, gp8, S;
     float* lml_g; int32_t* info_g; float* dls_g; float* dos_g; float* dnz_g; float* dc_g;
     long* adv_counter;
-    int o_hp, o_x, o_xs, o_y, o_nv, o_gl, o_gp, gpw, total;
+    float* xchg; int* sync;          // two networks = two workgroups: their outputs [2][64] and arrival counts [2] (see the kernel)
+    int o_hp, o_x, o_xs, o_y, o_nv, o_gl, o_gp, gpw, o_dummy, total;
 };
 
 typedef float __attribute__((ext_vector_type(4), aligned(4))) f4u;      // 16 bytes at 4-byte alignment (rows of theta)
@@ -162,36 +169,74 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
         } else lds[a.o_y + mv_s * n + (mv_r - n * d)] = mv_val;
     }
     if (t < tb && a.bnv) reinterpret_cast<int*>(lds + a.o_nv)[t] = nv_val;
-    if (t == 0 && a.adv_counter) *a.adv_counter += 1;
+    if (t == 0 && blockIdx.x == 0 && a.adv_counter) *a.adv_counter += 1;
     __syncthreads();
     MP_STAMP();
 
-    // the waves of a network: net k takes waves k * nw .. (k + 1) * nw - 1
-    const int nw = (MW_NT / 64) / a.nets;
-    const int k_net = wave / nw < a.nets ? wave / nw : a.nets - 1;
-    const int wl = wave - k_net * nw, tl = t - k_net * nw * 64, nthr = nw * 64;
+    // ONE WORKGROUP PER NETWORK (the first version ran both on one compute unit: its matrix cores were the bound, 4 100 cycles per
+    // 128 x 128 layer of the pair).  The two meet once, in front of the GP, which needs the mean AND the features: each publishes its
+    // network's outputs (<= 64 floats), counts its arrival and waits for the other's count to catch up -- both arrive exactly once per
+    // launch, so the counts stay in step without ever being reset (graph replays included) --, then BOTH run the GP on the same operands
+    // (5 000 cycles, in parallel) and each takes the gradient of its own network back down.  Two 1024-thread workgroups are always
+    // co-resident on this part; the wait spins on an agent-scope atomic load.
+    const int k_net = (int)blockIdx.x;
+    const int wl = wave, tl = t, nthr = MW_NT;
     const MwNet& N = a.net[k_net];
-    int max_nl = a.net[0].nl;
-    if (a.nets > 1 && a.net[1].nl > max_nl) max_nl = a.net[1].nl;
+    const int max_nl = N.nl;                             // (a workgroup follows its own network's depth)
 
     // ---- forward ---------------------------------------------------------------------------------------------------------------------
-    MwW wcur;
-    mw_load_w(a, N, 1, wl, r, g, wcur);                  // (layer 1's weights under the first layer's work)
+    // (three register sets, one per hidden layer >= 1, each loaded a layer ahead of its use: a rotating pair `wcur = wnext` made the copy
+    //  wait for the loads it had just issued -- the whole memory latency exposed once per layer)
+    MwW w1, w2, w3;
+    mw_load_w(a, N, 1, wl, r, g, w1);                    // (layer 1's weights under the first layer's work)
     asm volatile("" ::: "memory");                       // (the loads are issued HERE; the compiler would sink them to their use)
     mw_first_layer(a, N, lds, tl, nthr);
     __syncthreads();
     MP_STAMP();
-    for (int l = 1; l + 1 < max_nl; ++l) {
-        MwW wnext;
-        mw_load_w(a, N, l + 1 < MW_MAXL ? l + 1 : l, wl, r, g, wnext);
+    if (2 < max_nl) {
+        mw_load_w(a, N, 2, wl, r, g, w2);
         asm volatile("" ::: "memory");
-        if (l + 1 < N.nl) mw_hidden_layer(a, N, l, lds, wl, r, g, wcur);
-        wcur = wnext;
+        mw_hidden_layer(a, N, 1, lds, wl, r, g, w1);
+        __syncthreads();
+        MP_STAMP();
+    }
+    if (3 < max_nl) {
+        mw_load_w(a, N, 3, wl, r, g, w3);
+        asm volatile("" ::: "memory");
+        mw_hidden_layer(a, N, 2, lds, wl, r, g, w2);
+        __syncthreads();
+        MP_STAMP();
+    }
+    if (4 < max_nl) {
+        mw_hidden_layer(a, N, 3, lds, wl, r, g, w3);
         __syncthreads();
         MP_STAMP();
     }
     mw_output_layer(a, N, lds, tl, nthr);
     __syncthreads();
+    if (a.nets > 1) {
+        const MwNet& No = a.net[1 - k_net];
+        // (the payload as agent-scope atomic stores -- written through, no cache line to flush -- and ONE thread's release on the count: a
+        //  __threadfence() by all 1 024 threads on either side of the wait made this hand-off 18 000 cycles)
+        for (int e = t; e < pts * N.s_out; e += MW_NT) __hip_atomic_store(a.xchg + k_net * 64 + e, lds[N.o_out + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        __shared__ int arrived;
+        if (t == 0) {
+            const int mine = __hip_atomic_fetch_add(a.sync + k_net, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            // (bounded: counts that were never zeroed -- a workspace without pacoh_map_task_setup -- must not hang the device; the
+            //  partner's outputs then read NaN and the iteration's loss says so)
+            int ok = 0;
+            for (int spin = 0; spin < (1 << 20); ++spin) {
+                if (__hip_atomic_load(a.sync + (1 - k_net), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= mine) { ok = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            arrived = ok;
+        }
+        __syncthreads();
+        for (int e = t; e < pts * No.s_out; e += MW_NT)
+            lds[No.o_out + e] = arrived ? __hip_atomic_load(a.xchg + (1 - k_net) * 64 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NAN;
+        __syncthreads();
+    }
     MP_STAMP();
 
     // ---- GP: one wave per task ----------------------------------------------------------------------------------------------------------
@@ -207,10 +252,13 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
         gq.ls = hp; gq.os = has_os ? hp + 4 : nullptr; gq.noise = hp + 5;
         gq.n_valid = a.bnv ? reinterpret_cast<int*>(lds + a.o_nv) : nullptr;
         gq.g_lml = lds + a.o_gl;
-        gq.lml = a.lml_g; gq.info = a.info_g;
+        // (the per-task outputs belong to workgroup 0; the other one's copies go to a scratch corner of its LDS)
+        const bool owner = blockIdx.x == 0;
+        float* dum = lds + a.o_dummy;
+        gq.lml = owner ? a.lml_g : dum; gq.info = owner ? a.info_g : reinterpret_cast<int32_t*>(dum + 16);
         gq.d_z = kernel_nn ? lds + Nk.o_gout : nullptr;
-        gq.d_mean = mean_mode == PACOH_MEAN_VECTOR ? lds + Nm.o_gout : (mean_mode == PACOH_MEAN_CONST ? a.dc_g : nullptr);
-        gq.d_ls = a.dls_g; gq.d_os = has_os ? a.dos_g : nullptr; gq.d_noise = a.dnz_g;
+        gq.d_mean = mean_mode == PACOH_MEAN_VECTOR ? lds + Nm.o_gout : (mean_mode == PACOH_MEAN_CONST ? (owner ? a.dc_g : dum + 32) : nullptr);
+        gq.d_ls = owner ? a.dls_g : dum + 48; gq.d_os = has_os ? (owner ? a.dos_g : dum + 112) : nullptr; gq.d_noise = owner ? a.dnz_g : dum + 128;
         gq.B = tb; gq.P = 1; gq.n = sg(n); gq.f = sg(f);
         if (sg(a.gp8)) {
             if (f <= 2) gpreg::gp8_body<2>(gq, gpreg::WaveCtx{(unsigned)wave}); else gpreg::gp8_body<4>(gq, gpreg::WaveCtx{(unsigned)wave});
@@ -272,16 +320,17 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
                     for (int s = 0; s < 4; ++s) wt[c][s] = (dmine && c < nJ) ? wcol[(long)(16 * c + s) * L.in] : 0.0f;
                 asm volatile("" ::: "memory");           // (issued here, used behind the weight tiles)
             }
-            // weight tiles: wave wl takes row block J = wl (its delta operand is read once), every column block I;
+            // weight tiles: a wave takes row block J (its delta operand is read once) and every other column block I;
             // D[j][i] = sum_p delta[p][16 J + j] a[p][16 I + i]; lane (r, g) holds rows 4 g + s, column r
-            if (wl < nJ) {
+            const int Jw = wl & 7, Ih = wl >> 3;         // sixteen waves: row block J = wl mod 8, every other column block
+            if (Jw < nJ) {
                 const int nks = (pts + 3) >> 2;          // MFMA steps the points fill (the rows behind them are zero: nothing to add)
                 float dj[MW_PT / 4];
 #pragma unroll
-                for (int ks = 0; ks < MW_PT / 4; ++ks) dj[ks] = ks < nks ? del[(4 * ks + g) * S + 16 * wl + r] : 0.0f;
-                float* dst0 = slab + (L.w_flat - N.flat0) + (long)(16 * wl + 4 * g) * L.in + r;
+                for (int ks = 0; ks < MW_PT / 4; ++ks) dj[ks] = ks < nks ? del[(4 * ks + g) * S + 16 * Jw + r] : 0.0f;
+                float* dst0 = slab + (L.w_flat - N.flat0) + (long)(16 * Jw + 4 * g) * L.in + r;
 #pragma unroll 2
-                for (int I = 0; I < nI; ++I) {
+                for (int I = Ih; I < nI; I += 2) {
                     gpreg::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < MW_PT / 4; ++ks) if (ks < nks) acc = gpreg::mfma_(dj[ks], ain[(4 * ks + g) * S + 16 * I + r], acc);
@@ -382,6 +431,7 @@ int mw_plan(MwArgs& a, int n, int d, int tb, int mean_mode, int off_mean, const 
     const int FPp = f <= 2 ? 2 : 4;
     a.gpw = (2 * 16 * FPp + 2 * 16 + gpreg::GPR_SCR + 4 + 3) & ~3;
     a.o_gp = take(a.gp8 ? 4 : a.gpw * tb);
+    a.o_dummy = take(160);
     a.total = top;
     if ((size_t)top * sizeof(float) > (size_t)MP_LDS_BYTES) return PACOH_ELIMIT;
     return PACOH_OK;
@@ -404,8 +454,13 @@ int map_wide_launch(const void* theta, const void* bx, const void* by, const int
     for (int k = 0; k < a.nets; ++k) o_slab[k] = carve((size_t)a.net[k].dnet * sizeof(float));
     const size_t B_ = (size_t)tb_total;
     const size_t o_lml = carve(B_ * 4), o_dls = carve(B_ * f * 4), o_dos = carve(B_ * 4), o_dnz = carve(B_ * 4), o_dc = carve(B_ * 4), o_info = carve(B_ * 4);
+    const size_t o_xchg = carve(2 * 64 * 4), o_sync = carve(2 * 4);
     if (need_bytes) *need_bytes = off;
-    if (plan_only == 1 || plan_only == 2) return PACOH_OK;
+    if (plan_only == 1) return PACOH_OK;
+    if (plan_only == 2) {                               // (setup: the two workgroups' arrival counts start at zero, once per workspace)
+        if (!workspace || workspace_bytes < off) return PACOH_EINVAL;
+        return hipMemsetAsync((char*)workspace + o_sync, 0, 8, stream) == hipSuccess ? PACOH_OK : PACOH_ELAUNCH;
+    }
     for (int k = 0; k < a.nets; ++k) if (a.net[k].flat0 + a.net[k].dnet > D) return PACOH_EINVAL;
     if (!workspace || workspace_bytes < off) return PACOH_EINVAL;
     char* ws = (char*)workspace;
@@ -416,13 +471,14 @@ int map_wide_launch(const void* theta, const void* bx, const void* by, const int
     for (int k = 0; k < a.nets; ++k) a.net[k].slab = (float*)(ws + o_slab[k]);
     a.lml_g = (float*)(ws + o_lml); a.dls_g = (float*)(ws + o_dls); a.dos_g = (float*)(ws + o_dos); a.dnz_g = (float*)(ws + o_dnz);
     a.dc_g = (float*)(ws + o_dc); a.info_g = (int32_t*)(ws + o_info);
+    a.xchg = (float*)(ws + o_xchg); a.sync = (int*)(ws + o_sync);
     HyperBwdArgs<float> tail = *tail_in;
     tail.d_ls = a.dls_g; tail.d_os = hyp_os ? a.dos_g : nullptr; tail.d_noise = a.dnz_g; tail.d_const = mean_mode == PACOH_MEAN_CONST ? a.dc_g : nullptr;
     tail.lml = tail.lik ? a.lml_g : nullptr; tail.info = tail.fail_flag ? a.info_g : nullptr;
     a.adv_counter = const_cast<long*>(tail.nx.counter);
     static std::atomic<uint64_t> attr_done{0};
     { const int rc_a = lds_opt_in((const void*)map_wide_kernel, MP_LDS_BYTES, attr_done); if (rc_a != PACOH_OK) return rc_a; }
-    hipLaunchKernelGGL(map_wide_kernel, dim3(1), dim3(MW_NT), (size_t)a.total * sizeof(float), stream, a);
+    hipLaunchKernelGGL(map_wide_kernel, dim3((unsigned)a.nets), dim3(MW_NT), (size_t)a.total * sizeof(float), stream, a);
     if (launch_status() != PACOH_OK) return PACOH_ELAUNCH;
     return fused_reduce_launch(a.net[0].slab, a.net[0].dnet, a.net[0].flat0, a.nets > 1 ? a.net[1].slab : nullptr, a.nets > 1 ? a.net[1].dnet : 0,
                                a.nets > 1 ? a.net[1].flat0 : 0, a.nets, (float*)d_theta, d_theta_stride, 1, &tail, nullptr, nullptr, stream, 1);
