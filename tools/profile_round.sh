@@ -20,13 +20,14 @@ for c in 2 4; do
   cp $(ls $out/stats$c/*/*kernel_stats.csv | head -1) $out/cfg${c}_kernel_stats.csv; rm -rf $out/stats$c
 done
 # ... of the reference launchers' own SVGD / VI shape (task-fused likelihood launch) and of cfg #3's 1/8 strong-scaling shard (round 6)
-for c in ref_svgd ref_vi shard128; do
+for c in ref_svgd ref_vi ref_map shard128; do
   python bench.py --config $c --no-cpu-baseline > $out/bench_$c.json 2>> $out/bench.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$c -- python3 bench.py --config $c --no-cpu-baseline > /dev/null 2>&1
   cp $(ls $out/stats_$c/*/*kernel_stats.csv | head -1) $out/${c}_kernel_stats.csv; rm -rf $out/stats_$c
 done
 PACOH_SVGD_TASK_FUSED=0 python bench.py --config ref_svgd --no-cpu-baseline > $out/bench_ref_svgd_general.json 2>> $out/bench.err
 PACOH_SVGD_TASK_FUSED=0 python bench.py --config ref_vi --no-cpu-baseline > $out/bench_ref_vi_general.json 2>> $out/bench.err
+PACOH_MAP_TASK_FUSED=0 python bench.py --config ref_map --no-cpu-baseline > $out/bench_ref_map_general.json 2>> $out/bench.err
 # SQ counters of the task-fused kernel at the launcher shape
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/sqt/p1 -- python3 bench.py --config ref_svgd --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT --output-format csv -d $out/sqt/p2 -- python3 bench.py --config ref_svgd --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
