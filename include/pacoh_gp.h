@@ -573,7 +573,7 @@ int pacoh_map_persist(void* theta, void* exp_avg, void* exp_avg_sq, int D, const
  * counter of opt->next is advanced by launch (1).
  * WIDE networks (round 6, csrc/map_wide.hip): hidden widths that are multiples of 16 up to 128 -- the reference's PACOH-MAP launcher
  * runs 2 tasks x 5 points per iteration through two 4 x 128 networks (experiments/meta_GPR_mll_base_exp.py:29-47) -- take the same three
- * entry points when the whole batch is at most 16 points (tb n <= 16): launch (1) is then one workgroup per NETWORK that streams the
+ * entry points when the whole batch is at most 32 points of tasks of at most 16 (tb n <= 32, n <= 16): launch (1) is then one workgroup per NETWORK that streams the
  * weights from theta through the matrix cores layer by layer (no LDS image), the two meeting once in front of the GP; launch (2) is
  * unchanged.  pacoh_map_task_setup zeroes the workgroups' arrival counts in the workspace there (no parameter image exists).
  * pacoh_map_task_setup: the workspace also holds the networks' parameters in the padded layout launch (1) keeps them in (its prologue

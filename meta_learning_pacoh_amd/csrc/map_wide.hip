@@ -25,7 +25,7 @@
 // issued): 72 000 = 30 us.  What is left per workgroup: prologue 4 400, first layer 6 400, hidden layers 5 900 / 5 700 / 3 100, output
 // layer + hand-off 5 400, GP 5 400, top of the backward pass 3 800, three backward steps of 5 700 (weight tiles) + 2 500 (bias sums)
 // + 2 500 (delta), first layer's gradient 2 000.
-// Limits: fp32, RBF, tb x n <= 16 points per iteration, d <= 4, f <= 4, 1 .. 4 hidden layers of equal or different widths that are
+// Limits: fp32, RBF, tb x n <= 32 points per iteration (tasks of n <= 16), d <= 4, f <= 4, 1 .. 4 hidden layers of equal or different widths that are
 // multiples of 16 and <= 128 (narrower networks take map_task.hip / map_persist.hip).
 // Reference lines replaced: GPR_meta_mll.py:104-117, models.py:206-217, 505-519.
 #include "map_net.h"
@@ -40,7 +40,7 @@ namespace {
 constexpr int MW_NT = 1024;
 constexpr int MW_MAXL = 5;           // up to 4 hidden layers + the output layer
 constexpr int MW_MAXW = 128;
-constexpr int MW_PT = 16;            // points per iteration (one MFMA tile)
+constexpr int MW_PT = 32;            // points per iteration: one or two 16-point MFMA tiles
 
 struct MwLayer { int in, out, w_flat, b_flat; };
 struct MwNet {
@@ -58,7 +58,7 @@ struct MwArgs {
     int n, d, f, tb, pts, mean_mode, kernel_nn, off_const, gp8, S;
     float* lml_g; int32_t* info_g; float* dls_g; float* dos_g; float* dnz_g; float* dc_g;
     long* adv_counter;
-    float* xchg; int* sync;          // two networks = two workgroups: their outputs [2][64] and arrival counts [2] (see the kernel)
+    float* xchg; int* sync;          // two networks = two workgroups: their outputs [2][128] and arrival counts [2] (see the kernel)
     int o_hp, o_x, o_xs, o_y, o_nv, o_gl, o_gp, gpw, o_dummy, total;
 };
 
@@ -83,18 +83,20 @@ struct MwW { f4u wq[MW_MAXW / 16]; f4u bq; };
 __device__ __forceinline__ void mw_load_w(const MwArgs& a, const MwNet& N, int l, int wl, int r, int g, MwW& w) {
     const MwLayer& L = N.L[l];
     const int nc = L.in >> 4;
-    const bool mine = l >= 1 && l + 1 < N.nl && wl < (L.out >> 4);
-    const float* wrow = a.theta + L.w_flat + (long)(16 * wl + r) * L.in + 4 * g;
+    const int U = wl & 7;                                // (waves 8 .. 15: the same tiles for the second point tile)
+    const bool mine = l >= 1 && l + 1 < N.nl && U < (L.out >> 4) && 16 * (wl >> 3) < a.pts;
+    const float* wrow = a.theta + L.w_flat + (long)(16 * U + r) * L.in + 4 * g;
 #pragma unroll
     for (int c = 0; c < MW_MAXW / 16; ++c) w.wq[c] = (mine && c < nc) ? *reinterpret_cast<const f4u*>(wrow + 16 * c) : f4u{0.f, 0.f, 0.f, 0.f};
-    w.bq = mine ? *reinterpret_cast<const f4u*>(a.theta + L.b_flat + 16 * wl + 4 * g) : f4u{0.f, 0.f, 0.f, 0.f};
+    w.bq = mine ? *reinterpret_cast<const f4u*>(a.theta + L.b_flat + 16 * U + 4 * g) : f4u{0.f, 0.f, 0.f, 0.f};
 }
 __device__ __forceinline__ void mw_hidden_layer(const MwArgs& a, const MwNet& N, int l, float* lds, int wl, int r, int g, const MwW& w) {
     const MwLayer& L = N.L[l];
-    if (wl >= (L.out >> 4)) return;
-    const int S = a.S, nc = L.in >> 4;
-    const float* ain = lds + N.o_act + (l - 1) * MW_PT * S + r * S + 4 * g;
-    float* aout = lds + N.o_act + l * MW_PT * S + r * S + 4 * g;
+    const int U = wl & 7, Pt = wl >> 3;                  // output tile, point tile
+    if (U >= (L.out >> 4) || 16 * Pt >= a.pts) return;
+    const int S = a.S, nc = L.in >> 4, p = 16 * Pt + r;
+    const float* ain = lds + N.o_act + (l - 1) * MW_PT * S + p * S + 4 * g;
+    float* aout = lds + N.o_act + l * MW_PT * S + p * S + 4 * g;
     gpreg::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < MW_MAXW / 16; ++c) {
@@ -104,11 +106,11 @@ __device__ __forceinline__ void mw_hidden_layer(const MwArgs& a, const MwNet& N,
             acc = gpreg::mfma_(w.wq[c][2], av.z, acc); acc = gpreg::mfma_(w.wq[c][3], av.w, acc);
         }
     }
-    // lane (r, g) holds units 16 wl + 4 g + s of point r
+    // lane (r, g) holds units 16 U + 4 g + s of point p
     float4 v;
     v.x = act_tanh<float>(acc[0] + w.bq[0]); v.y = act_tanh<float>(acc[1] + w.bq[1]);
     v.z = act_tanh<float>(acc[2] + w.bq[2]); v.w = act_tanh<float>(acc[3] + w.bq[3]);
-    if (r < a.pts) *reinterpret_cast<float4*>(aout + 16 * wl) = v;
+    if (p < a.pts) *reinterpret_cast<float4*>(aout + 16 * U) = v;
 }
 
 // the output layer (out <= 4): out[p][o] = b[o] + W[o][:] . h[p][:], 16 lanes per (p, o) entry
@@ -218,7 +220,7 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
         const MwNet& No = a.net[1 - k_net];
         // (the payload as agent-scope atomic stores -- written through, no cache line to flush -- and ONE thread's release on the count: a
         //  __threadfence() by all 1 024 threads on either side of the wait made this hand-off 18 000 cycles)
-        for (int e = t; e < pts * N.s_out; e += MW_NT) __hip_atomic_store(a.xchg + k_net * 64 + e, lds[N.o_out + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int e = t; e < pts * N.s_out; e += MW_NT) __hip_atomic_store(a.xchg + k_net * 128 + e, lds[N.o_out + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         __shared__ int arrived;
         if (t == 0) {
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
         }
         __syncthreads();
         for (int e = t; e < pts * No.s_out; e += MW_NT)
-            lds[No.o_out + e] = arrived ? __hip_atomic_load(a.xchg + (1 - k_net) * 64 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NAN;
+            lds[No.o_out + e] = arrived ? __hip_atomic_load(a.xchg + (1 - k_net) * 128 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NAN;
         __syncthreads();
     }
     MP_STAMP();
@@ -311,9 +313,10 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
             // the transposed weights of the delta product (wave wl: input tile I = wl) are requested FIRST: W[16 c + 4 g + s][16 wl + r],
             // four strided loads per group of 16 outputs, under the weight-gradient tiles' LDS work
             float wt[MW_MAXW / 16][4];
-            const bool dmine = wl < nI;
+            const int Iw = wl & 7, Pw = wl >> 3;         // the delta product's tile of this wave: input block, point tile
+            const bool dmine = Iw < nI && 16 * Pw < pts;
             {
-                const float* wcol = a.theta + L.w_flat + 16 * wl + r + (long)(4 * g) * L.in;
+                const float* wcol = a.theta + L.w_flat + 16 * Iw + r + (long)(4 * g) * L.in;
 #pragma unroll
                 for (int c = 0; c < MW_MAXW / 16; ++c)
 #pragma unroll
@@ -352,16 +355,16 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
 #pragma unroll
                 for (int c = 0; c < MW_MAXW / 16; ++c) {
                     if (c < nJ) {
-                        const float4 dv = *reinterpret_cast<const float4*>(del + r * S + 16 * c + 4 * g);
+                        const float4 dv = *reinterpret_cast<const float4*>(del + (16 * Pw + r) * S + 16 * c + 4 * g);
                         acc = gpreg::mfma_(wt[c][0], dv.x, acc); acc = gpreg::mfma_(wt[c][1], dv.y, acc);
                         acc = gpreg::mfma_(wt[c][2], dv.z, acc); acc = gpreg::mfma_(wt[c][3], dv.w, acc);
                     }
                 }
-                const float4 hv = *reinterpret_cast<const float4*>(ain + r * S + 16 * wl + 4 * g);
+                const float4 hv = *reinterpret_cast<const float4*>(ain + (16 * Pw + r) * S + 16 * Iw + 4 * g);
                 float4 o4;
                 o4.x = acc[0] * fmaf(-hv.x, hv.x, 1.0f); o4.y = acc[1] * fmaf(-hv.y, hv.y, 1.0f);
                 o4.z = acc[2] * fmaf(-hv.z, hv.z, 1.0f); o4.w = acc[3] * fmaf(-hv.w, hv.w, 1.0f);
-                if (r < pts) *reinterpret_cast<float4*>(dnx + r * S + 16 * wl + 4 * g) = o4;
+                if (16 * Pw + r < pts) *reinterpret_cast<float4*>(dnx + (16 * Pw + r) * S + 16 * Iw + 4 * g) = o4;
             }
         }
         __syncthreads();
@@ -390,7 +393,7 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
 int mw_plan(MwArgs& a, int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden, int kernel_nn,
             int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f) {
     memset(&a, 0, sizeof(a));
-    if (n < 1 || d < 1 || d > 4 || f < 1 || f > 4 || tb < 1 || tb > MW_NT / 64 || tb * n > MW_PT || tb * n * (d + 1) > MW_NT) return PACOH_ELIMIT;
+    if (n < 1 || n > 16 || d < 1 || d > 4 || f < 1 || f > 4 || tb < 1 || tb > MW_NT / 64 || tb * n > MW_PT || tb * n * (d + 1) > MW_NT) return PACOH_ELIMIT;
     if (!kernel_nn && f != d) return PACOH_EINVAL;
     a.n = n; a.d = d; a.f = f; a.tb = tb; a.pts = tb * n; a.mean_mode = mean_mode; a.kernel_nn = kernel_nn;
     a.gp8 = (n <= 8 && g_sw.gp8) ? 1 : 0;
@@ -422,11 +425,15 @@ int mw_plan(MwArgs& a, int n, int d, int tb, int mean_mode, int off_mean, const 
     auto take = [&](int count) { const int o = top; top += (count + 3) & ~3; return o; };
     a.o_hp = take(8);
     a.o_x = take(MW_PT * 4); a.o_xs = take(MW_PT * d); a.o_y = take(MW_PT); a.o_nv = take(16); a.o_gl = take(16);
+    // (a workgroup works on ONE network: the activation and delta images of the two share their place; the small output / upstream-
+    //  gradient arrays exist for both -- the GP reads both networks' outputs)
+    int max_hidden = 1;
+    for (int k = 0; k < a.nets; ++k) if (a.net[k].nl - 1 > max_hidden) max_hidden = a.net[k].nl - 1;
+    const int o_act = take(max_hidden * MW_PT * a.S), o_del = take(2 * MW_PT * a.S);
     for (int k = 0; k < a.nets; ++k) {
         MwNet& N = a.net[k];
-        N.o_act = take((N.nl - 1) * MW_PT * a.S);
+        N.o_act = o_act; N.o_del = o_del;
         N.o_out = take(MW_PT * N.s_out); N.o_gout = take(MW_PT * N.s_out);
-        N.o_del = take(2 * MW_PT * a.S);
     }
     const int FPp = f <= 2 ? 2 : 4;
     a.gpw = (2 * 16 * FPp + 2 * 16 + gpreg::GPR_SCR + 4 + 3) & ~3;
@@ -454,7 +461,7 @@ int map_wide_launch(const void* theta, const void* bx, const void* by, const int
     for (int k = 0; k < a.nets; ++k) o_slab[k] = carve((size_t)a.net[k].dnet * sizeof(float));
     const size_t B_ = (size_t)tb_total;
     const size_t o_lml = carve(B_ * 4), o_dls = carve(B_ * f * 4), o_dos = carve(B_ * 4), o_dnz = carve(B_ * 4), o_dc = carve(B_ * 4), o_info = carve(B_ * 4);
-    const size_t o_xchg = carve(2 * 64 * 4), o_sync = carve(2 * 4);
+    const size_t o_xchg = carve(2 * 128 * 4), o_sync = carve(2 * 4);
     if (need_bytes) *need_bytes = off;
     if (plan_only == 1) return PACOH_OK;
     if (plan_only == 2) {                               // (setup: the two workgroups' arrival counts start at zero, once per workspace)

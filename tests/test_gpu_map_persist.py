@@ -250,10 +250,11 @@ WIDE_CFGS = [
 
 
 @pytest.mark.parametrize('cfg', WIDE_CFGS)
-@pytest.mark.parametrize('shape', [(20, 5, 1, 2), (8, 8, 2, 2), (6, 16, 1, 1), (7, 3, 4, 5), (9, 10, 3, 1)])
+@pytest.mark.parametrize('shape', [(20, 5, 1, 2), (8, 8, 2, 2), (6, 16, 1, 1), (7, 3, 4, 5), (9, 10, 3, 1),
+                                   (8, 8, 2, 4), (20, 5, 1, 5), (7, 12, 1, 2), (6, 16, 3, 2)])      # ... and two point tiles: 17 .. 32 points
 @pytest.mark.parametrize('graph', ['0', '1'])
 def test_wide_network_iteration_equals_the_general_sequence(M, cfg, shape, graph, monkeypatch):
-    """T tasks of n points (ragged), tb per iteration with tb x n <= 16: forward, GP and backward of the whole batch in ONE workgroup that
+    """T tasks of n <= 16 points (ragged), tb per iteration with tb x n <= 32: forward, GP and backward of the whole batch in ONE workgroup that
     streams the weights from theta (map_wide_kernel) + the slab reduction, against the layer-by-layer general sequence (~60 launches)
     on the same draws: parameters, both Adam moments, losses after 12 iterations, eagerly and as replayed graphs"""
     T, n, d, tb = shape
@@ -314,7 +315,9 @@ def test_wide_network_limits(M):
     h128, h32, h40 = L._hidden_arr([128] * 4), L._hidden_arr([32, 32]), L._hidden_arr([40, 40])
     D = 200000
     assert lib.pacoh_map_task_workspace_bytes(D, 5, 1, 2, L.MEAN_VECTOR, h128, 4, 1, h128, 4, 2, 0, L.F32) > 0
-    assert lib.pacoh_map_task_workspace_bytes(D, 5, 1, 4, L.MEAN_VECTOR, h128, 4, 1, h128, 4, 2, 0, L.F32) == 0        # 20 points > one tile
+    assert lib.pacoh_map_task_workspace_bytes(D, 5, 1, 6, L.MEAN_VECTOR, h128, 4, 1, h128, 4, 2, 0, L.F32) > 0         # 30 points: two tiles
+    assert lib.pacoh_map_task_workspace_bytes(D, 5, 1, 7, L.MEAN_VECTOR, h128, 4, 1, h128, 4, 2, 0, L.F32) == 0        # 35 points > two tiles
+    assert lib.pacoh_map_task_workspace_bytes(D, 17, 1, 1, L.MEAN_VECTOR, h128, 4, 1, h128, 4, 2, 0, L.F32) == 0       # tasks of more than 16 points
     assert lib.pacoh_map_task_workspace_bytes(D, 5, 1, 2, L.MEAN_VECTOR, h40, 2, 1, h40, 2, 2, 0, L.F32) == 0          # width no multiple of 16
     assert lib.pacoh_map_task_workspace_bytes(D, 5, 1, 2, L.MEAN_VECTOR, h32, 2, 1, h32, 2, 2, 0, L.F32) > 0           # narrow: the LDS-image kernel
     assert lib.pacoh_map_task_workspace_bytes(D, 5, 1, 2, L.MEAN_VECTOR, h128, 4, 1, h128, 4, 2, 0, L.F64) == 0
