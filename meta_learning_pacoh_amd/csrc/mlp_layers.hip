@@ -84,6 +84,26 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const T* __restrict__
     }
 }
 
+// the same for ALL layers of a network in one launch (blockIdx.z = layer; round 6: a launch per layer was 20 of the ~62 launches of a
+// PACOH-MAP iteration with two 4 x 128 networks, each ~4.6 us of pure latency).  Networks of more than PACK_MAXL layers keep the loop.
+constexpr int PACK_MAXL = 16;
+struct PackPlan { int n_layers; int in_real[PACK_MAXL], out_real[PACK_MAXL], inp[PACK_MAXL], outp[PACK_MAXL]; long w_off[PACK_MAXL], b_off[PACK_MAXL], th_off[PACK_MAXL]; };
+template <typename T>
+__global__ void __launch_bounds__(256) pack_all_kernel(const T* __restrict__ theta, long theta_stride, T* __restrict__ wp, long w_elems, PackPlan pp) {
+    const int p = blockIdx.y, l = blockIdx.z;
+    const int in_real = pp.in_real[l], out_real = pp.out_real[l], inp = pp.inp[l], outp = pp.outp[l];
+    const long w_off = pp.w_off[l], b_off = pp.b_off[l];
+    const T* th = theta + (long)p * theta_stride + pp.th_off[l];
+    T* dst = wp + (long)p * w_elems;
+    const long tot = (long)outp * (inp + 1);
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < tot; q += (long)gridDim.x * 256) {
+        if (q < outp) { dst[b_off + q] = q < out_real ? th[q] : T(0); continue; }
+        const long e = q - outp;
+        const int o = (int)(e / inp), k = (int)(e - (long)o * inp);
+        dst[w_off + e] = (o < out_real && k < in_real) ? th[out_real + (long)o * in_real + k] : T(0);
+    }
+}
+
 // rows of a particle: row rr = t*n + i -> problem b = t*P + p; x row = (b / x_div)*n + i, output row = b*n + i
 struct RowMap { int P, n, R, x_div; };
 __device__ __forceinline__ void map_row(const RowMap& m, int p, int rr, long& xrow, long& orow) {
@@ -289,6 +309,21 @@ size_t mlp_layers_workspace(int B, int P, int n, int d_in, const int32_t* hidden
 
 template <typename T>
 static void launch_pack(const LayerPlan& pl, const T* theta, long theta_stride, T* wp, int P, hipStream_t s) {
+    if (pl.n_layers <= PACK_MAXL) {
+        PackPlan pp;
+        pp.n_layers = pl.n_layers;
+        long maxtot = 0;
+        for (int l = 0; l < pl.n_layers; ++l) {
+            pp.in_real[l] = pl.in_real[l]; pp.out_real[l] = pl.out_real[l]; pp.inp[l] = pl.inp[l]; pp.outp[l] = pl.outp[l];
+            pp.w_off[l] = pl.w_off[l]; pp.b_off[l] = pl.b_off[l]; pp.th_off[l] = pl.th_off[l];
+            const long tot = (long)pl.outp[l] * (pl.inp[l] + 1);
+            if (tot > maxtot) maxtot = tot;
+        }
+        long blocks = (maxtot + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(pack_all_kernel<T>, dim3((unsigned)blocks, P, pl.n_layers), dim3(256), 0, s, theta, theta_stride, wp, pl.w_elems, pp);
+        return;
+    }
     for (int l = 0; l < pl.n_layers; ++l) {
         const long tot = (long)pl.outp[l] * (pl.inp[l] + 1);
         long blocks = (tot + 255) / 256;
