@@ -31,8 +31,10 @@ int mlp_fused_bwd(const void* x, int x_div, const void* theta, long theta_stride
                   const HyperBwdArgs<float>* tail, long col_base = 0);
 // mlp_layers.hip
 size_t mlp_layers_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype, int bwd);
-int mlp_layers_fwd(const void*, int, const void*, long, int, int, const int32_t*, int, int, void*, void*, int, int, int, hipStream_t);
-int mlp_layers_bwd(const void*, int, const void*, long, int, int, const int32_t*, int, int, const void*, void*, long, int, void*, int, int, int, hipStream_t);
+size_t mlp_layers_stash_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype);
+int mlp_layers_fwd(const void*, int, const void*, long, int, int, const int32_t*, int, int, void*, void*, int, int, int, hipStream_t, void* stash = nullptr);
+int mlp_layers_bwd(const void*, int, const void*, long, int, int, const int32_t*, int, int, const void*, void*, long, int, void*, int, int, int, hipStream_t,
+                   const void* stash = nullptr);
 
 // out[o] (+)= scale * sum_c in[c, o]; one wavefront per output element, lanes stride over c, fixed order
 template <typename T>
@@ -99,7 +101,7 @@ static int mlp_fwd_impl(const void* x, int x_div, const void* theta, long theta_
     case PATH_MFMA:
         return mlp_mfma_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, B, n, s);
     default:
-        return mlp_layers_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, workspace, B, n, dtype, s);
+        return mlp_layers_fwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, workspace, B, n, dtype, s, stash);
     }
 }
 
@@ -113,7 +115,11 @@ extern "C" int pacoh_mlp_fwd(const void* x, int x_div, const void* theta, long t
 // the activation stash of pacoh_mlp2_fwd / pacoh_mlp2_bwd for ONE network: bytes (0: this shape keeps none), and the forward that fills it
 extern "C" size_t pacoh_mlp_stash_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype) {
     if (P <= 0 || B <= 0 || n <= 0 || B % P != 0 || args_ok(d_in, hidden, n_hidden, d_out)) return 0;
-    if (pick_path(dtype, d_in, hidden, n_hidden, d_out, (long)B * n) != PATH_FUSED) return 0;
+    const MlpPath path = pick_path(dtype, d_in, hidden, n_hidden, d_out, (long)B * n);
+    // (round 6) the layer-by-layer path keeps its packed weights and hidden activations for the backward too: 9 launches less per
+    // network and step (5 repacks -> 0, 4 recomputed layers -> 0 at four hidden layers)
+    if (path == PATH_LAYERS) return align256(mlp_layers_stash_bytes(B, P, n, d_in, hidden, n_hidden, d_out, dtype));
+    if (path != PATH_FUSED) return 0;
     return mlp_fused_stash_bytes(B, P, n, n_hidden, 1);
 }
 extern "C" int pacoh_mlp_fwd_stash(const void* x, int x_div, const void* theta, long theta_stride, int P,
@@ -168,8 +174,11 @@ extern "C" size_t pacoh_mlp2_fwd_workspace_bytes(int B, int P, int n, int d_in, 
 extern "C" size_t pacoh_mlp2_stash_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out_a,
                                          int d_out_b, int dtype) {
     if (P <= 0 || B <= 0 || n <= 0 || B % P != 0 || args_ok(d_in, hidden, n_hidden, d_out_a) || args_ok(d_in, hidden, n_hidden, d_out_b)) return 0;
-    if (pick_path(dtype, d_in, hidden, n_hidden, d_out_a, (long)B * n) != PATH_FUSED ||
-        pick_path(dtype, d_in, hidden, n_hidden, d_out_b, (long)B * n) != PATH_FUSED) return 0;
+    const MlpPath pa = pick_path(dtype, d_in, hidden, n_hidden, d_out_a, (long)B * n), pb = pick_path(dtype, d_in, hidden, n_hidden, d_out_b, (long)B * n);
+    if (pa == PATH_LAYERS && pb == PATH_LAYERS)          // (one stash per network, back to back: mlp2_layers_stash)
+        return align256(mlp_layers_stash_bytes(B, P, n, d_in, hidden, n_hidden, d_out_a, dtype)) +
+               align256(mlp_layers_stash_bytes(B, P, n, d_in, hidden, n_hidden, d_out_b, dtype));
+    if (pa != PATH_FUSED || pb != PATH_FUSED) return 0;
     return mlp_fused_stash_bytes(B, P, n, n_hidden, 2);
 }
 
@@ -190,9 +199,15 @@ static int mlp2_fwd_impl(const void* x, int x_div, const void* theta, long theta
                              tail_done);
     }
     const size_t es = dtype == PACOH_F64 ? 8 : 4;
-    rc = pacoh_mlp_fwd(x, x_div, (const char*)theta + off_a * es, theta_stride, P, d_in, hidden, n_hidden, d_out_a, out_a, workspace, B, n, dtype, stream);
+    void* st_a = nullptr; void* st_b = nullptr;          // the layer-by-layer path's per-network stashes (pacoh_mlp2_stash_bytes)
+    if (stash && pick_path(dtype, d_in, hidden, n_hidden, d_out_a, (long)B * n) == PATH_LAYERS &&
+        pick_path(dtype, d_in, hidden, n_hidden, d_out_b, (long)B * n) == PATH_LAYERS) {
+        st_a = stash;
+        st_b = (char*)stash + align256(mlp_layers_stash_bytes(B, P, n, d_in, hidden, n_hidden, d_out_a, dtype));
+    }
+    rc = mlp_fwd_impl(x, x_div, (const char*)theta + off_a * es, theta_stride, P, d_in, hidden, n_hidden, d_out_a, out_a, workspace, st_a, B, n, dtype, stream);
     if (rc) return rc;
-    return pacoh_mlp_fwd(x, x_div, (const char*)theta + off_b * es, theta_stride, P, d_in, hidden, n_hidden, d_out_b, out_b, workspace, B, n, dtype, stream);
+    return mlp_fwd_impl(x, x_div, (const char*)theta + off_b * es, theta_stride, P, d_in, hidden, n_hidden, d_out_b, out_b, workspace, st_b, B, n, dtype, stream);
 }
 
 extern "C" int pacoh_mlp2_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in,
@@ -302,6 +317,16 @@ static int mlp2_bwd_impl(const void* x, int x_div, const void* theta, long theta
                              accumulate, workspace, stash, B, n, (hipStream_t)stream, tail);
     }
     const size_t es = dtype == PACOH_F64 ? 8 : 4;
+    if (stash && pick_path(dtype, d_in, hidden, n_hidden, d_out_a, (long)B * n) == PATH_LAYERS &&
+        pick_path(dtype, d_in, hidden, n_hidden, d_out_b, (long)B * n) == PATH_LAYERS) {
+        // the forward of the same step left each network's packed weights and hidden activations in its half of the stash
+        const void* st_b = (const char*)stash + align256(mlp_layers_stash_bytes(B, P, n, d_in, hidden, n_hidden, d_out_a, dtype));
+        rc = mlp_layers_bwd(x, x_div, (const char*)theta + off_a * es, theta_stride, P, d_in, hidden, n_hidden, d_out_a, g_a,
+                            (char*)d_theta + off_a * es, d_theta_stride, accumulate, workspace, B, n, dtype, (hipStream_t)stream, stash);
+        if (rc) return rc;
+        return mlp_layers_bwd(x, x_div, (const char*)theta + off_b * es, theta_stride, P, d_in, hidden, n_hidden, d_out_b, g_b,
+                              (char*)d_theta + off_b * es, d_theta_stride, accumulate, workspace, B, n, dtype, (hipStream_t)stream, st_b);
+    }
     rc = pacoh_mlp_bwd(x, x_div, (const char*)theta + off_a * es, theta_stride, P, d_in, hidden, n_hidden, d_out_a, g_a,
                        (char*)d_theta + off_a * es, d_theta_stride, accumulate, workspace, B, n, dtype, stream);
     if (rc) return rc;
@@ -398,8 +423,12 @@ extern "C" int pacoh_mlp_bwd_hyper(const void* x, int x_div, const void* theta, 
         return mlp_fused_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, 1, &off, &d_out, gs, d_theta, d_theta_stride,
                              0, workspace, stash, B, n, (hipStream_t)stream, &tail, (long)((const float*)d_theta - (const float*)grad_rows));
     }
-    rc = pacoh_mlp_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, 0, workspace, B, n,
-                       dtype, stream);
+    if (stash && !args_ok(d_in, hidden, n_hidden, d_out) && pick_path(dtype, d_in, hidden, n_hidden, d_out, (long)B * n) == PATH_LAYERS)
+        rc = mlp_layers_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, 0, workspace, B, n,
+                            dtype, (hipStream_t)stream, stash);      // (packed weights + hidden activations from pacoh_mlp_fwd_stash)
+    else
+        rc = pacoh_mlp_bwd(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, 0, workspace, B, n,
+                           dtype, stream);
     if (rc) return rc;
     rc = pacoh_hyper_bwd(theta_rows, theta_stride, P, T_, off_ls, f, off_os, off_noise, off_const, d_ls, d_os, d_noise, d_const, grad_rows,
                          d_theta_stride, lml, lik, lik_scale, info, fail_flag, svgd_workspace, svgd_P, svgd_D, nullptr, dtype, stream);

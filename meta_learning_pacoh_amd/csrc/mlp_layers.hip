@@ -301,6 +301,16 @@ static LayersWs layers_ws(const LayerPlan& pl, int P, long R, size_t es, bool bw
     return w;
 }
 
+// the forward's state a backward of the SAME inputs and parameters can start from instead of repacking the weights and recomputing the
+// hidden layers (round 6; mlp.hip hands it around as the "stash" the fused path has had since round 3): packed weights | every hidden
+// layer's activations, in the backward's own layout
+size_t mlp_layers_stash_bytes(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype) {
+    LayerPlan pl;
+    if (P <= 0 || B <= 0 || n <= 0 || make_plan(pl, d_in, hidden, n_hidden, d_out)) return 0;
+    const LayersWs w = layers_ws(pl, P, (long)(B / P) * n, dtype == PACOH_F64 ? 8 : 4, true);
+    return w.wp + w.act;
+}
+
 size_t mlp_layers_workspace(int B, int P, int n, int d_in, const int32_t* hidden, int n_hidden, int d_out, int dtype, int bwd) {
     LayerPlan pl;
     if (P <= 0 || B <= 0 || n <= 0 || make_plan(pl, d_in, hidden, n_hidden, d_out)) return 0;
@@ -355,19 +365,22 @@ static void launch_forward(const LayerPlan& pl, const T* x, int d_in, const T* w
 
 template <typename T>
 int mlp_layers_fwd_t(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
-                     int n_hidden, int d_out, void* out, void* workspace, int B, int n, hipStream_t s) {
+                     int n_hidden, int d_out, void* out, void* workspace, int B, int n, hipStream_t s, void* stash) {
     LayerPlan pl;
     int rc = make_plan(pl, d_in, hidden, n_hidden, d_out);
     if (rc) return rc;
-    if (!workspace) return PACOH_EINVAL;
+    if (!workspace && !stash) return PACOH_EINVAL;
     const long R = (long)(B / P) * n;
     if (R > 0x3fffffffL || (long)B * n > 0x7fffffffL) return PACOH_ELIMIT;
-    const LayersWs w = layers_ws(pl, P, R, sizeof(T), false);
-    T* wp = (T*)workspace;
-    T* act = (T*)((char*)workspace + w.wp);
+    // stash: the packed weights and EVERY hidden layer's activations stay behind for the backward (mlp_layers_stash_bytes)
+    const LayersWs w = layers_ws(pl, P, R, sizeof(T), stash != nullptr);
+    void* base = stash ? stash : workspace;
+    T* wp = (T*)base;
+    T* act = (T*)((char*)base + w.wp);
     launch_pack<T>(pl, (const T*)theta, theta_stride, wp, P, s);
     T* H[LMAXL];
-    for (int l = 0; l + 1 < pl.n_layers; ++l) H[l] = act + (size_t)(l & 1) * P * R * pl.max_w;     // ping-pong
+    for (int l = 0; l + 1 < pl.n_layers; ++l)
+        H[l] = stash ? act + (size_t)P * R * pl.act_off[l] : act + (size_t)(l & 1) * P * R * pl.max_w;     // kept / ping-pong
     RowMap m = {P, n, (int)R, x_div};
     launch_forward<T>(pl, (const T*)x, d_in, wp, H, (T*)out, d_out, P, m, s);
     return launch_status();
@@ -376,7 +389,7 @@ int mlp_layers_fwd_t(const void* x, int x_div, const void* theta, long theta_str
 template <typename T>
 int mlp_layers_bwd_t(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden,
                      int n_hidden, int d_out, const void* g_out, void* d_theta, long d_theta_stride, int accumulate,
-                     void* workspace, int B, int n, hipStream_t s) {
+                     void* workspace, int B, int n, hipStream_t s, const void* stash) {
     LayerPlan pl;
     int rc = make_plan(pl, d_in, hidden, n_hidden, d_out);
     if (rc) return rc;
@@ -384,17 +397,18 @@ int mlp_layers_bwd_t(const void* x, int x_div, const void* theta, long theta_str
     const long R = (long)(B / P) * n;
     if (R > 0x3fffffffL || (long)B * n > 0x7fffffffL) return PACOH_ELIMIT;
     const LayersWs w = layers_ws(pl, P, R, sizeof(T), true);
-    T* wp = (T*)workspace;
-    T* act = (T*)((char*)workspace + w.wp);
+    // stash: the forward of the same inputs and parameters left the packed weights and the hidden activations there
+    T* wp = stash ? (T*)const_cast<void*>(stash) : (T*)workspace;
+    T* act = stash ? (T*)((char*)const_cast<void*>(stash) + w.wp) : (T*)((char*)workspace + w.wp);
     T* delta = (T*)((char*)workspace + w.wp + w.act);
     T* slab = (T*)((char*)workspace + w.wp + w.act + w.delta);
-    launch_pack<T>(pl, (const T*)theta, theta_stride, wp, P, s);
+    if (!stash) launch_pack<T>(pl, (const T*)theta, theta_stride, wp, P, s);
     RowMap m = {P, n, (int)R, x_div};
     const int L = pl.n_layers;
     T* H[LMAXL];
     for (int l = 0; l + 1 < L; ++l) H[l] = act + (size_t)P * R * pl.act_off[l];
-    // forward recompute up to the last hidden layer (nothing is saved by pacoh_mlp_fwd)
-    if (L > 1) {
+    // forward recompute up to the last hidden layer (unless the forward stashed its activations)
+    if (L > 1 && !stash) {
         const unsigned rb = (unsigned)((R + 63) / 64);
         for (int l = 0; l < L - 1; ++l) {
             const dim3 grid(rb, pl.outp[l] / 16, P);
@@ -441,18 +455,18 @@ int mlp_layers_bwd_t(const void* x, int x_div, const void* theta, long theta_str
 }
 
 int mlp_layers_fwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden, int n_hidden,
-                   int d_out, void* out, void* workspace, int B, int n, int dtype, hipStream_t s) {
+                   int d_out, void* out, void* workspace, int B, int n, int dtype, hipStream_t s, void* stash) {
     return dtype == PACOH_F32
-        ? mlp_layers_fwd_t<float>(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, workspace, B, n, s)
-        : mlp_layers_fwd_t<double>(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, workspace, B, n, s);
+        ? mlp_layers_fwd_t<float>(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, workspace, B, n, s, stash)
+        : mlp_layers_fwd_t<double>(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, out, workspace, B, n, s, stash);
 }
 
 int mlp_layers_bwd(const void* x, int x_div, const void* theta, long theta_stride, int P, int d_in, const int32_t* hidden, int n_hidden,
                    int d_out, const void* g_out, void* d_theta, long d_theta_stride, int accumulate, void* workspace, int B, int n,
-                   int dtype, hipStream_t s) {
+                   int dtype, hipStream_t s, const void* stash) {
     return dtype == PACOH_F32
-        ? mlp_layers_bwd_t<float>(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, accumulate, workspace, B, n, s)
-        : mlp_layers_bwd_t<double>(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, accumulate, workspace, B, n, s);
+        ? mlp_layers_bwd_t<float>(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, accumulate, workspace, B, n, s, stash)
+        : mlp_layers_bwd_t<double>(x, x_div, theta, theta_stride, P, d_in, hidden, n_hidden, d_out, g_out, d_theta, d_theta_stride, accumulate, workspace, B, n, s, stash);
 }
 
 }  // namespace pacoh
