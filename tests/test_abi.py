@@ -80,7 +80,7 @@ def test_argument_validation_returns_error_codes_without_launching(lib):
     assert lib.pacoh_mlp2_stash_bytes(20, 10, 20, 1, hidden, 4, 1, 2, 0) == 3 * 2 * 10 * 4 * 2048
     assert lib.pacoh_mlp2_stash_bytes(20, 10, 20, 1, hidden, 4, 1, 2, 1) > 0                  # fp64: the layer-by-layer path keeps packed weights + activations (round 6)
     hidden = (ctypes.c_int32 * 4)(128, 128, 128, 128)
-    assert lib.pacoh_mlp2_stash_bytes(20, 10, 20, 1, hidden, 4, 1, 2, 0) == 0
+    assert lib.pacoh_mlp2_stash_bytes(20, 10, 20, 1, hidden, 4, 1, 2, 0) > 0                  # 4 x 128: layer by layer, same (round 6; was 0)
 
 
 def test_host_side_address_sanitizer_shim():
