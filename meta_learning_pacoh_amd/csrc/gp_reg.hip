@@ -13,7 +13,12 @@ namespace pacoh {
 // wave per SIMD, and the compiler, knowing that, spread over 396 registers.  With the blocks consumed where they are produced
 // (gp_reg_body.h) the n = 128, f <= 2 kernel takes 244 registers and 4.8 KB: 0.982 -> 0.682 ms per 20 480 problems
 // (profiles/r05_gp_two_waves.txt).  f <= 4 at n = 128 would spill 200 registers at that budget and stays at one wave.
-#define GPR_MINW(NB, FP, BWD) ((NB) > 4 ? ((FP) == 2 || (NB) == 6 ? 2 : 1) : ((NB) == 4 && (FP) == 4 ? ((BWD) ? 2 : 3) : 4))
+#ifdef PACOH_GPR_W5      // A/B: five waves per SIMD for the n = 64, f <= 2 backward kernel (96 registers: 30 of them spilled)
+#define GPR_W64 5
+#else
+#define GPR_W64 4
+#endif
+#define GPR_MINW(NB, FP, BWD) ((NB) > 4 ? ((FP) == 2 || (NB) == 6 ? 2 : 1) : ((NB) == 4 && (FP) == 4 ? ((BWD) ? 2 : 3) : ((NB) == 4 && (BWD) ? GPR_W64 : 4)))
 template <int NB, int FP, bool BWD, bool HAS_OS = true>
 __global__ void __launch_bounds__(64, GPR_MINW(NB, FP, BWD)) gp_reg_kernel(GpMfmaArgs a) {
     constexpr int NP = 16 * NB;
