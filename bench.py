@@ -276,6 +276,7 @@ def main():
 
     leg, wl, elapsed = timed_leg(args.scaling, True)
     gpu_only = wl['gpu_only']() if ('gpu_only' in wl and world == 1) else None
+    device_noise = wl['device_noise']() if ('device_noise' in wl and world == 1) else None
     finite = leg['finite']
     ms_per_step = elapsed / args.steps * 1e3
     host_ms = leg['host_ms_per_step']
@@ -347,6 +348,8 @@ def main():
             roofline=roofline, kernel_rooflines=kernel_rooflines, step_flops=step_flops, gram=gram, pp=pp, others=others, cpu=cpu)
         if gpu_only is not None:
             out['gpu_ms_per_step_noise_resident'] = gpu_only      # (PACOH-VI: the step without the host's noise draw, _vi_gpu_only)
+        if device_noise is not None:
+            out['ms_per_step_device_noise'] = device_noise        # (PACOH-VI with noise='device': wl_ref_vi)
         out['predictive'] = predictive                    # (row A11 beside the LML: predictive_leg; None outside the default N = 1 run)
         print(json.dumps(out))
     if world > 1:
@@ -621,6 +624,8 @@ def other_config_leg(cfg, M, L, steps=256):
         # (ms_per_step above includes the host's per-step noise draw from torch's CPU generator -- the reference's stream; this is the
         #  same step replayed with the noise already resident: _vi_gpu_only)
         out['gpu_ms_per_step_noise_resident'] = gpu_only
+    if 'device_noise' in wl:
+        out['ms_per_step_device_noise'] = wl['device_noise']()
     del wl
     torch.cuda.empty_cache()
     if cfg == 5:
@@ -833,7 +838,23 @@ def wl_ref_vi(world, scaling, M, L):
     model = M.GPRegressionMetaLearnedVI(sinusoid_tasks(29, 20, 20), weight_prior_std=0.5, prior_factor=0.1, covar_module='NN',
                                         mean_module='NN', kernel_nn_layers=REF_LAYERS, mean_nn_layers=REF_LAYERS, random_seed=28,
                                         optimizer='Adam', lr=1e-3, lr_decay=0.98, svi_batch_size=10, cov_type='diag', task_batch_size=2)
+    def device_noise():
+        # the same learner with noise='device' (an option the reference does not have: the reparameterisation noise from the device
+        # generator, nothing drawn on the host) as meta_fit runs it: what the step costs once the host's stream is out of the way
+        m2 = M.GPRegressionMetaLearnedVI(sinusoid_tasks(29, 20, 20), weight_prior_std=0.5, prior_factor=0.1, covar_module='NN',
+                                         mean_module='NN', kernel_nn_layers=REF_LAYERS, mean_nn_layers=REF_LAYERS, random_seed=28,
+                                         optimizer='Adam', lr=1e-3, lr_decay=0.98, svi_batch_size=10, cov_type='diag', task_batch_size=2,
+                                         noise='device')
+        for n in (64, 128, 64):
+            m2._train_steps(n)
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m2._train_steps(256)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 256 * 1e3
+        return round(ms, 5) if bool(torch.isfinite(m2.posterior).all()) else None
     return dict(run=model._train_steps, evals_per_step=20, dtype='f32', mode=lambda: _mode(model), gpu_only=_vi_gpu_only(model),
+                device_noise=device_noise,
                 finite=lambda: bool(torch.isfinite(model.posterior).all()),
                 metric='task-GP LML+grad evals/sec (PACOH-VI at the reference launcher\'s defaults: 2 tasks x 10 samples per step, n_ctx=20)',
                 flops=_ref_launcher_flops(10),

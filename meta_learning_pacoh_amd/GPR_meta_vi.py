@@ -57,13 +57,19 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
                  prior_factor=0.01, weight_prior_std=0.5, bias_prior_std=3.0,
                  covar_module='NN', mean_module='NN', mean_nn_layers=(32, 32), kernel_nn_layers=(32, 32),
                  optimizer='Adam', lr=1e-3, lr_decay=1.0, svi_batch_size=10, cov_type='diag',
-                 task_batch_size=-1, normalize_data=True, random_seed=None):
-        """Arguments as in the reference (GPR_meta_vi.py:16-44)."""
+                 task_batch_size=-1, normalize_data=True, random_seed=None, noise='host'):
+        """Arguments as in the reference (GPR_meta_vi.py:16-44), plus one it does not have:
+        noise: 'host' (default) draws the reparameterisation noise of every rsample from the torch CPU generator -- the reference's
+               stream, value for value; on one host thread that is ~2.3 ns per number, which BOUNDS the step wherever the GPU needs less
+               than S x D x 2.3 ns (the launchers' shape: 0.156 ms per step against 0.051 ms of GPU work).  'device' fills the same
+               buffers from the device's generator instead (torch.manual_seed seeds it too; same distribution, another stream):
+               meta_fit, predict and eval_datasets then draw nothing on the host."""
         super().__init__(normalize_data, random_seed)
         assert mean_module in ['NN', 'constant', 'zero'] and covar_module in ['NN', 'SE']
         assert optimizer in ['Adam', 'SGD']
         assert cov_type in ['diag', 'full']
-        self.cov_type = cov_type
+        assert noise in ['host', 'device']
+        self.cov_type, self.noise = cov_type, noise
         self.num_iter_fit, self.prior_factor, self.feature_dim = num_iter_fit, prior_factor, feature_dim
         self.weight_prior_std, self.bias_prior_std = weight_prior_std, bias_prior_std
         self.svi_batch_size, self.optimizer_name = svi_batch_size, optimizer
@@ -93,10 +99,13 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
     def _rsample(self, n):
         """Normal(loc, exp(scale)).rsample((n,)): eps from the torch CPU generator (reference stream);
         returns (theta[n,D], eps[n,D], log q(theta)[n])"""
-        up = getattr(self, '_eps_up', None)
-        if up is None:
-            up = self._eps_up = AsyncUploader(self.device, self.dtype)
-        eps = up.upload(standard_normal(n, self.layout.D))
+        if self.noise == 'device':
+            eps = torch.empty(n, self.layout.D, dtype=self.dtype, device=self.device).normal_()
+        else:
+            up = getattr(self, '_eps_up', None)
+            if up is None:
+                up = self._eps_up = AsyncUploader(self.device, self.dtype)
+            eps = up.upload(standard_normal(n, self.layout.D))
         theta, log_q = L.vi_sample(self.posterior, eps, full=self.cov_type == 'full')
         return theta, eps, log_q
 
@@ -187,8 +196,9 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
             # margin of 10 % on the slower hosts: cfg #4 read 0.42 or 0.49 ms per step depending on the box)
             k = first_chunk(n_steps, self._feed.chunk) if k == 0 else min(n_steps, self._feed.chunk, (k + k // 2 + 3) // 4 * 4)
             idx_rows, sc_rows = self._draw_steps(k, self.lr_scheduler, self.opt_step + 1)
-            # the reference's stream: one rsample per step, drawn straight into the pinned staging rows
-            self._feed.upload(idx_rows, sc_rows, lambda j, out: standard_normal(S, D, out=out))
+            # the reference's stream: one rsample per step, drawn straight into the pinned staging rows (noise='device': the chunk's
+            # rows filled by one launch of the device generator, nothing drawn or copied on the host)
+            self._feed.upload(idx_rows, sc_rows, 'device' if self.noise == 'device' else (lambda j, out: standard_normal(S, D, out=out)))
             if graphed and self._graphs is None:
                 self._build_graphs()                      # (captured with real operands in the feed; state and counter are restored)
             if graphed:
@@ -258,8 +268,11 @@ class GPRegressionMetaLearnedVI(_RandomGPLearner):
             return self.loc.reshape(1, -1).contiguous(), False, False
 
         def draw(T):
-            eps = torch.cat([standard_normal(n_posterior_samples, self.layout.D) for _ in range(T)])
-            theta, _ = L.vi_sample(self.posterior, eps.to(self.dtype).to(self.device), full=self.cov_type == 'full')
+            if self.noise == 'device':
+                eps = torch.empty(T * n_posterior_samples, self.layout.D, dtype=self.dtype, device=self.device).normal_()
+            else:
+                eps = torch.cat([standard_normal(n_posterior_samples, self.layout.D) for _ in range(T)]).to(self.dtype).to(self.device)
+            theta, _ = L.vi_sample(self.posterior, eps, full=self.cov_type == 'full')
             return theta
         return draw, True, True
 

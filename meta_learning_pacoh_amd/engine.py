@@ -191,7 +191,8 @@ class StepFeed:
 
     def upload(self, idx_rows, sc_rows, aux_rows=None):
         """idx_rows: int array [k, tb]; sc_rows: k rows of L.step_scalars(); aux_rows: tensor [k, ...], k tensors [...], a callable
-        (j, out_row) filling the pinned staging row of step j in place, or None; resets the counter"""
+        (j, out_row) filling the pinned staging row of step j in place, 'device' (standard normal rows drawn by the device generator,
+        no host copy), or None; resets the counter"""
         k = len(sc_rows)
         assert 0 < k <= self.chunk
         q = self._slot
@@ -214,7 +215,11 @@ class StepFeed:
             self.idx_all[:kk].copy_(self._h_idx[q][:kk], non_blocking=True)
         if self.aux_all is not None:
             ha = self._n_aux[q]
-            if callable(aux_rows):                       # aux_rows(j, out): writes step j's payload straight into the staging row
+            on_device = isinstance(aux_rows, str)
+            if on_device:                                # 'device': standard normal rows from the device generator (PACOH-VI, noise='device')
+                assert aux_rows == 'device'
+                self.aux_all[:kk].normal_()
+            elif callable(aux_rows):                     # aux_rows(j, out): writes step j's payload straight into the staging row
                 for j in range(k):
                     aux_rows(j, self._h_aux[q][j])
             elif torch.is_tensor(aux_rows):              # (any device / dtype / requires_grad: what copy_ used to accept)
@@ -222,8 +227,9 @@ class StepFeed:
             else:                                        # one tensor per step
                 for j, row in enumerate(aux_rows):
                     ha[j] = row.detach().to('cpu', self._h_aux[q].dtype).numpy().reshape(ha[j].shape)
-            ha[k:kk] = ha[k - 1]
-            self.aux_all[:kk].copy_(self._h_aux[q][:kk], non_blocking=True)
+            if not on_device:
+                ha[k:kk] = ha[k - 1]
+                self.aux_all[:kk].copy_(self._h_aux[q][:kk], non_blocking=True)
         self.ctr.fill_(-1 if self.sc2 is not None else 0)      # (pipelined step: the first forward makes it 0 -- prologue())
         self._ev[q] = self._ev[q] or torch.cuda.Event()
         self._ev[q].record()

@@ -198,6 +198,9 @@ def test_bench_line_contract():
         assert abs(leg['value'] - evals_of[key] / (leg['ms_per_step'] * 1e-3)) <= 2e-3 * leg['value'], key
         assert 0 < leg['dominant_kernel']['algorithmic_frac'] < 1, key
     assert oc['ref_svgd']['cpu_baseline']['value'] > 0 and oc['ref_vi']['cpu_baseline']['value'] > 0 and oc['ref_map']['cpu_baseline']['value'] > 0
+    # PACOH-VI at the launcher's shape: host-noise step >= the same step with the noise resident; the noise='device' step in between
+    assert 0 < oc['ref_vi']['gpu_ms_per_step_noise_resident'] <= oc['ref_vi']['ms_per_step']
+    assert 0 < oc['ref_vi']['ms_per_step_device_noise'] < oc['ref_vi']['ms_per_step']
     assert oc['cfg5']['dtype'] == 'f64' and oc['cfg1']['dtype'] == oc['cfg2']['dtype'] == oc['cfg4']['dtype'] == 'f32'
     # ... and the marginal posterior predictive at the context sizes of cfg #3 / cfg #4 (row A11)
     pr = d['predictive']

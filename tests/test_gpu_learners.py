@@ -1123,3 +1123,71 @@ def test_vi_fused_update_equals_the_launch_sequence_it_replaces(M, monkeypatch):
         out.append((m.posterior.clone(), float(loss)))
     assert float((out[0][0] - out[1][0]).abs().max()) < 2e-5 * float(out[0][0].abs().max())
     assert abs(out[0][1] - out[1][1]) < 1e-5 * abs(out[0][1])
+
+
+@pytest.mark.parametrize('graph', ['0', '1'])
+def test_vi_device_noise_changes_the_noise_source_and_nothing_else(M, graph, monkeypatch):
+    """noise='device' (not in the reference: the reparameterisation noise from the device generator instead of torch's CPU stream,
+    which bounds the step at the launchers' shape): the rows the device generator wrote, fed to a noise='host' learner through its
+    own staging path, must give the same posterior bit for bit; the rows are standard normal; two seeded runs agree"""
+    import meta_learning_pacoh_amd.GPR_meta_vi as V
+    monkeypatch.setenv('PACOH_GRAPH', graph)
+    tasks = O.sinusoid_tasks_nd(8, 10, 1, seed0=61)
+    kw = dict(svi_batch_size=6, task_batch_size=3, lr=1e-2, lr_decay=0.9, mean_nn_layers=(16, 16), kernel_nn_layers=(16, 16), random_seed=11)
+
+    def run_device(record):
+        m = M.GPRegressionMetaLearnedVI(tasks, noise='device', **kw)
+        m._setup_step(m._local_batch_size())
+        feed_upload = m._feed.upload
+
+        def spy(idx_rows, sc_rows, aux_rows=None):
+            feed_upload(idx_rows, sc_rows, aux_rows)
+            assert aux_rows == 'device'
+            record.append(m._feed.aux_all[:len(sc_rows)].cpu().clone())
+        m._feed.upload = spy
+        loss = m.meta_fit(verbose=False, n_iter=41, log_period=20)
+        return m.posterior.clone(), float(loss)
+
+    rows, rows2 = [], []
+    post_a, loss_a = run_device(rows)
+    post_b, loss_b = run_device(rows2)
+    assert torch.equal(post_a, post_b) and loss_a == loss_b                      # seeded: the device generator is seeded too
+    assert np.isfinite(loss_a) and bool(torch.isfinite(post_a).all())
+    eps = torch.cat([r.reshape(-1) for r in rows]).double()
+    assert eps.numel() == 41 * 6 * post_a.shape[1]
+    assert abs(float(eps.mean())) < 0.02 and abs(float(eps.std()) - 1.0) < 0.02
+    assert abs(float((eps ** 3).mean())) < 0.05 and abs(float((eps ** 4).mean()) - 3.0) < 0.1
+
+    # the same rows through the host path
+    flat = [row for r in rows for row in r]                                       # one [S, D] row per step, in step order
+    it = iter(flat)
+
+    def replayed(n, D, out=None):
+        row = next(it)
+        assert row.shape == (n, D)
+        if out is not None:
+            out.copy_(row)
+            return out
+        return row.clone()
+    monkeypatch.setattr(V, 'standard_normal', replayed)
+    m = M.GPRegressionMetaLearnedVI(tasks, noise='host', **kw)
+    loss_h = m.meta_fit(verbose=False, n_iter=41, log_period=20)
+    assert torch.equal(m.posterior, post_a) and float(loss_h) == loss_a
+
+
+def test_vi_device_noise_predict_and_eval(M):
+    """predict / eval_datasets with noise='device': posterior samples from the device generator -- finite, calibrated like the
+    host-noise learner's (same posterior, another sample of it)"""
+    train, test = demo_data()
+    out = []
+    for noise in ('host', 'device'):
+        m = M.GPRegressionMetaLearnedVI(train, noise=noise, svi_batch_size=5, task_batch_size=4, lr=5e-3, mean_nn_layers=(16, 16),
+                                        kernel_nn_layers=(16, 16), random_seed=3, num_iter_fit=60)
+        m.meta_fit(verbose=False, log_period=30)
+        x_c, y_c, x_t, y_t = test[0]
+        mu, std = m.predict(x_c, y_c, x_t, n_posterior_samples=40)
+        assert np.all(np.isfinite(mu)) and np.all(np.isfinite(std)) and np.all(std > 0) and mu.shape == std.shape and mu.shape[0] == x_t.shape[0]
+        ll, rmse, calib = m.eval_datasets(test, n_posterior_samples=40)
+        assert np.isfinite(ll) and np.isfinite(rmse) and np.isfinite(calib)
+        out.append((ll, rmse))
+    assert abs(out[0][1] - out[1][1]) < 0.25 * max(out[0][1], out[1][1])         # same model class, 60 steps: the same ballpark
