@@ -440,13 +440,24 @@ __global__ void __launch_bounds__(256) vi_update_kernel(T* __restrict__ post, co
         const T pscale = prior_factor / (sdv * sdv);
         const T lconst = t_log<T>(sdv) + T(0.9189385332046727);
         T gl = 0, gs = 0;
-        for (int s_ = 0; s_ < S; ++s_) {
-            const long q = (long)s_ * D + d;
-            const T dv = theta[q] - md, zv = dv / sdv;
-            lp += T(-0.5) * zv * zv - lconst;
-            const T st = pref * score[q] - pscale * dv;
-            gl += st;
-            gs += st * sig * eps[q] + prior_factor;
+        // (twelve samples per trip, their loads requested together: one sample per trip was one memory round trip per sample)
+        constexpr int U = 12;
+        for (int s0 = 0; s0 < S; s0 += U) {
+            T tq[U], sq[U], eq[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long q = (long)(s0 + u < S ? s0 + u : S - 1) * D + d;
+                tq[u] = theta[q]; sq[u] = score[q]; eq[u] = eps[q];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (s0 + u >= S) break;
+                const T dv = tq[u] - md, zv = dv / sdv;
+                lp += T(-0.5) * zv * zv - lconst;
+                const T st = pref * sq[u] - pscale * dv;
+                gl += st;
+                gs += st * sig * eq[u] + prior_factor;
+            }
         }
         const T decay_mul = sc[4], step_size = sc[5], bc2_sqrt = sc[6], epsv = sc[7];
 #pragma unroll
@@ -472,14 +483,32 @@ __global__ void __launch_bounds__(256) vi_update_kernel(T* __restrict__ post, co
         last_s = atomicAdd(ticket, 1u) == gridDim.x - 1;
     }
     __syncthreads();
-    if (last_s && threadIdx.x == 0) {
+    if (last_s) {
+        // the same sums in the same order as one thread walking the three arrays -- but the values come in through 256 parallel loads
+        // per trip and are added up out of LDS: as dependent global loads by one thread (26 partials + 2 x 10 samples at the launchers'
+        // shape) the walk was ~36 memory round trips, most of this launch's 11 us
+        __shared__ T stage[256];
         __threadfence();
         T tot = 0, lq = 0;
-        for (unsigned k = 0; k < gridDim.x; ++k) tot += ((volatile T*)partial)[k];
+        for (unsigned k0 = 0; k0 < gridDim.x; k0 += 256) {
+            const unsigned cnt = gridDim.x - k0 < 256u ? gridDim.x - k0 : 256u;
+            if (threadIdx.x < cnt) stage[threadIdx.x] = __hip_atomic_load(partial + k0 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (threadIdx.x == 0) for (unsigned k = 0; k < cnt; ++k) tot += stage[k];
+            __syncthreads();
+        }
         tot *= prior_factor;
-        for (int s_ = 0; s_ < S; ++s_) { tot += pref * lik[s_]; lq += log_q[s_]; }
-        *loss = (prior_factor * lq - tot) / T(S);
-        *ticket = 0;                                   // (ready for the next launch / replay)
+        for (int s0 = 0; s0 < S; s0 += 128) {
+            const int cnt = S - s0 < 128 ? S - s0 : 128;
+            if ((int)threadIdx.x < cnt) { stage[threadIdx.x] = lik[s0 + threadIdx.x]; stage[128 + threadIdx.x] = log_q[s0 + threadIdx.x]; }
+            __syncthreads();
+            if (threadIdx.x == 0) for (int k = 0; k < cnt; ++k) { tot += pref * stage[k]; lq += stage[128 + k]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            *loss = (prior_factor * lq - tot) / T(S);
+            *ticket = 0;                               // (ready for the next launch / replay)
+        }
     }
 }
 
@@ -572,8 +601,19 @@ __global__ void __launch_bounds__(256) step_begin_kernel(StepBeginArgs<T> a) {
             }
         }
     } else if (blk < a.tb + 2 + a.aux_blocks) {
+        // (2 048 entries per block and trip, eight per thread, loaded before any is stored: the members are not __restrict__, and as a
+        //  load-store loop every entry of a thread was a memory round trip of its own -- most of this launch's 15 us at PACOH-VI's
+        //  launcher shape, 10 x 6 566 noise entries in 33 blocks)
         const int nb = a.aux_blocks;
-        for (long q = (long)(blk - a.tb - 2) * 256 + threadIdx.x; q < a.n_aux; q += (long)nb * 256) a.aux_out[q] = a.aux_all[row * a.n_aux + q];
+        const T* __restrict__ src = a.aux_all + row * a.n_aux;
+        T* __restrict__ dst = a.aux_out;
+        for (long q0 = (long)(blk - a.tb - 2) * 2048; q0 < a.n_aux; q0 += (long)nb * 2048) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const long q = q0 + threadIdx.x + 256 * u; v[u] = src[q < a.n_aux ? q : a.n_aux - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const long q = q0 + threadIdx.x + 256 * u; if (q < a.n_aux) dst[q] = v[u]; }
+        }
     } else if (a.vi_post == nullptr || blk < a.tb + 2 + a.aux_blocks + (a.sv_X ? a.sv_P * a.sv_P : 0)) {
         // the particles do not change before the step's update: their distance matrix (and the snapshot the in-place update reads)
         // can be had here, a launch earlier and off the path behind the all-reduce
@@ -584,16 +624,29 @@ __global__ void __launch_bounds__(256) step_begin_kernel(StepBeginArgs<T> a) {
         const T* eps = a.aux_all + row * a.n_aux + (long)s_ * D;
         const T HALF_LOG2PI = T(0.9189385332046727);
         T acc = 0;
-        for (int d = threadIdx.x; d < D; d += 256) {
-            const T e = eps[d], sc = a.vi_post[D + d];
-            const T th = a.vi_post[d] + t_exp<T>(sc) * e;
-            a.vi_theta[(long)s_ * D + d] = th;
-            acc += T(-0.5) * e * e - sc - HALF_LOG2PI;
-            if (a.ls) {
-                if (d == a.off_noise) a.noise[s_] = softplus_t<T>(th) + a.noise_floor;
-                else if (a.os && d == a.off_os) a.os[s_] = softplus_t<T>(th);
-                else if (a.tie) { if (d == a.off_ls) { const T v1 = softplus_t<T>(th); for (int e2 = 0; e2 < a.f; ++e2) a.ls[s_ * a.f + e2] = v1; } }
-                else if (d >= a.off_ls && d < a.off_ls + a.f) a.ls[s_ * a.f + (d - a.off_ls)] = softplus_t<T>(th);
+        // (sixteen entries per thread and trip, all their loads requested before the first is used: as one entry per trip the 26 trips
+        //  of the launchers' D = 6 566 were 26 dependent memory round trips -- 15 us for a launch of ten such blocks)
+        constexpr int U = 16;
+        for (int d0 = threadIdx.x; d0 < D; d0 += 256 * U) {
+            T e[U], sc[U], lc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int d = d0 + 256 * u, dc = d < D ? d : D - 1;
+                e[u] = eps[dc]; sc[u] = a.vi_post[D + dc]; lc[u] = a.vi_post[dc];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int d = d0 + 256 * u;
+                if (d >= D) break;
+                const T th = lc[u] + t_exp<T>(sc[u]) * e[u];
+                a.vi_theta[(long)s_ * D + d] = th;
+                acc += T(-0.5) * e[u] * e[u] - sc[u] - HALF_LOG2PI;
+                if (a.ls) {
+                    if (d == a.off_noise) a.noise[s_] = softplus_t<T>(th) + a.noise_floor;
+                    else if (a.os && d == a.off_os) a.os[s_] = softplus_t<T>(th);
+                    else if (a.tie) { if (d == a.off_ls) { const T v1 = softplus_t<T>(th); for (int e2 = 0; e2 < a.f; ++e2) a.ls[s_ * a.f + e2] = v1; } }
+                    else if (d >= a.off_ls && d < a.off_ls + a.f) a.ls[s_ * a.f + (d - a.off_ls)] = softplus_t<T>(th);
+                }
             }
         }
         acc = subwave_sum<T>(acc, 64);
