@@ -413,7 +413,8 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
     }
     if (mt_plan(ka) != PACOH_OK) return PACOH_ELIMIT;        // (needs flat0[]: the slab-relative entries)
     const int Dmax = D;                                 // (the index map covers the whole parameter row)
-    for (int k = 0; k < a.nets; ++k) if (plan_only != 1 && ka.flat0[k] + ka.dnet[k] > D) return PACOH_EINVAL;
+    for (int k = 0; k < a.nets; ++k)
+        if (plan_only != 1 && (ka.flat0[k] < 0 || ka.flat0[k] + ka.dnet[k] > D || (plan_only == 0 && ka.flat0[k] + ka.dnet[k] > d_theta_stride))) return PACOH_EINVAL;
     const size_t o_img = carve((size_t)a.DP * 4), o_map = carve(multi ? 256 : (size_t)Dmax * 4);      // (multi: o_img holds the gather map)
     const size_t B_ = (size_t)tb_total * P;
     const size_t o_lml = carve(B_ * 4), o_dls = carve(B_ * f * 4), o_dos = carve(B_ * 4), o_dnz = carve(B_ * 4), o_dc = carve(B_ * 4),

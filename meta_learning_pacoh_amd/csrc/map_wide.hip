@@ -468,7 +468,8 @@ int map_wide_launch(const void* theta, const void* bx, const void* by, const int
         if (!workspace || workspace_bytes < off) return PACOH_EINVAL;
         return hipMemsetAsync((char*)workspace + o_sync, 0, 8, stream) == hipSuccess ? PACOH_OK : PACOH_ELAUNCH;
     }
-    for (int k = 0; k < a.nets; ++k) if (a.net[k].flat0 + a.net[k].dnet > D) return PACOH_EINVAL;
+    for (int k = 0; k < a.nets; ++k)
+        if (a.net[k].flat0 < 0 || a.net[k].flat0 + a.net[k].dnet > D || a.net[k].flat0 + a.net[k].dnet > d_theta_stride) return PACOH_EINVAL;
     if (!workspace || workspace_bytes < off) return PACOH_EINVAL;
     char* ws = (char*)workspace;
     a.theta = (const float*)theta;

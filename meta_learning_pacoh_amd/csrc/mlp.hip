@@ -481,6 +481,17 @@ extern "C" int pacoh_map_task_setup(const void* theta, int D, int n, int d, int 
                            kernel_hidden, n_kernel_hidden, features_of(f), nullptr, nullptr, nullptr, workspace, workspace_bytes, nullptr, 0, &none, 2,
                            nullptr, D, (hipStream_t)stream);      // (no parameter image to build: the wide kernel reads theta itself)
 }
+// every entry of a parameter row the task kernels and their reduction tail read or WRITE (d_theta, and theta itself with the inline
+// optimizer step) must lie inside the row: a wrong layout from a direct C caller must be an error, not a device write out of bounds
+static bool task_offsets_ok(long row, int off_ls, int f, int off_os, int off_noise, int mean_mode, int off_mean, int kernel_nn, int off_kernel) {
+    auto in_row = [row](long lo, long len) { return lo >= 0 && len >= 0 && lo + len <= row; };
+    if (!in_row(off_ls, features_of(f)) || !in_row(off_noise, 1) || (off_os >= 0 && !in_row(off_os, 1))) return false;
+    if (mean_mode == PACOH_MEAN_CONST && !in_row(off_mean, 1)) return false;
+    if (mean_mode == PACOH_MEAN_VECTOR && !in_row(off_mean, 1)) return false;      // (the networks' extents: map_task_launch / map_wide_launch)
+    if (kernel_nn && !in_row(off_kernel, 1)) return false;
+    return true;
+}
+
 extern "C" int pacoh_map_task_step(const void* theta, long theta_stride, const void* batch_x, const void* batch_y, const int32_t* batch_n_valid,
                                    int n, int d, int tb, int mean_mode, int off_mean, const int32_t* mean_hidden, int n_mean_hidden,
                                    int kernel_nn, int off_kernel, const int32_t* kernel_hidden, int n_kernel_hidden, int f,
@@ -494,6 +505,8 @@ extern "C" int pacoh_map_task_step(const void* theta, long theta_stride, const v
         return PACOH_EINVAL;
     if (opt && (!adam_inline_ok(opt, 1, lik) || opt->n_seg < 1)) return PACOH_EINVAL;
     if (opt && opt->next && !step_next_ok(opt->next)) return PACOH_EINVAL;
+    if (!task_offsets_ok(theta_stride < d_theta_stride ? theta_stride : d_theta_stride, off_ls, f, off_os, off_noise, mean_mode, off_mean, kernel_nn,
+                         off_kernel)) return PACOH_EINVAL;
     HyperBwdArgs<float> tail = {(const float*)theta, theta_stride, 1, tb, off_ls, features_of(f), off_os, off_noise,
                                 mean_mode == PACOH_MEAN_CONST ? off_mean : -1, nullptr, nullptr, nullptr, nullptr, (float*)d_theta, d_theta_stride,
                                 nullptr, (float*)lik, (float)lik_scale, nullptr, fail_flag, 0, nullptr, 0, nullptr,
@@ -546,6 +559,8 @@ extern "C" int pacoh_svgd_task_step(const void* theta, long theta_stride, int P,
         (os == nullptr) != (off_os < 0) || theta_stride <= 0) return PACOH_EINVAL;
     if ((svgd_X == nullptr) != (svgd_workspace == nullptr) || (svgd_X && svgd_D <= 0) || (want_bandwidth && !svgd_workspace)) return PACOH_EINVAL;
     if (want_bandwidth && P > 64) return PACOH_ELIMIT;
+    if (!task_offsets_ok(theta_stride < d_theta_stride ? theta_stride : d_theta_stride, off_ls, f, off_os, off_noise, mean_mode, off_mean, kernel_nn,
+                         off_kernel)) return PACOH_EINVAL;
     float* d2 = (float*)svgd_workspace;
     SvgdDistTail<float> sv = {(const float*)svgd_X, d2, d2 ? d2 + P * P : nullptr, P, svgd_D, (long*)counter};
     HyperBwdArgs<float> tail = {(const float*)theta, theta_stride, P, tb, off_ls, features_of(f), off_os, off_noise,

@@ -122,6 +122,18 @@ int main() {
         EXPECT(pacoh_svgd_task_step(fake, 2534, 10, fake, fake, nullptr, 20, 1, 2, PACOH_MEAN_VECTOR, 0, hm, 2, 1, 1200, hm, 2, 2, fake, nullptr, fake,
                                     2530, -1, 2533, fake, 2534, fake, 1.0, nullptr, fake, 1 << 20, nullptr, nullptr, 0, nullptr, 0, PACOH_F64,
                                     nullptr) == PACOH_ELIMIT);
+        // hyper-parameter / network offsets beyond the parameter row: an error, not a device write out of bounds
+        EXPECT(pacoh_svgd_task_step(fake, 2534, 10, fake, fake, nullptr, 20, 1, 2, PACOH_MEAN_VECTOR, 0, hm, 2, 1, 1200, hm, 2, 2, fake, nullptr, fake,
+                                    2533, -1, 2533, fake, 2534, fake, 1.0, nullptr, fake, 1 << 20, nullptr, nullptr, 0, nullptr, 0, PACOH_F32,
+                                    nullptr) == PACOH_EINVAL);                                                                       // off_ls + f > row
+        EXPECT(pacoh_svgd_task_step(fake, 2534, 10, fake, fake, nullptr, 20, 1, 2, PACOH_MEAN_VECTOR, 0, hm, 2, 1, 1200, hm, 2, 2, fake, nullptr, fake,
+                                    2530, -1, 2533, fake, 2000, fake, 1.0, nullptr, fake, 1 << 20, nullptr, nullptr, 0, nullptr, 0, PACOH_F32,
+                                    nullptr) == PACOH_EINVAL);                                                                       // d_theta rows shorter than the offsets
+        EXPECT(pacoh_svgd_task_step(fake, 2534, 10, fake, fake, nullptr, 20, 1, 2, PACOH_MEAN_VECTOR, -4, hm, 2, 1, 1200, hm, 2, 2, fake, nullptr, fake,
+                                    2530, -1, 2533, fake, 2534, fake, 1.0, nullptr, fake, 1 << 20, nullptr, nullptr, 0, nullptr, 0, PACOH_F32,
+                                    nullptr) == PACOH_EINVAL);                                                                       // negative network offset
+        EXPECT(pacoh_map_task_step(fake, 2000, fake, fake, nullptr, 32, 1, 256, PACOH_MEAN_VECTOR, 0, hm, 2, 0, -1, nullptr, 0, 1, fake, nullptr, fake,
+                                   1990, -1, 2000, fake, 2000, nullptr, 1.0, nullptr, fake, 1 << 20, nullptr, PACOH_F32, nullptr) == PACOH_EINVAL);   // off_noise == row
         std::free(hm); std::free(hk);
     }
     EXPECT(pacoh_gp_lml_fwd(nullptr, 1, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 4, 1, 16, 2,
