@@ -381,9 +381,9 @@ __device__ __forceinline__ void mp_adam_entry(float* __restrict__ th, float* __r
 // (r, g) then holds columns 4 g .. 4 g + 3 of row r -- four consecutive entries of the parameter image, so that parameters, both
 // moments and the trained-flags move as one 16-byte LDS access each and the update runs without a branch per entry (a tile's
 // AdamW was 28 dword accesses and four exec-mask branches per lane in the row-per-register orientation).
-// bias (out): flags bit 3 -- this tile also sums the layer's bias gradient of its 16 rows, sum_p d_out[p][j]: a second accumulator
-// with the constant 1 as the A operand and the SAME B operand, so every lane (r, .) ends up holding the sum of row j = r.  (A task of
-// its own per layer -- a wave reading the column again, one entry per lane -- made 20 tasks of 16 at demo.py's shape: a second round.)
+// bias (out): flags bit 3 -- this tile also sums the layer's bias gradient of its 16 rows, sum_p d_out[p][j], from the B operands it
+// loads anyway: every lane (r, .) ends up holding the sum of row j = r.  (A task of its own per layer -- a wave reading the column
+// again, one entry per lane -- made 20 tasks of 16 at demo.py's shape: a second round.)
 __device__ __forceinline__ f32x4 mp_wgrad_acc(const int4 d0, const int4 d1, const int4 d2, const int4 d3, const float* __restrict__ lds,
                                               int a0_off, int pts, int r, int g, float& bias) {
     const int S = d0.y, steps = (pts + 3) >> 2, s_d = d1.x;      // (pts: the caller's actual point count, wave-uniform)
@@ -392,14 +392,17 @@ __device__ __forceinline__ f32x4 mp_wgrad_acc(const int4 d0, const int4 d1, cons
     const float* dp = lds + d0.w + (jok ? r : 0) + g * s_d;                              // d_out[4 ks + g][16 J + r]
     const float* ap = lds + d1.y + ((d3.x & 2) ? a0_off : 0) + r + g * S;               // a[4 ks + g][16 I + r]
     const int dstep = 4 * s_d, astep = 4 * S;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     MP_STAMP();
     // every step but the last has four valid points; the last is clamped and masked (padding points would enter the sums)
+    // (the bias sums: this phase is bound by the instruction issue of ONE compute unit -- 16 waves in step -- and its matrix pipes; a
+    //  second product per step with the constant 1 as A operand cost more of both than a vector add per step and two cross-row adds)
+    float bsum = 0.0f;
     if (with_bias) {
 #pragma unroll 4
         for (int ks = 0; ks + 1 < steps; ++ks) {
             const float dv = jok ? *dp : 0.0f;
-            acc = mfma_(*ap, dv, acc); acc1 = mfma_(1.0f, dv, acc1);
+            acc = mfma_(*ap, dv, acc); bsum += dv;
             ap += astep; dp += dstep;
         }
     } else {
@@ -412,10 +415,11 @@ __device__ __forceinline__ f32x4 mp_wgrad_acc(const int4 d0, const int4 d1, cons
         const float av = ap[ok ? 0 : -back * S], dv = dp[ok ? 0 : -back * s_d];
         const float dm = ok && jok ? dv : 0.0f;
         acc = mfma_(ok ? av : 0.0f, dm, acc);
-        if (with_bias) acc1 = mfma_(1.0f, dm, acc1);
+        bsum += dm;
     }
     MP_STAMP();
-    bias = acc1[0];
+    bsum += __shfl_xor(bsum, 16, 64); bsum += __shfl_xor(bsum, 32, 64);                    // over the four lane rows: every lane (r, .) holds row r's sum
+    bias = bsum;
     return acc;
 }
 

@@ -26,6 +26,7 @@
 // Phases per iteration for L hidden layers: L + 1 forward, GP, L + 1 backward: 2 L + 3 workgroup barriers.
 
 #include "map_net.h"
+#include <type_traits>
 
 namespace pacoh {
 namespace {
@@ -122,21 +123,47 @@ __global__ void __launch_bounds__(MP_NT) map_persist_kernel(MpArgs a) {
     if (t == 0 && max_nl > 0) mp_plan(a, ltab, tasks, ntask);
     __syncthreads();
     const int slots = a.slots;
-    // task q of phase ph -> the wave's tile
-    auto run_phase = [&](int ph, int a0_off, const MpAdam& ad) {
-        const int nt = sgi(ntask[ph]);
-        // task q of the first 16 runs on wave q, later rounds from the last wave down: the tasks are sorted by weight (mp_plan), so
-        // a second task goes to a wave whose first one was light
-        for (int rd = 0; rd * NW < nt; ++rd) {
+    // task q of phase ph -> the wave's tile.  The table does not change during a launch and wave w's first task of a phase is always
+    // task w: its descriptor is read and made scalar ONCE, in front of the iteration loop (as four LDS reads and their
+    // v_readfirstlane per phase and iteration the decode was ~700 cycles at the head of every phase, right behind a barrier)
+    auto run_task = [&](const int4 d0, const int4 d1, const int4 d2, const int4 d3, int a0_off, const MpAdam& ad) {
+        const int kind = sgi(d0.x);
+        const bool w32 = sgi(d3.x) & 4;
+        if (kind == MP_FWD) { if (w32) mp_fwd_chain32(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, a0_off, r16, g4); else mp_fwd_chain(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, a0_off, r16, g4); }
+        else if (kind == MP_DELTA) { if (w32) mp_delta_chain32(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, r16, g4); else mp_delta_chain(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, r16, g4); }
+        else if (kind == MP_WGRAD) mp_wgrad_tile(d0, d1, d2, d3, th, mm, vv, flat, lds, a0_off, pts, r16, g4, ad);
+    };
+    int4 pre[3][4];
+    bool has[3];
+    int ntk[3];
+#pragma unroll
+    for (int ph = 0; ph < 3; ++ph) {
+        ntk[ph] = max_nl > 0 ? sgi(ntask[ph]) : 0;
+        has[ph] = wave < ntk[ph];
+        const int4* e = reinterpret_cast<const int4*>(tasks + ph * slots + (has[ph] ? wave : 0));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int4 v = max_nl > 0 ? e[k] : int4{0, 0, 0, 0};
+            pre[ph][k] = int4{sgi(v.x), sgi(v.y), sgi(v.z), sgi(v.w)};
+        }
+    }
+    auto run_phase = [&](auto ph_c, int a0_off, const MpAdam& ad) {
+        constexpr int ph = decltype(ph_c)::value;
+        const int nt = ntk[ph];
+        if (has[ph]) {
+            if constexpr (ph < 2) run_task(pre[ph][0], pre[ph][1], pre[ph][2], pre[ph][3], a0_off, ad);
+            else {                                        // (the weight tiles' sixteen words stay in LDS: as scalars held across the loop they spilled)
+                const int4* e = reinterpret_cast<const int4*>(tasks + ph * slots + wave);
+                run_task(e[0], e[1], e[2], e[3], a0_off, ad);
+            }
+        }
+        // later rounds (more tasks than waves) from the last wave down: the tasks are sorted by weight (mp_plan), so a second task
+        // goes to a wave whose first one was light
+        for (int rd = 1; rd * NW < nt; ++rd) {
             const int q = rd * NW + ((rd & 1) ? NW - 1 - wave : wave);
             if (q >= nt) continue;
             const int4* e = reinterpret_cast<const int4*>(tasks + ph * slots + q);
-            const int4 d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3];
-            const int kind = sgi(d0.x);
-            const bool w32 = sgi(d3.x) & 4;
-            if (kind == MP_FWD) { if (w32) mp_fwd_chain32(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, a0_off, r16, g4); else mp_fwd_chain(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, a0_off, r16, g4); }
-            else if (kind == MP_DELTA) { if (w32) mp_delta_chain32(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, r16, g4); else mp_delta_chain(ltab, sgi(d0.z), sgi(d2.z), sgi(d0.w), pts, th, lds, r16, g4); }
-            else if (kind == MP_WGRAD) mp_wgrad_tile(d0, d1, d2, d3, th, mm, vv, flat, lds, a0_off, pts, r16, g4, ad);
+            run_task(e[0], e[1], e[2], e[3], a0_off, ad);
         }
     };
 
@@ -164,7 +191,7 @@ __global__ void __launch_bounds__(MP_NT) map_persist_kernel(MpArgs a) {
         // ---- forward: one wave per (network, 16-point tile) runs the network's layers back to back ----------------------------------
         const int a0_off = a.o_a0 + buf * a.a0_sz;
         if (max_nl > 0) {
-            run_phase(0, a0_off, MpAdam{});
+            run_phase(std::integral_constant<int, 0>{}, a0_off, MpAdam{});
             MP_STAMP();
             __syncthreads();
             MP_STAMP();
@@ -255,11 +282,11 @@ __global__ void __launch_bounds__(MP_NT) map_persist_kernel(MpArgs a) {
         // ---- backward: the delta chains (one wave per network and point tile), then every layer's weight step + AdamW ----------------
         const MpAdam ad = {dm, a.one_minus_b1, a.b2, a.one_minus_b2, ss, 1.0f / bc2, eps};
         if (max_nl > 0) {
-            run_phase(1, a0_off, ad);
+            run_phase(std::integral_constant<int, 1>{}, a0_off, ad);
             MP_STAMP();
             __syncthreads();
             MP_STAMP();
-            run_phase(2, a0_off, ad);
+            run_phase(std::integral_constant<int, 2>{}, a0_off, ad);
             if (it + 1 < a.K) land(buf ^ 1, pf_val, pf_nv);
             __syncthreads();
             MP_STAMP();
