@@ -15,6 +15,7 @@ import torch
 
 from . import _lib as L
 from . import parallel
+from .util import gc_paused
 
 
 def nn_param_layout(input_dim, output_dim, layer_sizes):
@@ -366,8 +367,9 @@ def capture_graph(body, warmup=2, before=None):
     # several ranks: torch.distributed's watchdog thread polls events while this thread captures; with the default (global) capture
     # mode that is an error raised into the capture
     kw = {'capture_error_mode': 'thread_local'} if parallel.world()[1] > 1 else {}
-    with torch.cuda.graph(graph, **kw):
-        body()
+    with gc_paused():                                     # (no garbage collection inside the capture: util.gc_paused)
+        with torch.cuda.graph(graph, **kw):
+            body()
     return graph
 
 

@@ -21,6 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
+from .util import gc_paused
 
 _direct = None      # RcclComm once enable_direct_rccl() has run; False = tried and given up (torch.distributed carries the exchange)
 
@@ -190,7 +191,7 @@ class RcclComm:
             buf.fill_(float(rank + 1))
             g = torch.cuda.CUDAGraph()
             kw = {'capture_error_mode': 'thread_local'} if w > 1 else {}      # (torch.distributed's watchdog thread: see capture_graph)
-            with warnings.catch_warnings():
+            with warnings.catch_warnings(), gc_paused():   # (no garbage collection inside a capture: util.gc_paused)
                 warnings.simplefilter('ignore')            # (one rank: RCCL enqueues nothing for an in-place sum -> "graph is empty")
                 with torch.cuda.graph(g, **kw):
                     self.all_reduce_(buf)

@@ -1,6 +1,8 @@
 """Host-side helpers with the interface of meta_learn/util.py: input shape handling (util.py:44-58), the 'gp-priors' logger
 (util.py:60-92) and the learning-rate schedule.  (The quantile bisection of util.py:9-42 is the HIP kernel behind
 pacoh_mixture_icdf.)"""
+import contextlib
+import gc
 import logging
 import os
 
@@ -99,3 +101,20 @@ def host_cpu_budget():
     if quota is not None:
         n = min(n, max(1, int(quota)))
     return max(1, n)
+
+
+@contextlib.contextmanager
+def gc_paused():
+    """No garbage collection inside a stream capture: a dead reference cycle that holds graphs, events or pinned memory of its own
+    (a discarded learner, say) would be finalised by whatever allocation happens to trigger the collector, and destroying those
+    inside a capture aborts the process.  torch.cuda.graph() no longer collects before capturing
+    (torch.compiler.config.force_cudagraph_gc), so: collect on entry, keep the collector off until the block has ended."""
+    was_on = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_on:
+            gc.enable()
+

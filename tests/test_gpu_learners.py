@@ -1146,6 +1146,7 @@ def test_vi_device_noise_changes_the_noise_source_and_nothing_else(M, graph, mon
             record.append(m._feed.aux_all[:len(sc_rows)].cpu().clone())
         m._feed.upload = spy
         loss = m.meta_fit(verbose=False, n_iter=41, log_period=20)
+        del m._feed.upload                                                     # (the spy closes over m: no reference cycle left behind)
         return m.posterior.clone(), float(loss)
 
     rows, rows2 = [], []
@@ -1191,3 +1192,32 @@ def test_vi_device_noise_predict_and_eval(M):
         assert np.isfinite(ll) and np.isfinite(rmse) and np.isfinite(calib)
         out.append((ll, rmse))
     assert abs(out[0][1] - out[1][1]) < 0.25 * max(out[0][1], out[1][1])         # same model class, 60 steps: the same ballpark
+
+
+def test_graph_capture_survives_a_dead_reference_cycle_that_holds_graphs(M, monkeypatch):
+    """A discarded learner caught in a reference cycle keeps its hipGraphs, events and pinned staging buffers until the garbage collector
+    finds it -- at some allocation of its own choosing.  If that is inside another learner's stream capture the process aborts
+    (destroying a graph inside a capture); torch.cuda.graph() does not collect before capturing any more.  engine.capture_graph
+    collects first and keeps the collector off during the capture (util.gc_paused): with the collector set to run at every
+    allocation this test ended the process before that."""
+    import gc
+    monkeypatch.setenv('PACOH_GRAPH', '1')
+    tasks = O.sinusoid_tasks_nd(6, 10, 1, seed0=70)
+    kw = dict(num_particles=3, task_batch_size=2, mean_nn_layers=(8, 8), kernel_nn_layers=(8, 8), random_seed=2)
+    old = gc.get_threshold()
+    gc.collect()
+    gc.disable()
+    try:
+        m = M.GPRegressionMetaLearnedSVGD(tasks, **kw)
+        m.meta_fit(verbose=False, n_iter=9, log_period=100)
+        assert m._graphs is not None                                         # (it holds captured graphs)
+        m._cycle = m                                                         # a cycle: only the collector can free it
+        del m
+        gc.set_threshold(1, 1, 1)                                            # the collector runs at (nearly) every allocation from here on
+        gc.enable()
+        m2 = M.GPRegressionMetaLearnedSVGD(tasks, **kw)
+        m2.meta_fit(verbose=False, n_iter=9, log_period=100)
+        assert bool(torch.isfinite(m2.particles).all()) and m2._graphs is not None
+    finally:
+        gc.set_threshold(*old)
+        gc.enable()
