@@ -17,7 +17,9 @@ int fused_reduce_launch(const float* slab0, int wd0, long off0, const float* sla
 
 namespace {
 
-constexpr int MT_NT = 512;           // 8 waves: 256 registers per lane (the two-block GP needs 90-112), cheaper barriers
+constexpr int MT_NT = 512;           // 8 waves: 256 registers per lane (the two-block GP needs 90-112), cheaper barriers ...
+constexpr int MT_NT_DEEP = 1024;     // ... 16 waves where the weight tiles would take 8 waves more than two rounds (two 4 x 32 networks: 32 tiles;
+                                     // the kernel needs 102 registers there): PACOH-SVGD at the launchers' shape 0.0297 -> 0.0283 ms per step
 constexpr int MT_MAXTASKS = 36;      // task descriptors that fit the kernel-argument segment beside the layer table
 
 struct MtArgs {
@@ -118,15 +120,15 @@ __global__ void __launch_bounds__(MT_NT) map_task_setup_kernel(MtArgs ka, float*
         }
 }
 
-template <int NB, int FP, bool MULTI>
-__global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
+template <int NB, int FP, bool MULTI, int NT>
+__global__ void __launch_bounds__(NT) map_task_kernel(MtArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ __attribute__((aligned(16))) int ltab[2 * MP_MAXL * 16];
     const MpArgs& a = ka.p;
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lane = t & 63, r16 = t & 15, g4 = (t >> 4) & 3;
-    constexpr int NW = MT_NT / 64;
+    constexpr int NW = NT / 64;
     const int n = a.n, d = a.d, f = a.f;
     const int P = MULTI ? ka.P : 1;
     if (MULTI && (int)blockIdx.x >= ka.groups * P) {       // the SVGD step's distance matrix, snapshot and counter increment
@@ -161,8 +163,8 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
     // MULTI: this row's image is gathered through a map (two dependent round trips).  The map words are requested HERE, in front of
     // the LDS zeroing and its barrier, and the row entries right behind that barrier in one burst: as a loop of load / gather / store
     // per 16 bytes the compiler made six dependent round trips of it -- 10 000-11 000 of the kernel's 52 000 cycles
-    constexpr int GI = 7;                                  // 7 x 448 lanes x 4 = 12 544 image entries >= two networks of five 32 x 36 layers
-    constexpr int IT = MT_NT - 64;                         // (the last wave copies the plan instead)
+    constexpr int GI = NT >= 1024 ? 4 : 7;                 // 7 x 448 (4 x 960) lanes x 4 = 12 544 (15 360) image entries >= two networks of five 32 x 36 layers
+    constexpr int IT = NT - 64;                         // (the last wave copies the plan instead)
     const int ng = a.DP >> 2;
     int4 m4[GI];
     if (MULTI && wave != NW - 1) {
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(MT_NT) map_task_kernel(MtArgs ka) {
     }
     {
         float4* l4 = reinterpret_cast<float4*>(lds);
-        for (int q = t; q < (a.total + 3) >> 2; q += MT_NT) l4[q] = float4{0.f, 0.f, 0.f, 0.f};
+        for (int q = t; q < (a.total + 3) >> 2; q += NT) l4[q] = float4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
     MP_STAMP();
@@ -412,6 +414,8 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
         o_slab[k] = carve((size_t)wgs * ka.dnet[k] * sizeof(float));
     }
     if (mt_plan(ka) != PACOH_OK) return PACOH_ELIMIT;        // (needs flat0[]: the slab-relative entries)
+    // threads per workgroup: 16 waves where 8 would walk the weight tiles in more than two rounds (PACOH_MT_NT=512 | 1024 forces one: A/B)
+    const int nt = g_sw.mt_nt == MT_NT || g_sw.mt_nt == MT_NT_DEEP ? g_sw.mt_nt : (ka.ntask[2] > 2 * (MT_NT / 64) ? MT_NT_DEEP : MT_NT);
     const int Dmax = D;                                 // (the index map covers the whole parameter row)
     for (int k = 0; k < a.nets; ++k)
         if (plan_only != 1 && (ka.flat0[k] < 0 || ka.flat0[k] + ka.dnet[k] > D || (plan_only == 0 && ka.flat0[k] + ka.dnet[k] > d_theta_stride))) return PACOH_EINVAL;
@@ -429,14 +433,16 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
         const size_t lds_bytes = (size_t)a.total * sizeof(float);
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-#define PACOH_MT_OCC(nb, fp, mu) do { \
+#define PACOH_MT_OCC(nb, fp, mu, nt_) do { \
             static std::atomic<uint64_t> attr_done{0}; \
-            if (lds_opt_in((const void*)map_task_kernel<nb, fp, mu>, MP_LDS_BYTES, attr_done) != PACOH_OK) e = hipErrorUnknown; \
-            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_task_kernel<nb, fp, mu>, MT_NT, lds_bytes); } while (0)
+            if (lds_opt_in((const void*)map_task_kernel<nb, fp, mu, nt_>, MP_LDS_BYTES, attr_done) != PACOH_OK) e = hipErrorUnknown; \
+            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_task_kernel<nb, fp, mu, nt_>, nt_, lds_bytes); } while (0)
+#define PACOH_MT_OCC_NT(nb, fp, mu) do { if (nt == MT_NT_DEEP) PACOH_MT_OCC(nb, fp, mu, MT_NT_DEEP); else PACOH_MT_OCC(nb, fp, mu, MT_NT); } while (0)
         if (e == hipSuccess) {
-            if (multi) { if (NB == 1 && FP == 2) PACOH_MT_OCC(1, 2, true); else if (NB == 1) PACOH_MT_OCC(1, 4, true); else if (FP == 2) PACOH_MT_OCC(2, 2, true); else PACOH_MT_OCC(2, 4, true); }
-            else { if (NB == 1 && FP == 2) PACOH_MT_OCC(1, 2, false); else if (NB == 1) PACOH_MT_OCC(1, 4, false); else if (FP == 2) PACOH_MT_OCC(2, 2, false); else PACOH_MT_OCC(2, 4, false); }
+            if (multi) { if (NB == 1 && FP == 2) PACOH_MT_OCC_NT(1, 2, true); else if (NB == 1) PACOH_MT_OCC_NT(1, 4, true); else if (FP == 2) PACOH_MT_OCC_NT(2, 2, true); else PACOH_MT_OCC_NT(2, 4, true); }
+            else { if (NB == 1 && FP == 2) PACOH_MT_OCC_NT(1, 2, false); else if (NB == 1) PACOH_MT_OCC_NT(1, 4, false); else if (FP == 2) PACOH_MT_OCC_NT(2, 2, false); else PACOH_MT_OCC_NT(2, 4, false); }
         }
+#undef PACOH_MT_OCC_NT
 #undef PACOH_MT_OCC
         (void)hipGetLastError();
         if (e == hipSuccess && cus > 0 && per_cu > 0 && (long)wgs > (long)cus * per_cu) return PACOH_ELIMIT;
@@ -469,10 +475,11 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
     tail.lml = tail.lik ? ka.lml_g : nullptr; tail.info = tail.fail_flag ? ka.info_g : nullptr;
     ka.adv_counter = multi ? nullptr : const_cast<long*>(tail.nx.counter);
     const size_t bytes = (size_t)a.total * sizeof(float);
-#define PACOH_MT_LAUNCH(nb, fp, mu) do { \
+#define PACOH_MT_LAUNCH_NT(nb, fp, mu, nt_) do { \
         static std::atomic<uint64_t> attr_done{0}; \
-        { const int rc_a = lds_opt_in((const void*)map_task_kernel<nb, fp, mu>, MP_LDS_BYTES, attr_done); if (rc_a != PACOH_OK) return rc_a; } \
-        hipLaunchKernelGGL((map_task_kernel<nb, fp, mu>), dim3((unsigned)(wgs + tail_wgs)), dim3(MT_NT), bytes, stream, ka); } while (0)
+        { const int rc_a = lds_opt_in((const void*)map_task_kernel<nb, fp, mu, nt_>, MP_LDS_BYTES, attr_done); if (rc_a != PACOH_OK) return rc_a; } \
+        hipLaunchKernelGGL((map_task_kernel<nb, fp, mu, nt_>), dim3((unsigned)(wgs + tail_wgs)), dim3(nt_), bytes, stream, ka); } while (0)
+#define PACOH_MT_LAUNCH(nb, fp, mu) do { if (nt == MT_NT_DEEP) PACOH_MT_LAUNCH_NT(nb, fp, mu, MT_NT_DEEP); else PACOH_MT_LAUNCH_NT(nb, fp, mu, MT_NT); } while (0)
 #define PACOH_MT_PICK(mu) do { \
         if (NB == 1 && FP == 2) PACOH_MT_LAUNCH(1, 2, mu); \
         else if (NB == 1) PACOH_MT_LAUNCH(1, 4, mu); \
@@ -481,6 +488,7 @@ int map_task_launch(const void* theta, const void* bx, const void* by, const int
     if (multi) PACOH_MT_PICK(true); else PACOH_MT_PICK(false);
 #undef PACOH_MT_PICK
 #undef PACOH_MT_LAUNCH
+#undef PACOH_MT_LAUNCH_NT
     if (launch_status() != PACOH_OK) return PACOH_ELAUNCH;
     return fused_reduce_launch(ka.slab[0], ka.dnet[0], ka.flat0[0], a.nets > 1 ? ka.slab[1] : nullptr, a.nets > 1 ? ka.dnet[1] : 0,
                                a.nets > 1 ? ka.flat0[1] : 0, a.nets, (float*)d_theta, d_theta_stride, groups, &tail,

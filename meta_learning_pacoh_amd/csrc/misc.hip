@@ -27,6 +27,7 @@ void read_switches(Switches& s) {
     s.mlp_path = !e ? 0 : (!strcmp(e, "mfma") ? 1 : (!strcmp(e, "layers") ? 3 : 0));
     s.mlp_stash = num("PACOH_MLP_STASH", -1);
     s.lds_pad_gp = num("PACOH_LDS_PAD_GP", -1); s.lds_pad_mlp = num("PACOH_LDS_PAD_MLP", -1);
+    s.mt_nt = num("PACOH_MT_NT", 0);
     s.fused_bwd_pb = num("PACOH_FUSED_BWD_PB", 0); s.fused_fwd_pb = num("PACOH_FUSED_FWD_PB", 0); s.fused_fwd_tpw = num("PACOH_FUSED_FWD_TPW", 0);
 }
 Switches g_sw = []() { Switches s; read_switches(s); return s; }();

@@ -20,6 +20,7 @@ struct Switches {
     // A/B: extra dynamic LDS per workgroup of the register-resident GP kernel / the fused MLP kernels (bytes; -1: the launchers' own
     // choice) -- caps the workgroups a CU takes, i.e. spreads an under-filled grid over all CUs (spread_pad, common.h)
     int lds_pad_gp, lds_pad_mlp;
+    int mt_nt;                 // PACOH_MT_NT=512 | 1024: threads per workgroup of the task-fused kernels (A/B; anything else: by the number of weight tiles)
 };
 
 extern Switches g_sw;

@@ -210,6 +210,30 @@ def test_svgd_task_fused_replay_equals_eager_bit_for_bit(M, monkeypatch):
     assert torch.equal(res[0], res[1])
 
 
+@pytest.mark.parametrize('layers', [(32, 32), (32, 32, 32, 32)])
+def test_workgroup_size_of_the_task_kernel_does_not_change_the_bits(M, layers, monkeypatch):
+    """8 waves per workgroup or 16 (the launch picks 16 where the weight tiles would take 8 waves more than two rounds: two 4 x 32
+    networks; PACOH_MT_NT forces one): the tiles land on other waves, every tile's arithmetic and every slab entry stay what they were"""
+    from meta_learning_pacoh_amd import _lib as L
+    monkeypatch.setenv('PACOH_SVGD_TASK_FUSED', '1')
+    monkeypatch.setenv('PACOH_GRAPH', '0')
+    tasks = make_tasks(8, 10, 20, 1, ragged=True)
+    res = []
+    try:
+        for nt in ('512', '1024', '0'):
+            monkeypatch.setenv('PACOH_MT_NT', nt)
+            L.reload_env()
+            m = M.GPRegressionMetaLearnedSVGD(tasks, num_particles=6, task_batch_size=2, random_seed=4, mean_nn_layers=layers,
+                                              kernel_nn_layers=layers, bandwidth=0.1, prior_factor=0.1)
+            m.meta_fit(verbose=False, n_iter=9, log_period=10)
+            assert m._task_ws is not None
+            res.append(m.particles.clone())
+    finally:
+        monkeypatch.delenv('PACOH_MT_NT')
+        L.reload_env()
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+
+
 @pytest.mark.parametrize('cfg', [dict(), dict(mean_nn_layers=(32, 32, 32, 32), kernel_nn_layers=(32, 32, 32, 32)),
                                  dict(covar_module='SE', mean_module='NN')])
 @pytest.mark.parametrize('graph', ['0', '1'])
