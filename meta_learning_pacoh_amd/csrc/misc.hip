@@ -626,7 +626,9 @@ __global__ void __launch_bounds__(256) step_begin_kernel(StepBeginArgs<T> a) {
         const T HALF_LOG2PI = T(0.9189385332046727);
         T acc = 0;
         // (sixteen entries per thread and trip, all their loads requested before the first is used: as one entry per trip the 26 trips
-        //  of the launchers' D = 6 566 were 26 dependent memory round trips -- 15 us for a launch of ten such blocks)
+        //  of the launchers' D = 6 566 were 26 dependent memory round trips -- 15 us for a launch of ten such blocks.  What is left of
+        //  this launch's 10.5 us at that shape is these ten blocks' own work, 26 entries per thread with an exp each: without them the
+        //  launch takes 4.9 us -- spreading a sample over several blocks needs a second stage for log q, not built)
         constexpr int U = 16;
         for (int d0 = threadIdx.x; d0 < D; d0 += 256 * U) {
             T e[U], sc[U], lc[U];
