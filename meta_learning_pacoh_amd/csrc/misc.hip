@@ -379,22 +379,43 @@ __global__ void adam_dev_kernel(T* __restrict__ param, const T* __restrict__ gra
 
 // ---- PACOH-VI: reparameterised sample of the diagonal Gaussian posterior and the ELBO gradient (A10) ----
 // theta[s,d] = loc[d] + exp(scale[d]) * eps[s,d];  log_q[s] = sum_d (-eps^2/2 - scale[d] - log(2 pi)/2)
-template <typename T>
-__global__ void __launch_bounds__(256) vi_sample_kernel(const T* __restrict__ post /*[2,D]*/, const T* __restrict__ eps,
-                                                        T* __restrict__ theta, T* __restrict__ log_q, int D) {
-    __shared__ T red[4];
+// sum over a block of NT threads, in thread 0: wave sums, then the waves' sums in a fixed tree (NT = 256: the four-term expression
+// every kernel of this file has always used -- same bits)
+template <typename T, int NT>
+__device__ __forceinline__ T block_sum_(T acc, T* red /*[NT / 64]*/) {
+    acc = subwave_sum<T>(acc, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    T tot = 0;
+    if (threadIdx.x == 0) {
+        if constexpr (NT == 256) tot = (red[0] + red[1]) + (red[2] + red[3]);
+        else {
+            T q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = (red[4 * k] + red[4 * k + 1]) + (red[4 * k + 2] + red[4 * k + 3]);
+            tot = (q[0] + q[1]) + (q[2] + q[3]);
+        }
+    }
+    return tot;
+}
+// threads per sample block: 1 024 where a row is long (D > 2 048: PACOH-VI at the launchers' 4 x 32 networks has D = 6 566 -- 26
+// entries with an exp each per thread of a 256-thread block were 5.5 us of the step's first launch), else 256
+__host__ __device__ constexpr int vi_sample_nt(int D) { return D > 2048 ? 1024 : 256; }
+
+template <typename T, int NT>
+__global__ void __launch_bounds__(NT) vi_sample_kernel(const T* __restrict__ post /*[2,D]*/, const T* __restrict__ eps,
+                                                       T* __restrict__ theta, T* __restrict__ log_q, int D) {
+    __shared__ T red[NT / 64];
     const int s_ = blockIdx.x;
     const T HALF_LOG2PI = T(0.9189385332046727);
     T acc = 0;
-    for (int d = threadIdx.x; d < D; d += 256) {
+    for (int d = threadIdx.x; d < D; d += NT) {
         const T e = eps[(long)s_ * D + d], sc = post[D + d];
         theta[(long)s_ * D + d] = post[d] + t_exp<T>(sc) * e;
         acc += T(-0.5) * e * e - sc - HALF_LOG2PI;
     }
-    acc = subwave_sum<T>(acc, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) log_q[s_] = (red[0] + red[1]) + (red[2] + red[3]);
+    const T tot = block_sum_<T, NT>(acc, red);
+    if (threadIdx.x == 0) log_q[s_] = tot;
 }
 
 // grad[0,d] = -mean_s score[s,d];  grad[1,d] = -mean_s (score[s,d] * exp(scale[d]) * eps[s,d] + prior_factor)
@@ -575,8 +596,8 @@ struct StepBeginArgs {
     const T* vi_post; T* vi_theta; T* vi_logq; int vi_S, vi_D;
 };
 
-template <typename T>
-__global__ void __launch_bounds__(256) step_begin_kernel(StepBeginArgs<T> a) {
+template <typename T, int NT>
+__global__ void __launch_bounds__(NT) step_begin_kernel(StepBeginArgs<T> a) {
     const long row = *a.counter;
     const int blk = blockIdx.x;
     if (blk < a.tb) {
@@ -585,15 +606,15 @@ __global__ void __launch_bounds__(256) step_begin_kernel(StepBeginArgs<T> a) {
         const T* sy = a.y + t * a.ny;
         T* dx = a.ox + (long)blk * a.nx;
         T* dy = a.oy + (long)blk * a.ny;
-        for (int q = threadIdx.x; q < a.nx; q += 256) dx[q] = sx[q];
-        for (int q = threadIdx.x; q < a.ny; q += 256) dy[q] = sy[q];
+        for (int q = threadIdx.x; q < a.nx; q += NT) dx[q] = sx[q];
+        for (int q = threadIdx.x; q < a.ny; q += NT) dy[q] = sy[q];
         if (threadIdx.x == 0 && a.n_valid) a.onv[blk] = a.n_valid[t];
     } else if (blk == a.tb) {
-        for (int q = threadIdx.x; q < a.n_sc; q += 256) a.sc_out[q] = a.sc_all[row * a.n_sc + q];
+        for (int q = threadIdx.x; q < a.n_sc; q += NT) a.sc_out[q] = a.sc_all[row * a.n_sc + q];
     } else if (blk == a.tb + 1) {
         if (a.theta) {
             const int per = a.f + 2;
-            for (int q = threadIdx.x; q < a.P * per; q += 256) {
+            for (int q = threadIdx.x; q < a.P * per; q += NT) {
                 const int p = q / per, e = q - p * per;
                 const T* th = a.theta + (long)p * a.stride;
                 if (e < a.f) a.ls[p * a.f + e] = softplus_t<T>(th[a.off_ls + (a.tie ? 0 : e)]);
@@ -608,38 +629,38 @@ __global__ void __launch_bounds__(256) step_begin_kernel(StepBeginArgs<T> a) {
         const int nb = a.aux_blocks;
         const T* __restrict__ src = a.aux_all + row * a.n_aux;
         T* __restrict__ dst = a.aux_out;
-        for (long q0 = (long)(blk - a.tb - 2) * 2048; q0 < a.n_aux; q0 += (long)nb * 2048) {
+        for (long q0 = (long)(blk - a.tb - 2) * (8 * NT); q0 < a.n_aux; q0 += (long)nb * (8 * NT)) {
             T v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const long q = q0 + threadIdx.x + 256 * u; v[u] = src[q < a.n_aux ? q : a.n_aux - 1]; }
+            for (int u = 0; u < 8; ++u) { const long q = q0 + threadIdx.x + NT * u; v[u] = src[q < a.n_aux ? q : a.n_aux - 1]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const long q = q0 + threadIdx.x + 256 * u; if (q < a.n_aux) dst[q] = v[u]; }
+            for (int u = 0; u < 8; ++u) { const long q = q0 + threadIdx.x + NT * u; if (q < a.n_aux) dst[q] = v[u]; }
         }
     } else if (a.vi_post == nullptr || blk < a.tb + 2 + a.aux_blocks + (a.sv_X ? a.sv_P * a.sv_P : 0)) {
         // the particles do not change before the step's update: their distance matrix (and the snapshot the in-place update reads)
         // can be had here, a launch earlier and off the path behind the all-reduce
         svgd_dist_block<T>(a.sv_X, a.sv_d2, a.sv_P, a.sv_D, a.sv_snap, blk - (a.tb + 2 + a.aux_blocks));
     } else {
-        __shared__ T red[4];                                     // (arithmetic and summation order of vi_sample_kernel / hyper_fwd_kernel)
+        __shared__ T red[NT / 64];                               // (arithmetic and summation order of vi_sample_kernel<T, NT> / hyper_fwd_kernel)
         const int s_ = blk - (a.tb + 2 + a.aux_blocks + (a.sv_X ? a.sv_P * a.sv_P : 0)), D = a.vi_D;
         const T* eps = a.aux_all + row * a.n_aux + (long)s_ * D;
         const T HALF_LOG2PI = T(0.9189385332046727);
         T acc = 0;
         // (sixteen entries per thread and trip, all their loads requested before the first is used: as one entry per trip the 26 trips
-        //  of the launchers' D = 6 566 were 26 dependent memory round trips -- 15 us for a launch of ten such blocks.  What is left of
-        //  this launch's 10.5 us at that shape is these ten blocks' own work, 26 entries per thread with an exp each: without them the
-        //  launch takes 4.9 us -- spreading a sample over several blocks needs a second stage for log q, not built)
-        constexpr int U = 16;
-        for (int d0 = threadIdx.x; d0 < D; d0 += 256 * U) {
+        //  of the launchers' D = 6 566 were 26 dependent memory round trips -- 15 us for a launch of ten such blocks.  With that gone,
+        //  5.5 of the launch's 10.5 us were still these blocks' own work at 256 threads, 26 entries with an exp each per thread:
+        //  long rows get 1 024 threads -- vi_sample_nt)
+        constexpr int U = NT >= 1024 ? 8 : 16;
+        for (int d0 = threadIdx.x; d0 < D; d0 += NT * U) {
             T e[U], sc[U], lc[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int d = d0 + 256 * u, dc = d < D ? d : D - 1;
+                const int d = d0 + NT * u, dc = d < D ? d : D - 1;
                 e[u] = eps[dc]; sc[u] = a.vi_post[D + dc]; lc[u] = a.vi_post[dc];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int d = d0 + 256 * u;
+                const int d = d0 + NT * u;
                 if (d >= D) break;
                 const T th = lc[u] + t_exp<T>(sc[u]) * e[u];
                 a.vi_theta[(long)s_ * D + d] = th;
@@ -652,10 +673,8 @@ __global__ void __launch_bounds__(256) step_begin_kernel(StepBeginArgs<T> a) {
                 }
             }
         }
-        acc = subwave_sum<T>(acc, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) a.vi_logq[s_] = (red[0] + red[1]) + (red[2] + red[3]);
+        const T tot = block_sum_<T, NT>(acc, red);
+        if (threadIdx.x == 0) a.vi_logq[s_] = tot;
     }
 }
 
@@ -703,7 +722,9 @@ static int step_begin_launch(const int64_t* idx_all, int tb, const void* sc_all,
                           (int)ab, (const T*)svgd_X, d2, svgd_X ? d2 + svgd_P * svgd_P : nullptr, svgd_P, svgd_D,
                           kernel_of(f) != PACOH_KERNEL_RBF, (const T*)vi_post, (T*)vi_theta, (T*)vi_logq, vi_S, vi_D};
     const long sb = svgd_X ? (long)svgd_P * svgd_P : 0;
-    hipLaunchKernelGGL(step_begin_kernel<T>, dim3((unsigned)(tb + 2 + ab + sb + (vi_post ? vi_S : 0))), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)(tb + 2 + ab + sb + (vi_post ? vi_S : 0)));
+    if (vi_post && vi_sample_nt(vi_D) == 1024) hipLaunchKernelGGL((step_begin_kernel<T, 1024>), grid, dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL((step_begin_kernel<T, 256>), grid, dim3(256), 0, s, a);
     if (advance) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, (long*)counter);
     return launch_status();
 }
@@ -1117,12 +1138,11 @@ extern "C" int pacoh_adam_step_dev(void* param, const void* grad, void* exp_avg,
 extern "C" int pacoh_vi_sample(const void* posterior, const void* eps, void* theta, void* log_q, int S, int D, int dtype, void* stream) {
     if (check_dtype(dtype)) return PACOH_EDTYPE;
     if (!posterior || !eps || !theta || !log_q || S <= 0 || D <= 0) return PACOH_EINVAL;
-    if (dtype == PACOH_F32)
-        hipLaunchKernelGGL(vi_sample_kernel<float>, dim3(S), dim3(256), 0, (hipStream_t)stream, (const float*)posterior, (const float*)eps,
-                           (float*)theta, (float*)log_q, D);
-    else
-        hipLaunchKernelGGL(vi_sample_kernel<double>, dim3(S), dim3(256), 0, (hipStream_t)stream, (const double*)posterior, (const double*)eps,
-                           (double*)theta, (double*)log_q, D);
+#define PACOH_VI_SAMPLE(T_, NT_) hipLaunchKernelGGL((vi_sample_kernel<T_, NT_>), dim3(S), dim3(NT_), 0, (hipStream_t)stream, (const T_*)posterior, \
+                                                  (const T_*)eps, (T_*)theta, (T_*)log_q, D)
+    if (vi_sample_nt(D) == 1024) { if (dtype == PACOH_F32) PACOH_VI_SAMPLE(float, 1024); else PACOH_VI_SAMPLE(double, 1024); }
+    else { if (dtype == PACOH_F32) PACOH_VI_SAMPLE(float, 256); else PACOH_VI_SAMPLE(double, 256); }
+#undef PACOH_VI_SAMPLE
     return launch_status();
 }
 
