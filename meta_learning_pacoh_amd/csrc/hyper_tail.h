@@ -89,7 +89,13 @@ __device__ __forceinline__ void hyper_bwd_block(const HyperBwdArgs<T>& a, int w,
     if (a.info && a.fail_flag && w % per == a.f + 1) {
         const int pp = w / per;
         bool bad = false;
-        for (int t = threadIdx.x; t < a.Tt; t += 256) bad |= a.info[(long)t * a.P + pp] < 0;
+        for (int t0 = threadIdx.x; t0 < a.Tt; t0 += 4 * 256) {
+            int v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int t = t0 + 256 * u; v[u] = a.info[(long)(t < a.Tt ? t : a.Tt - 1) * a.P + pp]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bad |= v[u] < 0;      // (a clamped copy of the last task's value: the same verdict)
+        }
         if (bad) atomicOr(a.fail_flag, 1);
     }
     const int p = w / per, e = w - p * per;
@@ -105,8 +111,20 @@ __device__ __forceinline__ void hyper_bwd_block(const HyperBwdArgs<T>& a, int w,
     else { src = a.lml; width = 1; col = 0; off = 0; }
     if (!src || off < 0) return;
     T s = 0;
-    for (int t = threadIdx.x; t < a.Tt; t += 256)
-        for (int c = 0; c < ncol; ++c) s += src[((long)t * a.P + p) * width + col + c];
+    if (ncol == 1) {
+        // (four tasks per trip, their loads requested together, added in the same order: one task per trip was one memory round trip
+        //  per 256 tasks -- four in a row at cfg #3's 1 024 tasks per step)
+        for (int t0 = threadIdx.x; t0 < a.Tt; t0 += 4 * 256) {
+            T v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int t = t0 + 256 * u; v[u] = src[((long)(t < a.Tt ? t : a.Tt - 1) * a.P + p) * width + col]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (t0 + 256 * u < a.Tt) s += v[u];
+        }
+    } else {
+        for (int t = threadIdx.x; t < a.Tt; t += 256)
+            for (int c = 0; c < ncol; ++c) s += src[((long)t * a.P + p) * width + col + c];
+    }
     s = subwave_sum<T>(s, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
