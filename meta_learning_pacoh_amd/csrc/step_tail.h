@@ -27,13 +27,31 @@ __device__ __forceinline__ void svgd_dist_block(const T* __restrict__ X, T* __re
     const T* xi = X + (long)i * D;
     const bool worker = threadIdx.x < 256;
     if (snap && i == j) {                       // the diagonal pairs copy their particle: the in-place update reads the snapshot
-        if (worker) for (int d = threadIdx.x; d < D; d += 256) snap[(long)i * D + d] = xi[d];
+        if (worker) {                           // (eight entries per trip, loaded before any is stored: one entry per trip is one memory round trip each)
+            for (int d0 = threadIdx.x; d0 < D; d0 += 8 * 256) {
+                T v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int d = d0 + 256 * u; v[u] = xi[d < D ? d : D - 1]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int d = d0 + 256 * u; if (d < D) snap[(long)i * D + d] = v[u]; }
+            }
+        }
         if (threadIdx.x == 0) d2[i * P + i] = T(0);
         return;
     }
     const T* xj = X + (long)j * D;
     T acc = 0;
-    if (worker) for (int d = threadIdx.x; d < D; d += 256) { T df = xi[d] - xj[d]; acc = fma(df, df, acc); }
+    if (worker) {
+        // (eight entries of both particles per trip, requested together, accumulated in the same order: at the launchers' D = 6 566 the
+        //  one-entry loop was 26 memory round trips in a row -- as long as the likelihood workgroups this block rides beside)
+        for (int d0 = threadIdx.x; d0 < D; d0 += 8 * 256) {
+            T vi[8], vj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int d = d0 + 256 * u, dc = d < D ? d : D - 1; vi[u] = xi[dc]; vj[u] = xj[dc]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (d0 + 256 * u < D) { const T df = vi[u] - vj[u]; acc = fma(df, df, acc); }
+        }
+    }
     acc = subwave_sum<T>(acc, 64);
     if (worker && (threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
