@@ -332,6 +332,16 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < MW_PT / 4; ++ks) dj[ks] = ks < nks ? del[(4 * ks + g) * S + 16 * Jw + r] : 0.0f;
                 float* dst0 = slab + (L.w_flat - N.flat0) + (long)(16 * Jw + 4 * g) * L.in + r;
+                // the bias gradient of the wave's 16 rows, sum_p delta[p][16 J + r], from the operand it holds anyway: a vector add per
+                // step and two cross-row adds (as a phase of its own -- 128 threads walking the points through LDS one by one -- it
+                // was 2 100 cycles per layer)
+                if (Ih == 0) {
+                    float bs = 0.0f;
+#pragma unroll
+                    for (int ks = 0; ks < MW_PT / 4; ++ks) bs += dj[ks];
+                    bs += __shfl_xor(bs, 16, 64); bs += __shfl_xor(bs, 32, 64);
+                    if (g == 0) slab[L.b_flat - N.flat0 + 16 * Jw + r] = bs;
+                }
 #pragma unroll 2
                 for (int I = Ih; I < nI; I += 2) {
                     gpreg::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -341,12 +351,6 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) dst[(long)s * L.in] = acc[s];
                 }
-            }
-            MP_STAMP();
-            for (int j = tl; j < L.out; j += nthr) {       // bias gradient: sum over the points
-                float v = 0.0f;
-                for (int p = 0; p < pts; ++p) v += del[p * S + j];
-                slab[L.b_flat - N.flat0 + j] = v;
             }
             MP_STAMP();
             // delta of the layer below: D[i][p] = sum_j W[j][16 I + i] delta[p][j], times (1 - a^2)
