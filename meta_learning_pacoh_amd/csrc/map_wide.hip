@@ -65,10 +65,37 @@ struct MwArgs {
 typedef float __attribute__((ext_vector_type(4), aligned(4))) f4u;      // 16 bytes at 4-byte alignment (rows of theta)
 
 // out[p][u] = tanh(b[u] + sum_c W[u][c] x[p][c]) of the first layer (in = d <= 4): one (point, unit) per thread and round
-__device__ __forceinline__ void mw_first_layer(const MwArgs& a, const MwNet& N, float* lds, int tl, int nthr) {
+// (the first two entries of a thread -- all of them up to 2 048 point x unit pairs -- get their bias and weight row REQUESTED at the top
+//  of the kernel, beside the task's points: behind the prologue's barrier they were two more cold round trips, 6 600 cycles of the
+//  launcher's 75 000)
+struct MwFirst { float b[2]; float w[2][4]; };
+__device__ __forceinline__ void mw_first_load(const MwArgs& a, const MwNet& N, int tl, int nthr, MwFirst& F) {
     const MwLayer& L = N.L[0];
     const float* W = a.theta + L.w_flat; const float* b = a.theta + L.b_flat;
-    for (int e = tl; e < a.pts * L.out; e += nthr) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = tl + k * nthr;
+        const int u = e < a.pts * L.out ? e % L.out : 0;
+        F.b[k] = b[u];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) F.w[k][c] = W[u * L.in + (c < L.in ? c : 0)];
+    }
+}
+__device__ __forceinline__ void mw_first_layer(const MwArgs& a, const MwNet& N, float* lds, int tl, int nthr, const MwFirst& F) {
+    const MwLayer& L = N.L[0];
+    const float* W = a.theta + L.w_flat; const float* b = a.theta + L.b_flat;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = tl + k * nthr;
+        if (e < a.pts * L.out) {
+            const int p = e / L.out, u = e - p * L.out;
+            float v = F.b[k];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < L.in) v = fmaf(F.w[k][c], lds[a.o_x + p * 4 + c], v);
+            lds[N.o_act + p * a.S + u] = act_tanh<float>(v);
+        }
+    }
+    for (int e = tl + 2 * nthr; e < a.pts * L.out; e += nthr) {
         const int p = e / L.out, u = e - p * L.out;
         float v = b[u];
         for (int c = 0; c < L.in; ++c) v = fmaf(W[u * L.in + c], lds[a.o_x + p * 4 + c], v);
@@ -114,11 +141,47 @@ __device__ __forceinline__ void mw_hidden_layer(const MwArgs& a, const MwNet& N,
 }
 
 // the output layer (out <= 4): out[p][o] = b[o] + W[o][:] . h[p][:], 16 lanes per (p, o) entry
-__device__ __forceinline__ void mw_output_layer(const MwArgs& a, const MwNet& N, float* lds, int tl, int nthr) {
+// (the output layer's weight pieces and bias of a thread's first entry -- the only one up to 64 point x output pairs -- are requested a
+//  layer ahead, like the hidden layers' rows)
+struct MwOut { f4u w[2]; float b; };
+__device__ __forceinline__ void mw_output_load(const MwArgs& a, const MwNet& N, int tl, int nthr, MwOut& O) {
+    const MwLayer& L = N.L[N.nl - 1];
+    const int sub = tl & 15, e = tl >> 4;
+    const int o = e < a.pts * L.out ? e % L.out : 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int k4 = sub + 16 * k;
+        O.w[k] = k4 < (L.in >> 2) ? *reinterpret_cast<const f4u*>(a.theta + L.w_flat + o * L.in + 4 * k4) : f4u{0.f, 0.f, 0.f, 0.f};
+    }
+    O.b = a.theta[L.b_flat + o];
+}
+__device__ __forceinline__ void mw_output_layer(const MwArgs& a, const MwNet& N, float* lds, int tl, int nthr, const MwOut& O) {
     const MwLayer& L = N.L[N.nl - 1];
     const int sub = tl & 15, S = a.S;
     const float* h = lds + N.o_act + (N.nl - 2) * MW_PT * S;
-    for (int e = tl >> 4; e < a.pts * L.out; e += nthr >> 4) {
+    {
+        const int e = tl >> 4;
+        if (e < a.pts * L.out) {
+            const int p = e / L.out, o = e - p * L.out;
+            float v = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int k4 = sub + 16 * k;
+                if (k4 < (L.in >> 2)) {
+                    const float4 hv = *reinterpret_cast<const float4*>(h + p * S + 4 * k4);
+                    v = fmaf(O.w[k][0], hv.x, v); v = fmaf(O.w[k][1], hv.y, v); v = fmaf(O.w[k][2], hv.z, v); v = fmaf(O.w[k][3], hv.w, v);
+                }
+            }
+            for (int k4 = sub + 32; k4 < (L.in >> 2); k4 += 16) {      // (never at widths <= 128)
+                const f4u w = *reinterpret_cast<const f4u*>(a.theta + L.w_flat + o * L.in + 4 * k4);
+                const float4 hv = *reinterpret_cast<const float4*>(h + p * S + 4 * k4);
+                v = fmaf(w[0], hv.x, v); v = fmaf(w[1], hv.y, v); v = fmaf(w[2], hv.z, v); v = fmaf(w[3], hv.w, v);
+            }
+            v = gpreg::row_sum_(v);
+            if (sub == 0) lds[N.o_out + p * N.s_out + o] = v + O.b;
+        }
+    }
+    for (int e = (tl >> 4) + (nthr >> 4); e < a.pts * L.out; e += nthr >> 4) {
         const int p = e / L.out, o = e - p * L.out;
         float v = 0.0f;
         for (int k4 = sub; k4 < (L.in >> 2); k4 += 16) {
@@ -157,6 +220,17 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
                           : (t == 4 ? a.hyp_os : (t == 5 ? a.hyp_noise : ((t == 6 && a.off_const >= 0) ? a.theta + a.off_const : nullptr)));
         if (t < 7 && hsrc) hp_val = *hsrc;
     }
+    // (the first layer's operands and layer 1's weight rows too: requested here, beside the task's points, they travel under the LDS
+    //  zeroing and its barrier)
+    const int k_net = (int)blockIdx.x;
+    const int wl = wave, tl = t, nthr = MW_NT;
+    const MwNet& N = a.net[k_net];
+    const int max_nl = N.nl;                             // (a workgroup follows its own network's depth)
+    MwFirst wf;
+    MwW w1, w2, w3;
+    mw_first_load(a, N, tl, nthr, wf);
+    mw_load_w(a, N, 1, wl, r, g, w1);
+    asm volatile("" ::: "memory");                       // (the loads are issued HERE; the compiler would sink them to their use)
     {
         float4* l4 = reinterpret_cast<float4*>(lds);
         for (int q = t; q < (a.total + 3) >> 2; q += MW_NT) l4[q] = float4{0.f, 0.f, 0.f, 0.f};
@@ -181,18 +255,15 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
     // launch, so the counts stay in step without ever being reset (graph replays included) --, then BOTH run the GP on the same operands
     // (5 000 cycles, in parallel) and each takes the gradient of its own network back down.  Two 1024-thread workgroups are always
     // co-resident on this part; the wait spins on an agent-scope atomic load.
-    const int k_net = (int)blockIdx.x;
-    const int wl = wave, tl = t, nthr = MW_NT;
-    const MwNet& N = a.net[k_net];
-    const int max_nl = N.nl;                             // (a workgroup follows its own network's depth)
 
     // ---- forward ---------------------------------------------------------------------------------------------------------------------
     // (three register sets, one per hidden layer >= 1, each loaded a layer ahead of its use: a rotating pair `wcur = wnext` made the copy
-    //  wait for the loads it had just issued -- the whole memory latency exposed once per layer)
-    MwW w1, w2, w3;
-    mw_load_w(a, N, 1, wl, r, g, w1);                    // (layer 1's weights under the first layer's work)
-    asm volatile("" ::: "memory");                       // (the loads are issued HERE; the compiler would sink them to their use)
-    mw_first_layer(a, N, lds, tl, nthr);
+    //  wait for the loads it had just issued -- the whole memory latency exposed once per layer.  TWO layers ahead was measured too:
+    //  0.0379 against 0.0382 ms per iteration with two registers spilled -- not kept)
+    MwOut wo;
+    mw_output_load(a, N, tl, nthr, wo);                  // (the output layer's pieces: four layers ahead, nine registers)
+    asm volatile("" ::: "memory");
+    mw_first_layer(a, N, lds, tl, nthr, wf);
     __syncthreads();
     MP_STAMP();
     if (2 < max_nl) {
@@ -214,7 +285,7 @@ __global__ void __launch_bounds__(MW_NT) map_wide_kernel(MwArgs a) {
         __syncthreads();
         MP_STAMP();
     }
-    mw_output_layer(a, N, lds, tl, nthr);
+    mw_output_layer(a, N, lds, tl, nthr, wo);
     __syncthreads();
     if (a.nets > 1) {
         const MwNet& No = a.net[1 - k_net];
